@@ -1,0 +1,402 @@
+"""Per-kernel parity cases shared by the CPU-emulator tests (small shapes) and the `-m gpu` tests
+(true shapes).  Every case computes the expected result with the oracle (oracle/cpu_ref.py, fp32 torch
+ops with bf16 rounding emulation where the kernel rounds) and compares the kernel's output.
+
+Backends expose the same C-ABI symbols (include/vcoder_kernels.h):
+  EmuBackend : tests/emu/libvcoder_emu.so   (host pointers, thread-per-lane functional emulator; CPU only)
+  HipBackend : vcoder_amd/lib/libvcoder_hip.so (device pointers; real gfx950 kernels)
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import cpu_ref  # noqa: E402  (oracle: test infrastructure)
+from vcoder_amd import synth  # noqa: E402
+
+c_p = ctypes.c_void_p
+
+
+def bf16_round(x: np.ndarray) -> np.ndarray:
+    return synth.round_to_bf16(np.asarray(x, dtype=np.float32))
+
+
+class EmuBackend:
+    name = "emu"
+
+    def __init__(self):
+        path = os.path.join(ROOT, "tests", "emu", "libvcoder_emu.so")
+        if not os.path.exists(path):
+            import subprocess
+
+            subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build_emu.sh")])
+        self.lib = ctypes.CDLL(path)
+
+    # arrays are numpy; bf16 arrays are uint16 bit patterns
+    def f32(self, a):
+        return np.ascontiguousarray(a, dtype=np.float32)
+
+    def bf16(self, a):
+        return synth.to_bf16_bits(np.asarray(a, dtype=np.float32)).reshape(np.shape(a))
+
+    def i32(self, a):
+        return np.ascontiguousarray(a, dtype=np.int32)
+
+    def zeros(self, shape, kind):
+        return np.zeros(shape, dtype={"f32": np.float32, "bf16": np.uint16, "i32": np.int32}[kind])
+
+    def ptr(self, a):
+        return None if a is None else a.ctypes.data_as(c_p)
+
+    def host_f32(self, a):
+        return synth.from_bf16_bits(a).reshape(a.shape) if a.dtype == np.uint16 else np.array(a)
+
+    def host_i32(self, a):
+        return np.array(a)
+
+    def sync(self):
+        pass
+
+
+class HipBackend:
+    name = "hip"
+
+    def __init__(self):
+        from vcoder_amd import _lib
+
+        self.lib = _lib.load()
+        self.dev = torch.device("cuda:0")
+
+    def f32(self, a):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.dev)
+
+    def bf16(self, a):
+        bits = synth.to_bf16_bits(np.asarray(a, dtype=np.float32)).reshape(np.shape(a))
+        return torch.from_numpy(bits.view(np.int16)).to(self.dev)
+
+    def i32(self, a):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(self.dev)
+
+    def zeros(self, shape, kind):
+        dt = {"f32": torch.float32, "bf16": torch.int16, "i32": torch.int32}[kind]
+        return torch.zeros(shape, dtype=dt, device=self.dev)
+
+    def ptr(self, a):
+        return None if a is None else c_p(a.data_ptr())
+
+    def host_f32(self, a):
+        if a.dtype == torch.int16:
+            return synth.from_bf16_bits(a.cpu().numpy().view(np.uint16)).reshape(tuple(a.shape))
+        return a.cpu().numpy()
+
+    def host_i32(self, a):
+        return a.cpu().numpy()
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+
+def _call(be, fn, *args):
+    conv = []
+    for a in args:
+        if a is None:
+            conv.append(None)
+        elif isinstance(a, (np.ndarray, torch.Tensor)):
+            conv.append(be.ptr(a))
+        elif isinstance(a, float):
+            conv.append(ctypes.c_float(a))
+        elif isinstance(a, int):
+            conv.append(ctypes.c_int(a))
+        else:
+            conv.append(a)
+    getattr(be.lib, fn)(*conv, None)  # last arg: stream = default
+    be.sync()
+
+
+def rel_err(got, ref):
+    return float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-12))
+
+
+# ------------------------------------------------------------------------------------------------
+def check_gemm(be, M, N, K, epi, bias=True, seed=0):
+    rng = np.random.RandomState(seed)
+    A = bf16_round(rng.randn(M, K))
+    W = bf16_round(rng.randn(N, K) * 0.05)
+    b = rng.randn(N).astype(np.float32) * 0.1 if bias else None
+    ref = A.astype(np.float64) @ W.T.astype(np.float64) + (b if bias else 0.0)
+    t = torch.from_numpy(ref).float()
+    if epi in (0, 1, 2):
+        out = be.zeros((M, N), "bf16")
+        if epi == 1:
+            t = cpu_ref.quick_gelu(t)
+        if epi == 2:
+            t = torch.nn.functional.gelu(t)
+    elif epi == 3:
+        out = be.zeros((M, N), "f32")
+    elif epi == 4:
+        r0 = rng.randn(M, N).astype(np.float32)
+        out = be.f32(r0)
+        t = t + torch.from_numpy(r0)
+    else:
+        out = be.zeros((M, N // 2), "bf16")
+        t = torch.nn.functional.silu(t[:, 0::2]) * t[:, 1::2]
+    ldo = N // 2 if epi == 5 else N
+    _call(be, "vck_gemm", be.bf16(A), be.bf16(W), be.f32(b) if bias else None, out, M, N, K, K, K, ldo, epi)
+    got = be.host_f32(out)
+    ref = t.numpy()
+    tol = 2 ** -8 if epi in (0, 1, 2, 5) else 1e-5  # bf16 output rounding vs fp32 accumulate
+    e = rel_err(got, ref)
+    assert e < tol, f"gemm M{M} N{N} K{K} epi{epi}: rel err {e}"
+    return e
+
+
+def check_gemv(be, M, N, K, epi, seed=0):
+    rng = np.random.RandomState(seed)
+    X = bf16_round(rng.randn(M, K))
+    W = bf16_round(rng.randn(N, K) * 0.05)
+    Wb = be.bf16(W)
+    Wp = be.zeros((N * K,), "bf16")
+    _call(be, "vck_pack_weight", Wb, Wp, N, K)
+    t = torch.from_numpy(X.astype(np.float64) @ W.T.astype(np.float64)).float()
+    if epi == 0:
+        out = be.zeros((M, N), "bf16")
+    elif epi == 1:
+        out = be.zeros((M, N), "f32")
+    elif epi == 2:
+        r0 = rng.randn(M, N).astype(np.float32)
+        out = be.f32(r0)
+        t = t + torch.from_numpy(r0)
+    else:
+        out = be.zeros((M, N // 2), "bf16")
+        t = torch.nn.functional.silu(t[:, 0::2]) * t[:, 1::2]
+    _call(be, "vck_gemv", be.bf16(X), Wp, out, M, N, K, N // 2 if epi == 3 else N, epi)
+    e = rel_err(be.host_f32(out), t.numpy())
+    assert e < (2 ** -8 if epi in (0, 3) else 1e-5), f"gemv M{M} N{N} K{K} epi{epi}: rel err {e}"
+    return e
+
+
+def check_interleave(be, F, K):
+    rng = np.random.RandomState(1)
+    g, u = bf16_round(rng.randn(F, K)), bf16_round(rng.randn(F, K))
+    out = be.zeros((2 * F, K), "bf16")
+    _call(be, "vck_interleave_rows", be.bf16(g), be.bf16(u), out, F, K)
+    got = be.host_f32(out)
+    assert np.array_equal(got[0::2], g) and np.array_equal(got[1::2], u)
+
+
+def check_layernorm(be, rows, D, seed=0):
+    rng = np.random.RandomState(seed)
+    x = (rng.randn(rows, D) * 2 + 0.3).astype(np.float32)
+    w, b = (rng.rand(D) + 0.5).astype(np.float32), (rng.randn(D) * 0.1).astype(np.float32)
+    y = be.zeros((rows, D), "bf16")
+    _call(be, "vck_layernorm", be.f32(x), be.f32(w), be.f32(b), y, rows, D, 1e-5)
+    ref = cpu_ref.layer_norm(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), 1e-5).numpy()
+    e = rel_err(be.host_f32(y), ref)
+    assert e < 2 ** -8, f"layernorm rel err {e}"
+
+
+def check_rmsnorm(be, rows, D, gather=False, seed=0):
+    rng = np.random.RandomState(seed)
+    x = (rng.randn(rows * (3 if gather else 1), D) * 3).astype(np.float32)
+    w = (rng.rand(D) + 0.5).astype(np.float32)
+    idx = rng.permutation(x.shape[0])[:rows].astype(np.int32) if gather else None
+    y = be.zeros((rows, D), "bf16")
+    _call(be, "vck_rmsnorm", be.f32(x), be.i32(idx) if gather else None, be.f32(w), y, rows, D, 1e-5)
+    src = x[idx] if gather else x
+    ref = cpu_ref.rms_norm(torch.from_numpy(src), torch.from_numpy(w), 1e-5).numpy()
+    e = rel_err(be.host_f32(y), ref)
+    assert e < 2 ** -8, f"rmsnorm rel err {e}"
+
+
+class _VitCfg:
+    def __init__(self, image, patch):
+        self.vit_image_size, self.vit_patch_size = image, patch
+
+
+def check_im2col(be, n_img, image, patch, Kpad):
+    rng = np.random.RandomState(3)
+    px = rng.randn(n_img, 3, image, image).astype(np.float32)
+    g = image // patch
+    cols = be.zeros((n_img * g * g, Kpad), "bf16")
+    _call(be, "vck_im2col", be.f32(px), cols, n_img, image, patch, Kpad)
+    sd = {"embeddings.patch_embedding.weight": torch.zeros(4, 3, patch, patch)}
+    ref, _ = cpu_ref.vit_embed(torch.from_numpy(px), sd, "", _VitCfg(image, patch))
+    got = be.host_f32(cols)
+    assert np.array_equal(got[:, :3 * patch * patch], bf16_round(ref.numpy()))
+    assert not got[:, 3 * patch * patch:].any()
+
+
+def check_vit_embed_ln(be, n_img, T, D):
+    rng = np.random.RandomState(4)
+    patches = rng.randn(n_img * (T - 1), D).astype(np.float32)
+    cls, pos = rng.randn(D).astype(np.float32), rng.randn(T, D).astype(np.float32)
+    w, b = (rng.rand(D) + 0.5).astype(np.float32), (rng.randn(D) * 0.1).astype(np.float32)
+    x = be.zeros((n_img, T, D), "f32")
+    _call(be, "vck_vit_embed_ln", be.f32(patches), be.f32(cls), be.f32(pos), be.f32(w), be.f32(b), x, n_img, T, D, 1e-5)
+    pre = np.concatenate([np.broadcast_to(cls, (n_img, 1, D)), patches.reshape(n_img, T - 1, D)], 1) + pos[None]
+    ref = cpu_ref.layer_norm(torch.from_numpy(pre), torch.from_numpy(w), torch.from_numpy(b), 1e-5).numpy()
+    e = rel_err(be.host_f32(x), ref)
+    assert e < 1e-5, f"vit_embed_ln rel err {e}"
+
+
+def check_select_rows(be, n_img, T, D):
+    rng = np.random.RandomState(5)
+    x = rng.randn(n_img, T, D).astype(np.float32)
+    y = be.zeros((n_img * (T - 1), D), "bf16")
+    _call(be, "vck_select_rows_bf16", be.f32(x), y, n_img, T, 1, D)
+    assert np.array_equal(be.host_f32(y), bf16_round(x[:, 1:].reshape(-1, D)))
+
+
+def rope_tables(max_pos, hd, theta=10000.0):
+    cos, sin = cpu_ref.rope_cos_sin(torch.arange(max_pos), hd, theta)
+    return cos[:, : hd // 2].contiguous().numpy(), sin[:, : hd // 2].contiguous().numpy()
+
+
+def _split_ref(qkv, B, T, H, hd, rope, pos0=0):
+    D = H * hd
+    t = torch.from_numpy(qkv).reshape(B, T, 3, H, hd).permute(2, 0, 3, 1, 4)  # [3,B,H,T,hd]
+    q, k, v = t[0], t[1], t[2]
+    if rope:
+        cos, sin = cpu_ref.rope_cos_sin(torch.arange(pos0, pos0 + T), hd, 10000.0)
+        q = cpu_ref.apply_rope(q, cos, sin)
+        k = cpu_ref.apply_rope(k, cos, sin)
+    return bf16_round(q.numpy()), bf16_round(k.numpy()), v.numpy()
+
+
+def check_qkv_split(be, B, T, H, hd, rope):
+    rng = np.random.RandomState(6)
+    D = H * hd
+    qkv = bf16_round(rng.randn(B * T, 3 * D))
+    Ts = (T + 63) // 64 * 64
+    q, k, vt = be.zeros((B, H, Ts, hd), "bf16"), be.zeros((B, H, Ts, hd), "bf16"), be.zeros((B, H, hd, Ts), "bf16")
+    cos, sin = rope_tables(Ts, hd)
+    _call(be, "vck_qkv_split", be.bf16(qkv), q, k, vt, B, T, H, hd, Ts, Ts, None,
+          be.f32(cos) if rope else None, be.f32(sin) if rope else None)
+    rq, rk, rv = _split_ref(qkv, B, T, H, hd, rope)
+    gq, gk, gv = be.host_f32(q), be.host_f32(k), be.host_f32(vt)
+    assert np.abs(gq[:, :, :T] - rq).max() <= 2 ** -7 * np.abs(rq).max()
+    assert np.abs(gk[:, :, :T] - rk).max() <= 2 ** -7 * np.abs(rk).max()
+    if not rope:
+        assert np.array_equal(gq[:, :, :T], rq) and np.array_equal(gk[:, :, :T], rk)
+    assert np.array_equal(gv[:, :, :, :T], rv.transpose(0, 1, 3, 2))
+    assert not gv[:, :, :, T:].any() and not gq[:, :, T:].any()
+
+
+def check_qkv_append(be, B, H, hd, pos):
+    rng = np.random.RandomState(7)
+    D = H * hd
+    S = 64 * ((pos + 64) // 64)
+    qkv = bf16_round(rng.randn(B, 3 * D))
+    q, k, vt = be.zeros((B, H, hd), "bf16"), be.zeros((B, H, S, hd), "bf16"), be.zeros((B, H, hd, S), "bf16")
+    cos, sin = rope_tables(S, hd)
+    _call(be, "vck_qkv_split", be.bf16(qkv), q, k, vt, B, 1, H, hd, 1, S, be.i32([pos]), be.f32(cos), be.f32(sin))
+    rq, rk, rv = _split_ref(qkv, B, 1, H, hd, True, pos0=pos)
+    assert np.abs(be.host_f32(q) - rq[:, :, 0]).max() <= 2 ** -7 * np.abs(rq).max()
+    gk, gv = be.host_f32(k), be.host_f32(vt)
+    assert np.abs(gk[:, :, pos] - rk[:, :, 0]).max() <= 2 ** -7 * np.abs(rk).max()
+    assert np.array_equal(gv[:, :, :, pos], rv[:, :, 0])
+    gk[:, :, pos] = 0
+    gv[:, :, :, pos] = 0
+    assert not gk.any() and not gv.any()
+
+
+def check_attention(be, B, H, T, hd, causal, seed=0, spike=False):
+    rng = np.random.RandomState(seed)
+    Ts = (T + 63) // 64 * 64
+    q = bf16_round(rng.randn(B, H, T, hd))
+    k = bf16_round(rng.randn(B, H, T, hd))
+    v = bf16_round(rng.randn(B, H, T, hd))
+    if spike:  # force a late running-max jump (online-softmax rescale branch)
+        k[:, :, T - 3] = q[:, :, T - 1] * 4
+    qp, kp = np.zeros((B, H, Ts, hd), np.float32), np.zeros((B, H, Ts, hd), np.float32)
+    vtp = np.zeros((B, H, hd, Ts), np.float32)
+    qp[:, :, :T], kp[:, :, :T], vtp[:, :, :, :T] = q, k, v.transpose(0, 1, 3, 2)
+    out = be.zeros((B * T, H * hd), "bf16")
+    scale = 1.0 / math.sqrt(hd)
+    _call(be, "vck_attention", be.bf16(qp), be.bf16(kp), be.bf16(vtp), out, B, H, T, hd, Ts, Ts, int(causal), scale)
+    ref = cpu_ref.softmax_attention(torch.from_numpy(q), torch.from_numpy(k), torch.from_numpy(v), scale, causal,
+                                    cpu_ref.Rounder(True))
+    ref = ref.transpose(1, 2).reshape(B * T, H * hd).numpy()
+    got = be.host_f32(out)
+    err = np.abs(got - ref).max()
+    assert err < 2 ** -7 * max(1.0, np.abs(ref).max()), f"attention B{B} H{H} T{T} hd{hd} causal{causal}: abs err {err}"
+    return err
+
+
+def check_attention_decode(be, B, H, hd, ctx, seed=0):
+    rng = np.random.RandomState(seed)
+    S = (ctx + 63) // 64 * 64 + 64
+    q = bf16_round(rng.randn(B, H, 1, hd))
+    k = bf16_round(rng.randn(B, H, ctx, hd))
+    v = bf16_round(rng.randn(B, H, ctx, hd))
+    kp, vtp = rng.randn(B, H, S, hd).astype(np.float32), rng.randn(B, H, hd, S).astype(np.float32)  # stale garbage
+    kp[:, :, :ctx], vtp[:, :, :, :ctx] = k, v.transpose(0, 1, 3, 2)
+    out = be.zeros((B, H * hd), "bf16")
+    scale = 1.0 / math.sqrt(hd)
+    _call(be, "vck_attention_decode", be.bf16(q[:, :, 0]), be.bf16(kp), be.bf16(vtp), out, B, H, hd, S,
+          be.i32([ctx]), scale)
+    ref = cpu_ref.softmax_attention(torch.from_numpy(q), torch.from_numpy(k), torch.from_numpy(v), scale, False,
+                                    cpu_ref.Rounder(False))
+    ref = ref.transpose(1, 2).reshape(B, H * hd).numpy()
+    err = np.abs(be.host_f32(out) - ref).max()
+    assert err < 2 ** -8 * max(1.0, np.abs(ref).max()), f"attention_decode ctx{ctx}: abs err {err}"
+
+
+def check_splice(be, D):
+    rng = np.random.RandomState(8)
+    V, NF = 50, 12
+    embed, feats = bf16_round(rng.randn(V, D)), bf16_round(rng.randn(NF, D))
+    rows = [(0, 3), (0, 49), (1, 0), (1, 11), (2, 0), (0, 7), (1, 5)]
+    x = be.f32(rng.randn(len(rows), D))
+    _call(be, "vck_splice", be.i32(np.array(rows).reshape(-1)), len(rows), be.bf16(embed), be.bf16(feats), x, D)
+    got = be.host_f32(x)
+    for r, (kind, src) in enumerate(rows):
+        exp = embed[src] if kind == 0 else feats[src] if kind == 1 else np.zeros(D, np.float32)
+        assert np.array_equal(got[r], exp)
+    tok = [4, 9, 0]
+    x2 = be.zeros((3, D), "f32")
+    _call(be, "vck_embed_tokens", be.i32(tok), be.bf16(embed), x2, 3, D)
+    assert np.array_equal(be.host_f32(x2), embed[tok])
+
+
+def check_greedy(be, B, V):
+    rng = np.random.RandomState(9)
+    lg = rng.randn(B, V).astype(np.float32)
+    lg[0, 17] = lg[0, 5] = lg[0].max() + 1.0       # tie -> lowest index
+    lg[1, V - 1] = lg[1].max() + 2.0
+    eos, pad, max_new = 2, 0, 4
+    if B > 2:
+        lg[2, eos] = lg[2].max() + 1.0               # row 2 emits EOS at step 0 then pads
+    nxt, out, fin = be.zeros((B,), "i32"), be.zeros((B, max_new), "i32"), be.zeros((B,), "i32")
+    step = be.i32([0])
+    for _ in range(2):
+        _call(be, "vck_greedy", be.f32(lg), nxt, out, fin, step, B, V, max_new, eos, pad)
+        _call(be, "vck_advance", step, None, None)
+    o = be.host_i32(out)
+    exp = torch.argmax(torch.from_numpy(lg), -1).numpy()
+    assert o[0, 0] == 5 and o[1, 0] == V - 1
+    for b in range(B):
+        assert o[b, 0] == exp[b]
+        assert o[b, 1] == (pad if exp[b] == eos else exp[b])
+    assert be.host_i32(step)[0] == 2
+
+
+def check_synth(be, name="model.layers.3.mlp.up_proj.weight", n=5000):
+    ts = synth.tensor_seed(name, 42)
+    hw = 0.02 * math.sqrt(3)
+    ob, of = be.zeros((n,), "bf16"), be.zeros((n,), "f32")
+    lib = be.lib
+    lib.vck_synth_bf16(be.ptr(ob), ctypes.c_uint64(n), ctypes.c_uint32(ts), ctypes.c_float(0.0), ctypes.c_float(hw), None)
+    lib.vck_synth_f32(be.ptr(of), ctypes.c_uint64(n), ctypes.c_uint32(ts), ctypes.c_float(1.0), ctypes.c_float(0.1), None)
+    be.sync()
+    assert np.array_equal(be.host_f32(ob), synth.synth_tensor(name, (n,), 42, 0.0, hw))
+    assert np.array_equal(be.host_f32(of), synth.synth_tensor(name, (n,), 42, 1.0, 0.1))

@@ -1,0 +1,71 @@
+"""CPU tests of the HIP kernels' logic through the thread-per-lane emulator (tests/emu): index math,
+LDS layouts/swizzles, MFMA fragment plumbing, reductions, masks — at small shapes, against the oracle.
+These do NOT prove hardware semantics (that is what `-m gpu` is for); they keep the GPU budget for
+measurement instead of debugging."""
+import pytest
+
+import kernel_cases as kc
+
+
+@pytest.fixture(scope="module")
+def be():
+    return kc.EmuBackend()
+
+
+@pytest.mark.parametrize("M,N,K,epi,bias", [(128, 128, 64, 3, True), (200, 136, 128, 0, True), (70, 264, 192, 1, True),
+                                            (64, 128, 64, 2, True), (100, 128, 128, 4, False), (100, 256, 64, 5, False)])
+def test_gemm(be, M, N, K, epi, bias):
+    kc.check_gemm(be, M, N, K, epi, bias)
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(8, 64, 256, 0), (3, 32, 1024, 1), (16, 48, 288, 2), (8, 64, 256, 3),
+                                       (1, 16, 32, 1)])
+def test_gemv(be, M, N, K, epi):
+    kc.check_gemv(be, M, N, K, epi)
+
+
+def test_interleave(be):
+    kc.check_interleave(be, 24, 64)
+
+
+@pytest.mark.parametrize("rows,D", [(5, 128), (9, 1024)])
+def test_layernorm(be, rows, D):
+    kc.check_layernorm(be, rows, D)
+
+
+@pytest.mark.parametrize("rows,D,gather", [(3, 256, False), (6, 4096, False), (2, 5120, True)])
+def test_rmsnorm(be, rows, D, gather):
+    kc.check_rmsnorm(be, rows, D, gather)
+
+
+def test_vit_front(be):
+    kc.check_im2col(be, 2, 56, 14, 640)
+    kc.check_vit_embed_ln(be, 2, 17, 128)
+    kc.check_select_rows(be, 2, 17, 128)
+
+
+@pytest.mark.parametrize("B,T,H,hd,rope", [(1, 70, 2, 128, True), (2, 17, 2, 64, False)])
+def test_qkv_split(be, B, T, H, hd, rope):
+    kc.check_qkv_split(be, B, T, H, hd, rope)
+
+
+def test_qkv_append(be):
+    kc.check_qkv_append(be, 2, 2, 128, 70)
+    kc.check_qkv_append(be, 1, 1, 64, 5)
+
+
+@pytest.mark.parametrize("B,H,T,hd,causal,spike", [(1, 1, 17, 64, False, False), (1, 2, 150, 64, False, True),
+                                                   (1, 1, 70, 128, True, False), (1, 1, 200, 128, True, True)])
+def test_attention(be, B, H, T, hd, causal, spike):
+    kc.check_attention(be, B, H, T, hd, causal, spike=spike)
+
+
+@pytest.mark.parametrize("hd,ctx", [(128, 70), (128, 129), (64, 33)])
+def test_attention_decode(be, hd, ctx):
+    kc.check_attention_decode(be, 1, 2, hd, ctx)
+
+
+def test_splice_greedy_synth(be):
+    kc.check_splice(be, 256)
+    kc.check_greedy(be, 3, 320)
+    kc.check_synth(be)

@@ -1,0 +1,380 @@
+// attn.hip — attention for the VCoder hot path on gfx950.
+//
+//   qkv_split   : fused-QKV GEMM output -> Q [B,H,Tq,hd], K cache [B,H,S,hd], V^T cache [B,H,hd,S] (+RoPE)
+//                 RoPE = rotate_half form of [HF] llama/modeling_llama.py:113-160 (cos/sin fp32 table)      K13/K14
+//   attention   : flash-style softmax(Q K^T * scale [+causal]) V, fp32 online softmax, MFMA 16x16x32 bf16
+//                 ViT: [HF] clip/modeling_clip.py:259-277,320-330 (non-causal, hd 64, T 577)              K5
+//                 LLM prefill: [HF] llama eager_attention_forward :191-214 (causal, hd 128)               K15
+//   attention_decode : q_len = 1 over the KV cache (HBM-streaming, VALU dot products)                    K15
+//
+// Layout choices are ours (the reference has none): K is key-major so K tiles are MFMA A-operands for
+// S^T = K Q^T straight from LDS; V is stored TRANSPOSED (d-major) so V^T tiles are A-operands for
+// O^T = V^T P^T; with S^T in the MFMA C layout each lane already owns the P values of ONE query, so
+// row max / row sum need only 2 cross-lane steps and P feeds the second MFMA from registers (the
+// contraction order over keys is permuted identically on both operands).
+#include "vc_device.h"
+#include "kernels.h"
+
+namespace vc {
+
+// =============================================================================================
+// qkv split (+RoPE), prefill form: one workgroup = (64-token tile, head, batch)
+// =============================================================================================
+template <int HD>
+__global__ __launch_bounds__(256) void qkv_split_kernel(QkvSplitArgs p) {
+    const float* __restrict__ rope_cos = p.rope_cos;
+    const float* __restrict__ rope_sin = p.rope_sin;
+    __shared__ __attribute__((aligned(16))) bf16_t vt_tile[64][HD + 8];  // +8 bf16 pad: transposed reads spread banks
+    const int t0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x;
+    const int D = p.H * HD;
+    constexpr int CPT = HD / 16;  // rope work items per token: chunk c pairs d0=8c with d0+HD/2
+    const bool rope = rope_cos != nullptr;
+    for (int w = tid; w < 64 * CPT; w += 256) {
+        const int tl = w / CPT, c = w % CPT, t = t0 + tl;
+        if (t >= p.T) continue;
+        const bf16_t* row = p.qkv + ((size_t)b * p.T + t) * (3 * D) + h * HD;
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {  // 0 = q, 1 = k
+            const bf16_t* src = row + which * D;
+            const u32x4 lo = ld16(src + c * 8), hi = ld16(src + HD / 2 + c * 8);
+            u32x4 olo = lo, ohi = hi;
+            if (rope) {
+                const float* cs = rope_cos + (size_t)t * (HD / 2) + c * 8;
+                const float* sn = rope_sin + (size_t)t * (HD / 2) + c * 8;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x0 = bf2f_lo(lo[e]), x1 = bf2f_hi(lo[e]), y0 = bf2f_lo(hi[e]), y1 = bf2f_hi(hi[e]);
+                    const float c0 = cs[2 * e], c1 = cs[2 * e + 1], s0 = sn[2 * e], s1 = sn[2 * e + 1];
+                    // out[d] = x*cos - y*sin ; out[d+hd/2] = y*cos + x*sin
+                    olo[e] = pack_bf2(x0 * c0 - y0 * s0, x1 * c1 - y1 * s1);
+                    ohi[e] = pack_bf2(y0 * c0 + x0 * s0, y1 * c1 + x1 * s1);
+                }
+            }
+            bf16_t* dst = which == 0 ? p.q + (((size_t)b * p.H + h) * p.q_stride + t) * HD
+                                     : p.k + (((size_t)b * p.H + h) * p.kv_stride + t) * HD;
+            st16(dst + c * 8, olo);
+            st16(dst + HD / 2 + c * 8, ohi);
+        }
+    }
+    // V: stage [token][d] tile, then write V^T rows 16 bytes (8 tokens) at a time
+    for (int w = tid; w < 64 * (HD / 8); w += 256) {
+        const int tl = w / (HD / 8), c = w % (HD / 8), t = t0 + tl;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (t < p.T) v = ld16(p.qkv + ((size_t)b * p.T + t) * (3 * D) + 2 * D + h * HD + c * 8);
+        st16(&vt_tile[tl][c * 8], v);
+    }
+    __syncthreads();
+    for (int w = tid; w < HD * 8; w += 256) {
+        const int d = w >> 3, tc = w & 7;
+        if (t0 + tc * 8 >= p.T) continue;
+        uint32_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            o[e] = (uint32_t)vt_tile[tc * 8 + 2 * e][d] | ((uint32_t)vt_tile[tc * 8 + 2 * e + 1][d] << 16);
+        st16(p.vt + (((size_t)b * p.H + h) * HD + d) * p.kv_stride + t0 + tc * 8, u32x4{o[0], o[1], o[2], o[3]});
+    }
+}
+
+// decode form (T == 1): position read from a device scalar; one wave per (b,h)
+template <int HD>
+__global__ __launch_bounds__(64) void qkv_append_kernel(QkvSplitArgs p) {
+    const float* __restrict__ rope_cos = p.rope_cos;
+    const float* __restrict__ rope_sin = p.rope_sin;
+    const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
+    if (d >= HD / 2) return;
+    const int pos = *p.pos0_dev;
+    const int D = p.H * HD;
+    const bf16_t* row = p.qkv + (size_t)b * (3 * D) + h * HD;
+    const float c = rope_cos[(size_t)pos * (HD / 2) + d], s = rope_sin[(size_t)pos * (HD / 2) + d];
+    const float q0 = bf2f(row[d]), q1 = bf2f(row[d + HD / 2]);
+    const float k0 = bf2f(row[D + d]), k1 = bf2f(row[D + d + HD / 2]);
+    bf16_t* qo = p.q + ((size_t)b * p.H + h) * HD;
+    qo[d] = f2bf(q0 * c - q1 * s);
+    qo[d + HD / 2] = f2bf(q1 * c + q0 * s);
+    bf16_t* ko = p.k + (((size_t)b * p.H + h) * p.kv_stride + pos) * HD;
+    ko[d] = f2bf(k0 * c - k1 * s);
+    ko[d + HD / 2] = f2bf(k1 * c + k0 * s);
+    bf16_t* vo = p.vt + ((size_t)b * p.H + h) * HD * (size_t)p.kv_stride + pos;
+    vo[(size_t)d * p.kv_stride] = row[2 * D + d];
+    vo[(size_t)(d + HD / 2) * p.kv_stride] = row[2 * D + d + HD / 2];
+}
+
+void launch_qkv_split(const QkvSplitArgs& a, hipStream_t s) {
+    if (a.pos0_dev != nullptr) {  // decode append
+        const dim3 grid(a.H, a.B), block(64);
+        if (a.hd == 128) VC_LAUNCH((qkv_append_kernel<128>), grid, block, 0, s, a);
+        else VC_LAUNCH((qkv_append_kernel<64>), grid, block, 0, s, a);
+        return;
+    }
+    const dim3 grid((a.T + 63) / 64, a.H, a.B), block(256);
+    if (a.hd == 128) VC_LAUNCH((qkv_split_kernel<128>), grid, block, 0, s, a);
+    else VC_LAUNCH((qkv_split_kernel<64>), grid, block, 0, s, a);
+}
+
+// =============================================================================================
+// flash attention: workgroup = 128 queries of one (b,h); 4 waves x 32 queries; KV tiles of 64 keys
+// =============================================================================================
+template <int HD> VC_DEV int swz_k(int row, int chunk) {  // K tile [64][HD] bf16, 16-B chunks
+    if constexpr (HD == 128) return row * 256 + ((chunk ^ (row & 15)) << 4);
+    else return row * 128 + ((chunk ^ (row & 7)) << 4);
+}
+VC_DEV int swz_v(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }  // V^T tile [HD][64]
+
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
+    constexpr int KS = HD / 32;        // k-steps of the QK^T contraction
+    constexpr int DT = HD / 16;        // 16-wide d tiles of the output
+    constexpr int KCH = HD / 8;        // 16-B chunks per K row
+    __shared__ __attribute__((aligned(16))) char k_lds[64 * HD * 2];
+    __shared__ __attribute__((aligned(16))) char v_lds[HD * 128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, j = lane & 15;
+    const int q0 = blockIdx.x * 128, h = blockIdx.y, b = blockIdx.z;
+    const size_t bh = (size_t)b * p.H + h;
+    const bf16_t* qbase = p.q + bh * p.q_stride * HD;
+    const bf16_t* kbase = p.k + bh * p.kv_stride * HD;
+    const bf16_t* vbase = p.vt + bh * HD * (size_t)p.kv_stride;
+
+    // Q fragments (MFMA B operand): lane holds Q[query j][d = ks*32 + g*8 .. +8]
+    u32x4 qf[2][KS];
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+        const int qrow = min(q0 + wave * 32 + qs * 16 + j, p.T - 1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[qs][ks] = ld16(qbase + (size_t)qrow * HD + ks * 32 + g * 8);
+    }
+    f32x4 o[2][DT];
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[qs][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+
+    const int kv_end = CAUSAL ? min(p.T, q0 + 128) : p.T;
+    const int nkt = (kv_end + 63) / 64;
+    constexpr int KLD = (64 * KCH) / 256, VLD = (HD * 8) / 256;  // staged 16-B chunks per thread
+    u32x4 rk[KLD], rv[VLD];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < KLD; ++i) {
+            const int c = tid + i * 256, row = c / KCH, ch = c % KCH;
+            rk[i] = ld16(kbase + (size_t)(kt * 64 + row) * HD + ch * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < VLD; ++i) {
+            const int c = tid + i * 256, row = c >> 3, ch = c & 7;
+            rv[i] = ld16(vbase + (size_t)row * p.kv_stride + kt * 64 + ch * 8);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < KLD; ++i) {
+            const int c = tid + i * 256;
+            st16(k_lds + swz_k<HD>(c / KCH, c % KCH), rk[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < VLD; ++i) {
+            const int c = tid + i * 256;
+            st16(v_lds + swz_v(c >> 3, c & 7), rv[i]);
+        }
+    };
+
+    load_tile(0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < nkt) load_tile(kt + 1);
+        const int k0 = kt * 64;
+        // ---- S^T = K Q^T
+        f32x4 sacc[2][4];
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub) sacc[qs][sub] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const u32x4 kf = ld16(k_lds + swz_k<HD>(sub * 16 + j, ks * 4 + g));
+                sacc[0][sub] = mfma16(kf, qf[0][ks], sacc[0][sub]);
+                sacc[1][sub] = mfma16(kf, qf[1][ks], sacc[1][sub]);
+            }
+        // ---- online softmax (lane owns query j of each q-subtile; keys spread over regs and the 4 lane groups)
+        u32x4 pb[2][2];
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+            const int query = q0 + wave * 32 + qs * 16 + j;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = k0 + sub * 16 + g * 4 + r;
+                    float v = sacc[qs][sub][r] * p.scale;
+                    if (key >= p.T || (CAUSAL && key > query)) v = -INFINITY;
+                    sacc[qs][sub][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, shfl_xor(mx, 16));
+            mx = fmaxf(mx, shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run[qs], mx);
+            const float alpha = __expf(m_run[qs] - m_new);  // first tile: exp(-inf) = 0
+            m_run[qs] = m_new;
+            float rs = 0.f;
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __expf(sacc[qs][sub][r] - m_new);
+                    sacc[qs][sub][r] = e;
+                    rs += e;
+                }
+            l_run[qs] = l_run[qs] * alpha + rs;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) o[qs][dt] = o[qs][dt] * alpha;
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+                pb[qs][kh] = u32x4{pack_bf2(sacc[qs][2 * kh][0], sacc[qs][2 * kh][1]),
+                                   pack_bf2(sacc[qs][2 * kh][2], sacc[qs][2 * kh][3]),
+                                   pack_bf2(sacc[qs][2 * kh + 1][0], sacc[qs][2 * kh + 1][1]),
+                                   pack_bf2(sacc[qs][2 * kh + 1][2], sacc[qs][2 * kh + 1][3])};
+        }
+        // ---- O^T += V^T P^T   (contraction slot (g,e) <-> key kh*32 + (e>>2)*16 + 4g + (e&3) on both operands)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+                const int row = dt * 16 + j;
+                const int c0 = kh * 4 + (g >> 1), within = (g & 1) * 8;
+                const u32x2 lo = ld8(v_lds + swz_v(row, c0) + within);
+                const u32x2 hi = ld8(v_lds + swz_v(row, c0 + 2) + within);
+                const u32x4 vf = {lo[0], lo[1], hi[0], hi[1]};
+                o[0][dt] = mfma16(vf, pb[0][kh], o[0][dt]);
+                o[1][dt] = mfma16(vf, pb[1][kh], o[1][dt]);
+            }
+        __syncthreads();
+    }
+    // ---- normalise and store: lane holds out[query j][d = dt*16 + g*4 .. +4]
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+        float l = l_run[qs];
+        l += shfl_xor(l, 16);
+        l += shfl_xor(l, 32);
+        const float inv = 1.0f / l;
+        const int query = q0 + wave * 32 + qs * 16 + j;
+        if (query < p.T) {
+            bf16_t* dst = p.out + ((size_t)b * p.T + query) * ((size_t)p.H * HD) + h * HD + g * 4;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const f32x4 v = o[qs][dt] * inv;
+                st8(dst + dt * 16, u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])});
+            }
+        }
+    }
+}
+
+void launch_attention(const AttnArgs& a, hipStream_t s) {
+    const dim3 grid((a.T + 127) / 128, a.H, a.B), block(256);
+    if (a.hd == 128) {
+        if (a.causal) VC_LAUNCH((attention_kernel<128, true>), grid, block, 0, s, a);
+        else VC_LAUNCH((attention_kernel<128, false>), grid, block, 0, s, a);
+    } else {
+        if (a.causal) VC_LAUNCH((attention_kernel<64, true>), grid, block, 0, s, a);
+        else VC_LAUNCH((attention_kernel<64, false>), grid, block, 0, s, a);
+    }
+}
+
+// =============================================================================================
+// decode attention: one 512-thread workgroup per (b,h); K rows / V^T rows streamed once from HBM
+// =============================================================================================
+constexpr int DEC_MAX_CTX = 4096;
+
+template <int HD>
+__global__ __launch_bounds__(512) void attention_decode_kernel(AttnDecodeArgs p) {
+    constexpr int LPK = HD / 8;           // lanes per key (each lane owns 8 dims)
+    constexpr int KPW = 64 / LPK;         // keys per wave-instruction
+    __shared__ __attribute__((aligned(16))) float sc[DEC_MAX_CTX];
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const size_t bh = (size_t)b * p.H + h;
+    const int ctx = *p.ctx_len_dev;
+    const int ctx64 = (ctx + 63) & ~63;
+    const bf16_t* kbase = p.k + bh * p.kv_stride * HD;
+    const bf16_t* vbase = p.vt + bh * HD * (size_t)p.kv_stride;
+
+    // ---- phase 1: scores
+    float qv[8];
+    {
+        const u32x4 q = ld16(p.q + bh * HD + (lane % LPK) * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { qv[2 * e] = bf2f_lo(q[e]); qv[2 * e + 1] = bf2f_hi(q[e]); }
+    }
+    for (int kb = wave * KPW; kb < ctx64; kb += 8 * KPW) {
+        const int key = kb + lane / LPK;
+        const u32x4 kv = ld16(kbase + (size_t)min(key, ctx - 1) * HD + (lane % LPK) * 8);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += qv[2 * e] * bf2f_lo(kv[e]) + qv[2 * e + 1] * bf2f_hi(kv[e]);
+#pragma unroll
+        for (int mk = 1; mk < LPK; mk <<= 1) s += shfl_xor(s, mk);
+        if ((lane % LPK) == 0) sc[key] = key < ctx ? s * p.scale : -INFINITY;
+    }
+    __syncthreads();
+    // ---- phase 2: softmax over sc[0..ctx64)
+    float mx = -INFINITY;
+    for (int i = tid; i < ctx64; i += 512) mx = fmaxf(mx, sc[i]);
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = red[0];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) mx = fmaxf(mx, red[w]);
+    __syncthreads();
+    float sum = 0.f;
+    for (int i = tid; i < ctx64; i += 512) {
+        const float e = __expf(sc[i] - mx);  // masked keys: exp(-inf) = 0
+        sc[i] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) sum += red[w];
+    const float inv = 1.0f / sum;
+    // ---- phase 3: out[d] = sum_key p[key] V^T[d][key]; 8 lanes per d row, 64 keys per instruction
+    constexpr int DG = HD / 64;  // d-row groups (of 8 rows) per wave: 8 waves x 8 rows = 64 rows per pass
+    const int dr = lane >> 3, kc = lane & 7;
+    float acc[DG];
+#pragma unroll
+    for (int i = 0; i < DG; ++i) acc[i] = 0.f;
+    for (int kb = 0; kb < ctx64; kb += 64) {
+        const f32x4 p0 = ld16f(&sc[kb + kc * 8]), p1 = ld16f(&sc[kb + kc * 8 + 4]);
+#pragma unroll
+        for (int i = 0; i < DG; ++i) {
+            const int d = (i * 8 + wave) * 8 + dr;
+            const u32x4 v = ld16(vbase + (size_t)d * p.kv_stride + kb + kc * 8);
+            acc[i] += p0[0] * bf2f_lo(v[0]) + p0[1] * bf2f_hi(v[0]) + p0[2] * bf2f_lo(v[1]) + p0[3] * bf2f_hi(v[1]) +
+                      p1[0] * bf2f_lo(v[2]) + p1[1] * bf2f_hi(v[2]) + p1[2] * bf2f_lo(v[3]) + p1[3] * bf2f_hi(v[3]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < DG; ++i) {
+        float a = acc[i];
+        a += shfl_xor(a, 1);
+        a += shfl_xor(a, 2);
+        a += shfl_xor(a, 4);
+        if (kc == 0) p.out[(size_t)b * p.H * HD + h * HD + (i * 8 + wave) * 8 + dr] = f2bf(a * inv);
+    }
+}
+
+void launch_attention_decode(const AttnDecodeArgs& a, hipStream_t s) {
+    const dim3 grid(a.H, a.B), block(512);
+    if (a.hd == 128) VC_LAUNCH((attention_decode_kernel<128>), grid, block, 0, s, a);
+    else VC_LAUNCH((attention_decode_kernel<64>), grid, block, 0, s, a);
+}
+
+}  // namespace vc

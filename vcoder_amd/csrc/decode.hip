@@ -1,0 +1,125 @@
+// decode.hip — weight-streaming skinny GEMM for the decode steps (M = batch <= 16 tokens).
+//
+//   out[m][n] = epilogue( sum_k X[m][k] * W[n][k] )        (Llama linears have no bias)
+//
+// Replaces nn.Linear at q/k/v/o_proj, gate/up/down_proj and lm_head of
+// [HF] llama/modeling_llama.py:174-176,254-256,280,413 + vcoder_ds_llava_llama.py:93 during the
+// generate() loop.  Each decode step streams every decoder weight
+// exactly once, so this kernel is bound by HBM, not MFMA: the weights are PRE-PACKED at load time in
+// MFMA-fragment order ([N/16][K/32][64 lanes][8 bf16]) so that one wave-instruction reads one fully
+// contiguous 1 KiB block with non-temporal loads, and a v_mfma_f32_16x16x32_bf16 per block does the
+// 16 outputs x 16 token-slots x 32 k dot products (tokens >= M are fed zeros).  K is split across the
+// waves of a workgroup and reduced through LDS; epilogues (fp32 residual add, SwiGLU) are fused.
+#include "vc_device.h"
+#include "kernels.h"
+
+namespace vc {
+
+#ifdef VC_EMU
+VC_DEV u32x4 ld16_stream(const void* p) { return ld16(p); }
+#else
+VC_DEV u32x4 ld16_stream(const void* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); }
+#endif
+
+template <int WAVES, int EPI>
+__global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
+    __shared__ __attribute__((aligned(16))) float red[WAVES][64][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nt = blockIdx.x;
+    const int nkt = p.K >> 5;
+    const int per = (nkt + WAVES - 1) / WAVES;
+    const int kt0 = wave * per, kt1 = min(nkt, kt0 + per);
+    const int m = lane & 15, g = lane >> 4;
+    const bool mvalid = m < p.M;
+    const bf16_t* wp = p.Wp + ((size_t)nt * nkt * 64 + lane) * 8;
+    const bf16_t* xp = p.X + (size_t)(mvalid ? m : 0) * p.K + g * 8;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 8;
+    int kt = kt0;
+    for (; kt + U <= kt1; kt += U) {
+        u32x4 wv[U], xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) wv[u] = ld16_stream(wp + (size_t)(kt + u) * 512);
+#pragma unroll
+        for (int u = 0; u < U; ++u) xv[u] = mvalid ? ld16(xp + (kt + u) * 32) : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = mfma16(wv[u], xv[u], acc);
+    }
+    for (; kt < kt1; ++kt) {
+        const u32x4 wv = ld16_stream(wp + (size_t)kt * 512);
+        const u32x4 xv = mvalid ? ld16(xp + kt * 32) : u32x4{0u, 0u, 0u, 0u};
+        acc = mfma16(wv, xv, acc);
+    }
+    st16f(&red[wave][lane][0], acc);
+    __syncthreads();
+    if (wave != 0) return;
+    f32x4 v = ld16f(&red[0][lane][0]);
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) v = v + ld16f(&red[w][lane][0]);
+    if (!mvalid) return;
+    const int n = nt * 16 + g * 4;  // lane holds out[m][n..n+3]
+    if constexpr (EPI == GEMV_BF16) {
+        st8(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo + n, u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])});
+    } else if constexpr (EPI == GEMV_F32) {
+        st16f(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n, v);
+    } else if constexpr (EPI == GEMV_RESID_F32) {
+        float* o = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n;
+        st16f(o, ld16f(o) + v);
+    } else {
+        *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo + (n >> 1)) =
+            pack_bf2(silu(v[0]) * v[1], silu(v[2]) * v[3]);
+    }
+}
+
+template <int WAVES>
+static void launch_gemv_w(const GemvArgs& a, int epi, hipStream_t s) {
+    const dim3 grid(a.N / 16), block(WAVES * 64);
+    switch (epi) {
+        case GEMV_BF16: VC_LAUNCH((gemv_kernel<WAVES, GEMV_BF16>), grid, block, 0, s, a); break;
+        case GEMV_F32: VC_LAUNCH((gemv_kernel<WAVES, GEMV_F32>), grid, block, 0, s, a); break;
+        case GEMV_RESID_F32: VC_LAUNCH((gemv_kernel<WAVES, GEMV_RESID_F32>), grid, block, 0, s, a); break;
+        default: VC_LAUNCH((gemv_kernel<WAVES, GEMV_SWIGLU>), grid, block, 0, s, a); break;
+    }
+}
+
+void launch_gemv(const GemvArgs& a, int epilogue, hipStream_t s) {
+    // >= ~2048 waves in flight: few output tiles -> more K-splitting waves per workgroup
+    if (a.N / 16 <= 512) launch_gemv_w<8>(a, epilogue, s);
+    else launch_gemv_w<4>(a, epilogue, s);
+}
+
+// W [N,K] row-major -> packed fragment order (done once at weight-load time)
+__global__ __launch_bounds__(256) void pack_weight_kernel(const bf16_t* W, bf16_t* Wp, int N, int K) {
+    const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;  // one 16-B chunk each
+    const size_t total = (size_t)N * K / 8;
+    if (id >= total) return;
+    const int lane = (int)(id & 63);
+    const size_t tile = id >> 6;
+    const int nkt = K >> 5;
+    const size_t nt = tile / nkt;
+    const int kt = (int)(tile % nkt);
+    const u32x4 v = ld16(W + (nt * 16 + (lane & 15)) * (size_t)K + kt * 32 + (lane >> 4) * 8);
+    st16(Wp + id * 8, v);
+}
+void launch_pack_weight(const bf16_t* W, bf16_t* Wp, int N, int K, hipStream_t s) {
+    const size_t total = (size_t)N * K / 8;
+    VC_LAUNCH(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, W, Wp, N, K);
+}
+
+__global__ __launch_bounds__(256) void interleave_rows_kernel(const bf16_t* gate, const bf16_t* up, bf16_t* out, int F,
+                                                              int K) {
+    const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int cpr = K / 8;
+    const size_t total = (size_t)2 * F * cpr;
+    if (id >= total) return;
+    const size_t row = id / cpr;
+    const int c = (int)(id % cpr);
+    const bf16_t* src = (row & 1) ? up : gate;
+    st16(out + row * K + c * 8, ld16(src + (row >> 1) * K + c * 8));
+}
+void launch_interleave_rows(const bf16_t* gate, const bf16_t* up, bf16_t* out, int F, int K, hipStream_t s) {
+    const size_t total = (size_t)2 * F * (K / 8);
+    VC_LAUNCH(interleave_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, gate, up, out, F, K);
+}
+
+}  // namespace vc

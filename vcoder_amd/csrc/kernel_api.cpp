@@ -1,0 +1,87 @@
+// kernel_api.cpp — C-ABI entry points over the individual kernel launchers (declared in
+// include/vcoder_kernels.h).  The `-m gpu` parity tests call every kernel through these with device
+// pointers; the CPU emulator build (tests/emu) exports the same symbols over host pointers.
+#include "kernels.h"
+using namespace vc;
+
+#define VCK_EXPORT extern "C" __attribute__((visibility("default")))
+static inline hipStream_t S(void* s) { return (hipStream_t)s; }
+
+VCK_EXPORT void vck_gemm(const uint16_t* A, const uint16_t* W, const float* bias, void* out, int M, int N, int K,
+                         int lda, int ldw, int ldo, int epi, void* stream) {
+    GemmArgs a{A, W, bias, out, M, N, K, lda, ldw, ldo};
+    launch_gemm(a, epi, S(stream));
+}
+VCK_EXPORT void vck_gemv(const uint16_t* X, const uint16_t* Wp, void* out, int M, int N, int K, int ldo, int epi,
+                         void* stream) {
+    GemvArgs a{X, Wp, out, M, N, K, ldo};
+    launch_gemv(a, epi, S(stream));
+}
+VCK_EXPORT void vck_pack_weight(const uint16_t* W, uint16_t* Wp, int N, int K, void* stream) {
+    launch_pack_weight(W, Wp, N, K, S(stream));
+}
+VCK_EXPORT void vck_interleave_rows(const uint16_t* g, const uint16_t* u, uint16_t* out, int F, int K, void* stream) {
+    launch_interleave_rows(g, u, out, F, K, S(stream));
+}
+VCK_EXPORT void vck_layernorm(const float* x, const float* w, const float* b, uint16_t* y, int rows, int D, float eps,
+                              void* stream) {
+    launch_layernorm(x, w, b, y, rows, D, eps, S(stream));
+}
+VCK_EXPORT void vck_rmsnorm(const float* x, const int* row_idx, const float* w, uint16_t* y, int rows, int D, float eps,
+                            void* stream) {
+    if (row_idx) launch_rmsnorm_rows(x, row_idx, w, y, rows, D, eps, S(stream));
+    else launch_rmsnorm(x, w, y, rows, D, eps, S(stream));
+}
+VCK_EXPORT void vck_im2col(const float* pixels, uint16_t* cols, int n_img, int image, int patch, int Kpad, void* stream) {
+    launch_im2col(pixels, cols, n_img, image, patch, Kpad, S(stream));
+}
+VCK_EXPORT void vck_vit_embed_ln(const float* patches, const float* cls, const float* pos, const float* w,
+                                 const float* b, float* x, int n_img, int T, int D, float eps, void* stream) {
+    launch_vit_embed_ln(patches, cls, pos, w, b, x, n_img, T, D, eps, S(stream));
+}
+VCK_EXPORT void vck_select_rows_bf16(const float* x, uint16_t* y, int n_img, int T, int skip, int D, void* stream) {
+    launch_select_rows_bf16(x, y, n_img, T, skip, D, S(stream));
+}
+VCK_EXPORT void vck_qkv_split(const uint16_t* qkv, uint16_t* q, uint16_t* k, uint16_t* vt, int B, int T, int H, int hd,
+                              int q_stride, int kv_stride, const int* pos0_dev, const float* rope_cos,
+                              const float* rope_sin, void* stream) {
+    QkvSplitArgs a{qkv, q, k, vt, B, T, H, hd, q_stride, kv_stride, pos0_dev, rope_cos, rope_sin};
+    launch_qkv_split(a, S(stream));
+}
+VCK_EXPORT void vck_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, uint16_t* out, int B, int H,
+                              int T, int hd, int q_stride, int kv_stride, int causal, float scale, void* stream) {
+    AttnArgs a{q, k, vt, out, B, H, T, hd, q_stride, kv_stride, causal, scale};
+    launch_attention(a, S(stream));
+}
+VCK_EXPORT void vck_attention_decode(const uint16_t* q, const uint16_t* k, const uint16_t* vt, uint16_t* out, int B,
+                                     int H, int hd, int kv_stride, const int* ctx_len_dev, float scale, void* stream) {
+    AttnDecodeArgs a{q, k, vt, out, B, H, hd, kv_stride, ctx_len_dev, scale};
+    launch_attention_decode(a, S(stream));
+}
+VCK_EXPORT void vck_splice(const int* row_src, int nrows, const uint16_t* embed, const uint16_t* feats, float* x, int D,
+                           void* stream) {
+    launch_splice(row_src, nrows, embed, feats, x, D, S(stream));
+}
+VCK_EXPORT void vck_embed_tokens(const int* tok, const uint16_t* embed, float* x, int B, int D, void* stream) {
+    launch_embed_tokens(tok, embed, x, B, D, S(stream));
+}
+VCK_EXPORT void vck_greedy(const float* logits, int* next_tok, int* out_ids, int* finished, int* step_dev, int B, int V,
+                           int max_new, int eos_id, int pad_id, void* stream) {
+    GreedyArgs a{logits, next_tok, out_ids, finished, step_dev, B, V, max_new, eos_id, pad_id};
+    launch_greedy(a, S(stream));
+}
+VCK_EXPORT void vck_advance(int* step_dev, int* pos_dev, int* ctx_dev, void* stream) {
+    launch_advance(step_dev, pos_dev, ctx_dev, S(stream));
+}
+VCK_EXPORT void vck_synth_bf16(uint16_t* out, uint64_t n, uint32_t tseed, float offset, float halfwidth, void* stream) {
+    launch_synth_bf16(out, (size_t)n, tseed, offset, halfwidth, S(stream));
+}
+VCK_EXPORT void vck_synth_f32(float* out, uint64_t n, uint32_t tseed, float offset, float halfwidth, void* stream) {
+    launch_synth_f32(out, (size_t)n, tseed, offset, halfwidth, S(stream));
+}
+VCK_EXPORT void vck_f32_to_bf16(const float* in, uint16_t* out, uint64_t n, void* stream) {
+    launch_f32_to_bf16(in, out, (size_t)n, S(stream));
+}
+VCK_EXPORT void vck_bf16_to_f32(const uint16_t* in, float* out, uint64_t n, void* stream) {
+    launch_bf16_to_f32(in, out, (size_t)n, S(stream));
+}

@@ -1,0 +1,144 @@
+// kernels.h — launcher declarations for the gfx950 kernels of the VCoder hot path.
+// Every launcher enqueues on `stream` and returns immediately; pointers are device pointers
+// (host pointers under the test-only emulator build).  SURVEY.md §2 work-list ids (K1..K19) are
+// quoted next to each launcher.
+#pragma once
+#include <stdint.h>
+#ifdef VC_EMU
+#include "hip_emu.h"
+#else
+#include <hip/hip_runtime.h>
+#endif
+
+namespace vc {
+
+typedef uint16_t bf16_t;
+
+enum GemmEpilogue : int {
+    EPI_BF16 = 0,        // out bf16 [M,N]   = acc + bias
+    EPI_BF16_QGELU = 1,  // out bf16 [M,N]   = quick_gelu(acc + bias)            (CLIP fc1, K7)
+    EPI_BF16_GELU = 2,   // out bf16 [M,N]   = erf_gelu(acc + bias)              (adapter, K9)
+    EPI_F32 = 3,         // out fp32 [M,N]   = acc + bias                        (patchify K1, logits K18)
+    EPI_RESID_F32 = 4,   // out fp32 [M,N]  += acc + bias  (in-place residual)   (K6, K7, K16, K17)
+    EPI_SWIGLU = 5,      // W rows interleaved (gate,up): out bf16 [M,N/2] = silu(g)*u   (K17)
+};
+
+struct GemmArgs {
+    const bf16_t* A;   // activations [M, lda], K contiguous
+    const bf16_t* W;   // weights     [N, ldw], K contiguous (HF Linear layout: out_features x in_features)
+    const float* bias; // [N] or nullptr
+    void* out;         // see GemmEpilogue
+    int M, N, K;       // K % 64 == 0, N % 8 == 0
+    int lda, ldw, ldo; // leading dims in elements
+};
+void launch_gemm(const GemmArgs& a, int epilogue, hipStream_t s);
+
+// Skinny GEMM for decode (M <= 16): weights pre-packed in MFMA-fragment order, streamed once.  K12/K16/K17/K18.
+// packed W layout: [N/16][K/32][64 lanes][8 bf16]; lane l of tile (nt,kt) holds W[nt*16+(l&15)][kt*32+(l>>4)*8 + e].
+enum GemvEpilogue : int {
+    GEMV_BF16 = 0,       // out bf16 [M, N]
+    GEMV_F32 = 1,        // out fp32 [M, N]             (logits)
+    GEMV_RESID_F32 = 2,  // out fp32 [M, N] += acc     (o_proj / down_proj into the residual stream)
+    GEMV_SWIGLU = 3,     // interleaved (gate,up) rows: out bf16 [M, N/2]
+};
+struct GemvArgs {
+    const bf16_t* X;   // [M, K] bf16 activations (M <= 16)
+    const bf16_t* Wp;  // packed weights
+    void* out;
+    int M, N, K;       // N % 16 == 0, K % 32 == 0
+    int ldo;
+};
+void launch_gemv(const GemvArgs& a, int epilogue, hipStream_t s);
+void launch_pack_weight(const bf16_t* W, bf16_t* Wp, int N, int K, hipStream_t s);
+// interleave gate/up rows: out[2f] = gate[f], out[2f+1] = up[f]
+void launch_interleave_rows(const bf16_t* gate, const bf16_t* up, bf16_t* out, int F, int K, hipStream_t s);
+
+// ---- norms (wave-per-row, fp32 statistics) --------------------------------------------------
+// K3: LayerNorm(D) fp32 in -> bf16 out.  K11: RMSNorm.
+void launch_layernorm(const float* x, const float* w, const float* b, bf16_t* y, int rows, int D, float eps,
+                      hipStream_t s);
+void launch_rmsnorm(const float* x, const float* w, bf16_t* y, int rows, int D, float eps, hipStream_t s);
+// rows gathered through an index (final norm over the last token of each sample): row r reads x[idx[r]]
+void launch_rmsnorm_rows(const float* x, const int* row_idx, const float* w, bf16_t* y, int rows, int D, float eps,
+                         hipStream_t s);
+
+// ---- ViT front end ---------------------------------------------------------------------------
+// K1 (im2col half): pixels fp32 [N,3,S,S] -> cols bf16 [N*g*g, Kpad] (zero padded from 3*P*P to Kpad)
+void launch_im2col(const float* pixels, bf16_t* cols, int n_img, int image, int patch, int Kpad, hipStream_t s);
+// K2: x[n][0] = cls + pos[0]; x[n][1+p] = patches[n*g2+p] + pos[1+p]; then pre-LayerNorm, fp32 out [N,T,D]
+void launch_vit_embed_ln(const float* patches, const float* cls, const float* pos, const float* w, const float* b,
+                         float* x, int n_img, int T, int D, float eps, hipStream_t s);
+
+// K8 feature_select: x fp32 [N,T,D] -> y bf16 [N*(T-skip), D] dropping the first `skip` rows (CLS) of each image
+void launch_select_rows_bf16(const float* x, bf16_t* y, int n_img, int T, int skip, int D, hipStream_t s);
+
+// ---- attention -------------------------------------------------------------------------------
+// qkv split (+RoPE for the LLM, K13/K14): qkv bf16 [B*T, 3*D] -> Q [B,H,Tq_stride,hd], K [B,H,S_stride,hd] at pos0..,
+// V^T [B,H,hd,S_stride].
+struct QkvSplitArgs {
+    const bf16_t* qkv;
+    bf16_t* q;
+    bf16_t* k;
+    bf16_t* vt;
+    int B, T, H, hd;
+    int q_stride;   // rows per (b,h) in Q
+    int kv_stride;  // rows (keys) per (b,h) in K / columns in V^T
+    const int* pos0_dev;  // decode append form (T == 1): device scalar holding the position; nullptr -> prefill from 0
+    const float* rope_cos;  // fp32 [max_pos, hd/2] tables (LlamaRotaryEmbedding); nullptr disables RoPE (ViT)
+    const float* rope_sin;
+};
+void launch_qkv_split(const QkvSplitArgs& a, hipStream_t s);
+
+// K5/K15 flash attention (prefill / ViT): out bf16 [B*T, H*hd]
+struct AttnArgs {
+    const bf16_t* q;
+    const bf16_t* k;
+    const bf16_t* vt;
+    bf16_t* out;
+    int B, H, T, hd;  // T queries == T keys (self attention from position 0)
+    int q_stride, kv_stride;
+    int causal;
+    float scale;
+};
+void launch_attention(const AttnArgs& a, hipStream_t s);
+
+// decode attention (q_len = 1, K15): ctx length read from a device scalar (hipGraph-replayable)
+struct AttnDecodeArgs {
+    const bf16_t* q;    // [B,H,hd]
+    const bf16_t* k;    // [B,H,kv_stride,hd]
+    const bf16_t* vt;   // [B,H,hd,kv_stride]
+    bf16_t* out;        // [B, H*hd]
+    int B, H, hd, kv_stride;
+    const int* ctx_len_dev;  // number of valid keys (including the token just appended)
+    float scale;
+};
+void launch_attention_decode(const AttnDecodeArgs& a, hipStream_t s);
+
+// ---- splice / embedding (K10) ------------------------------------------------------------------
+// per destination row r of inputs_embeds [B*S, D]: row_src[2r] = kind (0 = token id -> embed_tokens row,
+// 1 = row of the projected feature buffer, 2 = zero padding row), row_src[2r+1] = token id / feature row.
+// The table is the host-side splice plan of prepare_inputs_labels_for_multimodal (vcoder_ds_llava_arch.py:175-305).
+void launch_splice(const int* row_src, int nrows, const bf16_t* embed, const bf16_t* feats, float* x, int D,
+                   hipStream_t s);
+void launch_embed_tokens(const int* tok, const bf16_t* embed, float* x, int B, int D, hipStream_t s);
+
+// ---- greedy select (K19) ----------------------------------------------------------------------
+// logits fp32 [B,V] -> next token (lowest index on ties); EOS/pad bookkeeping; appends to out_ids[b*max_new+step]
+struct GreedyArgs {
+    const float* logits;
+    int* next_tok;      // [B]
+    int* out_ids;       // [B, max_new]
+    int* finished;      // [B]
+    int* step_dev;      // device scalar (read here; advanced by launch_advance)
+    int B, V, max_new, eos_id, pad_id;
+};
+void launch_greedy(const GreedyArgs& a, hipStream_t s);
+void launch_advance(int* step_dev, int* pos_dev, int* ctx_dev, hipStream_t s);
+
+// ---- misc ---------------------------------------------------------------------------------------
+void launch_synth_bf16(bf16_t* out, size_t n, uint32_t tseed, float offset, float halfwidth, hipStream_t s);
+void launch_synth_f32(float* out, size_t n, uint32_t tseed, float offset, float halfwidth, hipStream_t s);
+void launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
+void launch_bf16_to_f32(const bf16_t* in, float* out, size_t n, hipStream_t s);
+
+}  // namespace vc

@@ -1,0 +1,136 @@
+// misc.hip — splice/gather, greedy select, step bookkeeping, synthetic-weight generator, dtype converts.
+//
+//   splice        : embedding gather + <image>/<seg>/<depth> feature splice into inputs_embeds
+//                   (vcoder_ds_llava_arch.py:173-276,305; vcoder_llava_arch.py:180-287)                   K10
+//   embed_tokens  : decode-step embedding lookup ([HF] llama/modeling_llama.py:377)                        K10
+//   greedy        : fp32 argmax, lowest index on ties, EOS -> pad bookkeeping
+//                   ([HF] generation/utils.py:2894,2925-2929)                        K19
+#include "vc_device.h"
+#include "kernels.h"
+
+namespace vc {
+
+// one wave per destination row: bf16 source row -> fp32 residual-stream row
+__global__ __launch_bounds__(256) void splice_kernel(const int* row_src, int nrows, const bf16_t* embed,
+                                                     const bf16_t* feats, float* x, int D) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const int lane = threadIdx.x & 63;
+    const int kind = row_src[2 * row], src = row_src[2 * row + 1];
+    const bf16_t* sp = kind == 0 ? embed + (size_t)src * D : feats + (size_t)src * D;
+    float* dp = x + (size_t)row * D;
+    for (int c = lane; c < D / 8; c += 64) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (kind != 2) v = ld16(sp + c * 8);
+        st16f(dp + c * 8, f32x4{bf2f_lo(v[0]), bf2f_hi(v[0]), bf2f_lo(v[1]), bf2f_hi(v[1])});
+        st16f(dp + c * 8 + 4, f32x4{bf2f_lo(v[2]), bf2f_hi(v[2]), bf2f_lo(v[3]), bf2f_hi(v[3])});
+    }
+}
+void launch_splice(const int* row_src, int nrows, const bf16_t* embed, const bf16_t* feats, float* x, int D,
+                   hipStream_t s) {
+    VC_LAUNCH(splice_kernel, dim3((nrows + 3) / 4), dim3(256), 0, s, row_src, nrows, embed, feats, x, D);
+}
+
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const int* tok, const bf16_t* embed, float* x, int B, int D) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const int lane = threadIdx.x & 63;
+    const bf16_t* sp = embed + (size_t)tok[row] * D;
+    float* dp = x + (size_t)row * D;
+    for (int c = lane; c < D / 8; c += 64) {
+        const u32x4 v = ld16(sp + c * 8);
+        st16f(dp + c * 8, f32x4{bf2f_lo(v[0]), bf2f_hi(v[0]), bf2f_lo(v[1]), bf2f_hi(v[1])});
+        st16f(dp + c * 8 + 4, f32x4{bf2f_lo(v[2]), bf2f_hi(v[2]), bf2f_lo(v[3]), bf2f_hi(v[3])});
+    }
+}
+void launch_embed_tokens(const int* tok, const bf16_t* embed, float* x, int B, int D, hipStream_t s) {
+    VC_LAUNCH(embed_tokens_kernel, dim3((B + 3) / 4), dim3(256), 0, s, tok, embed, x, B, D);
+}
+
+// ---- greedy select: one workgroup per batch row ------------------------------------------------------
+VC_DEV void argmax_combine(float& v, int& i, float ov, int oi) {
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
+__global__ __launch_bounds__(256) void greedy_kernel(GreedyArgs p) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* lg = p.logits + (size_t)b * p.V;
+    float best = -INFINITY;
+    int bi = 0x7FFFFFFF;
+    for (int i = tid; i < p.V; i += 256) argmax_combine(best, bi, lg[i], i);
+#pragma unroll
+    for (int mk = 32; mk >= 1; mk >>= 1) {
+        const float ov = shfl_xor(best, mk);
+        const int oi = shfl_xor(bi, mk);
+        argmax_combine(best, bi, ov, oi);
+    }
+    if (lane == 0) { sv[wave] = best; si[wave] = bi; }
+    __syncthreads();
+    if (tid != 0) return;
+    for (int w = 1; w < 4; ++w) argmax_combine(best, bi, sv[w], si[w]);
+    int tok = bi;
+    if (p.eos_id >= 0) {
+        if (p.finished[b]) tok = p.pad_id;
+        if (tok == p.eos_id) p.finished[b] = 1;
+    }
+    p.next_tok[b] = tok;
+    const int step = *p.step_dev;
+    if (step < p.max_new) p.out_ids[(size_t)b * p.max_new + step] = tok;
+}
+void launch_greedy(const GreedyArgs& a, hipStream_t s) {
+    VC_LAUNCH(greedy_kernel, dim3(a.B), dim3(256), 0, s, a);
+}
+
+__global__ __launch_bounds__(64) void advance_kernel(int* step_dev, int* pos_dev, int* ctx_dev) {
+    if (threadIdx.x != 0) return;
+    if (step_dev) *step_dev += 1;
+    if (pos_dev) *pos_dev += 1;
+    if (ctx_dev) *ctx_dev += 1;
+}
+void launch_advance(int* step_dev, int* pos_dev, int* ctx_dev, hipStream_t s) {
+    VC_LAUNCH(advance_kernel, dim3(1), dim3(64), 0, s, step_dev, pos_dev, ctx_dev);
+}
+
+// ---- synthetic checkpoint generator: bit-identical to vcoder_amd/synth.py:synth_tensor ----------------
+VC_DEV float synth_value(uint32_t idx, uint32_t tseed, float offset, float scale) {
+    uint32_t x = idx * 0x9E3779B1u + tseed;
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    const float u = (float)(x >> 8);
+    float v = __fmul_rn(u - 8388607.5f, scale);
+    if (offset != 0.f) v = __fadd_rn(v, offset);
+    return bf2f(f2bf(v));
+}
+__global__ __launch_bounds__(256) void synth_bf16_kernel(bf16_t* out, size_t n, uint32_t tseed, float offset,
+                                                         float scale) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = f2bf(synth_value((uint32_t)i, tseed, offset, scale));
+}
+__global__ __launch_bounds__(256) void synth_f32_kernel(float* out, size_t n, uint32_t tseed, float offset, float scale) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = synth_value((uint32_t)i, tseed, offset, scale);
+}
+static unsigned grid_for(size_t n) { return (unsigned)min((size_t)8192, (n + 255) / 256); }
+void launch_synth_bf16(bf16_t* out, size_t n, uint32_t tseed, float offset, float halfwidth, hipStream_t s) {
+    VC_LAUNCH(synth_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, s, out, n, tseed, offset,
+              (float)(halfwidth / 8388608.0));
+}
+void launch_synth_f32(float* out, size_t n, uint32_t tseed, float offset, float halfwidth, hipStream_t s) {
+    VC_LAUNCH(synth_f32_kernel, dim3(grid_for(n)), dim3(256), 0, s, out, n, tseed, offset,
+              (float)(halfwidth / 8388608.0));
+}
+
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* in, bf16_t* out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = f2bf(in[i]);
+}
+__global__ __launch_bounds__(256) void bf16_to_f32_kernel(const bf16_t* in, float* out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = bf2f(in[i]);
+}
+void launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s) {
+    VC_LAUNCH(f32_to_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, s, in, out, n);
+}
+void launch_bf16_to_f32(const bf16_t* in, float* out, size_t n, hipStream_t s) {
+    VC_LAUNCH(bf16_to_f32_kernel, dim3(grid_for(n)), dim3(256), 0, s, in, out, n);
+}
+
+}  // namespace vc

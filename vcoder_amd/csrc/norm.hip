@@ -1,0 +1,171 @@
+// norm.hip — wavefront-reduction normalisation kernels + the ViT front end.
+//
+//   LayerNorm  ([HF] clip/modeling_clip.py:370,379,642; nn.LayerNorm, biased variance, eps 1e-5)       K2/K3
+//   RMSNorm    ([HF] llama/modeling_llama.py:53-70: fp32 variance, x*rsqrt(var+eps), then *weight)       K11
+//   im2col     (Conv2d(3->Dv, k=s=14, no bias) of [HF] clip :149-155,209 restated as a GEMM operand)      K1
+//   embed+preLN([HF] clip :212-217 CLS concat + position add, :642 pre_layrnorm)                         K2
+//   feature_select (multimodal_encoder/clip_encoder.py:29-37: hidden_states[-2], drop CLS)               K8
+//
+// One 64-lane wave owns one row; the row lives in registers (float4 per lane per 256 columns), statistics
+// are two-pass in fp32 and reduced with 6 cross-lane xor steps — no LDS, no barriers.  HBM-bound.
+#include "vc_device.h"
+#include "kernels.h"
+
+namespace vc {
+
+// MAXV float4 per lane -> rows up to MAXV*256 columns
+template <int MAXV, bool RMS, bool OUT_F32>
+VC_DEV void norm_row(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                     void* __restrict__ y, int D, float eps, const float* __restrict__ add0,
+                     const float* __restrict__ add1) {
+    const int lane = lane_id();
+    const int nch = D >> 2;
+    f32x4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+            v[i] = ld16f(x + c * 4);
+            if (add0) v[i] = v[i] + ld16f(add0 + c * 4);
+            if (add1) v[i] = v[i] + ld16f(add1 + c * 4);
+        } else {
+            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    float mean = 0.f;
+    if (!RMS) mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[i][e] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+            const f32x4 wv = ld16f(w + c * 4);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * wv[e];
+            if (!RMS) o = o + ld16f(b + c * 4);
+            if (OUT_F32) {
+                st16f(reinterpret_cast<float*>(y) + c * 4, o);
+            } else {
+                u32x2 pk = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+                st8(reinterpret_cast<bf16_t*>(y) + c * 4, pk);
+            }
+        }
+    }
+}
+
+template <int MAXV, bool RMS>
+__global__ __launch_bounds__(256) void norm_kernel(const float* x, const int* row_idx, const float* w, const float* b,
+                                                   bf16_t* y, int rows, int D, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;  // wave-uniform
+    const int src = row_idx ? row_idx[row] : row;
+    norm_row<MAXV, RMS, false>(x + (size_t)src * D, w, b, y + (size_t)row * D, D, eps, nullptr, nullptr);
+}
+
+template <bool RMS>
+static void launch_norm(const float* x, const int* idx, const float* w, const float* b, bf16_t* y, int rows, int D,
+                        float eps, hipStream_t s) {
+    const dim3 grid((rows + 3) / 4), block(256);
+    if (D <= 1024) VC_LAUNCH((norm_kernel<4, RMS>), grid, block, 0, s, x, idx, w, b, y, rows, D, eps);
+    else if (D <= 4096) VC_LAUNCH((norm_kernel<16, RMS>), grid, block, 0, s, x, idx, w, b, y, rows, D, eps);
+    else VC_LAUNCH((norm_kernel<32, RMS>), grid, block, 0, s, x, idx, w, b, y, rows, D, eps);
+}
+
+void launch_layernorm(const float* x, const float* w, const float* b, bf16_t* y, int rows, int D, float eps,
+                      hipStream_t s) {
+    launch_norm<false>(x, nullptr, w, b, y, rows, D, eps, s);
+}
+void launch_rmsnorm(const float* x, const float* w, bf16_t* y, int rows, int D, float eps, hipStream_t s) {
+    launch_norm<true>(x, nullptr, w, nullptr, y, rows, D, eps, s);
+}
+void launch_rmsnorm_rows(const float* x, const int* row_idx, const float* w, bf16_t* y, int rows, int D, float eps,
+                         hipStream_t s) {
+    launch_norm<true>(x, row_idx, w, nullptr, y, rows, D, eps, s);
+}
+
+// ---- K2: CLS concat + position embedding + pre-LayerNorm -> fp32 residual stream ----------------------
+template <int MAXV>
+__global__ __launch_bounds__(256) void vit_embed_ln_kernel(const float* patches, const float* cls, const float* pos,
+                                                           const float* w, const float* b, float* x, int n_img, int T,
+                                                           int D, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_img * T) return;
+    const int n = row / T, t = row % T;
+    const float* src = t == 0 ? cls : patches + ((size_t)n * (T - 1) + (t - 1)) * D;
+    norm_row<MAXV, false, true>(src, w, b, x + (size_t)row * D, D, eps, pos + (size_t)t * D, nullptr);
+}
+void launch_vit_embed_ln(const float* patches, const float* cls, const float* pos, const float* w, const float* b,
+                         float* x, int n_img, int T, int D, float eps, hipStream_t s) {
+    const dim3 grid((n_img * T + 3) / 4), block(256);
+    if (D <= 1024) VC_LAUNCH((vit_embed_ln_kernel<4>), grid, block, 0, s, patches, cls, pos, w, b, x, n_img, T, D, eps);
+    else VC_LAUNCH((vit_embed_ln_kernel<16>), grid, block, 0, s, patches, cls, pos, w, b, x, n_img, T, D, eps);
+}
+
+// ---- K1: im2col (pixels fp32 NCHW -> bf16 [N*g*g, Kpad]); column = c*P*P + py*P + px ---------------------
+__global__ __launch_bounds__(256) void im2col_kernel(const float* pixels, bf16_t* cols, int n_img, int S, int P,
+                                                     int Kpad) {
+    const int g = S / P, chunks = Kpad >> 3;
+    const size_t total = (size_t)n_img * g * g * chunks;
+    const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= total) return;
+    const int ch = (int)(id % chunks);
+    const size_t row = id / chunks;
+    const int n = (int)(row / (g * g)), gy = (int)((row / g) % g), gx = (int)(row % g);
+    const int Kreal = 3 * P * P;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int col = ch * 8 + e;
+        if (col < Kreal) {
+            const int c = col / (P * P), py = (col / P) % P, px = col % P;
+            v[e] = pixels[(((size_t)n * 3 + c) * S + (gy * P + py)) * S + gx * P + px];
+        } else {
+            v[e] = 0.f;
+        }
+    }
+    u32x4 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+    st16(cols + row * Kpad + ch * 8, o);
+}
+void launch_im2col(const float* pixels, bf16_t* cols, int n_img, int image, int patch, int Kpad, hipStream_t s) {
+    const int g = image / patch;
+    const size_t total = (size_t)n_img * g * g * (Kpad / 8);
+    VC_LAUNCH(im2col_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, pixels, cols, n_img, image, patch,
+              Kpad);
+}
+
+// ---- K8: feature_select — drop the first `skip` rows of every image, fp32 -> bf16 ----------------------
+__global__ __launch_bounds__(256) void select_rows_kernel(const float* x, bf16_t* y, int n_img, int T, int skip,
+                                                          int D) {
+    const int chunks = D >> 3;
+    const size_t total = (size_t)n_img * (T - skip) * chunks;
+    const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= total) return;
+    const int ch = (int)(id % chunks);
+    const size_t orow = id / chunks;
+    const size_t n = orow / (T - skip), t = orow % (T - skip) + skip;
+    const float* src = x + (n * T + t) * D + ch * 8;
+    const f32x4 a = ld16f(src), b = ld16f(src + 4);
+    u32x4 o = {pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3]), pack_bf2(b[0], b[1]), pack_bf2(b[2], b[3])};
+    st16(y + orow * D + ch * 8, o);
+}
+void launch_select_rows_bf16(const float* x, bf16_t* y, int n_img, int T, int skip, int D, hipStream_t s) {
+    const size_t total = (size_t)n_img * (T - skip) * (D / 8);
+    VC_LAUNCH(select_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, y, n_img, T, skip, D);
+}
+
+}  // namespace vc

@@ -1,0 +1,87 @@
+// vc_device.h — device-side primitives for the VCoder gfx950 (CDNA4) kernels.
+//
+// The kernels are written once and built two ways:
+//   * hipcc --offload-arch=gfx950           -> the product library (libvcoder_hip.so)
+//   * host clang++ -DVC_EMU (tests/emu/)    -> a thread-per-lane functional emulator used ONLY by the
+//     CPU test-suite to check index math / LDS layouts / reductions before a GPU is available.  The
+//     product never links or loads the emulator.
+//
+// wave = 64 lanes; MFMA = v_mfma_f32_16x16x32_bf16 (A[i][k]: lane i+16*(k/8), elem k%8;
+// B[k][j]: lane j+16*(k/8), elem k%8; D[i][j]: lane j+16*(i/4), reg i%4).
+#pragma once
+#include <stdint.h>
+
+#ifdef VC_EMU
+#include "hip_emu.h"
+#else
+#include <hip/hip_runtime.h>
+#define VC_DYNAMIC_SMEM(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
+#define VC_LAUNCH(kernel, grid, block, shmem, stream, ...) \
+    hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__)
+#endif
+
+#define VC_DEV __device__ __forceinline__
+#define VC_WAVE 64
+
+namespace vc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef uint16_t bf16_t;  // raw bf16 bit pattern
+
+// ---- bf16 <-> fp32 -------------------------------------------------------------------------
+VC_DEV float bf2f(bf16_t b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }
+VC_DEV float bf2f_lo(uint32_t packed) { return __builtin_bit_cast(float, packed << 16); }
+VC_DEV float bf2f_hi(uint32_t packed) { return __builtin_bit_cast(float, packed & 0xFFFF0000u); }
+
+#ifdef VC_EMU
+VC_DEV bf16_t f2bf(float f) {
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+#else
+VC_DEV bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }  // v_cvt_pk_bf16_f32 (RNE)
+#endif
+VC_DEV uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+// ---- MFMA ----------------------------------------------------------------------------------
+#ifndef VC_EMU
+typedef __bf16 bf16x8_hw __attribute__((ext_vector_type(8)));
+VC_DEV f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_hw, a),
+                                                   __builtin_bit_cast(bf16x8_hw, b), c, 0, 0, 0);
+}
+VC_DEV int lane_id() { return (int)(threadIdx.x & 63); }
+template <class T> VC_DEV T shfl_xor(T v, int mask) { return __shfl_xor(v, mask, 64); }
+template <class T> VC_DEV T shfl(T v, int src) { return __shfl(v, src, 64); }
+#endif
+
+// ---- wave / block reductions ---------------------------------------------------------------
+VC_DEV float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);
+    return v;
+}
+VC_DEV float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, shfl_xor(v, m));
+    return v;
+}
+
+// 16-byte global/LDS accessors on raw pointers
+VC_DEV u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+VC_DEV void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+VC_DEV u32x2 ld8(const void* p) { return *reinterpret_cast<const u32x2*>(p); }
+VC_DEV void st8(void* p, u32x2 v) { *reinterpret_cast<u32x2*>(p) = v; }
+VC_DEV f32x4 ld16f(const void* p) { return *reinterpret_cast<const f32x4*>(p); }
+VC_DEV void st16f(void* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// ---- activations (fp32) --------------------------------------------------------------------
+VC_DEV float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }   // x*sigmoid(1.702x)
+VC_DEV float erf_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+VC_DEV float silu(float x) { return x / (1.0f + __expf(-x)); }
+
+}  // namespace vc
