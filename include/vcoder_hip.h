@@ -1,0 +1,116 @@
+/* vcoder_hip.h — C ABI of libvcoder_hip.so: the MI355X-native VCoder inference hot path.
+ *
+ * The reference (SHI-Labs/VCoder) has no FFI: its boundary is the Python model API
+ *   load_pretrained_model()                     vcoder_llava/model/builder.py:25-154
+ *   VCoder[DS]LlavaLlamaForCausalLM.forward()   vcoder_llava/model/language_model/vcoder_ds_llava_llama.py:57-118
+ *   .generate() (HF GenerationMixin)            called at vcoder_llava/serve/cli.py:122-132
+ * This library owns all device work behind that API; vcoder_amd/ (Python, ctypes) re-creates the
+ * reference's import surface on top of it.  Plain C: opaque handles, pointers and sizes,
+ * no C++ types, no exceptions across the boundary.
+ *
+ * Ownership: the caller owns every input/output buffer; the library owns weights, KV cache, workspaces,
+ * streams and hipGraph objects.  `vc_model_load_tensor` copies (the caller may free immediately).
+ * Threading: one vc_model = one device + one stream; not thread-safe (matches the reference's callers).
+ * Errors: every call returns VC_OK (0) or a negative vc_status; vc_last_error() gives the message.
+ */
+#ifndef VCODER_HIP_H
+#define VCODER_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vc_ctx vc_ctx;
+typedef struct vc_model vc_model;
+
+typedef enum {
+    VC_OK = 0,
+    VC_IGNORED = 1,          /* load_tensor: key accepted but dead at inference */
+    VC_ERR_INVALID = -1,     /* bad argument / shape / unknown key            -> ValueError   */
+    VC_ERR_HIP = -2,         /* HIP runtime failure                           -> RuntimeError */
+    VC_ERR_STATE = -3,       /* call order violation (e.g. decode before prefill) -> RuntimeError */
+    VC_ERR_INDEX = -4,       /* a placeholder id reached the embedding lookup -> IndexError (vcoder_llava_arch.py:187 quirk) */
+    VC_ERR_UNEQUAL = -5      /* unequal spliced lengths with attention_mask   -> UnboundLocalError (vcoder_ds_llava_arch.py:295-297) */
+} vc_status;
+
+/* which reference class: llava_arch.py / vcoder_llava_arch.py / vcoder_ds_llava_arch.py */
+typedef enum { VC_VARIANT_LLAVA = 0, VC_VARIANT_VCODER = 1, VC_VARIANT_VCODER_DS = 2 } vc_variant;
+typedef enum { VC_F32 = 0, VC_BF16 = 1 } vc_dtype;
+typedef enum { VC_MOD_IMAGE = 0, VC_MOD_SEG = 1, VC_MOD_DEPTH = 2 } vc_modality;
+
+/* Mirrors the config keys the reference constructors read. */
+typedef struct vc_model_cfg {
+    int32_t variant;            /* vc_variant */
+    /* CLIP ViT (multimodal_encoder/clip_encoder.py) */
+    int32_t vit_hidden, vit_heads, vit_ffn, vit_layers, vit_layers_used, vit_image, vit_patch;
+    int32_t vit_keep_cls;       /* mm_vision_select_feature == 'cls_patch' */
+    float vit_ln_eps;
+    /* Llama decoder */
+    int32_t hidden, heads, ffn, layers, vocab, max_positions;
+    float rms_eps, rope_theta;
+    /* adapters: 0 = identity, 1 = linear, N = mlpNx_gelu  (multimodal_projector/builder.py:33-51) */
+    int32_t mm_proj_depth, seg_proj_depth;
+    int32_t pad_token_id;
+} vc_model_cfg;
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+int vc_init(int device_id, vc_ctx** out);
+void vc_shutdown(vc_ctx* ctx);
+const char* vc_last_error(vc_ctx* ctx);
+int vc_synchronize(vc_ctx* ctx);
+void* vc_stream(vc_ctx* ctx);                 /* the hipStream_t all work of this context is enqueued on */
+
+int vc_model_create(vc_ctx* ctx, const vc_model_cfg* cfg, vc_model** out);
+void vc_model_destroy(vc_model* m);
+
+/* ---- weights: replaces HF from_pretrained() of builder.py:93-108 + CLIPVisionTower.load_model() ---- */
+/* hf_key = state-dict key of the reference checkpoint; host_ptr = row-major tensor of `dtype`. */
+int vc_model_load_tensor(vc_model* m, const char* hf_key, const void* host_ptr, int dtype, const int64_t* shape,
+                         int ndim);
+/* device-side deterministic generator, bit-identical to vcoder_amd/synth.py:synth_tensor (benchmarks, tests) */
+int vc_model_synth_tensor(vc_model* m, const char* hf_key, const int64_t* shape, int ndim, uint32_t tensor_seed,
+                          float offset, float halfwidth);
+/* after the last tensor: fuses QKV / interleaves gate-up / packs decode copies; fails listing a missing key */
+int vc_model_finalize(vc_model* m);
+
+/* ---- hot path ------------------------------------------------------------------------------ */
+/* encode_images / encode_seg_images / encode_depth_images (vcoder_ds_llava_arch.py:106-119):
+ * pixels fp32 [B,3,S,S] (host, or device when pixels_on_device) -> projected features fp32 [B,P,hidden] on host. */
+int vc_encode(vc_model* m, int modality, const float* pixels, int pixels_on_device, int B, float* out_feats_host);
+
+/* prepare_inputs_labels_for_multimodal + LlamaModel + lm_head (vcoder_ds_llava_llama.py:57-118), prefill.
+ * ids [B,T] int64 host with -200/-300/-400 placeholders; seg/depth may be NULL.  has_attention_mask only
+ * selects the reference's behaviour for unequal spliced lengths (error vs zero right-padding).
+ * logits_last [B,V] and/or logits_all [B,S,V] (host fp32) may be NULL.  Leaves the KV cache at length S. */
+int vc_prefill(vc_model* m, const int64_t* ids, int B, int T, const float* img, const float* seg, const float* depth,
+               int pixels_on_device, int has_attention_mask, float* logits_last, float* logits_all, int* S_out);
+/* encode + splice only: inputs_embeds [B,S,hidden] fp32 to host (what prepare_inputs_labels_for_multimodal returns) */
+int vc_prefill_embeds_only(vc_model* m, const int64_t* ids, int B, int T, const float* img, const float* seg,
+                           const float* depth, int pixels_on_device, int has_attention_mask, float* out_host,
+                           int* S_out);
+
+/* one cached decode step (input_ids.shape[1]==1 fast path, vcoder_ds_llava_arch.py:130-133).
+ * tok [B] host (NULL: use the token the previous step selected on device); logits [B,V] host or NULL;
+ * next_tok [B] host (greedy argmax, lowest index on ties) or NULL. */
+int vc_decode_step(vc_model* m, const int32_t* tok, float* logits, int32_t* next_tok);
+
+/* greedy generate(): encode + splice + prefill + (max_new-1) hipGraph-replayed decode steps, HF semantics
+ * (SURVEY.md Appendix C): eos_id < 0 disables EOS; finished rows emit pad_id; stops when all rows finished.
+ * generate() always carries an attention_mask, so unequal spliced lengths fail with VC_ERR_UNEQUAL (quirk 6).
+ * out_ids [B,max_new] int32 host (row-major, unused tail = pad_id); n_generated = columns produced. */
+int vc_generate_greedy(vc_model* m, const int64_t* ids, int B, int T, const float* img, const float* seg,
+                       const float* depth, int pixels_on_device, int max_new, int eos_id, int pad_id,
+                       int32_t* out_ids, int* n_generated);
+
+/* ---- measurement hooks (bench.py) ---------------------------------------------------------------- */
+/* times `reps` sweeps of every decode GEMV launch of one step (4 per layer + lm_head) with HIP events on the
+ * model's stream; returns launches per sweep, average microseconds per launch, algorithmic weight bytes per launch */
+int vc_profile_decode_gemv(vc_model* m, int B, int reps, int* launches, double* avg_us, double* avg_bytes);
+/* wall-clock split of the last vc_generate_greedy in ms (HIP events): encode, prefill, decode */
+int vc_last_timings(vc_model* m, float* encode_ms, float* prefill_ms, float* decode_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VCODER_HIP_H */

@@ -6,8 +6,14 @@ thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 namespace vc_emu {
 thread_local BlockCtx* g_ctx = nullptr;
 thread_local int g_lane = 0, g_wave = 0;
+Graph* g_capturing = nullptr;
 
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {
+    if (g_capturing) {  // stream capture: record, run at hipGraphLaunch
+        Graph* g = g_capturing;
+        g->ops.push_back([=]() { launch(grid, block, shmem, body); });
+        return;
+    }
     const int nthreads = (int)(block.x * block.y * block.z);
     if (nthreads % 64 != 0 || nthreads > 1024) {
         fprintf(stderr, "emu: block size %d must be a multiple of 64 (<=1024)\n", nthreads);

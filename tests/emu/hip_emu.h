@@ -52,6 +52,53 @@ extern thread_local int g_lane, g_wave;
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
 }  // namespace vc_emu
 
+
+// ---- minimal HIP runtime shims so that the host engine (engine.hip) also runs under the emulator ----------
+#include <chrono>
+typedef int hipError_t;
+static const hipError_t hipSuccess = 0;
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
+enum hipStreamCaptureMode { hipStreamCaptureModeGlobal };
+inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+inline hipError_t hipMalloc(void** p, size_t n) { *p = aligned_alloc(256, (n + 255) / 256 * 256 + 256); return *p ? 0 : 1; }
+template <class T> inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
+inline hipError_t hipFree(void* p) { free(p); return 0; }
+inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return 0; }
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return 0; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return 0; }
+inline hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t) {
+    for (size_t r = 0; r < h; ++r) memcpy((char*)d + r * dp, (const char*)s + r * sp, w);
+    return 0;
+}
+inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return 0; }
+inline hipError_t hipSetDevice(int) { return 0; }
+inline hipError_t hipStreamCreate(hipStream_t* s) { *s = (void*)0x1; return 0; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+struct EmuEvent { double t; };
+typedef EmuEvent* hipEvent_t;
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new EmuEvent{0}; return 0; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return 0; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) {
+    e->t = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    return 0;
+}
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return 0; }
+namespace vc_emu {
+struct Graph { std::vector<std::function<void()>> ops; };
+extern Graph* g_capturing;
+}
+typedef vc_emu::Graph* hipGraph_t;
+typedef vc_emu::Graph* hipGraphExec_t;
+typedef void* hipGraphNode_t;
+inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { vc_emu::g_capturing = new vc_emu::Graph(); return 0; }
+inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = vc_emu::g_capturing; vc_emu::g_capturing = nullptr; return 0; }
+inline hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t g, hipGraphNode_t*, char*, size_t) { *e = new vc_emu::Graph(*g); return 0; }
+inline hipError_t hipGraphDestroy(hipGraph_t g) { delete g; return 0; }
+inline hipError_t hipGraphExecDestroy(hipGraphExec_t g) { delete g; return 0; }
+inline hipError_t hipGraphLaunch(hipGraphExec_t g, hipStream_t) { for (auto& f : g->ops) f(); return 0; }
+
 extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 
 inline void __syncthreads() { pthread_barrier_wait(&vc_emu::g_ctx->bar); }

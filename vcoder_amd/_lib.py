@@ -1,0 +1,77 @@
+"""ctypes binding of libvcoder_hip.so (include/vcoder_hip.h + include/vcoder_kernels.h).
+
+The product has exactly one compute path: the HIP library.  There is no CPU fallback — if the
+library is missing or there is no GPU, loading fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libvcoder_hip.so")
+
+VC_OK, VC_IGNORED = 0, 1
+VC_ERR_INVALID, VC_ERR_HIP, VC_ERR_STATE, VC_ERR_INDEX, VC_ERR_UNEQUAL = -1, -2, -3, -4, -5
+VC_F32, VC_BF16 = 0, 1
+VARIANTS = {"llava": 0, "vcoder": 1, "vcoder_ds": 2}
+MODALITY = {"img": 0, "seg": 1, "depth": 2}
+
+
+class ModelCfg(C.Structure):
+    _fields_ = [("variant", C.c_int32),
+                ("vit_hidden", C.c_int32), ("vit_heads", C.c_int32), ("vit_ffn", C.c_int32), ("vit_layers", C.c_int32),
+                ("vit_layers_used", C.c_int32), ("vit_image", C.c_int32), ("vit_patch", C.c_int32),
+                ("vit_keep_cls", C.c_int32), ("vit_ln_eps", C.c_float),
+                ("hidden", C.c_int32), ("heads", C.c_int32), ("ffn", C.c_int32), ("layers", C.c_int32),
+                ("vocab", C.c_int32), ("max_positions", C.c_int32), ("rms_eps", C.c_float), ("rope_theta", C.c_float),
+                ("mm_proj_depth", C.c_int32), ("seg_proj_depth", C.c_int32), ("pad_token_id", C.c_int32)]
+
+
+def declare(lib: C.CDLL) -> C.CDLL:
+    """Attach argtypes/restypes of the model-level ABI (the vck_* kernel entry points are called with
+    explicit ctypes values by the tests)."""
+    vp, i32, f32p = C.c_void_p, C.c_int, C.POINTER(C.c_float)
+    i64p, i32p = C.POINTER(C.c_int64), C.POINTER(C.c_int32)
+    lib.vc_init.argtypes = [i32, C.POINTER(vp)]
+    lib.vc_shutdown.argtypes = [vp]
+    lib.vc_shutdown.restype = None
+    lib.vc_last_error.argtypes = [vp]
+    lib.vc_last_error.restype = C.c_char_p
+    lib.vc_synchronize.argtypes = [vp]
+    lib.vc_stream.argtypes = [vp]
+    lib.vc_stream.restype = vp
+    lib.vc_model_create.argtypes = [vp, C.POINTER(ModelCfg), C.POINTER(vp)]
+    lib.vc_model_destroy.argtypes = [vp]
+    lib.vc_model_destroy.restype = None
+    lib.vc_model_load_tensor.argtypes = [vp, C.c_char_p, vp, i32, i64p, i32]
+    lib.vc_model_synth_tensor.argtypes = [vp, C.c_char_p, i64p, i32, C.c_uint32, C.c_float, C.c_float]
+    lib.vc_model_finalize.argtypes = [vp]
+    lib.vc_encode.argtypes = [vp, i32, vp, i32, i32, vp]
+    lib.vc_prefill.argtypes = [vp, vp, i32, i32, vp, vp, vp, i32, i32, vp, vp, C.POINTER(C.c_int)]
+    lib.vc_prefill_embeds_only.argtypes = [vp, vp, i32, i32, vp, vp, vp, i32, i32, vp, C.POINTER(C.c_int)]
+    lib.vc_decode_step.argtypes = [vp, vp, vp, vp]
+    lib.vc_generate_greedy.argtypes = [vp, vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, vp, C.POINTER(C.c_int)]
+    lib.vc_profile_decode_gemv.argtypes = [vp, i32, i32, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.vc_last_timings.argtypes = [vp, f32p, f32p, f32p]
+    for name in ("vc_init", "vc_synchronize", "vc_model_create", "vc_model_load_tensor", "vc_model_synth_tensor",
+                 "vc_model_finalize", "vc_encode", "vc_prefill", "vc_prefill_embeds_only", "vc_decode_step",
+                 "vc_generate_greedy", "vc_profile_decode_gemv", "vc_last_timings"):
+        getattr(lib, name).restype = C.c_int
+    return lib
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library.  Raises if it has not been built — never falls back to anything else."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m vcoder_amd.build` (hipcc, gfx950). "
+            "vcoder_amd has no CPU fallback.")
+    _lib = declare(C.CDLL(LIB_PATH))
+    return _lib

@@ -1,0 +1,1074 @@
+// engine.hip — host-side engine + C ABI (include/vcoder_hip.h) of the MI355X-native VCoder hot path.
+//
+// Owns: weights (HF key -> fused / interleaved / MFMA-packed device layouts), the ViT and LLM workspaces,
+// the KV cache (K key-major, V transposed), rope tables, the splice planner, and the hipGraph of one
+// decode step.  Replaces L0-L2 (+ forward/generate of L3) of the reference:
+//   CLIPVisionTower.forward            vcoder_llava/model/multimodal_encoder/clip_encoder.py:39-51
+//   encode_*                            vcoder_llava/model/vcoder_ds_llava_arch.py:106-124
+//   prepare_inputs_labels_for_multimodal  vcoder_ds_llava_arch.py:126-314, vcoder_llava_arch.py:146-296, llava_arch.py:99-199
+//   ...ForCausalLM.forward              vcoder_llava/model/language_model/vcoder_ds_llava_llama.py:57-118
+//   HF greedy loop                      SURVEY.md Appendix C
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/vcoder_hip.h"
+#include "kernels.h"
+
+using namespace vc;
+
+#define VC_API extern "C" __attribute__((visibility("default")))
+
+static const int IMAGE_TOKEN_INDEX = -200;  // vcoder_llava/constants.py:5
+static const int SEG_TOKEN_INDEX = -300;    // constants.py:8
+static const int DEPTH_TOKEN_INDEX = -400;  // constants.py:11
+
+struct vc_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+};
+
+namespace {
+
+struct Fail {
+    int code;
+    std::string msg;
+};
+#define HIPCHK(x)                                                                                       \
+    do {                                                                                                \
+        hipError_t e_ = (x);                                                                            \
+        if (e_ != hipSuccess)                                                                           \
+            throw Fail{VC_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)};                     \
+    } while (0)
+#define REQUIRE(cond, code, ...)                                                                        \
+    do {                                                                                                \
+        if (!(cond)) {                                                                                  \
+            char b_[512];                                                                               \
+            snprintf(b_, sizeof b_, __VA_ARGS__);                                                       \
+            throw Fail{code, b_};                                                                       \
+        }                                                                                               \
+    } while (0)
+
+inline size_t rup(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct Buf {  // grow-only device buffer
+    void* p = nullptr;
+    size_t cap = 0;
+    void ensure(size_t bytes, bool zero = false) {
+        if (bytes <= cap) return;
+        if (p) HIPCHK(hipFree(p));
+        p = nullptr;
+        cap = 0;
+        HIPCHK(hipMalloc(&p, rup(bytes, 256)));
+        cap = rup(bytes, 256);
+        if (zero) HIPCHK(hipMemset(p, 0, cap));
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct VitLayer {
+    float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *qkv_b, *out_b, *fc1_b, *fc2_b;
+    bf16_t *qkv_w, *out_w, *fc1_w, *fc2_w;
+};
+struct LlmLayer {
+    float *in_norm, *post_norm;
+    bf16_t *qkv_w, *o_w, *gate_tmp, *up_tmp, *gu_w, *down_w;  // row-major (prefill GEMM)
+    bf16_t *qkv_p, *o_p, *gu_p, *down_p;                      // MFMA-fragment packed (decode GEMV)
+};
+struct Projector {
+    int depth = 0;
+    std::vector<bf16_t*> w;
+    std::vector<float*> b;
+};
+
+}  // namespace
+
+struct vc_model {
+    vc_ctx* ctx;
+    vc_model_cfg c;
+    hipStream_t st;
+    bool finalized = false;
+    // derived
+    int P, Tv, Kpatch, Kpad, hd, vhd;
+    std::vector<void*> owned;  // every weight allocation
+    std::map<std::string, bool> need;
+    // weights
+    float *vit_cls = nullptr, *vit_pos = nullptr, *vit_pre_w = nullptr, *vit_pre_b = nullptr;
+    bf16_t* vit_patch_w = nullptr;
+    std::vector<VitLayer> vit;
+    std::vector<LlmLayer> llm;
+    Projector mm, seg;
+    bf16_t *embed = nullptr, *lm_head = nullptr, *lm_head_p = nullptr;
+    float* final_norm = nullptr;
+    float *rope_cos = nullptr, *rope_sin = nullptr;
+    // staging
+    Buf stage, stage2;
+    // ViT workspace
+    Buf v_pixels, v_cols, v_patches, v_x, v_xn, v_qkv, v_q, v_k, v_vt, v_attn, v_h, v_sel, v_mid, feats;
+    int feat_rows[3] = {0, 0, 0}, feat_off[3] = {0, 0, 0};
+    // LLM workspace
+    Buf x, xn, qkv, q, attn, h, kc, vtc, row_src, last_idx, xl, logits_all;
+    int capB = 0, capS = 0;  // KV capacity
+    int curB = 0, curS = 0, cur_pos = -1;
+    // decode state
+    Buf x_dec, xn_dec, qkv_dec, q_dec, attn_dec, h_dec, logits, next_tok, finished, out_ids, scalars, dsum;
+    int out_cap = 0;
+    int* step_dev() { return scalars.as<int>(); }
+    int* pos_dev() { return scalars.as<int>() + 1; }
+    int* ctx_dev() { return scalars.as<int>() + 2; }
+    hipGraphExec_t graph = nullptr;
+    int graph_B = 0, graph_eos = -2, graph_pad = 0, graph_maxnew = 0;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    float t_encode = 0, t_prefill = 0, t_decode = 0;
+};
+
+namespace {
+
+template <class T> T* walloc(vc_model* m, size_t n, bool zero = false) {
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, rup(n * sizeof(T), 256)));
+    if (zero) HIPCHK(hipMemset(p, 0, rup(n * sizeof(T), 256)));
+    m->owned.push_back(p);
+    return reinterpret_cast<T*>(p);
+}
+
+void mark_needed(vc_model* m) {
+    auto& n = m->need;
+    const vc_model_cfg& c = m->c;
+    n["model.embed_tokens.weight"] = false;
+    n["lm_head.weight"] = false;
+    n["model.norm.weight"] = false;
+    for (int i = 0; i < c.layers; ++i) {
+        const std::string p = "model.layers." + std::to_string(i) + ".";
+        for (const char* s : {"input_layernorm.weight", "post_attention_layernorm.weight", "self_attn.q_proj.weight",
+                              "self_attn.k_proj.weight", "self_attn.v_proj.weight", "self_attn.o_proj.weight",
+                              "mlp.gate_proj.weight", "mlp.up_proj.weight", "mlp.down_proj.weight"})
+            n[p + s] = false;
+    }
+    auto proj = [&](const std::string& prefix, int depth) {
+        if (depth == 1) {
+            n[prefix + ".weight"] = false;
+            n[prefix + ".bias"] = false;
+        }
+        for (int j = 0; depth > 1 && j < depth; ++j) {
+            n[prefix + "." + std::to_string(2 * j) + ".weight"] = false;
+            n[prefix + "." + std::to_string(2 * j) + ".bias"] = false;
+        }
+    };
+    proj("model.mm_projector", c.mm_proj_depth);
+    if (c.variant != VC_VARIANT_LLAVA) proj("model.seg_mm_projector", c.seg_proj_depth);
+    n["vit.embeddings.class_embedding"] = false;
+    n["vit.embeddings.patch_embedding.weight"] = false;
+    n["vit.embeddings.position_embedding.weight"] = false;
+    n["vit.pre_layrnorm.weight"] = false;
+    n["vit.pre_layrnorm.bias"] = false;
+    for (int j = 0; j < c.vit_layers_used; ++j) {
+        const std::string p = "vit.encoder.layers." + std::to_string(j) + ".";
+        for (const char* s : {"layer_norm1", "layer_norm2", "self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj",
+                              "self_attn.out_proj", "mlp.fc1", "mlp.fc2"}) {
+            n[p + s + ".weight"] = false;
+            n[p + s + ".bias"] = false;
+        }
+    }
+}
+
+// canonical key: strips the CLIP prefixes of both Transformers generations
+std::string canon_key(const std::string& k) {
+    static const char* pre[] = {"model.vision_tower.vision_tower.vision_model.", "model.vision_tower.vision_tower.",
+                                "vision_tower.vision_model.", "vision_model."};
+    for (const char* p : pre) {
+        const size_t n = strlen(p);
+        if (k.compare(0, n, p) == 0) return "vit." + k.substr(n);
+    }
+    if (k.compare(0, 11, "embeddings.") == 0 || k.compare(0, 8, "encoder.") == 0 ||
+        k.compare(0, 13, "pre_layrnorm.") == 0 || k.compare(0, 15, "post_layernorm.") == 0)
+        return "vit." + k;
+    return k;
+}
+
+void to_bf16(vc_model* m, bf16_t* dst, const void* src, int dtype, size_t n) {
+    if (dtype == VC_BF16) HIPCHK(hipMemcpyAsync(dst, src, n * 2, hipMemcpyDeviceToDevice, m->st));
+    else launch_f32_to_bf16(reinterpret_cast<const float*>(src), dst, n, m->st);
+}
+void to_f32(vc_model* m, float* dst, const void* src, int dtype, size_t n) {
+    if (dtype == VC_F32) HIPCHK(hipMemcpyAsync(dst, src, n * 4, hipMemcpyDeviceToDevice, m->st));
+    else launch_bf16_to_f32(reinterpret_cast<const bf16_t*>(src), dst, n, m->st);
+}
+
+// place a tensor that already sits on the device (`src`, dtype) into its inference layout
+int place_tensor(vc_model* m, const std::string& raw_key, const void* src, int dtype, const int64_t* shape, int ndim) {
+    const vc_model_cfg& c = m->c;
+    const std::string key = canon_key(raw_key);
+    size_t numel = 1;
+    for (int i = 0; i < ndim; ++i) numel *= (size_t)shape[i];
+    auto expect = [&](std::initializer_list<int64_t> dims) {
+        size_t e = 1;
+        for (auto d : dims) e *= (size_t)d;
+        REQUIRE(e == numel, VC_ERR_INVALID, "%s: expected %zu elements, got %zu", raw_key.c_str(), e, numel);
+    };
+    const int D = c.hidden, F = c.ffn, V = c.vocab, Dv = c.vit_hidden, Fv = c.vit_ffn;
+    // ---- dead at inference or simply unused
+    if (key.find("depth_mm_projector") != std::string::npos || key.find("mm2_projector") != std::string::npos ||
+        key == "model.vcoder_lm_emb.weight" || key.compare(0, 19, "vit.post_layernorm.") == 0 ||
+        key.find("position_ids") != std::string::npos || key.find("rotary_emb.inv_freq") != std::string::npos)
+        return VC_IGNORED;
+    if (c.variant == VC_VARIANT_LLAVA && key.find("seg_mm_projector") != std::string::npos) return VC_IGNORED;
+    auto it = m->need.find(key);
+    int layer = -1;
+    char rest[128] = {0};
+    if (sscanf(key.c_str(), "vit.encoder.layers.%d.%127s", &layer, rest) == 2 && layer >= c.vit_layers_used)
+        return VC_IGNORED;  // layers after hidden_states[select_layer] are never evaluated
+    REQUIRE(it != m->need.end(), VC_ERR_INVALID, "unexpected tensor key '%s'", raw_key.c_str());
+
+    if (key == "model.embed_tokens.weight") { expect({V, D}); to_bf16(m, m->embed, src, dtype, numel); }
+    else if (key == "lm_head.weight") { expect({V, D}); to_bf16(m, m->lm_head, src, dtype, numel); }
+    else if (key == "model.norm.weight") { expect({D}); to_f32(m, m->final_norm, src, dtype, numel); }
+    else if (sscanf(key.c_str(), "model.layers.%d.%127s", &layer, rest) == 2) {
+        REQUIRE(layer >= 0 && layer < c.layers, VC_ERR_INVALID, "layer index out of range in %s", raw_key.c_str());
+        LlmLayer& L = m->llm[layer];
+        const std::string r = rest;
+        if (r == "input_layernorm.weight") { expect({D}); to_f32(m, L.in_norm, src, dtype, numel); }
+        else if (r == "post_attention_layernorm.weight") { expect({D}); to_f32(m, L.post_norm, src, dtype, numel); }
+        else if (r == "self_attn.q_proj.weight") { expect({D, D}); to_bf16(m, L.qkv_w, src, dtype, numel); }
+        else if (r == "self_attn.k_proj.weight") { expect({D, D}); to_bf16(m, L.qkv_w + (size_t)D * D, src, dtype, numel); }
+        else if (r == "self_attn.v_proj.weight") { expect({D, D}); to_bf16(m, L.qkv_w + (size_t)2 * D * D, src, dtype, numel); }
+        else if (r == "self_attn.o_proj.weight") { expect({D, D}); to_bf16(m, L.o_w, src, dtype, numel); }
+        else if (r == "mlp.gate_proj.weight") { expect({F, D}); to_bf16(m, L.gate_tmp, src, dtype, numel); }
+        else if (r == "mlp.up_proj.weight") { expect({F, D}); to_bf16(m, L.up_tmp, src, dtype, numel); }
+        else if (r == "mlp.down_proj.weight") { expect({D, F}); to_bf16(m, L.down_w, src, dtype, numel); }
+        else REQUIRE(false, VC_ERR_INVALID, "unexpected tensor key '%s'", raw_key.c_str());
+    } else if (key.compare(0, 19, "model.mm_projector.") == 0 || key.compare(0, 23, "model.seg_mm_projector.") == 0) {
+        const bool is_seg = key.compare(0, 23, "model.seg_mm_projector.") == 0;
+        Projector& pj = is_seg ? m->seg : m->mm;
+        const std::string r = key.substr(is_seg ? 23 : 19);
+        int idx = 0;
+        char what[32] = {0};
+        if (sscanf(r.c_str(), "%d.%31s", &idx, what) == 2) idx /= 2;
+        else { idx = 0; snprintf(what, sizeof what, "%s", r.c_str()); }
+        REQUIRE(idx >= 0 && idx < pj.depth, VC_ERR_INVALID, "projector layer out of range in %s", raw_key.c_str());
+        const int in = idx == 0 ? Dv : D;
+        if (!strcmp(what, "weight")) { expect({D, in}); to_bf16(m, pj.w[idx], src, dtype, numel); }
+        else { expect({D}); to_f32(m, pj.b[idx], src, dtype, numel); }
+    } else if (key == "vit.embeddings.class_embedding") { expect({Dv}); to_f32(m, m->vit_cls, src, dtype, numel); }
+    else if (key == "vit.embeddings.position_embedding.weight") { expect({m->Tv, Dv}); to_f32(m, m->vit_pos, src, dtype, numel); }
+    else if (key == "vit.embeddings.patch_embedding.weight") {
+        expect({Dv, m->Kpatch});
+        m->stage2.ensure(numel * 2);
+        to_bf16(m, m->stage2.as<bf16_t>(), src, dtype, numel);
+        HIPCHK(hipMemcpy2DAsync(m->vit_patch_w, (size_t)m->Kpad * 2, m->stage2.p, (size_t)m->Kpatch * 2,
+                                (size_t)m->Kpatch * 2, Dv, hipMemcpyDeviceToDevice, m->st));
+    } else if (key == "vit.pre_layrnorm.weight") { expect({Dv}); to_f32(m, m->vit_pre_w, src, dtype, numel); }
+    else if (key == "vit.pre_layrnorm.bias") { expect({Dv}); to_f32(m, m->vit_pre_b, src, dtype, numel); }
+    else if (sscanf(key.c_str(), "vit.encoder.layers.%d.%127s", &layer, rest) == 2) {
+        VitLayer& L = m->vit[layer];
+        const std::string r = rest;
+        const size_t DD = (size_t)Dv * Dv;
+        if (r == "layer_norm1.weight") { expect({Dv}); to_f32(m, L.ln1_w, src, dtype, numel); }
+        else if (r == "layer_norm1.bias") { expect({Dv}); to_f32(m, L.ln1_b, src, dtype, numel); }
+        else if (r == "layer_norm2.weight") { expect({Dv}); to_f32(m, L.ln2_w, src, dtype, numel); }
+        else if (r == "layer_norm2.bias") { expect({Dv}); to_f32(m, L.ln2_b, src, dtype, numel); }
+        else if (r == "self_attn.q_proj.weight") { expect({Dv, Dv}); to_bf16(m, L.qkv_w, src, dtype, numel); }
+        else if (r == "self_attn.k_proj.weight") { expect({Dv, Dv}); to_bf16(m, L.qkv_w + DD, src, dtype, numel); }
+        else if (r == "self_attn.v_proj.weight") { expect({Dv, Dv}); to_bf16(m, L.qkv_w + 2 * DD, src, dtype, numel); }
+        else if (r == "self_attn.q_proj.bias") { expect({Dv}); to_f32(m, L.qkv_b, src, dtype, numel); }
+        else if (r == "self_attn.k_proj.bias") { expect({Dv}); to_f32(m, L.qkv_b + Dv, src, dtype, numel); }
+        else if (r == "self_attn.v_proj.bias") { expect({Dv}); to_f32(m, L.qkv_b + 2 * Dv, src, dtype, numel); }
+        else if (r == "self_attn.out_proj.weight") { expect({Dv, Dv}); to_bf16(m, L.out_w, src, dtype, numel); }
+        else if (r == "self_attn.out_proj.bias") { expect({Dv}); to_f32(m, L.out_b, src, dtype, numel); }
+        else if (r == "mlp.fc1.weight") { expect({Fv, Dv}); to_bf16(m, L.fc1_w, src, dtype, numel); }
+        else if (r == "mlp.fc1.bias") { expect({Fv}); to_f32(m, L.fc1_b, src, dtype, numel); }
+        else if (r == "mlp.fc2.weight") { expect({Dv, Fv}); to_bf16(m, L.fc2_w, src, dtype, numel); }
+        else if (r == "mlp.fc2.bias") { expect({Dv}); to_f32(m, L.fc2_b, src, dtype, numel); }
+        else REQUIRE(false, VC_ERR_INVALID, "unexpected tensor key '%s'", raw_key.c_str());
+    } else {
+        REQUIRE(false, VC_ERR_INVALID, "unexpected tensor key '%s'", raw_key.c_str());
+    }
+    it->second = true;
+    HIPCHK(hipStreamSynchronize(m->st));  // staging buffers are reused by the next call
+    return VC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEMM helpers
+void gemm(vc_model* m, const bf16_t* A, const bf16_t* W, const float* bias, void* out, int M, int N, int K, int ldo,
+          int epi) {
+    GemmArgs a{A, W, bias, out, M, N, K, K, K, ldo};
+    launch_gemm(a, epi, m->st);
+}
+void gemv(vc_model* m, const bf16_t* X, const bf16_t* Wp, void* out, int M, int N, int K, int ldo, int epi) {
+    const size_t esz = (epi == GEMV_F32 || epi == GEMV_RESID_F32) ? 4 : 2;
+    for (int m0 = 0; m0 < M; m0 += 16) {  // the skinny kernel holds 16 token slots; larger batches re-stream
+        GemvArgs a{X + (size_t)m0 * K, Wp, reinterpret_cast<char*>(out) + (size_t)m0 * ldo * esz, std::min(16, M - m0),
+                   N, K, ldo};
+        launch_gemv(a, epi, m->st);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ViT: pixels of all modalities batched into ONE tower pass (the tower weights are shared)
+void run_vit_and_adapters(vc_model* m, const float* const pix[3], int pixels_on_device, int B) {
+    const vc_model_cfg& c = m->c;
+    const int Dv = c.vit_hidden, Fv = c.vit_ffn, H = c.vit_heads, Tv = m->Tv, P = m->P, D = c.hidden;
+    int nmod = 0, order[3];
+    for (int k = 0; k < 3; ++k)
+        if (pix[k]) order[nmod++] = k;
+    const int N = nmod * B;
+    const size_t img_elems = (size_t)3 * c.vit_image * c.vit_image;
+    m->v_pixels.ensure((size_t)N * img_elems * 4);
+    for (int i = 0; i < nmod; ++i)
+        HIPCHK(hipMemcpyAsync(m->v_pixels.as<float>() + (size_t)i * B * img_elems, pix[order[i]], (size_t)B * img_elems * 4,
+                              pixels_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, m->st));
+    const int M = N * Tv, Mp = N * P;
+    const int Ts = (int)rup(Tv, 64);
+    m->v_cols.ensure((size_t)Mp * m->Kpad * 2);
+    m->v_patches.ensure((size_t)Mp * Dv * 4);
+    m->v_x.ensure((size_t)M * Dv * 4);
+    m->v_xn.ensure((size_t)M * Dv * 2);
+    m->v_qkv.ensure((size_t)M * 3 * Dv * 2);
+    m->v_q.ensure((size_t)N * H * Ts * m->vhd * 2, true);
+    m->v_k.ensure((size_t)N * H * Ts * m->vhd * 2, true);
+    m->v_vt.ensure((size_t)N * H * Ts * m->vhd * 2, true);
+    m->v_attn.ensure((size_t)M * Dv * 2);
+    m->v_h.ensure((size_t)M * Fv * 2);
+    launch_im2col(m->v_pixels.as<float>(), m->v_cols.as<bf16_t>(), N, c.vit_image, c.vit_patch, m->Kpad, m->st);
+    gemm(m, m->v_cols.as<bf16_t>(), m->vit_patch_w, nullptr, m->v_patches.p, Mp, Dv, m->Kpad, Dv, EPI_F32);
+    launch_vit_embed_ln(m->v_patches.as<float>(), m->vit_cls, m->vit_pos, m->vit_pre_w, m->vit_pre_b, m->v_x.as<float>(),
+                        N, Tv, Dv, c.vit_ln_eps, m->st);
+    for (int j = 0; j < c.vit_layers_used; ++j) {
+        const VitLayer& L = m->vit[j];
+        launch_layernorm(m->v_x.as<float>(), L.ln1_w, L.ln1_b, m->v_xn.as<bf16_t>(), M, Dv, c.vit_ln_eps, m->st);
+        gemm(m, m->v_xn.as<bf16_t>(), L.qkv_w, L.qkv_b, m->v_qkv.p, M, 3 * Dv, Dv, 3 * Dv, EPI_BF16);
+        QkvSplitArgs qa{m->v_qkv.as<bf16_t>(), m->v_q.as<bf16_t>(), m->v_k.as<bf16_t>(), m->v_vt.as<bf16_t>(), N, Tv, H,
+                        m->vhd, Ts, Ts, nullptr, nullptr, nullptr};
+        launch_qkv_split(qa, m->st);
+        AttnArgs aa{m->v_q.as<bf16_t>(), m->v_k.as<bf16_t>(), m->v_vt.as<bf16_t>(), m->v_attn.as<bf16_t>(), N, H, Tv,
+                    m->vhd, Ts, Ts, 0, 1.0f / sqrtf((float)m->vhd)};
+        launch_attention(aa, m->st);
+        gemm(m, m->v_attn.as<bf16_t>(), L.out_w, L.out_b, m->v_x.p, M, Dv, Dv, Dv, EPI_RESID_F32);
+        launch_layernorm(m->v_x.as<float>(), L.ln2_w, L.ln2_b, m->v_xn.as<bf16_t>(), M, Dv, c.vit_ln_eps, m->st);
+        gemm(m, m->v_xn.as<bf16_t>(), L.fc1_w, L.fc1_b, m->v_h.p, M, Fv, Dv, Fv, EPI_BF16_QGELU);
+        gemm(m, m->v_h.as<bf16_t>(), L.fc2_w, L.fc2_b, m->v_x.p, M, Dv, Fv, Dv, EPI_RESID_F32);
+    }
+    // feature_select (hidden_states[select_layer], drop CLS) + adapters
+    const int skip = c.vit_keep_cls ? 0 : 1;
+    const int R = Tv - skip;  // feature rows per image
+    m->v_sel.ensure((size_t)N * R * Dv * 2);
+    launch_select_rows_bf16(m->v_x.as<float>(), m->v_sel.as<bf16_t>(), N, Tv, skip, Dv, m->st);
+    m->feats.ensure((size_t)N * R * D * 2);
+    m->v_mid.ensure((size_t)N * R * D * 2);
+    for (int k = 0; k < 3; ++k) m->feat_rows[k] = 0;
+    for (int i = 0; i < nmod; ++i) {
+        const int mod = order[i];
+        // images -> mm_projector; seg AND depth -> seg_mm_projector (quirk 1, vcoder_ds_llava_arch.py:111-114);
+        // mm2_projector is unreachable (quirk 2, :137,145)
+        const Projector& pj = mod == VC_MOD_IMAGE ? m->mm : m->seg;
+        const int rows = B * R;
+        const bf16_t* in = m->v_sel.as<bf16_t>() + (size_t)i * rows * Dv;
+        bf16_t* out = m->feats.as<bf16_t>() + (size_t)i * rows * D;
+        m->feat_off[mod] = i * rows;
+        m->feat_rows[mod] = rows;
+        if (pj.depth == 0) {
+            REQUIRE(Dv == D, VC_ERR_INVALID, "identity projector needs mm_hidden_size == hidden_size");
+            HIPCHK(hipMemcpyAsync(out, in, (size_t)rows * D * 2, hipMemcpyDeviceToDevice, m->st));
+            continue;
+        }
+        const bf16_t* cur = in;
+        int K = Dv;
+        for (int l = 0; l < pj.depth; ++l) {
+            const bool last = l == pj.depth - 1;
+            bf16_t* dst = last ? out : (l % 2 == 0 ? m->v_mid.as<bf16_t>() : m->v_h.as<bf16_t>());
+            if (!last && l % 2 == 1) m->v_h.ensure((size_t)rows * D * 2);
+            gemm(m, cur, pj.w[l], pj.b[l], dst, rows, D, K, D, last ? EPI_BF16 : EPI_BF16_GELU);
+            cur = dst;
+            K = D;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// splice planner (host).  One (kind, src) pair per destination row of inputs_embeds.
+struct RowSrc { int kind, src; };
+
+void plan_rows(vc_model* m, const int64_t* ids, int B, int T, bool has_seg, const std::vector<bool>* depth_zero,
+               int R, std::vector<std::vector<RowSrc>>& out) {
+    const int variant = m->c.variant;
+    int img_i = 0, seg_i = 0, dep_i = 0;
+    auto text = [&](std::vector<RowSrc>& rows, const int64_t* p, int n) {
+        for (int i = 0; i < n; ++i) {
+            REQUIRE(p[i] >= 0 && p[i] < m->c.vocab, VC_ERR_INDEX,
+                    "index out of range in self (id %lld reached the embedding lookup)", (long long)p[i]);
+            rows.push_back({0, (int)p[i]});
+        }
+    };
+    auto feat = [&](std::vector<RowSrc>& rows, int mod, int idx, bool emit) {
+        REQUIRE(idx * R < m->feat_rows[mod], VC_ERR_INDEX, "index %d is out of bounds for dimension 0 with size %d", idx,
+                m->feat_rows[mod] / R);
+        for (int r = 0; emit && r < R; ++r) rows.push_back({1, m->feat_off[mod] + idx * R + r});
+    };
+    auto find = [](const int64_t* p, int n, int tok) {
+        for (int i = 0; i < n; ++i)
+            if (p[i] == tok) return i;
+        return -1;
+    };
+    out.assign(B, {});
+    for (int b = 0; b < B; ++b) {
+        const int64_t* cur = ids + (size_t)b * T;
+        int n = T;
+        std::vector<RowSrc>& rows = out[b];
+        int n_img = 0, n_seg = 0;
+        for (int i = 0; i < T; ++i) {
+            n_img += cur[i] == IMAGE_TOKEN_INDEX;
+            n_seg += cur[i] == SEG_TOKEN_INDEX;
+        }
+        // "not multimodal" guard: llava_arch.py:118, vcoder_llava_arch.py:187 (`or`), vcoder_ds_llava_arch.py:181 (`and`)
+        const bool plain = variant == VC_VARIANT_LLAVA ? n_img == 0
+                           : variant == VC_VARIANT_VCODER ? (n_img == 0 || n_seg == 0)
+                                                          : (n_img == 0 && n_seg == 0);
+        if (plain) {
+            feat(rows, VC_MOD_IMAGE, img_i, false);  // the reference indexes the features before embedding the ids
+            if (variant != VC_VARIANT_LLAVA && has_seg) feat(rows, VC_MOD_SEG, seg_i, false);
+            text(rows, cur, n);
+            ++img_i; ++seg_i; ++dep_i;
+            continue;
+        }
+        for (int at; (at = find(cur, n, IMAGE_TOKEN_INDEX)) >= 0;) {
+            feat(rows, VC_MOD_IMAGE, img_i, false);
+            text(rows, cur, at);
+            feat(rows, VC_MOD_IMAGE, img_i++, true);
+            cur += at + 1;
+            n -= at + 1;
+        }
+        if (variant != VC_VARIANT_LLAVA && has_seg) {
+            for (int at; (at = find(cur, n, SEG_TOKEN_INDEX)) >= 0;) {
+                feat(rows, VC_MOD_SEG, seg_i, false);
+                if (variant == VC_VARIANT_VCODER) text(rows, cur, at);  // vcoder_llava_arch.py:236 keeps the text,
+                feat(rows, VC_MOD_SEG, seg_i++, true);                  // vcoder_ds_llava_arch.py:238 drops it
+                cur += at + 1;
+                n -= at + 1;
+            }
+        }
+        if (variant == VC_VARIANT_VCODER_DS) {
+            const bool dz = depth_zero ? (*depth_zero)[dep_i] : true;
+            if (!dz) {
+                for (int at; (at = find(cur, n, DEPTH_TOKEN_INDEX)) >= 0;) {
+                    feat(rows, VC_MOD_DEPTH, dep_i, false);
+                    text(rows, cur, at);
+                    feat(rows, VC_MOD_DEPTH, dep_i++, true);
+                    cur += at + 1;
+                    n -= at + 1;
+                }
+            } else {
+                ++dep_i;
+            }
+        }
+        if (n > 0) text(rows, cur, n);
+    }
+}
+
+void ensure_llm(vc_model* m, int B, int S_total) {
+    const vc_model_cfg& c = m->c;
+    const int D = c.hidden, F = c.ffn, H = c.heads;
+    const int Scap = (int)rup(S_total, 64);
+    REQUIRE(Scap <= c.max_positions && Scap <= 4096, VC_ERR_INVALID,
+            "sequence %d exceeds max_position_embeddings=%d / decode-attention limit 4096", Scap, c.max_positions);
+    if (B != m->capB || Scap > m->capS) {
+        const int newS = std::max(Scap, m->capB == B ? m->capS : 0);
+        const size_t per_layer = (size_t)B * H * newS * m->hd;
+        m->kc.release();
+        m->vtc.release();
+        m->kc.ensure(per_layer * c.layers * 2, true);
+        m->vtc.ensure(per_layer * c.layers * 2, true);
+        m->capB = B;
+        m->capS = newS;
+        if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
+    }
+    const size_t Mrows = (size_t)B * Scap;
+    m->x.ensure(Mrows * D * 4);
+    m->xn.ensure(Mrows * D * 2);
+    m->qkv.ensure(Mrows * 3 * D * 2);
+    m->q.ensure(Mrows * D * 2, true);
+    m->attn.ensure(Mrows * D * 2);
+    m->h.ensure(Mrows * F * 2);
+    m->row_src.ensure(Mrows * 8);
+    const int Bp = (int)rup(B, 16);
+    m->last_idx.ensure(Bp * 4);
+    m->xl.ensure((size_t)Bp * D * 2, true);
+    m->x_dec.ensure((size_t)Bp * D * 4, true);
+    m->xn_dec.ensure((size_t)Bp * D * 2, true);
+    m->qkv_dec.ensure((size_t)Bp * 3 * D * 2, true);
+    m->q_dec.ensure((size_t)Bp * D * 2, true);
+    m->attn_dec.ensure((size_t)Bp * D * 2, true);
+    m->h_dec.ensure((size_t)Bp * F * 2, true);
+    m->logits.ensure((size_t)Bp * c.vocab * 4, true);
+    m->next_tok.ensure(Bp * 4, true);
+    m->finished.ensure(Bp * 4, true);
+    m->scalars.ensure(64, true);
+    m->dsum.ensure(Bp * 4, true);
+}
+
+bf16_t* kcache(vc_model* m, int l) { return m->kc.as<bf16_t>() + (size_t)l * m->capB * m->c.heads * m->capS * m->hd; }
+bf16_t* vtcache(vc_model* m, int l) { return m->vtc.as<bf16_t>() + (size_t)l * m->capB * m->c.heads * m->capS * m->hd; }
+
+void run_prefill_layers(vc_model* m, int B, int S) {
+    const vc_model_cfg& c = m->c;
+    const int D = c.hidden, F = c.ffn, H = c.heads, M = B * S;
+    for (int l = 0; l < c.layers; ++l) {
+        const LlmLayer& L = m->llm[l];
+        launch_rmsnorm(m->x.as<float>(), L.in_norm, m->xn.as<bf16_t>(), M, D, c.rms_eps, m->st);
+        gemm(m, m->xn.as<bf16_t>(), L.qkv_w, nullptr, m->qkv.p, M, 3 * D, D, 3 * D, EPI_BF16);
+        QkvSplitArgs qa{m->qkv.as<bf16_t>(), m->q.as<bf16_t>(), kcache(m, l), vtcache(m, l), B, S, H, m->hd, S, m->capS,
+                        nullptr, m->rope_cos, m->rope_sin};
+        launch_qkv_split(qa, m->st);
+        AttnArgs aa{m->q.as<bf16_t>(), kcache(m, l), vtcache(m, l), m->attn.as<bf16_t>(), B, H, S, m->hd, S, m->capS, 1,
+                    1.0f / sqrtf((float)m->hd)};
+        launch_attention(aa, m->st);
+        gemm(m, m->attn.as<bf16_t>(), L.o_w, nullptr, m->x.p, M, D, D, D, EPI_RESID_F32);
+        launch_rmsnorm(m->x.as<float>(), L.post_norm, m->xn.as<bf16_t>(), M, D, c.rms_eps, m->st);
+        gemm(m, m->xn.as<bf16_t>(), L.gu_w, nullptr, m->h.p, M, 2 * F, D, F, EPI_SWIGLU);
+        gemm(m, m->h.as<bf16_t>(), L.down_w, nullptr, m->x.p, M, D, F, D, EPI_RESID_F32);
+    }
+}
+
+// the kernels of one cached decode step (captured into a hipGraph)
+void enqueue_decode_step(vc_model* m, int B, int max_new, int eos_id, int pad_id) {
+    const vc_model_cfg& c = m->c;
+    const int D = c.hidden, F = c.ffn, H = c.heads;
+    launch_embed_tokens(m->next_tok.as<int>(), m->embed, m->x_dec.as<float>(), B, D, m->st);
+    for (int l = 0; l < c.layers; ++l) {
+        const LlmLayer& L = m->llm[l];
+        launch_rmsnorm(m->x_dec.as<float>(), L.in_norm, m->xn_dec.as<bf16_t>(), B, D, c.rms_eps, m->st);
+        gemv(m, m->xn_dec.as<bf16_t>(), L.qkv_p, m->qkv_dec.p, B, 3 * D, D, 3 * D, GEMV_BF16);
+        QkvSplitArgs qa{m->qkv_dec.as<bf16_t>(), m->q_dec.as<bf16_t>(), kcache(m, l), vtcache(m, l), B, 1, H, m->hd, 1,
+                        m->capS, m->pos_dev(), m->rope_cos, m->rope_sin};
+        launch_qkv_split(qa, m->st);
+        AttnDecodeArgs da{m->q_dec.as<bf16_t>(), kcache(m, l), vtcache(m, l), m->attn_dec.as<bf16_t>(), B, H, m->hd,
+                          m->capS, m->ctx_dev(), 1.0f / sqrtf((float)m->hd)};
+        launch_attention_decode(da, m->st);
+        gemv(m, m->attn_dec.as<bf16_t>(), L.o_p, m->x_dec.p, B, D, D, D, GEMV_RESID_F32);
+        launch_rmsnorm(m->x_dec.as<float>(), L.post_norm, m->xn_dec.as<bf16_t>(), B, D, c.rms_eps, m->st);
+        gemv(m, m->xn_dec.as<bf16_t>(), L.gu_p, m->h_dec.p, B, 2 * F, D, F, GEMV_SWIGLU);
+        gemv(m, m->h_dec.as<bf16_t>(), L.down_p, m->x_dec.p, B, D, F, D, GEMV_RESID_F32);
+    }
+    launch_rmsnorm(m->x_dec.as<float>(), m->final_norm, m->xn_dec.as<bf16_t>(), B, D, c.rms_eps, m->st);
+    gemv(m, m->xn_dec.as<bf16_t>(), m->lm_head_p, m->logits.p, B, c.vocab, D, c.vocab, GEMV_F32);
+    launch_advance(nullptr, m->pos_dev(), m->ctx_dev(), m->st);  // cache now holds pos+1 keys
+    GreedyArgs ga{m->logits.as<float>(), m->next_tok.as<int>(), m->out_ids.as<int>(), m->finished.as<int>(),
+                  m->step_dev(), B, c.vocab, max_new, eos_id, pad_id};
+    launch_greedy(ga, m->st);
+    launch_advance(m->step_dev(), nullptr, nullptr, m->st);
+}
+
+void ensure_graph(vc_model* m, int B, int max_new, int eos_id, int pad_id) {
+    if (m->graph && m->graph_B == B && m->graph_eos == eos_id && m->graph_pad == pad_id && m->graph_maxnew == max_new)
+        return;
+    if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
+    hipGraph_t g = nullptr;
+    HIPCHK(hipStreamBeginCapture(m->st, hipStreamCaptureModeGlobal));
+    try {
+        enqueue_decode_step(m, B, max_new, eos_id, pad_id);
+    } catch (...) {
+        (void)hipStreamEndCapture(m->st, &g);
+        throw;
+    }
+    HIPCHK(hipStreamEndCapture(m->st, &g));
+    HIPCHK(hipGraphInstantiate(&m->graph, g, nullptr, nullptr, 0));
+    HIPCHK(hipGraphDestroy(g));
+    m->graph_B = B;
+    m->graph_eos = eos_id;
+    m->graph_pad = pad_id;
+    m->graph_maxnew = max_new;
+}
+
+void ensure_out_ids(vc_model* m, int B, int max_new) {
+    const size_t n = (size_t)rup(B, 16) * max_new;
+    if ((size_t)m->out_cap < n) {
+        m->out_ids.ensure(n * 4);
+        m->out_cap = (int)n;
+        if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }  // pointer baked into the graph
+    }
+}
+
+// prefill through the last-row logits; leaves logits [B,V] on device
+void do_prefill(vc_model* m, const int64_t* ids, int B, int T, const float* img, const float* seg, const float* depth,
+                int on_dev, int has_mask, int reserve_new, float* logits_all_host, int* S_out) {
+    const vc_model_cfg& c = m->c;
+    REQUIRE(m->finalized, VC_ERR_STATE, "vc_model_finalize() has not been called");
+    REQUIRE(B >= 1 && T >= 1 && ids, VC_ERR_INVALID, "bad ids/B/T");
+    REQUIRE(img, VC_ERR_INVALID, "images is required for a multimodal forward");
+    if (c.variant == VC_VARIANT_LLAVA) seg = depth = nullptr;
+    if (c.variant != VC_VARIANT_VCODER_DS) depth = nullptr;
+    const float* pix[3] = {img, seg, depth};
+    if (m->ev[0]) HIPCHK(hipEventRecord(m->ev[0], m->st));
+    run_vit_and_adapters(m, pix, on_dev, B);
+    const int R = m->Tv - (c.vit_keep_cls ? 0 : 1);
+    std::vector<bool> dz;
+    if (depth) {  // is_depth_zero = [mean(d) == 0 ...]  (vcoder_ds_llava_arch.py:161) — one host sync, as the reference
+        m->dsum.ensure(rup(B, 16) * 4);
+        int di = 0;
+        for (int k = 0; k < 2; ++k) di += pix[k] != nullptr;
+        const size_t img_elems = (size_t)3 * c.vit_image * c.vit_image;
+        launch_row_sum(m->v_pixels.as<float>() + (size_t)di * B * img_elems, img_elems, B, m->dsum.as<float>(), m->st);
+        std::vector<float> hs(B);
+        HIPCHK(hipMemcpyAsync(hs.data(), m->dsum.p, B * 4, hipMemcpyDeviceToHost, m->st));
+        HIPCHK(hipStreamSynchronize(m->st));
+        for (int b = 0; b < B; ++b) dz.push_back(hs[b] / (float)img_elems == 0.0f);
+    }
+    if (m->ev[1]) HIPCHK(hipEventRecord(m->ev[1], m->st));
+    std::vector<std::vector<RowSrc>> rows;
+    plan_rows(m, ids, B, T, seg != nullptr, depth ? &dz : nullptr, R, rows);
+    size_t S = 0;
+    bool unequal = false;
+    for (auto& r : rows) {
+        S = std::max(S, r.size());
+        unequal |= r.size() != rows[0].size();
+    }
+    // quirk 6: unequal spliced lengths with an attention_mask and no labels die at vcoder_ds_llava_arch.py:295-297
+    REQUIRE(!(unequal && has_mask), VC_ERR_UNEQUAL, "local variable '_new_labels' referenced before assignment");
+    REQUIRE(S >= 1, VC_ERR_INVALID, "empty sequence");
+    ensure_llm(m, B, (int)S + std::max(reserve_new, 1));
+    std::vector<int> flat((size_t)B * S * 2);
+    for (int b = 0; b < B; ++b)
+        for (size_t s = 0; s < S; ++s) {
+            const RowSrc r = s < rows[b].size() ? rows[b][s] : RowSrc{2, 0};  // zero right-padding (:283)
+            flat[((size_t)b * S + s) * 2] = r.kind;
+            flat[((size_t)b * S + s) * 2 + 1] = r.src;
+        }
+    HIPCHK(hipMemcpyAsync(m->row_src.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, m->st));
+    launch_splice(m->row_src.as<int>(), (int)(B * S), m->embed, m->feats.as<bf16_t>(), m->x.as<float>(), c.hidden, m->st);
+    HIPCHK(hipStreamSynchronize(m->st));  // `flat` is host memory
+    m->curB = B;
+    m->curS = (int)S;
+    if (S_out) *S_out = (int)S;
+}
+
+void finish_prefill(vc_model* m, float* logits_all_host) {
+    const vc_model_cfg& c = m->c;
+    const int B = m->curB, S = m->curS, D = c.hidden;
+    run_prefill_layers(m, B, S);
+    std::vector<int> idx(B);
+    for (int b = 0; b < B; ++b) idx[b] = b * S + S - 1;
+    HIPCHK(hipMemcpyAsync(m->last_idx.p, idx.data(), B * 4, hipMemcpyHostToDevice, m->st));
+    launch_rmsnorm_rows(m->x.as<float>(), m->last_idx.as<int>(), m->final_norm, m->xl.as<bf16_t>(), B, D, c.rms_eps, m->st);
+    gemv(m, m->xl.as<bf16_t>(), m->lm_head_p, m->logits.p, B, c.vocab, D, c.vocab, GEMV_F32);
+    if (logits_all_host) {  // lm_head over ALL S positions, as the reference's forward returns (:93)
+        const size_t Mr = (size_t)B * S;
+        m->logits_all.ensure(Mr * c.vocab * 4);
+        launch_rmsnorm(m->x.as<float>(), m->final_norm, m->xn.as<bf16_t>(), (int)Mr, D, c.rms_eps, m->st);
+        gemm(m, m->xn.as<bf16_t>(), m->lm_head, nullptr, m->logits_all.p, (int)Mr, c.vocab, D, c.vocab, EPI_F32);
+        HIPCHK(hipMemcpyAsync(logits_all_host, m->logits_all.p, Mr * c.vocab * 4, hipMemcpyDeviceToHost, m->st));
+    }
+    const int sc[3] = {0, S, S + 1};  // step, pos (next token's position), ctx (keys after it is appended)
+    HIPCHK(hipMemcpyAsync(m->scalars.p, sc, sizeof sc, hipMemcpyHostToDevice, m->st));
+    HIPCHK(hipMemsetAsync(m->finished.p, 0, rup(B, 16) * 4, m->st));
+    HIPCHK(hipStreamSynchronize(m->st));
+    m->cur_pos = S;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+#define GUARD_BEGIN try {
+#define GUARD_END(ctxp)                                   \
+    }                                                     \
+    catch (const Fail& f) {                               \
+        if (ctxp) (ctxp)->err = f.msg;                    \
+        return f.code;                                    \
+    }                                                     \
+    catch (const std::exception& e) {                     \
+        if (ctxp) (ctxp)->err = e.what();                 \
+        return VC_ERR_INVALID;                            \
+    }                                                     \
+    return VC_OK;
+
+VC_API int vc_init(int device_id, vc_ctx** out) {
+    if (!out) return VC_ERR_INVALID;
+    *out = nullptr;
+    vc_ctx* ctx = new vc_ctx();
+    GUARD_BEGIN
+    int n = 0;
+    HIPCHK(hipGetDeviceCount(&n));
+    REQUIRE(n > 0 && device_id >= 0 && device_id < n, VC_ERR_HIP, "no HIP device %d (found %d)", device_id, n);
+    HIPCHK(hipSetDevice(device_id));
+    ctx->device = device_id;
+    HIPCHK(hipStreamCreate(&ctx->stream));
+    *out = ctx;
+    GUARD_END(ctx)
+}
+VC_API void vc_shutdown(vc_ctx* ctx) {
+    if (!ctx) return;
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+VC_API const char* vc_last_error(vc_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+VC_API int vc_synchronize(vc_ctx* ctx) {
+    GUARD_BEGIN
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    GUARD_END(ctx)
+}
+VC_API void* vc_stream(vc_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+VC_API int vc_model_create(vc_ctx* ctx, const vc_model_cfg* cfg, vc_model** out) {
+    if (!ctx || !cfg || !out) return VC_ERR_INVALID;
+    *out = nullptr;
+    vc_model* m = nullptr;
+    GUARD_BEGIN
+    const vc_model_cfg& c = *cfg;
+    REQUIRE(c.variant >= 0 && c.variant <= 2, VC_ERR_INVALID, "bad variant %d", c.variant);
+    REQUIRE(c.hidden % c.heads == 0 && c.vit_hidden % c.vit_heads == 0, VC_ERR_INVALID, "hidden %% heads != 0");
+    const int hd = c.hidden / c.heads, vhd = c.vit_hidden / c.vit_heads;
+    REQUIRE((hd == 128 || hd == 64) && (vhd == 64 || vhd == 128), VC_ERR_INVALID,
+            "head dims (%d LLM, %d ViT) must be 64 or 128", hd, vhd);
+    REQUIRE(c.hidden % 64 == 0 && c.ffn % 64 == 0 && c.vit_hidden % 64 == 0 && c.vit_ffn % 64 == 0 && c.vocab % 16 == 0,
+            VC_ERR_INVALID, "hidden/ffn sizes must be multiples of 64 and vocab of 16");
+    REQUIRE(c.vit_layers_used >= 0 && c.vit_layers_used <= c.vit_layers, VC_ERR_INVALID, "bad vit_layers_used");
+    REQUIRE(c.vit_image % c.vit_patch == 0, VC_ERR_INVALID, "image size must be a multiple of the patch size");
+    REQUIRE(c.mm_proj_depth >= 0 && c.seg_proj_depth >= 0, VC_ERR_INVALID, "bad projector depth");
+    m = new vc_model();
+    m->ctx = ctx;
+    m->c = c;
+    m->st = ctx->stream;
+    m->hd = hd;
+    m->vhd = vhd;
+    const int g = c.vit_image / c.vit_patch;
+    m->P = g * g;
+    m->Tv = m->P + 1;
+    m->Kpatch = 3 * c.vit_patch * c.vit_patch;
+    m->Kpad = (int)rup(m->Kpatch, 64);
+    const int D = c.hidden, F = c.ffn, V = c.vocab, Dv = c.vit_hidden, Fv = c.vit_ffn;
+    m->embed = walloc<bf16_t>(m, (size_t)V * D);
+    m->lm_head = walloc<bf16_t>(m, (size_t)V * D);
+    m->final_norm = walloc<float>(m, D);
+    m->llm.resize(c.layers);
+    for (auto& L : m->llm) {
+        L.in_norm = walloc<float>(m, D);
+        L.post_norm = walloc<float>(m, D);
+        L.qkv_w = walloc<bf16_t>(m, (size_t)3 * D * D);
+        L.o_w = walloc<bf16_t>(m, (size_t)D * D);
+        L.gate_tmp = walloc<bf16_t>(m, (size_t)F * D);
+        L.up_tmp = walloc<bf16_t>(m, (size_t)F * D);
+        L.gu_w = walloc<bf16_t>(m, (size_t)2 * F * D);
+        L.down_w = walloc<bf16_t>(m, (size_t)D * F);
+        L.qkv_p = L.o_p = L.gu_p = L.down_p = nullptr;
+    }
+    auto mkproj = [&](Projector& pj, int depth) {
+        pj.depth = depth;
+        for (int l = 0; l < depth; ++l) {
+            pj.w.push_back(walloc<bf16_t>(m, (size_t)D * (l == 0 ? Dv : D)));
+            pj.b.push_back(walloc<float>(m, D));
+        }
+    };
+    mkproj(m->mm, c.mm_proj_depth);
+    if (c.variant != VC_VARIANT_LLAVA) mkproj(m->seg, c.seg_proj_depth);
+    m->vit_cls = walloc<float>(m, Dv);
+    m->vit_pos = walloc<float>(m, (size_t)m->Tv * Dv);
+    m->vit_pre_w = walloc<float>(m, Dv);
+    m->vit_pre_b = walloc<float>(m, Dv);
+    m->vit_patch_w = walloc<bf16_t>(m, (size_t)Dv * m->Kpad, true);
+    m->vit.resize(c.vit_layers_used);
+    for (auto& L : m->vit) {
+        L.ln1_w = walloc<float>(m, Dv); L.ln1_b = walloc<float>(m, Dv);
+        L.ln2_w = walloc<float>(m, Dv); L.ln2_b = walloc<float>(m, Dv);
+        L.qkv_w = walloc<bf16_t>(m, (size_t)3 * Dv * Dv); L.qkv_b = walloc<float>(m, 3 * Dv);
+        L.out_w = walloc<bf16_t>(m, (size_t)Dv * Dv); L.out_b = walloc<float>(m, Dv);
+        L.fc1_w = walloc<bf16_t>(m, (size_t)Fv * Dv); L.fc1_b = walloc<float>(m, Fv);
+        L.fc2_w = walloc<bf16_t>(m, (size_t)Dv * Fv); L.fc2_b = walloc<float>(m, Dv);
+    }
+    mark_needed(m);
+    for (auto& e : m->ev) HIPCHK(hipEventCreate(&e));
+    *out = m;
+    GUARD_END(ctx)
+}
+
+VC_API void vc_model_destroy(vc_model* m) {
+    if (!m) return;
+    (void)hipStreamSynchronize(m->st);
+    if (m->graph) (void)hipGraphExecDestroy(m->graph);
+    for (void* p : m->owned) (void)hipFree(p);
+    for (Buf* b : {&m->stage, &m->stage2, &m->v_pixels, &m->v_cols, &m->v_patches, &m->v_x, &m->v_xn, &m->v_qkv, &m->v_q,
+                   &m->v_k, &m->v_vt, &m->v_attn, &m->v_h, &m->v_sel, &m->v_mid, &m->feats, &m->x, &m->xn, &m->qkv, &m->q,
+                   &m->attn, &m->h, &m->kc, &m->vtc, &m->row_src, &m->last_idx, &m->xl, &m->logits_all, &m->x_dec,
+                   &m->xn_dec, &m->qkv_dec, &m->q_dec, &m->attn_dec, &m->h_dec, &m->logits, &m->next_tok, &m->finished,
+                   &m->out_ids, &m->scalars, &m->dsum})
+        b->release();
+    for (auto& e : m->ev)
+        if (e) (void)hipEventDestroy(e);
+    delete m;
+}
+
+VC_API int vc_model_load_tensor(vc_model* m, const char* hf_key, const void* host_ptr, int dtype, const int64_t* shape,
+                                int ndim) {
+    if (!m) return VC_ERR_INVALID;
+    int rc = VC_OK;
+    GUARD_BEGIN
+    REQUIRE(hf_key && host_ptr && shape && ndim >= 1 && ndim <= 8, VC_ERR_INVALID, "bad load_tensor arguments");
+    REQUIRE(dtype == VC_F32 || dtype == VC_BF16, VC_ERR_INVALID, "dtype must be VC_F32 or VC_BF16");
+    REQUIRE(!m->finalized, VC_ERR_STATE, "model already finalized");
+    size_t numel = 1;
+    for (int i = 0; i < ndim; ++i) numel *= (size_t)shape[i];
+    const size_t bytes = numel * (dtype == VC_F32 ? 4 : 2);
+    m->stage.ensure(bytes);
+    HIPCHK(hipMemcpyAsync(m->stage.p, host_ptr, bytes, hipMemcpyHostToDevice, m->st));
+    rc = place_tensor(m, hf_key, m->stage.p, dtype, shape, ndim);
+    HIPCHK(hipStreamSynchronize(m->st));
+    if (rc != VC_OK) return rc;
+    GUARD_END(m->ctx)
+}
+
+VC_API int vc_model_synth_tensor(vc_model* m, const char* hf_key, const int64_t* shape, int ndim, uint32_t tensor_seed,
+                                 float offset, float halfwidth) {
+    if (!m) return VC_ERR_INVALID;
+    int rc = VC_OK;
+    GUARD_BEGIN
+    REQUIRE(hf_key && shape && ndim >= 1 && ndim <= 8, VC_ERR_INVALID, "bad synth_tensor arguments");
+    REQUIRE(!m->finalized, VC_ERR_STATE, "model already finalized");
+    size_t numel = 1;
+    for (int i = 0; i < ndim; ++i) numel *= (size_t)shape[i];
+    REQUIRE(numel < ((size_t)1 << 32), VC_ERR_INVALID, "tensor too large for the 32-bit generator");
+    m->stage.ensure(numel * 2);
+    launch_synth_bf16(m->stage.as<bf16_t>(), numel, tensor_seed, offset, halfwidth, m->st);
+    rc = place_tensor(m, hf_key, m->stage.p, VC_BF16, shape, ndim);
+    HIPCHK(hipStreamSynchronize(m->st));
+    if (rc != VC_OK) return rc;
+    GUARD_END(m->ctx)
+}
+
+VC_API int vc_model_finalize(vc_model* m) {
+    if (!m) return VC_ERR_INVALID;
+    GUARD_BEGIN
+    if (m->finalized) return VC_OK;
+    for (auto& kv : m->need) REQUIRE(kv.second, VC_ERR_STATE, "missing tensor '%s'", kv.first.c_str());
+    const vc_model_cfg& c = m->c;
+    const int D = c.hidden, F = c.ffn, V = c.vocab;
+    for (auto& L : m->llm) {
+        launch_interleave_rows(L.gate_tmp, L.up_tmp, L.gu_w, F, D, m->st);
+        L.qkv_p = walloc<bf16_t>(m, (size_t)3 * D * D);
+        L.o_p = walloc<bf16_t>(m, (size_t)D * D);
+        L.gu_p = walloc<bf16_t>(m, (size_t)2 * F * D);
+        L.down_p = walloc<bf16_t>(m, (size_t)D * F);
+        launch_pack_weight(L.qkv_w, L.qkv_p, 3 * D, D, m->st);
+        launch_pack_weight(L.o_w, L.o_p, D, D, m->st);
+        launch_pack_weight(L.gu_w, L.gu_p, 2 * F, D, m->st);
+        launch_pack_weight(L.down_w, L.down_p, D, F, m->st);
+    }
+    m->lm_head_p = walloc<bf16_t>(m, (size_t)V * D);
+    launch_pack_weight(m->lm_head, m->lm_head_p, V, D, m->st);
+    HIPCHK(hipStreamSynchronize(m->st));
+    // gate/up staging copies are no longer needed
+    for (auto& L : m->llm) {
+        for (bf16_t** t : {&L.gate_tmp, &L.up_tmp}) {
+            for (auto& o : m->owned)
+                if (o == *t) { (void)hipFree(o); o = nullptr; }
+            *t = nullptr;
+        }
+    }
+    // rope tables (LlamaRotaryEmbedding, [HF] llama/modeling_llama.py:73-127): inv_freq = theta^(-2i/hd) in fp32,
+    // angle = pos * inv_freq in fp32, cos/sin in fp32
+    const int half = m->hd / 2;
+    std::vector<float> hc((size_t)c.max_positions * half), hs((size_t)c.max_positions * half);
+    for (int i = 0; i < half; ++i) {
+        const float inv = (float)(1.0 / pow((double)c.rope_theta, (double)(2 * i) / (double)m->hd));
+        for (int p = 0; p < c.max_positions; ++p) {
+            const float ang = (float)p * inv;
+            hc[(size_t)p * half + i] = (float)cos((double)ang);
+            hs[(size_t)p * half + i] = (float)sin((double)ang);
+        }
+    }
+    m->rope_cos = walloc<float>(m, hc.size());
+    m->rope_sin = walloc<float>(m, hs.size());
+    HIPCHK(hipMemcpy(m->rope_cos, hc.data(), hc.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(m->rope_sin, hs.data(), hs.size() * 4, hipMemcpyHostToDevice));
+    m->stage.release();
+    m->stage2.release();
+    m->finalized = true;
+    GUARD_END(m->ctx)
+}
+
+VC_API int vc_encode(vc_model* m, int modality, const float* pixels, int pixels_on_device, int B, float* out) {
+    if (!m) return VC_ERR_INVALID;
+    GUARD_BEGIN
+    REQUIRE(m->finalized, VC_ERR_STATE, "vc_model_finalize() has not been called");
+    REQUIRE(pixels && B >= 1 && modality >= 0 && modality <= 2, VC_ERR_INVALID, "bad encode arguments");
+    REQUIRE(modality == VC_MOD_IMAGE || m->c.variant != VC_VARIANT_LLAVA, VC_ERR_INVALID, "llava has no seg/depth encoder");
+    const float* pix[3] = {nullptr, nullptr, nullptr};
+    pix[modality] = pixels;
+    run_vit_and_adapters(m, pix, pixels_on_device, B);
+    if (out) {
+        const size_t n = (size_t)m->feat_rows[modality] * m->c.hidden;
+        m->v_patches.ensure(n * 4);
+        launch_bf16_to_f32(m->feats.as<bf16_t>() + (size_t)m->feat_off[modality] * m->c.hidden, m->v_patches.as<float>(), n,
+                           m->st);
+        HIPCHK(hipMemcpyAsync(out, m->v_patches.p, n * 4, hipMemcpyDeviceToHost, m->st));
+    }
+    HIPCHK(hipStreamSynchronize(m->st));
+    GUARD_END(m->ctx)
+}
+
+VC_API int vc_prefill(vc_model* m, const int64_t* ids, int B, int T, const float* img, const float* seg,
+                      const float* depth, int pixels_on_device, int has_attention_mask, float* logits_last,
+                      float* logits_all, int* S_out) {
+    if (!m) return VC_ERR_INVALID;
+    GUARD_BEGIN
+    m->cur_pos = -1;
+    do_prefill(m, ids, B, T, img, seg, depth, pixels_on_device, has_attention_mask, 64, logits_all, S_out);
+    finish_prefill(m, logits_all);
+    // greedy choice of the prefill logits, so that vc_decode_step(tok = NULL) continues the sequence
+    GreedyArgs ga{m->logits.as<float>(), m->next_tok.as<int>(), nullptr, m->finished.as<int>(), m->step_dev(), B,
+                  m->c.vocab, 0, -1, 0};
+    launch_greedy(ga, m->st);
+    HIPCHK(hipStreamSynchronize(m->st));
+    if (logits_last) HIPCHK(hipMemcpy(logits_last, m->logits.p, (size_t)B * m->c.vocab * 4, hipMemcpyDeviceToHost));
+    GUARD_END(m->ctx)
+}
+
+/* splice only (no decoder layers): inputs_embeds [B,S,hidden] fp32 to host.  Used by the parity tests of a7. */
+VC_API int vc_prefill_embeds_only(vc_model* m, const int64_t* ids, int B, int T, const float* img, const float* seg,
+                                  const float* depth, int pixels_on_device, int has_attention_mask, float* out_host,
+                                  int* S_out) {
+    if (!m) return VC_ERR_INVALID;
+    GUARD_BEGIN
+    m->cur_pos = -1;
+    int S = 0;
+    do_prefill(m, ids, B, T, img, seg, depth, pixels_on_device, has_attention_mask, 64, nullptr, &S);
+    if (S_out) *S_out = S;
+    if (out_host) HIPCHK(hipMemcpy(out_host, m->x.p, (size_t)B * S * m->c.hidden * 4, hipMemcpyDeviceToHost));
+    GUARD_END(m->ctx)
+}
+
+VC_API int vc_decode_step(vc_model* m, const int32_t* tok, float* logits, int32_t* next_tok) {
+    if (!m) return VC_ERR_INVALID;
+    GUARD_BEGIN
+    REQUIRE(m->cur_pos >= 0, VC_ERR_STATE, "vc_decode_step before vc_prefill");
+    REQUIRE(m->cur_pos + 1 <= m->capS, VC_ERR_STATE, "KV cache full (%d)", m->capS);
+    const int B = m->curB;
+    if (tok) HIPCHK(hipMemcpyAsync(m->next_tok.p, tok, B * 4, hipMemcpyHostToDevice, m->st));
+    ensure_out_ids(m, B, 1);
+    ensure_graph(m, B, 0, -1, 0);  // max_new 0: out_ids untouched, no EOS bookkeeping
+    HIPCHK(hipGraphLaunch(m->graph, m->st));
+    m->cur_pos += 1;
+    if (logits) HIPCHK(hipMemcpyAsync(logits, m->logits.p, (size_t)B * m->c.vocab * 4, hipMemcpyDeviceToHost, m->st));
+    if (next_tok) HIPCHK(hipMemcpyAsync(next_tok, m->next_tok.p, B * 4, hipMemcpyDeviceToHost, m->st));
+    HIPCHK(hipStreamSynchronize(m->st));
+    GUARD_END(m->ctx)
+}
+
+VC_API int vc_generate_greedy(vc_model* m, const int64_t* ids, int B, int T, const float* img, const float* seg,
+                              const float* depth, int pixels_on_device, int max_new, int eos_id, int pad_id,
+                              int32_t* out_ids, int* n_generated) {
+    if (!m) return VC_ERR_INVALID;
+    GUARD_BEGIN
+    REQUIRE(max_new >= 1 && out_ids, VC_ERR_INVALID, "bad max_new/out_ids");
+    m->cur_pos = -1;
+    int S = 0;
+    do_prefill(m, ids, B, T, img, seg, depth, pixels_on_device, 1, max_new, nullptr, &S);  // generate() always builds a mask
+    REQUIRE(S + max_new <= m->capS, VC_ERR_INVALID, "prompt %d + max_new %d exceeds the KV capacity %d", S, max_new, m->capS);
+    ensure_out_ids(m, B, max_new);
+    finish_prefill(m, nullptr);
+    if (m->ev[2]) HIPCHK(hipEventRecord(m->ev[2], m->st));
+    // token 0 comes from the prefill logits
+    GreedyArgs ga{m->logits.as<float>(), m->next_tok.as<int>(), m->out_ids.as<int>(), m->finished.as<int>(), m->step_dev(),
+                  B, m->c.vocab, max_new, eos_id, pad_id};
+    std::vector<int> fill((size_t)B * max_new, pad_id);
+    HIPCHK(hipMemcpyAsync(m->out_ids.p, fill.data(), fill.size() * 4, hipMemcpyHostToDevice, m->st));
+    launch_greedy(ga, m->st);
+    launch_advance(m->step_dev(), nullptr, nullptr, m->st);
+    HIPCHK(hipStreamSynchronize(m->st));
+    int produced = 1;
+    std::vector<int> fin(B);
+    auto all_finished = [&]() {
+        if (eos_id < 0) return false;
+        HIPCHK(hipMemcpy(fin.data(), m->finished.p, B * 4, hipMemcpyDeviceToHost));
+        for (int b = 0; b < B; ++b)
+            if (!fin[b]) return false;
+        return true;
+    };
+    if (max_new > 1 && !all_finished()) {
+        ensure_graph(m, B, max_new, eos_id, pad_id);
+        for (int step = 1; step < max_new; ++step) {
+            HIPCHK(hipGraphLaunch(m->graph, m->st));
+            m->cur_pos += 1;
+            produced = step + 1;
+            // the reference checks its stopping criteria on the host every token; checking every 8 tokens only
+            // trims later (rows past EOS already emit pad), it never changes the returned ids
+            if (eos_id >= 0 && (step % 8 == 7 || step == max_new - 1)) {
+                HIPCHK(hipStreamSynchronize(m->st));
+                if (all_finished()) break;
+            }
+        }
+    }
+    if (m->ev[3]) HIPCHK(hipEventRecord(m->ev[3], m->st));
+    HIPCHK(hipMemcpyAsync(out_ids, m->out_ids.p, (size_t)B * max_new * 4, hipMemcpyDeviceToHost, m->st));
+    HIPCHK(hipStreamSynchronize(m->st));
+    if (eos_id >= 0) {  // HF stops right after the first step at which every row has produced EOS
+        int last = 0;
+        for (int b = 0; b < B; ++b) {
+            int e = produced;
+            for (int s = 0; s < produced; ++s)
+                if (out_ids[(size_t)b * max_new + s] == eos_id) { e = s + 1; break; }
+            last = std::max(last, e);
+        }
+        produced = std::min(produced, last);
+    }
+    if (n_generated) *n_generated = produced;
+    if (m->ev[0]) {
+        (void)hipEventElapsedTime(&m->t_encode, m->ev[0], m->ev[1]);
+        (void)hipEventElapsedTime(&m->t_prefill, m->ev[1], m->ev[2]);
+        (void)hipEventElapsedTime(&m->t_decode, m->ev[2], m->ev[3]);
+    }
+    GUARD_END(m->ctx)
+}
+
+VC_API int vc_last_timings(vc_model* m, float* encode_ms, float* prefill_ms, float* decode_ms) {
+    if (!m) return VC_ERR_INVALID;
+    if (encode_ms) *encode_ms = m->t_encode;
+    if (prefill_ms) *prefill_ms = m->t_prefill;
+    if (decode_ms) *decode_ms = m->t_decode;
+    return VC_OK;
+}
+
+VC_API int vc_profile_decode_gemv(vc_model* m, int B, int reps, int* launches, double* avg_us, double* avg_bytes) {
+    if (!m) return VC_ERR_INVALID;
+    GUARD_BEGIN
+    REQUIRE(m->finalized && B >= 1 && B <= 16 && reps >= 1, VC_ERR_INVALID, "bad profile arguments");
+    const vc_model_cfg& c = m->c;
+    const int D = c.hidden, F = c.ffn;
+    ensure_llm(m, B, 64);
+    auto sweep = [&]() {
+        for (int l = 0; l < c.layers; ++l) {
+            const LlmLayer& L = m->llm[l];
+            gemv(m, m->xn_dec.as<bf16_t>(), L.qkv_p, m->qkv_dec.p, B, 3 * D, D, 3 * D, GEMV_BF16);
+            gemv(m, m->attn_dec.as<bf16_t>(), L.o_p, m->x_dec.p, B, D, D, D, GEMV_RESID_F32);
+            gemv(m, m->xn_dec.as<bf16_t>(), L.gu_p, m->h_dec.p, B, 2 * F, D, F, GEMV_SWIGLU);
+            gemv(m, m->h_dec.as<bf16_t>(), L.down_p, m->x_dec.p, B, D, F, D, GEMV_RESID_F32);
+        }
+        gemv(m, m->xn_dec.as<bf16_t>(), m->lm_head_p, m->logits.p, B, c.vocab, D, c.vocab, GEMV_F32);
+    };
+    sweep();  // warm
+    HIPCHK(hipEventRecord(m->ev[0], m->st));
+    for (int r = 0; r < reps; ++r) sweep();
+    HIPCHK(hipEventRecord(m->ev[1], m->st));
+    HIPCHK(hipStreamSynchronize(m->st));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, m->ev[0], m->ev[1]));
+    const int n = 4 * c.layers + 1;
+    const double bytes = 2.0 * ((double)c.layers * (4.0 * D * D + 3.0 * D * F) + (double)D * c.vocab);
+    if (launches) *launches = n;
+    if (avg_us) *avg_us = (double)ms * 1e3 / ((double)reps * n);
+    if (avg_bytes) *avg_bytes = bytes / n;
+    HIPCHK(hipMemsetAsync(m->x_dec.p, 0, m->x_dec.cap, m->st));
+    HIPCHK(hipStreamSynchronize(m->st));
+    GUARD_END(m->ctx)
+}

@@ -138,6 +138,7 @@ void launch_advance(int* step_dev, int* pos_dev, int* ctx_dev, hipStream_t s);
 // ---- misc ---------------------------------------------------------------------------------------
 void launch_synth_bf16(bf16_t* out, size_t n, uint32_t tseed, float offset, float halfwidth, hipStream_t s);
 void launch_synth_f32(float* out, size_t n, uint32_t tseed, float offset, float halfwidth, hipStream_t s);
+void launch_row_sum(const float* x, size_t n_per_row, int rows, float* out, hipStream_t s);
 void launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
 void launch_bf16_to_f32(const bf16_t* in, float* out, size_t n, hipStream_t s);
 

@@ -120,6 +120,21 @@ void launch_synth_f32(float* out, size_t n, uint32_t tseed, float offset, float 
               (float)(halfwidth / 8388608.0));
 }
 
+// per-row fp32 sum (is_depth_zero = mean(depth)==0, vcoder_ds_llava_arch.py:161)
+__global__ __launch_bounds__(256) void row_sum_kernel(const float* x, size_t n_per_row, float* out) {
+    __shared__ float red[4];
+    const float* r = x + (size_t)blockIdx.x * n_per_row;
+    float s = 0.f;
+    for (size_t i = threadIdx.x; i < n_per_row; i += 256) s += r[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+void launch_row_sum(const float* x, size_t n_per_row, int rows, float* out, hipStream_t s) {
+    VC_LAUNCH(row_sum_kernel, dim3(rows), dim3(256), 0, s, x, n_per_row, out);
+}
+
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* in, bf16_t* out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = f2bf(in[i]);
 }

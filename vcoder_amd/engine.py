@@ -1,0 +1,266 @@
+"""Thin Python owner of a `vc_model` (include/vcoder_hip.h).  All arithmetic happens in libvcoder_hip.so;
+this file only marshals pointers, shapes and errors."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Iterable, Optional, Tuple
+
+import numpy as np
+
+from . import _lib, synth
+from .config import VCoderConfig
+
+_ERRORS = {_lib.VC_ERR_INVALID: ValueError, _lib.VC_ERR_HIP: RuntimeError, _lib.VC_ERR_STATE: RuntimeError,
+           _lib.VC_ERR_INDEX: IndexError, _lib.VC_ERR_UNEQUAL: UnboundLocalError}
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+class HipEngine:
+    """One model replica on one GPU (one HIP stream).  `lib` is injectable ONLY for the CPU emulator tests;
+    product code always goes through `_lib.load()`, which has no fallback."""
+
+    def __init__(self, cfg: VCoderConfig, device_index: int = 0, lib: Optional[C.CDLL] = None):
+        cfg.validate()
+        self.cfg = cfg
+        self.lib = lib if lib is not None else _lib.load()
+        if lib is not None:
+            _lib.declare(self.lib)
+        self.device_index = device_index
+        self._ctx = C.c_void_p()
+        self._model = C.c_void_p()
+        rc = self.lib.vc_init(device_index, C.byref(self._ctx))
+        if rc != 0 or not self._ctx:
+            raise RuntimeError(f"vc_init(device {device_index}) failed with status {rc}: no usable HIP device")
+        c = _lib.ModelCfg(
+            variant=_lib.VARIANTS[cfg.variant], vit_hidden=cfg.mm_hidden_size, vit_heads=cfg.vit_num_heads,
+            vit_ffn=cfg.vit_intermediate_size, vit_layers=cfg.vit_num_layers, vit_layers_used=cfg.vit_layers_used,
+            vit_image=cfg.vit_image_size, vit_patch=cfg.vit_patch_size,
+            vit_keep_cls=int(cfg.mm_vision_select_feature == "cls_patch"), vit_ln_eps=cfg.vit_layer_norm_eps,
+            hidden=cfg.hidden_size, heads=cfg.num_attention_heads, ffn=cfg.intermediate_size,
+            layers=cfg.num_hidden_layers, vocab=cfg.vocab_size,
+            max_positions=min(int(cfg.max_position_embeddings), 4096), rms_eps=cfg.rms_norm_eps,
+            rope_theta=cfg.rope_theta, mm_proj_depth=synth.projector_depth(cfg.mm_projector_type),
+            seg_proj_depth=synth.projector_depth(cfg.seg_mm_projector_type) if cfg.variant != "llava" else 0,
+            pad_token_id=int(cfg.pad_token_id or 0))
+        self._check(self.lib.vc_model_create(self._ctx, C.byref(c), C.byref(self._model)))
+        self.finalized = False
+        self.last_S = 0
+
+    # ---- plumbing -----------------------------------------------------------------------------------
+    def _check(self, rc: int) -> int:
+        if rc < 0:
+            msg = self.lib.vc_last_error(self._ctx)
+            msg = msg.decode("utf-8", "replace") if msg else f"status {rc}"
+            raise _ERRORS.get(rc, RuntimeError)(msg)
+        return rc
+
+    def close(self):
+        if getattr(self, "_model", None):
+            self.lib.vc_model_destroy(self._model)
+            self._model = C.c_void_p()
+        if getattr(self, "_ctx", None):
+            self.lib.vc_shutdown(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def stream_ptr(self) -> int:
+        return int(self.lib.vc_stream(self._ctx) or 0)
+
+    def synchronize(self):
+        self._check(self.lib.vc_synchronize(self._ctx))
+
+    # ---- weights ------------------------------------------------------------------------------------
+    def load_tensor(self, key: str, value) -> bool:
+        """Returns False when the key is accepted but dead at inference (depth_mm_projector, mm2_projector,
+        vcoder_lm_emb, unused CLIP layers)."""
+        if _is_torch(value):
+            import torch
+
+            t = value.detach()
+            if t.dtype == torch.bfloat16:
+                arr = t.contiguous().cpu().view(torch.int16).numpy()
+                dt = _lib.VC_BF16
+            else:
+                arr = t.to(torch.float32).contiguous().cpu().numpy()
+                dt = _lib.VC_F32
+        else:
+            arr = np.ascontiguousarray(value, dtype=np.float32)
+            dt = _lib.VC_F32
+        shape = (C.c_int64 * max(arr.ndim, 1))(*(arr.shape if arr.ndim else (1,)))
+        rc = self._check(self.lib.vc_model_load_tensor(self._model, key.encode(), arr.ctypes.data_as(C.c_void_p), dt,
+                                                       shape, max(arr.ndim, 1)))
+        return rc == _lib.VC_OK
+
+    def load_state_dict(self, sd: Dict[str, object]) -> Tuple[int, int]:
+        used = dead = 0
+        for k, v in sd.items():
+            if self.load_tensor(k, v):
+                used += 1
+            else:
+                dead += 1
+        return used, dead
+
+    def load_synthetic(self, seed: int = 42):
+        """Seeded synthetic checkpoint generated ON THE DEVICE, bit-identical to synth.synth_state_dict."""
+        for key, shape, off, hw in synth.tensor_specs(self.cfg):
+            sh = (C.c_int64 * len(shape))(*shape)
+            self._check(self.lib.vc_model_synth_tensor(self._model, key.encode(), sh, len(shape),
+                                                       C.c_uint32(synth.tensor_seed(key, seed)), C.c_float(off),
+                                                       C.c_float(hw)))
+
+    def finalize(self):
+        self._check(self.lib.vc_model_finalize(self._model))
+        self.finalized = True
+
+    # ---- inputs -------------------------------------------------------------------------------------
+    def _pixels(self, *arrs):
+        """-> (ctypes pointers, on_device flag, keep-alive list).  All given arrays share one residency."""
+        present = [a for a in arrs if a is not None]
+        on_dev = bool(present) and all(_is_torch(a) and a.is_cuda for a in present)
+        keep, ptrs = [], []
+        for a in arrs:
+            if a is None:
+                ptrs.append(None)
+                continue
+            if on_dev:
+                import torch
+
+                t = a.to(torch.float32).contiguous()
+                keep.append(t)
+                ptrs.append(C.c_void_p(t.data_ptr()))
+            else:
+                if _is_torch(a):
+                    a = a.detach().float().cpu().numpy()
+                n = np.ascontiguousarray(a, dtype=np.float32)
+                keep.append(n)
+                ptrs.append(n.ctypes.data_as(C.c_void_p))
+        return ptrs, int(on_dev), keep
+
+    def _check_pixels(self, a, B):
+        if a is None:
+            return
+        s = self.cfg.vit_image_size
+        if tuple(a.shape) != (B, 3, s, s):
+            raise ValueError(f"expected pixel tensor [{B},3,{s},{s}], got {tuple(a.shape)}")
+
+    @staticmethod
+    def _ids(input_ids) -> np.ndarray:
+        if _is_torch(input_ids):
+            input_ids = input_ids.detach().cpu().numpy()
+        ids = np.ascontiguousarray(input_ids, dtype=np.int64)
+        if ids.ndim != 2:
+            raise ValueError("input_ids must be [B,T]")
+        return ids
+
+    # ---- hot path -----------------------------------------------------------------------------------
+    def encode(self, pixels, modality: str = "img") -> np.ndarray:
+        B = int(pixels.shape[0])
+        self._check_pixels(pixels, B)
+        (p,), on_dev, keep = self._pixels(pixels)
+        rows = self.cfg.num_patches + (1 if self.cfg.mm_vision_select_feature == "cls_patch" else 0)
+        out = np.empty((B, rows, self.cfg.hidden_size), dtype=np.float32)
+        self._check(self.lib.vc_encode(self._model, _lib.MODALITY[modality], p, on_dev, B,
+                                       out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def inputs_embeds(self, input_ids, images, segs=None, depths=None, has_attention_mask: bool = False) -> np.ndarray:
+        ids = self._ids(input_ids)
+        B, T = ids.shape
+        for a in (images, segs, depths):
+            self._check_pixels(a, B)
+        (pi, ps, pd), on_dev, keep = self._pixels(images, segs, depths)
+        S = C.c_int(0)
+        # first call sizes the output; lengths are only known after the splice plan, so run twice is avoided by
+        # allocating for the worst case: every placeholder expands to a feature block
+        rows = self.cfg.num_patches + (1 if self.cfg.mm_vision_select_feature == "cls_patch" else 0)
+        worst = T + 3 * rows * max(1, int((ids < 0).sum(axis=1).max()))
+        out = np.empty((B * worst * self.cfg.hidden_size,), dtype=np.float32)
+        self._check(self.lib.vc_prefill_embeds_only(self._model, ids.ctypes.data_as(C.c_void_p), B, T, pi, ps, pd, on_dev,
+                                                    int(has_attention_mask), out.ctypes.data_as(C.c_void_p), C.byref(S)))
+        self.last_S = S.value
+        return out[: B * S.value * self.cfg.hidden_size].reshape(B, S.value, self.cfg.hidden_size).copy()
+
+    def prefill(self, input_ids, images, segs=None, depths=None, has_attention_mask: bool = False,
+                all_logits: bool = False):
+        """-> (logits_last [B,V], logits_all [B,S,V] or None, S)"""
+        ids = self._ids(input_ids)
+        B, T = ids.shape
+        for a in (images, segs, depths):
+            self._check_pixels(a, B)
+        (pi, ps, pd), on_dev, keep = self._pixels(images, segs, depths)
+        V = self.cfg.vocab_size
+        last = np.empty((B, V), dtype=np.float32)
+        S = C.c_int(0)
+        if not all_logits:
+            self._check(self.lib.vc_prefill(self._model, ids.ctypes.data_as(C.c_void_p), B, T, pi, ps, pd, on_dev,
+                                            int(has_attention_mask), last.ctypes.data_as(C.c_void_p), None, C.byref(S)))
+            self.last_S = S.value
+            self._cur_batch = B
+            return last, None, S.value
+        rows = self.cfg.num_patches + (1 if self.cfg.mm_vision_select_feature == "cls_patch" else 0)
+        worst = T + 3 * rows * max(1, int((ids < 0).sum(axis=1).max()))
+        full = np.empty((B * worst * V,), dtype=np.float32)
+        self._check(self.lib.vc_prefill(self._model, ids.ctypes.data_as(C.c_void_p), B, T, pi, ps, pd, on_dev,
+                                        int(has_attention_mask), last.ctypes.data_as(C.c_void_p),
+                                        full.ctypes.data_as(C.c_void_p), C.byref(S)))
+        self.last_S = S.value
+        self._cur_batch = B
+        return last, full[: B * S.value * V].reshape(B, S.value, V).copy(), S.value
+
+    def decode_step(self, tokens=None, want_logits: bool = True):
+        """-> (logits [B,V] or None, next_tok [B] int32)"""
+        B = self._cur_batch
+        tok_p = None
+        if tokens is not None:
+            tk = np.ascontiguousarray(np.asarray(tokens).reshape(-1), dtype=np.int32)
+            if tk.shape[0] != B:
+                raise ValueError(f"expected {B} tokens")
+            tok_p = tk.ctypes.data_as(C.c_void_p)
+        lg = np.empty((B, self.cfg.vocab_size), dtype=np.float32) if want_logits else None
+        nxt = np.empty((B,), dtype=np.int32)
+        self._check(self.lib.vc_decode_step(self._model, tok_p, lg.ctypes.data_as(C.c_void_p) if want_logits else None,
+                                            nxt.ctypes.data_as(C.c_void_p)))
+        return lg, nxt
+
+    _cur_batch = 0
+
+    def generate_greedy(self, input_ids, images, segs=None, depths=None, max_new_tokens: int = 128,
+                        eos_token_id: Optional[int] = None, pad_token_id: Optional[int] = None) -> np.ndarray:
+        """-> new token ids [B, n_generated] int32 (prompt not included)."""
+        ids = self._ids(input_ids)
+        B, T = ids.shape
+        for a in (images, segs, depths):
+            self._check_pixels(a, B)
+        (pi, ps, pd), on_dev, keep = self._pixels(images, segs, depths)
+        out = np.empty((B, max_new_tokens), dtype=np.int32)
+        n = C.c_int(0)
+        pad = int(self.cfg.pad_token_id or 0) if pad_token_id is None else int(pad_token_id)
+        eos = -1 if eos_token_id is None else int(eos_token_id)
+        self._check(self.lib.vc_generate_greedy(self._model, ids.ctypes.data_as(C.c_void_p), B, T, pi, ps, pd, on_dev,
+                                                int(max_new_tokens), eos, pad, out.ctypes.data_as(C.c_void_p),
+                                                C.byref(n)))
+        self._cur_batch = B
+        return out[:, : n.value].copy()
+
+    # bookkeeping used by decode_step
+    def note_prefill(self, B: int):
+        self._cur_batch = B
+
+    def last_timings(self):
+        e, p, d = C.c_float(), C.c_float(), C.c_float()
+        self._check(self.lib.vc_last_timings(self._model, C.byref(e), C.byref(p), C.byref(d)))
+        return {"encode_ms": e.value, "prefill_ms": p.value, "decode_ms": d.value}
+
+    def profile_decode_gemv(self, B: int, reps: int = 3):
+        n, us, by = C.c_int(), C.c_double(), C.c_double()
+        self._check(self.lib.vc_profile_decode_gemv(self._model, B, reps, C.byref(n), C.byref(us), C.byref(by)))
+        return {"launches_per_step": n.value, "avg_us": us.value, "avg_bytes": by.value}
