@@ -1,0 +1,67 @@
+"""`-m gpu`: every HIP kernel at the TRUE shapes of VCoder-DS LLaVA-1.5-7b / CLIP ViT-L/14@336, called through
+the C ABI of libvcoder_hip.so (include/vcoder_kernels.h) and compared with the oracle."""
+import pytest
+
+import kernel_cases as kc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def be():
+    return kc.HipBackend()
+
+
+# (M, N, K, epilogue): ViT QKV/out/fc1/fc2, patchify, adapters, Llama qkv/o/gate-up/down, ragged edges
+@pytest.mark.parametrize("M,N,K,epi,bias", [
+    (1154, 3072, 1024, 0, True), (1154, 1024, 1024, 4, True), (1154, 4096, 1024, 1, True), (1154, 1024, 4096, 4, True),
+    (1152, 1024, 640, 3, False), (1152, 4096, 1024, 2, True), (1152, 4096, 4096, 0, True),
+    (1216, 12288, 4096, 0, False), (1216, 4096, 4096, 4, False), (1216, 22016, 4096, 5, False),
+    (1216, 4096, 11008, 4, False), (70, 264, 192, 0, True), (300, 320, 256, 3, False)])
+def test_gemm(be, M, N, K, epi, bias):
+    kc.check_gemm(be, M, N, K, epi, bias)
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(8, 12288, 4096, 0), (8, 4096, 4096, 2), (8, 22016, 4096, 3),
+                                       (8, 4096, 11008, 2), (8, 32000, 4096, 1), (16, 15360, 5120, 0), (1, 320, 256, 1),
+                                       (3, 48, 288, 1)])
+def test_gemv(be, M, N, K, epi):
+    kc.check_gemv(be, M, N, K, epi)
+
+
+def test_small_ops(be):
+    kc.check_interleave(be, 11008, 256)
+    kc.check_layernorm(be, 4616, 1024)
+    kc.check_layernorm(be, 5, 128)
+    kc.check_rmsnorm(be, 9728, 4096)
+    kc.check_rmsnorm(be, 8, 5120, gather=True)
+    kc.check_rmsnorm(be, 3, 256)
+    kc.check_im2col(be, 3, 336, 14, 640)
+    kc.check_im2col(be, 2, 56, 14, 640)
+    kc.check_vit_embed_ln(be, 3, 577, 1024)
+    kc.check_select_rows(be, 3, 577, 1024)
+    kc.check_splice(be, 4096)
+    kc.check_greedy(be, 8, 32000)
+    kc.check_synth(be, n=1 << 20)
+
+
+@pytest.mark.parametrize("B,T,H,hd,rope", [(2, 1216, 4, 128, True), (3, 577, 16, 64, False), (1, 70, 2, 128, True)])
+def test_qkv_split(be, B, T, H, hd, rope):
+    kc.check_qkv_split(be, B, T, H, hd, rope)
+
+
+def test_qkv_append(be):
+    kc.check_qkv_append(be, 8, 32, 128, 1216)
+    kc.check_qkv_append(be, 2, 2, 64, 5)
+
+
+@pytest.mark.parametrize("B,H,T,hd,causal,spike", [(2, 16, 577, 64, False, False), (1, 4, 577, 64, False, True),
+                                                   (2, 8, 1216, 128, True, False), (1, 2, 1216, 128, True, True),
+                                                   (1, 1, 17, 64, False, False), (1, 2, 200, 128, True, True)])
+def test_attention(be, B, H, T, hd, causal, spike):
+    kc.check_attention(be, B, H, T, hd, causal, spike=spike)
+
+
+@pytest.mark.parametrize("hd,ctx", [(128, 1217), (128, 1344), (128, 70), (64, 33)])
+def test_attention_decode(be, hd, ctx):
+    kc.check_attention_decode(be, 2, 4, hd, ctx)
