@@ -1,12 +1,147 @@
-// TEST-ONLY: runtime of the thread-per-lane emulator (see hip_emu.h).
+// TEST-ONLY: runtime of the fiber-per-lane emulator (see hip_emu.h).
+//
+// A launch spawns up to NWORKERS OS threads; each takes workgroups round-robin.  The threads of one workgroup are
+// fibers with a hand-rolled x86-64 context switch (callee-saved registers + stack pointer), scheduled
+// round-robin; a fiber yields when it waits at __syncthreads() or at a wave-level collective (shuffle / MFMA).
+// Like the hardware, barriers count only threads that have not exited.
 #include "hip_emu.h"
-#include <stdio.h>
 
-thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+#include <stdio.h>
+#include <sys/mman.h>
+
+extern "C" void vc_emu_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl vc_emu_switch
+.type vc_emu_switch,@function
+vc_emu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+)");
+
 namespace vc_emu {
-thread_local BlockCtx* g_ctx = nullptr;
-thread_local int g_lane = 0, g_wave = 0;
+thread_local Fiber* g_cur = nullptr;
 Graph* g_capturing = nullptr;
+
+static const size_t STACK_BYTES = 256 * 1024;
+
+void yield_to_scheduler() {
+    Fiber* f = g_cur;
+    vc_emu_switch(&f->sp, f->blk->sched_sp);
+}
+
+void block_barrier() {
+    BlockCtx* b = g_cur->blk;
+    const unsigned gen = b->bar_gen;
+    if (++b->bar_arrived >= b->alive) {
+        b->bar_arrived = 0;
+        ++b->bar_gen;
+        ++b->progress;
+        return;
+    }
+    while (b->bar_gen == gen) yield_to_scheduler();
+}
+
+void wave_sync() {
+    BlockCtx* b = g_cur->blk;
+    WaveCtx& w = b->waves[g_cur->wave];
+    const unsigned gen = w.gen;
+    if (++w.arrived >= b->wave_alive[g_cur->wave]) {
+        w.arrived = 0;
+        ++w.gen;
+        ++b->progress;
+        return;
+    }
+    while (w.gen == gen) yield_to_scheduler();
+}
+
+static void fiber_finished(Fiber* f) {
+    BlockCtx* b = f->blk;
+    f->done = true;
+    --b->alive;
+    --b->wave_alive[f->wave];
+    ++b->progress;
+    // a thread that exits releases barriers the remaining threads are all waiting at
+    if (b->alive > 0 && b->bar_arrived >= b->alive && b->bar_arrived > 0) {
+        b->bar_arrived = 0;
+        ++b->bar_gen;
+    }
+    WaveCtx& w = b->waves[f->wave];
+    if (b->wave_alive[f->wave] > 0 && w.arrived >= b->wave_alive[f->wave] && w.arrived > 0) {
+        w.arrived = 0;
+        ++w.gen;
+    }
+}
+
+static void fiber_entry() {
+    Fiber* f = g_cur;
+    (*f->blk->body)();
+    fiber_finished(f);
+    void* dummy;
+    vc_emu_switch(&dummy, f->blk->sched_sp);
+    abort();  // never resumed
+}
+
+static void run_block(BlockCtx* b, std::vector<Fiber>& fibers) {
+    const int n = b->nthreads;
+    b->alive = n;
+    b->bar_arrived = 0;
+    for (int w = 0; w < n / 64; ++w) {
+        b->wave_alive[w] = 64;
+        b->waves[w].arrived = 0;
+    }
+    for (int t = 0; t < n; ++t) {
+        Fiber& f = fibers[t];
+        f.done = false;
+        f.blk = b;
+        f.lane = t & 63;
+        f.wave = t >> 6;
+        f.tidx = dim3(t % b->bdim.x, (t / b->bdim.x) % b->bdim.y, t / (b->bdim.x * b->bdim.y));
+        // initial frame: 6 callee-saved slots + return address = fiber_entry; rsp % 16 == 8 at function entry
+        uintptr_t top = ((uintptr_t)f.stack + STACK_BYTES) & ~(uintptr_t)15;
+        void** sp = (void**)(top - 8);
+        *--sp = (void*)&fiber_entry;
+        for (int i = 0; i < 6; ++i) *--sp = nullptr;
+        f.sp = sp;
+    }
+    while (b->alive > 0) {
+        const unsigned long before = b->progress;
+        for (int t = 0; t < n; ++t) {
+            Fiber& f = fibers[t];
+            if (f.done) continue;
+            g_cur = &f;
+            vc_emu_switch(&b->sched_sp, f.sp);
+        }
+        if (b->progress == before && b->alive > 0) {
+            fprintf(stderr, "emu: deadlock in block (%u,%u,%u): %d threads alive, barrier %d arrived\n", b->bidx.x,
+                    b->bidx.y, b->bidx.z, b->alive, b->bar_arrived);
+            abort();
+        }
+    }
+    g_cur = nullptr;
+}
+
+static int n_workers() {
+    static int n = [] {
+        const char* e = getenv("VC_EMU_WORKERS");
+        int v = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+        return std::max(1, std::min(v, 32));
+    }();
+    return n;
+}
 
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {
     if (g_capturing) {  // stream capture: record, run at hipGraphLaunch
@@ -19,35 +154,34 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
         fprintf(stderr, "emu: block size %d must be a multiple of 64 (<=1024)\n", nthreads);
         abort();
     }
-    BlockCtx* ctx = new BlockCtx();
-    ctx->nthreads = nthreads;
-    pthread_barrier_init(&ctx->bar, nullptr, nthreads);
-    const int nwaves = nthreads / 64;
-    for (int w = 0; w < nwaves; ++w) pthread_barrier_init(&ctx->waves[w].bar, nullptr, 64);
-    ctx->dyn_smem = (char*)aligned_alloc(256, (shmem + 255) / 256 * 256 + 256);
-    std::vector<std::thread> th;
-    th.reserve(nthreads);
-    for (int t = 0; t < nthreads; ++t) {
-        th.emplace_back([=]() {
-            g_ctx = ctx;
-            g_lane = t & 63;
-            g_wave = t >> 6;
-            ::blockDim = block;
-            ::gridDim = grid;
-            ::threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
-            for (unsigned bz = 0; bz < grid.z; ++bz)
-                for (unsigned by = 0; by < grid.y; ++by)
-                    for (unsigned bx = 0; bx < grid.x; ++bx) {
-                        ::blockIdx = dim3(bx, by, bz);
-                        body();
-                        pthread_barrier_wait(&ctx->bar);  // blocks run one after another
-                    }
-        });
+    const size_t nblocks = (size_t)grid.x * grid.y * grid.z;
+    const int workers = (int)std::min<size_t>(n_workers(), nblocks);
+    auto work = [&](int wid) {
+        char* stacks = (char*)mmap(nullptr, STACK_BYTES * nthreads, PROT_READ | PROT_WRITE,
+                                   MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (stacks == MAP_FAILED) abort();
+        std::vector<Fiber> fibers(nthreads);
+        for (int t = 0; t < nthreads; ++t) fibers[t].stack = stacks + (size_t)t * STACK_BYTES;
+        BlockCtx* b = new BlockCtx();
+        b->nthreads = nthreads;
+        b->bdim = block;
+        b->gdim = grid;
+        b->body = &body;
+        b->dyn_smem = (char*)aligned_alloc(256, (shmem + 255) / 256 * 256 + 256);
+        for (size_t i = wid; i < nblocks; i += workers) {
+            b->bidx = dim3((unsigned)(i % grid.x), (unsigned)((i / grid.x) % grid.y), (unsigned)(i / ((size_t)grid.x * grid.y)));
+            run_block(b, fibers);
+        }
+        free(b->dyn_smem);
+        delete b;
+        munmap(stacks, STACK_BYTES * nthreads);
+    };
+    if (workers == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int w = 0; w < workers; ++w) th.emplace_back(work, w);
+        for (auto& t : th) t.join();
     }
-    for (auto& t : th) t.join();
-    pthread_barrier_destroy(&ctx->bar);
-    for (int w = 0; w < nwaves; ++w) pthread_barrier_destroy(&ctx->waves[w].bar);
-    free(ctx->dyn_smem);
-    delete ctx;
 }
 }  // namespace vc_emu

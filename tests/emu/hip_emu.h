@@ -1,4 +1,4 @@
-// hip_emu.h — TEST-ONLY functional emulator for the gfx950 kernels (thread-per-lane, pthread barriers).
+// hip_emu.h — TEST-ONLY functional emulator for the gfx950 kernels (fiber-per-lane, cooperative scheduling).
 //
 // Purpose: there is no GPU in the build container and only ~90 GPU-minutes per round, so the kernels'
 // index arithmetic, LDS layouts, MFMA fragment plumbing and reductions are first checked on the CPU
@@ -7,10 +7,10 @@
 // vcoder_amd/ (the product) includes or links this file without -DVC_EMU, and the product library is
 // built exclusively by hipcc.
 //
-// Blocks of one launch run sequentially (so `__shared__` can be a function-local static); the threads
-// of a block are real OS threads synchronised by pthread barriers.
+// Every GPU thread is a user-level fiber (hand-rolled x86-64 context switch); the fibers of one workgroup run
+// round-robin on ONE OS thread and yield at barriers / cross-lane collectives, so `__shared__` is a
+// `static thread_local` and several workgroups run concurrently on different OS threads.
 #pragma once
-#include <pthread.h>
 #include <stdint.h>
 #include <string.h>
 #include <math.h>
@@ -32,23 +32,41 @@ using std::max;
 #define __device__
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
-#define __shared__ static
+#define __shared__ static thread_local
 #define __launch_bounds__(...)
 #define __restrict__ __restrict
 
 namespace vc_emu {
 struct WaveCtx {
-    pthread_barrier_t bar;
+    int arrived = 0;
+    unsigned gen = 0;
     alignas(16) unsigned char xchg[64][64];
 };
-struct BlockCtx {
-    pthread_barrier_t bar;
-    int nthreads;
-    WaveCtx waves[16];
-    char* dyn_smem;
+struct BlockCtx;
+struct Fiber {
+    void* sp = nullptr;
+    char* stack = nullptr;
+    bool done = false;
+    int lane = 0, wave = 0;
+    dim3 tidx;
+    BlockCtx* blk = nullptr;
 };
-extern thread_local BlockCtx* g_ctx;
-extern thread_local int g_lane, g_wave;
+struct BlockCtx {
+    int nthreads = 0, alive = 0;
+    int bar_arrived = 0;
+    unsigned bar_gen = 0;
+    int wave_alive[16];
+    WaveCtx waves[16];
+    char* dyn_smem = nullptr;
+    dim3 bidx, bdim, gdim;
+    unsigned long progress = 0;
+    const std::function<void()>* body = nullptr;
+    void* sched_sp = nullptr;
+};
+extern thread_local Fiber* g_cur;
+void yield_to_scheduler();
+void block_barrier();
+void wave_sync();
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
 }  // namespace vc_emu
 
@@ -99,15 +117,18 @@ inline hipError_t hipGraphDestroy(hipGraph_t g) { delete g; return 0; }
 inline hipError_t hipGraphExecDestroy(hipGraphExec_t g) { delete g; return 0; }
 inline hipError_t hipGraphLaunch(hipGraphExec_t g, hipStream_t) { for (auto& f : g->ops) f(); return 0; }
 
-extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+#define threadIdx (vc_emu::g_cur->tidx)
+#define blockIdx (vc_emu::g_cur->blk->bidx)
+#define blockDim (vc_emu::g_cur->blk->bdim)
+#define gridDim (vc_emu::g_cur->blk->gdim)
 
-inline void __syncthreads() { pthread_barrier_wait(&vc_emu::g_ctx->bar); }
+inline void __syncthreads() { vc_emu::block_barrier(); }
 inline float __expf(float x) { return expf(x); }
 inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 inline float __fmul_rn(float a, float b) { return a * b; }
 inline float __fadd_rn(float a, float b) { return a + b; }
 
-#define VC_DYNAMIC_SMEM(type, name) type* name = reinterpret_cast<type*>(vc_emu::g_ctx->dyn_smem)
+#define VC_DYNAMIC_SMEM(type, name) type* name = reinterpret_cast<type*>(vc_emu::g_cur->blk->dyn_smem)
 #define VC_LAUNCH(kernel, grid, block, shmem, stream, ...) \
     vc_emu::launch(grid, block, shmem, [=]() { kernel(__VA_ARGS__); })
 
@@ -115,35 +136,35 @@ namespace vc {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-inline int lane_id() { return vc_emu::g_lane; }
+inline int lane_id() { return vc_emu::g_cur->lane; }
 
 template <class T> inline T shfl_xor(T v, int mask) {
     static_assert(sizeof(T) <= 64, "xchg slot");
-    auto& w = vc_emu::g_ctx->waves[vc_emu::g_wave];
-    memcpy(w.xchg[vc_emu::g_lane], &v, sizeof(T));
-    pthread_barrier_wait(&w.bar);
+    auto& w = vc_emu::g_cur->blk->waves[vc_emu::g_cur->wave];
+    memcpy(w.xchg[vc_emu::g_cur->lane], &v, sizeof(T));
+    vc_emu::wave_sync();
     T r;
-    memcpy(&r, w.xchg[(vc_emu::g_lane ^ mask) & 63], sizeof(T));
-    pthread_barrier_wait(&w.bar);
+    memcpy(&r, w.xchg[(vc_emu::g_cur->lane ^ mask) & 63], sizeof(T));
+    vc_emu::wave_sync();
     return r;
 }
 template <class T> inline T shfl(T v, int src) {
-    auto& w = vc_emu::g_ctx->waves[vc_emu::g_wave];
-    memcpy(w.xchg[vc_emu::g_lane], &v, sizeof(T));
-    pthread_barrier_wait(&w.bar);
+    auto& w = vc_emu::g_cur->blk->waves[vc_emu::g_cur->wave];
+    memcpy(w.xchg[vc_emu::g_cur->lane], &v, sizeof(T));
+    vc_emu::wave_sync();
     T r;
     memcpy(&r, w.xchg[src & 63], sizeof(T));
-    pthread_barrier_wait(&w.bar);
+    vc_emu::wave_sync();
     return r;
 }
 
 // v_mfma_f32_16x16x32_bf16 under the assumed fragment maps (see vc_device.h header).
 inline f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
-    auto& w = vc_emu::g_ctx->waves[vc_emu::g_wave];
-    const int lane = vc_emu::g_lane;
+    auto& w = vc_emu::g_cur->blk->waves[vc_emu::g_cur->wave];
+    const int lane = vc_emu::g_cur->lane;
     memcpy(w.xchg[lane], &a, 16);
     memcpy(w.xchg[lane] + 16, &b, 16);
-    pthread_barrier_wait(&w.bar);
+    vc_emu::wave_sync();
     const int j = lane & 15;
     f32x4 d = c;
     for (int r = 0; r < 4; ++r) {
@@ -161,7 +182,7 @@ inline f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
         }
         d[r] = c[r] + acc;
     }
-    pthread_barrier_wait(&w.bar);
+    vc_emu::wave_sync();
     return d;
 }
 }  // namespace vc

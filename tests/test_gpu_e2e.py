@@ -49,7 +49,8 @@ def test_quirks():
     with pytest.raises(UnboundLocalError):
         eng.prefill(ragged, imgs, segs, deps, has_attention_mask=True)
     _, _, S = eng.prefill(ragged, imgs, segs, deps, has_attention_mask=False)  # zero right-padding instead
-    assert S == int(g["spliced_len"])
+    # row 0 drops <depth> and splices 2 blocks (42 rows); row 1 keeps its 3 text ids after <image> (43 rows) -> S = 43
+    assert S == int(g["spliced_len"]) + 1
     # quirk 5: non-DS image-only prompt reaches the embedding lookup with -200 -> IndexError
     vc = e2e_cases.engine_for("vcoder")
     g2, _, ids2, imgs2, segs2, _ = e2e_cases.fixture_inputs("vc_img_seg")
