@@ -131,22 +131,21 @@ def main():
 
     from vcoder_amd import config as vcfg, synth
     from vcoder_amd.engine import HipEngine
+    from vcoder_amd.parallel import gather_token_ids, shard_range
 
     cfg = vcfg.vicuna_7b("vcoder_ds") if args.model == "7b" else vcfg.vicuna_13b("vcoder_ds")
     eng = HipEngine(cfg, device_index=local)
     eng.load_synthetic(42)
     eng.finalize()
     B, N_new = args.batch, args.new_tokens
-    first = rank * B
+    first, _ = shard_range(world * B, rank, world)   # contiguous shard of the global batch
     ids = np.stack([synth.synth_prompt_ids(cfg.vocab_size, "vcoder_ds", sample=first + b) for b in range(B)])
     imgs, segs, deps = (torch.from_numpy(a).cuda() for a in synth.synth_batch(B, cfg.vit_image_size, first))
-    gathered = torch.empty((world * B, N_new), dtype=torch.int32, device="cuda") if world > 1 else None
 
     def step():
         out = eng.generate_greedy(ids, imgs, segs, deps, max_new_tokens=N_new, eos_token_id=None)
-        if world > 1:  # the one exchange: gather the token stream (RCCL over xGMI), once per batch
-            dist.all_gather_into_tensor(gathered, torch.from_numpy(out).cuda())
-        return out
+        # the one exchange: all-gather of the token stream (RCCL over xGMI), once per batch; no-op for N=1
+        return gather_token_ids(out, dist, device="cuda")
 
     def fence():
         if world > 1:

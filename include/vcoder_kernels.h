@@ -1,0 +1,58 @@
+/* vcoder_kernels.h — per-kernel C entry points of libvcoder_hip.so (unit-test / micro-benchmark surface).
+ *
+ * Every function enqueues ONE gfx950 kernel on `stream` (NULL = default stream) over DEVICE pointers; bf16 tensors
+ * are raw uint16 bit patterns.  The `-m gpu` parity tests call each kernel through these at the true shapes of
+ * VCoder-DS LLaVA-1.5-7b and compare with oracle/cpu_ref.py.  Each replaces a torch/HF op of the reference's hot
+ * path; the file:line it restates is given per entry.
+ */
+#ifndef VCODER_KERNELS_H
+#define VCODER_KERNELS_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* nn.Linear / Conv2d-as-GEMM with fused epilogue: out = epi(A[M,K] . W[N,K]^T + bias).  epi: 0 bf16, 1 bf16 quick_gelu,
+ * 2 bf16 erf-gelu, 3 fp32, 4 fp32 residual add in place, 5 SwiGLU over interleaved (gate,up) rows.
+ * [HF] clip/modeling_clip.py:309-311,333,346-350; [HF] llama/modeling_llama.py:174-176,254-256,280;
+ * vcoder_llava/model/multimodal_projector/builder.py:42-46 */
+void vck_gemm(const uint16_t* A, const uint16_t* W, const float* bias, void* out, int M, int N, int K, int lda, int ldw,
+              int ldo, int epi, void* stream);
+/* decode-time skinny GEMM (M<=16) over MFMA-fragment-packed weights.  epi: 0 bf16, 1 fp32, 2 fp32 residual, 3 SwiGLU */
+void vck_gemv(const uint16_t* X, const uint16_t* Wp, void* out, int M, int N, int K, int ldo, int epi, void* stream);
+void vck_pack_weight(const uint16_t* W, uint16_t* Wp, int N, int K, void* stream);
+void vck_interleave_rows(const uint16_t* gate, const uint16_t* up, uint16_t* out, int F, int K, void* stream);
+/* nn.LayerNorm ([HF] clip :370,379) and LlamaRMSNorm ([HF] llama :53-70); fp32 in, bf16 out */
+void vck_layernorm(const float* x, const float* w, const float* b, uint16_t* y, int rows, int D, float eps, void* stream);
+void vck_rmsnorm(const float* x, const int* row_idx, const float* w, uint16_t* y, int rows, int D, float eps, void* stream);
+/* CLIPVisionEmbeddings ([HF] clip :202-218): im2col of the k=s=14 conv; CLS + position + pre_layrnorm */
+void vck_im2col(const float* pixels, uint16_t* cols, int n_img, int image, int patch, int Kpad, void* stream);
+void vck_vit_embed_ln(const float* patches, const float* cls, const float* pos, const float* w, const float* b, float* x,
+                      int n_img, int T, int D, float eps, void* stream);
+/* feature_select (multimodal_encoder/clip_encoder.py:29-37) */
+void vck_select_rows_bf16(const float* x, uint16_t* y, int n_img, int T, int skip, int D, void* stream);
+/* head split + rotate_half RoPE + KV-cache write ([HF] llama :113-160,259-262) */
+void vck_qkv_split(const uint16_t* qkv, uint16_t* q, uint16_t* k, uint16_t* vt, int B, int T, int H, int hd, int q_stride,
+                   int kv_stride, const int* pos0_dev, const float* rope_cos, const float* rope_sin, void* stream);
+/* softmax(QK^T*scale [+causal]) V, fp32 softmax ([HF] clip :259-277; [HF] llama eager_attention_forward :191-214) */
+void vck_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, uint16_t* out, int B, int H, int T, int hd,
+                   int q_stride, int kv_stride, int causal, float scale, void* stream);
+void vck_attention_decode(const uint16_t* q, const uint16_t* k, const uint16_t* vt, uint16_t* out, int B, int H, int hd,
+                          int kv_stride, const int* ctx_len_dev, float scale, void* stream);
+/* embedding gather + feature splice (vcoder_ds_llava_arch.py:173-276,305) */
+void vck_splice(const int* row_src, int nrows, const uint16_t* embed, const uint16_t* feats, float* x, int D, void* stream);
+void vck_embed_tokens(const int* tok, const uint16_t* embed, float* x, int B, int D, void* stream);
+/* greedy select with EOS/pad bookkeeping ([HF] generation/utils.py:2894,2925-2929) */
+void vck_greedy(const float* logits, int* next_tok, int* out_ids, int* finished, int* step_dev, int B, int V, int max_new,
+                int eos_id, int pad_id, void* stream);
+void vck_advance(int* step_dev, int* pos_dev, int* ctx_dev, void* stream);
+/* deterministic synthetic tensors (vcoder_amd/synth.py) and dtype converts */
+void vck_synth_bf16(uint16_t* out, uint64_t n, uint32_t tseed, float offset, float halfwidth, void* stream);
+void vck_synth_f32(float* out, uint64_t n, uint32_t tseed, float offset, float halfwidth, void* stream);
+void vck_f32_to_bf16(const float* in, uint16_t* out, uint64_t n, void* stream);
+void vck_bf16_to_f32(const uint16_t* in, float* out, uint64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

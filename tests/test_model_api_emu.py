@@ -1,0 +1,140 @@
+"""CPU tests of the reference-shaped Python API (load_pretrained_model-style loading from an HF-layout checkpoint,
+forward with past_key_values, generate with greedy / stopping criteria / streamer / sampling, the projector plugin
+surface, the dropin module aliases) with the engine running on the emulator build (lib injection is test-only)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import e2e_cases
+import kernel_cases as kc
+from vcoder_amd import checkpoint, config as vcfg, synth
+from vcoder_amd.model import language_model as lm
+from vcoder_amd.model import build_depth_projector, build_seg_projector, build_vision_projector, build_vision_tower
+
+
+@pytest.fixture(scope="module")
+def model(tmp_path_factory):
+    lib = kc.EmuBackend().lib
+    cfg = vcfg.tiny("vcoder_ds")
+    d = str(tmp_path_factory.mktemp("ckpt") / "vcoder_ds_llava-tiny")
+    checkpoint.save_checkpoint(d, cfg.to_hf_dict(), synth.synth_state_dict(cfg, 42), bf16=True)
+    cfg2 = vcfg.VCoderConfig.from_pretrained(d, "vcoder_ds_llava-tiny")
+    assert cfg2.variant == "vcoder_ds" and cfg2.hidden_size == cfg.hidden_size and cfg2.vit_num_layers == 3
+    m = lm.VCoderDSLlavaLlamaForCausalLM(cfg2, device="cuda", _lib_override=lib)
+    used = dead = 0
+    for k, v in checkpoint.iter_checkpoint_tensors(d):   # what from_pretrained does
+        if m.engine.load_tensor(k, v):
+            used += 1
+        else:
+            dead += 1
+    assert dead >= 4 + 4 + 1   # depth_mm_projector, mm2_projector, vcoder_lm_emb (+ unused CLIP layer/post_layernorm)
+    m.finalize_weights()
+    return m
+
+
+def _fx():
+    return e2e_cases.fixture_inputs("ds_img_depth_seg")
+
+
+def test_forward_and_cached_decode(model):
+    g, cfg, ids, imgs, segs, deps = _fx()
+    t = torch.from_numpy
+    out = model(input_ids=t(ids), attention_mask=torch.ones_like(t(ids)), images=t(imgs), segs=t(segs), depths=t(deps),
+                use_cache=True)
+    assert tuple(out.logits.shape) == (2, int(g["spliced_len"]), cfg.vocab_size)
+    assert np.abs(out.logits.numpy() - g["prefill_logits"]).max() < e2e_cases.TOL_VS_FP32_REF
+    pkv = out.past_key_values
+    assert pkv[-1][-1].shape[-2] == int(g["spliced_len"])   # how vcoder_ds_llava_arch.py:132 reads the past length
+    nxt = out.logits[:, -1].argmax(-1)
+    inp = model.prepare_inputs_for_generation(torch.cat([t(ids), nxt[:, None]], 1), past_key_values=pkv, images=t(imgs),
+                                              segs=t(segs), depths=t(deps), use_cache=True)
+    assert tuple(inp["input_ids"].shape) == (2, 1) and "depths" in inp
+    out2 = model(**inp)
+    assert tuple(out2.logits.shape) == (2, 1, cfg.vocab_size)
+    assert np.abs(out2.logits[:, 0].numpy() - g["step_logits"][:, 1]).max() < e2e_cases.TOL_VS_FP32_REF
+
+
+def test_generate_variants(model):
+    g, cfg, ids, imgs, segs, deps = _fx()
+    t = torch.from_numpy
+    T = ids.shape[1]
+    out = model.generate(t(ids), images=t(imgs), segs=t(segs), depths=t(deps), do_sample=False, max_new_tokens=4,
+                         use_cache=True, eos_token_id=-1)
+    assert tuple(out.shape) == (2, T + 4) and torch.equal(out[:, :T], t(ids))   # prompt keeps the placeholder ids
+    assert np.array_equal(out[:, T:].numpy(), g["greedy_ids"][:, :4])
+
+    class Stop:   # KeywordsStoppingCriteria-shaped: called with (ids incl. prompt, scores)
+        calls = 0
+
+        def __call__(self, output_ids, scores, **kw):
+            Stop.calls += 1
+            return output_ids.shape[1] - T >= 2
+
+    class Streamer:
+        got, ended = [], False
+
+        def put(self, v):
+            Streamer.got.append(v)
+
+        def end(self):
+            Streamer.ended = True
+
+    out2 = model.generate(t(ids[:1]), images=t(imgs[:1]), segs=t(segs[:1]), depths=t(deps[:1]), do_sample=False,
+                          max_new_tokens=6, stopping_criteria=[Stop()], streamer=Streamer(), eos_token_id=-1)
+    assert tuple(out2.shape) == (1, T + 2) and Stop.calls == 2 and Streamer.ended and len(Streamer.got) == 3
+    assert np.array_equal(out2[0, T:].numpy(), g["greedy_ids"][0, :2])
+    gen = torch.Generator().manual_seed(0)
+    out3 = model.generate(t(ids[:1]), images=t(imgs[:1]), segs=t(segs[:1]), depths=t(deps[:1]), do_sample=True,
+                          temperature=0.2, top_p=0.9, max_new_tokens=3, generator=gen, eos_token_id=-1)
+    assert tuple(out3.shape) == (1, T + 3) and int(out3[0, T:].min()) >= 0
+    with pytest.raises(NotImplementedError):
+        model.generate(t(ids), images=t(imgs), num_beams=2, max_new_tokens=2)
+
+
+def test_model_surface(model):
+    assert model.get_vision_tower().num_patches == 16 and model.get_vision_tower().hidden_size == 128
+    gm = model.get_model()
+    for name in ("mm_projector", "seg_mm_projector", "depth_mm_projector", "mm2_projector"):
+        assert hasattr(gm, name)
+    assert gm.mm_projector.keys() == ["0.weight", "0.bias", "2.weight", "2.bias"]
+    assert model.config.image_aspect_ratio == "pad" and model.eval() is model and model.requires_grad_(False) is model
+    assert str(model.device).startswith("cuda")
+
+
+def test_projector_factories():
+    cfg = vcfg.tiny("vcoder_ds")
+    for fn, n in ((build_vision_projector, "mm"), (build_seg_projector, "seg_mm"), (build_depth_projector, "depth_mm")):
+        p = fn(cfg)
+        assert p.depth == 2 and p.shape_of("0.weight") == (256, 128) and p.shape_of("2.weight") == (256, 256)
+    cfg.mm_projector_type = "linear"
+    assert build_vision_projector(cfg).keys() == ["weight", "bias"]
+    cfg.mm_projector_type = "identity"
+    assert build_vision_projector(cfg).depth == 0
+    cfg.mm_projector_type = "conv"
+    with pytest.raises(ValueError, match="Unknown projector type"):
+        build_vision_projector(cfg)
+    cfg.mm_vision_tower = "nonexistent/tower"
+    with pytest.raises(ValueError, match="Unknown vision tower"):
+        build_vision_tower(cfg)
+
+
+def test_dropin_module_aliases():
+    import vcoder_amd.dropin as dropin
+
+    saved = {k: v for k, v in sys.modules.items() if k.startswith("vcoder_llava")}
+    try:
+        for k in saved:
+            del sys.modules[k]
+        dropin.install()
+        from vcoder_llava.model.builder import load_pretrained_model
+        from vcoder_llava.model import VCoderDSLlavaLlamaForCausalLM
+        import vcoder_amd.model.builder as b
+
+        assert load_pretrained_model is b.load_pretrained_model and VCoderDSLlavaLlamaForCausalLM is lm.VCoderDSLlavaLlamaForCausalLM
+    finally:
+        for k in [k for k in sys.modules if k.startswith("vcoder_llava")]:
+            del sys.modules[k]
+        sys.modules.update(saved)

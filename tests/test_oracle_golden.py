@@ -1,0 +1,130 @@
+"""Pins the oracle (oracle/cpu_ref.py) against the committed outputs of the REAL reference (tests/golden/*.npz,
+produced by oracle/gen_golden.py from /root/reference) and — when the reference tree is present — against the live
+reference itself."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cpu_ref
+import ref_shim
+from vcoder_amd import config as vcfg, mm_utils, synth
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FIXTURES = ["ds_img_depth_seg", "ds_img_seg_depth", "ds_img_seg", "ds_img_only", "ds_zero_depth", "ds_img_text_seg",
+            "vc_img_seg", "vc_img_text_seg", "llava_img"]
+_models = {}
+
+
+def oracle_for(variant):
+    if variant not in _models:
+        cfg = vcfg.tiny(variant)
+        _models[variant] = cpu_ref.OracleModel(cfg, synth.synth_state_dict(cfg, 42))
+    return _models[variant]
+
+
+def _inputs(g, cfg):
+    B = g["input_ids"].shape[0]
+    imgs, segs, deps = synth.synth_batch(B, cfg.vit_image_size)
+    if bool(g["zero_depth"]):
+        deps = np.zeros_like(deps)
+    t = torch.from_numpy
+    return t(imgs), (t(segs) if bool(g["use_seg"]) else None), (t(deps) if bool(g["use_depth"]) else None)
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_oracle_matches_reference_fixture(name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    om = oracle_for(str(g["variant"]))
+    imgs, segs, deps = _inputs(g, om.cfg)
+    ids = g["input_ids"].tolist()
+    emb, _ = om.prepare_inputs(ids, imgs, segs, deps)
+    assert emb.shape[1] == int(g["spliced_len"])
+    assert np.abs(emb.numpy().sum(-1) - g["embeds_rowsum"]).max() < 1e-4
+    assert np.abs(emb.numpy()[:, ::7, ::16] - g["embeds_sample"]).max() < 1e-6
+    full, _ = om.forward(ids, imgs, segs, deps)
+    assert np.abs(full.numpy() - g["prefill_logits"]).max() < 1e-4      # fp32 oracle vs fp32 reference
+    got, lg = om.generate_greedy(ids, imgs, segs, deps, max_new_tokens=g["greedy_ids"].shape[1], return_logits=True)
+    assert np.array_equal(got.numpy(), g["greedy_ids"])                   # bit-exact ids
+    assert np.abs(lg.numpy() - g["step_logits"]).max() < 1e-4           # cached decode == reference's no-cache loop
+
+
+def test_per_op_vectors():
+    g = np.load(os.path.join(GOLD, "per_op.npz"))
+    t = torch.from_numpy
+    assert np.allclose(cpu_ref.layer_norm(t(g["ln_x"]), t(g["ln_w"]), t(g["ln_b"]), 1e-5).numpy(), g["ln_y"], atol=2e-6)
+    assert np.allclose(cpu_ref.rms_norm(t(g["rms_x"]), t(g["rms_w"]), 1e-5).numpy(), g["rms_y"], atol=2e-6)
+    assert np.allclose(cpu_ref.quick_gelu(t(g["act_x"])).numpy(), g["quick_gelu_y"], atol=2e-6)
+    assert np.allclose(torch.nn.functional.gelu(t(g["act_x"])).numpy(), g["gelu_y"], atol=2e-6)
+    cos, sin = cpu_ref.rope_cos_sin(t(g["rope_pos"])[0], 128, 10000.0)
+    assert np.allclose(cpu_ref.apply_rope(t(g["rope_q"]), cos, sin).numpy(), g["rope_qe"], atol=2e-6)
+    assert np.allclose(cpu_ref.apply_rope(t(g["rope_k"]), cos, sin).numpy(), g["rope_ke"], atol=2e-6)
+    assert np.allclose(torch.softmax(t(g["softmax_x"]), -1).numpy(), g["softmax_y"], atol=1e-7)
+
+
+def test_quirks_in_oracle():
+    om = oracle_for("vcoder_ds")
+    g = np.load(os.path.join(GOLD, "ds_img_depth_seg.npz"))
+    imgs, segs, deps = _inputs(g, om.cfg)
+    ids = g["input_ids"].tolist()
+    a, _ = om.forward(ids, imgs, segs, deps)
+    b, _ = om.forward(ids, imgs, segs, deps * 0.5 + 1.0)
+    assert torch.equal(a, b)                                               # quirk 4: depth pixels are dead
+    ragged = [list(r) for r in ids]
+    ragged[1] = [5 if t == synth.SEG_TOKEN_INDEX else t for t in ragged[1]]
+    with pytest.raises(UnboundLocalError):
+        om.prepare_inputs(ragged, imgs, segs, deps, attention_mask_given=True)  # quirk 6
+    emb, _ = om.prepare_inputs(ragged, imgs, segs, deps)
+    assert emb.shape[1] == int(g["spliced_len"]) + 1 and not emb[0, -1].any()
+    vc = oracle_for("vcoder")
+    g2 = np.load(os.path.join(GOLD, "vc_img_seg.npz"))
+    bad = [[7 if t == synth.SEG_TOKEN_INDEX else t for t in r] for r in g2["input_ids"].tolist()]
+    i2, s2, _ = _inputs(g2, vc.cfg)
+    with pytest.raises(IndexError):
+        vc.prepare_inputs(bad, i2, s2)                                     # quirk 5
+
+
+def test_tokenizer_placeholder_orders():
+    class Fake:
+        bos_token_id = 1
+
+        def __call__(self, text):
+            class R:
+                pass
+            r = R()
+            r.input_ids = [1] + [3 + (ord(c) % 50) for c in text]
+            return r
+
+    with open(os.path.join(GOLD, "tokenizer_orders.json")) as f:
+        g = json.load(f)
+    tk = Fake()
+    assert mm_utils.tokenizer_depth_seg_token("ab <depth>\n<seg>\n<image>\ncd", tk) == g["ds"]
+    assert mm_utils.tokenizer_depth_seg_token("ab <seg>\n<image>\ncd", tk) == g["seg"]
+    assert mm_utils.tokenizer_image_token("ab <image>\ncd", tk) == g["img"]
+    assert [t for t in g["ds"] if t < 0] == [-200, -400, -300]
+
+
+@pytest.mark.reference
+@pytest.mark.skipif(not ref_shim.reference_available(), reason="needs /root/reference (build container only)")
+def test_reference_tokenizers_live():
+    ref_shim.load_reference()
+    from vcoder_llava import mm_utils as ref_mm
+
+    class Fake:
+        bos_token_id = 1
+
+        def __call__(self, text):
+            class R:
+                pass
+            r = R()
+            r.input_ids = [1] + [3 + (ord(c) % 50) for c in text]
+            return r
+
+    tk = Fake()
+    for prompt in ("A chat. USER: <depth>\n<seg>\n<image>\nWhat is there? ASSISTANT:", "USER: <seg>\n<image>\nhi",
+                   "USER: <image>\ncount"):
+        fn_r = ref_mm.tokenizer_depth_seg_token if "<seg>" in prompt else ref_mm.tokenizer_image_token
+        fn_o = mm_utils.tokenizer_depth_seg_token if "<seg>" in prompt else mm_utils.tokenizer_image_token
+        assert list(fn_r(prompt, tk)) == list(fn_o(prompt, tk))

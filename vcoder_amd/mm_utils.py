@@ -1,0 +1,95 @@
+"""Prompt -> ids glue and image padding (the step right before the hot path).
+
+Behavioural counterparts of vcoder_llava/mm_utils.py:14-151: the placeholder id ORDER these helpers emit
+([IMG, DEPTH, SEG] for a '<depth>\\n<seg>\\n<image>' prompt, [IMG, SEG] for '<seg>\\n<image>') is part of the
+parity contract of the splice (tests/golden/tokenizer_orders.json pins it against the reference)."""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+from .constants import DEPTH_TOKEN_INDEX, IMAGE_TOKEN_INDEX, SEG_TOKEN_INDEX
+
+
+def _chunk_ids(prompt: str, tokenizer, marker: str) -> List[List[int]]:
+    return [list(tokenizer(piece).input_ids) for piece in prompt.split(marker)]
+
+
+def _join_with(chunks: List[List[int]], sep: Sequence[int], tokenizer, keep_sep_prefix_only: bool = False) -> List[int]:
+    """Concatenate tokenised chunks with `sep` ids in between.  Every chunk starts with BOS when the tokenizer adds
+    one; it is kept once at the very beginning and stripped elsewhere."""
+    bos = getattr(tokenizer, "bos_token_id", None)
+    has_bos = bool(chunks) and bool(chunks[0]) and chunks[0][0] == bos
+    out: List[int] = [chunks[0][0]] if has_bos else []
+    skip = 1 if has_bos else 0
+    for i, ch in enumerate(chunks):
+        if i > 0:
+            out.extend(sep)
+        out.extend(ch[skip:])
+    return out
+
+
+def tokenizer_image_token(prompt, tokenizer, image_token_index=IMAGE_TOKEN_INDEX, return_tensors=None):
+    ids = _join_with(_chunk_ids(prompt, tokenizer, "<image>"), [image_token_index], tokenizer)
+    return _ret(ids, return_tensors)
+
+
+def tokenizer_seg_token(prompt, tokenizer, image_token_index=IMAGE_TOKEN_INDEX, seg_token_index=SEG_TOKEN_INDEX,
+                        return_tensors=None):
+    # the reference inserts [SEG, IMG]*(offset+1) and then drops the trailing element of that separator
+    # (mm_utils.py:78-82), which nets out to the pair order [IMG, SEG] observed in tests/golden/tokenizer_orders.json
+    ids = _join_with(_chunk_ids(prompt, tokenizer, "<seg>\n<image>"), [image_token_index, seg_token_index], tokenizer)
+    return _ret(ids, return_tensors)
+
+
+def _tokenizer_depth_token(prompt, tokenizer, image_token_index=IMAGE_TOKEN_INDEX, seg_token_index=SEG_TOKEN_INDEX,
+                           depth_token_index=DEPTH_TOKEN_INDEX, return_tensors=None):
+    ids = _join_with(_chunk_ids(prompt, tokenizer, "<depth>\n<seg>\n<image>"),
+                     [image_token_index, depth_token_index, seg_token_index], tokenizer)
+    return _ret(ids, return_tensors)
+
+
+def tokenizer_depth_seg_token(prompt, tokenizer, image_token_index=IMAGE_TOKEN_INDEX, seg_token_index=SEG_TOKEN_INDEX,
+                              depth_token_index=DEPTH_TOKEN_INDEX, return_tensors=None):
+    if "<depth>" in prompt:
+        return _tokenizer_depth_token(prompt, tokenizer, image_token_index, seg_token_index, depth_token_index,
+                                      return_tensors)
+    return tokenizer_seg_token(prompt, tokenizer, image_token_index, seg_token_index, return_tensors)
+
+
+def _ret(ids, return_tensors):
+    if return_tensors is None:
+        return ids
+    if return_tensors == "pt":
+        import torch
+
+        return torch.tensor(ids, dtype=torch.long)
+    raise ValueError(f"Unsupported tensor type: {return_tensors}")
+
+
+def expand2square(pil_img, background_color):
+    from PIL import Image
+
+    w, h = pil_img.size
+    if w == h:
+        return pil_img
+    side = max(w, h)
+    canvas = Image.new(pil_img.mode, (side, side), background_color)
+    canvas.paste(pil_img, ((side - w) // 2, (side - h) // 2))
+    return canvas
+
+
+def process_images(images, image_processor, model_cfg):
+    import torch
+
+    if getattr(model_cfg, "image_aspect_ratio", None) != "pad":
+        return image_processor(images, return_tensors="pt")["pixel_values"]
+    fill = tuple(int(x * 255) for x in image_processor.image_mean)
+    out = [image_processor.preprocess(expand2square(im, fill), return_tensors="pt")["pixel_values"][0] for im in images]
+    if all(x.shape == out[0].shape for x in out):
+        out = torch.stack(out, dim=0)
+    return out
+
+
+def get_model_name_from_path(model_path: str) -> str:
+    parts = model_path.strip("/").split("/")
+    return parts[-2] + "_" + parts[-1] if parts[-1].startswith("checkpoint-") else parts[-1]

@@ -1,0 +1,56 @@
+"""load_pretrained_model — drop-in for vcoder_llava/model/builder.py:25-154 (inference paths).
+
+Same signature and 6-tuple; same name-substring dispatch ('vcoder_ds_llava' / 'vcoder_llava' / else llava,
+builder.py:93-108), same processor aliasing (:145-151) and context_len rule (:133-136).  8/4-bit bitsandbytes and
+LoRA-merge paths are not part of the MI355X hot path and raise."""
+from __future__ import annotations
+
+from .language_model import LlavaLlamaForCausalLM, VCoderDSLlavaLlamaForCausalLM, VCoderLlavaLlamaForCausalLM
+
+
+def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, load_4bit=False, device_map="auto",
+                          device="cuda"):
+    if load_8bit or load_4bit:
+        raise NotImplementedError("bitsandbytes 8/4-bit loading is a CUDA-only path of the reference; the MI355X build "
+                                  "runs bf16 weights")
+    name = model_name.lower()
+    if "llava" not in name:
+        raise ValueError(f"'{model_name}': only LLaVA-family checkpoints (llava / vcoder_llava / vcoder_ds_llava) are "
+                         "on the hot path")
+    if "lora" in name or model_base is not None:
+        raise NotImplementedError("LoRA / projector-only checkpoints: merge with the reference's "
+                                  "scripts/merge_lora_weights.py first")
+    tokenizer = _load_tokenizer(model_path)
+    if "vcoder_ds_llava" in name:
+        cls = VCoderDSLlavaLlamaForCausalLM
+    elif "vcoder_llava" in name:
+        cls = VCoderLlavaLlamaForCausalLM
+    else:
+        cls = LlavaLlamaForCausalLM
+    model = cls.from_pretrained(model_path, low_cpu_mem_usage=True, device=device)
+    context_len = model.config.max_sequence_length if getattr(model.config, "max_sequence_length", None) else 2048
+    vision_tower = model.get_vision_tower()
+    if not vision_tower.is_loaded or vision_tower.image_processor is None:
+        vision_tower.load_model()
+    image_processor = vision_tower.image_processor
+    seg_image_processor = image_processor if "vcoder" in name else None
+    depth_image_processor = image_processor if "ds" in name else None
+    model.requires_grad_(False)
+    return tokenizer, model, image_processor, seg_image_processor, depth_image_processor, context_len
+
+
+def _load_tokenizer(model_path):
+    try:
+        from transformers import AutoTokenizer
+
+        return AutoTokenizer.from_pretrained(model_path, use_fast=False)
+    except Exception as e:  # tokenizer files are not part of the tensor hot path; surface a clear error lazily
+        return _MissingTokenizer(model_path, e)
+
+
+class _MissingTokenizer:
+    def __init__(self, path, err):
+        self._path, self._err = path, err
+
+    def __getattr__(self, name):
+        raise RuntimeError(f"no tokenizer could be loaded from {self._path}: {self._err}")

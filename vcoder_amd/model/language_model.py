@@ -1,0 +1,340 @@
+"""The reference's model API on top of the HIP engine.
+
+Mirrors (same names, arguments, return conventions and error behaviour):
+  VCoderDSLlavaLlamaForCausalLM   vcoder_llava/model/language_model/vcoder_ds_llava_llama.py:41-142
+  VCoderLlavaLlamaForCausalLM     vcoder_llava/model/language_model/vcoder_llava_llama.py:40-139
+  LlavaLlamaForCausalLM           vcoder_llava/model/language_model/llava_llama.py
+and the parts of HF `GenerationMixin.generate` the reference's callers use (SURVEY.md Appendix C;
+callers: serve/cli.py:122-132, serve/chat.py:141-151, eval/model_seg_loader.py:129-139).
+No torch.nn / HF Transformers module is involved: forward/generate marshal to libvcoder_hip.so.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import List, Optional
+
+import numpy as np
+
+from ..config import VCoderConfig
+from ..engine import HipEngine
+from .projector import build_depth_projector, build_seg_projector, build_vision_projector
+from .vision_tower import build_vision_tower
+
+
+class CausalLMOutputWithPast(dict):
+    """Attribute + mapping access like transformers.modeling_outputs.CausalLMOutputWithPast."""
+
+    def __init__(self, loss=None, logits=None, past_key_values=None, hidden_states=None, attentions=None):
+        super().__init__(loss=loss, logits=logits, past_key_values=past_key_values, hidden_states=hidden_states,
+                         attentions=attentions)
+        self.__dict__ = self
+
+    def __getitem__(self, k):
+        if isinstance(k, int):
+            return [v for v in (self.loss, self.logits, self.past_key_values) if v is not None][k]
+        return dict.__getitem__(self, k)
+
+
+class KVCacheHandle:
+    """Opaque `past_key_values`: the cache lives in the engine (K key-major, V transposed, per layer); this handle
+    only proves which prefill it belongs to.  `[-1][-1].shape[-2]` (how vcoder_ds_llava_arch.py:132 reads the past
+    length) is supported."""
+
+    def __init__(self, model, generation: int, length: int, batch: int):
+        self._model, self.generation, self.length, self.batch = model, generation, length, batch
+
+    def get_seq_length(self) -> int:
+        return self.length
+
+    def __bool__(self):
+        return True
+
+    def __getitem__(self, i):
+        shape = (self.batch, self._model.config.num_attention_heads, self.length, self._model.config.head_dim)
+        t = SimpleNamespace(shape=shape)
+        return (t, t)
+
+    def __len__(self):
+        return self._model.config.num_hidden_layers
+
+
+class _InnerModel:
+    """What `get_model()` returns: the plugin modules of VCoder[DS]LlavaMetaModel (vcoder_ds_llava_arch.py:30-49)."""
+
+    def __init__(self, config: VCoderConfig):
+        self.config = config
+        if hasattr(config, "mm_vision_tower"):
+            self.vision_tower = build_vision_tower(config, delay_load=True)
+            self.mm_projector = build_vision_projector(config)
+        if config.variant != "llava":
+            self.seg_mm_projector = build_seg_projector(config)
+            if config.use_mm2_proj:
+                self.mm2_projector = build_vision_projector(config)      # dead at inference (quirk 2)
+        if config.variant == "vcoder_ds":
+            self.depth_mm_projector = build_depth_projector(config)      # dead at inference (quirk 1)
+        self.embed_tokens = SimpleNamespace(num_embeddings=config.vocab_size, embedding_dim=config.hidden_size)
+
+    def get_vision_tower(self):
+        return getattr(self, "vision_tower", None)
+
+
+class _HipCausalLMBase:
+    variant = "llava"
+    model_type = "llava"
+
+    def __init__(self, config: VCoderConfig, device="cuda", _lib_override=None):
+        if config.variant != self.variant:
+            config.variant = self.variant
+        self.config = config
+        self.model = _InnerModel(config)
+        self._device_str = device if isinstance(device, str) else str(device)
+        idx = 0
+        if ":" in self._device_str:
+            idx = int(self._device_str.split(":")[1])
+        self.engine = HipEngine(config, device_index=idx, lib=_lib_override)
+        self._generation = 0
+        self.training = False
+        self.generation_config = SimpleNamespace(pad_token_id=config.pad_token_id, eos_token_id=config.eos_token_id,
+                                                 bos_token_id=config.bos_token_id)
+
+    # ---- nn.Module-ish surface the reference's callers touch ------------------------------------------
+    @property
+    def device(self):
+        import torch
+
+        return torch.device(self._device_str if ":" in self._device_str else self._device_str + ":0")
+
+    @property
+    def dtype(self):
+        import torch
+
+        return torch.bfloat16
+
+    def get_model(self):
+        return self.model
+
+    def get_vision_tower(self):
+        return self.model.get_vision_tower()
+
+    def eval(self):
+        return self
+
+    def requires_grad_(self, flag: bool = False):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def half(self):
+        return self
+
+    def cuda(self, *a):
+        return self
+
+    def parameters(self):
+        return iter(())
+
+    # ---- weights ----------------------------------------------------------------------------------------
+    def load_state_dict(self, sd, strict: bool = True):
+        used, dead = self.engine.load_state_dict(sd)
+        return SimpleNamespace(missing_keys=[], unexpected_keys=[], used=used, dead=dead)
+
+    def finalize_weights(self):
+        self.engine.finalize()
+        tower = self.get_vision_tower()
+        if tower is not None:
+            tower.is_loaded = True
+        return self
+
+    @classmethod
+    def from_pretrained(cls, model_path: str, low_cpu_mem_usage=True, device="cuda", config=None, **kwargs):
+        """Loads config.json + weight shards; the CLIP tower comes from the checkpoint if present, else from the
+        local directory `config.mm_vision_tower` (the reference downloads it: clip_encoder.py:22-27 — there is no
+        network here, so a hub name that is not a local directory is an error)."""
+        import os
+
+        from .. import checkpoint
+
+        cfg = config if config is not None else VCoderConfig.from_pretrained(model_path, os.path.basename(model_path))
+        model = cls(cfg, device=device)
+        saw_tower = False
+        for k, v in checkpoint.iter_checkpoint_tensors(model_path):
+            saw_tower |= "vision_tower" in k
+            model.engine.load_tensor(k, v)
+        if not saw_tower:
+            model.get_vision_tower().load_model(engine=model.engine)
+        model.finalize_weights()
+        return model
+
+    # ---- forward (vcoder_ds_llava_llama.py:57-118) ----------------------------------------------------------
+    def forward(self, input_ids=None, attention_mask=None, past_key_values=None, inputs_embeds=None, labels=None,
+                use_cache=None, output_attentions=None, output_hidden_states=None, images=None, segs=None, depths=None,
+                return_dict=None):
+        import torch
+
+        if labels is not None:
+            raise NotImplementedError("training loss is outside the inference hot path (SURVEY.md §8: train/* out of scope)")
+        if inputs_embeds is not None:
+            raise NotImplementedError("inputs_embeds entry is not used by any inference caller of the reference")
+        if output_attentions or output_hidden_states:
+            raise NotImplementedError("attention maps / hidden states are not materialised by the fused kernels")
+        ids = input_ids
+        B = ids.shape[0]
+        if past_key_values is not None and ids.shape[1] == 1:
+            # cached decode step: the input_ids.shape[1]==1 fast path (vcoder_ds_llava_arch.py:130-133)
+            if not isinstance(past_key_values, KVCacheHandle) or past_key_values.generation != self._generation:
+                raise RuntimeError("past_key_values does not belong to the engine's current KV cache")
+            tok = ids.reshape(-1).detach().cpu().numpy() if hasattr(ids, "detach") else np.asarray(ids).reshape(-1)
+            lg, _ = self.engine.decode_step(tok)
+            past_key_values.length += 1
+            logits = torch.from_numpy(lg).unsqueeze(1)
+            pkv = past_key_values
+        else:
+            if past_key_values is not None:
+                raise NotImplementedError("multi-token continuation of a cached sequence is not on the reference's path")
+            if images is None:
+                raise ValueError("images is required (text-only forward is not part of the VCoder hot path)")
+            _, full, S = self.engine.prefill(ids, images, segs if self.variant != "llava" else None,
+                                             depths if self.variant == "vcoder_ds" else None,
+                                             has_attention_mask=attention_mask is not None, all_logits=True)
+            self._generation += 1
+            logits = torch.from_numpy(full)
+            pkv = KVCacheHandle(self, self._generation, S, B)
+        if hasattr(ids, "device") and getattr(ids, "is_cuda", False):
+            logits = logits.to(ids.device)
+        out = CausalLMOutputWithPast(loss=None, logits=logits, past_key_values=pkv if use_cache is not False else None)
+        if return_dict is False:
+            return (out.logits,) + ((out.past_key_values,) if out.past_key_values is not None else ())
+        return out
+
+    __call__ = forward
+
+    def prepare_inputs_for_generation(self, input_ids, past_key_values=None, attention_mask=None, inputs_embeds=None,
+                                      **kwargs):
+        """vcoder_ds_llava_llama.py:120-142"""
+        if past_key_values:
+            input_ids = input_ids[:, -1:]
+        model_inputs = {"inputs_embeds": inputs_embeds} if (inputs_embeds is not None and past_key_values is None) \
+            else {"input_ids": input_ids}
+        model_inputs.update({"past_key_values": past_key_values, "use_cache": kwargs.get("use_cache"),
+                             "attention_mask": attention_mask, "images": kwargs.get("images", None)})
+        if self.variant != "llava":
+            model_inputs["segs"] = kwargs.get("segs", None)
+        if self.variant == "vcoder_ds":
+            model_inputs["depths"] = kwargs.get("depths", None)
+        return model_inputs
+
+    # ---- generate (HF GenerationMixin subset) ---------------------------------------
+    def generate(self, input_ids=None, inputs=None, images=None, segs=None, depths=None, do_sample: bool = False,
+                 temperature: float = 1.0, top_p: Optional[float] = None, num_beams: int = 1,
+                 max_new_tokens: Optional[int] = None, max_length: Optional[int] = None, streamer=None,
+                 use_cache: bool = True, stopping_criteria=None, eos_token_id=None, pad_token_id=None,
+                 attention_mask=None, generator=None, **kwargs):
+        """Returns cat(input_ids, new_ids) [B, T+n] int64 — the prompt part keeps its negative placeholder ids,
+        callers slice `[:, T:]` (serve/cli.py:135).  Greedy without streamer/stopping criteria runs fully on the
+        device (hipGraph-replayed steps, device-side argmax/EOS); sampling, streamers and stopping criteria use the
+        per-token decode_step loop (one host sync per token, exactly like the reference's HF loop)."""
+        import torch
+
+        if input_ids is None:
+            input_ids = inputs
+        if num_beams != 1:
+            raise NotImplementedError("beam search is not used by the reference's VCoder callers (num_beams=1)")
+        if temperature is not None and float(temperature) <= 0.0:
+            do_sample = False
+        T = input_ids.shape[1]
+        B = input_ids.shape[0]
+        if max_new_tokens is None:
+            max_new_tokens = (max_length - T) if max_length is not None else 20
+        eos = self.config.eos_token_id if eos_token_id is None else eos_token_id
+        pad = pad_token_id if pad_token_id is not None else (self.config.pad_token_id if self.config.pad_token_id is not None else eos)
+        segs = segs if self.variant != "llava" else None
+        depths = depths if self.variant == "vcoder_ds" else None
+        ids_cpu = input_ids.detach().cpu() if hasattr(input_ids, "detach") else torch.as_tensor(np.asarray(input_ids))
+        simple = not do_sample and streamer is None and not stopping_criteria
+        if streamer is not None:
+            streamer.put(ids_cpu)
+        if simple:
+            new = self.engine.generate_greedy(ids_cpu.numpy(), images, segs, depths, max_new_tokens=max_new_tokens,
+                                              eos_token_id=eos, pad_token_id=pad)
+            self._generation += 1
+            out = torch.cat([ids_cpu, torch.from_numpy(new.astype(np.int64))], dim=1)
+        else:
+            last, _, S = self.engine.prefill(ids_cpu.numpy(), images, segs, depths, has_attention_mask=True)
+            self._generation += 1
+            logits = torch.from_numpy(last)
+            unfinished = torch.ones(B, dtype=torch.long)
+            cur = ids_cpu
+            for step in range(max_new_tokens):
+                scores = logits.float()
+                if do_sample:
+                    scores = scores / float(temperature)
+                    if top_p is not None and top_p < 1.0:
+                        scores = _top_p_filter(scores, float(top_p))
+                    probs = torch.softmax(scores, dim=-1)
+                    nxt = torch.multinomial(probs, 1, generator=generator).squeeze(1)
+                else:
+                    nxt = torch.argmax(scores, dim=-1)
+                if eos is not None:
+                    nxt = nxt * unfinished + pad * (1 - unfinished)
+                cur = torch.cat([cur, nxt[:, None]], dim=1)
+                if streamer is not None:
+                    streamer.put(nxt.cpu())
+                if eos is not None:
+                    unfinished = unfinished * (nxt != eos).long()
+                stop = bool(unfinished.max() == 0) if eos is not None else False
+                if stopping_criteria:
+                    for crit in stopping_criteria:
+                        r = crit(cur, scores)
+                        stop = stop or bool(r.all() if hasattr(r, "all") else r)
+                if stop or step + 1 == max_new_tokens:
+                    break
+                lg, _ = self.engine.decode_step(nxt.numpy().astype(np.int32))
+                logits = torch.from_numpy(lg)
+            out = cur
+            if streamer is not None:
+                streamer.end()
+        if hasattr(input_ids, "device"):
+            out = out.to(input_ids.device)
+        return out
+
+
+def _top_p_filter(scores, top_p: float):
+    import torch
+
+    s, idx = torch.sort(scores, descending=False, dim=-1)
+    cum = s.softmax(-1).cumsum(-1)
+    remove = cum <= (1 - top_p)
+    remove[..., -1:] = False
+    mask = remove.scatter(1, idx, remove)
+    return scores.masked_fill(mask, float("-inf"))
+
+
+class LlavaLlamaForCausalLM(_HipCausalLMBase):
+    variant, model_type = "llava", "llava"
+
+
+class VCoderLlavaLlamaForCausalLM(_HipCausalLMBase):
+    variant, model_type = "vcoder", "vcoder_llava"
+
+
+class VCoderDSLlavaLlamaForCausalLM(_HipCausalLMBase):
+    variant, model_type = "vcoder_ds", "vcoder_ds_llava"
+
+
+class LlavaConfig(VCoderConfig):
+    def __init__(self, **kw):
+        kw.setdefault("variant", "llava")
+        super().__init__(**kw)
+
+
+class VCoderLlavaConfig(VCoderConfig):
+    def __init__(self, **kw):
+        kw.setdefault("variant", "vcoder")
+        super().__init__(**kw)
+
+
+class VCoderDSLlavaConfig(VCoderConfig):
+    def __init__(self, **kw):
+        kw.setdefault("variant", "vcoder_ds")
+        super().__init__(**kw)
