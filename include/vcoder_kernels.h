@@ -20,6 +20,10 @@ void vck_gemm(const uint16_t* A, const uint16_t* W, const float* bias, void* out
               int ldo, int epi, void* stream);
 /* decode-time skinny GEMM (M<=16) over MFMA-fragment-packed weights.  epi: 0 bf16, 1 fp32, 2 fp32 residual, 3 SwiGLU */
 void vck_gemv(const uint16_t* X, const uint16_t* Wp, void* out, int M, int N, int K, int ldo, int epi, void* stream);
+/* same with the RMSNorm of [HF] llama :53-70 fused as a prologue over the fp32 residual rows Xf (rstd from `npart`
+ * deterministic sum-of-squares partials) and, for epi 2, the partials of the updated rows published to ssq_out */
+void vck_gemv_norm(const float* Xf, const float* norm_w, const float* ssq_in, int npart, float eps, const uint16_t* X,
+                   const uint16_t* Wp, void* out, float* ssq_out, int M, int N, int K, int ldo, int epi, void* stream);
 void vck_pack_weight(const uint16_t* W, uint16_t* Wp, int N, int K, void* stream);
 void vck_interleave_rows(const uint16_t* gate, const uint16_t* up, uint16_t* out, int F, int K, void* stream);
 /* nn.LayerNorm ([HF] clip :370,379) and LlamaRMSNorm ([HF] llama :53-70); fp32 in, bf16 out */
@@ -39,12 +43,21 @@ void vck_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, uin
                    int q_stride, int kv_stride, int causal, float scale, void* stream);
 void vck_attention_decode(const uint16_t* q, const uint16_t* k, const uint16_t* vt, uint16_t* out, int B, int H, int hd,
                           int kv_stride, const int* ctx_len_dev, float scale, void* stream);
+/* decode step, one launch per layer: RoPE of the new q/k + KV append + attention over the cache */
+void vck_attention_decode_fused(const uint16_t* qkv, uint16_t* k, uint16_t* vt, uint16_t* out, int B, int H, int hd,
+                                int kv_stride, const int* pos_dev, const float* rope_cos, const float* rope_sin, float scale,
+                                void* stream);
 /* embedding gather + feature splice (vcoder_ds_llava_arch.py:173-276,305) */
 void vck_splice(const int* row_src, int nrows, const uint16_t* embed, const uint16_t* feats, float* x, int D, void* stream);
 void vck_embed_tokens(const int* tok, const uint16_t* embed, float* x, int B, int D, void* stream);
 /* greedy select with EOS/pad bookkeeping ([HF] generation/utils.py:2894,2925-2929) */
 void vck_greedy(const float* logits, int* next_tok, int* out_ids, int* finished, int* step_dev, int B, int V, int max_new,
                 int eos_id, int pad_id, void* stream);
+/* greedy select of all rows + embedding of the selected tokens (+ RMSNorm partials) + step/pos/ctx advance */
+void vck_greedy_embed(const float* logits, int* next_tok, int* out_ids, int* finished, int* step_dev, int B, int V,
+                      int max_new, int eos_id, int pad_id, const uint16_t* embed, float* x, float* ssq, int D, int npart,
+                      int* pos_dev, int* ctx_dev, int advance, void* stream);
+void vck_embed_tokens_ssq(const int* tok, const uint16_t* embed, float* x, float* ssq, int B, int D, int npart, void* stream);
 void vck_advance(int* step_dev, int* pos_dev, int* ctx_dev, void* stream);
 /* deterministic synthetic tensors (vcoder_amd/synth.py) and dtype converts */
 void vck_synth_bf16(uint16_t* out, uint64_t n, uint32_t tseed, float offset, float halfwidth, void* stream);

@@ -400,3 +400,110 @@ def check_synth(be, name="model.layers.3.mlp.up_proj.weight", n=5000):
     be.sync()
     assert np.array_equal(be.host_f32(ob), synth.synth_tensor(name, (n,), 42, 0.0, hw))
     assert np.array_equal(be.host_f32(of), synth.synth_tensor(name, (n,), 42, 1.0, 0.1))
+
+
+# ---- fused decode-step kernels ------------------------------------------------------------------------------------
+def check_gemv_norm_chain(be, M, D, N, seed=0):
+    """embed_tokens_ssq -> [RMSNorm+GEMV] -> RESID GEMV (publishes partials) -> [RMSNorm+GEMV]: the decode-step chain."""
+    rng = np.random.RandomState(seed)
+    V = 64
+    npart = (D // 16 + 15) // 16 * 16
+    embed = bf16_round(rng.randn(V, D))
+    tok = rng.randint(0, V, size=M).astype(np.int32)
+    w1 = (rng.rand(D) + 0.5).astype(np.float32)
+    W1 = bf16_round(rng.randn(N, D) * 0.05)
+    Wo = bf16_round(rng.randn(D, N) * 0.05)
+    x = be.zeros((16, D), "f32")
+    ssq = be.f32(rng.randn(16, npart))          # garbage: the kernels must fully overwrite the valid rows
+    _call(be, "vck_embed_tokens_ssq", be.i32(tok), be.bf16(embed), x, ssq, M, D, npart)
+    assert np.array_equal(be.host_f32(x)[:M], embed[tok])
+    W1p, Wop = be.zeros((N * D,), "bf16"), be.zeros((N * D,), "bf16")
+    _call(be, "vck_pack_weight", be.bf16(W1), W1p, N, D)
+    _call(be, "vck_pack_weight", be.bf16(Wo), Wop, D, N)
+    h = be.zeros((M, N), "bf16")
+    lib_args = lambda *a: a
+    be.lib.vck_gemv_norm(be.ptr(x), be.ptr(be.f32(w1)), be.ptr(ssq), ctypes.c_int(npart), ctypes.c_float(1e-5), None,
+                         be.ptr(W1p), be.ptr(h), None, M, N, D, N, 0, None)
+    be.sync()
+    xn = bf16_round(cpu_ref.rms_norm(torch.from_numpy(embed[tok]), torch.from_numpy(w1), 1e-5).numpy())
+    ref_h = xn.astype(np.float64) @ W1.T.astype(np.float64)
+    e = rel_err(be.host_f32(h), ref_h)
+    assert e < 2 ** -7, f"norm+gemv rel err {e}"
+    # RESID gemv: x += h @ Wo^T, partials of the new rows
+    hb = be.host_f32(h)
+    be.lib.vck_gemv_norm(None, None, None, ctypes.c_int(npart), ctypes.c_float(1e-5), be.ptr(h), be.ptr(Wop), be.ptr(x),
+                         be.ptr(ssq), M, D, N, D, 2, None)
+    be.sync()
+    x_new = embed[tok].astype(np.float64) + hb.astype(np.float64) @ Wo.T.astype(np.float64)
+    assert rel_err(be.host_f32(x)[:M], x_new) < 1e-5
+    got_ss = be.host_f32(ssq)[:M, : D // 16].sum(-1)
+    assert np.abs(got_ss / (x_new ** 2).sum(-1) - 1).max() < 1e-5
+    # second fused norm consumes the published partials
+    y = be.zeros((M, N), "f32")
+    be.lib.vck_gemv_norm(be.ptr(x), be.ptr(be.f32(w1)), be.ptr(ssq), ctypes.c_int(npart), ctypes.c_float(1e-5), None,
+                         be.ptr(W1p), be.ptr(y), None, M, N, D, N, 1, None)
+    be.sync()
+    xn2 = bf16_round(cpu_ref.rms_norm(torch.from_numpy(be.host_f32(x)[:M]), torch.from_numpy(w1), 1e-5).numpy())
+    e = rel_err(be.host_f32(y), xn2.astype(np.float64) @ W1.T.astype(np.float64))
+    assert e < 3e-3, f"second norm+gemv rel err {e}"   # bf16 rounding-boundary flips of xn only
+
+
+def check_attention_decode_fused(be, B, H, hd, pos, seed=0):
+    rng = np.random.RandomState(seed)
+    D = H * hd
+    S = (pos + 1 + 63) // 64 * 64 + 64
+    qkv = bf16_round(rng.randn(B, 3 * D))
+    k_old = bf16_round(rng.randn(B, H, pos, hd))
+    v_old = bf16_round(rng.randn(B, H, pos, hd))
+    kp, vtp = rng.randn(B, H, S, hd).astype(np.float32), rng.randn(B, H, hd, S).astype(np.float32)  # stale garbage
+    kp[:, :, :pos], vtp[:, :, :, :pos] = k_old, v_old.transpose(0, 1, 3, 2)
+    kd, vd = be.bf16(kp), be.bf16(vtp)
+    out = be.zeros((B, D), "bf16")
+    cos, sin = rope_tables(S, hd)
+    scale = 1.0 / math.sqrt(hd)
+    be.lib.vck_attention_decode_fused(be.ptr(be.bf16(qkv)), be.ptr(kd), be.ptr(vd), be.ptr(out), B, H, hd, S,
+                                      be.ptr(be.i32([pos])), be.ptr(be.f32(cos)), be.ptr(be.f32(sin)),
+                                      ctypes.c_float(scale), None)
+    be.sync()
+    rq, rk, rv = _split_ref(qkv, B, 1, H, hd, True, pos0=pos)     # roped+rounded q,k and raw v of the new token
+    gk, gv = be.host_f32(kd), be.host_f32(vd)
+    assert np.abs(gk[:, :, pos] - rk[:, :, 0]).max() <= 2 ** -7 * np.abs(rk).max()
+    assert np.array_equal(gv[:, :, :, pos], rv[:, :, 0])
+    assert np.array_equal(gk[:, :, :pos], bf16_round(kp[:, :, :pos]))      # the rest of the cache is untouched
+    k_all = np.concatenate([k_old, gk[:, :, pos:pos + 1]], 2)
+    v_all = np.concatenate([v_old, rv], 2)
+    ref = cpu_ref.softmax_attention(torch.from_numpy(rq), torch.from_numpy(k_all), torch.from_numpy(v_all), scale, False,
+                                    cpu_ref.Rounder(False))
+    ref = ref.transpose(1, 2).reshape(B, D).numpy()
+    err = np.abs(be.host_f32(out) - ref).max()
+    assert err < 2 ** -7 * max(1.0, np.abs(ref).max()), f"attention_decode_fused pos{pos}: abs err {err}"
+
+
+def check_greedy_embed(be, B, V, D):
+    rng = np.random.RandomState(11)
+    npart = (D // 16 + 15) // 16 * 16
+    lg = rng.randn(B, V).astype(np.float32)
+    lg[0, 17] = lg[0, 5] = lg[0].max() + 1.0
+    eos, pad, max_new = 2, 0, 4
+    if B > 2:
+        lg[2, eos] = lg[2].max() + 1.0
+    embed = bf16_round(rng.randn(V, D))
+    nxt, out, fin = be.zeros((16,), "i32"), be.zeros((16, max_new), "i32"), be.zeros((16,), "i32")
+    sc = be.i32([0, 100, 101])
+    x, ssq = be.zeros((16, D), "f32"), be.f32(rng.randn(16, npart))
+    step_p = be.ptr(sc)
+    base = sc.ctypes.data if isinstance(sc, np.ndarray) else sc.data_ptr()
+    for it in range(2):
+        be.lib.vck_greedy_embed(be.ptr(be.f32(lg)), be.ptr(nxt), be.ptr(out), be.ptr(fin), c_p(base), B, V, max_new, eos,
+                                pad, be.ptr(be.bf16(embed)), be.ptr(x), be.ptr(ssq), D, npart, c_p(base + 4), c_p(base + 8),
+                                1 if it == 0 else 3, None)
+        be.sync()
+    o = be.host_i32(out)
+    exp = torch.argmax(torch.from_numpy(lg), -1).numpy()
+    assert o[0, 0] == 5
+    for b in range(B):
+        assert o[b, 0] == exp[b] and o[b, 1] == (pad if exp[b] == eos else exp[b])
+    assert list(be.host_i32(sc)) == [2, 101, 102]
+    last = [pad if exp[b] == eos else exp[b] for b in range(B)]
+    assert np.array_equal(be.host_f32(x)[:B], embed[last])
+    assert np.abs(be.host_f32(ssq)[:B].sum(-1) / (embed[last] ** 2).sum(-1) - 1).max() < 1e-5

@@ -65,3 +65,13 @@ def test_attention(be, B, H, T, hd, causal, spike):
 @pytest.mark.parametrize("hd,ctx", [(128, 1217), (128, 1344), (128, 70), (64, 33)])
 def test_attention_decode(be, hd, ctx):
     kc.check_attention_decode(be, 2, 4, hd, ctx)
+
+
+def test_fused_decode_kernels(be):
+    kc.check_gemv_norm_chain(be, 8, 4096, 12288)
+    kc.check_gemv_norm_chain(be, 16, 5120, 1024, seed=1)
+    kc.check_gemv_norm_chain(be, 3, 256, 64, seed=2)
+    kc.check_attention_decode_fused(be, 8, 32, 128, 1216)
+    kc.check_attention_decode_fused(be, 2, 4, 128, 1343)
+    kc.check_attention_decode_fused(be, 1, 2, 64, 5)
+    kc.check_greedy_embed(be, 8, 32000, 4096)

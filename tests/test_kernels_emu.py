@@ -69,3 +69,12 @@ def test_splice_greedy_synth(be):
     kc.check_splice(be, 256)
     kc.check_greedy(be, 3, 320)
     kc.check_synth(be)
+
+
+def test_fused_decode_kernels(be):
+    kc.check_gemv_norm_chain(be, 8, 256, 64)
+    kc.check_gemv_norm_chain(be, 3, 512, 96, seed=1)
+    kc.check_attention_decode_fused(be, 2, 2, 128, 70)
+    kc.check_attention_decode_fused(be, 1, 2, 128, 128)
+    kc.check_attention_decode_fused(be, 1, 1, 64, 5)
+    kc.check_greedy_embed(be, 3, 320, 256)

@@ -377,4 +377,130 @@ void launch_attention_decode(const AttnDecodeArgs& a, hipStream_t s) {
     else VC_LAUNCH((attention_decode_kernel<64>), grid, block, 0, s, a);
 }
 
+// =============================================================================================
+// fused decode attention: RoPE + KV append + softmax(q K^T) V for the one new token of each (b,h).
+// One 512-thread workgroup per (b,h).  K rows and V^T rows are streamed once from HBM with many independent
+// 16-byte loads in flight per wave (4 keys x 4 per wave in the score pass; 16 d-rows per wave in the PV pass).
+// =============================================================================================
+template <int HD>
+__global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeFusedArgs p) {
+    constexpr int LPK = HD / 8;           // lanes per key
+    constexpr int KPW = 64 / LPK;         // keys per wave-instruction
+    constexpr int UK = 4;                 // independent key loads in flight per lane in the score pass
+    constexpr int NR = HD / 8;            // d-row groups (8 rows per wave-instruction) in the PV pass
+    __shared__ __attribute__((aligned(16))) float sc[DEC_MAX_CTX];
+    __shared__ __attribute__((aligned(16))) float q_s[HD];
+    __shared__ __attribute__((aligned(16))) float part[8][HD];
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const size_t bh = (size_t)b * p.H + h;
+    const int pos = *p.pos_dev;
+    const int ctx = pos + 1;
+    const int D = p.H * HD;
+    bf16_t* kbase = p.k + bh * p.kv_stride * HD;
+    bf16_t* vbase = p.vt + bh * HD * (size_t)p.kv_stride;
+    // ---- phase 0: rotate q,k of the new token, append k / v to the cache (global) and keep q in LDS
+    if (tid < HD / 2) {
+        const int d = tid;
+        const bf16_t* row = p.qkv + (size_t)b * (3 * D) + h * HD;
+        const float c = p.rope_cos[(size_t)pos * (HD / 2) + d], s = p.rope_sin[(size_t)pos * (HD / 2) + d];
+        const float q0 = bf2f(row[d]), q1 = bf2f(row[d + HD / 2]);
+        const float k0 = bf2f(row[D + d]), k1 = bf2f(row[D + d + HD / 2]);
+        q_s[d] = bf2f(f2bf(q0 * c - q1 * s));            // q is rounded to bf16 exactly like the unfused path
+        q_s[d + HD / 2] = bf2f(f2bf(q1 * c + q0 * s));
+        bf16_t* ko = kbase + (size_t)pos * HD;
+        ko[d] = f2bf(k0 * c - k1 * s);
+        ko[d + HD / 2] = f2bf(k1 * c + k0 * s);
+        vbase[(size_t)d * p.kv_stride + pos] = row[2 * D + d];
+        vbase[(size_t)(d + HD / 2) * p.kv_stride + pos] = row[2 * D + d + HD / 2];
+    }
+    __syncthreads();  // workgroup-scope release/acquire: the appended K row / V^T column are visible to this block
+    // ---- phase 1: scores
+    float qv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qv[e] = q_s[(lane % LPK) * 8 + e];
+    const int ctx_pad = (ctx + 8 * KPW * UK - 1) / (8 * KPW * UK) * (8 * KPW * UK);
+    for (int kb = wave * KPW * UK; kb < ctx_pad; kb += 8 * KPW * UK) {
+        u32x4 kv[UK];
+#pragma unroll
+        for (int u = 0; u < UK; ++u) {
+            const int key = kb + u * KPW + lane / LPK;
+            kv[u] = ld16(kbase + (size_t)min(key, ctx - 1) * HD + (lane % LPK) * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < UK; ++u) {
+            const int key = kb + u * KPW + lane / LPK;
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s += qv[2 * e] * bf2f_lo(kv[u][e]) + qv[2 * e + 1] * bf2f_hi(kv[u][e]);
+#pragma unroll
+            for (int mk = 1; mk < LPK; mk <<= 1) s += shfl_xor(s, mk);
+            if ((lane % LPK) == 0) sc[key] = key < ctx ? s * p.scale : -INFINITY;
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: softmax over sc[0..ctx_pad)
+    float mx = -INFINITY;
+    for (int i = tid; i < ctx_pad; i += 512) mx = fmaxf(mx, sc[i]);
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = red[0];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) mx = fmaxf(mx, red[w]);
+    __syncthreads();
+    float sum = 0.f;
+    for (int i = tid; i < ctx_pad; i += 512) {
+        const float e = __expf(sc[i] - mx);
+        sc[i] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) sum += red[w];
+    const float inv = 1.0f / sum;
+    // ---- phase 3: waves split the 64-key blocks; per block a wave issues NR independent 16-byte V^T loads
+    const int dr = lane >> 3, kc = lane & 7;
+    float acc[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) acc[i] = 0.f;
+    const int ctx64 = (ctx + 63) & ~63;
+    for (int kb = wave * 64; kb < ctx64; kb += 8 * 64) {
+        const f32x4 p0 = ld16f(&sc[kb + kc * 8]), p1 = ld16f(&sc[kb + kc * 8 + 4]);
+        u32x4 v[NR];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) v[i] = ld16(vbase + (size_t)(i * 8 + dr) * p.kv_stride + kb + kc * 8);
+#pragma unroll
+        for (int i = 0; i < NR; ++i)
+            acc[i] += p0[0] * bf2f_lo(v[i][0]) + p0[1] * bf2f_hi(v[i][0]) + p0[2] * bf2f_lo(v[i][1]) +
+                      p0[3] * bf2f_hi(v[i][1]) + p1[0] * bf2f_lo(v[i][2]) + p1[1] * bf2f_hi(v[i][2]) +
+                      p1[2] * bf2f_lo(v[i][3]) + p1[3] * bf2f_hi(v[i][3]);
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        float a = acc[i];
+        a += shfl_xor(a, 1);
+        a += shfl_xor(a, 2);
+        a += shfl_xor(a, 4);
+        if (kc == 0) part[wave][i * 8 + dr] = a;
+    }
+    __syncthreads();
+    if (tid < HD) {
+        float a = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) a += part[w][tid];
+        p.out[(size_t)b * D + h * HD + tid] = f2bf(a * inv);
+    }
+}
+
+void launch_attention_decode_fused(const AttnDecodeFusedArgs& a, hipStream_t s) {
+    const dim3 grid(a.H, a.B), block(512);
+    if (a.hd == 128) VC_LAUNCH((attention_decode_fused_kernel<128>), grid, block, 0, s, a);
+    else VC_LAUNCH((attention_decode_fused_kernel<64>), grid, block, 0, s, a);
+}
+
 }  // namespace vc

@@ -21,7 +21,14 @@ VC_DEV u32x4 ld16_stream(const void* p) { return ld16(p); }
 VC_DEV u32x4 ld16_stream(const void* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); }
 #endif
 
-template <int WAVES, int EPI>
+// normalised bf16 fragment of 8 activations: bf16( (x * rstd) * w )   ([HF] llama/modeling_llama.py:62-67)
+VC_DEV u32x4 norm_frag(const float* xp, const float* wp, float rstd) {
+    const f32x4 x0 = ld16f(xp), x1 = ld16f(xp + 4), w0 = ld16f(wp), w1 = ld16f(wp + 4);
+    return u32x4{pack_bf2((x0[0] * rstd) * w0[0], (x0[1] * rstd) * w0[1]), pack_bf2((x0[2] * rstd) * w0[2], (x0[3] * rstd) * w0[3]),
+                 pack_bf2((x1[0] * rstd) * w1[0], (x1[1] * rstd) * w1[1]), pack_bf2((x1[2] * rstd) * w1[2], (x1[3] * rstd) * w1[3])};
+}
+
+template <int WAVES, int EPI, bool NORM>
 __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
     __shared__ __attribute__((aligned(16))) float red[WAVES][64][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -33,6 +40,23 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
     const bool mvalid = m < p.M;
     const bf16_t* wp = p.Wp + ((size_t)nt * nkt * 64 + lane) * 8;
     const bf16_t* xp = p.X + (size_t)(mvalid ? m : 0) * p.K + g * 8;
+    const float* xf = nullptr;
+    const float* nw = nullptr;
+    float rstd = 0.f;
+    if constexpr (NORM) {
+        // per-row 1/rms from the producer's deterministic partial sums (fixed summation order -> bit-reproducible)
+        const float* sp = p.ssq_in + (size_t)m * p.npart;
+        float ss = 0.f;
+        for (int q = g; q < (p.npart >> 2); q += 4) {
+            const f32x4 v = ld16f(sp + q * 4);
+            ss += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+        ss += shfl_xor(ss, 16);
+        ss += shfl_xor(ss, 32);
+        rstd = rsqrtf(ss / (float)p.K + p.eps);
+        xf = p.Xf + (size_t)(mvalid ? m : 0) * p.K + g * 8;
+        nw = p.norm_w + g * 8;
+    }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     constexpr int U = 8;
     int kt = kt0;
@@ -41,13 +65,20 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
 #pragma unroll
         for (int u = 0; u < U; ++u) wv[u] = ld16_stream(wp + (size_t)(kt + u) * 512);
 #pragma unroll
-        for (int u = 0; u < U; ++u) xv[u] = mvalid ? ld16(xp + (kt + u) * 32) : u32x4{0u, 0u, 0u, 0u};
+        for (int u = 0; u < U; ++u) {
+            if constexpr (NORM) xv[u] = mvalid ? norm_frag(xf + (kt + u) * 32, nw + (kt + u) * 32, rstd) : u32x4{0u, 0u, 0u, 0u};
+            else xv[u] = mvalid ? ld16(xp + (kt + u) * 32) : u32x4{0u, 0u, 0u, 0u};
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) acc = mfma16(wv[u], xv[u], acc);
     }
     for (; kt < kt1; ++kt) {
         const u32x4 wv = ld16_stream(wp + (size_t)kt * 512);
-        const u32x4 xv = mvalid ? ld16(xp + kt * 32) : u32x4{0u, 0u, 0u, 0u};
+        u32x4 xv = {0u, 0u, 0u, 0u};
+        if (mvalid) {
+            if constexpr (NORM) xv = norm_frag(xf + kt * 32, nw + kt * 32, rstd);
+            else xv = ld16(xp + kt * 32);
+        }
         acc = mfma16(wv, xv, acc);
     }
     st16f(&red[wave][lane][0], acc);
@@ -56,36 +87,53 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
     f32x4 v = ld16f(&red[0][lane][0]);
 #pragma unroll
     for (int w = 1; w < WAVES; ++w) v = v + ld16f(&red[w][lane][0]);
-    if (!mvalid) return;
     const int n = nt * 16 + g * 4;  // lane holds out[m][n..n+3]
+    if constexpr (EPI == GEMV_RESID_F32) {
+        float* o = reinterpret_cast<float*>(p.out) + (size_t)(mvalid ? m : 0) * p.ldo + n;
+        if (mvalid) {
+            v = ld16f(o) + v;
+            st16f(o, v);
+        }
+        if (p.ssq_out) {  // sum of squares of this tile's 16 new residual values of token m (fixed order)
+            float sq = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            sq += shfl_xor(sq, 16);
+            sq += shfl_xor(sq, 32);
+            if (g == 0 && mvalid) p.ssq_out[(size_t)m * p.npart + nt] = sq;
+        }
+        return;
+    }
+    if (!mvalid) return;
     if constexpr (EPI == GEMV_BF16) {
         st8(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo + n, u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])});
     } else if constexpr (EPI == GEMV_F32) {
         st16f(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n, v);
-    } else if constexpr (EPI == GEMV_RESID_F32) {
-        float* o = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n;
-        st16f(o, ld16f(o) + v);
-    } else {
+    } else if constexpr (EPI == GEMV_SWIGLU) {
         *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo + (n >> 1)) =
             pack_bf2(silu(v[0]) * v[1], silu(v[2]) * v[3]);
     }
 }
 
-template <int WAVES>
+template <int WAVES, bool NORM>
 static void launch_gemv_w(const GemvArgs& a, int epi, hipStream_t s) {
     const dim3 grid(a.N / 16), block(WAVES * 64);
     switch (epi) {
-        case GEMV_BF16: VC_LAUNCH((gemv_kernel<WAVES, GEMV_BF16>), grid, block, 0, s, a); break;
-        case GEMV_F32: VC_LAUNCH((gemv_kernel<WAVES, GEMV_F32>), grid, block, 0, s, a); break;
-        case GEMV_RESID_F32: VC_LAUNCH((gemv_kernel<WAVES, GEMV_RESID_F32>), grid, block, 0, s, a); break;
-        default: VC_LAUNCH((gemv_kernel<WAVES, GEMV_SWIGLU>), grid, block, 0, s, a); break;
+        case GEMV_BF16: VC_LAUNCH((gemv_kernel<WAVES, GEMV_BF16, NORM>), grid, block, 0, s, a); break;
+        case GEMV_F32: VC_LAUNCH((gemv_kernel<WAVES, GEMV_F32, NORM>), grid, block, 0, s, a); break;
+        case GEMV_RESID_F32: VC_LAUNCH((gemv_kernel<WAVES, GEMV_RESID_F32, NORM>), grid, block, 0, s, a); break;
+        default: VC_LAUNCH((gemv_kernel<WAVES, GEMV_SWIGLU, NORM>), grid, block, 0, s, a); break;
     }
 }
 
 void launch_gemv(const GemvArgs& a, int epilogue, hipStream_t s) {
     // >= ~2048 waves in flight: few output tiles -> more K-splitting waves per workgroup
-    if (a.N / 16 <= 512) launch_gemv_w<8>(a, epilogue, s);
-    else launch_gemv_w<4>(a, epilogue, s);
+    const bool norm = a.Xf != nullptr;
+    if (a.N / 16 <= 512) {
+        if (norm) launch_gemv_w<8, true>(a, epilogue, s);
+        else launch_gemv_w<8, false>(a, epilogue, s);
+    } else {
+        if (norm) launch_gemv_w<4, true>(a, epilogue, s);
+        else launch_gemv_w<4, false>(a, epilogue, s);
+    }
 }
 
 // W [N,K] row-major -> packed fragment order (done once at weight-load time)

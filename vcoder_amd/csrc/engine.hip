@@ -101,7 +101,7 @@ struct vc_model {
     hipStream_t st;
     bool finalized = false;
     // derived
-    int P, Tv, Kpatch, Kpad, hd, vhd;
+    int P, Tv, Kpatch, Kpad, hd, vhd, npart;
     std::vector<void*> owned;  // every weight allocation
     std::map<std::string, bool> need;
     // weights
@@ -123,7 +123,7 @@ struct vc_model {
     int capB = 0, capS = 0;  // KV capacity
     int curB = 0, curS = 0, cur_pos = -1;
     // decode state
-    Buf x_dec, xn_dec, qkv_dec, q_dec, attn_dec, h_dec, logits, next_tok, finished, out_ids, scalars, dsum;
+    Buf x_dec, xn_dec, qkv_dec, q_dec, attn_dec, h_dec, logits, next_tok, finished, out_ids, scalars, dsum, ssq;
     int out_cap = 0;
     int* step_dev() { return scalars.as<int>(); }
     int* pos_dev() { return scalars.as<int>() + 1; }
@@ -307,11 +307,29 @@ void gemm(vc_model* m, const bf16_t* A, const bf16_t* W, const float* bias, void
     GemmArgs a{A, W, bias, out, M, N, K, K, K, ldo};
     launch_gemm(a, epi, m->st);
 }
-void gemv(vc_model* m, const bf16_t* X, const bf16_t* Wp, void* out, int M, int N, int K, int ldo, int epi) {
+// norm_w != nullptr: fused RMSNorm prologue over the fp32 decode residual stream (x_dec + its ssq partials);
+// write_ssq: RESID epilogue publishes the sum-of-squares partials of the updated residual rows
+void gemv(vc_model* m, const bf16_t* X, const bf16_t* Wp, void* out, int M, int N, int K, int ldo, int epi,
+          const float* norm_w = nullptr, bool write_ssq = false) {
     const size_t esz = (epi == GEMV_F32 || epi == GEMV_RESID_F32) ? 4 : 2;
+    const int np = m->npart;
     for (int m0 = 0; m0 < M; m0 += 16) {  // the skinny kernel holds 16 token slots; larger batches re-stream
-        GemvArgs a{X + (size_t)m0 * K, Wp, reinterpret_cast<char*>(out) + (size_t)m0 * ldo * esz, std::min(16, M - m0),
-                   N, K, ldo};
+        GemvArgs a{};
+        a.X = X ? X + (size_t)m0 * K : nullptr;
+        a.Wp = Wp;
+        a.out = reinterpret_cast<char*>(out) + (size_t)m0 * ldo * esz;
+        a.M = std::min(16, M - m0);
+        a.N = N;
+        a.K = K;
+        a.ldo = ldo;
+        if (norm_w) {
+            a.Xf = m->x_dec.as<float>() + (size_t)m0 * K;
+            a.norm_w = norm_w;
+            a.ssq_in = m->ssq.as<float>() + (size_t)m0 * np;
+        }
+        a.ssq_out = write_ssq ? m->ssq.as<float>() + (size_t)m0 * np : nullptr;
+        a.npart = np;
+        a.eps = m->c.rms_eps;
         launch_gemv(a, epi, m->st);
     }
 }
@@ -516,6 +534,7 @@ void ensure_llm(vc_model* m, int B, int S_total) {
     m->finished.ensure(Bp * 4, true);
     m->scalars.ensure(64, true);
     m->dsum.ensure(Bp * 4, true);
+    m->ssq.ensure((size_t)Bp * m->npart * 4, true);
 }
 
 bf16_t* kcache(vc_model* m, int l) { return m->kc.as<bf16_t>() + (size_t)l * m->capB * m->c.heads * m->capS * m->hd; }
@@ -541,33 +560,39 @@ void run_prefill_layers(vc_model* m, int B, int S) {
     }
 }
 
-// the kernels of one cached decode step (captured into a hipGraph)
+// the kernels of one cached decode step (captured into a hipGraph): 5 launches per layer + 2.
+// x_dec (fp32 residual rows of the new tokens) and its sum-of-squares partials are prepared by the previous step's
+// greedy_embed kernel (or by embed_tokens_ssq when the host supplies the tokens).
+GreedyEmbedArgs greedy_embed_args(vc_model* m, int B, int max_new, int eos_id, int pad_id, int advance) {
+    GreedyEmbedArgs a{};
+    a.g = GreedyArgs{m->logits.as<float>(), m->next_tok.as<int>(), m->out_ids.as<int>(), m->finished.as<int>(),
+                     m->step_dev(), B, m->c.vocab, max_new, eos_id, pad_id};
+    a.embed = m->embed;
+    a.x = m->x_dec.as<float>();
+    a.ssq = m->ssq.as<float>();
+    a.D = m->c.hidden;
+    a.npart = m->npart;
+    a.pos_dev = m->pos_dev();
+    a.ctx_dev = m->ctx_dev();
+    a.advance = advance;
+    return a;
+}
+
 void enqueue_decode_step(vc_model* m, int B, int max_new, int eos_id, int pad_id) {
     const vc_model_cfg& c = m->c;
     const int D = c.hidden, F = c.ffn, H = c.heads;
-    launch_embed_tokens(m->next_tok.as<int>(), m->embed, m->x_dec.as<float>(), B, D, m->st);
     for (int l = 0; l < c.layers; ++l) {
         const LlmLayer& L = m->llm[l];
-        launch_rmsnorm(m->x_dec.as<float>(), L.in_norm, m->xn_dec.as<bf16_t>(), B, D, c.rms_eps, m->st);
-        gemv(m, m->xn_dec.as<bf16_t>(), L.qkv_p, m->qkv_dec.p, B, 3 * D, D, 3 * D, GEMV_BF16);
-        QkvSplitArgs qa{m->qkv_dec.as<bf16_t>(), m->q_dec.as<bf16_t>(), kcache(m, l), vtcache(m, l), B, 1, H, m->hd, 1,
-                        m->capS, m->pos_dev(), m->rope_cos, m->rope_sin};
-        launch_qkv_split(qa, m->st);
-        AttnDecodeArgs da{m->q_dec.as<bf16_t>(), kcache(m, l), vtcache(m, l), m->attn_dec.as<bf16_t>(), B, H, m->hd,
-                          m->capS, m->ctx_dev(), 1.0f / sqrtf((float)m->hd)};
-        launch_attention_decode(da, m->st);
-        gemv(m, m->attn_dec.as<bf16_t>(), L.o_p, m->x_dec.p, B, D, D, D, GEMV_RESID_F32);
-        launch_rmsnorm(m->x_dec.as<float>(), L.post_norm, m->xn_dec.as<bf16_t>(), B, D, c.rms_eps, m->st);
-        gemv(m, m->xn_dec.as<bf16_t>(), L.gu_p, m->h_dec.p, B, 2 * F, D, F, GEMV_SWIGLU);
-        gemv(m, m->h_dec.as<bf16_t>(), L.down_p, m->x_dec.p, B, D, F, D, GEMV_RESID_F32);
+        gemv(m, nullptr, L.qkv_p, m->qkv_dec.p, B, 3 * D, D, 3 * D, GEMV_BF16, L.in_norm);             // K11+K12
+        AttnDecodeFusedArgs da{m->qkv_dec.as<bf16_t>(), kcache(m, l), vtcache(m, l), m->attn_dec.as<bf16_t>(), B, H, m->hd,
+                               m->capS, m->pos_dev(), m->rope_cos, m->rope_sin, 1.0f / sqrtf((float)m->hd)};
+        launch_attention_decode_fused(da, m->st);                                                          // K13-K15
+        gemv(m, m->attn_dec.as<bf16_t>(), L.o_p, m->x_dec.p, B, D, D, D, GEMV_RESID_F32, nullptr, true);  // K16
+        gemv(m, nullptr, L.gu_p, m->h_dec.p, B, 2 * F, D, F, GEMV_SWIGLU, L.post_norm);                    // K11+K17
+        gemv(m, m->h_dec.as<bf16_t>(), L.down_p, m->x_dec.p, B, D, F, D, GEMV_RESID_F32, nullptr, true);  // K17
     }
-    launch_rmsnorm(m->x_dec.as<float>(), m->final_norm, m->xn_dec.as<bf16_t>(), B, D, c.rms_eps, m->st);
-    gemv(m, m->xn_dec.as<bf16_t>(), m->lm_head_p, m->logits.p, B, c.vocab, D, c.vocab, GEMV_F32);
-    launch_advance(nullptr, m->pos_dev(), m->ctx_dev(), m->st);  // cache now holds pos+1 keys
-    GreedyArgs ga{m->logits.as<float>(), m->next_tok.as<int>(), m->out_ids.as<int>(), m->finished.as<int>(),
-                  m->step_dev(), B, c.vocab, max_new, eos_id, pad_id};
-    launch_greedy(ga, m->st);
-    launch_advance(m->step_dev(), nullptr, nullptr, m->st);
+    gemv(m, nullptr, m->lm_head_p, m->logits.p, B, c.vocab, D, c.vocab, GEMV_F32, m->final_norm);          // K11+K18
+    launch_greedy_embed(greedy_embed_args(m, B, max_new, eos_id, pad_id, 3), m->st);                       // K19+K10
 }
 
 void ensure_graph(vc_model* m, int B, int max_new, int eos_id, int pad_id) {
@@ -748,6 +773,7 @@ VC_API int vc_model_create(vc_ctx* ctx, const vc_model_cfg* cfg, vc_model** out)
     m->Tv = m->P + 1;
     m->Kpatch = 3 * c.vit_patch * c.vit_patch;
     m->Kpad = (int)rup(m->Kpatch, 64);
+    m->npart = (int)rup(c.hidden / 16, 16);
     const int D = c.hidden, F = c.ffn, V = c.vocab, Dv = c.vit_hidden, Fv = c.vit_ffn;
     m->embed = walloc<bf16_t>(m, (size_t)V * D);
     m->lm_head = walloc<bf16_t>(m, (size_t)V * D);
@@ -802,7 +828,7 @@ VC_API void vc_model_destroy(vc_model* m) {
                    &m->v_k, &m->v_vt, &m->v_attn, &m->v_h, &m->v_sel, &m->v_mid, &m->feats, &m->x, &m->xn, &m->qkv, &m->q,
                    &m->attn, &m->h, &m->kc, &m->vtc, &m->row_src, &m->last_idx, &m->xl, &m->logits_all, &m->x_dec,
                    &m->xn_dec, &m->qkv_dec, &m->q_dec, &m->attn_dec, &m->h_dec, &m->logits, &m->next_tok, &m->finished,
-                   &m->out_ids, &m->scalars, &m->dsum})
+                   &m->out_ids, &m->scalars, &m->dsum, &m->ssq})
         b->release();
     for (auto& e : m->ev)
         if (e) (void)hipEventDestroy(e);
@@ -926,9 +952,7 @@ VC_API int vc_prefill(vc_model* m, const int64_t* ids, int B, int T, const float
     do_prefill(m, ids, B, T, img, seg, depth, pixels_on_device, has_attention_mask, 64, logits_all, S_out);
     finish_prefill(m, logits_all);
     // greedy choice of the prefill logits, so that vc_decode_step(tok = NULL) continues the sequence
-    GreedyArgs ga{m->logits.as<float>(), m->next_tok.as<int>(), nullptr, m->finished.as<int>(), m->step_dev(), B,
-                  m->c.vocab, 0, -1, 0};
-    launch_greedy(ga, m->st);
+    launch_greedy_embed(greedy_embed_args(m, B, 0, -1, 0, 0), m->st);
     HIPCHK(hipStreamSynchronize(m->st));
     if (logits_last) HIPCHK(hipMemcpy(logits_last, m->logits.p, (size_t)B * m->c.vocab * 4, hipMemcpyDeviceToHost));
     GUARD_END(m->ctx)
@@ -954,7 +978,13 @@ VC_API int vc_decode_step(vc_model* m, const int32_t* tok, float* logits, int32_
     REQUIRE(m->cur_pos >= 0, VC_ERR_STATE, "vc_decode_step before vc_prefill");
     REQUIRE(m->cur_pos + 1 <= m->capS, VC_ERR_STATE, "KV cache full (%d)", m->capS);
     const int B = m->curB;
-    if (tok) HIPCHK(hipMemcpyAsync(m->next_tok.p, tok, B * 4, hipMemcpyHostToDevice, m->st));
+    if (tok) {
+        for (int b = 0; b < B; ++b)
+            REQUIRE(tok[b] >= 0 && tok[b] < m->c.vocab, VC_ERR_INDEX, "index out of range in self (token id %d)", tok[b]);
+        HIPCHK(hipMemcpyAsync(m->next_tok.p, tok, B * 4, hipMemcpyHostToDevice, m->st));
+        launch_embed_tokens_ssq(m->next_tok.as<int>(), m->embed, m->x_dec.as<float>(), m->ssq.as<float>(), B, m->c.hidden,
+                                m->npart, m->st);
+    }
     ensure_out_ids(m, B, 1);
     ensure_graph(m, B, 0, -1, 0);  // max_new 0: out_ids untouched, no EOS bookkeeping
     HIPCHK(hipGraphLaunch(m->graph, m->st));
@@ -979,12 +1009,9 @@ VC_API int vc_generate_greedy(vc_model* m, const int64_t* ids, int B, int T, con
     finish_prefill(m, nullptr);
     if (m->ev[2]) HIPCHK(hipEventRecord(m->ev[2], m->st));
     // token 0 comes from the prefill logits
-    GreedyArgs ga{m->logits.as<float>(), m->next_tok.as<int>(), m->out_ids.as<int>(), m->finished.as<int>(), m->step_dev(),
-                  B, m->c.vocab, max_new, eos_id, pad_id};
     std::vector<int> fill((size_t)B * max_new, pad_id);
     HIPCHK(hipMemcpyAsync(m->out_ids.p, fill.data(), fill.size() * 4, hipMemcpyHostToDevice, m->st));
-    launch_greedy(ga, m->st);
-    launch_advance(m->step_dev(), nullptr, nullptr, m->st);
+    launch_greedy_embed(greedy_embed_args(m, B, max_new, eos_id, pad_id, 1), m->st);  // step 0 -> 1; pos stays at S
     HIPCHK(hipStreamSynchronize(m->st));
     int produced = 1;
     std::vector<int> fin(B);
@@ -1049,12 +1076,12 @@ VC_API int vc_profile_decode_gemv(vc_model* m, int B, int reps, int* launches, d
     auto sweep = [&]() {
         for (int l = 0; l < c.layers; ++l) {
             const LlmLayer& L = m->llm[l];
-            gemv(m, m->xn_dec.as<bf16_t>(), L.qkv_p, m->qkv_dec.p, B, 3 * D, D, 3 * D, GEMV_BF16);
-            gemv(m, m->attn_dec.as<bf16_t>(), L.o_p, m->x_dec.p, B, D, D, D, GEMV_RESID_F32);
-            gemv(m, m->xn_dec.as<bf16_t>(), L.gu_p, m->h_dec.p, B, 2 * F, D, F, GEMV_SWIGLU);
-            gemv(m, m->h_dec.as<bf16_t>(), L.down_p, m->x_dec.p, B, D, F, D, GEMV_RESID_F32);
+            gemv(m, nullptr, L.qkv_p, m->qkv_dec.p, B, 3 * D, D, 3 * D, GEMV_BF16, L.in_norm);
+            gemv(m, m->attn_dec.as<bf16_t>(), L.o_p, m->x_dec.p, B, D, D, D, GEMV_RESID_F32, nullptr, true);
+            gemv(m, nullptr, L.gu_p, m->h_dec.p, B, 2 * F, D, F, GEMV_SWIGLU, L.post_norm);
+            gemv(m, m->h_dec.as<bf16_t>(), L.down_p, m->x_dec.p, B, D, F, D, GEMV_RESID_F32, nullptr, true);
         }
-        gemv(m, m->xn_dec.as<bf16_t>(), m->lm_head_p, m->logits.p, B, c.vocab, D, c.vocab, GEMV_F32);
+        gemv(m, nullptr, m->lm_head_p, m->logits.p, B, c.vocab, D, c.vocab, GEMV_F32, m->final_norm);
     };
     sweep();  // warm
     HIPCHK(hipEventRecord(m->ev[0], m->st));

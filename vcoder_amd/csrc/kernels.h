@@ -42,11 +42,20 @@ enum GemvEpilogue : int {
     GEMV_SWIGLU = 3,     // interleaved (gate,up) rows: out bf16 [M, N/2]
 };
 struct GemvArgs {
-    const bf16_t* X;   // [M, K] bf16 activations (M <= 16)
+    const bf16_t* X;   // [M, K] bf16 activations (M <= 16); unused when Xf is set
     const bf16_t* Wp;  // packed weights
     void* out;
     int M, N, K;       // N % 16 == 0, K % 32 == 0
     int ldo;
+    // fused RMSNorm prologue (K11 folded into K12/K17/K18): activations = bf16( (Xf * rstd[m]) * norm_w ), with
+    // rstd[m] = rsqrt(sum_p ssq_in[m][p] / K + eps) — the per-row sum of squares arrives as `npart` deterministic
+    // partials written by the kernel that produced Xf (a RESID gemv's `ssq_out`, or the embedding kernel).
+    const float* Xf;       // [16, K] fp32 residual stream, or nullptr
+    const float* norm_w;   // [K]
+    const float* ssq_in;   // [16, npart]
+    float* ssq_out;        // RESID epilogue: ssq_out[m][n_tile] = sum over this tile's 16 columns of out^2, or nullptr
+    int npart;             // partials per row (multiple of 16)
+    float eps;
 };
 void launch_gemv(const GemvArgs& a, int epilogue, hipStream_t s);
 void launch_pack_weight(const bf16_t* W, bf16_t* Wp, int N, int K, hipStream_t s);
@@ -102,6 +111,21 @@ struct AttnArgs {
 };
 void launch_attention(const AttnArgs& a, hipStream_t s);
 
+// fused decode attention (K13+K14+K15 for q_len = 1): RoPE of the new q/k, KV-cache append and attention over the cache
+// in ONE launch per layer; the position is read from a device scalar (hipGraph-replayable)
+struct AttnDecodeFusedArgs {
+    const bf16_t* qkv;   // [B, 3*H*hd] fused projection output of the new token
+    bf16_t* k;           // [B,H,kv_stride,hd]   (row `pos` is written)
+    bf16_t* vt;          // [B,H,hd,kv_stride]   (column `pos` is written)
+    bf16_t* out;         // [B, H*hd]
+    int B, H, hd, kv_stride;
+    const int* pos_dev;  // position of the new token == number of keys already cached
+    const float* rope_cos;
+    const float* rope_sin;
+    float scale;
+};
+void launch_attention_decode_fused(const AttnDecodeFusedArgs& a, hipStream_t s);
+
 // decode attention (q_len = 1, K15): ctx length read from a device scalar (hipGraph-replayable)
 struct AttnDecodeArgs {
     const bf16_t* q;    // [B,H,hd]
@@ -133,6 +157,22 @@ struct GreedyArgs {
     int B, V, max_new, eos_id, pad_id;
 };
 void launch_greedy(const GreedyArgs& a, hipStream_t s);
+// greedy select for ALL rows + embedding of the selected tokens into the decode residual stream (+ its sum-of-squares
+// partials for the fused RMSNorm of the next GEMV) + step/pos/ctx advance: the tail of one decode step in one launch.
+struct GreedyEmbedArgs {
+    GreedyArgs g;
+    const bf16_t* embed;  // [V, D]
+    float* x;             // [16, D] fp32 residual stream of the next step
+    float* ssq;           // [16, npart]
+    int D, npart;
+    int* pos_dev;         // advanced by `advance` (may be nullptr)
+    int* ctx_dev;
+    int advance;          // bit 0: step += 1; bit 1: pos += 1 and ctx += 1 (after the selection)
+};
+void launch_greedy_embed(const GreedyEmbedArgs& a, hipStream_t s);
+// embedding + sum-of-squares partials for tokens supplied by the host (vc_decode_step with explicit tokens)
+void launch_embed_tokens_ssq(const int* tok, const bf16_t* embed, float* x, float* ssq, int B, int D, int npart,
+                             hipStream_t s);
 void launch_advance(int* step_dev, int* pos_dev, int* ctx_dev, hipStream_t s);
 
 // ---- misc ---------------------------------------------------------------------------------------

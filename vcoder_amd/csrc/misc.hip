@@ -82,6 +82,76 @@ void launch_greedy(const GreedyArgs& a, hipStream_t s) {
     VC_LAUNCH(greedy_kernel, dim3(a.B), dim3(256), 0, s, a);
 }
 
+// ---- tail of one decode step in ONE launch: greedy select of every row, embedding of the selected tokens into the
+//      next step's residual stream (+ sum-of-squares partials for the fused RMSNorm), step/pos/ctx advance ---------
+VC_DEV void embed_row_ssq(const bf16_t* sp, float* dp, float* ssq_row, int D, int npart, int lane) {
+    float ss = 0.f;
+    for (int c = lane; c < D / 8; c += 64) {
+        const u32x4 v = ld16(sp + c * 8);
+        const f32x4 a = {bf2f_lo(v[0]), bf2f_hi(v[0]), bf2f_lo(v[1]), bf2f_hi(v[1])};
+        const f32x4 b = {bf2f_lo(v[2]), bf2f_hi(v[2]), bf2f_lo(v[3]), bf2f_hi(v[3])};
+        st16f(dp + c * 8, a);
+        st16f(dp + c * 8 + 4, b);
+        ss += ((a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3])) +
+              ((b[0] * b[0] + b[1] * b[1]) + (b[2] * b[2] + b[3] * b[3]));
+    }
+    ss = wave_sum(ss);
+    for (int q = lane; q < npart; q += 64) ssq_row[q] = q == 0 ? ss : 0.f;
+}
+
+__global__ __launch_bounds__(1024) void greedy_embed_kernel(GreedyEmbedArgs p) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const GreedyArgs& g = p.g;
+    const int step = *g.step_dev;
+    for (int b = wave; b < g.B; b += 16) {  // one wave per batch row
+        const float* lg = g.logits + (size_t)b * g.V;
+        const int was_finished = g.eos_id >= 0 ? g.finished[b] : 0;  // read before any lane may set it below
+        float best = -INFINITY;
+        int bi = 0x7FFFFFFF;
+        for (int i = lane * 4; i < g.V; i += 256) {
+            const f32x4 v = ld16f(lg + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) argmax_combine(best, bi, v[e], i + e);
+        }
+#pragma unroll
+        for (int mk = 32; mk >= 1; mk >>= 1) {
+            const float ov = shfl_xor(best, mk);
+            const int oi = shfl_xor(bi, mk);
+            argmax_combine(best, bi, ov, oi);
+        }
+        int tok = bi;
+        if (g.eos_id >= 0) {
+            if (was_finished) tok = g.pad_id;
+            if (lane == 0 && tok == g.eos_id) g.finished[b] = 1;
+        }
+        if (lane == 0) {
+            g.next_tok[b] = tok;
+            if (step < g.max_new) g.out_ids[(size_t)b * g.max_new + step] = tok;
+        }
+        embed_row_ssq(p.embed + (size_t)tok * p.D, p.x + (size_t)b * p.D, p.ssq + (size_t)b * p.npart, p.D, p.npart, lane);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (p.advance & 1) *g.step_dev = step + 1;
+        if ((p.advance & 2) && p.pos_dev) *p.pos_dev += 1;
+        if ((p.advance & 2) && p.ctx_dev) *p.ctx_dev += 1;
+    }
+}
+void launch_greedy_embed(const GreedyEmbedArgs& a, hipStream_t s) {
+    VC_LAUNCH(greedy_embed_kernel, dim3(1), dim3(1024), 0, s, a);
+}
+
+__global__ __launch_bounds__(256) void embed_tokens_ssq_kernel(const int* tok, const bf16_t* embed, float* x, float* ssq,
+                                                               int B, int D, int npart) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    embed_row_ssq(embed + (size_t)tok[row] * D, x + (size_t)row * D, ssq + (size_t)row * npart, D, npart, threadIdx.x & 63);
+}
+void launch_embed_tokens_ssq(const int* tok, const bf16_t* embed, float* x, float* ssq, int B, int D, int npart,
+                             hipStream_t s) {
+    VC_LAUNCH(embed_tokens_ssq_kernel, dim3((B + 3) / 4), dim3(256), 0, s, tok, embed, x, ssq, B, D, npart);
+}
+
 __global__ __launch_bounds__(64) void advance_kernel(int* step_dev, int* pos_dev, int* ctx_dev) {
     if (threadIdx.x != 0) return;
     if (step_dev) *step_dev += 1;
