@@ -421,8 +421,8 @@ def check_gemv_norm_chain(be, M, D, N, seed=0):
     _call(be, "vck_pack_weight", be.bf16(W1), W1p, N, D)
     _call(be, "vck_pack_weight", be.bf16(Wo), Wop, D, N)
     h = be.zeros((M, N), "bf16")
-    lib_args = lambda *a: a
-    be.lib.vck_gemv_norm(be.ptr(x), be.ptr(be.f32(w1)), be.ptr(ssq), ctypes.c_int(npart), ctypes.c_float(1e-5), None,
+    w1d = be.f32(w1)   # keep every device array referenced until after sync(): the call only sees raw pointers
+    be.lib.vck_gemv_norm(be.ptr(x), be.ptr(w1d), be.ptr(ssq), ctypes.c_int(npart), ctypes.c_float(1e-5), None,
                          be.ptr(W1p), be.ptr(h), None, M, N, D, N, 0, None)
     be.sync()
     xn = bf16_round(cpu_ref.rms_norm(torch.from_numpy(embed[tok]), torch.from_numpy(w1), 1e-5).numpy())
@@ -440,7 +440,7 @@ def check_gemv_norm_chain(be, M, D, N, seed=0):
     assert np.abs(got_ss / (x_new ** 2).sum(-1) - 1).max() < 1e-5
     # second fused norm consumes the published partials
     y = be.zeros((M, N), "f32")
-    be.lib.vck_gemv_norm(be.ptr(x), be.ptr(be.f32(w1)), be.ptr(ssq), ctypes.c_int(npart), ctypes.c_float(1e-5), None,
+    be.lib.vck_gemv_norm(be.ptr(x), be.ptr(w1d), be.ptr(ssq), ctypes.c_int(npart), ctypes.c_float(1e-5), None,
                          be.ptr(W1p), be.ptr(y), None, M, N, D, N, 1, None)
     be.sync()
     xn2 = bf16_round(cpu_ref.rms_norm(torch.from_numpy(be.host_f32(x)[:M]), torch.from_numpy(w1), 1e-5).numpy())
@@ -461,9 +461,9 @@ def check_attention_decode_fused(be, B, H, hd, pos, seed=0):
     out = be.zeros((B, D), "bf16")
     cos, sin = rope_tables(S, hd)
     scale = 1.0 / math.sqrt(hd)
-    be.lib.vck_attention_decode_fused(be.ptr(be.bf16(qkv)), be.ptr(kd), be.ptr(vd), be.ptr(out), B, H, hd, S,
-                                      be.ptr(be.i32([pos])), be.ptr(be.f32(cos)), be.ptr(be.f32(sin)),
-                                      ctypes.c_float(scale), None)
+    qd, pd, cd, sd = be.bf16(qkv), be.i32([pos]), be.f32(cos), be.f32(sin)   # keep alive until sync()
+    be.lib.vck_attention_decode_fused(be.ptr(qd), be.ptr(kd), be.ptr(vd), be.ptr(out), B, H, hd, S, be.ptr(pd),
+                                      be.ptr(cd), be.ptr(sd), ctypes.c_float(scale), None)
     be.sync()
     rq, rk, rv = _split_ref(qkv, B, 1, H, hd, True, pos0=pos)     # roped+rounded q,k and raw v of the new token
     gk, gv = be.host_f32(kd), be.host_f32(vd)
@@ -491,11 +491,11 @@ def check_greedy_embed(be, B, V, D):
     nxt, out, fin = be.zeros((16,), "i32"), be.zeros((16, max_new), "i32"), be.zeros((16,), "i32")
     sc = be.i32([0, 100, 101])
     x, ssq = be.zeros((16, D), "f32"), be.f32(rng.randn(16, npart))
-    step_p = be.ptr(sc)
     base = sc.ctypes.data if isinstance(sc, np.ndarray) else sc.data_ptr()
+    lgd, embd = be.f32(lg), be.bf16(embed)   # keep alive until sync()
     for it in range(2):
-        be.lib.vck_greedy_embed(be.ptr(be.f32(lg)), be.ptr(nxt), be.ptr(out), be.ptr(fin), c_p(base), B, V, max_new, eos,
-                                pad, be.ptr(be.bf16(embed)), be.ptr(x), be.ptr(ssq), D, npart, c_p(base + 4), c_p(base + 8),
+        be.lib.vck_greedy_embed(be.ptr(lgd), be.ptr(nxt), be.ptr(out), be.ptr(fin), c_p(base), B, V, max_new, eos,
+                                pad, be.ptr(embd), be.ptr(x), be.ptr(ssq), D, npart, c_p(base + 4), c_p(base + 8),
                                 1 if it == 0 else 3, None)
         be.sync()
     o = be.host_i32(out)

@@ -28,17 +28,22 @@ VC_DEV u32x4 norm_frag(const float* xp, const float* wp, float rstd) {
                  pack_bf2((x1[0] * rstd) * w1[0], (x1[1] * rstd) * w1[1]), pack_bf2((x1[2] * rstd) * w1[2], (x1[3] * rstd) * w1[3])};
 }
 
-template <int WAVES, int EPI, bool NORM>
+// WAVES waves split K; each workgroup owns NT consecutive 16-output tiles so that one (normalised) activation
+// fragment feeds NT weight tiles — this halves the L2 traffic of the activation operand for NT = 2.
+template <int WAVES, int NT, int EPI, bool NORM>
 __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
-    __shared__ __attribute__((aligned(16))) float red[WAVES][64][4];
+    __shared__ __attribute__((aligned(16))) float red[WAVES][NT][64][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nt = blockIdx.x;
+    const int ntiles = p.N >> 4;
+    const int nt0 = blockIdx.x * NT;
     const int nkt = p.K >> 5;
     const int per = (nkt + WAVES - 1) / WAVES;
     const int kt0 = wave * per, kt1 = min(nkt, kt0 + per);
     const int m = lane & 15, g = lane >> 4;
     const bool mvalid = m < p.M;
-    const bf16_t* wp = p.Wp + ((size_t)nt * nkt * 64 + lane) * 8;
+    const bf16_t* wp[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wp[t] = p.Wp + ((size_t)min(nt0 + t, ntiles - 1) * nkt * 64 + lane) * 8;
     const bf16_t* xp = p.X + (size_t)(mvalid ? m : 0) * p.K + g * 8;
     const float* xf = nullptr;
     const float* nw = nullptr;
@@ -57,36 +62,45 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
         xf = p.Xf + (size_t)(mvalid ? m : 0) * p.K + g * 8;
         nw = p.norm_w + g * 8;
     }
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    constexpr int U = 8;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 8 / NT;
     int kt = kt0;
     for (; kt + U <= kt1; kt += U) {
-        u32x4 wv[U], xv[U];
+        u32x4 wv[NT][U], xv[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) wv[u] = ld16_stream(wp + (size_t)(kt + u) * 512);
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) wv[t][u] = ld16_stream(wp[t] + (size_t)(kt + u) * 512);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if constexpr (NORM) xv[u] = mvalid ? norm_frag(xf + (kt + u) * 32, nw + (kt + u) * 32, rstd) : u32x4{0u, 0u, 0u, 0u};
             else xv[u] = mvalid ? ld16(xp + (kt + u) * 32) : u32x4{0u, 0u, 0u, 0u};
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) acc = mfma16(wv[u], xv[u], acc);
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = mfma16(wv[t][u], xv[u], acc[t]);
     }
     for (; kt < kt1; ++kt) {
-        const u32x4 wv = ld16_stream(wp + (size_t)kt * 512);
         u32x4 xv = {0u, 0u, 0u, 0u};
         if (mvalid) {
             if constexpr (NORM) xv = norm_frag(xf + kt * 32, nw + kt * 32, rstd);
             else xv = ld16(xp + kt * 32);
         }
-        acc = mfma16(wv, xv, acc);
-    }
-    st16f(&red[wave][lane][0], acc);
-    __syncthreads();
-    if (wave != 0) return;
-    f32x4 v = ld16f(&red[0][lane][0]);
 #pragma unroll
-    for (int w = 1; w < WAVES; ++w) v = v + ld16f(&red[w][lane][0]);
+        for (int t = 0; t < NT; ++t) acc[t] = mfma16(ld16_stream(wp[t] + (size_t)kt * 512), xv, acc[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) st16f(&red[wave][t][lane][0], acc[t]);
+    __syncthreads();
+    if (wave >= NT) return;
+    const int nt = nt0 + wave;  // wave t finishes tile t
+    if (nt >= ntiles) return;
+    f32x4 v = ld16f(&red[0][wave][lane][0]);
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) v = v + ld16f(&red[w][wave][lane][0]);
     const int n = nt * 16 + g * 4;  // lane holds out[m][n..n+3]
     if constexpr (EPI == GEMV_RESID_F32) {
         float* o = reinterpret_cast<float*>(p.out) + (size_t)(mvalid ? m : 0) * p.ldo + n;
@@ -113,27 +127,25 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
     }
 }
 
-template <int WAVES, bool NORM>
+template <int WAVES, int NT, bool NORM>
 static void launch_gemv_w(const GemvArgs& a, int epi, hipStream_t s) {
-    const dim3 grid(a.N / 16), block(WAVES * 64);
+    const dim3 grid((a.N / 16 + NT - 1) / NT), block(WAVES * 64);
     switch (epi) {
-        case GEMV_BF16: VC_LAUNCH((gemv_kernel<WAVES, GEMV_BF16, NORM>), grid, block, 0, s, a); break;
-        case GEMV_F32: VC_LAUNCH((gemv_kernel<WAVES, GEMV_F32, NORM>), grid, block, 0, s, a); break;
-        case GEMV_RESID_F32: VC_LAUNCH((gemv_kernel<WAVES, GEMV_RESID_F32, NORM>), grid, block, 0, s, a); break;
-        default: VC_LAUNCH((gemv_kernel<WAVES, GEMV_SWIGLU, NORM>), grid, block, 0, s, a); break;
+        case GEMV_BF16: VC_LAUNCH((gemv_kernel<WAVES, NT, GEMV_BF16, NORM>), grid, block, 0, s, a); break;
+        case GEMV_F32: VC_LAUNCH((gemv_kernel<WAVES, NT, GEMV_F32, NORM>), grid, block, 0, s, a); break;
+        case GEMV_RESID_F32: VC_LAUNCH((gemv_kernel<WAVES, NT, GEMV_RESID_F32, NORM>), grid, block, 0, s, a); break;
+        default: VC_LAUNCH((gemv_kernel<WAVES, NT, GEMV_SWIGLU, NORM>), grid, block, 0, s, a); break;
     }
 }
 
 void launch_gemv(const GemvArgs& a, int epilogue, hipStream_t s) {
-    // >= ~2048 waves in flight: few output tiles -> more K-splitting waves per workgroup
-    const bool norm = a.Xf != nullptr;
-    if (a.N / 16 <= 512) {
-        if (norm) launch_gemv_w<8, true>(a, epilogue, s);
-        else launch_gemv_w<8, false>(a, epilogue, s);
-    } else {
-        if (norm) launch_gemv_w<4, true>(a, epilogue, s);
-        else launch_gemv_w<4, false>(a, epilogue, s);
+    if (a.Xf != nullptr) {  // fused RMSNorm prologue: 2 tiles per workgroup share every normalised fragment
+        launch_gemv_w<8, 2, true>(a, epilogue, s);
+        return;
     }
+    // plain activations: >= ~2048 waves in flight — few output tiles -> more K-splitting waves per workgroup
+    if (a.N / 16 <= 512) launch_gemv_w<8, 1, false>(a, epilogue, s);
+    else launch_gemv_w<4, 1, false>(a, epilogue, s);
 }
 
 // W [N,K] row-major -> packed fragment order (done once at weight-load time)

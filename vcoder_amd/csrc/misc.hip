@@ -100,26 +100,50 @@ VC_DEV void embed_row_ssq(const bf16_t* sp, float* dp, float* ssq_row, int D, in
 }
 
 __global__ __launch_bounds__(1024) void greedy_embed_kernel(GreedyEmbedArgs p) {
+    constexpr int MAXB = 16;
+    __shared__ float sv[16][MAXB];
+    __shared__ int si[16][MAXB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const GreedyArgs& g = p.g;
     const int step = *g.step_dev;
-    for (int b = wave; b < g.B; b += 16) {  // one wave per batch row
-        const float* lg = g.logits + (size_t)b * g.V;
-        const int was_finished = g.eos_id >= 0 ? g.finished[b] : 0;  // read before any lane may set it below
-        float best = -INFINITY;
-        int bi = 0x7FFFFFFF;
-        for (int i = lane * 4; i < g.V; i += 256) {
-            const f32x4 v = ld16f(lg + i);
+    // phase A: every thread scans its columns of ALL rows (B independent 16-byte loads in flight per iteration)
+    float best[MAXB];
+    int bi[MAXB];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) argmax_combine(best, bi, v[e], i + e);
-        }
+    for (int b = 0; b < MAXB; ++b) { best[b] = -INFINITY; bi[b] = 0x7FFFFFFF; }
+    for (int i = tid * 4; i < g.V; i += 4096) {
 #pragma unroll
-        for (int mk = 32; mk >= 1; mk >>= 1) {
-            const float ov = shfl_xor(best, mk);
-            const int oi = shfl_xor(bi, mk);
-            argmax_combine(best, bi, ov, oi);
+        for (int b = 0; b < MAXB; ++b) {
+            if (b < g.B) {
+                const f32x4 v = ld16f(g.logits + (size_t)b * g.V + i);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) argmax_combine(best[b], bi[b], v[e], i + e);
+            }
         }
-        int tok = bi;
+    }
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b) {
+        if (b < g.B) {
+#pragma unroll
+            for (int mk = 32; mk >= 1; mk >>= 1) {
+                const float ov = shfl_xor(best[b], mk);
+                const int oi = shfl_xor(bi[b], mk);
+                argmax_combine(best[b], bi[b], ov, oi);
+            }
+            if (lane == 0) { sv[wave][b] = best[b]; si[wave][b] = bi[b]; }
+        }
+    }
+    __syncthreads();
+    // phase B: wave b finishes row b (combine the 16 wave results, EOS/pad bookkeeping, embed the selected token)
+    if (wave < g.B) {
+        const int b = wave;
+        float bv = sv[0][b];
+        int bidx = si[0][b];
+        for (int w = 1; w < 16; ++w) argmax_combine(bv, bidx, sv[w][b], si[w][b]);
+        const int was_finished = g.eos_id >= 0 ? g.finished[b] : 0;
+        int tok = bidx;
+        // all lanes computed the same tok; one shuffle keeps the read of finished[] ahead of lane 0's write below
+        tok = shfl(tok, 0);
         if (g.eos_id >= 0) {
             if (was_finished) tok = g.pad_id;
             if (lane == 0 && tok == g.eos_id) g.finished[b] = 1;
