@@ -30,9 +30,17 @@ VC_DEV u32x4 norm_frag(const float* xp, const float* wp, float rstd) {
 
 // WAVES waves split K; each workgroup owns NT consecutive 16-output tiles so that one (normalised) activation
 // fragment feeds NT weight tiles — this halves the L2 traffic of the activation operand for NT = 2.
-template <int WAVES, int NT, int EPI, bool NORM>
+//
+// NORM (fused RMSNorm) comes in two forms.  STAGE: the workgroup first normalises all M rows ONCE into LDS
+// (bf16, rows padded by 16 B so the 16 token rows of a fragment read hit 16 different bank groups) and the K loop
+// then reads activation fragments with ds_read_b128 — the streaming loop is as lean as the plain one.  !STAGE
+// (rows do not fit the 160 KiB LDS): every wave normalises its own fragments straight from L2.
+template <int WAVES, int NT, int EPI, bool NORM, bool STAGE>
 __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
-    __shared__ __attribute__((aligned(16))) float red[WAVES][NT][64][4];
+    VC_DYNAMIC_SMEM(char, dsm);  // STAGE: normalised activations, later re-used for the cross-wave reduction
+    __shared__ __attribute__((aligned(16))) float red_static[STAGE ? 1 : WAVES * NT * 64 * 4];
+    __shared__ float rstd_s[16];
+    float* red = STAGE ? reinterpret_cast<float*>(dsm) : red_static;  // [WAVES][NT][64][4]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntiles = p.N >> 4;
     const int nt0 = blockIdx.x * NT;
@@ -48,7 +56,27 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
     const float* xf = nullptr;
     const float* nw = nullptr;
     float rstd = 0.f;
-    if constexpr (NORM) {
+    const int row_bytes = p.K * 2 + 16;
+    if constexpr (NORM && STAGE) {
+        const int Mp = p.M <= 8 ? 8 : 16;
+        for (int r = wave; r < Mp; r += WAVES) {  // 1/rms per row from the producer's partials (fixed order)
+            float ss = 0.f;
+            for (int q = lane; q < p.npart; q += 64) ss += p.ssq_in[(size_t)r * p.npart + q];
+            ss = wave_sum(ss);
+            if (lane == 0) rstd_s[r] = rsqrtf(ss / (float)p.K + p.eps);
+        }
+        __syncthreads();
+        const int cpr = p.K >> 3;
+        for (int idx = tid; idx < Mp * cpr; idx += WAVES * 64) {
+            const int r = idx / cpr, c = idx - r * cpr;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (r < p.M) v = norm_frag(p.Xf + (size_t)r * p.K + c * 8, p.norm_w + c * 8, rstd_s[r]);
+            st16(dsm + (size_t)r * row_bytes + c * 16, v);
+        }
+        __syncthreads();
+    }
+    const char* xs = dsm + (size_t)m * row_bytes + g * 16;
+    if constexpr (NORM && !STAGE) {
         // per-row 1/rms from the producer's deterministic partial sums (fixed summation order -> bit-reproducible)
         const float* sp = p.ssq_in + (size_t)m * p.npart;
         float ss = 0.f;
@@ -75,7 +103,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
             for (int t = 0; t < NT; ++t) wv[t][u] = ld16_stream(wp[t] + (size_t)(kt + u) * 512);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if constexpr (NORM) xv[u] = mvalid ? norm_frag(xf + (kt + u) * 32, nw + (kt + u) * 32, rstd) : u32x4{0u, 0u, 0u, 0u};
+            if constexpr (NORM && STAGE) xv[u] = mvalid ? ld16(xs + (kt + u) * 64) : u32x4{0u, 0u, 0u, 0u};
+            else if constexpr (NORM) xv[u] = mvalid ? norm_frag(xf + (kt + u) * 32, nw + (kt + u) * 32, rstd) : u32x4{0u, 0u, 0u, 0u};
             else xv[u] = mvalid ? ld16(xp + (kt + u) * 32) : u32x4{0u, 0u, 0u, 0u};
         }
 #pragma unroll
@@ -86,21 +115,23 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
     for (; kt < kt1; ++kt) {
         u32x4 xv = {0u, 0u, 0u, 0u};
         if (mvalid) {
-            if constexpr (NORM) xv = norm_frag(xf + kt * 32, nw + kt * 32, rstd);
+            if constexpr (NORM && STAGE) xv = ld16(xs + kt * 64);
+            else if constexpr (NORM) xv = norm_frag(xf + kt * 32, nw + kt * 32, rstd);
             else xv = ld16(xp + kt * 32);
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = mfma16(ld16_stream(wp[t] + (size_t)kt * 512), xv, acc[t]);
     }
+    if constexpr (STAGE) __syncthreads();  // every wave is done with the staged activations before `red` overwrites them
 #pragma unroll
-    for (int t = 0; t < NT; ++t) st16f(&red[wave][t][lane][0], acc[t]);
+    for (int t = 0; t < NT; ++t) st16f(red + ((wave * NT + t) * 64 + lane) * 4, acc[t]);
     __syncthreads();
     if (wave >= NT) return;
     const int nt = nt0 + wave;  // wave t finishes tile t
     if (nt >= ntiles) return;
-    f32x4 v = ld16f(&red[0][wave][lane][0]);
+    f32x4 v = ld16f(red + ((0 * NT + wave) * 64 + lane) * 4);
 #pragma unroll
-    for (int w = 1; w < WAVES; ++w) v = v + ld16f(&red[w][wave][lane][0]);
+    for (int w = 1; w < WAVES; ++w) v = v + ld16f(red + ((w * NT + wave) * 64 + lane) * 4);
     const int n = nt * 16 + g * 4;  // lane holds out[m][n..n+3]
     if constexpr (EPI == GEMV_RESID_F32) {
         float* o = reinterpret_cast<float*>(p.out) + (size_t)(mvalid ? m : 0) * p.ldo + n;
@@ -127,25 +158,48 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
     }
 }
 
-template <int WAVES, int NT, bool NORM>
-static void launch_gemv_w(const GemvArgs& a, int epi, hipStream_t s) {
+template <class K>
+static void allow_big_lds(K kernel, size_t bytes) {
+#ifndef VC_EMU
+    if (bytes > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+#endif
+}
+
+template <int WAVES, int NT, bool NORM, bool STAGE>
+static void launch_gemv_w(const GemvArgs& a, int epi, size_t shmem, hipStream_t s) {
     const dim3 grid((a.N / 16 + NT - 1) / NT), block(WAVES * 64);
     switch (epi) {
-        case GEMV_BF16: VC_LAUNCH((gemv_kernel<WAVES, NT, GEMV_BF16, NORM>), grid, block, 0, s, a); break;
-        case GEMV_F32: VC_LAUNCH((gemv_kernel<WAVES, NT, GEMV_F32, NORM>), grid, block, 0, s, a); break;
-        case GEMV_RESID_F32: VC_LAUNCH((gemv_kernel<WAVES, NT, GEMV_RESID_F32, NORM>), grid, block, 0, s, a); break;
-        default: VC_LAUNCH((gemv_kernel<WAVES, NT, GEMV_SWIGLU, NORM>), grid, block, 0, s, a); break;
+        case GEMV_BF16:
+            allow_big_lds(gemv_kernel<WAVES, NT, GEMV_BF16, NORM, STAGE>, shmem);
+            VC_LAUNCH((gemv_kernel<WAVES, NT, GEMV_BF16, NORM, STAGE>), grid, block, shmem, s, a);
+            break;
+        case GEMV_F32:
+            allow_big_lds(gemv_kernel<WAVES, NT, GEMV_F32, NORM, STAGE>, shmem);
+            VC_LAUNCH((gemv_kernel<WAVES, NT, GEMV_F32, NORM, STAGE>), grid, block, shmem, s, a);
+            break;
+        case GEMV_RESID_F32:
+            allow_big_lds(gemv_kernel<WAVES, NT, GEMV_RESID_F32, NORM, STAGE>, shmem);
+            VC_LAUNCH((gemv_kernel<WAVES, NT, GEMV_RESID_F32, NORM, STAGE>), grid, block, shmem, s, a);
+            break;
+        default:
+            allow_big_lds(gemv_kernel<WAVES, NT, GEMV_SWIGLU, NORM, STAGE>, shmem);
+            VC_LAUNCH((gemv_kernel<WAVES, NT, GEMV_SWIGLU, NORM, STAGE>), grid, block, shmem, s, a);
+            break;
     }
 }
 
 void launch_gemv(const GemvArgs& a, int epilogue, hipStream_t s) {
-    if (a.Xf != nullptr) {  // fused RMSNorm prologue: 2 tiles per workgroup share every normalised fragment
-        launch_gemv_w<8, 2, true>(a, epilogue, s);
+    if (a.Xf != nullptr) {  // fused RMSNorm prologue; 2 tiles per workgroup share every activation fragment
+        const size_t stage = (size_t)(a.M <= 8 ? 8 : 16) * ((size_t)a.K * 2 + 16);
+        const size_t need = stage > (size_t)8 * 2 * 64 * 16 ? stage : (size_t)8 * 2 * 64 * 16;  // also holds `red`
+        if (need <= 150 * 1024) launch_gemv_w<8, 2, true, true>(a, epilogue, need, s);
+        else launch_gemv_w<8, 2, true, false>(a, epilogue, 0, s);
         return;
     }
     // plain activations: >= ~2048 waves in flight — few output tiles -> more K-splitting waves per workgroup
-    if (a.N / 16 <= 512) launch_gemv_w<8, 1, false>(a, epilogue, s);
-    else launch_gemv_w<4, 1, false>(a, epilogue, s);
+    if (a.N / 16 <= 512) launch_gemv_w<8, 1, false, false>(a, epilogue, 0, s);
+    else launch_gemv_w<4, 1, false, false>(a, epilogue, 0, s);
 }
 
 // W [N,K] row-major -> packed fragment order (done once at weight-load time)
