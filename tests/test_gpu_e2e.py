@@ -93,3 +93,38 @@ def test_true_shape_7b_layer_smoke():
     _, nxt = eng.decode_step(out[:, 0])
     assert np.array_equal(nxt, out[:, 1])
     eng.close()
+
+
+def test_true_dims_against_oracle():
+    """TRUE 7b / ViT-L dimensions (D 4096, F 11008, V 32000, hd 128; ViT 1024/4096, 577 tokens, 336 px), cut to
+    2 decoder + 2 ViT layers so the CPU oracle finishes in about a minute: prefill logits (S = 1216) and the first
+    decode step against oracle/cpu_ref.py with the same bf16 rounding points, on identical synthetic weights."""
+    import torch
+    import cpu_ref
+
+    cfg = vcfg.vicuna_7b("vcoder_ds")
+    cfg.num_hidden_layers = 2
+    cfg.vit_num_layers = 3
+    sd = synth.synth_state_dict(cfg, 11)
+    eng = HipEngine(cfg)
+    eng.load_synthetic(11)
+    eng.finalize()
+    ids = synth.synth_prompt_ids(cfg.vocab_size, "vcoder_ds", sample=3)[None]
+    imgs, segs, deps = synth.synth_batch(1, 336, first=3)
+    last, _, S = eng.prefill(ids, imgs, segs, deps)
+    lg2, nxt2 = eng.decode_step(np.argmax(last, -1).astype(np.int32))
+    om = cpu_ref.OracleModel(cfg, sd, emu_bf16=True)
+    t = torch.from_numpy
+    with torch.no_grad():
+        o_last, cache = om.forward(ids.tolist(), t(imgs), t(segs), t(deps), last_only=True)
+        o_lg2 = om.decode_step(np.argmax(last, -1).tolist(), cache)
+    o_last, o_lg2 = o_last[:, -1].numpy(), o_lg2[:, -1].numpy()
+    e1, e2 = np.abs(last - o_last).max(), np.abs(lg2 - o_lg2).max()
+    scale = np.abs(o_last).max()
+    print(f"true-dims parity: S={S} |logits|max={scale:.3f} prefill err={e1:.4f} decode err={e2:.4f}")
+    assert S == 1216
+    assert e1 < 2e-2 * max(1.0, scale) and e2 < 2e-2 * max(1.0, scale)
+    m = np.sort(o_last[0])[-1] - np.sort(o_last[0])[-2]
+    if m > 4 * e1:
+        assert int(np.argmax(last)) == int(np.argmax(o_last))
+    eng.close()

@@ -1,0 +1,113 @@
+#!/usr/bin/env python
+"""Per-kernel micro-benchmark on an MI355X through the vck_* C ABI (include/vcoder_kernels.h), timed with events on the
+default stream.  usage: python tools/kbench.py [gemm] [gemv] [attn] [dattn]   (env knobs are read by the library)"""
+import ctypes as C
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from vcoder_amd import _lib  # noqa: E402
+
+lib = _lib.load()
+dev = torch.device("cuda:0")
+P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3  # us
+
+
+def bf16(*shape, scale=1.0):
+    return (torch.randn(*shape, device=dev) * scale).to(torch.bfloat16)
+
+
+def bench_gemm():
+    for (M, N, K, epi, name) in [(9728, 12288, 4096, 0, "llm qkv"), (9728, 4096, 4096, 4, "llm o"),
+                                 (9728, 22016, 4096, 5, "llm gate-up"), (9728, 4096, 11008, 4, "llm down"),
+                                 (13848, 3072, 1024, 0, "vit qkv"), (13848, 4096, 1024, 1, "vit fc1"),
+                                 (13848, 1024, 4096, 4, "vit fc2"), (13824, 4096, 4096, 0, "adapter 2")]:
+        A, W = bf16(M, K), bf16(N, K, scale=0.02)
+        out = torch.zeros((M, N), dtype=torch.float32 if epi in (3, 4) else torch.bfloat16, device=dev)
+        ldo = N // 2 if epi == 5 else N
+        us = timeit(lambda: lib.vck_gemm(P(A), P(W), None, P(out), M, N, K, K, K, ldo, epi, None), iters=10)
+        print(f"gemm {name:12s} M{M} N{N} K{K} epi{epi}: {us:9.1f} us  {2 * M * N * K / us / 1e6:7.1f} TFLOP/s", flush=True)
+
+
+def bench_gemv():
+    M = 8
+    for (N, K, epi, name) in [(12288, 4096, 0, "qkv"), (4096, 4096, 2, "o"), (22016, 4096, 3, "gate-up"),
+                              (4096, 11008, 2, "down"), (32000, 4096, 1, "lm_head")]:
+        X = bf16(M, K)
+        # rotate over 8 weight copies so the 256 MB Infinity Cache cannot hold them
+        Ws = [bf16(N * K, scale=0.02) for _ in range(8)]
+        out = torch.zeros((M, N), dtype=torch.float32 if epi in (1, 2) else torch.bfloat16, device=dev)
+        ldo = N // 2 if epi == 3 else N
+        it = [0]
+
+        def f():
+            it[0] += 1
+            lib.vck_gemv(P(X), P(Ws[it[0] % 8]), P(out), M, N, K, ldo, epi, None)
+        us = timeit(f, iters=40)
+        print(f"gemv {name:8s} N{N} K{K} epi{epi}: {us:7.1f} us  {2 * N * K / us / 1e3:7.1f} GB/s", flush=True)
+        if epi in (0, 1, 3):
+            xf = torch.randn(16, K, device=dev)
+            w = torch.rand(K, device=dev) + 0.5
+            npart = (K // 16 + 15) // 16 * 16
+            ssq = torch.rand(16, npart, device=dev)
+
+            def g():
+                it[0] += 1
+                lib.vck_gemv_norm(P(xf), P(w), P(ssq), npart, C.c_float(1e-5), None, P(Ws[it[0] % 8]), P(out), None, M, N,
+                                  K, ldo, epi, None)
+            us = timeit(g, iters=40)
+            print(f"gemv+norm {name:8s}          : {us:7.1f} us  {2 * N * K / us / 1e3:7.1f} GB/s", flush=True)
+
+
+def bench_attn():
+    for (B, H, T, hd, causal, name) in [(8, 32, 1216, 128, 1, "llm prefill"), (24, 16, 577, 64, 0, "vit")]:
+        Ts = (T + 63) // 64 * 64
+        q, k, vt = bf16(B, H, Ts, hd), bf16(B, H, Ts, hd), bf16(B, H, hd, Ts)
+        out = torch.zeros((B * T, H * hd), dtype=torch.bfloat16, device=dev)
+        us = timeit(lambda: lib.vck_attention(P(q), P(k), P(vt), P(out), B, H, T, hd, Ts, Ts, causal,
+                                              C.c_float(1 / math.sqrt(hd)), None), iters=10)
+        fl = 4.0 * B * H * T * T * hd * (0.5 if causal else 1.0)
+        print(f"attention {name:12s} variant={os.environ.get('VC_ATTN_VARIANT', '0')}: {us:8.1f} us  "
+              f"{fl / us / 1e6:7.1f} TFLOP/s", flush=True)
+
+
+def bench_dattn():
+    B, H, hd, pos = 8, 32, 128, 1280
+    S = 1344
+    D = H * hd
+    qkv = bf16(B, 3 * D)
+    ks = [bf16(B, H, S, hd) for _ in range(4)]
+    vs = [bf16(B, H, hd, S) for _ in range(4)]
+    out = torch.zeros((B, D), dtype=torch.bfloat16, device=dev)
+    posd = torch.tensor([pos], dtype=torch.int32, device=dev)
+    cos, sin = torch.rand(S, hd // 2, device=dev), torch.rand(S, hd // 2, device=dev)
+    it = [0]
+
+    def f():
+        it[0] += 1
+        lib.vck_attention_decode_fused(P(qkv), P(ks[it[0] % 4]), P(vs[it[0] % 4]), P(out), B, H, hd, S, P(posd), P(cos),
+                                       P(sin), C.c_float(1 / math.sqrt(hd)), None)
+    us = timeit(f, iters=40)
+    print(f"decode attention ctx={pos + 1}: {us:7.1f} us  {4.0 * B * (pos + 1) * D / us / 1e3:7.1f} GB/s", flush=True)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["gemm", "gemv", "attn", "dattn"]
+    for w in what:
+        {"gemm": bench_gemm, "gemv": bench_gemv, "attn": bench_attn, "dattn": bench_dattn}[w]()

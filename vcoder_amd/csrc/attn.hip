@@ -12,6 +12,8 @@
 // O^T = V^T P^T; with S^T in the MFMA C layout each lane already owns the P values of ONE query, so
 // row max / row sum need only 2 cross-lane steps and P feeds the second MFMA from registers (the
 // contraction order over keys is permuted identically on both operands).
+#include <stdlib.h>
+
 #include "vc_device.h"
 #include "kernels.h"
 
@@ -113,7 +115,7 @@ void launch_qkv_split(const QkvSplitArgs& a, hipStream_t s) {
 }
 
 // =============================================================================================
-// flash attention: workgroup = 128 queries of one (b,h); 4 waves x 32 queries; KV tiles of 64 keys
+// flash attention: workgroup = 128 queries of one (b,h) as WAVES waves x QS 16-query sub-tiles; KV tiles of 64 keys
 // =============================================================================================
 template <int HD> VC_DEV int swz_k(int row, int chunk) {  // K tile [64][HD] bf16, 16-B chunks
     if constexpr (HD == 128) return row * 256 + ((chunk ^ (row & 15)) << 4);
@@ -121,8 +123,10 @@ template <int HD> VC_DEV int swz_k(int row, int chunk) {  // K tile [64][HD] bf1
 }
 VC_DEV int swz_v(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }  // V^T tile [HD][64]
 
-template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
+template <int HD, bool CAUSAL, int WAVES, int QS>
+__global__ __launch_bounds__(WAVES * 64) void attention_kernel(AttnArgs p) {
+    constexpr int NTH = WAVES * 64;       // threads per workgroup
+    constexpr int QB = WAVES * QS * 16;   // queries per workgroup
     constexpr int KS = HD / 32;        // k-steps of the QK^T contraction
     constexpr int DT = HD / 16;        // 16-wide d tiles of the output
     constexpr int KCH = HD / 8;        // 16-B chunks per K row
@@ -130,52 +134,54 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char v_lds[HD * 128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, j = lane & 15;
-    const int q0 = blockIdx.x * 128, h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * QB, h = blockIdx.y, b = blockIdx.z;
     const size_t bh = (size_t)b * p.H + h;
     const bf16_t* qbase = p.q + bh * p.q_stride * HD;
     const bf16_t* kbase = p.k + bh * p.kv_stride * HD;
     const bf16_t* vbase = p.vt + bh * HD * (size_t)p.kv_stride;
 
     // Q fragments (MFMA B operand): lane holds Q[query j][d = ks*32 + g*8 .. +8]
-    u32x4 qf[2][KS];
+    u32x4 qf[QS][KS];
 #pragma unroll
-    for (int qs = 0; qs < 2; ++qs) {
-        const int qrow = min(q0 + wave * 32 + qs * 16 + j, p.T - 1);
+    for (int qs = 0; qs < QS; ++qs) {
+        const int qrow = min(q0 + wave * (QS * 16) + qs * 16 + j, p.T - 1);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[qs][ks] = ld16(qbase + (size_t)qrow * HD + ks * 32 + g * 8);
     }
-    f32x4 o[2][DT];
+    f32x4 o[QS][DT];
 #pragma unroll
-    for (int qs = 0; qs < 2; ++qs)
+    for (int qs = 0; qs < QS; ++qs)
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[qs][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    float m_run[QS], l_run[QS];
+#pragma unroll
+    for (int qs = 0; qs < QS; ++qs) { m_run[qs] = -INFINITY; l_run[qs] = 0.f; }
 
-    const int kv_end = CAUSAL ? min(p.T, q0 + 128) : p.T;
+    const int kv_end = CAUSAL ? min(p.T, q0 + QB) : p.T;
     const int nkt = (kv_end + 63) / 64;
-    constexpr int KLD = (64 * KCH) / 256, VLD = (HD * 8) / 256;  // staged 16-B chunks per thread
+    constexpr int KLD = (64 * KCH) / NTH, VLD = (HD * 8) / NTH;  // staged 16-B chunks per thread
     u32x4 rk[KLD], rv[VLD];
     auto load_tile = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < KLD; ++i) {
-            const int c = tid + i * 256, row = c / KCH, ch = c % KCH;
+            const int c = tid + i * NTH, row = c / KCH, ch = c % KCH;
             rk[i] = ld16(kbase + (size_t)(kt * 64 + row) * HD + ch * 8);
         }
 #pragma unroll
         for (int i = 0; i < VLD; ++i) {
-            const int c = tid + i * 256, row = c >> 3, ch = c & 7;
+            const int c = tid + i * NTH, row = c >> 3, ch = c & 7;
             rv[i] = ld16(vbase + (size_t)row * p.kv_stride + kt * 64 + ch * 8);
         }
     };
     auto store_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < KLD; ++i) {
-            const int c = tid + i * 256;
+            const int c = tid + i * NTH;
             st16(k_lds + swz_k<HD>(c / KCH, c % KCH), rk[i]);
         }
 #pragma unroll
         for (int i = 0; i < VLD; ++i) {
-            const int c = tid + i * 256;
+            const int c = tid + i * NTH;
             st16(v_lds + swz_v(c >> 3, c & 7), rv[i]);
         }
     };
@@ -187,9 +193,9 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
         if (kt + 1 < nkt) load_tile(kt + 1);
         const int k0 = kt * 64;
         // ---- S^T = K Q^T
-        f32x4 sacc[2][4];
+        f32x4 sacc[QS][4];
 #pragma unroll
-        for (int qs = 0; qs < 2; ++qs)
+        for (int qs = 0; qs < QS; ++qs)
 #pragma unroll
             for (int sub = 0; sub < 4; ++sub) sacc[qs][sub] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -197,14 +203,14 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const u32x4 kf = ld16(k_lds + swz_k<HD>(sub * 16 + j, ks * 4 + g));
-                sacc[0][sub] = mfma16(kf, qf[0][ks], sacc[0][sub]);
-                sacc[1][sub] = mfma16(kf, qf[1][ks], sacc[1][sub]);
+#pragma unroll
+                for (int qs = 0; qs < QS; ++qs) sacc[qs][sub] = mfma16(kf, qf[qs][ks], sacc[qs][sub]);
             }
         // ---- online softmax (lane owns query j of each q-subtile; keys spread over regs and the 4 lane groups)
-        u32x4 pb[2][2];
+        u32x4 pb[QS][2];
 #pragma unroll
-        for (int qs = 0; qs < 2; ++qs) {
-            const int query = q0 + wave * 32 + qs * 16 + j;
+        for (int qs = 0; qs < QS; ++qs) {
+            const int query = q0 + wave * (QS * 16) + qs * 16 + j;
             float mx = -INFINITY;
 #pragma unroll
             for (int sub = 0; sub < 4; ++sub)
@@ -250,19 +256,19 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
                 const u32x2 lo = ld8(v_lds + swz_v(row, c0) + within);
                 const u32x2 hi = ld8(v_lds + swz_v(row, c0 + 2) + within);
                 const u32x4 vf = {lo[0], lo[1], hi[0], hi[1]};
-                o[0][dt] = mfma16(vf, pb[0][kh], o[0][dt]);
-                o[1][dt] = mfma16(vf, pb[1][kh], o[1][dt]);
+#pragma unroll
+                for (int qs = 0; qs < QS; ++qs) o[qs][dt] = mfma16(vf, pb[qs][kh], o[qs][dt]);
             }
         __syncthreads();
     }
     // ---- normalise and store: lane holds out[query j][d = dt*16 + g*4 .. +4]
 #pragma unroll
-    for (int qs = 0; qs < 2; ++qs) {
+    for (int qs = 0; qs < QS; ++qs) {
         float l = l_run[qs];
         l += shfl_xor(l, 16);
         l += shfl_xor(l, 32);
         const float inv = 1.0f / l;
-        const int query = q0 + wave * 32 + qs * 16 + j;
+        const int query = q0 + wave * (QS * 16) + qs * 16 + j;
         if (query < p.T) {
             bf16_t* dst = p.out + ((size_t)b * p.T + query) * ((size_t)p.H * HD) + h * HD + g * 4;
 #pragma unroll
@@ -274,14 +280,23 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
     }
 }
 
+template <int HD, int WAVES, int QS>
+static void launch_attention_v(const AttnArgs& a, hipStream_t s) {
+    const int QB = WAVES * QS * 16;
+    const dim3 grid((a.T + QB - 1) / QB, a.H, a.B), block(WAVES * 64);
+    if (a.causal) VC_LAUNCH((attention_kernel<HD, true, WAVES, QS>), grid, block, 0, s, a);
+    else VC_LAUNCH((attention_kernel<HD, false, WAVES, QS>), grid, block, 0, s, a);
+}
+
 void launch_attention(const AttnArgs& a, hipStream_t s) {
-    const dim3 grid((a.T + 127) / 128, a.H, a.B), block(256);
+    // hd 128: 8 waves x 16 queries keeps the kernel near 128 VGPRs (the 4x32 form needs ~250 -> 1 wave/SIMD).
+    static const int variant = getenv("VC_ATTN_VARIANT") ? atoi(getenv("VC_ATTN_VARIANT")) : 0;
     if (a.hd == 128) {
-        if (a.causal) VC_LAUNCH((attention_kernel<128, true>), grid, block, 0, s, a);
-        else VC_LAUNCH((attention_kernel<128, false>), grid, block, 0, s, a);
+        if (variant == 1) launch_attention_v<128, 4, 2>(a, s);
+        else launch_attention_v<128, 8, 1>(a, s);
     } else {
-        if (a.causal) VC_LAUNCH((attention_kernel<64, true>), grid, block, 0, s, a);
-        else VC_LAUNCH((attention_kernel<64, false>), grid, block, 0, s, a);
+        if (variant == 1) launch_attention_v<64, 8, 1>(a, s);
+        else launch_attention_v<64, 4, 2>(a, s);
     }
 }
 
