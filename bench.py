@@ -104,11 +104,15 @@ def cpu_baseline(cfg, B_for_rate: int, new_tokens: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=8, help="samples per GPU (BASELINE configs[1]: 8)")
     ap.add_argument("--new-tokens", type=int, default=128)
     ap.add_argument("--model", default="7b", choices=["7b", "13b"])
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="batches in flight per GPU: independent sessions (own stream + KV cache, shared weights) driven by "
+                         "host threads, so one batch's MFMA-bound prefill and per-launch ramps overlap another's "
+                         "HBM-bound decode.  1 = strictly one batch at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pmc-traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass")
@@ -142,22 +146,38 @@ def main():
     ids = np.stack([synth.synth_prompt_ids(cfg.vocab_size, "vcoder_ds", sample=first + b) for b in range(B)])
     imgs, segs, deps = (torch.from_numpy(a).cuda() for a in synth.synth_batch(B, cfg.vit_image_size, first))
 
-    def step():
-        out = eng.generate_greedy(ids, imgs, segs, deps, max_new_tokens=N_new, eos_token_id=None)
+    import threading
+
+    n_sess = max(1, min(args.inflight, args.steps))
+    sessions = [eng] + [eng.fork() for _ in range(n_sess - 1)]
+
+    def run_steps(k: int):
+        """k steps (= k batches of B per GPU), distributed round-robin over the in-flight sessions; every step is the
+        complete hot path for its batch.  Token ids are all-gathered across ranks once per step, in step order."""
+        outs = [None] * k
+
+        def worker(si):
+            for j in range(si, k, n_sess):
+                outs[j] = sessions[si].generate_greedy(ids, imgs, segs, deps, max_new_tokens=N_new, eos_token_id=None)
+
+        ths = [threading.Thread(target=worker, args=(si,)) for si in range(n_sess)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
         # the one exchange: all-gather of the token stream (RCCL over xGMI), once per batch; no-op for N=1
-        return gather_token_ids(out, dist, device="cuda")
+        return [gather_token_ids(o, dist, device="cuda") for o in outs]
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    if args.warmup > 0:
+        run_steps(max(args.warmup, n_sess))  # every session captures its decode graph before the timed region
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    run_steps(args.steps)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -178,7 +198,8 @@ def main():
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"VCoder-DS LLaVA-1.5-{args.model} bf16, batch={B}/GPU RGB+seg+depth 336x336, "
                                    f"prefill S={S}, {N_new}-token greedy decode", "global_batch": world * B,
-                       "parallelism": f"dp{world}", "weights": "seeded synthetic (vcoder_amd/synth.py)"},
+                       "parallelism": f"dp{world}", "weights": "seeded synthetic (vcoder_amd/synth.py)",
+                       "in_flight_batches_per_gpu": n_sess},
             "phase_ms": timings,
             "roofline": {"bound": "hbm", "kernel": "gemv_kernel (decode weight streaming)", "achieved": ach,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,

@@ -63,6 +63,9 @@ void* vc_stream(vc_ctx* ctx);                 /* the hipStream_t all work of thi
 
 int vc_model_create(vc_ctx* ctx, const vc_model_cfg* cfg, vc_model** out);
 void vc_model_destroy(vc_model* m);
+/* another session (own stream = `ctx`, own KV cache / workspaces / graph) on the finalized weights of `parent`,
+ * shared read-only; `parent` must outlive it.  Sessions on different contexts may run concurrently. */
+int vc_model_create_shared(vc_ctx* ctx, vc_model* parent, vc_model** out);
 
 /* ---- weights: replaces HF from_pretrained() of builder.py:93-108 + CLIPVisionTower.load_model() ---- */
 /* hf_key = state-dict key of the reference checkpoint; host_ptr = row-major tensor of `dtype`. */

@@ -138,3 +138,16 @@ def test_dropin_module_aliases():
         for k in [k for k in sys.modules if k.startswith("vcoder_llava")]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+def test_forked_session_shares_weights(model):
+    """vc_model_create_shared: a second session (own stream / KV cache / graph) on the same weights gives identical
+    results, and closing it leaves the parent usable."""
+    g, cfg, ids, imgs, segs, deps = _fx()
+    a = model.engine.generate_greedy(ids, imgs, segs, deps, max_new_tokens=3)
+    f = model.engine.fork()
+    b = f.generate_greedy(ids[:1], imgs[:1], segs[:1], deps[:1], max_new_tokens=3)   # different batch size: own buffers
+    c = model.engine.generate_greedy(ids, imgs, segs, deps, max_new_tokens=3)
+    assert np.array_equal(a[:1], b) and np.array_equal(a, c)
+    f.close()
+    assert np.array_equal(model.engine.generate_greedy(ids, imgs, segs, deps, max_new_tokens=3), a)

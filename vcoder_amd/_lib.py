@@ -42,6 +42,8 @@ def declare(lib: C.CDLL) -> C.CDLL:
     lib.vc_stream.argtypes = [vp]
     lib.vc_stream.restype = vp
     lib.vc_model_create.argtypes = [vp, C.POINTER(ModelCfg), C.POINTER(vp)]
+    lib.vc_model_create_shared.argtypes = [vp, vp, C.POINTER(vp)]
+    lib.vc_model_create_shared.restype = C.c_int
     lib.vc_model_destroy.argtypes = [vp]
     lib.vc_model_destroy.restype = None
     lib.vc_model_load_tensor.argtypes = [vp, C.c_char_p, vp, i32, i64p, i32]

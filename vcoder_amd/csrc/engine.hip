@@ -100,6 +100,7 @@ struct vc_model {
     vc_model_cfg c;
     hipStream_t st;
     bool finalized = false;
+    bool owns_weights = true;  // false: a session created by vc_model_create_shared (weights belong to the parent)
     // derived
     int P, Tv, Kpatch, Kpad, hd, vhd, npart;
     std::vector<void*> owned;  // every weight allocation
@@ -820,11 +821,38 @@ VC_API int vc_model_create(vc_ctx* ctx, const vc_model_cfg* cfg, vc_model** out)
     GUARD_END(ctx)
 }
 
+/* A second SESSION on the same weights: own stream (the new ctx), own workspaces / KV cache / hipGraph; weight tensors are
+ * shared read-only with `parent` (which must be finalized and must outlive the session).  Several sessions let the GPU
+ * overlap one batch's MFMA-bound prefill and per-launch ramps with another batch's HBM-bound decode. */
+VC_API int vc_model_create_shared(vc_ctx* ctx, vc_model* parent, vc_model** out) {
+    if (!ctx || !parent || !out) return VC_ERR_INVALID;
+    *out = nullptr;
+    GUARD_BEGIN
+    REQUIRE(parent->finalized, VC_ERR_STATE, "parent model is not finalized");
+    vc_model* m = new vc_model();
+    m->ctx = ctx;
+    m->c = parent->c;
+    m->st = ctx->stream;
+    m->finalized = true;
+    m->owns_weights = false;
+    m->P = parent->P; m->Tv = parent->Tv; m->Kpatch = parent->Kpatch; m->Kpad = parent->Kpad;
+    m->hd = parent->hd; m->vhd = parent->vhd; m->npart = parent->npart;
+    m->vit_cls = parent->vit_cls; m->vit_pos = parent->vit_pos; m->vit_pre_w = parent->vit_pre_w;
+    m->vit_pre_b = parent->vit_pre_b; m->vit_patch_w = parent->vit_patch_w;
+    m->vit = parent->vit; m->llm = parent->llm; m->mm = parent->mm; m->seg = parent->seg;
+    m->embed = parent->embed; m->lm_head = parent->lm_head; m->lm_head_p = parent->lm_head_p;
+    m->final_norm = parent->final_norm; m->rope_cos = parent->rope_cos; m->rope_sin = parent->rope_sin;
+    for (auto& e : m->ev) HIPCHK(hipEventCreate(&e));
+    *out = m;
+    GUARD_END(ctx)
+}
+
 VC_API void vc_model_destroy(vc_model* m) {
     if (!m) return;
     (void)hipStreamSynchronize(m->st);
     if (m->graph) (void)hipGraphExecDestroy(m->graph);
-    for (void* p : m->owned) (void)hipFree(p);
+    if (m->owns_weights)
+        for (void* p : m->owned) (void)hipFree(p);
     for (Buf* b : {&m->stage, &m->stage2, &m->v_pixels, &m->v_cols, &m->v_patches, &m->v_x, &m->v_xn, &m->v_qkv, &m->v_q,
                    &m->v_k, &m->v_vt, &m->v_attn, &m->v_h, &m->v_sel, &m->v_mid, &m->feats, &m->x, &m->xn, &m->qkv, &m->q,
                    &m->attn, &m->h, &m->kc, &m->vtc, &m->row_src, &m->last_idx, &m->xl, &m->logits_all, &m->x_dec,

@@ -22,18 +22,25 @@ class HipEngine:
     """One model replica on one GPU (one HIP stream).  `lib` is injectable ONLY for the CPU emulator tests;
     product code always goes through `_lib.load()`, which has no fallback."""
 
-    def __init__(self, cfg: VCoderConfig, device_index: int = 0, lib: Optional[C.CDLL] = None):
+    def __init__(self, cfg: VCoderConfig, device_index: int = 0, lib: Optional[C.CDLL] = None, _parent=None):
         cfg.validate()
         self.cfg = cfg
         self.lib = lib if lib is not None else _lib.load()
+        self._lib_arg = lib
         if lib is not None:
             _lib.declare(self.lib)
         self.device_index = device_index
         self._ctx = C.c_void_p()
         self._model = C.c_void_p()
+        self._parent = _parent
+        self.last_S = 0
         rc = self.lib.vc_init(device_index, C.byref(self._ctx))
         if rc != 0 or not self._ctx:
             raise RuntimeError(f"vc_init(device {device_index}) failed with status {rc}: no usable HIP device")
+        if _parent is not None:  # a session sharing the parent's weights (own stream, KV cache, workspaces, graph)
+            self._check(self.lib.vc_model_create_shared(self._ctx, _parent._model, C.byref(self._model)))
+            self.finalized = True
+            return
         c = _lib.ModelCfg(
             variant=_lib.VARIANTS[cfg.variant], vit_hidden=cfg.mm_hidden_size, vit_heads=cfg.vit_num_heads,
             vit_ffn=cfg.vit_intermediate_size, vit_layers=cfg.vit_num_layers, vit_layers_used=cfg.vit_layers_used,
@@ -48,6 +55,14 @@ class HipEngine:
         self._check(self.lib.vc_model_create(self._ctx, C.byref(c), C.byref(self._model)))
         self.finalized = False
         self.last_S = 0
+
+    def fork(self) -> "HipEngine":
+        """A new session on the same (finalized) weights: own HIP stream, KV cache and hipGraph.  Sessions can be
+        driven from different host threads concurrently (ctypes releases the GIL during the C calls)."""
+        if not self.finalized:
+            raise RuntimeError("fork() needs a finalized engine")
+        root = self._parent if self._parent is not None else self
+        return HipEngine(self.cfg, self.device_index, lib=self._lib_arg, _parent=root)
 
     # ---- plumbing -----------------------------------------------------------------------------------
     def _check(self, rc: int) -> int:
