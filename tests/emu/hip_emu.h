@@ -76,7 +76,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
 typedef int hipError_t;
 static const hipError_t hipSuccess = 0;
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
-enum hipStreamCaptureMode { hipStreamCaptureModeGlobal };
+enum hipStreamCaptureMode { hipStreamCaptureModeGlobal, hipStreamCaptureModeThreadLocal };
 inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = aligned_alloc(256, (n + 255) / 256 * 256 + 256); return *p ? 0 : 1; }
 template <class T> inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }

@@ -602,7 +602,8 @@ void ensure_graph(vc_model* m, int B, int max_new, int eos_id, int pad_id) {
         return;
     if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
     hipGraph_t g = nullptr;
-    HIPCHK(hipStreamBeginCapture(m->st, hipStreamCaptureModeGlobal));
+    // thread-local mode: other sessions (host threads) may allocate / copy while this thread captures
+    HIPCHK(hipStreamBeginCapture(m->st, hipStreamCaptureModeThreadLocal));
     try {
         enqueue_decode_step(m, B, max_new, eos_id, pad_id);
     } catch (...) {
