@@ -155,16 +155,22 @@ def main():
         """k steps (= k batches of B per GPU), distributed round-robin over the in-flight sessions; every step is the
         complete hot path for its batch.  Token ids are all-gathered across ranks once per step, in step order."""
         outs = [None] * k
+        errs = []
 
         def worker(si):
-            for j in range(si, k, n_sess):
-                outs[j] = sessions[si].generate_greedy(ids, imgs, segs, deps, max_new_tokens=N_new, eos_token_id=None)
+            try:
+                for j in range(si, k, n_sess):
+                    outs[j] = sessions[si].generate_greedy(ids, imgs, segs, deps, max_new_tokens=N_new, eos_token_id=None)
+            except BaseException as e:  # surface failures of a session thread in the main thread
+                errs.append(e)
 
         ths = [threading.Thread(target=worker, args=(si,)) for si in range(n_sess)]
         for t in ths:
             t.start()
         for t in ths:
             t.join()
+        if errs:
+            raise errs[0]
         # the one exchange: all-gather of the token stream (RCCL over xGMI), once per batch; no-op for N=1
         return [gather_token_ids(o, dist, device="cuda") for o in outs]
 
