@@ -115,7 +115,8 @@ def main():
                          "HBM-bound decode.  1 = strictly one batch at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pmc-traffic-bytes", type=float, default=None,
-                    help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass")
+                    help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass "
+                         "(default: profiles/r01_pmc_traffic.json, the committed FETCH_SIZE pass of this kernel)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -194,6 +195,11 @@ def main():
     prof = eng.profile_decode_gemv(min(B, 16), reps=3)
 
     if rank == 0:
+        traffic = args.pmc_traffic_bytes
+        pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if traffic is None and args.model == "7b" and B == 8 and os.path.exists(pmc_file):
+            with open(pmc_file) as f:   # separate --pmc pass, gfx950 x2 correction applied (see the file)
+                traffic = json.load(f)["hbm_read_bytes_per_launch"]
         S = 64 + 2 * cfg.num_patches
         ach = prof["avg_bytes"] / (prof["avg_us"] * 1e-6) / 1e9
         res = {
@@ -209,7 +215,7 @@ def main():
             "phase_ms": timings,
             "roofline": {"bound": "hbm", "kernel": "gemv_kernel (decode weight streaming)", "achieved": ach,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": args.pmc_traffic_bytes, "avg_launch_us": prof["avg_us"],
+                         "traffic": traffic, "avg_launch_us": prof["avg_us"],
                          "algorithmic_bytes_per_launch": prof["avg_bytes"],
                          "launches_per_decode_step": prof["launches_per_step"]},
         }
