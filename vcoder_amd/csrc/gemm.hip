@@ -13,6 +13,8 @@
 // The WEIGHT tile is the MFMA A operand and the ACTIVATION tile the B operand, so each lane ends up with
 // 4 consecutive output features of one token: epilogues (bias, GELU, residual add, SwiGLU) are lane-local
 // and stores are 8/16 bytes per lane.
+#include <stdlib.h>
+
 #include "vc_device.h"
 #include "kernels.h"
 
@@ -148,10 +150,122 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     }
 }
 
+// ---- variant with LDS-DMA staging: same tile / swizzle / MFMA schedule, but the next k-tile is copied global->LDS
+// by global_load_lds_dwordx4 (no staging VGPRs, no ds_write_b128 — the ds_write pass was the larger half of this
+// kernel's LDS time) while the MFMAs of the current tile run; the compiler's vmcnt(0) before the tile's closing
+// barrier retires it.  One wave-instruction fills 8 swizzled rows (1 KiB): lane p writes slot p%8 of row p/8, so it
+// FETCHES chunk (p%8)^(row&7) of that row.
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_dma_kernel(GemmArgs p) {
+    VC_DYNAMIC_SMEM(char, smem);  // [2 stages][W tile | A tile]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wm = wave & 1;
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    int tm, tn;
+    tile_coords(blockIdx.x, tiles_m * tiles_n, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const char* a_src[4];
+    const char* w_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = i * 4 + wave;              // 16 pieces of 8 rows per operand tile
+        const int row = piece * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ (row & 7);    // source chunk that belongs at LDS slot lane&7 of this row
+        const int am = min(m0 + row, p.M - 1), wr = min(n0 + row, p.N - 1);
+        a_src[i] = reinterpret_cast<const char*>(p.A + (size_t)am * p.lda) + chunk * 16;
+        w_src[i] = reinterpret_cast<const char*>(p.W + (size_t)wr * p.ldw) + chunk * 16;
+    }
+    auto issue_tile = [&](int kt, int stage) {
+        char* ws = smem + stage * (2 * TILE_BYTES);
+        char* as = ws + TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = i * 4 + wave;
+            glds16(w_src[i] + (size_t)kt * (BK * 2), ws + piece * 1024);
+            glds16(a_src[i] + (size_t)kt * (BK * 2), as + piece * 1024);
+        }
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nk = p.K / BK;
+    issue_tile(0, 0);
+    __syncthreads();
+    const int frow = lane & 15, fchunk = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) issue_tile(kt + 1, (kt + 1) & 1);
+        const char* ws = smem + (kt & 1) * (2 * TILE_BYTES);
+        const char* as = ws + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 fw[4], fa[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fw[i] = ld16(ws + swz(wn * 64 + i * 16 + frow, ks * 4 + fchunk));
+                fa[i] = ld16(as + swz(wm * 64 + i * 16 + frow, ks * 4 + fchunk));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fw[i], fa[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds out[m][n..n+3], m = .. + (lane&15), n = .. + (lane>>4)*4
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
+        if (n >= p.N) continue;
+        f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bv = ld16f(p.bias + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + wm * 64 + j * 16 + (lane & 15);
+            if (m >= p.M) continue;
+            f32x4 v = acc[i][j] + bv;
+            if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_QGELU || EPI == EPI_BF16_GELU) {
+                if constexpr (EPI == EPI_BF16_QGELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+                }
+                if constexpr (EPI == EPI_BF16_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = erf_gelu(v[e]);
+                }
+                u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                st8(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo + n, o);
+            } else if constexpr (EPI == EPI_F32) {
+                st16f(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n, v);
+            } else if constexpr (EPI == EPI_RESID_F32) {
+                float* o = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n;
+                st16f(o, ld16f(o) + v);
+            } else {  // EPI_SWIGLU: (g0,u0,g1,u1) -> 2 outputs
+                const uint32_t o = pack_bf2(silu(v[0]) * v[1], silu(v[2]) * v[3]);
+                *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo + (n >> 1)) = o;
+            }
+        }
+    }
+}
+
 void launch_gemm(const GemmArgs& a, int epilogue, hipStream_t s) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const dim3 grid(tiles), block(256);
     const size_t shmem = 4 * TILE_BYTES;
+    static const int variant = getenv("VC_GEMM_VARIANT") ? atoi(getenv("VC_GEMM_VARIANT")) : 0;
+    if (variant == 1) {  // LDS-DMA staging
+        switch (epilogue) {
+            case EPI_BF16: VC_LAUNCH((gemm_bf16_dma_kernel<EPI_BF16>), grid, block, shmem, s, a); break;
+            case EPI_BF16_QGELU: VC_LAUNCH((gemm_bf16_dma_kernel<EPI_BF16_QGELU>), grid, block, shmem, s, a); break;
+            case EPI_BF16_GELU: VC_LAUNCH((gemm_bf16_dma_kernel<EPI_BF16_GELU>), grid, block, shmem, s, a); break;
+            case EPI_F32: VC_LAUNCH((gemm_bf16_dma_kernel<EPI_F32>), grid, block, shmem, s, a); break;
+            case EPI_RESID_F32: VC_LAUNCH((gemm_bf16_dma_kernel<EPI_RESID_F32>), grid, block, shmem, s, a); break;
+            default: VC_LAUNCH((gemm_bf16_dma_kernel<EPI_SWIGLU>), grid, block, shmem, s, a); break;
+        }
+        return;
+    }
     switch (epilogue) {
         case EPI_BF16: VC_LAUNCH((gemm_bf16_kernel<EPI_BF16>), grid, block, shmem, s, a); break;
         case EPI_BF16_QGELU: VC_LAUNCH((gemm_bf16_kernel<EPI_BF16_QGELU>), grid, block, shmem, s, a); break;

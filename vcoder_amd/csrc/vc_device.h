@@ -79,6 +79,20 @@ VC_DEV void st8(void* p, u32x2 v) { *reinterpret_cast<u32x2*>(p) = v; }
 VC_DEV f32x4 ld16f(const void* p) { return *reinterpret_cast<const f32x4*>(p); }
 VC_DEV void st16f(void* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
+// ---- LDS-DMA: 16 bytes per lane, global -> LDS without passing through VGPRs (global_load_lds_dwordx4).
+// The LDS destination is WAVE-UNIFORM base + lane*16; the global source is per lane (so LDS swizzles are applied to
+// the source address).  Completion is tracked by vmcnt; hipcc waits vmcnt(0) before the next __syncthreads().
+#ifdef VC_EMU
+VC_DEV void glds16(const void* gsrc_lane, void* lds_wave_base) {
+    memcpy(reinterpret_cast<char*>(lds_wave_base) + lane_id() * 16, gsrc_lane, 16);
+}
+#else
+VC_DEV void glds16(const void* gsrc_lane, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+#endif
+
 // ---- activations (fp32) --------------------------------------------------------------------
 VC_DEV float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }   // x*sigmoid(1.702x)
 VC_DEV float erf_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
