@@ -80,3 +80,16 @@ def test_fused_decode_kernels(be):
     kc.check_attention_decode_fused(be, 1, 2, 128, 128)
     kc.check_attention_decode_fused(be, 1, 1, 64, 5)
     kc.check_greedy_embed(be, 3, 320, 256)
+
+
+def test_alternate_kernel_variants():
+    """The non-default template variants (register-staged GEMM, 4x32 attention) stay correct: same cases in a
+    subprocess with the tuning knobs flipped (the library reads them once)."""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, VC_GEMM_VARIANT="0", VC_ATTN_VARIANT="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
+                        "test_gemm or test_attention"], env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]

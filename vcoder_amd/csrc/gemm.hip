@@ -7,9 +7,10 @@
 //  [HF] llama/modeling_llama.py:174-176,254-256,280; vcoder_llava/model/multimodal_projector/builder.py:42-46).
 //
 // Design (CDNA4): 128x128 output tile per 256-thread workgroup (4 waves, 2x2, 64x64 each = 4x4 MFMA
-// 16x16x32 fragments, 64 fp32 accumulators per lane), BK=64, two LDS stages (64 KiB) filled through
-// registers (global_load_dwordx4 issued before the MFMAs of the current tile, ds_write_b128 after),
-// XOR-swizzled LDS rows so the ds_read_b128 fragment reads are bank-conflict free.
+// 16x16x32 fragments, 64 fp32 accumulators per lane), BK=64, two LDS stages (64 KiB -> 2 workgroups/CU),
+// XOR-swizzled LDS rows so the ds_read_b128 fragment reads are bank-conflict free.  Two staging forms:
+// LDS-DMA (global_load_lds_dwordx4, default) and register staging (global_load_dwordx4 issued before the
+// MFMAs of the current tile, ds_write_b128 after).
 // The WEIGHT tile is the MFMA A operand and the ACTIVATION tile the B operand, so each lane ends up with
 // 4 consecutive output features of one token: epilogues (bias, GELU, residual add, SwiGLU) are lane-local
 // and stores are 8/16 bytes per lane.
@@ -254,8 +255,10 @@ void launch_gemm(const GemmArgs& a, int epilogue, hipStream_t s) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const dim3 grid(tiles), block(256);
     const size_t shmem = 4 * TILE_BYTES;
-    static const int variant = getenv("VC_GEMM_VARIANT") ? atoi(getenv("VC_GEMM_VARIANT")) : 0;
-    if (variant == 1) {  // LDS-DMA staging
+    // default: LDS-DMA staging (+8..16 % on MI355X: 870-990 vs 790-900 TFLOP/s on the ViT / Llama shapes);
+    // VC_GEMM_VARIANT=0 selects the register-staged form
+    static const int variant = getenv("VC_GEMM_VARIANT") ? atoi(getenv("VC_GEMM_VARIANT")) : 1;
+    if (variant == 1) {
         switch (epilogue) {
             case EPI_BF16: VC_LAUNCH((gemm_bf16_dma_kernel<EPI_BF16>), grid, block, shmem, s, a); break;
             case EPI_BF16_QGELU: VC_LAUNCH((gemm_bf16_dma_kernel<EPI_BF16_QGELU>), grid, block, shmem, s, a); break;
