@@ -710,6 +710,8 @@ void finish_prefill(vc_model* m, float* logits_all_host) {
 // C ABI
 // =================================================================================================
 #define GUARD_BEGIN try {
+// the HIP current device is per host thread: sessions may be driven from any thread
+#define USE_DEVICE(ctxp) HIPCHK(hipSetDevice((ctxp)->device))
 #define GUARD_END(ctxp)                                   \
     }                                                     \
     catch (const Fail& f) {                               \
@@ -744,6 +746,7 @@ VC_API void vc_shutdown(vc_ctx* ctx) {
 VC_API const char* vc_last_error(vc_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 VC_API int vc_synchronize(vc_ctx* ctx) {
     GUARD_BEGIN
+    USE_DEVICE(ctx);
     HIPCHK(hipStreamSynchronize(ctx->stream));
     GUARD_END(ctx)
 }
@@ -754,6 +757,7 @@ VC_API int vc_model_create(vc_ctx* ctx, const vc_model_cfg* cfg, vc_model** out)
     *out = nullptr;
     vc_model* m = nullptr;
     GUARD_BEGIN
+    USE_DEVICE(ctx);
     const vc_model_cfg& c = *cfg;
     REQUIRE(c.variant >= 0 && c.variant <= 2, VC_ERR_INVALID, "bad variant %d", c.variant);
     REQUIRE(c.hidden % c.heads == 0 && c.vit_hidden % c.vit_heads == 0, VC_ERR_INVALID, "hidden %% heads != 0");
@@ -829,6 +833,7 @@ VC_API int vc_model_create_shared(vc_ctx* ctx, vc_model* parent, vc_model** out)
     if (!ctx || !parent || !out) return VC_ERR_INVALID;
     *out = nullptr;
     GUARD_BEGIN
+    USE_DEVICE(ctx);
     REQUIRE(parent->finalized, VC_ERR_STATE, "parent model is not finalized");
     vc_model* m = new vc_model();
     m->ctx = ctx;
@@ -850,6 +855,7 @@ VC_API int vc_model_create_shared(vc_ctx* ctx, vc_model* parent, vc_model** out)
 
 VC_API void vc_model_destroy(vc_model* m) {
     if (!m) return;
+    (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->st);
     if (m->graph) (void)hipGraphExecDestroy(m->graph);
     if (m->owns_weights)
@@ -870,6 +876,7 @@ VC_API int vc_model_load_tensor(vc_model* m, const char* hf_key, const void* hos
     if (!m) return VC_ERR_INVALID;
     int rc = VC_OK;
     GUARD_BEGIN
+    USE_DEVICE(m->ctx);
     REQUIRE(hf_key && host_ptr && shape && ndim >= 1 && ndim <= 8, VC_ERR_INVALID, "bad load_tensor arguments");
     REQUIRE(dtype == VC_F32 || dtype == VC_BF16, VC_ERR_INVALID, "dtype must be VC_F32 or VC_BF16");
     REQUIRE(!m->finalized, VC_ERR_STATE, "model already finalized");
@@ -889,6 +896,7 @@ VC_API int vc_model_synth_tensor(vc_model* m, const char* hf_key, const int64_t*
     if (!m) return VC_ERR_INVALID;
     int rc = VC_OK;
     GUARD_BEGIN
+    USE_DEVICE(m->ctx);
     REQUIRE(hf_key && shape && ndim >= 1 && ndim <= 8, VC_ERR_INVALID, "bad synth_tensor arguments");
     REQUIRE(!m->finalized, VC_ERR_STATE, "model already finalized");
     size_t numel = 1;
@@ -905,6 +913,7 @@ VC_API int vc_model_synth_tensor(vc_model* m, const char* hf_key, const int64_t*
 VC_API int vc_model_finalize(vc_model* m) {
     if (!m) return VC_ERR_INVALID;
     GUARD_BEGIN
+    USE_DEVICE(m->ctx);
     if (m->finalized) return VC_OK;
     for (auto& kv : m->need) REQUIRE(kv.second, VC_ERR_STATE, "missing tensor '%s'", kv.first.c_str());
     const vc_model_cfg& c = m->c;
@@ -956,6 +965,7 @@ VC_API int vc_model_finalize(vc_model* m) {
 VC_API int vc_encode(vc_model* m, int modality, const float* pixels, int pixels_on_device, int B, float* out) {
     if (!m) return VC_ERR_INVALID;
     GUARD_BEGIN
+    USE_DEVICE(m->ctx);
     REQUIRE(m->finalized, VC_ERR_STATE, "vc_model_finalize() has not been called");
     REQUIRE(pixels && B >= 1 && modality >= 0 && modality <= 2, VC_ERR_INVALID, "bad encode arguments");
     REQUIRE(modality == VC_MOD_IMAGE || m->c.variant != VC_VARIANT_LLAVA, VC_ERR_INVALID, "llava has no seg/depth encoder");
@@ -978,6 +988,7 @@ VC_API int vc_prefill(vc_model* m, const int64_t* ids, int B, int T, const float
                       float* logits_all, int* S_out) {
     if (!m) return VC_ERR_INVALID;
     GUARD_BEGIN
+    USE_DEVICE(m->ctx);
     m->cur_pos = -1;
     do_prefill(m, ids, B, T, img, seg, depth, pixels_on_device, has_attention_mask, 64, logits_all, S_out);
     finish_prefill(m, logits_all);
@@ -994,6 +1005,7 @@ VC_API int vc_prefill_embeds_only(vc_model* m, const int64_t* ids, int B, int T,
                                   int* S_out) {
     if (!m) return VC_ERR_INVALID;
     GUARD_BEGIN
+    USE_DEVICE(m->ctx);
     m->cur_pos = -1;
     int S = 0;
     do_prefill(m, ids, B, T, img, seg, depth, pixels_on_device, has_attention_mask, 64, nullptr, &S);
@@ -1005,6 +1017,7 @@ VC_API int vc_prefill_embeds_only(vc_model* m, const int64_t* ids, int B, int T,
 VC_API int vc_decode_step(vc_model* m, const int32_t* tok, float* logits, int32_t* next_tok) {
     if (!m) return VC_ERR_INVALID;
     GUARD_BEGIN
+    USE_DEVICE(m->ctx);
     REQUIRE(m->cur_pos >= 0, VC_ERR_STATE, "vc_decode_step before vc_prefill");
     REQUIRE(m->cur_pos + 1 <= m->capS, VC_ERR_STATE, "KV cache full (%d)", m->capS);
     const int B = m->curB;
@@ -1030,6 +1043,7 @@ VC_API int vc_generate_greedy(vc_model* m, const int64_t* ids, int B, int T, con
                               int32_t* out_ids, int* n_generated) {
     if (!m) return VC_ERR_INVALID;
     GUARD_BEGIN
+    USE_DEVICE(m->ctx);
     REQUIRE(max_new >= 1 && out_ids, VC_ERR_INVALID, "bad max_new/out_ids");
     m->cur_pos = -1;
     int S = 0;
@@ -1099,6 +1113,7 @@ VC_API int vc_last_timings(vc_model* m, float* encode_ms, float* prefill_ms, flo
 VC_API int vc_profile_decode_gemv(vc_model* m, int B, int reps, int* launches, double* avg_us, double* avg_bytes) {
     if (!m) return VC_ERR_INVALID;
     GUARD_BEGIN
+    USE_DEVICE(m->ctx);
     REQUIRE(m->finalized && B >= 1 && B <= 16 && reps >= 1, VC_ERR_INVALID, "bad profile arguments");
     const vc_model_cfg& c = m->c;
     const int D = c.hidden, F = c.ffn;
