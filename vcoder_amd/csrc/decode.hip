@@ -57,24 +57,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
     const float* nw = nullptr;
     float rstd = 0.f;
     const int row_bytes = p.K * 2 + 16;
-    if constexpr (NORM && STAGE) {
-        const int Mp = p.M <= 8 ? 8 : 16;
-        for (int r = wave; r < Mp; r += WAVES) {  // 1/rms per row from the producer's partials (fixed order)
-            float ss = 0.f;
-            for (int q = lane; q < p.npart; q += 64) ss += p.ssq_in[(size_t)r * p.npart + q];
-            ss = wave_sum(ss);
-            if (lane == 0) rstd_s[r] = rsqrtf(ss / (float)p.K + p.eps);
-        }
-        __syncthreads();
-        const int cpr = p.K >> 3;
-        for (int idx = tid; idx < Mp * cpr; idx += WAVES * 64) {
-            const int r = idx / cpr, c = idx - r * cpr;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (r < p.M) v = norm_frag(p.Xf + (size_t)r * p.K + c * 8, p.norm_w + c * 8, rstd_s[r]);
-            st16(dsm + (size_t)r * row_bytes + c * 16, v);
-        }
-        __syncthreads();
-    }
     const char* xs = dsm + (size_t)m * row_bytes + g * 16;
     if constexpr (NORM && !STAGE) {
         // per-row 1/rms from the producer's deterministic partial sums (fixed summation order -> bit-reproducible)
@@ -93,14 +75,38 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
     f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // K loop, software-pipelined over batches of U k-tiles with two register sets: the weight loads of batch b+1 are in
+    // flight while the MFMAs of batch b run, and the first batch is requested BEFORE the normalise prologue.
     constexpr int U = 8 / NT;
-    int kt = kt0;
-    for (; kt + U <= kt1; kt += U) {
-        u32x4 wv[NT][U], xv[U];
+    const int nb = (kt1 - kt0) / U;  // full batches of this wave (wave-uniform)
+    u32x4 wa[NT][U], wb[NT][U];
+    auto load_w = [&](u32x4 (&w)[NT][U], int kt) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) wv[t][u] = ld16_stream(wp[t] + (size_t)(kt + u) * 512);
+            for (int t = 0; t < NT; ++t) w[t][u] = ld16_stream(wp[t] + (size_t)(kt + u) * 512);
+    };
+    if (nb > 0) load_w(wa, kt0);
+    if constexpr (NORM && STAGE) {
+        const int Mp = p.M <= 8 ? 8 : 16;
+        for (int r = wave; r < Mp; r += WAVES) {  // 1/rms per row from the producer's partials (fixed order)
+            float ss = 0.f;
+            for (int q = lane; q < p.npart; q += 64) ss += p.ssq_in[(size_t)r * p.npart + q];
+            ss = wave_sum(ss);
+            if (lane == 0) rstd_s[r] = rsqrtf(ss / (float)p.K + p.eps);
+        }
+        __syncthreads();
+        const int cpr = p.K >> 3;
+        for (int idx = tid; idx < Mp * cpr; idx += WAVES * 64) {
+            const int r = idx / cpr, c = idx - r * cpr;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (r < p.M) v = norm_frag(p.Xf + (size_t)r * p.K + c * 8, p.norm_w + c * 8, rstd_s[r]);
+            st16(dsm + (size_t)r * row_bytes + c * 16, v);
+        }
+        __syncthreads();
+    }
+    auto compute = [&](u32x4 (&w)[NT][U], int kt) {
+        u32x4 xv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if constexpr (NORM && STAGE) xv[u] = mvalid ? ld16(xs + (kt + u) * 64) : u32x4{0u, 0u, 0u, 0u};
@@ -110,9 +116,17 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = mfma16(wv[t][u], xv[u], acc[t]);
+            for (int t = 0; t < NT; ++t) acc[t] = mfma16(w[t][u], xv[u], acc[t]);
+    };
+    for (int b = 0; b < nb; b += 2) {
+        if (b + 1 < nb) load_w(wb, kt0 + (b + 1) * U);
+        compute(wa, kt0 + b * U);
+        if (b + 1 < nb) {
+            if (b + 2 < nb) load_w(wa, kt0 + (b + 2) * U);
+            compute(wb, kt0 + (b + 1) * U);
+        }
     }
-    for (; kt < kt1; ++kt) {
+    for (int kt = kt0 + nb * U; kt < kt1; ++kt) {
         u32x4 xv = {0u, 0u, 0u, 0u};
         if (mvalid) {
             if constexpr (NORM && STAGE) xv = ld16(xs + kt * 64);
