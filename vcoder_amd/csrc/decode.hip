@@ -96,12 +96,23 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
             if (lane == 0) rstd_s[r] = rsqrtf(ss / (float)p.K + p.eps);
         }
         __syncthreads();
+        // normalise: thread t owns 16-byte chunks t, t+512, ... of EVERY row; the row loop is unrolled so the 4 loads of
+        // all rows are in flight together (an un-unrolled loop pays one L2 round trip per row)
         const int cpr = p.K >> 3;
-        for (int idx = tid; idx < Mp * cpr; idx += WAVES * 64) {
-            const int r = idx / cpr, c = idx - r * cpr;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (r < p.M) v = norm_frag(p.Xf + (size_t)r * p.K + c * 8, p.norm_w + c * 8, rstd_s[r]);
-            st16(dsm + (size_t)r * row_bytes + c * 16, v);
+        for (int c = tid; c < cpr; c += WAVES * 64) {
+            const f32x4 w0 = ld16f(p.norm_w + c * 8), w1 = ld16f(p.norm_w + c * 8 + 4);
+#pragma unroll 8
+            for (int r = 0; r < Mp; ++r) {
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (r < p.M) {
+                    const float* xr = p.Xf + (size_t)r * p.K + c * 8;
+                    const f32x4 x0 = ld16f(xr), x1 = ld16f(xr + 4);
+                    const float rs = rstd_s[r];
+                    v = u32x4{pack_bf2((x0[0] * rs) * w0[0], (x0[1] * rs) * w0[1]), pack_bf2((x0[2] * rs) * w0[2], (x0[3] * rs) * w0[3]),
+                              pack_bf2((x1[0] * rs) * w1[0], (x1[1] * rs) * w1[1]), pack_bf2((x1[2] * rs) * w1[2], (x1[3] * rs) * w1[3])};
+                }
+                st16(dsm + (size_t)r * row_bytes + c * 16, v);
+            }
         }
         __syncthreads();
     }
