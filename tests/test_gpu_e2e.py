@@ -128,3 +128,54 @@ def test_true_dims_against_oracle():
     if m > 4 * e1:
         assert int(np.argmax(last)) == int(np.argmax(o_last))
     eng.close()
+
+
+def test_concurrent_sessions_match_single_session():
+    """3 sessions on shared weights driven from 3 host threads at once (what bench.py does with --inflight 3) produce
+    exactly the ids of a lone session — the overlap changes timing only."""
+    import threading
+
+    eng = e2e_cases.engine_for("vcoder_ds")
+    g, cfg, ids, imgs, segs, deps = e2e_cases.fixture_inputs("ds_img_depth_seg")
+    ref = eng.generate_greedy(ids, imgs, segs, deps, max_new_tokens=8)
+    sessions = [eng, eng.fork(), eng.fork()]
+    outs = [[None] * 4 for _ in sessions]
+
+    def work(si):
+        for j in range(4):
+            outs[si][j] = sessions[si].generate_greedy(ids, imgs, segs, deps, max_new_tokens=8)
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for si in range(3):
+        for j in range(4):
+            assert np.array_equal(outs[si][j], ref)
+    for s in sessions[1:]:
+        s.close()
+
+
+def test_true_dims_13b_geometry():
+    """VCoder-DS 13b geometry (D 5120, 40 heads, F 13824) cut to 2 layers, batch 16 (BASELINE config 3): runs the
+    direct (non-LDS-staged) fused-norm GEMV path (16 x 5120 rows do not fit) and 16-row decode; prefill == incremental."""
+    cfg = vcfg.vicuna_13b("vcoder_ds")
+    cfg.num_hidden_layers = 2
+    cfg.vit_num_layers = 2
+    eng = HipEngine(cfg)
+    eng.load_synthetic(5)
+    eng.finalize()
+    B = 16
+    ids = np.stack([synth.synth_prompt_ids(cfg.vocab_size, "vcoder_ds", sample=b) for b in range(B)])
+    imgs, segs, deps = synth.synth_batch(B, 336)
+    out = eng.generate_greedy(ids, imgs, segs, deps, max_new_tokens=3)
+    assert out.shape == (B, 3)
+    last, _, S = eng.prefill(ids, imgs, segs, deps)
+    assert S == 1216 and np.array_equal(np.argmax(last, -1), out[:, 0])
+    _, nxt = eng.decode_step(out[:, 0])
+    assert np.array_equal(nxt, out[:, 1])
+    # rows of the batch are independent: sample 5 alone gives the same first tokens
+    one = eng.generate_greedy(ids[5:6], imgs[5:6], segs[5:6], deps[5:6], max_new_tokens=3)
+    assert np.array_equal(one[0], out[5])
+    eng.close()
