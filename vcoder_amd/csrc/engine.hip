@@ -58,6 +58,11 @@ struct Fail {
 
 inline size_t rup(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// stream of the session whose C-ABI call is running on this host thread (set by USE_DEVICE); zero-fills of freshly
+// allocated buffers are enqueued on it — never on the legacy NULL stream, which would implicitly synchronise with (and
+// invalidate the graph capture of) other sessions' streams
+thread_local hipStream_t t_stream = nullptr;
+
 struct Buf {  // grow-only device buffer
     void* p = nullptr;
     size_t cap = 0;
@@ -68,7 +73,10 @@ struct Buf {  // grow-only device buffer
         cap = 0;
         HIPCHK(hipMalloc(&p, rup(bytes, 256)));
         cap = rup(bytes, 256);
-        if (zero) HIPCHK(hipMemset(p, 0, cap));
+        if (zero) {
+            HIPCHK(hipMemsetAsync(p, 0, cap, t_stream));
+            HIPCHK(hipStreamSynchronize(t_stream));
+        }
     }
     void release() {
         if (p) (void)hipFree(p);
@@ -140,7 +148,10 @@ namespace {
 template <class T> T* walloc(vc_model* m, size_t n, bool zero = false) {
     void* p = nullptr;
     HIPCHK(hipMalloc(&p, rup(n * sizeof(T), 256)));
-    if (zero) HIPCHK(hipMemset(p, 0, rup(n * sizeof(T), 256)));
+    if (zero) {
+        HIPCHK(hipMemsetAsync(p, 0, rup(n * sizeof(T), 256), m->st));
+        HIPCHK(hipStreamSynchronize(m->st));
+    }
     m->owned.push_back(p);
     return reinterpret_cast<T*>(p);
 }
@@ -711,7 +722,11 @@ void finish_prefill(vc_model* m, float* logits_all_host) {
 // =================================================================================================
 #define GUARD_BEGIN try {
 // the HIP current device is per host thread: sessions may be driven from any thread
-#define USE_DEVICE(ctxp) HIPCHK(hipSetDevice((ctxp)->device))
+#define USE_DEVICE(ctxp)                       \
+    do {                                       \
+        HIPCHK(hipSetDevice((ctxp)->device)); \
+        t_stream = (ctxp)->stream;             \
+    } while (0)
 #define GUARD_END(ctxp)                                   \
     }                                                     \
     catch (const Fail& f) {                               \
@@ -734,7 +749,8 @@ VC_API int vc_init(int device_id, vc_ctx** out) {
     REQUIRE(n > 0 && device_id >= 0 && device_id < n, VC_ERR_HIP, "no HIP device %d (found %d)", device_id, n);
     HIPCHK(hipSetDevice(device_id));
     ctx->device = device_id;
-    HIPCHK(hipStreamCreate(&ctx->stream));
+    // non-blocking: no implicit synchronisation with the legacy NULL stream (torch's default stream, other sessions)
+    HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     *out = ctx;
     GUARD_END(ctx)
 }
@@ -954,8 +970,9 @@ VC_API int vc_model_finalize(vc_model* m) {
     }
     m->rope_cos = walloc<float>(m, hc.size());
     m->rope_sin = walloc<float>(m, hs.size());
-    HIPCHK(hipMemcpy(m->rope_cos, hc.data(), hc.size() * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(m->rope_sin, hs.data(), hs.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpyAsync(m->rope_cos, hc.data(), hc.size() * 4, hipMemcpyHostToDevice, m->st));
+    HIPCHK(hipMemcpyAsync(m->rope_sin, hs.data(), hs.size() * 4, hipMemcpyHostToDevice, m->st));
+    HIPCHK(hipStreamSynchronize(m->st));
     m->stage.release();
     m->stage2.release();
     m->finalized = true;
@@ -995,7 +1012,10 @@ VC_API int vc_prefill(vc_model* m, const int64_t* ids, int B, int T, const float
     // greedy choice of the prefill logits, so that vc_decode_step(tok = NULL) continues the sequence
     launch_greedy_embed(greedy_embed_args(m, B, 0, -1, 0, 0), m->st);
     HIPCHK(hipStreamSynchronize(m->st));
-    if (logits_last) HIPCHK(hipMemcpy(logits_last, m->logits.p, (size_t)B * m->c.vocab * 4, hipMemcpyDeviceToHost));
+    if (logits_last) {
+        HIPCHK(hipMemcpyAsync(logits_last, m->logits.p, (size_t)B * m->c.vocab * 4, hipMemcpyDeviceToHost, m->st));
+        HIPCHK(hipStreamSynchronize(m->st));
+    }
     GUARD_END(m->ctx)
 }
 
@@ -1010,7 +1030,10 @@ VC_API int vc_prefill_embeds_only(vc_model* m, const int64_t* ids, int B, int T,
     int S = 0;
     do_prefill(m, ids, B, T, img, seg, depth, pixels_on_device, has_attention_mask, 64, nullptr, &S);
     if (S_out) *S_out = S;
-    if (out_host) HIPCHK(hipMemcpy(out_host, m->x.p, (size_t)B * S * m->c.hidden * 4, hipMemcpyDeviceToHost));
+    if (out_host) {
+        HIPCHK(hipMemcpyAsync(out_host, m->x.p, (size_t)B * S * m->c.hidden * 4, hipMemcpyDeviceToHost, m->st));
+        HIPCHK(hipStreamSynchronize(m->st));
+    }
     GUARD_END(m->ctx)
 }
 
@@ -1061,7 +1084,8 @@ VC_API int vc_generate_greedy(vc_model* m, const int64_t* ids, int B, int T, con
     std::vector<int> fin(B);
     auto all_finished = [&]() {
         if (eos_id < 0) return false;
-        HIPCHK(hipMemcpy(fin.data(), m->finished.p, B * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpyAsync(fin.data(), m->finished.p, B * 4, hipMemcpyDeviceToHost, m->st));
+        HIPCHK(hipStreamSynchronize(m->st));
         for (int b = 0; b < B; ++b)
             if (!fin[b]) return false;
         return true;

@@ -152,6 +152,8 @@ class HipEngine:
                 t = a.to(torch.float32).contiguous()
                 keep.append(t)
                 ptrs.append(C.c_void_p(t.data_ptr()))
+                # the engine's stream is non-blocking: make whatever produced the tensor on torch's stream visible
+                torch.cuda.current_stream(t.device).synchronize()
             else:
                 if _is_torch(a):
                     a = a.detach().float().cpu().numpy()
