@@ -77,6 +77,11 @@ int vc_model_synth_tensor(vc_model* m, const char* hf_key, const int64_t* shape,
 /* after the last tensor: fuses QKV / interleaves gate-up / packs decode copies; fails listing a missing key */
 int vc_model_finalize(vc_model* m);
 
+/* arithmetic mode: 0 = bf16 MFMA operands, fp32 accumulate/residual/softmax (default; what bench.py measures);
+ * 1 = strict: fp32 activations end to end on fp32 MFMA (slow) — within ~1e-5 of the reference's fp32 CPU path, for the
+ * "logits within 1e-3, greedy ids bit-exact" bar of BASELINE.json.  Takes effect at the next prefill. */
+int vc_model_set_precision(vc_model* m, int mode);
+
 /* ---- hot path ------------------------------------------------------------------------------ */
 /* encode_images / encode_seg_images / encode_depth_images (vcoder_ds_llava_arch.py:106-119):
  * pixels fp32 [B,3,S,S] (host, or device when pixels_on_device) -> projected features fp32 [B,P,hidden] on host. */

@@ -59,6 +59,14 @@ void vck_greedy_embed(const float* logits, int* next_tok, int* out_ids, int* fin
                       int* pos_dev, int* ctx_dev, int advance, void* stream);
 void vck_embed_tokens_ssq(const int* tok, const uint16_t* embed, float* x, float* ssq, int B, int D, int npart, void* stream);
 void vck_advance(int* step_dev, int* pos_dev, int* ctx_dev, void* stream);
+/* strict (fp32-faithful) kernels behind vc_model_set_precision(m, 1): fp32 activations x bf16 weights on the exact
+ * v_mfma_f32_16x16x4_f32, fp32 attention, fp32 head split + RoPE.  epi ids as vck_gemm (all outputs fp32). */
+void vck_gemm_f32(const float* A, const uint16_t* W, const float* bias, float* out, int M, int N, int K, int lda, int ldw,
+                  int ldo, int epi, void* stream);
+void vck_attention_f32(const float* q, const float* k, const float* v, float* out, int B, int H, int Tq, int hd, int q_stride,
+                       int kv_stride, int causal, int Tk, const int* pos0_dev, float scale, void* stream);
+void vck_qkv_rope_f32(const float* qkv, float* q, float* k, float* v, int B, int T, int H, int hd, int q_stride, int kv_stride,
+                      const int* pos0_dev, const float* rope_cos, const float* rope_sin, void* stream);
 /* deterministic synthetic tensors (vcoder_amd/synth.py) and dtype converts */
 void vck_synth_bf16(uint16_t* out, uint64_t n, uint32_t tseed, float offset, float halfwidth, void* stream);
 void vck_synth_f32(float* out, uint64_t n, uint32_t tseed, float offset, float halfwidth, void* stream);

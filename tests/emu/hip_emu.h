@@ -160,6 +160,30 @@ template <class T> inline T shfl(T v, int src) {
     return r;
 }
 
+// v_mfma_f32_16x16x4_f32: A[i][k] in lane i+16k, B[k][j] in lane j+16k, D[i][j] in lane j+16*(i/4) reg i%4
+inline f32x4 mfma16_f32(float a, float b, f32x4 c) {
+    auto& w = vc_emu::g_cur->blk->waves[vc_emu::g_cur->wave];
+    const int lane = vc_emu::g_cur->lane;
+    memcpy(w.xchg[lane], &a, 4);
+    memcpy(w.xchg[lane] + 4, &b, 4);
+    vc_emu::wave_sync();
+    const int j = lane & 15;
+    f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int i = (lane >> 4) * 4 + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) {
+            float af, bf;
+            memcpy(&af, w.xchg[i + 16 * k], 4);
+            memcpy(&bf, w.xchg[j + 16 * k] + 4, 4);
+            acc = fmaf(af, bf, acc);
+        }
+        d[r] = acc;
+    }
+    vc_emu::wave_sync();
+    return d;
+}
+
 // v_mfma_f32_16x16x32_bf16 under the assumed fragment maps (see vc_device.h header).
 inline f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
     auto& w = vc_emu::g_cur->blk->waves[vc_emu::g_cur->wave];

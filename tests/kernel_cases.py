@@ -507,3 +507,67 @@ def check_greedy_embed(be, B, V, D):
     last = [pad if exp[b] == eos else exp[b] for b in range(B)]
     assert np.array_equal(be.host_f32(x)[:B], embed[last])
     assert np.abs(be.host_f32(ssq)[:B].sum(-1) / (embed[last] ** 2).sum(-1) - 1).max() < 1e-5
+
+
+# ---- strict (fp32) kernels ----------------------------------------------------------------------------------------
+def check_gemm_f32(be, M, N, K, epi, bias=True, seed=0):
+    rng = np.random.RandomState(seed)
+    A = rng.randn(M, K).astype(np.float32)
+    W = bf16_round(rng.randn(N, K) * 0.05)
+    b = (rng.randn(N) * 0.1).astype(np.float32) if bias else None
+    t = torch.from_numpy(A.astype(np.float64) @ W.T.astype(np.float64) + (b if bias else 0.0)).float()
+    r0 = rng.randn(M, N).astype(np.float32)
+    out = be.f32(r0) if epi == 4 else be.zeros((M, N // 2 if epi == 5 else N), "f32")
+    if epi == 1:
+        t = cpu_ref.quick_gelu(t)
+    elif epi == 2:
+        t = torch.nn.functional.gelu(t)
+    elif epi == 4:
+        t = t + torch.from_numpy(r0)
+    elif epi == 5:
+        t = torch.nn.functional.silu(t[:, 0::2]) * t[:, 1::2]
+    Ad, Wd, bd = be.f32(A), be.bf16(W), (be.f32(b) if bias else None)
+    _call(be, "vck_gemm_f32", Ad, Wd, bd, out, M, N, K, K, K, N // 2 if epi == 5 else N, epi)
+    e = rel_err(be.host_f32(out), t.numpy())
+    assert e < 2e-6, f"gemm_f32 M{M} N{N} K{K} epi{epi}: rel err {e}"
+
+
+def check_attention_f32(be, B, H, T, hd, causal, decode_pos=None, seed=0):
+    rng = np.random.RandomState(seed)
+    scale = 1.0 / math.sqrt(hd)
+    if decode_pos is None:
+        q, k, v = (rng.randn(B, H, T, hd).astype(np.float32) for _ in range(3))
+        out = be.zeros((B * T, H * hd), "f32")
+        qd, kd, vd = be.f32(q), be.f32(k), be.f32(v)
+        _call(be, "vck_attention_f32", qd, kd, vd, out, B, H, T, hd, T, T, int(causal), T, None, scale)
+        ref = cpu_ref.softmax_attention(torch.from_numpy(q), torch.from_numpy(k), torch.from_numpy(v), scale, causal,
+                                        cpu_ref.Rounder(False)).transpose(1, 2).reshape(B * T, H * hd).numpy()
+    else:
+        S = decode_pos + 9
+        q = rng.randn(B, H, 1, hd).astype(np.float32)
+        k, v = (rng.randn(B, H, S, hd).astype(np.float32) for _ in range(2))
+        out = be.zeros((B, H * hd), "f32")
+        qd, kd, vd, pd = be.f32(q), be.f32(k), be.f32(v), be.i32([decode_pos])
+        _call(be, "vck_attention_f32", qd, kd, vd, out, B, H, 1, hd, 1, S, 1, 0, pd, scale)
+        n = decode_pos + 1
+        ref = cpu_ref.softmax_attention(torch.from_numpy(q), torch.from_numpy(k[:, :, :n]), torch.from_numpy(v[:, :, :n]),
+                                        scale, False, cpu_ref.Rounder(False)).transpose(1, 2).reshape(B, H * hd).numpy()
+    err = np.abs(be.host_f32(out) - ref).max()
+    assert err < 2e-6 * max(1.0, np.abs(ref).max()) + 2e-6, f"attention_f32 abs err {err}"
+
+
+def check_qkv_rope_f32(be, B, T, H, hd, pos0):
+    rng = np.random.RandomState(3)
+    D = H * hd
+    S = pos0 + T + 3
+    qkv = rng.randn(B * T, 3 * D).astype(np.float32)
+    q, k, v = be.zeros((B, H, T, hd), "f32"), be.zeros((B, H, S, hd), "f32"), be.zeros((B, H, S, hd), "f32")
+    cos, sin = rope_tables(S, hd)
+    qd, cd, sd, pd = be.f32(qkv), be.f32(cos), be.f32(sin), be.i32([pos0])
+    _call(be, "vck_qkv_rope_f32", qd, q, k, v, B, T, H, hd, T, S, pd, cd, sd)
+    t = torch.from_numpy(qkv).reshape(B, T, 3, H, hd).permute(2, 0, 3, 1, 4)
+    c, s_ = cpu_ref.rope_cos_sin(torch.arange(pos0, pos0 + T), hd, 10000.0)
+    rq, rk = cpu_ref.apply_rope(t[0], c, s_).numpy(), cpu_ref.apply_rope(t[1], c, s_).numpy()
+    assert np.abs(be.host_f32(q) - rq).max() < 1e-5
+    gk, gv = be.host_f32(k), be.host_f32(v)
+    assert np.abs(gk[:, :, pos0:pos0 + T] - rk).max() < 1e-5 and np.array_equal(gv[:, :, pos0:pos0 + T], t[2].numpy())

@@ -18,3 +18,10 @@ def emu_lib():
 def test_ds_reference_order_fixture(emu_lib):
     r = e2e_cases.check_fixture("ds_img_only", lib=emu_lib, check_generate=False, check_emu_oracle=False)
     assert r["logits_err_vs_ref"] < e2e_cases.TOL_VS_FP32_REF
+
+
+@pytest.mark.parametrize("name", ["ds_img_depth_seg", "vc_img_text_seg", "llava_img"])
+def test_strict_mode_meets_north_star_bar(emu_lib, name):
+    """Strict (fp32) mode through the same engine: logits within 1e-3 of the real reference, ids bit-exact."""
+    r = e2e_cases.check_fixture_strict(name, lib=emu_lib)
+    assert r["logits_err"] < 1e-4 and r["decode_logits_err"] < 1e-4

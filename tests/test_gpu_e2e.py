@@ -179,3 +179,39 @@ def test_true_dims_13b_geometry():
     one = eng.generate_greedy(ids[5:6], imgs[5:6], segs[5:6], deps[5:6], max_new_tokens=3)
     assert np.array_equal(one[0], out[5])
     eng.close()
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_fixture_strict_mode(name):
+    """The literal BASELINE.json bar through the HIP path: logits within 1e-3 of the reference's fp32 CPU outputs at
+    every position and decode step, greedy ids bit-exact (vc_model_set_precision = strict, fp32 MFMA)."""
+    print(name, e2e_cases.check_fixture_strict(name))
+
+
+def test_true_dims_strict_against_fp32_oracle():
+    """True 7b / ViT-L dims (2+2 layers), strict mode vs the fp32 oracle (= the reference's CPU path): 1e-3."""
+    import torch
+    import cpu_ref
+
+    cfg = vcfg.vicuna_7b("vcoder_ds")
+    cfg.num_hidden_layers = 2
+    cfg.vit_num_layers = 3
+    sd = synth.synth_state_dict(cfg, 11)
+    eng = HipEngine(cfg)
+    eng.load_synthetic(11)
+    eng.finalize()
+    eng.set_precision("strict")
+    ids = synth.synth_prompt_ids(cfg.vocab_size, "vcoder_ds", sample=3)[None]
+    imgs, segs, deps = synth.synth_batch(1, 336, first=3)
+    last, _, S = eng.prefill(ids, imgs, segs, deps)
+    lg2, _ = eng.decode_step(np.argmax(last, -1).astype(np.int32))
+    om = cpu_ref.OracleModel(cfg, sd, emu_bf16=False)
+    t = torch.from_numpy
+    with torch.no_grad():
+        o_last, cache = om.forward(ids.tolist(), t(imgs), t(segs), t(deps), last_only=True)
+        o_lg2 = om.decode_step(np.argmax(last, -1).tolist(), cache)
+    e1 = np.abs(last - o_last[:, -1].numpy()).max()
+    e2 = np.abs(lg2 - o_lg2[:, -1].numpy()).max()
+    print(f"true-dims STRICT parity: prefill err={e1:.2e} decode err={e2:.2e}")
+    assert e1 < 1e-3 and e2 < 1e-3 and int(np.argmax(last)) == int(np.argmax(o_last[:, -1].numpy()))
+    eng.close()

@@ -75,3 +75,16 @@ def test_fused_decode_kernels(be):
     kc.check_attention_decode_fused(be, 2, 4, 128, 1343)
     kc.check_attention_decode_fused(be, 1, 2, 64, 5)
     kc.check_greedy_embed(be, 8, 32000, 4096)
+
+
+def test_strict_fp32_kernels(be):
+    kc.check_gemm_f32(be, 1216, 12288, 4096, 3, bias=False)
+    kc.check_gemm_f32(be, 577, 4096, 1024, 1)
+    kc.check_gemm_f32(be, 300, 1024, 4096, 4)
+    kc.check_gemm_f32(be, 70, 22016, 4096, 5, bias=False)
+    kc.check_gemm_f32(be, 576, 1024, 588, 3, bias=False)
+    kc.check_attention_f32(be, 2, 16, 577, 64, False)
+    kc.check_attention_f32(be, 1, 4, 1216, 128, True)
+    kc.check_attention_f32(be, 8, 32, 1, 128, True, decode_pos=1300)
+    kc.check_qkv_rope_f32(be, 2, 64, 32, 128, 0)
+    kc.check_qkv_rope_f32(be, 8, 1, 32, 128, 1216)

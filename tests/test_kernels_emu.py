@@ -82,6 +82,19 @@ def test_fused_decode_kernels(be):
     kc.check_greedy_embed(be, 3, 320, 256)
 
 
+def test_strict_fp32_kernels(be):
+    kc.check_gemm_f32(be, 70, 72, 40, 3)
+    kc.check_gemm_f32(be, 64, 64, 64, 1)
+    kc.check_gemm_f32(be, 33, 128, 100, 4, bias=False)
+    kc.check_gemm_f32(be, 20, 64, 32, 5, bias=False)
+    kc.check_gemm_f32(be, 5, 16, 588, 2)
+    kc.check_attention_f32(be, 1, 2, 17, 64, False)
+    kc.check_attention_f32(be, 1, 2, 40, 128, True)
+    kc.check_attention_f32(be, 2, 2, 1, 128, True, decode_pos=37)
+    kc.check_qkv_rope_f32(be, 2, 5, 2, 128, 0)
+    kc.check_qkv_rope_f32(be, 1, 1, 2, 64, 11)
+
+
 def test_alternate_kernel_variants():
     """The non-default template variants (register-staged GEMM, 4x32 attention) stay correct: same cases in a
     subprocess with the tuning knobs flipped (the library reads them once)."""

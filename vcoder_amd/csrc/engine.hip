@@ -108,7 +108,11 @@ struct vc_model {
     vc_model_cfg c;
     hipStream_t st;
     bool finalized = false;
-    bool owns_weights = true;  // false: a session created by vc_model_create_shared (weights belong to the parent)
+    bool owns_weights = true;
+    int precision = 0;  // 0: bf16 MFMA fast path; 1: strict fp32 path (strict.hip)
+    Buf s_cols, s_patches, s_vx, s_vxn, s_vqkv, s_vq, s_vk, s_vv, s_vattn, s_vh, s_sel, s_mid, s_feats;
+    Buf s_xn, s_qkv, s_q, s_attn, s_h, s_kc, s_vc, s_xl;
+    int s_capB = 0, s_capS = 0;  // false: a session created by vc_model_create_shared (weights belong to the parent)
     // derived
     int P, Tv, Kpatch, Kpad, hd, vhd, npart;
     std::vector<void*> owned;  // every weight allocation
@@ -428,6 +432,141 @@ void run_vit_and_adapters(vc_model* m, const float* const pix[3], int pixels_on_
 }
 
 // ------------------------------------------------------------------------------------------------
+// STRICT (fp32-faithful) path: same sequence of operations, fp32 activations, strict.hip kernels, no graph.
+void gemm32(vc_model* m, const float* A, const bf16_t* W, const float* bias, float* out, int M, int N, int K, int lda,
+            int ldw, int ldo, int epi) {
+    GemmF32Args a{A, W, bias, out, M, N, K, lda, ldw, ldo};
+    launch_gemm_f32(a, epi, m->st);
+}
+
+void run_vit_and_adapters_strict(vc_model* m, const float* const pix[3], int pixels_on_device, int B) {
+    const vc_model_cfg& c = m->c;
+    const int Dv = c.vit_hidden, Fv = c.vit_ffn, H = c.vit_heads, Tv = m->Tv, P = m->P, D = c.hidden;
+    int nmod = 0, order[3];
+    for (int k = 0; k < 3; ++k)
+        if (pix[k]) order[nmod++] = k;
+    const int N = nmod * B;
+    const size_t img_elems = (size_t)3 * c.vit_image * c.vit_image;
+    m->v_pixels.ensure((size_t)N * img_elems * 4);
+    for (int i = 0; i < nmod; ++i)
+        HIPCHK(hipMemcpyAsync(m->v_pixels.as<float>() + (size_t)i * B * img_elems, pix[order[i]], (size_t)B * img_elems * 4,
+                              pixels_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, m->st));
+    const int M = N * Tv, Mp = N * P;
+    m->s_cols.ensure((size_t)Mp * m->Kpatch * 4);
+    m->s_patches.ensure((size_t)Mp * Dv * 4);
+    m->s_vx.ensure((size_t)M * Dv * 4);
+    m->s_vxn.ensure((size_t)M * Dv * 4);
+    m->s_vqkv.ensure((size_t)M * 3 * Dv * 4);
+    m->s_vq.ensure((size_t)M * Dv * 4);
+    m->s_vk.ensure((size_t)M * Dv * 4);
+    m->s_vv.ensure((size_t)M * Dv * 4);
+    m->s_vattn.ensure((size_t)M * Dv * 4);
+    m->s_vh.ensure((size_t)M * std::max(Fv, D) * 4);
+    float *x = m->s_vx.as<float>(), *xn = m->s_vxn.as<float>();
+    launch_im2col_f32(m->v_pixels.as<float>(), m->s_cols.as<float>(), N, c.vit_image, c.vit_patch, m->st);
+    gemm32(m, m->s_cols.as<float>(), m->vit_patch_w, nullptr, m->s_patches.as<float>(), Mp, Dv, m->Kpatch, m->Kpatch, m->Kpad,
+           Dv, EPI_F32);
+    launch_vit_embed_ln(m->s_patches.as<float>(), m->vit_cls, m->vit_pos, m->vit_pre_w, m->vit_pre_b, x, N, Tv, Dv,
+                        c.vit_ln_eps, m->st);
+    for (int j = 0; j < c.vit_layers_used; ++j) {
+        const VitLayer& L = m->vit[j];
+        launch_layernorm_f32(x, L.ln1_w, L.ln1_b, xn, M, Dv, c.vit_ln_eps, m->st);
+        gemm32(m, xn, L.qkv_w, L.qkv_b, m->s_vqkv.as<float>(), M, 3 * Dv, Dv, Dv, Dv, 3 * Dv, EPI_F32);
+        QkvF32Args qa{m->s_vqkv.as<float>(), m->s_vq.as<float>(), m->s_vk.as<float>(), m->s_vv.as<float>(), N, Tv, H, m->vhd,
+                      Tv, Tv, nullptr, nullptr, nullptr};
+        launch_qkv_rope_f32(qa, m->st);
+        AttnF32Args aa{m->s_vq.as<float>(), m->s_vk.as<float>(), m->s_vv.as<float>(), m->s_vattn.as<float>(), N, H, Tv, m->vhd,
+                       Tv, Tv, 0, Tv, nullptr, 1.0f / sqrtf((float)m->vhd)};
+        launch_attention_f32(aa, m->st);
+        gemm32(m, m->s_vattn.as<float>(), L.out_w, L.out_b, x, M, Dv, Dv, Dv, Dv, Dv, EPI_RESID_F32);
+        launch_layernorm_f32(x, L.ln2_w, L.ln2_b, xn, M, Dv, c.vit_ln_eps, m->st);
+        gemm32(m, xn, L.fc1_w, L.fc1_b, m->s_vh.as<float>(), M, Fv, Dv, Dv, Dv, Fv, EPI_BF16_QGELU);
+        gemm32(m, m->s_vh.as<float>(), L.fc2_w, L.fc2_b, x, M, Dv, Fv, Fv, Fv, Dv, EPI_RESID_F32);
+    }
+    const int skip = c.vit_keep_cls ? 0 : 1;
+    const int R = Tv - skip;
+    m->s_sel.ensure((size_t)N * R * Dv * 4);
+    launch_select_rows_f32(x, m->s_sel.as<float>(), N, Tv, skip, Dv, m->st);
+    m->s_feats.ensure((size_t)N * R * D * 4);
+    m->s_mid.ensure((size_t)N * R * D * 4);
+    for (int k = 0; k < 3; ++k) m->feat_rows[k] = 0;
+    for (int i = 0; i < nmod; ++i) {
+        const int mod = order[i];
+        const Projector& pj = mod == VC_MOD_IMAGE ? m->mm : m->seg;  // quirk 1: depth -> seg_mm_projector
+        const int rows = B * R;
+        const float* in = m->s_sel.as<float>() + (size_t)i * rows * Dv;
+        float* out = m->s_feats.as<float>() + (size_t)i * rows * D;
+        m->feat_off[mod] = i * rows;
+        m->feat_rows[mod] = rows;
+        if (pj.depth == 0) {
+            REQUIRE(Dv == D, VC_ERR_INVALID, "identity projector needs mm_hidden_size == hidden_size");
+            HIPCHK(hipMemcpyAsync(out, in, (size_t)rows * D * 4, hipMemcpyDeviceToDevice, m->st));
+            continue;
+        }
+        const float* cur = in;
+        int K = Dv;
+        for (int l = 0; l < pj.depth; ++l) {
+            const bool last = l == pj.depth - 1;
+            float* dst = last ? out : (l % 2 == 0 ? m->s_mid.as<float>() : m->s_vh.as<float>());
+            gemm32(m, cur, pj.w[l], pj.b[l], dst, rows, D, K, K, K, D, last ? EPI_F32 : EPI_BF16_GELU);
+            cur = dst;
+            K = D;
+        }
+    }
+}
+
+void ensure_strict(vc_model* m, int B, int Scap) {
+    const vc_model_cfg& c = m->c;
+    const int D = c.hidden, F = c.ffn, H = c.heads;
+    if (B != m->s_capB || Scap > m->s_capS) {
+        const size_t per_layer = (size_t)B * H * Scap * m->hd;
+        m->s_kc.release();
+        m->s_vc.release();
+        m->s_kc.ensure(per_layer * c.layers * 4, true);
+        m->s_vc.ensure(per_layer * c.layers * 4, true);
+        m->s_capB = B;
+        m->s_capS = Scap;
+    }
+    const size_t Mr = (size_t)B * Scap;
+    m->s_xn.ensure(Mr * D * 4);
+    m->s_qkv.ensure(Mr * 3 * D * 4);
+    m->s_q.ensure(Mr * D * 4);
+    m->s_attn.ensure(Mr * D * 4);
+    m->s_h.ensure(Mr * F * 4);
+    m->s_xl.ensure((size_t)rup(B, 16) * D * 4);
+}
+float* s_kcache(vc_model* m, int l) { return m->s_kc.as<float>() + (size_t)l * m->s_capB * m->c.heads * m->s_capS * m->hd; }
+float* s_vcache(vc_model* m, int l) { return m->s_vc.as<float>() + (size_t)l * m->s_capB * m->c.heads * m->s_capS * m->hd; }
+
+// one decoder stack pass over `T` new tokens per sample starting at the device-scalar position (prefill: pos 0)
+void run_llm_layers_strict(vc_model* m, float* x, int B, int T, const int* pos_dev) {
+    const vc_model_cfg& c = m->c;
+    const int D = c.hidden, F = c.ffn, H = c.heads, M = B * T;
+    float *xn = m->s_xn.as<float>(), *qkv = m->s_qkv.as<float>(), *q = m->s_q.as<float>(), *at = m->s_attn.as<float>(),
+          *h = m->s_h.as<float>();
+    for (int l = 0; l < c.layers; ++l) {
+        const LlmLayer& L = m->llm[l];
+        launch_rmsnorm_f32(x, nullptr, L.in_norm, xn, M, D, c.rms_eps, m->st);
+        gemm32(m, xn, L.qkv_w, nullptr, qkv, M, 3 * D, D, D, D, 3 * D, EPI_F32);
+        QkvF32Args qa{qkv, q, s_kcache(m, l), s_vcache(m, l), B, T, H, m->hd, T, m->s_capS, pos_dev, m->rope_cos, m->rope_sin};
+        launch_qkv_rope_f32(qa, m->st);
+        AttnF32Args aa{q, s_kcache(m, l), s_vcache(m, l), at, B, H, T, m->hd, T, m->s_capS, 1, 0, pos_dev,
+                       1.0f / sqrtf((float)m->hd)};
+        launch_attention_f32(aa, m->st);
+        gemm32(m, at, L.o_w, nullptr, x, M, D, D, D, D, D, EPI_RESID_F32);
+        launch_rmsnorm_f32(x, nullptr, L.post_norm, xn, M, D, c.rms_eps, m->st);
+        gemm32(m, xn, L.gu_w, nullptr, h, M, 2 * F, D, D, D, F, EPI_SWIGLU);
+        gemm32(m, h, L.down_w, nullptr, x, M, D, F, F, F, D, EPI_RESID_F32);
+    }
+}
+
+void logits_strict(vc_model* m, const float* x, const int* row_idx, int rows) {
+    launch_rmsnorm_f32(x, row_idx, m->final_norm, m->s_xl.as<float>(), rows, m->c.hidden, m->c.rms_eps, m->st);
+    gemm32(m, m->s_xl.as<float>(), m->lm_head, nullptr, m->logits.as<float>(), rows, m->c.vocab, m->c.hidden, m->c.hidden,
+           m->c.hidden, m->c.vocab, EPI_F32);
+}
+
+// ------------------------------------------------------------------------------------------------
 // splice planner (host).  One (kind, src) pair per destination row of inputs_embeds.
 struct RowSrc { int kind, src; };
 
@@ -608,6 +747,12 @@ void enqueue_decode_step(vc_model* m, int B, int max_new, int eos_id, int pad_id
     launch_greedy_embed(greedy_embed_args(m, B, max_new, eos_id, pad_id, 3), m->st);                       // K19+K10
 }
 
+void enqueue_decode_step_strict(vc_model* m, int B, int max_new, int eos_id, int pad_id) {
+    run_llm_layers_strict(m, m->x_dec.as<float>(), B, 1, m->pos_dev());
+    logits_strict(m, m->x_dec.as<float>(), nullptr, B);
+    launch_greedy_embed(greedy_embed_args(m, B, max_new, eos_id, pad_id, 3), m->st);
+}
+
 void ensure_graph(vc_model* m, int B, int max_new, int eos_id, int pad_id) {
     if (m->graph && m->graph_B == B && m->graph_eos == eos_id && m->graph_pad == pad_id && m->graph_maxnew == max_new)
         return;
@@ -650,7 +795,8 @@ void do_prefill(vc_model* m, const int64_t* ids, int B, int T, const float* img,
     if (c.variant != VC_VARIANT_VCODER_DS) depth = nullptr;
     const float* pix[3] = {img, seg, depth};
     if (m->ev[0]) HIPCHK(hipEventRecord(m->ev[0], m->st));
-    run_vit_and_adapters(m, pix, on_dev, B);
+    if (m->precision) run_vit_and_adapters_strict(m, pix, on_dev, B);
+    else run_vit_and_adapters(m, pix, on_dev, B);
     const int R = m->Tv - (c.vit_keep_cls ? 0 : 1);
     std::vector<bool> dz;
     if (depth) {  // is_depth_zero = [mean(d) == 0 ...]  (vcoder_ds_llava_arch.py:161) — one host sync, as the reference
@@ -685,7 +831,13 @@ void do_prefill(vc_model* m, const int64_t* ids, int B, int T, const float* img,
             flat[((size_t)b * S + s) * 2 + 1] = r.src;
         }
     HIPCHK(hipMemcpyAsync(m->row_src.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, m->st));
-    launch_splice(m->row_src.as<int>(), (int)(B * S), m->embed, m->feats.as<bf16_t>(), m->x.as<float>(), c.hidden, m->st);
+    if (m->precision) {
+        ensure_strict(m, B, m->capS);
+        launch_splice_f32(m->row_src.as<int>(), (int)(B * S), m->embed, m->s_feats.as<float>(), m->x.as<float>(), c.hidden,
+                          m->st);
+    } else {
+        launch_splice(m->row_src.as<int>(), (int)(B * S), m->embed, m->feats.as<bf16_t>(), m->x.as<float>(), c.hidden, m->st);
+    }
     HIPCHK(hipStreamSynchronize(m->st));  // `flat` is host memory
     m->curB = B;
     m->curS = (int)S;
@@ -695,17 +847,28 @@ void do_prefill(vc_model* m, const int64_t* ids, int B, int T, const float* img,
 void finish_prefill(vc_model* m, float* logits_all_host) {
     const vc_model_cfg& c = m->c;
     const int B = m->curB, S = m->curS, D = c.hidden;
-    run_prefill_layers(m, B, S);
     std::vector<int> idx(B);
     for (int b = 0; b < B; ++b) idx[b] = b * S + S - 1;
     HIPCHK(hipMemcpyAsync(m->last_idx.p, idx.data(), B * 4, hipMemcpyHostToDevice, m->st));
-    launch_rmsnorm_rows(m->x.as<float>(), m->last_idx.as<int>(), m->final_norm, m->xl.as<bf16_t>(), B, D, c.rms_eps, m->st);
-    gemv(m, m->xl.as<bf16_t>(), m->lm_head_p, m->logits.p, B, c.vocab, D, c.vocab, GEMV_F32);
+    if (m->precision) {
+        run_llm_layers_strict(m, m->x.as<float>(), B, S, nullptr);
+        logits_strict(m, m->x.as<float>(), m->last_idx.as<int>(), B);
+    } else {
+        run_prefill_layers(m, B, S);
+        launch_rmsnorm_rows(m->x.as<float>(), m->last_idx.as<int>(), m->final_norm, m->xl.as<bf16_t>(), B, D, c.rms_eps, m->st);
+        gemv(m, m->xl.as<bf16_t>(), m->lm_head_p, m->logits.p, B, c.vocab, D, c.vocab, GEMV_F32);
+    }
     if (logits_all_host) {  // lm_head over ALL S positions, as the reference's forward returns (:93)
         const size_t Mr = (size_t)B * S;
         m->logits_all.ensure(Mr * c.vocab * 4);
-        launch_rmsnorm(m->x.as<float>(), m->final_norm, m->xn.as<bf16_t>(), (int)Mr, D, c.rms_eps, m->st);
-        gemm(m, m->xn.as<bf16_t>(), m->lm_head, nullptr, m->logits_all.p, (int)Mr, c.vocab, D, c.vocab, EPI_F32);
+        if (m->precision) {
+            launch_rmsnorm_f32(m->x.as<float>(), nullptr, m->final_norm, m->s_xn.as<float>(), (int)Mr, D, c.rms_eps, m->st);
+            gemm32(m, m->s_xn.as<float>(), m->lm_head, nullptr, m->logits_all.as<float>(), (int)Mr, c.vocab, D, D, D, c.vocab,
+                   EPI_F32);
+        } else {
+            launch_rmsnorm(m->x.as<float>(), m->final_norm, m->xn.as<bf16_t>(), (int)Mr, D, c.rms_eps, m->st);
+            gemm(m, m->xn.as<bf16_t>(), m->lm_head, nullptr, m->logits_all.p, (int)Mr, c.vocab, D, c.vocab, EPI_F32);
+        }
         HIPCHK(hipMemcpyAsync(logits_all_host, m->logits_all.p, Mr * c.vocab * 4, hipMemcpyDeviceToHost, m->st));
     }
     const int sc[3] = {0, S, S + 1};  // step, pos (next token's position), ctx (keys after it is appended)
@@ -880,7 +1043,9 @@ VC_API void vc_model_destroy(vc_model* m) {
                    &m->v_k, &m->v_vt, &m->v_attn, &m->v_h, &m->v_sel, &m->v_mid, &m->feats, &m->x, &m->xn, &m->qkv, &m->q,
                    &m->attn, &m->h, &m->kc, &m->vtc, &m->row_src, &m->last_idx, &m->xl, &m->logits_all, &m->x_dec,
                    &m->xn_dec, &m->qkv_dec, &m->q_dec, &m->attn_dec, &m->h_dec, &m->logits, &m->next_tok, &m->finished,
-                   &m->out_ids, &m->scalars, &m->dsum, &m->ssq})
+                   &m->out_ids, &m->scalars, &m->dsum, &m->ssq, &m->s_cols, &m->s_patches, &m->s_vx, &m->s_vxn, &m->s_vqkv,
+                   &m->s_vq, &m->s_vk, &m->s_vv, &m->s_vattn, &m->s_vh, &m->s_sel, &m->s_mid, &m->s_feats, &m->s_xn, &m->s_qkv,
+                   &m->s_q, &m->s_attn, &m->s_h, &m->s_kc, &m->s_vc, &m->s_xl})
         b->release();
     for (auto& e : m->ev)
         if (e) (void)hipEventDestroy(e);
@@ -924,6 +1089,15 @@ VC_API int vc_model_synth_tensor(vc_model* m, const char* hf_key, const int64_t*
     HIPCHK(hipStreamSynchronize(m->st));
     if (rc != VC_OK) return rc;
     GUARD_END(m->ctx)
+}
+
+/* 0: bf16 MFMA path (default, benchmarked); 1: strict fp32 path (fp32 activations + fp32 MFMA, ~1e-6 from the fp32 CPU
+ * reference; slow).  Takes effect at the next prefill. */
+VC_API int vc_model_set_precision(vc_model* m, int mode) {
+    if (!m || (mode != 0 && mode != 1)) return VC_ERR_INVALID;
+    m->precision = mode;
+    m->cur_pos = -1;
+    return VC_OK;
 }
 
 VC_API int vc_model_finalize(vc_model* m) {
@@ -988,13 +1162,19 @@ VC_API int vc_encode(vc_model* m, int modality, const float* pixels, int pixels_
     REQUIRE(modality == VC_MOD_IMAGE || m->c.variant != VC_VARIANT_LLAVA, VC_ERR_INVALID, "llava has no seg/depth encoder");
     const float* pix[3] = {nullptr, nullptr, nullptr};
     pix[modality] = pixels;
-    run_vit_and_adapters(m, pix, pixels_on_device, B);
+    if (m->precision) run_vit_and_adapters_strict(m, pix, pixels_on_device, B);
+    else run_vit_and_adapters(m, pix, pixels_on_device, B);
     if (out) {
         const size_t n = (size_t)m->feat_rows[modality] * m->c.hidden;
-        m->v_patches.ensure(n * 4);
-        launch_bf16_to_f32(m->feats.as<bf16_t>() + (size_t)m->feat_off[modality] * m->c.hidden, m->v_patches.as<float>(), n,
-                           m->st);
-        HIPCHK(hipMemcpyAsync(out, m->v_patches.p, n * 4, hipMemcpyDeviceToHost, m->st));
+        if (m->precision) {
+            HIPCHK(hipMemcpyAsync(out, m->s_feats.as<float>() + (size_t)m->feat_off[modality] * m->c.hidden, n * 4,
+                                  hipMemcpyDeviceToHost, m->st));
+        } else {
+            m->v_patches.ensure(n * 4);
+            launch_bf16_to_f32(m->feats.as<bf16_t>() + (size_t)m->feat_off[modality] * m->c.hidden, m->v_patches.as<float>(),
+                               n, m->st);
+            HIPCHK(hipMemcpyAsync(out, m->v_patches.p, n * 4, hipMemcpyDeviceToHost, m->st));
+        }
     }
     HIPCHK(hipStreamSynchronize(m->st));
     GUARD_END(m->ctx)
@@ -1052,8 +1232,12 @@ VC_API int vc_decode_step(vc_model* m, const int32_t* tok, float* logits, int32_
                                 m->npart, m->st);
     }
     ensure_out_ids(m, B, 1);
-    ensure_graph(m, B, 0, -1, 0);  // max_new 0: out_ids untouched, no EOS bookkeeping
-    HIPCHK(hipGraphLaunch(m->graph, m->st));
+    if (m->precision) {
+        enqueue_decode_step_strict(m, B, 0, -1, 0);
+    } else {
+        ensure_graph(m, B, 0, -1, 0);  // max_new 0: out_ids untouched, no EOS bookkeeping
+        HIPCHK(hipGraphLaunch(m->graph, m->st));
+    }
     m->cur_pos += 1;
     if (logits) HIPCHK(hipMemcpyAsync(logits, m->logits.p, (size_t)B * m->c.vocab * 4, hipMemcpyDeviceToHost, m->st));
     if (next_tok) HIPCHK(hipMemcpyAsync(next_tok, m->next_tok.p, B * 4, hipMemcpyDeviceToHost, m->st));
@@ -1091,9 +1275,10 @@ VC_API int vc_generate_greedy(vc_model* m, const int64_t* ids, int B, int T, con
         return true;
     };
     if (max_new > 1 && !all_finished()) {
-        ensure_graph(m, B, max_new, eos_id, pad_id);
+        if (!m->precision) ensure_graph(m, B, max_new, eos_id, pad_id);
         for (int step = 1; step < max_new; ++step) {
-            HIPCHK(hipGraphLaunch(m->graph, m->st));
+            if (m->precision) enqueue_decode_step_strict(m, B, max_new, eos_id, pad_id);
+            else HIPCHK(hipGraphLaunch(m->graph, m->st));
             m->cur_pos += 1;
             produced = step + 1;
             // the reference checks its stopping criteria on the host every token; checking every 8 tokens only

@@ -113,3 +113,22 @@ VCK_EXPORT void vck_f32_to_bf16(const float* in, uint16_t* out, uint64_t n, void
 VCK_EXPORT void vck_bf16_to_f32(const uint16_t* in, float* out, uint64_t n, void* stream) {
     launch_bf16_to_f32(in, out, (size_t)n, S(stream));
 }
+
+// ---- strict (fp32) kernels -----------------------------------------------------------------------------------------
+VCK_EXPORT void vck_gemm_f32(const float* A, const uint16_t* W, const float* bias, float* out, int M, int N, int K, int lda,
+                             int ldw, int ldo, int epi, void* stream) {
+    GemmF32Args a{A, W, bias, out, M, N, K, lda, ldw, ldo};
+    launch_gemm_f32(a, epi, S(stream));
+}
+VCK_EXPORT void vck_attention_f32(const float* q, const float* k, const float* v, float* out, int B, int H, int Tq, int hd,
+                                  int q_stride, int kv_stride, int causal, int Tk, const int* pos0_dev, float scale,
+                                  void* stream) {
+    AttnF32Args a{q, k, v, out, B, H, Tq, hd, q_stride, kv_stride, causal, Tk, pos0_dev, scale};
+    launch_attention_f32(a, S(stream));
+}
+VCK_EXPORT void vck_qkv_rope_f32(const float* qkv, float* q, float* k, float* v, int B, int T, int H, int hd, int q_stride,
+                                 int kv_stride, const int* pos0_dev, const float* rope_cos, const float* rope_sin,
+                                 void* stream) {
+    QkvF32Args a{qkv, q, k, v, B, T, H, hd, q_stride, kv_stride, pos0_dev, rope_cos, rope_sin};
+    launch_qkv_rope_f32(a, S(stream));
+}

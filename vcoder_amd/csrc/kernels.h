@@ -175,6 +175,46 @@ void launch_embed_tokens_ssq(const int* tok, const bf16_t* embed, float* x, floa
                              hipStream_t s);
 void launch_advance(int* step_dev, int* pos_dev, int* ctx_dev, hipStream_t s);
 
+// ---- strict (fp32-faithful) path: see strict.hip -------------------------------------------------------------------
+struct GemmF32Args {
+    const float* A;     // fp32 activations [M, lda]
+    const bf16_t* W;    // bf16 weights [N, ldw] (widened exactly)
+    const float* bias;  // [N] or nullptr
+    float* out;         // fp32; epilogue ids reuse GemmEpilogue: EPI_F32 (also for EPI_BF16), *_QGELU, *_GELU, RESID, SWIGLU
+    int M, N, K;
+    int lda, ldw, ldo;
+};
+void launch_gemm_f32(const GemmF32Args& a, int epilogue, hipStream_t s);
+struct AttnF32Args {
+    const float* q;   // [B,H,q_stride,hd]
+    const float* k;   // [B,H,kv_stride,hd]
+    const float* v;   // [B,H,kv_stride,hd]
+    float* out;       // [B*Tq, H*hd]
+    int B, H, Tq, hd, q_stride, kv_stride;
+    int causal;       // 1: query t attends keys 0..pos0+t ; 0: keys 0..Tk-1
+    int Tk;
+    const int* pos0_dev;  // device scalar: absolute position of query 0 (nullptr -> 0)
+    float scale;
+};
+void launch_attention_f32(const AttnF32Args& a, hipStream_t s);
+struct QkvF32Args {
+    const float* qkv;  // [B*T, 3*H*hd]
+    float* q;          // [B,H,q_stride,hd]
+    float* k;          // [B,H,kv_stride,hd], rows pos0..pos0+T-1 written
+    float* v;
+    int B, T, H, hd, q_stride, kv_stride;
+    const int* pos0_dev;
+    const float* rope_cos;  // nullptr: no RoPE (ViT)
+    const float* rope_sin;
+};
+void launch_qkv_rope_f32(const QkvF32Args& a, hipStream_t s);
+void launch_layernorm_f32(const float* x, const float* w, const float* b, float* y, int rows, int D, float eps, hipStream_t s);
+void launch_rmsnorm_f32(const float* x, const int* row_idx, const float* w, float* y, int rows, int D, float eps,
+                        hipStream_t s);
+void launch_im2col_f32(const float* pixels, float* cols, int n_img, int image, int patch, hipStream_t s);
+void launch_select_rows_f32(const float* x, float* y, int n_img, int T, int skip, int D, hipStream_t s);
+void launch_splice_f32(const int* row_src, int nrows, const bf16_t* embed, const float* feats, float* x, int D, hipStream_t s);
+
 // ---- misc ---------------------------------------------------------------------------------------
 void launch_synth_bf16(bf16_t* out, size_t n, uint32_t tseed, float offset, float halfwidth, hipStream_t s);
 void launch_synth_f32(float* out, size_t n, uint32_t tseed, float offset, float halfwidth, hipStream_t s);

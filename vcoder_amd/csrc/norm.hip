@@ -77,6 +77,32 @@ __global__ __launch_bounds__(256) void norm_kernel(const float* x, const int* ro
     norm_row<MAXV, RMS, false>(x + (size_t)src * D, w, b, y + (size_t)row * D, D, eps, nullptr, nullptr);
 }
 
+// fp32-out form for the strict path
+template <int MAXV, bool RMS>
+__global__ __launch_bounds__(256) void norm_f32_kernel(const float* x, const int* row_idx, const float* w, const float* b,
+                                                       float* y, int rows, int D, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int src = row_idx ? row_idx[row] : row;
+    norm_row<MAXV, RMS, true>(x + (size_t)src * D, w, b, y + (size_t)row * D, D, eps, nullptr, nullptr);
+}
+template <bool RMS>
+static void launch_norm_f32(const float* x, const int* idx, const float* w, const float* b, float* y, int rows, int D,
+                            float eps, hipStream_t s) {
+    const dim3 grid((rows + 3) / 4), block(256);
+    if (D <= 1024) VC_LAUNCH((norm_f32_kernel<4, RMS>), grid, block, 0, s, x, idx, w, b, y, rows, D, eps);
+    else if (D <= 4096) VC_LAUNCH((norm_f32_kernel<16, RMS>), grid, block, 0, s, x, idx, w, b, y, rows, D, eps);
+    else VC_LAUNCH((norm_f32_kernel<32, RMS>), grid, block, 0, s, x, idx, w, b, y, rows, D, eps);
+}
+void launch_layernorm_f32(const float* x, const float* w, const float* b, float* y, int rows, int D, float eps,
+                          hipStream_t s) {
+    launch_norm_f32<false>(x, nullptr, w, b, y, rows, D, eps, s);
+}
+void launch_rmsnorm_f32(const float* x, const int* row_idx, const float* w, float* y, int rows, int D, float eps,
+                        hipStream_t s) {
+    launch_norm_f32<true>(x, row_idx, w, nullptr, y, rows, D, eps, s);
+}
+
 template <bool RMS>
 static void launch_norm(const float* x, const int* idx, const float* w, const float* b, bf16_t* y, int rows, int D,
                         float eps, hipStream_t s) {

@@ -54,6 +54,8 @@ VC_DEV f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_hw, a),
                                                    __builtin_bit_cast(bf16x8_hw, b), c, 0, 0, 0);
 }
+// v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain): A[i][k]: lane i+16k; B[k][j]: lane j+16k; D as for bf16
+VC_DEV f32x4 mfma16_f32(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 VC_DEV int lane_id() { return (int)(threadIdx.x & 63); }
 template <class T> VC_DEV T shfl_xor(T v, int mask) { return __shfl_xor(v, mask, 64); }
 template <class T> VC_DEV T shfl(T v, int src) { return __shfl(v, src, 64); }

@@ -132,6 +132,11 @@ class HipEngine:
                                                        C.c_uint32(synth.tensor_seed(key, seed)), C.c_float(off),
                                                        C.c_float(hw)))
 
+    def set_precision(self, mode: str):
+        """'bf16' (default: bf16 MFMA operands, what the benchmark runs) or 'strict' (fp32 activations on fp32 MFMA —
+        fp32-faithful to the reference's CPU path, slow)."""
+        self._check(self.lib.vc_model_set_precision(self._model, {"bf16": 0, "fast": 0, "strict": 1, "fp32": 1}[mode]))
+
     def finalize(self):
         self._check(self.lib.vc_model_finalize(self._model))
         self.finalized = True
