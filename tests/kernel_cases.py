@@ -529,7 +529,7 @@ def check_gemm_f32(be, M, N, K, epi, bias=True, seed=0):
     Ad, Wd, bd = be.f32(A), be.bf16(W), (be.f32(b) if bias else None)
     _call(be, "vck_gemm_f32", Ad, Wd, bd, out, M, N, K, K, K, N // 2 if epi == 5 else N, epi)
     e = rel_err(be.host_f32(out), t.numpy())
-    assert e < 2e-6, f"gemm_f32 M{M} N{N} K{K} epi{epi}: rel err {e}"
+    assert e < 1e-5, f"gemm_f32 M{M} N{N} K{K} epi{epi}: rel err {e}"   # fp32 FMA chain over K (<= 3.5e-7*sqrt-ish growth)
 
 
 def check_attention_f32(be, B, H, T, hd, causal, decode_pos=None, seed=0):
