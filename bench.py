@@ -126,6 +126,10 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False and there is no CPU fallback")
+    # debugging knobs for exercising the multi-process path on a 1-GPU box: all ranks on one device, gloo gather
+    if os.environ.get("VC_BENCH_FORCE_DEVICE") is not None:
+        local = int(os.environ["VC_BENCH_FORCE_DEVICE"])
+    backend = os.environ.get("VC_BENCH_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
@@ -133,7 +137,10 @@ def main():
 
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     from vcoder_amd import config as vcfg, synth
     from vcoder_amd.engine import HipEngine
@@ -174,11 +181,14 @@ def main():
         if errs:
             raise errs[0]
         # the one exchange: all-gather of the token stream (RCCL over xGMI), once per batch; no-op for N=1
-        return [gather_token_ids(o, dist, device="cuda") for o in outs]
+        return [gather_token_ids(o, dist, device="cuda" if backend == "nccl" else None) for o in outs]
 
     def fence():
         if world > 1:
-            dist.barrier()
+            if backend == "nccl":
+                dist.barrier(device_ids=[local])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     if args.warmup > 0:
@@ -189,7 +199,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     timings = eng.last_timings()
@@ -224,7 +234,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(cfg, B, N_new)
         print(json.dumps(res), flush=True)
     if world > 1:
-        dist.barrier()
+        fence()
         dist.destroy_process_group()
 
 

@@ -74,8 +74,13 @@ def load() -> C.CDLL:
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
-        raise RuntimeError(
-            f"{LIB_PATH} is missing: build it with `python -m vcoder_amd.build` (hipcc, gfx950). "
-            "vcoder_amd has no CPU fallback.")
+        try:  # not a fallback: the same HIP library, compiled now (hipcc, gfx950, a few seconds)
+            from . import build as _build
+
+            _build.build(verbose=False)
+        except Exception as e:
+            raise RuntimeError(
+                f"{LIB_PATH} is missing and could not be built ({e}): run `python -m vcoder_amd.build` (hipcc, gfx950). "
+                "vcoder_amd has no CPU fallback.") from e
     _lib = declare(C.CDLL(LIB_PATH))
     return _lib
