@@ -215,3 +215,53 @@ def test_true_dims_strict_against_fp32_oracle():
     print(f"true-dims STRICT parity: prefill err={e1:.2e} decode err={e2:.2e}")
     assert e1 < 1e-3 and e2 < 1e-3 and int(np.argmax(last)) == int(np.argmax(o_last[:, -1].numpy()))
     eng.close()
+
+
+def test_load_pretrained_model_from_hf_layout(tmp_path):
+    """The reference's loader entry point on real HF-layout directories: (a) VCoder checkpoint embedding the CLIP tower,
+    (b) tower in a separate local CLIP directory named by config.mm_vision_tower (the reference's layout).  Same 6-tuple,
+    name-substring dispatch and processor aliasing as builder.py:25-154; generate() returns [B, T+n] with the prompt."""
+    import json
+    import torch
+    from vcoder_amd import checkpoint
+    from vcoder_amd.model import load_pretrained_model
+
+    cfg = vcfg.tiny("vcoder_ds")
+    sd = synth.synth_state_dict(cfg, 42)
+    g, _, ids, imgs, segs, deps = e2e_cases.fixture_inputs("ds_img_depth_seg")
+    # (b) first: separate CLIP directory
+    clip_dir = str(tmp_path / "clip-tiny")
+    vt = "model.vision_tower.vision_tower."
+    checkpoint.save_checkpoint(clip_dir, {"model_type": "clip_vision_model"},
+                               {k[len(vt):]: v for k, v in sd.items() if k.startswith(vt)})
+    with open(f"{clip_dir}/preprocessor_config.json", "w") as f:
+        json.dump({"crop_size": 56, "size": 56, "do_center_crop": True, "do_normalize": True, "do_resize": True,
+                   "image_mean": synth.CLIP_MEAN.tolist(), "image_std": synth.CLIP_STD.tolist(), "resample": 3,
+                   "image_processor_type": "CLIPImageProcessor"}, f)
+    cfg.mm_vision_tower = clip_dir
+    d = str(tmp_path / "vcoder_ds_llava-v1.5-tiny")
+    checkpoint.save_checkpoint(d, cfg.to_hf_dict(), {k: v for k, v in sd.items() if not k.startswith(vt)})
+    tok, model, ip, sip, dip, ctx = load_pretrained_model(d, None, "vcoder_ds_llava-v1.5-tiny")
+    assert ip is not None and sip is ip and dip is ip and ctx == 2048
+    assert type(model).__name__ == "VCoderDSLlavaLlamaForCausalLM" and model.get_vision_tower().is_loaded
+    t = torch.from_numpy
+    out = model.generate(t(ids).cuda(), images=t(imgs).cuda(), segs=t(segs).cuda(), depths=t(deps).cuda(), do_sample=False,
+                         max_new_tokens=8, use_cache=True, eos_token_id=-1)
+    assert out.is_cuda and tuple(out.shape) == (2, ids.shape[1] + 8)
+    assert np.array_equal(out[:, ids.shape[1]:].cpu().numpy(), g["greedy_ids"])
+    with pytest.raises(RuntimeError):
+        tok("hello")   # no tokenizer files in a synthetic checkpoint: the error surfaces lazily, not at load
+    model.engine.close()
+    # (a) tower embedded in the VCoder checkpoint; non-DS name dispatch
+    cfg2 = vcfg.tiny("vcoder")
+    cfg2.mm_vision_tower = clip_dir
+    d2 = str(tmp_path / "vcoder_llava-v1.5-tiny")
+    checkpoint.save_checkpoint(d2, cfg2.to_hf_dict(), synth.synth_state_dict(cfg2, 42))
+    _, model2, ip2, sip2, dip2, _ = load_pretrained_model(d2, None, "vcoder_llava-v1.5-tiny")
+    assert type(model2).__name__ == "VCoderLlavaLlamaForCausalLM" and sip2 is ip2 and dip2 is None
+    g2, _, ids2, imgs2, segs2, _ = e2e_cases.fixture_inputs("vc_img_seg")
+    out2 = model2.generate(t(ids2), images=t(imgs2), segs=t(segs2), do_sample=False, max_new_tokens=8, eos_token_id=-1)
+    assert np.array_equal(out2[:, ids2.shape[1]:].numpy(), g2["greedy_ids"])
+    model2.engine.close()
+    with pytest.raises(NotImplementedError):
+        load_pretrained_model(d, None, "vcoder_ds_llava-v1.5-tiny", load_4bit=True)
