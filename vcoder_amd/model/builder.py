@@ -54,3 +54,6 @@ class _MissingTokenizer:
 
     def __getattr__(self, name):
         raise RuntimeError(f"no tokenizer could be loaded from {self._path}: {self._err}")
+
+    def __call__(self, *a, **k):
+        raise RuntimeError(f"no tokenizer could be loaded from {self._path}: {self._err}")
