@@ -111,6 +111,13 @@ int vc_generate_greedy(vc_model* m, const int64_t* ids, int B, int T, const floa
                        const float* depth, int pixels_on_device, int max_new, int eos_id, int pad_id,
                        int32_t* out_ids, int* n_generated);
 
+/* ---- next row §8(f)2: image preprocessing on the device ------------------------------------------------------------
+ * process_images() of vcoder_llava/mm_utils.py:28-40 for ONE image: expand2square(mean colour) when pad_to_square,
+ * PIL-exact bicubic resize (shortest edge -> S) + center crop, rescale 1/255, (x-mean)/std, HWC->CHW.
+ * rgb: uint8 [h,w,3] on the host; out: fp32 [3,S,S] (device pointer when out_on_device, else host). */
+int vc_preprocess_image(vc_model* m, const uint8_t* rgb, int h, int w, int pad_to_square, const float* mean,
+                        const float* stdv, float* out, int out_on_device);
+
 /* ---- measurement hooks (bench.py) ---------------------------------------------------------------- */
 /* times `reps` sweeps of every decode GEMV launch of one step (4 per layer + lm_head) with HIP events on the
  * model's stream; returns launches per sweep, average microseconds per launch, algorithmic weight bytes per launch */

@@ -25,3 +25,11 @@ def test_strict_mode_meets_north_star_bar(emu_lib, name):
     """Strict (fp32) mode through the same engine: logits within 1e-3 of the real reference, ids bit-exact."""
     r = e2e_cases.check_fixture_strict(name, lib=emu_lib)
     assert r["logits_err"] < 1e-4 and r["decode_logits_err"] < 1e-4
+
+
+def test_device_preprocessing_matches_pil(emu_lib, tmp_path):
+    import preprocess_cases as pc
+
+    eng = e2e_cases.engine_for("vcoder_ds", emu_lib)   # 56 x 56 tower
+    pc.check_preprocess(eng, [(56, 56), (40, 100), (120, 75), (200, 200), (30, 31)])
+    pc.check_against_hf_processor(eng, tmp_path)

@@ -265,3 +265,33 @@ def test_load_pretrained_model_from_hf_layout(tmp_path):
     model2.engine.close()
     with pytest.raises(NotImplementedError):
         load_pretrained_model(d, None, "vcoder_ds_llava-v1.5-tiny", load_4bit=True)
+
+
+def test_device_preprocessing_matches_pil(tmp_path):
+    """§8(f) row 2 on the GPU at the real tower size (336): COCO-like shapes, both aspect modes, bit-exact uint8 stages
+    (1e-6 after normalisation) against PIL / CLIPImageProcessor; plus the throughput next to host PIL."""
+    import time
+    import preprocess_cases as pc
+    from PIL import Image
+
+    cfg = vcfg.vicuna_7b("vcoder_ds")
+    cfg.num_hidden_layers = 1
+    cfg.vit_num_layers = 2
+    eng = HipEngine(cfg)
+    eng.load_synthetic(1)
+    eng.finalize()
+    pc.check_preprocess(eng, [(480, 640), (640, 427), (336, 336), (500, 375), (1024, 768), (200, 300)])
+    pc.check_preprocess(eng, [(480, 640)], to_device=True)
+    pc.check_against_hf_processor(eng, tmp_path)
+    rng = np.random.RandomState(0)
+    imgs = [Image.fromarray(rng.randint(0, 256, size=(480, 640, 3)).astype(np.uint8)) for _ in range(24)]
+    eng.preprocess(imgs[:2], to_device=True)
+    t0 = time.perf_counter()
+    eng.preprocess(imgs, to_device=True)
+    t_dev = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for im in imgs:
+        pc.expected(im, 336, True)
+    t_pil = time.perf_counter() - t0
+    print(f"preprocess 24 x 480x640 -> 336: device path {t_dev * 1e3:.1f} ms, host PIL+numpy {t_pil * 1e3:.1f} ms")
+    eng.close()

@@ -58,6 +58,8 @@ def declare(lib: C.CDLL) -> C.CDLL:
     lib.vc_generate_greedy.argtypes = [vp, vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, vp, C.POINTER(C.c_int)]
     lib.vc_profile_decode_gemv.argtypes = [vp, i32, i32, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.vc_last_timings.argtypes = [vp, f32p, f32p, f32p]
+    lib.vc_preprocess_image.argtypes = [vp, vp, i32, i32, i32, f32p, f32p, vp, i32]
+    lib.vc_preprocess_image.restype = C.c_int
     for name in ("vc_init", "vc_synchronize", "vc_model_create", "vc_model_load_tensor", "vc_model_synth_tensor",
                  "vc_model_finalize", "vc_encode", "vc_prefill", "vc_prefill_embeds_only", "vc_decode_step",
                  "vc_generate_greedy", "vc_profile_decode_gemv", "vc_last_timings"):

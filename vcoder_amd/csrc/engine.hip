@@ -112,6 +112,7 @@ struct vc_model {
     int precision = 0;  // 0: bf16 MFMA fast path; 1: strict fp32 path (strict.hip)
     Buf s_cols, s_patches, s_vx, s_vxn, s_vqkv, s_vq, s_vk, s_vv, s_vattn, s_vh, s_sel, s_mid, s_feats;
     Buf s_xn, s_qkv, s_q, s_attn, s_h, s_kc, s_vc, s_xl;
+    Buf pp_src, pp_sq, pp_tmp, pp_out, pp_tab, pp_f32;
     int s_capB = 0, s_capS = 0;  // false: a session created by vc_model_create_shared (weights belong to the parent)
     // derived
     int P, Tv, Kpatch, Kpad, hd, vhd, npart;
@@ -1045,7 +1046,8 @@ VC_API void vc_model_destroy(vc_model* m) {
                    &m->xn_dec, &m->qkv_dec, &m->q_dec, &m->attn_dec, &m->h_dec, &m->logits, &m->next_tok, &m->finished,
                    &m->out_ids, &m->scalars, &m->dsum, &m->ssq, &m->s_cols, &m->s_patches, &m->s_vx, &m->s_vxn, &m->s_vqkv,
                    &m->s_vq, &m->s_vk, &m->s_vv, &m->s_vattn, &m->s_vh, &m->s_sel, &m->s_mid, &m->s_feats, &m->s_xn, &m->s_qkv,
-                   &m->s_q, &m->s_attn, &m->s_h, &m->s_kc, &m->s_vc, &m->s_xl})
+                   &m->s_q, &m->s_attn, &m->s_h, &m->s_kc, &m->s_vc, &m->s_xl, &m->pp_src, &m->pp_sq, &m->pp_tmp, &m->pp_out,
+                   &m->pp_tab, &m->pp_f32})
         b->release();
     for (auto& e : m->ev)
         if (e) (void)hipEventDestroy(e);
@@ -1308,6 +1310,115 @@ VC_API int vc_generate_greedy(vc_model* m, const int64_t* ids, int B, int T, con
         (void)hipEventElapsedTime(&m->t_prefill, m->ev[1], m->ev[2]);
         (void)hipEventElapsedTime(&m->t_decode, m->ev[2], m->ev[3]);
     }
+    GUARD_END(m->ctx)
+}
+
+
+// ---- image preprocessing: PIL's 8-bit bicubic coefficient tables (Pillow Resample.c: precompute_coeffs +
+// normalize_coeffs_8bpc), built in double on the host ----------------------------------------------------------------
+namespace {
+double bicubic_filter(double x) {
+    const double a = -0.5;
+    if (x < 0.0) x = -x;
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+    return 0.0;
+}
+// bounds[2*o] = first tap, bounds[2*o+1] = tap count; kk[o*ksize + t] = fixed-point weight
+int resample_coeffs(int in_size, int out_size, std::vector<int>& bounds, std::vector<int>& kk) {
+    const double scale = (double)in_size / out_size;
+    const double fs = scale < 1.0 ? 1.0 : scale;
+    const double support = 2.0 * fs;
+    const int ksize = (int)ceil(support) * 2 + 1;
+    bounds.assign((size_t)out_size * 2, 0);
+    kk.assign((size_t)out_size * ksize, 0);
+    std::vector<double> w(ksize);
+    for (int xx = 0; xx < out_size; ++xx) {
+        const double center = (xx + 0.5) * scale, ss = 1.0 / fs;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        const int n = xmax - xmin;
+        double tot = 0.0;
+        for (int x = 0; x < n; ++x) {
+            w[x] = bicubic_filter((x + xmin - center + 0.5) * ss);
+            tot += w[x];
+        }
+        for (int x = 0; x < n; ++x) {
+            const double v = tot != 0.0 ? w[x] / tot : w[x];
+            kk[(size_t)xx * ksize + x] = v < 0 ? (int)(-0.5 + v * (double)(1 << 22)) : (int)(0.5 + v * (double)(1 << 22));
+        }
+        bounds[2 * xx] = xmin;
+        bounds[2 * xx + 1] = n;
+    }
+    return ksize;
+}
+}  // namespace
+
+/* One image: uint8 RGB [h,w,3] (host) -> fp32 [3,S,S] CLIP-normalised pixels (device when out_on_device, else host).
+ * pad_to_square = the reference's image_aspect_ratio == 'pad' path (mm_utils.py:31-35): expand2square with the mean
+ * colour, then resize to S x S; otherwise resize the shortest edge to S (bicubic) and center-crop S x S. */
+VC_API int vc_preprocess_image(vc_model* m, const uint8_t* rgb, int h, int w, int pad_to_square, const float* mean,
+                               const float* stdv, float* out, int out_on_device) {
+    if (!m) return VC_ERR_INVALID;
+    GUARD_BEGIN
+    USE_DEVICE(m->ctx);
+    REQUIRE(rgb && out && mean && stdv && h > 0 && w > 0, VC_ERR_INVALID, "bad preprocess arguments");
+    const int S = m->c.vit_image;
+    m->pp_src.ensure((size_t)h * w * 3);
+    HIPCHK(hipMemcpyAsync(m->pp_src.p, rgb, (size_t)h * w * 3, hipMemcpyHostToDevice, m->st));
+    const uint8_t* cur = m->pp_src.as<uint8_t>();
+    int ch = h, cw = w;
+    if (pad_to_square && h != w) {
+        const int side = h > w ? h : w;
+        const int fill[3] = {(int)(mean[0] * 255), (int)(mean[1] * 255), (int)(mean[2] * 255)};  // int(x*255), mm_utils.py:33
+        m->pp_sq.ensure((size_t)side * side * 3);
+        launch_pad_square(cur, h, w, m->pp_sq.as<uint8_t>(), side, (side - w) / 2, (side - h) / 2, fill, m->st);
+        cur = m->pp_sq.as<uint8_t>();
+        ch = cw = side;
+    }
+    // shortest edge -> S, long edge = int(S * long / short)   ([HF] get_resize_output_image_size, default_to_square=False)
+    int nh, nw;
+    if (ch <= cw) { nh = S; nw = (int)((double)S * cw / ch); }
+    else { nw = S; nh = (int)((double)S * ch / cw); }
+    if (nh != ch || nw != cw) {
+        std::vector<int> bh, kh, bv, kv;
+        const int ksh = resample_coeffs(cw, nw, bh, kh), ksv = resample_coeffs(ch, nh, bv, kv);
+        const size_t tab = bh.size() + kh.size() + bv.size() + kv.size();
+        m->pp_tab.ensure(tab * 4);
+        int* t = m->pp_tab.as<int>();
+        int *d_bh = t, *d_kh = d_bh + bh.size(), *d_bv = d_kh + kh.size(), *d_kv = d_bv + bv.size();
+        HIPCHK(hipMemcpyAsync(d_bh, bh.data(), bh.size() * 4, hipMemcpyHostToDevice, m->st));
+        HIPCHK(hipMemcpyAsync(d_kh, kh.data(), kh.size() * 4, hipMemcpyHostToDevice, m->st));
+        HIPCHK(hipMemcpyAsync(d_bv, bv.data(), bv.size() * 4, hipMemcpyHostToDevice, m->st));
+        HIPCHK(hipMemcpyAsync(d_kv, kv.data(), kv.size() * 4, hipMemcpyHostToDevice, m->st));
+        m->pp_tmp.ensure((size_t)ch * nw * 3);
+        m->pp_out.ensure((size_t)nh * nw * 3);
+        // PIL skips a pass whose size does not change, and runs horizontal first
+        const uint8_t* src = cur;
+        int th = ch;
+        if (nw != cw) {
+            launch_resample(src, ch, cw, m->pp_tmp.as<uint8_t>(), ch, nw, d_bh, d_kh, ksh, 1, m->st);
+            src = m->pp_tmp.as<uint8_t>();
+        }
+        if (nh != ch) {
+            launch_resample(src, th, nw, m->pp_out.as<uint8_t>(), nh, nw, d_bv, d_kv, ksv, 0, m->st);
+            src = m->pp_out.as<uint8_t>();
+        }
+        cur = src;
+        HIPCHK(hipStreamSynchronize(m->st));  // the host coefficient vectors go out of scope
+    }
+    const int top = (nh - S) / 2, left = (nw - S) / 2;
+    float* dst = out;
+    if (!out_on_device) {
+        m->pp_f32.ensure((size_t)3 * S * S * 4);
+        dst = m->pp_f32.as<float>();
+    }
+    launch_crop_normalize(cur, nh, nw, top, left, dst, S, mean, stdv, m->st);
+    if (!out_on_device)
+        HIPCHK(hipMemcpyAsync(out, dst, (size_t)3 * S * S * 4, hipMemcpyDeviceToHost, m->st));
+    HIPCHK(hipStreamSynchronize(m->st));
     GUARD_END(m->ctx)
 }
 

@@ -215,6 +215,14 @@ void launch_im2col_f32(const float* pixels, float* cols, int n_img, int image, i
 void launch_select_rows_f32(const float* x, float* y, int n_img, int T, int skip, int D, hipStream_t s);
 void launch_splice_f32(const int* row_src, int nrows, const bf16_t* embed, const float* feats, float* x, int D, hipStream_t s);
 
+// ---- device-side image preprocessing (preprocess.hip) --------------------------------------------------------------
+void launch_pad_square(const uint8_t* src, int h, int w, uint8_t* dst, int side, int ox, int oy, const int fill[3],
+                       hipStream_t s);
+void launch_resample(const uint8_t* in, int in_h, int in_w, uint8_t* out, int out_h, int out_w, const int* bounds,
+                     const int* kk, int ksize, int horizontal, hipStream_t s);
+void launch_crop_normalize(const uint8_t* in, int in_h, int in_w, int top, int left, float* out, int S, const float mean[3],
+                           const float stdv[3], hipStream_t s);
+
 // ---- misc ---------------------------------------------------------------------------------------
 void launch_synth_bf16(bf16_t* out, size_t n, uint32_t tseed, float offset, float halfwidth, hipStream_t s);
 void launch_synth_f32(float* out, size_t n, uint32_t tseed, float offset, float halfwidth, hipStream_t s);

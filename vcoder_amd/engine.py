@@ -277,6 +277,29 @@ class HipEngine:
     def note_prefill(self, B: int):
         self._cur_batch = B
 
+    def preprocess(self, images, pad: bool = True, mean=None, std=None, to_device: bool = False):
+        """process_images() on the device (vcoder_llava/mm_utils.py:28-40): list of PIL images / uint8 [h,w,3] arrays ->
+        fp32 [N,3,S,S] CLIP-normalised pixels (numpy, or a torch CUDA tensor when to_device).  PIL-exact bicubic."""
+        S = self.cfg.vit_image_size
+        mean = np.ascontiguousarray(synth.CLIP_MEAN if mean is None else mean, dtype=np.float32)
+        std = np.ascontiguousarray(synth.CLIP_STD if std is None else std, dtype=np.float32)
+        f32p = C.POINTER(C.c_float)
+        if to_device:
+            import torch
+
+            out = torch.empty((len(images), 3, S, S), dtype=torch.float32, device=f"cuda:{self.device_index}")
+        else:
+            out = np.empty((len(images), 3, S, S), dtype=np.float32)
+        for i, im in enumerate(images):
+            a = np.ascontiguousarray(np.asarray(im.convert("RGB") if hasattr(im, "convert") else im), dtype=np.uint8)
+            if a.ndim != 3 or a.shape[2] != 3:
+                raise ValueError("expected an RGB image [h,w,3]")
+            dst = C.c_void_p(out[i].data_ptr()) if to_device else out[i].ctypes.data_as(C.c_void_p)
+            self._check(self.lib.vc_preprocess_image(self._model, a.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1],
+                                                     int(pad), mean.ctypes.data_as(f32p), std.ctypes.data_as(f32p), dst,
+                                                     int(to_device)))
+        return out
+
     def last_timings(self):
         e, p, d = C.c_float(), C.c_float(), C.c_float()
         self._check(self.lib.vc_last_timings(self._model, C.byref(e), C.byref(p), C.byref(d)))

@@ -93,3 +93,16 @@ def process_images(images, image_processor, model_cfg):
 def get_model_name_from_path(model_path: str) -> str:
     parts = model_path.strip("/").split("/")
     return parts[-2] + "_" + parts[-1] if parts[-1].startswith("checkpoint-") else parts[-1]
+
+
+def process_images_device(images, model, model_cfg=None, to_device: bool = True):
+    """process_images() with the resize / pad / normalise work done by libvcoder_hip (vc_preprocess_image) instead of
+    PIL + numpy on the host: PIL-exact bicubic, same expand2square fill colour, same rescale/normalise arithmetic.
+    `model` is a vcoder_amd model (or engine); returns fp32 [N,3,S,S] on the model's GPU."""
+    engine = getattr(model, "engine", model)
+    cfg = model_cfg if model_cfg is not None else getattr(model, "config", None)
+    pad = getattr(cfg, "image_aspect_ratio", None) == "pad"
+    proc = getattr(getattr(model, "get_vision_tower", lambda: None)(), "image_processor", None)
+    mean = getattr(proc, "image_mean", None)
+    std = getattr(proc, "image_std", None)
+    return engine.preprocess(list(images), pad=pad, mean=mean, std=std, to_device=to_device)
