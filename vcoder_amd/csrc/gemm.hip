@@ -156,75 +156,83 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
 // kernel's LDS time) while the MFMAs of the current tile run; the compiler's vmcnt(0) before the tile's closing
 // barrier retires it.  One wave-instruction fills 8 swizzled rows (1 KiB): lane p writes slot p%8 of row p/8, so it
 // FETCHES chunk (p%8)^(row&7) of that row.
-template <int EPI>
-__global__ __launch_bounds__(256) void gemm_bf16_dma_kernel(GemmArgs p) {
+// Geometry: WN x WM waves, each owning FI x FJ MFMA tiles (16 features x 16 tokens) -> workgroup tile
+// BNt = WN*FI*16 features x BMt = WM*FJ*16 tokens.  <2,2,4,4> = 128x128 / 4 waves / 64 KiB LDS (2 workgroups per CU);
+// <2,4,8,4> = 256x256 / 8 waves / 128 KiB LDS (1 workgroup per CU): twice the MFMAs per fragment read and a k-tile
+// compute phase (64 MFMAs per wave) long enough to cover the LDS-DMA's HBM latency with a one-tile prefetch distance.
+template <int EPI, int WN, int WM, int FI, int FJ>
+__global__ __launch_bounds__(WN * WM * 64) void gemm_bf16_dma_kernel(GemmArgs p) {
+    constexpr int BNt = WN * FI * 16, BMt = WM * FJ * 16, NW = WN * WM;
+    constexpr int W_BYTES = BNt * 128, A_BYTES = BMt * 128, STAGE = W_BYTES + A_BYTES;
+    constexpr int WP = BNt / 8 / NW, AP = BMt / 8 / NW;  // 1-KiB DMA pieces per wave per operand tile
     VC_DYNAMIC_SMEM(char, smem);  // [2 stages][W tile | A tile]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = wave >> 1, wm = wave & 1;
-    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int wn = wave / WM, wm = wave % WM;
+    const int tiles_m = (p.M + BMt - 1) / BMt, tiles_n = (p.N + BNt - 1) / BNt;
     int tm, tn;
     tile_coords(blockIdx.x, tiles_m * tiles_n, tiles_m, tiles_n, tm, tn);
-    const int m0 = tm * BM, n0 = tn * BN;
-    const char* a_src[4];
-    const char* w_src[4];
+    const int m0 = tm * BMt, n0 = tn * BNt;
+    const char* a_src[AP];
+    const char* w_src[WP];
+    // a 1-KiB piece = 8 swizzled rows; lane p fills slot p%8 of row p/8, i.e. fetches chunk (p%8)^(row&7) of that row
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int piece = i * 4 + wave;              // 16 pieces of 8 rows per operand tile
-        const int row = piece * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ (row & 7);    // source chunk that belongs at LDS slot lane&7 of this row
-        const int am = min(m0 + row, p.M - 1), wr = min(n0 + row, p.N - 1);
-        a_src[i] = reinterpret_cast<const char*>(p.A + (size_t)am * p.lda) + chunk * 16;
-        w_src[i] = reinterpret_cast<const char*>(p.W + (size_t)wr * p.ldw) + chunk * 16;
+    for (int i = 0; i < WP; ++i) {
+        const int row = (i * NW + wave) * 8 + (lane >> 3);
+        const int wr = min(n0 + row, p.N - 1);
+        w_src[i] = reinterpret_cast<const char*>(p.W + (size_t)wr * p.ldw) + (((lane & 7) ^ (row & 7)) << 4);
+    }
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+        const int row = (i * NW + wave) * 8 + (lane >> 3);
+        const int am = min(m0 + row, p.M - 1);
+        a_src[i] = reinterpret_cast<const char*>(p.A + (size_t)am * p.lda) + (((lane & 7) ^ (row & 7)) << 4);
     }
     auto issue_tile = [&](int kt, int stage) {
-        char* ws = smem + stage * (2 * TILE_BYTES);
-        char* as = ws + TILE_BYTES;
+        char* ws = smem + stage * STAGE;
+        char* as = ws + W_BYTES;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int piece = i * 4 + wave;
-            glds16(w_src[i] + (size_t)kt * (BK * 2), ws + piece * 1024);
-            glds16(a_src[i] + (size_t)kt * (BK * 2), as + piece * 1024);
-        }
+        for (int i = 0; i < WP; ++i) glds16(w_src[i] + (size_t)kt * (BK * 2), ws + (i * NW + wave) * 1024);
+#pragma unroll
+        for (int i = 0; i < AP; ++i) glds16(a_src[i] + (size_t)kt * (BK * 2), as + (i * NW + wave) * 1024);
     };
-    f32x4 acc[4][4];
+    f32x4 acc[FI][FJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < FI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nk = p.K / BK;
     issue_tile(0, 0);
     __syncthreads();
     const int frow = lane & 15, fchunk = lane >> 4;
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) issue_tile(kt + 1, (kt + 1) & 1);
-        const char* ws = smem + (kt & 1) * (2 * TILE_BYTES);
-        const char* as = ws + TILE_BYTES;
+        const char* ws = smem + (kt & 1) * STAGE;
+        const char* as = ws + W_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            u32x4 fw[4], fa[4];
+            u32x4 fw[FI], fa[FJ];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                fw[i] = ld16(ws + swz(wn * 64 + i * 16 + frow, ks * 4 + fchunk));
-                fa[i] = ld16(as + swz(wm * 64 + i * 16 + frow, ks * 4 + fchunk));
-            }
+            for (int i = 0; i < FI; ++i) fw[i] = ld16(ws + swz(wn * (FI * 16) + i * 16 + frow, ks * 4 + fchunk));
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < FJ; ++j) fa[j] = ld16(as + swz(wm * (FJ * 16) + j * 16 + frow, ks * 4 + fchunk));
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fw[i], fa[j], acc[i][j]);
+            for (int i = 0; i < FI; ++i)
+#pragma unroll
+                for (int j = 0; j < FJ; ++j) acc[i][j] = mfma16(fw[i], fa[j], acc[i][j]);
         }
         __syncthreads();
     }
 
     // ---- epilogue: lane holds out[m][n..n+3], m = .. + (lane&15), n = .. + (lane>>4)*4
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
+    for (int i = 0; i < FI; ++i) {
+        const int n = n0 + wn * (FI * 16) + i * 16 + (lane >> 4) * 4;
         if (n >= p.N) continue;
         f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
         if (p.bias) bv = ld16f(p.bias + n);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + wm * 64 + j * 16 + (lane & 15);
+        for (int j = 0; j < FJ; ++j) {
+            const int m = m0 + wm * (FJ * 16) + j * 16 + (lane & 15);
             if (m >= p.M) continue;
             f32x4 v = acc[i][j] + bv;
             if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_QGELU || EPI == EPI_BF16_GELU) {
@@ -251,6 +259,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_dma_kernel(GemmArgs p) {
     }
 }
 
+template <class K>
+static void allow_big_lds_gemm(K kernel, size_t bytes) {
+#ifndef VC_EMU
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+#endif
+}
+
 void launch_gemm(const GemmArgs& a, int epilogue, hipStream_t s) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const dim3 grid(tiles), block(256);
@@ -258,14 +273,40 @@ void launch_gemm(const GemmArgs& a, int epilogue, hipStream_t s) {
     // default: LDS-DMA staging (+8..16 % on MI355X: 870-990 vs 790-900 TFLOP/s on the ViT / Llama shapes);
     // VC_GEMM_VARIANT=0 selects the register-staged form
     static const int variant = getenv("VC_GEMM_VARIANT") ? atoi(getenv("VC_GEMM_VARIANT")) : 1;
-    if (variant == 1) {
+    if (variant >= 1) {
+        // 256x256 / 8 waves when the grid still fills the chip several times over, else 128x128 / 4 waves
+        const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+        const bool big = variant == 2 || (variant == 1 && t256 >= 1024);
+        if (big) {
+            const dim3 g2((unsigned)t256), b2(512);
+            const size_t sh2 = 2 * (256 * 128 + 256 * 128);
+#define VC_G256(E)                                                                                         \
+    do {                                                                                                   \
+        static bool once = false;                                                                          \
+        if (!once) {                                                                                       \
+            allow_big_lds_gemm(gemm_bf16_dma_kernel<E, 2, 4, 8, 4>, sh2);                                  \
+            once = true;                                                                                   \
+        }                                                                                                  \
+        VC_LAUNCH((gemm_bf16_dma_kernel<E, 2, 4, 8, 4>), g2, b2, sh2, s, a);                               \
+    } while (0)
+            switch (epilogue) {
+                case EPI_BF16: VC_G256(EPI_BF16); break;
+                case EPI_BF16_QGELU: VC_G256(EPI_BF16_QGELU); break;
+                case EPI_BF16_GELU: VC_G256(EPI_BF16_GELU); break;
+                case EPI_F32: VC_G256(EPI_F32); break;
+                case EPI_RESID_F32: VC_G256(EPI_RESID_F32); break;
+                default: VC_G256(EPI_SWIGLU); break;
+            }
+#undef VC_G256
+            return;
+        }
         switch (epilogue) {
-            case EPI_BF16: VC_LAUNCH((gemm_bf16_dma_kernel<EPI_BF16>), grid, block, shmem, s, a); break;
-            case EPI_BF16_QGELU: VC_LAUNCH((gemm_bf16_dma_kernel<EPI_BF16_QGELU>), grid, block, shmem, s, a); break;
-            case EPI_BF16_GELU: VC_LAUNCH((gemm_bf16_dma_kernel<EPI_BF16_GELU>), grid, block, shmem, s, a); break;
-            case EPI_F32: VC_LAUNCH((gemm_bf16_dma_kernel<EPI_F32>), grid, block, shmem, s, a); break;
-            case EPI_RESID_F32: VC_LAUNCH((gemm_bf16_dma_kernel<EPI_RESID_F32>), grid, block, shmem, s, a); break;
-            default: VC_LAUNCH((gemm_bf16_dma_kernel<EPI_SWIGLU>), grid, block, shmem, s, a); break;
+            case EPI_BF16: VC_LAUNCH((gemm_bf16_dma_kernel<EPI_BF16, 2, 2, 4, 4>), grid, block, shmem, s, a); break;
+            case EPI_BF16_QGELU: VC_LAUNCH((gemm_bf16_dma_kernel<EPI_BF16_QGELU, 2, 2, 4, 4>), grid, block, shmem, s, a); break;
+            case EPI_BF16_GELU: VC_LAUNCH((gemm_bf16_dma_kernel<EPI_BF16_GELU, 2, 2, 4, 4>), grid, block, shmem, s, a); break;
+            case EPI_F32: VC_LAUNCH((gemm_bf16_dma_kernel<EPI_F32, 2, 2, 4, 4>), grid, block, shmem, s, a); break;
+            case EPI_RESID_F32: VC_LAUNCH((gemm_bf16_dma_kernel<EPI_RESID_F32, 2, 2, 4, 4>), grid, block, shmem, s, a); break;
+            default: VC_LAUNCH((gemm_bf16_dma_kernel<EPI_SWIGLU, 2, 2, 4, 4>), grid, block, shmem, s, a); break;
         }
         return;
     }
