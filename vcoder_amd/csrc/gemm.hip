@@ -270,13 +270,14 @@ void launch_gemm(const GemmArgs& a, int epilogue, hipStream_t s) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const dim3 grid(tiles), block(256);
     const size_t shmem = 4 * TILE_BYTES;
-    // default: LDS-DMA staging (+8..16 % on MI355X: 870-990 vs 790-900 TFLOP/s on the ViT / Llama shapes);
-    // VC_GEMM_VARIANT=0 selects the register-staged form
+    // default (1): LDS-DMA staging, geometry by problem size.  0: register-staged 128x128 (8-16 % slower than the DMA
+    // form of the same geometry: 790-900 vs 870-990 TFLOP/s); 2: force 256x256; 3: force DMA 128x128
     static const int variant = getenv("VC_GEMM_VARIANT") ? atoi(getenv("VC_GEMM_VARIANT")) : 1;
     if (variant >= 1) {
-        // 256x256 / 8 waves when the grid still fills the chip several times over, else 128x128 / 4 waves
+        // 256x256 / 8 waves for every large problem (measured faster on all ViT / adapter / Llama prefill shapes except a
+        // 2 % loss on o_proj), 128x128 / 4 waves for small ones; VC_GEMM_VARIANT=2 / 3 force one geometry
         const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-        const bool big = variant == 2 || (variant == 1 && t256 >= 1024);
+        const bool big = variant == 2 || (variant == 1 && a.M >= 1024 && a.N >= 512);
         if (big) {
             const dim3 g2((unsigned)t256), b2(512);
             const size_t sh2 = 2 * (256 * 128 + 256 * 128);
