@@ -10,6 +10,8 @@
 // contiguous 1 KiB block with non-temporal loads, and a v_mfma_f32_16x16x32_bf16 per block does the
 // 16 outputs x 16 token-slots x 32 k dot products (tokens >= M are fed zeros).  K is split across the
 // waves of a workgroup and reduced through LDS; epilogues (fp32 residual add, SwiGLU) are fused.
+#include <stdlib.h>
+
 #include "vc_device.h"
 #include "kernels.h"
 
@@ -218,7 +220,8 @@ void launch_gemv(const GemvArgs& a, int epilogue, hipStream_t s) {
     if (a.Xf != nullptr) {  // fused RMSNorm prologue; 2 tiles per workgroup share every activation fragment
         const size_t stage = (size_t)(a.M <= 8 ? 8 : 16) * ((size_t)a.K * 2 + 16);
         const size_t need = stage > (size_t)8 * 2 * 64 * 16 ? stage : (size_t)8 * 2 * 64 * 16;  // also holds `red`
-        if (need <= 150 * 1024) launch_gemv_w<8, 2, true, true>(a, epilogue, need, s);
+        static const int stage_ok = getenv("VC_GEMV_STAGE") ? atoi(getenv("VC_GEMV_STAGE")) : 1;
+        if (stage_ok && need <= 150 * 1024) launch_gemv_w<8, 2, true, true>(a, epilogue, need, s);
         else launch_gemv_w<8, 2, true, false>(a, epilogue, 0, s);
         return;
     }
