@@ -259,136 +259,6 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_bf16_dma_kernel(GemmArgs p)
     }
 }
 
-// ---- phase-split 256x256 schedule ------------------------------------------------------------------------------------
-// Same tile / LDS image / DMA as gemm_bf16_dma_kernel<EPI,2,4,8,4>, but the 8 waves are two groups (A = waves 0-3,
-// B = waves 4-7; each SIMD hosts one wave of each) that run HALF A K-STEP OUT OF PHASE: in every sub-phase one group
-// issues its 32 MFMAs (s_setprio 1) while the other group reads its next 12 fragments from LDS, 4 raw s_barriers per
-// k-tile.  The matrix pipe of a SIMD is therefore fed by one wave at a time back to back, instead of both waves
-// computing together and then both waiting on LDS.  The LDS-DMA of tile t+1 is issued at the top of tile t and
-// retired by ONE s_waitcnt vmcnt(0) before the tile's last barrier (raw barriers do not drain it).
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(GemmArgs p) {
-    constexpr int WN = 2, WM = 4, FI = 8, FJ = 4, NW = 8;
-    constexpr int BNt = 256, BMt = 256;
-    constexpr int W_BYTES = BNt * 128, A_BYTES = BMt * 128, STAGE = W_BYTES + A_BYTES;
-    constexpr int WP = BNt / 8 / NW, AP = BMt / 8 / NW;
-    VC_DYNAMIC_SMEM(char, smem);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = wave / WM, wm = wave % WM;
-    const bool grpA = wave < 4;
-    const int tiles_m = (p.M + BMt - 1) / BMt, tiles_n = (p.N + BNt - 1) / BNt;
-    int tm, tn;
-    tile_coords(blockIdx.x, tiles_m * tiles_n, tiles_m, tiles_n, tm, tn);
-    const int m0 = tm * BMt, n0 = tn * BNt;
-    const char* a_src[AP];
-    const char* w_src[WP];
-#pragma unroll
-    for (int i = 0; i < WP; ++i) {
-        const int row = (i * NW + wave) * 8 + (lane >> 3);
-        const int wr = min(n0 + row, p.N - 1);
-        w_src[i] = reinterpret_cast<const char*>(p.W + (size_t)wr * p.ldw) + (((lane & 7) ^ (row & 7)) << 4);
-    }
-#pragma unroll
-    for (int i = 0; i < AP; ++i) {
-        const int row = (i * NW + wave) * 8 + (lane >> 3);
-        const int am = min(m0 + row, p.M - 1);
-        a_src[i] = reinterpret_cast<const char*>(p.A + (size_t)am * p.lda) + (((lane & 7) ^ (row & 7)) << 4);
-    }
-    auto issue_tile = [&](int kt, int stage) {
-        char* ws = smem + stage * STAGE;
-        char* as = ws + W_BYTES;
-#pragma unroll
-        for (int i = 0; i < WP; ++i) glds16(w_src[i] + (size_t)kt * (BK * 2), ws + (i * NW + wave) * 1024);
-#pragma unroll
-        for (int i = 0; i < AP; ++i) glds16(a_src[i] + (size_t)kt * (BK * 2), as + (i * NW + wave) * 1024);
-    };
-    f32x4 acc[FI][FJ];
-#pragma unroll
-    for (int i = 0; i < FI; ++i)
-#pragma unroll
-        for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    u32x4 fw[FI], fa[FJ];
-    const int frow = lane & 15, fchunk = lane >> 4;
-    auto read_frags = [&](int stage, int ks) {
-        const char* ws = smem + stage * STAGE;
-        const char* as = ws + W_BYTES;
-#pragma unroll
-        for (int i = 0; i < FI; ++i) fw[i] = ld16(ws + swz(wn * (FI * 16) + i * 16 + frow, ks * 4 + fchunk));
-#pragma unroll
-        for (int j = 0; j < FJ; ++j) fa[j] = ld16(as + swz(wm * (FJ * 16) + j * 16 + frow, ks * 4 + fchunk));
-    };
-    auto mfma_all = [&]() {
-        setprio(1);
-#pragma unroll
-        for (int i = 0; i < FI; ++i)
-#pragma unroll
-            for (int j = 0; j < FJ; ++j) acc[i][j] = mfma16(fw[i], fa[j], acc[i][j]);
-        setprio(0);
-    };
-    const int nk = p.K / BK;
-    issue_tile(0, 0);
-    wait_vmcnt0();
-    raw_barrier();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int st = kt & 1;
-        if (kt + 1 < nk) issue_tile(kt + 1, st ^ 1);
-        // sub-phase 1: A reads ks0 | B finishes the previous tile (its ks1 fragments are still in registers)
-        if (grpA) read_frags(st, 0);
-        else if (kt > 0) mfma_all();
-        raw_barrier();
-        // sub-phase 2: A computes ks0 | B reads ks0
-        if (grpA) mfma_all();
-        else read_frags(st, 0);
-        raw_barrier();
-        // sub-phase 3: A reads ks1 | B computes ks0
-        if (grpA) read_frags(st, 1);
-        else mfma_all();
-        raw_barrier();
-        // sub-phase 4: A computes ks1 | B reads ks1
-        if (grpA) mfma_all();
-        else read_frags(st, 1);
-        wait_lgkmcnt0();  // B's reads of this stage are complete before anyone refills it
-        wait_vmcnt0();    // this wave's DMA pieces of tile kt+1 have landed
-        raw_barrier();
-    }
-    if (!grpA) mfma_all();  // B's last half step
-
-    // ---- epilogue: lane holds out[m][n..n+3], m = .. + (lane&15), n = .. + (lane>>4)*4
-#pragma unroll
-    for (int i = 0; i < FI; ++i) {
-        const int n = n0 + wn * (FI * 16) + i * 16 + (lane >> 4) * 4;
-        if (n >= p.N) continue;
-        f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (p.bias) bv = ld16f(p.bias + n);
-#pragma unroll
-        for (int j = 0; j < FJ; ++j) {
-            const int m = m0 + wm * (FJ * 16) + j * 16 + (lane & 15);
-            if (m >= p.M) continue;
-            f32x4 v = acc[i][j] + bv;
-            if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_QGELU || EPI == EPI_BF16_GELU) {
-                if constexpr (EPI == EPI_BF16_QGELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
-                }
-                if constexpr (EPI == EPI_BF16_GELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = erf_gelu(v[e]);
-                }
-                u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-                st8(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo + n, o);
-            } else if constexpr (EPI == EPI_F32) {
-                st16f(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n, v);
-            } else if constexpr (EPI == EPI_RESID_F32) {
-                float* o = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n;
-                st16f(o, ld16f(o) + v);
-            } else {  // EPI_SWIGLU: (g0,u0,g1,u1) -> 2 outputs
-                const uint32_t o = pack_bf2(silu(v[0]) * v[1], silu(v[2]) * v[3]);
-                *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo + (n >> 1)) = o;
-            }
-        }
-    }
-}
-
 template <class K>
 static void allow_big_lds_gemm(K kernel, size_t bytes) {
 #ifndef VC_EMU
@@ -407,8 +277,7 @@ void launch_gemm(const GemmArgs& a, int epilogue, hipStream_t s) {
         // 256x256 / 8 waves for every large problem (measured faster on all ViT / adapter / Llama prefill shapes except a
         // 2 % loss on o_proj), 128x128 / 4 waves for small ones; VC_GEMM_VARIANT=2 / 3 force one geometry
         const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-        const bool big = variant == 2 || variant == 4 || (variant == 1 && a.M >= 1024 && a.N >= 512);
-        const bool phase_split = variant == 4;
+        const bool big = variant == 2 || (variant == 1 && a.M >= 1024 && a.N >= 512);
         if (big) {
             const dim3 g2((unsigned)t256), b2(512);
             const size_t sh2 = 2 * (256 * 128 + 256 * 128);
@@ -417,11 +286,9 @@ void launch_gemm(const GemmArgs& a, int epilogue, hipStream_t s) {
         static bool once = false;                                                                          \
         if (!once) {                                                                                       \
             allow_big_lds_gemm(gemm_bf16_dma_kernel<E, 2, 4, 8, 4>, sh2);                                  \
-            allow_big_lds_gemm(gemm_bf16_ph_kernel<E>, sh2);                                               \
             once = true;                                                                                   \
         }                                                                                                  \
-        if (phase_split) VC_LAUNCH((gemm_bf16_ph_kernel<E>), g2, b2, sh2, s, a);                           \
-        else VC_LAUNCH((gemm_bf16_dma_kernel<E, 2, 4, 8, 4>), g2, b2, sh2, s, a);                          \
+        VC_LAUNCH((gemm_bf16_dma_kernel<E, 2, 4, 8, 4>), g2, b2, sh2, s, a);                               \
     } while (0)
             switch (epilogue) {
                 case EPI_BF16: VC_G256(EPI_BF16); break;

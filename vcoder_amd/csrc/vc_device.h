@@ -95,19 +95,6 @@ VC_DEV void glds16(const void* gsrc_lane, void* lds_wave_base) {
 }
 #endif
 
-// ---- raw synchronisation pieces for hand-scheduled pipelines (no-ops / plain barrier under the emulator) ------------
-#ifdef VC_EMU
-VC_DEV void raw_barrier() { __syncthreads(); }
-VC_DEV void wait_vmcnt0() {}
-VC_DEV void wait_lgkmcnt0() {}
-VC_DEV void setprio(int) {}
-#else
-VC_DEV void raw_barrier() { __builtin_amdgcn_s_barrier(); }                       // no implied vmcnt/lgkmcnt drain
-VC_DEV void wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }    // LDS-DMA pieces of this wave landed
-VC_DEV void wait_lgkmcnt0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-#define setprio(x) __builtin_amdgcn_s_setprio(x)
-#endif
-
 // ---- activations (fp32) --------------------------------------------------------------------
 VC_DEV float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }   // x*sigmoid(1.702x)
 VC_DEV float erf_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
