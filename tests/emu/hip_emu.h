@@ -95,8 +95,6 @@ inline hipError_t hipStreamCreate(hipStream_t* s) { *s = (void*)0x1; return 0; }
 static const unsigned hipStreamNonBlocking = 1;
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (void*)0x1; return 0; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
-inline hipError_t hipDeviceGetStreamPriorityRange(int* l, int* g) { *l = 0; *g = -1; return 0; }
-inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = (void*)0x2; return 0; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 struct EmuEvent { double t; };
 typedef EmuEvent* hipEvent_t;

@@ -32,7 +32,6 @@ static const int DEPTH_TOKEN_INDEX = -400;  // constants.py:11
 struct vc_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream_hi = nullptr;  // optional high-priority stream for the decode graph replays (VC_DECODE_PRIO=1)
     std::string err;
 };
 
@@ -916,18 +915,12 @@ VC_API int vc_init(int device_id, vc_ctx** out) {
     ctx->device = device_id;
     // non-blocking: no implicit synchronisation with the legacy NULL stream (torch's default stream, other sessions)
     HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    if (getenv("VC_DECODE_PRIO") && atoi(getenv("VC_DECODE_PRIO"))) {
-        int least = 0, greatest = 0;
-        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIPCHK(hipStreamCreateWithPriority(&ctx->stream_hi, hipStreamNonBlocking, greatest));
-    }
     *out = ctx;
     GUARD_END(ctx)
 }
 VC_API void vc_shutdown(vc_ctx* ctx) {
     if (!ctx) return;
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
-    if (ctx->stream_hi) (void)hipStreamDestroy(ctx->stream_hi);
     delete ctx;
 }
 VC_API const char* vc_last_error(vc_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
@@ -1273,14 +1266,12 @@ VC_API int vc_generate_greedy(vc_model* m, const int64_t* ids, int B, int T, con
     HIPCHK(hipMemcpyAsync(m->out_ids.p, fill.data(), fill.size() * 4, hipMemcpyHostToDevice, m->st));
     launch_greedy_embed(greedy_embed_args(m, B, max_new, eos_id, pad_id, 1), m->st);  // step 0 -> 1; pos stays at S
     HIPCHK(hipStreamSynchronize(m->st));
-    // the prefill stream is idle here (synchronised above): the decode steps may run on the high-priority stream
-    hipStream_t ds = (m->ctx->stream_hi && !m->precision) ? m->ctx->stream_hi : m->st;
     int produced = 1;
     std::vector<int> fin(B);
     auto all_finished = [&]() {
         if (eos_id < 0) return false;
-        HIPCHK(hipMemcpyAsync(fin.data(), m->finished.p, B * 4, hipMemcpyDeviceToHost, ds));
-        HIPCHK(hipStreamSynchronize(ds));
+        HIPCHK(hipMemcpyAsync(fin.data(), m->finished.p, B * 4, hipMemcpyDeviceToHost, m->st));
+        HIPCHK(hipStreamSynchronize(m->st));
         for (int b = 0; b < B; ++b)
             if (!fin[b]) return false;
         return true;
@@ -1289,20 +1280,20 @@ VC_API int vc_generate_greedy(vc_model* m, const int64_t* ids, int B, int T, con
         if (!m->precision) ensure_graph(m, B, max_new, eos_id, pad_id);
         for (int step = 1; step < max_new; ++step) {
             if (m->precision) enqueue_decode_step_strict(m, B, max_new, eos_id, pad_id);
-            else HIPCHK(hipGraphLaunch(m->graph, ds));
+            else HIPCHK(hipGraphLaunch(m->graph, m->st));
             m->cur_pos += 1;
             produced = step + 1;
             // the reference checks its stopping criteria on the host every token; checking every 8 tokens only
             // trims later (rows past EOS already emit pad), it never changes the returned ids
             if (eos_id >= 0 && (step % 8 == 7 || step == max_new - 1)) {
-                HIPCHK(hipStreamSynchronize(ds));
+                HIPCHK(hipStreamSynchronize(m->st));
                 if (all_finished()) break;
             }
         }
     }
-    if (m->ev[3]) HIPCHK(hipEventRecord(m->ev[3], ds));
-    HIPCHK(hipMemcpyAsync(out_ids, m->out_ids.p, (size_t)B * max_new * 4, hipMemcpyDeviceToHost, ds));
-    HIPCHK(hipStreamSynchronize(ds));
+    if (m->ev[3]) HIPCHK(hipEventRecord(m->ev[3], m->st));
+    HIPCHK(hipMemcpyAsync(out_ids, m->out_ids.p, (size_t)B * max_new * 4, hipMemcpyDeviceToHost, m->st));
+    HIPCHK(hipStreamSynchronize(m->st));
     if (eos_id >= 0) {  // HF stops right after the first step at which every row has produced EOS
         int last = 0;
         for (int b = 0; b < B; ++b) {
