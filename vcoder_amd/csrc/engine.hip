@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1256,6 +1257,12 @@ VC_API int vc_generate_greedy(vc_model* m, const int64_t* ids, int B, int T, con
     REQUIRE(max_new >= 1 && out_ids, VC_ERR_INVALID, "bad max_new/out_ids");
     m->cur_pos = -1;
     int S = 0;
+    // Sessions of one process take turns in the MFMA-bound encode+prefill phase: two prefills side by side only slow
+    // each other (and every decode in flight), while ONE prefill overlaps well with the HBM-bound decodes of the others.
+    static std::mutex prefill_gate;
+    static const bool use_gate = !(getenv("VC_PREFILL_GATE") && atoi(getenv("VC_PREFILL_GATE")) == 0);
+    std::unique_lock<std::mutex> gate(prefill_gate, std::defer_lock);
+    if (use_gate) gate.lock();
     do_prefill(m, ids, B, T, img, seg, depth, pixels_on_device, 1, max_new, nullptr, &S);  // generate() always builds a mask
     REQUIRE(S + max_new <= m->capS, VC_ERR_INVALID, "prompt %d + max_new %d exceeds the KV capacity %d", S, max_new, m->capS);
     ensure_out_ids(m, B, max_new);
@@ -1266,6 +1273,7 @@ VC_API int vc_generate_greedy(vc_model* m, const int64_t* ids, int B, int T, con
     HIPCHK(hipMemcpyAsync(m->out_ids.p, fill.data(), fill.size() * 4, hipMemcpyHostToDevice, m->st));
     launch_greedy_embed(greedy_embed_args(m, B, max_new, eos_id, pad_id, 1), m->st);  // step 0 -> 1; pos stays at S
     HIPCHK(hipStreamSynchronize(m->st));
+    if (use_gate) gate.unlock();
     int produced = 1;
     std::vector<int> fin(B);
     auto all_finished = [&]() {
