@@ -105,7 +105,7 @@ def cpu_baseline(cfg, B_for_rate: int, new_tokens: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=8, help="samples per GPU (BASELINE configs[1]: 8)")
     ap.add_argument("--new-tokens", type=int, default=128)
