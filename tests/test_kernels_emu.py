@@ -74,7 +74,8 @@ def test_splice_greedy_synth(be):
 def test_fused_decode_kernels(be):
     kc.check_gemv_norm_chain(be, 8, 256, 64)
     kc.check_gemv_norm_chain(be, 3, 512, 96, seed=1)
-    kc.check_gemv_norm_chain(be, 16, 5120, 32, seed=3)   # rows too large for LDS staging -> direct path
+    kc.check_gemv_norm_chain(be, 16, 5120, 32, seed=3)   # 16 x 5120 rows: staged in 4 chunks of K
+    kc.check_gemv_norm_chain(be, 5, 288, 64, seed=5)     # K not chunkable -> direct (unstaged) normalisation
     kc.check_gemv_norm_chain(be, 12, 1024, 64, seed=4)   # 16-row staging
     kc.check_attention_decode_fused(be, 2, 2, 128, 70)
     kc.check_attention_decode_fused(be, 1, 2, 128, 128)

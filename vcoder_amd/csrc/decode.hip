@@ -47,8 +47,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
     const int ntiles = p.N >> 4;
     const int nt0 = blockIdx.x * NT;
     const int nkt = p.K >> 5;
-    const int per = (nkt + WAVES - 1) / WAVES;
-    const int kt0 = wave * per, kt1 = min(nkt, kt0 + per);
     const int m = lane & 15, g = lane >> 4;
     const bool mvalid = m < p.M;
     const bf16_t* wp[NT];
@@ -58,8 +56,18 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
     const float* xf = nullptr;
     const float* nw = nullptr;
     float rstd = 0.f;
-    const int row_bytes = p.K * 2 + 16;
-    const char* xs = dsm + (size_t)m * row_bytes + g * 16;
+    // STAGE: K is walked in chunks of p.kc columns so that the normalised rows of a chunk (Mp x kc bf16) fit in LDS
+    const int kc_tiles = STAGE ? (p.kc >> 5) : nkt;
+    const int row_bytes = (STAGE ? p.kc : p.K) * 2 + 16;
+    const int Mp = p.M <= 8 ? 8 : 16;
+    if constexpr (NORM && STAGE) {
+        for (int r = wave; r < Mp; r += WAVES) {  // 1/rms per row from the producer's partials (fixed order)
+            float ss = 0.f;
+            for (int q = lane; q < p.npart; q += 64) ss += p.ssq_in[(size_t)r * p.npart + q];
+            ss = wave_sum(ss);
+            if (lane == 0) rstd_s[r] = rsqrtf(ss / (float)p.K + p.eps);
+        }
+    }
     if constexpr (NORM && !STAGE) {
         // per-row 1/rms from the producer's deterministic partial sums (fixed summation order -> bit-reproducible)
         const float* sp = p.ssq_in + (size_t)m * p.npart;
@@ -78,9 +86,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     // K loop, software-pipelined over batches of U k-tiles with two register sets: the weight loads of batch b+1 are in
-    // flight while the MFMAs of batch b run, and the first batch is requested BEFORE the normalise prologue.
+    // flight while the MFMAs of batch b run, and the first batch of a chunk is requested BEFORE its normalise prologue.
     constexpr int U = 8 / NT;
-    const int nb = (kt1 - kt0) / U;  // full batches of this wave (wave-uniform)
     u32x4 wa[NT][U], wb[NT][U];
     auto load_w = [&](u32x4 (&w)[NT][U], int kt) {
 #pragma unroll
@@ -88,66 +95,66 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) w[t][u] = ld16_stream(wp[t] + (size_t)(kt + u) * 512);
     };
-    if (nb > 0) load_w(wa, kt0);
-    if constexpr (NORM && STAGE) {
-        const int Mp = p.M <= 8 ? 8 : 16;
-        for (int r = wave; r < Mp; r += WAVES) {  // 1/rms per row from the producer's partials (fixed order)
-            float ss = 0.f;
-            for (int q = lane; q < p.npart; q += 64) ss += p.ssq_in[(size_t)r * p.npart + q];
-            ss = wave_sum(ss);
-            if (lane == 0) rstd_s[r] = rsqrtf(ss / (float)p.K + p.eps);
-        }
-        __syncthreads();
-        // normalise: thread t owns 16-byte chunks t, t+512, ... of EVERY row; the row loop is unrolled so the 4 loads of
-        // all rows are in flight together (an un-unrolled loop pays one L2 round trip per row)
-        const int cpr = p.K >> 3;
-        for (int c = tid; c < cpr; c += WAVES * 64) {
-            const f32x4 w0 = ld16f(p.norm_w + c * 8), w1 = ld16f(p.norm_w + c * 8 + 4);
+    for (int cbase = 0; cbase < nkt; cbase += kc_tiles) {
+        const int per = (kc_tiles + WAVES - 1) / WAVES;
+        const int kt0 = cbase + wave * per, kt1 = min(cbase + kc_tiles, kt0 + per);
+        const int nb = max(kt1 - kt0, 0) / U;  // full batches of this wave in this chunk (wave-uniform)
+        if (nb > 0) load_w(wa, kt0);
+        if constexpr (NORM && STAGE) {
+            __syncthreads();  // rstd_s ready / every wave finished reading the previous chunk's rows
+            // normalise: thread t owns 16-byte column groups t, t+512, ... of EVERY row; the row loop is unrolled so the
+            // loads of all rows are in flight together (an un-unrolled loop pays one L2 round trip per row)
+            const int cpr = p.kc >> 3, col0 = cbase * 32;
+            for (int c = tid; c < cpr; c += WAVES * 64) {
+                const f32x4 w0 = ld16f(p.norm_w + col0 + c * 8), w1 = ld16f(p.norm_w + col0 + c * 8 + 4);
 #pragma unroll 8
-            for (int r = 0; r < Mp; ++r) {
-                u32x4 v = {0u, 0u, 0u, 0u};
-                if (r < p.M) {
-                    const float* xr = p.Xf + (size_t)r * p.K + c * 8;
-                    const f32x4 x0 = ld16f(xr), x1 = ld16f(xr + 4);
-                    const float rs = rstd_s[r];
-                    v = u32x4{pack_bf2((x0[0] * rs) * w0[0], (x0[1] * rs) * w0[1]), pack_bf2((x0[2] * rs) * w0[2], (x0[3] * rs) * w0[3]),
-                              pack_bf2((x1[0] * rs) * w1[0], (x1[1] * rs) * w1[1]), pack_bf2((x1[2] * rs) * w1[2], (x1[3] * rs) * w1[3])};
+                for (int r = 0; r < Mp; ++r) {
+                    u32x4 v = {0u, 0u, 0u, 0u};
+                    if (r < p.M) {
+                        const float* xr = p.Xf + (size_t)r * p.K + col0 + c * 8;
+                        const f32x4 x0 = ld16f(xr), x1 = ld16f(xr + 4);
+                        const float rs = rstd_s[r];
+                        v = u32x4{pack_bf2((x0[0] * rs) * w0[0], (x0[1] * rs) * w0[1]), pack_bf2((x0[2] * rs) * w0[2], (x0[3] * rs) * w0[3]),
+                                  pack_bf2((x1[0] * rs) * w1[0], (x1[1] * rs) * w1[1]), pack_bf2((x1[2] * rs) * w1[2], (x1[3] * rs) * w1[3])};
+                    }
+                    st16(dsm + (size_t)r * row_bytes + c * 16, v);
                 }
-                st16(dsm + (size_t)r * row_bytes + c * 16, v);
+            }
+            __syncthreads();
+        }
+        // staged fragment of k-tile kt: row m, chunk-relative column (kt - cbase)*32 + g*8
+        const char* xs = dsm + (size_t)m * row_bytes + g * 16 - (size_t)cbase * 64;
+        auto compute = [&](u32x4 (&w)[NT][U], int kt) {
+            u32x4 xv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if constexpr (NORM && STAGE) xv[u] = mvalid ? ld16(xs + (kt + u) * 64) : u32x4{0u, 0u, 0u, 0u};
+                else if constexpr (NORM) xv[u] = mvalid ? norm_frag(xf + (kt + u) * 32, nw + (kt + u) * 32, rstd) : u32x4{0u, 0u, 0u, 0u};
+                else xv[u] = mvalid ? ld16(xp + (kt + u) * 32) : u32x4{0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = mfma16(w[t][u], xv[u], acc[t]);
+        };
+        for (int b = 0; b < nb; b += 2) {
+            if (b + 1 < nb) load_w(wb, kt0 + (b + 1) * U);
+            compute(wa, kt0 + b * U);
+            if (b + 1 < nb) {
+                if (b + 2 < nb) load_w(wa, kt0 + (b + 2) * U);
+                compute(wb, kt0 + (b + 1) * U);
             }
         }
-        __syncthreads();
-    }
-    auto compute = [&](u32x4 (&w)[NT][U], int kt) {
-        u32x4 xv[U];
+        for (int kt = kt0 + nb * U; kt < kt1; ++kt) {
+            u32x4 xv = {0u, 0u, 0u, 0u};
+            if (mvalid) {
+                if constexpr (NORM && STAGE) xv = ld16(xs + kt * 64);
+                else if constexpr (NORM) xv = norm_frag(xf + kt * 32, nw + kt * 32, rstd);
+                else xv = ld16(xp + kt * 32);
+            }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if constexpr (NORM && STAGE) xv[u] = mvalid ? ld16(xs + (kt + u) * 64) : u32x4{0u, 0u, 0u, 0u};
-            else if constexpr (NORM) xv[u] = mvalid ? norm_frag(xf + (kt + u) * 32, nw + (kt + u) * 32, rstd) : u32x4{0u, 0u, 0u, 0u};
-            else xv[u] = mvalid ? ld16(xp + (kt + u) * 32) : u32x4{0u, 0u, 0u, 0u};
+            for (int t = 0; t < NT; ++t) acc[t] = mfma16(ld16_stream(wp[t] + (size_t)kt * 512), xv, acc[t]);
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = mfma16(w[t][u], xv[u], acc[t]);
-    };
-    for (int b = 0; b < nb; b += 2) {
-        if (b + 1 < nb) load_w(wb, kt0 + (b + 1) * U);
-        compute(wa, kt0 + b * U);
-        if (b + 1 < nb) {
-            if (b + 2 < nb) load_w(wa, kt0 + (b + 2) * U);
-            compute(wb, kt0 + (b + 1) * U);
-        }
-    }
-    for (int kt = kt0 + nb * U; kt < kt1; ++kt) {
-        u32x4 xv = {0u, 0u, 0u, 0u};
-        if (mvalid) {
-            if constexpr (NORM && STAGE) xv = ld16(xs + kt * 64);
-            else if constexpr (NORM) xv = norm_frag(xf + kt * 32, nw + kt * 32, rstd);
-            else xv = ld16(xp + kt * 32);
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = mfma16(ld16_stream(wp[t] + (size_t)kt * 512), xv, acc[t]);
     }
     if constexpr (STAGE) __syncthreads();  // every wave is done with the staged activations before `red` overwrites them
 #pragma unroll
@@ -218,11 +225,22 @@ static void launch_gemv_w(const GemvArgs& a, int epi, size_t shmem, hipStream_t 
 
 void launch_gemv(const GemvArgs& a, int epilogue, hipStream_t s) {
     if (a.Xf != nullptr) {  // fused RMSNorm prologue; 2 tiles per workgroup share every activation fragment
-        const size_t stage = (size_t)(a.M <= 8 ? 8 : 16) * ((size_t)a.K * 2 + 16);
-        const size_t need = stage > (size_t)8 * 2 * 64 * 16 ? stage : (size_t)8 * 2 * 64 * 16;  // also holds `red`
+        // chunk K so that one chunk of normalised rows (Mp x kc bf16, 16-byte row pad) stays <= 70 KiB -> 2 workgroups
+        // per CU; kc must keep every wave's k-tile share whole (multiple of 8 waves x 32)
+        const size_t Mp = a.M <= 8 ? 8 : 16;
+        int nch = 0;
+        for (int c = 1; c <= 16 && !nch; ++c)
+            if (a.K % c == 0 && (a.K / c) % 256 == 0 && Mp * ((size_t)(a.K / c) * 2 + 16) <= 70 * 1024) nch = c;
         static const int stage_ok = getenv("VC_GEMV_STAGE") ? atoi(getenv("VC_GEMV_STAGE")) : 1;
-        if (stage_ok && need <= 150 * 1024) launch_gemv_w<8, 2, true, true>(a, epilogue, need, s);
-        else launch_gemv_w<8, 2, true, false>(a, epilogue, 0, s);
+        if (stage_ok && nch) {
+            GemvArgs b = a;
+            b.kc = a.K / nch;
+            const size_t stage = Mp * ((size_t)b.kc * 2 + 16);
+            const size_t need = stage > (size_t)8 * 2 * 64 * 16 ? stage : (size_t)8 * 2 * 64 * 16;  // also holds `red`
+            launch_gemv_w<8, 2, true, true>(b, epilogue, need, s);
+        } else {
+            launch_gemv_w<8, 2, true, false>(a, epilogue, 0, s);
+        }
         return;
     }
     // plain activations: >= ~2048 waves in flight — few output tiles -> more K-splitting waves per workgroup

@@ -55,6 +55,7 @@ struct GemvArgs {
     const float* ssq_in;   // [16, npart]
     float* ssq_out;        // RESID epilogue: ssq_out[m][n_tile] = sum over this tile's 16 columns of out^2, or nullptr
     int npart;             // partials per row (multiple of 16)
+    int kc;                // set by the launcher: columns of K staged in LDS at a time (fused-norm form)
     float eps;
 };
 void launch_gemv(const GemvArgs& a, int epilogue, hipStream_t s);
