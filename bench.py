@@ -110,6 +110,9 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="samples per GPU (BASELINE configs[1]: 8)")
     ap.add_argument("--new-tokens", type=int, default=128)
     ap.add_argument("--model", default="7b", choices=["7b", "13b"])
+    ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"],
+                    help="decoder weight storage: bf16 (BASELINE configs[1], the default metric) or fp8 = W8A16 e4m3 with "
+                         "per-row power-of-two scales (the weight format of BASELINE configs[4])")
     ap.add_argument("--inflight", type=int, default=3,
                     help="batches in flight per GPU: independent sessions (own stream + KV cache, shared weights) driven by "
                          "host threads, so one batch's MFMA-bound prefill and per-launch ramps overlap another's "
@@ -149,6 +152,8 @@ def main():
     cfg = vcfg.vicuna_7b("vcoder_ds") if args.model == "7b" else vcfg.vicuna_13b("vcoder_ds")
     eng = HipEngine(cfg, device_index=local)
     eng.load_synthetic(42)
+    if args.weights == "fp8":
+        eng.set_weight_format("fp8")
     eng.finalize()
     B, N_new = args.batch, args.new_tokens
     first, _ = shard_range(world * B, rank, world)   # contiguous shard of the global batch
@@ -208,7 +213,7 @@ def main():
     if rank == 0:
         traffic = args.pmc_traffic_bytes
         pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if traffic is None and args.model == "7b" and B == 8 and os.path.exists(pmc_file):
+        if traffic is None and args.model == "7b" and B == 8 and args.weights == "bf16" and os.path.exists(pmc_file):
             with open(pmc_file) as f:   # separate --pmc pass, gfx950 x2 correction applied (see the file)
                 traffic = json.load(f)["hbm_read_bytes_per_launch"]
         S = 64 + 2 * cfg.num_patches
@@ -219,7 +224,7 @@ def main():
             "value": world * B * args.steps / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"VCoder-DS LLaVA-1.5-{args.model} bf16, batch={B}/GPU RGB+seg+depth 336x336, "
+            "config": {"workload": f"VCoder-DS LLaVA-1.5-{args.model} {'bf16' if args.weights == 'bf16' else 'bf16 activations / fp8-e4m3 decoder weights (W8A16)'}, batch={B}/GPU RGB+seg+depth 336x336, "
                                    f"prefill S={S}, {N_new}-token greedy decode", "global_batch": world * B,
                        "parallelism": f"dp{world}", "weights": "seeded synthetic (vcoder_amd/synth.py)",
                        "in_flight_batches_per_gpu": n_sess},

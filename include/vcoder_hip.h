@@ -82,6 +82,13 @@ int vc_model_finalize(vc_model* m);
  * "logits within 1e-3, greedy ids bit-exact" bar of BASELINE.json.  Takes effect at the next prefill. */
 int vc_model_set_precision(vc_model* m, int mode);
 
+/* decoder weight storage: 0 = bf16 (default); 1 = W8A16 — the seven linears of every decoder layer are quantised at
+ * vc_model_finalize to OCP fp8 e4m3 with one power-of-two scale per output row and streamed as bytes by the decode
+ * GEMV (half the HBM traffic of the decode step); the prefill GEMMs read the same dequantised values in bf16, so both
+ * phases compute with one set of effective weights.  This is the "fp8 weights" axis of BASELINE.json configs[4]; the
+ * reference's counterpart is `load_8bit` (builder.py:31-33, bitsandbytes int8).  Call before vc_model_finalize. */
+int vc_model_set_weight_format(vc_model* m, int fmt);
+
 /* ---- hot path ------------------------------------------------------------------------------ */
 /* encode_images / encode_seg_images / encode_depth_images (vcoder_ds_llava_arch.py:106-119):
  * pixels fp32 [B,3,S,S] (host, or device when pixels_on_device) -> projected features fp32 [B,P,hidden] on host. */

@@ -25,6 +25,13 @@ void vck_gemv(const uint16_t* X, const uint16_t* Wp, void* out, int M, int N, in
 void vck_gemv_norm(const float* Xf, const float* norm_w, const float* ssq_in, int npart, float eps, const uint16_t* X,
                    const uint16_t* Wp, void* out, float* ssq_out, int M, int N, int K, int ldo, int epi, void* stream);
 void vck_pack_weight(const uint16_t* W, uint16_t* Wp, int N, int K, void* stream);
+/* W8A16 decode weights (BASELINE config C5): per-output-row power-of-two scale + OCP e4m3 bytes in the gemv's 64-wide
+ * k super-tile order; W [N,K] bf16 is overwritten with the dequantised values (what the prefill GEMMs then read).
+ * vck_gemv_fp8 = vck_gemv / vck_gemv_norm over those bytes (Xf == NULL selects the plain-activation form). */
+void vck_quantize_fp8(uint16_t* W, uint8_t* Wq, float* scale, int N, int K, void* stream);
+void vck_gemv_fp8(const float* Xf, const float* norm_w, const float* ssq_in, int npart, float eps, const uint16_t* X,
+                  const uint8_t* Wq, const float* wscale, void* out, float* ssq_out, int M, int N, int K, int ldo, int epi,
+                  void* stream);
 void vck_interleave_rows(const uint16_t* gate, const uint16_t* up, uint16_t* out, int F, int K, void* stream);
 /* nn.LayerNorm ([HF] clip :370,379) and LlamaRMSNorm ([HF] llama :53-70); fp32 in, bf16 out */
 void vck_layernorm(const float* x, const float* w, const float* b, uint16_t* y, int rows, int D, float eps, void* stream);

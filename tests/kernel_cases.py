@@ -52,7 +52,7 @@ class EmuBackend:
         return np.ascontiguousarray(a, dtype=np.int32)
 
     def zeros(self, shape, kind):
-        return np.zeros(shape, dtype={"f32": np.float32, "bf16": np.uint16, "i32": np.int32}[kind])
+        return np.zeros(shape, dtype={"f32": np.float32, "bf16": np.uint16, "i32": np.int32, "u8": np.uint8}[kind])
 
     def ptr(self, a):
         return None if a is None else a.ctypes.data_as(c_p)
@@ -87,7 +87,7 @@ class HipBackend:
         return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(self.dev)
 
     def zeros(self, shape, kind):
-        dt = {"f32": torch.float32, "bf16": torch.int16, "i32": torch.int32}[kind]
+        dt = {"f32": torch.float32, "bf16": torch.int16, "i32": torch.int32, "u8": torch.uint8}[kind]
         return torch.zeros(shape, dtype=dt, device=self.dev)
 
     def ptr(self, a):
@@ -181,6 +181,59 @@ def check_gemv(be, M, N, K, epi, seed=0):
     _call(be, "vck_gemv", be.bf16(X), Wp, out, M, N, K, N // 2 if epi == 3 else N, epi)
     e = rel_err(be.host_f32(out), t.numpy())
     assert e < (2 ** -8 if epi in (0, 3) else 1e-5), f"gemv M{M} N{N} K{K} epi{epi}: rel err {e}"
+    return e
+
+
+def check_gemv_fp8(be, M, N, K, epi, norm=False, seed=0):
+    """W8A16: the device quantiser is bit-identical to vcoder_amd/quant.py (bytes, scales, dequantised bf16 rewrite),
+    and the byte-streaming GEMV equals X @ W_eff^T."""
+    from vcoder_amd import quant
+
+    rng = np.random.RandomState(seed)
+    W = rng.randn(N, K) * 0.05 * np.exp2(rng.randint(-6, 4, size=(N, 1)))  # row magnitudes over 10 octaves
+    W[rng.randint(N)] = 0.0                                                 # an all-zero row (scale 1)
+    W[rng.randint(N), rng.randint(K)] = 37.0                                # an outlier: the rest of that row underflows
+    W = bf16_round(W)
+    q, s, w_eff = quant.quantize_rows(W)
+    Wb, Wq, sc = be.bf16(W), be.zeros((N * K,), "u8"), be.zeros((N,), "f32")
+    _call(be, "vck_quantize_fp8", Wb, Wq, sc, N, K)
+    got_q = np.asarray(Wq.cpu().numpy() if hasattr(Wq, "cpu") else Wq)
+    assert np.array_equal(be.host_f32(sc), s), "row scales differ from quant.row_scales"
+    assert np.array_equal(got_q, quant.pack_supertiles(q)), "e4m3 bytes differ from quant.e4m3_encode"
+    assert np.array_equal(be.host_f32(Wb), w_eff), "dequantised rewrite differs"
+    assert np.array_equal(bf16_round(w_eff), w_eff)
+    X = bf16_round(rng.randn(M, K))
+    Xd = be.bf16(X)
+    npart = 16
+    xf = ssq = nw = None
+    if norm:
+        x32 = (rng.randn(M, K) * 1.5).astype(np.float32)
+        w1 = (rng.rand(K) + 0.5).astype(np.float32)
+        part = np.zeros((16, npart), np.float32)
+        part[:M, : npart // 2] = ((x32.astype(np.float64) ** 2).sum(-1) / (npart // 2))[:, None]
+        xp = np.zeros((16, K), np.float32)
+        xp[:M] = x32
+        xf, ssq, nw = be.f32(xp), be.f32(part), be.f32(w1)
+        X = bf16_round(cpu_ref.rms_norm(torch.from_numpy(x32), torch.from_numpy(w1), 1e-5).numpy())
+    t = torch.from_numpy(X.astype(np.float64) @ w_eff.T.astype(np.float64)).float()
+    if epi == 0:
+        out = be.zeros((M, N), "bf16")
+    elif epi == 1:
+        out = be.zeros((M, N), "f32")
+    elif epi == 2:
+        r0 = rng.randn(M, N).astype(np.float32)
+        out = be.f32(r0)
+        t = t + torch.from_numpy(r0)
+    else:
+        out = be.zeros((M, N // 2), "bf16")
+        t = torch.nn.functional.silu(t[:, 0::2]) * t[:, 1::2]
+    be.lib.vck_gemv_fp8(be.ptr(xf), be.ptr(nw), be.ptr(ssq), ctypes.c_int(npart), ctypes.c_float(1e-5),
+                        None if norm else be.ptr(Xd), be.ptr(Wq), be.ptr(sc), be.ptr(out), None, M, N, K,
+                        N // 2 if epi == 3 else N, epi, None)
+    be.sync()
+    e = rel_err(be.host_f32(out), t.numpy())
+    tol = (2 ** -8 if epi in (0, 3) else 1e-5) if not norm else 3e-3  # norm: bf16 boundary flips of the activations
+    assert e < tol, f"gemv_fp8 M{M} N{N} K{K} epi{epi} norm{norm}: rel err {e}"
     return e
 
 

@@ -33,3 +33,9 @@ def test_device_preprocessing_matches_pil(emu_lib, tmp_path):
     eng = e2e_cases.engine_for("vcoder_ds", emu_lib)   # 56 x 56 tower
     pc.check_preprocess(eng, [(56, 56), (40, 100), (120, 75), (200, 200), (30, 31)])
     pc.check_against_hf_processor(eng, tmp_path)
+
+
+def test_fp8_weight_format(emu_lib):
+    """W8A16 decoder weights through the emulator: quantise-at-finalize, byte-streaming GEMV, strict + fast paths."""
+    r = e2e_cases.check_fp8_weights("ds_img_only", lib=emu_lib, n_new=4)
+    assert r["strict_err"] < 1e-4

@@ -295,3 +295,42 @@ def test_device_preprocessing_matches_pil(tmp_path):
     t_pil = time.perf_counter() - t0
     print(f"preprocess 24 x 480x640 -> 336: device path {t_dev * 1e3:.1f} ms, host PIL+numpy {t_pil * 1e3:.1f} ms")
     eng.close()
+
+
+@pytest.mark.parametrize("name", ["ds_img_depth_seg", "vc_img_seg"])
+def test_fp8_weight_format(name):
+    """W8A16 decoder weights (BASELINE configs[4] weight format) on the tiny fixtures: strict + fast paths."""
+    r = e2e_cases.check_fp8_weights(name, n_new=8)
+    print(f"fp8 weights {name}: {r}")
+
+
+def test_fp8_weights_true_dims_against_oracle():
+    """13b geometry (D 5120, F 13824, 2 layers), B=2: the device quantiser + byte-streaming GEMV against the bf16-emulating
+    oracle run on the host-quantised effective weights (vcoder_amd/quant.py)."""
+    import torch
+    import cpu_ref
+    from vcoder_amd import quant
+
+    cfg = vcfg.vicuna_13b("vcoder_ds")
+    cfg.num_hidden_layers = 2
+    cfg.vit_num_layers = 2
+    sd = quant.effective_state_dict(synth.synth_state_dict(cfg, 13))
+    eng = HipEngine(cfg)
+    eng.load_synthetic(13)
+    eng.set_weight_format("fp8")
+    eng.finalize()
+    ids = synth.synth_prompt_ids(cfg.vocab_size, "vcoder_ds", sample=1)[None]
+    imgs, segs, deps = synth.synth_batch(1, 336, first=1)
+    last, _, S = eng.prefill(ids, imgs, segs, deps)
+    lg2, _ = eng.decode_step(np.argmax(last, -1).astype(np.int32))
+    om = cpu_ref.OracleModel(cfg, sd, emu_bf16=True)
+    t = torch.from_numpy
+    with torch.no_grad():
+        o_last, cache = om.forward(ids.tolist(), t(imgs), t(segs), t(deps), last_only=True)
+        o_lg2 = om.decode_step(np.argmax(last, -1).tolist(), cache)
+    o_last, o_lg2 = o_last[:, -1].numpy(), o_lg2[:, -1].numpy()
+    e1, e2 = np.abs(last - o_last).max(), np.abs(lg2 - o_lg2).max()
+    scale = np.abs(o_last).max()
+    print(f"fp8 true-dims parity: |logits|max={scale:.3f} prefill err={e1:.4f} decode(fp8 gemv) err={e2:.4f}")
+    assert e1 < 2e-2 * max(1.0, scale) and e2 < 2e-2 * max(1.0, scale)
+    eng.close()

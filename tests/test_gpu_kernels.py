@@ -29,6 +29,13 @@ def test_gemv(be, M, N, K, epi):
     kc.check_gemv(be, M, N, K, epi)
 
 
+@pytest.mark.parametrize("M,N,K,epi,norm", [(8, 12288, 4096, 0, True), (8, 4096, 4096, 2, False), (8, 22016, 4096, 3, True),
+                                            (8, 4096, 11008, 2, False), (16, 15360, 5120, 0, True),
+                                            (16, 5120, 13824, 2, False), (3, 48, 320, 1, False), (5, 32, 320, 1, True)])
+def test_gemv_fp8(be, M, N, K, epi, norm):
+    kc.check_gemv_fp8(be, M, N, K, epi, norm)
+
+
 def test_small_ops(be):
     kc.check_interleave(be, 11008, 256)
     kc.check_layernorm(be, 4616, 1024)

@@ -24,6 +24,13 @@ def test_gemv(be, M, N, K, epi):
     kc.check_gemv(be, M, N, K, epi)
 
 
+@pytest.mark.parametrize("M,N,K,epi,norm", [(8, 64, 256, 0, False), (3, 32, 1024, 1, False), (16, 48, 320, 2, False),
+                                            (8, 64, 256, 3, False), (1, 16, 64, 1, False), (8, 64, 512, 0, True),
+                                            (16, 32, 5120, 3, True), (5, 32, 320, 1, True)])
+def test_gemv_fp8(be, M, N, K, epi, norm):
+    kc.check_gemv_fp8(be, M, N, K, epi, norm)
+
+
 def test_interleave(be):
     kc.check_interleave(be, 24, 64)
 

@@ -51,6 +51,8 @@ def declare(lib: C.CDLL) -> C.CDLL:
     lib.vc_model_finalize.argtypes = [vp]
     lib.vc_model_set_precision.argtypes = [vp, i32]
     lib.vc_model_set_precision.restype = C.c_int
+    lib.vc_model_set_weight_format.argtypes = [vp, i32]
+    lib.vc_model_set_weight_format.restype = C.c_int
     lib.vc_encode.argtypes = [vp, i32, vp, i32, i32, vp]
     lib.vc_prefill.argtypes = [vp, vp, i32, i32, vp, vp, vp, i32, i32, vp, vp, C.POINTER(C.c_int)]
     lib.vc_prefill_embeds_only.argtypes = [vp, vp, i32, i32, vp, vp, vp, i32, i32, vp, C.POINTER(C.c_int)]

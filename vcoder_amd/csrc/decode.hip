@@ -37,8 +37,16 @@ VC_DEV u32x4 norm_frag(const float* xp, const float* wp, float rstd) {
 // (bf16, rows padded by 16 B so the 16 token rows of a fragment read hit 16 different bank groups) and the K loop
 // then reads activation fragments with ds_read_b128 — the streaming loop is as lean as the plain one.  !STAGE
 // (rows do not fit the 160 KiB LDS): every wave normalises its own fragments straight from L2.
-template <int WAVES, int NT, int EPI, bool NORM, bool STAGE>
+//
+// FP8 (W8A16): the packed weights are e4m3 bytes, one 16-byte load per lane = 16 consecutive k of one output row, i.e. a
+// 64-wide k "super tile" per wave-instruction ([N/16][K/64][64 lanes][16 B]; lane = n%16 + 16*((k%64)/16)).  The bytes
+// are widened to bf16 fragments in registers (exact) and fed to two MFMAs whose activation fragments use the same k
+// assignment; the per-output-row power-of-two scale multiplies the fp32 accumulator in the epilogue (exact).
+template <int WAVES, int NT, int EPI, bool NORM, bool STAGE, bool FP8>
 __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
+    constexpr int KT = FP8 ? 64 : 32;   // k columns per 16-byte weight load
+    constexpr int KSH = FP8 ? 6 : 5;
+    constexpr int GK = KT / 4;          // k columns per lane group
     VC_DYNAMIC_SMEM(char, dsm);  // STAGE: normalised activations, later re-used for the cross-wave reduction
     __shared__ __attribute__((aligned(16))) float red_static[STAGE ? 1 : WAVES * NT * 64 * 4];
     __shared__ float rstd_s[16];
@@ -46,18 +54,18 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntiles = p.N >> 4;
     const int nt0 = blockIdx.x * NT;
-    const int nkt = p.K >> 5;
+    const int nkt = p.K >> KSH;
     const int m = lane & 15, g = lane >> 4;
     const bool mvalid = m < p.M;
     const bf16_t* wp[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) wp[t] = p.Wp + ((size_t)min(nt0 + t, ntiles - 1) * nkt * 64 + lane) * 8;
-    const bf16_t* xp = p.X + (size_t)(mvalid ? m : 0) * p.K + g * 8;
+    const bf16_t* xp = p.X + (size_t)(mvalid ? m : 0) * p.K + g * GK;
     const float* xf = nullptr;
     const float* nw = nullptr;
     float rstd = 0.f;
     // STAGE: K is walked in chunks of p.kc columns so that the normalised rows of a chunk (Mp x kc bf16) fit in LDS
-    const int kc_tiles = STAGE ? (p.kc >> 5) : nkt;
+    const int kc_tiles = STAGE ? (p.kc >> KSH) : nkt;
     const int row_bytes = (STAGE ? p.kc : p.K) * 2 + 16;
     const int Mp = p.M <= 8 ? 8 : 16;
     if constexpr (NORM && STAGE) {
@@ -79,8 +87,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
         ss += shfl_xor(ss, 16);
         ss += shfl_xor(ss, 32);
         rstd = rsqrtf(ss / (float)p.K + p.eps);
-        xf = p.Xf + (size_t)(mvalid ? m : 0) * p.K + g * 8;
-        nw = p.norm_w + g * 8;
+        xf = p.Xf + (size_t)(mvalid ? m : 0) * p.K + g * GK;
+        nw = p.norm_w + g * GK;
     }
     f32x4 acc[NT];
 #pragma unroll
@@ -104,7 +112,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
             __syncthreads();  // rstd_s ready / every wave finished reading the previous chunk's rows
             // normalise: thread t owns 16-byte column groups t, t+512, ... of EVERY row; the row loop is unrolled so the
             // loads of all rows are in flight together (an un-unrolled loop pays one L2 round trip per row)
-            const int cpr = p.kc >> 3, col0 = cbase * 32;
+            const int cpr = p.kc >> 3, col0 = cbase * KT;
             for (int c = tid; c < cpr; c += WAVES * 64) {
                 const f32x4 w0 = ld16f(p.norm_w + col0 + c * 8), w1 = ld16f(p.norm_w + col0 + c * 8 + 4);
 #pragma unroll 8
@@ -122,20 +130,36 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
             }
             __syncthreads();
         }
-        // staged fragment of k-tile kt: row m, chunk-relative column (kt - cbase)*32 + g*8
-        const char* xs = dsm + (size_t)m * row_bytes + g * 16 - (size_t)cbase * 64;
+        // staged fragment of k-tile kt: row m, chunk-relative column (kt - cbase)*KT + g*GK
+        const char* xs = dsm + (size_t)m * row_bytes + g * (GK * 2) - (size_t)cbase * (KT * 2);
+        // activation fragment h (8 columns) of k-tile kt
+        auto xfrag = [&](int kt, int h) -> u32x4 {
+            if (!mvalid) return u32x4{0u, 0u, 0u, 0u};
+            if constexpr (NORM && STAGE) return ld16(xs + kt * (KT * 2) + h * 16);
+            else if constexpr (NORM) return norm_frag(xf + kt * KT + h * 8, nw + kt * KT + h * 8, rstd);
+            else return ld16(xp + kt * KT + h * 8);
+        };
+        auto fma_tile = [&](f32x4& a, const u32x4& w, const u32x4& x0, const u32x4& x1) {
+            if constexpr (FP8) {
+                const u32x2 b0 = fp8x4_to_bf16x4(w[0]), b1 = fp8x4_to_bf16x4(w[1]);
+                const u32x2 b2 = fp8x4_to_bf16x4(w[2]), b3 = fp8x4_to_bf16x4(w[3]);
+                a = mfma16(u32x4{b0[0], b0[1], b1[0], b1[1]}, x0, a);
+                a = mfma16(u32x4{b2[0], b2[1], b3[0], b3[1]}, x1, a);
+            } else {
+                a = mfma16(w, x0, a);
+            }
+        };
         auto compute = [&](u32x4 (&w)[NT][U], int kt) {
-            u32x4 xv[U];
+            u32x4 xv[U], xw[FP8 ? U : 1];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if constexpr (NORM && STAGE) xv[u] = mvalid ? ld16(xs + (kt + u) * 64) : u32x4{0u, 0u, 0u, 0u};
-                else if constexpr (NORM) xv[u] = mvalid ? norm_frag(xf + (kt + u) * 32, nw + (kt + u) * 32, rstd) : u32x4{0u, 0u, 0u, 0u};
-                else xv[u] = mvalid ? ld16(xp + (kt + u) * 32) : u32x4{0u, 0u, 0u, 0u};
+                xv[u] = xfrag(kt + u, 0);
+                if constexpr (FP8) xw[u] = xfrag(kt + u, 1);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = mfma16(w[t][u], xv[u], acc[t]);
+                for (int t = 0; t < NT; ++t) fma_tile(acc[t], w[t][u], xv[u], xw[FP8 ? u : 0]);
         };
         for (int b = 0; b < nb; b += 2) {
             if (b + 1 < nb) load_w(wb, kt0 + (b + 1) * U);
@@ -146,14 +170,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
             }
         }
         for (int kt = kt0 + nb * U; kt < kt1; ++kt) {
-            u32x4 xv = {0u, 0u, 0u, 0u};
-            if (mvalid) {
-                if constexpr (NORM && STAGE) xv = ld16(xs + kt * 64);
-                else if constexpr (NORM) xv = norm_frag(xf + kt * 32, nw + kt * 32, rstd);
-                else xv = ld16(xp + kt * 32);
-            }
+            const u32x4 x0 = xfrag(kt, 0), x1 = FP8 ? xfrag(kt, 1) : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = mfma16(ld16_stream(wp[t] + (size_t)kt * 512), xv, acc[t]);
+            for (int t = 0; t < NT; ++t) fma_tile(acc[t], ld16_stream(wp[t] + (size_t)kt * 512), x0, x1);
         }
     }
     if constexpr (STAGE) __syncthreads();  // every wave is done with the staged activations before `red` overwrites them
@@ -167,6 +186,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
 #pragma unroll
     for (int w = 1; w < WAVES; ++w) v = v + ld16f(red + ((w * NT + wave) * 64 + lane) * 4);
     const int n = nt * 16 + g * 4;  // lane holds out[m][n..n+3]
+    if constexpr (FP8) v = v * ld16f(p.wscale + n);
     if constexpr (EPI == GEMV_RESID_F32) {
         float* o = reinterpret_cast<float*>(p.out) + (size_t)(mvalid ? m : 0) * p.ldo + n;
         if (mvalid) {
@@ -200,52 +220,105 @@ static void allow_big_lds(K kernel, size_t bytes) {
 #endif
 }
 
-template <int WAVES, int NT, bool NORM, bool STAGE>
+template <int WAVES, int NT, bool NORM, bool STAGE, bool FP8>
 static void launch_gemv_w(const GemvArgs& a, int epi, size_t shmem, hipStream_t s) {
     const dim3 grid((a.N / 16 + NT - 1) / NT), block(WAVES * 64);
     switch (epi) {
         case GEMV_BF16:
-            allow_big_lds(gemv_kernel<WAVES, NT, GEMV_BF16, NORM, STAGE>, shmem);
-            VC_LAUNCH((gemv_kernel<WAVES, NT, GEMV_BF16, NORM, STAGE>), grid, block, shmem, s, a);
+            allow_big_lds(gemv_kernel<WAVES, NT, GEMV_BF16, NORM, STAGE, FP8>, shmem);
+            VC_LAUNCH((gemv_kernel<WAVES, NT, GEMV_BF16, NORM, STAGE, FP8>), grid, block, shmem, s, a);
             break;
         case GEMV_F32:
-            allow_big_lds(gemv_kernel<WAVES, NT, GEMV_F32, NORM, STAGE>, shmem);
-            VC_LAUNCH((gemv_kernel<WAVES, NT, GEMV_F32, NORM, STAGE>), grid, block, shmem, s, a);
+            allow_big_lds(gemv_kernel<WAVES, NT, GEMV_F32, NORM, STAGE, FP8>, shmem);
+            VC_LAUNCH((gemv_kernel<WAVES, NT, GEMV_F32, NORM, STAGE, FP8>), grid, block, shmem, s, a);
             break;
         case GEMV_RESID_F32:
-            allow_big_lds(gemv_kernel<WAVES, NT, GEMV_RESID_F32, NORM, STAGE>, shmem);
-            VC_LAUNCH((gemv_kernel<WAVES, NT, GEMV_RESID_F32, NORM, STAGE>), grid, block, shmem, s, a);
+            allow_big_lds(gemv_kernel<WAVES, NT, GEMV_RESID_F32, NORM, STAGE, FP8>, shmem);
+            VC_LAUNCH((gemv_kernel<WAVES, NT, GEMV_RESID_F32, NORM, STAGE, FP8>), grid, block, shmem, s, a);
             break;
         default:
-            allow_big_lds(gemv_kernel<WAVES, NT, GEMV_SWIGLU, NORM, STAGE>, shmem);
-            VC_LAUNCH((gemv_kernel<WAVES, NT, GEMV_SWIGLU, NORM, STAGE>), grid, block, shmem, s, a);
+            allow_big_lds(gemv_kernel<WAVES, NT, GEMV_SWIGLU, NORM, STAGE, FP8>, shmem);
+            VC_LAUNCH((gemv_kernel<WAVES, NT, GEMV_SWIGLU, NORM, STAGE, FP8>), grid, block, shmem, s, a);
             break;
     }
 }
 
-void launch_gemv(const GemvArgs& a, int epilogue, hipStream_t s) {
+template <bool FP8>
+static void launch_gemv_f(const GemvArgs& a, int epilogue, hipStream_t s) {
     if (a.Xf != nullptr) {  // fused RMSNorm prologue; 2 tiles per workgroup share every activation fragment
         // chunk K so that one chunk of normalised rows (Mp x kc bf16, 16-byte row pad) stays <= 70 KiB -> 2 workgroups
-        // per CU; kc must keep every wave's k-tile share whole (multiple of 8 waves x 32)
+        // per CU; kc must keep every wave's k-tile share whole (multiple of 8 waves x the k-tile width)
         const size_t Mp = a.M <= 8 ? 8 : 16;
+        const int align = FP8 ? 512 : 256;
         int nch = 0;
         for (int c = 1; c <= 16 && !nch; ++c)
-            if (a.K % c == 0 && (a.K / c) % 256 == 0 && Mp * ((size_t)(a.K / c) * 2 + 16) <= 70 * 1024) nch = c;
+            if (a.K % c == 0 && (a.K / c) % align == 0 && Mp * ((size_t)(a.K / c) * 2 + 16) <= 70 * 1024) nch = c;
         static const int stage_ok = getenv("VC_GEMV_STAGE") ? atoi(getenv("VC_GEMV_STAGE")) : 1;
         if (stage_ok && nch) {
             GemvArgs b = a;
             b.kc = a.K / nch;
             const size_t stage = Mp * ((size_t)b.kc * 2 + 16);
             const size_t need = stage > (size_t)8 * 2 * 64 * 16 ? stage : (size_t)8 * 2 * 64 * 16;  // also holds `red`
-            launch_gemv_w<8, 2, true, true>(b, epilogue, need, s);
+            launch_gemv_w<8, 2, true, true, FP8>(b, epilogue, need, s);
         } else {
-            launch_gemv_w<8, 2, true, false>(a, epilogue, 0, s);
+            launch_gemv_w<8, 2, true, false, FP8>(a, epilogue, 0, s);
         }
         return;
     }
     // plain activations: >= ~2048 waves in flight — few output tiles -> more K-splitting waves per workgroup
-    if (a.N / 16 <= 512) launch_gemv_w<8, 1, false, false>(a, epilogue, 0, s);
-    else launch_gemv_w<4, 1, false, false>(a, epilogue, 0, s);
+    if (a.N / 16 <= 512) launch_gemv_w<8, 1, false, false, FP8>(a, epilogue, 0, s);
+    else launch_gemv_w<4, 1, false, false, FP8>(a, epilogue, 0, s);
+}
+void launch_gemv(const GemvArgs& a, int epilogue, hipStream_t s) {
+    if (a.wscale) launch_gemv_f<true>(a, epilogue, s);
+    else launch_gemv_f<false>(a, epilogue, s);
+}
+
+// ---- W8A16 quantiser (load time).  One workgroup per output row n of W [N, K] bf16:
+//   s_n = 2^e, e = the smallest integer with absmax_n <= 448 * 2^e     (power of two -> W/s and q*s are exact)
+//   q   = e4m3(W / s_n)  (RNE)  -> packed super-tile layout for gemv_kernel<FP8>
+//   W  <- bf16(q * s_n)  IN PLACE, so the prefill GEMMs (bf16 row-major) see exactly the weights decode sees.
+__global__ __launch_bounds__(256) void quantize_fp8_kernel(bf16_t* W, uint8_t* Wq, float* scale, int N, int K) {
+    __shared__ float red[4];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    bf16_t* row = W + (size_t)n * K;
+    float amax = 0.f;
+    for (int c = tid; c < (K >> 3); c += 256) {
+        const u32x4 v = ld16(row + c * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(bf2f_lo(v[e])), fabsf(bf2f_hi(v[e]))));
+    }
+    amax = wave_max(amax);
+    if ((tid & 63) == 0) red[tid >> 6] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    int e = 0;
+    if (amax > 0.f) {
+        const uint32_t u = __builtin_bit_cast(uint32_t, amax);
+        e = (int)(u >> 23) - 127 - ((u & 0x007FFFFFu) <= 0x00600000u ? 8 : 7);  // 448 = 1.75 * 2^8
+    }
+    const float s = __builtin_bit_cast(float, (uint32_t)(e + 127) << 23), inv = __builtin_bit_cast(float, (uint32_t)(127 - e) << 23);
+    if (tid == 0) scale[n] = s;
+    const int nst = K >> 6;
+    for (int c = tid; c < (K >> 4); c += 256) {  // 16 consecutive k -> one lane's 16 bytes
+        const u32x4 v0 = ld16(row + c * 16), v1 = ld16(row + c * 16 + 8);
+        uint32_t q[4], o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t pk = j < 4 ? v0[j] : v1[j - 4];
+            const uint32_t a = f2fp8(bf2f_lo(pk) * inv), b = f2fp8(bf2f_hi(pk) * inv);
+            if ((j & 1) == 0) q[j >> 1] = a | (b << 8);
+            else q[j >> 1] |= (a << 16) | (b << 24);
+            o[j] = pack_bf2(fp82f_sw(a) * s, fp82f_sw(b) * s);
+        }
+        st16(row + c * 16, u32x4{o[0], o[1], o[2], o[3]});
+        st16(row + c * 16 + 8, u32x4{o[4], o[5], o[6], o[7]});
+        const int st = c >> 2, lane = (n & 15) + 16 * (c & 3);
+        st16(Wq + (((size_t)(n >> 4) * nst + st) * 64 + lane) * 16, u32x4{q[0], q[1], q[2], q[3]});
+    }
+}
+void launch_quantize_fp8(bf16_t* W, uint8_t* Wq, float* scale, int N, int K, hipStream_t s) {
+    VC_LAUNCH(quantize_fp8_kernel, dim3((unsigned)N), dim3(256), 0, s, W, Wq, scale, N, K);
 }
 
 // W [N,K] row-major -> packed fragment order (done once at weight-load time)

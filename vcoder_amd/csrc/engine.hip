@@ -94,7 +94,8 @@ struct VitLayer {
 struct LlmLayer {
     float *in_norm, *post_norm;
     bf16_t *qkv_w, *o_w, *gate_tmp, *up_tmp, *gu_w, *down_w;  // row-major (prefill GEMM)
-    bf16_t *qkv_p, *o_p, *gu_p, *down_p;                      // MFMA-fragment packed (decode GEMV)
+    bf16_t *qkv_p, *o_p, *gu_p, *down_p;                      // MFMA-fragment packed (decode GEMV); e4m3 bytes if W8A16
+    float *qkv_s = nullptr, *o_s = nullptr, *gu_s = nullptr, *down_s = nullptr;  // W8A16 per-output-row scales
 };
 struct Projector {
     int depth = 0;
@@ -111,6 +112,7 @@ struct vc_model {
     bool finalized = false;
     bool owns_weights = true;
     int precision = 0;  // 0: bf16 MFMA fast path; 1: strict fp32 path (strict.hip)
+    int weight_format = 0;  // 0: bf16; 1: W8A16 — decoder linears stored as e4m3 + per-row scales for the decode GEMV
     Buf s_cols, s_patches, s_vx, s_vxn, s_vqkv, s_vq, s_vk, s_vv, s_vattn, s_vh, s_sel, s_mid, s_feats;
     Buf s_xn, s_qkv, s_q, s_attn, s_h, s_kc, s_vc, s_xl;
     Buf pp_src, pp_sq, pp_tmp, pp_out, pp_tab, pp_f32;
@@ -328,13 +330,14 @@ void gemm(vc_model* m, const bf16_t* A, const bf16_t* W, const float* bias, void
 // norm_w != nullptr: fused RMSNorm prologue over the fp32 decode residual stream (x_dec + its ssq partials);
 // write_ssq: RESID epilogue publishes the sum-of-squares partials of the updated residual rows
 void gemv(vc_model* m, const bf16_t* X, const bf16_t* Wp, void* out, int M, int N, int K, int ldo, int epi,
-          const float* norm_w = nullptr, bool write_ssq = false) {
+          const float* norm_w = nullptr, bool write_ssq = false, const float* wscale = nullptr) {
     const size_t esz = (epi == GEMV_F32 || epi == GEMV_RESID_F32) ? 4 : 2;
     const int np = m->npart;
     for (int m0 = 0; m0 < M; m0 += 16) {  // the skinny kernel holds 16 token slots; larger batches re-stream
         GemvArgs a{};
         a.X = X ? X + (size_t)m0 * K : nullptr;
         a.Wp = Wp;
+        a.wscale = wscale;
         a.out = reinterpret_cast<char*>(out) + (size_t)m0 * ldo * esz;
         a.M = std::min(16, M - m0);
         a.N = N;
@@ -737,13 +740,13 @@ void enqueue_decode_step(vc_model* m, int B, int max_new, int eos_id, int pad_id
     const int D = c.hidden, F = c.ffn, H = c.heads;
     for (int l = 0; l < c.layers; ++l) {
         const LlmLayer& L = m->llm[l];
-        gemv(m, nullptr, L.qkv_p, m->qkv_dec.p, B, 3 * D, D, 3 * D, GEMV_BF16, L.in_norm);             // K11+K12
+        gemv(m, nullptr, L.qkv_p, m->qkv_dec.p, B, 3 * D, D, 3 * D, GEMV_BF16, L.in_norm, false, L.qkv_s);             // K11+K12
         AttnDecodeFusedArgs da{m->qkv_dec.as<bf16_t>(), kcache(m, l), vtcache(m, l), m->attn_dec.as<bf16_t>(), B, H, m->hd,
                                m->capS, m->pos_dev(), m->rope_cos, m->rope_sin, 1.0f / sqrtf((float)m->hd)};
         launch_attention_decode_fused(da, m->st);                                                          // K13-K15
-        gemv(m, m->attn_dec.as<bf16_t>(), L.o_p, m->x_dec.p, B, D, D, D, GEMV_RESID_F32, nullptr, true);  // K16
-        gemv(m, nullptr, L.gu_p, m->h_dec.p, B, 2 * F, D, F, GEMV_SWIGLU, L.post_norm);                    // K11+K17
-        gemv(m, m->h_dec.as<bf16_t>(), L.down_p, m->x_dec.p, B, D, F, D, GEMV_RESID_F32, nullptr, true);  // K17
+        gemv(m, m->attn_dec.as<bf16_t>(), L.o_p, m->x_dec.p, B, D, D, D, GEMV_RESID_F32, nullptr, true, L.o_s);  // K16
+        gemv(m, nullptr, L.gu_p, m->h_dec.p, B, 2 * F, D, F, GEMV_SWIGLU, L.post_norm, false, L.gu_s);                    // K11+K17
+        gemv(m, m->h_dec.as<bf16_t>(), L.down_p, m->x_dec.p, B, D, F, D, GEMV_RESID_F32, nullptr, true, L.down_s);  // K17
     }
     gemv(m, nullptr, m->lm_head_p, m->logits.p, B, c.vocab, D, c.vocab, GEMV_F32, m->final_norm);          // K11+K18
     launch_greedy_embed(greedy_embed_args(m, B, max_new, eos_id, pad_id, 3), m->st);                       // K19+K10
@@ -1022,6 +1025,7 @@ VC_API int vc_model_create_shared(vc_ctx* ctx, vc_model* parent, vc_model** out)
     m->st = ctx->stream;
     m->finalized = true;
     m->owns_weights = false;
+    m->weight_format = parent->weight_format;
     m->P = parent->P; m->Tv = parent->Tv; m->Kpatch = parent->Kpatch; m->Kpad = parent->Kpad;
     m->hd = parent->hd; m->vhd = parent->vhd; m->npart = parent->npart;
     m->vit_cls = parent->vit_cls; m->vit_pos = parent->vit_pos; m->vit_pre_w = parent->vit_pre_w;
@@ -1103,6 +1107,16 @@ VC_API int vc_model_set_precision(vc_model* m, int mode) {
     return VC_OK;
 }
 
+/* 0: bf16 weights (default).  1: W8A16 — q/k/v/o/gate/up/down of every decoder layer are quantised at finalize to OCP
+ * e4m3 with a per-output-row power-of-two scale (BASELINE config C5); embeddings, lm_head, norms, the CLIP tower and the
+ * adapters stay bf16/fp32.  Must be called before vc_model_finalize. */
+VC_API int vc_model_set_weight_format(vc_model* m, int fmt) {
+    if (!m || (fmt != 0 && fmt != 1)) return VC_ERR_INVALID;
+    if (m->finalized) return VC_ERR_STATE;
+    m->weight_format = fmt;
+    return VC_OK;
+}
+
 VC_API int vc_model_finalize(vc_model* m) {
     if (!m) return VC_ERR_INVALID;
     GUARD_BEGIN
@@ -1111,16 +1125,26 @@ VC_API int vc_model_finalize(vc_model* m) {
     for (auto& kv : m->need) REQUIRE(kv.second, VC_ERR_STATE, "missing tensor '%s'", kv.first.c_str());
     const vc_model_cfg& c = m->c;
     const int D = c.hidden, F = c.ffn, V = c.vocab;
+    // decode copy of one decoder linear: MFMA-packed bf16, or (W8A16) e4m3 super-tiles + per-row scales — the quantiser
+    // also rewrites the row-major bf16 matrix with the dequantised values so prefill and decode share one set of weights
+    auto decode_copy = [&](bf16_t* W, int N, int K, bf16_t*& Wp, float*& Ws) {
+        if (m->weight_format == 1) {
+            Wp = reinterpret_cast<bf16_t*>(walloc<uint8_t>(m, (size_t)N * K));
+            Ws = walloc<float>(m, N);
+            launch_quantize_fp8(W, reinterpret_cast<uint8_t*>(Wp), Ws, N, K, m->st);
+        } else {
+            Wp = walloc<bf16_t>(m, (size_t)N * K);
+            launch_pack_weight(W, Wp, N, K, m->st);
+        }
+    };
+    if (m->weight_format == 1)
+        REQUIRE(D % 64 == 0 && F % 64 == 0, VC_ERR_INVALID, "W8A16 needs hidden and ffn sizes divisible by 64");
     for (auto& L : m->llm) {
         launch_interleave_rows(L.gate_tmp, L.up_tmp, L.gu_w, F, D, m->st);
-        L.qkv_p = walloc<bf16_t>(m, (size_t)3 * D * D);
-        L.o_p = walloc<bf16_t>(m, (size_t)D * D);
-        L.gu_p = walloc<bf16_t>(m, (size_t)2 * F * D);
-        L.down_p = walloc<bf16_t>(m, (size_t)D * F);
-        launch_pack_weight(L.qkv_w, L.qkv_p, 3 * D, D, m->st);
-        launch_pack_weight(L.o_w, L.o_p, D, D, m->st);
-        launch_pack_weight(L.gu_w, L.gu_p, 2 * F, D, m->st);
-        launch_pack_weight(L.down_w, L.down_p, D, F, m->st);
+        decode_copy(L.qkv_w, 3 * D, D, L.qkv_p, L.qkv_s);
+        decode_copy(L.o_w, D, D, L.o_p, L.o_s);
+        decode_copy(L.gu_w, 2 * F, D, L.gu_p, L.gu_s);
+        decode_copy(L.down_w, D, F, L.down_p, L.down_s);
     }
     m->lm_head_p = walloc<bf16_t>(m, (size_t)V * D);
     launch_pack_weight(m->lm_head, m->lm_head_p, V, D, m->st);
@@ -1449,10 +1473,10 @@ VC_API int vc_profile_decode_gemv(vc_model* m, int B, int reps, int* launches, d
     auto sweep = [&]() {
         for (int l = 0; l < c.layers; ++l) {
             const LlmLayer& L = m->llm[l];
-            gemv(m, nullptr, L.qkv_p, m->qkv_dec.p, B, 3 * D, D, 3 * D, GEMV_BF16, L.in_norm);
-            gemv(m, m->attn_dec.as<bf16_t>(), L.o_p, m->x_dec.p, B, D, D, D, GEMV_RESID_F32, nullptr, true);
-            gemv(m, nullptr, L.gu_p, m->h_dec.p, B, 2 * F, D, F, GEMV_SWIGLU, L.post_norm);
-            gemv(m, m->h_dec.as<bf16_t>(), L.down_p, m->x_dec.p, B, D, F, D, GEMV_RESID_F32, nullptr, true);
+            gemv(m, nullptr, L.qkv_p, m->qkv_dec.p, B, 3 * D, D, 3 * D, GEMV_BF16, L.in_norm, false, L.qkv_s);
+            gemv(m, m->attn_dec.as<bf16_t>(), L.o_p, m->x_dec.p, B, D, D, D, GEMV_RESID_F32, nullptr, true, L.o_s);
+            gemv(m, nullptr, L.gu_p, m->h_dec.p, B, 2 * F, D, F, GEMV_SWIGLU, L.post_norm, false, L.gu_s);
+            gemv(m, m->h_dec.as<bf16_t>(), L.down_p, m->x_dec.p, B, D, F, D, GEMV_RESID_F32, nullptr, true, L.down_s);
         }
         gemv(m, nullptr, m->lm_head_p, m->logits.p, B, c.vocab, D, c.vocab, GEMV_F32, m->final_norm);
     };
@@ -1464,7 +1488,8 @@ VC_API int vc_profile_decode_gemv(vc_model* m, int B, int reps, int* launches, d
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, m->ev[0], m->ev[1]));
     const int n = 4 * c.layers + 1;
-    const double bytes = 2.0 * ((double)c.layers * (4.0 * D * D + 3.0 * D * F) + (double)D * c.vocab);
+    const double wb = m->weight_format == 1 ? 1.0 : 2.0;  // bytes per decoder-linear weight (lm_head stays bf16)
+    const double bytes = wb * (double)c.layers * (4.0 * D * D + 3.0 * D * F) + 2.0 * (double)D * c.vocab;
     if (launches) *launches = n;
     if (avg_us) *avg_us = (double)ms * 1e3 / ((double)reps * n);
     if (avg_bytes) *avg_bytes = bytes / n;

@@ -45,6 +45,17 @@ VCK_EXPORT void vck_embed_tokens_ssq(const int* tok, const uint16_t* embed, floa
                                      void* stream) {
     launch_embed_tokens_ssq(tok, embed, x, ssq, B, D, npart, S(stream));
 }
+VCK_EXPORT void vck_gemv_fp8(const float* Xf, const float* norm_w, const float* ssq_in, int npart, float eps,
+                             const uint16_t* X, const uint8_t* Wq, const float* wscale, void* out, float* ssq_out, int M, int N,
+                             int K, int ldo, int epi, void* stream) {
+    GemvArgs a{};
+    a.X = X; a.Wp = reinterpret_cast<const uint16_t*>(Wq); a.wscale = wscale; a.out = out; a.M = M; a.N = N; a.K = K; a.ldo = ldo;
+    a.Xf = Xf; a.norm_w = norm_w; a.ssq_in = ssq_in; a.ssq_out = ssq_out; a.npart = npart; a.eps = eps;
+    launch_gemv(a, epi, S(stream));
+}
+VCK_EXPORT void vck_quantize_fp8(uint16_t* W, uint8_t* Wq, float* scale, int N, int K, void* stream) {
+    launch_quantize_fp8(W, Wq, scale, N, K, S(stream));
+}
 VCK_EXPORT void vck_pack_weight(const uint16_t* W, uint16_t* Wp, int N, int K, void* stream) {
     launch_pack_weight(W, Wp, N, K, S(stream));
 }

@@ -57,9 +57,14 @@ struct GemvArgs {
     int npart;             // partials per row (multiple of 16)
     int kc;                // set by the launcher: columns of K staged in LDS at a time (fused-norm form)
     float eps;
+    // W8A16: Wp holds e4m3 bytes in the 64-wide super-tile layout (launch_quantize_fp8) and wscale[n] the per-output-row
+    // power-of-two scale; nullptr = bf16 weights.  K % 64 == 0.
+    const float* wscale;
 };
 void launch_gemv(const GemvArgs& a, int epilogue, hipStream_t s);
 void launch_pack_weight(const bf16_t* W, bf16_t* Wp, int N, int K, hipStream_t s);
+// W [N,K] bf16 -> e4m3 packed + per-row scales; W is overwritten with the dequantised values (see decode.hip)
+void launch_quantize_fp8(bf16_t* W, uint8_t* Wq, float* scale, int N, int K, hipStream_t s);
 // interleave gate/up rows: out[2f] = gate[f], out[2f+1] = up[f]
 void launch_interleave_rows(const bf16_t* gate, const bf16_t* up, bf16_t* out, int F, int K, hipStream_t s);
 

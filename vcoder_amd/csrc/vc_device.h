@@ -47,6 +47,44 @@ VC_DEV bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }  /
 #endif
 VC_DEV uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
 
+// ---- fp8 (OCP e4m3fn: 1-4-3, bias 7, max 448, no inf) ----------------------------------------
+// Encode is software on both builds (load-time only; round-to-nearest-even, saturating) so the device, the emulator
+// and vcoder_amd/quant.py produce identical bytes.  Every e4m3 value is exactly representable in bf16, so the
+// decode direction is exact whichever unit does it.
+VC_DEV uint8_t f2fp8(float x) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, x);
+    const uint32_t sign = (u >> 24) & 0x80u;
+    const float a = __builtin_fabsf(x);
+    if (!(a < 448.f)) return (uint8_t)(sign | 0x7Eu);
+    if (a < 0.015625f) return (uint8_t)(sign | (uint32_t)(int)rintf(a * 512.f));  // subnormals: units of 2^-9 (8 -> 2^-6)
+    const int e = (int)((u >> 23) & 0xFFu) - 127;                                   // -6 .. 8
+    const float m = __builtin_bit_cast(float, (u & 0x007FFFFFu) | 0x3F800000u);     // [1, 2)
+    const uint32_t code = ((uint32_t)(e + 7) << 3) + (uint32_t)(int)rintf((m - 1.f) * 8.f);  // mantissa carry rolls over
+    return (uint8_t)(sign | (code > 0x7Eu ? 0x7Eu : code));
+}
+VC_DEV float fp82f_sw(uint32_t b) {
+    const int e = (int)((b >> 3) & 15u), m = (int)(b & 7u);
+    const float mag = e == 0 ? (float)m * 0.001953125f
+                             : __builtin_bit_cast(float, (uint32_t)(e + 120) << 23 | (uint32_t)m << 20);
+    return (b & 0x80u) ? -mag : mag;
+}
+// 4 packed fp8 -> 4 bf16 (two packed words), exact
+#ifdef VC_EMU
+VC_DEV u32x2 fp8x4_to_bf16x4(uint32_t v) {
+    auto hi16 = [](float f) { return __builtin_bit_cast(uint32_t, f) >> 16; };
+    return u32x2{hi16(fp82f_sw(v & 0xFF)) | (hi16(fp82f_sw((v >> 8) & 0xFF)) << 16),
+                 hi16(fp82f_sw((v >> 16) & 0xFF)) | (hi16(fp82f_sw(v >> 24)) << 16)};
+}
+#else
+typedef float f32x2_hw __attribute__((ext_vector_type(2)));
+VC_DEV u32x2 fp8x4_to_bf16x4(uint32_t v) {
+    const f32x2_hw lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)v, false), hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)v, true);
+    // exact values: the bf16 pattern is the top half of the fp32 pattern
+    return u32x2{__builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, lo[1]), __builtin_bit_cast(uint32_t, lo[0]), 0x07060302u),
+                 __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi[1]), __builtin_bit_cast(uint32_t, hi[0]), 0x07060302u)};
+}
+#endif
+
 // ---- MFMA ----------------------------------------------------------------------------------
 #ifndef VC_EMU
 typedef __bf16 bf16x8_hw __attribute__((ext_vector_type(8)));

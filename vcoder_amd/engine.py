@@ -137,6 +137,12 @@ class HipEngine:
         fp32-faithful to the reference's CPU path, slow)."""
         self._check(self.lib.vc_model_set_precision(self._model, {"bf16": 0, "fast": 0, "strict": 1, "fp32": 1}[mode]))
 
+    def set_weight_format(self, fmt: str):
+        """'bf16' (default) or 'fp8' (W8A16: decoder linears as e4m3 + per-row power-of-two scales, quantised at
+        finalize; see vcoder_amd/quant.py for the host restatement).  Before finalize()."""
+        self._check(self.lib.vc_model_set_weight_format(self._model, {"bf16": 0, "fp8": 1, "w8a16": 1}[fmt]))
+        self.weight_format = "fp8" if fmt != "bf16" else "bf16"
+
     def finalize(self):
         self._check(self.lib.vc_model_finalize(self._model))
         self.finalized = True
