@@ -114,3 +114,10 @@ def test_alternate_kernel_variants():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
                         "test_gemm or test_attention"], env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
+    # 5: the counted-vmcnt 8-phase 256x256 kernel forced onto every (small, ragged, 1-3 k-tile) case;
+    # 2: the one-barrier 256x256 kernel; 4: 256x256 as 4 waves x (128 x 128)
+    for v in ("5", "2", "4"):
+        env = dict(os.environ, VC_GEMM_VARIANT=v)
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "test_gemm"],
+                           env=env, capture_output=True, text=True)
+        assert r.returncode == 0, f"VC_GEMM_VARIANT={v}: " + r.stdout[-2000:]

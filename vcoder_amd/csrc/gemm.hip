@@ -259,6 +259,179 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_bf16_dma_kernel(GemmArgs p)
     }
 }
 
+
+// epilogue store of out[m][n..n+3] (shared by the DMA kernels)
+template <int EPI>
+VC_DEV void store_out(const GemmArgs& p, int m, int n, f32x4 v) {
+    if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_QGELU || EPI == EPI_BF16_GELU) {
+        if constexpr (EPI == EPI_BF16_QGELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+        }
+        if constexpr (EPI == EPI_BF16_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = erf_gelu(v[e]);
+        }
+        u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        st8(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo + n, o);
+    } else if constexpr (EPI == EPI_F32) {
+        st16f(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n, v);
+    } else if constexpr (EPI == EPI_RESID_F32) {
+        float* o = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n;
+        st16f(o, ld16f(o) + v);
+    } else {  // EPI_SWIGLU: (g0,u0,g1,u1) -> 2 outputs
+        const uint32_t o = pack_bf2(silu(v[0]) * v[1], silu(v[2]) * v[3]);
+        *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo + (n >> 1)) = o;
+    }
+}
+
+// ---- 256 x 256 tile, 8 waves, counted-vmcnt "8-phase" schedule ----------------------------------------------------------
+// The one-barrier loop above drains the LDS-DMA queue (vmcnt(0)) at every k-tile barrier, so HBM/L2 latency is exposed
+// once per tile.  Here the DMA stream runs 3 half-tiles ahead and is never drained inside the loop:
+//   * a k-tile (BK = 64) is staged as four 16-KiB half-tiles  Y0 | X0 | Y1 | X1  (X = weight rows n, Y = activation rows
+//     m; half h = tile rows [128h, 128h+128)), double-buffered: 2 x 64 KiB;
+//   * wave (g, q) = (wave/4, wave%4) owns n rows {64g..64g+63} of BOTH X halves and m rows {32q..32q+31} of BOTH Y halves,
+//     i.e. a 128 x 64 output made of four 64 x 32 quadrants; one quadrant x BK = 16 MFMAs = one phase;
+//   * phase r of k-tile t:  r=0 reads Y0,X0 (12 fragments) and stages X1(t+1);  r=1 reads Y1, stages Y0(t+2);
+//     r=2 reads X1, stages X0(t+2);  r=3 reads nothing, stages Y1(t+2) and waits vmcnt(6) — everything except the three
+//     most recent half-tiles has landed, which is exactly k-tile t+1.  Every restage targets a half-tile whose last
+//     fragment read retired at least one full barrier earlier (Y0: lgkmcnt(8) before the r=0 barrier);
+//   * the two wave groups g = 0/1 (the two waves of every SIMD) run one barrier apart, so one group's 16 MFMAs (under
+//     s_setprio 1) overlap the other group's fragment reads + DMA issue; barriers are bare s_barrier.
+// LDS-DMA data is ordered for a ds_read only by the issuing wave's vmcnt wait followed by a barrier the reader passes;
+// the r=3 wait precedes that phase's first barrier and the first read of the retired buffer is a phase later.
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
+    constexpr int HALF = 128 * 128, TILE = 4 * HALF;  // bytes
+    constexpr int SY0 = 0, SX0 = HALF, SY1 = 2 * HALF, SX1 = 3 * HALF;
+    VC_DYNAMIC_SMEM(char, smem);  // [2][Y0 | X0 | Y1 | X1]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = wave >> 2, q = wave & 3;
+    const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
+    int tm, tn;
+    tile_coords(blockIdx.x, tiles_m * tiles_n, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * 256, n0 = tn * 256;
+    // DMA sources: every wave moves pieces {wave, 8 + wave} (8 swizzled rows = 1 KiB each) of every half-tile
+    const char* x_src[2][2];
+    const char* y_src[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (i * 8 + wave) * 8 + (lane >> 3);
+            const int sw = ((lane & 7) ^ (row & 7)) << 4;
+            x_src[h][i] = reinterpret_cast<const char*>(p.W + (size_t)min(n0 + h * 128 + row, p.N - 1) * p.ldw) + sw;
+            y_src[h][i] = reinterpret_cast<const char*>(p.A + (size_t)min(m0 + h * 128 + row, p.M - 1) * p.lda) + sw;
+        }
+    const int nk = p.K / BK;
+    auto stage_x = [&](int h, int kt) {
+        if (kt >= nk) return;
+        char* dst = smem + (kt & 1) * TILE + (h ? SX1 : SX0) + wave * 1024;
+        glds16(x_src[h][0] + (size_t)kt * (BK * 2), dst);
+        glds16(x_src[h][1] + (size_t)kt * (BK * 2), dst + 8192);
+    };
+    auto stage_y = [&](int h, int kt) {
+        if (kt >= nk) return;
+        char* dst = smem + (kt & 1) * TILE + (h ? SY1 : SY0) + wave * 1024;
+        glds16(y_src[h][0] + (size_t)kt * (BK * 2), dst);
+        glds16(y_src[h][1] + (size_t)kt * (BK * 2), dst + 8192);
+    };
+    f32x4 acc[2][4][2][2];  // [x half][i][y half][j]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][i][b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fchunk = lane >> 4;
+    u32x4 fx[2][4][2], fy[2][2][2];  // [half][fragment][ks]
+    auto read_x = [&](const char* base, int h) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fx[h][i][ks] = ld16(base + (h ? SX1 : SX0) + swz(g * 64 + i * 16 + frow, ks * 4 + fchunk));
+    };
+    auto read_y = [&](const char* base, int h) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fy[h][j][ks] = ld16(base + (h ? SY1 : SY0) + swz(q * 32 + j * 16 + frow, ks * 4 + fchunk));
+    };
+    auto quadrant = [&](int hx, int hy) {
+        set_prio<1>();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[hx][i][hy][j] = mfma16(fx[hx][i][ks], fy[hy][j][ks], acc[hx][i][hy][j]);
+        set_prio<0>();
+    };
+    // prologue: k-tile 0 complete, the first three half-tiles of k-tile 1 in flight
+    stage_y(0, 0); stage_x(0, 0); stage_y(1, 0); stage_x(1, 0);
+    stage_y(0, 1); stage_x(0, 1); stage_y(1, 1);
+    if (nk > 1) wait_vmcnt<6>();
+    else wait_vmcnt<0>();
+    wg_barrier_raw();
+    if (g == 1) wg_barrier_raw();  // group 1 runs one barrier behind group 0
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* base = smem + (kt & 1) * TILE;
+        // r = 0
+        read_y(base, 0);
+        sched_fence();
+        read_x(base, 0);
+        stage_x(1, kt + 1);
+        wait_lgkmcnt<8>();  // the Y0 reads (issued first) have retired: Y0 may be restaged next phase
+        wg_barrier_raw();
+        wait_lgkmcnt<0>();
+        quadrant(0, 0);
+        wg_barrier_raw();
+        // r = 1
+        read_y(base, 1);
+        stage_y(0, kt + 2);
+        wg_barrier_raw();
+        wait_lgkmcnt<0>();
+        quadrant(0, 1);
+        wg_barrier_raw();
+        // r = 2
+        read_x(base, 1);
+        stage_x(0, kt + 2);
+        wg_barrier_raw();
+        wait_lgkmcnt<0>();
+        quadrant(1, 1);
+        wg_barrier_raw();
+        // r = 3
+        stage_y(1, kt + 2);
+        if (kt + 2 < nk) wait_vmcnt<6>();  // all of k-tile kt+1 has landed (3 newer half-tiles may be in flight)
+        else wait_vmcnt<0>();
+        wg_barrier_raw();
+        quadrant(1, 0);
+        wg_barrier_raw();
+    }
+    if (g == 0) wg_barrier_raw();
+
+    // ---- epilogue: lane holds out[m][n..n+3]
+#pragma unroll
+    for (int hx = 0; hx < 2; ++hx)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + hx * 128 + g * 64 + i * 16 + (lane >> 4) * 4;
+            if (n >= p.N) continue;
+            f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.bias) bv = ld16f(p.bias + n);
+#pragma unroll
+            for (int hy = 0; hy < 2; ++hy)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int m = m0 + hy * 128 + q * 32 + j * 16 + (lane & 15);
+                    if (m >= p.M) continue;
+                    store_out<EPI>(p, m, n, acc[hx][i][hy][j] + bv);
+                }
+        }
+}
+
 template <class K>
 static void allow_big_lds_gemm(K kernel, size_t bytes) {
 #ifndef VC_EMU
@@ -270,25 +443,32 @@ void launch_gemm(const GemmArgs& a, int epilogue, hipStream_t s) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const dim3 grid(tiles), block(256);
     const size_t shmem = 4 * TILE_BYTES;
-    // default (1): LDS-DMA staging, geometry by problem size.  0: register-staged 128x128 (8-16 % slower than the DMA
-    // form of the same geometry: 790-900 vs 870-990 TFLOP/s); 2: force 256x256; 3: force DMA 128x128
+    // default (1): 256x256 counted-vmcnt 8-phase kernel for large problems, 128x128 LDS-DMA kernel for small ones.
+    // Tuning / regression knobs (VC_GEMM_VARIANT): 0 register-staged 128x128 (8-16 % slower than the DMA form of the
+    // same geometry); 2 force the one-barrier 256x256 DMA kernel (947-1087 TFLOP/s where the 8-phase schedule reaches
+    // 1068-1281); 3 force DMA 128x128; 4 force 256x256 as 4 waves x (128x128) (1 wave per SIMD: 20-25 % slower than 2
+    // with this simple loop); 5 force the 8-phase kernel for every size
     static const int variant = getenv("VC_GEMM_VARIANT") ? atoi(getenv("VC_GEMM_VARIANT")) : 1;
     if (variant >= 1) {
-        // 256x256 / 8 waves for every large problem (measured faster on all ViT / adapter / Llama prefill shapes except a
-        // 2 % loss on o_proj), 128x128 / 4 waves for small ones; VC_GEMM_VARIANT=2 / 3 force one geometry
         const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-        const bool big = variant == 2 || (variant == 1 && a.M >= 1024 && a.N >= 512);
+        const bool big = variant == 2 || variant == 4 || variant == 5 || (variant == 1 && a.M >= 1024 && a.N >= 512);
         if (big) {
-            const dim3 g2((unsigned)t256), b2(512);
             const size_t sh2 = 2 * (256 * 128 + 256 * 128);
+            const bool wide = variant == 4;  // 4 waves x (128 x 128): fewer LDS fragment reads per MFMA, 1 wave per SIMD
+            const bool phased = variant == 5 || variant == 1;  // counted-vmcnt 8-phase schedule
+            const dim3 g2((unsigned)t256), b2(wide ? 256 : 512);
 #define VC_G256(E)                                                                                         \
     do {                                                                                                   \
         static bool once = false;                                                                          \
         if (!once) {                                                                                       \
             allow_big_lds_gemm(gemm_bf16_dma_kernel<E, 2, 4, 8, 4>, sh2);                                  \
+            allow_big_lds_gemm(gemm_bf16_dma_kernel<E, 2, 2, 8, 8>, sh2);                                  \
+            allow_big_lds_gemm(gemm_bf16_8phase_kernel<E>, sh2);                                           \
             once = true;                                                                                   \
         }                                                                                                  \
-        VC_LAUNCH((gemm_bf16_dma_kernel<E, 2, 4, 8, 4>), g2, b2, sh2, s, a);                               \
+        if (phased) VC_LAUNCH((gemm_bf16_8phase_kernel<E>), g2, b2, sh2, s, a);                            \
+        else if (wide) VC_LAUNCH((gemm_bf16_dma_kernel<E, 2, 2, 8, 8>), g2, b2, sh2, s, a);                \
+        else VC_LAUNCH((gemm_bf16_dma_kernel<E, 2, 4, 8, 4>), g2, b2, sh2, s, a);                          \
     } while (0)
             switch (epilogue) {
                 case EPI_BF16: VC_G256(EPI_BF16); break;

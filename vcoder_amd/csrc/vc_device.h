@@ -79,9 +79,10 @@ VC_DEV u32x2 fp8x4_to_bf16x4(uint32_t v) {
 typedef float f32x2_hw __attribute__((ext_vector_type(2)));
 VC_DEV u32x2 fp8x4_to_bf16x4(uint32_t v) {
     const f32x2_hw lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)v, false), hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)v, true);
-    // exact values: the bf16 pattern is the top half of the fp32 pattern
-    return u32x2{__builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, lo[1]), __builtin_bit_cast(uint32_t, lo[0]), 0x07060302u),
-                 __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi[1]), __builtin_bit_cast(uint32_t, hi[0]), 0x07060302u)};
+    // exact values, so the RNE pack (one v_cvt_pk_bf16_f32 per pair) is lossless.  (A v_perm_b32 of the fp32 top halves
+    // would do as well, but hipcc 7.2 folds __builtin_amdgcn_perm over the two halves of this builtin's result into a
+    // perm of lo[0] with itself.)
+    return u32x2{pack_bf2(lo[0], lo[1]), pack_bf2(hi[0], hi[1])};
 }
 #endif
 
@@ -131,6 +132,21 @@ VC_DEV void glds16(const void* gsrc_lane, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+#endif
+
+// ---- hand-placed synchronisation for the counted-vmcnt GEMM schedule (gemm.hip, 8-phase kernel) ---------------
+#ifdef VC_EMU
+VC_DEV void wg_barrier_raw() { __syncthreads(); }
+template <int N> VC_DEV void wait_vmcnt() {}
+template <int N> VC_DEV void wait_lgkmcnt() {}
+template <int P> VC_DEV void set_prio() {}
+VC_DEV void sched_fence() {}
+#else
+VC_DEV void wg_barrier_raw() { __builtin_amdgcn_s_barrier(); }  // bare s_barrier: no implied vmcnt/lgkmcnt drain
+template <int N> VC_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N> VC_DEV void wait_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+template <int P> VC_DEV void set_prio() { __builtin_amdgcn_s_setprio(P); }
+VC_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 #endif
 
 // ---- activations (fp32) --------------------------------------------------------------------
