@@ -20,18 +20,19 @@ void vck_gemm(const uint16_t* A, const uint16_t* W, const float* bias, void* out
               int ldo, int epi, void* stream);
 /* decode-time skinny GEMM (M<=16) over MFMA-fragment-packed weights.  epi: 0 bf16, 1 fp32, 2 fp32 residual, 3 SwiGLU */
 void vck_gemv(const uint16_t* X, const uint16_t* Wp, void* out, int M, int N, int K, int ldo, int epi, void* stream);
-/* same with the RMSNorm of [HF] llama :53-70 fused as a prologue over the fp32 residual rows Xf (rstd from `npart`
- * deterministic sum-of-squares partials) and, for epi 2, the partials of the updated rows published to ssq_out */
-void vck_gemv_norm(const float* Xf, const float* norm_w, const float* ssq_in, int npart, float eps, const uint16_t* X,
-                   const uint16_t* Wp, void* out, float* ssq_out, int M, int N, int K, int ldo, int epi, void* stream);
+/* general form.  RMSNorm ([HF] llama :53-70) is folded across producer and consumer instead of run as a pass:
+ *   consumer  (ssq_in != NULL): X is xg = bf16(x * g) written by the producer and out = rstd[m] * (X @ W^T), with
+ *             rstd[m] = rsqrt(sum_p ssq_in[m][p] / K + eps) from `npart` deterministic sum-of-squares partials;
+ *   producer  (epi 2): ssq_out gets the partials of the updated residual rows and xg_out = bf16(residual * xg_w).
+ * wscale != NULL: Wp holds W8A16 e4m3 bytes (vck_quantize_fp8) and wscale the per-output-row scales. */
+void vck_gemv_ex(const uint16_t* X, const void* Wp, const float* wscale, void* out, const float* ssq_in, float* ssq_out,
+                 const float* xg_w, uint16_t* xg_out, int npart, float eps, int M, int N, int K, int ldo, int epi,
+                 void* stream);
 void vck_pack_weight(const uint16_t* W, uint16_t* Wp, int N, int K, void* stream);
 /* W8A16 decode weights (BASELINE config C5): per-output-row power-of-two scale + OCP e4m3 bytes in the gemv's 64-wide
  * k super-tile order; W [N,K] bf16 is overwritten with the dequantised values (what the prefill GEMMs then read).
- * vck_gemv_fp8 = vck_gemv / vck_gemv_norm over those bytes (Xf == NULL selects the plain-activation form). */
+ * vck_gemv_ex streams the bytes. */
 void vck_quantize_fp8(uint16_t* W, uint8_t* Wq, float* scale, int N, int K, void* stream);
-void vck_gemv_fp8(const float* Xf, const float* norm_w, const float* ssq_in, int npart, float eps, const uint16_t* X,
-                  const uint8_t* Wq, const float* wscale, void* out, float* ssq_out, int M, int N, int K, int ldo, int epi,
-                  void* stream);
 void vck_interleave_rows(const uint16_t* gate, const uint16_t* up, uint16_t* out, int F, int K, void* stream);
 /* nn.LayerNorm ([HF] clip :370,379) and LlamaRMSNorm ([HF] llama :53-70); fp32 in, bf16 out */
 void vck_layernorm(const float* x, const float* w, const float* b, uint16_t* y, int rows, int D, float eps, void* stream);
@@ -60,11 +61,13 @@ void vck_embed_tokens(const int* tok, const uint16_t* embed, float* x, int B, in
 /* greedy select with EOS/pad bookkeeping ([HF] generation/utils.py:2894,2925-2929) */
 void vck_greedy(const float* logits, int* next_tok, int* out_ids, int* finished, int* step_dev, int B, int V, int max_new,
                 int eos_id, int pad_id, void* stream);
-/* greedy select of all rows + embedding of the selected tokens (+ RMSNorm partials) + step/pos/ctx advance */
+/* greedy select of all rows + embedding of the selected tokens (fp32 rows x, RMSNorm partials ssq, and the first
+ * GEMV's operand xg = bf16(x * xg_w)) + step/pos/ctx advance */
 void vck_greedy_embed(const float* logits, int* next_tok, int* out_ids, int* finished, int* step_dev, int B, int V,
-                      int max_new, int eos_id, int pad_id, const uint16_t* embed, float* x, float* ssq, int D, int npart,
-                      int* pos_dev, int* ctx_dev, int advance, void* stream);
-void vck_embed_tokens_ssq(const int* tok, const uint16_t* embed, float* x, float* ssq, int B, int D, int npart, void* stream);
+                      int max_new, int eos_id, int pad_id, const uint16_t* embed, float* x, float* ssq, const float* xg_w,
+                      uint16_t* xg, int D, int npart, int* pos_dev, int* ctx_dev, int advance, void* stream);
+void vck_embed_tokens_ssq(const int* tok, const uint16_t* embed, float* x, float* ssq, const float* xg_w, uint16_t* xg, int B,
+                          int D, int npart, void* stream);
 void vck_advance(int* step_dev, int* pos_dev, int* ctx_dev, void* stream);
 /* strict (fp32-faithful) kernels behind vc_model_set_precision(m, 1): fp32 activations x bf16 weights on the exact
  * v_mfma_f32_16x16x4_f32, fp32 attention, fp32 head split + RoPE.  epi ids as vck_gemm (all outputs fp32). */

@@ -184,6 +184,17 @@ def check_gemv(be, M, N, K, epi, seed=0):
     return e
 
 
+
+def _gemv_ex(be, X, Wp, wscale, out, ssq_in, ssq_out, xg_w, xg_out, npart, M, N, K, ldo, epi):
+    """vck_gemv_ex through raw pointers; every array must stay referenced by the caller until be.sync()."""
+    be.lib.vck_gemv_ex(be.ptr(X), be.ptr(Wp), be.ptr(wscale), be.ptr(out), be.ptr(ssq_in), be.ptr(ssq_out), be.ptr(xg_w),
+                       be.ptr(xg_out), ctypes.c_int(npart), ctypes.c_float(1e-5), M, N, K, ldo, epi, None)
+    be.sync()
+
+
+def _rstd(x, eps=1e-5):
+    return 1.0 / np.sqrt((x.astype(np.float64) ** 2).mean(-1, keepdims=True) + eps)
+
 def check_gemv_fp8(be, M, N, K, epi, norm=False, seed=0):
     """W8A16: the device quantiser is bit-identical to vcoder_amd/quant.py (bytes, scales, dequantised bf16 rewrite),
     and the byte-streaming GEMV equals X @ W_eff^T."""
@@ -202,20 +213,20 @@ def check_gemv_fp8(be, M, N, K, epi, norm=False, seed=0):
     assert np.array_equal(got_q, quant.pack_supertiles(q)), "e4m3 bytes differ from quant.e4m3_encode"
     assert np.array_equal(be.host_f32(Wb), w_eff), "dequantised rewrite differs"
     assert np.array_equal(bf16_round(w_eff), w_eff)
-    X = bf16_round(rng.randn(M, K))
-    Xd = be.bf16(X)
     npart = 16
-    xf = ssq = nw = None
-    if norm:
+    ssq = None
+    scale_rows = 1.0
+    X = bf16_round(rng.randn(M, K))
+    if norm:   # consumer form: X is the producer's bf16(x * g); the output is scaled by rstd from the partials
         x32 = (rng.randn(M, K) * 1.5).astype(np.float32)
-        w1 = (rng.rand(K) + 0.5).astype(np.float32)
+        g = (rng.rand(K) + 0.5).astype(np.float32)
+        X = bf16_round(x32 * g)
         part = np.zeros((16, npart), np.float32)
         part[:M, : npart // 2] = ((x32.astype(np.float64) ** 2).sum(-1) / (npart // 2))[:, None]
-        xp = np.zeros((16, K), np.float32)
-        xp[:M] = x32
-        xf, ssq, nw = be.f32(xp), be.f32(part), be.f32(w1)
-        X = bf16_round(cpu_ref.rms_norm(torch.from_numpy(x32), torch.from_numpy(w1), 1e-5).numpy())
-    t = torch.from_numpy(X.astype(np.float64) @ w_eff.T.astype(np.float64)).float()
+        ssq = be.f32(part)
+        scale_rows = _rstd(x32)
+    Xd = be.bf16(X)
+    t = torch.from_numpy((X.astype(np.float64) @ w_eff.T.astype(np.float64)) * scale_rows).float()
     if epi == 0:
         out = be.zeros((M, N), "bf16")
     elif epi == 1:
@@ -227,12 +238,9 @@ def check_gemv_fp8(be, M, N, K, epi, norm=False, seed=0):
     else:
         out = be.zeros((M, N // 2), "bf16")
         t = torch.nn.functional.silu(t[:, 0::2]) * t[:, 1::2]
-    be.lib.vck_gemv_fp8(be.ptr(xf), be.ptr(nw), be.ptr(ssq), ctypes.c_int(npart), ctypes.c_float(1e-5),
-                        None if norm else be.ptr(Xd), be.ptr(Wq), be.ptr(sc), be.ptr(out), None, M, N, K,
-                        N // 2 if epi == 3 else N, epi, None)
-    be.sync()
+    _gemv_ex(be, Xd, Wq, sc, out, ssq, None, None, None, npart, M, N, K, N // 2 if epi == 3 else N, epi)
     e = rel_err(be.host_f32(out), t.numpy())
-    tol = (2 ** -8 if epi in (0, 3) else 1e-5) if not norm else 3e-3  # norm: bf16 boundary flips of the activations
+    tol = 2 ** -8 if epi in (0, 3) else 2e-5
     assert e < tol, f"gemv_fp8 M{M} N{N} K{K} epi{epi} norm{norm}: rel err {e}"
     return e
 
@@ -457,48 +465,52 @@ def check_synth(be, name="model.layers.3.mlp.up_proj.weight", n=5000):
 
 # ---- fused decode-step kernels ------------------------------------------------------------------------------------
 def check_gemv_norm_chain(be, M, D, N, seed=0):
-    """embed_tokens_ssq -> [RMSNorm+GEMV] -> RESID GEMV (publishes partials) -> [RMSNorm+GEMV]: the decode-step chain."""
+    """The decode-step chain with RMSNorm folded across producer and consumer:
+    embed_tokens_ssq (x, partials, xg = bf16(x*g1)) -> consumer GEMV (rstd * xg @ W1^T) -> RESID GEMV (x += h @ Wo^T,
+    new partials, xg = bf16(x*g2)) -> consumer GEMV on the new rows."""
     rng = np.random.RandomState(seed)
     V = 64
     npart = (D // 16 + 15) // 16 * 16
     embed = bf16_round(rng.randn(V, D))
     tok = rng.randint(0, V, size=M).astype(np.int32)
-    w1 = (rng.rand(D) + 0.5).astype(np.float32)
+    g1 = (rng.rand(D) + 0.5).astype(np.float32)
+    g2 = (rng.rand(D) + 0.5).astype(np.float32)
     W1 = bf16_round(rng.randn(N, D) * 0.05)
     Wo = bf16_round(rng.randn(D, N) * 0.05)
     x = be.zeros((16, D), "f32")
-    ssq = be.f32(rng.randn(16, npart))          # garbage: the kernels must fully overwrite the valid rows
-    _call(be, "vck_embed_tokens_ssq", be.i32(tok), be.bf16(embed), x, ssq, M, D, npart)
-    assert np.array_equal(be.host_f32(x)[:M], embed[tok])
+    xg = be.bf16(rng.randn(16, D))              # garbage: the kernels must fully overwrite the valid rows
+    ssq = be.f32(rng.randn(16, npart))
+    tokd, embd, g1d, g2d = be.i32(tok), be.bf16(embed), be.f32(g1), be.f32(g2)
+    be.lib.vck_embed_tokens_ssq(be.ptr(tokd), be.ptr(embd), be.ptr(x), be.ptr(ssq), be.ptr(g1d), be.ptr(xg), M, D, npart, None)
+    be.sync()
+    x0 = embed[tok]
+    assert np.array_equal(be.host_f32(x)[:M], x0)
+    assert np.array_equal(be.host_f32(xg)[:M], bf16_round(x0 * g1)), "xg operand of the embedding kernel"
     W1p, Wop = be.zeros((N * D,), "bf16"), be.zeros((N * D,), "bf16")
-    _call(be, "vck_pack_weight", be.bf16(W1), W1p, N, D)
-    _call(be, "vck_pack_weight", be.bf16(Wo), Wop, D, N)
+    W1d, Wod = be.bf16(W1), be.bf16(Wo)
+    _call(be, "vck_pack_weight", W1d, W1p, N, D)
+    _call(be, "vck_pack_weight", Wod, Wop, D, N)
+    # consumer: h = rstd * (xg @ W1^T)
     h = be.zeros((M, N), "bf16")
-    w1d = be.f32(w1)   # keep every device array referenced until after sync(): the call only sees raw pointers
-    be.lib.vck_gemv_norm(be.ptr(x), be.ptr(w1d), be.ptr(ssq), ctypes.c_int(npart), ctypes.c_float(1e-5), None,
-                         be.ptr(W1p), be.ptr(h), None, M, N, D, N, 0, None)
-    be.sync()
-    xn = bf16_round(cpu_ref.rms_norm(torch.from_numpy(embed[tok]), torch.from_numpy(w1), 1e-5).numpy())
-    ref_h = xn.astype(np.float64) @ W1.T.astype(np.float64)
+    _gemv_ex(be, xg, W1p, None, h, ssq, None, None, None, npart, M, N, D, N, 0)
+    ref_h = (bf16_round(x0 * g1).astype(np.float64) @ W1.T.astype(np.float64)) * _rstd(x0)
     e = rel_err(be.host_f32(h), ref_h)
-    assert e < 2 ** -7, f"norm+gemv rel err {e}"
-    # RESID gemv: x += h @ Wo^T, partials of the new rows
+    assert e < 2 ** -8, f"consumer gemv rel err {e}"
+    # producer: x += h @ Wo^T, partials of the new rows, xg = bf16(x_new * g2)
     hb = be.host_f32(h)
-    be.lib.vck_gemv_norm(None, None, None, ctypes.c_int(npart), ctypes.c_float(1e-5), be.ptr(h), be.ptr(Wop), be.ptr(x),
-                         be.ptr(ssq), M, D, N, D, 2, None)
-    be.sync()
-    x_new = embed[tok].astype(np.float64) + hb.astype(np.float64) @ Wo.T.astype(np.float64)
-    assert rel_err(be.host_f32(x)[:M], x_new) < 1e-5
+    _gemv_ex(be, h, Wop, None, x, None, ssq, g2d, xg, npart, M, D, N, D, 2)
+    x_new = x0.astype(np.float64) + hb.astype(np.float64) @ Wo.T.astype(np.float64)
+    got_x = be.host_f32(x)[:M]
+    assert rel_err(got_x, x_new) < 1e-5
     got_ss = be.host_f32(ssq)[:M, : D // 16].sum(-1)
     assert np.abs(got_ss / (x_new ** 2).sum(-1) - 1).max() < 1e-5
-    # second fused norm consumes the published partials
+    assert np.array_equal(be.host_f32(xg)[:M], bf16_round(got_x * g2)), "xg operand of the RESID epilogue"
+    # second consumer on the published partials
     y = be.zeros((M, N), "f32")
-    be.lib.vck_gemv_norm(be.ptr(x), be.ptr(w1d), be.ptr(ssq), ctypes.c_int(npart), ctypes.c_float(1e-5), None,
-                         be.ptr(W1p), be.ptr(y), None, M, N, D, N, 1, None)
-    be.sync()
-    xn2 = bf16_round(cpu_ref.rms_norm(torch.from_numpy(be.host_f32(x)[:M]), torch.from_numpy(w1), 1e-5).numpy())
-    e = rel_err(be.host_f32(y), xn2.astype(np.float64) @ W1.T.astype(np.float64))
-    assert e < 3e-3, f"second norm+gemv rel err {e}"   # bf16 rounding-boundary flips of xn only
+    _gemv_ex(be, xg, W1p, None, y, ssq, None, None, None, npart, M, N, D, N, 1)
+    ref_y = (bf16_round(got_x * g2).astype(np.float64) @ W1.T.astype(np.float64)) * _rstd(got_x)
+    e = rel_err(be.host_f32(y), ref_y)
+    assert e < 2e-5, f"second consumer gemv rel err {e}"
 
 
 def check_attention_decode_fused(be, B, H, hd, pos, seed=0):
@@ -544,12 +556,14 @@ def check_greedy_embed(be, B, V, D):
     nxt, out, fin = be.zeros((16,), "i32"), be.zeros((16, max_new), "i32"), be.zeros((16,), "i32")
     sc = be.i32([0, 100, 101])
     x, ssq = be.zeros((16, D), "f32"), be.f32(rng.randn(16, npart))
+    gw = (rng.rand(D) + 0.5).astype(np.float32)
+    gwd, xg = be.f32(gw), be.zeros((16, D), "bf16")
     base = sc.ctypes.data if isinstance(sc, np.ndarray) else sc.data_ptr()
     lgd, embd = be.f32(lg), be.bf16(embed)   # keep alive until sync()
     for it in range(2):
         be.lib.vck_greedy_embed(be.ptr(lgd), be.ptr(nxt), be.ptr(out), be.ptr(fin), c_p(base), B, V, max_new, eos,
-                                pad, be.ptr(embd), be.ptr(x), be.ptr(ssq), D, npart, c_p(base + 4), c_p(base + 8),
-                                1 if it == 0 else 3, None)
+                                pad, be.ptr(embd), be.ptr(x), be.ptr(ssq), be.ptr(gwd), be.ptr(xg), D, npart, c_p(base + 4),
+                                c_p(base + 8), 1 if it == 0 else 3, None)
         be.sync()
     o = be.host_i32(out)
     exp = torch.argmax(torch.from_numpy(lg), -1).numpy()
@@ -559,6 +573,7 @@ def check_greedy_embed(be, B, V, D):
     assert list(be.host_i32(sc)) == [2, 101, 102]
     last = [pad if exp[b] == eos else exp[b] for b in range(B)]
     assert np.array_equal(be.host_f32(x)[:B], embed[last])
+    assert np.array_equal(be.host_f32(xg)[:B], bf16_round(embed[last] * gw))
     assert np.abs(be.host_f32(ssq)[:B].sum(-1) / (embed[last] ** 2).sum(-1) - 1).max() < 1e-5
 
 

@@ -69,10 +69,36 @@ def bench_gemv():
 
             def g():
                 it[0] += 1
-                lib.vck_gemv_norm(P(xf), P(w), P(ssq), npart, C.c_float(1e-5), None, P(Ws[it[0] % 8]), P(out), None, M, N,
-                                  K, ldo, epi, None)
+                lib.vck_gemv_ex(P(X), P(Ws[it[0] % 8]), None, P(out), P(ssq), None, None, None, npart, C.c_float(1e-5), M, N,
+                                K, ldo, epi, None)
             us = timeit(g, iters=40)
-            print(f"gemv+norm {name:8s}          : {us:7.1f} us  {2 * N * K / us / 1e3:7.1f} GB/s", flush=True)
+            print(f"gemv+rstd {name:8s}          : {us:7.1f} us  {2 * N * K / us / 1e3:7.1f} GB/s", flush=True)
+
+
+def bench_gemv_fp8():
+    """W8A16 form: same shapes, e4m3 bytes (random bytes: the kernel's speed does not depend on the values)."""
+    for M in (8, 16):
+        for (N, K, epi, name) in [(12288, 4096, 0, "qkv"), (4096, 4096, 2, "o"), (22016, 4096, 3, "gate-up"),
+                                  (4096, 11008, 2, "down")]:
+            X = bf16(M, K)
+            Ws = [torch.randint(0, 120, (N * K,), dtype=torch.uint8, device=dev) for _ in range(8)]
+            sc = torch.ones(N, device=dev)
+            out = torch.zeros((M, N), dtype=torch.float32 if epi in (1, 2) else torch.bfloat16, device=dev)
+            ldo = N // 2 if epi == 3 else N
+            it = [0]
+            xf = torch.randn(16, K, device=dev)
+            w = torch.rand(K, device=dev) + 0.5
+            npart = (K // 16 + 15) // 16 * 16
+            ssq = torch.rand(16, npart, device=dev)
+            norm = epi in (0, 1, 3)
+
+            def f():
+                it[0] += 1
+                lib.vck_gemv_ex(P(X), P(Ws[it[0] % 8]), P(sc), P(out), P(ssq) if norm else None, None, None, None, npart,
+                                C.c_float(1e-5), M, N, K, ldo, epi, None)
+            us = timeit(f, iters=40)
+            print(f"gemv_fp8 M{M} {name:8s} N{N} K{K} epi{epi} norm{int(norm)}: {us:7.1f} us  {N * K / us / 1e3:7.1f} GB/s",
+                  flush=True)
 
 
 def bench_attn():
@@ -109,5 +135,8 @@ def bench_dattn():
 
 if __name__ == "__main__":
     what = sys.argv[1:] or ["gemm", "gemv", "attn", "dattn"]
+    if "gemv_fp8" in what:
+        bench_gemv_fp8()
     for w in what:
-        {"gemm": bench_gemm, "gemv": bench_gemv, "attn": bench_attn, "dattn": bench_dattn}[w]()
+        {"gemm": bench_gemm, "gemv": bench_gemv, "attn": bench_attn, "dattn": bench_dattn,
+         "gemv_fp8": lambda: None}[w]()

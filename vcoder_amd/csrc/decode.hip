@@ -23,34 +23,27 @@ VC_DEV u32x4 ld16_stream(const void* p) { return ld16(p); }
 VC_DEV u32x4 ld16_stream(const void* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); }
 #endif
 
-// normalised bf16 fragment of 8 activations: bf16( (x * rstd) * w )   ([HF] llama/modeling_llama.py:62-67)
-VC_DEV u32x4 norm_frag(const float* xp, const float* wp, float rstd) {
-    const f32x4 x0 = ld16f(xp), x1 = ld16f(xp + 4), w0 = ld16f(wp), w1 = ld16f(wp + 4);
-    return u32x4{pack_bf2((x0[0] * rstd) * w0[0], (x0[1] * rstd) * w0[1]), pack_bf2((x0[2] * rstd) * w0[2], (x0[3] * rstd) * w0[3]),
-                 pack_bf2((x1[0] * rstd) * w1[0], (x1[1] * rstd) * w1[1]), pack_bf2((x1[2] * rstd) * w1[2], (x1[3] * rstd) * w1[3])};
-}
-
-// WAVES waves split K; each workgroup owns NT consecutive 16-output tiles so that one (normalised) activation
-// fragment feeds NT weight tiles — this halves the L2 traffic of the activation operand for NT = 2.
+// WAVES waves split K (k-tiles interleaved: wave w takes tiles w, w + WAVES, ... so the workgroup reads the packed
+// stream in contiguous 1-KiB x WAVES runs and every wave's share differs by at most one tile); a workgroup owns NT
+// consecutive 16-output tiles so one activation fragment feeds NT weight tiles.  Activation fragments come straight
+// from L2 (bf16 [M, K], at most 16 x K x 2 B per launch).
 //
-// NORM (fused RMSNorm) comes in two forms.  STAGE: the workgroup first normalises all M rows ONCE into LDS
-// (bf16, rows padded by 16 B so the 16 token rows of a fragment read hit 16 different bank groups) and the K loop
-// then reads activation fragments with ds_read_b128 — the streaming loop is as lean as the plain one.  !STAGE
-// (rows do not fit the 160 KiB LDS): every wave normalises its own fragments straight from L2.
+// RMSNorm is folded WITHOUT a prologue: out = rstd[m] * sum_k (x[m][k] * g[k]) * W[n][k], so the kernel that produces
+// the residual row also writes xg = bf16(x * g) for its consumer (RESID epilogue below / the embedding kernels) together
+// with deterministic sum-of-squares partials, and the consumer multiplies its fp32 accumulator by
+// rstd[m] = rsqrt(sum_p ssq[m][p] / K + eps) in the epilogue ([HF] llama/modeling_llama.py:62-67 with the scalar factor
+// moved out of the dot product).  The partials are fetched while the weights stream.
 //
 // FP8 (W8A16): the packed weights are e4m3 bytes, one 16-byte load per lane = 16 consecutive k of one output row, i.e. a
 // 64-wide k "super tile" per wave-instruction ([N/16][K/64][64 lanes][16 B]; lane = n%16 + 16*((k%64)/16)).  The bytes
 // are widened to bf16 fragments in registers (exact) and fed to two MFMAs whose activation fragments use the same k
 // assignment; the per-output-row power-of-two scale multiplies the fp32 accumulator in the epilogue (exact).
-template <int WAVES, int NT, int EPI, bool NORM, bool STAGE, bool FP8>
+template <int WAVES, int NT, int EPI, bool FP8>
 __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
     constexpr int KT = FP8 ? 64 : 32;   // k columns per 16-byte weight load
     constexpr int KSH = FP8 ? 6 : 5;
     constexpr int GK = KT / 4;          // k columns per lane group
-    VC_DYNAMIC_SMEM(char, dsm);  // STAGE: normalised activations, later re-used for the cross-wave reduction
-    __shared__ __attribute__((aligned(16))) float red_static[STAGE ? 1 : WAVES * NT * 64 * 4];
-    __shared__ float rstd_s[16];
-    float* red = STAGE ? reinterpret_cast<float*>(dsm) : red_static;  // [WAVES][NT][64][4]
+    __shared__ __attribute__((aligned(16))) float red[WAVES * NT * 64 * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntiles = p.N >> 4;
     const int nt0 = blockIdx.x * NT;
@@ -61,23 +54,28 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) wp[t] = p.Wp + ((size_t)min(nt0 + t, ntiles - 1) * nkt * 64 + lane) * 8;
     const bf16_t* xp = p.X + (size_t)(mvalid ? m : 0) * p.K + g * GK;
-    const float* xf = nullptr;
-    const float* nw = nullptr;
-    float rstd = 0.f;
-    // STAGE: K is walked in chunks of p.kc columns so that the normalised rows of a chunk (Mp x kc bf16) fit in LDS
-    const int kc_tiles = STAGE ? (p.kc >> KSH) : nkt;
-    const int row_bytes = (STAGE ? p.kc : p.K) * 2 + 16;
-    const int Mp = p.M <= 8 ? 8 : 16;
-    if constexpr (NORM && STAGE) {
-        for (int r = wave; r < Mp; r += WAVES) {  // 1/rms per row from the producer's partials (fixed order)
-            float ss = 0.f;
-            for (int q = lane; q < p.npart; q += 64) ss += p.ssq_in[(size_t)r * p.npart + q];
-            ss = wave_sum(ss);
-            if (lane == 0) rstd_s[r] = rsqrtf(ss / (float)p.K + p.eps);
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // K loop, software-pipelined over batches of U k-tiles with two register sets: the weight loads of batch b+1 are in
+    // flight while the MFMAs of batch b run.  Tiles past the end re-read the last tile against zero activations, so
+    // there is no unpipelined tail.
+    constexpr int U = 8 / NT;
+    const int cnt = (nkt - wave + WAVES - 1) / WAVES;  // k-tiles of this wave (wave-uniform)
+    const int nb = (cnt + U - 1) / U;
+    u32x4 wa[NT][U], wb[NT][U];
+    auto load_w = [&](u32x4 (&w)[NT][U], int b) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kt = min(wave + (b * U + u) * WAVES, nkt - 1);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) w[t][u] = ld16_stream(wp[t] + (size_t)kt * 512);
         }
-    }
-    if constexpr (NORM && !STAGE) {
-        // per-row 1/rms from the producer's deterministic partial sums (fixed summation order -> bit-reproducible)
+    };
+    if (nb > 0) load_w(wa, 0);
+    // 1/rms of row m from the producer's partials (fixed order -> bit-reproducible); only the finishing waves need it
+    float rstd = 1.f;
+    if (p.ssq_in != nullptr && wave < NT) {
         const float* sp = p.ssq_in + (size_t)m * p.npart;
         float ss = 0.f;
         for (int q = g; q < (p.npart >> 2); q += 4) {
@@ -87,95 +85,45 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
         ss += shfl_xor(ss, 16);
         ss += shfl_xor(ss, 32);
         rstd = rsqrtf(ss / (float)p.K + p.eps);
-        xf = p.Xf + (size_t)(mvalid ? m : 0) * p.K + g * GK;
-        nw = p.norm_w + g * GK;
     }
-    f32x4 acc[NT];
+    auto fma_tile = [&](f32x4& a, const u32x4& w, const u32x4& x0, const u32x4& x1) {
+        if constexpr (FP8) {
+            const u32x2 b0 = fp8x4_to_bf16x4(w[0]), b1 = fp8x4_to_bf16x4(w[1]);
+            const u32x2 b2 = fp8x4_to_bf16x4(w[2]), b3 = fp8x4_to_bf16x4(w[3]);
+            a = mfma16(u32x4{b0[0], b0[1], b1[0], b1[1]}, x0, a);
+            a = mfma16(u32x4{b2[0], b2[1], b3[0], b3[1]}, x1, a);
+        } else {
+            a = mfma16(w, x0, a);
+        }
+    };
+    auto compute = [&](u32x4 (&w)[NT][U], int b) {
+        u32x4 xv[U], xw[FP8 ? U : 1];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // K loop, software-pipelined over batches of U k-tiles with two register sets: the weight loads of batch b+1 are in
-    // flight while the MFMAs of batch b run, and the first batch of a chunk is requested BEFORE its normalise prologue.
-    constexpr int U = 8 / NT;
-    u32x4 wa[NT][U], wb[NT][U];
-    auto load_w = [&](u32x4 (&w)[NT][U], int kt) {
+        for (int u = 0; u < U; ++u) {
+            const int kt = wave + (b * U + u) * WAVES;
+            const bool ok = mvalid && kt < nkt;
+            const bf16_t* xq = xp + (size_t)min(kt, nkt - 1) * KT;
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            xv[u] = ld16(xq);
+            if (!ok) xv[u] = z;
+            if constexpr (FP8) {
+                xw[u] = ld16(xq + 8);
+                if (!ok) xw[u] = z;
+            }
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) w[t][u] = ld16_stream(wp[t] + (size_t)(kt + u) * 512);
+            for (int t = 0; t < NT; ++t) fma_tile(acc[t], w[t][u], xv[u], xw[FP8 ? u : 0]);
     };
-    for (int cbase = 0; cbase < nkt; cbase += kc_tiles) {
-        const int per = (kc_tiles + WAVES - 1) / WAVES;
-        const int kt0 = cbase + wave * per, kt1 = min(cbase + kc_tiles, kt0 + per);
-        const int nb = max(kt1 - kt0, 0) / U;  // full batches of this wave in this chunk (wave-uniform)
-        if (nb > 0) load_w(wa, kt0);
-        if constexpr (NORM && STAGE) {
-            __syncthreads();  // rstd_s ready / every wave finished reading the previous chunk's rows
-            // normalise: thread t owns 16-byte column groups t, t+512, ... of EVERY row; the row loop is unrolled so the
-            // loads of all rows are in flight together (an un-unrolled loop pays one L2 round trip per row)
-            const int cpr = p.kc >> 3, col0 = cbase * KT;
-            for (int c = tid; c < cpr; c += WAVES * 64) {
-                const f32x4 w0 = ld16f(p.norm_w + col0 + c * 8), w1 = ld16f(p.norm_w + col0 + c * 8 + 4);
-#pragma unroll 8
-                for (int r = 0; r < Mp; ++r) {
-                    u32x4 v = {0u, 0u, 0u, 0u};
-                    if (r < p.M) {
-                        const float* xr = p.Xf + (size_t)r * p.K + col0 + c * 8;
-                        const f32x4 x0 = ld16f(xr), x1 = ld16f(xr + 4);
-                        const float rs = rstd_s[r];
-                        v = u32x4{pack_bf2((x0[0] * rs) * w0[0], (x0[1] * rs) * w0[1]), pack_bf2((x0[2] * rs) * w0[2], (x0[3] * rs) * w0[3]),
-                                  pack_bf2((x1[0] * rs) * w1[0], (x1[1] * rs) * w1[1]), pack_bf2((x1[2] * rs) * w1[2], (x1[3] * rs) * w1[3])};
-                    }
-                    st16(dsm + (size_t)r * row_bytes + c * 16, v);
-                }
-            }
-            __syncthreads();
-        }
-        // staged fragment of k-tile kt: row m, chunk-relative column (kt - cbase)*KT + g*GK
-        const char* xs = dsm + (size_t)m * row_bytes + g * (GK * 2) - (size_t)cbase * (KT * 2);
-        // activation fragment h (8 columns) of k-tile kt
-        auto xfrag = [&](int kt, int h) -> u32x4 {
-            if (!mvalid) return u32x4{0u, 0u, 0u, 0u};
-            if constexpr (NORM && STAGE) return ld16(xs + kt * (KT * 2) + h * 16);
-            else if constexpr (NORM) return norm_frag(xf + kt * KT + h * 8, nw + kt * KT + h * 8, rstd);
-            else return ld16(xp + kt * KT + h * 8);
-        };
-        auto fma_tile = [&](f32x4& a, const u32x4& w, const u32x4& x0, const u32x4& x1) {
-            if constexpr (FP8) {
-                const u32x2 b0 = fp8x4_to_bf16x4(w[0]), b1 = fp8x4_to_bf16x4(w[1]);
-                const u32x2 b2 = fp8x4_to_bf16x4(w[2]), b3 = fp8x4_to_bf16x4(w[3]);
-                a = mfma16(u32x4{b0[0], b0[1], b1[0], b1[1]}, x0, a);
-                a = mfma16(u32x4{b2[0], b2[1], b3[0], b3[1]}, x1, a);
-            } else {
-                a = mfma16(w, x0, a);
-            }
-        };
-        auto compute = [&](u32x4 (&w)[NT][U], int kt) {
-            u32x4 xv[U], xw[FP8 ? U : 1];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                xv[u] = xfrag(kt + u, 0);
-                if constexpr (FP8) xw[u] = xfrag(kt + u, 1);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) fma_tile(acc[t], w[t][u], xv[u], xw[FP8 ? u : 0]);
-        };
-        for (int b = 0; b < nb; b += 2) {
-            if (b + 1 < nb) load_w(wb, kt0 + (b + 1) * U);
-            compute(wa, kt0 + b * U);
-            if (b + 1 < nb) {
-                if (b + 2 < nb) load_w(wa, kt0 + (b + 2) * U);
-                compute(wb, kt0 + (b + 1) * U);
-            }
-        }
-        for (int kt = kt0 + nb * U; kt < kt1; ++kt) {
-            const u32x4 x0 = xfrag(kt, 0), x1 = FP8 ? xfrag(kt, 1) : u32x4{0u, 0u, 0u, 0u};
-#pragma unroll
-            for (int t = 0; t < NT; ++t) fma_tile(acc[t], ld16_stream(wp[t] + (size_t)kt * 512), x0, x1);
+    for (int b = 0; b < nb; b += 2) {
+        if (b + 1 < nb) load_w(wb, b + 1);
+        compute(wa, b);
+        if (b + 1 < nb) {
+            if (b + 2 < nb) load_w(wa, b + 2);
+            compute(wb, b + 1);
         }
     }
-    if constexpr (STAGE) __syncthreads();  // every wave is done with the staged activations before `red` overwrites them
 #pragma unroll
     for (int t = 0; t < NT; ++t) st16f(red + ((wave * NT + t) * 64 + lane) * 4, acc[t]);
     __syncthreads();
@@ -187,11 +135,16 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
     for (int w = 1; w < WAVES; ++w) v = v + ld16f(red + ((w * NT + wave) * 64 + lane) * 4);
     const int n = nt * 16 + g * 4;  // lane holds out[m][n..n+3]
     if constexpr (FP8) v = v * ld16f(p.wscale + n);
+    v = v * rstd;
     if constexpr (EPI == GEMV_RESID_F32) {
         float* o = reinterpret_cast<float*>(p.out) + (size_t)(mvalid ? m : 0) * p.ldo + n;
         if (mvalid) {
             v = ld16f(o) + v;
             st16f(o, v);
+            if (p.xg_out) {  // the consumer's operand: bf16(x * g) of the updated residual values
+                const f32x4 gw = ld16f(p.xg_w + n);
+                st8(p.xg_out + (size_t)m * p.N + n, u32x2{pack_bf2(v[0] * gw[0], v[1] * gw[1]), pack_bf2(v[2] * gw[2], v[3] * gw[3])});
+            }
         }
         if (p.ssq_out) {  // sum of squares of this tile's 16 new residual values of token m (fixed order)
             float sq = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
@@ -212,62 +165,26 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
     }
 }
 
-template <class K>
-static void allow_big_lds(K kernel, size_t bytes) {
-#ifndef VC_EMU
-    if (bytes > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-#endif
-}
-
-template <int WAVES, int NT, bool NORM, bool STAGE, bool FP8>
-static void launch_gemv_w(const GemvArgs& a, int epi, size_t shmem, hipStream_t s) {
+template <int WAVES, int NT, bool FP8>
+static void launch_gemv_w(const GemvArgs& a, int epi, hipStream_t s) {
     const dim3 grid((a.N / 16 + NT - 1) / NT), block(WAVES * 64);
     switch (epi) {
-        case GEMV_BF16:
-            allow_big_lds(gemv_kernel<WAVES, NT, GEMV_BF16, NORM, STAGE, FP8>, shmem);
-            VC_LAUNCH((gemv_kernel<WAVES, NT, GEMV_BF16, NORM, STAGE, FP8>), grid, block, shmem, s, a);
-            break;
-        case GEMV_F32:
-            allow_big_lds(gemv_kernel<WAVES, NT, GEMV_F32, NORM, STAGE, FP8>, shmem);
-            VC_LAUNCH((gemv_kernel<WAVES, NT, GEMV_F32, NORM, STAGE, FP8>), grid, block, shmem, s, a);
-            break;
-        case GEMV_RESID_F32:
-            allow_big_lds(gemv_kernel<WAVES, NT, GEMV_RESID_F32, NORM, STAGE, FP8>, shmem);
-            VC_LAUNCH((gemv_kernel<WAVES, NT, GEMV_RESID_F32, NORM, STAGE, FP8>), grid, block, shmem, s, a);
-            break;
-        default:
-            allow_big_lds(gemv_kernel<WAVES, NT, GEMV_SWIGLU, NORM, STAGE, FP8>, shmem);
-            VC_LAUNCH((gemv_kernel<WAVES, NT, GEMV_SWIGLU, NORM, STAGE, FP8>), grid, block, shmem, s, a);
-            break;
+        case GEMV_BF16: VC_LAUNCH((gemv_kernel<WAVES, NT, GEMV_BF16, FP8>), grid, block, 0, s, a); break;
+        case GEMV_F32: VC_LAUNCH((gemv_kernel<WAVES, NT, GEMV_F32, FP8>), grid, block, 0, s, a); break;
+        case GEMV_RESID_F32: VC_LAUNCH((gemv_kernel<WAVES, NT, GEMV_RESID_F32, FP8>), grid, block, 0, s, a); break;
+        default: VC_LAUNCH((gemv_kernel<WAVES, NT, GEMV_SWIGLU, FP8>), grid, block, 0, s, a); break;
     }
 }
 
 template <bool FP8>
 static void launch_gemv_f(const GemvArgs& a, int epilogue, hipStream_t s) {
-    if (a.Xf != nullptr) {  // fused RMSNorm prologue; 2 tiles per workgroup share every activation fragment
-        // chunk K so that one chunk of normalised rows (Mp x kc bf16, 16-byte row pad) stays <= 70 KiB -> 2 workgroups
-        // per CU; kc must keep every wave's k-tile share whole (multiple of 8 waves x the k-tile width)
-        const size_t Mp = a.M <= 8 ? 8 : 16;
-        const int align = FP8 ? 512 : 256;
-        int nch = 0;
-        for (int c = 1; c <= 16 && !nch; ++c)
-            if (a.K % c == 0 && (a.K / c) % align == 0 && Mp * ((size_t)(a.K / c) * 2 + 16) <= 70 * 1024) nch = c;
-        static const int stage_ok = getenv("VC_GEMV_STAGE") ? atoi(getenv("VC_GEMV_STAGE")) : 1;
-        if (stage_ok && nch) {
-            GemvArgs b = a;
-            b.kc = a.K / nch;
-            const size_t stage = Mp * ((size_t)b.kc * 2 + 16);
-            const size_t need = stage > (size_t)8 * 2 * 64 * 16 ? stage : (size_t)8 * 2 * 64 * 16;  // also holds `red`
-            launch_gemv_w<8, 2, true, true, FP8>(b, epilogue, need, s);
-        } else {
-            launch_gemv_w<8, 2, true, false, FP8>(a, epilogue, 0, s);
-        }
-        return;
-    }
-    // plain activations: >= ~2048 waves in flight — few output tiles -> more K-splitting waves per workgroup
-    if (a.N / 16 <= 512) launch_gemv_w<8, 1, false, false, FP8>(a, epilogue, 0, s);
-    else launch_gemv_w<4, 1, false, false, FP8>(a, epilogue, 0, s);
+    // >= ~2048 waves in flight: few output tiles -> more K-splitting waves per workgroup.  VC_GEMV_NT=2 pairs output
+    // tiles per workgroup (halves the L2 traffic of the activation operand; tuning knob)
+    static const int nt2 = getenv("VC_GEMV_NT") ? atoi(getenv("VC_GEMV_NT")) == 2 : 0;
+    const int tiles = a.N / 16;
+    if (nt2 && tiles > 512) launch_gemv_w<8, 2, FP8>(a, epilogue, s);
+    else if (tiles <= 512) launch_gemv_w<8, 1, FP8>(a, epilogue, s);
+    else launch_gemv_w<4, 1, FP8>(a, epilogue, s);
 }
 void launch_gemv(const GemvArgs& a, int epilogue, hipStream_t s) {
     if (a.wscale) launch_gemv_f<true>(a, epilogue, s);

@@ -327,15 +327,16 @@ void gemm(vc_model* m, const bf16_t* A, const bf16_t* W, const float* bias, void
     GemmArgs a{A, W, bias, out, M, N, K, K, K, ldo};
     launch_gemm(a, epi, m->st);
 }
-// norm_w != nullptr: fused RMSNorm prologue over the fp32 decode residual stream (x_dec + its ssq partials);
-// write_ssq: RESID epilogue publishes the sum-of-squares partials of the updated residual rows
-void gemv(vc_model* m, const bf16_t* X, const bf16_t* Wp, void* out, int M, int N, int K, int ldo, int epi,
-          const float* norm_w = nullptr, bool write_ssq = false, const float* wscale = nullptr) {
+// decode-time linear over `X` (bf16 [M, K]).  use_rstd: X is the xg operand (bf16(x * g)) and the output is scaled by the
+// rows' 1/rms from the ssq partials; next_norm_w (RESID epilogue only): publish the ssq partials of the updated residual
+// rows and the next consumer's xg operand
+void gemv(vc_model* m, const bf16_t* X, const bf16_t* Wp, const float* wscale, void* out, int M, int N, int K, int ldo,
+          int epi, bool use_rstd = false, const float* next_norm_w = nullptr) {
     const size_t esz = (epi == GEMV_F32 || epi == GEMV_RESID_F32) ? 4 : 2;
     const int np = m->npart;
     for (int m0 = 0; m0 < M; m0 += 16) {  // the skinny kernel holds 16 token slots; larger batches re-stream
         GemvArgs a{};
-        a.X = X ? X + (size_t)m0 * K : nullptr;
+        a.X = X + (size_t)m0 * K;
         a.Wp = Wp;
         a.wscale = wscale;
         a.out = reinterpret_cast<char*>(out) + (size_t)m0 * ldo * esz;
@@ -343,16 +344,34 @@ void gemv(vc_model* m, const bf16_t* X, const bf16_t* Wp, void* out, int M, int 
         a.N = N;
         a.K = K;
         a.ldo = ldo;
-        if (norm_w) {
-            a.Xf = m->x_dec.as<float>() + (size_t)m0 * K;
-            a.norm_w = norm_w;
-            a.ssq_in = m->ssq.as<float>() + (size_t)m0 * np;
+        a.ssq_in = use_rstd ? m->ssq.as<float>() + (size_t)m0 * np : nullptr;
+        if (next_norm_w) {
+            a.ssq_out = m->ssq.as<float>() + (size_t)m0 * np;
+            a.xg_w = next_norm_w;
+            a.xg_out = m->xn_dec.as<bf16_t>() + (size_t)m0 * N;
         }
-        a.ssq_out = write_ssq ? m->ssq.as<float>() + (size_t)m0 * np : nullptr;
         a.npart = np;
         a.eps = m->c.rms_eps;
         launch_gemv(a, epi, m->st);
     }
+}
+
+// the GEMVs of one decode step; `between(l)` runs after the qkv projection of layer l (the attention)
+template <class F>
+void decode_linears(vc_model* m, int B, F&& between) {
+    const vc_model_cfg& c = m->c;
+    const int D = c.hidden, Fd = c.ffn;
+    const bf16_t* xg = m->xn_dec.as<bf16_t>();
+    for (int l = 0; l < c.layers; ++l) {
+        const LlmLayer& L = m->llm[l];
+        const float* next_in = l + 1 < c.layers ? m->llm[l + 1].in_norm : m->final_norm;
+        gemv(m, xg, L.qkv_p, L.qkv_s, m->qkv_dec.p, B, 3 * D, D, 3 * D, GEMV_BF16, true);                          // K11+K12
+        between(l);                                                                                                // K13-K15
+        gemv(m, m->attn_dec.as<bf16_t>(), L.o_p, L.o_s, m->x_dec.p, B, D, D, D, GEMV_RESID_F32, false, L.post_norm);  // K16
+        gemv(m, xg, L.gu_p, L.gu_s, m->h_dec.p, B, 2 * Fd, D, Fd, GEMV_SWIGLU, true);                              // K11+K17
+        gemv(m, m->h_dec.as<bf16_t>(), L.down_p, L.down_s, m->x_dec.p, B, D, Fd, D, GEMV_RESID_F32, false, next_in);  // K17
+    }
+    gemv(m, xg, m->lm_head_p, nullptr, m->logits.p, B, c.vocab, D, c.vocab, GEMV_F32, true);                        // K11+K18
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -727,6 +746,8 @@ GreedyEmbedArgs greedy_embed_args(vc_model* m, int B, int max_new, int eos_id, i
     a.embed = m->embed;
     a.x = m->x_dec.as<float>();
     a.ssq = m->ssq.as<float>();
+    a.xg_w = m->llm[0].in_norm;
+    a.xg = m->xn_dec.as<bf16_t>();
     a.D = m->c.hidden;
     a.npart = m->npart;
     a.pos_dev = m->pos_dev();
@@ -736,19 +757,11 @@ GreedyEmbedArgs greedy_embed_args(vc_model* m, int B, int max_new, int eos_id, i
 }
 
 void enqueue_decode_step(vc_model* m, int B, int max_new, int eos_id, int pad_id) {
-    const vc_model_cfg& c = m->c;
-    const int D = c.hidden, F = c.ffn, H = c.heads;
-    for (int l = 0; l < c.layers; ++l) {
-        const LlmLayer& L = m->llm[l];
-        gemv(m, nullptr, L.qkv_p, m->qkv_dec.p, B, 3 * D, D, 3 * D, GEMV_BF16, L.in_norm, false, L.qkv_s);             // K11+K12
-        AttnDecodeFusedArgs da{m->qkv_dec.as<bf16_t>(), kcache(m, l), vtcache(m, l), m->attn_dec.as<bf16_t>(), B, H, m->hd,
-                               m->capS, m->pos_dev(), m->rope_cos, m->rope_sin, 1.0f / sqrtf((float)m->hd)};
-        launch_attention_decode_fused(da, m->st);                                                          // K13-K15
-        gemv(m, m->attn_dec.as<bf16_t>(), L.o_p, m->x_dec.p, B, D, D, D, GEMV_RESID_F32, nullptr, true, L.o_s);  // K16
-        gemv(m, nullptr, L.gu_p, m->h_dec.p, B, 2 * F, D, F, GEMV_SWIGLU, L.post_norm, false, L.gu_s);                    // K11+K17
-        gemv(m, m->h_dec.as<bf16_t>(), L.down_p, m->x_dec.p, B, D, F, D, GEMV_RESID_F32, nullptr, true, L.down_s);  // K17
-    }
-    gemv(m, nullptr, m->lm_head_p, m->logits.p, B, c.vocab, D, c.vocab, GEMV_F32, m->final_norm);          // K11+K18
+    decode_linears(m, B, [&](int l) {
+        AttnDecodeFusedArgs da{m->qkv_dec.as<bf16_t>(), kcache(m, l), vtcache(m, l), m->attn_dec.as<bf16_t>(), B, m->c.heads,
+                               m->hd, m->capS, m->pos_dev(), m->rope_cos, m->rope_sin, 1.0f / sqrtf((float)m->hd)};
+        launch_attention_decode_fused(da, m->st);
+    });
     launch_greedy_embed(greedy_embed_args(m, B, max_new, eos_id, pad_id, 3), m->st);                       // K19+K10
 }
 
@@ -861,7 +874,7 @@ void finish_prefill(vc_model* m, float* logits_all_host) {
     } else {
         run_prefill_layers(m, B, S);
         launch_rmsnorm_rows(m->x.as<float>(), m->last_idx.as<int>(), m->final_norm, m->xl.as<bf16_t>(), B, D, c.rms_eps, m->st);
-        gemv(m, m->xl.as<bf16_t>(), m->lm_head_p, m->logits.p, B, c.vocab, D, c.vocab, GEMV_F32);
+        gemv(m, m->xl.as<bf16_t>(), m->lm_head_p, nullptr, m->logits.p, B, c.vocab, D, c.vocab, GEMV_F32);
     }
     if (logits_all_host) {  // lm_head over ALL S positions, as the reference's forward returns (:93)
         const size_t Mr = (size_t)B * S;
@@ -1255,8 +1268,8 @@ VC_API int vc_decode_step(vc_model* m, const int32_t* tok, float* logits, int32_
         for (int b = 0; b < B; ++b)
             REQUIRE(tok[b] >= 0 && tok[b] < m->c.vocab, VC_ERR_INDEX, "index out of range in self (token id %d)", tok[b]);
         HIPCHK(hipMemcpyAsync(m->next_tok.p, tok, B * 4, hipMemcpyHostToDevice, m->st));
-        launch_embed_tokens_ssq(m->next_tok.as<int>(), m->embed, m->x_dec.as<float>(), m->ssq.as<float>(), B, m->c.hidden,
-                                m->npart, m->st);
+        launch_embed_tokens_ssq(m->next_tok.as<int>(), m->embed, m->x_dec.as<float>(), m->ssq.as<float>(), m->llm[0].in_norm,
+                                m->xn_dec.as<bf16_t>(), B, m->c.hidden, m->npart, m->st);
     }
     ensure_out_ids(m, B, 1);
     if (m->precision) {
@@ -1470,16 +1483,7 @@ VC_API int vc_profile_decode_gemv(vc_model* m, int B, int reps, int* launches, d
     const vc_model_cfg& c = m->c;
     const int D = c.hidden, F = c.ffn;
     ensure_llm(m, B, 64);
-    auto sweep = [&]() {
-        for (int l = 0; l < c.layers; ++l) {
-            const LlmLayer& L = m->llm[l];
-            gemv(m, nullptr, L.qkv_p, m->qkv_dec.p, B, 3 * D, D, 3 * D, GEMV_BF16, L.in_norm, false, L.qkv_s);
-            gemv(m, m->attn_dec.as<bf16_t>(), L.o_p, m->x_dec.p, B, D, D, D, GEMV_RESID_F32, nullptr, true, L.o_s);
-            gemv(m, nullptr, L.gu_p, m->h_dec.p, B, 2 * F, D, F, GEMV_SWIGLU, L.post_norm, false, L.gu_s);
-            gemv(m, m->h_dec.as<bf16_t>(), L.down_p, m->x_dec.p, B, D, F, D, GEMV_RESID_F32, nullptr, true, L.down_s);
-        }
-        gemv(m, nullptr, m->lm_head_p, m->logits.p, B, c.vocab, D, c.vocab, GEMV_F32, m->final_norm);
-    };
+    auto sweep = [&]() { decode_linears(m, B, [](int) {}); };
     sweep();  // warm
     HIPCHK(hipEventRecord(m->ev[0], m->st));
     for (int r = 0; r < reps; ++r) sweep();

@@ -18,12 +18,12 @@ VCK_EXPORT void vck_gemv(const uint16_t* X, const uint16_t* Wp, void* out, int M
     a.X = X; a.Wp = Wp; a.out = out; a.M = M; a.N = N; a.K = K; a.ldo = ldo;
     launch_gemv(a, epi, S(stream));
 }
-VCK_EXPORT void vck_gemv_norm(const float* Xf, const float* norm_w, const float* ssq_in, int npart, float eps,
-                              const uint16_t* X, const uint16_t* Wp, void* out, float* ssq_out, int M, int N, int K, int ldo,
-                              int epi, void* stream) {
+VCK_EXPORT void vck_gemv_ex(const uint16_t* X, const void* Wp, const float* wscale, void* out, const float* ssq_in,
+                            float* ssq_out, const float* xg_w, uint16_t* xg_out, int npart, float eps, int M, int N, int K,
+                            int ldo, int epi, void* stream) {
     GemvArgs a{};
-    a.X = X; a.Wp = Wp; a.out = out; a.M = M; a.N = N; a.K = K; a.ldo = ldo;
-    a.Xf = Xf; a.norm_w = norm_w; a.ssq_in = ssq_in; a.ssq_out = ssq_out; a.npart = npart; a.eps = eps;
+    a.X = X; a.Wp = reinterpret_cast<const uint16_t*>(Wp); a.wscale = wscale; a.out = out; a.M = M; a.N = N; a.K = K; a.ldo = ldo;
+    a.ssq_in = ssq_in; a.ssq_out = ssq_out; a.xg_w = xg_w; a.xg_out = xg_out; a.npart = npart; a.eps = eps;
     launch_gemv(a, epi, S(stream));
 }
 VCK_EXPORT void vck_attention_decode_fused(const uint16_t* qkv, uint16_t* k, uint16_t* vt, uint16_t* out, int B, int H,
@@ -34,24 +34,18 @@ VCK_EXPORT void vck_attention_decode_fused(const uint16_t* qkv, uint16_t* k, uin
 }
 VCK_EXPORT void vck_greedy_embed(const float* logits, int* next_tok, int* out_ids, int* finished, int* step_dev, int B,
                                  int V, int max_new, int eos_id, int pad_id, const uint16_t* embed, float* x, float* ssq,
-                                 int D, int npart, int* pos_dev, int* ctx_dev, int advance, void* stream) {
+                                 const float* xg_w, uint16_t* xg, int D, int npart, int* pos_dev, int* ctx_dev, int advance,
+                                 void* stream) {
     GreedyEmbedArgs a{};
+    a.xg_w = xg_w; a.xg = xg;
     a.g = GreedyArgs{logits, next_tok, out_ids, finished, step_dev, B, V, max_new, eos_id, pad_id};
     a.embed = embed; a.x = x; a.ssq = ssq; a.D = D; a.npart = npart; a.pos_dev = pos_dev; a.ctx_dev = ctx_dev;
     a.advance = advance;
     launch_greedy_embed(a, S(stream));
 }
-VCK_EXPORT void vck_embed_tokens_ssq(const int* tok, const uint16_t* embed, float* x, float* ssq, int B, int D, int npart,
-                                     void* stream) {
-    launch_embed_tokens_ssq(tok, embed, x, ssq, B, D, npart, S(stream));
-}
-VCK_EXPORT void vck_gemv_fp8(const float* Xf, const float* norm_w, const float* ssq_in, int npart, float eps,
-                             const uint16_t* X, const uint8_t* Wq, const float* wscale, void* out, float* ssq_out, int M, int N,
-                             int K, int ldo, int epi, void* stream) {
-    GemvArgs a{};
-    a.X = X; a.Wp = reinterpret_cast<const uint16_t*>(Wq); a.wscale = wscale; a.out = out; a.M = M; a.N = N; a.K = K; a.ldo = ldo;
-    a.Xf = Xf; a.norm_w = norm_w; a.ssq_in = ssq_in; a.ssq_out = ssq_out; a.npart = npart; a.eps = eps;
-    launch_gemv(a, epi, S(stream));
+VCK_EXPORT void vck_embed_tokens_ssq(const int* tok, const uint16_t* embed, float* x, float* ssq, const float* xg_w,
+                                     uint16_t* xg, int B, int D, int npart, void* stream) {
+    launch_embed_tokens_ssq(tok, embed, x, ssq, xg_w, xg, B, D, npart, S(stream));
 }
 VCK_EXPORT void vck_quantize_fp8(uint16_t* W, uint8_t* Wq, float* scale, int N, int K, void* stream) {
     launch_quantize_fp8(W, Wq, scale, N, K, S(stream));

@@ -42,24 +42,25 @@ enum GemvEpilogue : int {
     GEMV_SWIGLU = 3,     // interleaved (gate,up) rows: out bf16 [M, N/2]
 };
 struct GemvArgs {
-    const bf16_t* X;   // [M, K] bf16 activations (M <= 16); unused when Xf is set
+    const bf16_t* X;   // [M, K] bf16 activations (M <= 16)
     const bf16_t* Wp;  // packed weights
     void* out;
-    int M, N, K;       // N % 16 == 0, K % 32 == 0
+    int M, N, K;       // N % 16 == 0, K % 32 == 0 (K % 64 == 0 for W8A16)
     int ldo;
-    // fused RMSNorm prologue (K11 folded into K12/K17/K18): activations = bf16( (Xf * rstd[m]) * norm_w ), with
-    // rstd[m] = rsqrt(sum_p ssq_in[m][p] / K + eps) — the per-row sum of squares arrives as `npart` deterministic
-    // partials written by the kernel that produced Xf (a RESID gemv's `ssq_out`, or the embedding kernel).
-    const float* Xf;       // [16, K] fp32 residual stream, or nullptr
-    const float* norm_w;   // [K]
-    const float* ssq_in;   // [16, npart]
-    float* ssq_out;        // RESID epilogue: ssq_out[m][n_tile] = sum over this tile's 16 columns of out^2, or nullptr
-    int npart;             // partials per row (multiple of 16)
-    int kc;                // set by the launcher: columns of K staged in LDS at a time (fused-norm form)
-    float eps;
     // W8A16: Wp holds e4m3 bytes in the 64-wide super-tile layout (launch_quantize_fp8) and wscale[n] the per-output-row
-    // power-of-two scale; nullptr = bf16 weights.  K % 64 == 0.
+    // power-of-two scale; nullptr = bf16 weights.
     const float* wscale;
+    // RMSNorm folded into producer + consumer (K11 of SURVEY.md §2 spread over K12/K16/K17/K18):
+    //  consumer: ssq_in != nullptr -> out = rstd[m] * acc with rstd[m] = rsqrt(sum_p ssq_in[m][p] / K + eps); X is then
+    //            the producer's xg = bf16(x * g)
+    //  producer (RESID epilogue): ssq_out[m][n_tile] = sum over the tile's 16 columns of the updated residual^2, and
+    //            xg_out[m][n] = bf16(residual * xg_w[n]) — the next consumer's activation operand
+    const float* ssq_in;   // [16, npart] or nullptr
+    float* ssq_out;        // [16, npart] or nullptr
+    const float* xg_w;     // [N] norm weight of the consumer, or nullptr
+    bf16_t* xg_out;        // [M, N]
+    int npart;             // partials per row (multiple of 16)
+    float eps;
 };
 void launch_gemv(const GemvArgs& a, int epilogue, hipStream_t s);
 void launch_pack_weight(const bf16_t* W, bf16_t* Wp, int N, int K, hipStream_t s);
@@ -170,6 +171,8 @@ struct GreedyEmbedArgs {
     const bf16_t* embed;  // [V, D]
     float* x;             // [16, D] fp32 residual stream of the next step
     float* ssq;           // [16, npart]
+    const float* xg_w;    // [D] first decoder layer's input_layernorm weight
+    bf16_t* xg;           // [16, D] bf16(x * xg_w): the first GEMV's activation operand
     int D, npart;
     int* pos_dev;         // advanced by `advance` (may be nullptr)
     int* ctx_dev;
@@ -177,7 +180,7 @@ struct GreedyEmbedArgs {
 };
 void launch_greedy_embed(const GreedyEmbedArgs& a, hipStream_t s);
 // embedding + sum-of-squares partials for tokens supplied by the host (vc_decode_step with explicit tokens)
-void launch_embed_tokens_ssq(const int* tok, const bf16_t* embed, float* x, float* ssq, int B, int D, int npart,
+void launch_embed_tokens_ssq(const int* tok, const bf16_t* embed, float* x, float* ssq, const float* xg_w, bf16_t* xg, int B, int D, int npart,
                              hipStream_t s);
 void launch_advance(int* step_dev, int* pos_dev, int* ctx_dev, hipStream_t s);
 

@@ -84,7 +84,8 @@ void launch_greedy(const GreedyArgs& a, hipStream_t s) {
 
 // ---- tail of one decode step in ONE launch: greedy select of every row, embedding of the selected tokens into the
 //      next step's residual stream (+ sum-of-squares partials for the fused RMSNorm), step/pos/ctx advance ---------
-VC_DEV void embed_row_ssq(const bf16_t* sp, float* dp, float* ssq_row, int D, int npart, int lane) {
+VC_DEV void embed_row_ssq(const bf16_t* sp, float* dp, float* ssq_row, const float* gw, bf16_t* xg, int D, int npart,
+                          int lane) {
     float ss = 0.f;
     for (int c = lane; c < D / 8; c += 64) {
         const u32x4 v = ld16(sp + c * 8);
@@ -92,6 +93,9 @@ VC_DEV void embed_row_ssq(const bf16_t* sp, float* dp, float* ssq_row, int D, in
         const f32x4 b = {bf2f_lo(v[2]), bf2f_hi(v[2]), bf2f_lo(v[3]), bf2f_hi(v[3])};
         st16f(dp + c * 8, a);
         st16f(dp + c * 8 + 4, b);
+        const f32x4 g0 = ld16f(gw + c * 8), g1 = ld16f(gw + c * 8 + 4);
+        st16(xg + c * 8, u32x4{pack_bf2(a[0] * g0[0], a[1] * g0[1]), pack_bf2(a[2] * g0[2], a[3] * g0[3]),
+                               pack_bf2(b[0] * g1[0], b[1] * g1[1]), pack_bf2(b[2] * g1[2], b[3] * g1[3])});
         ss += ((a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3])) +
               ((b[0] * b[0] + b[1] * b[1]) + (b[2] * b[2] + b[3] * b[3]));
     }
@@ -152,7 +156,8 @@ __global__ __launch_bounds__(1024) void greedy_embed_kernel(GreedyEmbedArgs p) {
             g.next_tok[b] = tok;
             if (step < g.max_new) g.out_ids[(size_t)b * g.max_new + step] = tok;
         }
-        embed_row_ssq(p.embed + (size_t)tok * p.D, p.x + (size_t)b * p.D, p.ssq + (size_t)b * p.npart, p.D, p.npart, lane);
+        embed_row_ssq(p.embed + (size_t)tok * p.D, p.x + (size_t)b * p.D, p.ssq + (size_t)b * p.npart, p.xg_w,
+                      p.xg + (size_t)b * p.D, p.D, p.npart, lane);
     }
     __syncthreads();
     if (tid == 0) {
@@ -166,14 +171,15 @@ void launch_greedy_embed(const GreedyEmbedArgs& a, hipStream_t s) {
 }
 
 __global__ __launch_bounds__(256) void embed_tokens_ssq_kernel(const int* tok, const bf16_t* embed, float* x, float* ssq,
-                                                               int B, int D, int npart) {
+                                                               const float* xg_w, bf16_t* xg, int B, int D, int npart) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B) return;
-    embed_row_ssq(embed + (size_t)tok[row] * D, x + (size_t)row * D, ssq + (size_t)row * npart, D, npart, threadIdx.x & 63);
+    embed_row_ssq(embed + (size_t)tok[row] * D, x + (size_t)row * D, ssq + (size_t)row * npart, xg_w, xg + (size_t)row * D, D,
+                  npart, threadIdx.x & 63);
 }
-void launch_embed_tokens_ssq(const int* tok, const bf16_t* embed, float* x, float* ssq, int B, int D, int npart,
-                             hipStream_t s) {
-    VC_LAUNCH(embed_tokens_ssq_kernel, dim3((B + 3) / 4), dim3(256), 0, s, tok, embed, x, ssq, B, D, npart);
+void launch_embed_tokens_ssq(const int* tok, const bf16_t* embed, float* x, float* ssq, const float* xg_w, bf16_t* xg, int B,
+                             int D, int npart, hipStream_t s) {
+    VC_LAUNCH(embed_tokens_ssq_kernel, dim3((B + 3) / 4), dim3(256), 0, s, tok, embed, x, ssq, xg_w, xg, B, D, npart);
 }
 
 __global__ __launch_bounds__(64) void advance_kernel(int* step_dev, int* pos_dev, int* ctx_dev) {
