@@ -402,7 +402,7 @@ template <int HD>
 __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeFusedArgs p) {
     constexpr int LPK = HD / 8;           // lanes per key
     constexpr int KPW = 64 / LPK;         // keys per wave-instruction
-    constexpr int UK = 4;                 // independent key loads in flight per lane in the score pass
+    constexpr int UK = 8;                 // independent key loads in flight per lane in the score pass
     constexpr int NR = HD / 8;            // d-row groups (8 rows per wave-instruction) in the PV pass
     __shared__ __attribute__((aligned(16))) float sc[DEC_MAX_CTX];
     __shared__ __attribute__((aligned(16))) float q_s[HD];
@@ -455,6 +455,15 @@ __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeF
             if ((lane % LPK) == 0) sc[key] = key < ctx ? s * p.scale : -INFINITY;
         }
     }
+    // the first V^T batch of every wave does not depend on the scores: request it now so HBM stays busy through the
+    // LDS-only softmax below
+    const int dr = lane >> 3, kc = lane & 7;
+    const int ctx64 = (ctx + 63) & ~63;
+    u32x4 v0[NR];
+    if (wave * 64 < ctx64) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) v0[i] = ld16(vbase + (size_t)(i * 8 + dr) * p.kv_stride + wave * 64 + kc * 8);
+    }
     __syncthreads();
     // ---- phase 2: softmax over sc[0..ctx_pad)
     float mx = -INFINITY;
@@ -480,21 +489,32 @@ __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeF
     for (int w = 0; w < 8; ++w) sum += red[w];
     const float inv = 1.0f / sum;
     // ---- phase 3: waves split the 64-key blocks; per block a wave issues NR independent 16-byte V^T loads
-    const int dr = lane >> 3, kc = lane & 7;
     float acc[NR];
 #pragma unroll
     for (int i = 0; i < NR; ++i) acc[i] = 0.f;
-    const int ctx64 = (ctx + 63) & ~63;
-    for (int kb = wave * 64; kb < ctx64; kb += 8 * 64) {
+    auto pv = [&](const u32x4 (&v)[NR], int kb) {
         const f32x4 p0 = ld16f(&sc[kb + kc * 8]), p1 = ld16f(&sc[kb + kc * 8 + 4]);
-        u32x4 v[NR];
-#pragma unroll
-        for (int i = 0; i < NR; ++i) v[i] = ld16(vbase + (size_t)(i * 8 + dr) * p.kv_stride + kb + kc * 8);
 #pragma unroll
         for (int i = 0; i < NR; ++i)
             acc[i] += p0[0] * bf2f_lo(v[i][0]) + p0[1] * bf2f_hi(v[i][0]) + p0[2] * bf2f_lo(v[i][1]) +
                       p0[3] * bf2f_hi(v[i][1]) + p1[0] * bf2f_lo(v[i][2]) + p1[1] * bf2f_hi(v[i][2]) +
                       p1[2] * bf2f_lo(v[i][3]) + p1[3] * bf2f_hi(v[i][3]);
+    };
+    // software-pipelined over 64-key blocks with two register sets: the next block's V^T loads are in flight while
+    // this one accumulates
+    auto load_v = [&](u32x4 (&v)[NR], int kb) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) v[i] = ld16(vbase + (size_t)(i * 8 + dr) * p.kv_stride + kb + kc * 8);
+    };
+    u32x4 v1[NR];
+    for (int kb = wave * 64; kb < ctx64; kb += 2 * 8 * 64) {
+        const int kb1 = kb + 8 * 64, kb2 = kb + 2 * 8 * 64;
+        if (kb1 < ctx64) load_v(v1, kb1);
+        pv(v0, kb);
+        if (kb1 < ctx64) {
+            if (kb2 < ctx64) load_v(v0, kb2);
+            pv(v1, kb1);
+        }
     }
 #pragma unroll
     for (int i = 0; i < NR; ++i) {

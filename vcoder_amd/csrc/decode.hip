@@ -73,18 +73,24 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
         }
     };
     if (nb > 0) load_w(wa, 0);
-    // 1/rms of row m from the producer's partials (fixed order -> bit-reproducible); only the finishing waves need it
-    float rstd = 1.f;
-    if (p.ssq_in != nullptr && wave < NT) {
+    // 1/rms of row m from the producer's partials: every wave sums a slice (independent loads issued behind the first
+    // weight batch), the slices meet in LDS at the barrier that also ends the K loop; fixed order -> bit-reproducible
+    __shared__ float ss_part[WAVES][16];
+    if (p.ssq_in != nullptr) {
         const float* sp = p.ssq_in + (size_t)m * p.npart;
-        float ss = 0.f;
-        for (int q = g; q < (p.npart >> 2); q += 4) {
+        float s0 = 0.f, s1 = 0.f;
+        const int nq = p.npart >> 2;
+        for (int q = wave * 4 + g; q < nq; q += WAVES * 8) {
             const f32x4 v = ld16f(sp + q * 4);
-            ss += (v[0] + v[1]) + (v[2] + v[3]);
+            f32x4 u = {0.f, 0.f, 0.f, 0.f};
+            if (q + WAVES * 4 < nq) u = ld16f(sp + (q + WAVES * 4) * 4);
+            s0 += (v[0] + v[1]) + (v[2] + v[3]);
+            s1 += (u[0] + u[1]) + (u[2] + u[3]);
         }
+        float ss = s0 + s1;
         ss += shfl_xor(ss, 16);
         ss += shfl_xor(ss, 32);
-        rstd = rsqrtf(ss / (float)p.K + p.eps);
+        if (g == 0) ss_part[wave][m] = ss;
     }
     auto fma_tile = [&](f32x4& a, const u32x4& w, const u32x4& x0, const u32x4& x1) {
         if constexpr (FP8) {
@@ -135,7 +141,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
     for (int w = 1; w < WAVES; ++w) v = v + ld16f(red + ((w * NT + wave) * 64 + lane) * 4);
     const int n = nt * 16 + g * 4;  // lane holds out[m][n..n+3]
     if constexpr (FP8) v = v * ld16f(p.wscale + n);
-    v = v * rstd;
+    if (p.ssq_in != nullptr) {
+        float ss = ss_part[0][m];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) ss += ss_part[w][m];
+        v = v * rsqrtf(ss / (float)p.K + p.eps);
+    }
     if constexpr (EPI == GEMV_RESID_F32) {
         float* o = reinterpret_cast<float*>(p.out) + (size_t)(mvalid ? m : 0) * p.ldo + n;
         if (mvalid) {
@@ -180,7 +191,8 @@ template <bool FP8>
 static void launch_gemv_f(const GemvArgs& a, int epilogue, hipStream_t s) {
     // >= ~2048 waves in flight: few output tiles -> more K-splitting waves per workgroup.  VC_GEMV_NT=2 pairs output
     // tiles per workgroup (halves the L2 traffic of the activation operand; tuning knob)
-    static const int nt2 = getenv("VC_GEMV_NT") ? atoi(getenv("VC_GEMV_NT")) == 2 : 0;
+    // (measured: bf16 -4...-10 % with pairs, W8A16 +20 % — there the activation fragments are twice the weight bytes)
+    static const int nt2 = getenv("VC_GEMV_NT") ? atoi(getenv("VC_GEMV_NT")) == 2 : (FP8 ? 1 : 0);
     const int tiles = a.N / 16;
     if (nt2 && tiles > 512) launch_gemv_w<8, 2, FP8>(a, epilogue, s);
     else if (tiles <= 512) launch_gemv_w<8, 1, FP8>(a, epilogue, s);

@@ -346,12 +346,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[a][i][b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int frow = lane & 15, fchunk = lane >> 4;
-    u32x4 fx[2][4][2], fy[2][2][2];  // [half][fragment][ks]
+    // X0 is dead after phase 1 and X1 is first read in phase 2: one register set serves both halves
+    u32x4 fx[4][2], fy[2][2][2];  // [fragment][ks], [half][fragment][ks]
     auto read_x = [&](const char* base, int h) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fx[h][i][ks] = ld16(base + (h ? SX1 : SX0) + swz(g * 64 + i * 16 + frow, ks * 4 + fchunk));
+            for (int ks = 0; ks < 2; ++ks) fx[i][ks] = ld16(base + (h ? SX1 : SX0) + swz(g * 64 + i * 16 + frow, ks * 4 + fchunk));
     };
     auto read_y = [&](const char* base, int h) {
 #pragma unroll
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[hx][i][hy][j] = mfma16(fx[hx][i][ks], fy[hy][j][ks], acc[hx][i][hy][j]);
+                for (int j = 0; j < 2; ++j) acc[hx][i][hy][j] = mfma16(fx[i][ks], fy[hy][j][ks], acc[hx][i][hy][j]);
         set_prio<0>();
     };
     // prologue: k-tile 0 complete, the first three half-tiles of k-tile 1 in flight
