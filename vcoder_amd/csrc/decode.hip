@@ -23,6 +23,46 @@ VC_DEV u32x4 ld16_stream(const void* p) { return ld16(p); }
 VC_DEV u32x4 ld16_stream(const void* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); }
 #endif
 
+// shared epilogue: `v` = out[m][n..n+3] partial sums already reduced over the waves of the workgroup
+template <int WAVES, int EPI, bool FP8>
+VC_DEV void gemv_epilogue(const GemvArgs& p, f32x4 v, const float* ss_part /*[WAVES][16]*/, int nt, int m, int g, bool mvalid) {
+    const int n = nt * 16 + g * 4;  // lane holds out[m][n..n+3]
+    if constexpr (FP8) v = v * ld16f(p.wscale + n);
+    if (p.ssq_in != nullptr) {
+        float ss = ss_part[m];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) ss += ss_part[w * 16 + m];
+        v = v * rsqrtf(ss / (float)p.K + p.eps);
+    }
+    if constexpr (EPI == GEMV_RESID_F32) {
+        float* o = reinterpret_cast<float*>(p.out) + (size_t)(mvalid ? m : 0) * p.ldo + n;
+        if (mvalid) {
+            v = ld16f(o) + v;
+            st16f(o, v);
+            if (p.xg_out) {  // the consumer's operand: bf16(x * g) of the updated residual values
+                const f32x4 gw = ld16f(p.xg_w + n);
+                st8(p.xg_out + (size_t)m * p.N + n, u32x2{pack_bf2(v[0] * gw[0], v[1] * gw[1]), pack_bf2(v[2] * gw[2], v[3] * gw[3])});
+            }
+        }
+        if (p.ssq_out) {  // sum of squares of this tile's 16 new residual values of token m (fixed order)
+            float sq = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            sq += shfl_xor(sq, 16);
+            sq += shfl_xor(sq, 32);
+            if (g == 0 && mvalid) p.ssq_out[(size_t)m * p.npart + nt] = sq;
+        }
+        return;
+    }
+    if (!mvalid) return;
+    if constexpr (EPI == GEMV_BF16) {
+        st8(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo + n, u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])});
+    } else if constexpr (EPI == GEMV_F32) {
+        st16f(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n, v);
+    } else if constexpr (EPI == GEMV_SWIGLU) {
+        *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo + (n >> 1)) =
+            pack_bf2(silu(v[0]) * v[1], silu(v[2]) * v[3]);
+    }
+}
+
 // WAVES waves split K (k-tiles interleaved: wave w takes tiles w, w + WAVES, ... so the workgroup reads the packed
 // stream in contiguous 1-KiB x WAVES runs and every wave's share differs by at most one tile); a workgroup owns NT
 // consecutive 16-output tiles so one activation fragment feeds NT weight tiles.  Activation fragments come straight
@@ -139,41 +179,146 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
     f32x4 v = ld16f(red + ((0 * NT + wave) * 64 + lane) * 4);
 #pragma unroll
     for (int w = 1; w < WAVES; ++w) v = v + ld16f(red + ((w * NT + wave) * 64 + lane) * 4);
-    const int n = nt * 16 + g * 4;  // lane holds out[m][n..n+3]
-    if constexpr (FP8) v = v * ld16f(p.wscale + n);
-    if (p.ssq_in != nullptr) {
-        float ss = ss_part[0][m];
+    gemv_epilogue<WAVES, EPI, FP8>(p, v, &ss_part[0][0], nt, m, g, mvalid);
+}
+
+// ---- LDS-DMA form (default) ----------------------------------------------------------------------------------------------
+// Same arithmetic and epilogues as gemv_kernel, but nothing of the stream ever sits in VGPRs: every wave owns a private
+// ring of R slots in LDS; one slot = the NT packed 1-KiB weight blocks of a k-tile (non-temporal global_load_lds) plus the
+// matching activation fragment piece(s) (one 16-byte gather per lane, default cache policy: every workgroup re-reads
+// them from L2).  All vector-memory operations of the loop are DMAs issued in program order, OPS per k-tile, so the
+// oldest k-tile in flight has landed exactly when vmcnt <= (R-1)*OPS — a counted wait, never a drain; the slot is then
+// read back with ds_read_b128 (lane-linear, conflict-free), fed to the MFMAs and re-armed for k-tile i+R.  A wave only
+// ever reads LDS bytes that it DMA'd itself, so its own vmcnt wait is the only ordering needed (no barrier in the loop).
+// ~40 VGPRs per wave: occupancy is set by the ring size alone.  A pure stream of this shape measures 5.8-6.1 TB/s at the
+// qkv / gate-up launch sizes (tools/experiments/corun.hip) against 5.0-5.3 for the register-staged loop above.
+template <int WAVES, int NT, int R, int EPI, bool FP8>
+__global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
+    constexpr int KT = FP8 ? 64 : 32;
+    constexpr int KSH = FP8 ? 6 : 5;
+    constexpr int GK = KT / 4;
+    constexpr int XS = FP8 ? 2 : 1;          // 1-KiB activation pieces per k-tile
+    constexpr int OPS = NT + XS;             // DMA instructions per k-tile
+    constexpr int SLOT = OPS * 1024;
+    static_assert(WAVES * R * SLOT >= WAVES * NT * 1024, "the ring is re-used for the cross-wave reduction");
+    VC_DYNAMIC_SMEM(char, ring);             // [WAVES][R][SLOT]
+    __shared__ float ss_part[WAVES][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntiles = p.N >> 4;
+    const int nt0 = blockIdx.x * NT;
+    const int nkt = p.K >> KSH;
+    const int m = lane & 15, g = lane >> 4;
+    const bool mvalid = m < p.M;
+    char* my = ring + wave * (R * SLOT);
+    const char* wsrc[NT];
 #pragma unroll
-        for (int w = 1; w < WAVES; ++w) ss += ss_part[w][m];
-        v = v * rsqrtf(ss / (float)p.K + p.eps);
-    }
-    if constexpr (EPI == GEMV_RESID_F32) {
-        float* o = reinterpret_cast<float*>(p.out) + (size_t)(mvalid ? m : 0) * p.ldo + n;
-        if (mvalid) {
-            v = ld16f(o) + v;
-            st16f(o, v);
-            if (p.xg_out) {  // the consumer's operand: bf16(x * g) of the updated residual values
-                const f32x4 gw = ld16f(p.xg_w + n);
-                st8(p.xg_out + (size_t)m * p.N + n, u32x2{pack_bf2(v[0] * gw[0], v[1] * gw[1]), pack_bf2(v[2] * gw[2], v[3] * gw[3])});
+    for (int t = 0; t < NT; ++t)
+        wsrc[t] = reinterpret_cast<const char*>(p.Wp) + ((size_t)min(nt0 + t, ntiles - 1) * nkt * 64 + lane) * 16;
+    const char* xsrc = reinterpret_cast<const char*>(p.X + (size_t)(mvalid ? m : 0) * p.K + g * GK);
+    auto issue = [&](int i, int slot) {
+        const size_t kt = (size_t)(wave + i * WAVES);
+        char* dst = my + slot * SLOT;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) glds16_nt(wsrc[t] + kt * 1024, dst + t * 1024);
+        glds16(xsrc + kt * (KT * 2), dst + NT * 1024);
+        if constexpr (FP8) glds16(xsrc + kt * (KT * 2) + 16, dst + (NT + 1) * 1024);
+    };
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto consume = [&](int slot) {
+        const char* s = my + slot * SLOT + lane * 16;
+        u32x4 w[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) w[t] = ld16(s + t * 1024);
+        u32x4 x0 = ld16(s + NT * 1024), x1 = {0u, 0u, 0u, 0u};
+        if constexpr (FP8) x1 = ld16(s + (NT + 1) * 1024);
+        if (!mvalid) x0 = x1 = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if constexpr (FP8) {
+                const u32x2 b0 = fp8x4_to_bf16x4(w[t][0]), b1 = fp8x4_to_bf16x4(w[t][1]);
+                const u32x2 b2 = fp8x4_to_bf16x4(w[t][2]), b3 = fp8x4_to_bf16x4(w[t][3]);
+                acc[t] = mfma16(u32x4{b0[0], b0[1], b1[0], b1[1]}, x0, acc[t]);
+                acc[t] = mfma16(u32x4{b2[0], b2[1], b3[0], b3[1]}, x1, acc[t]);
+            } else {
+                acc[t] = mfma16(w[t], x0, acc[t]);
             }
         }
-        if (p.ssq_out) {  // sum of squares of this tile's 16 new residual values of token m (fixed order)
-            float sq = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-            sq += shfl_xor(sq, 16);
-            sq += shfl_xor(sq, 32);
-            if (g == 0 && mvalid) p.ssq_out[(size_t)m * p.npart + nt] = sq;
+        wait_lgkmcnt<0>();  // the slot's fragment reads have retired before it is re-armed
+    };
+    const int cnt = (nkt - wave + WAVES - 1) / WAVES;  // k-tiles of this wave (wave-uniform)
+    const int primed = min(cnt, R);
+    // 1/rms of row m from the producer's partials: the register loads are issued BEFORE the ring is primed, so the wait
+    // the compiler places at their first use leaves every DMA in flight (vmcnt counts in order)
+    constexpr int SQ = 6;
+    f32x4 sq[SQ];
+    const int nq = p.npart >> 2;
+    if (p.ssq_in != nullptr) {
+        const float* sp = p.ssq_in + (size_t)m * p.npart;
+#pragma unroll
+        for (int j = 0; j < SQ; ++j) {
+            const int q = wave * 4 + g + j * WAVES * 4;
+            sq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (q < nq) sq[j] = ld16f(sp + q * 4);
         }
-        return;
     }
-    if (!mvalid) return;
-    if constexpr (EPI == GEMV_BF16) {
-        st8(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo + n, u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])});
-    } else if constexpr (EPI == GEMV_F32) {
-        st16f(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n, v);
-    } else if constexpr (EPI == GEMV_SWIGLU) {
-        *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo + (n >> 1)) =
-            pack_bf2(silu(v[0]) * v[1], silu(v[2]) * v[3]);
+    for (int r = 0; r < primed; ++r) issue(r, r);
+    if (p.ssq_in != nullptr) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < SQ; j += 2) {
+            s0 += (sq[j][0] + sq[j][1]) + (sq[j][2] + sq[j][3]);
+            s1 += (sq[j + 1][0] + sq[j + 1][1]) + (sq[j + 1][2] + sq[j + 1][3]);
+        }
+        float ss = s0 + s1;
+        const float* sp = p.ssq_in + (size_t)m * p.npart;
+        for (int q = wave * 4 + g + SQ * WAVES * 4; q < nq; q += WAVES * 4) {  // rows wider than 16*SQ*WAVES*... (rare)
+            const f32x4 v = ld16f(sp + q * 4);
+            ss += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+        ss += shfl_xor(ss, 16);
+        ss += shfl_xor(ss, 32);
+        if (g == 0) ss_part[wave][m] = ss;
     }
+    if (cnt >= R) {
+        int slot = 0;
+        for (int i = 0; i < cnt - R; ++i) {
+            wait_vmcnt<(R - 1) * OPS>();
+            consume(slot);
+            issue(i + R, slot);
+            slot = slot + 1 == R ? 0 : slot + 1;
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) {  // drain: nothing new is issued, the outstanding count shrinks by OPS per step
+            wait_vmcnt_n((R - 1 - j) * OPS);
+            consume(slot);
+            slot = slot + 1 == R ? 0 : slot + 1;
+        }
+    } else {
+        wait_vmcnt<0>();
+        for (int r = 0; r < cnt; ++r) consume(r);
+    }
+    __syncthreads();  // every wave is done with its ring before `red` overwrites it
+    float* red = reinterpret_cast<float*>(ring);  // [WAVES][NT][64][4]
+#pragma unroll
+    for (int t = 0; t < NT; ++t) st16f(red + ((wave * NT + t) * 64 + lane) * 4, acc[t]);
+    __syncthreads();
+    if (wave >= NT) return;
+    const int nt = nt0 + wave;  // wave t finishes tile t
+    if (nt >= ntiles) return;
+    f32x4 v = ld16f(red + ((0 * NT + wave) * 64 + lane) * 4);
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) v = v + ld16f(red + ((w * NT + wave) * 64 + lane) * 4);
+    gemv_epilogue<WAVES, EPI, FP8>(p, v, &ss_part[0][0], nt, m, g, mvalid);
+}
+
+template <class K>
+static void allow_big_lds(K kernel, size_t bytes) {
+#ifndef VC_EMU
+    if (bytes > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+#endif
 }
 
 template <int WAVES, int NT, bool FP8>
@@ -187,13 +332,48 @@ static void launch_gemv_w(const GemvArgs& a, int epi, hipStream_t s) {
     }
 }
 
+template <int WAVES, int NT, int R, bool FP8>
+static void launch_gemv_dma(const GemvArgs& a, int epi, hipStream_t s) {
+    const dim3 grid((a.N / 16 + NT - 1) / NT), block(WAVES * 64);
+    constexpr size_t shmem = (size_t)WAVES * R * (NT + (FP8 ? 2 : 1)) * 1024;
+#define VC_GEMV_DMA(E)                                                                                                  \
+    do {                                                                                                                \
+        static bool once = false;                                                                                       \
+        if (!once) {                                                                                                    \
+            allow_big_lds(gemv_dma_kernel<WAVES, NT, R, E, FP8>, shmem);                                                \
+            once = true;                                                                                                \
+        }                                                                                                               \
+        VC_LAUNCH((gemv_dma_kernel<WAVES, NT, R, E, FP8>), grid, block, shmem, s, a);                                   \
+    } while (0)
+    switch (epi) {
+        case GEMV_BF16: VC_GEMV_DMA(GEMV_BF16); break;
+        case GEMV_F32: VC_GEMV_DMA(GEMV_F32); break;
+        case GEMV_RESID_F32: VC_GEMV_DMA(GEMV_RESID_F32); break;
+        default: VC_GEMV_DMA(GEMV_SWIGLU); break;
+    }
+#undef VC_GEMV_DMA
+}
+
 template <bool FP8>
 static void launch_gemv_f(const GemvArgs& a, int epilogue, hipStream_t s) {
-    // >= ~2048 waves in flight: few output tiles -> more K-splitting waves per workgroup.  VC_GEMV_NT=2 pairs output
-    // tiles per workgroup (halves the L2 traffic of the activation operand; tuning knob)
-    // (measured: bf16 -4...-10 % with pairs, W8A16 +20 % — there the activation fragments are twice the weight bytes)
+    // VC_GEMV_PATH=0: the register-staged kernel; default 1: the LDS-DMA ring kernel
+    static const int path = getenv("VC_GEMV_PATH") ? atoi(getenv("VC_GEMV_PATH")) : 1;
+    // VC_GEMV_NT=2 pairs output tiles per workgroup (halves the L2 traffic of the activation operand).  Register-staged
+    // form measured: bf16 -4...-10 % with pairs, W8A16 +20 % — there the activation fragments are twice the weight bytes
     static const int nt2 = getenv("VC_GEMV_NT") ? atoi(getenv("VC_GEMV_NT")) == 2 : (FP8 ? 1 : 0);
     const int tiles = a.N / 16;
+    if (path == 1) {
+        // many tiles: 4-wave workgroups, several per CU; few tiles (one workgroup per CU): 8 waves and a deep ring
+        // pairs of tiles per workgroup pay off for the widest matrices (gate/up, lm_head: 30.3 vs 33.1 us, 40.8 vs 45.5)
+        if (tiles > 512) {
+            if (nt2 || tiles > 1024) launch_gemv_dma<4, 2, FP8 ? 3 : 4, FP8>(a, epilogue, s);
+            else launch_gemv_dma<4, 1, 4, FP8>(a, epilogue, s);
+        } else {
+            launch_gemv_dma<8, 1, FP8 ? 5 : 8, FP8>(a, epilogue, s);
+        }
+        return;
+    }
+    // >= ~2048 waves in flight: few output tiles -> more K-splitting waves per workgroup
     if (nt2 && tiles > 512) launch_gemv_w<8, 2, FP8>(a, epilogue, s);
     else if (tiles <= 512) launch_gemv_w<8, 1, FP8>(a, epilogue, s);
     else launch_gemv_w<4, 1, FP8>(a, epilogue, s);

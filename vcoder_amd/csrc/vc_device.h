@@ -149,6 +149,28 @@ template <int P> VC_DEV void set_prio() { __builtin_amdgcn_s_setprio(P); }
 VC_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 #endif
 
+// non-temporal LDS-DMA for streams read exactly once (decode weights): measured 6.8 vs 6.0 TB/s on a pure stream
+#ifdef VC_EMU
+VC_DEV void glds16_nt(const void* gsrc_lane, void* lds_wave_base) { glds16(gsrc_lane, lds_wave_base); }
+VC_DEV void wait_vmcnt_n(int) {}
+#else
+VC_DEV void glds16_nt(const void* gsrc_lane, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 2);
+}
+// s_waitcnt vmcnt(n) for an n that folds to a constant after unrolling (anything else drains)
+VC_DEV void wait_vmcnt_n(int n) {
+    switch (n) {
+#define VC_VMCASE(N) case N: wait_vmcnt<N>(); break;
+        VC_VMCASE(1) VC_VMCASE(2) VC_VMCASE(3) VC_VMCASE(4) VC_VMCASE(5) VC_VMCASE(6) VC_VMCASE(7) VC_VMCASE(8) VC_VMCASE(9)
+        VC_VMCASE(10) VC_VMCASE(11) VC_VMCASE(12) VC_VMCASE(13) VC_VMCASE(14) VC_VMCASE(15) VC_VMCASE(16) VC_VMCASE(18)
+        VC_VMCASE(20) VC_VMCASE(21) VC_VMCASE(24) VC_VMCASE(28) VC_VMCASE(32)
+#undef VC_VMCASE
+        default: wait_vmcnt<0>(); break;
+    }
+}
+#endif
+
 // ---- activations (fp32) --------------------------------------------------------------------
 VC_DEV float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }   // x*sigmoid(1.702x)
 VC_DEV float erf_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
