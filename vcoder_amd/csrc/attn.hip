@@ -442,7 +442,7 @@ __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeF
 #pragma unroll
         for (int u = 0; u < UK; ++u) {
             const int key = kb + u * KPW + lane / LPK;
-            kv[u] = ld16(kbase + (size_t)min(key, ctx - 1) * HD + (lane % LPK) * 8);
+            kv[u] = ld16_stream(kbase + (size_t)min(key, ctx - 1) * HD + (lane % LPK) * 8);
         }
 #pragma unroll
         for (int u = 0; u < UK; ++u) {
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeF
     u32x4 v0[NR];
     if (wave * 64 < ctx64) {
 #pragma unroll
-        for (int i = 0; i < NR; ++i) v0[i] = ld16(vbase + (size_t)(i * 8 + dr) * p.kv_stride + wave * 64 + kc * 8);
+        for (int i = 0; i < NR; ++i) v0[i] = ld16_stream(vbase + (size_t)(i * 8 + dr) * p.kv_stride + wave * 64 + kc * 8);
     }
     __syncthreads();
     // ---- phase 2: softmax over sc[0..ctx_pad)
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeF
     // this one accumulates
     auto load_v = [&](u32x4 (&v)[NR], int kb) {
 #pragma unroll
-        for (int i = 0; i < NR; ++i) v[i] = ld16(vbase + (size_t)(i * 8 + dr) * p.kv_stride + kb + kc * 8);
+        for (int i = 0; i < NR; ++i) v[i] = ld16_stream(vbase + (size_t)(i * 8 + dr) * p.kv_stride + kb + kc * 8);
     };
     u32x4 v1[NR];
     for (int kb = wave * 64; kb < ctx64; kb += 2 * 8 * 64) {

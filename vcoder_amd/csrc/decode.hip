@@ -17,11 +17,6 @@
 
 namespace vc {
 
-#ifdef VC_EMU
-VC_DEV u32x4 ld16_stream(const void* p) { return ld16(p); }
-#else
-VC_DEV u32x4 ld16_stream(const void* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); }
-#endif
 
 // shared epilogue: `v` = out[m][n..n+3] partial sums already reduced over the waves of the workgroup
 template <int WAVES, int EPI, bool FP8>

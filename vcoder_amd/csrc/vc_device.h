@@ -120,6 +120,13 @@ VC_DEV void st8(void* p, u32x2 v) { *reinterpret_cast<u32x2*>(p) = v; }
 VC_DEV f32x4 ld16f(const void* p) { return *reinterpret_cast<const f32x4*>(p); }
 VC_DEV void st16f(void* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
+// non-temporal 16-byte load for streams that are read once per launch (decode weights, KV cache rows)
+#ifdef VC_EMU
+VC_DEV u32x4 ld16_stream(const void* p) { return ld16(p); }
+#else
+VC_DEV u32x4 ld16_stream(const void* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); }
+#endif
+
 // ---- LDS-DMA: 16 bytes per lane, global -> LDS without passing through VGPRs (global_load_lds_dwordx4).
 // The LDS destination is WAVE-UNIFORM base + lane*16; the global source is per lane (so LDS swizzles are applied to
 // the source address).  Completion is tracked by vmcnt; hipcc waits vmcnt(0) before the next __syncthreads().
