@@ -265,6 +265,18 @@ def test_load_pretrained_model_from_hf_layout(tmp_path):
     model2.engine.close()
     with pytest.raises(NotImplementedError):
         load_pretrained_model(d, None, "vcoder_ds_llava-v1.5-tiny", load_4bit=True)
+    # load_8bit -> the W8A16 weight format: same ids as an engine that was told set_weight_format("fp8") directly
+    _, model8, _, _, _, _ = load_pretrained_model(d, None, "vcoder_ds_llava-v1.5-tiny", load_8bit=True)
+    out8 = model8.generate(t(ids), images=t(imgs), segs=t(segs), depths=t(deps), do_sample=False, max_new_tokens=4,
+                           eos_token_id=-1)
+    eng8 = HipEngine(cfg)
+    eng8.load_synthetic(42)
+    eng8.set_weight_format("fp8")
+    eng8.finalize()
+    ref8 = eng8.generate_greedy(ids, imgs, segs, deps, max_new_tokens=4)
+    assert np.array_equal(out8[:, ids.shape[1]:].numpy(), ref8)
+    model8.engine.close()
+    eng8.close()
 
 
 def test_device_preprocessing_matches_pil(tmp_path):

@@ -1,8 +1,10 @@
 """load_pretrained_model — drop-in for vcoder_llava/model/builder.py:25-154 (inference paths).
 
 Same signature and 6-tuple; same name-substring dispatch ('vcoder_ds_llava' / 'vcoder_llava' / else llava,
-builder.py:93-108), same processor aliasing (:145-151) and context_len rule (:133-136).  8/4-bit bitsandbytes and
-LoRA-merge paths are not part of the MI355X hot path and raise."""
+builder.py:93-108), same processor aliasing (:145-151) and context_len rule (:133-136).  `load_8bit=True` (the
+reference: bitsandbytes LLM.int8, builder.py:31-33) selects this build's 8-bit weight format instead: W8A16, decoder
+linears as fp8-e4m3 with per-row power-of-two scales (vcoder_amd/quant.py).  4-bit (NF4) and the LoRA-merge paths are not
+part of the MI355X hot path and raise."""
 from __future__ import annotations
 
 from .language_model import LlavaLlamaForCausalLM, VCoderDSLlavaLlamaForCausalLM, VCoderLlavaLlamaForCausalLM
@@ -10,9 +12,9 @@ from .language_model import LlavaLlamaForCausalLM, VCoderDSLlavaLlamaForCausalLM
 
 def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, load_4bit=False, device_map="auto",
                           device="cuda"):
-    if load_8bit or load_4bit:
-        raise NotImplementedError("bitsandbytes 8/4-bit loading is a CUDA-only path of the reference; the MI355X build "
-                                  "runs bf16 weights")
+    if load_4bit:
+        raise NotImplementedError("bitsandbytes NF4 loading is a CUDA-only path of the reference; the MI355X build runs "
+                                  "bf16 weights or, with load_8bit=True, fp8-e4m3 decoder weights")
     name = model_name.lower()
     if "llava" not in name:
         raise ValueError(f"'{model_name}': only LLaVA-family checkpoints (llava / vcoder_llava / vcoder_ds_llava) are "
@@ -27,7 +29,8 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, l
         cls = VCoderLlavaLlamaForCausalLM
     else:
         cls = LlavaLlamaForCausalLM
-    model = cls.from_pretrained(model_path, low_cpu_mem_usage=True, device=device)
+    model = cls.from_pretrained(model_path, low_cpu_mem_usage=True, device=device,
+                                weight_format="fp8" if load_8bit else "bf16")
     context_len = model.config.max_sequence_length if getattr(model.config, "max_sequence_length", None) else 2048
     vision_tower = model.get_vision_tower()
     if not vision_tower.is_loaded or vision_tower.image_processor is None:

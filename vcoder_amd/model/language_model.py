@@ -147,7 +147,8 @@ class _HipCausalLMBase:
         return self
 
     @classmethod
-    def from_pretrained(cls, model_path: str, low_cpu_mem_usage=True, device="cuda", config=None, **kwargs):
+    def from_pretrained(cls, model_path: str, low_cpu_mem_usage=True, device="cuda", config=None, weight_format="bf16",
+                        **kwargs):
         """Loads config.json + weight shards; the CLIP tower comes from the checkpoint if present, else from the
         local directory `config.mm_vision_tower` (the reference downloads it: clip_encoder.py:22-27 — there is no
         network here, so a hub name that is not a local directory is an error)."""
@@ -163,6 +164,8 @@ class _HipCausalLMBase:
             model.engine.load_tensor(k, v)
         if not saw_tower:
             model.get_vision_tower().load_model(engine=model.engine)
+        if weight_format != "bf16":
+            model.engine.set_weight_format(weight_format)   # W8A16: quantised on the device at finalize
         model.finalize_weights()
         return model
 
