@@ -102,7 +102,7 @@ def test_dma_kernels_are_race_free_and_bit_reproducible(be):
     misplaced wait shows up as rare wrong tiles that depend on timing.  Screen: many back-to-back launches of the true
     shapes (odd k-tile counts, ragged M, both ring geometries) must all produce the bit pattern of the first launch, and
     that pattern must match the oracle (checked by test_gemm / test_gemv on the same shapes)."""
-    import ctypes
+    import numpy as np
     import torch
 
     rng = np.random.RandomState(3)
