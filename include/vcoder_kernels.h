@@ -24,10 +24,13 @@ void vck_gemv(const uint16_t* X, const uint16_t* Wp, void* out, int M, int N, in
  *   consumer  (ssq_in != NULL): X is xg = bf16(x * g) written by the producer and out = rstd[m] * (X @ W^T), with
  *             rstd[m] = rsqrt(sum_p ssq_in[m][p] / K + eps) from `npart` deterministic sum-of-squares partials;
  *   producer  (epi 2): ssq_out gets the partials of the updated residual rows and xg_out = bf16(residual * xg_w).
- * wscale != NULL: Wp holds W8A16 e4m3 bytes (vck_quantize_fp8) and wscale the per-output-row scales. */
+ * wscale != NULL: Wp holds W8A16 e4m3 bytes (vck_quantize_fp8) and wscale the per-output-row scales.
+ * sk_scratch/sk_counters != NULL: deterministic split-K for matrices with few output tiles — `ksplit` workgroups per
+ * tile (0 = let the launcher choose), partials [ksplit][N/16][256] fp32 summed in k order by the last arriver;
+ * sk_counters [N/16] must be zero before the first launch (the kernel re-arms them). */
 void vck_gemv_ex(const uint16_t* X, const void* Wp, const float* wscale, void* out, const float* ssq_in, float* ssq_out,
-                 const float* xg_w, uint16_t* xg_out, int npart, float eps, int M, int N, int K, int ldo, int epi,
-                 void* stream);
+                 const float* xg_w, uint16_t* xg_out, int npart, float eps, float* sk_scratch, unsigned* sk_counters,
+                 int ksplit, int M, int N, int K, int ldo, int epi, void* stream);
 void vck_pack_weight(const uint16_t* W, uint16_t* Wp, int N, int K, void* stream);
 /* W8A16 decode weights (BASELINE config C5): per-output-row power-of-two scale + OCP e4m3 bytes in the gemv's 64-wide
  * k super-tile order; W [N,K] bf16 is overwritten with the dequantised values (what the prefill GEMMs then read).

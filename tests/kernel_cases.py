@@ -185,10 +185,12 @@ def check_gemv(be, M, N, K, epi, seed=0):
 
 
 
-def _gemv_ex(be, X, Wp, wscale, out, ssq_in, ssq_out, xg_w, xg_out, npart, M, N, K, ldo, epi):
-    """vck_gemv_ex through raw pointers; every array must stay referenced by the caller until be.sync()."""
+def _gemv_ex(be, X, Wp, wscale, out, ssq_in, ssq_out, xg_w, xg_out, npart, M, N, K, ldo, epi, sk=None, ksplit=0):
+    """vck_gemv_ex through raw pointers; every array must stay referenced by the caller until be.sync().
+    sk = (scratch f32 [ksplit*N/16*256], counters i32 [N/16]) enables the split-K finisher."""
     be.lib.vck_gemv_ex(be.ptr(X), be.ptr(Wp), be.ptr(wscale), be.ptr(out), be.ptr(ssq_in), be.ptr(ssq_out), be.ptr(xg_w),
-                       be.ptr(xg_out), ctypes.c_int(npart), ctypes.c_float(1e-5), M, N, K, ldo, epi, None)
+                       be.ptr(xg_out), ctypes.c_int(npart), ctypes.c_float(1e-5), be.ptr(sk[0]) if sk else None,
+                       be.ptr(sk[1]) if sk else None, ctypes.c_int(ksplit), M, N, K, ldo, epi, None)
     be.sync()
 
 
@@ -243,6 +245,34 @@ def check_gemv_fp8(be, M, N, K, epi, norm=False, seed=0):
     tol = 2 ** -8 if epi in (0, 3) else 2e-5
     assert e < tol, f"gemv_fp8 M{M} N{N} K{K} epi{epi} norm{norm}: rel err {e}"
     return e
+
+
+def check_gemv_splitk(be, M, N, K, ksplit, seed=0):
+    """Split-K RESID form (o_proj / down): x += h @ W^T with ssq partials and the xg operand published by the tile's last
+    arriver; equal to the unsplit launch up to fp32 summation order, bit-identical across repeated launches, and the
+    arrival counters are left at zero."""
+    rng = np.random.RandomState(seed)
+    npart = (N // 16 + 15) // 16 * 16
+    X = bf16_round(rng.randn(M, K))
+    W = bf16_round(rng.randn(N, K) * 0.05)
+    g = (rng.rand(N) + 0.5).astype(np.float32)
+    r0 = rng.randn(M, N).astype(np.float32)
+    Xd, Wd, gd = be.bf16(X), be.bf16(W), be.f32(g)
+    Wp = be.zeros((N * K,), "bf16")
+    _call(be, "vck_pack_weight", Wd, Wp, N, K)
+    ref = r0.astype(np.float64) + X.astype(np.float64) @ W.T.astype(np.float64)
+    scratch, counters = be.zeros((max(ksplit, 1) * (N // 16) * 256,), "f32"), be.zeros((N // 16,), "i32")
+    outs = []
+    for it in range(3):
+        out, ssq, xg = be.f32(r0.copy()), be.zeros((16, npart), "f32"), be.zeros((M, N), "bf16")   # f32() may alias its input
+        _gemv_ex(be, Xd, Wp, None, out, None, ssq, gd, xg, npart, M, N, K, N, 2, sk=(scratch, counters), ksplit=ksplit)
+        got = be.host_f32(out)
+        assert rel_err(got, ref) < 1e-5, f"split-K {ksplit}: rel err {rel_err(got, ref)}"
+        assert np.array_equal(be.host_f32(xg), bf16_round(got * g))
+        assert np.abs(be.host_f32(ssq)[:M, : N // 16].sum(-1) / (ref ** 2).sum(-1) - 1).max() < 1e-5
+        assert not be.host_i32(counters).any(), "arrival counters must be re-armed"
+        outs.append(got)
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]), "split-K result depends on arrival order"
 
 
 def check_interleave(be, F, K):

@@ -36,6 +36,12 @@ def test_gemv_fp8(be, M, N, K, epi, norm):
     kc.check_gemv_fp8(be, M, N, K, epi, norm)
 
 
+@pytest.mark.parametrize("M,N,K,ks", [(8, 4096, 4096, 2), (8, 4096, 11008, 3), (16, 5120, 13824, 4), (16, 5120, 5120, 4),
+                                      (3, 48, 320, 3)])
+def test_gemv_splitk(be, M, N, K, ks):
+    kc.check_gemv_splitk(be, M, N, K, ks)
+
+
 def test_small_ops(be):
     kc.check_interleave(be, 11008, 256)
     kc.check_layernorm(be, 4616, 1024)

@@ -31,6 +31,11 @@ def test_gemv_fp8(be, M, N, K, epi, norm):
     kc.check_gemv_fp8(be, M, N, K, epi, norm)
 
 
+@pytest.mark.parametrize("M,N,K,ks", [(8, 64, 512, 2), (16, 48, 320, 3), (3, 32, 1024, 4), (8, 32, 64, 4)])
+def test_gemv_splitk(be, M, N, K, ks):
+    kc.check_gemv_splitk(be, M, N, K, ks)
+
+
 def test_interleave(be):
     kc.check_interleave(be, 24, 64)
 

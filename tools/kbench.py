@@ -61,6 +61,16 @@ def bench_gemv():
             lib.vck_gemv(P(X), P(Ws[it[0] % 8]), P(out), M, N, K, ldo, epi, None)
         us = timeit(f, iters=40)
         print(f"gemv {name:8s} N{N} K{K} epi{epi}: {us:7.1f} us  {2 * N * K / us / 1e3:7.1f} GB/s", flush=True)
+        if epi == 2:
+            scratch = torch.zeros(4 * (N // 16) * 256, device=dev)
+            counters = torch.zeros(N // 16, dtype=torch.int32, device=dev)
+            for ks in (2, 3, 4):
+                def h():
+                    it[0] += 1
+                    lib.vck_gemv_ex(P(X), P(Ws[it[0] % 8]), None, P(out), None, None, None, None, 16, C.c_float(1e-5), P(scratch),
+                                    P(counters), ks, M, N, K, ldo, epi, None)
+                us = timeit(h, iters=40)
+                print(f"gemv {name:8s} split-K {ks}: {us:7.1f} us  {2 * N * K / us / 1e3:7.1f} GB/s", flush=True)
         if epi in (0, 1, 3):
             xf = torch.randn(16, K, device=dev)
             w = torch.rand(K, device=dev) + 0.5
@@ -69,10 +79,38 @@ def bench_gemv():
 
             def g():
                 it[0] += 1
-                lib.vck_gemv_ex(P(X), P(Ws[it[0] % 8]), None, P(out), P(ssq), None, None, None, npart, C.c_float(1e-5), M, N,
-                                K, ldo, epi, None)
+                lib.vck_gemv_ex(P(X), P(Ws[it[0] % 8]), None, P(out), P(ssq), None, None, None, npart, C.c_float(1e-5), None, None,
+                                0, M, N, K, ldo, epi, None)
             us = timeit(g, iters=40)
             print(f"gemv+rstd {name:8s}          : {us:7.1f} us  {2 * N * K / us / 1e3:7.1f} GB/s", flush=True)
+
+
+def bench_gemv13():
+    """VCoder-DS 13b decode shapes at M = 16 and M = 8 (config C3 runs M = 16)."""
+    for M in (16, 8):
+        for (N, K, epi, name) in [(15360, 5120, 0, "qkv"), (5120, 5120, 2, "o"), (27648, 5120, 3, "gate-up"),
+                                  (5120, 13824, 2, "down"), (32000, 5120, 1, "lm_head")]:
+            X = bf16(M, K)
+            Ws = [bf16(N * K, scale=0.02) for _ in range(4)]
+            out = torch.zeros((M, N), dtype=torch.float32 if epi in (1, 2) else torch.bfloat16, device=dev)
+            ldo = N // 2 if epi == 3 else N
+            it = [0]
+
+            def f():
+                it[0] += 1
+                lib.vck_gemv(P(X), P(Ws[it[0] % 4]), P(out), M, N, K, ldo, epi, None)
+            us = timeit(f, iters=40)
+            print(f"gemv13 M{M} {name:8s} N{N} K{K} epi{epi}: {us:7.1f} us  {2 * N * K / us / 1e3:7.1f} GB/s", flush=True)
+            if epi == 2:
+                scratch = torch.zeros(4 * (N // 16) * 256, device=dev)
+                counters = torch.zeros(N // 16, dtype=torch.int32, device=dev)
+                for ks in (2, 3, 4):
+                    def h():
+                        it[0] += 1
+                        lib.vck_gemv_ex(P(X), P(Ws[it[0] % 4]), None, P(out), None, None, None, None, 16, C.c_float(1e-5),
+                                        P(scratch), P(counters), ks, M, N, K, ldo, epi, None)
+                    us = timeit(h, iters=40)
+                    print(f"gemv13 M{M} {name:8s} split-K {ks}: {us:7.1f} us  {2 * N * K / us / 1e3:7.1f} GB/s", flush=True)
 
 
 def bench_gemv_fp8():
@@ -95,7 +133,7 @@ def bench_gemv_fp8():
             def f():
                 it[0] += 1
                 lib.vck_gemv_ex(P(X), P(Ws[it[0] % 8]), P(sc), P(out), P(ssq) if norm else None, None, None, None, npart,
-                                C.c_float(1e-5), M, N, K, ldo, epi, None)
+                                C.c_float(1e-5), None, None, 0, M, N, K, ldo, epi, None)
             us = timeit(f, iters=40)
             print(f"gemv_fp8 M{M} {name:8s} N{N} K{K} epi{epi} norm{int(norm)}: {us:7.1f} us  {N * K / us / 1e3:7.1f} GB/s",
                   flush=True)
@@ -137,6 +175,8 @@ if __name__ == "__main__":
     what = sys.argv[1:] or ["gemm", "gemv", "attn", "dattn"]
     if "gemv_fp8" in what:
         bench_gemv_fp8()
+    if "gemv13" in what:
+        bench_gemv13()
     for w in what:
         {"gemm": bench_gemm, "gemv": bench_gemv, "attn": bench_attn, "dattn": bench_dattn,
-         "gemv_fp8": lambda: None}[w]()
+         "gemv_fp8": lambda: None, "gemv13": lambda: None}[w]()

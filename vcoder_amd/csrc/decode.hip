@@ -193,15 +193,23 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
     constexpr int KSH = FP8 ? 6 : 5;
     constexpr int GK = KT / 4;
     constexpr int XS = FP8 ? 2 : 1;          // 1-KiB activation pieces per k-tile
-    constexpr int OPS = NT + XS;             // DMA instructions per k-tile
+    // k-tiles per ring slot: bf16 takes them in PAIRS so that the two activation gathers of a slot touch the two 64-byte
+    // halves of the same 128-byte lines back to back (the second is an L1 hit: half the L2 requests of the X operand);
+    // a W8A16 k-tile already spans whole lines
+    constexpr int KPI = FP8 ? 1 : 2;
+    constexpr int OPS = KPI * (NT + XS);     // DMA instructions per slot
     constexpr int SLOT = OPS * 1024;
     static_assert(WAVES * R * SLOT >= WAVES * NT * 1024, "the ring is re-used for the cross-wave reduction");
     VC_DYNAMIC_SMEM(char, ring);             // [WAVES][R][SLOT]
     __shared__ float ss_part[WAVES][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntiles = p.N >> 4;
-    const int nt0 = blockIdx.x * NT;
+    const int KS = p.ksplit > 1 ? p.ksplit : 1;
+    const int ks = (int)blockIdx.x % KS;
+    const int nt0 = ((int)blockIdx.x / KS) * NT;
     const int nkt = p.K >> KSH;
+    const int nit = (nkt + KPI - 1) / KPI;   // slots' worth of k-tiles in the matrix
+    const int it0 = (int)((long)ks * nit / KS), it1 = (int)((long)(ks + 1) * nit / KS);  // this workgroup's share of K
     const int m = lane & 15, g = lane >> 4;
     const bool mvalid = m < p.M;
     char* my = ring + wave * (R * SLOT);
@@ -211,38 +219,45 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
         wsrc[t] = reinterpret_cast<const char*>(p.Wp) + ((size_t)min(nt0 + t, ntiles - 1) * nkt * 64 + lane) * 16;
     const char* xsrc = reinterpret_cast<const char*>(p.X + (size_t)(mvalid ? m : 0) * p.K + g * GK);
     auto issue = [&](int i, int slot) {
-        const size_t kt = (size_t)(wave + i * WAVES);
         char* dst = my + slot * SLOT;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) glds16_nt(wsrc[t] + kt * 1024, dst + t * 1024);
-        glds16(xsrc + kt * (KT * 2), dst + NT * 1024);
-        if constexpr (FP8) glds16(xsrc + kt * (KT * 2) + 16, dst + (NT + 1) * 1024);
+        for (int kk = 0; kk < KPI; ++kk) {
+            const size_t kt = (size_t)min((it0 + wave + i * WAVES) * KPI + kk, nkt - 1);  // an odd tail re-reads the last tile
+#pragma unroll
+            for (int t = 0; t < NT; ++t) glds16_nt(wsrc[t] + kt * 1024, dst + (kk * (NT + XS) + t) * 1024);
+            glds16(xsrc + kt * (KT * 2), dst + (kk * (NT + XS) + NT) * 1024);
+            if constexpr (FP8) glds16(xsrc + kt * (KT * 2) + 16, dst + (kk * (NT + XS) + NT + 1) * 1024);
+        }
     };
     f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto consume = [&](int slot) {
+    auto consume = [&](int i, int slot) {
         const char* s = my + slot * SLOT + lane * 16;
-        u32x4 w[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) w[t] = ld16(s + t * 1024);
-        u32x4 x0 = ld16(s + NT * 1024), x1 = {0u, 0u, 0u, 0u};
-        if constexpr (FP8) x1 = ld16(s + (NT + 1) * 1024);
-        if (!mvalid) x0 = x1 = u32x4{0u, 0u, 0u, 0u};
+        for (int kk = 0; kk < KPI; ++kk) {
+            const char* sk = s + kk * (NT + XS) * 1024;
+            u32x4 w[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if constexpr (FP8) {
-                const u32x2 b0 = fp8x4_to_bf16x4(w[t][0]), b1 = fp8x4_to_bf16x4(w[t][1]);
-                const u32x2 b2 = fp8x4_to_bf16x4(w[t][2]), b3 = fp8x4_to_bf16x4(w[t][3]);
-                acc[t] = mfma16(u32x4{b0[0], b0[1], b1[0], b1[1]}, x0, acc[t]);
-                acc[t] = mfma16(u32x4{b2[0], b2[1], b3[0], b3[1]}, x1, acc[t]);
-            } else {
-                acc[t] = mfma16(w[t], x0, acc[t]);
+            for (int t = 0; t < NT; ++t) w[t] = ld16(sk + t * 1024);
+            u32x4 x0 = ld16(sk + NT * 1024), x1 = {0u, 0u, 0u, 0u};
+            if constexpr (FP8) x1 = ld16(sk + (NT + 1) * 1024);
+            if (!mvalid || (KPI > 1 && (it0 + wave + i * WAVES) * KPI + kk >= nkt)) x0 = x1 = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if constexpr (FP8) {
+                    const u32x2 b0 = fp8x4_to_bf16x4(w[t][0]), b1 = fp8x4_to_bf16x4(w[t][1]);
+                    const u32x2 b2 = fp8x4_to_bf16x4(w[t][2]), b3 = fp8x4_to_bf16x4(w[t][3]);
+                    acc[t] = mfma16(u32x4{b0[0], b0[1], b1[0], b1[1]}, x0, acc[t]);
+                    acc[t] = mfma16(u32x4{b2[0], b2[1], b3[0], b3[1]}, x1, acc[t]);
+                } else {
+                    acc[t] = mfma16(w[t], x0, acc[t]);
+                }
             }
         }
         wait_lgkmcnt<0>();  // the slot's fragment reads have retired before it is re-armed
     };
-    const int cnt = (nkt - wave + WAVES - 1) / WAVES;  // k-tiles of this wave (wave-uniform)
+    const int cnt = max(0, (it1 - it0 - wave + WAVES - 1) / WAVES);  // slots of this wave (wave-uniform)
     const int primed = min(cnt, R);
     // 1/rms of row m from the producer's partials: the register loads are issued BEFORE the ring is primed, so the wait
     // the compiler places at their first use leaves every DMA in flight (vmcnt counts in order)
@@ -280,19 +295,19 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
         int slot = 0;
         for (int i = 0; i < cnt - R; ++i) {
             wait_vmcnt<(R - 1) * OPS>();
-            consume(slot);
+            consume(i, slot);
             issue(i + R, slot);
             slot = slot + 1 == R ? 0 : slot + 1;
         }
 #pragma unroll
         for (int j = 0; j < R; ++j) {  // drain: nothing new is issued, the outstanding count shrinks by OPS per step
             wait_vmcnt_n((R - 1 - j) * OPS);
-            consume(slot);
+            consume(cnt - R + j, slot);
             slot = slot + 1 == R ? 0 : slot + 1;
         }
     } else {
         wait_vmcnt<0>();
-        for (int r = 0; r < cnt; ++r) consume(r);
+        for (int r = 0; r < cnt; ++r) consume(r, r);
     }
     __syncthreads();  // every wave is done with its ring before `red` overwrites it
     float* red = reinterpret_cast<float*>(ring);  // [WAVES][NT][64][4]
@@ -305,6 +320,24 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
     f32x4 v = ld16f(red + ((0 * NT + wave) * 64 + lane) * 4);
 #pragma unroll
     for (int w = 1; w < WAVES; ++w) v = v + ld16f(red + ((w * NT + wave) * 64 + lane) * 4);
+    if (KS > 1) {
+        // hand the partial to whoever finishes this tile last; it adds the KS partials in k order
+        float* mine = p.sk_scratch + (((size_t)ks * ntiles + nt) * 64 + lane) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) st_agent(mine + e, v[e]);
+        wait_vmcnt<0>();  // the write-through stores have been acknowledged before the arrival is counted
+        unsigned arrived = 0;
+        if (lane == 0) arrived = atomic_inc_agent(&p.sk_counters[nt]);
+        arrived = shfl(arrived, 0);
+        if (arrived != (unsigned)(KS - 1)) return;
+        v = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < KS; ++k) {
+            const float* q = p.sk_scratch + (((size_t)k * ntiles + nt) * 64 + lane) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += ld_agent(q + e);
+        }
+        if (lane == 0) st_agent_u32(&p.sk_counters[nt], 0u);  // re-armed for the next launch (stream order)
+    }
     gemv_epilogue<WAVES, EPI, FP8>(p, v, &ss_part[0][0], nt, m, g, mvalid);
 }
 
@@ -329,8 +362,8 @@ static void launch_gemv_w(const GemvArgs& a, int epi, hipStream_t s) {
 
 template <int WAVES, int NT, int R, bool FP8>
 static void launch_gemv_dma(const GemvArgs& a, int epi, hipStream_t s) {
-    const dim3 grid((a.N / 16 + NT - 1) / NT), block(WAVES * 64);
-    constexpr size_t shmem = (size_t)WAVES * R * (NT + (FP8 ? 2 : 1)) * 1024;
+    const dim3 grid(((a.N / 16 + NT - 1) / NT) * (a.ksplit > 1 ? a.ksplit : 1)), block(WAVES * 64);
+    constexpr size_t shmem = (size_t)WAVES * R * (FP8 ? 1 : 2) * (NT + (FP8 ? 2 : 1)) * 1024;
 #define VC_GEMV_DMA(E)                                                                                                  \
     do {                                                                                                                \
         static bool once = false;                                                                                       \
@@ -355,17 +388,33 @@ static void launch_gemv_f(const GemvArgs& a, int epilogue, hipStream_t s) {
     static const int path = getenv("VC_GEMV_PATH") ? atoi(getenv("VC_GEMV_PATH")) : 1;
     // VC_GEMV_NT=2 pairs output tiles per workgroup (halves the L2 traffic of the activation operand).  Register-staged
     // form measured: bf16 -4...-10 % with pairs, W8A16 +20 % — there the activation fragments are twice the weight bytes
-    static const int nt2 = getenv("VC_GEMV_NT") ? atoi(getenv("VC_GEMV_NT")) == 2 : (FP8 ? 1 : 0);
+    static const int nt2 = getenv("VC_GEMV_NT") ? atoi(getenv("VC_GEMV_NT")) == 2 : 0;
     const int tiles = a.N / 16;
     if (path == 1) {
-        // many tiles: 4-wave workgroups, several per CU; few tiles (one workgroup per CU): 8 waves and a deep ring
-        // pairs of tiles per workgroup pay off for the widest matrices (gate/up, lm_head: 30.3 vs 33.1 us, 40.8 vs 45.5)
-        if (tiles > 512) {
-            if (nt2 || tiles > 1024) launch_gemv_dma<4, 2, FP8 ? 3 : 4, FP8>(a, epilogue, s);
-            else launch_gemv_dma<4, 1, 4, FP8>(a, epilogue, s);
-        } else {
-            launch_gemv_dma<8, 1, FP8 ? 5 : 8, FP8>(a, epilogue, s);
+        // Geometry by tile count, so that (where possible) every workgroup of the launch is resident at once — a tail of
+        // late workgroups cannot keep enough bytes in flight to use the HBM (13b o_proj/down: 320 tiles at one
+        // 128-KiB workgroup per CU ran a 64-workgroup second round at a third of the rate):
+        //   <= 256 tiles: 8 waves, deep ring (1 workgroup/CU);  <= 512: 4 waves, 5-slot ring (2 workgroups/CU);
+        //   <= 768: 4 waves x 1 tile (3/CU);  wider: 4 waves x 2 tiles (pairs share the activation fragments:
+        //   gate/up 30.0 vs 33.1 us, lm_head 40.6 vs 45.5).  bf16 slots hold a k-tile pair, W8A16 slots one super-tile.
+        // 257..512 tiles (13b o_proj / down: 320) neither fill the chip one-per-CU nor balance two-per-CU: with the
+        // split-K buffers, pairs of tiles x 3 K-slices = 480 workgroups, all resident (2/CU), activation fragments
+        // shared by the pair (measured M=16: down 43.0 -> 30.2 us, o_proj 20.1 -> 14.9; for <= 256 tiles every split
+        // loses: 8.5 -> 10 us).  VC_GEMV_KS overrides the slice count (1 = off); an explicit a.ksplit is honoured.
+        static const int ks_env = getenv("VC_GEMV_KS") ? atoi(getenv("VC_GEMV_KS")) : -1;
+        if (a.ksplit > 1 || (a.sk_scratch && a.sk_counters && a.ksplit == 0 && tiles > 256 && tiles <= 512)) {
+            GemvArgs b = a;
+            if (b.ksplit <= 1) b.ksplit = ks_env >= 0 ? ks_env : 3;
+            if (b.ksplit > 1) {
+                if (a.ksplit > 1 && !nt2 && tiles <= 256) launch_gemv_dma<4, 1, 3, FP8>(b, epilogue, s);
+                else launch_gemv_dma<4, 2, 3, FP8>(b, epilogue, s);
+                return;
+            }
         }
+        if (tiles <= 256) launch_gemv_dma<8, 1, FP8 ? 5 : 4, FP8>(a, epilogue, s);
+        else if (tiles <= 512) launch_gemv_dma<4, 1, 5, FP8>(a, epilogue, s);
+        else if (tiles <= 768 && !nt2 && !FP8) launch_gemv_dma<4, 1, 3, FP8>(a, epilogue, s);  // W8A16: always pairs (X is 2x W)
+        else launch_gemv_dma<4, 2, 3, FP8>(a, epilogue, s);
         return;
     }
     // >= ~2048 waves in flight: few output tiles -> more K-splitting waves per workgroup

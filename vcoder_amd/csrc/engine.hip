@@ -141,6 +141,7 @@ struct vc_model {
     int curB = 0, curS = 0, cur_pos = -1;
     // decode state
     Buf x_dec, xn_dec, qkv_dec, q_dec, attn_dec, h_dec, logits, next_tok, finished, out_ids, scalars, dsum, ssq;
+    Buf sk_scratch, sk_counters;  // split-K partials / arrival counters of the decode GEMV (few-tile matrices)
     int out_cap = 0;
     int* step_dev() { return scalars.as<int>(); }
     int* pos_dev() { return scalars.as<int>() + 1; }
@@ -352,6 +353,10 @@ void gemv(vc_model* m, const bf16_t* X, const bf16_t* Wp, const float* wscale, v
         }
         a.npart = np;
         a.eps = m->c.rms_eps;
+        if (N / 16 <= 512) {  // o_proj / down: the launcher may split K over several workgroups per tile
+            a.sk_scratch = m->sk_scratch.as<float>();
+            a.sk_counters = m->sk_counters.as<unsigned>();
+        }
         launch_gemv(a, epi, m->st);
     }
 }
@@ -711,6 +716,8 @@ void ensure_llm(vc_model* m, int B, int S_total) {
     m->scalars.ensure(64, true);
     m->dsum.ensure(Bp * 4, true);
     m->ssq.ensure((size_t)Bp * m->npart * 4, true);
+    m->sk_scratch.ensure((size_t)4 * 512 * 256 * 4);
+    m->sk_counters.ensure(512 * 4, true);
 }
 
 bf16_t* kcache(vc_model* m, int l) { return m->kc.as<bf16_t>() + (size_t)l * m->capB * m->c.heads * m->capS * m->hd; }
@@ -1062,7 +1069,7 @@ VC_API void vc_model_destroy(vc_model* m) {
                    &m->v_k, &m->v_vt, &m->v_attn, &m->v_h, &m->v_sel, &m->v_mid, &m->feats, &m->x, &m->xn, &m->qkv, &m->q,
                    &m->attn, &m->h, &m->kc, &m->vtc, &m->row_src, &m->last_idx, &m->xl, &m->logits_all, &m->x_dec,
                    &m->xn_dec, &m->qkv_dec, &m->q_dec, &m->attn_dec, &m->h_dec, &m->logits, &m->next_tok, &m->finished,
-                   &m->out_ids, &m->scalars, &m->dsum, &m->ssq, &m->s_cols, &m->s_patches, &m->s_vx, &m->s_vxn, &m->s_vqkv,
+                   &m->out_ids, &m->scalars, &m->dsum, &m->ssq, &m->sk_scratch, &m->sk_counters, &m->s_cols, &m->s_patches, &m->s_vx, &m->s_vxn, &m->s_vqkv,
                    &m->s_vq, &m->s_vk, &m->s_vv, &m->s_vattn, &m->s_vh, &m->s_sel, &m->s_mid, &m->s_feats, &m->s_xn, &m->s_qkv,
                    &m->s_q, &m->s_attn, &m->s_h, &m->s_kc, &m->s_vc, &m->s_xl, &m->pp_src, &m->pp_sq, &m->pp_tmp, &m->pp_out,
                    &m->pp_tab, &m->pp_f32})

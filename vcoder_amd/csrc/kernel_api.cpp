@@ -19,11 +19,12 @@ VCK_EXPORT void vck_gemv(const uint16_t* X, const uint16_t* Wp, void* out, int M
     launch_gemv(a, epi, S(stream));
 }
 VCK_EXPORT void vck_gemv_ex(const uint16_t* X, const void* Wp, const float* wscale, void* out, const float* ssq_in,
-                            float* ssq_out, const float* xg_w, uint16_t* xg_out, int npart, float eps, int M, int N, int K,
-                            int ldo, int epi, void* stream) {
+                            float* ssq_out, const float* xg_w, uint16_t* xg_out, int npart, float eps, float* sk_scratch,
+                            unsigned* sk_counters, int ksplit, int M, int N, int K, int ldo, int epi, void* stream) {
     GemvArgs a{};
     a.X = X; a.Wp = reinterpret_cast<const uint16_t*>(Wp); a.wscale = wscale; a.out = out; a.M = M; a.N = N; a.K = K; a.ldo = ldo;
     a.ssq_in = ssq_in; a.ssq_out = ssq_out; a.xg_w = xg_w; a.xg_out = xg_out; a.npart = npart; a.eps = eps;
+    a.sk_scratch = sk_scratch; a.sk_counters = sk_counters; a.ksplit = ksplit;
     launch_gemv(a, epi, S(stream));
 }
 VCK_EXPORT void vck_attention_decode_fused(const uint16_t* qkv, uint16_t* k, uint16_t* vt, uint16_t* out, int B, int H,

@@ -61,6 +61,12 @@ struct GemvArgs {
     bf16_t* xg_out;        // [M, N]
     int npart;             // partials per row (multiple of 16)
     float eps;
+    // deterministic split-K for matrices with few output tiles (o_proj, down): `ksplit` workgroups share one tile,
+    // each writes its fp32 partial to sk_scratch[ks][tile][64 lanes][4]; the LAST to arrive (sk_counters[tile]) sums
+    // the partials in k order — the result does not depend on arrival order — runs the epilogue and re-arms the counter
+    float* sk_scratch;       // [ksplit][N/16][256] or nullptr
+    unsigned* sk_counters;   // [N/16], zero between launches
+    int ksplit;              // 0/1 = off (launcher decides when the two buffers are given)
 };
 void launch_gemv(const GemvArgs& a, int epilogue, hipStream_t s);
 void launch_pack_weight(const bf16_t* W, bf16_t* Wp, int N, int K, hipStream_t s);

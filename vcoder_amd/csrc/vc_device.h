@@ -178,6 +178,22 @@ VC_DEV void wait_vmcnt_n(int n) {
 }
 #endif
 
+// ---- device-scope hand-off between workgroups (split-K finisher of the decode GEMV) ------------------------------
+// Payload moves with agent-scope relaxed atomics = write-through `sc1` stores / cache-bypassing `sc1` loads; the producer
+// drains them (vmcnt(0)) before it counts its arrival.  No agent-scope FENCE: on this multi-XCD part a release/acquire
+// fence writes back / invalidates the XCD's whole L2 (measured: 4-8x slower launches).
+#ifdef VC_EMU
+VC_DEV void st_agent(float* p, float v) { *p = v; }
+VC_DEV float ld_agent(const float* p) { return *p; }
+VC_DEV void st_agent_u32(unsigned* p, unsigned v) { *p = v; }
+VC_DEV unsigned atomic_inc_agent(unsigned* p) { return (*p)++; }  // emulated workgroups run one after another
+#else
+VC_DEV void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+VC_DEV float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+VC_DEV void st_agent_u32(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+VC_DEV unsigned atomic_inc_agent(unsigned* p) { return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
+
 // ---- activations (fp32) --------------------------------------------------------------------
 VC_DEV float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }   // x*sigmoid(1.702x)
 VC_DEV float erf_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
