@@ -86,9 +86,9 @@ def test_splice_greedy_synth(be):
 def test_fused_decode_kernels(be):
     kc.check_gemv_norm_chain(be, 8, 256, 64)
     kc.check_gemv_norm_chain(be, 3, 512, 96, seed=1)
-    kc.check_gemv_norm_chain(be, 16, 5120, 32, seed=3)   # 16 x 5120 rows: staged in 4 chunks of K
-    kc.check_gemv_norm_chain(be, 5, 288, 64, seed=5)     # K not chunkable -> direct (unstaged) normalisation
-    kc.check_gemv_norm_chain(be, 12, 1024, 64, seed=4)   # 16-row staging
+    kc.check_gemv_norm_chain(be, 16, 5120, 32, seed=3)   # 13b row width, all 16 token slots
+    kc.check_gemv_norm_chain(be, 5, 288, 64, seed=5)     # odd k-tile count: the last ring slot holds half a pair
+    kc.check_gemv_norm_chain(be, 12, 1024, 64, seed=4)
     kc.check_attention_decode_fused(be, 2, 2, 128, 70)
     kc.check_attention_decode_fused(be, 1, 2, 128, 128)
     kc.check_attention_decode_fused(be, 1, 1, 64, 5)
@@ -119,6 +119,11 @@ def test_alternate_kernel_variants():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
                         "test_gemm or test_attention"], env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
+    # the register-staged GEMV (the LDS-DMA ring kernel is the default)
+    env = dict(os.environ, VC_GEMV_PATH="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
+                        "test_gemv or test_fused_decode"], env=env, capture_output=True, text=True)
+    assert r.returncode == 0, "VC_GEMV_PATH=0: " + r.stdout[-2000:]
     # 5: the counted-vmcnt 8-phase 256x256 kernel forced onto every (small, ragged, 1-3 k-tile) case;
     # 2: the one-barrier 256x256 kernel; 4: 256x256 as 4 waves x (128 x 128)
     for v in ("5", "2", "4"):
