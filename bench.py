@@ -229,7 +229,7 @@ def main():
                        "parallelism": f"dp{world}", "weights": "seeded synthetic (vcoder_amd/synth.py)",
                        "in_flight_batches_per_gpu": n_sess},
             "phase_ms_one_session": timings,  # wall time of the last batch's phases; they overlap other batches when in flight > 1
-            "roofline": {"bound": "hbm", "kernel": "gemv_kernel (decode weight streaming)", "achieved": ach,
+            "roofline": {"bound": "hbm", "kernel": "gemv_dma_kernel (decode weight streaming, all 129 GEMV launches of a step)", "achieved": ach,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": traffic, "avg_launch_us": prof["avg_us"],
                          "algorithmic_bytes_per_launch": prof["avg_bytes"],
