@@ -119,6 +119,11 @@ def test_alternate_kernel_variants():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
                         "test_gemm or test_attention"], env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
+    # the single-pass (online softmax) decode attention
+    env = dict(os.environ, VC_DATTN_VARIANT="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "test_fused_decode"],
+                       env=env, capture_output=True, text=True)
+    assert r.returncode == 0, "VC_DATTN_VARIANT=1: " + r.stdout[-2000:]
     # the register-staged GEMV (the LDS-DMA ring kernel is the default)
     env = dict(os.environ, VC_GEMV_PATH="0")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",

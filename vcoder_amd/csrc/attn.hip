@@ -533,10 +533,145 @@ __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeF
     }
 }
 
+// =============================================================================================
+// single-pass ("flash") form of the fused decode attention (contexts beyond DEC_MAX_CTX; VC_DATTN_VARIANT=1).  Same phase 0 (RoPE + append); then every wave
+// walks its own 64-key blocks (wave, wave+8, ...) with an online softmax, so the K rows and V^T rows of a (b,h) are ONE
+// continuous non-temporal stream — no workgroup-wide softmax barrier with HBM idle behind it, no context-length limit:
+//   scores of the block (16 lanes per key)  ->  wave-private LDS  ->  running max / sum, rescale of the accumulators
+//   ->  P·V^T with the block's probabilities (lane = 8 d-rows x 8 key-chunks)
+// The next block's K rows are requested as soon as the scores are out of the registers, its V^T rows as soon as the PV
+// sums are done, so 16-32 KiB per wave stay in flight.  The 8 waves' (max, sum, acc) are merged once at the end.
+// =============================================================================================
+template <int HD>
+__global__ __launch_bounds__(512) void attention_decode_flash_kernel(AttnDecodeFusedArgs p) {
+    constexpr int LPK = HD / 8;           // lanes per key
+    constexpr int KPW = 64 / LPK;         // keys per wave-instruction
+    constexpr int NKI = 64 / KPW;         // K instructions per 64-key block
+    constexpr int NR = HD / 8;            // V^T instructions per block (8 d-rows each)
+    __shared__ __attribute__((aligned(16))) float q_s[HD];
+    __shared__ __attribute__((aligned(16))) float sc[8][64];
+    __shared__ __attribute__((aligned(16))) float part[8][HD];
+    __shared__ float ml[8][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const size_t bh = (size_t)b * p.H + h;
+    const int pos = *p.pos_dev;
+    const int ctx = pos + 1;
+    const int D = p.H * HD;
+    bf16_t* kbase = p.k + bh * p.kv_stride * HD;
+    bf16_t* vbase = p.vt + bh * HD * (size_t)p.kv_stride;
+    if (tid < HD / 2) {  // phase 0: rotate q,k of the new token, append k / v (global), keep q in LDS
+        const int d = tid;
+        const bf16_t* row = p.qkv + (size_t)b * (3 * D) + h * HD;
+        const float c = p.rope_cos[(size_t)pos * (HD / 2) + d], s = p.rope_sin[(size_t)pos * (HD / 2) + d];
+        const float q0 = bf2f(row[d]), q1 = bf2f(row[d + HD / 2]);
+        const float k0 = bf2f(row[D + d]), k1 = bf2f(row[D + d + HD / 2]);
+        q_s[d] = bf2f(f2bf(q0 * c - q1 * s));
+        q_s[d + HD / 2] = bf2f(f2bf(q1 * c + q0 * s));
+        bf16_t* ko = kbase + (size_t)pos * HD;
+        ko[d] = f2bf(k0 * c - k1 * s);
+        ko[d + HD / 2] = f2bf(k1 * c + k0 * s);
+        vbase[(size_t)d * p.kv_stride + pos] = row[2 * D + d];
+        vbase[(size_t)(d + HD / 2) * p.kv_stride + pos] = row[2 * D + d + HD / 2];
+    }
+    __syncthreads();  // workgroup-scope release/acquire: the appended K row / V^T column are visible to this block
+    float qv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qv[e] = q_s[(lane % LPK) * 8 + e];
+    const int nblk = (ctx + 63) >> 6;
+    const int dr = lane >> 3, kc = lane & 7;
+    float m_run = -INFINITY, l_run = 0.f;
+    float acc[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) acc[i] = 0.f;
+    u32x4 kv[NKI], vv[NR];
+    auto load_k = [&](int blk) {
+#pragma unroll
+        for (int u = 0; u < NKI; ++u) {
+            const int key = blk * 64 + u * KPW + lane / LPK;
+            kv[u] = ld16_stream(kbase + (size_t)min(key, ctx - 1) * HD + (lane % LPK) * 8);
+        }
+    };
+    auto load_v = [&](int blk) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) vv[i] = ld16_stream(vbase + (size_t)(i * 8 + dr) * p.kv_stride + blk * 64 + kc * 8);
+    };
+    int blk = wave;
+    if (blk < nblk) {
+        load_k(blk);
+        load_v(blk);
+    }
+    for (; blk < nblk; blk += 8) {
+#pragma unroll
+        for (int u = 0; u < NKI; ++u) {
+            const int key = blk * 64 + u * KPW + lane / LPK;
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s += qv[2 * e] * bf2f_lo(kv[u][e]) + qv[2 * e + 1] * bf2f_hi(kv[u][e]);
+#pragma unroll
+            for (int mk = 1; mk < LPK; mk <<= 1) s += shfl_xor(s, mk);
+            if ((lane % LPK) == 0) sc[wave][u * KPW + lane / LPK] = key < ctx ? s * p.scale : -INFINITY;
+        }
+        const int nxt = blk + 8;
+        if (nxt < nblk) load_k(nxt);
+        wave_lds_fence();
+        const float s_l = sc[wave][lane];
+        const float m_new = fmaxf(m_run, wave_max(s_l));  // finite: every block holds at least one live key
+        const float corr = __expf(m_run - m_new);
+        const float p_l = __expf(s_l - m_new);
+        l_run = l_run * corr + wave_sum(p_l);
+        m_run = m_new;
+        wave_lds_fence();
+        sc[wave][lane] = p_l;
+        wave_lds_fence();
+        const f32x4 p0 = ld16f(&sc[wave][kc * 8]), p1 = ld16f(&sc[wave][kc * 8 + 4]);
+#pragma unroll
+        for (int i = 0; i < NR; ++i)
+            acc[i] = acc[i] * corr + (p0[0] * bf2f_lo(vv[i][0]) + p0[1] * bf2f_hi(vv[i][0]) + p0[2] * bf2f_lo(vv[i][1]) +
+                                      p0[3] * bf2f_hi(vv[i][1]) + p1[0] * bf2f_lo(vv[i][2]) + p1[1] * bf2f_hi(vv[i][2]) +
+                                      p1[2] * bf2f_lo(vv[i][3]) + p1[3] * bf2f_hi(vv[i][3]));
+        wave_lds_fence();  // the probabilities are consumed before the next block's scores overwrite them
+        if (nxt < nblk) load_v(nxt);
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        float a = acc[i];
+        a += shfl_xor(a, 1);
+        a += shfl_xor(a, 2);
+        a += shfl_xor(a, 4);
+        if (kc == 0) part[wave][i * 8 + dr] = a;
+    }
+    if (lane == 0) { ml[wave][0] = m_run; ml[wave][1] = l_run; }
+    __syncthreads();
+    if (tid < HD) {
+        float M = ml[0][0];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) M = fmaxf(M, ml[w][0]);
+        float L = 0.f, a = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const float f = __expf(ml[w][0] - M);  // 0 for waves that saw no block
+            L += ml[w][1] * f;
+            a += part[w][tid] * f;
+        }
+        p.out[(size_t)b * D + h * HD + tid] = f2bf(a / L);
+    }
+}
+
 void launch_attention_decode_fused(const AttnDecodeFusedArgs& a, hipStream_t s) {
     const dim3 grid(a.H, a.B), block(512);
-    if (a.hd == 128) VC_LAUNCH((attention_decode_fused_kernel<128>), grid, block, 0, s, a);
-    else VC_LAUNCH((attention_decode_fused_kernel<64>), grid, block, 0, s, a);
+    // default: the two-pass form (scores of the whole context in LDS, so the cache capacity must be <= DEC_MAX_CTX): two
+    // long fully independent load phases stream better (33.0 us = 5.1 TB/s at B=8, ctx 1281) than the single-pass
+    // online-softmax form (38.9 us: 2-3 serial score -> rescale -> PV chains per wave), which is used for longer
+    // contexts and kept selectable with VC_DATTN_VARIANT=1
+    static const int variant = getenv("VC_DATTN_VARIANT") ? atoi(getenv("VC_DATTN_VARIANT")) : 0;
+    if (variant == 0 && a.kv_stride <= DEC_MAX_CTX) {
+        if (a.hd == 128) VC_LAUNCH((attention_decode_fused_kernel<128>), grid, block, 0, s, a);
+        else VC_LAUNCH((attention_decode_fused_kernel<64>), grid, block, 0, s, a);
+        return;
+    }
+    if (a.hd == 128) VC_LAUNCH((attention_decode_flash_kernel<128>), grid, block, 0, s, a);
+    else VC_LAUNCH((attention_decode_flash_kernel<64>), grid, block, 0, s, a);
 }
 
 }  // namespace vc

@@ -680,8 +680,7 @@ void ensure_llm(vc_model* m, int B, int S_total) {
     const int D = c.hidden, F = c.ffn, H = c.heads;
     const int Scap = (int)rup(S_total, 64);
     REQUIRE(B <= 16, VC_ERR_INVALID, "batch %d: at most 16 sequences per GPU replica (shard larger batches over ranks)", B);
-    REQUIRE(Scap <= c.max_positions && Scap <= 4096, VC_ERR_INVALID,
-            "sequence %d exceeds max_position_embeddings=%d / decode-attention limit 4096", Scap, c.max_positions);
+    REQUIRE(Scap <= c.max_positions, VC_ERR_INVALID, "sequence %d exceeds max_position_embeddings=%d", Scap, c.max_positions);
     if (B != m->capB || Scap > m->capS) {
         const int newS = std::max(Scap, m->capB == B ? m->capS : 0);
         const size_t per_layer = (size_t)B * H * newS * m->hd;

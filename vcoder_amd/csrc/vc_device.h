@@ -178,6 +178,14 @@ VC_DEV void wait_vmcnt_n(int n) {
 }
 #endif
 
+// LDS hand-off between lanes of ONE wave (write by some lanes, read by others, no other wave involved): the LDS queue of
+// a wave is in order, so the hardware needs nothing; the emulator's lane fibers need a rendezvous
+#ifdef VC_EMU
+VC_DEV void wave_lds_fence() { vc_emu::wave_sync(); }
+#else
+VC_DEV void wave_lds_fence() { __builtin_amdgcn_wave_barrier(); }
+#endif
+
 // ---- device-scope hand-off between workgroups (split-K finisher of the decode GEMV) ------------------------------
 // Payload moves with agent-scope relaxed atomics = write-through `sc1` stores / cache-bypassing `sc1` loads; the producer
 // drains them (vmcnt(0)) before it counts its arrival.  No agent-scope FENCE: on this multi-XCD part a release/acquire
