@@ -92,6 +92,7 @@ def test_fused_decode_kernels(be):
     kc.check_attention_decode_fused(be, 2, 2, 128, 70)
     kc.check_attention_decode_fused(be, 1, 2, 128, 128)
     kc.check_attention_decode_fused(be, 1, 1, 64, 5)
+    kc.check_attention_decode_fused(be, 1, 1, 128, 4100)   # cache capacity > 4096 keys: the single-pass kernel
     kc.check_greedy_embed(be, 3, 320, 256)
 
 
