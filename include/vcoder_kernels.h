@@ -18,6 +18,10 @@ extern "C" {
  * vcoder_llava/model/multimodal_projector/builder.py:42-46 */
 void vck_gemm(const uint16_t* A, const uint16_t* W, const float* bias, void* out, int M, int N, int K, int lda, int ldw,
               int ldo, int epi, void* stream);
+/* same with an fp32 workspace (>= 64 MiB covers every shape): enables the deterministic split-K of a short last round of
+ * 256x256 tiles (partials summed in k order by a fix-up launch) */
+void vck_gemm_ws(const uint16_t* A, const uint16_t* W, const float* bias, void* out, int M, int N, int K, int lda, int ldw,
+                 int ldo, int epi, float* ws, size_t ws_bytes, void* stream);
 /* decode-time skinny GEMM (M<=16) over MFMA-fragment-packed weights.  epi: 0 bf16, 1 fp32, 2 fp32 residual, 3 SwiGLU */
 void vck_gemv(const uint16_t* X, const uint16_t* Wp, void* out, int M, int N, int K, int ldo, int epi, void* stream);
 /* general form.  RMSNorm ([HF] llama :53-70) is folded across producer and consumer instead of run as a pass:

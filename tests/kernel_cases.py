@@ -127,7 +127,8 @@ def rel_err(got, ref):
 
 
 # ------------------------------------------------------------------------------------------------
-def check_gemm(be, M, N, K, epi, bias=True, seed=0):
+def check_gemm(be, M, N, K, epi, bias=True, seed=0, ws_mb=0):
+    """ws_mb > 0: through vck_gemm_ws with an fp32 workspace of that many MiB (enables the split-K remainder round)."""
     rng = np.random.RandomState(seed)
     A = bf16_round(rng.randn(M, K))
     W = bf16_round(rng.randn(N, K) * 0.05)
@@ -144,13 +145,20 @@ def check_gemm(be, M, N, K, epi, bias=True, seed=0):
         out = be.zeros((M, N), "f32")
     elif epi == 4:
         r0 = rng.randn(M, N).astype(np.float32)
-        out = be.f32(r0)
+        out = be.f32(r0.copy())
         t = t + torch.from_numpy(r0)
     else:
         out = be.zeros((M, N // 2), "bf16")
         t = torch.nn.functional.silu(t[:, 0::2]) * t[:, 1::2]
     ldo = N // 2 if epi == 5 else N
-    _call(be, "vck_gemm", be.bf16(A), be.bf16(W), be.f32(b) if bias else None, out, M, N, K, K, K, ldo, epi)
+    if ws_mb:
+        Ad, Wd, bd = be.bf16(A), be.bf16(W), (be.f32(b) if bias else None)
+        ws = be.zeros((ws_mb << 18,), "f32")
+        be.lib.vck_gemm_ws(be.ptr(Ad), be.ptr(Wd), be.ptr(bd), be.ptr(out), M, N, K, K, K, ldo, epi, be.ptr(ws),
+                           ctypes.c_size_t(ws_mb << 20), None)
+        be.sync()
+    else:
+        _call(be, "vck_gemm", be.bf16(A), be.bf16(W), be.f32(b) if bias else None, out, M, N, K, K, K, ldo, epi)
     got = be.host_f32(out)
     ref = t.numpy()
     tol = 2 ** -8 if epi in (0, 1, 2, 5) else 1e-5  # bf16 output rounding vs fp32 accumulate

@@ -42,6 +42,15 @@ def test_gemv_splitk(be, M, N, K, ks):
     kc.check_gemv_splitk(be, M, N, K, ks)
 
 
+@pytest.mark.parametrize("M,N,K,epi,bias", [(9728, 4096, 4096, 4, False), (9728, 12288, 4096, 0, False),
+                                            (13848, 4096, 1024, 1, True), (9728, 4096, 11008, 4, False),
+                                            (13824, 4096, 4096, 2, True)])
+def test_gemm_splitk_remainder_round(be, M, N, K, epi, bias):
+    """The shapes whose last round of 256x256 tiles is short (608 = 2x256+96, 1824 = 7x256+32, 880, 864 tiles): K-slices of
+    the remainder tiles + fix-up launch against the oracle."""
+    kc.check_gemm(be, M, N, K, epi, bias, ws_mb=64)
+
+
 def test_small_ops(be):
     kc.check_interleave(be, 11008, 256)
     kc.check_layernorm(be, 4616, 1024)

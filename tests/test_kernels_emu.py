@@ -18,6 +18,12 @@ def test_gemm(be, M, N, K, epi, bias):
     kc.check_gemm(be, M, N, K, epi, bias)
 
 
+def test_gemm_splitk_remainder_round(be):
+    """260 tiles of 256x256 = one full round + 4 remainder tiles, cut into 2 K-slices each and finished by the fix-up
+    launch (bias + quick-GELU epilogue; ragged M)."""
+    kc.check_gemm(be, 1000 + 24, 16640 - 8, 128, 1, True, seed=2, ws_mb=4)
+
+
 @pytest.mark.parametrize("M,N,K,epi", [(8, 64, 256, 0), (3, 32, 1024, 1), (16, 48, 288, 2), (8, 64, 256, 3),
                                        (1, 16, 32, 1)])
 def test_gemv(be, M, N, K, epi):

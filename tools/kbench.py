@@ -43,6 +43,10 @@ def bench_gemm():
         ldo = N // 2 if epi == 5 else N
         us = timeit(lambda: lib.vck_gemm(P(A), P(W), None, P(out), M, N, K, K, K, ldo, epi, None), iters=10)
         print(f"gemm {name:12s} M{M} N{N} K{K} epi{epi}: {us:9.1f} us  {2 * M * N * K / us / 1e6:7.1f} TFLOP/s", flush=True)
+        ws = torch.zeros(16 << 20, device=dev)   # 64 MiB fp32 workspace: split-K of a short last round of tiles
+        us = timeit(lambda: lib.vck_gemm_ws(P(A), P(W), None, P(out), M, N, K, K, K, ldo, epi, P(ws), C.c_size_t(64 << 20), None),
+                    iters=10)
+        print(f"gemm+ws {name:9s}                         : {us:9.1f} us  {2 * M * N * K / us / 1e6:7.1f} TFLOP/s", flush=True)
 
 
 def bench_gemv():

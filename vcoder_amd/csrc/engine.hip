@@ -142,6 +142,7 @@ struct vc_model {
     // decode state
     Buf x_dec, xn_dec, qkv_dec, q_dec, attn_dec, h_dec, logits, next_tok, finished, out_ids, scalars, dsum, ssq;
     Buf sk_scratch, sk_counters;  // split-K partials / arrival counters of the decode GEMV (few-tile matrices)
+    Buf gemm_ws;                  // fp32 workspace of the GEMM's split-K remainder round (64 MiB)
     int out_cap = 0;
     int* step_dev() { return scalars.as<int>(); }
     int* pos_dev() { return scalars.as<int>() + 1; }
@@ -326,6 +327,11 @@ int place_tensor(vc_model* m, const std::string& raw_key, const void* src, int d
 void gemm(vc_model* m, const bf16_t* A, const bf16_t* W, const float* bias, void* out, int M, int N, int K, int ldo,
           int epi) {
     GemmArgs a{A, W, bias, out, M, N, K, K, K, ldo};
+    if ((long)((M + 255) / 256) * ((N + 255) / 256) > 256) {  // only problems with more than one round of tiles can use it
+        m->gemm_ws.ensure((size_t)64 << 20);
+        a.ws = m->gemm_ws.as<float>();
+        a.ws_bytes = m->gemm_ws.cap;
+    }
     launch_gemm(a, epi, m->st);
 }
 // decode-time linear over `X` (bf16 [M, K]).  use_rstd: X is the xg operand (bf16(x * g)) and the output is scaled by the
@@ -1068,7 +1074,7 @@ VC_API void vc_model_destroy(vc_model* m) {
                    &m->v_k, &m->v_vt, &m->v_attn, &m->v_h, &m->v_sel, &m->v_mid, &m->feats, &m->x, &m->xn, &m->qkv, &m->q,
                    &m->attn, &m->h, &m->kc, &m->vtc, &m->row_src, &m->last_idx, &m->xl, &m->logits_all, &m->x_dec,
                    &m->xn_dec, &m->qkv_dec, &m->q_dec, &m->attn_dec, &m->h_dec, &m->logits, &m->next_tok, &m->finished,
-                   &m->out_ids, &m->scalars, &m->dsum, &m->ssq, &m->sk_scratch, &m->sk_counters, &m->s_cols, &m->s_patches, &m->s_vx, &m->s_vxn, &m->s_vqkv,
+                   &m->out_ids, &m->scalars, &m->dsum, &m->ssq, &m->sk_scratch, &m->sk_counters, &m->gemm_ws, &m->s_cols, &m->s_patches, &m->s_vx, &m->s_vxn, &m->s_vqkv,
                    &m->s_vq, &m->s_vk, &m->s_vv, &m->s_vattn, &m->s_vh, &m->s_sel, &m->s_mid, &m->s_feats, &m->s_xn, &m->s_qkv,
                    &m->s_q, &m->s_attn, &m->s_h, &m->s_kc, &m->s_vc, &m->s_xl, &m->pp_src, &m->pp_sq, &m->pp_tmp, &m->pp_out,
                    &m->pp_tab, &m->pp_f32})

@@ -17,6 +17,8 @@
 #include <stdlib.h>
 
 #include "vc_device.h"
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace vc {
@@ -30,9 +32,11 @@ VC_DEV int swz(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
 // map linear workgroup id -> (tile_m, tile_n): XCD-contiguous remap (block b runs on XCD b%8; give each
 // XCD a contiguous range of tiles so neighbours share operand panels in that XCD's L2), then groups of
 // 8 m-tiles sweep n so a group re-uses its activation panel while streaming weights.
-VC_DEV void tile_coords(int bid, int nblk, int tiles_m, int tiles_n, int& tm, int& tn) {
+VC_DEV int xcd_remap(int bid, int nblk) {
     const int q = nblk / 8, r = nblk % 8, x = bid % 8, i = bid / 8;
-    const int pid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+VC_DEV void tile_from_pid(int pid, int tiles_m, int tiles_n, int& tm, int& tn) {
     const int GROUP = 8;
     const int per_group = GROUP * tiles_n;
     const int g = pid / per_group;
@@ -40,6 +44,9 @@ VC_DEV void tile_coords(int bid, int nblk, int tiles_m, int tiles_n, int& tm, in
     const int gsz = min(tiles_m - first_m, GROUP);
     tm = first_m + (pid % per_group) % gsz;
     tn = (pid % per_group) / gsz;
+}
+VC_DEV void tile_coords(int bid, int nblk, int tiles_m, int tiles_n, int& tm, int& tn) {
+    tile_from_pid(xcd_remap(bid, nblk), tiles_m, tiles_n, tm, tn);
 }
 
 template <int EPI>
@@ -308,9 +315,21 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = wave >> 2, q = wave & 3;
     const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
+    // split-K remainder round: workgroups [sk_full, ...) are sk_ks K-slices of each of the last tiles
+    int pid, ks = 0, KS = 1;
+    if (p.sk_ks > 1 && (int)blockIdx.x >= p.sk_full) {
+        const int r = (int)blockIdx.x - p.sk_full;
+        pid = p.sk_full + r / p.sk_ks;
+        ks = r % p.sk_ks;
+        KS = p.sk_ks;
+    } else {
+        pid = xcd_remap(blockIdx.x, p.sk_ks > 1 ? p.sk_full : tiles_m * tiles_n);
+    }
     int tm, tn;
-    tile_coords(blockIdx.x, tiles_m * tiles_n, tiles_m, tiles_n, tm, tn);
+    tile_from_pid(pid, tiles_m, tiles_n, tm, tn);
     const int m0 = tm * 256, n0 = tn * 256;
+    const int nk_all = p.K / BK;
+    const int kt_first = (int)((long)ks * nk_all / KS);
     // DMA sources: every wave moves pieces {wave, 8 + wave} (8 swizzled rows = 1 KiB each) of every half-tile
     const char* x_src[2][2];
     const char* y_src[2][2];
@@ -320,10 +339,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
         for (int i = 0; i < 2; ++i) {
             const int row = (i * 8 + wave) * 8 + (lane >> 3);
             const int sw = ((lane & 7) ^ (row & 7)) << 4;
-            x_src[h][i] = reinterpret_cast<const char*>(p.W + (size_t)min(n0 + h * 128 + row, p.N - 1) * p.ldw) + sw;
-            y_src[h][i] = reinterpret_cast<const char*>(p.A + (size_t)min(m0 + h * 128 + row, p.M - 1) * p.lda) + sw;
+            x_src[h][i] = reinterpret_cast<const char*>(p.W + (size_t)min(n0 + h * 128 + row, p.N - 1) * p.ldw) + sw +
+                          (size_t)kt_first * (BK * 2);
+            y_src[h][i] = reinterpret_cast<const char*>(p.A + (size_t)min(m0 + h * 128 + row, p.M - 1) * p.lda) + sw +
+                          (size_t)kt_first * (BK * 2);
         }
-    const int nk = p.K / BK;
+    const int nk = (int)((long)(ks + 1) * nk_all / KS) - kt_first;  // k-tiles of this workgroup
     auto stage_x = [&](int h, int kt) {
         if (kt >= nk) return;
         char* dst = smem + (kt & 1) * TILE + (h ? SX1 : SX0) + wave * 1024;
@@ -413,6 +434,20 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     }
     if (g == 0) wg_barrier_raw();
 
+    if (KS > 1) {  // partial tile -> workspace [remainder tile][slice][256 m][256 n]; the fix-up launch finishes it
+        float* base = p.ws + ((size_t)(pid - p.sk_full) * KS + ks) * 65536;
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int hy = 0; hy < 2; ++hy)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        st16f(base + (hy * 128 + q * 32 + j * 16 + (lane & 15)) * 256 + hx * 128 + g * 64 + i * 16 + (lane >> 4) * 4,
+                              acc[hx][i][hy][j]);
+        return;
+    }
     // ---- epilogue: lane holds out[m][n..n+3]
 #pragma unroll
     for (int hx = 0; hx < 2; ++hx)
@@ -431,6 +466,24 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
                     store_out<EPI>(p, m, n, acc[hx][i][hy][j] + bv);
                 }
         }
+}
+
+// sums the K-slices of the split remainder tiles in k order and applies the epilogue (one thread = out[m][n..n+3])
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_splitk_fixup_kernel(GemmArgs p) {
+    const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
+    const int r = blockIdx.x >> 6;
+    const int idx = ((int)(blockIdx.x & 63) << 8) + threadIdx.x;
+    const int ml = idx >> 6, nl = (idx & 63) << 2;
+    int tm, tn;
+    tile_from_pid(p.sk_full + r, tiles_m, tiles_n, tm, tn);
+    const int m = tm * 256 + ml, n = tn * 256 + nl;
+    if (m >= p.M || n >= p.N) return;
+    const float* base = p.ws + (size_t)r * p.sk_ks * 65536 + ml * 256 + nl;
+    f32x4 v = ld16f(base);
+    for (int k = 1; k < p.sk_ks; ++k) v = v + ld16f(base + (size_t)k * 65536);
+    if (p.bias) v = v + ld16f(p.bias + n);
+    store_out<EPI>(p, m, n, v);
 }
 
 template <class K>
@@ -458,6 +511,23 @@ void launch_gemm(const GemmArgs& a, int epilogue, hipStream_t s) {
             const bool wide = variant == 4;  // 4 waves x (128 x 128): fewer LDS fragment reads per MFMA, 1 wave per SIMD
             const bool phased = variant == 5 || variant == 1;  // counted-vmcnt 8-phase schedule
             const dim3 g2((unsigned)t256), b2(wide ? 256 : 512);
+            // split-K for a short last round of the 8-phase kernel (VC_GEMM_SPLITK=0 disables): rem tiles left over
+            // after the full rounds of 256 are cut into ks = 256 / rem K-slices each, so the round is ~1/ks as long
+            static const int sk_on = getenv("VC_GEMM_SPLITK") ? atoi(getenv("VC_GEMM_SPLITK")) : 1;
+            GemmArgs ask = a;
+            ask.sk_full = (int)t256;
+            ask.sk_ks = 1;
+            long rem = t256 % 256;
+            if (phased && sk_on && a.ws && t256 > 256 && rem > 0 && rem <= 128) {
+                int ks = (int)std::min<long>(256 / rem, 8);
+                ks = std::min(ks, a.K / BK);
+                while (ks > 1 && (size_t)rem * ks * 65536 * 4 > a.ws_bytes) --ks;
+                if (ks > 1) {
+                    ask.sk_full = (int)(t256 - rem);
+                    ask.sk_ks = ks;
+                }
+            }
+            const dim3 gsk((unsigned)(ask.sk_ks > 1 ? ask.sk_full + rem * ask.sk_ks : t256));
 #define VC_G256(E)                                                                                         \
     do {                                                                                                   \
         static bool once = false;                                                                          \
@@ -467,7 +537,11 @@ void launch_gemm(const GemmArgs& a, int epilogue, hipStream_t s) {
             allow_big_lds_gemm(gemm_bf16_8phase_kernel<E>, sh2);                                           \
             once = true;                                                                                   \
         }                                                                                                  \
-        if (phased) VC_LAUNCH((gemm_bf16_8phase_kernel<E>), g2, b2, sh2, s, a);                            \
+        if (phased) {                                                                                      \
+            VC_LAUNCH((gemm_bf16_8phase_kernel<E>), gsk, b2, sh2, s, ask);                                 \
+            if (ask.sk_ks > 1)                                                                             \
+                VC_LAUNCH((gemm_splitk_fixup_kernel<E>), dim3((unsigned)(rem * 64)), dim3(256), 0, s, ask); \
+        }                                                                                                  \
         else if (wide) VC_LAUNCH((gemm_bf16_dma_kernel<E, 2, 2, 8, 8>), g2, b2, sh2, s, a);                \
         else VC_LAUNCH((gemm_bf16_dma_kernel<E, 2, 4, 8, 4>), g2, b2, sh2, s, a);                          \
     } while (0)

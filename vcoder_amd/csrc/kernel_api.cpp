@@ -12,6 +12,13 @@ VCK_EXPORT void vck_gemm(const uint16_t* A, const uint16_t* W, const float* bias
     GemmArgs a{A, W, bias, out, M, N, K, lda, ldw, ldo};
     launch_gemm(a, epi, S(stream));
 }
+VCK_EXPORT void vck_gemm_ws(const uint16_t* A, const uint16_t* W, const float* bias, void* out, int M, int N, int K,
+                            int lda, int ldw, int ldo, int epi, float* ws, size_t ws_bytes, void* stream) {
+    GemmArgs a{A, W, bias, out, M, N, K, lda, ldw, ldo};
+    a.ws = ws;
+    a.ws_bytes = ws_bytes;
+    launch_gemm(a, epi, S(stream));
+}
 VCK_EXPORT void vck_gemv(const uint16_t* X, const uint16_t* Wp, void* out, int M, int N, int K, int ldo, int epi,
                          void* stream) {
     GemvArgs a{};

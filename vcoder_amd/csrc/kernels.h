@@ -30,6 +30,12 @@ struct GemmArgs {
     void* out;         // see GemmEpilogue
     int M, N, K;       // K % 64 == 0, N % 8 == 0
     int lda, ldw, ldo; // leading dims in elements
+    // optional fp32 workspace: lets the launcher split K for the tiles of a short last round (256x256 tiles on 256 CUs:
+    // 608 tiles = 2.4 rounds) — `sk_ks` workgroups per remainder tile write partial tiles here and a fix-up launch adds
+    // them in k order and applies the epilogue (deterministic).  sk_full / sk_ks are filled in by launch_gemm.
+    float* ws;
+    size_t ws_bytes;
+    int sk_full, sk_ks;
 };
 void launch_gemm(const GemmArgs& a, int epilogue, hipStream_t s);
 
