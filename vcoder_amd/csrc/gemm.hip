@@ -36,8 +36,7 @@ VC_DEV int xcd_remap(int bid, int nblk) {
     const int q = nblk / 8, r = nblk % 8, x = bid % 8, i = bid / 8;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
-VC_DEV void tile_from_pid(int pid, int tiles_m, int tiles_n, int& tm, int& tn) {
-    const int GROUP = 8;
+VC_DEV void tile_from_pid(int pid, int tiles_m, int tiles_n, int& tm, int& tn, int GROUP = 8) {
     const int per_group = GROUP * tiles_n;
     const int g = pid / per_group;
     const int first_m = g * GROUP;
@@ -323,10 +322,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
         ks = r % p.sk_ks;
         KS = p.sk_ks;
     } else {
-        pid = xcd_remap(blockIdx.x, p.sk_ks > 1 ? p.sk_full : tiles_m * tiles_n);
+        pid = p.xcd_remap_on ? xcd_remap(blockIdx.x, p.sk_ks > 1 ? p.sk_full : tiles_m * tiles_n) : (int)blockIdx.x;
     }
     int tm, tn;
-    tile_from_pid(pid, tiles_m, tiles_n, tm, tn);
+    tile_from_pid(pid, tiles_m, tiles_n, tm, tn, p.tile_group);
     const int m0 = tm * 256, n0 = tn * 256;
     const int nk_all = p.K / BK;
     const int kt_first = (int)((long)ks * nk_all / KS);
@@ -476,7 +475,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_fixup_kernel(GemmArgs p) {
     const int idx = ((int)(blockIdx.x & 63) << 8) + threadIdx.x;
     const int ml = idx >> 6, nl = (idx & 63) << 2;
     int tm, tn;
-    tile_from_pid(p.sk_full + r, tiles_m, tiles_n, tm, tn);
+    tile_from_pid(p.sk_full + r, tiles_m, tiles_n, tm, tn, p.tile_group);
     const int m = tm * 256 + ml, n = tn * 256 + nl;
     if (m >= p.M || n >= p.N) return;
     const float* base = p.ws + (size_t)r * p.sk_ks * 65536 + ml * 256 + nl;
@@ -514,7 +513,11 @@ void launch_gemm(const GemmArgs& a, int epilogue, hipStream_t s) {
             // split-K for a short last round of the 8-phase kernel (VC_GEMM_SPLITK=0 disables): rem tiles left over
             // after the full rounds of 256 are cut into ks = 256 / rem K-slices each, so the round is ~1/ks as long
             static const int sk_on = getenv("VC_GEMM_SPLITK") ? atoi(getenv("VC_GEMM_SPLITK")) : 1;
+            static const int tile_group = getenv("VC_GEMM_GROUP") ? atoi(getenv("VC_GEMM_GROUP")) : 4;  // m-tiles per sweep group (measured: 4 and 2 beat 8 / 16 / 38 by 2-6 %)
+            static const int xcd_on = getenv("VC_GEMM_XCD") ? atoi(getenv("VC_GEMM_XCD")) : 1;
             GemmArgs ask = a;
+            ask.tile_group = tile_group;
+            ask.xcd_remap_on = xcd_on;
             ask.sk_full = (int)t256;
             ask.sk_ks = 1;
             long rem = t256 % 256;

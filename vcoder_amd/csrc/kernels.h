@@ -36,6 +36,7 @@ struct GemmArgs {
     float* ws;
     size_t ws_bytes;
     int sk_full, sk_ks;
+    int tile_group, xcd_remap_on;  // tile-order tuning knobs (launch_gemm fills them: VC_GEMM_GROUP / VC_GEMM_XCD)
 };
 void launch_gemm(const GemmArgs& a, int epilogue, hipStream_t s);
 
