@@ -140,7 +140,7 @@ struct vc_model {
     int capB = 0, capS = 0;  // KV capacity
     int curB = 0, curS = 0, cur_pos = -1;
     // decode state
-    Buf x_dec, xn_dec, qkv_dec, q_dec, attn_dec, h_dec, logits, next_tok, finished, out_ids, scalars, dsum, ssq;
+    Buf x_dec, xg_dec, qkv_dec, attn_dec, h_dec, logits, next_tok, finished, out_ids, scalars, dsum, ssq;
     Buf sk_scratch, sk_counters;  // split-K partials / arrival counters of the decode GEMV (few-tile matrices)
     Buf gemm_ws;                  // fp32 workspace of the GEMM's split-K remainder round (64 MiB)
     int out_cap = 0;
@@ -355,7 +355,7 @@ void gemv(vc_model* m, const bf16_t* X, const bf16_t* Wp, const float* wscale, v
         if (next_norm_w) {
             a.ssq_out = m->ssq.as<float>() + (size_t)m0 * np;
             a.xg_w = next_norm_w;
-            a.xg_out = m->xn_dec.as<bf16_t>() + (size_t)m0 * N;
+            a.xg_out = m->xg_dec.as<bf16_t>() + (size_t)m0 * N;
         }
         a.npart = np;
         a.eps = m->c.rms_eps;
@@ -372,7 +372,7 @@ template <class F>
 void decode_linears(vc_model* m, int B, F&& between) {
     const vc_model_cfg& c = m->c;
     const int D = c.hidden, Fd = c.ffn;
-    const bf16_t* xg = m->xn_dec.as<bf16_t>();
+    const bf16_t* xg = m->xg_dec.as<bf16_t>();
     for (int l = 0; l < c.layers; ++l) {
         const LlmLayer& L = m->llm[l];
         const float* next_in = l + 1 < c.layers ? m->llm[l + 1].in_norm : m->final_norm;
@@ -710,9 +710,8 @@ void ensure_llm(vc_model* m, int B, int S_total) {
     m->last_idx.ensure(Bp * 4);
     m->xl.ensure((size_t)Bp * D * 2, true);
     m->x_dec.ensure((size_t)Bp * D * 4, true);
-    m->xn_dec.ensure((size_t)Bp * D * 2, true);
+    m->xg_dec.ensure((size_t)Bp * D * 2, true);
     m->qkv_dec.ensure((size_t)Bp * 3 * D * 2, true);
-    m->q_dec.ensure((size_t)Bp * D * 2, true);
     m->attn_dec.ensure((size_t)Bp * D * 2, true);
     m->h_dec.ensure((size_t)Bp * F * 2, true);
     m->logits.ensure((size_t)Bp * c.vocab * 4, true);
@@ -759,7 +758,7 @@ GreedyEmbedArgs greedy_embed_args(vc_model* m, int B, int max_new, int eos_id, i
     a.x = m->x_dec.as<float>();
     a.ssq = m->ssq.as<float>();
     a.xg_w = m->llm[0].in_norm;
-    a.xg = m->xn_dec.as<bf16_t>();
+    a.xg = m->xg_dec.as<bf16_t>();
     a.D = m->c.hidden;
     a.npart = m->npart;
     a.pos_dev = m->pos_dev();
@@ -1073,7 +1072,7 @@ VC_API void vc_model_destroy(vc_model* m) {
     for (Buf* b : {&m->stage, &m->stage2, &m->v_pixels, &m->v_cols, &m->v_patches, &m->v_x, &m->v_xn, &m->v_qkv, &m->v_q,
                    &m->v_k, &m->v_vt, &m->v_attn, &m->v_h, &m->v_sel, &m->v_mid, &m->feats, &m->x, &m->xn, &m->qkv, &m->q,
                    &m->attn, &m->h, &m->kc, &m->vtc, &m->row_src, &m->last_idx, &m->xl, &m->logits_all, &m->x_dec,
-                   &m->xn_dec, &m->qkv_dec, &m->q_dec, &m->attn_dec, &m->h_dec, &m->logits, &m->next_tok, &m->finished,
+                   &m->xg_dec, &m->qkv_dec, &m->attn_dec, &m->h_dec, &m->logits, &m->next_tok, &m->finished,
                    &m->out_ids, &m->scalars, &m->dsum, &m->ssq, &m->sk_scratch, &m->sk_counters, &m->gemm_ws, &m->s_cols, &m->s_patches, &m->s_vx, &m->s_vxn, &m->s_vqkv,
                    &m->s_vq, &m->s_vk, &m->s_vv, &m->s_vattn, &m->s_vh, &m->s_sel, &m->s_mid, &m->s_feats, &m->s_xn, &m->s_qkv,
                    &m->s_q, &m->s_attn, &m->s_h, &m->s_kc, &m->s_vc, &m->s_xl, &m->pp_src, &m->pp_sq, &m->pp_tmp, &m->pp_out,
@@ -1281,7 +1280,7 @@ VC_API int vc_decode_step(vc_model* m, const int32_t* tok, float* logits, int32_
             REQUIRE(tok[b] >= 0 && tok[b] < m->c.vocab, VC_ERR_INDEX, "index out of range in self (token id %d)", tok[b]);
         HIPCHK(hipMemcpyAsync(m->next_tok.p, tok, B * 4, hipMemcpyHostToDevice, m->st));
         launch_embed_tokens_ssq(m->next_tok.as<int>(), m->embed, m->x_dec.as<float>(), m->ssq.as<float>(), m->llm[0].in_norm,
-                                m->xn_dec.as<bf16_t>(), B, m->c.hidden, m->npart, m->st);
+                                m->xg_dec.as<bf16_t>(), B, m->c.hidden, m->npart, m->st);
     }
     ensure_out_ids(m, B, 1);
     if (m->precision) {

@@ -178,7 +178,8 @@ struct GreedyArgs {
 };
 void launch_greedy(const GreedyArgs& a, hipStream_t s);
 // greedy select for ALL rows + embedding of the selected tokens into the decode residual stream (+ its sum-of-squares
-// partials for the fused RMSNorm of the next GEMV) + step/pos/ctx advance: the tail of one decode step in one launch.
+// partials and the xg = bf16(x*g) operand of the first GEMV, see GemvArgs) + step/pos/ctx advance: the tail of one decode
+// step in one launch.
 struct GreedyEmbedArgs {
     GreedyArgs g;
     const bf16_t* embed;  // [V, D]

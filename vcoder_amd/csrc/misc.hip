@@ -83,7 +83,8 @@ void launch_greedy(const GreedyArgs& a, hipStream_t s) {
 }
 
 // ---- tail of one decode step in ONE launch: greedy select of every row, embedding of the selected tokens into the
-//      next step's residual stream (+ sum-of-squares partials for the fused RMSNorm), step/pos/ctx advance ---------
+//      next step's residual stream (+ sum-of-squares partials and the xg operand of the folded RMSNorm), step/pos/ctx
+//      advance ----------------------------------------------------------------------------------------------------
 VC_DEV void embed_row_ssq(const bf16_t* sp, float* dp, float* ssq_row, const float* gw, bf16_t* xg, int D, int npart,
                           int lane) {
     float ss = 0.f;
