@@ -396,7 +396,8 @@ static void launch_gemv_f(const GemvArgs& a, int epilogue, hipStream_t s) {
         // 128-KiB workgroup per CU ran a 64-workgroup second round at a third of the rate):
         //   <= 256 tiles: 8 waves, deep ring (1 workgroup/CU);  <= 512: 4 waves, 5-slot ring (2 workgroups/CU);
         //   <= 768: 4 waves x 1 tile (3/CU);  wider: 4 waves x 2 tiles (pairs share the activation fragments:
-        //   gate/up 30.0 vs 33.1 us, lm_head 40.6 vs 45.5).  bf16 slots hold a k-tile pair, W8A16 slots one super-tile.
+        //   gate/up 30.0 vs 33.1 us, lm_head 40.6 vs 45.5; 4 tiles per workgroup measured slower: W8A16 gate/up 23.2 vs
+        //   19.7 us).  bf16 slots hold a k-tile pair, W8A16 slots one super-tile.
         // 257..512 tiles (13b o_proj / down: 320) neither fill the chip one-per-CU nor balance two-per-CU: with the
         // split-K buffers, pairs of tiles x 3 K-slices = 480 workgroups, all resident (2/CU), activation fragments
         // shared by the pair (measured M=16: down 43.0 -> 30.2 us, o_proj 20.1 -> 14.9; for <= 256 tiles every split
