@@ -89,6 +89,49 @@ def bench_gemv():
             print(f"gemv+rstd {name:8s}          : {us:7.1f} us  {2 * N * K / us / 1e3:7.1f} GB/s", flush=True)
 
 
+def bench_gemv_pair():
+    """Two streams run the SAME GEMV (same weights, different activations / outputs) at the same time: does the second
+    reader hit the Infinity Cache / merge with the first?  pair time ~ single time => yes."""
+    M = 8
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for (N, K, epi, name) in [(12288, 4096, 0, "qkv"), (22016, 4096, 3, "gate-up"), (4096, 11008, 1, "down(f32)")]:
+        X1, X2 = bf16(M, K), bf16(M, K)
+        Ws = [bf16(N * K, scale=0.02) for _ in range(8)]
+        dt = torch.float32 if epi in (1, 2) else torch.bfloat16
+        o1 = torch.zeros((M, N), dtype=dt, device=dev)
+        o2 = torch.zeros((M, N), dtype=dt, device=dev)
+        ldo = N // 2 if epi == 3 else N
+        it = [0]
+
+        def single():
+            it[0] += 1
+            lib.vck_gemv(P(X1), P(Ws[it[0] % 8]), P(o1), M, N, K, ldo, epi, C.c_void_p(s1.cuda_stream))
+
+        def pair_same():
+            it[0] += 1
+            w = Ws[it[0] % 8]
+            lib.vck_gemv(P(X1), P(w), P(o1), M, N, K, ldo, epi, C.c_void_p(s1.cuda_stream))
+            lib.vck_gemv(P(X2), P(w), P(o2), M, N, K, ldo, epi, C.c_void_p(s2.cuda_stream))
+
+        def pair_diff():
+            it[0] += 1
+            lib.vck_gemv(P(X1), P(Ws[it[0] % 8]), P(o1), M, N, K, ldo, epi, C.c_void_p(s1.cuda_stream))
+            lib.vck_gemv(P(X2), P(Ws[(it[0] + 4) % 8]), P(o2), M, N, K, ldo, epi, C.c_void_p(s2.cuda_stream))
+
+        def wall(fn, iters=40):
+            for _ in range(4):
+                fn()
+            torch.cuda.synchronize()
+            import time
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / iters * 1e6
+        print(f"pair {name:10s}: single {wall(single):6.1f} us | two streams, same weights {wall(pair_same):6.1f} us | "
+              f"two streams, different weights {wall(pair_diff):6.1f} us", flush=True)
+
+
 def bench_gemv13():
     """VCoder-DS 13b decode shapes at M = 16 and M = 8 (config C3 runs M = 16)."""
     for M in (16, 8):
@@ -181,6 +224,8 @@ if __name__ == "__main__":
         bench_gemv_fp8()
     if "gemv13" in what:
         bench_gemv13()
+    if "gemv_pair" in what:
+        bench_gemv_pair()
     for w in what:
         {"gemm": bench_gemm, "gemv": bench_gemv, "attn": bench_attn, "dattn": bench_dattn,
-         "gemv_fp8": lambda: None, "gemv13": lambda: None}[w]()
+         "gemv_fp8": lambda: None, "gemv13": lambda: None, "gemv_pair": lambda: None}[w]()

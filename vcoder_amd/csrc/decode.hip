@@ -224,7 +224,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
         for (int kk = 0; kk < KPI; ++kk) {
             const size_t kt = (size_t)min((it0 + wave + i * WAVES) * KPI + kk, nkt - 1);  // an odd tail re-reads the last tile
 #pragma unroll
-            for (int t = 0; t < NT; ++t) glds16_nt(wsrc[t] + kt * 1024, dst + (kk * (NT + XS) + t) * 1024);
+            for (int t = 0; t < NT; ++t) {
+                if (p.w_cached) glds16(wsrc[t] + kt * 1024, dst + (kk * (NT + XS) + t) * 1024);
+                else glds16_nt(wsrc[t] + kt * 1024, dst + (kk * (NT + XS) + t) * 1024);
+            }
             glds16(xsrc + kt * (KT * 2), dst + (kk * (NT + XS) + NT) * 1024);
             if constexpr (FP8) glds16(xsrc + kt * (KT * 2) + 16, dst + (kk * (NT + XS) + NT + 1) * 1024);
         }
@@ -423,7 +426,10 @@ static void launch_gemv_f(const GemvArgs& a, int epilogue, hipStream_t s) {
     else if (tiles <= 512) launch_gemv_w<8, 1, FP8>(a, epilogue, s);
     else launch_gemv_w<4, 1, FP8>(a, epilogue, s);
 }
-void launch_gemv(const GemvArgs& a, int epilogue, hipStream_t s) {
+void launch_gemv(const GemvArgs& a0, int epilogue, hipStream_t s) {
+    static const int w_cached = getenv("VC_GEMV_WCACHED") ? atoi(getenv("VC_GEMV_WCACHED")) : 0;
+    GemvArgs a = a0;
+    a.w_cached = w_cached;
     if (a.wscale) launch_gemv_f<true>(a, epilogue, s);
     else launch_gemv_f<false>(a, epilogue, s);
 }

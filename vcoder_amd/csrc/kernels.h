@@ -74,6 +74,7 @@ struct GemvArgs {
     float* sk_scratch;       // [ksplit][N/16][256] or nullptr
     unsigned* sk_counters;   // [N/16], zero between launches
     int ksplit;              // 0/1 = off (launcher decides when the two buffers are given)
+    int w_cached;            // 1: stream the weights with the default cache policy instead of non-temporal (VC_GEMV_WCACHED)
 };
 void launch_gemv(const GemvArgs& a, int epilogue, hipStream_t s);
 void launch_pack_weight(const bf16_t* W, bf16_t* Wp, int N, int K, hipStream_t s);
