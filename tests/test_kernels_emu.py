@@ -126,6 +126,11 @@ def test_alternate_kernel_variants():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
                         "test_gemm or test_attention"], env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
+    # tile-order knobs of the GEMM, cacheable weight loads of the GEMV
+    env = dict(os.environ, VC_GEMM_VARIANT="5", VC_GEMM_GROUP="2", VC_GEMM_XCD="0", VC_GEMV_WCACHED="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "test_gemm or test_gemv"],
+                       env=env, capture_output=True, text=True)
+    assert r.returncode == 0, "tile-order / cache-policy knobs: " + r.stdout[-2000:]
     # the single-pass (online softmax) decode attention
     env = dict(os.environ, VC_DATTN_VARIANT="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "test_fused_decode"],
