@@ -118,6 +118,9 @@ def main():
                          "host threads, so one batch's MFMA-bound prefill and per-launch ramps overlap another's "
                          "HBM-bound decode.  1 = strictly one batch at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-pixels", action="store_true",
+                    help="hand the pixel tensors over as HOST buffers (fp32, pageable): the PCIe-inclusive rate noted in "
+                         "DESIGN.md; the default (and `value`) has the inputs resident in HBM")
     ap.add_argument("--pmc-traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass "
                          "(default: profiles/r01_pmc_traffic.json, the committed FETCH_SIZE pass of this kernel)")
@@ -158,7 +161,9 @@ def main():
     B, N_new = args.batch, args.new_tokens
     first, _ = shard_range(world * B, rank, world)   # contiguous shard of the global batch
     ids = np.stack([synth.synth_prompt_ids(cfg.vocab_size, "vcoder_ds", sample=first + b) for b in range(B)])
-    imgs, segs, deps = (torch.from_numpy(a).cuda() for a in synth.synth_batch(B, cfg.vit_image_size, first))
+    imgs, segs, deps = synth.synth_batch(B, cfg.vit_image_size, first)
+    if not args.host_pixels:
+        imgs, segs, deps = (torch.from_numpy(a).cuda() for a in (imgs, segs, deps))
 
     import threading
 
@@ -227,7 +232,8 @@ def main():
             "config": {"workload": f"VCoder-DS LLaVA-1.5-{args.model} {'bf16' if args.weights == 'bf16' else 'bf16 activations / fp8-e4m3 decoder weights (W8A16)'}, batch={B}/GPU RGB+seg+depth 336x336, "
                                    f"prefill S={S}, {N_new}-token greedy decode", "global_batch": world * B,
                        "parallelism": f"dp{world}", "weights": "seeded synthetic (vcoder_amd/synth.py)",
-                       "in_flight_batches_per_gpu": n_sess},
+                       "in_flight_batches_per_gpu": n_sess,
+                       "inputs": "host buffers (PCIe inclusive)" if args.host_pixels else "resident in HBM"},
             "phase_ms_one_session": timings,  # wall time of the last batch's phases; they overlap other batches when in flight > 1
             "roofline": {"bound": "hbm", "kernel": "gemv_dma_kernel (decode weight streaming, all 129 GEMV launches of a step)", "achieved": ach,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
