@@ -117,6 +117,15 @@ int vc_decode_step(vc_model* m, const int32_t* tok, float* logits, int32_t* next
 int vc_generate_greedy(vc_model* m, const int64_t* ids, int B, int T, const float* img, const float* seg,
                        const float* depth, int pixels_on_device, int max_new, int eos_id, int pad_id,
                        int32_t* out_ids, int* n_generated);
+/* the same with a device-side keyword stop: n_stop token sequences (stop_ids flattened,
+ * stop_lens[i] ids each; at most 8 sequences of at most 8 ids).  A row is finished — later tokens are pad_id — once
+ * its ids (prompt tail + generated) end with one of them; generation ends when every row is finished by EOS or a stop.
+ * Batched, hipGraph-friendly form of KeywordsStoppingCriteria's id match (vcoder_llava/mm_utils.py:128-151: batch size
+ * 1, evaluated on the host after every token). */
+int vc_generate_greedy_stop(vc_model* m, const int64_t* ids, int B, int T, const float* img, const float* seg,
+                            const float* depth, int pixels_on_device, int max_new, int eos_id, int pad_id,
+                            const int32_t* stop_ids, const int32_t* stop_lens, int n_stop, int32_t* out_ids,
+                            int* n_generated);
 
 /* ---- next row §8(f)2: image preprocessing on the device ------------------------------------------------------------
  * process_images() of vcoder_llava/mm_utils.py:28-40 for ONE image: expand2square(mean colour) when pad_to_square,

@@ -72,7 +72,10 @@ void vck_greedy(const float* logits, int* next_tok, int* out_ids, int* finished,
  * GEMV's operand xg = bf16(x * xg_w)) + step/pos/ctx advance */
 void vck_greedy_embed(const float* logits, int* next_tok, int* out_ids, int* finished, int* step_dev, int B, int V,
                       int max_new, int eos_id, int pad_id, const uint16_t* embed, float* x, float* ssq, const float* xg_w,
-                      uint16_t* xg, int D, int npart, int* pos_dev, int* ctx_dev, int advance, void* stream);
+                      uint16_t* xg, int D, int npart, int* pos_dev, int* ctx_dev, int advance, const int* stop_tab,
+                      const int* prompt_tail, void* stream);
+/* stop_tab / prompt_tail (may be NULL): device-side keyword stop — [0] = n sequences (<= 8), then per sequence 9 ints
+ * (length <= 8, ids); prompt_tail [B][7] = last prompt ids of each row.  A row whose ids end with a sequence is finished. */
 void vck_embed_tokens_ssq(const int* tok, const uint16_t* embed, float* x, float* ssq, const float* xg_w, uint16_t* xg, int B,
                           int D, int npart, void* stream);
 void vck_advance(int* step_dev, int* pos_dev, int* ctx_dev, void* stream);

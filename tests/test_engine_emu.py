@@ -39,3 +39,7 @@ def test_fp8_weight_format(emu_lib):
     """W8A16 decoder weights through the emulator: quantise-at-finalize, byte-streaming GEMV, strict + fast paths."""
     r = e2e_cases.check_fp8_weights("ds_img_only", lib=emu_lib, n_new=4)
     assert r["strict_err"] < 1e-4
+
+
+def test_device_side_stop_sequences(emu_lib):
+    e2e_cases.check_stop_sequences("ds_img_only", lib=emu_lib)

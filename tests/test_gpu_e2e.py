@@ -346,3 +346,8 @@ def test_fp8_weights_true_dims_against_oracle():
     print(f"fp8 true-dims parity: |logits|max={scale:.3f} prefill err={e1:.4f} decode(fp8 gemv) err={e2:.4f}")
     assert e1 < 2e-2 * max(1.0, scale) and e2 < 2e-2 * max(1.0, scale)
     eng.close()
+
+
+@pytest.mark.parametrize("name", ["ds_img_depth_seg", "vc_img_seg"])
+def test_device_side_stop_sequences(name):
+    e2e_cases.check_stop_sequences(name)

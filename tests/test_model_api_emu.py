@@ -151,3 +151,61 @@ def test_forked_session_shares_weights(model):
     assert np.array_equal(a[:1], b) and np.array_equal(a, c)
     f.close()
     assert np.array_equal(model.engine.generate_greedy(ids, imgs, segs, deps, max_new_tokens=3), a)
+
+
+def test_keyword_stopping_criteria_runs_on_device(model):
+    """A KeywordsStoppingCriteria whose keywords are single special tokens (the reference's `["</s>"]`) takes the
+    device-side stop inside generate() and returns exactly what the per-token host loop returns; the counterpart class
+    also handles batch > 1 and multi-token keywords on the host."""
+    from vcoder_amd.mm_utils import KeywordsStoppingCriteria
+
+    g, cfg, ids, imgs, segs, deps = _fx()
+    t = torch.from_numpy
+    T = ids.shape[1]
+    stop_tok = int(g["greedy_ids"][0, 2])
+
+    class Tok:   # the slice of a tokenizer the criterion uses
+        bos_token_id = 1
+        all_special_ids = [1, 2, stop_tok]
+
+        def __call__(self, text):
+            class R:
+                input_ids = [1, stop_tok] if text == "<stop>" else [1, 7, 8]
+            return R()
+
+        def batch_decode(self, rows, skip_special_tokens=True):
+            return ["" for _ in rows]
+
+    crit = KeywordsStoppingCriteria(["<stop>"], Tok(), t(ids[:1]))
+    assert crit.device_stop_sequences() == [[stop_tok]]
+    calls = []
+    orig = model.engine.generate_greedy
+
+    def spy(*a, **k):
+        calls.append(k.get("stop_sequences"))
+        return orig(*a, **k)
+
+    model.engine.generate_greedy = spy
+    try:
+        fast = model.generate(t(ids[:1]), images=t(imgs[:1]), segs=t(segs[:1]), depths=t(deps[:1]), do_sample=False,
+                              max_new_tokens=6, stopping_criteria=[crit], eos_token_id=-1)
+    finally:
+        model.engine.generate_greedy = orig
+    assert calls == [[[stop_tok]]], "the criterion must be handed to the engine as a device-side stop"
+
+    class HostOnly:   # same decision, but opaque to generate(): forces the per-token host loop
+        def __call__(self, output_ids, scores, **kw):
+            return crit(output_ids, scores)
+
+    slow = model.generate(t(ids[:1]), images=t(imgs[:1]), segs=t(segs[:1]), depths=t(deps[:1]), do_sample=False,
+                          max_new_tokens=6, stopping_criteria=[HostOnly()], eos_token_id=-1)
+    first = int(np.argmax(g["greedy_ids"][0] == stop_tok)) + 1   # the token may occur before step 2
+    assert torch.equal(fast, slow) and tuple(fast.shape) == (1, T + first)
+    assert np.array_equal(fast[0, T:].numpy(), g["greedy_ids"][0, :first])
+    # multi-token keyword / batch 2: host path of the counterpart class
+    crit2 = KeywordsStoppingCriteria(["multi"], Tok(), t(ids))
+    assert crit2.device_stop_sequences() is None and crit2.keyword_ids == [[7, 8]]
+    rows = torch.tensor([[5, 7, 8], [7, 8, 9]])
+    crit2.start_len = 0
+    assert crit2(rows, None) is False
+    assert crit2(torch.tensor([[5, 7, 8], [1, 7, 8]]), None) is True

@@ -58,6 +58,9 @@ def declare(lib: C.CDLL) -> C.CDLL:
     lib.vc_prefill_embeds_only.argtypes = [vp, vp, i32, i32, vp, vp, vp, i32, i32, vp, C.POINTER(C.c_int)]
     lib.vc_decode_step.argtypes = [vp, vp, vp, vp]
     lib.vc_generate_greedy.argtypes = [vp, vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, vp, C.POINTER(C.c_int)]
+    lib.vc_generate_greedy_stop.argtypes = [vp, vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, vp,
+                                            C.POINTER(C.c_int)]
+    lib.vc_generate_greedy_stop.restype = C.c_int
     lib.vc_profile_decode_gemv.argtypes = [vp, i32, i32, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.vc_last_timings.argtypes = [vp, f32p, f32p, f32p]
     lib.vc_preprocess_image.argtypes = [vp, vp, i32, i32, i32, f32p, f32p, vp, i32]

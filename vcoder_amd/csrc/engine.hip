@@ -143,6 +143,8 @@ struct vc_model {
     Buf x_dec, xg_dec, qkv_dec, attn_dec, h_dec, logits, next_tok, finished, out_ids, scalars, dsum, ssq;
     Buf sk_scratch, sk_counters;  // split-K partials / arrival counters of the decode GEMV (few-tile matrices)
     Buf gemm_ws;                  // fp32 workspace of the GEMM's split-K remainder round (64 MiB)
+    Buf stop_tab, prompt_tail;    // device-side keyword stop of generate (fixed capacity: the decode graph keeps the pointers)
+    int n_stop = 0;
     int out_cap = 0;
     int* step_dev() { return scalars.as<int>(); }
     int* pos_dev() { return scalars.as<int>() + 1; }
@@ -722,6 +724,8 @@ void ensure_llm(vc_model* m, int B, int S_total) {
     m->ssq.ensure((size_t)Bp * m->npart * 4, true);
     m->sk_scratch.ensure((size_t)4 * 512 * 256 * 4);
     m->sk_counters.ensure(512 * 4, true);
+    m->stop_tab.ensure((1 + VC_MAX_STOP * (1 + VC_MAX_STOP_LEN)) * 4, true);
+    m->prompt_tail.ensure((size_t)Bp * (VC_MAX_STOP_LEN - 1) * 4, true);
 }
 
 bf16_t* kcache(vc_model* m, int l) { return m->kc.as<bf16_t>() + (size_t)l * m->capB * m->c.heads * m->capS * m->hd; }
@@ -753,7 +757,7 @@ void run_prefill_layers(vc_model* m, int B, int S) {
 GreedyEmbedArgs greedy_embed_args(vc_model* m, int B, int max_new, int eos_id, int pad_id, int advance) {
     GreedyEmbedArgs a{};
     a.g = GreedyArgs{m->logits.as<float>(), m->next_tok.as<int>(), m->out_ids.as<int>(), m->finished.as<int>(),
-                     m->step_dev(), B, m->c.vocab, max_new, eos_id, pad_id};
+                     m->step_dev(), B, m->c.vocab, max_new, eos_id, pad_id, m->stop_tab.as<int>(), m->prompt_tail.as<int>()};
     a.embed = m->embed;
     a.x = m->x_dec.as<float>();
     a.ssq = m->ssq.as<float>();
@@ -1073,7 +1077,7 @@ VC_API void vc_model_destroy(vc_model* m) {
                    &m->v_k, &m->v_vt, &m->v_attn, &m->v_h, &m->v_sel, &m->v_mid, &m->feats, &m->x, &m->xn, &m->qkv, &m->q,
                    &m->attn, &m->h, &m->kc, &m->vtc, &m->row_src, &m->last_idx, &m->xl, &m->logits_all, &m->x_dec,
                    &m->xg_dec, &m->qkv_dec, &m->attn_dec, &m->h_dec, &m->logits, &m->next_tok, &m->finished,
-                   &m->out_ids, &m->scalars, &m->dsum, &m->ssq, &m->sk_scratch, &m->sk_counters, &m->gemm_ws, &m->s_cols, &m->s_patches, &m->s_vx, &m->s_vxn, &m->s_vqkv,
+                   &m->out_ids, &m->scalars, &m->dsum, &m->ssq, &m->sk_scratch, &m->sk_counters, &m->gemm_ws, &m->stop_tab, &m->prompt_tail, &m->s_cols, &m->s_patches, &m->s_vx, &m->s_vxn, &m->s_vqkv,
                    &m->s_vq, &m->s_vk, &m->s_vv, &m->s_vattn, &m->s_vh, &m->s_sel, &m->s_mid, &m->s_feats, &m->s_xn, &m->s_qkv,
                    &m->s_q, &m->s_attn, &m->s_h, &m->s_kc, &m->s_vc, &m->s_xl, &m->pp_src, &m->pp_sq, &m->pp_tmp, &m->pp_out,
                    &m->pp_tab, &m->pp_f32})
@@ -1296,13 +1300,48 @@ VC_API int vc_decode_step(vc_model* m, const int32_t* tok, float* logits, int32_
     GUARD_END(m->ctx)
 }
 
-VC_API int vc_generate_greedy(vc_model* m, const int64_t* ids, int B, int T, const float* img, const float* seg,
-                              const float* depth, int pixels_on_device, int max_new, int eos_id, int pad_id,
-                              int32_t* out_ids, int* n_generated) {
+/* vc_generate_greedy with a device-side keyword stop: `n_stop` token sequences (stop_ids flattened, stop_lens[i] ids
+ * each, <= 8 sequences of <= 8 ids).  A row is finished — later tokens are pad_id — as soon as its ids (the tail of
+ * its prompt followed by what it has generated) END WITH one of the sequences; generation stops when every row is
+ * finished by EOS or by a stop.  This is the batched, graph-friendly form of the reference's KeywordsStoppingCriteria
+ * id match (vcoder_llava/mm_utils.py:142-146, which asserts batch size 1 and is evaluated on the host every token). */
+VC_API int vc_generate_greedy_stop(vc_model* m, const int64_t* ids, int B, int T, const float* img, const float* seg,
+                                   const float* depth, int pixels_on_device, int max_new, int eos_id, int pad_id,
+                                   const int32_t* stop_ids, const int32_t* stop_lens, int n_stop, int32_t* out_ids,
+                                   int* n_generated) {
     if (!m) return VC_ERR_INVALID;
     GUARD_BEGIN
     USE_DEVICE(m->ctx);
     REQUIRE(max_new >= 1 && out_ids, VC_ERR_INVALID, "bad max_new/out_ids");
+    REQUIRE(n_stop >= 0 && n_stop <= VC_MAX_STOP && (n_stop == 0 || (stop_ids && stop_lens)), VC_ERR_INVALID,
+            "at most %d stop sequences", VC_MAX_STOP);
+    std::vector<int> tab(1 + VC_MAX_STOP * (1 + VC_MAX_STOP_LEN), 0);
+    tab[0] = n_stop;
+    for (int i = 0, off = 0; i < n_stop; ++i) {
+        REQUIRE(stop_lens[i] >= 1 && stop_lens[i] <= VC_MAX_STOP_LEN, VC_ERR_INVALID, "stop sequence %d: 1..%d ids", i,
+                VC_MAX_STOP_LEN);
+        tab[1 + i * (1 + VC_MAX_STOP_LEN)] = stop_lens[i];
+        for (int j = 0; j < stop_lens[i]; ++j) tab[2 + i * (1 + VC_MAX_STOP_LEN) + j] = stop_ids[off + j];
+        off += stop_lens[i];
+    }
+    constexpr int TL = VC_MAX_STOP_LEN - 1;
+    std::vector<int> tail((size_t)B * TL, INT32_MIN);  // ids never equal INT32_MIN
+    for (int b = 0; b < B; ++b)
+        for (int j = 0; j < TL && j < T; ++j) tail[(size_t)b * TL + TL - 1 - j] = (int)ids[(size_t)b * T + T - 1 - j];
+    auto row_stop_end = [&](const int32_t* row, int b, int produced) {  // first column count at which row b is stopped
+        for (int st = 0; st < produced; ++st)
+            for (int i = 0; i < n_stop; ++i) {
+                const int L = tab[1 + i * (1 + VC_MAX_STOP_LEN)];
+                bool ok = true;
+                for (int j = 0; j < L && ok; ++j) {
+                    const int back = L - 1 - j;
+                    const int v = st - back >= 0 ? row[st - back] : tail[(size_t)b * TL + TL + (st - back)];
+                    ok = v == tab[2 + i * (1 + VC_MAX_STOP_LEN) + j];
+                }
+                if (ok) return st + 1;
+            }
+        return produced;
+    };
     m->cur_pos = -1;
     int S = 0;
     // Sessions of one process take turns in the MFMA-bound encode+prefill phase: two prefills side by side only slow
@@ -1314,6 +1353,9 @@ VC_API int vc_generate_greedy(vc_model* m, const int64_t* ids, int B, int T, con
     do_prefill(m, ids, B, T, img, seg, depth, pixels_on_device, 1, max_new, nullptr, &S);  // generate() always builds a mask
     REQUIRE(S + max_new <= m->capS, VC_ERR_INVALID, "prompt %d + max_new %d exceeds the KV capacity %d", S, max_new, m->capS);
     ensure_out_ids(m, B, max_new);
+    HIPCHK(hipMemcpyAsync(m->stop_tab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, m->st));
+    HIPCHK(hipMemcpyAsync(m->prompt_tail.p, tail.data(), tail.size() * 4, hipMemcpyHostToDevice, m->st));
+    m->n_stop = n_stop;
     finish_prefill(m, nullptr);
     if (m->ev[2]) HIPCHK(hipEventRecord(m->ev[2], m->st));
     // token 0 comes from the prefill logits
@@ -1324,8 +1366,9 @@ VC_API int vc_generate_greedy(vc_model* m, const int64_t* ids, int B, int T, con
     if (use_gate) gate.unlock();
     int produced = 1;
     std::vector<int> fin(B);
+    const bool can_finish = eos_id >= 0 || n_stop > 0;
     auto all_finished = [&]() {
-        if (eos_id < 0) return false;
+        if (!can_finish) return false;
         HIPCHK(hipMemcpyAsync(fin.data(), m->finished.p, B * 4, hipMemcpyDeviceToHost, m->st));
         HIPCHK(hipStreamSynchronize(m->st));
         for (int b = 0; b < B; ++b)
@@ -1341,7 +1384,7 @@ VC_API int vc_generate_greedy(vc_model* m, const int64_t* ids, int B, int T, con
             produced = step + 1;
             // the reference checks its stopping criteria on the host every token; checking every 8 tokens only
             // trims later (rows past EOS already emit pad), it never changes the returned ids
-            if (eos_id >= 0 && (step % 8 == 7 || step == max_new - 1)) {
+            if (can_finish && (step % 8 == 7 || step == max_new - 1)) {
                 HIPCHK(hipStreamSynchronize(m->st));
                 if (all_finished()) break;
             }
@@ -1350,12 +1393,14 @@ VC_API int vc_generate_greedy(vc_model* m, const int64_t* ids, int B, int T, con
     if (m->ev[3]) HIPCHK(hipEventRecord(m->ev[3], m->st));
     HIPCHK(hipMemcpyAsync(out_ids, m->out_ids.p, (size_t)B * max_new * 4, hipMemcpyDeviceToHost, m->st));
     HIPCHK(hipStreamSynchronize(m->st));
-    if (eos_id >= 0) {  // HF stops right after the first step at which every row has produced EOS
+    if (can_finish) {  // HF stops right after the first step at which every row has produced EOS / met a stop
         int last = 0;
         for (int b = 0; b < B; ++b) {
             int e = produced;
-            for (int s = 0; s < produced; ++s)
-                if (out_ids[(size_t)b * max_new + s] == eos_id) { e = s + 1; break; }
+            if (eos_id >= 0)
+                for (int s = 0; s < produced; ++s)
+                    if (out_ids[(size_t)b * max_new + s] == eos_id) { e = s + 1; break; }
+            if (n_stop > 0) e = std::min(e, row_stop_end(out_ids + (size_t)b * max_new, b, produced));
             last = std::max(last, e);
         }
         produced = std::min(produced, last);
@@ -1369,6 +1414,13 @@ VC_API int vc_generate_greedy(vc_model* m, const int64_t* ids, int B, int T, con
     GUARD_END(m->ctx)
 }
 
+
+VC_API int vc_generate_greedy(vc_model* m, const int64_t* ids, int B, int T, const float* img, const float* seg,
+                              const float* depth, int pixels_on_device, int max_new, int eos_id, int pad_id,
+                              int32_t* out_ids, int* n_generated) {
+    return vc_generate_greedy_stop(m, ids, B, T, img, seg, depth, pixels_on_device, max_new, eos_id, pad_id, nullptr, nullptr,
+                                   0, out_ids, n_generated);
+}
 
 // ---- image preprocessing: PIL's 8-bit bicubic coefficient tables (Pillow Resample.c: precompute_coeffs +
 // normalize_coeffs_8bpc), built in double on the host ----------------------------------------------------------------

@@ -43,10 +43,10 @@ VCK_EXPORT void vck_attention_decode_fused(const uint16_t* qkv, uint16_t* k, uin
 VCK_EXPORT void vck_greedy_embed(const float* logits, int* next_tok, int* out_ids, int* finished, int* step_dev, int B,
                                  int V, int max_new, int eos_id, int pad_id, const uint16_t* embed, float* x, float* ssq,
                                  const float* xg_w, uint16_t* xg, int D, int npart, int* pos_dev, int* ctx_dev, int advance,
-                                 void* stream) {
+                                 const int* stop_tab, const int* prompt_tail, void* stream) {
     GreedyEmbedArgs a{};
     a.xg_w = xg_w; a.xg = xg;
-    a.g = GreedyArgs{logits, next_tok, out_ids, finished, step_dev, B, V, max_new, eos_id, pad_id};
+    a.g = GreedyArgs{logits, next_tok, out_ids, finished, step_dev, B, V, max_new, eos_id, pad_id, stop_tab, prompt_tail};
     a.embed = embed; a.x = x; a.ssq = ssq; a.D = D; a.npart = npart; a.pos_dev = pos_dev; a.ctx_dev = ctx_dev;
     a.advance = advance;
     launch_greedy_embed(a, S(stream));

@@ -176,7 +176,14 @@ struct GreedyArgs {
     int* finished;      // [B]
     int* step_dev;      // device scalar (read here; advanced by launch_advance)
     int B, V, max_new, eos_id, pad_id;
+    // device-side keyword stop (greedy_embed only): a row is finished as soon as the ids it has produced (continued
+    // backwards into the tail of its prompt) end with one of the stop sequences.
+    //   stop_tab: [0] = number of sequences (<= VC_MAX_STOP), then per sequence 1 + VC_MAX_STOP_LEN ints (length, ids)
+    //   prompt_tail: [B][VC_MAX_STOP_LEN - 1] last prompt ids of every row (right-aligned)
+    const int* stop_tab;     // nullptr = none
+    const int* prompt_tail;
 };
+constexpr int VC_MAX_STOP = 8, VC_MAX_STOP_LEN = 8;
 void launch_greedy(const GreedyArgs& a, hipStream_t s);
 // greedy select for ALL rows + embedding of the selected tokens into the decode residual stream (+ its sum-of-squares
 // partials and the xg = bf16(x*g) operand of the first GEMV, see GemvArgs) + step/pos/ctx advance: the tail of one decode

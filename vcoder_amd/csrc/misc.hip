@@ -145,17 +145,36 @@ __global__ __launch_bounds__(1024) void greedy_embed_kernel(GreedyEmbedArgs p) {
         float bv = sv[0][b];
         int bidx = si[0][b];
         for (int w = 1; w < 16; ++w) argmax_combine(bv, bidx, sv[w][b], si[w][b]);
-        const int was_finished = g.eos_id >= 0 ? g.finished[b] : 0;
+        const int was_finished = (g.eos_id >= 0 || (g.stop_tab != nullptr && g.stop_tab[0] > 0)) ? g.finished[b] : 0;
         int tok = bidx;
         // all lanes computed the same tok; one shuffle keeps the read of finished[] ahead of lane 0's write below
         tok = shfl(tok, 0);
-        if (g.eos_id >= 0) {
+        const bool stops = g.stop_tab != nullptr && g.stop_tab[0] > 0;
+        if (g.eos_id >= 0 || stops) {
             if (was_finished) tok = g.pad_id;
-            if (lane == 0 && tok == g.eos_id) g.finished[b] = 1;
+            if (lane == 0 && g.eos_id >= 0 && tok == g.eos_id) g.finished[b] = 1;
         }
         if (lane == 0) {
             g.next_tok[b] = tok;
             if (step < g.max_new) g.out_ids[(size_t)b * g.max_new + step] = tok;
+            if (stops && !was_finished) {  // suffix match of the row's ids (prompt tail | generated so far | tok)
+                bool hit = false;
+                for (int sq = 0; sq < g.stop_tab[0]; ++sq) {
+                    const int* e = g.stop_tab + 1 + sq * (1 + VC_MAX_STOP_LEN);
+                    const int L = e[0];
+                    bool ok = L > 0;
+                    for (int i = 0; i < L && ok; ++i) {
+                        const int back = L - 1 - i;  // 0 = the token just selected
+                        int v;
+                        if (back == 0) v = tok;
+                        else if (step - back >= 0) v = g.out_ids[(size_t)b * g.max_new + step - back];
+                        else v = g.prompt_tail[b * (VC_MAX_STOP_LEN - 1) + (VC_MAX_STOP_LEN - 1) + (step - back)];
+                        ok = v == e[1 + i];
+                    }
+                    hit = hit || ok;
+                }
+                if (hit) g.finished[b] = 1;
+            }
         }
         embed_row_ssq(p.embed + (size_t)tok * p.D, p.x + (size_t)b * p.D, p.ssq + (size_t)b * p.npart, p.xg_w,
                       p.xg + (size_t)b * p.D, p.D, p.npart, lane);

@@ -3,7 +3,7 @@ this file only marshals pointers, shapes and errors."""
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, Iterable, Optional, Tuple
+from typing import Sequence, Dict, Iterable, Optional, Tuple
 
 import numpy as np
 
@@ -262,8 +262,10 @@ class HipEngine:
     _cur_batch = 0
 
     def generate_greedy(self, input_ids, images, segs=None, depths=None, max_new_tokens: int = 128,
-                        eos_token_id: Optional[int] = None, pad_token_id: Optional[int] = None) -> np.ndarray:
-        """-> new token ids [B, n_generated] int32 (prompt not included)."""
+                        eos_token_id: Optional[int] = None, pad_token_id: Optional[int] = None,
+                        stop_sequences: Optional[Sequence[Sequence[int]]] = None) -> np.ndarray:
+        """-> new token ids [B, n_generated] int32 (prompt not included).  stop_sequences: up to 8 token-id sequences of
+        up to 8 ids; a row is finished (pads afterwards) once its ids end with one of them — checked on the device."""
         ids = self._ids(input_ids)
         B, T = ids.shape
         for a in (images, segs, depths):
@@ -273,9 +275,14 @@ class HipEngine:
         n = C.c_int(0)
         pad = int(self.cfg.pad_token_id or 0) if pad_token_id is None else int(pad_token_id)
         eos = -1 if eos_token_id is None else int(eos_token_id)
-        self._check(self.lib.vc_generate_greedy(self._model, ids.ctypes.data_as(C.c_void_p), B, T, pi, ps, pd, on_dev,
-                                                int(max_new_tokens), eos, pad, out.ctypes.data_as(C.c_void_p),
-                                                C.byref(n)))
+        stops = [list(map(int, q)) for q in (stop_sequences or [])]
+        flat = np.ascontiguousarray([t for q in stops for t in q], dtype=np.int32)
+        lens = np.ascontiguousarray([len(q) for q in stops], dtype=np.int32)
+        self._check(self.lib.vc_generate_greedy_stop(self._model, ids.ctypes.data_as(C.c_void_p), B, T, pi, ps, pd, on_dev,
+                                                     int(max_new_tokens), eos, pad,
+                                                     flat.ctypes.data_as(C.c_void_p) if stops else None,
+                                                     lens.ctypes.data_as(C.c_void_p) if stops else None, len(stops),
+                                                     out.ctypes.data_as(C.c_void_p), C.byref(n)))
         self._cur_batch = B
         return out[:, : n.value].copy()
 

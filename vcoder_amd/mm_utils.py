@@ -106,3 +106,49 @@ def process_images_device(images, model, model_cfg=None, to_device: bool = True)
     mean = getattr(proc, "image_mean", None)
     std = getattr(proc, "image_std", None)
     return engine.preprocess(list(images), pad=pad, mean=mean, std=std, to_device=to_device)
+
+
+
+class KeywordsStoppingCriteria:
+    """Counterpart of vcoder_llava/mm_utils.py:128-151 with batch > 1 support.
+
+    Reference behaviour kept for batch size 1: stop when the sequence ends with the ids of a keyword, or when the text of
+    the last <= 3 generated tokens (special tokens skipped) contains a keyword.  Differences, both documented: (i) any
+    batch size — the call returns True only when EVERY row has met a keyword (rows are checked independently);
+    (ii) multi-token keywords are compared element-wise (the reference's `if tensor == tensor:` raises for them).
+
+    `device_stop_sequences()` returns the id sequences when the id match alone decides (every keyword is a single special
+    token, which the text check can never see because it skips special tokens) — `generate()` then runs the stop on the
+    device inside the hipGraph-replayed decode loop (vc_generate_greedy_stop) instead of syncing with the host every token."""
+
+    def __init__(self, keywords, tokenizer, input_ids):
+        self.keywords = list(keywords)
+        self.keyword_ids = []
+        for keyword in self.keywords:
+            cur = list(tokenizer(keyword).input_ids)
+            if len(cur) > 1 and cur[0] == tokenizer.bos_token_id:
+                cur = cur[1:]
+            self.keyword_ids.append(cur)
+        self.tokenizer = tokenizer
+        self.start_len = input_ids.shape[1]
+
+    def _row_done(self, row) -> bool:
+        ids = [int(t) for t in row]
+        for kw in self.keyword_ids:
+            if len(kw) <= len(ids) and ids[len(ids) - len(kw):] == kw:
+                return True
+        offset = min(len(ids) - self.start_len, 3)
+        if offset > 0:
+            text = self.tokenizer.batch_decode([ids[-offset:]], skip_special_tokens=True)[0]
+            if any(k in text for k in self.keywords):
+                return True
+        return False
+
+    def __call__(self, output_ids, scores=None, **kwargs) -> bool:
+        return all(self._row_done(row) for row in output_ids)
+
+    def device_stop_sequences(self):
+        special = set(getattr(self.tokenizer, "all_special_ids", []) or [])
+        if self.keyword_ids and all(len(kw) == 1 and kw[0] in special for kw in self.keyword_ids) and len(self.keyword_ids) <= 8:
+            return [list(kw) for kw in self.keyword_ids]
+        return None

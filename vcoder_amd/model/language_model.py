@@ -254,12 +254,21 @@ class _HipCausalLMBase:
         segs = segs if self.variant != "llava" else None
         depths = depths if self.variant == "vcoder_ds" else None
         ids_cpu = input_ids.detach().cpu() if hasattr(input_ids, "detach") else torch.as_tensor(np.asarray(input_ids))
-        simple = not do_sample and streamer is None and not stopping_criteria
+        # stopping criteria that reduce to a token-id suffix match run on the device: the
+        # reference's KeywordsStoppingCriteria(["</s>"]) of cli.py / the eval loaders is of that kind
+        stops = []
+        for crit in (stopping_criteria or []):
+            seqs = crit.device_stop_sequences() if hasattr(crit, "device_stop_sequences") else _reference_keyword_stop(crit)
+            if seqs is None:
+                stops = None
+                break
+            stops += seqs
+        simple = not do_sample and streamer is None and stops is not None and len(stops) <= 8
         if streamer is not None:
             streamer.put(ids_cpu)
         if simple:
             new = self.engine.generate_greedy(ids_cpu.numpy(), images, segs, depths, max_new_tokens=max_new_tokens,
-                                              eos_token_id=eos, pad_token_id=pad)
+                                              eos_token_id=eos, pad_token_id=pad, stop_sequences=stops or None)
             self._generation += 1
             out = torch.cat([ids_cpu, torch.from_numpy(new.astype(np.int64))], dim=1)
         else:
@@ -300,6 +309,23 @@ class _HipCausalLMBase:
         if hasattr(input_ids, "device"):
             out = out.to(input_ids.device)
         return out
+
+
+def _reference_keyword_stop(crit):
+    """The reference's own KeywordsStoppingCriteria object (vcoder_llava/mm_utils.py:128-151): usable on the device when
+    every keyword is ONE special token — its text check decodes with skip_special_tokens=True and can never match one, and
+    its id check only works for single-token keywords in the first place.  Anything else -> None (host loop)."""
+    kws, tok = getattr(crit, "keyword_ids", None), getattr(crit, "tokenizer", None)
+    if kws is None or tok is None or not hasattr(crit, "keywords"):
+        return None
+    special = set(getattr(tok, "all_special_ids", []) or [])
+    out = []
+    for k in kws:
+        ids = [int(t) for t in (k.tolist() if hasattr(k, "tolist") else k)]
+        if len(ids) != 1 or ids[0] not in special:
+            return None
+        out.append(ids)
+    return out
 
 
 def _top_p_filter(scores, top_p: float):
