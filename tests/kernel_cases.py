@@ -601,7 +601,7 @@ def check_greedy_embed(be, B, V, D):
     for it in range(2):
         be.lib.vck_greedy_embed(be.ptr(lgd), be.ptr(nxt), be.ptr(out), be.ptr(fin), c_p(base), B, V, max_new, eos,
                                 pad, be.ptr(embd), be.ptr(x), be.ptr(ssq), be.ptr(gwd), be.ptr(xg), D, npart, c_p(base + 4),
-                                c_p(base + 8), 1 if it == 0 else 3, None)
+                                c_p(base + 8), 1 if it == 0 else 3, None, None, None)
         be.sync()
     o = be.host_i32(out)
     exp = torch.argmax(torch.from_numpy(lg), -1).numpy()
