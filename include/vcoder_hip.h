@@ -127,6 +127,10 @@ int vc_generate_greedy_stop(vc_model* m, const int64_t* ids, int B, int T, const
                             const int32_t* stop_ids, const int32_t* stop_lens, int n_stop, int32_t* out_ids,
                             int* n_generated);
 
+/* spliced sequence length (text rows + feature rows) of the last vc_generate_greedy* call: lets a caller that splits a large
+ * batch into replica-sized pieces reproduce the reference's whole-batch behaviour for unequal lengths (quirk 6) */
+int vc_last_spliced_len(vc_model* m);
+
 /* ---- next row §8(f)2: image preprocessing on the device ------------------------------------------------------------
  * process_images() of vcoder_llava/mm_utils.py:28-40 for ONE image: expand2square(mean colour) when pad_to_square,
  * PIL-exact bicubic resize (shortest edge -> S) + center crop, rescale 1/255, (x-mean)/std, HWC->CHW.

@@ -43,3 +43,32 @@ def test_fp8_weight_format(emu_lib):
 
 def test_device_side_stop_sequences(emu_lib):
     e2e_cases.check_stop_sequences("ds_img_only", lib=emu_lib)
+
+
+def test_generate_splits_batches_larger_than_a_replica(emu_lib):
+    """B = 18 > 16: generate runs two pieces; rows equal the rows of smaller calls, and unequal spliced lengths across the
+    pieces raise like they do inside one batch (quirk 6)."""
+    import numpy as np
+    import pytest as _pt
+    from vcoder_amd import synth
+
+    g, cfg, ids, imgs, segs, deps = e2e_cases.fixture_inputs("ds_img_only")
+    eng = e2e_cases.engine_for(cfg.variant, emu_lib)
+    B = 18
+    big_ids = np.concatenate([ids] * (B // ids.shape[0]), axis=0)
+    pix, _, _ = synth.synth_batch(B, cfg.vit_image_size)
+    out = eng.generate_greedy(big_ids, pix, None, None, max_new_tokens=3)
+    assert out.shape == (B, 3)
+    tail = eng.generate_greedy(big_ids[16:], pix[16:], None, None, max_new_tokens=3)
+    head = eng.generate_greedy(big_ids[:4], pix[:4], None, None, max_new_tokens=3)
+    assert np.array_equal(out[16:], tail) and np.array_equal(out[:4], head)
+    # second piece with a different spliced length: its rows carry no <seg> placeholder (a text token instead)
+    g2, cfg2, ids2, imgs2, segs2, _ = e2e_cases.fixture_inputs("ds_img_seg")
+    big2 = np.concatenate([ids2] * (B // ids2.shape[0]), axis=0)
+    pix2, seg2, _ = synth.synth_batch(B, cfg2.vit_image_size)
+    mixed = big2.copy()
+    mixed[16:][mixed[16:] == -300] = 5
+    same = eng.generate_greedy(big2, pix2, seg2, None, max_new_tokens=2)
+    assert same.shape == (B, 2)
+    with _pt.raises(UnboundLocalError):
+        eng.generate_greedy(mixed, pix2, seg2, None, max_new_tokens=2)

@@ -145,6 +145,7 @@ struct vc_model {
     Buf gemm_ws;                  // fp32 workspace of the GEMM's split-K remainder round (64 MiB)
     Buf stop_tab, prompt_tail;    // device-side keyword stop of generate (fixed capacity: the decode graph keeps the pointers)
     int n_stop = 0;
+    int last_S = 0;               // spliced prompt length of the last prefill / generate
     int out_cap = 0;
     int* step_dev() { return scalars.as<int>(); }
     int* pos_dev() { return scalars.as<int>() + 1; }
@@ -1351,6 +1352,7 @@ VC_API int vc_generate_greedy_stop(vc_model* m, const int64_t* ids, int B, int T
     std::unique_lock<std::mutex> gate(prefill_gate, std::defer_lock);
     if (use_gate) gate.lock();
     do_prefill(m, ids, B, T, img, seg, depth, pixels_on_device, 1, max_new, nullptr, &S);  // generate() always builds a mask
+    m->last_S = S;
     REQUIRE(S + max_new <= m->capS, VC_ERR_INVALID, "prompt %d + max_new %d exceeds the KV capacity %d", S, max_new, m->capS);
     ensure_out_ids(m, B, max_new);
     HIPCHK(hipMemcpyAsync(m->stop_tab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, m->st));
@@ -1414,6 +1416,9 @@ VC_API int vc_generate_greedy_stop(vc_model* m, const int64_t* ids, int B, int T
     GUARD_END(m->ctx)
 }
 
+
+/* spliced sequence length (text + feature rows) of the last vc_generate_greedy* call of this model / session */
+VC_API int vc_last_spliced_len(vc_model* m) { return m ? m->last_S : VC_ERR_INVALID; }
 
 VC_API int vc_generate_greedy(vc_model* m, const int64_t* ids, int B, int T, const float* img, const float* seg,
                               const float* depth, int pixels_on_device, int max_new, int eos_id, int pad_id,

@@ -22,6 +22,8 @@ class HipEngine:
     """One model replica on one GPU (one HIP stream).  `lib` is injectable ONLY for the CPU emulator tests;
     product code always goes through `_lib.load()`, which has no fallback."""
 
+    MAX_BATCH = 16   # sequences a replica prefills / decodes at a time (csrc/engine.hip)
+
     def __init__(self, cfg: VCoderConfig, device_index: int = 0, lib: Optional[C.CDLL] = None, _parent=None):
         cfg.validate()
         self.cfg = cfg
@@ -270,10 +272,25 @@ class HipEngine:
         B, T = ids.shape
         for a in (images, segs, depths):
             self._check_pixels(a, B)
+        pad = int(self.cfg.pad_token_id or 0) if pad_token_id is None else int(pad_token_id)
+        if B > self.MAX_BATCH:
+            # a replica decodes at most 16 sequences at a time: larger batches run as consecutive pieces.  Rows are
+            # independent, so the result equals the whole-batch one: finished rows pad to the longest piece, and unequal
+            # spliced lengths ACROSS pieces fail like they do inside one (the reference's quirk 6)
+            parts, lens = [], set()
+            for b0 in range(0, B, self.MAX_BATCH):
+                sl = slice(b0, b0 + self.MAX_BATCH)
+                parts.append(self.generate_greedy(ids[sl], *(None if a is None else a[sl] for a in (images, segs, depths)),
+                                                  max_new_tokens=max_new_tokens, eos_token_id=eos_token_id,
+                                                  pad_token_id=pad_token_id, stop_sequences=stop_sequences))
+                lens.add(int(self.lib.vc_last_spliced_len(self._model)))
+            if len(lens) > 1:
+                raise UnboundLocalError("local variable '_new_labels' referenced before assignment")
+            n = max(p.shape[1] for p in parts)
+            return np.concatenate([np.pad(p, ((0, 0), (0, n - p.shape[1])), constant_values=pad) for p in parts], axis=0)
         (pi, ps, pd), on_dev, keep = self._pixels(images, segs, depths)
         out = np.empty((B, max_new_tokens), dtype=np.int32)
         n = C.c_int(0)
-        pad = int(self.cfg.pad_token_id or 0) if pad_token_id is None else int(pad_token_id)
         eos = -1 if eos_token_id is None else int(eos_token_id)
         stops = [list(map(int, q)) for q in (stop_sequences or [])]
         flat = np.ascontiguousarray([t for q in stops for t in q], dtype=np.int32)
