@@ -213,6 +213,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     timings = eng.last_timings()
+    # transparency leg (outside the timed region): the same step strictly one batch at a time on this rank
+    solo = None
+    if n_sess > 1:
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            sessions[0].generate_greedy(ids, imgs, segs, deps, max_new_tokens=N_new, eos_token_id=None)
+        torch.cuda.synchronize()
+        solo = (time.perf_counter() - t1) / 2
+        timings = sessions[0].last_timings()
     prof = eng.profile_decode_gemv(min(B, 16), reps=3)
 
     if rank == 0:
@@ -234,7 +244,9 @@ def main():
                        "parallelism": f"dp{world}", "weights": "seeded synthetic (vcoder_amd/synth.py)",
                        "in_flight_batches_per_gpu": n_sess,
                        "inputs": "host buffers (PCIe inclusive)" if args.host_pixels else "resident in HBM"},
-            "phase_ms_one_session": timings,  # wall time of the last batch's phases; they overlap other batches when in flight > 1
+            "phase_ms_one_session": timings,  # encode / prefill / decode wall time of one batch run alone
+            "one_batch_at_a_time": None if solo is None else {"value": B / solo, "unit": "images/s per GPU",
+                                                              "ms_per_step": solo * 1e3},
             "roofline": {"bound": "hbm", "kernel": "gemv_dma_kernel (decode weight streaming, all 129 GEMV launches of a step)", "achieved": ach,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": traffic, "avg_launch_us": prof["avg_us"],
