@@ -159,3 +159,26 @@ def test_load_errors(emu_engines):
     with pytest.raises(RuntimeError):
         e.finalize()                                                                              # missing tensors
     e.close()
+
+
+def test_checkpoint_reader_handles_sharded_bin_layout(tmp_path):
+    """The released VCoder / Vicuna checkpoints ship `pytorch_model-0000i-of-0000n.bin` shards (fp16); the reader yields
+    every tensor of every shard under its HF key, and safetensors take precedence when both are present."""
+    import torch
+    from vcoder_amd import checkpoint
+
+    d = str(tmp_path / "ckpt")
+    os.makedirs(d)
+    a = {"model.layers.0.self_attn.q_proj.weight": torch.randn(4, 4).half(), "model.norm.weight": torch.ones(4).half()}
+    b = {"lm_head.weight": torch.randn(8, 4).half(), "model.mm_projector.0.bias": torch.zeros(4).half()}
+    torch.save(a, os.path.join(d, "pytorch_model-00001-of-00002.bin"))
+    torch.save(b, os.path.join(d, "pytorch_model-00002-of-00002.bin"))
+    assert checkpoint.has_weights(d)
+    got = dict(checkpoint.iter_checkpoint_tensors(d))
+    assert set(got) == set(a) | set(b)
+    for k, v in {**a, **b}.items():
+        assert got[k].dtype == torch.float16 and torch.equal(got[k], v)
+    with pytest.raises(FileNotFoundError):
+        list(checkpoint.iter_checkpoint_tensors(str(tmp_path)))
+    checkpoint.save_checkpoint(d, {"model_type": "llava"}, {"only.safetensors": np.ones((2, 2), np.float32)})
+    assert list(dict(checkpoint.iter_checkpoint_tensors(d))) == ["only.safetensors"]
