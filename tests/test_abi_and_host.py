@@ -5,6 +5,7 @@ import ctypes
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -182,3 +183,13 @@ def test_checkpoint_reader_handles_sharded_bin_layout(tmp_path):
         list(checkpoint.iter_checkpoint_tensors(str(tmp_path)))
     checkpoint.save_checkpoint(d, {"model_type": "llava"}, {"only.safetensors": np.ones((2, 2), np.float32)})
     assert list(dict(checkpoint.iter_checkpoint_tensors(d))) == ["only.safetensors"]
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    """bench.py is a GPU measurement: without a HIP device it must exit loudly, not fall back to anything."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True,
+                       text=True)
+    assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
+    assert not any(line.startswith("{") for line in r.stdout.splitlines()), "no result line may be printed"
