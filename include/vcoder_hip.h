@@ -68,7 +68,8 @@ void vc_model_destroy(vc_model* m);
 int vc_model_create_shared(vc_ctx* ctx, vc_model* parent, vc_model** out);
 
 /* ---- weights: replaces HF from_pretrained() of builder.py:93-108 + CLIPVisionTower.load_model() ---- */
-/* hf_key = state-dict key of the reference checkpoint; host_ptr = row-major tensor of `dtype`. */
+/* hf_key = state-dict key of the reference checkpoint; host_ptr = row-major tensor of `dtype`; the full shape is checked
+ * (a transposed matrix is an error, not a silent load). */
 int vc_model_load_tensor(vc_model* m, const char* hf_key, const void* host_ptr, int dtype, const int64_t* shape,
                          int ndim);
 /* device-side deterministic generator, bit-identical to vcoder_amd/synth.py:synth_tensor (benchmarks, tests) */
@@ -93,6 +94,21 @@ int vc_model_set_weight_format(vc_model* m, int fmt);
 /* encode_images / encode_seg_images / encode_depth_images (vcoder_ds_llava_arch.py:106-119):
  * pixels fp32 [B,3,S,S] (host, or device when pixels_on_device) -> projected features fp32 [B,P,hidden] on host. */
 int vc_encode(vc_model* m, int modality, const float* pixels, int pixels_on_device, int B, float* out_feats_host);
+
+/* CLIPVisionTower.forward + feature_select (vcoder_llava/model/multimodal_encoder/clip_encoder.py:29-51): the un-projected
+ * tower output the reference's encode_* hand to the adapters — hidden_states[mm_vision_select_layer] of N images with the
+ * CLS row dropped for 'patch'.  pixels fp32 [N,3,S,S] -> out fp32 [N, R, vit_hidden] on the host (R = patches, +1 for
+ * 'cls_patch'). */
+int vc_vision_tower_forward(vc_model* m, const float* pixels, int pixels_on_device, int N, float* out_host);
+
+/* images per sample for the NEXT vc_prefill* / vc_generate* call (one-shot): the reference's list / 5-D image form
+ * (vcoder_ds_llava_arch.py:135-169) — sample b owns counts[b] images of a modality, whose feature rows are spliced as ONE
+ * block at its placeholder; the pixel pointer of that modality then holds sum(counts) images.  NULL = one per sample. */
+int vc_set_image_counts(vc_model* m, const int32_t* img_counts, const int32_t* seg_counts, const int32_t* depth_counts, int B);
+
+/* KV-cache slots the next vc_prefill keeps free behind the prompt for vc_decode_step loops (default 64, clamped to
+ * max_position_embeddings).  A loop that outruns the reserve still works: the cache grows (one copy of the live prefix). */
+int vc_model_reserve_decode(vc_model* m, int max_new_tokens);
 
 /* prepare_inputs_labels_for_multimodal + LlamaModel + lm_head (vcoder_ds_llava_llama.py:57-118), prefill.
  * ids [B,T] int64 host with -200/-300/-400 placeholders; seg/depth may be NULL.  has_attention_mask only
@@ -126,6 +142,24 @@ int vc_generate_greedy_stop(vc_model* m, const int64_t* ids, int B, int T, const
                             const float* depth, int pixels_on_device, int max_new, int eos_id, int pad_id,
                             const int32_t* stop_ids, const int32_t* stop_lens, int n_stop, int32_t* out_ids,
                             int* n_generated);
+
+/* generate() in full — what vcoder_llava/serve/cli.py:122-132 and serve/chat.py:141-151 call: greedy, or sampling on the
+ * device when samp->do_sample (HF order: temperature, top-k, top-p, multinomial).  The draw is a
+ * counter-based generator keyed by (seed, row of the batch, step, vocabulary index): the same seed gives the same tokens.
+ * cb (may be NULL): streamer hook, called on the calling thread with the ids of steps [first_step, first_step + n_steps)
+ * of every row (ids [B][n_steps] row-major) every cb_every steps — the decode loop stays hipGraph-replayed in between. */
+typedef struct vc_sampling {
+    int32_t do_sample;   /* 0: greedy */
+    float temperature;   /* > 0 */
+    int32_t top_k;       /* <= 0: off (HF's GenerationConfig default is 50) */
+    float top_p;         /* (0, 1]; 1: off */
+    uint64_t seed;
+} vc_sampling;
+typedef void (*vc_token_cb)(void* user, int first_step, int n_steps, int B, const int32_t* ids);
+int vc_generate(vc_model* m, const int64_t* ids, int B, int T, const float* img, const float* seg, const float* depth,
+                int pixels_on_device, int max_new, int eos_id, int pad_id, const int32_t* stop_ids, const int32_t* stop_lens,
+                int n_stop, const vc_sampling* samp, vc_token_cb cb, void* cb_user, int cb_every, int32_t* out_ids,
+                int* n_generated);
 
 /* spliced sequence length (text rows + feature rows) of the last vc_generate_greedy* call: lets a caller that splits a large
  * batch into replica-sized pieces reproduce the reference's whole-batch behaviour for unequal lengths (quirk 6) */

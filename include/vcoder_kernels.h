@@ -62,20 +62,27 @@ void vck_attention_decode(const uint16_t* q, const uint16_t* k, const uint16_t* 
 void vck_attention_decode_fused(const uint16_t* qkv, uint16_t* k, uint16_t* vt, uint16_t* out, int B, int H, int hd,
                                 int kv_stride, const int* pos_dev, const float* rope_cos, const float* rope_sin, float scale,
                                 void* stream);
+/* the same with one position per row (row b reads pos_rows[b * pos_stride]; rows with active_rows[b * pos_stride] == 0 are
+ * skipped): rows of different requests — different prompt lengths and step counts — share one decode step */
+void vck_attention_decode_rows(const uint16_t* qkv, uint16_t* k, uint16_t* vt, uint16_t* out, int B, int H, int hd,
+                               int kv_stride, const int* pos_rows, int pos_stride, const int* active_rows,
+                               const float* rope_cos, const float* rope_sin, float scale, void* stream);
 /* embedding gather + feature splice (vcoder_ds_llava_arch.py:173-276,305) */
 void vck_splice(const int* row_src, int nrows, const uint16_t* embed, const uint16_t* feats, float* x, int D, void* stream);
 void vck_embed_tokens(const int* tok, const uint16_t* embed, float* x, int B, int D, void* stream);
 /* greedy select with EOS/pad bookkeeping ([HF] generation/utils.py:2894,2925-2929) */
 void vck_greedy(const float* logits, int* next_tok, int* out_ids, int* finished, int* step_dev, int B, int V, int max_new,
                 int eos_id, int pad_id, void* stream);
-/* greedy select of all rows + embedding of the selected tokens (fp32 rows x, RMSNorm partials ssq, and the first
- * GEMV's operand xg = bf16(x * xg_w)) + step/pos/ctx advance */
-void vck_greedy_embed(const float* logits, int* next_tok, int* out_ids, int* finished, int* step_dev, int B, int V,
-                      int max_new, int eos_id, int pad_id, const uint16_t* embed, float* x, float* ssq, const float* xg_w,
-                      uint16_t* xg, int D, int npart, int* pos_dev, int* ctx_dev, int advance, const int* stop_tab,
-                      const int* prompt_tail, void* stream);
-/* stop_tab / prompt_tail (may be NULL): device-side keyword stop — [0] = n sequences (<= 8), then per sequence 9 ints
- * (length <= 8, ids); prompt_tail [B][7] = last prompt ids of each row.  A row whose ids end with a sequence is finished. */
+/* tail of a decode step, one workgroup per row (csrc/select.hip): token selection — greedy, or temperature / top-k / top-p
+ * sampling ([HF] generation/logits_process.py warpers + multinomial; serve/cli.py:122-132, serve/chat.py:141-151) — EOS /
+ * pad / keyword-stop bookkeeping (mm_utils.py:128-151), embedding of the selected token (fp32 row x, RMSNorm partials ssq,
+ * first GEMV operand xg = bf16(x * xg_w)) and the row's step / position advance (bit 0 / bit 1 of `advance`).  Every
+ * per-row parameter lives in the row's record of `rows` ([nrows][vck_row_state_stride()] ints, csrc/kernels.h
+ * RowStateField); row r writes its id to out_ids[rows[r][RS_OUT_OFF] + step]. */
+void vck_select_embed(const float* logits, int ldl, int* rows, int* next_tok, int* out_ids, const uint16_t* embed, float* x,
+                      float* ssq, const float* xg_w, uint16_t* xg, int D, int npart, int V, int nrows, int advance,
+                      void* stream);
+int vck_row_state_stride(void);
 void vck_embed_tokens_ssq(const int* tok, const uint16_t* embed, float* x, float* ssq, const float* xg_w, uint16_t* xg, int B,
                           int D, int npart, void* stream);
 void vck_advance(int* step_dev, int* pos_dev, int* ctx_dev, void* stream);

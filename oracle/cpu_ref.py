@@ -379,19 +379,30 @@ class OracleModel:
         # vcoder_lm_emb is overwritten with embed_tokens on every multimodal forward (quirk 3, :173)
         return self.sd["model.embed_tokens.weight"][torch.tensor(list(ids), dtype=torch.long)]
 
+    def _encode_any(self, images, modality: str):
+        """The three input forms of vcoder_ds_llava_arch.py:135-169: a 4-D tensor [B,3,S,S] -> features [B,P,D]; a list
+        of [n_b,3,S,S] tensors or a 5-D tensor -> concat, encode, split by n_b and `flatten(0, 1)`: a LIST of
+        [n_b*P, D] blocks, one per sample."""
+        if type(images) is list or images.ndim == 5:
+            items = [im for im in images]
+            feats = self.encode(torch.cat(items, dim=0), modality)
+            parts = torch.split(feats, [im.shape[0] for im in items], dim=0)
+            return [x.flatten(0, 1) for x in parts]
+        return self.encode(images, modality)
+
     def prepare_inputs(self, input_ids, images, segs=None, depths=None, attention_mask_given: bool = False):
         """Returns (inputs_embeds [B,S,D], plans).  Equal spliced lengths are stacked; unequal lengths are
         right-padded with zero rows when no attention_mask was passed (:278-285) and raise when one was
         (quirk 6: the reference dies with UnboundLocalError at :297)."""
         cfg = self.cfg
-        img_f = self.encode(images, "img")
-        seg_f = self.encode(segs, "seg") if (segs is not None and cfg.variant != "llava") else None
+        img_f = self._encode_any(images, "img")
+        seg_f = self._encode_any(segs, "seg") if (segs is not None and cfg.variant != "llava") else None
         dep_f, dz = None, None
         if cfg.variant == "vcoder_ds" and depths is not None:
             dz = [bool(torch.mean(d) == 0) for d in depths]          # :161
-            dep_f = self.encode(depths, "depth")                     # computed even if never spliced
-        plans = splice_plan(input_ids, cfg.variant, seg_f is not None, dz, img_f.shape[0],
-                            0 if seg_f is None else seg_f.shape[0], 0 if dep_f is None else dep_f.shape[0])
+            dep_f = self._encode_any(depths, "depth")                # computed even if never spliced
+        n_of = lambda f: 0 if f is None else (len(f) if isinstance(f, list) else f.shape[0])
+        plans = splice_plan(input_ids, cfg.variant, seg_f is not None, dz, n_of(img_f), n_of(seg_f), n_of(dep_f))
         rows = []
         for plan in plans:
             parts = []

@@ -152,6 +152,56 @@ def run_case(model, oracle, cfg, name, ids_list, use_seg=True, use_depth=True, n
                         step_logits=lg.astype(np.float32), top2_margin=top2_margin(lg).astype(np.float32))
 
 
+def run_list_case(model, oracle, cfg, name, ids_list, counts):
+    """The list / 5-D image input form (vcoder_ds_llava_arch.py:135-169): sample b owns counts[k][b] images of modality k
+    (k = img, seg, depth); their features are spliced as ONE block at the placeholder.  Stores the reference's spliced
+    length, inputs_embeds sample and prefill logits; the pixel data are regenerated from synth.synth_batch."""
+    B = len(ids_list)
+    size = cfg.vit_image_size
+    ids = torch.tensor(np.stack(ids_list), dtype=torch.long)
+    tot = [int(sum(c)) for c in counts]
+    pools = synth.synth_batch(max(tot), size)                       # (images, segs, depths) pools of max(tot) images
+    lists = []
+    for k in range(3):
+        off, items = 0, []
+        for b in range(B):
+            items.append(torch.from_numpy(pools[k][off:off + counts[k][b]]))
+            off += counts[k][b]
+        lists.append(items)
+    with torch.no_grad():
+        out = model(input_ids=ids, images=lists[0], segs=lists[1], depths=lists[2], use_cache=False)
+        full = out.logits.float().numpy()
+        emb = model.prepare_inputs_labels_for_multimodal(ids, torch.ones_like(ids), None, None, lists[0], lists[1],
+                                                         lists[2])[3].detach().float().numpy()
+        # the 5-D tensor form of the same inputs (equal counts only) must agree with the list form
+        if all(len(set(c)) == 1 for c in counts):
+            five = [torch.stack(l, 0) for l in lists]
+            full5 = model(input_ids=ids, images=five[0], segs=five[1], depths=five[2], use_cache=False).logits.float().numpy()
+            assert np.array_equal(full, full5), "5-D form differs from the list form"
+    o_emb, _ = oracle.prepare_inputs(ids.tolist(), lists[0], lists[1], lists[2])
+    o_full, _ = oracle.forward(ids.tolist(), lists[0], lists[1], lists[2])
+    e1, e3 = float(np.abs(o_emb.numpy() - emb).max()), float(np.abs(o_full.numpy() - full).max())
+    print(f"[{name}] S={emb.shape[1]} embeds|d|={e1:.2e} full|d|={e3:.2e}")
+    assert e1 < 1e-5 and e3 < 2e-4, "oracle/cpu_ref.py disagrees with the reference on list-form images"
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), variant=cfg.variant, seed=SEED, input_ids=ids.numpy(),
+                        counts=np.asarray(counts, dtype=np.int64), spliced_len=emb.shape[1],
+                        embeds_sample=emb[:, ::7, ::16].astype(np.float32), prefill_logits=full.astype(np.float32))
+
+
+def tower_vectors(model, cfg, name):
+    """a2: CLIPVisionTower.forward of the live reference (clip_encoder.py:39-51) on the tiny tower — un-projected
+    hidden_states[-2] without CLS — for 3 synthetic images; also pins cpu_ref.vit_forward."""
+    imgs = torch.from_numpy(synth.synth_batch(3, cfg.vit_image_size)[0])
+    with torch.no_grad():
+        feats = model.get_vision_tower()(imgs).float().numpy()
+    sd = cpu_ref.as_torch_state(synth.synth_state_dict(cfg, SEED, only_prefix="model.vision_tower"))
+    o = cpu_ref.vit_forward(imgs, sd, cfg).numpy()
+    e = float(np.abs(o - feats).max())
+    print(f"[{name}] tower features {feats.shape} oracle|d|={e:.2e}")
+    assert e < 1e-5
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), variant=cfg.variant, seed=SEED, features=feats.astype(np.float32))
+
+
 def per_op_vectors():
     """G3: per-op vectors at TRUE inner dims from the third-party modules the reference calls
     (HF CLIP / Llama building blocks + torch.nn), a few rows each."""
@@ -213,15 +263,54 @@ def tokenizer_orders():
             r.input_ids = [1] + [3 + (ord(c) % 50) for c in text]
             return r
 
-    tk = Fake()
+    class NoBos(Fake):   # a tokenizer that prepends nothing: the reference's offset == 0 paths (mm_utils.py:50-54,73-82)
+        bos_token_id = 1
+
+        def __call__(self, text):
+            r = Fake.__call__(self, text)
+            r.input_ids = r.input_ids[1:]
+            return r
+
+    tk, nb = Fake(), NoBos()
     out = {
         "ds": mm_utils.tokenizer_depth_seg_token("ab <depth>\n<seg>\n<image>\ncd", tk),
         "seg": mm_utils.tokenizer_depth_seg_token("ab <seg>\n<image>\ncd", tk),
         "img": mm_utils.tokenizer_image_token("ab <image>\ncd", tk),
+        "ds_nobos": mm_utils.tokenizer_depth_seg_token("ab <depth>\n<seg>\n<image>\ncd", nb),
+        "seg_nobos": mm_utils.tokenizer_depth_seg_token("ab <seg>\n<image>\ncd", nb),
+        "img_nobos": mm_utils.tokenizer_image_token("ab <image>\ncd", nb),
     }
     with open(os.path.join(GOLD, "tokenizer_orders.json"), "w") as f:
         json.dump({k: [int(t) for t in v] for k, v in out.items()}, f)
     print("[tokenizer]", {k: [t for t in v if t < 0] for k, v in out.items()})
+
+
+def main_round2():
+    """Fixtures added in round 2 (list-form images, the tower boundary, BOS-less tokenizer orders); the round-1 fixtures
+    are left untouched (`python oracle/gen_golden.py --round2`)."""
+    os.makedirs(GOLD, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    tokenizer_orders()
+    I, S, D = synth.IMAGE_TOKEN_INDEX, synth.SEG_TOKEN_INDEX, synth.DEPTH_TOKEN_INDEX
+    with tempfile.TemporaryDirectory() as tmp:
+        cfg = vcfg.tiny("vcoder_ds")
+        clip_dir = os.path.join(tmp, "clip")
+        make_clip_dir(cfg, clip_dir)
+        sd = synth.synth_state_dict(cfg, SEED)
+        model = build_reference_model(cfg, sd, clip_dir)
+        oracle = cpu_ref.OracleModel(cfg, sd)
+        V = cfg.vocab_size
+        p = lambda s, ph: np.concatenate([[1], synth.synth_prompt_ids(V, "llava", 5, 4, s)[1:6], ph,
+                                          synth.synth_prompt_ids(V, "llava", 5, 4, s)[7:]]).astype(np.int64)
+        tower_vectors(model, cfg, "tower_tiny")
+        # two images per sample for every modality, hand order [IMG, SEG, DEPTH] so that depth blocks are spliced too
+        run_list_case(model, oracle, cfg, "ds_list_two_each", [p(0, [I, S, D]), p(1, [I, S, D])],
+                      [[2, 2], [2, 2], [2, 2]])
+        # uneven image counts with equal totals per sample (equal spliced lengths): 2+1+1 and 1+2+1
+        run_list_case(model, oracle, cfg, "ds_list_uneven", [p(2, [I, S, D]), p(3, [I, S, D])],
+                      [[2, 1], [1, 2], [1, 1]])
+    print("round-2 fixtures written to", GOLD)
 
 
 def main():
@@ -296,4 +385,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--round2" in sys.argv:
+        main_round2()
+    else:
+        main()
+        main_round2()

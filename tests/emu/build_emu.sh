@@ -5,7 +5,7 @@ cd "$(dirname "$0")"
 CXX=${CXX:-/opt/rocm/lib/llvm/bin/clang++}
 SRC=../../vcoder_amd/csrc
 OBJS=""
-for f in $SRC/gemm.hip $SRC/norm.hip $SRC/attn.hip $SRC/decode.hip $SRC/misc.hip $SRC/strict.hip $SRC/preprocess.hip $SRC/engine.hip; do
+for f in $SRC/gemm.hip $SRC/norm.hip $SRC/attn.hip $SRC/decode.hip $SRC/misc.hip $SRC/select.hip $SRC/strict.hip $SRC/preprocess.hip $SRC/engine.hip; do
   [ -f "$f" ] || continue
   o=build/$(basename $f .hip).o
   mkdir -p build

@@ -126,6 +126,7 @@ inline hipError_t hipGraphLaunch(hipGraphExec_t g, hipStream_t) { for (auto& f :
 
 inline void __syncthreads() { vc_emu::block_barrier(); }
 inline float __expf(float x) { return expf(x); }
+inline float __logf(float x) { return logf(x); }
 inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 inline float __fmul_rn(float a, float b) { return a * b; }
 inline float __fadd_rn(float a, float b) { return a + b; }

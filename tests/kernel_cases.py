@@ -582,37 +582,131 @@ def check_attention_decode_fused(be, B, H, hd, pos, seed=0):
     assert err < 2 ** -7 * max(1.0, np.abs(ref).max()), f"attention_decode_fused pos{pos}: abs err {err}"
 
 
-def check_greedy_embed(be, B, V, D):
-    rng = np.random.RandomState(11)
+RS = dict(ACTIVE=0, FINISHED=1, STEP=2, POS=3, MAXNEW=4, EOS=5, PAD=6, NSTOP=7, SAMPLE=8, INVTEMP=9, TOPK=10, TOPP=11,
+          SEED_LO=12, SEED_HI=13, OUT_OFF=14, TAIL=16, STOP=24, STRIDE=128)   # csrc/kernels.h RowStateField
+
+
+def _f32_bits(x: float) -> int:
+    return int(np.float32(x).view(np.int32))
+
+
+def make_rows(n, **fields):
+    """host-side RowState records [n, 128] int32; a field value is a scalar or a per-row list"""
+    r = np.zeros((n, RS["STRIDE"]), dtype=np.int32)
+    r[:, RS["ACTIVE"]] = 1
+    r[:, RS["EOS"]] = -1
+    r[:, RS["INVTEMP"]] = _f32_bits(1.0)
+    r[:, RS["TOPP"]] = _f32_bits(1.0)
+    r[:, RS["TAIL"]:RS["TAIL"] + 7] = np.iinfo(np.int32).min
+    for k, v in fields.items():
+        r[:, RS[k]] = v
+    return r
+
+
+def _select(be, lg, rows, out, D, V, embed=None, advance=3, gw=None):
+    """one launch of vck_select_embed; returns (next_tok, rows, x, xg, ssq) on the host"""
+    n = rows.shape[0]
     npart = (D // 16 + 15) // 16 * 16
+    nxt = be.zeros((n,), "i32")
+    x, ssq, xg = be.zeros((n, D), "f32"), be.zeros((n, npart), "f32"), be.zeros((n, D), "bf16")
+    lgd, rd = be.f32(lg), be.i32(rows)
+    embd = be.bf16(embed) if embed is not None else None
+    gwd = be.f32(gw if gw is not None else np.ones(D, np.float32))
+    be.lib.vck_select_embed(be.ptr(lgd), V, be.ptr(rd), be.ptr(nxt), be.ptr(out), be.ptr(embd), be.ptr(x), be.ptr(ssq),
+                            be.ptr(gwd), be.ptr(xg), D, npart, V, n, advance, None)
+    be.sync()
+    return be.host_i32(nxt), be.host_i32(rd), be.host_f32(x), be.host_f32(xg), be.host_f32(ssq)
+
+
+def check_select_embed(be, B, V, D):
+    """greedy selection (lowest index on ties), EOS -> pad bookkeeping, inactive rows, per-row step / position advance,
+    embedding + RMSNorm partials + xg of the selected token ([HF] generation/utils.py:2894,2925-2929)."""
+    assert int(be.lib.vck_row_state_stride()) == RS["STRIDE"]
+    rng = np.random.RandomState(11)
     lg = rng.randn(B, V).astype(np.float32)
     lg[0, 17] = lg[0, 5] = lg[0].max() + 1.0
     eos, pad, max_new = 2, 0, 4
     if B > 2:
         lg[2, eos] = lg[2].max() + 1.0
     embed = bf16_round(rng.randn(V, D))
-    nxt, out, fin = be.zeros((16,), "i32"), be.zeros((16, max_new), "i32"), be.zeros((16,), "i32")
-    sc = be.i32([0, 100, 101])
-    x, ssq = be.zeros((16, D), "f32"), be.f32(rng.randn(16, npart))
     gw = (rng.rand(D) + 0.5).astype(np.float32)
-    gwd, xg = be.f32(gw), be.zeros((16, D), "bf16")
-    base = sc.ctypes.data if isinstance(sc, np.ndarray) else sc.data_ptr()
-    lgd, embd = be.f32(lg), be.bf16(embed)   # keep alive until sync()
-    for it in range(2):
-        be.lib.vck_greedy_embed(be.ptr(lgd), be.ptr(nxt), be.ptr(out), be.ptr(fin), c_p(base), B, V, max_new, eos,
-                                pad, be.ptr(embd), be.ptr(x), be.ptr(ssq), be.ptr(gwd), be.ptr(xg), D, npart, c_p(base + 4),
-                                c_p(base + 8), 1 if it == 0 else 3, None, None, None)
-        be.sync()
+    rows = make_rows(B, MAXNEW=max_new, EOS=eos, PAD=pad, POS=[100 + 3 * b for b in range(B)],
+                     OUT_OFF=[b * max_new for b in range(B)])
+    if B > 1:
+        rows[1, RS["ACTIVE"]] = 0        # a free row: nothing of it may change
+    out = be.zeros((B, max_new), "i32")
+    nxt, r1, x, xg, ssq = _select(be, lg, rows, out, D, V, embed, advance=1, gw=gw)
+    nxt, r2, x, xg, ssq = _select(be, lg, r1, out, D, V, embed, advance=3, gw=gw)
     o = be.host_i32(out)
-    exp = torch.argmax(torch.from_numpy(lg), -1).numpy()
+    exp = np.argmax(lg, -1)
     assert o[0, 0] == 5
     for b in range(B):
+        if B > 1 and b == 1:
+            assert (o[b] == 0).all() and np.array_equal(r2[b], rows[b])
+            continue
         assert o[b, 0] == exp[b] and o[b, 1] == (pad if exp[b] == eos else exp[b])
-    assert list(be.host_i32(sc)) == [2, 101, 102]
-    last = [pad if exp[b] == eos else exp[b] for b in range(B)]
-    assert np.array_equal(be.host_f32(x)[:B], embed[last])
-    assert np.array_equal(be.host_f32(xg)[:B], bf16_round(embed[last] * gw))
-    assert np.abs(be.host_f32(ssq)[:B].sum(-1) / (embed[last] ** 2).sum(-1) - 1).max() < 1e-5
+        assert r2[b, RS["STEP"]] == 2 and r2[b, RS["POS"]] == 100 + 3 * b + 1
+        assert r2[b, RS["FINISHED"]] == int(exp[b] == eos)
+        last = pad if exp[b] == eos else exp[b]
+        assert nxt[b] == last
+        assert np.array_equal(x[b], embed[last])
+        assert np.array_equal(xg[b], bf16_round(embed[last] * gw))
+        assert abs(ssq[b].sum() / (embed[last] ** 2).sum() - 1) < 1e-5
+
+
+def sample_reference_probs(lg, temperature, top_k, top_p):
+    """HF warper order (logits_process.py): temperature -> top-k -> top-p, then softmax; fp64."""
+    z = lg.astype(np.float64) / temperature
+    if top_k and 0 < top_k < z.shape[-1]:
+        kth = np.sort(z)[-top_k]
+        z = np.where(z < kth, -np.inf, z)
+    if top_p < 1.0:
+        order = np.argsort(z, kind="stable")                    # ascending
+        p = np.exp(z[order] - z.max())
+        p /= p.sum()
+        remove = np.cumsum(p) <= (1.0 - top_p)
+        remove[-1] = False
+        z = z.copy()
+        z[order[remove]] = -np.inf
+    p = np.exp(z - z.max())
+    return p / p.sum()
+
+
+def check_sampling(be, V, temperature, top_k, top_p, draws=2048, seed0=1234):
+    """device sampling (vck_select_embed, RS_SAMPLE): (i) the same seed gives the same token, (ii) no draw ever leaves the
+    top-k / top-p support of the reference warpers, (iii) the empirical distribution matches softmax of the warped logits
+    (total variation < 4 sigma of the multinomial noise), (iv) the step counter is part of the key."""
+    rng = np.random.RandomState(5)
+    lg1 = (rng.randn(V) * 1.5).astype(np.float32)
+    probs = sample_reference_probs(lg1, temperature, top_k, top_p)
+    support = probs > 0
+    R = 16
+    lg = np.tile(lg1, (R, 1))
+    counts = np.zeros(V, dtype=np.int64)
+    first = None
+    out = be.zeros((R, 1), "i32")
+    for it in range(draws // R):
+        rows = make_rows(R, MAXNEW=1, SAMPLE=1, INVTEMP=_f32_bits(1.0 / temperature), TOPK=top_k, TOPP=_f32_bits(top_p),
+                         SEED_LO=[(seed0 + 7919 * (it * R + r)) & 0x7FFFFFFF for r in range(R)], SEED_HI=77,
+                         OUT_OFF=list(range(R)))
+        nxt, _, _, _, _ = _select(be, lg, rows, out, 64, V, None, advance=0)
+        if it == 0:
+            first = nxt.copy()
+            again, _, _, _, _ = _select(be, lg, rows, out, 64, V, None, advance=0)
+            assert np.array_equal(first, again), "same seed, same step -> same token"
+            rows2 = rows.copy()
+            rows2[:, RS["STEP"]] = 1
+            other, _, _, _, _ = _select(be, lg, rows2, out, 64, V, None, advance=0)
+            if support.sum() > 4:
+                assert not np.array_equal(first, other), "the step counter must change the draw"
+        assert support[nxt].all(), f"a draw left the top-k/top-p support: {nxt[~support[nxt]]}"
+        np.add.at(counts, nxt, 1)
+    n = counts.sum()
+    tv = 0.5 * np.abs(counts / n - probs).sum()
+    # E[TV] of an n-sample multinomial ~ sum_i sqrt(p_i (1 - p_i) / (2 pi n)) ; allow 4x
+    bound = 4.0 * np.sqrt(probs * (1 - probs) / (2 * np.pi * n)).sum() + 1e-3
+    assert tv < bound, f"sampling T={temperature} k={top_k} p={top_p}: total variation {tv:.4f} > {bound:.4f}"
+    return tv
 
 
 # ---- strict (fp32) kernels ----------------------------------------------------------------------------------------

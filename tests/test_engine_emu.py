@@ -72,3 +72,70 @@ def test_generate_splits_batches_larger_than_a_replica(emu_lib):
     assert same.shape == (B, 2)
     with _pt.raises(UnboundLocalError):
         eng.generate_greedy(mixed, pix2, seg2, None, max_new_tokens=2)
+
+
+def test_list_and_5d_image_inputs(emu_lib):
+    """Several images per sample (list / 5-D form) against the live reference's fixture, through the engine."""
+    r = e2e_cases.check_list_fixture("ds_list_uneven", lib=emu_lib)
+    assert r["logits_err_vs_ref"] < e2e_cases.TOL_VS_FP32_REF
+
+
+def test_vision_tower_boundary(emu_lib):
+    """vc_vision_tower_forward (CLIPVisionTower.forward + feature_select) vs the live reference's tower output."""
+    assert e2e_cases.check_tower_fixture(lib=emu_lib, strict=True) < 1e-4
+    e2e_cases.check_tower_fixture(lib=emu_lib)
+
+
+def test_kv_cache_grows_under_a_long_decode_loop(emu_lib):
+    """A host-driven decode_step loop far past the prefill's reserve (what the reference CLI's max_new_tokens=512 host loop
+    does): the cache grows and the tokens equal those of a run that reserved the space up front."""
+    import numpy as np
+
+    g, cfg, ids, imgs, segs, deps = e2e_cases.fixture_inputs("ds_img_only")
+    eng = e2e_cases.engine_for(cfg.variant, emu_lib)
+    n = 200
+    ref = eng.generate_greedy(ids, imgs, segs, deps, max_new_tokens=n + 1)      # sized for n up front
+    last, _, S = eng.prefill(ids, imgs, segs, deps, reserve=8)                   # tiny reserve: forces two growths
+    tok = np.argmax(last, -1).astype(np.int32)
+    toks = [tok]
+    for _ in range(n):
+        _, tok = eng.decode_step(tok, want_logits=False)
+        toks.append(tok)
+    assert np.array_equal(np.stack(toks, 1), ref)
+    eng.prefill(ids, imgs, segs, deps, reserve=64)
+
+
+def test_load_tensor_checks_the_full_shape(emu_lib):
+    """A transposed weight has the right element count and the wrong meaning: refused."""
+    import numpy as np
+    import pytest as _pt
+    from vcoder_amd import config as vcfg
+    from vcoder_amd.engine import HipEngine
+
+    cfg = vcfg.tiny("vcoder_ds")
+    eng = HipEngine(cfg, lib=emu_lib)
+    F, D = cfg.intermediate_size, cfg.hidden_size
+    assert eng.load_tensor("model.layers.0.mlp.down_proj.weight", np.zeros((D, F), np.float32))
+    with _pt.raises(ValueError, match="expected shape"):
+        eng.load_tensor("model.layers.0.mlp.down_proj.weight", np.zeros((F, D), np.float32))
+    # the conv patch embedding may come as [Dv,3,P,P] or flattened
+    Dv, P = cfg.mm_hidden_size, cfg.vit_patch_size
+    assert eng.load_tensor("vision_model.embeddings.patch_embedding.weight", np.zeros((Dv, 3, P, P), np.float32))
+    assert eng.load_tensor("vision_model.embeddings.patch_embedding.weight", np.zeros((Dv, 3 * P * P), np.float32))
+    eng.close()
+
+
+def test_generate_rejects_bad_pad_and_depth_index(emu_lib):
+    import numpy as np
+    import pytest as _pt
+    from vcoder_amd import synth
+
+    g, cfg, ids, imgs, segs, deps = e2e_cases.fixture_inputs("ds_img_seg_depth")
+    eng = e2e_cases.engine_for(cfg.variant, emu_lib)
+    with _pt.raises(IndexError, match="pad_token_id"):
+        eng.generate_greedy(ids, imgs, segs, deps, max_new_tokens=2, eos_token_id=2, pad_token_id=cfg.vocab_size + 5)
+    # two <depth> placeholders in row 0 advance the depth index twice: row 1 then indexes past the list (reference: IndexError)
+    bad = np.concatenate([ids, np.full((ids.shape[0], 1), 9)], axis=1)
+    bad[0, -1] = synth.DEPTH_TOKEN_INDEX
+    with _pt.raises(IndexError):
+        eng.prefill(bad, imgs, segs, deps)

@@ -99,7 +99,15 @@ def test_fused_decode_kernels(be):
     kc.check_attention_decode_fused(be, 1, 2, 128, 128)
     kc.check_attention_decode_fused(be, 1, 1, 64, 5)
     kc.check_attention_decode_fused(be, 1, 1, 128, 4100)   # cache capacity > 4096 keys: the single-pass kernel
-    kc.check_greedy_embed(be, 3, 320, 256)
+    kc.check_select_embed(be, 3, 320, 256)
+
+
+def test_device_sampling(be):
+    """temperature / top-k / top-p sampling in the select kernel against the HF warper semantics (small vocabulary)."""
+    kc.check_sampling(be, 64, 0.7, 0, 1.0, draws=512)
+    kc.check_sampling(be, 64, 0.2, 5, 1.0, draws=256)        # serve/cli.py: temperature 0.2 (+ HF's default top_k)
+    kc.check_sampling(be, 96, 1.0, 0, 0.6, draws=512)        # serve/chat.py: top_p
+    kc.check_sampling(be, 64, 1.3, 12, 0.8, draws=512)
 
 
 def test_strict_fp32_kernels(be):

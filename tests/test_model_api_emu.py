@@ -179,18 +179,18 @@ def test_keyword_stopping_criteria_runs_on_device(model):
     crit = KeywordsStoppingCriteria(["<stop>"], Tok(), t(ids[:1]))
     assert crit.device_stop_sequences() == [[stop_tok]]
     calls = []
-    orig = model.engine.generate_greedy
+    orig = model.engine.generate
 
     def spy(*a, **k):
         calls.append(k.get("stop_sequences"))
         return orig(*a, **k)
 
-    model.engine.generate_greedy = spy
+    model.engine.generate = spy
     try:
         fast = model.generate(t(ids[:1]), images=t(imgs[:1]), segs=t(segs[:1]), depths=t(deps[:1]), do_sample=False,
                               max_new_tokens=6, stopping_criteria=[crit], eos_token_id=-1)
     finally:
-        model.engine.generate_greedy = orig
+        model.engine.generate = orig
     assert calls == [[[stop_tok]]], "the criterion must be handed to the engine as a device-side stop"
 
     class HostOnly:   # same decision, but opaque to generate(): forces the per-token host loop
@@ -209,3 +209,86 @@ def test_keyword_stopping_criteria_runs_on_device(model):
     crit2.start_len = 0
     assert crit2(rows, None) is False
     assert crit2(torch.tensor([[5, 7, 8], [1, 7, 8]]), None) is True
+
+
+def test_sampling_and_streaming_stay_on_the_device(model):
+    """What serve/cli.py:122-132 asks for — do_sample=True, temperature=0.2, a streamer, KeywordsStoppingCriteria(["</s>"]) —
+    runs inside vc_generate (device-side sampling, callback-fed streamer): seeded runs repeat, the streamer sees exactly
+    the returned tokens one [B] tensor per step, and a tiny temperature collapses onto the greedy ids."""
+    g, cfg, ids, imgs, segs, deps = _fx()
+    t = torch.from_numpy
+    T = ids.shape[1]
+    calls = []
+    orig = model.engine.generate
+
+    def spy(*a, **k):
+        calls.append((k.get("do_sample"), k.get("top_k"), k.get("on_tokens") is not None))
+        return orig(*a, **k)
+
+    class Streamer:
+        def __init__(self):
+            self.got, self.ended = [], False
+
+        def put(self, v):
+            self.got.append(v.clone())
+
+        def end(self):
+            self.ended = True
+
+    model.engine.generate = spy
+    try:
+        st = Streamer()
+        a = model.generate(t(ids), images=t(imgs), segs=t(segs), depths=t(deps), do_sample=True, temperature=0.8,
+                           max_new_tokens=6, streamer=st, eos_token_id=-1, seed=123)
+        b = model.generate(t(ids), images=t(imgs), segs=t(segs), depths=t(deps), do_sample=True, temperature=0.8,
+                           max_new_tokens=6, eos_token_id=-1, seed=123)
+        c = model.generate(t(ids), images=t(imgs), segs=t(segs), depths=t(deps), do_sample=True, temperature=0.8,
+                           max_new_tokens=6, eos_token_id=-1, seed=124)
+        cold = model.generate(t(ids), images=t(imgs), segs=t(segs), depths=t(deps), do_sample=True, temperature=1e-6,
+                              max_new_tokens=6, eos_token_id=-1, seed=5)
+    finally:
+        model.engine.generate = orig
+    assert calls[0] == (True, 50, True), "sampling + streamer must reach the engine's device path (HF default top_k=50)"
+    assert torch.equal(a, b) and not torch.equal(a, c), "same seed -> same tokens; another seed -> another draw"
+    assert st.ended and len(st.got) == 1 + 6 and torch.equal(st.got[0], t(ids))      # prompt first, then one [B] per step
+    assert torch.equal(torch.stack(st.got[1:], 1), a[:, T:])
+    assert np.array_equal(cold[:, T:].numpy(), g["greedy_ids"][:, :6])              # T -> 0 is greedy
+    assert int(a[:, T:].min()) >= 0 and int(a[:, T:].max()) < cfg.vocab_size
+
+
+def test_attention_mask_contents_are_honoured_or_refused(model):
+    g, cfg, ids, imgs, segs, deps = _fx()
+    t = torch.from_numpy
+    ones = torch.ones_like(t(ids))
+    model(input_ids=t(ids), attention_mask=ones, images=t(imgs), segs=t(segs), depths=t(deps))      # all ones: fine
+    padded = ones.clone()
+    padded[1, 0] = 0
+    with pytest.raises(NotImplementedError, match="attention_mask"):
+        model(input_ids=t(ids), attention_mask=padded, images=t(imgs), segs=t(segs), depths=t(deps))
+    with pytest.raises(NotImplementedError, match="attention_mask"):
+        model.generate(t(ids), images=t(imgs), segs=t(segs), depths=t(deps), attention_mask=padded, max_new_tokens=2)
+
+
+def test_vision_tower_forward_and_feature_select(model):
+    """CLIPVisionTower.forward / feature_select (clip_encoder.py:29-51) on the tower object get_vision_tower() returns —
+    what the reference's encode_images calls (vcoder_ds_llava_arch.py:116-119)."""
+    gold = np.load(os.path.join(e2e_cases.GOLD, "tower_tiny.npz"))
+    tower = model.get_vision_tower()
+    imgs = torch.from_numpy(synth.synth_batch(3, model.config.vit_image_size)[0])
+    feats = tower(imgs)
+    assert tuple(feats.shape) == (3, tower.num_patches, tower.hidden_size) and feats.dtype == imgs.dtype
+    assert np.abs(feats.numpy() - gold["features"]).max() < 2e-2 * max(1.0, np.abs(gold["features"]).max())
+    as_list = tower([imgs[0], imgs[1]])                       # list of [3,S,S] images -> list of [1,P,D]
+    assert len(as_list) == 2 and torch.equal(as_list[1][0], feats[1])
+    half = tower(imgs.half())
+    assert half.dtype == torch.float16
+    from types import SimpleNamespace
+    hs = [torch.zeros(2, 17, 8) + i for i in range(5)]
+    assert torch.equal(tower.feature_select(SimpleNamespace(hidden_states=hs)), hs[-2][:, 1:])
+
+
+def test_loader_refuses_vcoder_it(tmp_path):
+    from vcoder_amd.model import load_pretrained_model
+
+    with pytest.raises(NotImplementedError, match="vcoder_it"):
+        load_pretrained_model(str(tmp_path), None, "vcoder_it_llava-v1.5-7b")

@@ -106,6 +106,52 @@ def test_tokenizer_placeholder_orders():
     assert [t for t in g["ds"] if t < 0] == [-200, -400, -300]
 
 
+def test_tokenizer_orders_without_bos():
+    """A tokenizer that prepends no BOS (the reference's offset == 0 paths, mm_utils.py:50-54,73-82): the seg helper keeps
+    ONLY [SEG] — the <image> placeholder is lost — and the counterparts reproduce that (fixture from the live reference)."""
+    class NoBos:
+        bos_token_id = 1
+
+        def __call__(self, text):
+            class R:
+                pass
+            r = R()
+            r.input_ids = [3 + (ord(c) % 50) for c in text]
+            return r
+
+    with open(os.path.join(GOLD, "tokenizer_orders.json")) as f:
+        g = json.load(f)
+    tk = NoBos()
+    assert mm_utils.tokenizer_depth_seg_token("ab <depth>\n<seg>\n<image>\ncd", tk) == g["ds_nobos"]
+    assert mm_utils.tokenizer_depth_seg_token("ab <seg>\n<image>\ncd", tk) == g["seg_nobos"]
+    assert mm_utils.tokenizer_image_token("ab <image>\ncd", tk) == g["img_nobos"]
+    assert [t for t in g["seg_nobos"] if t < 0] == [-300]
+
+
+@pytest.mark.parametrize("name", ["ds_list_two_each", "ds_list_uneven"])
+def test_oracle_list_image_form(name):
+    """list / 5-D image inputs (vcoder_ds_llava_arch.py:135-169) against the live reference's fixture."""
+    import e2e_cases
+
+    g, cfg, ids, lists = e2e_cases.list_fixture_inputs(name)
+    om = oracle_for(cfg.variant)
+    t = lambda l: [torch.from_numpy(a) for a in l]
+    emb, _ = om.prepare_inputs(ids.tolist(), t(lists[0]), t(lists[1]), t(lists[2]))
+    assert emb.shape[1] == int(g["spliced_len"])
+    assert np.abs(emb.numpy()[:, ::7, ::16] - g["embeds_sample"]).max() < 1e-6
+    full, _ = om.forward(ids.tolist(), t(lists[0]), t(lists[1]), t(lists[2]))
+    assert np.abs(full.numpy() - g["prefill_logits"]).max() < 1e-4
+
+
+def test_oracle_tower_boundary():
+    """cpu_ref.vit_forward == CLIPVisionTower.forward of the live reference (tests/golden/tower_tiny.npz)."""
+    g = np.load(os.path.join(GOLD, "tower_tiny.npz"))
+    cfg = vcfg.tiny(str(g["variant"]))
+    sd = cpu_ref.as_torch_state(synth.synth_state_dict(cfg, int(g["seed"]), only_prefix="model.vision_tower"))
+    feats = cpu_ref.vit_forward(torch.from_numpy(synth.synth_batch(3, cfg.vit_image_size)[0]), sd, cfg).numpy()
+    assert np.abs(feats - g["features"]).max() < 1e-5
+
+
 @pytest.mark.reference
 @pytest.mark.skipif(not ref_shim.reference_available(), reason="needs /root/reference (build container only)")
 def test_reference_tokenizers_live():
@@ -122,9 +168,15 @@ def test_reference_tokenizers_live():
             r.input_ids = [1] + [3 + (ord(c) % 50) for c in text]
             return r
 
-    tk = Fake()
-    for prompt in ("A chat. USER: <depth>\n<seg>\n<image>\nWhat is there? ASSISTANT:", "USER: <seg>\n<image>\nhi",
-                   "USER: <image>\ncount"):
-        fn_r = ref_mm.tokenizer_depth_seg_token if "<seg>" in prompt else ref_mm.tokenizer_image_token
-        fn_o = mm_utils.tokenizer_depth_seg_token if "<seg>" in prompt else mm_utils.tokenizer_image_token
-        assert list(fn_r(prompt, tk)) == list(fn_o(prompt, tk))
+    class NoBos(Fake):
+        def __call__(self, text):
+            r = Fake.__call__(self, text)
+            r.input_ids = r.input_ids[1:]
+            return r
+
+    for tk in (Fake(), NoBos()):
+        for prompt in ("A chat. USER: <depth>\n<seg>\n<image>\nWhat is there? ASSISTANT:", "USER: <seg>\n<image>\nhi",
+                       "USER: <image>\ncount", "<seg>\n<image>\nfirst USER: <seg>\n<image>\nsecond"):
+            fn_r = ref_mm.tokenizer_depth_seg_token if "<seg>" in prompt else ref_mm.tokenizer_image_token
+            fn_o = mm_utils.tokenizer_depth_seg_token if "<seg>" in prompt else mm_utils.tokenizer_image_token
+            assert list(fn_r(prompt, tk)) == list(fn_o(prompt, tk)), (type(tk).__name__, prompt)

@@ -28,6 +28,14 @@ class ModelCfg(C.Structure):
                 ("mm_proj_depth", C.c_int32), ("seg_proj_depth", C.c_int32), ("pad_token_id", C.c_int32)]
 
 
+class Sampling(C.Structure):
+    _fields_ = [("do_sample", C.c_int32), ("temperature", C.c_float), ("top_k", C.c_int32), ("top_p", C.c_float),
+                ("seed", C.c_uint64)]
+
+
+TOKEN_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32))
+
+
 def declare(lib: C.CDLL) -> C.CDLL:
     """Attach argtypes/restypes of the model-level ABI (the vck_* kernel entry points are called with
     explicit ctypes values by the tests)."""
@@ -61,6 +69,15 @@ def declare(lib: C.CDLL) -> C.CDLL:
     lib.vc_generate_greedy_stop.argtypes = [vp, vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, vp,
                                             C.POINTER(C.c_int)]
     lib.vc_generate_greedy_stop.restype = C.c_int
+    lib.vc_generate.argtypes = [vp, vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, C.POINTER(Sampling), TOKEN_CB,
+                                vp, i32, vp, C.POINTER(C.c_int)]
+    lib.vc_generate.restype = C.c_int
+    lib.vc_vision_tower_forward.argtypes = [vp, vp, i32, i32, vp]
+    lib.vc_vision_tower_forward.restype = C.c_int
+    lib.vc_set_image_counts.argtypes = [vp, vp, vp, vp, i32]
+    lib.vc_set_image_counts.restype = C.c_int
+    lib.vc_model_reserve_decode.argtypes = [vp, i32]
+    lib.vc_model_reserve_decode.restype = C.c_int
     lib.vc_last_spliced_len.argtypes = [vp]
     lib.vc_last_spliced_len.restype = C.c_int
     lib.vc_profile_decode_gemv.argtypes = [vp, i32, i32, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]

@@ -411,7 +411,8 @@ __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeF
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.x, b = blockIdx.y;
     const size_t bh = (size_t)b * p.H + h;
-    const int pos = *p.pos_dev;
+    if (p.active_dev != nullptr && p.active_dev[(size_t)b * p.pos_stride] == 0) return;  // a free row of the decode pool
+    const int pos = p.pos_dev[(size_t)b * p.pos_stride];
     const int ctx = pos + 1;
     const int D = p.H * HD;
     bf16_t* kbase = p.k + bh * p.kv_stride * HD;
@@ -555,7 +556,8 @@ __global__ __launch_bounds__(512) void attention_decode_flash_kernel(AttnDecodeF
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.x, b = blockIdx.y;
     const size_t bh = (size_t)b * p.H + h;
-    const int pos = *p.pos_dev;
+    if (p.active_dev != nullptr && p.active_dev[(size_t)b * p.pos_stride] == 0) return;  // a free row of the decode pool
+    const int pos = p.pos_dev[(size_t)b * p.pos_stride];
     const int ctx = pos + 1;
     const int D = p.H * HD;
     bf16_t* kbase = p.k + bh * p.kv_stride * HD;

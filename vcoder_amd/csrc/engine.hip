@@ -29,6 +29,8 @@ using namespace vc;
 static const int IMAGE_TOKEN_INDEX = -200;  // vcoder_llava/constants.py:5
 static const int SEG_TOKEN_INDEX = -300;    // constants.py:8
 static const int DEPTH_TOKEN_INDEX = -400;  // constants.py:11
+static const int VC_MAX_ROWS = 16;          // sequences one prefill / one session loop handles
+static const int VC_POOL_ROWS = 32;         // rows of the shared decode pool (two MFMA token-slot groups)
 
 struct vc_ctx {
     int device = 0;
@@ -135,23 +137,24 @@ struct vc_model {
     // ViT workspace
     Buf v_pixels, v_cols, v_patches, v_x, v_xn, v_qkv, v_q, v_k, v_vt, v_attn, v_h, v_sel, v_mid, feats;
     int feat_rows[3] = {0, 0, 0}, feat_off[3] = {0, 0, 0};
+    // list / 5-D image form (vcoder_ds_llava_arch.py:135-169): images per sample and modality for the NEXT prefill
+    // (vc_set_image_counts; empty = one image per sample), and the running first-image index of every sample
+    std::vector<int> img_counts[3], img_first[3];
+    int reserve_new = 64;         // KV slots a vc_prefill keeps free behind the prompt (vc_model_reserve_decode)
     // LLM workspace
     Buf x, xn, qkv, q, attn, h, kc, vtc, row_src, last_idx, xl, logits_all;
     int capB = 0, capS = 0;  // KV capacity
     int curB = 0, curS = 0, cur_pos = -1;
-    // decode state
-    Buf x_dec, xg_dec, qkv_dec, attn_dec, h_dec, logits, next_tok, finished, out_ids, scalars, dsum, ssq;
+    // decode state of this session's own loop (vc_prefill / vc_decode_step, strict mode, generate with the pool off)
+    Buf x_dec, xg_dec, qkv_dec, attn_dec, h_dec, logits, next_tok, out_ids, rows, dsum, ssq;
     Buf sk_scratch, sk_counters;  // split-K partials / arrival counters of the decode GEMV (few-tile matrices)
     Buf gemm_ws;                  // fp32 workspace of the GEMM's split-K remainder round (64 MiB)
-    Buf stop_tab, prompt_tail;    // device-side keyword stop of generate (fixed capacity: the decode graph keeps the pointers)
-    int n_stop = 0;
+    int out_stride = 0;           // out_ids ints per row
     int last_S = 0;               // spliced prompt length of the last prefill / generate
-    int out_cap = 0;
-    int* step_dev() { return scalars.as<int>(); }
-    int* pos_dev() { return scalars.as<int>() + 1; }
-    int* ctx_dev() { return scalars.as<int>() + 2; }
-    hipGraphExec_t graph = nullptr;
-    int graph_B = 0, graph_eos = -2, graph_pad = 0, graph_maxnew = 0;
+    hipGraphExec_t graph = nullptr;  // one decode step over graph_rows rows (parameters live in the RowState records)
+    int graph_rows = 0;
+    struct vc_pool* pool = nullptr;  // the root model's shared decode pool (created on first use; sessions point at it)
+    vc_model* root = nullptr;        // the model that owns the weights (itself for a root)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float t_encode = 0, t_prefill = 0, t_decode = 0;
 };
@@ -238,10 +241,27 @@ int place_tensor(vc_model* m, const std::string& raw_key, const void* src, int d
     const std::string key = canon_key(raw_key);
     size_t numel = 1;
     for (int i = 0; i < ndim; ++i) numel *= (size_t)shape[i];
+    // full shape comparison (a transposed [K,N] matrix has the right element count and the wrong meaning); dimensions of
+    // extent 1 are ignored so that [D] / [1,D] / [D,1,1] spellings of a vector all pass, and the patch embedding may come
+    // as [Dv,3,P,P] or flattened [Dv, 3*P*P]
     auto expect = [&](std::initializer_list<int64_t> dims) {
-        size_t e = 1;
-        for (auto d : dims) e *= (size_t)d;
-        REQUIRE(e == numel, VC_ERR_INVALID, "%s: expected %zu elements, got %zu", raw_key.c_str(), e, numel);
+        std::vector<int64_t> want, got;
+        for (auto d : dims)
+            if (d != 1) want.push_back(d);
+        for (int i = 0; i < ndim; ++i)
+            if (shape[i] != 1) got.push_back(shape[i]);
+        bool ok = want == got;
+        if (!ok && want.size() == 2 && got.size() > 2 && got[0] == want[0]) {  // conv weight [out, c, kh, kw]
+            int64_t r = 1;
+            for (size_t i = 1; i < got.size(); ++i) r *= got[i];
+            ok = r == want[1];
+        }
+        if (!ok) {
+            std::string w, g;
+            for (auto d : want) w += (w.empty() ? "" : ",") + std::to_string(d);
+            for (auto d : got) g += (g.empty() ? "" : ",") + std::to_string(d);
+            REQUIRE(false, VC_ERR_INVALID, "%s: expected shape [%s], got [%s]", raw_key.c_str(), w.c_str(), g.c_str());
+        }
     };
     const int D = c.hidden, F = c.ffn, V = c.vocab, Dv = c.vit_hidden, Fv = c.vit_ffn;
     // ---- dead at inference or simply unused
@@ -337,71 +357,103 @@ void gemm(vc_model* m, const bf16_t* A, const bf16_t* W, const float* bias, void
     }
     launch_gemm(a, epi, m->st);
 }
+// Everything one decode step touches besides the weights: the buffers of a session's own loop or of the shared pool.
+struct LoopView {
+    hipStream_t st;
+    bf16_t *kc, *vtc;  // [L][capR][H][capS][hd] K key-major / [L][capR][H][hd][capS] V transposed
+    int capR, capS;
+    int* rows;         // RowState records
+    float* x_dec;
+    bf16_t *xg_dec, *qkv_dec, *attn_dec, *h_dec;
+    float* logits;
+    int *next_tok, *out_ids;
+    float *ssq, *sk_scratch;
+    unsigned* sk_counters;
+};
+
 // decode-time linear over `X` (bf16 [M, K]).  use_rstd: X is the xg operand (bf16(x * g)) and the output is scaled by the
 // rows' 1/rms from the ssq partials; next_norm_w (RESID epilogue only): publish the ssq partials of the updated residual
 // rows and the next consumer's xg operand
-void gemv(vc_model* m, const bf16_t* X, const bf16_t* Wp, const float* wscale, void* out, int M, int N, int K, int ldo,
-          int epi, bool use_rstd = false, const float* next_norm_w = nullptr) {
+void gemv(vc_model* m, const LoopView& v, const bf16_t* X, const bf16_t* Wp, const float* wscale, void* out, int M, int N, int K,
+          int ldo, int epi, bool use_rstd = false, const float* next_norm_w = nullptr) {
     const size_t esz = (epi == GEMV_F32 || epi == GEMV_RESID_F32) ? 4 : 2;
     const int np = m->npart;
-    for (int m0 = 0; m0 < M; m0 += 16) {  // the skinny kernel holds 16 token slots; larger batches re-stream
+    for (int m0 = 0; m0 < M; m0 += VC_GEMV_MAX_M) {  // the skinny kernel holds VC_GEMV_MAX_M token slots per weight pass
         GemvArgs a{};
         a.X = X + (size_t)m0 * K;
         a.Wp = Wp;
         a.wscale = wscale;
         a.out = reinterpret_cast<char*>(out) + (size_t)m0 * ldo * esz;
-        a.M = std::min(16, M - m0);
+        a.M = std::min(VC_GEMV_MAX_M, M - m0);
         a.N = N;
         a.K = K;
         a.ldo = ldo;
-        a.ssq_in = use_rstd ? m->ssq.as<float>() + (size_t)m0 * np : nullptr;
+        a.ssq_in = use_rstd ? v.ssq + (size_t)m0 * np : nullptr;
         if (next_norm_w) {
-            a.ssq_out = m->ssq.as<float>() + (size_t)m0 * np;
+            a.ssq_out = v.ssq + (size_t)m0 * np;
             a.xg_w = next_norm_w;
-            a.xg_out = m->xg_dec.as<bf16_t>() + (size_t)m0 * N;
+            a.xg_out = v.xg_dec + (size_t)m0 * N;
         }
         a.npart = np;
         a.eps = m->c.rms_eps;
         if (N / 16 <= 512) {  // o_proj / down: the launcher may split K over several workgroups per tile
-            a.sk_scratch = m->sk_scratch.as<float>();
-            a.sk_counters = m->sk_counters.as<unsigned>();
+            a.sk_scratch = v.sk_scratch;
+            a.sk_counters = v.sk_counters;
         }
-        launch_gemv(a, epi, m->st);
+        launch_gemv(a, epi, v.st);
     }
 }
 
-// the GEMVs of one decode step; `between(l)` runs after the qkv projection of layer l (the attention)
+// the GEMVs of one decode step over the first M rows; `between(l)` runs after the qkv projection of layer l (the attention)
 template <class F>
-void decode_linears(vc_model* m, int B, F&& between) {
+void decode_linears(vc_model* m, const LoopView& v, int M, F&& between) {
     const vc_model_cfg& c = m->c;
     const int D = c.hidden, Fd = c.ffn;
-    const bf16_t* xg = m->xg_dec.as<bf16_t>();
+    const bf16_t* xg = v.xg_dec;
     for (int l = 0; l < c.layers; ++l) {
         const LlmLayer& L = m->llm[l];
         const float* next_in = l + 1 < c.layers ? m->llm[l + 1].in_norm : m->final_norm;
-        gemv(m, xg, L.qkv_p, L.qkv_s, m->qkv_dec.p, B, 3 * D, D, 3 * D, GEMV_BF16, true);                          // K11+K12
-        between(l);                                                                                                // K13-K15
-        gemv(m, m->attn_dec.as<bf16_t>(), L.o_p, L.o_s, m->x_dec.p, B, D, D, D, GEMV_RESID_F32, false, L.post_norm);  // K16
-        gemv(m, xg, L.gu_p, L.gu_s, m->h_dec.p, B, 2 * Fd, D, Fd, GEMV_SWIGLU, true);                              // K11+K17
-        gemv(m, m->h_dec.as<bf16_t>(), L.down_p, L.down_s, m->x_dec.p, B, D, Fd, D, GEMV_RESID_F32, false, next_in);  // K17
+        gemv(m, v, xg, L.qkv_p, L.qkv_s, v.qkv_dec, M, 3 * D, D, 3 * D, GEMV_BF16, true);                      // K11+K12
+        between(l);                                                                                          // K13-K15
+        gemv(m, v, v.attn_dec, L.o_p, L.o_s, v.x_dec, M, D, D, D, GEMV_RESID_F32, false, L.post_norm);          // K16
+        gemv(m, v, xg, L.gu_p, L.gu_s, v.h_dec, M, 2 * Fd, D, Fd, GEMV_SWIGLU, true);                          // K11+K17
+        gemv(m, v, v.h_dec, L.down_p, L.down_s, v.x_dec, M, D, Fd, D, GEMV_RESID_F32, false, next_in);          // K17
     }
-    gemv(m, xg, m->lm_head_p, nullptr, m->logits.p, B, c.vocab, D, c.vocab, GEMV_F32, true);                        // K11+K18
+    gemv(m, v, xg, m->lm_head_p, nullptr, v.logits, M, c.vocab, D, c.vocab, GEMV_F32, true);                    // K11+K18
 }
 
 // ------------------------------------------------------------------------------------------------
-// ViT: pixels of all modalities batched into ONE tower pass (the tower weights are shared)
-void run_vit_and_adapters(vc_model* m, const float* const pix[3], int pixels_on_device, int B) {
+// ViT: pixels of all modalities batched into ONE tower pass (the tower weights are shared).  A modality may carry
+// any number of images (the reference's list / 5-D image form gives a sample several images, vcoder_ds_llava_arch.py:
+// 135-143); the common 4-D form has one image per sample and modality.
+struct PixSet {
+    const float* p[3];  // IMAGE, SEG, DEPTH pixel blocks (nullptr = modality absent)
+    int n[3];           // images in each block
+};
+
+// CLIPVisionTower.forward (clip_encoder.py:39-51) up to hidden_states[select_layer]: leaves the fp32 residual stream of
+// all N images in v_x [N*Tv, Dv]; returns N and the block order
+int run_vit_tower(vc_model* m, const PixSet& in, int pixels_on_device, int order[3], int first_img[3]) {
     const vc_model_cfg& c = m->c;
-    const int Dv = c.vit_hidden, Fv = c.vit_ffn, H = c.vit_heads, Tv = m->Tv, P = m->P, D = c.hidden;
-    int nmod = 0, order[3];
-    for (int k = 0; k < 3; ++k)
-        if (pix[k]) order[nmod++] = k;
-    const int N = nmod * B;
+    const int Dv = c.vit_hidden, Fv = c.vit_ffn, H = c.vit_heads, Tv = m->Tv, P = m->P;
+    int nmod = 0, N = 0;
+    for (int k = 0; k < 3; ++k) {
+        first_img[k] = 0;
+        if (in.p[k] && in.n[k] > 0) {
+            order[nmod++] = k;
+            first_img[k] = N;
+            N += in.n[k];
+        }
+    }
+    REQUIRE(N > 0, VC_ERR_INVALID, "no images");
     const size_t img_elems = (size_t)3 * c.vit_image * c.vit_image;
     m->v_pixels.ensure((size_t)N * img_elems * 4);
-    for (int i = 0; i < nmod; ++i)
-        HIPCHK(hipMemcpyAsync(m->v_pixels.as<float>() + (size_t)i * B * img_elems, pix[order[i]], (size_t)B * img_elems * 4,
+    for (int i = 0; i < nmod; ++i) {
+        const int k = order[i];
+        HIPCHK(hipMemcpyAsync(m->v_pixels.as<float>() + (size_t)first_img[k] * img_elems, in.p[k],
+                              (size_t)in.n[k] * img_elems * 4,
                               pixels_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, m->st));
+    }
     const int M = N * Tv, Mp = N * P;
     const int Ts = (int)rup(Tv, 64);
     m->v_cols.ensure((size_t)Mp * m->Kpad * 2);
@@ -433,35 +485,44 @@ void run_vit_and_adapters(vc_model* m, const float* const pix[3], int pixels_on_
         gemm(m, m->v_xn.as<bf16_t>(), L.fc1_w, L.fc1_b, m->v_h.p, M, Fv, Dv, Fv, EPI_BF16_QGELU);
         gemm(m, m->v_h.as<bf16_t>(), L.fc2_w, L.fc2_b, m->v_x.p, M, Dv, Fv, Dv, EPI_RESID_F32);
     }
-    // feature_select (hidden_states[select_layer], drop CLS) + adapters
+    // feature_select (clip_encoder.py:29-37): hidden_states[select_layer] is the last layer evaluated; drop CLS for 'patch'
     const int skip = c.vit_keep_cls ? 0 : 1;
-    const int R = Tv - skip;  // feature rows per image
+    const int R = Tv - skip;
     m->v_sel.ensure((size_t)N * R * Dv * 2);
     launch_select_rows_bf16(m->v_x.as<float>(), m->v_sel.as<bf16_t>(), N, Tv, skip, Dv, m->st);
+    return N;
+}
+
+void run_vit_and_adapters(vc_model* m, const PixSet& in, int pixels_on_device) {
+    const vc_model_cfg& c = m->c;
+    const int Dv = c.vit_hidden, D = c.hidden;
+    int order[3], first_img[3];
+    const int N = run_vit_tower(m, in, pixels_on_device, order, first_img);
+    const int R = m->Tv - (c.vit_keep_cls ? 0 : 1);  // feature rows per image
     m->feats.ensure((size_t)N * R * D * 2);
     m->v_mid.ensure((size_t)N * R * D * 2);
     for (int k = 0; k < 3; ++k) m->feat_rows[k] = 0;
-    for (int i = 0; i < nmod; ++i) {
-        const int mod = order[i];
+    for (int mod = 0; mod < 3; ++mod) {
+        if (!(in.p[mod] && in.n[mod] > 0)) continue;
         // images -> mm_projector; seg AND depth -> seg_mm_projector (quirk 1, vcoder_ds_llava_arch.py:111-114);
         // mm2_projector is unreachable (quirk 2, :137,145)
         const Projector& pj = mod == VC_MOD_IMAGE ? m->mm : m->seg;
-        const int rows = B * R;
-        const bf16_t* in = m->v_sel.as<bf16_t>() + (size_t)i * rows * Dv;
-        bf16_t* out = m->feats.as<bf16_t>() + (size_t)i * rows * D;
-        m->feat_off[mod] = i * rows;
+        const int rows = in.n[mod] * R;
+        const bf16_t* src = m->v_sel.as<bf16_t>() + (size_t)first_img[mod] * R * Dv;
+        bf16_t* out = m->feats.as<bf16_t>() + (size_t)first_img[mod] * R * D;
+        m->feat_off[mod] = first_img[mod] * R;
         m->feat_rows[mod] = rows;
         if (pj.depth == 0) {
             REQUIRE(Dv == D, VC_ERR_INVALID, "identity projector needs mm_hidden_size == hidden_size");
-            HIPCHK(hipMemcpyAsync(out, in, (size_t)rows * D * 2, hipMemcpyDeviceToDevice, m->st));
+            HIPCHK(hipMemcpyAsync(out, src, (size_t)rows * D * 2, hipMemcpyDeviceToDevice, m->st));
             continue;
         }
-        const bf16_t* cur = in;
+        const bf16_t* cur = src;
         int K = Dv;
         for (int l = 0; l < pj.depth; ++l) {
             const bool last = l == pj.depth - 1;
-            bf16_t* dst = last ? out : (l % 2 == 0 ? m->v_mid.as<bf16_t>() : m->v_h.as<bf16_t>());
             if (!last && l % 2 == 1) m->v_h.ensure((size_t)rows * D * 2);
+            bf16_t* dst = last ? out : (l % 2 == 0 ? m->v_mid.as<bf16_t>() : m->v_h.as<bf16_t>());
             gemm(m, cur, pj.w[l], pj.b[l], dst, rows, D, K, D, last ? EPI_BF16 : EPI_BF16_GELU);
             cur = dst;
             K = D;
@@ -477,18 +538,27 @@ void gemm32(vc_model* m, const float* A, const bf16_t* W, const float* bias, flo
     launch_gemm_f32(a, epi, m->st);
 }
 
-void run_vit_and_adapters_strict(vc_model* m, const float* const pix[3], int pixels_on_device, int B) {
+int run_vit_tower_strict(vc_model* m, const PixSet& in, int pixels_on_device, int order[3], int first_img[3]) {
     const vc_model_cfg& c = m->c;
     const int Dv = c.vit_hidden, Fv = c.vit_ffn, H = c.vit_heads, Tv = m->Tv, P = m->P, D = c.hidden;
-    int nmod = 0, order[3];
-    for (int k = 0; k < 3; ++k)
-        if (pix[k]) order[nmod++] = k;
-    const int N = nmod * B;
+    int nmod = 0, N = 0;
+    for (int k = 0; k < 3; ++k) {
+        first_img[k] = 0;
+        if (in.p[k] && in.n[k] > 0) {
+            order[nmod++] = k;
+            first_img[k] = N;
+            N += in.n[k];
+        }
+    }
+    REQUIRE(N > 0, VC_ERR_INVALID, "no images");
     const size_t img_elems = (size_t)3 * c.vit_image * c.vit_image;
     m->v_pixels.ensure((size_t)N * img_elems * 4);
-    for (int i = 0; i < nmod; ++i)
-        HIPCHK(hipMemcpyAsync(m->v_pixels.as<float>() + (size_t)i * B * img_elems, pix[order[i]], (size_t)B * img_elems * 4,
+    for (int i = 0; i < nmod; ++i) {
+        const int k = order[i];
+        HIPCHK(hipMemcpyAsync(m->v_pixels.as<float>() + (size_t)first_img[k] * img_elems, in.p[k],
+                              (size_t)in.n[k] * img_elems * 4,
                               pixels_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, m->st));
+    }
     const int M = N * Tv, Mp = N * P;
     m->s_cols.ensure((size_t)Mp * m->Kpatch * 4);
     m->s_patches.ensure((size_t)Mp * Dv * 4);
@@ -525,23 +595,32 @@ void run_vit_and_adapters_strict(vc_model* m, const float* const pix[3], int pix
     const int R = Tv - skip;
     m->s_sel.ensure((size_t)N * R * Dv * 4);
     launch_select_rows_f32(x, m->s_sel.as<float>(), N, Tv, skip, Dv, m->st);
+    return N;
+}
+
+void run_vit_and_adapters_strict(vc_model* m, const PixSet& in, int pixels_on_device) {
+    const vc_model_cfg& c = m->c;
+    const int Dv = c.vit_hidden, D = c.hidden;
+    int order[3], first_img[3];
+    const int N = run_vit_tower_strict(m, in, pixels_on_device, order, first_img);
+    const int R = m->Tv - (c.vit_keep_cls ? 0 : 1);
     m->s_feats.ensure((size_t)N * R * D * 4);
     m->s_mid.ensure((size_t)N * R * D * 4);
     for (int k = 0; k < 3; ++k) m->feat_rows[k] = 0;
-    for (int i = 0; i < nmod; ++i) {
-        const int mod = order[i];
+    for (int mod = 0; mod < 3; ++mod) {
+        if (!(in.p[mod] && in.n[mod] > 0)) continue;
         const Projector& pj = mod == VC_MOD_IMAGE ? m->mm : m->seg;  // quirk 1: depth -> seg_mm_projector
-        const int rows = B * R;
-        const float* in = m->s_sel.as<float>() + (size_t)i * rows * Dv;
-        float* out = m->s_feats.as<float>() + (size_t)i * rows * D;
-        m->feat_off[mod] = i * rows;
+        const int rows = in.n[mod] * R;
+        const float* src = m->s_sel.as<float>() + (size_t)first_img[mod] * R * Dv;
+        float* out = m->s_feats.as<float>() + (size_t)first_img[mod] * R * D;
+        m->feat_off[mod] = first_img[mod] * R;
         m->feat_rows[mod] = rows;
         if (pj.depth == 0) {
             REQUIRE(Dv == D, VC_ERR_INVALID, "identity projector needs mm_hidden_size == hidden_size");
-            HIPCHK(hipMemcpyAsync(out, in, (size_t)rows * D * 4, hipMemcpyDeviceToDevice, m->st));
+            HIPCHK(hipMemcpyAsync(out, src, (size_t)rows * D * 4, hipMemcpyDeviceToDevice, m->st));
             continue;
         }
-        const float* cur = in;
+        const float* cur = src;
         int K = Dv;
         for (int l = 0; l < pj.depth; ++l) {
             const bool last = l == pj.depth - 1;
@@ -619,10 +698,14 @@ void plan_rows(vc_model* m, const int64_t* ids, int B, int T, bool has_seg, cons
             rows.push_back({0, (int)p[i]});
         }
     };
+    // features[idx] of the reference: the block of sample idx — R rows per image, all images of the sample flattened
+    // (`[x.flatten(0, 1) for x in image_features]`, vcoder_ds_llava_arch.py:143); one image per sample in the 4-D form
     auto feat = [&](std::vector<RowSrc>& rows, int mod, int idx, bool emit) {
-        REQUIRE(idx * R < m->feat_rows[mod], VC_ERR_INDEX, "index %d is out of bounds for dimension 0 with size %d", idx,
-                m->feat_rows[mod] / R);
-        for (int r = 0; emit && r < R; ++r) rows.push_back({1, m->feat_off[mod] + idx * R + r});
+        const std::vector<int>& first = m->img_first[mod];
+        const int nblocks = first.empty() ? m->feat_rows[mod] / R : (int)first.size() - 1;
+        REQUIRE(idx < nblocks, VC_ERR_INDEX, "index %d is out of bounds for dimension 0 with size %d", idx, nblocks);
+        const int i0 = first.empty() ? idx : first[idx], i1 = first.empty() ? idx + 1 : first[idx + 1];
+        for (int r = i0 * R; emit && r < i1 * R; ++r) rows.push_back({1, m->feat_off[mod] + r});
     };
     auto find = [](const int64_t* p, int n, int tok) {
         for (int i = 0; i < n; ++i)
@@ -667,6 +750,10 @@ void plan_rows(vc_model* m, const int64_t* ids, int B, int T, bool has_seg, cons
             }
         }
         if (variant == VC_VARIANT_VCODER_DS) {
+            // a row with several <depth> placeholders advances the depth index more than once: later rows then index past
+            // the per-sample list, where the reference raises IndexError (vcoder_ds_llava_arch.py:246)
+            REQUIRE(!depth_zero || dep_i < (int)depth_zero->size(), VC_ERR_INDEX, "list index out of range (depth index %d of %zu)",
+                    dep_i, depth_zero ? depth_zero->size() : (size_t)0);
             const bool dz = depth_zero ? (*depth_zero)[dep_i] : true;
             if (!dz) {
                 for (int at; (at = find(cur, n, DEPTH_TOKEN_INDEX)) >= 0;) {
@@ -684,23 +771,10 @@ void plan_rows(vc_model* m, const int64_t* ids, int B, int T, bool has_seg, cons
     }
 }
 
-void ensure_llm(vc_model* m, int B, int S_total) {
+// workspaces of a prefill of B sequences of up to Scap rows (independent of where the KV cache lives)
+void ensure_prefill_ws(vc_model* m, int B, int Scap) {
     const vc_model_cfg& c = m->c;
-    const int D = c.hidden, F = c.ffn, H = c.heads;
-    const int Scap = (int)rup(S_total, 64);
-    REQUIRE(B <= 16, VC_ERR_INVALID, "batch %d: at most 16 sequences per GPU replica (shard larger batches over ranks)", B);
-    REQUIRE(Scap <= c.max_positions, VC_ERR_INVALID, "sequence %d exceeds max_position_embeddings=%d", Scap, c.max_positions);
-    if (B != m->capB || Scap > m->capS) {
-        const int newS = std::max(Scap, m->capB == B ? m->capS : 0);
-        const size_t per_layer = (size_t)B * H * newS * m->hd;
-        m->kc.release();
-        m->vtc.release();
-        m->kc.ensure(per_layer * c.layers * 2, true);
-        m->vtc.ensure(per_layer * c.layers * 2, true);
-        m->capB = B;
-        m->capS = newS;
-        if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
-    }
+    const int D = c.hidden, F = c.ffn;
     const size_t Mrows = (size_t)B * Scap;
     m->x.ensure(Mrows * D * 4);
     m->xn.ensure(Mrows * D * 2);
@@ -712,37 +786,142 @@ void ensure_llm(vc_model* m, int B, int S_total) {
     const int Bp = (int)rup(B, 16);
     m->last_idx.ensure(Bp * 4);
     m->xl.ensure((size_t)Bp * D * 2, true);
+    m->logits.ensure((size_t)Bp * c.vocab * 4, true);
+}
+
+void drop_graph(vc_model* m) {
+    if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
+}
+
+// the session's own decode loop: KV cache for B sequences of S_total positions + the per-step buffers
+void ensure_llm(vc_model* m, int B, int S_total) {
+    const vc_model_cfg& c = m->c;
+    const int D = c.hidden, F = c.ffn, H = c.heads;
+    const int Scap = (int)rup(S_total, 64);
+    REQUIRE(B <= VC_MAX_ROWS, VC_ERR_INVALID, "batch %d: at most %d sequences per GPU replica (shard larger batches over ranks)",
+            B, VC_MAX_ROWS);
+    REQUIRE(Scap <= c.max_positions, VC_ERR_INVALID, "sequence %d exceeds max_position_embeddings=%d", Scap, c.max_positions);
+    if (B != m->capB || Scap > m->capS) {
+        const int newS = std::max(Scap, m->capB == B ? m->capS : 0);
+        const size_t per_layer = (size_t)B * H * newS * m->hd;
+        m->kc.release();
+        m->vtc.release();
+        m->kc.ensure(per_layer * c.layers * 2, true);
+        m->vtc.ensure(per_layer * c.layers * 2, true);
+        m->capB = B;
+        m->capS = newS;
+        drop_graph(m);
+    }
+    const void* before[] = {m->x_dec.p, m->xg_dec.p, m->qkv_dec.p, m->attn_dec.p, m->h_dec.p, m->next_tok.p, m->rows.p, m->ssq.p,
+                            m->logits.p};
+    ensure_prefill_ws(m, B, Scap);
+    const int Bp = (int)rup(B, 16);
     m->x_dec.ensure((size_t)Bp * D * 4, true);
     m->xg_dec.ensure((size_t)Bp * D * 2, true);
     m->qkv_dec.ensure((size_t)Bp * 3 * D * 2, true);
     m->attn_dec.ensure((size_t)Bp * D * 2, true);
     m->h_dec.ensure((size_t)Bp * F * 2, true);
-    m->logits.ensure((size_t)Bp * c.vocab * 4, true);
     m->next_tok.ensure(Bp * 4, true);
-    m->finished.ensure(Bp * 4, true);
-    m->scalars.ensure(64, true);
+    m->rows.ensure((size_t)Bp * RS_STRIDE * 4, true);
     m->dsum.ensure(Bp * 4, true);
     m->ssq.ensure((size_t)Bp * m->npart * 4, true);
     m->sk_scratch.ensure((size_t)4 * 512 * 256 * 4);
     m->sk_counters.ensure(512 * 4, true);
-    m->stop_tab.ensure((1 + VC_MAX_STOP * (1 + VC_MAX_STOP_LEN)) * 4, true);
-    m->prompt_tail.ensure((size_t)Bp * (VC_MAX_STOP_LEN - 1) * 4, true);
+    const void* after[] = {m->x_dec.p, m->xg_dec.p, m->qkv_dec.p, m->attn_dec.p, m->h_dec.p, m->next_tok.p, m->rows.p, m->ssq.p,
+                           m->logits.p};
+    for (size_t i = 0; i < sizeof(before) / sizeof(before[0]); ++i)
+        if (before[i] != after[i]) drop_graph(m);  // the decode graph bakes these pointers in
 }
 
-bf16_t* kcache(vc_model* m, int l) { return m->kc.as<bf16_t>() + (size_t)l * m->capB * m->c.heads * m->capS * m->hd; }
-bf16_t* vtcache(vc_model* m, int l) { return m->vtc.as<bf16_t>() + (size_t)l * m->capB * m->c.heads * m->capS * m->hd; }
+LoopView session_view(vc_model* m) {
+    LoopView v{};
+    v.st = m->st;
+    v.kc = m->kc.as<bf16_t>();
+    v.vtc = m->vtc.as<bf16_t>();
+    v.capR = m->capB;
+    v.capS = m->capS;
+    v.rows = m->rows.as<int>();
+    v.x_dec = m->x_dec.as<float>();
+    v.xg_dec = m->xg_dec.as<bf16_t>();
+    v.qkv_dec = m->qkv_dec.as<bf16_t>();
+    v.attn_dec = m->attn_dec.as<bf16_t>();
+    v.h_dec = m->h_dec.as<bf16_t>();
+    v.logits = m->logits.as<float>();
+    v.next_tok = m->next_tok.as<int>();
+    v.out_ids = m->out_ids.as<int>();
+    v.ssq = m->ssq.as<float>();
+    v.sk_scratch = m->sk_scratch.as<float>();
+    v.sk_counters = m->sk_counters.as<unsigned>();
+    return v;
+}
 
-void run_prefill_layers(vc_model* m, int B, int S) {
+// where a prefill writes its keys / values: rows [row0, row0 + B) of a cache with capR rows of capS positions
+struct KvTarget {
+    bf16_t *kc, *vtc;
+    int capR, capS, row0;
+};
+bf16_t* kcache(const vc_model* m, const KvTarget& t, int l) {
+    return t.kc + ((size_t)l * t.capR + t.row0) * m->c.heads * t.capS * m->hd;
+}
+bf16_t* vtcache(const vc_model* m, const KvTarget& t, int l) {
+    return t.vtc + ((size_t)l * t.capR + t.row0) * m->c.heads * t.capS * m->hd;
+}
+KvTarget session_kv(vc_model* m) { return KvTarget{m->kc.as<bf16_t>(), m->vtc.as<bf16_t>(), m->capB, m->capS, 0}; }
+bf16_t* kcache(const LoopView& v, const vc_model* m, int l) { return v.kc + (size_t)l * v.capR * m->c.heads * v.capS * m->hd; }
+bf16_t* vtcache(const LoopView& v, const vc_model* m, int l) { return v.vtc + (size_t)l * v.capR * m->c.heads * v.capS * m->hd; }
+
+// The decode loop outran the cache (a host-driven vc_decode_step loop past the reserve of its prefill): re-allocate with
+// room for `need` positions and move the live prefix — K rows are contiguous per (layer, sample, head), V^T rows are
+// hd x capS, so both are strided 2-D copies.  The decode graph bakes the cache pointers in and is re-captured.
+void grow_kv(vc_model* m, int need) {
+    const vc_model_cfg& c = m->c;
+    const int oldS = m->capS, live = m->cur_pos;
+    int newS = (int)rup(std::max(need, std::min(2 * oldS, c.max_positions)), 64);
+    newS = std::min(newS, c.max_positions / 64 * 64);
+    REQUIRE(newS >= need, VC_ERR_STATE, "KV cache full: position %d exceeds max_position_embeddings=%d", need, c.max_positions);
+    const size_t heads = (size_t)c.layers * m->capB * c.heads;
+    Buf nk, nv;
+    nk.ensure(heads * newS * m->hd * 2, true);
+    nv.ensure(heads * newS * m->hd * 2, true);
+    HIPCHK(hipMemcpy2DAsync(nk.p, (size_t)newS * m->hd * 2, m->kc.p, (size_t)oldS * m->hd * 2, (size_t)live * m->hd * 2, heads,
+                            hipMemcpyDeviceToDevice, m->st));
+    HIPCHK(hipMemcpy2DAsync(nv.p, (size_t)newS * 2, m->vtc.p, (size_t)oldS * 2, (size_t)live * 2, heads * m->hd,
+                            hipMemcpyDeviceToDevice, m->st));
+    HIPCHK(hipStreamSynchronize(m->st));
+    m->kc.release();
+    m->vtc.release();
+    m->kc = nk;
+    m->vtc = nv;
+    if (m->precision && m->s_capS == oldS && m->s_capB == m->capB) {  // the strict path's fp32 caches (K and V key-major)
+        Buf sk, sv;
+        sk.ensure(heads * newS * m->hd * 4, true);
+        sv.ensure(heads * newS * m->hd * 4, true);
+        HIPCHK(hipMemcpy2DAsync(sk.p, (size_t)newS * m->hd * 4, m->s_kc.p, (size_t)oldS * m->hd * 4, (size_t)live * m->hd * 4,
+                                heads, hipMemcpyDeviceToDevice, m->st));
+        HIPCHK(hipMemcpy2DAsync(sv.p, (size_t)newS * m->hd * 4, m->s_vc.p, (size_t)oldS * m->hd * 4, (size_t)live * m->hd * 4,
+                                heads, hipMemcpyDeviceToDevice, m->st));
+        HIPCHK(hipStreamSynchronize(m->st));
+        m->s_kc.release();
+        m->s_vc.release();
+        m->s_kc = sk;
+        m->s_vc = sv;
+        m->s_capS = newS;
+    }
+    m->capS = newS;
+    drop_graph(m);
+}
+
+void run_prefill_layers(vc_model* m, const KvTarget& kv, int B, int S) {
     const vc_model_cfg& c = m->c;
     const int D = c.hidden, F = c.ffn, H = c.heads, M = B * S;
     for (int l = 0; l < c.layers; ++l) {
         const LlmLayer& L = m->llm[l];
         launch_rmsnorm(m->x.as<float>(), L.in_norm, m->xn.as<bf16_t>(), M, D, c.rms_eps, m->st);
         gemm(m, m->xn.as<bf16_t>(), L.qkv_w, nullptr, m->qkv.p, M, 3 * D, D, 3 * D, EPI_BF16);
-        QkvSplitArgs qa{m->qkv.as<bf16_t>(), m->q.as<bf16_t>(), kcache(m, l), vtcache(m, l), B, S, H, m->hd, S, m->capS,
+        QkvSplitArgs qa{m->qkv.as<bf16_t>(), m->q.as<bf16_t>(), kcache(m, kv, l), vtcache(m, kv, l), B, S, H, m->hd, S, kv.capS,
                         nullptr, m->rope_cos, m->rope_sin};
         launch_qkv_split(qa, m->st);
-        AttnArgs aa{m->q.as<bf16_t>(), kcache(m, l), vtcache(m, l), m->attn.as<bf16_t>(), B, H, S, m->hd, S, m->capS, 1,
+        AttnArgs aa{m->q.as<bf16_t>(), kcache(m, kv, l), vtcache(m, kv, l), m->attn.as<bf16_t>(), B, H, S, m->hd, S, kv.capS, 1,
                     1.0f / sqrtf((float)m->hd)};
         launch_attention(aa, m->st);
         gemm(m, m->attn.as<bf16_t>(), L.o_w, nullptr, m->x.p, M, D, D, D, EPI_RESID_F32);
@@ -752,97 +931,175 @@ void run_prefill_layers(vc_model* m, int B, int S) {
     }
 }
 
-// the kernels of one cached decode step (captured into a hipGraph): 5 launches per layer + 2.
-// x_dec (fp32 residual rows of the new tokens) and its sum-of-squares partials are prepared by the previous step's
-// greedy_embed kernel (or by embed_tokens_ssq when the host supplies the tokens).
-GreedyEmbedArgs greedy_embed_args(vc_model* m, int B, int max_new, int eos_id, int pad_id, int advance) {
-    GreedyEmbedArgs a{};
-    a.g = GreedyArgs{m->logits.as<float>(), m->next_tok.as<int>(), m->out_ids.as<int>(), m->finished.as<int>(),
-                     m->step_dev(), B, m->c.vocab, max_new, eos_id, pad_id, m->stop_tab.as<int>(), m->prompt_tail.as<int>()};
+// ---- one cached decode step over the first `nrows` rows of a loop (captured into a hipGraph): 5 launches per layer + 2.
+// x_dec (fp32 residual rows of the new tokens), their sum-of-squares partials and xg are prepared by the previous step's
+// select kernel (or by embed_tokens_ssq when the host supplies the tokens).  Positions, step counts and every
+// generation parameter are read from the rows' RowState records.
+SelectArgs select_args(vc_model* m, const LoopView& v, const float* logits, int nrows, int advance) {
+    SelectArgs a{};
+    a.logits = logits;
+    a.ldl = m->c.vocab;
+    a.rows = v.rows;
+    a.next_tok = v.next_tok;
+    a.out_ids = v.out_ids;
     a.embed = m->embed;
-    a.x = m->x_dec.as<float>();
-    a.ssq = m->ssq.as<float>();
+    a.x = v.x_dec;
+    a.ssq = v.ssq;
     a.xg_w = m->llm[0].in_norm;
-    a.xg = m->xg_dec.as<bf16_t>();
+    a.xg = v.xg_dec;
     a.D = m->c.hidden;
     a.npart = m->npart;
-    a.pos_dev = m->pos_dev();
-    a.ctx_dev = m->ctx_dev();
+    a.V = m->c.vocab;
+    a.nrows = nrows;
     a.advance = advance;
     return a;
 }
 
-void enqueue_decode_step(vc_model* m, int B, int max_new, int eos_id, int pad_id) {
-    decode_linears(m, B, [&](int l) {
-        AttnDecodeFusedArgs da{m->qkv_dec.as<bf16_t>(), kcache(m, l), vtcache(m, l), m->attn_dec.as<bf16_t>(), B, m->c.heads,
-                               m->hd, m->capS, m->pos_dev(), m->rope_cos, m->rope_sin, 1.0f / sqrtf((float)m->hd)};
-        launch_attention_decode_fused(da, m->st);
+void enqueue_decode_step(vc_model* m, const LoopView& v, int nrows) {
+    decode_linears(m, v, nrows, [&](int l) {
+        AttnDecodeFusedArgs da{v.qkv_dec, kcache(v, m, l), vtcache(v, m, l), v.attn_dec, nrows, m->c.heads, m->hd, v.capS,
+                               v.rows + RS_POS, m->rope_cos, m->rope_sin, 1.0f / sqrtf((float)m->hd), RS_STRIDE,
+                               v.rows + RS_ACTIVE};
+        launch_attention_decode_fused(da, v.st);
     });
-    launch_greedy_embed(greedy_embed_args(m, B, max_new, eos_id, pad_id, 3), m->st);                       // K19+K10
+    launch_select_embed(select_args(m, v, v.logits, nrows, 3), v.st);                                        // K19/K20+K10
 }
 
-void enqueue_decode_step_strict(vc_model* m, int B, int max_new, int eos_id, int pad_id) {
-    run_llm_layers_strict(m, m->x_dec.as<float>(), B, 1, m->pos_dev());
+// strict mode: the rows of a session advance in lockstep, so row 0's position serves every row of the fp32 kernels
+void enqueue_decode_step_strict(vc_model* m, int B) {
+    const LoopView v = session_view(m);
+    run_llm_layers_strict(m, m->x_dec.as<float>(), B, 1, v.rows + RS_POS);
     logits_strict(m, m->x_dec.as<float>(), nullptr, B);
-    launch_greedy_embed(greedy_embed_args(m, B, max_new, eos_id, pad_id, 3), m->st);
+    launch_select_embed(select_args(m, v, v.logits, B, 3), v.st);
 }
 
-void ensure_graph(vc_model* m, int B, int max_new, int eos_id, int pad_id) {
-    if (m->graph && m->graph_B == B && m->graph_eos == eos_id && m->graph_pad == pad_id && m->graph_maxnew == max_new)
-        return;
-    if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
+hipGraphExec_t capture_step(vc_model* m, const LoopView& v, int nrows) {
     hipGraph_t g = nullptr;
+    hipGraphExec_t exec = nullptr;
     // thread-local mode: other sessions (host threads) may allocate / copy while this thread captures
-    HIPCHK(hipStreamBeginCapture(m->st, hipStreamCaptureModeThreadLocal));
+    HIPCHK(hipStreamBeginCapture(v.st, hipStreamCaptureModeThreadLocal));
     try {
-        enqueue_decode_step(m, B, max_new, eos_id, pad_id);
+        enqueue_decode_step(m, v, nrows);
     } catch (...) {
-        (void)hipStreamEndCapture(m->st, &g);
+        (void)hipStreamEndCapture(v.st, &g);
         throw;
     }
-    HIPCHK(hipStreamEndCapture(m->st, &g));
-    HIPCHK(hipGraphInstantiate(&m->graph, g, nullptr, nullptr, 0));
+    HIPCHK(hipStreamEndCapture(v.st, &g));
+    HIPCHK(hipGraphInstantiate(&exec, g, nullptr, nullptr, 0));
     HIPCHK(hipGraphDestroy(g));
-    m->graph_B = B;
-    m->graph_eos = eos_id;
-    m->graph_pad = pad_id;
-    m->graph_maxnew = max_new;
+    return exec;
+}
+
+void ensure_graph(vc_model* m, int B) {
+    if (m->graph && m->graph_rows == B) return;
+    drop_graph(m);
+    m->graph = capture_step(m, session_view(m), B);
+    m->graph_rows = B;
 }
 
 void ensure_out_ids(vc_model* m, int B, int max_new) {
-    const size_t n = (size_t)rup(B, 16) * max_new;
-    if ((size_t)m->out_cap < n) {
-        m->out_ids.ensure(n * 4);
-        m->out_cap = (int)n;
-        if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }  // pointer baked into the graph
+    const int stride = std::max(max_new, 1);
+    if (stride > m->out_stride || m->out_ids.cap < (size_t)rup(B, 16) * stride * 4) {
+        m->out_stride = std::max(stride, m->out_stride);
+        m->out_ids.ensure((size_t)rup(B, 16) * m->out_stride * 4);
+        drop_graph(m);  // pointer baked into the graph
+    }
+}
+
+// ---- host-side RowState records ---------------------------------------------------------------------------------
+struct GenParams {  // what a generate() call asks for (HF GenerationMixin subset)
+    int max_new = 0, eos = -1, pad = 0;
+    int do_sample = 0, top_k = 0;
+    float temperature = 1.f, top_p = 1.f;
+    uint64_t seed = 0;
+    int n_stop = 0;
+    int stop[VC_MAX_STOP][1 + VC_MAX_STOP_LEN] = {};
+};
+
+uint32_t mix_seed(uint64_t seed, uint32_t row, uint32_t salt) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(row + 1) + salt;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return (uint32_t)(z ^ (z >> 31));
+}
+
+// records of the B rows of one request (row b of the request = record b); `tail` = last prompt ids per row, right-aligned
+void fill_rows(int* rec, int B, const GenParams& g, int pos, const int* tail /*[B][VC_MAX_STOP_LEN-1] or null*/, int out_off0,
+               int out_stride) {
+    memset(rec, 0, (size_t)B * RS_STRIDE * sizeof(int));
+    const float inv_t = 1.0f / g.temperature;
+    for (int b = 0; b < B; ++b) {
+        int* r = rec + (size_t)b * RS_STRIDE;
+        r[RS_ACTIVE] = 1;
+        r[RS_POS] = pos;
+        r[RS_MAXNEW] = g.max_new;
+        r[RS_EOS] = g.eos;
+        r[RS_PAD] = g.pad;
+        r[RS_NSTOP] = g.n_stop;
+        r[RS_SAMPLE] = g.do_sample;
+        memcpy(&r[RS_INVTEMP], &inv_t, 4);
+        r[RS_TOPK] = g.top_k;
+        memcpy(&r[RS_TOPP], &g.top_p, 4);
+        r[RS_SEED_LO] = (int)mix_seed(g.seed, (uint32_t)b, 0x51u);  // per-row streams: independent of the row's slot
+        r[RS_SEED_HI] = (int)mix_seed(g.seed, (uint32_t)b, 0xA7u);
+        r[RS_OUT_OFF] = out_off0 + b * out_stride;
+        for (int j = 0; j < VC_MAX_STOP_LEN - 1; ++j) r[RS_TAIL + j] = tail ? tail[b * (VC_MAX_STOP_LEN - 1) + j] : INT32_MIN;
+        for (int q = 0; q < g.n_stop; ++q)
+            for (int j = 0; j < 1 + VC_MAX_STOP_LEN; ++j) r[RS_STOP + q * (1 + VC_MAX_STOP_LEN) + j] = g.stop[q][j];
     }
 }
 
 // prefill through the last-row logits; leaves logits [B,V] on device
+// encode + splice: inputs_embeds of the batch in m->x.  `own_kv`: size the session's own KV cache / decode loop for the
+// spliced length plus reserve_new positions (reserve_new < 0: a hint, see below); otherwise only the prefill workspaces
+// (the keys go to a pool's cache and the caller checks the capacity).
 void do_prefill(vc_model* m, const int64_t* ids, int B, int T, const float* img, const float* seg, const float* depth,
-                int on_dev, int has_mask, int reserve_new, float* logits_all_host, int* S_out) {
+                int on_dev, int has_mask, int reserve_new, bool own_kv, int* S_out) {
     const vc_model_cfg& c = m->c;
     REQUIRE(m->finalized, VC_ERR_STATE, "vc_model_finalize() has not been called");
     REQUIRE(B >= 1 && T >= 1 && ids, VC_ERR_INVALID, "bad ids/B/T");
+    REQUIRE(B <= VC_MAX_ROWS, VC_ERR_INVALID, "batch %d: at most %d sequences per prefill (larger batches run in pieces)", B,
+            VC_MAX_ROWS);
     REQUIRE(img, VC_ERR_INVALID, "images is required for a multimodal forward");
     if (c.variant == VC_VARIANT_LLAVA) seg = depth = nullptr;
     if (c.variant != VC_VARIANT_VCODER_DS) depth = nullptr;
-    const float* pix[3] = {img, seg, depth};
+    PixSet pix{{img, seg, depth}, {0, 0, 0}};
+    for (int k = 0; k < 3; ++k) {
+        m->img_first[k].clear();
+        if (!pix.p[k]) continue;
+        if (m->img_counts[k].empty()) {
+            pix.n[k] = B;
+        } else {
+            REQUIRE((int)m->img_counts[k].size() == B, VC_ERR_INVALID, "image counts given for %zu samples, batch is %d",
+                    m->img_counts[k].size(), B);
+            m->img_first[k].push_back(0);
+            for (int b = 0; b < B; ++b) m->img_first[k].push_back(m->img_first[k].back() + m->img_counts[k][b]);
+            pix.n[k] = m->img_first[k].back();
+        }
+    }
+    for (auto& v : m->img_counts) v.clear();  // one-shot
     if (m->ev[0]) HIPCHK(hipEventRecord(m->ev[0], m->st));
-    if (m->precision) run_vit_and_adapters_strict(m, pix, on_dev, B);
-    else run_vit_and_adapters(m, pix, on_dev, B);
+    if (m->precision) run_vit_and_adapters_strict(m, pix, on_dev);
+    else run_vit_and_adapters(m, pix, on_dev);
     const int R = m->Tv - (c.vit_keep_cls ? 0 : 1);
     std::vector<bool> dz;
-    if (depth) {  // is_depth_zero = [mean(d) == 0 ...]  (vcoder_ds_llava_arch.py:161) — one host sync, as the reference
-        m->dsum.ensure(rup(B, 16) * 4);
+    if (depth) {  // is_depth_zero = [mean(d) == 0 for d in depth_images]  (vcoder_ds_llava_arch.py:161) — one host sync, as the reference
+        const int nd = pix.n[VC_MOD_DEPTH];
+        m->dsum.ensure(rup(nd, 16) * 4);
         int di = 0;
-        for (int k = 0; k < 2; ++k) di += pix[k] != nullptr;
+        for (int k = 0; k < 2; ++k) di += pix.n[k];
         const size_t img_elems = (size_t)3 * c.vit_image * c.vit_image;
-        launch_row_sum(m->v_pixels.as<float>() + (size_t)di * B * img_elems, img_elems, B, m->dsum.as<float>(), m->st);
-        std::vector<float> hs(B);
-        HIPCHK(hipMemcpyAsync(hs.data(), m->dsum.p, B * 4, hipMemcpyDeviceToHost, m->st));
+        launch_row_sum(m->v_pixels.as<float>() + (size_t)di * img_elems, img_elems, nd, m->dsum.as<float>(), m->st);
+        std::vector<float> hs(nd);
+        HIPCHK(hipMemcpyAsync(hs.data(), m->dsum.p, nd * 4, hipMemcpyDeviceToHost, m->st));
         HIPCHK(hipStreamSynchronize(m->st));
-        for (int b = 0; b < B; ++b) dz.push_back(hs[b] / (float)img_elems == 0.0f);
+        const std::vector<int>& first = m->img_first[VC_MOD_DEPTH];
+        for (int b = 0; b < B; ++b) {
+            const int i0 = first.empty() ? b : first[b], i1 = first.empty() ? b + 1 : first[b + 1];
+            float tot = 0.f;
+            for (int i = i0; i < i1; ++i) tot += hs[i];
+            dz.push_back(i1 > i0 && tot / ((float)(i1 - i0) * (float)img_elems) == 0.0f);
+        }
     }
     if (m->ev[1]) HIPCHK(hipEventRecord(m->ev[1], m->st));
     std::vector<std::vector<RowSrc>> rows;
@@ -856,7 +1113,13 @@ void do_prefill(vc_model* m, const int64_t* ids, int B, int T, const float* img,
     // quirk 6: unequal spliced lengths with an attention_mask and no labels die at vcoder_ds_llava_arch.py:295-297
     REQUIRE(!(unequal && has_mask), VC_ERR_UNEQUAL, "local variable '_new_labels' referenced before assignment");
     REQUIRE(S >= 1, VC_ERR_INVALID, "empty sequence");
-    ensure_llm(m, B, (int)S + std::max(reserve_new, 1));
+    {   // reserve_new < 0: a hint (vc_prefill): as many of -reserve_new decode slots as max_position_embeddings allows;
+        // reserve_new >= 0: required (generate) — exceeding max_position_embeddings is an error
+        int want = (int)S + std::max(reserve_new < 0 ? -reserve_new : reserve_new, 1);
+        if (reserve_new < 0) want = std::max((int)S + 1, std::min(want, c.max_positions / 64 * 64));
+        if (own_kv) ensure_llm(m, B, want);
+        else ensure_prefill_ws(m, B, (int)rup(S, 64));
+    }
     std::vector<int> flat((size_t)B * S * 2);
     for (int b = 0; b < B; ++b)
         for (size_t s = 0; s < S; ++s) {
@@ -866,6 +1129,7 @@ void do_prefill(vc_model* m, const int64_t* ids, int B, int T, const float* img,
         }
     HIPCHK(hipMemcpyAsync(m->row_src.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, m->st));
     if (m->precision) {
+        REQUIRE(own_kv, VC_ERR_STATE, "strict mode runs on the session's own decode loop");
         ensure_strict(m, B, m->capS);
         launch_splice_f32(m->row_src.as<int>(), (int)(B * S), m->embed, m->s_feats.as<float>(), m->x.as<float>(), c.hidden,
                           m->st);
@@ -878,7 +1142,8 @@ void do_prefill(vc_model* m, const int64_t* ids, int B, int T, const float* img,
     if (S_out) *S_out = (int)S;
 }
 
-void finish_prefill(vc_model* m, float* logits_all_host) {
+// decoder stack over the spliced batch + last-row logits (m->logits [B,V]); keys / values go to `kv`
+void finish_prefill(vc_model* m, const KvTarget& kv, float* logits_all_host) {
     const vc_model_cfg& c = m->c;
     const int B = m->curB, S = m->curS, D = c.hidden;
     std::vector<int> idx(B);
@@ -888,9 +1153,11 @@ void finish_prefill(vc_model* m, float* logits_all_host) {
         run_llm_layers_strict(m, m->x.as<float>(), B, S, nullptr);
         logits_strict(m, m->x.as<float>(), m->last_idx.as<int>(), B);
     } else {
-        run_prefill_layers(m, B, S);
+        run_prefill_layers(m, kv, B, S);
         launch_rmsnorm_rows(m->x.as<float>(), m->last_idx.as<int>(), m->final_norm, m->xl.as<bf16_t>(), B, D, c.rms_eps, m->st);
-        gemv(m, m->xl.as<bf16_t>(), m->lm_head_p, nullptr, m->logits.p, B, c.vocab, D, c.vocab, GEMV_F32);
+        LoopView lv{};  // the lm_head GEMV over the last rows only needs a stream
+        lv.st = m->st;
+        gemv(m, lv, m->xl.as<bf16_t>(), m->lm_head_p, nullptr, m->logits.p, B, c.vocab, D, c.vocab, GEMV_F32);
     }
     if (logits_all_host) {  // lm_head over ALL S positions, as the reference's forward returns (:93)
         const size_t Mr = (size_t)B * S;
@@ -905,9 +1172,16 @@ void finish_prefill(vc_model* m, float* logits_all_host) {
         }
         HIPCHK(hipMemcpyAsync(logits_all_host, m->logits_all.p, Mr * c.vocab * 4, hipMemcpyDeviceToHost, m->st));
     }
-    const int sc[3] = {0, S, S + 1};  // step, pos (next token's position), ctx (keys after it is appended)
-    HIPCHK(hipMemcpyAsync(m->scalars.p, sc, sizeof sc, hipMemcpyHostToDevice, m->st));
-    HIPCHK(hipMemsetAsync(m->finished.p, 0, rup(B, 16) * 4, m->st));
+    HIPCHK(hipStreamSynchronize(m->st));  // `idx` is host memory
+}
+
+// arm the session's own loop for the B rows just prefilled: every row at position S, step 0
+void arm_session_rows(vc_model* m, const GenParams& g, const int* tail) {
+    const int B = m->curB, S = m->curS;
+    std::vector<int> rec((size_t)B * RS_STRIDE);
+    fill_rows(rec.data(), B, g, S, tail, 0, m->out_stride);
+    HIPCHK(hipMemsetAsync(m->rows.p, 0, m->rows.cap, m->st));
+    HIPCHK(hipMemcpyAsync(m->rows.p, rec.data(), rec.size() * 4, hipMemcpyHostToDevice, m->st));
     HIPCHK(hipStreamSynchronize(m->st));
     m->cur_pos = S;
 }
@@ -1054,6 +1328,7 @@ VC_API int vc_model_create_shared(vc_ctx* ctx, vc_model* parent, vc_model** out)
     m->st = ctx->stream;
     m->finalized = true;
     m->owns_weights = false;
+    m->root = parent->root ? parent->root : parent;
     m->weight_format = parent->weight_format;
     m->P = parent->P; m->Tv = parent->Tv; m->Kpatch = parent->Kpatch; m->Kpad = parent->Kpad;
     m->hd = parent->hd; m->vhd = parent->vhd; m->npart = parent->npart;
@@ -1077,8 +1352,8 @@ VC_API void vc_model_destroy(vc_model* m) {
     for (Buf* b : {&m->stage, &m->stage2, &m->v_pixels, &m->v_cols, &m->v_patches, &m->v_x, &m->v_xn, &m->v_qkv, &m->v_q,
                    &m->v_k, &m->v_vt, &m->v_attn, &m->v_h, &m->v_sel, &m->v_mid, &m->feats, &m->x, &m->xn, &m->qkv, &m->q,
                    &m->attn, &m->h, &m->kc, &m->vtc, &m->row_src, &m->last_idx, &m->xl, &m->logits_all, &m->x_dec,
-                   &m->xg_dec, &m->qkv_dec, &m->attn_dec, &m->h_dec, &m->logits, &m->next_tok, &m->finished,
-                   &m->out_ids, &m->scalars, &m->dsum, &m->ssq, &m->sk_scratch, &m->sk_counters, &m->gemm_ws, &m->stop_tab, &m->prompt_tail, &m->s_cols, &m->s_patches, &m->s_vx, &m->s_vxn, &m->s_vqkv,
+                   &m->xg_dec, &m->qkv_dec, &m->attn_dec, &m->h_dec, &m->logits, &m->next_tok, &m->rows,
+                   &m->out_ids, &m->dsum, &m->ssq, &m->sk_scratch, &m->sk_counters, &m->gemm_ws, &m->s_cols, &m->s_patches, &m->s_vx, &m->s_vxn, &m->s_vqkv,
                    &m->s_vq, &m->s_vk, &m->s_vv, &m->s_vattn, &m->s_vh, &m->s_sel, &m->s_mid, &m->s_feats, &m->s_xn, &m->s_qkv,
                    &m->s_q, &m->s_attn, &m->s_h, &m->s_kc, &m->s_vc, &m->s_xl, &m->pp_src, &m->pp_sq, &m->pp_tmp, &m->pp_out,
                    &m->pp_tab, &m->pp_f32})
@@ -1216,10 +1491,11 @@ VC_API int vc_encode(vc_model* m, int modality, const float* pixels, int pixels_
     REQUIRE(m->finalized, VC_ERR_STATE, "vc_model_finalize() has not been called");
     REQUIRE(pixels && B >= 1 && modality >= 0 && modality <= 2, VC_ERR_INVALID, "bad encode arguments");
     REQUIRE(modality == VC_MOD_IMAGE || m->c.variant != VC_VARIANT_LLAVA, VC_ERR_INVALID, "llava has no seg/depth encoder");
-    const float* pix[3] = {nullptr, nullptr, nullptr};
-    pix[modality] = pixels;
-    if (m->precision) run_vit_and_adapters_strict(m, pix, pixels_on_device, B);
-    else run_vit_and_adapters(m, pix, pixels_on_device, B);
+    PixSet pix{{nullptr, nullptr, nullptr}, {0, 0, 0}};
+    pix.p[modality] = pixels;
+    pix.n[modality] = B;
+    if (m->precision) run_vit_and_adapters_strict(m, pix, pixels_on_device);
+    else run_vit_and_adapters(m, pix, pixels_on_device);
     if (out) {
         const size_t n = (size_t)m->feat_rows[modality] * m->c.hidden;
         if (m->precision) {
@@ -1236,6 +1512,61 @@ VC_API int vc_encode(vc_model* m, int modality, const float* pixels, int pixels_
     GUARD_END(m->ctx)
 }
 
+/* CLIPVisionTower.forward + feature_select (multimodal_encoder/clip_encoder.py:29-51): the UN-projected tower output the
+ * reference's encode_* functions hand to the adapters — hidden_states[select_layer] of N images, CLS dropped for 'patch'.
+ * out [N, R, vit_hidden] fp32 on the host (R = patches, +1 with 'cls_patch'). */
+VC_API int vc_vision_tower_forward(vc_model* m, const float* pixels, int pixels_on_device, int N, float* out) {
+    if (!m) return VC_ERR_INVALID;
+    GUARD_BEGIN
+    USE_DEVICE(m->ctx);
+    REQUIRE(m->finalized, VC_ERR_STATE, "vc_model_finalize() has not been called");
+    REQUIRE(pixels && out && N >= 1, VC_ERR_INVALID, "bad vision tower arguments");
+    PixSet pix{{pixels, nullptr, nullptr}, {N, 0, 0}};
+    int order[3], first[3];
+    const int R = m->Tv - (m->c.vit_keep_cls ? 0 : 1);
+    const size_t n = (size_t)N * R * m->c.vit_hidden;
+    if (m->precision) {
+        run_vit_tower_strict(m, pix, pixels_on_device, order, first);
+        HIPCHK(hipMemcpyAsync(out, m->s_sel.p, n * 4, hipMemcpyDeviceToHost, m->st));
+    } else {
+        run_vit_tower(m, pix, pixels_on_device, order, first);
+        m->v_patches.ensure(n * 4);
+        launch_bf16_to_f32(m->v_sel.as<bf16_t>(), m->v_patches.as<float>(), n, m->st);
+        HIPCHK(hipMemcpyAsync(out, m->v_patches.p, n * 4, hipMemcpyDeviceToHost, m->st));
+    }
+    HIPCHK(hipStreamSynchronize(m->st));
+    GUARD_END(m->ctx)
+}
+
+/* images per sample for the NEXT vc_prefill* / vc_generate* call (one-shot): the reference's list / 5-D image form
+ * (vcoder_ds_llava_arch.py:135-169), where sample b owns counts[b] images whose feature rows are spliced as ONE block at
+ * its placeholder.  The pixel pointers of that call then hold sum(counts) images.  NULL = one image per sample. */
+VC_API int vc_set_image_counts(vc_model* m, const int32_t* img, const int32_t* seg, const int32_t* depth, int B) {
+    if (!m || B < 1) return VC_ERR_INVALID;
+    const int32_t* src[3] = {img, seg, depth};
+    for (int k = 0; k < 3; ++k) {
+        m->img_counts[k].clear();
+        if (!src[k]) continue;
+        for (int b = 0; b < B; ++b) {
+            if (src[k][b] < 1) {
+                for (auto& v : m->img_counts) v.clear();
+                m->ctx->err = "every sample needs at least one image per modality";
+                return VC_ERR_INVALID;
+            }
+            m->img_counts[k].push_back(src[k][b]);
+        }
+    }
+    return VC_OK;
+}
+
+/* KV-cache slots the next vc_prefill keeps free behind the prompt for vc_decode_step (default 64; clamped to
+ * max_position_embeddings).  A decode loop that outruns the reserve still works — the cache grows, at the cost of a copy. */
+VC_API int vc_model_reserve_decode(vc_model* m, int max_new_tokens) {
+    if (!m || max_new_tokens < 0) return VC_ERR_INVALID;
+    m->reserve_new = max_new_tokens;
+    return VC_OK;
+}
+
 VC_API int vc_prefill(vc_model* m, const int64_t* ids, int B, int T, const float* img, const float* seg,
                       const float* depth, int pixels_on_device, int has_attention_mask, float* logits_last,
                       float* logits_all, int* S_out) {
@@ -1243,10 +1574,15 @@ VC_API int vc_prefill(vc_model* m, const int64_t* ids, int B, int T, const float
     GUARD_BEGIN
     USE_DEVICE(m->ctx);
     m->cur_pos = -1;
-    do_prefill(m, ids, B, T, img, seg, depth, pixels_on_device, has_attention_mask, 64, logits_all, S_out);
-    finish_prefill(m, logits_all);
-    // greedy choice of the prefill logits, so that vc_decode_step(tok = NULL) continues the sequence
-    launch_greedy_embed(greedy_embed_args(m, B, 0, -1, 0, 0), m->st);
+    do_prefill(m, ids, B, T, img, seg, depth, pixels_on_device, has_attention_mask, -std::max(m->reserve_new, 1), true, S_out);
+    ensure_out_ids(m, B, 1);
+    finish_prefill(m, session_kv(m), logits_all);
+    // greedy choice of the prefill logits, so that vc_decode_step(tok = NULL) continues the sequence: nothing is recorded
+    // (max_new 0), no EOS bookkeeping, the position stays at S
+    GenParams g;
+    arm_session_rows(m, g, nullptr);
+    const LoopView v = session_view(m);
+    launch_select_embed(select_args(m, v, v.logits, B, 0), m->st);
     HIPCHK(hipStreamSynchronize(m->st));
     if (logits_last) {
         HIPCHK(hipMemcpyAsync(logits_last, m->logits.p, (size_t)B * m->c.vocab * 4, hipMemcpyDeviceToHost, m->st));
@@ -1264,7 +1600,7 @@ VC_API int vc_prefill_embeds_only(vc_model* m, const int64_t* ids, int B, int T,
     USE_DEVICE(m->ctx);
     m->cur_pos = -1;
     int S = 0;
-    do_prefill(m, ids, B, T, img, seg, depth, pixels_on_device, has_attention_mask, 64, nullptr, &S);
+    do_prefill(m, ids, B, T, img, seg, depth, pixels_on_device, has_attention_mask, -1, true, &S);
     if (S_out) *S_out = S;
     if (out_host) {
         HIPCHK(hipMemcpyAsync(out_host, m->x.p, (size_t)B * S * m->c.hidden * 4, hipMemcpyDeviceToHost, m->st));
@@ -1278,7 +1614,7 @@ VC_API int vc_decode_step(vc_model* m, const int32_t* tok, float* logits, int32_
     GUARD_BEGIN
     USE_DEVICE(m->ctx);
     REQUIRE(m->cur_pos >= 0, VC_ERR_STATE, "vc_decode_step before vc_prefill");
-    REQUIRE(m->cur_pos + 1 <= m->capS, VC_ERR_STATE, "KV cache full (%d)", m->capS);
+    if (m->cur_pos + 1 > m->capS) grow_kv(m, m->cur_pos + 1);
     const int B = m->curB;
     if (tok) {
         for (int b = 0; b < B; ++b)
@@ -1287,11 +1623,10 @@ VC_API int vc_decode_step(vc_model* m, const int32_t* tok, float* logits, int32_
         launch_embed_tokens_ssq(m->next_tok.as<int>(), m->embed, m->x_dec.as<float>(), m->ssq.as<float>(), m->llm[0].in_norm,
                                 m->xg_dec.as<bf16_t>(), B, m->c.hidden, m->npart, m->st);
     }
-    ensure_out_ids(m, B, 1);
     if (m->precision) {
-        enqueue_decode_step_strict(m, B, 0, -1, 0);
+        enqueue_decode_step_strict(m, B);
     } else {
-        ensure_graph(m, B, 0, -1, 0);  // max_new 0: out_ids untouched, no EOS bookkeeping
+        ensure_graph(m, B);
         HIPCHK(hipGraphLaunch(m->graph, m->st));
     }
     m->cur_pos += 1;
@@ -1301,121 +1636,177 @@ VC_API int vc_decode_step(vc_model* m, const int32_t* tok, float* logits, int32_
     GUARD_END(m->ctx)
 }
 
-/* vc_generate_greedy with a device-side keyword stop: `n_stop` token sequences (stop_ids flattened, stop_lens[i] ids
- * each, <= 8 sequences of <= 8 ids).  A row is finished — later tokens are pad_id — as soon as its ids (the tail of
- * its prompt followed by what it has generated) END WITH one of the sequences; generation stops when every row is
- * finished by EOS or by a stop.  This is the batched, graph-friendly form of the reference's KeywordsStoppingCriteria
- * id match (vcoder_llava/mm_utils.py:142-146, which asserts batch size 1 and is evaluated on the host every token). */
-VC_API int vc_generate_greedy_stop(vc_model* m, const int64_t* ids, int B, int T, const float* img, const float* seg,
-                                   const float* depth, int pixels_on_device, int max_new, int eos_id, int pad_id,
-                                   const int32_t* stop_ids, const int32_t* stop_lens, int n_stop, int32_t* out_ids,
-                                   int* n_generated) {
-    if (!m) return VC_ERR_INVALID;
-    GUARD_BEGIN
-    USE_DEVICE(m->ctx);
-    REQUIRE(max_new >= 1 && out_ids, VC_ERR_INVALID, "bad max_new/out_ids");
-    REQUIRE(n_stop >= 0 && n_stop <= VC_MAX_STOP && (n_stop == 0 || (stop_ids && stop_lens)), VC_ERR_INVALID,
-            "at most %d stop sequences", VC_MAX_STOP);
-    std::vector<int> tab(1 + VC_MAX_STOP * (1 + VC_MAX_STOP_LEN), 0);
-    tab[0] = n_stop;
-    for (int i = 0, off = 0; i < n_stop; ++i) {
-        REQUIRE(stop_lens[i] >= 1 && stop_lens[i] <= VC_MAX_STOP_LEN, VC_ERR_INVALID, "stop sequence %d: 1..%d ids", i,
-                VC_MAX_STOP_LEN);
-        tab[1 + i * (1 + VC_MAX_STOP_LEN)] = stop_lens[i];
-        for (int j = 0; j < stop_lens[i]; ++j) tab[2 + i * (1 + VC_MAX_STOP_LEN) + j] = stop_ids[off + j];
-        off += stop_lens[i];
-    }
+namespace {
+
+// first column count at which a row of `produced` ids is stopped by one of the stop sequences (host restatement of the
+// select kernel's suffix match; used to trim the returned columns exactly where HF's loop would have stopped)
+int row_stop_end(const GenParams& g, const int32_t* row, const int* tail_b, int produced) {
     constexpr int TL = VC_MAX_STOP_LEN - 1;
-    std::vector<int> tail((size_t)B * TL, INT32_MIN);  // ids never equal INT32_MIN
-    for (int b = 0; b < B; ++b)
-        for (int j = 0; j < TL && j < T; ++j) tail[(size_t)b * TL + TL - 1 - j] = (int)ids[(size_t)b * T + T - 1 - j];
-    auto row_stop_end = [&](const int32_t* row, int b, int produced) {  // first column count at which row b is stopped
-        for (int st = 0; st < produced; ++st)
-            for (int i = 0; i < n_stop; ++i) {
-                const int L = tab[1 + i * (1 + VC_MAX_STOP_LEN)];
-                bool ok = true;
-                for (int j = 0; j < L && ok; ++j) {
-                    const int back = L - 1 - j;
-                    const int v = st - back >= 0 ? row[st - back] : tail[(size_t)b * TL + TL + (st - back)];
-                    ok = v == tab[2 + i * (1 + VC_MAX_STOP_LEN) + j];
-                }
-                if (ok) return st + 1;
+    for (int st = 0; st < produced; ++st)
+        for (int i = 0; i < g.n_stop; ++i) {
+            const int L = g.stop[i][0];
+            bool ok = L > 0;
+            for (int j = 0; j < L && ok; ++j) {
+                const int back = L - 1 - j;
+                const int v = st - back >= 0 ? row[st - back] : tail_b[TL + (st - back)];
+                ok = v == g.stop[i][1 + j];
             }
-        return produced;
-    };
+            if (ok) return st + 1;
+        }
+    return produced;
+}
+
+// columns HF's loop would have returned: it stops right after the first step at which every row has produced EOS / met a stop
+int trim_columns(const GenParams& g, const int32_t* out_ids, int ld, const int* tail, int B, int produced) {
+    if (!(g.eos >= 0 || g.n_stop > 0)) return produced;
+    int last = 0;
+    for (int b = 0; b < B; ++b) {
+        int e = produced;
+        if (g.eos >= 0)
+            for (int s_ = 0; s_ < produced; ++s_)
+                if (out_ids[(size_t)b * ld + s_] == g.eos) { e = s_ + 1; break; }
+        if (g.n_stop > 0) e = std::min(e, row_stop_end(g, out_ids + (size_t)b * ld, tail + (size_t)b * (VC_MAX_STOP_LEN - 1), produced));
+        last = std::max(last, e);
+    }
+    return std::min(produced, last);
+}
+
+std::mutex g_prefill_gate;
+
+// generate() on the session's own loop: prefill, then max_new - 1 graph-replayed (strict: eagerly enqueued) decode steps
+void generate_on_session(vc_model* m, const int64_t* ids, int B, int T, const float* img, const float* seg, const float* depth,
+                         int on_dev, const GenParams& g, const std::vector<int>& tail, vc_token_cb cb, void* cb_user,
+                         int cb_every, int32_t* out_ids, int* n_generated) {
+    const int max_new = g.max_new;
     m->cur_pos = -1;
     int S = 0;
     // Sessions of one process take turns in the MFMA-bound encode+prefill phase: two prefills side by side only slow
     // each other (and every decode in flight), while ONE prefill overlaps well with the HBM-bound decodes of the others.
-    static std::mutex prefill_gate;
     static const bool use_gate = !(getenv("VC_PREFILL_GATE") && atoi(getenv("VC_PREFILL_GATE")) == 0);
-    std::unique_lock<std::mutex> gate(prefill_gate, std::defer_lock);
+    std::unique_lock<std::mutex> gate(g_prefill_gate, std::defer_lock);
     if (use_gate) gate.lock();
-    do_prefill(m, ids, B, T, img, seg, depth, pixels_on_device, 1, max_new, nullptr, &S);  // generate() always builds a mask
+    do_prefill(m, ids, B, T, img, seg, depth, on_dev, 1, max_new, true, &S);  // generate() always builds a mask
     m->last_S = S;
     REQUIRE(S + max_new <= m->capS, VC_ERR_INVALID, "prompt %d + max_new %d exceeds the KV capacity %d", S, max_new, m->capS);
     ensure_out_ids(m, B, max_new);
-    HIPCHK(hipMemcpyAsync(m->stop_tab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, m->st));
-    HIPCHK(hipMemcpyAsync(m->prompt_tail.p, tail.data(), tail.size() * 4, hipMemcpyHostToDevice, m->st));
-    m->n_stop = n_stop;
-    finish_prefill(m, nullptr);
+    finish_prefill(m, session_kv(m), nullptr);
     if (m->ev[2]) HIPCHK(hipEventRecord(m->ev[2], m->st));
+    arm_session_rows(m, g, tail.data());
+    const LoopView v = session_view(m);
     // token 0 comes from the prefill logits
-    std::vector<int> fill((size_t)B * max_new, pad_id);
+    std::vector<int> fill((size_t)B * m->out_stride, g.pad);
     HIPCHK(hipMemcpyAsync(m->out_ids.p, fill.data(), fill.size() * 4, hipMemcpyHostToDevice, m->st));
-    launch_greedy_embed(greedy_embed_args(m, B, max_new, eos_id, pad_id, 1), m->st);  // step 0 -> 1; pos stays at S
+    launch_select_embed(select_args(m, v, v.logits, B, 1), m->st);  // step 0 -> 1; the position stays at S
     HIPCHK(hipStreamSynchronize(m->st));
     if (use_gate) gate.unlock();
-    int produced = 1;
-    std::vector<int> fin(B);
-    const bool can_finish = eos_id >= 0 || n_stop > 0;
+    int produced = 1, reported = 0;
+    const bool can_finish = g.eos >= 0 || g.n_stop > 0;
+    std::vector<int> rec((size_t)B * RS_STRIDE), part;
     auto all_finished = [&]() {
         if (!can_finish) return false;
-        HIPCHK(hipMemcpyAsync(fin.data(), m->finished.p, B * 4, hipMemcpyDeviceToHost, m->st));
+        HIPCHK(hipMemcpyAsync(rec.data(), m->rows.p, rec.size() * 4, hipMemcpyDeviceToHost, m->st));
         HIPCHK(hipStreamSynchronize(m->st));
         for (int b = 0; b < B; ++b)
-            if (!fin[b]) return false;
+            if (!rec[(size_t)b * RS_STRIDE + RS_FINISHED]) return false;
         return true;
     };
+    auto report = [&](int upto) {  // streamer callback: columns [reported, upto) of every row
+        if (!cb || upto <= reported) return;
+        part.resize((size_t)B * (upto - reported));
+        HIPCHK(hipMemcpy2DAsync(part.data(), (size_t)(upto - reported) * 4, m->out_ids.as<int>() + reported,
+                                (size_t)m->out_stride * 4, (size_t)(upto - reported) * 4, B, hipMemcpyDeviceToHost, m->st));
+        HIPCHK(hipStreamSynchronize(m->st));
+        cb(cb_user, reported, upto - reported, B, part.data());
+        reported = upto;
+    };
+    const int every = cb ? std::max(cb_every, 1) : 8;
+    if (cb && every == 1) report(1);
     if (max_new > 1 && !all_finished()) {
-        if (!m->precision) ensure_graph(m, B, max_new, eos_id, pad_id);
+        if (!m->precision) ensure_graph(m, B);
         for (int step = 1; step < max_new; ++step) {
-            if (m->precision) enqueue_decode_step_strict(m, B, max_new, eos_id, pad_id);
+            if (m->precision) enqueue_decode_step_strict(m, B);
             else HIPCHK(hipGraphLaunch(m->graph, m->st));
             m->cur_pos += 1;
             produced = step + 1;
-            // the reference checks its stopping criteria on the host every token; checking every 8 tokens only
+            // the reference checks its stopping criteria on the host every token; checking every few tokens only
             // trims later (rows past EOS already emit pad), it never changes the returned ids
-            if (can_finish && (step % 8 == 7 || step == max_new - 1)) {
-                HIPCHK(hipStreamSynchronize(m->st));
-                if (all_finished()) break;
+            if ((step + 1) % every == 0 || step == max_new - 1) {
+                if (cb) report(produced);
+                if (can_finish) {
+                    HIPCHK(hipStreamSynchronize(m->st));
+                    if (all_finished()) break;
+                }
             }
         }
     }
     if (m->ev[3]) HIPCHK(hipEventRecord(m->ev[3], m->st));
-    HIPCHK(hipMemcpyAsync(out_ids, m->out_ids.p, (size_t)B * max_new * 4, hipMemcpyDeviceToHost, m->st));
+    HIPCHK(hipMemcpy2DAsync(out_ids, (size_t)max_new * 4, m->out_ids.p, (size_t)m->out_stride * 4, (size_t)max_new * 4, B,
+                            hipMemcpyDeviceToHost, m->st));
     HIPCHK(hipStreamSynchronize(m->st));
-    if (can_finish) {  // HF stops right after the first step at which every row has produced EOS / met a stop
-        int last = 0;
-        for (int b = 0; b < B; ++b) {
-            int e = produced;
-            if (eos_id >= 0)
-                for (int s = 0; s < produced; ++s)
-                    if (out_ids[(size_t)b * max_new + s] == eos_id) { e = s + 1; break; }
-            if (n_stop > 0) e = std::min(e, row_stop_end(out_ids + (size_t)b * max_new, b, produced));
-            last = std::max(last, e);
-        }
-        produced = std::min(produced, last);
-    }
+    produced = trim_columns(g, out_ids, max_new, tail.data(), B, produced);
+    if (cb) report(produced);
     if (n_generated) *n_generated = produced;
     if (m->ev[0]) {
         (void)hipEventElapsedTime(&m->t_encode, m->ev[0], m->ev[1]);
         (void)hipEventElapsedTime(&m->t_prefill, m->ev[1], m->ev[2]);
         (void)hipEventElapsedTime(&m->t_decode, m->ev[2], m->ev[3]);
     }
+}
+
+}  // namespace
+
+/* generate(): encode + splice + prefill + (max_new - 1) decode steps with the token selection on the device — greedy
+ * (samp NULL or do_sample 0) or temperature / top-k / top-p sampling — EOS / pad bookkeeping, device-side keyword stops
+ * and an optional streamer callback.  See include/vcoder_hip.h. */
+VC_API int vc_generate(vc_model* m, const int64_t* ids, int B, int T, const float* img, const float* seg, const float* depth,
+                       int pixels_on_device, int max_new, int eos_id, int pad_id, const int32_t* stop_ids,
+                       const int32_t* stop_lens, int n_stop, const vc_sampling* samp, vc_token_cb cb, void* cb_user,
+                       int cb_every, int32_t* out_ids, int* n_generated) {
+    if (!m) return VC_ERR_INVALID;
+    GUARD_BEGIN
+    USE_DEVICE(m->ctx);
+    REQUIRE(max_new >= 1 && out_ids, VC_ERR_INVALID, "bad max_new/out_ids");
+    REQUIRE(n_stop >= 0 && n_stop <= VC_MAX_STOP && (n_stop == 0 || (stop_ids && stop_lens)), VC_ERR_INVALID,
+            "at most %d stop sequences", VC_MAX_STOP);
+    // finished rows are fed the pad token's embedding: it must be a real row of embed_tokens
+    REQUIRE(!(eos_id >= 0 || n_stop > 0) || (pad_id >= 0 && pad_id < m->c.vocab), VC_ERR_INDEX,
+            "pad_token_id %d is outside the vocabulary (%d)", pad_id, m->c.vocab);
+    GenParams g;
+    g.max_new = max_new;
+    g.eos = eos_id;
+    g.pad = pad_id;
+    g.n_stop = n_stop;
+    for (int i = 0, off = 0; i < n_stop; ++i) {
+        REQUIRE(stop_lens[i] >= 1 && stop_lens[i] <= VC_MAX_STOP_LEN, VC_ERR_INVALID, "stop sequence %d: 1..%d ids", i,
+                VC_MAX_STOP_LEN);
+        g.stop[i][0] = stop_lens[i];
+        for (int j = 0; j < stop_lens[i]; ++j) g.stop[i][1 + j] = stop_ids[off + j];
+        off += stop_lens[i];
+    }
+    if (samp && samp->do_sample) {
+        REQUIRE(samp->temperature > 0.f, VC_ERR_INVALID, "temperature must be positive (got %g)", (double)samp->temperature);
+        REQUIRE(samp->top_p > 0.f && samp->top_p <= 1.f, VC_ERR_INVALID, "top_p must be in (0, 1] (got %g)", (double)samp->top_p);
+        g.do_sample = 1;
+        g.temperature = samp->temperature;
+        g.top_k = samp->top_k;
+        g.top_p = samp->top_p;
+        g.seed = samp->seed;
+    }
+    constexpr int TL = VC_MAX_STOP_LEN - 1;
+    std::vector<int> tail((size_t)B * TL, INT32_MIN);  // ids never equal INT32_MIN
+    for (int b = 0; b < B; ++b)
+        for (int j = 0; j < TL && j < T; ++j) tail[(size_t)b * TL + TL - 1 - j] = (int)ids[(size_t)b * T + T - 1 - j];
+    generate_on_session(m, ids, B, T, img, seg, depth, pixels_on_device, g, tail, cb, cb_user, cb_every, out_ids, n_generated);
     GUARD_END(m->ctx)
 }
 
+VC_API int vc_generate_greedy_stop(vc_model* m, const int64_t* ids, int B, int T, const float* img, const float* seg,
+                                   const float* depth, int pixels_on_device, int max_new, int eos_id, int pad_id,
+                                   const int32_t* stop_ids, const int32_t* stop_lens, int n_stop, int32_t* out_ids,
+                                   int* n_generated) {
+    return vc_generate(m, ids, B, T, img, seg, depth, pixels_on_device, max_new, eos_id, pad_id, stop_ids, stop_lens, n_stop,
+                       nullptr, nullptr, nullptr, 0, out_ids, n_generated);
+}
 
 /* spliced sequence length (text + feature rows) of the last vc_generate_greedy* call of this model / session */
 VC_API int vc_last_spliced_len(vc_model* m) { return m ? m->last_S : VC_ERR_INVALID; }
@@ -1551,7 +1942,8 @@ VC_API int vc_profile_decode_gemv(vc_model* m, int B, int reps, int* launches, d
     const vc_model_cfg& c = m->c;
     const int D = c.hidden, F = c.ffn;
     ensure_llm(m, B, 64);
-    auto sweep = [&]() { decode_linears(m, B, [](int) {}); };
+    const LoopView v = session_view(m);
+    auto sweep = [&]() { decode_linears(m, v, B, [](int) {}); };
     sweep();  // warm
     HIPCHK(hipEventRecord(m->ev[0], m->st));
     for (int r = 0; r < reps; ++r) sweep();

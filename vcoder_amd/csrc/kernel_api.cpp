@@ -37,20 +37,22 @@ VCK_EXPORT void vck_gemv_ex(const uint16_t* X, const void* Wp, const float* wsca
 VCK_EXPORT void vck_attention_decode_fused(const uint16_t* qkv, uint16_t* k, uint16_t* vt, uint16_t* out, int B, int H,
                                            int hd, int kv_stride, const int* pos_dev, const float* rope_cos,
                                            const float* rope_sin, float scale, void* stream) {
-    AttnDecodeFusedArgs a{qkv, k, vt, out, B, H, hd, kv_stride, pos_dev, rope_cos, rope_sin, scale};
+    AttnDecodeFusedArgs a{qkv, k, vt, out, B, H, hd, kv_stride, pos_dev, rope_cos, rope_sin, scale, 0, nullptr};
     launch_attention_decode_fused(a, S(stream));
 }
-VCK_EXPORT void vck_greedy_embed(const float* logits, int* next_tok, int* out_ids, int* finished, int* step_dev, int B,
-                                 int V, int max_new, int eos_id, int pad_id, const uint16_t* embed, float* x, float* ssq,
-                                 const float* xg_w, uint16_t* xg, int D, int npart, int* pos_dev, int* ctx_dev, int advance,
-                                 const int* stop_tab, const int* prompt_tail, void* stream) {
-    GreedyEmbedArgs a{};
-    a.xg_w = xg_w; a.xg = xg;
-    a.g = GreedyArgs{logits, next_tok, out_ids, finished, step_dev, B, V, max_new, eos_id, pad_id, stop_tab, prompt_tail};
-    a.embed = embed; a.x = x; a.ssq = ssq; a.D = D; a.npart = npart; a.pos_dev = pos_dev; a.ctx_dev = ctx_dev;
-    a.advance = advance;
-    launch_greedy_embed(a, S(stream));
+VCK_EXPORT void vck_attention_decode_rows(const uint16_t* qkv, uint16_t* k, uint16_t* vt, uint16_t* out, int B, int H, int hd,
+                                          int kv_stride, const int* pos_rows, int pos_stride, const int* active_rows,
+                                          const float* rope_cos, const float* rope_sin, float scale, void* stream) {
+    AttnDecodeFusedArgs a{qkv, k, vt, out, B, H, hd, kv_stride, pos_rows, rope_cos, rope_sin, scale, pos_stride, active_rows};
+    launch_attention_decode_fused(a, S(stream));
 }
+VCK_EXPORT void vck_select_embed(const float* logits, int ldl, int* rows, int* next_tok, int* out_ids, const uint16_t* embed,
+                                 float* x, float* ssq, const float* xg_w, uint16_t* xg, int D, int npart, int V, int nrows,
+                                 int advance, void* stream) {
+    SelectArgs a{logits, ldl, rows, next_tok, out_ids, embed, x, ssq, xg_w, xg, D, npart, V, nrows, advance, 0};
+    launch_select_embed(a, S(stream));
+}
+VCK_EXPORT int vck_row_state_stride() { return RS_STRIDE; }
 VCK_EXPORT void vck_embed_tokens_ssq(const int* tok, const uint16_t* embed, float* x, float* ssq, const float* xg_w,
                                      uint16_t* xg, int B, int D, int npart, void* stream) {
     launch_embed_tokens_ssq(tok, embed, x, ssq, xg_w, xg, B, D, npart, S(stream));

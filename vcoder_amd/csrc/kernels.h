@@ -48,8 +48,9 @@ enum GemvEpilogue : int {
     GEMV_RESID_F32 = 2,  // out fp32 [M, N] += acc     (o_proj / down_proj into the residual stream)
     GEMV_SWIGLU = 3,     // interleaved (gate,up) rows: out bf16 [M, N/2]
 };
+constexpr int VC_GEMV_MAX_M = 16;  // token slots one weight pass of launch_gemv serves
 struct GemvArgs {
-    const bf16_t* X;   // [M, K] bf16 activations (M <= 16)
+    const bf16_t* X;   // [M, K] bf16 activations (M <= VC_GEMV_MAX_M)
     const bf16_t* Wp;  // packed weights
     void* out;
     int M, N, K;       // N % 16 == 0, K % 32 == 0 (K % 64 == 0 for W8A16)
@@ -140,10 +141,12 @@ struct AttnDecodeFusedArgs {
     bf16_t* vt;          // [B,H,hd,kv_stride]   (column `pos` is written)
     bf16_t* out;         // [B, H*hd]
     int B, H, hd, kv_stride;
-    const int* pos_dev;  // position of the new token == number of keys already cached
+    const int* pos_dev;  // position of the new token == number of keys already cached; row b reads pos_dev[b * pos_stride]
     const float* rope_cos;
     const float* rope_sin;
     float scale;
+    int pos_stride;         // 0: one position for every row
+    const int* active_dev;  // nullptr, or row b is skipped when active_dev[b * pos_stride] == 0
 };
 void launch_attention_decode_fused(const AttnDecodeFusedArgs& a, hipStream_t s);
 
@@ -185,22 +188,52 @@ struct GreedyArgs {
 };
 constexpr int VC_MAX_STOP = 8, VC_MAX_STOP_LEN = 8;
 void launch_greedy(const GreedyArgs& a, hipStream_t s);
-// greedy select for ALL rows + embedding of the selected tokens into the decode residual stream (+ its sum-of-squares
-// partials and the xg = bf16(x*g) operand of the first GEMV, see GemvArgs) + step/pos/ctx advance: the tail of one decode
-// step in one launch.
-struct GreedyEmbedArgs {
-    GreedyArgs g;
-    const bf16_t* embed;  // [V, D]
-    float* x;             // [16, D] fp32 residual stream of the next step
-    float* ssq;           // [16, npart]
-    const float* xg_w;    // [D] first decoder layer's input_layernorm weight
-    bf16_t* xg;           // [16, D] bf16(x * xg_w): the first GEMV's activation operand
-    int D, npart;
-    int* pos_dev;         // advanced by `advance` (may be nullptr)
-    int* ctx_dev;
-    int advance;          // bit 0: step += 1; bit 1: pos += 1 and ctx += 1 (after the selection)
+// ---- per-row decode state (select.hip) ------------------------------------------------------------------------------
+// One record of RS_STRIDE ints per row of the decode loop, in device memory.  Every kernel of a decode step that needs a
+// position, a step count or a parameter of a row reads it here, so one captured graph serves rows of different requests.
+enum RowStateField : int {
+    RS_ACTIVE = 0,    // 0: the row is skipped by attention and selection (its GEMV lanes compute garbage nobody reads)
+    RS_FINISHED = 1,  // EOS seen / stop sequence matched: later tokens are pad
+    RS_STEP = 2,      // tokens produced so far = index of the next entry of the row's out_ids
+    RS_POS = 3,       // position of the token the next step processes = keys already in the row's KV cache
+    RS_MAXNEW = 4,    // out_ids entries of the row (0: nothing is recorded — vc_decode_step)
+    RS_EOS = 5,       // < 0: disabled
+    RS_PAD = 6,
+    RS_NSTOP = 7,     // stop sequences in RS_STOP (<= VC_MAX_STOP)
+    RS_SAMPLE = 8,    // 0 greedy, 1 temperature / top-k / top-p sampling
+    RS_INVTEMP = 9,   // float bits: 1 / temperature
+    RS_TOPK = 10,     // <= 0: off
+    RS_TOPP = 11,     // float bits; >= 1: off
+    RS_SEED_LO = 12,
+    RS_SEED_HI = 13,
+    RS_OUT_OFF = 14,  // offset (ints) of the row's out_ids inside SelectArgs::out_ids
+    RS_TAIL = 16,     // VC_MAX_STOP_LEN - 1 last prompt ids, right-aligned (suffix matches that reach into the prompt)
+    RS_STOP = 24,     // VC_MAX_STOP x (length, VC_MAX_STOP_LEN ids)
+    RS_STRIDE = 128,
 };
-void launch_greedy_embed(const GreedyEmbedArgs& a, hipStream_t s);
+static_assert(RS_STOP + VC_MAX_STOP * (1 + VC_MAX_STOP_LEN) <= RS_STRIDE, "row record overflow");
+
+// selection (greedy / sampled) + EOS / stop bookkeeping + embedding of the selected token (fp32 residual row x, RMSNorm
+// partials ssq, first GEMV operand xg = bf16(x * xg_w)) + per-row step / position advance: one workgroup per row
+struct SelectArgs {
+    const float* logits;  // [nrows, ldl] fp32
+    int ldl;
+    int* rows;            // [nrows][RS_STRIDE]
+    int* next_tok;        // [nrows]
+    int* out_ids;         // base of the id store; row r writes out_ids[rows[r][RS_OUT_OFF] + step]
+    const bf16_t* embed;  // [V, D]; nullptr: no embedding (selection only)
+    float* x;             // [nrows, D]
+    float* ssq;           // [nrows, npart]
+    const float* xg_w;    // [D]
+    bf16_t* xg;           // [nrows, D]
+    int D, npart, V;
+    int nrows;
+    int advance;          // bit 0: step += 1; bit 1: pos += 1 (after the selection)
+    int lds_floats;       // filled by the launcher: floats of LDS staging available to the sampler
+};
+void launch_select_embed(const SelectArgs& a, hipStream_t s);
+// rows[row0 .. row0+nrows) <- src[0 .. nrows) (whole records), stream-ordered
+void launch_rows_write(int* rows, const int* src, int row0, int nrows, hipStream_t s);
 // embedding + sum-of-squares partials for tokens supplied by the host (vc_decode_step with explicit tokens)
 void launch_embed_tokens_ssq(const int* tok, const bf16_t* embed, float* x, float* ssq, const float* xg_w, bf16_t* xg, int B, int D, int npart,
                              hipStream_t s);

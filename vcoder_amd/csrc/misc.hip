@@ -82,126 +82,6 @@ void launch_greedy(const GreedyArgs& a, hipStream_t s) {
     VC_LAUNCH(greedy_kernel, dim3(a.B), dim3(256), 0, s, a);
 }
 
-// ---- tail of one decode step in ONE launch: greedy select of every row, embedding of the selected tokens into the
-//      next step's residual stream (+ sum-of-squares partials and the xg operand of the folded RMSNorm), step/pos/ctx
-//      advance ----------------------------------------------------------------------------------------------------
-VC_DEV void embed_row_ssq(const bf16_t* sp, float* dp, float* ssq_row, const float* gw, bf16_t* xg, int D, int npart,
-                          int lane) {
-    float ss = 0.f;
-    for (int c = lane; c < D / 8; c += 64) {
-        const u32x4 v = ld16(sp + c * 8);
-        const f32x4 a = {bf2f_lo(v[0]), bf2f_hi(v[0]), bf2f_lo(v[1]), bf2f_hi(v[1])};
-        const f32x4 b = {bf2f_lo(v[2]), bf2f_hi(v[2]), bf2f_lo(v[3]), bf2f_hi(v[3])};
-        st16f(dp + c * 8, a);
-        st16f(dp + c * 8 + 4, b);
-        const f32x4 g0 = ld16f(gw + c * 8), g1 = ld16f(gw + c * 8 + 4);
-        st16(xg + c * 8, u32x4{pack_bf2(a[0] * g0[0], a[1] * g0[1]), pack_bf2(a[2] * g0[2], a[3] * g0[3]),
-                               pack_bf2(b[0] * g1[0], b[1] * g1[1]), pack_bf2(b[2] * g1[2], b[3] * g1[3])});
-        ss += ((a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3])) +
-              ((b[0] * b[0] + b[1] * b[1]) + (b[2] * b[2] + b[3] * b[3]));
-    }
-    ss = wave_sum(ss);
-    for (int q = lane; q < npart; q += 64) ssq_row[q] = q == 0 ? ss : 0.f;
-}
-
-__global__ __launch_bounds__(1024) void greedy_embed_kernel(GreedyEmbedArgs p) {
-    constexpr int MAXB = 16;
-    __shared__ float sv[16][MAXB];
-    __shared__ int si[16][MAXB];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const GreedyArgs& g = p.g;
-    const int step = *g.step_dev;
-    // phase A: every thread scans its columns of ALL rows (B independent 16-byte loads in flight per iteration)
-    float best[MAXB];
-    int bi[MAXB];
-#pragma unroll
-    for (int b = 0; b < MAXB; ++b) { best[b] = -INFINITY; bi[b] = 0x7FFFFFFF; }
-    for (int i = tid * 4; i < g.V; i += 4096) {
-#pragma unroll
-        for (int b = 0; b < MAXB; ++b) {
-            if (b < g.B) {
-                const f32x4 v = ld16f(g.logits + (size_t)b * g.V + i);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) argmax_combine(best[b], bi[b], v[e], i + e);
-            }
-        }
-    }
-#pragma unroll
-    for (int b = 0; b < MAXB; ++b) {
-        if (b < g.B) {
-#pragma unroll
-            for (int mk = 32; mk >= 1; mk >>= 1) {
-                const float ov = shfl_xor(best[b], mk);
-                const int oi = shfl_xor(bi[b], mk);
-                argmax_combine(best[b], bi[b], ov, oi);
-            }
-            if (lane == 0) { sv[wave][b] = best[b]; si[wave][b] = bi[b]; }
-        }
-    }
-    __syncthreads();
-    // phase B: wave b finishes row b (combine the 16 wave results, EOS/pad bookkeeping, embed the selected token)
-    if (wave < g.B) {
-        const int b = wave;
-        float bv = sv[0][b];
-        int bidx = si[0][b];
-        for (int w = 1; w < 16; ++w) argmax_combine(bv, bidx, sv[w][b], si[w][b]);
-        const int was_finished = (g.eos_id >= 0 || (g.stop_tab != nullptr && g.stop_tab[0] > 0)) ? g.finished[b] : 0;
-        int tok = bidx;
-        // all lanes computed the same tok; one shuffle keeps the read of finished[] ahead of lane 0's write below
-        tok = shfl(tok, 0);
-        const bool stops = g.stop_tab != nullptr && g.stop_tab[0] > 0;
-        if (g.eos_id >= 0 || stops) {
-            if (was_finished) tok = g.pad_id;
-            if (lane == 0 && g.eos_id >= 0 && tok == g.eos_id) g.finished[b] = 1;
-        }
-        if (lane == 0) {
-            g.next_tok[b] = tok;
-            if (step < g.max_new) g.out_ids[(size_t)b * g.max_new + step] = tok;
-            if (stops && !was_finished) {  // suffix match of the row's ids (prompt tail | generated so far | tok)
-                bool hit = false;
-                for (int sq = 0; sq < g.stop_tab[0]; ++sq) {
-                    const int* e = g.stop_tab + 1 + sq * (1 + VC_MAX_STOP_LEN);
-                    const int L = e[0];
-                    bool ok = L > 0;
-                    for (int i = 0; i < L && ok; ++i) {
-                        const int back = L - 1 - i;  // 0 = the token just selected
-                        int v;
-                        if (back == 0) v = tok;
-                        else if (step - back >= 0) v = g.out_ids[(size_t)b * g.max_new + step - back];
-                        else v = g.prompt_tail[b * (VC_MAX_STOP_LEN - 1) + (VC_MAX_STOP_LEN - 1) + (step - back)];
-                        ok = v == e[1 + i];
-                    }
-                    hit = hit || ok;
-                }
-                if (hit) g.finished[b] = 1;
-            }
-        }
-        embed_row_ssq(p.embed + (size_t)tok * p.D, p.x + (size_t)b * p.D, p.ssq + (size_t)b * p.npart, p.xg_w,
-                      p.xg + (size_t)b * p.D, p.D, p.npart, lane);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        if (p.advance & 1) *g.step_dev = step + 1;
-        if ((p.advance & 2) && p.pos_dev) *p.pos_dev += 1;
-        if ((p.advance & 2) && p.ctx_dev) *p.ctx_dev += 1;
-    }
-}
-void launch_greedy_embed(const GreedyEmbedArgs& a, hipStream_t s) {
-    VC_LAUNCH(greedy_embed_kernel, dim3(1), dim3(1024), 0, s, a);
-}
-
-__global__ __launch_bounds__(256) void embed_tokens_ssq_kernel(const int* tok, const bf16_t* embed, float* x, float* ssq,
-                                                               const float* xg_w, bf16_t* xg, int B, int D, int npart) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= B) return;
-    embed_row_ssq(embed + (size_t)tok[row] * D, x + (size_t)row * D, ssq + (size_t)row * npart, xg_w, xg + (size_t)row * D, D,
-                  npart, threadIdx.x & 63);
-}
-void launch_embed_tokens_ssq(const int* tok, const bf16_t* embed, float* x, float* ssq, const float* xg_w, bf16_t* xg, int B,
-                             int D, int npart, hipStream_t s) {
-    VC_LAUNCH(embed_tokens_ssq_kernel, dim3((B + 3) / 4), dim3(256), 0, s, tok, embed, x, ssq, xg_w, xg, B, D, npart);
-}
-
 __global__ __launch_bounds__(64) void advance_kernel(int* step_dev, int* pos_dev, int* ctx_dev) {
     if (threadIdx.x != 0) return;
     if (step_dev) *step_dev += 1;

@@ -1,0 +1,275 @@
+// select.hip — the tail of a decode step: token selection (greedy or sampled), EOS / keyword-stop bookkeeping, embedding
+// of the selected token into the next step's residual stream and the per-row position advance — one workgroup per row.
+//
+//   greedy   : fp32 argmax, lowest index on ties            [HF] generation/utils.py:2894,2925
+//   sampling : temperature -> top-k -> top-p -> multinomial  [HF] generation/logits_process.py (TemperatureLogitsWarper,
+//              TopKLogitsWarper, TopPLogitsWarper) + utils.py:2921-2923; what vcoder_llava/serve/cli.py:122-132 asks for
+//              (do_sample=True, temperature=0.2) and serve/chat.py:141-151 (temperature, top_p)
+//   finished rows emit pad, EOS finishes a row                [HF] generation/utils.py:2928-2929
+//   keyword stop: suffix match of the row's ids               vcoder_llava/mm_utils.py:128-151 (KeywordsStoppingCriteria)
+//   embedding of the chosen token                             [HF] llama/modeling_llama.py:377
+//
+// Everything a row needs lives in its RowState record in device memory (kernels.h: RS_*), so ONE captured hipGraph serves
+// every step of every request: rows of different requests (different prompt lengths, step counts, sampling parameters,
+// stop sequences) can share a decode step.  Rows are independent; a row only ever touches its own record.
+//
+// Sampling runs entirely on the device: the scaled logits of the row sit in LDS (V * 4 bytes; 125 KiB for Llama's 32000),
+// top-k and top-p thresholds are found by bit-wise bisection over the order-preserving integer image of the fp32 values
+// (exact: 32 counting / mass passes over LDS, no sort), and the draw is a Gumbel-max over the kept set with a counter-based
+// generator keyed by (seed, step, vocabulary index) — the same seed reproduces the same tokens, on any launch geometry.
+#include "vc_device.h"
+#include "kernels.h"
+
+namespace vc {
+
+VC_DEV void argmax_combine2(float& v, int& i, float ov, int oi) {
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
+
+// order-preserving map fp32 -> uint32 (negative values reversed, positive offset): a < b  <=>  key(a) < key(b)
+VC_DEV uint32_t fkey(float f) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+VC_DEV uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+// uniform in (0,1) from (seed, step, index): 24 random bits, never 0 or 1
+VC_DEV float sample_uniform(uint32_t seed_lo, uint32_t seed_hi, uint32_t step, uint32_t idx) {
+    uint32_t h = mix32(idx * 0x9E3779B1u + seed_lo);
+    h = mix32(h ^ (step * 0x85EBCA6Bu + seed_hi));
+    return ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}
+
+struct BlockRed {  // cross-wave scratch of the 1024-thread workgroup
+    float f[16];
+    int i[16];
+};
+
+VC_DEV int block_sum_i(int v, BlockRed& r, int lane, int wave) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);
+    if (lane == 0) r.i[wave] = v;
+    __syncthreads();
+    int s = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) s += r.i[w];
+    __syncthreads();
+    return s;
+}
+VC_DEV float block_sum_f(float v, BlockRed& r, int lane, int wave) {
+    v = wave_sum(v);
+    if (lane == 0) r.f[wave] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) s += r.f[w];  // fixed order: bit-reproducible
+    __syncthreads();
+    return s;
+}
+VC_DEV void block_argmax(float& v, int& i, BlockRed& r, int lane, int wave) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const float ov = shfl_xor(v, m);
+        const int oi = shfl_xor(i, m);
+        argmax_combine2(v, i, ov, oi);
+    }
+    if (lane == 0) { r.f[wave] = v; r.i[wave] = i; }
+    __syncthreads();
+    v = r.f[0];
+    i = r.i[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) argmax_combine2(v, i, r.f[w], r.i[w]);
+    __syncthreads();
+}
+
+// bf16 embedding row -> fp32 residual row + sum-of-squares partials + xg = bf16(x * g) (the first GEMV's operand)
+VC_DEV void embed_row_ssq(const bf16_t* sp, float* dp, float* ssq_row, const float* gw, bf16_t* xg, int D, int npart,
+                          int lane) {
+    float ss = 0.f;
+    for (int c = lane; c < D / 8; c += 64) {
+        const u32x4 v = ld16(sp + c * 8);
+        const f32x4 a = {bf2f_lo(v[0]), bf2f_hi(v[0]), bf2f_lo(v[1]), bf2f_hi(v[1])};
+        const f32x4 b = {bf2f_lo(v[2]), bf2f_hi(v[2]), bf2f_lo(v[3]), bf2f_hi(v[3])};
+        st16f(dp + c * 8, a);
+        st16f(dp + c * 8 + 4, b);
+        const f32x4 g0 = ld16f(gw + c * 8), g1 = ld16f(gw + c * 8 + 4);
+        st16(xg + c * 8, u32x4{pack_bf2(a[0] * g0[0], a[1] * g0[1]), pack_bf2(a[2] * g0[2], a[3] * g0[3]),
+                               pack_bf2(b[0] * g1[0], b[1] * g1[1]), pack_bf2(b[2] * g1[2], b[3] * g1[3])});
+        ss += ((a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3])) +
+              ((b[0] * b[0] + b[1] * b[1]) + (b[2] * b[2] + b[3] * b[3]));
+    }
+    ss = wave_sum(ss);
+    for (int q = lane; q < npart; q += 64) ssq_row[q] = q == 0 ? ss : 0.f;
+}
+
+__global__ __launch_bounds__(1024) void select_embed_kernel(SelectArgs p) {
+    VC_DYNAMIC_SMEM(float, zs);  // [V] scaled logits of the row (sampling only)
+    __shared__ BlockRed red;
+    __shared__ int tok_s;
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int* rs = p.rows + (size_t)r * RS_STRIDE;
+    if (!rs[RS_ACTIVE]) return;
+    const int step = rs[RS_STEP];
+    const float* lg = p.logits + (size_t)r * p.ldl;
+    const int V = p.V;
+    float best = -INFINITY;
+    int bi = 0x7FFFFFFF;
+    if (!rs[RS_SAMPLE]) {
+        for (int i = tid * 4; i < V; i += 4096) {
+            const f32x4 v = ld16f(lg + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) argmax_combine2(best, bi, v[e], i + e);
+        }
+        block_argmax(best, bi, red, lane, wave);
+    } else {
+        const float inv_t = __builtin_bit_cast(float, rs[RS_INVTEMP]);
+        const int top_k = rs[RS_TOPK];
+        const float top_p = __builtin_bit_cast(float, rs[RS_TOPP]);
+        const uint32_t seed_lo = (uint32_t)rs[RS_SEED_LO], seed_hi = (uint32_t)rs[RS_SEED_HI];
+        const bool staged = p.lds_floats >= V;
+        auto z = [&](int i) { return staged ? zs[i] : lg[i] * inv_t; };
+        if (staged) {
+            for (int i = tid; i < V; i += 1024) zs[i] = lg[i] * inv_t;
+            __syncthreads();
+        }
+        // ---- top-k: keep z >= (k-th largest value); ties at the threshold are all kept, as TopKLogitsWarper does
+        uint32_t kmin = 0;  // keep keys >= kmin
+        if (top_k > 0 && top_k < V) {
+            uint32_t t = 0;
+            for (int bit = 31; bit >= 0; --bit) {
+                const uint32_t cand = t | (1u << bit);
+                int c = 0;
+                for (int i = tid; i < V; i += 1024) c += fkey(z(i)) >= cand;
+                if (block_sum_i(c, red, lane, wave) >= top_k) t = cand;
+            }
+            kmin = t;
+        }
+        // ---- top-p over the survivors: ascending cumulative probability <= 1 - top_p is removed (TopPLogitsWarper)
+        uint32_t kgt = 0;  // keep keys > kgt (0 = none removed: no finite value has key 0)
+        bool only_max = false;
+        if (top_p < 1.0f) {
+            float mx = -INFINITY;
+            for (int i = tid; i < V; i += 1024) mx = fmaxf(mx, z(i));
+            int dummy = 0;
+            block_argmax(mx, dummy, red, lane, wave);
+            float zsum = 0.f;
+            for (int i = tid; i < V; i += 1024) {
+                const float v = z(i);
+                if (fkey(v) >= kmin) zsum += __expf(v - mx);
+            }
+            zsum = block_sum_f(zsum, red, lane, wave);
+            const float target = (1.0f - top_p) * zsum;
+            if (!(top_p > 0.f)) {
+                only_max = true;
+            } else {
+                uint32_t t = 0;
+                for (int bit = 31; bit >= 0; --bit) {
+                    const uint32_t cand = t | (1u << bit);
+                    float mass = 0.f;
+                    for (int i = tid; i < V; i += 1024) {
+                        const float v = z(i);
+                        const uint32_t k = fkey(v);
+                        if (k >= kmin && k <= cand) mass += __expf(v - mx);
+                    }
+                    if (block_sum_f(mass, red, lane, wave) <= target) t = cand;
+                }
+                kgt = t;
+            }
+        }
+        // ---- multinomial over the kept set as a Gumbel-max: argmax_i (z_i - log(-log u_i)) ~ softmax(z) restricted to it
+        for (int i = tid; i < V; i += 1024) {
+            const float v = z(i);
+            const uint32_t k = fkey(v);
+            if (k < kmin || k <= kgt || !(v > -INFINITY)) continue;
+            const float g = only_max ? 0.f : -__logf(-__logf(sample_uniform(seed_lo, seed_hi, (uint32_t)step, (uint32_t)i)));
+            argmax_combine2(best, bi, v + g, i);
+        }
+        block_argmax(best, bi, red, lane, wave);
+    }
+    // ---- bookkeeping (one lane) ----------------------------------------------------------------------------------
+    if (tid == 0) {
+        const int eos = rs[RS_EOS], pad = rs[RS_PAD], nstop = rs[RS_NSTOP], max_new = rs[RS_MAXNEW];
+        const bool can_finish = eos >= 0 || nstop > 0;
+        const int was_finished = can_finish ? rs[RS_FINISHED] : 0;
+        int tok = bi;
+        if (can_finish) {
+            if (was_finished) tok = pad;
+            if (eos >= 0 && tok == eos) rs[RS_FINISHED] = 1;
+        }
+        p.next_tok[r] = tok;
+        int* out = p.out_ids + rs[RS_OUT_OFF];
+        if (step < max_new) out[step] = tok;
+        if (nstop > 0 && !was_finished) {  // suffix match of the row's ids (prompt tail | generated so far | tok)
+            bool hit = false;
+            for (int sq = 0; sq < nstop; ++sq) {
+                const int* e = rs + RS_STOP + sq * (1 + VC_MAX_STOP_LEN);
+                const int L = e[0];
+                bool ok = L > 0;
+                for (int i = 0; i < L && ok; ++i) {
+                    const int back = L - 1 - i;  // 0 = the token just selected
+                    int v;
+                    if (back == 0) v = tok;
+                    else if (step - back >= 0) v = out[step - back];
+                    else v = rs[RS_TAIL + (VC_MAX_STOP_LEN - 1) + (step - back)];
+                    ok = v == e[1 + i];
+                }
+                hit = hit || ok;
+            }
+            if (hit) rs[RS_FINISHED] = 1;
+        }
+        tok_s = tok;
+        if (p.advance & 1) rs[RS_STEP] = step + 1;
+        if (p.advance & 2) rs[RS_POS] += 1;
+    }
+    __syncthreads();
+    if (wave == 0 && p.embed != nullptr) {
+        const int tok = tok_s;
+        embed_row_ssq(p.embed + (size_t)tok * p.D, p.x + (size_t)r * p.D, p.ssq + (size_t)r * p.npart, p.xg_w,
+                      p.xg + (size_t)r * p.D, p.D, p.npart, lane);
+    }
+}
+
+void launch_select_embed(const SelectArgs& a0, hipStream_t s) {
+    SelectArgs a = a0;
+    // the row's scaled logits are staged in LDS when they fit (sampling only reads them ~70 times)
+    size_t lds = (size_t)a.V * 4;
+    if (lds > 150 * 1024) lds = 0;
+    a.lds_floats = (int)(lds / 4);
+#ifndef VC_EMU
+    static size_t allowed = 0;
+    if (lds > 48 * 1024 && lds > allowed) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(select_embed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        allowed = lds;
+    }
+#endif
+    VC_LAUNCH(select_embed_kernel, dim3(a.nrows), dim3(1024), lds, s, a);
+}
+
+// embedding + sum-of-squares partials for tokens supplied by the host (vc_decode_step with explicit tokens)
+__global__ __launch_bounds__(256) void embed_tokens_ssq_kernel(const int* tok, const bf16_t* embed, float* x, float* ssq,
+                                                               const float* xg_w, bf16_t* xg, int B, int D, int npart) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    embed_row_ssq(embed + (size_t)tok[row] * D, x + (size_t)row * D, ssq + (size_t)row * npart, xg_w, xg + (size_t)row * D, D,
+                  npart, threadIdx.x & 63);
+}
+void launch_embed_tokens_ssq(const int* tok, const bf16_t* embed, float* x, float* ssq, const float* xg_w, bf16_t* xg, int B,
+                             int D, int npart, hipStream_t s) {
+    VC_LAUNCH(embed_tokens_ssq_kernel, dim3((B + 3) / 4), dim3(256), 0, s, tok, embed, x, ssq, xg_w, xg, B, D, npart);
+}
+
+// host-written row records: one launch copies `n` ints per row from a staging table into the live RowState array of the
+// decode loop, stream-ordered between two decode steps (rows join a running loop without a host synchronisation)
+__global__ __launch_bounds__(128) void rows_write_kernel(int* rows, const int* src, int row0) {
+    rows[(size_t)(row0 + blockIdx.x) * RS_STRIDE + threadIdx.x] = src[(size_t)blockIdx.x * RS_STRIDE + threadIdx.x];
+}
+void launch_rows_write(int* rows, const int* src, int row0, int nrows, hipStream_t s) {
+    static_assert(RS_STRIDE == 128, "one thread per record word");
+    VC_LAUNCH(rows_write_kernel, dim3(nrows), dim3(RS_STRIDE), 0, s, rows, src, row0);
+}
+
+}  // namespace vc

@@ -182,6 +182,42 @@ class HipEngine:
         if tuple(a.shape) != (B, 3, s, s):
             raise ValueError(f"expected pixel tensor [{B},3,{s},{s}], got {tuple(a.shape)}")
 
+    def _image_block(self, a, B):
+        """One modality of a batch -> (pixels [N,3,S,S], counts or None).  Accepts the reference's three input forms
+        (vcoder_ds_llava_arch.py:135-169): a 4-D tensor [B,3,S,S]; a list of B tensors [n_b,3,S,S]; a 5-D tensor
+        [B,n,3,S,S] — in the last two, sample b owns n_b images whose features are spliced as one block."""
+        if a is None:
+            return None, None
+        if not isinstance(a, (list, tuple)) and a.ndim != 5:
+            self._check_pixels(a, B)
+            return a, None
+        items = list(a)
+        if len(items) != B:
+            raise ValueError(f"expected {B} per-sample image groups, got {len(items)}")
+        s = self.cfg.vit_image_size
+        for it in items:
+            if it.ndim != 4 or tuple(it.shape[1:]) != (3, s, s):
+                raise ValueError(f"expected per-sample image groups [n,3,{s},{s}], got {tuple(it.shape)}")
+        counts = [int(it.shape[0]) for it in items]
+        if _is_torch(items[0]):
+            import torch
+
+            cat = torch.cat(items, dim=0)
+        else:
+            cat = np.concatenate([np.asarray(it) for it in items], axis=0)
+        return cat, (None if all(c == 1 for c in counts) else counts)
+
+    def _image_blocks(self, B, images, segs, depths):
+        """-> ([img, seg, depth] concatenated pixel blocks, keep-alive counts arrays); announces per-sample image counts
+        to the library (one-shot, consumed by the next prefill / generate call)."""
+        blocks, counts = zip(*(self._image_block(a, B) for a in (images, segs, depths)))
+        if any(c is not None for c in counts):
+            arrs = [None if blk is None else np.ascontiguousarray(c if c is not None else [1] * B, dtype=np.int32)
+                    for blk, c in zip(blocks, counts)]
+            self._check(self.lib.vc_set_image_counts(self._model, *(None if a is None else a.ctypes.data_as(C.c_void_p)
+                                                                    for a in arrs), B))
+        return list(blocks)
+
     @staticmethod
     def _ids(input_ids) -> np.ndarray:
         if _is_torch(input_ids):
@@ -205,14 +241,12 @@ class HipEngine:
     def inputs_embeds(self, input_ids, images, segs=None, depths=None, has_attention_mask: bool = False) -> np.ndarray:
         ids = self._ids(input_ids)
         B, T = ids.shape
-        for a in (images, segs, depths):
-            self._check_pixels(a, B)
-        (pi, ps, pd), on_dev, keep = self._pixels(images, segs, depths)
+        (pi, ps, pd), on_dev, keep = self._pixels(*self._image_blocks(B, images, segs, depths))
         S = C.c_int(0)
         # first call sizes the output; lengths are only known after the splice plan, so run twice is avoided by
         # allocating for the worst case: every placeholder expands to a feature block
         rows = self.cfg.num_patches + (1 if self.cfg.mm_vision_select_feature == "cls_patch" else 0)
-        worst = T + 3 * rows * max(1, int((ids < 0).sum(axis=1).max()))
+        worst = T + rows * self._max_feature_blocks(ids, keep)
         out = np.empty((B * worst * self.cfg.hidden_size,), dtype=np.float32)
         self._check(self.lib.vc_prefill_embeds_only(self._model, ids.ctypes.data_as(C.c_void_p), B, T, pi, ps, pd, on_dev,
                                                     int(has_attention_mask), out.ctypes.data_as(C.c_void_p), C.byref(S)))
@@ -220,13 +254,14 @@ class HipEngine:
         return out[: B * S.value * self.cfg.hidden_size].reshape(B, S.value, self.cfg.hidden_size).copy()
 
     def prefill(self, input_ids, images, segs=None, depths=None, has_attention_mask: bool = False,
-                all_logits: bool = False):
-        """-> (logits_last [B,V], logits_all [B,S,V] or None, S)"""
+                all_logits: bool = False, reserve: Optional[int] = None):
+        """-> (logits_last [B,V], logits_all [B,S,V] or None, S).  reserve: decode_step calls the caller intends to make
+        (sizes the KV cache up front; a longer loop still works — the cache grows)."""
         ids = self._ids(input_ids)
         B, T = ids.shape
-        for a in (images, segs, depths):
-            self._check_pixels(a, B)
-        (pi, ps, pd), on_dev, keep = self._pixels(images, segs, depths)
+        if reserve is not None:
+            self._check(self.lib.vc_model_reserve_decode(self._model, int(reserve)))
+        (pi, ps, pd), on_dev, keep = self._pixels(*self._image_blocks(B, images, segs, depths))
         V = self.cfg.vocab_size
         last = np.empty((B, V), dtype=np.float32)
         S = C.c_int(0)
@@ -237,7 +272,7 @@ class HipEngine:
             self._cur_batch = B
             return last, None, S.value
         rows = self.cfg.num_patches + (1 if self.cfg.mm_vision_select_feature == "cls_patch" else 0)
-        worst = T + 3 * rows * max(1, int((ids < 0).sum(axis=1).max()))
+        worst = T + rows * self._max_feature_blocks(ids, keep)
         full = np.empty((B * worst * V,), dtype=np.float32)
         self._check(self.lib.vc_prefill(self._model, ids.ctypes.data_as(C.c_void_p), B, T, pi, ps, pd, on_dev,
                                         int(has_attention_mask), last.ctypes.data_as(C.c_void_p),
@@ -245,6 +280,23 @@ class HipEngine:
         self.last_S = S.value
         self._cur_batch = B
         return last, full[: B * S.value * V].reshape(B, S.value, V).copy(), S.value
+
+    @staticmethod
+    def _max_feature_blocks(ids, pixel_blocks) -> int:
+        """upper bound of the image blocks (of `rows` feature rows) one sample can splice: every placeholder could expand
+        to all images of a modality"""
+        n_images = sum(int(b.shape[0]) for b in pixel_blocks)
+        return max(1, int((ids < 0).sum(axis=1).max())) * max(1, n_images)
+
+    def vision_tower_forward(self, pixels) -> np.ndarray:
+        """CLIPVisionTower.forward (clip_encoder.py:39-51): [N,3,S,S] -> un-projected features [N, R, mm_hidden_size]."""
+        N = int(pixels.shape[0])
+        self._check_pixels(pixels, N)
+        (p,), on_dev, keep = self._pixels(pixels)
+        rows = self.cfg.num_patches + (1 if self.cfg.mm_vision_select_feature == "cls_patch" else 0)
+        out = np.empty((N, rows, self.cfg.mm_hidden_size), dtype=np.float32)
+        self._check(self.lib.vc_vision_tower_forward(self._model, p, on_dev, N, out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def decode_step(self, tokens=None, want_logits: bool = True):
         """-> (logits [B,V] or None, next_tok [B] int32)"""
@@ -268,38 +320,66 @@ class HipEngine:
                         stop_sequences: Optional[Sequence[Sequence[int]]] = None) -> np.ndarray:
         """-> new token ids [B, n_generated] int32 (prompt not included).  stop_sequences: up to 8 token-id sequences of
         up to 8 ids; a row is finished (pads afterwards) once its ids end with one of them — checked on the device."""
+        return self.generate(input_ids, images, segs, depths, max_new_tokens=max_new_tokens, eos_token_id=eos_token_id,
+                             pad_token_id=pad_token_id, stop_sequences=stop_sequences)
+
+    def generate(self, input_ids, images, segs=None, depths=None, max_new_tokens: int = 128,
+                 eos_token_id: Optional[int] = None, pad_token_id: Optional[int] = None,
+                 stop_sequences: Optional[Sequence[Sequence[int]]] = None, do_sample: bool = False,
+                 temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0, seed: int = 0,
+                 on_tokens=None, stream_every: int = 1) -> np.ndarray:
+        """generate() on the device (vc_generate): greedy, or temperature / top-k / top-p sampling with a counter-based
+        generator (same seed -> same tokens).  on_tokens(first_step, ids [B, n]) is called with every `stream_every` new
+        columns while the hipGraph-replayed decode loop keeps running in between.  -> new ids [B, n_generated] int32."""
         ids = self._ids(input_ids)
         B, T = ids.shape
-        for a in (images, segs, depths):
-            self._check_pixels(a, B)
         pad = int(self.cfg.pad_token_id or 0) if pad_token_id is None else int(pad_token_id)
         if B > self.MAX_BATCH:
-            # a replica decodes at most 16 sequences at a time: larger batches run as consecutive pieces.  Rows are
+            # a replica prefills at most 16 sequences at a time: larger batches run as consecutive pieces.  Rows are
             # independent, so the result equals the whole-batch one: finished rows pad to the longest piece, and unequal
             # spliced lengths ACROSS pieces fail like they do inside one (the reference's quirk 6)
+            if on_tokens is not None:
+                raise ValueError(f"streaming needs a batch of at most {self.MAX_BATCH} sequences")
             parts, lens = [], set()
             for b0 in range(0, B, self.MAX_BATCH):
                 sl = slice(b0, b0 + self.MAX_BATCH)
-                parts.append(self.generate_greedy(ids[sl], *(None if a is None else a[sl] for a in (images, segs, depths)),
-                                                  max_new_tokens=max_new_tokens, eos_token_id=eos_token_id,
-                                                  pad_token_id=pad_token_id, stop_sequences=stop_sequences))
+                parts.append(self.generate(ids[sl], *(None if a is None else a[sl] for a in (images, segs, depths)),
+                                           max_new_tokens=max_new_tokens, eos_token_id=eos_token_id,
+                                           pad_token_id=pad_token_id, stop_sequences=stop_sequences, do_sample=do_sample,
+                                           temperature=temperature, top_k=top_k, top_p=top_p, seed=seed + b0))
                 lens.add(int(self.lib.vc_last_spliced_len(self._model)))
             if len(lens) > 1:
                 raise UnboundLocalError("local variable '_new_labels' referenced before assignment")
             n = max(p.shape[1] for p in parts)
             return np.concatenate([np.pad(p, ((0, 0), (0, n - p.shape[1])), constant_values=pad) for p in parts], axis=0)
-        (pi, ps, pd), on_dev, keep = self._pixels(images, segs, depths)
+        (pi, ps, pd), on_dev, keep = self._pixels(*self._image_blocks(B, images, segs, depths))
         out = np.empty((B, max_new_tokens), dtype=np.int32)
         n = C.c_int(0)
         eos = -1 if eos_token_id is None else int(eos_token_id)
         stops = [list(map(int, q)) for q in (stop_sequences or [])]
         flat = np.ascontiguousarray([t for q in stops for t in q], dtype=np.int32)
         lens = np.ascontiguousarray([len(q) for q in stops], dtype=np.int32)
-        self._check(self.lib.vc_generate_greedy_stop(self._model, ids.ctypes.data_as(C.c_void_p), B, T, pi, ps, pd, on_dev,
-                                                     int(max_new_tokens), eos, pad,
-                                                     flat.ctypes.data_as(C.c_void_p) if stops else None,
-                                                     lens.ctypes.data_as(C.c_void_p) if stops else None, len(stops),
-                                                     out.ctypes.data_as(C.c_void_p), C.byref(n)))
+        samp = None
+        if do_sample:
+            samp = _lib.Sampling(1, float(temperature), int(top_k or 0), float(1.0 if top_p is None else top_p),
+                                 int(seed) & 0xFFFFFFFFFFFFFFFF)
+        errs = []
+
+        def _cb(_user, first, nsteps, nb, ptr):
+            try:
+                on_tokens(first, np.ctypeslib.as_array(ptr, shape=(nb, nsteps)).copy())
+            except BaseException as e:   # never unwind through the C frames
+                errs.append(e)
+
+        cb = _lib.TOKEN_CB(_cb) if on_tokens is not None else _lib.TOKEN_CB()
+        self._check(self.lib.vc_generate(self._model, ids.ctypes.data_as(C.c_void_p), B, T, pi, ps, pd, on_dev,
+                                         int(max_new_tokens), eos, pad,
+                                         flat.ctypes.data_as(C.c_void_p) if stops else None,
+                                         lens.ctypes.data_as(C.c_void_p) if stops else None, len(stops),
+                                         C.byref(samp) if samp is not None else None, cb, None, int(stream_every),
+                                         out.ctypes.data_as(C.c_void_p), C.byref(n)))
+        if errs:
+            raise errs[0]
         self._cur_batch = B
         return out[:, : n.value].copy()
 

@@ -31,6 +31,10 @@ _SYSTEM = {
                  "The assistant gives helpful, detailed, and polite answers to the user's questions.",
 }
 STOP_STR = "</s>"
+# appended to the question when a sample has no segmentation map (model_seg_loader.py:72 / model_depth_loader.py)
+PARAGRAPH_INSTRUCTION = (" Return the answer in the paragraph format: 'The objects present in the image are: ...' and then "
+                         "list the objects with their count in word format (if greater than 1) in front of them, like "
+                         "'two people'.")
 
 
 def build_prompt(question: str, conv_mode: str = "llava_v1") -> str:
@@ -103,7 +107,7 @@ def generate_answers(model, tokenizer, samples: Sequence[Sample], batch_size: in
             if s.depth_file is not None:
                 q = DEFAULT_DEPTH_TOKEN + "\n" + q
         else:
-            q = DEFAULT_IMAGE_TOKEN + "\n" + q
+            q = DEFAULT_IMAGE_TOKEN + "\n" + q + PARAGRAPH_INSTRUCTION   # model_seg_loader.py:70-72
         p = build_prompt(q, conv_mode)
         prompts.append(p)
         buckets.setdefault(p, []).append(i)
@@ -141,7 +145,9 @@ def write_answers(path: str, samples: Sequence[Sample], answers: Sequence[str]) 
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     with open(path, "a") as f:
         for s, a in zip(samples, answers):
-            f.write(f"Image: {s.image_file}\n")
+            # the scorers key predictions by the bare file name (model_seg_loader.py:85 `image_file.split("/")[-1]`;
+            # eval_seg_accuracy.py:165, eval_depth_accuracy.py:42)
+            f.write(f"Image: {s.image_file.split('/')[-1]}\n")
             f.write(f"<<QUESTION>>: {s.question}\n")
             f.write(f"<<ANSWER>>: {a}\n")
             f.write("-------------------------------------------------------\n")

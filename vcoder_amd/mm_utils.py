@@ -35,10 +35,15 @@ def tokenizer_image_token(prompt, tokenizer, image_token_index=IMAGE_TOKEN_INDEX
 
 def tokenizer_seg_token(prompt, tokenizer, image_token_index=IMAGE_TOKEN_INDEX, seg_token_index=SEG_TOKEN_INDEX,
                         return_tensors=None):
-    # the reference inserts [SEG, IMG]*(offset+1) and then drops the trailing element of that separator
-    # (mm_utils.py:78-82), which nets out to the pair order [IMG, SEG] observed in tests/golden/tokenizer_orders.json
-    ids = _join_with(_chunk_ids(prompt, tokenizer, "<seg>\n<image>"), [image_token_index, seg_token_index], tokenizer)
-    return _ret(ids, return_tensors)
+    # the reference inserts [SEG, IMG]*(offset+1) between the chunks and keeps x[offset:-1] of it (mm_utils.py:78-82):
+    # with a BOS-prepending tokenizer (offset 1; every Llama tokenizer) that is the pair [IMG, SEG] observed in
+    # tests/golden/tokenizer_orders.json; with a tokenizer that adds no BOS (offset 0) only [SEG] survives — the <image>
+    # placeholder is lost.  Reproduced as is: the id order is part of the splice's parity contract.
+    chunks = _chunk_ids(prompt, tokenizer, "<seg>\n<image>")
+    bos = getattr(tokenizer, "bos_token_id", None)
+    has_bos = bool(chunks) and bool(chunks[0]) and chunks[0][0] == bos
+    sep = [image_token_index, seg_token_index] if has_bos else [seg_token_index]
+    return _ret(_join_with(chunks, sep, tokenizer), return_tensors)
 
 
 def _tokenizer_depth_token(prompt, tokenizer, image_token_index=IMAGE_TOKEN_INDEX, seg_token_index=SEG_TOKEN_INDEX,

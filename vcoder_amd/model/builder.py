@@ -22,6 +22,10 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, l
     if "lora" in name or model_base is not None:
         raise NotImplementedError("LoRA / projector-only checkpoints: merge with the reference's "
                                   "scripts/merge_lora_weights.py first")
+    if "vcoder_it" in name:
+        # the reference dispatches these names to VCoderITLlavaLlamaForCausalLM (builder.py:93), an unreleased variant that
+        # is not on the hot path — refuse rather than load it as a plain LLaVA
+        raise NotImplementedError("vcoder_it_llava checkpoints (VCoderITLlavaLlamaForCausalLM) are outside the MI355X hot path")
     tokenizer = _load_tokenizer(model_path)
     if "vcoder_ds_llava" in name:
         cls = VCoderDSLlavaLlamaForCausalLM

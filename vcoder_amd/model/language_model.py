@@ -92,6 +92,9 @@ class _HipCausalLMBase:
         if ":" in self._device_str:
             idx = int(self._device_str.split(":")[1])
         self.engine = HipEngine(config, device_index=idx, lib=_lib_override)
+        tower = self.model.get_vision_tower()
+        if tower is not None:
+            tower._engine = self.engine          # CLIPVisionTower.forward runs on the engine's tower kernels
         self._generation = 0
         self.training = False
         self.generation_config = SimpleNamespace(pad_token_id=config.pad_token_id, eos_token_id=config.eos_token_id,
@@ -183,6 +186,7 @@ class _HipCausalLMBase:
             raise NotImplementedError("attention maps / hidden states are not materialised by the fused kernels")
         ids = input_ids
         B = ids.shape[0]
+        _require_trivial_mask(attention_mask)
         if past_key_values is not None and ids.shape[1] == 1:
             # cached decode step: the input_ids.shape[1]==1 fast path (vcoder_ds_llava_arch.py:130-133)
             if not isinstance(past_key_values, KVCacheHandle) or past_key_values.generation != self._generation:
@@ -199,7 +203,8 @@ class _HipCausalLMBase:
                 raise ValueError("images is required (text-only forward is not part of the VCoder hot path)")
             _, full, S = self.engine.prefill(ids, images, segs if self.variant != "llava" else None,
                                              depths if self.variant == "vcoder_ds" else None,
-                                             has_attention_mask=attention_mask is not None, all_logits=True)
+                                             has_attention_mask=attention_mask is not None, all_logits=True,
+                                             reserve=self._decode_reserve)
             self._generation += 1
             logits = torch.from_numpy(full)
             pkv = KVCacheHandle(self, self._generation, S, B)
@@ -211,6 +216,10 @@ class _HipCausalLMBase:
         return out
 
     __call__ = forward
+
+    # KV slots a forward() prefill keeps free for the caller's cached decode steps (an HF-style external generate loop
+    # drives forward once per token); the cache grows if the loop runs longer
+    _decode_reserve = 512
 
     def prepare_inputs_for_generation(self, input_ids, past_key_values=None, attention_mask=None, inputs_embeds=None,
                                       **kwargs):
@@ -229,14 +238,21 @@ class _HipCausalLMBase:
 
     # ---- generate (HF GenerationMixin subset) ---------------------------------------
     def generate(self, input_ids=None, inputs=None, images=None, segs=None, depths=None, do_sample: bool = False,
-                 temperature: float = 1.0, top_p: Optional[float] = None, num_beams: int = 1,
+                 temperature: float = 1.0, top_p: Optional[float] = None, top_k: Optional[int] = None, num_beams: int = 1,
                  max_new_tokens: Optional[int] = None, max_length: Optional[int] = None, streamer=None,
                  use_cache: bool = True, stopping_criteria=None, eos_token_id=None, pad_token_id=None,
-                 attention_mask=None, generator=None, **kwargs):
+                 attention_mask=None, generator=None, seed: Optional[int] = None, **kwargs):
         """Returns cat(input_ids, new_ids) [B, T+n] int64 — the prompt part keeps its negative placeholder ids,
-        callers slice `[:, T:]` (serve/cli.py:135).  Greedy without streamer/stopping criteria runs fully on the
-        device (hipGraph-replayed steps, device-side argmax/EOS); sampling, streamers and stopping criteria use the
-        per-token decode_step loop (one host sync per token, exactly like the reference's HF loop)."""
+        callers slice `[:, T:]` (serve/cli.py:135).
+
+        Everything the reference's callers ask for runs on the device inside the hipGraph-replayed decode loop
+        (vc_generate): greedy argmax; sampling with HF's warper order temperature -> top-k -> top-p -> multinomial
+        (`top_k` defaults to 50 when sampling, HF's GenerationConfig default, which is what serve/cli.py:122-132 gets);
+        EOS / pad bookkeeping; stopping criteria that reduce to token-id suffixes (KeywordsStoppingCriteria(["</s>"]));
+        the streamer, fed from a callback every `stream_every` tokens.  Only a stopping criterion that needs host code
+        (a text match over several tokens) falls back to the per-token decode_step loop, like the reference's HF loop.
+        Sampling draws from a counter-based generator: pass `seed` (or a torch `generator`, whose initial seed is used)
+        for reproducible output; bit-equality with torch.multinomial's stream is not defined."""
         import torch
 
         if input_ids is None:
@@ -245,6 +261,7 @@ class _HipCausalLMBase:
             raise NotImplementedError("beam search is not used by the reference's VCoder callers (num_beams=1)")
         if temperature is not None and float(temperature) <= 0.0:
             do_sample = False
+        _require_trivial_mask(attention_mask)
         T = input_ids.shape[1]
         B = input_ids.shape[0]
         if max_new_tokens is None:
@@ -254,6 +271,13 @@ class _HipCausalLMBase:
         segs = segs if self.variant != "llava" else None
         depths = depths if self.variant == "vcoder_ds" else None
         ids_cpu = input_ids.detach().cpu() if hasattr(input_ids, "detach") else torch.as_tensor(np.asarray(input_ids))
+        if do_sample:
+            top_k = 50 if top_k is None else int(top_k)
+            top_p = 1.0 if top_p is None else float(top_p)
+            if seed is None:
+                seed = int(generator.initial_seed()) if generator is not None else int(torch.initial_seed())
+                seed = (seed + 0x9E3779B97F4A7C15 * self._sample_calls) & 0xFFFFFFFFFFFFFFFF   # successive calls differ
+                self._sample_calls += 1
         # stopping criteria that reduce to a token-id suffix match run on the device: the
         # reference's KeywordsStoppingCriteria(["</s>"]) of cli.py / the eval loaders is of that kind
         stops = []
@@ -263,24 +287,40 @@ class _HipCausalLMBase:
                 stops = None
                 break
             stops += seqs
-        simple = not do_sample and streamer is None and stops is not None and len(stops) <= 8
+        on_device = stops is not None and len(stops) <= 8
         if streamer is not None:
             streamer.put(ids_cpu)
-        if simple:
-            new = self.engine.generate_greedy(ids_cpu.numpy(), images, segs, depths, max_new_tokens=max_new_tokens,
-                                              eos_token_id=eos, pad_token_id=pad, stop_sequences=stops or None)
+        if on_device:
+            on_tokens = None
+            if streamer is not None:
+                def on_tokens(first, new_ids):   # HF feeds the streamer one [B] tensor per step
+                    for j in range(new_ids.shape[1]):
+                        streamer.put(torch.from_numpy(new_ids[:, j].astype(np.int64)))
+            new = self.engine.generate(ids_cpu.numpy(), images, segs, depths, max_new_tokens=max_new_tokens,
+                                       eos_token_id=eos, pad_token_id=pad, stop_sequences=stops or None,
+                                       do_sample=bool(do_sample), temperature=float(temperature or 1.0),
+                                       top_k=top_k or 0, top_p=1.0 if top_p is None else top_p, seed=seed or 0,
+                                       on_tokens=on_tokens, stream_every=kwargs.get("stream_every", 1))
             self._generation += 1
             out = torch.cat([ids_cpu, torch.from_numpy(new.astype(np.int64))], dim=1)
+            if streamer is not None:
+                streamer.end()
         else:
-            last, _, S = self.engine.prefill(ids_cpu.numpy(), images, segs, depths, has_attention_mask=True)
+            last, _, S = self.engine.prefill(ids_cpu.numpy(), images, segs, depths, has_attention_mask=True,
+                                             reserve=max_new_tokens)
             self._generation += 1
             logits = torch.from_numpy(last)
             unfinished = torch.ones(B, dtype=torch.long)
             cur = ids_cpu
+            if generator is None and do_sample:
+                generator = torch.Generator().manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)
             for step in range(max_new_tokens):
                 scores = logits.float()
                 if do_sample:
                     scores = scores / float(temperature)
+                    if top_k and 0 < top_k < scores.shape[-1]:
+                        kth = torch.topk(scores, top_k)[0][..., -1, None]
+                        scores = scores.masked_fill(scores < kth, float("-inf"))
                     if top_p is not None and top_p < 1.0:
                         scores = _top_p_filter(scores, float(top_p))
                     probs = torch.softmax(scores, dim=-1)
@@ -309,6 +349,21 @@ class _HipCausalLMBase:
         if hasattr(input_ids, "device"):
             out = out.to(input_ids.device)
         return out
+
+    _sample_calls = 0
+
+
+def _require_trivial_mask(attention_mask):
+    """The reference left-extends the caller's mask over the spliced feature rows (vcoder_ds_llava_arch.py:305-311) and
+    hands it to LlamaModel; every caller of the reference passes None or all ones (batch 1, no padding).  The fused
+    kernels implement exactly that case — a mask that actually hides positions is refused rather than ignored."""
+    if attention_mask is None:
+        return
+    m = attention_mask.detach().cpu().numpy() if hasattr(attention_mask, "detach") else np.asarray(attention_mask)
+    if m.size and not bool(np.all(m != 0)):
+        raise NotImplementedError("attention_mask with masked-out positions (padded batches) is not supported by the "
+                                  "MI355X hot path: pass equal-length prompts (the reference itself fails on unequal "
+                                  "spliced lengths, vcoder_ds_llava_arch.py:295-297)")
 
 
 def _reference_keyword_stop(crit):

@@ -60,14 +60,39 @@ class HipCLIPVisionTower:
     def num_patches(self):
         return (self.config.image_size // self.config.patch_size) ** 2
 
-    def feature_select(self, hidden_states):
-        raise NotImplementedError("feature_select is fused into the encoder (hidden_states[select_layer] is the last "
-                                  "layer evaluated; CLS is dropped by the select_rows kernel)")
+    def feature_select(self, image_forward_outs):
+        """clip_encoder.py:29-37 on a tower output.  The engine evaluates exactly hidden_states[select_layer] (later
+        layers are never computed), so the object forward() works with carries that one tensor (CLS row included);
+        an HF-style output with a `hidden_states` sequence is accepted too."""
+        hs = getattr(image_forward_outs, "hidden_states", None)
+        feats = hs[self.select_layer] if isinstance(hs, (list, tuple)) else image_forward_outs.selected_hidden_state
+        if self.select_feature == "patch":
+            return feats[:, 1:]
+        if self.select_feature == "cls_patch":
+            return feats
+        raise ValueError(f"Unexpected select feature: {self.select_feature}")
 
     def forward(self, images):
-        """[B,3,S,S] -> [B, num_patches, hidden_size] un-projected features are not exposed by the C ABI; use
-        model.engine.encode(images, modality) for projected features (encode_images of vcoder_ds_llava_arch.py:116)."""
-        raise NotImplementedError(self.forward.__doc__)
+        """clip_encoder.py:39-51: [B,3,S,S] tensor (or a list of [3,S,S] images) -> un-projected features
+        [B, num_patches, hidden_size] in the dtype / on the device of the input (vc_vision_tower_forward)."""
+        import numpy as np
+        import torch
+
+        if self._engine is None or not self._engine.finalized:
+            raise RuntimeError("vision tower weights are not loaded (load_model() / finalize_weights() first)")
+        if type(images) is list:
+            return [self.forward(im.unsqueeze(0)) for im in images]
+        t = images if isinstance(images, torch.Tensor) else torch.as_tensor(np.asarray(images))
+        feats = torch.from_numpy(self._engine.vision_tower_forward(t))
+        return feats.to(device=t.device, dtype=t.dtype if t.dtype.is_floating_point else torch.float32)
+
+    __call__ = forward
+
+    @property
+    def dummy_feature(self):
+        import torch
+
+        return torch.zeros(1, self.hidden_size)
 
 
 def load_image_processor(path: str, args):
