@@ -5,9 +5,12 @@ One "step" = one full pass of the hot path over one batch per GPU:
     3x CLIP ViT-L/14@336 encode (RGB, seg, depth) + adapters + splice + Llama prefill (S=1216)
     + 128 greedy tokens (1 from the prefill + 127 hipGraph-replayed decode steps), EOS disabled.
 Synthetic COST-shaped inputs, seeded synthetic weights (no network), bf16 MFMA compute, fp32 accumulate.
-Pixels are resident in HBM before the timed region.  N>1: one process per GPU (torchrun), batch sharded
-data-parallel with no collective on the data path; the only exchange is one RCCL all-gather of the
-generated token ids per step.
+`value`: inputs resident in HBM when the timed region starts (the task contract); the PCIe-inclusive rate (pixels
+handed over as host buffers) is measured in the same run and reported as `pcie_inclusive`.
+
+N > 1: one process per GPU, batch sharded data-parallel with no collective on the data path; the only exchange is
+one all-gather of the generated token ids per step over RCCL/xGMI.  `python bench.py --gpus N` starts its own N
+ranks (torch.distributed.run on 127.0.0.1); under an external torchrun (WORLD_SIZE set) it is one of the ranks.
 
 Prints ONE JSON line (rank 0).
 """
@@ -16,93 +19,19 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0    # dense bf16
 
 
-def cpu_baseline(cfg, B_for_rate: int, new_tokens: int):
-    """Oracle (oracle/cpu_ref.py, torch fp32, kind='port') timed on the host cores on a bounded sample:
-    one ViT encoder layer (1 image), one adapter, one Llama decoder layer prefill (B=1, S=1216) and one decoder
-    layer decode step (B=1, ctx=1216), extrapolated linearly to the full per-sample work."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import cpu_ref
-
-    torch.manual_seed(0)
-    cores = torch.get_num_threads()
-    g = lambda *s: torch.randn(*s) * 0.02
-    Dv, Fv, D, F, V = cfg.mm_hidden_size, cfg.vit_intermediate_size, cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size
-    vp = "vision_model."
-    sd = {vp + "embeddings.class_embedding": g(Dv),
-          vp + "embeddings.patch_embedding.weight": g(Dv, 3, cfg.vit_patch_size, cfg.vit_patch_size),
-          vp + "embeddings.position_embedding.weight": g(cfg.num_patches + 1, Dv),
-          vp + "pre_layrnorm.weight": torch.ones(Dv), vp + "pre_layrnorm.bias": torch.zeros(Dv)}
-    p = vp + "encoder.layers.0."
-    for ln in ("layer_norm1", "layer_norm2"):
-        sd[p + ln + ".weight"], sd[p + ln + ".bias"] = torch.ones(Dv), torch.zeros(Dv)
-    for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
-        sd[p + f"self_attn.{nm}.weight"], sd[p + f"self_attn.{nm}.bias"] = g(Dv, Dv), g(Dv)
-    sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"] = g(Fv, Dv), g(Fv)
-    sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"] = g(Dv, Fv), g(Dv)
-    sd["model.mm_projector.0.weight"], sd["model.mm_projector.0.bias"] = g(D, Dv), g(D)
-    sd["model.mm_projector.2.weight"], sd["model.mm_projector.2.bias"] = g(D, D), g(D)
-    lp = "model.layers.0."
-    sd[lp + "input_layernorm.weight"] = torch.ones(D)
-    sd[lp + "post_attention_layernorm.weight"] = torch.ones(D)
-    for nm in ("q", "k", "v", "o"):
-        sd[lp + f"self_attn.{nm}_proj.weight"] = g(D, D)
-    sd[lp + "mlp.gate_proj.weight"], sd[lp + "mlp.up_proj.weight"], sd[lp + "mlp.down_proj.weight"] = g(F, D), g(F, D), g(D, F)
-    sd["model.norm.weight"], sd["lm_head.weight"] = torch.ones(D), g(V, D)
-
-    class C1:  # one-layer views of the config
-        pass
-    c1 = C1()
-    for k in ("vit_patch_size", "vit_image_size", "vit_num_heads", "vit_layer_norm_eps", "mm_vision_select_feature",
-              "num_attention_heads", "rms_norm_eps", "rope_theta"):
-        setattr(c1, k, getattr(cfg, k))
-    c1.vit_layers_used, c1.num_hidden_layers = 1, 1
-    S = 64 + 2 * cfg.num_patches
-    px = torch.randn(1, 3, cfg.vit_image_size, cfg.vit_image_size)
-    def best_of(fn, reps):  # min over repetitions: excludes first-touch / thread-pool warm-up
-        ts = []
-        for _ in range(reps):
-            t0 = time.perf_counter()
-            r = fn()
-            ts.append(time.perf_counter() - t0)
-        return min(ts), r
-
-    with torch.no_grad():
-        t_vit1, feats = best_of(lambda: cpu_ref.vit_forward(px, sd, c1), 5)            # embed + 1 layer
-        t_ad, _ = best_of(lambda: cpu_ref.projector_forward(feats, sd, "model.mm_projector", "mlp2x_gelu"), 5)
-        x = torch.randn(1, S, D)
-        t_pre, _ = best_of(lambda: cpu_ref.llama_layer(x, sd, 0, c1, cpu_ref.KVCache(1), 0, cpu_ref.Rounder(False)), 4)
-        cache = cpu_ref.KVCache(1)
-        cpu_ref.llama_layer(x, sd, 0, c1, cache, 0, cpu_ref.Rounder(False))
-        xd = torch.randn(1, 1, D)
-        t0 = time.perf_counter()
-        for i in range(24):
-            cpu_ref.llama_layer(xd, sd, 0, c1, cache, S + i, cpu_ref.Rounder(False))
-        t_dec = (time.perf_counter() - t0) / 24
-        t_head, _ = best_of(lambda: torch.nn.functional.linear(xd, sd["lm_head.weight"]), 8)
-    per_sample = 3 * (cfg.vit_layers_used * t_vit1 + t_ad) + cfg.num_hidden_layers * t_pre + \
-        (new_tokens - 1) * (cfg.num_hidden_layers * t_dec + t_head)
-    return {"value": 1.0 / per_sample, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": (f"oracle/cpu_ref.py fp32 at true 7b dims, B=1: 1 ViT layer+embed ({t_vit1:.2f}s), adapter "
-                       f"({t_ad:.2f}s), 1 decoder layer prefill S={S} ({t_pre:.2f}s), 1 decoder layer decode step "
-                       f"({t_dec * 1e3:.0f}ms), lm_head ({t_head * 1e3:.0f}ms); linearly extrapolated to "
-                       f"3x{cfg.vit_layers_used} ViT layers + {cfg.num_hidden_layers} layers prefill + "
-                       f"{new_tokens - 1} decode steps per image")}
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
@@ -114,22 +43,170 @@ def main():
                     help="decoder weight storage: bf16 (BASELINE configs[1], the default metric) or fp8 = W8A16 e4m3 with "
                          "per-row power-of-two scales (the weight format of BASELINE configs[4])")
     ap.add_argument("--inflight", type=int, default=3,
-                    help="batches in flight per GPU: independent sessions (own stream + KV cache, shared weights) driven by "
-                         "host threads, so one batch's MFMA-bound prefill and per-launch ramps overlap another's "
-                         "HBM-bound decode.  1 = strictly one batch at a time")
+                    help="batches in flight per GPU: independent generate() calls (own stream + prefill workspaces, shared "
+                         "weights) driven by host threads.  1 = strictly one batch at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-c1", action="store_true",
+                    help="additionally run BASELINE configs[0] IN FULL on the host cores (VCoder 7b shape, B=1, RGB+seg, 32 "
+                         "greedy tokens through oracle/cpu_ref.py; minutes) and report it as cpu_c1")
     ap.add_argument("--host-pixels", action="store_true",
-                    help="hand the pixel tensors over as HOST buffers (fp32, pageable): the PCIe-inclusive rate noted in "
-                         "DESIGN.md; the default (and `value`) has the inputs resident in HBM")
+                    help="make the PCIe-inclusive form the timed one (pixels handed over as pageable host fp32 buffers)")
+    ap.add_argument("--gather", default="torch", choices=["torch", "cabi"],
+                    help="all-gather of the token ids: torch.distributed (backend nccl = RCCL) or the library's own "
+                         "vc_allgather_tokens (RCCL called through the C ABI)")
+    ap.add_argument("--dump-ids", default=None, help="write the gathered ids of the last timed step to this .npy (tests)")
     ap.add_argument("--pmc-traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass "
-                         "(default: profiles/r01_pmc_traffic.json, the committed FETCH_SIZE pass of this kernel)")
-    args = ap.parse_args()
+                         "(default: the committed FETCH_SIZE pass of this kernel under profiles/)")
+    return ap.parse_args()
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script on this node."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: required by RCCL on this host driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
+    return subprocess.call(cmd, env=env)
+
+
+# ---- algorithmic work of one sample (SURVEY.md §8(d)) --------------------------------------------------------------
+def work_per_sample(cfg, S, n_new, weight_bytes=2.0):
+    D, F, L, V = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers, cfg.vocab_size
+    Dv, Fv, Lv, P = cfg.mm_hidden_size, cfg.vit_intermediate_size, cfg.vit_layers_used, cfg.num_patches
+    T = P + 1
+    vit = 2 * P * 588 * Dv + Lv * (8 * T * Dv * Dv + 4 * T * T * Dv + 4 * T * Dv * Fv)
+    adapter = 2 * P * (Dv * D + D * D)
+    prefill = 2 * S * L * (4 * D * D + 3 * D * F) + 2 * S * S * D * L + 2 * D * V
+    mfma_flops = 3 * (vit + adapter) + prefill
+    dec_weight_bytes = weight_bytes * L * (4 * D * D + 3 * D * F) + 2 * D * V      # per decode step, shared by the rows in it
+    kv_bytes_per_pos = 4 * L * D                                                   # K + V, bf16, per sample and position
+    kv_bytes = sum(kv_bytes_per_pos * (S + t) for t in range(1, n_new))            # per sample over the decode steps
+    return mfma_flops, dec_weight_bytes, kv_bytes
+
+
+def cpu_baseline(cfg, n_new: int, decode_steps: int = 8):
+    """The oracle (oracle/cpu_ref.py, torch fp32, kind='port') timed on the host cores at the TRUE 7b dimensions, B = 1:
+    EVERY layer of the path — 3 x 23 ViT layers + adapters, all decoder layers of the S=1216 prefill, and `decode_steps`
+    complete cached decode steps (all layers + lm_head) — the decode leg extrapolated linearly from `decode_steps` to
+    n_new - 1 steps ("B=1 / N=8 and extrapolated").  Weights are constant fills (the arithmetic does not
+    depend on the values; distinct memory per layer, so nothing is served from cache that the real model would miss)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
+    import cpu_ref
+
+    cores = torch.get_num_threads()
+    D, F, V, L = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size, cfg.num_hidden_layers
+    Dv, Fv = cfg.mm_hidden_size, cfg.vit_intermediate_size
+    fill = lambda *s: torch.empty(*s).fill_(0.01)
+    vp = "vision_model."
+    sd = {vp + "embeddings.class_embedding": fill(Dv),
+          vp + "embeddings.patch_embedding.weight": fill(Dv, 3, cfg.vit_patch_size, cfg.vit_patch_size),
+          vp + "embeddings.position_embedding.weight": fill(cfg.num_patches + 1, Dv),
+          vp + "pre_layrnorm.weight": torch.ones(Dv), vp + "pre_layrnorm.bias": torch.zeros(Dv)}
+    for j in range(cfg.vit_layers_used):
+        p = vp + f"encoder.layers.{j}."
+        for ln in ("layer_norm1", "layer_norm2"):
+            sd[p + ln + ".weight"], sd[p + ln + ".bias"] = torch.ones(Dv), torch.zeros(Dv)
+        for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            sd[p + f"self_attn.{nm}.weight"], sd[p + f"self_attn.{nm}.bias"] = fill(Dv, Dv), fill(Dv)
+        sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"] = fill(Fv, Dv), fill(Fv)
+        sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"] = fill(Dv, Fv), fill(Dv)
+    for pj in ("model.mm_projector", "model.seg_mm_projector"):
+        sd[pj + ".0.weight"], sd[pj + ".0.bias"] = fill(D, Dv), fill(D)
+        sd[pj + ".2.weight"], sd[pj + ".2.bias"] = fill(D, D), fill(D)
+    for i in range(L):
+        lp = f"model.layers.{i}."
+        sd[lp + "input_layernorm.weight"] = torch.ones(D)
+        sd[lp + "post_attention_layernorm.weight"] = torch.ones(D)
+        for nm in ("q", "k", "v", "o"):
+            sd[lp + f"self_attn.{nm}_proj.weight"] = fill(D, D)
+        sd[lp + "mlp.gate_proj.weight"], sd[lp + "mlp.up_proj.weight"] = fill(F, D), fill(F, D)
+        sd[lp + "mlp.down_proj.weight"] = fill(D, F)
+    sd["model.norm.weight"], sd["lm_head.weight"], sd["model.embed_tokens.weight"] = torch.ones(D), fill(V, D), fill(V, D)
+    S = 64 + 2 * cfg.num_patches
+    px = torch.randn(3, 3, cfg.vit_image_size, cfg.vit_image_size)   # the three modalities of one sample
+    with torch.no_grad():
+        cpu_ref.vit_forward(px[:1], {k: v for k, v in sd.items()}, _one_vit_layer(cfg))   # thread-pool warm-up
+        t0 = time.perf_counter()
+        feats = cpu_ref.vit_forward(px, sd, cfg)
+        for pj in ("model.mm_projector", "model.seg_mm_projector", "model.seg_mm_projector"):
+            cpu_ref.projector_forward(feats[:1], sd, pj, "mlp2x_gelu")
+        t_enc = time.perf_counter() - t0
+        x = torch.randn(1, S, D) * 0.02
+        cache = cpu_ref.KVCache(L)
+        t0 = time.perf_counter()
+        logits = cpu_ref.llama_forward(x, sd, cfg, cache, last_only=True)
+        t_pre = time.perf_counter() - t0
+        xd = torch.randn(1, 1, D) * 0.02
+        t0 = time.perf_counter()
+        for _ in range(decode_steps):
+            cpu_ref.llama_forward(xd, sd, cfg, cache, last_only=True)
+        t_dec = (time.perf_counter() - t0) / decode_steps
+    per_sample = t_enc + t_pre + (n_new - 1) * t_dec
+    return {"value": 1.0 / per_sample, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": (f"oracle/cpu_ref.py fp32 at true {cfg.hidden_size}-wide dims, B=1, every layer: 3 modalities x "
+                       f"{cfg.vit_layers_used} ViT layers + adapters ({t_enc:.2f}s), {L}-layer prefill S={S} ({t_pre:.1f}s), "
+                       f"{decode_steps} full cached decode steps ({t_dec * 1e3:.0f}ms each) extrapolated linearly to "
+                       f"{n_new - 1} steps")}
+
+
+def _one_vit_layer(cfg):
+    class C1:
+        pass
+    c1 = C1()
+    for k in ("vit_patch_size", "vit_image_size", "vit_num_heads", "vit_layer_norm_eps", "mm_vision_select_feature"):
+        setattr(c1, k, getattr(cfg, k))
+    c1.vit_layers_used = 1
+    return c1
+
+
+def cpu_c1_full(new_tokens: int = 32):
+    """BASELINE configs[0] in full on the host cores: VCoder (non-DS) LLaVA-1.5-7b shape, ONE 336x336 RGB+seg pair, prompt
+    [1] + 34 text + [IMG, SEG] + 29 text (S = 1216), `new_tokens` greedy tokens through the oracle — the reference's CPU
+    plumbing case.  Weights: the seeded synthetic checkpoint generated on the GPU and copied back."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import torch
+    import cpu_ref
+    from test_gpu_fulldepth import device_state_dict
+    from vcoder_amd import config as vcfg, synth
+    from vcoder_amd.engine import HipEngine
+
+    cfg = vcfg.vicuna_7b("vcoder")
+    eng = HipEngine(cfg)
+    sd = device_state_dict(eng, cfg, 42)
+    eng.close()
+    ids = synth.synth_prompt_ids(cfg.vocab_size, "vcoder")[None]
+    imgs, segs, _ = synth.synth_batch(1, cfg.vit_image_size)
+    om = cpu_ref.OracleModel(cfg, sd)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        out = om.generate_greedy(ids.tolist(), torch.from_numpy(imgs), torch.from_numpy(segs), None, max_new_tokens=new_tokens)
+    dt = time.perf_counter() - t0
+    return {"config": "VCoder LLaVA-1.5-7b, single 336x336 RGB+seg pair, greedy %d tokens, oracle fp32 on the host cores" % new_tokens,
+            "seconds": dt, "images_per_s": 1.0 / dt, "cores": torch.get_num_threads(), "first_ids": out[0, :8].tolist()}
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
+    import numpy as np
+    import torch
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start bench.py directly (it launches its own ranks) or "
+                         f"with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False and there is no CPU fallback")
     # debugging knobs for exercising the multi-process path on a 1-GPU box: all ranks on one device, gloo gather
@@ -150,7 +227,7 @@ def main():
 
     from vcoder_amd import config as vcfg, synth
     from vcoder_amd.engine import HipEngine
-    from vcoder_amd.parallel import gather_token_ids, shard_range
+    from vcoder_amd.parallel import TokenComm, gather_token_ids, shard_range
 
     cfg = vcfg.vicuna_7b("vcoder_ds") if args.model == "7b" else vcfg.vicuna_13b("vcoder_ds")
     eng = HipEngine(cfg, device_index=local)
@@ -161,16 +238,28 @@ def main():
     B, N_new = args.batch, args.new_tokens
     first, _ = shard_range(world * B, rank, world)   # contiguous shard of the global batch
     ids = np.stack([synth.synth_prompt_ids(cfg.vocab_size, "vcoder_ds", sample=first + b) for b in range(B)])
-    imgs, segs, deps = synth.synth_batch(B, cfg.vit_image_size, first)
-    if not args.host_pixels:
-        imgs, segs, deps = (torch.from_numpy(a).cuda() for a in (imgs, segs, deps))
+    host_px = synth.synth_batch(B, cfg.vit_image_size, first)
+    dev_px = tuple(torch.from_numpy(a).cuda() for a in host_px)
+
+    comm = None
+    if args.gather == "cabi":
+        def exchange(raw: bytes) -> bytes:      # rank 0's RCCL unique id -> every rank, through the rendezvous store
+            box = [raw]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        comm = TokenComm(eng, rank, world, exchange if world > 1 else None)
+
+    def gather(local_ids):
+        if comm is not None:
+            return comm.allgather(local_ids)
+        return gather_token_ids(local_ids, dist, device="cuda" if backend == "nccl" else None)
 
     import threading
 
     n_sess = max(1, min(args.inflight, args.steps))
     sessions = [eng] + [eng.fork() for _ in range(n_sess - 1)]
 
-    def run_steps(k: int):
+    def run_steps(k: int, px):
         """k steps (= k batches of B per GPU), distributed round-robin over the in-flight sessions; every step is the
         complete hot path for its batch.  Token ids are all-gathered across ranks once per step, in step order."""
         outs = [None] * k
@@ -179,7 +268,7 @@ def main():
         def worker(si):
             try:
                 for j in range(si, k, n_sess):
-                    outs[j] = sessions[si].generate_greedy(ids, imgs, segs, deps, max_new_tokens=N_new, eos_token_id=None)
+                    outs[j] = sessions[si].generate_greedy(ids, *px, max_new_tokens=N_new, eos_token_id=None)
             except BaseException as e:  # surface failures of a session thread in the main thread
                 errs.append(e)
 
@@ -191,7 +280,7 @@ def main():
         if errs:
             raise errs[0]
         # the one exchange: all-gather of the token stream (RCCL over xGMI), once per batch; no-op for N=1
-        return [gather_token_ids(o, dist, device="cuda" if backend == "nccl" else None) for o in outs]
+        return [gather(o) for o in outs]
 
     def fence():
         if world > 1:
@@ -201,61 +290,98 @@ def main():
                 dist.barrier()
         torch.cuda.synchronize()
 
-    if args.warmup > 0:
-        run_steps(max(args.warmup, n_sess))  # every session captures its decode graph before the timed region
-    fence()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    timings = eng.last_timings()
-    # transparency leg (outside the timed region): the same step strictly one batch at a time on this rank
-    solo = None
-    if n_sess > 1:
+    def timed(k: int, px) -> float:
         fence()
-        t1 = time.perf_counter()
-        for _ in range(2):
-            sessions[0].generate_greedy(ids, imgs, segs, deps, max_new_tokens=N_new, eos_token_id=None)
-        torch.cuda.synchronize()
-        solo = (time.perf_counter() - t1) / 2
-        timings = sessions[0].last_timings()
+        t0 = time.perf_counter()
+        outs = run_steps(k, px)
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, outs
+
+    timed_px = host_px if args.host_pixels else dev_px
+    if args.warmup > 0:
+        run_steps(max(args.warmup, n_sess), timed_px)  # every session captures its decode graph before the timed region
+    dt, outs = timed(args.steps, timed_px)
+    if args.dump_ids and rank == 0:
+        np.save(args.dump_ids, outs[-1])
+    # ---- transparency legs, outside the timed region -----------------------------------------------------------------
+    # (a) the other residency of the inputs (PCIe-inclusive when `value` is resident, and vice versa)
+    k_side = max(n_sess, min(args.steps, 2 * n_sess))
+    other_px = dev_px if args.host_pixels else host_px
+    dt_other, _ = timed(k_side, other_px)
+    # (b) the same step strictly one batch at a time on this rank
+    fence()
+    t1 = time.perf_counter()
+    for _ in range(2):
+        sessions[0].generate_greedy(ids, *dev_px, max_new_tokens=N_new, eos_token_id=None)
+    torch.cuda.synchronize()
+    solo = (time.perf_counter() - t1) / 2
+    timings = sessions[0].last_timings()
     prof = eng.profile_decode_gemv(min(B, 16), reps=3)
 
     if rank == 0:
         traffic = args.pmc_traffic_bytes
-        pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if traffic is None and args.model == "7b" and B == 8 and args.weights == "bf16" and os.path.exists(pmc_file):
-            with open(pmc_file) as f:   # separate --pmc pass, gfx950 x2 correction applied (see the file)
-                traffic = json.load(f)["hbm_read_bytes_per_launch"]
+        if traffic is None and args.model == "7b" and B == 8 and args.weights == "bf16":
+            for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+                f_ = os.path.join(ROOT, "profiles", name)
+                if os.path.exists(f_):
+                    with open(f_) as f:   # separate --pmc pass, gfx950 x2 correction applied (see the file)
+                        traffic = json.load(f)["hbm_read_bytes_per_launch"]
+                    break
         S = 64 + 2 * cfg.num_patches
+        ms_step = dt / args.steps * 1e3
         ach = prof["avg_bytes"] / (prof["avg_us"] * 1e-6) / 1e9
+        # composite roofline of ONE batch of B alone: MFMA leg (encode + prefill) + HBM leg (decode)
+        flops, w_bytes, kv_bytes = work_per_sample(cfg, S, N_new, 1.0 if args.weights == "fp8" else 2.0)
+        mfma_ms = B * flops / (MFMA_PEAK_TFLOPS * 1e12) * 1e3
+        hbm_ms = ((N_new - 1) * w_bytes + B * kv_bytes) / (HBM_PEAK_GBS * 1e9) * 1e3
+        # with k batches in flight whose decode steps share one weight pass, the HBM leg of a batch shrinks to
+        # weights / k + its own KV: the bound of what `value` measures
+        hbm_ms_shared = ((N_new - 1) * w_bytes / n_sess + B * kv_bytes) / (HBM_PEAK_GBS * 1e9) * 1e3
         res = {
             "metric": "images/sec (3xViT encode + 128-tok decode), VCoder-DS-7b" if args.model == "7b"
                       else "images/sec (3xViT encode + 128-tok decode), VCoder-DS-13b",
             "value": world * B * args.steps / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"VCoder-DS LLaVA-1.5-{args.model} {'bf16' if args.weights == 'bf16' else 'bf16 activations / fp8-e4m3 decoder weights (W8A16)'}, batch={B}/GPU RGB+seg+depth 336x336, "
                                    f"prefill S={S}, {N_new}-token greedy decode", "global_batch": world * B,
                        "parallelism": f"dp{world}", "weights": "seeded synthetic (vcoder_amd/synth.py)",
                        "in_flight_batches_per_gpu": n_sess,
-                       "inputs": "host buffers (PCIe inclusive)" if args.host_pixels else "resident in HBM"},
+                       "value_is": (f"{n_sess} generate() calls of batch {B} in flight per GPU (each a complete, independent hot-path "
+                                    f"pass; see one_batch_at_a_time for a lone batch)") if n_sess > 1 else "one batch at a time",
+                       "inputs": "host buffers (PCIe inclusive)" if args.host_pixels else "resident in HBM",
+                       "token_gather": "vc_allgather_tokens (RCCL via the C ABI)" if comm is not None else
+                                       ("torch.distributed all_gather_into_tensor (%s)" % backend if world > 1 else "none (1 GPU)")},
             "phase_ms_one_session": timings,  # encode / prefill / decode wall time of one batch run alone
-            "one_batch_at_a_time": None if solo is None else {"value": B / solo, "unit": "images/s per GPU",
-                                                              "ms_per_step": solo * 1e3},
-            "roofline": {"bound": "hbm", "kernel": "gemv_dma_kernel (decode weight streaming, all 129 GEMV launches of a step)", "achieved": ach,
+            "one_batch_at_a_time": {"value": B / solo, "unit": "images/s per GPU", "ms_per_step": solo * 1e3},
+            ("resident_inputs" if args.host_pixels else "pcie_inclusive"): {
+                "value": world * B * k_side / dt_other, "unit": "images/s", "ms_per_step": dt_other / k_side * 1e3, "steps": k_side,
+                "note": "same loop, pixels %s" % ("resident in HBM" if args.host_pixels else
+                                                  "handed over as pageable host fp32 buffers (3 x %.1f MB per batch)" % (host_px[0].nbytes / 1e6))},
+            "composite_roofline": {"mfma_leg_ms": mfma_ms, "hbm_leg_ms": hbm_ms, "t_roof_ms": mfma_ms + hbm_ms,
+                                   "frac_one_batch": (mfma_ms + hbm_ms) / (solo * 1e3),
+                                   "hbm_leg_ms_weights_shared": hbm_ms_shared,
+                                   "frac_value": (mfma_ms + hbm_ms_shared) / ms_step,
+                                   "peaks": {"mfma_tflops": MFMA_PEAK_TFLOPS, "hbm_gbs": HBM_PEAK_GBS},
+                                   "measured_legs_ms": {"mfma": timings["encode_ms"] + timings["prefill_ms"], "hbm": timings["decode_ms"]}},
+            "roofline": {"bound": "hbm", "kernel": "gemv_dma_kernel (decode weight streaming, all GEMV launches of a step)", "achieved": ach,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": traffic, "avg_launch_us": prof["avg_us"],
                          "algorithmic_bytes_per_launch": prof["avg_bytes"],
                          "launches_per_decode_step": prof["launches_per_step"]},
         }
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(cfg, B, N_new)
+            res["cpu_baseline"] = cpu_baseline(cfg, N_new)
+        if args.cpu_c1 and world == 1:
+            res["cpu_c1"] = cpu_c1_full()
         print(json.dumps(res), flush=True)
+    if comm is not None:
+        comm.close()
     if world > 1:
         fence()
         dist.destroy_process_group()

@@ -83,6 +83,10 @@ int vc_model_finalize(vc_model* m);
  * "logits within 1e-3, greedy ids bit-exact" bar of BASELINE.json.  Takes effect at the next prefill. */
 int vc_model_set_precision(vc_model* m, int mode);
 
+/* parity diagnostic: prefills evaluate only the first n decoder layers (0 = all), final norm + lm_head applied to that
+ * hidden state — error growth with depth is measured on one loaded model (tests/test_gpu_fulldepth.py) */
+int vc_model_set_layer_limit(vc_model* m, int n_layers);
+
 /* decoder weight storage: 0 = bf16 (default); 1 = W8A16 — the seven linears of every decoder layer are quantised at
  * vc_model_finalize to OCP fp8 e4m3 with one power-of-two scale per output row and streamed as bytes by the decode
  * GEMV (half the HBM traffic of the decode step); the prefill GEMMs read the same dequantised values in bf16, so both
@@ -171,6 +175,18 @@ int vc_last_spliced_len(vc_model* m);
  * rgb: uint8 [h,w,3] on the host; out: fp32 [3,S,S] (device pointer when out_on_device, else host). */
 int vc_preprocess_image(vc_model* m, const uint8_t* rgb, int h, int w, int pad_to_square, const float* mean,
                         const float* stdv, float* out, int out_on_device);
+
+/* ---- multi-GPU: the one exchange of the data-parallel path ------------------------------------------
+ * Image batches shard over the GPUs of a node with no collective on the data path; the only exchange is an all-gather of
+ * the generated token ids (the reference: one answers file per GPU process + `cat`, scripts/v1_5/eval/cost_depth.sh:10-34).
+ * RCCL (ncclAllGather over xGMI) is called directly on the context's stream; librccl is bound with dlopen at first use.
+ * Rank 0 obtains the 128-byte RCCL unique id and distributes it through any side channel; world 1 needs no id and no RCCL. */
+typedef struct vc_comm vc_comm;
+int vc_comm_unique_id(vc_ctx* ctx, void* out128);
+int vc_comm_create(vc_ctx* ctx, int rank, int world, const void* unique_id128, vc_comm** out);
+/* global[r * n + i] = rank r's local[i]; host buffers (n int32 per rank) */
+int vc_allgather_tokens(vc_comm* comm, const int32_t* local, int n, int32_t* global);
+void vc_comm_destroy(vc_comm* comm);
 
 /* ---- measurement hooks (bench.py) ---------------------------------------------------------------- */
 /* times `reps` sweeps of every decode GEMV launch of one step (4 per layer + lm_head) with HIP events on the

@@ -679,7 +679,9 @@ def check_sampling(be, V, temperature, top_k, top_p, draws=2048, seed0=1234):
     rng = np.random.RandomState(5)
     lg1 = (rng.randn(V) * 1.5).astype(np.float32)
     probs = sample_reference_probs(lg1, temperature, top_k, top_p)
-    support = probs > 0
+    # the nucleus boundary is a floating-point comparison of a cumulative sum (fp32, block order on the device; fp64 here):
+    # a token sitting exactly on it may fall on either side, so "left the support" is judged against a hair wider nucleus
+    support = sample_reference_probs(lg1, temperature, top_k, min(1.0, top_p + 2e-3)) > 0 if top_p < 1.0 else probs > 0
     R = 16
     lg = np.tile(lg1, (R, 1))
     counts = np.zeros(V, dtype=np.int64)

@@ -139,3 +139,14 @@ def test_generate_rejects_bad_pad_and_depth_index(emu_lib):
     bad[0, -1] = synth.DEPTH_TOKEN_INDEX
     with _pt.raises(IndexError):
         eng.prefill(bad, imgs, segs, deps)
+
+
+def test_full_depth_parity_logic_on_the_tiny_model(emu_lib):
+    """The teacher-forced full-depth parity check of tests/test_gpu_fulldepth.py, run here on the tiny architecture through
+    the emulator so that its logic is validated before it meets the 7b / 13b models on the GPU box."""
+    import test_gpu_fulldepth as fd
+    from vcoder_amd import config as vcfg
+
+    r = fd.run_case(vcfg.tiny("vcoder_ds"), B=2, n_new=6, seed=42, emu_rows=1, checkpoints=(1, 2), strict_tokens=3,
+                    lib=emu_lib)
+    assert r["e_strict"] < 1e-4 and r["err32"].max() < e2e_cases.TOL_VS_FP32_REF

@@ -123,7 +123,8 @@ def test_true_dims_against_oracle():
     scale = np.abs(o_last).max()
     print(f"true-dims parity: S={S} |logits|max={scale:.3f} prefill err={e1:.4f} decode err={e2:.4f}")
     assert S == 1216
-    assert e1 < 2e-2 * max(1.0, scale) and e2 < 2e-2 * max(1.0, scale)
+    # relative to max|logits|; measured on MI355X 6.0e-3 (3.5e-2 absolute at |logits| <= 5.8): tolerance = 2x measured
+    assert e1 < 1.2e-2 * scale and e2 < 1.2e-2 * scale
     m = np.sort(o_last[0])[-1] - np.sort(o_last[0])[-2]
     if m > 4 * e1:
         assert int(np.argmax(last)) == int(np.argmax(o_last))
@@ -344,10 +345,147 @@ def test_fp8_weights_true_dims_against_oracle():
     e1, e2 = np.abs(last - o_last).max(), np.abs(lg2 - o_lg2).max()
     scale = np.abs(o_last).max()
     print(f"fp8 true-dims parity: |logits|max={scale:.3f} prefill err={e1:.4f} decode(fp8 gemv) err={e2:.4f}")
-    assert e1 < 2e-2 * max(1.0, scale) and e2 < 2e-2 * max(1.0, scale)
+    assert e1 < 1.2e-2 * scale and e2 < 1.2e-2 * scale   # 2x the measured relative deviation
     eng.close()
 
 
 @pytest.mark.parametrize("name", ["ds_img_depth_seg", "vc_img_seg"])
 def test_device_side_stop_sequences(name):
     e2e_cases.check_stop_sequences(name)
+
+
+@pytest.mark.parametrize("name", ["ds_list_two_each", "ds_list_uneven"])
+def test_list_and_5d_image_inputs(name):
+    """list / 5-D image form (vcoder_ds_llava_arch.py:135-169), several images per sample, vs the live reference's fixture"""
+    print(name, e2e_cases.check_list_fixture(name))
+
+
+def test_vision_tower_boundary():
+    """a2 at its own boundary: vc_vision_tower_forward vs CLIPVisionTower.forward of the live reference (tiny tower fixture)
+    and vs cpu_ref.vit_forward at the true ViT-L/14@336 dimensions (23 of 24 layers, 577 tokens)."""
+    import torch
+    import cpu_ref
+
+    print("tower fixture: strict", e2e_cases.check_tower_fixture(strict=True), "bf16", e2e_cases.check_tower_fixture())
+    cfg = vcfg.vicuna_7b("vcoder_ds")
+    cfg.num_hidden_layers = 1
+    eng = HipEngine(cfg)
+    eng.load_synthetic(3)
+    eng.finalize()
+    imgs = synth.synth_batch(2, 336, first=5)[0]
+    sd = cpu_ref.as_torch_state(synth.synth_state_dict(cfg, 3, only_prefix="model.vision_tower"))
+    with torch.no_grad():
+        ref32 = cpu_ref.vit_forward(torch.from_numpy(imgs), sd, cfg).numpy()
+        ref_emu = cpu_ref.vit_forward(torch.from_numpy(imgs), sd, cfg, emu_bf16=True).numpy()
+    got = eng.vision_tower_forward(imgs)
+    assert got.shape == (2, 576, 1024)
+    scale = float(np.abs(ref32).max())
+    e32, eemu = float(np.abs(got - ref32).max()), float(np.abs(got - ref_emu).max())
+    eng.set_precision("strict")
+    es = float(np.abs(eng.vision_tower_forward(imgs) - ref32).max())
+    print(f"ViT-L/14@336 tower, 23 layers: |feat|max={scale:.2f}  bf16 path vs fp32 oracle {e32:.4f} (rel {e32 / scale:.2e}), "
+          f"vs bf16-emulating oracle {eemu:.4f}, strict vs fp32 oracle {es:.2e}")
+    assert e32 < 3e-2 * scale and eemu < 2e-2 * scale and es < 1e-3 * max(1.0, scale)
+    eng.close()
+
+
+def test_sampling_on_device_true_vocab():
+    """Device sampling at the real vocabulary (32000 logits staged in LDS): support and distribution vs the HF warpers."""
+    import kernel_cases as kc
+
+    be = kc.HipBackend()
+    print("TV T=0.2 k=50:", kc.check_sampling(be, 32000, 0.2, 50, 1.0, draws=4096))
+    print("TV T=1.0 p=0.7:", kc.check_sampling(be, 32000, 1.0, 0, 0.7, draws=4096))
+    print("TV T=0.7 k=20 p=0.9:", kc.check_sampling(be, 32000, 0.7, 20, 0.9, draws=2048))
+    kc.check_select_embed(be, 8, 32000, 4096)
+
+
+def test_cost_harness_batched_equals_per_sample(tmp_path):
+    """SURVEY §8(f) row 3 on the GPU: the batched COST harness (eval_task over a synthetic image folder, device-side
+    preprocessing, question-bucketed batches) writes the same answers as one-sample-at-a-time generation, in the
+    reference's answers-file format (model_seg_loader.py:160-166, file names as keys)."""
+    from PIL import Image
+    from vcoder_amd.eval import cost_eval
+    from vcoder_amd.model import language_model as lm
+
+    cfg = vcfg.tiny("vcoder_ds")
+    model = lm.VCoderDSLlavaLlamaForCausalLM(cfg)
+    model.engine.load_synthetic(42)
+    model.finalize_weights()
+
+    class Tok:
+        bos_token_id, eos_token_id = 1, 2
+
+        def __call__(self, text):
+            class R:
+                pass
+            r = R()
+            r.input_ids = [1] + [3 + (b % (cfg.vocab_size - 3)) for b in text.encode()]
+            return r
+
+        def batch_decode(self, rows, skip_special_tokens=True):
+            return [" ".join(str(int(t)) for t in r if not (skip_special_tokens and int(t) in (0, 1, 2))) for r in rows]
+
+    rng = np.random.RandomState(0)
+    for sub in ("images", "segs/semantic_inference", "depths"):
+        (tmp_path / sub).mkdir(parents=True)
+    for i in range(7):
+        for sub in ("images", "segs/semantic_inference", "depths"):
+            Image.fromarray(rng.randint(0, 256, size=(70 + i, 90, 3)).astype(np.uint8)).save(tmp_path / sub / f"{i:03d}.jpg")
+    qs = ["What objects can be seen in the image?", "List the objects."]
+    kw = dict(questions=qs, max_new_tokens=5, seed=3)
+    out_b = cost_eval.eval_task(model, Tok(), "semantic", str(tmp_path / "images"), str(tmp_path / "segs"),
+                                str(tmp_path / "ans_batched"), depth_image_folder=str(tmp_path / "depths"), batch_size=4, **kw)
+    out_1 = cost_eval.eval_task(model, Tok(), "semantic", str(tmp_path / "images"), str(tmp_path / "segs"),
+                                str(tmp_path / "ans_single"), depth_image_folder=str(tmp_path / "depths"), batch_size=1, **kw)
+    a, b = open(out_b).read(), open(out_1).read()
+    assert a == b and a.count("<<ANSWER>>:") == 7
+    assert "Image: 000.jpg\n" in a and str(tmp_path) not in a          # bare file names, as the reference's scorers expect
+    model.engine.close()
+
+
+def test_bench_two_ranks_self_launched(tmp_path):
+    """`python bench.py --gpus 2` with WORLD_SIZE unset starts its own two ranks (torch.distributed.run on 127.0.0.1), shards
+    the global batch contiguously, and the gathered token stream equals the single-process one.  On this 1-GPU box both
+    ranks share device 0 and the id gather runs over gloo (VC_BENCH_FORCE_DEVICE / VC_BENCH_BACKEND: RCCL refuses two ranks
+    on one GPU); on a multi-GPU node the same command uses one GPU per rank and RCCL."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dump = str(tmp_path / "ids.npy")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(VC_BENCH_FORCE_DEVICE="0", VC_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0", "--batch",
+                        "2", "--new-tokens", "6", "--inflight", "2", "--dump-ids", dump], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 4 and res["config"]["parallelism"] == "dp2"
+    assert res["value"] > 0 and "roofline" in res and "composite_roofline" in res and "pcie_inclusive" in res
+    got = np.load(dump)
+    assert got.shape == (4, 6)
+    cfg = vcfg.vicuna_7b("vcoder_ds")
+    eng = HipEngine(cfg)
+    eng.load_synthetic(42)
+    eng.finalize()
+    ids = np.stack([synth.synth_prompt_ids(cfg.vocab_size, "vcoder_ds", sample=b) for b in range(4)])
+    imgs, segs, deps = synth.synth_batch(4, 336)
+    ref = eng.generate_greedy(ids, imgs, segs, deps, max_new_tokens=6)
+    eng.close()
+    assert np.array_equal(got, ref), "gathered ids of the 2-rank run differ from the single-process ids"
+
+
+def test_token_comm_c_abi_world1():
+    """vc_comm_create / vc_allgather_tokens at world 1 (identity, no RCCL needed); the multi-rank form needs one GPU per
+    rank and runs in the driver's multi-GPU bench (`bench.py --gather cabi`)."""
+    from vcoder_amd.parallel import TokenComm
+
+    eng = e2e_cases.engine_for("vcoder_ds")
+    c = TokenComm(eng, 0, 1)
+    x = np.arange(24, dtype=np.int32).reshape(3, 8)
+    assert np.array_equal(c.allgather(x), x)
+    c.close()

@@ -78,6 +78,16 @@ def declare(lib: C.CDLL) -> C.CDLL:
     lib.vc_set_image_counts.restype = C.c_int
     lib.vc_model_reserve_decode.argtypes = [vp, i32]
     lib.vc_model_reserve_decode.restype = C.c_int
+    lib.vc_comm_unique_id.argtypes = [vp, vp]
+    lib.vc_comm_unique_id.restype = C.c_int
+    lib.vc_comm_create.argtypes = [vp, i32, i32, vp, C.POINTER(vp)]
+    lib.vc_comm_create.restype = C.c_int
+    lib.vc_allgather_tokens.argtypes = [vp, vp, i32, vp]
+    lib.vc_allgather_tokens.restype = C.c_int
+    lib.vc_comm_destroy.argtypes = [vp]
+    lib.vc_comm_destroy.restype = None
+    lib.vc_model_set_layer_limit.argtypes = [vp, i32]
+    lib.vc_model_set_layer_limit.restype = C.c_int
     lib.vc_last_spliced_len.argtypes = [vp]
     lib.vc_last_spliced_len.restype = C.c_int
     lib.vc_profile_decode_gemv.argtypes = [vp, i32, i32, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]

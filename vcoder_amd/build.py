@@ -13,8 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libvcoder_hip.so")
-SOURCES = ["gemm.hip", "norm.hip", "attn.hip", "decode.hip", "misc.hip", "select.hip", "strict.hip", "preprocess.hip", "engine.hip", "kernel_api.cpp"]
-HEADERS = ["vc_device.h", "kernels.h", os.path.join("..", "..", "include", "vcoder_hip.h")]
+SOURCES = ["gemm.hip", "norm.hip", "attn.hip", "decode.hip", "misc.hip", "select.hip", "strict.hip", "preprocess.hip", "engine.hip", "comm.hip", "kernel_api.cpp"]
+HEADERS = ["vc_device.h", "kernels.h", "engine_ctx.h", os.path.join("..", "..", "include", "vcoder_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result"]
 
 

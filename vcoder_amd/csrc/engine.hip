@@ -32,11 +32,7 @@ static const int DEPTH_TOKEN_INDEX = -400;  // constants.py:11
 static const int VC_MAX_ROWS = 16;          // sequences one prefill / one session loop handles
 static const int VC_POOL_ROWS = 32;         // rows of the shared decode pool (two MFMA token-slot groups)
 
-struct vc_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    std::string err;
-};
+#include "engine_ctx.h"
 
 namespace {
 
@@ -141,6 +137,7 @@ struct vc_model {
     // (vc_set_image_counts; empty = one image per sample), and the running first-image index of every sample
     std::vector<int> img_counts[3], img_first[3];
     int reserve_new = 64;         // KV slots a vc_prefill keeps free behind the prompt (vc_model_reserve_decode)
+    int layer_limit = 0;          // > 0: a prefill evaluates only the first layer_limit decoder layers (vc_model_set_layer_limit)
     // LLM workspace
     Buf x, xn, qkv, q, attn, h, kc, vtc, row_src, last_idx, xl, logits_all;
     int capB = 0, capS = 0;  // KV capacity
@@ -661,7 +658,8 @@ void run_llm_layers_strict(vc_model* m, float* x, int B, int T, const int* pos_d
     const int D = c.hidden, F = c.ffn, H = c.heads, M = B * T;
     float *xn = m->s_xn.as<float>(), *qkv = m->s_qkv.as<float>(), *q = m->s_q.as<float>(), *at = m->s_attn.as<float>(),
           *h = m->s_h.as<float>();
-    for (int l = 0; l < c.layers; ++l) {
+    const int nl = (m->layer_limit > 0 && T > 1) ? std::min(m->layer_limit, c.layers) : c.layers;
+    for (int l = 0; l < nl; ++l) {
         const LlmLayer& L = m->llm[l];
         launch_rmsnorm_f32(x, nullptr, L.in_norm, xn, M, D, c.rms_eps, m->st);
         gemm32(m, xn, L.qkv_w, nullptr, qkv, M, 3 * D, D, D, D, 3 * D, EPI_F32);
@@ -914,7 +912,8 @@ void grow_kv(vc_model* m, int need) {
 void run_prefill_layers(vc_model* m, const KvTarget& kv, int B, int S) {
     const vc_model_cfg& c = m->c;
     const int D = c.hidden, F = c.ffn, H = c.heads, M = B * S;
-    for (int l = 0; l < c.layers; ++l) {
+    const int nl = m->layer_limit > 0 ? std::min(m->layer_limit, c.layers) : c.layers;
+    for (int l = 0; l < nl; ++l) {
         const LlmLayer& L = m->llm[l];
         launch_rmsnorm(m->x.as<float>(), L.in_norm, m->xn.as<bf16_t>(), M, D, c.rms_eps, m->st);
         gemm(m, m->xn.as<bf16_t>(), L.qkv_w, nullptr, m->qkv.p, M, 3 * D, D, 3 * D, EPI_BF16);
@@ -1418,6 +1417,16 @@ VC_API int vc_model_set_weight_format(vc_model* m, int fmt) {
     if (!m || (fmt != 0 && fmt != 1)) return VC_ERR_INVALID;
     if (m->finalized) return VC_ERR_STATE;
     m->weight_format = fmt;
+    return VC_OK;
+}
+
+/* Parity diagnostic: the next prefills evaluate only the first n decoder layers (0 = all) and apply the final norm +
+ * lm_head to that hidden state — the logits of the same checkpoint cut to n layers.  Lets a test chart how the bf16
+ * path's deviation from the fp32 oracle grows with depth on ONE loaded model.  Decode steps always use every layer. */
+VC_API int vc_model_set_layer_limit(vc_model* m, int n_layers) {
+    if (!m || n_layers < 0) return VC_ERR_INVALID;
+    m->layer_limit = n_layers;
+    m->cur_pos = -1;
     return VC_OK;
 }
 

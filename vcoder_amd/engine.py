@@ -145,6 +145,10 @@ class HipEngine:
         self._check(self.lib.vc_model_set_weight_format(self._model, {"bf16": 0, "fp8": 1, "w8a16": 1}[fmt]))
         self.weight_format = "fp8" if fmt != "bf16" else "bf16"
 
+    def set_layer_limit(self, n_layers: int):
+        """parity diagnostic: prefills evaluate only the first n decoder layers (0 = all)"""
+        self._check(self.lib.vc_model_set_layer_limit(self._model, int(n_layers)))
+
     def finalize(self):
         self._check(self.lib.vc_model_finalize(self._model))
         self.finalized = True

@@ -30,3 +30,40 @@ def gather_token_ids(local_ids: np.ndarray, dist=None, device=None) -> np.ndarra
     out = torch.empty((dist.get_world_size() * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     dist.all_gather_into_tensor(out, t)
     return out.cpu().numpy()
+
+
+class TokenComm:
+    """The C-ABI communicator (include/vcoder_hip.h: vc_comm_create / vc_allgather_tokens): RCCL over xGMI called directly
+    by libvcoder_hip.so on the engine's stream.  The 128-byte RCCL unique id travels from rank 0 to the others through
+    `exchange` (a callable bytes -> bytes that broadcasts rank 0's value; bench.py uses torch.distributed's store for it).
+    world 1 needs neither RCCL nor an exchange."""
+
+    def __init__(self, engine, rank: int = 0, world: int = 1, exchange=None):
+        import ctypes as C
+
+        self.lib, self.engine, self.rank, self.world = engine.lib, engine, rank, world
+        self._comm = C.c_void_p()
+        uid = None
+        if world > 1:
+            buf = C.create_string_buffer(128)
+            if rank == 0:
+                engine._check(self.lib.vc_comm_unique_id(engine._ctx, buf))
+            if exchange is None:
+                raise ValueError("world > 1 needs an `exchange` to distribute the RCCL unique id")
+            uid = C.create_string_buffer(exchange(buf.raw if rank == 0 else b""), 128)
+        engine._check(self.lib.vc_comm_create(engine._ctx, rank, world, uid, C.byref(self._comm)))
+
+    def allgather(self, local_ids: np.ndarray) -> np.ndarray:
+        """int32 [B_local, N] -> [world * B_local, N]"""
+        import ctypes as C
+
+        loc = np.ascontiguousarray(local_ids, dtype=np.int32)
+        out = np.empty((self.world * loc.shape[0],) + loc.shape[1:], dtype=np.int32)
+        self.engine._check(self.lib.vc_allgather_tokens(self._comm, loc.ctypes.data_as(C.c_void_p), int(loc.size),
+                                                        out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def close(self):
+        if self._comm:
+            self.lib.vc_comm_destroy(self._comm)
+            self._comm = None
