@@ -34,7 +34,7 @@ vc_emu_switch:
 
 namespace vc_emu {
 thread_local Fiber* g_cur = nullptr;
-Graph* g_capturing = nullptr;
+thread_local Graph* g_capturing = nullptr;
 
 static const size_t STACK_BYTES = 256 * 1024;
 

@@ -105,9 +105,18 @@ inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) {
     return 0;
 }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return 0; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+inline hipError_t hipEventQuery(hipEvent_t) { return 0; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
+inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = aligned_alloc(256, (n + 255) / 256 * 256 + 256); return *p ? 0 : 1; }
+inline hipError_t hipHostFree(void* p) { free(p); return 0; }
+inline hipError_t hipMemset2DAsync(void* d, size_t pitch, int v, size_t w, size_t h, hipStream_t) {
+    for (size_t r = 0; r < h; ++r) memset((char*)d + r * pitch, v, w);
+    return 0;
+}
 namespace vc_emu {
 struct Graph { std::vector<std::function<void()>> ops; };
-extern Graph* g_capturing;
+extern thread_local Graph* g_capturing;  // per host thread, like hipStreamCaptureModeThreadLocal
 }
 typedef vc_emu::Graph* hipGraph_t;
 typedef vc_emu::Graph* hipGraphExec_t;

@@ -515,9 +515,10 @@ def check_gemv_norm_chain(be, M, D, N, seed=0):
     g2 = (rng.rand(D) + 0.5).astype(np.float32)
     W1 = bf16_round(rng.randn(N, D) * 0.05)
     Wo = bf16_round(rng.randn(D, N) * 0.05)
-    x = be.zeros((16, D), "f32")
-    xg = be.bf16(rng.randn(16, D))              # garbage: the kernels must fully overwrite the valid rows
-    ssq = be.f32(rng.randn(16, npart))
+    Mp = (M + 15) // 16 * 16
+    x = be.zeros((Mp, D), "f32")
+    xg = be.bf16(rng.randn(Mp, D))              # garbage: the kernels must fully overwrite the valid rows
+    ssq = be.f32(rng.randn(Mp, npart))
     tokd, embd, g1d, g2d = be.i32(tok), be.bf16(embed), be.f32(g1), be.f32(g2)
     be.lib.vck_embed_tokens_ssq(be.ptr(tokd), be.ptr(embd), be.ptr(x), be.ptr(ssq), be.ptr(g1d), be.ptr(xg), M, D, npart, None)
     be.sync()
@@ -670,6 +671,56 @@ def sample_reference_probs(lg, temperature, top_k, top_p):
         z[order[remove]] = -np.inf
     p = np.exp(z - z.max())
     return p / p.sum()
+
+
+def check_gemv_rows_agree_across_variants(be, N, K, epi, norm=True, ksplit=0, seed=0):
+    """The decode pool's promise: a row gets bit-for-bit the same result from a 32-row pass (two MFMA row groups) as from a
+    16-row pass — rows 0..15 and 16..31 of an M = 29 launch against two launches of 16 and 13 rows."""
+    rng = np.random.RandomState(seed)
+    M = 29
+    npart = (K // 16 + 15) // 16 * 16
+    X = bf16_round(rng.randn(32, K))
+    W = bf16_round(rng.randn(N, K) * 0.05)
+    Wd, Wp = be.bf16(W), be.zeros((N * K,), "bf16")
+    _call(be, "vck_pack_weight", Wd, Wp, N, K)
+    ssq = np.zeros((32, npart), np.float32)
+    ssq[:, : K // 16] = rng.rand(32, K // 16).astype(np.float32) + 0.5
+    ssqd = be.f32(ssq) if norm else None
+    esz = {0: "bf16", 1: "f32", 2: "f32", 3: "bf16"}[epi]
+    No = N // 2 if epi == 3 else N
+    r0 = rng.randn(32, No).astype(np.float32)
+    mk = lambda: (be.f32(r0.copy()) if epi == 2 else be.zeros((32, No), esz))
+    sk = None
+    if ksplit:
+        sk = (be.zeros((ksplit * (N // 16) * 2 * 256,), "f32"), be.zeros((N // 16 * 2,), "i32"))
+    Xd = be.bf16(X)
+    big = mk()
+    _gemv_ex(be, Xd, Wp, None, big, ssqd, None, None, None, npart, M, N, K, No, epi, sk=sk, ksplit=ksplit)
+    be.sync()
+    lo, hi = mk(), mk()
+    _gemv_ex(be, Xd, Wp, None, lo, ssqd, None, None, None, npart, 16, N, K, No, epi, sk=sk, ksplit=ksplit)
+    be.sync()
+    Xh = be.bf16(X[16:])
+    ssqh = be.f32(ssq[16:]) if norm else None
+    _gemv_ex(be, Xh, Wp, None, hi, ssqh, None, None, None, npart, M - 16, N, K, No, epi, sk=sk, ksplit=ksplit)
+    be.sync()
+    b, l = be.host_f32(big), be.host_f32(lo)
+    # bit equality holds for the default (LDS-DMA) kernels, whose K partition is the same for both row counts; the
+    # register-staged regression variant (VC_GEMV_PATH=0) serves only the 16-row pass and sums in another order
+    same = np.array_equal if os.environ.get("VC_GEMV_PATH", "1") != "0" else (lambda u, v: rel_err(u, v) < 2 ** -7)
+    assert same(b[:16], l[:16]), "rows 0..15 differ between the 32-row and the 16-row pass"
+    if epi != 2:   # (the in-place residual form adds into whatever rows the buffer holds: only rows 0..15 line up)
+        assert same(b[16:M], be.host_f32(hi)[: M - 16]), "rows 16..28 differ between the 32-row and the 16-row pass"
+    ref = X[:M].astype(np.float64) @ W.T.astype(np.float64)
+    if norm:
+        ref = ref / np.sqrt(ssq[:M, : K // 16].sum(-1, keepdims=True) / K + 1e-5)
+    if epi == 3:
+        t = torch.from_numpy(ref).float()
+        ref = (torch.nn.functional.silu(t[:, 0::2]) * t[:, 1::2]).numpy()
+    if epi == 2:
+        ref = ref + r0[:M]
+    e = rel_err(b[:M], ref)
+    assert e < (2 ** -8 if epi in (0, 3) else 2e-5), f"gemv M=29 N{N} K{K} epi{epi}: rel err {e}"
 
 
 def check_sampling(be, V, temperature, top_k, top_p, draws=2048, seed0=1234):

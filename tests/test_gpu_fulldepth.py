@@ -170,9 +170,13 @@ def run_case(cfg, B, n_new, seed, emu_rows, checkpoints, strict_tokens, lib=None
     return dict(scale=scale, err32=err32, erre=erre, near=near, e_strict=e_strict)
 
 
-# Tolerances = 2x the deviations measured on MI355X, relative to max|logits| of the case.
-REL_TOL_VS_FP32 = 2.0e-2
-REL_TOL_VS_EMU = 1.2e-2
+# Tolerances = 2x the deviations measured on MI355X, relative to max|logits| of the case.  Measured at full
+# depth (7b, 32 layers, |logits|max 6.77): 2.0e-2 against the fp32 oracle (0.122 prefill / 0.136 decode absolute), growing
+# like sqrt(depth): 5.6e-3 @ 2 layers, 1.1e-2 @ 8, 1.35e-2 @ 16, 2.3e-2 @ 32.  The bf16-emulating oracle is NOT closer at
+# this depth (2.4e-2): after 32 layers two bf16 evaluations with different summation orders have decorrelated, so that
+# comparison only bounds the noise, it does not tighten it.
+REL_TOL_VS_FP32 = 4.0e-2
+REL_TOL_VS_EMU = 5.0e-2
 
 
 def test_full_depth_7b_c2():

@@ -42,6 +42,18 @@ def test_gemv_splitk(be, M, N, K, ks):
     kc.check_gemv_splitk(be, M, N, K, ks)
 
 
+@pytest.mark.parametrize("N,K,epi,norm,ks", [(32, 256, 0, True, 0), (48, 320, 1, True, 0), (64, 256, 3, True, 0),
+                                              (32, 512, 2, False, 0), (48, 320, 1, False, 3), (32, 1024, 0, True, 2)])
+def test_gemv_32_rows(be, N, K, epi, norm, ks):
+    """M in 17..32 (the decode pool): two row groups per weight pass, bit-identical per row to the 16-row pass."""
+    kc.check_gemv_rows_agree_across_variants(be, N, K, epi, norm, ks)
+
+
+def test_gemv_chain_24_rows(be):
+    kc.check_gemv_norm_chain(be, 24, 256, 64, seed=7)
+    kc.check_gemv_norm_chain(be, 32, 512, 96, seed=8)
+
+
 def test_interleave(be):
     kc.check_interleave(be, 24, 64)
 

@@ -1,0 +1,125 @@
+"""CPU tests of the decode pool (csrc/engine.hip: concurrent generate() calls share their decode steps) through the
+emulator: requests of different batch sizes, prompt lengths, EOS / stop / sampling parameters in flight together get
+exactly the ids their own session loop produces."""
+import threading
+
+import numpy as np
+import pytest
+
+import e2e_cases
+import kernel_cases as kc
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    return kc.EmuBackend().lib
+
+
+def session_loop_ids(eng, ids, imgs, segs, deps, n_new):
+    """greedy ids from the session's own loop (vc_prefill + vc_decode_step): never pooled"""
+    last, _, _ = eng.prefill(ids, imgs, segs, deps, reserve=n_new)
+    toks = [np.argmax(last, -1).astype(np.int32)]
+    for _ in range(n_new - 1):
+        _, nxt = eng.decode_step(toks[-1], want_logits=False)
+        toks.append(nxt)
+    return np.stack(toks, 1)
+
+
+def test_concurrent_requests_share_steps_and_keep_their_ids(emu_lib):
+    names = ["ds_img_depth_seg", "ds_img_only", "ds_img_seg"]            # B = 2 / 1 / 1, three spliced lengths
+    root = e2e_cases.engine_for("vcoder_ds", emu_lib)
+    cases, refs = [], []
+    for n in names:
+        g, cfg, ids, imgs, segs, deps = e2e_cases.fixture_inputs(n)
+        cases.append((ids, imgs, segs, deps))
+        refs.append(session_loop_ids(root, ids, imgs, segs, deps, 7))
+    sessions = [root, root.fork(), root.fork()]
+    outs = [[None] * 3 for _ in sessions]
+    errs = []
+
+    def work(si):
+        try:
+            for j in range(3):
+                ci = (si + j) % 3                                          # every session meets every case
+                outs[si][j] = (ci, sessions[si].generate_greedy(*cases[ci], max_new_tokens=7))
+        except BaseException as e:
+            errs.append(e)
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    for si in range(3):
+        for ci, got in outs[si]:
+            assert np.array_equal(got, refs[ci]), f"session {si} case {names[ci]}: pooled ids differ from the session loop"
+    for s in sessions[1:]:
+        s.close()
+
+
+def test_pool_mixes_eos_stops_and_sampling(emu_lib):
+    """Rows of one step with different generation parameters: an EOS request that ends early, a keyword-stop request, a
+    sampled request and a plain greedy one, all in flight together; each equals its lone run."""
+    root = e2e_cases.engine_for("vcoder_ds", emu_lib)
+    g, cfg, ids, imgs, segs, deps = e2e_cases.fixture_inputs("ds_img_depth_seg")
+    base = root.generate_greedy(ids, imgs, segs, deps, max_new_tokens=10)
+    eos = int(base[0, 2])
+    kws = [
+        dict(max_new_tokens=10),
+        dict(max_new_tokens=10, eos_token_id=eos, pad_token_id=0),
+        dict(max_new_tokens=10, stop_sequences=[[int(base[1, 3])]], pad_token_id=0),
+        dict(max_new_tokens=10, do_sample=True, temperature=0.9, top_k=20, top_p=0.95, seed=11),
+    ]
+    lone = [root.generate(ids, imgs, segs, deps, **kw) for kw in kws]
+    assert lone[1].shape[1] <= 10 and (lone[1][0, 3:] == 0).all()           # row 0 pads after its EOS
+    sessions = [root] + [root.fork() for _ in range(3)]
+    outs, errs = [None] * 4, []
+
+    def work(i):
+        try:
+            for _ in range(2):
+                outs[i] = sessions[i].generate(ids, imgs, segs, deps, **kws[i])
+        except BaseException as e:
+            errs.append(e)
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    for i in range(4):
+        assert np.array_equal(outs[i], lone[i]), f"request {i} ({kws[i]}) changed when pooled with the others"
+    for s in sessions[1:]:
+        s.close()
+
+
+def test_pool_queues_requests_beyond_its_rows(emu_lib):
+    """5 concurrent requests of 8 rows want 40 rows of a 32-row pool: the fifth waits for rows and still gets its ids."""
+    root = e2e_cases.engine_for("vcoder_ds", emu_lib)
+    g, cfg, ids, imgs, segs, deps = e2e_cases.fixture_inputs("ds_img_only")
+    from vcoder_amd import synth
+
+    ids8 = np.concatenate([ids] * 8, axis=0)
+    pix, _, _ = synth.synth_batch(8, cfg.vit_image_size)
+    ref = session_loop_ids(root, ids8, pix, None, None, 4)
+    sessions = [root] + [root.fork() for _ in range(4)]
+    outs, errs = [None] * 5, []
+
+    def work(i):
+        try:
+            outs[i] = sessions[i].generate_greedy(ids8, pix, None, None, max_new_tokens=4)
+        except BaseException as e:
+            errs.append(e)
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(5)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    for o in outs:
+        assert np.array_equal(o, ref)
+    for s in sessions[1:]:
+        s.close()

@@ -19,14 +19,15 @@ namespace vc {
 
 
 // shared epilogue: `v` = out[m][n..n+3] partial sums already reduced over the waves of the workgroup
-template <int WAVES, int EPI, bool FP8>
-VC_DEV void gemv_epilogue(const GemvArgs& p, f32x4 v, const float* ss_part /*[WAVES][16]*/, int nt, int m, int g, bool mvalid) {
+// `m` = token row (0 .. 16*MG-1), `SSW` = row slots per wave in ss_part (16 * MG)
+template <int WAVES, int EPI, bool FP8, int SSW = 16>
+VC_DEV void gemv_epilogue(const GemvArgs& p, f32x4 v, const float* ss_part /*[WAVES][SSW]*/, int nt, int m, int g, bool mvalid) {
     const int n = nt * 16 + g * 4;  // lane holds out[m][n..n+3]
     if constexpr (FP8) v = v * ld16f(p.wscale + n);
     if (p.ssq_in != nullptr) {
         float ss = ss_part[m];
 #pragma unroll
-        for (int w = 1; w < WAVES; ++w) ss += ss_part[w * 16 + m];
+        for (int w = 1; w < WAVES; ++w) ss += ss_part[w * SSW + m];
         v = v * rsqrtf(ss / (float)p.K + p.eps);
     }
     if constexpr (EPI == GEMV_RESID_F32) {
@@ -187,21 +188,27 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
 // ever reads LDS bytes that it DMA'd itself, so its own vmcnt wait is the only ordering needed (no barrier in the loop).
 // ~40 VGPRs per wave: occupancy is set by the ring size alone.  A pure stream of this shape measures 5.8-6.1 TB/s at the
 // qkv / gate-up launch sizes (tools/experiments/corun.hip) against 5.0-5.3 for the register-staged loop above.
-template <int WAVES, int NT, int R, int EPI, bool FP8>
+// MG = token-slot groups of 16 rows per weight pass (1: M <= 16; 2: M <= 32 — the decode pool's rows): every weight block
+// read from LDS feeds MG MFMAs against MG activation fragments.  The assignment of k-tiles to waves and K-slices does
+// not depend on MG (nor on NT / R), so a row's sum is formed in the same order whichever variant serves it: the pool's
+// 32-row steps give every row bit-for-bit what a 16-row step gives it.
+template <int WAVES, int NT, int R, int EPI, bool FP8, int MG = 1>
 __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
     constexpr int KT = FP8 ? 64 : 32;
     constexpr int KSH = FP8 ? 6 : 5;
     constexpr int GK = KT / 4;
-    constexpr int XS = FP8 ? 2 : 1;          // 1-KiB activation pieces per k-tile
+    constexpr int XS = (FP8 ? 2 : 1) * MG;   // 1-KiB activation pieces per k-tile
+    constexpr int XG = FP8 ? 2 : 1;          // ... per row group
     // k-tiles per ring slot: bf16 takes them in PAIRS so that the two activation gathers of a slot touch the two 64-byte
     // halves of the same 128-byte lines back to back (the second is an L1 hit: half the L2 requests of the X operand);
     // a W8A16 k-tile already spans whole lines
     constexpr int KPI = FP8 ? 1 : 2;
     constexpr int OPS = KPI * (NT + XS);     // DMA instructions per slot
     constexpr int SLOT = OPS * 1024;
-    static_assert(WAVES * R * SLOT >= WAVES * NT * 1024, "the ring is re-used for the cross-wave reduction");
+    static_assert(WAVES * R * SLOT >= WAVES * NT * MG * 1024, "the ring is re-used for the cross-wave reduction");
+    static_assert(WAVES >= NT * MG, "one finishing wave per (tile, row group)");
     VC_DYNAMIC_SMEM(char, ring);             // [WAVES][R][SLOT]
-    __shared__ float ss_part[WAVES][16];
+    __shared__ float ss_part[WAVES][16 * MG];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntiles = p.N >> 4;
     const int KS = p.ksplit > 1 ? p.ksplit : 1;
@@ -211,13 +218,18 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
     const int nit = (nkt + KPI - 1) / KPI;   // slots' worth of k-tiles in the matrix
     const int it0 = (int)((long)ks * nit / KS), it1 = (int)((long)(ks + 1) * nit / KS);  // this workgroup's share of K
     const int m = lane & 15, g = lane >> 4;
-    const bool mvalid = m < p.M;
+    bool mvalid[MG];
+#pragma unroll
+    for (int q = 0; q < MG; ++q) mvalid[q] = m + 16 * q < p.M;
     char* my = ring + wave * (R * SLOT);
     const char* wsrc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
         wsrc[t] = reinterpret_cast<const char*>(p.Wp) + ((size_t)min(nt0 + t, ntiles - 1) * nkt * 64 + lane) * 16;
-    const char* xsrc = reinterpret_cast<const char*>(p.X + (size_t)(mvalid ? m : 0) * p.K + g * GK);
+    const char* xsrc[MG];
+#pragma unroll
+    for (int q = 0; q < MG; ++q)
+        xsrc[q] = reinterpret_cast<const char*>(p.X + (size_t)(mvalid[q] ? m + 16 * q : 0) * p.K + g * GK);
     auto issue = [&](int i, int slot) {
         char* dst = my + slot * SLOT;
 #pragma unroll
@@ -228,13 +240,18 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
                 if (p.w_cached) glds16(wsrc[t] + kt * 1024, dst + (kk * (NT + XS) + t) * 1024);
                 else glds16_nt(wsrc[t] + kt * 1024, dst + (kk * (NT + XS) + t) * 1024);
             }
-            glds16(xsrc + kt * (KT * 2), dst + (kk * (NT + XS) + NT) * 1024);
-            if constexpr (FP8) glds16(xsrc + kt * (KT * 2) + 16, dst + (kk * (NT + XS) + NT + 1) * 1024);
+#pragma unroll
+            for (int q = 0; q < MG; ++q) {
+                glds16(xsrc[q] + kt * (KT * 2), dst + (kk * (NT + XS) + NT + q * XG) * 1024);
+                if constexpr (FP8) glds16(xsrc[q] + kt * (KT * 2) + 16, dst + (kk * (NT + XS) + NT + q * XG + 1) * 1024);
+            }
         }
     };
-    f32x4 acc[NT];
+    f32x4 acc[NT][MG];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < MG; ++q) acc[t][q] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto consume = [&](int i, int slot) {
         const char* s = my + slot * SLOT + lane * 16;
 #pragma unroll
@@ -243,18 +260,28 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
             u32x4 w[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) w[t] = ld16(sk + t * 1024);
-            u32x4 x0 = ld16(sk + NT * 1024), x1 = {0u, 0u, 0u, 0u};
-            if constexpr (FP8) x1 = ld16(sk + (NT + 1) * 1024);
-            if (!mvalid || (KPI > 1 && (it0 + wave + i * WAVES) * KPI + kk >= nkt)) x0 = x1 = u32x4{0u, 0u, 0u, 0u};
+            const bool tail = KPI > 1 && (it0 + wave + i * WAVES) * KPI + kk >= nkt;
+            u32x4 x0[MG], x1[MG];
+#pragma unroll
+            for (int q = 0; q < MG; ++q) {
+                x0[q] = ld16(sk + (NT + q * XG) * 1024);
+                x1[q] = u32x4{0u, 0u, 0u, 0u};
+                if constexpr (FP8) x1[q] = ld16(sk + (NT + q * XG + 1) * 1024);
+                if (!mvalid[q] || tail) x0[q] = x1[q] = u32x4{0u, 0u, 0u, 0u};
+            }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 if constexpr (FP8) {
                     const u32x2 b0 = fp8x4_to_bf16x4(w[t][0]), b1 = fp8x4_to_bf16x4(w[t][1]);
                     const u32x2 b2 = fp8x4_to_bf16x4(w[t][2]), b3 = fp8x4_to_bf16x4(w[t][3]);
-                    acc[t] = mfma16(u32x4{b0[0], b0[1], b1[0], b1[1]}, x0, acc[t]);
-                    acc[t] = mfma16(u32x4{b2[0], b2[1], b3[0], b3[1]}, x1, acc[t]);
+#pragma unroll
+                    for (int q = 0; q < MG; ++q) {
+                        acc[t][q] = mfma16(u32x4{b0[0], b0[1], b1[0], b1[1]}, x0[q], acc[t][q]);
+                        acc[t][q] = mfma16(u32x4{b2[0], b2[1], b3[0], b3[1]}, x1[q], acc[t][q]);
+                    }
                 } else {
-                    acc[t] = mfma16(w[t], x0, acc[t]);
+#pragma unroll
+                    for (int q = 0; q < MG; ++q) acc[t][q] = mfma16(w[t], x0[q], acc[t][q]);
                 }
             }
         }
@@ -262,37 +289,43 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
     };
     const int cnt = max(0, (it1 - it0 - wave + WAVES - 1) / WAVES);  // slots of this wave (wave-uniform)
     const int primed = min(cnt, R);
-    // 1/rms of row m from the producer's partials: the register loads are issued BEFORE the ring is primed, so the wait
+    // 1/rms of the rows from the producer's partials: the register loads are issued BEFORE the ring is primed, so the wait
     // the compiler places at their first use leaves every DMA in flight (vmcnt counts in order)
     constexpr int SQ = 6;
-    f32x4 sq[SQ];
+    f32x4 sq[MG][SQ];
     const int nq = p.npart >> 2;
     if (p.ssq_in != nullptr) {
-        const float* sp = p.ssq_in + (size_t)m * p.npart;
 #pragma unroll
-        for (int j = 0; j < SQ; ++j) {
-            const int q = wave * 4 + g + j * WAVES * 4;
-            sq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (q < nq) sq[j] = ld16f(sp + q * 4);
+        for (int q = 0; q < MG; ++q) {
+            const float* sp = p.ssq_in + (size_t)(mvalid[q] ? m + 16 * q : 0) * p.npart;
+#pragma unroll
+            for (int j = 0; j < SQ; ++j) {
+                const int qi = wave * 4 + g + j * WAVES * 4;
+                sq[q][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (qi < nq) sq[q][j] = ld16f(sp + qi * 4);
+            }
         }
     }
     for (int r = 0; r < primed; ++r) issue(r, r);
     if (p.ssq_in != nullptr) {
-        float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-        for (int j = 0; j < SQ; j += 2) {
-            s0 += (sq[j][0] + sq[j][1]) + (sq[j][2] + sq[j][3]);
-            s1 += (sq[j + 1][0] + sq[j + 1][1]) + (sq[j + 1][2] + sq[j + 1][3]);
+        for (int q = 0; q < MG; ++q) {
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < SQ; j += 2) {
+                s0 += (sq[q][j][0] + sq[q][j][1]) + (sq[q][j][2] + sq[q][j][3]);
+                s1 += (sq[q][j + 1][0] + sq[q][j + 1][1]) + (sq[q][j + 1][2] + sq[q][j + 1][3]);
+            }
+            float ss = s0 + s1;
+            const float* sp = p.ssq_in + (size_t)(mvalid[q] ? m + 16 * q : 0) * p.npart;
+            for (int qi = wave * 4 + g + SQ * WAVES * 4; qi < nq; qi += WAVES * 4) {  // rows wider than 16*SQ*WAVES*... (rare)
+                const f32x4 v = ld16f(sp + qi * 4);
+                ss += (v[0] + v[1]) + (v[2] + v[3]);
+            }
+            ss += shfl_xor(ss, 16);
+            ss += shfl_xor(ss, 32);
+            if (g == 0) ss_part[wave][16 * q + m] = ss;
         }
-        float ss = s0 + s1;
-        const float* sp = p.ssq_in + (size_t)m * p.npart;
-        for (int q = wave * 4 + g + SQ * WAVES * 4; q < nq; q += WAVES * 4) {  // rows wider than 16*SQ*WAVES*... (rare)
-            const f32x4 v = ld16f(sp + q * 4);
-            ss += (v[0] + v[1]) + (v[2] + v[3]);
-        }
-        ss += shfl_xor(ss, 16);
-        ss += shfl_xor(ss, 32);
-        if (g == 0) ss_part[wave][m] = ss;
     }
     if (cnt >= R) {
         int slot = 0;
@@ -313,35 +346,43 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
         for (int r = 0; r < cnt; ++r) consume(r, r);
     }
     __syncthreads();  // every wave is done with its ring before `red` overwrites it
-    float* red = reinterpret_cast<float*>(ring);  // [WAVES][NT][64][4]
+    float* red = reinterpret_cast<float*>(ring);  // [WAVES][NT][MG][64][4]
 #pragma unroll
-    for (int t = 0; t < NT; ++t) st16f(red + ((wave * NT + t) * 64 + lane) * 4, acc[t]);
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < MG; ++q) st16f(red + (((wave * NT + t) * MG + q) * 64 + lane) * 4, acc[t][q]);
     __syncthreads();
-    if (wave >= NT) return;
-    const int nt = nt0 + wave;  // wave t finishes tile t
+    if (wave >= NT * MG) return;
+    const int ft = wave % NT, fq = wave / NT;  // this wave finishes tile ft for row group fq
+    const int nt = nt0 + ft;
     if (nt >= ntiles) return;
-    f32x4 v = ld16f(red + ((0 * NT + wave) * 64 + lane) * 4);
+    f32x4 v = ld16f(red + (((0 * NT + ft) * MG + fq) * 64 + lane) * 4);
 #pragma unroll
-    for (int w = 1; w < WAVES; ++w) v = v + ld16f(red + ((w * NT + wave) * 64 + lane) * 4);
+    for (int w = 1; w < WAVES; ++w) v = v + ld16f(red + (((w * NT + ft) * MG + fq) * 64 + lane) * 4);
     if (KS > 1) {
-        // hand the partial to whoever finishes this tile last; it adds the KS partials in k order
-        float* mine = p.sk_scratch + (((size_t)ks * ntiles + nt) * 64 + lane) * 4;
+        // hand the partial to whoever finishes this (tile, row group) last; it adds the KS partials in k order.  Write-through
+        // (sc1) stores, drained, then a relaxed agent-scope arrival count; the finisher reads with cache-bypassing (sc1)
+        // loads: the "sc1 stores and loads on both sides" form of the CDNA hand-off rules (cdna_hip_programming.md §6 G16 /
+        // MI355X_MICROARCH.md "valid forms") — an agent-scope fence here writes back / invalidates the XCD's whole L2 and
+        // measured 4-8x slower launches
+        const size_t unit = (size_t)nt * MG + fq;
+        float* mine = p.sk_scratch + (((size_t)ks * ntiles * MG + unit) * 64 + lane) * 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) st_agent(mine + e, v[e]);
         wait_vmcnt<0>();  // the write-through stores have been acknowledged before the arrival is counted
         unsigned arrived = 0;
-        if (lane == 0) arrived = atomic_inc_agent(&p.sk_counters[nt]);
+        if (lane == 0) arrived = atomic_inc_agent(&p.sk_counters[unit]);
         arrived = shfl(arrived, 0);
         if (arrived != (unsigned)(KS - 1)) return;
         v = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int k = 0; k < KS; ++k) {
-            const float* q = p.sk_scratch + (((size_t)k * ntiles + nt) * 64 + lane) * 4;
+            const float* q = p.sk_scratch + (((size_t)k * ntiles * MG + unit) * 64 + lane) * 4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += ld_agent(q + e);
         }
-        if (lane == 0) st_agent_u32(&p.sk_counters[nt], 0u);  // re-armed for the next launch (stream order)
+        if (lane == 0) st_agent_u32(&p.sk_counters[unit], 0u);  // re-armed for the next launch (stream order)
     }
-    gemv_epilogue<WAVES, EPI, FP8>(p, v, &ss_part[0][0], nt, m, g, mvalid);
+    gemv_epilogue<WAVES, EPI, FP8, 16 * MG>(p, v, &ss_part[0][0], nt, m + 16 * fq, g, mvalid[fq]);
 }
 
 template <class K>
@@ -363,18 +404,19 @@ static void launch_gemv_w(const GemvArgs& a, int epi, hipStream_t s) {
     }
 }
 
-template <int WAVES, int NT, int R, bool FP8>
+template <int WAVES, int NT, int R, bool FP8, int MG = 1>
 static void launch_gemv_dma(const GemvArgs& a, int epi, hipStream_t s) {
     const dim3 grid(((a.N / 16 + NT - 1) / NT) * (a.ksplit > 1 ? a.ksplit : 1)), block(WAVES * 64);
-    constexpr size_t shmem = (size_t)WAVES * R * (FP8 ? 1 : 2) * (NT + (FP8 ? 2 : 1)) * 1024;
+    constexpr size_t shmem = (size_t)WAVES * R * (FP8 ? 1 : 2) * (NT + (FP8 ? 2 : 1) * MG) * 1024;
+    static_assert(shmem <= 160 * 1024, "ring exceeds the LDS of a CU");
 #define VC_GEMV_DMA(E)                                                                                                  \
     do {                                                                                                                \
         static bool once = false;                                                                                       \
         if (!once) {                                                                                                    \
-            allow_big_lds(gemv_dma_kernel<WAVES, NT, R, E, FP8>, shmem);                                                \
+            allow_big_lds(gemv_dma_kernel<WAVES, NT, R, E, FP8, MG>, shmem);                                            \
             once = true;                                                                                                \
         }                                                                                                               \
-        VC_LAUNCH((gemv_dma_kernel<WAVES, NT, R, E, FP8>), grid, block, shmem, s, a);                                   \
+        VC_LAUNCH((gemv_dma_kernel<WAVES, NT, R, E, FP8, MG>), grid, block, shmem, s, a);                               \
     } while (0)
     switch (epi) {
         case GEMV_BF16: VC_GEMV_DMA(GEMV_BF16); break;
@@ -385,6 +427,31 @@ static void launch_gemv_dma(const GemvArgs& a, int epi, hipStream_t s) {
 #undef VC_GEMV_DMA
 }
 
+// M in 17..32 (the decode pool): two row groups per weight pass.  The K partition (waves per workgroup, K-slices) of every
+// tile-count class equals the 16-row launcher's below, so a row's result does not depend on which variant served it; only
+// the tiles per workgroup and the ring depth are re-balanced for the larger slots (LDS: all workgroups resident).
+template <bool FP8>
+static void launch_gemv_m32(const GemvArgs& a, int epilogue, hipStream_t s) {
+    const int tiles = a.N / 16;
+    static const int ks_env = getenv("VC_GEMV_KS") ? atoi(getenv("VC_GEMV_KS")) : -1;
+    // VC_GEMV2_GEOM: tuning knob for the 513..768-tile class (7b qkv): 0 = 4 waves x 1 tile, 2-slot ring (3 workgroups/CU),
+    // 1 = 4 waves x 2 tiles, 2-slot ring (2/CU, the pair shares the activation fragments)
+    static const int geom = getenv("VC_GEMV2_GEOM") ? atoi(getenv("VC_GEMV2_GEOM")) : 1;
+    if (a.ksplit > 1 || (a.sk_scratch && a.sk_counters && a.ksplit == 0 && tiles > 256 && tiles <= 512)) {
+        GemvArgs b = a;
+        if (b.ksplit <= 1) b.ksplit = ks_env >= 0 ? ks_env : 3;
+        if (b.ksplit > 1) {
+            if (a.ksplit > 1 && tiles <= 256) launch_gemv_dma<4, 1, 2, FP8, 2>(b, epilogue, s);
+            else launch_gemv_dma<4, 2, 2, FP8, 2>(b, epilogue, s);
+            return;
+        }
+    }
+    if (tiles <= 256) launch_gemv_dma<8, 1, FP8 ? 4 : 3, FP8, 2>(a, epilogue, s);
+    else if (tiles <= 512) launch_gemv_dma<4, 1, 3, FP8, 2>(a, epilogue, s);
+    else if (tiles <= 768 && !FP8 && geom == 0) launch_gemv_dma<4, 1, 2, FP8, 2>(a, epilogue, s);
+    else launch_gemv_dma<4, 2, 2, FP8, 2>(a, epilogue, s);
+}
+
 template <bool FP8>
 static void launch_gemv_f(const GemvArgs& a, int epilogue, hipStream_t s) {
     // VC_GEMV_PATH=0: the register-staged kernel; default 1: the LDS-DMA ring kernel
@@ -393,6 +460,10 @@ static void launch_gemv_f(const GemvArgs& a, int epilogue, hipStream_t s) {
     // form measured: bf16 -4...-10 % with pairs, W8A16 +20 % — there the activation fragments are twice the weight bytes
     static const int nt2 = getenv("VC_GEMV_NT") ? atoi(getenv("VC_GEMV_NT")) == 2 : 0;
     const int tiles = a.N / 16;
+    if (a.M > 16) {  // the decode pool's 17..32 rows: LDS-DMA form only
+        launch_gemv_m32<FP8>(a, epilogue, s);
+        return;
+    }
     if (path == 1) {
         // Geometry by tile count, so that (where possible) every workgroup of the launch is resident at once — a tail of
         // late workgroups cannot keep enough bytes in flight to use the HBM (13b o_proj/down: 320 tiles at one

@@ -14,9 +14,13 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/vcoder_hip.h"
@@ -155,6 +159,11 @@ struct vc_model {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float t_encode = 0, t_prefill = 0, t_decode = 0;
 };
+
+struct vc_pool;
+namespace {
+void pool_destroy(vc_pool* p);
+}
 
 namespace {
 
@@ -1345,6 +1354,10 @@ VC_API void vc_model_destroy(vc_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->st);
+    if (m->pool) {  // the root's decode pool (sessions must be gone: they prefill into its rows)
+        pool_destroy(m->pool);
+        m->pool = nullptr;
+    }
     if (m->graph) (void)hipGraphExecDestroy(m->graph);
     if (m->owns_weights)
         for (void* p : m->owned) (void)hipFree(p);
@@ -1682,6 +1695,413 @@ int trim_columns(const GenParams& g, const int32_t* out_ids, int ld, const int* 
 
 std::mutex g_prefill_gate;
 
+// =================================================================================================
+// Decode pool: the cached decode steps of CONCURRENT generate() calls share one step.
+//
+// A decode step streams every decoder weight once whatever the number of rows in it (<= 32: two MFMA token-slot groups
+// per weight tile), so k requests decoding side by side on private loops read the weights k times per token where one
+// pooled step reads them once — the HBM leg of the composite roofline per image drops from  W + KV  to  W / k + KV
+// (DESIGN.md section 2b).  The reference's callers issue independent generate() calls (serve/cli.py:122, the eval
+// loaders' per-sample loop, one process per GPU in scripts/v1_5/eval/cost_depth.sh); the pool is what lets several of them
+// in flight on one GPU behave like one larger batch during decode without changing what any of them computes: rows are
+// independent in every kernel of the step, a row's arithmetic does not depend on which other rows are present, and the
+// ids a request gets are bit-identical to the ones its own loop would produce (tests: pooled == session loop).
+//
+//   request thread (vc_generate)                         driver thread (one per pool)
+//   ---------------------------------------------       ---------------------------------------------------------------
+//   take B free rows of the pool                         loop:
+//   encode + prefill on ITS stream, keys / values          admit pending requests between two steps: wait for their prefill
+//     written straight into the pool's KV rows               event on the pool stream, write their RowState records, select
+//   record prefill-done event, queue the request             token 0 from the request's prefill logits (select kernel)
+//   sleep until done (streaming: wake per report)          replay the step graph over the first 16 / all 32 rows
+//   copy its out_ids rows, free the rows                    count steps per request; retire finished ones (rows inactive)
+//
+// Only the driver touches the pool's decode state, always on the pool's stream, so joins and retirements are ordered
+// between steps without any host synchronisation of the GPU; the only host waits are a bounded run-ahead (two steps) and
+// the completion events the request threads sleep on.
+struct PoolRequest {
+    vc_model* sess = nullptr;
+    int row0 = 0, B = 0;
+    GenParams g;
+    std::vector<int> tail;
+    int* rec = nullptr;               // pinned host copy of the B RowState records
+    hipEvent_t prefill_done = nullptr, join_ev = nullptr, done_ev = nullptr, report_ev = nullptr;
+    int steps_left = 0;               // pool steps still to run for it
+    int produced = 0;                 // columns of out_ids written so far (driver's count)
+    bool can_finish = false;
+    // early finish poll (EOS / stops): FINISHED words copied out asynchronously
+    int* fin_host = nullptr;          // pinned [B]
+    hipEvent_t fin_ev = nullptr;
+    bool fin_pending = false;
+    int fin_at = 0;                   // `produced` at the time the poll was issued
+    // hand-off to the request thread
+    bool done = false, failed = false;
+    std::string err;
+    int avail = 0;                    // columns the request thread may read (streaming)
+    bool report_taken = true;
+    vc_token_cb cb = nullptr;
+    int cb_every = 1;
+    std::condition_variable cv;
+};
+
+}  // namespace
+
+struct vc_pool {
+    vc_model* root = nullptr;
+    int device = 0;
+    hipStream_t st = nullptr;
+    int R = VC_POOL_ROWS, capS = 0, out_stride = 0;
+    Buf kc, vtc, rows, x_dec, xg_dec, qkv_dec, attn_dec, h_dec, logits, next_tok, out_ids, ssq, sk_scratch, sk_counters;
+    hipGraphExec_t graph[2] = {nullptr, nullptr};  // one decode step over rows [0,16) / [0,32)
+    std::mutex mu;
+    std::condition_variable cv_driver, cv_rows;
+    std::deque<PoolRequest*> pending;
+    std::vector<PoolRequest*> active;
+    bool used[VC_POOL_ROWS] = {};
+    int users = 0;                    // generate() calls inside the pool (rows held or waited for)
+    bool stop = false;
+    std::thread driver;
+    hipEvent_t step_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned long steps_run = 0;
+};
+
+namespace {
+
+LoopView pool_view(vc_pool* p) {
+    LoopView v{};
+    v.st = p->st;
+    v.kc = p->kc.as<bf16_t>();
+    v.vtc = p->vtc.as<bf16_t>();
+    v.capR = p->R;
+    v.capS = p->capS;
+    v.rows = p->rows.as<int>();
+    v.x_dec = p->x_dec.as<float>();
+    v.xg_dec = p->xg_dec.as<bf16_t>();
+    v.qkv_dec = p->qkv_dec.as<bf16_t>();
+    v.attn_dec = p->attn_dec.as<bf16_t>();
+    v.h_dec = p->h_dec.as<bf16_t>();
+    v.logits = p->logits.as<float>();
+    v.next_tok = p->next_tok.as<int>();
+    v.out_ids = p->out_ids.as<int>();
+    v.ssq = p->ssq.as<float>();
+    v.sk_scratch = p->sk_scratch.as<float>();
+    v.sk_counters = p->sk_counters.as<unsigned>();
+    return v;
+}
+
+void pool_retire(vc_pool* p, PoolRequest* rq, bool failed, const std::string& err) {  // p->mu held
+    rq->done = true;
+    rq->failed = failed;
+    rq->err = err;
+    rq->avail = rq->produced;
+    rq->cv.notify_all();
+}
+
+void pool_driver(vc_pool* p) {
+    (void)hipSetDevice(p->device);
+    t_stream = p->st;
+    const LoopView v = pool_view(p);
+    vc_model* m = p->root;
+    std::unique_lock<std::mutex> lk(p->mu);
+    try {
+        for (;;) {
+            p->cv_driver.wait(lk, [&] { return p->stop || !p->pending.empty() || !p->active.empty(); });
+            if (p->stop) break;
+            // ---- admit: everything is enqueued on the pool stream between two steps
+            while (!p->pending.empty()) {
+                PoolRequest* rq = p->pending.front();
+                p->pending.pop_front();
+                HIPCHK(hipStreamWaitEvent(p->st, rq->prefill_done, 0));
+                HIPCHK(hipMemcpyAsync(v.rows + (size_t)rq->row0 * RS_STRIDE, rq->rec, (size_t)rq->B * RS_STRIDE * 4,
+                                      hipMemcpyHostToDevice, p->st));
+                HIPCHK(hipEventRecord(rq->join_ev, p->st));
+                SelectArgs sa = select_args(m, v, rq->sess->logits.as<float>(), rq->B, 1);  // token 0: step 0 -> 1, position stays
+                sa.row0 = rq->row0;
+                launch_select_embed(sa, p->st);
+                rq->produced = 1;
+                rq->steps_left = rq->g.max_new - 1;
+                p->active.push_back(rq);
+            }
+            // ---- retire requests that need no (further) step, before and after stepping
+            auto retire_finished = [&]() {
+                for (size_t i = 0; i < p->active.size();) {
+                    PoolRequest* rq = p->active[i];
+                    bool over = rq->steps_left <= 0;
+                    if (!over && rq->fin_pending && hipEventQuery(rq->fin_ev) == hipSuccess) {
+                        rq->fin_pending = false;
+                        bool all = true;
+                        for (int b = 0; b < rq->B; ++b) all = all && rq->fin_host[b] != 0;
+                        if (all) {  // every row had finished when the poll was taken: later columns are pads
+                            rq->produced = std::min(rq->produced, std::max(rq->fin_at, 1));
+                            over = true;
+                        }
+                    }
+                    if (!over) { ++i; continue; }
+                    // rows go inactive (RS_ACTIVE is word 0 of each record), stream-ordered after the request's last step
+                    HIPCHK(hipMemset2DAsync(v.rows + (size_t)rq->row0 * RS_STRIDE, (size_t)RS_STRIDE * 4, 0, 4, rq->B, p->st));
+                    HIPCHK(hipEventRecord(rq->done_ev, p->st));
+                    p->active.erase(p->active.begin() + i);
+                    pool_retire(p, rq, false, "");
+                }
+            };
+            retire_finished();
+            if (p->active.empty()) continue;
+            int top = 0;
+            for (PoolRequest* rq : p->active) top = std::max(top, rq->row0 + rq->B);
+            const int gi = top > 16 ? 1 : 0;
+            // bounded run-ahead: at most two steps queued beyond the one executing (a joining request waits that long)
+            const unsigned long n = p->steps_run;
+            if (n >= 2) {
+                hipEvent_t e = p->step_ev[(n - 2) % 4];
+                lk.unlock();
+                HIPCHK(hipEventSynchronize(e));
+                lk.lock();
+            }
+            HIPCHK(hipGraphLaunch(p->graph[gi], p->st));
+            HIPCHK(hipEventRecord(p->step_ev[n % 4], p->st));
+            p->steps_run = n + 1;
+            for (PoolRequest* rq : p->active) {
+                rq->steps_left -= 1;
+                rq->produced += 1;
+                // streamer: hand the request thread an event every cb_every columns (skipped while it is still busy)
+                if (rq->cb && rq->report_taken && rq->produced - rq->avail >= rq->cb_every && rq->steps_left > 0) {
+                    HIPCHK(hipEventRecord(rq->report_ev, p->st));
+                    rq->avail = rq->produced;
+                    rq->report_taken = false;
+                    rq->cv.notify_all();
+                }
+                // EOS / stop: look at the rows' FINISHED words every 8 columns without stalling the stream
+                if (rq->can_finish && !rq->fin_pending && rq->produced % 8 == 0 && rq->steps_left > 0) {
+                    HIPCHK(hipMemcpy2DAsync(rq->fin_host, 4, v.rows + (size_t)rq->row0 * RS_STRIDE + RS_FINISHED,
+                                            (size_t)RS_STRIDE * 4, 4, rq->B, hipMemcpyDeviceToHost, p->st));
+                    HIPCHK(hipEventRecord(rq->fin_ev, p->st));
+                    rq->fin_pending = true;
+                    rq->fin_at = rq->produced;
+                }
+            }
+            retire_finished();
+        }
+    } catch (const Fail& f) {
+        for (PoolRequest* rq : p->active) pool_retire(p, rq, true, f.msg);
+        for (PoolRequest* rq : p->pending) pool_retire(p, rq, true, f.msg);
+        p->active.clear();
+        p->pending.clear();
+        p->stop = true;
+    }
+}
+
+void pool_destroy(vc_pool* p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->stop = true;
+    }
+    p->cv_driver.notify_all();
+    if (p->driver.joinable()) p->driver.join();
+    (void)hipSetDevice(p->device);
+    (void)hipStreamSynchronize(p->st);
+    for (auto& g : p->graph)
+        if (g) (void)hipGraphExecDestroy(g);
+    for (Buf* b : {&p->kc, &p->vtc, &p->rows, &p->x_dec, &p->xg_dec, &p->qkv_dec, &p->attn_dec, &p->h_dec, &p->logits,
+                   &p->next_tok, &p->out_ids, &p->ssq, &p->sk_scratch, &p->sk_counters})
+        b->release();
+    for (auto& e : p->step_ev)
+        if (e) (void)hipEventDestroy(e);
+    if (p->st) (void)hipStreamDestroy(p->st);
+    delete p;
+}
+
+std::mutex g_pool_create;
+
+// the root model's pool with room for `need_S` positions and `need_out` ids per row; an idle pool that is too small is
+// rebuilt, a busy one makes the caller wait for it to drain
+vc_pool* pool_for(vc_model* m, int need_S, int need_out) {
+    vc_model* root = m->root ? m->root : m;
+    const vc_model_cfg& c = root->c;
+    std::unique_lock<std::mutex> create(g_pool_create);
+    vc_pool* p = root->pool;
+    if (p && (p->capS < need_S || p->out_stride < need_out)) {
+        std::unique_lock<std::mutex> lk(p->mu);
+        p->cv_rows.wait(lk, [&] { return p->users == 0; });
+        lk.unlock();
+        pool_destroy(p);
+        root->pool = p = nullptr;
+    }
+    if (p) return p;
+    p = new vc_pool();
+    p->root = root;
+    p->device = root->ctx->device;
+    const int D = c.hidden, F = c.ffn, H = c.heads, R = p->R;
+    p->capS = std::min((int)rup(std::max(need_S, 2048), 64), c.max_positions / 64 * 64);
+    p->out_stride = std::max(need_out, p->capS);
+    REQUIRE(p->capS >= need_S, VC_ERR_INVALID, "sequence %d exceeds max_position_embeddings=%d", need_S, c.max_positions);
+    HIPCHK(hipStreamCreateWithFlags(&p->st, hipStreamNonBlocking));
+    t_stream = p->st;  // zero-fills of the new buffers
+    const size_t kvb = (size_t)c.layers * R * H * p->capS * root->hd * 2;
+    p->kc.ensure(kvb, true);
+    p->vtc.ensure(kvb, true);
+    p->rows.ensure((size_t)R * RS_STRIDE * 4, true);
+    p->x_dec.ensure((size_t)R * D * 4, true);
+    p->xg_dec.ensure((size_t)R * D * 2, true);
+    p->qkv_dec.ensure((size_t)R * 3 * D * 2, true);
+    p->attn_dec.ensure((size_t)R * D * 2, true);
+    p->h_dec.ensure((size_t)R * F * 2, true);
+    p->logits.ensure((size_t)R * c.vocab * 4, true);
+    p->next_tok.ensure(R * 4, true);
+    p->out_ids.ensure((size_t)R * p->out_stride * 4, true);
+    p->ssq.ensure((size_t)R * root->npart * 4, true);
+    p->sk_scratch.ensure((size_t)4 * 512 * 2 * 256 * 4);   // [ksplit <= 4][tiles <= 512][2 row groups][256]
+    p->sk_counters.ensure(512 * 2 * 4, true);
+    t_stream = m->st;
+    for (auto& e : p->step_ev) HIPCHK(hipEventCreate(&e));
+    const LoopView v = pool_view(p);
+    p->graph[0] = capture_step(root, v, 16);
+    p->graph[1] = capture_step(root, v, R);
+    p->driver = std::thread(pool_driver, p);
+    root->pool = p;
+    return p;
+}
+
+// generate() through the pool: prefill on the session's stream into pool rows, decode steps shared with whoever else is in
+void generate_on_pool(vc_model* m, const int64_t* ids, int B, int T, const float* img, const float* seg, const float* depth,
+                      int on_dev, const GenParams& g, const std::vector<int>& tail, vc_token_cb cb, void* cb_user,
+                      int cb_every, int32_t* out_ids, int* n_generated) {
+    const vc_model_cfg& c = m->c;
+    const int max_new = g.max_new;
+    // the spliced length is only known after the splice plan; an upper bound sizes the pool: every placeholder could
+    // expand to a feature block
+    int n_ph = 0;
+    for (int t = 0; t < T; ++t) n_ph += ids[t] < 0;
+    const int R_img = m->Tv;
+    const int S_bound = std::min(c.max_positions, T + std::max(n_ph, 1) * 3 * R_img);
+    vc_pool* p = pool_for(m, std::min(S_bound + max_new, c.max_positions / 64 * 64), max_new);
+    PoolRequest rq;
+    rq.sess = m;
+    rq.B = B;
+    rq.g = g;
+    rq.tail = tail;
+    rq.cb = cb;
+    rq.cb_every = std::max(cb_every, 1);
+    rq.can_finish = g.eos >= 0 || g.n_stop > 0;
+    // ---- rows: first fit of B contiguous free rows; blocks while the pool is full
+    {
+        std::unique_lock<std::mutex> lk(p->mu);
+        p->users += 1;
+        int row0 = -1;
+        p->cv_rows.wait(lk, [&] {
+            for (int r0 = 0; r0 + B <= p->R; ++r0) {
+                bool free_ = true;
+                for (int r = r0; r < r0 + B && free_; ++r) free_ = !p->used[r];
+                if (free_) { row0 = r0; return true; }
+            }
+            return false;
+        });
+        for (int r = row0; r < row0 + B; ++r) p->used[r] = true;
+        rq.row0 = row0;
+    }
+    auto release_rows = [&]() {
+        std::lock_guard<std::mutex> lk(p->mu);
+        for (int r = rq.row0; r < rq.row0 + B; ++r) p->used[r] = false;
+        p->users -= 1;
+        p->cv_rows.notify_all();
+    };
+    hipEvent_t* evs[] = {&rq.prefill_done, &rq.join_ev, &rq.done_ev, &rq.report_ev, &rq.fin_ev};
+    auto cleanup = [&]() {
+        for (hipEvent_t* e : evs)
+            if (*e) (void)hipEventDestroy(*e);
+        if (rq.rec) (void)hipHostFree(rq.rec);
+        if (rq.fin_host) (void)hipHostFree(rq.fin_host);
+    };
+    try {
+        for (hipEvent_t* e : evs) HIPCHK(hipEventCreate(e));
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&rq.rec), (size_t)B * RS_STRIDE * 4, 0));
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&rq.fin_host), (size_t)B * 4, 0));
+        // ---- encode + prefill, keys / values straight into the pool's rows
+        m->cur_pos = -1;
+        int S = 0;
+        static const bool use_gate = !(getenv("VC_PREFILL_GATE") && atoi(getenv("VC_PREFILL_GATE")) == 0);
+        std::unique_lock<std::mutex> gate(g_prefill_gate, std::defer_lock);
+        if (use_gate) gate.lock();
+        do_prefill(m, ids, B, T, img, seg, depth, on_dev, 1, max_new, false, &S);
+        m->last_S = S;
+        REQUIRE(S + max_new <= p->capS, VC_ERR_INVALID, "prompt %d + max_new %d exceeds the pool's KV capacity %d", S, max_new,
+                p->capS);
+        finish_prefill(m, KvTarget{p->kc.as<bf16_t>(), p->vtc.as<bf16_t>(), p->R, p->capS, rq.row0}, nullptr);
+        if (m->ev[2]) HIPCHK(hipEventRecord(m->ev[2], m->st));
+        HIPCHK(hipEventRecord(rq.prefill_done, m->st));
+        if (use_gate) gate.unlock();
+        fill_rows(rq.rec, B, g, S, tail.data(), rq.row0 * p->out_stride, p->out_stride);
+        // ---- join, then sleep until the driver retires the request (streaming: wake per report)
+        std::unique_lock<std::mutex> lk(p->mu);
+        REQUIRE(!p->stop, VC_ERR_STATE, "the decode pool has stopped after an error");
+        p->pending.push_back(&rq);
+        p->cv_driver.notify_all();
+        int reported = 0;
+        std::vector<int> part;
+        auto report = [&](int upto, hipEvent_t after) {  // called with lk held; drops it around the copy + callback
+            if (!cb || upto <= reported) return;
+            lk.unlock();
+            HIPCHK(hipStreamWaitEvent(m->st, after, 0));
+            part.resize((size_t)B * (upto - reported));
+            HIPCHK(hipMemcpy2DAsync(part.data(), (size_t)(upto - reported) * 4,
+                                    p->out_ids.as<int>() + (size_t)rq.row0 * p->out_stride + reported,
+                                    (size_t)p->out_stride * 4, (size_t)(upto - reported) * 4, B, hipMemcpyDeviceToHost, m->st));
+            HIPCHK(hipStreamSynchronize(m->st));
+            cb(cb_user, reported, upto - reported, B, part.data());
+            reported = upto;
+            lk.lock();
+        };
+        for (;;) {
+            rq.cv.wait(lk, [&] { return rq.done || !rq.report_taken; });
+            if (rq.done) break;
+            const int upto = rq.avail;
+            report(upto, rq.report_ev);
+            rq.report_taken = true;
+        }
+        REQUIRE(!rq.failed, VC_ERR_HIP, "decode pool: %s", rq.err.c_str());
+        int produced = rq.produced;
+        lk.unlock();
+        HIPCHK(hipStreamWaitEvent(m->st, rq.done_ev, 0));
+        HIPCHK(hipMemcpy2DAsync(out_ids, (size_t)max_new * 4, p->out_ids.as<int>() + (size_t)rq.row0 * p->out_stride,
+                                (size_t)p->out_stride * 4, (size_t)max_new * 4, B, hipMemcpyDeviceToHost, m->st));
+        HIPCHK(hipStreamSynchronize(m->st));
+        for (int b = 0; b < B; ++b)  // columns the loop never reached read as pad, like the session loop's pre-filled store
+            for (int s_ = produced; s_ < max_new; ++s_) out_ids[(size_t)b * max_new + s_] = g.pad;
+        produced = trim_columns(g, out_ids, max_new, tail.data(), B, produced);
+        if (cb && produced > reported) {
+            part.resize((size_t)B * (produced - reported));
+            for (int b = 0; b < B; ++b)
+                memcpy(part.data() + (size_t)b * (produced - reported), out_ids + (size_t)b * max_new + reported,
+                       (size_t)(produced - reported) * 4);
+            cb(cb_user, reported, produced - reported, B, part.data());
+        }
+        if (n_generated) *n_generated = produced;
+        if (m->ev[0]) {
+            (void)hipEventElapsedTime(&m->t_encode, m->ev[0], m->ev[1]);
+            (void)hipEventElapsedTime(&m->t_prefill, m->ev[1], m->ev[2]);
+            (void)hipEventElapsedTime(&m->t_decode, rq.join_ev, rq.done_ev);
+        }
+    } catch (...) {
+        {   // a request that is still queued / active must not outlive this frame
+            std::unique_lock<std::mutex> lk(p->mu);
+            auto it = std::find(p->pending.begin(), p->pending.end(), &rq);
+            if (it != p->pending.end()) p->pending.erase(it);
+            else if (!rq.done && std::find(p->active.begin(), p->active.end(), &rq) != p->active.end()) {
+                rq.steps_left = 0;  // the driver retires it at its next pass
+                p->cv_driver.notify_all();
+                rq.cv.wait(lk, [&] { return rq.done; });
+            }
+        }
+        (void)hipStreamSynchronize(m->st);
+        release_rows();
+        cleanup();
+        throw;
+    }
+    release_rows();
+    cleanup();
+}
+
+
 // generate() on the session's own loop: prefill, then max_new - 1 graph-replayed (strict: eagerly enqueued) decode steps
 void generate_on_session(vc_model* m, const int64_t* ids, int B, int T, const float* img, const float* seg, const float* depth,
                          int on_dev, const GenParams& g, const std::vector<int>& tail, vc_token_cb cb, void* cb_user,
@@ -1805,7 +2225,14 @@ VC_API int vc_generate(vc_model* m, const int64_t* ids, int B, int T, const floa
     std::vector<int> tail((size_t)B * TL, INT32_MIN);  // ids never equal INT32_MIN
     for (int b = 0; b < B; ++b)
         for (int j = 0; j < TL && j < T; ++j) tail[(size_t)b * TL + TL - 1 - j] = (int)ids[(size_t)b * T + T - 1 - j];
-    generate_on_session(m, ids, B, T, img, seg, depth, pixels_on_device, g, tail, cb, cb_user, cb_every, out_ids, n_generated);
+    // concurrent generate() calls share their decode steps in the root model's pool (VC_POOL=0: every call on its own
+    // loop); strict mode keeps fp32 caches of its own
+    static const bool use_pool = !(getenv("VC_POOL") && atoi(getenv("VC_POOL")) == 0);
+    if (use_pool && !m->precision)
+        generate_on_pool(m, ids, B, T, img, seg, depth, pixels_on_device, g, tail, cb, cb_user, cb_every, out_ids, n_generated);
+    else
+        generate_on_session(m, ids, B, T, img, seg, depth, pixels_on_device, g, tail, cb, cb_user, cb_every, out_ids,
+                            n_generated);
     GUARD_END(m->ctx)
 }
 

@@ -49,7 +49,7 @@ VCK_EXPORT void vck_attention_decode_rows(const uint16_t* qkv, uint16_t* k, uint
 VCK_EXPORT void vck_select_embed(const float* logits, int ldl, int* rows, int* next_tok, int* out_ids, const uint16_t* embed,
                                  float* x, float* ssq, const float* xg_w, uint16_t* xg, int D, int npart, int V, int nrows,
                                  int advance, void* stream) {
-    SelectArgs a{logits, ldl, rows, next_tok, out_ids, embed, x, ssq, xg_w, xg, D, npart, V, nrows, advance, 0};
+    SelectArgs a{logits, ldl, rows, next_tok, out_ids, embed, x, ssq, xg_w, xg, D, npart, V, nrows, advance, 0, 0};
     launch_select_embed(a, S(stream));
 }
 VCK_EXPORT int vck_row_state_stride() { return RS_STRIDE; }

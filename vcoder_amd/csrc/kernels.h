@@ -48,7 +48,7 @@ enum GemvEpilogue : int {
     GEMV_RESID_F32 = 2,  // out fp32 [M, N] += acc     (o_proj / down_proj into the residual stream)
     GEMV_SWIGLU = 3,     // interleaved (gate,up) rows: out bf16 [M, N/2]
 };
-constexpr int VC_GEMV_MAX_M = 16;  // token slots one weight pass of launch_gemv serves
+constexpr int VC_GEMV_MAX_M = 32;  // token rows one weight pass of launch_gemv serves (two MFMA row groups above 16)
 struct GemvArgs {
     const bf16_t* X;   // [M, K] bf16 activations (M <= VC_GEMV_MAX_M)
     const bf16_t* Wp;  // packed weights
@@ -63,8 +63,8 @@ struct GemvArgs {
     //            the producer's xg = bf16(x * g)
     //  producer (RESID epilogue): ssq_out[m][n_tile] = sum over the tile's 16 columns of the updated residual^2, and
     //            xg_out[m][n] = bf16(residual * xg_w[n]) — the next consumer's activation operand
-    const float* ssq_in;   // [16, npart] or nullptr
-    float* ssq_out;        // [16, npart] or nullptr
+    const float* ssq_in;   // [M, npart] or nullptr
+    float* ssq_out;        // [M, npart] or nullptr
     const float* xg_w;     // [N] norm weight of the consumer, or nullptr
     bf16_t* xg_out;        // [M, N]
     int npart;             // partials per row (multiple of 16)
@@ -72,8 +72,8 @@ struct GemvArgs {
     // deterministic split-K for matrices with few output tiles (o_proj, down): `ksplit` workgroups share one tile,
     // each writes its fp32 partial to sk_scratch[ks][tile][64 lanes][4]; the LAST to arrive (sk_counters[tile]) sums
     // the partials in k order — the result does not depend on arrival order — runs the epilogue and re-arms the counter
-    float* sk_scratch;       // [ksplit][N/16][256] or nullptr
-    unsigned* sk_counters;   // [N/16], zero between launches
+    float* sk_scratch;       // [ksplit][N/16][row groups][256] or nullptr (row groups = 1 for M <= 16, else 2)
+    unsigned* sk_counters;   // [N/16][row groups], zero between launches
     int ksplit;              // 0/1 = off (launcher decides when the two buffers are given)
     int w_cached;            // 1: stream the weights with the default cache policy instead of non-temporal (VC_GEMV_WCACHED)
 };
@@ -230,6 +230,8 @@ struct SelectArgs {
     int nrows;
     int advance;          // bit 0: step += 1; bit 1: pos += 1 (after the selection)
     int lds_floats;       // filled by the launcher: floats of LDS staging available to the sampler
+    int row0;             // workgroup i handles state row row0 + i (rows / next_tok / x / ssq / xg) with logits row i: rows
+                          // that join a running loop are selected from their prefill's own logits buffer
 };
 void launch_select_embed(const SelectArgs& a, hipStream_t s);
 // rows[row0 .. row0+nrows) <- src[0 .. nrows) (whole records), stream-ordered

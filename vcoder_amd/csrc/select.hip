@@ -109,11 +109,11 @@ __global__ __launch_bounds__(1024) void select_embed_kernel(SelectArgs p) {
     VC_DYNAMIC_SMEM(float, zs);  // [V] scaled logits of the row (sampling only)
     __shared__ BlockRed red;
     __shared__ int tok_s;
-    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = p.row0 + (int)blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int* rs = p.rows + (size_t)r * RS_STRIDE;
     if (!rs[RS_ACTIVE]) return;
     const int step = rs[RS_STEP];
-    const float* lg = p.logits + (size_t)r * p.ldl;
+    const float* lg = p.logits + (size_t)blockIdx.x * p.ldl;
     const int V = p.V;
     float best = -INFINITY;
     int bi = 0x7FFFFFFF;
