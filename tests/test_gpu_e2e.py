@@ -490,3 +490,58 @@ def test_token_comm_c_abi_world1():
     x = np.arange(24, dtype=np.int32).reshape(3, 8)
     assert np.array_equal(c.allgather(x), x)
     c.close()
+
+
+def test_decode_pool_tiny():
+    """the decode pool on the GPU (tiny model): the three scenarios of tests/test_pool_emu.py — concurrent requests of
+    different shapes, mixed EOS / stop / sampling parameters, more requests than rows — each equal to its lone run"""
+    import test_pool_emu as tp
+
+    tp.test_concurrent_requests_share_steps_and_keep_their_ids(None)
+    tp.test_pool_mixes_eos_stops_and_sampling(None)
+    tp.test_pool_queues_requests_beyond_its_rows(None)
+
+
+def test_decode_pool_true_dims():
+    """TRUE 7b dimensions (4 decoder layers): three concurrent generate() calls of batch 8 — the bench's configuration —
+    share 32-row decode steps (two MFMA row groups per weight pass) and each gets bit-for-bit the ids of the session's own
+    16-row loop; a lone call (16-row steps) gets them too."""
+    import threading
+    import test_pool_emu as tp
+
+    cfg = vcfg.vicuna_7b("vcoder_ds")
+    cfg.num_hidden_layers = 4
+    cfg.vit_num_layers = 3
+    root = HipEngine(cfg)
+    root.load_synthetic(9)
+    root.finalize()
+    B, n = 8, 12
+    cases, refs = [], []
+    for k in range(3):
+        ids = np.stack([synth.synth_prompt_ids(cfg.vocab_size, "vcoder_ds", sample=8 * k + b) for b in range(B)])
+        px = synth.synth_batch(B, 336, first=8 * k)
+        cases.append((ids, *px))
+        refs.append(tp.session_loop_ids(root, ids, *px, n))
+    assert np.array_equal(root.generate_greedy(*cases[0], max_new_tokens=n), refs[0])      # lone request: 16-row steps
+    sessions = [root, root.fork(), root.fork()]
+    outs, errs = [[None] * 2 for _ in sessions], []
+
+    def work(si):
+        try:
+            for j in range(2):
+                outs[si][j] = sessions[si].generate_greedy(*cases[si], max_new_tokens=n)
+        except BaseException as e:
+            errs.append(e)
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    for si in range(3):
+        for j in range(2):
+            assert np.array_equal(outs[si][j], refs[si]), f"session {si} run {j}: pooled ids differ from the session loop"
+    for s in sessions[1:]:
+        s.close()
+    root.close()

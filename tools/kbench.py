@@ -89,6 +89,63 @@ def bench_gemv():
             print(f"gemv+rstd {name:8s}          : {us:7.1f} us  {2 * N * K / us / 1e3:7.1f} GB/s", flush=True)
 
 
+def bench_gemv_rows():
+    """The decode pool's question: what does a weight pass cost at M = 8 / 16 (one row group) and M = 24 / 32 (two)?
+    7b shapes with the folded-RMSNorm operands the engine uses (consumers scale by rstd; producers publish partials + xg)."""
+    for M in (8, 16, 24, 32):
+        tot = 0.0
+        for (N, K, epi, name, cnt) in [(12288, 4096, 0, "qkv", 32), (4096, 4096, 2, "o", 32), (22016, 4096, 3, "gate-up", 32),
+                                       (4096, 11008, 2, "down", 32), (32000, 4096, 1, "lm_head", 1)]:
+            X = bf16(32, K)
+            Ws = [bf16(N * K, scale=0.02) for _ in range(8)]
+            out = torch.zeros((32, N), dtype=torch.float32 if epi in (1, 2) else torch.bfloat16, device=dev)
+            ldo = N // 2 if epi == 3 else N
+            npart = (4096 // 16 + 15) // 16 * 16
+            ssq = torch.rand(32, npart, device=dev)
+            gw = torch.rand(N, device=dev) + 0.5
+            xg = torch.zeros((32, N), dtype=torch.bfloat16, device=dev)
+            scratch = torch.zeros(4 * (N // 16) * 2 * 256, device=dev)
+            counters = torch.zeros(N // 16 * 2, dtype=torch.int32, device=dev)
+            it = [0]
+
+            def f():
+                it[0] += 1
+                if epi == 2:
+                    lib.vck_gemv_ex(P(X), P(Ws[it[0] % 8]), None, P(out), None, P(ssq), P(gw), P(xg), npart, C.c_float(1e-5),
+                                    P(scratch), P(counters), 0, M, N, K, ldo, epi, None)
+                else:
+                    lib.vck_gemv_ex(P(X), P(Ws[it[0] % 8]), None, P(out), P(ssq), None, None, None, npart, C.c_float(1e-5),
+                                    None, None, 0, M, N, K, ldo, epi, None)
+            us = timeit(f, iters=40)
+            tot += us * cnt
+            print(f"gemv_rows M{M:2d} {name:8s} N{N} K{K}: {us:7.1f} us  {2 * N * K / us / 1e3:7.1f} GB/s", flush=True)
+        print(f"gemv_rows M{M:2d} all GEMVs of a 7b decode step: {tot / 1e3:6.3f} ms = {tot / 1e3 / M:6.4f} ms per row "
+              f"(geom {os.environ.get('VC_GEMV2_GEOM', 'default')})", flush=True)
+
+
+def bench_dattn_rows():
+    """decode attention over B rows with per-row positions (the pool's form), ctx ~1280"""
+    H, hd, S = 32, 128, 2048
+    D = H * hd
+    cos, sin = torch.rand(S, hd // 2, device=dev), torch.rand(S, hd // 2, device=dev)
+    for B in (8, 16, 24, 32):
+        qkv = bf16(B, 3 * D)
+        ks = [bf16(B, H, S, hd) for _ in range(2)]
+        vs = [bf16(B, H, hd, S) for _ in range(2)]
+        out = torch.zeros((B, D), dtype=torch.bfloat16, device=dev)
+        pos = torch.tensor([1216 + (7 * b) % 128 for b in range(B)], dtype=torch.int32, device=dev)
+        act = torch.ones(B, dtype=torch.int32, device=dev)
+        it = [0]
+
+        def f():
+            it[0] += 1
+            lib.vck_attention_decode_rows(P(qkv), P(ks[it[0] % 2]), P(vs[it[0] % 2]), P(out), B, H, hd, S, P(pos), 1, P(act),
+                                          P(cos), P(sin), C.c_float(1 / math.sqrt(hd)), None)
+        us = timeit(f, iters=40)
+        byts = 4.0 * float((pos + 1).sum().item()) * D
+        print(f"decode attention rows B={B:2d} ctx~1280: {us:7.1f} us  {byts / us / 1e3:7.1f} GB/s", flush=True)
+
+
 def bench_gemv_pair():
     """Two streams run the SAME GEMV (same weights, different activations / outputs) at the same time: does the second
     reader hit the Infinity Cache / merge with the first?  pair time ~ single time => yes."""
@@ -226,6 +283,11 @@ if __name__ == "__main__":
         bench_gemv13()
     if "gemv_pair" in what:
         bench_gemv_pair()
+    if "gemv_rows" in what:
+        bench_gemv_rows()
+    if "dattn_rows" in what:
+        bench_dattn_rows()
     for w in what:
         {"gemm": bench_gemm, "gemv": bench_gemv, "attn": bench_attn, "dattn": bench_dattn,
-         "gemv_fp8": lambda: None, "gemv13": lambda: None, "gemv_pair": lambda: None}[w]()
+         "gemv_fp8": lambda: None, "gemv13": lambda: None, "gemv_pair": lambda: None, "gemv_rows": lambda: None,
+         "dattn_rows": lambda: None}[w]()
