@@ -321,17 +321,24 @@ def main():
     torch.cuda.synchronize()
     solo = (time.perf_counter() - t1) / 2
     timings = sessions[0].last_timings()
-    prof = eng.profile_decode_gemv(min(B, 16), reps=3)
+    # the dominant kernel as the timed configuration runs it: the decode GEMV over the rows that share a step (the in-flight
+    # batches' rows in the pool, up to 32), and over one batch alone for reference
+    pooled = os.environ.get("VC_POOL", "1") != "0"
+    rows_step = min(n_sess * B, 32) if pooled else min(B, 16)
+    prof = eng.profile_decode_gemv(rows_step, reps=3)
+    prof_one = eng.profile_decode_gemv(min(B, 16), reps=3) if rows_step != min(B, 16) else prof
 
     if rank == 0:
         traffic = args.pmc_traffic_bytes
         if traffic is None and args.model == "7b" and B == 8 and args.weights == "bf16":
-            for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-                f_ = os.path.join(ROOT, "profiles", name)
-                if os.path.exists(f_):
-                    with open(f_) as f:   # separate --pmc pass, gfx950 x2 correction applied (see the file)
-                        traffic = json.load(f)["hbm_read_bytes_per_launch"]
-                    break
+            # separate --pmc FETCH_SIZE pass of this kernel at this row count (gfx950 x2 correction applied, see the file)
+            f_ = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+            if os.path.exists(f_):
+                with open(f_) as f:
+                    traffic = json.load(f).get("hbm_read_bytes_per_launch_by_rows", {}).get(str(rows_step))
+            if traffic is None and rows_step == 8 and os.path.exists(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")):
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                    traffic = json.load(f)["hbm_read_bytes_per_launch"]
         S = 64 + 2 * cfg.num_patches
         ms_step = dt / args.steps * 1e3
         ach = prof["avg_bytes"] / (prof["avg_us"] * 1e-6) / 1e9
@@ -341,7 +348,8 @@ def main():
         hbm_ms = ((N_new - 1) * w_bytes + B * kv_bytes) / (HBM_PEAK_GBS * 1e9) * 1e3
         # with k batches in flight whose decode steps share one weight pass, the HBM leg of a batch shrinks to
         # weights / k + its own KV: the bound of what `value` measures
-        hbm_ms_shared = ((N_new - 1) * w_bytes / n_sess + B * kv_bytes) / (HBM_PEAK_GBS * 1e9) * 1e3
+        share = n_sess if pooled else 1
+        hbm_ms_shared = ((N_new - 1) * w_bytes / share + B * kv_bytes) / (HBM_PEAK_GBS * 1e9) * 1e3
         res = {
             "metric": "images/sec (3xViT encode + 128-tok decode), VCoder-DS-7b" if args.model == "7b"
                       else "images/sec (3xViT encode + 128-tok decode), VCoder-DS-13b",
@@ -352,8 +360,10 @@ def main():
                                    f"prefill S={S}, {N_new}-token greedy decode", "global_batch": world * B,
                        "parallelism": f"dp{world}", "weights": "seeded synthetic (vcoder_amd/synth.py)",
                        "in_flight_batches_per_gpu": n_sess,
-                       "value_is": (f"{n_sess} generate() calls of batch {B} in flight per GPU (each a complete, independent hot-path "
-                                    f"pass; see one_batch_at_a_time for a lone batch)") if n_sess > 1 else "one batch at a time",
+                       "value_is": (f"{n_sess} generate() calls of batch {B} in flight per GPU, each a complete, independent hot-path "
+                                    f"pass; their cached decode steps " + ("share weight passes in the decode pool" if pooled else "run on private loops (VC_POOL=0)")
+                                    + "; see one_batch_at_a_time for a lone batch") if n_sess > 1 else "one batch at a time",
+                       "decode_pool": pooled,
                        "inputs": "host buffers (PCIe inclusive)" if args.host_pixels else "resident in HBM",
                        "token_gather": "vc_allgather_tokens (RCCL via the C ABI)" if comm is not None else
                                        ("torch.distributed all_gather_into_tensor (%s)" % backend if world > 1 else "none (1 GPU)")},
@@ -369,11 +379,13 @@ def main():
                                    "frac_value": (mfma_ms + hbm_ms_shared) / ms_step,
                                    "peaks": {"mfma_tflops": MFMA_PEAK_TFLOPS, "hbm_gbs": HBM_PEAK_GBS},
                                    "measured_legs_ms": {"mfma": timings["encode_ms"] + timings["prefill_ms"], "hbm": timings["decode_ms"]}},
-            "roofline": {"bound": "hbm", "kernel": "gemv_dma_kernel (decode weight streaming, all GEMV launches of a step)", "achieved": ach,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": f"gemv_dma_kernel (decode weight streaming, all GEMV launches of a step, {rows_step} rows per weight pass)",
+                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": traffic, "avg_launch_us": prof["avg_us"],
                          "algorithmic_bytes_per_launch": prof["avg_bytes"],
-                         "launches_per_decode_step": prof["launches_per_step"]},
+                         "launches_per_decode_step": prof["launches_per_step"], "rows_per_weight_pass": rows_step,
+                         "one_batch_alone": {"rows": min(B, 16), "avg_launch_us": prof_one["avg_us"],
+                                             "achieved": prof_one["avg_bytes"] / (prof_one["avg_us"] * 1e-6) / 1e9}},
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, N_new)

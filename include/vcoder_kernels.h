@@ -30,8 +30,9 @@ void vck_gemv(const uint16_t* X, const uint16_t* Wp, void* out, int M, int N, in
  *   producer  (epi 2): ssq_out gets the partials of the updated residual rows and xg_out = bf16(residual * xg_w).
  * wscale != NULL: Wp holds W8A16 e4m3 bytes (vck_quantize_fp8) and wscale the per-output-row scales.
  * sk_scratch/sk_counters != NULL: deterministic split-K for matrices with few output tiles — `ksplit` workgroups per
- * tile (0 = let the launcher choose), partials [ksplit][N/16][256] fp32 summed in k order by the last arriver;
- * sk_counters [N/16] must be zero before the first launch (the kernel re-arms them). */
+ * tile (0 = let the launcher choose), partials [ksplit][N/16][2][256] fp32 summed in k order by the last arriver;
+ * sk_counters [N/16][2] must be zero before the first launch (the kernel re-arms them).  M <= 32: rows 16..31 form a
+ * second MFMA row group served by the same weight pass (the decode pool's steps). */
 void vck_gemv_ex(const uint16_t* X, const void* Wp, const float* wscale, void* out, const float* ssq_in, float* ssq_out,
                  const float* xg_w, uint16_t* xg_out, int npart, float eps, float* sk_scratch, unsigned* sk_counters,
                  int ksplit, int M, int N, int K, int ldo, int epi, void* stream);

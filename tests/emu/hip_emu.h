@@ -105,6 +105,7 @@ inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) {
     return 0;
 }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return 0; }
+inline hipError_t hipGetLastError() { return 0; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
 inline hipError_t hipEventQuery(hipEvent_t) { return 0; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }

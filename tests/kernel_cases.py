@@ -195,7 +195,7 @@ def check_gemv(be, M, N, K, epi, seed=0):
 
 def _gemv_ex(be, X, Wp, wscale, out, ssq_in, ssq_out, xg_w, xg_out, npart, M, N, K, ldo, epi, sk=None, ksplit=0):
     """vck_gemv_ex through raw pointers; every array must stay referenced by the caller until be.sync().
-    sk = (scratch f32 [ksplit*N/16*256], counters i32 [N/16]) enables the split-K finisher."""
+    sk = (scratch f32 [ksplit*N/16*2*256], counters i32 [N/16*2]) enables the split-K finisher."""
     be.lib.vck_gemv_ex(be.ptr(X), be.ptr(Wp), be.ptr(wscale), be.ptr(out), be.ptr(ssq_in), be.ptr(ssq_out), be.ptr(xg_w),
                        be.ptr(xg_out), ctypes.c_int(npart), ctypes.c_float(1e-5), be.ptr(sk[0]) if sk else None,
                        be.ptr(sk[1]) if sk else None, ctypes.c_int(ksplit), M, N, K, ldo, epi, None)
@@ -269,7 +269,7 @@ def check_gemv_splitk(be, M, N, K, ksplit, seed=0):
     Wp = be.zeros((N * K,), "bf16")
     _call(be, "vck_pack_weight", Wd, Wp, N, K)
     ref = r0.astype(np.float64) + X.astype(np.float64) @ W.T.astype(np.float64)
-    scratch, counters = be.zeros((max(ksplit, 1) * (N // 16) * 256,), "f32"), be.zeros((N // 16,), "i32")
+    scratch, counters = be.zeros((max(ksplit, 1) * (N // 16) * 2 * 256,), "f32"), be.zeros((N // 16 * 2,), "i32")
     outs = []
     for it in range(3):
         out, ssq, xg = be.f32(r0.copy()), be.zeros((16, npart), "f32"), be.zeros((M, N), "bf16")   # f32() may alias its input

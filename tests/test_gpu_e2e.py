@@ -475,7 +475,11 @@ def test_bench_two_ranks_self_launched(tmp_path):
     eng.finalize()
     ids = np.stack([synth.synth_prompt_ids(cfg.vocab_size, "vcoder_ds", sample=b) for b in range(4)])
     imgs, segs, deps = synth.synth_batch(4, 336)
-    ref = eng.generate_greedy(ids, imgs, segs, deps, max_new_tokens=6)
+    # the same shards the ranks ran (2 samples each): a GEMM's split-K remainder round depends on the number of tiles, so a
+    # prefill of 4 samples is not bit-for-bit two prefills of 2 at these dimensions, and greedy ids on random weights
+    # have near-ties that notice
+    ref = np.concatenate([eng.generate_greedy(ids[r:r + 2], imgs[r:r + 2], segs[r:r + 2], deps[r:r + 2], max_new_tokens=6)
+                          for r in (0, 2)], axis=0)
     eng.close()
     assert np.array_equal(got, ref), "gathered ids of the 2-rank run differ from the single-process ids"
 

@@ -97,7 +97,7 @@ def test_fused_decode_kernels(be):
     kc.check_attention_decode_fused(be, 2, 4, 128, 1343)
     kc.check_attention_decode_fused(be, 1, 2, 64, 5)
     kc.check_attention_decode_fused(be, 2, 4, 128, 5000)   # cache capacity > 4096 keys: the single-pass kernel
-    kc.check_greedy_embed(be, 8, 32000, 4096)
+    kc.check_select_embed(be, 8, 32000, 4096)
 
 
 def test_strict_fp32_kernels(be):

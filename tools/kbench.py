@@ -66,8 +66,8 @@ def bench_gemv():
         us = timeit(f, iters=40)
         print(f"gemv {name:8s} N{N} K{K} epi{epi}: {us:7.1f} us  {2 * N * K / us / 1e3:7.1f} GB/s", flush=True)
         if epi == 2:
-            scratch = torch.zeros(4 * (N // 16) * 256, device=dev)
-            counters = torch.zeros(N // 16, dtype=torch.int32, device=dev)
+            scratch = torch.zeros(4 * (N // 16) * 2 * 256, device=dev)
+            counters = torch.zeros(N // 16 * 2, dtype=torch.int32, device=dev)
             for ks in (2, 3, 4):
                 def h():
                     it[0] += 1
@@ -206,8 +206,8 @@ def bench_gemv13():
             us = timeit(f, iters=40)
             print(f"gemv13 M{M} {name:8s} N{N} K{K} epi{epi}: {us:7.1f} us  {2 * N * K / us / 1e3:7.1f} GB/s", flush=True)
             if epi == 2:
-                scratch = torch.zeros(4 * (N // 16) * 256, device=dev)
-                counters = torch.zeros(N // 16, dtype=torch.int32, device=dev)
+                scratch = torch.zeros(4 * (N // 16) * 2 * 256, device=dev)
+                counters = torch.zeros(N // 16 * 2, dtype=torch.int32, device=dev)
                 for ks in (2, 3, 4):
                     def h():
                         it[0] += 1

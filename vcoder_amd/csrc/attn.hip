@@ -398,8 +398,12 @@ void launch_attention_decode(const AttnDecodeArgs& a, hipStream_t s) {
 // One 512-thread workgroup per (b,h).  K rows and V^T rows are streamed once from HBM with many independent
 // 16-byte loads in flight per wave (4 keys x 4 per wave in the score pass; 16 d-rows per wave in the PV pass).
 // =============================================================================================
-template <int HD>
-__global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeFusedArgs p) {
+// HALF: the V^T stream of a 64-key block is taken in two halves of HD/2 rows with one half always in flight while the other
+// accumulates — half the registers of the two-full-sets form (212 -> <= 128 VGPRs at HD = 128), so TWO workgroups are
+// resident per CU and one's RoPE/append, softmax and reduction phases (HBM idle for that workgroup) hide behind the other's
+// streaming.  Same loads, same accumulation order per output element.
+template <int HD, bool HALF>
+__global__ __launch_bounds__(512, HALF ? 4 : 2) void attention_decode_fused_kernel(AttnDecodeFusedArgs p) {
     constexpr int LPK = HD / 8;           // lanes per key
     constexpr int KPW = 64 / LPK;         // keys per wave-instruction
     constexpr int UK = 8;                 // independent key loads in flight per lane in the score pass
@@ -460,10 +464,25 @@ __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeF
     // LDS-only softmax below
     const int dr = lane >> 3, kc = lane & 7;
     const int ctx64 = (ctx + 63) & ~63;
-    u32x4 v0[NR];
-    if (wave * 64 < ctx64) {
+    constexpr int NV = HALF ? NR / 2 : NR;  // row groups per register set
+    u32x4 v0[NV], v1[NV];
+    // address = wave-uniform row-group base (scalar registers) + ONE 32-bit per-lane offset shared by all the loads of a
+    // set: 64-bit per-row pointers kept live across the loop are what spilled the half-set form
+    const uint32_t v_lane_off = ((uint32_t)dr * (uint32_t)p.kv_stride + (uint32_t)kc * 8u) * 2u;
+    // live == false (past the last block; wave-uniform): every lane re-reads one cached 16-byte word instead — a branch
+    // around the loads makes the compiler rotate the loop and spill
+    auto load_v = [&](u32x4 (&v)[NV], int kb, int h, bool live = true) {  // h: which half of the d rows (HALF) — 0 otherwise
+        const uint32_t loff = live ? v_lane_off : 0u;
 #pragma unroll
-        for (int i = 0; i < NR; ++i) v0[i] = ld16_stream(vbase + (size_t)(i * 8 + dr) * p.kv_stride + wave * 64 + kc * 8);
+        for (int i = 0; i < NV; ++i) {
+            const char* ub = live ? reinterpret_cast<const char*>(vbase) + ((size_t)((h * NV + i) * 8) * p.kv_stride + kb) * 2
+                                  : reinterpret_cast<const char*>(p.rope_cos);
+            v[i] = ld16_stream(ub + loff);
+        }
+    };
+    if (wave * 64 < ctx64) {
+        load_v(v0, wave * 64, 0);
+        if constexpr (HALF) load_v(v1, wave * 64, 1);
     }
     __syncthreads();
     // ---- phase 2: softmax over sc[0..ctx_pad)
@@ -493,28 +512,41 @@ __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeF
     float acc[NR];
 #pragma unroll
     for (int i = 0; i < NR; ++i) acc[i] = 0.f;
-    auto pv = [&](const u32x4 (&v)[NR], int kb) {
+    auto pv = [&](const u32x4 (&v)[NV], int kb, int h) {
         const f32x4 p0 = ld16f(&sc[kb + kc * 8]), p1 = ld16f(&sc[kb + kc * 8 + 4]);
 #pragma unroll
-        for (int i = 0; i < NR; ++i)
-            acc[i] += p0[0] * bf2f_lo(v[i][0]) + p0[1] * bf2f_hi(v[i][0]) + p0[2] * bf2f_lo(v[i][1]) +
-                      p0[3] * bf2f_hi(v[i][1]) + p1[0] * bf2f_lo(v[i][2]) + p1[1] * bf2f_hi(v[i][2]) +
-                      p1[2] * bf2f_lo(v[i][3]) + p1[3] * bf2f_hi(v[i][3]);
+        for (int i = 0; i < NV; ++i)
+            acc[h * NV + i] += p0[0] * bf2f_lo(v[i][0]) + p0[1] * bf2f_hi(v[i][0]) + p0[2] * bf2f_lo(v[i][1]) +
+                               p0[3] * bf2f_hi(v[i][1]) + p1[0] * bf2f_lo(v[i][2]) + p1[1] * bf2f_hi(v[i][2]) +
+                               p1[2] * bf2f_lo(v[i][3]) + p1[3] * bf2f_hi(v[i][3]);
     };
-    // software-pipelined over 64-key blocks with two register sets: the next block's V^T loads are in flight while
-    // this one accumulates
-    auto load_v = [&](u32x4 (&v)[NR], int kb) {
-#pragma unroll
-        for (int i = 0; i < NR; ++i) v[i] = ld16_stream(vbase + (size_t)(i * 8 + dr) * p.kv_stride + kb + kc * 8);
-    };
-    u32x4 v1[NR];
-    for (int kb = wave * 64; kb < ctx64; kb += 2 * 8 * 64) {
-        const int kb1 = kb + 8 * 64, kb2 = kb + 2 * 8 * 64;
-        if (kb1 < ctx64) load_v(v1, kb1);
-        pv(v0, kb);
-        if (kb1 < ctx64) {
-            if (kb2 < ctx64) load_v(v0, kb2);
-            pv(v1, kb1);
+    if constexpr (HALF) {
+        // v0 = rows [0, HD/2), v1 = rows [HD/2, HD) of the current block; each set is re-requested for the next block as soon
+        // as it has been consumed, so one half is always in flight
+        // (the scheduling fences keep the compiler from hoisting a set's next loads above the arithmetic that still reads
+        // it — that needs a third set of registers and spilled)
+        for (int kb = wave * 64; kb < ctx64; kb += 8 * 64) {
+            const int nxt = kb + 8 * 64;
+            pv(v0, kb, 0);
+            sched_fence();
+            load_v(v0, nxt, 0, nxt < ctx64);
+            sched_fence();
+            pv(v1, kb, 1);
+            sched_fence();
+            load_v(v1, nxt, 1, nxt < ctx64);
+            sched_fence();
+        }
+    } else {
+        // software-pipelined over 64-key blocks with two register sets: the next block's V^T loads are in flight while
+        // this one accumulates
+        for (int kb = wave * 64; kb < ctx64; kb += 2 * 8 * 64) {
+            const int kb1 = kb + 8 * 64, kb2 = kb + 2 * 8 * 64;
+            if (kb1 < ctx64) load_v(v1, kb1, 0);
+            pv(v0, kb, 0);
+            if (kb1 < ctx64) {
+                if (kb2 < ctx64) load_v(v0, kb2, 0);
+                pv(v1, kb1, 0);
+            }
         }
     }
 #pragma unroll
@@ -667,9 +699,14 @@ void launch_attention_decode_fused(const AttnDecodeFusedArgs& a, hipStream_t s) 
     // online-softmax form (38.9 us: 2-3 serial score -> rescale -> PV chains per wave), which is used for longer
     // contexts and kept selectable with VC_DATTN_VARIANT=1
     static const int variant = getenv("VC_DATTN_VARIANT") ? atoi(getenv("VC_DATTN_VARIANT")) : 0;
-    if (variant == 0 && a.kv_stride <= DEC_MAX_CTX) {
-        if (a.hd == 128) VC_LAUNCH((attention_decode_fused_kernel<128>), grid, block, 0, s, a);
-        else VC_LAUNCH((attention_decode_fused_kernel<64>), grid, block, 0, s, a);
+    if ((variant == 0 || variant == 2) && a.kv_stride <= DEC_MAX_CTX) {
+        // 0 (default): V^T in two half-sets, two workgroups per CU; 2: two full register sets, one workgroup per CU
+        if (a.hd == 128) {
+            if (variant == 0) VC_LAUNCH((attention_decode_fused_kernel<128, true>), grid, block, 0, s, a);
+            else VC_LAUNCH((attention_decode_fused_kernel<128, false>), grid, block, 0, s, a);
+        } else {
+            VC_LAUNCH((attention_decode_fused_kernel<64, false>), grid, block, 0, s, a);   // 126 VGPRs already
+        }
         return;
     }
     if (a.hd == 128) VC_LAUNCH((attention_decode_flash_kernel<128>), grid, block, 0, s, a);

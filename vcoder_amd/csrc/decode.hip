@@ -188,22 +188,26 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
 // ever reads LDS bytes that it DMA'd itself, so its own vmcnt wait is the only ordering needed (no barrier in the loop).
 // ~40 VGPRs per wave: occupancy is set by the ring size alone.  A pure stream of this shape measures 5.8-6.1 TB/s at the
 // qkv / gate-up launch sizes (tools/experiments/corun.hip) against 5.0-5.3 for the register-staged loop above.
-// MG = token-slot groups of 16 rows per weight pass (1: M <= 16; 2: M <= 32 — the decode pool's rows): every weight block
-// read from LDS feeds MG MFMAs against MG activation fragments.  The assignment of k-tiles to waves and K-slices does
-// not depend on MG (nor on NT / R), so a row's sum is formed in the same order whichever variant serves it: the pool's
-// 32-row steps give every row bit-for-bit what a 16-row step gives it.
-template <int WAVES, int NT, int R, int EPI, bool FP8, int MG = 1>
+// XP = 8-row pieces of the activation operand per ring slot (1..4: M <= 8 / 16 / 24 / 32); MG = (XP + 1) / 2 MFMA row groups
+// of 16 token rows, each weight block read from LDS feeding MG MFMAs.  The assignment of k-tiles to waves and K-slices does
+// not depend on XP (nor on NT / R), so a row's sum is formed in the same order whichever variant serves it: the decode
+// pool's 32-row steps give every row bit-for-bit what an 8-row step gives it.
+//
+// Activation operand: every workgroup re-reads X [M, K] from L2 — M / (16 NT) bytes of it per weight byte, more than the
+// weight stream itself from M = 24 on — so it is fetched in FULL 128-byte lines: one DMA instruction = 8 rows x 128 B
+// (64 k of bf16 = the k-tile pair of a bf16 slot / the 64-wide super-tile of a W8A16 slot), half the line requests of a
+// fragment-shaped gather (16 rows x 64 B per instruction).  The LDS image of a piece is lane-linear [8 rows][8 chunks of
+// 16 B]; the chunk a lane fetches is XOR-swizzled by (row >> 1) & 7 on the SOURCE side (the DMA writes linearly), so the
+// 16 lanes of a ds_read_b128 group — 16 rows, one chunk column — hit 16 distinct 16-byte bank slots.
+template <int WAVES, int NT, int R, int EPI, bool FP8, int XP = 2>
 __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
-    constexpr int KT = FP8 ? 64 : 32;
+    constexpr int MG = (XP + 1) / 2;
     constexpr int KSH = FP8 ? 6 : 5;
-    constexpr int GK = KT / 4;
-    constexpr int XS = (FP8 ? 2 : 1) * MG;   // 1-KiB activation pieces per k-tile
-    constexpr int XG = FP8 ? 2 : 1;          // ... per row group
-    // k-tiles per ring slot: bf16 takes them in PAIRS so that the two activation gathers of a slot touch the two 64-byte
-    // halves of the same 128-byte lines back to back (the second is an L1 hit: half the L2 requests of the X operand);
-    // a W8A16 k-tile already spans whole lines
+    // k-tiles per ring slot: a slot always spans 64 k = one 128-byte line of every activation row: a PAIR of 32-wide bf16
+    // k-tiles, or one 64-wide W8A16 super-tile
     constexpr int KPI = FP8 ? 1 : 2;
-    constexpr int OPS = KPI * (NT + XS);     // DMA instructions per slot
+    constexpr int WB = KPI * NT;             // 1-KiB weight blocks per slot
+    constexpr int OPS = WB + XP;             // DMA instructions per slot
     constexpr int SLOT = OPS * 1024;
     static_assert(WAVES * R * SLOT >= WAVES * NT * MG * 1024, "the ring is re-used for the cross-wave reduction");
     static_assert(WAVES >= NT * MG, "one finishing wave per (tile, row group)");
@@ -226,25 +230,37 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
         wsrc[t] = reinterpret_cast<const char*>(p.Wp) + ((size_t)min(nt0 + t, ntiles - 1) * nkt * 64 + lane) * 16;
-    const char* xsrc[MG];
+    // activation pieces: lane = (row r of the piece, slot s of the line); it fetches chunk `xc` of its row
+    const int xr = lane >> 3, xs = lane & 7;
+    const char* xsrc[XP];
+    int xc[XP];
 #pragma unroll
-    for (int q = 0; q < MG; ++q)
-        xsrc[q] = reinterpret_cast<const char*>(p.X + (size_t)(mvalid[q] ? m + 16 * q : 0) * p.K + g * GK);
+    for (int x = 0; x < XP; ++x) {
+        const int row = 8 * x + xr;
+        const int pc = xs ^ ((row >> 1) & 7);                               // physical chunk held by slot s of this row
+        xc[x] = FP8 ? (((pc & 3) << 1) | (pc >> 2)) : pc;                   // W8A16: physical p = logical (c >> 1) | ((c & 1) << 2)
+        xsrc[x] = reinterpret_cast<const char*>(p.X + (size_t)(row < p.M ? row : 0) * p.K);
+    }
+    const int kline_last = (p.K * 2 + 127) / 128 - 1;                        // last (possibly half) 128-byte line of a row
+    const bool half_line = (p.K * 2) % 128 != 0;                             // bf16, odd k-tile count: 64 valid bytes in it
     auto issue = [&](int i, int slot) {
         char* dst = my + slot * SLOT;
+        const int is = it0 + wave + i * WAVES;                               // slot index along K = line index of X
 #pragma unroll
         for (int kk = 0; kk < KPI; ++kk) {
-            const size_t kt = (size_t)min((it0 + wave + i * WAVES) * KPI + kk, nkt - 1);  // an odd tail re-reads the last tile
+            const size_t kt = (size_t)min(is * KPI + kk, nkt - 1);           // an odd tail re-reads the last tile
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                if (p.w_cached) glds16(wsrc[t] + kt * 1024, dst + (kk * (NT + XS) + t) * 1024);
-                else glds16_nt(wsrc[t] + kt * 1024, dst + (kk * (NT + XS) + t) * 1024);
+                if (p.w_cached) glds16(wsrc[t] + kt * 1024, dst + (kk * NT + t) * 1024);
+                else glds16_nt(wsrc[t] + kt * 1024, dst + (kk * NT + t) * 1024);
             }
+        }
 #pragma unroll
-            for (int q = 0; q < MG; ++q) {
-                glds16(xsrc[q] + kt * (KT * 2), dst + (kk * (NT + XS) + NT + q * XG) * 1024);
-                if constexpr (FP8) glds16(xsrc[q] + kt * (KT * 2) + 16, dst + (kk * (NT + XS) + NT + q * XG + 1) * 1024);
-            }
+        for (int x = 0; x < XP; ++x) {
+            // the half line at the end of an odd-k-tile row holds only chunks 0..3: the other lanes re-read a valid chunk
+            // (their values meet zeroed weights' partner: the consumer zeroes the activation fragment of that k-tile)
+            const int c = (half_line && is >= kline_last) ? (xc[x] & 3) : xc[x];
+            glds16(xsrc[x] + (size_t)min(is, kline_last) * 128 + c * 16, dst + (WB + x) * 1024);
         }
     };
     f32x4 acc[NT][MG];
@@ -252,21 +268,33 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int q = 0; q < MG; ++q) acc[t][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // LDS offset of logical chunk c of row 16q + m inside the slot's activation area
+    auto xoff = [&](int q, int c) {
+        const int row = 16 * q + m;
+        const int pc = FP8 ? ((c >> 1) | ((c & 1) << 2)) : c;
+        return (WB + (row >> 3)) * 1024 + ((row & 7) * 8 + (pc ^ ((row >> 1) & 7))) * 16;
+    };
     auto consume = [&](int i, int slot) {
-        const char* s = my + slot * SLOT + lane * 16;
+        const char* s = my + slot * SLOT;
+        const char* sl = s + lane * 16;
+        // the activation pieces are read across lanes (a lane reads bytes other lanes of its wave DMA'd): the wave's counted
+        // vmcnt wait covers them on the hardware (the wave issues as one); the emulator's lane fibers need the rendezvous
+        wave_lds_fence();
 #pragma unroll
         for (int kk = 0; kk < KPI; ++kk) {
-            const char* sk = s + kk * (NT + XS) * 1024;
             u32x4 w[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) w[t] = ld16(sk + t * 1024);
+            for (int t = 0; t < NT; ++t) w[t] = ld16(sl + (kk * NT + t) * 1024);
             const bool tail = KPI > 1 && (it0 + wave + i * WAVES) * KPI + kk >= nkt;
             u32x4 x0[MG], x1[MG];
 #pragma unroll
             for (int q = 0; q < MG; ++q) {
-                x0[q] = ld16(sk + (NT + q * XG) * 1024);
-                x1[q] = u32x4{0u, 0u, 0u, 0u};
-                if constexpr (FP8) x1[q] = ld16(sk + (NT + q * XG + 1) * 1024);
+                const bool have = 2 * q + (m >> 3) < XP;                    // the piece holding this row was fetched
+                x0[q] = x1[q] = u32x4{0u, 0u, 0u, 0u};
+                if (have) {
+                    x0[q] = ld16(s + xoff(q, FP8 ? 2 * g : kk * 4 + g));
+                    if constexpr (FP8) x1[q] = ld16(s + xoff(q, 2 * g + 1));
+                }
                 if (!mvalid[q] || tail) x0[q] = x1[q] = u32x4{0u, 0u, 0u, 0u};
             }
 #pragma unroll
@@ -286,6 +314,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
             }
         }
         wait_lgkmcnt<0>();  // the slot's fragment reads have retired before it is re-armed
+        wave_lds_fence();
     };
     const int cnt = max(0, (it1 - it0 - wave + WAVES - 1) / WAVES);  // slots of this wave (wave-uniform)
     const int primed = min(cnt, R);
@@ -364,9 +393,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
         // (sc1) stores, drained, then a relaxed agent-scope arrival count; the finisher reads with cache-bypassing (sc1)
         // loads: the "sc1 stores and loads on both sides" form of the CDNA hand-off rules (cdna_hip_programming.md §6 G16 /
         // MI355X_MICROARCH.md "valid forms") — an agent-scope fence here writes back / invalidates the XCD's whole L2 and
-        // measured 4-8x slower launches
-        const size_t unit = (size_t)nt * MG + fq;
-        float* mine = p.sk_scratch + (((size_t)ks * ntiles * MG + unit) * 64 + lane) * 4;
+        // measured 4-8x slower launches.  The scratch is laid out for two row groups whatever MG is.
+        const size_t unit = (size_t)nt * 2 + fq;
+        float* mine = p.sk_scratch + (((size_t)ks * ntiles * 2 + unit) * 64 + lane) * 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) st_agent(mine + e, v[e]);
         wait_vmcnt<0>();  // the write-through stores have been acknowledged before the arrival is counted
@@ -376,7 +405,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
         if (arrived != (unsigned)(KS - 1)) return;
         v = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int k = 0; k < KS; ++k) {
-            const float* q = p.sk_scratch + (((size_t)k * ntiles * MG + unit) * 64 + lane) * 4;
+            const float* q = p.sk_scratch + (((size_t)k * ntiles * 2 + unit) * 64 + lane) * 4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += ld_agent(q + e);
         }
@@ -404,19 +433,19 @@ static void launch_gemv_w(const GemvArgs& a, int epi, hipStream_t s) {
     }
 }
 
-template <int WAVES, int NT, int R, bool FP8, int MG = 1>
-static void launch_gemv_dma(const GemvArgs& a, int epi, hipStream_t s) {
+template <int WAVES, int NT, int R, bool FP8, int XP>
+static void launch_gemv_dma_x(const GemvArgs& a, int epi, hipStream_t s) {
     const dim3 grid(((a.N / 16 + NT - 1) / NT) * (a.ksplit > 1 ? a.ksplit : 1)), block(WAVES * 64);
-    constexpr size_t shmem = (size_t)WAVES * R * (FP8 ? 1 : 2) * (NT + (FP8 ? 2 : 1) * MG) * 1024;
+    constexpr size_t shmem = (size_t)WAVES * R * ((FP8 ? 1 : 2) * NT + XP) * 1024;
     static_assert(shmem <= 160 * 1024, "ring exceeds the LDS of a CU");
 #define VC_GEMV_DMA(E)                                                                                                  \
     do {                                                                                                                \
         static bool once = false;                                                                                       \
         if (!once) {                                                                                                    \
-            allow_big_lds(gemv_dma_kernel<WAVES, NT, R, E, FP8, MG>, shmem);                                            \
+            allow_big_lds(gemv_dma_kernel<WAVES, NT, R, E, FP8, XP>, shmem);                                            \
             once = true;                                                                                                \
         }                                                                                                               \
-        VC_LAUNCH((gemv_dma_kernel<WAVES, NT, R, E, FP8, MG>), grid, block, shmem, s, a);                               \
+        VC_LAUNCH((gemv_dma_kernel<WAVES, NT, R, E, FP8, XP>), grid, block, shmem, s, a);                               \
     } while (0)
     switch (epi) {
         case GEMV_BF16: VC_GEMV_DMA(GEMV_BF16); break;
@@ -427,6 +456,19 @@ static void launch_gemv_dma(const GemvArgs& a, int epi, hipStream_t s) {
 #undef VC_GEMV_DMA
 }
 
+// M <= 16: one MFMA row group, one (M <= 8) or two 8-row activation pieces per slot
+template <int WAVES, int NT, int R, bool FP8>
+static void launch_gemv_dma(const GemvArgs& a, int epi, hipStream_t s) {
+    if (a.M <= 8) launch_gemv_dma_x<WAVES, NT, R, FP8, 1>(a, epi, s);
+    else launch_gemv_dma_x<WAVES, NT, R, FP8, 2>(a, epi, s);
+}
+// M in 17..32: two row groups, three or four pieces
+template <int WAVES, int NT, int R, bool FP8>
+static void launch_gemv_dma2(const GemvArgs& a, int epi, hipStream_t s) {
+    if (a.M <= 24) launch_gemv_dma_x<WAVES, NT, R, FP8, 3>(a, epi, s);
+    else launch_gemv_dma_x<WAVES, NT, R, FP8, 4>(a, epi, s);
+}
+
 // M in 17..32 (the decode pool): two row groups per weight pass.  The K partition (waves per workgroup, K-slices) of every
 // tile-count class equals the 16-row launcher's below, so a row's result does not depend on which variant served it; only
 // the tiles per workgroup and the ring depth are re-balanced for the larger slots (LDS: all workgroups resident).
@@ -435,21 +477,21 @@ static void launch_gemv_m32(const GemvArgs& a, int epilogue, hipStream_t s) {
     const int tiles = a.N / 16;
     static const int ks_env = getenv("VC_GEMV_KS") ? atoi(getenv("VC_GEMV_KS")) : -1;
     // VC_GEMV2_GEOM: tuning knob for the 513..768-tile class (7b qkv): 0 = 4 waves x 1 tile, 2-slot ring (3 workgroups/CU),
-    // 1 = 4 waves x 2 tiles, 2-slot ring (2/CU, the pair shares the activation fragments)
+    // 1 = 4 waves x 2 tiles, 2-slot ring (2/CU, the pair shares the activation pieces; measured 28.3 vs 33.9 us at M = 24)
     static const int geom = getenv("VC_GEMV2_GEOM") ? atoi(getenv("VC_GEMV2_GEOM")) : 1;
     if (a.ksplit > 1 || (a.sk_scratch && a.sk_counters && a.ksplit == 0 && tiles > 256 && tiles <= 512)) {
         GemvArgs b = a;
         if (b.ksplit <= 1) b.ksplit = ks_env >= 0 ? ks_env : 3;
         if (b.ksplit > 1) {
-            if (a.ksplit > 1 && tiles <= 256) launch_gemv_dma<4, 1, 2, FP8, 2>(b, epilogue, s);
-            else launch_gemv_dma<4, 2, 2, FP8, 2>(b, epilogue, s);
+            if (a.ksplit > 1 && tiles <= 256) launch_gemv_dma2<4, 1, 2, FP8>(b, epilogue, s);
+            else launch_gemv_dma2<4, 2, 2, FP8>(b, epilogue, s);
             return;
         }
     }
-    if (tiles <= 256) launch_gemv_dma<8, 1, FP8 ? 4 : 3, FP8, 2>(a, epilogue, s);
-    else if (tiles <= 512) launch_gemv_dma<4, 1, 3, FP8, 2>(a, epilogue, s);
-    else if (tiles <= 768 && !FP8 && geom == 0) launch_gemv_dma<4, 1, 2, FP8, 2>(a, epilogue, s);
-    else launch_gemv_dma<4, 2, 2, FP8, 2>(a, epilogue, s);
+    if (tiles <= 256) launch_gemv_dma2<8, 1, FP8 ? 4 : 3, FP8>(a, epilogue, s);
+    else if (tiles <= 512) launch_gemv_dma2<4, 1, 3, FP8>(a, epilogue, s);
+    else if (tiles <= 768 && !FP8 && geom == 0) launch_gemv_dma2<4, 1, 2, FP8>(a, epilogue, s);
+    else launch_gemv_dma2<4, 2, 2, FP8>(a, epilogue, s);
 }
 
 template <bool FP8>

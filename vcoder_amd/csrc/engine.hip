@@ -830,10 +830,9 @@ void ensure_llm(vc_model* m, int B, int S_total) {
     m->h_dec.ensure((size_t)Bp * F * 2, true);
     m->next_tok.ensure(Bp * 4, true);
     m->rows.ensure((size_t)Bp * RS_STRIDE * 4, true);
-    m->dsum.ensure(Bp * 4, true);
     m->ssq.ensure((size_t)Bp * m->npart * 4, true);
-    m->sk_scratch.ensure((size_t)4 * 512 * 256 * 4);
-    m->sk_counters.ensure(512 * 4, true);
+    m->sk_scratch.ensure((size_t)4 * 512 * 2 * 256 * 4);   // [ksplit <= 4][tiles <= 512][2 row groups][256]
+    m->sk_counters.ensure(512 * 2 * 4, true);
     const void* after[] = {m->x_dec.p, m->xg_dec.p, m->qkv_dec.p, m->attn_dec.p, m->h_dec.p, m->next_tok.p, m->rows.p, m->ssq.p,
                            m->logits.p};
     for (size_t i = 0; i < sizeof(before) / sizeof(before[0]); ++i)
@@ -1093,14 +1092,16 @@ void do_prefill(vc_model* m, const int64_t* ids, int B, int T, const float* img,
     std::vector<bool> dz;
     if (depth) {  // is_depth_zero = [mean(d) == 0 for d in depth_images]  (vcoder_ds_llava_arch.py:161) — one host sync, as the reference
         const int nd = pix.n[VC_MOD_DEPTH];
-        m->dsum.ensure(rup(nd, 16) * 4);
+        m->dsum.ensure((size_t)rup(nd, 16) * ROW_SUM_PARTS * 4);
         int di = 0;
         for (int k = 0; k < 2; ++k) di += pix.n[k];
         const size_t img_elems = (size_t)3 * c.vit_image * c.vit_image;
         launch_row_sum(m->v_pixels.as<float>() + (size_t)di * img_elems, img_elems, nd, m->dsum.as<float>(), m->st);
-        std::vector<float> hs(nd);
-        HIPCHK(hipMemcpyAsync(hs.data(), m->dsum.p, nd * 4, hipMemcpyDeviceToHost, m->st));
+        std::vector<float> hp((size_t)nd * ROW_SUM_PARTS), hs(nd, 0.f);
+        HIPCHK(hipMemcpyAsync(hp.data(), m->dsum.p, hp.size() * 4, hipMemcpyDeviceToHost, m->st));
         HIPCHK(hipStreamSynchronize(m->st));
+        for (int i = 0; i < nd; ++i)
+            for (int q = 0; q < ROW_SUM_PARTS; ++q) hs[i] += hp[(size_t)i * ROW_SUM_PARTS + q];
         const std::vector<int>& first = m->img_first[VC_MOD_DEPTH];
         for (int b = 0; b < B; ++b) {
             const int i0 = first.empty() ? b : first[b], i1 = first.empty() ? b + 1 : first[b + 1];
@@ -1206,16 +1207,28 @@ void arm_session_rows(vc_model* m, const GenParams& g, const int* tail) {
         HIPCHK(hipSetDevice((ctxp)->device)); \
         t_stream = (ctxp)->stream;             \
     } while (0)
+// The HIP runtime keeps a per-thread "last error" that a LATER caller of hipGetLastError() — torch checks it after its own
+// launches — would inherit from a query of ours that legitimately returned non-success (hipEventQuery: not ready, ...).
+// Every entry point leaves it clean; VC_DEBUG_HIP=1 reports what it found.
+#define CLEAR_HIP_LAST_ERROR(where)                                                                  \
+    do {                                                                                             \
+        hipError_t le_ = hipGetLastError();                                                          \
+        if (le_ != hipSuccess && getenv("VC_DEBUG_HIP"))                                             \
+            fprintf(stderr, "[vcoder_amd] %s left HIP last-error %d (%s)\n", where, (int)le_, hipGetErrorString(le_)); \
+    } while (0)
 #define GUARD_END(ctxp)                                   \
     }                                                     \
     catch (const Fail& f) {                               \
         if (ctxp) (ctxp)->err = f.msg;                    \
+        CLEAR_HIP_LAST_ERROR(__func__);                   \
         return f.code;                                    \
     }                                                     \
     catch (const std::exception& e) {                     \
         if (ctxp) (ctxp)->err = e.what();                 \
+        CLEAR_HIP_LAST_ERROR(__func__);                   \
         return VC_ERR_INVALID;                            \
     }                                                     \
+    CLEAR_HIP_LAST_ERROR(__func__);                       \
     return VC_OK;
 
 VC_API int vc_init(int device_id, vc_ctx** out) {
@@ -1359,6 +1372,7 @@ VC_API void vc_model_destroy(vc_model* m) {
         m->pool = nullptr;
     }
     if (m->graph) (void)hipGraphExecDestroy(m->graph);
+    m->graph = nullptr;
     if (m->owns_weights)
         for (void* p : m->owned) (void)hipFree(p);
     for (Buf* b : {&m->stage, &m->stage2, &m->v_pixels, &m->v_cols, &m->v_patches, &m->v_x, &m->v_xn, &m->v_qkv, &m->v_q,
@@ -1373,6 +1387,7 @@ VC_API void vc_model_destroy(vc_model* m) {
     for (auto& e : m->ev)
         if (e) (void)hipEventDestroy(e);
     delete m;
+    CLEAR_HIP_LAST_ERROR("vc_model_destroy");
 }
 
 VC_API int vc_model_load_tensor(vc_model* m, const char* hf_key, const void* host_ptr, int dtype, const int64_t* shape,
@@ -1752,7 +1767,7 @@ struct vc_pool {
     hipStream_t st = nullptr;
     int R = VC_POOL_ROWS, capS = 0, out_stride = 0;
     Buf kc, vtc, rows, x_dec, xg_dec, qkv_dec, attn_dec, h_dec, logits, next_tok, out_ids, ssq, sk_scratch, sk_counters;
-    hipGraphExec_t graph[2] = {nullptr, nullptr};  // one decode step over rows [0,16) / [0,32)
+    hipGraphExec_t graph[VC_POOL_ROWS / 8] = {};    // one decode step over rows [0, 8 * (i + 1))
     std::mutex mu;
     std::condition_variable cv_driver, cv_rows;
     std::deque<PoolRequest*> pending;
@@ -1848,7 +1863,7 @@ void pool_driver(vc_pool* p) {
             if (p->active.empty()) continue;
             int top = 0;
             for (PoolRequest* rq : p->active) top = std::max(top, rq->row0 + rq->B);
-            const int gi = top > 16 ? 1 : 0;
+            const int gi = (top + 7) / 8 - 1;  // the step covers rows [0, top) rounded up to 8: free rows above cost nothing
             // bounded run-ahead: at most two steps queued beyond the one executing (a joining request waits that long)
             const unsigned long n = p->steps_run;
             if (n >= 2) {
@@ -1955,8 +1970,7 @@ vc_pool* pool_for(vc_model* m, int need_S, int need_out) {
     t_stream = m->st;
     for (auto& e : p->step_ev) HIPCHK(hipEventCreate(&e));
     const LoopView v = pool_view(p);
-    p->graph[0] = capture_step(root, v, 16);
-    p->graph[1] = capture_step(root, v, R);
+    for (int i = 0; i < R / 8; ++i) p->graph[i] = capture_step(root, v, 8 * (i + 1));
     p->driver = std::thread(pool_driver, p);
     root->pool = p;
     return p;
@@ -2374,11 +2388,23 @@ VC_API int vc_profile_decode_gemv(vc_model* m, int B, int reps, int* launches, d
     if (!m) return VC_ERR_INVALID;
     GUARD_BEGIN
     USE_DEVICE(m->ctx);
-    REQUIRE(m->finalized && B >= 1 && B <= 16 && reps >= 1, VC_ERR_INVALID, "bad profile arguments");
+    REQUIRE(m->finalized && B >= 1 && B <= VC_POOL_ROWS && reps >= 1, VC_ERR_INVALID, "bad profile arguments");
     const vc_model_cfg& c = m->c;
     const int D = c.hidden, F = c.ffn;
-    ensure_llm(m, B, 64);
-    const LoopView v = session_view(m);
+    LoopView v;
+    if (B <= VC_MAX_ROWS) {
+        ensure_llm(m, B, 64);
+        v = session_view(m);
+    } else {  // 17..32 rows: the decode pool's buffers (it must be idle), launches on this session's stream
+        vc_pool* p = pool_for(m, 64, 1);
+        {
+            std::lock_guard<std::mutex> lk(p->mu);
+            REQUIRE(p->users == 0 && p->active.empty() && p->pending.empty(), VC_ERR_STATE, "the decode pool is busy");
+        }
+        HIPCHK(hipStreamSynchronize(p->st));
+        v = pool_view(p);
+        v.st = m->st;
+    }
     auto sweep = [&]() { decode_linears(m, v, B, [](int) {}); };
     sweep();  // warm
     HIPCHK(hipEventRecord(m->ev[0], m->st));
@@ -2393,7 +2419,7 @@ VC_API int vc_profile_decode_gemv(vc_model* m, int B, int reps, int* launches, d
     if (launches) *launches = n;
     if (avg_us) *avg_us = (double)ms * 1e3 / ((double)reps * n);
     if (avg_bytes) *avg_bytes = bytes / n;
-    HIPCHK(hipMemsetAsync(m->x_dec.p, 0, m->x_dec.cap, m->st));
+    HIPCHK(hipMemsetAsync(v.x_dec, 0, (size_t)rup(B, 16) * D * 4, m->st));
     HIPCHK(hipStreamSynchronize(m->st));
     GUARD_END(m->ctx)
 }

@@ -72,8 +72,8 @@ struct GemvArgs {
     // deterministic split-K for matrices with few output tiles (o_proj, down): `ksplit` workgroups share one tile,
     // each writes its fp32 partial to sk_scratch[ks][tile][64 lanes][4]; the LAST to arrive (sk_counters[tile]) sums
     // the partials in k order — the result does not depend on arrival order — runs the epilogue and re-arms the counter
-    float* sk_scratch;       // [ksplit][N/16][row groups][256] or nullptr (row groups = 1 for M <= 16, else 2)
-    unsigned* sk_counters;   // [N/16][row groups], zero between launches
+    float* sk_scratch;       // [ksplit][N/16][2 row groups][256] or nullptr
+    unsigned* sk_counters;   // [N/16][2 row groups], zero between launches
     int ksplit;              // 0/1 = off (launcher decides when the two buffers are given)
     int w_cached;            // 1: stream the weights with the default cache policy instead of non-temporal (VC_GEMV_WCACHED)
 };
@@ -292,6 +292,7 @@ void launch_crop_normalize(const uint8_t* in, int in_h, int in_w, int top, int l
 // ---- misc ---------------------------------------------------------------------------------------
 void launch_synth_bf16(bf16_t* out, size_t n, uint32_t tseed, float offset, float halfwidth, hipStream_t s);
 void launch_synth_f32(float* out, size_t n, uint32_t tseed, float offset, float halfwidth, hipStream_t s);
+constexpr int ROW_SUM_PARTS = 32;  // out: [rows][ROW_SUM_PARTS] partial sums
 void launch_row_sum(const float* x, size_t n_per_row, int rows, float* out, hipStream_t s);
 void launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
 void launch_bf16_to_f32(const bf16_t* in, float* out, size_t n, hipStream_t s);

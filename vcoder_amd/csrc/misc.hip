@@ -120,19 +120,23 @@ void launch_synth_f32(float* out, size_t n, uint32_t tseed, float offset, float 
               (float)(halfwidth / 8388608.0));
 }
 
-// per-row fp32 sum (is_depth_zero = mean(depth)==0, vcoder_ds_llava_arch.py:161)
+// per-row fp32 partial sums (is_depth_zero = mean(depth)==0, vcoder_ds_llava_arch.py:161): ROW_SUM_PARTS workgroups per
+// row, each a contiguous slice; the host adds the partials (only "== 0" matters, and zeros sum to zero in any order)
 __global__ __launch_bounds__(256) void row_sum_kernel(const float* x, size_t n_per_row, float* out) {
     __shared__ float red[4];
+    const int part = blockIdx.y;
+    const size_t per = (n_per_row + ROW_SUM_PARTS - 1) / ROW_SUM_PARTS;
+    const size_t i0 = (size_t)part * per, i1 = min(n_per_row, i0 + per);
     const float* r = x + (size_t)blockIdx.x * n_per_row;
     float s = 0.f;
-    for (size_t i = threadIdx.x; i < n_per_row; i += 256) s += r[i];
+    for (size_t i = i0 + threadIdx.x; i < i1; i += 256) s += r[i];
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) out[(size_t)blockIdx.x * ROW_SUM_PARTS + part] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 void launch_row_sum(const float* x, size_t n_per_row, int rows, float* out, hipStream_t s) {
-    VC_LAUNCH(row_sum_kernel, dim3(rows), dim3(256), 0, s, x, n_per_row, out);
+    VC_LAUNCH(row_sum_kernel, dim3(rows, ROW_SUM_PARTS), dim3(256), 0, s, x, n_per_row, out);
 }
 
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* in, bf16_t* out, size_t n) {
