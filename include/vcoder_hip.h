@@ -189,9 +189,12 @@ int vc_allgather_tokens(vc_comm* comm, const int32_t* local, int n, int32_t* glo
 void vc_comm_destroy(vc_comm* comm);
 
 /* ---- measurement hooks (bench.py) ---------------------------------------------------------------- */
-/* times `reps` sweeps of every decode GEMV launch of one step (4 per layer + lm_head) with HIP events on the
- * model's stream; returns launches per sweep, average microseconds per launch, algorithmic weight bytes per launch */
+/* times `reps` sweeps of every decode GEMV launch of one step (4 per layer + lm_head) over B <= 32 rows with HIP events on
+ * the model's stream; returns launches per sweep, average microseconds per launch, algorithmic weight bytes per launch */
 int vc_profile_decode_gemv(vc_model* m, int B, int reps, int* launches, double* avg_us, double* avg_bytes);
+/* the same for the decode attention launches of one step (one per layer) over B rows at context ~ctx: launches per sweep,
+ * average microseconds per launch, algorithmic KV bytes per launch (K and V rows of every key, bf16) */
+int vc_profile_decode_attention(vc_model* m, int B, int ctx, int reps, int* launches, double* avg_us, double* avg_bytes);
 /* wall-clock split of the last vc_generate_greedy in ms (HIP events): encode, prefill, decode */
 int vc_last_timings(vc_model* m, float* encode_ms, float* prefill_ms, float* decode_ms);
 

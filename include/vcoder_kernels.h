@@ -51,21 +51,25 @@ void vck_vit_embed_ln(const float* patches, const float* cls, const float* pos, 
                       int n_img, int T, int D, float eps, void* stream);
 /* feature_select (multimodal_encoder/clip_encoder.py:29-37) */
 void vck_select_rows_bf16(const float* x, uint16_t* y, int n_img, int T, int skip, int D, void* stream);
-/* head split + rotate_half RoPE + KV-cache write ([HF] llama :113-160,259-262) */
+/* head split + rotate_half RoPE ([HF] llama :113-160,259-262): qkv bf16 [B*T, 3*H*hd] -> Q [B,H,q_stride,hd],
+ * K [B,H,kv_stride,hd], V^T [B,H,hd,kv_stride] (the MFMA A operand of the flash kernel's P.V).  pos0_dev is unused. */
 void vck_qkv_split(const uint16_t* qkv, uint16_t* q, uint16_t* k, uint16_t* vt, int B, int T, int H, int hd, int q_stride,
                    int kv_stride, const int* pos0_dev, const float* rope_cos, const float* rope_sin, void* stream);
+/* the LLM prefill form: K and V rows into the key-major KV cache (kv_stride keys per (b,h)) — what the decode steps stream —
+ * and V^T into a per-call scratch of vt_stride columns for this layer's flash attention */
+void vck_qkv_split_kv(const uint16_t* qkv, uint16_t* q, uint16_t* k, uint16_t* v, uint16_t* vt, int B, int T, int H, int hd,
+                      int q_stride, int kv_stride, int vt_stride, const float* rope_cos, const float* rope_sin, void* stream);
 /* softmax(QK^T*scale [+causal]) V, fp32 softmax ([HF] clip :259-277; [HF] llama eager_attention_forward :191-214) */
 void vck_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, uint16_t* out, int B, int H, int T, int hd,
                    int q_stride, int kv_stride, int causal, float scale, void* stream);
-void vck_attention_decode(const uint16_t* q, const uint16_t* k, const uint16_t* vt, uint16_t* out, int B, int H, int hd,
-                          int kv_stride, const int* ctx_len_dev, float scale, void* stream);
-/* decode step, one launch per layer: RoPE of the new q/k + KV append + attention over the cache */
-void vck_attention_decode_fused(const uint16_t* qkv, uint16_t* k, uint16_t* vt, uint16_t* out, int B, int H, int hd,
+/* decode step, one launch per layer: RoPE of the new q/k + append of the K and V rows + attention over the cache.
+ * K and V are both key-major [B,H,kv_stride,hd] (kv_stride <= 4096: a row's scores sit in LDS). */
+void vck_attention_decode_fused(const uint16_t* qkv, uint16_t* k, uint16_t* v, uint16_t* out, int B, int H, int hd,
                                 int kv_stride, const int* pos_dev, const float* rope_cos, const float* rope_sin, float scale,
                                 void* stream);
 /* the same with one position per row (row b reads pos_rows[b * pos_stride]; rows with active_rows[b * pos_stride] == 0 are
  * skipped): rows of different requests — different prompt lengths and step counts — share one decode step */
-void vck_attention_decode_rows(const uint16_t* qkv, uint16_t* k, uint16_t* vt, uint16_t* out, int B, int H, int hd,
+void vck_attention_decode_rows(const uint16_t* qkv, uint16_t* k, uint16_t* v, uint16_t* out, int B, int H, int hd,
                                int kv_stride, const int* pos_rows, int pos_stride, const int* active_rows,
                                const float* rope_cos, const float* rope_sin, float scale, void* stream);
 /* embedding gather + feature splice (vcoder_ds_llava_arch.py:173-276,305) */

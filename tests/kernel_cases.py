@@ -388,24 +388,17 @@ def check_qkv_split(be, B, T, H, hd, rope):
         assert np.array_equal(gq[:, :, :T], rq) and np.array_equal(gk[:, :, :T], rk)
     assert np.array_equal(gv[:, :, :, :T], rv.transpose(0, 1, 3, 2))
     assert not gv[:, :, :, T:].any() and not gq[:, :, T:].any()
-
-
-def check_qkv_append(be, B, H, hd, pos):
-    rng = np.random.RandomState(7)
-    D = H * hd
-    S = 64 * ((pos + 64) // 64)
-    qkv = bf16_round(rng.randn(B, 3 * D))
-    q, k, vt = be.zeros((B, H, hd), "bf16"), be.zeros((B, H, S, hd), "bf16"), be.zeros((B, H, hd, S), "bf16")
-    cos, sin = rope_tables(S, hd)
-    _call(be, "vck_qkv_split", be.bf16(qkv), q, k, vt, B, 1, H, hd, 1, S, be.i32([pos]), be.f32(cos), be.f32(sin))
-    rq, rk, rv = _split_ref(qkv, B, 1, H, hd, True, pos0=pos)
-    assert np.abs(be.host_f32(q) - rq[:, :, 0]).max() <= 2 ** -7 * np.abs(rq).max()
-    gk, gv = be.host_f32(k), be.host_f32(vt)
-    assert np.abs(gk[:, :, pos] - rk[:, :, 0]).max() <= 2 ** -7 * np.abs(rk).max()
-    assert np.array_equal(gv[:, :, :, pos], rv[:, :, 0])
-    gk[:, :, pos] = 0
-    gv[:, :, :, pos] = 0
-    assert not gk.any() and not gv.any()
+    # the LLM prefill form: K and V rows into a cache of S_cap keys, V^T into a scratch of its own stride
+    S_cap = Ts + 64
+    k2, v2 = be.zeros((B, H, S_cap, hd), "bf16"), be.zeros((B, H, S_cap, hd), "bf16")
+    q2, vt2 = be.zeros((B, H, Ts, hd), "bf16"), be.zeros((B, H, hd, Ts), "bf16")
+    qd, cd, sd = be.bf16(qkv), (be.f32(cos) if rope else None), (be.f32(sin) if rope else None)
+    be.lib.vck_qkv_split_kv(be.ptr(qd), be.ptr(q2), be.ptr(k2), be.ptr(v2), be.ptr(vt2), B, T, H, hd, Ts, S_cap, Ts, be.ptr(cd),
+                            be.ptr(sd), None)
+    be.sync()
+    assert np.array_equal(be.host_f32(k2)[:, :, :T], gk[:, :, :T]) and np.array_equal(be.host_f32(q2), gq)
+    assert np.array_equal(be.host_f32(v2)[:, :, :T], rv) and not be.host_f32(v2)[:, :, T:].any()
+    assert np.array_equal(be.host_f32(vt2), gv)
 
 
 def check_attention(be, B, H, T, hd, causal, seed=0, spike=False):
@@ -429,25 +422,6 @@ def check_attention(be, B, H, T, hd, causal, seed=0, spike=False):
     err = np.abs(got - ref).max()
     assert err < 2 ** -7 * max(1.0, np.abs(ref).max()), f"attention B{B} H{H} T{T} hd{hd} causal{causal}: abs err {err}"
     return err
-
-
-def check_attention_decode(be, B, H, hd, ctx, seed=0):
-    rng = np.random.RandomState(seed)
-    S = (ctx + 63) // 64 * 64 + 64
-    q = bf16_round(rng.randn(B, H, 1, hd))
-    k = bf16_round(rng.randn(B, H, ctx, hd))
-    v = bf16_round(rng.randn(B, H, ctx, hd))
-    kp, vtp = rng.randn(B, H, S, hd).astype(np.float32), rng.randn(B, H, hd, S).astype(np.float32)  # stale garbage
-    kp[:, :, :ctx], vtp[:, :, :, :ctx] = k, v.transpose(0, 1, 3, 2)
-    out = be.zeros((B, H * hd), "bf16")
-    scale = 1.0 / math.sqrt(hd)
-    _call(be, "vck_attention_decode", be.bf16(q[:, :, 0]), be.bf16(kp), be.bf16(vtp), out, B, H, hd, S,
-          be.i32([ctx]), scale)
-    ref = cpu_ref.softmax_attention(torch.from_numpy(q), torch.from_numpy(k), torch.from_numpy(v), scale, False,
-                                    cpu_ref.Rounder(False))
-    ref = ref.transpose(1, 2).reshape(B, H * hd).numpy()
-    err = np.abs(be.host_f32(out) - ref).max()
-    assert err < 2 ** -8 * max(1.0, np.abs(ref).max()), f"attention_decode ctx{ctx}: abs err {err}"
 
 
 def check_splice(be, D):
@@ -552,35 +526,56 @@ def check_gemv_norm_chain(be, M, D, N, seed=0):
     assert e < 2e-5, f"second consumer gemv rel err {e}"
 
 
-def check_attention_decode_fused(be, B, H, hd, pos, seed=0):
+def check_attention_decode_fused(be, B, H, hd, pos, seed=0, per_row=False):
+    """fused decode attention (RoPE + append + attention over the key-major K / V cache).  per_row: every row at its own
+    position, one row inactive (the decode pool's form, vck_attention_decode_rows)."""
     rng = np.random.RandomState(seed)
     D = H * hd
+    poss = [max(1, pos - 13 * b) for b in range(B)] if per_row else [pos] * B
     S = (pos + 1 + 63) // 64 * 64 + 64
     qkv = bf16_round(rng.randn(B, 3 * D))
-    k_old = bf16_round(rng.randn(B, H, pos, hd))
-    v_old = bf16_round(rng.randn(B, H, pos, hd))
-    kp, vtp = rng.randn(B, H, S, hd).astype(np.float32), rng.randn(B, H, hd, S).astype(np.float32)  # stale garbage
-    kp[:, :, :pos], vtp[:, :, :, :pos] = k_old, v_old.transpose(0, 1, 3, 2)
-    kd, vd = be.bf16(kp), be.bf16(vtp)
+    k_old = bf16_round(rng.randn(B, H, S, hd))
+    v_old = bf16_round(rng.randn(B, H, S, hd))          # beyond a row's position: stale garbage that must not be read
+    kd, vd = be.bf16(k_old), be.bf16(v_old)
     out = be.zeros((B, D), "bf16")
     cos, sin = rope_tables(S, hd)
     scale = 1.0 / math.sqrt(hd)
-    qd, pd, cd, sd = be.bf16(qkv), be.i32([pos]), be.f32(cos), be.f32(sin)   # keep alive until sync()
-    be.lib.vck_attention_decode_fused(be.ptr(qd), be.ptr(kd), be.ptr(vd), be.ptr(out), B, H, hd, S, be.ptr(pd),
-                                      be.ptr(cd), be.ptr(sd), ctypes.c_float(scale), None)
+    qd, cd, sd = be.bf16(qkv), be.f32(cos), be.f32(sin)   # keep alive until sync()
+    inactive = B - 1 if (per_row and B > 1) else -1
+    if per_row:
+        rows = np.zeros((B, 4), np.int32)
+        rows[:, 0] = 1
+        rows[:, 1] = poss
+        if inactive >= 0:
+            rows[inactive, 0] = 0
+        rd = be.i32(rows)
+        base = rd.ctypes.data if isinstance(rd, np.ndarray) else rd.data_ptr()
+        be.lib.vck_attention_decode_rows(be.ptr(qd), be.ptr(kd), be.ptr(vd), be.ptr(out), B, H, hd, S, c_p(base + 4), 4,
+                                         c_p(base), be.ptr(cd), be.ptr(sd), ctypes.c_float(scale), None)
+    else:
+        pd = be.i32([pos])
+        be.lib.vck_attention_decode_fused(be.ptr(qd), be.ptr(kd), be.ptr(vd), be.ptr(out), B, H, hd, S, be.ptr(pd),
+                                          be.ptr(cd), be.ptr(sd), ctypes.c_float(scale), None)
     be.sync()
-    rq, rk, rv = _split_ref(qkv, B, 1, H, hd, True, pos0=pos)     # roped+rounded q,k and raw v of the new token
-    gk, gv = be.host_f32(kd), be.host_f32(vd)
-    assert np.abs(gk[:, :, pos] - rk[:, :, 0]).max() <= 2 ** -7 * np.abs(rk).max()
-    assert np.array_equal(gv[:, :, :, pos], rv[:, :, 0])
-    assert np.array_equal(gk[:, :, :pos], bf16_round(kp[:, :, :pos]))      # the rest of the cache is untouched
-    k_all = np.concatenate([k_old, gk[:, :, pos:pos + 1]], 2)
-    v_all = np.concatenate([v_old, rv], 2)
-    ref = cpu_ref.softmax_attention(torch.from_numpy(rq), torch.from_numpy(k_all), torch.from_numpy(v_all), scale, False,
-                                    cpu_ref.Rounder(False))
-    ref = ref.transpose(1, 2).reshape(B, D).numpy()
-    err = np.abs(be.host_f32(out) - ref).max()
-    assert err < 2 ** -7 * max(1.0, np.abs(ref).max()), f"attention_decode_fused pos{pos}: abs err {err}"
+    gk, gv, got = be.host_f32(kd), be.host_f32(vd), be.host_f32(out)
+    for b in range(B):
+        pb = poss[b]
+        if b == inactive:
+            assert np.array_equal(gk[b], k_old[b]) and np.array_equal(gv[b], v_old[b]) and not got[b].any()
+            continue
+        rq, rk, rv = _split_ref(qkv[b:b + 1], 1, 1, H, hd, True, pos0=pb)   # roped+rounded q,k and raw v of the new token
+        assert np.abs(gk[b, :, pb] - rk[0, :, 0]).max() <= 2 ** -7 * np.abs(rk).max()
+        assert np.array_equal(gv[b, :, pb], rv[0, :, 0])
+        keep = np.ones(S, bool)
+        keep[pb] = False
+        assert np.array_equal(gk[b][:, keep], k_old[b][:, keep]) and np.array_equal(gv[b][:, keep], v_old[b][:, keep])
+        k_all = np.concatenate([k_old[b:b + 1, :, :pb], gk[b:b + 1, :, pb:pb + 1]], 2)
+        v_all = np.concatenate([v_old[b:b + 1, :, :pb], rv], 2)
+        ref = cpu_ref.softmax_attention(torch.from_numpy(rq), torch.from_numpy(k_all), torch.from_numpy(v_all), scale, False,
+                                        cpu_ref.Rounder(False))
+        ref = ref.transpose(1, 2).reshape(D).numpy()
+        err = np.abs(got[b] - ref).max()
+        assert err < 2 ** -7 * max(1.0, np.abs(ref).max()), f"attention_decode_fused row {b} pos {pb}: abs err {err}"
 
 
 RS = dict(ACTIVE=0, FINISHED=1, STEP=2, POS=3, MAXNEW=4, EOS=5, PAD=6, NSTOP=7, SAMPLE=8, INVTEMP=9, TOPK=10, TOPP=11,

@@ -72,11 +72,6 @@ def test_qkv_split(be, B, T, H, hd, rope):
     kc.check_qkv_split(be, B, T, H, hd, rope)
 
 
-def test_qkv_append(be):
-    kc.check_qkv_append(be, 8, 32, 128, 1216)
-    kc.check_qkv_append(be, 2, 2, 64, 5)
-
-
 @pytest.mark.parametrize("B,H,T,hd,causal,spike", [(2, 16, 577, 64, False, False), (1, 4, 577, 64, False, True),
                                                    (2, 8, 1216, 128, True, False), (1, 2, 1216, 128, True, True),
                                                    (1, 1, 17, 64, False, False), (1, 2, 200, 128, True, True)])
@@ -84,19 +79,17 @@ def test_attention(be, B, H, T, hd, causal, spike):
     kc.check_attention(be, B, H, T, hd, causal, spike=spike)
 
 
-@pytest.mark.parametrize("hd,ctx", [(128, 1217), (128, 1344), (128, 70), (64, 33)])
-def test_attention_decode(be, hd, ctx):
-    kc.check_attention_decode(be, 2, 4, hd, ctx)
-
-
 def test_fused_decode_kernels(be):
     kc.check_gemv_norm_chain(be, 8, 4096, 12288)
     kc.check_gemv_norm_chain(be, 16, 5120, 1024, seed=1)
+    kc.check_gemv_norm_chain(be, 24, 4096, 12288, seed=2)     # the decode pool: 17..32 rows per weight pass
+    kc.check_gemv_norm_chain(be, 32, 4096, 4096, seed=3)
     kc.check_gemv_norm_chain(be, 3, 256, 64, seed=2)
     kc.check_attention_decode_fused(be, 8, 32, 128, 1216)
     kc.check_attention_decode_fused(be, 2, 4, 128, 1343)
     kc.check_attention_decode_fused(be, 1, 2, 64, 5)
-    kc.check_attention_decode_fused(be, 2, 4, 128, 5000)   # cache capacity > 4096 keys: the single-pass kernel
+    kc.check_attention_decode_fused(be, 2, 4, 128, 4000)   # near the 4096-key limit of the LDS score buffer
+    kc.check_attention_decode_fused(be, 24, 32, 128, 1300, per_row=True)   # the decode pool: a position per row
     kc.check_select_embed(be, 8, 32000, 4096)
 
 

@@ -131,7 +131,7 @@ def bench_dattn_rows():
     for B in (8, 16, 24, 32):
         qkv = bf16(B, 3 * D)
         ks = [bf16(B, H, S, hd) for _ in range(2)]
-        vs = [bf16(B, H, hd, S) for _ in range(2)]
+        vs = [bf16(B, H, S, hd) for _ in range(2)]
         out = torch.zeros((B, D), dtype=torch.bfloat16, device=dev)
         pos = torch.tensor([1216 + (7 * b) % 128 for b in range(B)], dtype=torch.int32, device=dev)
         act = torch.ones(B, dtype=torch.int32, device=dev)
@@ -261,7 +261,7 @@ def bench_dattn():
     D = H * hd
     qkv = bf16(B, 3 * D)
     ks = [bf16(B, H, S, hd) for _ in range(4)]
-    vs = [bf16(B, H, hd, S) for _ in range(4)]
+    vs = [bf16(B, H, S, hd) for _ in range(4)]
     out = torch.zeros((B, D), dtype=torch.bfloat16, device=dev)
     posd = torch.tensor([pos], dtype=torch.int32, device=dev)
     cos, sin = torch.rand(S, hd // 2, device=dev), torch.rand(S, hd // 2, device=dev)

@@ -143,7 +143,7 @@ struct vc_model {
     int reserve_new = 64;         // KV slots a vc_prefill keeps free behind the prompt (vc_model_reserve_decode)
     int layer_limit = 0;          // > 0: a prefill evaluates only the first layer_limit decoder layers (vc_model_set_layer_limit)
     // LLM workspace
-    Buf x, xn, qkv, q, attn, h, kc, vtc, row_src, last_idx, xl, logits_all;
+    Buf x, xn, qkv, q, attn, h, kc, vc, vt_pre, row_src, last_idx, xl, logits_all;
     int capB = 0, capS = 0;  // KV capacity
     int curB = 0, curS = 0, cur_pos = -1;
     // decode state of this session's own loop (vc_prefill / vc_decode_step, strict mode, generate with the pool off)
@@ -366,7 +366,7 @@ void gemm(vc_model* m, const bf16_t* A, const bf16_t* W, const float* bias, void
 // Everything one decode step touches besides the weights: the buffers of a session's own loop or of the shared pool.
 struct LoopView {
     hipStream_t st;
-    bf16_t *kc, *vtc;  // [L][capR][H][capS][hd] K key-major / [L][capR][H][hd][capS] V transposed
+    bf16_t *kc, *vc;   // [L][capR][H][capS][hd]: K and V, both key-major
     int capR, capS;
     int* rows;         // RowState records
     float* x_dec;
@@ -812,9 +812,9 @@ void ensure_llm(vc_model* m, int B, int S_total) {
         const int newS = std::max(Scap, m->capB == B ? m->capS : 0);
         const size_t per_layer = (size_t)B * H * newS * m->hd;
         m->kc.release();
-        m->vtc.release();
+        m->vc.release();
         m->kc.ensure(per_layer * c.layers * 2, true);
-        m->vtc.ensure(per_layer * c.layers * 2, true);
+        m->vc.ensure(per_layer * c.layers * 2, true);
         m->capB = B;
         m->capS = newS;
         drop_graph(m);
@@ -843,7 +843,7 @@ LoopView session_view(vc_model* m) {
     LoopView v{};
     v.st = m->st;
     v.kc = m->kc.as<bf16_t>();
-    v.vtc = m->vtc.as<bf16_t>();
+    v.vc = m->vc.as<bf16_t>();
     v.capR = m->capB;
     v.capS = m->capS;
     v.rows = m->rows.as<int>();
@@ -863,22 +863,22 @@ LoopView session_view(vc_model* m) {
 
 // where a prefill writes its keys / values: rows [row0, row0 + B) of a cache with capR rows of capS positions
 struct KvTarget {
-    bf16_t *kc, *vtc;
+    bf16_t *kc, *vc;
     int capR, capS, row0;
 };
 bf16_t* kcache(const vc_model* m, const KvTarget& t, int l) {
     return t.kc + ((size_t)l * t.capR + t.row0) * m->c.heads * t.capS * m->hd;
 }
-bf16_t* vtcache(const vc_model* m, const KvTarget& t, int l) {
-    return t.vtc + ((size_t)l * t.capR + t.row0) * m->c.heads * t.capS * m->hd;
+bf16_t* vcache(const vc_model* m, const KvTarget& t, int l) {
+    return t.vc + ((size_t)l * t.capR + t.row0) * m->c.heads * t.capS * m->hd;
 }
-KvTarget session_kv(vc_model* m) { return KvTarget{m->kc.as<bf16_t>(), m->vtc.as<bf16_t>(), m->capB, m->capS, 0}; }
+KvTarget session_kv(vc_model* m) { return KvTarget{m->kc.as<bf16_t>(), m->vc.as<bf16_t>(), m->capB, m->capS, 0}; }
 bf16_t* kcache(const LoopView& v, const vc_model* m, int l) { return v.kc + (size_t)l * v.capR * m->c.heads * v.capS * m->hd; }
-bf16_t* vtcache(const LoopView& v, const vc_model* m, int l) { return v.vtc + (size_t)l * v.capR * m->c.heads * v.capS * m->hd; }
+bf16_t* vcache(const LoopView& v, const vc_model* m, int l) { return v.vc + (size_t)l * v.capR * m->c.heads * v.capS * m->hd; }
 
 // The decode loop outran the cache (a host-driven vc_decode_step loop past the reserve of its prefill): re-allocate with
-// room for `need` positions and move the live prefix — K rows are contiguous per (layer, sample, head), V^T rows are
-// hd x capS, so both are strided 2-D copies.  The decode graph bakes the cache pointers in and is re-captured.
+// room for `need` positions and move the live prefix — K and V rows are contiguous per (layer, sample, head), so each is
+// one strided 2-D copy.  The decode graph bakes the cache pointers in and is re-captured.
 void grow_kv(vc_model* m, int need) {
     const vc_model_cfg& c = m->c;
     const int oldS = m->capS, live = m->cur_pos;
@@ -891,13 +891,13 @@ void grow_kv(vc_model* m, int need) {
     nv.ensure(heads * newS * m->hd * 2, true);
     HIPCHK(hipMemcpy2DAsync(nk.p, (size_t)newS * m->hd * 2, m->kc.p, (size_t)oldS * m->hd * 2, (size_t)live * m->hd * 2, heads,
                             hipMemcpyDeviceToDevice, m->st));
-    HIPCHK(hipMemcpy2DAsync(nv.p, (size_t)newS * 2, m->vtc.p, (size_t)oldS * 2, (size_t)live * 2, heads * m->hd,
+    HIPCHK(hipMemcpy2DAsync(nv.p, (size_t)newS * m->hd * 2, m->vc.p, (size_t)oldS * m->hd * 2, (size_t)live * m->hd * 2, heads,
                             hipMemcpyDeviceToDevice, m->st));
     HIPCHK(hipStreamSynchronize(m->st));
     m->kc.release();
-    m->vtc.release();
+    m->vc.release();
     m->kc = nk;
-    m->vtc = nv;
+    m->vc = nv;
     if (m->precision && m->s_capS == oldS && m->s_capB == m->capB) {  // the strict path's fp32 caches (K and V key-major)
         Buf sk, sv;
         sk.ensure(heads * newS * m->hd * 4, true);
@@ -921,15 +921,19 @@ void run_prefill_layers(vc_model* m, const KvTarget& kv, int B, int S) {
     const vc_model_cfg& c = m->c;
     const int D = c.hidden, F = c.ffn, H = c.heads, M = B * S;
     const int nl = m->layer_limit > 0 ? std::min(m->layer_limit, c.layers) : c.layers;
+    const int Sr = (int)rup(S, 64);
+    m->vt_pre.ensure((size_t)B * H * m->hd * Sr * 2, true);
     for (int l = 0; l < nl; ++l) {
         const LlmLayer& L = m->llm[l];
         launch_rmsnorm(m->x.as<float>(), L.in_norm, m->xn.as<bf16_t>(), M, D, c.rms_eps, m->st);
         gemm(m, m->xn.as<bf16_t>(), L.qkv_w, nullptr, m->qkv.p, M, 3 * D, D, 3 * D, EPI_BF16);
-        QkvSplitArgs qa{m->qkv.as<bf16_t>(), m->q.as<bf16_t>(), kcache(m, kv, l), vtcache(m, kv, l), B, S, H, m->hd, S, kv.capS,
-                        nullptr, m->rope_cos, m->rope_sin};
+        // K and V rows go to the cache (key-major: what the decode steps stream); the V^T tiles of this layer's flash
+        // attention live in a per-call scratch [B,H,hd,Sr]
+        QkvSplitArgs qa{m->qkv.as<bf16_t>(), m->q.as<bf16_t>(), kcache(m, kv, l), m->vt_pre.as<bf16_t>(), B, S, H, m->hd, S, kv.capS,
+                        nullptr, m->rope_cos, m->rope_sin, vcache(m, kv, l), Sr};
         launch_qkv_split(qa, m->st);
-        AttnArgs aa{m->q.as<bf16_t>(), kcache(m, kv, l), vtcache(m, kv, l), m->attn.as<bf16_t>(), B, H, S, m->hd, S, kv.capS, 1,
-                    1.0f / sqrtf((float)m->hd)};
+        AttnArgs aa{m->q.as<bf16_t>(), kcache(m, kv, l), m->vt_pre.as<bf16_t>(), m->attn.as<bf16_t>(), B, H, S, m->hd, S, kv.capS, 1,
+                    1.0f / sqrtf((float)m->hd), Sr};
         launch_attention(aa, m->st);
         gemm(m, m->attn.as<bf16_t>(), L.o_w, nullptr, m->x.p, M, D, D, D, EPI_RESID_F32);
         launch_rmsnorm(m->x.as<float>(), L.post_norm, m->xn.as<bf16_t>(), M, D, c.rms_eps, m->st);
@@ -964,7 +968,7 @@ SelectArgs select_args(vc_model* m, const LoopView& v, const float* logits, int 
 
 void enqueue_decode_step(vc_model* m, const LoopView& v, int nrows) {
     decode_linears(m, v, nrows, [&](int l) {
-        AttnDecodeFusedArgs da{v.qkv_dec, kcache(v, m, l), vtcache(v, m, l), v.attn_dec, nrows, m->c.heads, m->hd, v.capS,
+        AttnDecodeFusedArgs da{v.qkv_dec, kcache(v, m, l), vcache(v, m, l), v.attn_dec, nrows, m->c.heads, m->hd, v.capS,
                                v.rows + RS_POS, m->rope_cos, m->rope_sin, 1.0f / sqrtf((float)m->hd), RS_STRIDE,
                                v.rows + RS_ACTIVE};
         launch_attention_decode_fused(da, v.st);
@@ -1277,6 +1281,8 @@ VC_API int vc_model_create(vc_ctx* ctx, const vc_model_cfg* cfg, vc_model** out)
     REQUIRE(c.vit_layers_used >= 0 && c.vit_layers_used <= c.vit_layers, VC_ERR_INVALID, "bad vit_layers_used");
     REQUIRE(c.vit_image % c.vit_patch == 0, VC_ERR_INVALID, "image size must be a multiple of the patch size");
     REQUIRE(c.mm_proj_depth >= 0 && c.seg_proj_depth >= 0, VC_ERR_INVALID, "bad projector depth");
+    REQUIRE(c.max_positions >= 64 && c.max_positions <= 4096, VC_ERR_INVALID,
+            "max_positions %d: the decode attention keeps a row's scores in LDS (<= 4096 keys)", c.max_positions);
     m = new vc_model();
     m->ctx = ctx;
     m->c = c;
@@ -1377,7 +1383,7 @@ VC_API void vc_model_destroy(vc_model* m) {
         for (void* p : m->owned) (void)hipFree(p);
     for (Buf* b : {&m->stage, &m->stage2, &m->v_pixels, &m->v_cols, &m->v_patches, &m->v_x, &m->v_xn, &m->v_qkv, &m->v_q,
                    &m->v_k, &m->v_vt, &m->v_attn, &m->v_h, &m->v_sel, &m->v_mid, &m->feats, &m->x, &m->xn, &m->qkv, &m->q,
-                   &m->attn, &m->h, &m->kc, &m->vtc, &m->row_src, &m->last_idx, &m->xl, &m->logits_all, &m->x_dec,
+                   &m->attn, &m->h, &m->kc, &m->vc, &m->vt_pre, &m->row_src, &m->last_idx, &m->xl, &m->logits_all, &m->x_dec,
                    &m->xg_dec, &m->qkv_dec, &m->attn_dec, &m->h_dec, &m->logits, &m->next_tok, &m->rows,
                    &m->out_ids, &m->dsum, &m->ssq, &m->sk_scratch, &m->sk_counters, &m->gemm_ws, &m->s_cols, &m->s_patches, &m->s_vx, &m->s_vxn, &m->s_vqkv,
                    &m->s_vq, &m->s_vk, &m->s_vv, &m->s_vattn, &m->s_vh, &m->s_sel, &m->s_mid, &m->s_feats, &m->s_xn, &m->s_qkv,
@@ -1766,7 +1772,7 @@ struct vc_pool {
     int device = 0;
     hipStream_t st = nullptr;
     int R = VC_POOL_ROWS, capS = 0, out_stride = 0;
-    Buf kc, vtc, rows, x_dec, xg_dec, qkv_dec, attn_dec, h_dec, logits, next_tok, out_ids, ssq, sk_scratch, sk_counters;
+    Buf kc, vc, rows, x_dec, xg_dec, qkv_dec, attn_dec, h_dec, logits, next_tok, out_ids, ssq, sk_scratch, sk_counters;
     hipGraphExec_t graph[VC_POOL_ROWS / 8] = {};    // one decode step over rows [0, 8 * (i + 1))
     std::mutex mu;
     std::condition_variable cv_driver, cv_rows;
@@ -1786,7 +1792,7 @@ LoopView pool_view(vc_pool* p) {
     LoopView v{};
     v.st = p->st;
     v.kc = p->kc.as<bf16_t>();
-    v.vtc = p->vtc.as<bf16_t>();
+    v.vc = p->vc.as<bf16_t>();
     v.capR = p->R;
     v.capS = p->capS;
     v.rows = p->rows.as<int>();
@@ -1917,7 +1923,7 @@ void pool_destroy(vc_pool* p) {
     (void)hipStreamSynchronize(p->st);
     for (auto& g : p->graph)
         if (g) (void)hipGraphExecDestroy(g);
-    for (Buf* b : {&p->kc, &p->vtc, &p->rows, &p->x_dec, &p->xg_dec, &p->qkv_dec, &p->attn_dec, &p->h_dec, &p->logits,
+    for (Buf* b : {&p->kc, &p->vc, &p->rows, &p->x_dec, &p->xg_dec, &p->qkv_dec, &p->attn_dec, &p->h_dec, &p->logits,
                    &p->next_tok, &p->out_ids, &p->ssq, &p->sk_scratch, &p->sk_counters})
         b->release();
     for (auto& e : p->step_ev)
@@ -1954,7 +1960,7 @@ vc_pool* pool_for(vc_model* m, int need_S, int need_out) {
     t_stream = p->st;  // zero-fills of the new buffers
     const size_t kvb = (size_t)c.layers * R * H * p->capS * root->hd * 2;
     p->kc.ensure(kvb, true);
-    p->vtc.ensure(kvb, true);
+    p->vc.ensure(kvb, true);
     p->rows.ensure((size_t)R * RS_STRIDE * 4, true);
     p->x_dec.ensure((size_t)R * D * 4, true);
     p->xg_dec.ensure((size_t)R * D * 2, true);
@@ -1977,6 +1983,15 @@ vc_pool* pool_for(vc_model* m, int need_S, int need_out) {
 }
 
 // generate() through the pool: prefill on the session's stream into pool rows, decode steps shared with whoever else is in
+#define DBG_HIP(tag)                                                                                         \
+    do {                                                                                                     \
+        if (g_dbg_hip) {                                                                                     \
+            hipError_t e_ = hipGetLastError();                                                               \
+            if (e_ != hipSuccess) fprintf(stderr, "[vcoder_amd] last-error %d (%s) after %s\n", (int)e_, hipGetErrorString(e_), tag); \
+        }                                                                                                    \
+    } while (0)
+const bool g_dbg_hip = getenv("VC_DEBUG_HIP") != nullptr;
+
 void generate_on_pool(vc_model* m, const int64_t* ids, int B, int T, const float* img, const float* seg, const float* depth,
                       int on_dev, const GenParams& g, const std::vector<int>& tail, vc_token_cb cb, void* cb_user,
                       int cb_every, int32_t* out_ids, int* n_generated) {
@@ -2030,6 +2045,7 @@ void generate_on_pool(vc_model* m, const int64_t* ids, int B, int T, const float
         for (hipEvent_t* e : evs) HIPCHK(hipEventCreate(e));
         HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&rq.rec), (size_t)B * RS_STRIDE * 4, 0));
         HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&rq.fin_host), (size_t)B * 4, 0));
+        DBG_HIP("pool request setup");
         // ---- encode + prefill, keys / values straight into the pool's rows
         m->cur_pos = -1;
         int S = 0;
@@ -2037,12 +2053,14 @@ void generate_on_pool(vc_model* m, const int64_t* ids, int B, int T, const float
         std::unique_lock<std::mutex> gate(g_prefill_gate, std::defer_lock);
         if (use_gate) gate.lock();
         do_prefill(m, ids, B, T, img, seg, depth, on_dev, 1, max_new, false, &S);
+        DBG_HIP("do_prefill");
         m->last_S = S;
         REQUIRE(S + max_new <= p->capS, VC_ERR_INVALID, "prompt %d + max_new %d exceeds the pool's KV capacity %d", S, max_new,
                 p->capS);
-        finish_prefill(m, KvTarget{p->kc.as<bf16_t>(), p->vtc.as<bf16_t>(), p->R, p->capS, rq.row0}, nullptr);
+        finish_prefill(m, KvTarget{p->kc.as<bf16_t>(), p->vc.as<bf16_t>(), p->R, p->capS, rq.row0}, nullptr);
         if (m->ev[2]) HIPCHK(hipEventRecord(m->ev[2], m->st));
         HIPCHK(hipEventRecord(rq.prefill_done, m->st));
+        DBG_HIP("finish_prefill");
         if (use_gate) gate.unlock();
         fill_rows(rq.rec, B, g, S, tail.data(), rq.row0 * p->out_stride, p->out_stride);
         // ---- join, then sleep until the driver retires the request (streaming: wake per report)
@@ -2079,6 +2097,7 @@ void generate_on_pool(vc_model* m, const int64_t* ids, int B, int T, const float
         HIPCHK(hipMemcpy2DAsync(out_ids, (size_t)max_new * 4, p->out_ids.as<int>() + (size_t)rq.row0 * p->out_stride,
                                 (size_t)p->out_stride * 4, (size_t)max_new * 4, B, hipMemcpyDeviceToHost, m->st));
         HIPCHK(hipStreamSynchronize(m->st));
+        DBG_HIP("pool result copy");
         for (int b = 0; b < B; ++b)  // columns the loop never reached read as pad, like the session loop's pre-filled store
             for (int s_ = produced; s_ < max_new; ++s_) out_ids[(size_t)b * max_new + s_] = g.pad;
         produced = trim_columns(g, out_ids, max_new, tail.data(), B, produced);
@@ -2095,6 +2114,7 @@ void generate_on_pool(vc_model* m, const int64_t* ids, int B, int T, const float
             (void)hipEventElapsedTime(&m->t_prefill, m->ev[1], m->ev[2]);
             (void)hipEventElapsedTime(&m->t_decode, rq.join_ev, rq.done_ev);
         }
+        DBG_HIP("pool timings");
     } catch (...) {
         {   // a request that is still queued / active must not outlive this frame
             std::unique_lock<std::mutex> lk(p->mu);
@@ -2382,6 +2402,64 @@ VC_API int vc_last_timings(vc_model* m, float* encode_ms, float* prefill_ms, flo
     if (prefill_ms) *prefill_ms = m->t_prefill;
     if (decode_ms) *decode_ms = m->t_decode;
     return VC_OK;
+}
+
+/* times `reps` sweeps of the decode attention launches of one step (one per layer) over `B` rows at context `ctx` (keys per
+ * row before the append; row b sits at ctx - (7 b) % 64 so the rows differ like concurrent requests do) with HIP events on the
+ * model's stream; the KV contents are whatever the cache holds (the kernel's speed does not depend on the values).  Returns
+ * launches per sweep, average microseconds per launch and the algorithmic KV bytes per launch (4 * sum(ctx_b + 1) * hidden). */
+VC_API int vc_profile_decode_attention(vc_model* m, int B, int ctx, int reps, int* launches, double* avg_us, double* avg_bytes) {
+    if (!m) return VC_ERR_INVALID;
+    GUARD_BEGIN
+    USE_DEVICE(m->ctx);
+    REQUIRE(m->finalized && B >= 1 && B <= VC_POOL_ROWS && reps >= 1 && ctx >= 64, VC_ERR_INVALID, "bad profile arguments");
+    const vc_model_cfg& c = m->c;
+    LoopView v;
+    if (B <= VC_MAX_ROWS) {
+        ensure_llm(m, B, ctx + 64);
+        v = session_view(m);
+    } else {
+        vc_pool* p = pool_for(m, ctx + 64, 1);
+        {
+            std::lock_guard<std::mutex> lk(p->mu);
+            REQUIRE(p->users == 0 && p->active.empty() && p->pending.empty(), VC_ERR_STATE, "the decode pool is busy");
+        }
+        HIPCHK(hipStreamSynchronize(p->st));
+        v = pool_view(p);
+        v.st = m->st;
+    }
+    REQUIRE(ctx + 1 <= v.capS, VC_ERR_INVALID, "context %d exceeds the cache capacity %d", ctx, v.capS);
+    std::vector<int> rec((size_t)B * RS_STRIDE, 0);
+    double keys = 0;
+    for (int b = 0; b < B; ++b) {
+        rec[(size_t)b * RS_STRIDE + RS_ACTIVE] = 1;
+        rec[(size_t)b * RS_STRIDE + RS_POS] = ctx - (7 * b) % 64;
+        keys += rec[(size_t)b * RS_STRIDE + RS_POS] + 1;
+    }
+    HIPCHK(hipMemcpyAsync(v.rows, rec.data(), rec.size() * 4, hipMemcpyHostToDevice, m->st));
+    HIPCHK(hipStreamSynchronize(m->st));
+    auto sweep = [&]() {
+        for (int l = 0; l < c.layers; ++l) {
+            AttnDecodeFusedArgs da{v.qkv_dec, kcache(v, m, l), vcache(v, m, l), v.attn_dec, B, c.heads, m->hd, v.capS,
+                                   v.rows + RS_POS, m->rope_cos, m->rope_sin, 1.0f / sqrtf((float)m->hd), RS_STRIDE,
+                                   v.rows + RS_ACTIVE};
+            launch_attention_decode_fused(da, m->st);
+        }
+    };
+    sweep();  // warm
+    HIPCHK(hipEventRecord(m->ev[0], m->st));
+    for (int r = 0; r < reps; ++r) sweep();
+    HIPCHK(hipEventRecord(m->ev[1], m->st));
+    HIPCHK(hipStreamSynchronize(m->st));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, m->ev[0], m->ev[1]));
+    if (launches) *launches = c.layers;
+    if (avg_us) *avg_us = (double)ms * 1e3 / ((double)reps * c.layers);
+    if (avg_bytes) *avg_bytes = 4.0 * keys * (double)c.hidden;
+    HIPCHK(hipMemsetAsync(v.rows, 0, (size_t)B * RS_STRIDE * 4, m->st));
+    HIPCHK(hipStreamSynchronize(m->st));
+    m->cur_pos = -1;
+    GUARD_END(m->ctx)
 }
 
 VC_API int vc_profile_decode_gemv(vc_model* m, int B, int reps, int* launches, double* avg_us, double* avg_bytes) {

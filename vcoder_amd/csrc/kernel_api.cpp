@@ -34,16 +34,16 @@ VCK_EXPORT void vck_gemv_ex(const uint16_t* X, const void* Wp, const float* wsca
     a.sk_scratch = sk_scratch; a.sk_counters = sk_counters; a.ksplit = ksplit;
     launch_gemv(a, epi, S(stream));
 }
-VCK_EXPORT void vck_attention_decode_fused(const uint16_t* qkv, uint16_t* k, uint16_t* vt, uint16_t* out, int B, int H,
+VCK_EXPORT void vck_attention_decode_fused(const uint16_t* qkv, uint16_t* k, uint16_t* v, uint16_t* out, int B, int H,
                                            int hd, int kv_stride, const int* pos_dev, const float* rope_cos,
                                            const float* rope_sin, float scale, void* stream) {
-    AttnDecodeFusedArgs a{qkv, k, vt, out, B, H, hd, kv_stride, pos_dev, rope_cos, rope_sin, scale, 0, nullptr};
+    AttnDecodeFusedArgs a{qkv, k, v, out, B, H, hd, kv_stride, pos_dev, rope_cos, rope_sin, scale, 0, nullptr};
     launch_attention_decode_fused(a, S(stream));
 }
-VCK_EXPORT void vck_attention_decode_rows(const uint16_t* qkv, uint16_t* k, uint16_t* vt, uint16_t* out, int B, int H, int hd,
+VCK_EXPORT void vck_attention_decode_rows(const uint16_t* qkv, uint16_t* k, uint16_t* v, uint16_t* out, int B, int H, int hd,
                                           int kv_stride, const int* pos_rows, int pos_stride, const int* active_rows,
                                           const float* rope_cos, const float* rope_sin, float scale, void* stream) {
-    AttnDecodeFusedArgs a{qkv, k, vt, out, B, H, hd, kv_stride, pos_rows, rope_cos, rope_sin, scale, pos_stride, active_rows};
+    AttnDecodeFusedArgs a{qkv, k, v, out, B, H, hd, kv_stride, pos_rows, rope_cos, rope_sin, scale, pos_stride, active_rows};
     launch_attention_decode_fused(a, S(stream));
 }
 VCK_EXPORT void vck_select_embed(const float* logits, int ldl, int* rows, int* next_tok, int* out_ids, const uint16_t* embed,
@@ -88,18 +88,20 @@ VCK_EXPORT void vck_select_rows_bf16(const float* x, uint16_t* y, int n_img, int
 VCK_EXPORT void vck_qkv_split(const uint16_t* qkv, uint16_t* q, uint16_t* k, uint16_t* vt, int B, int T, int H, int hd,
                               int q_stride, int kv_stride, const int* pos0_dev, const float* rope_cos,
                               const float* rope_sin, void* stream) {
-    QkvSplitArgs a{qkv, q, k, vt, B, T, H, hd, q_stride, kv_stride, pos0_dev, rope_cos, rope_sin};
+    QkvSplitArgs a{qkv, q, k, vt, B, T, H, hd, q_stride, kv_stride, nullptr, rope_cos, rope_sin, nullptr, 0};
+    (void)pos0_dev;
+    launch_qkv_split(a, S(stream));
+}
+VCK_EXPORT void vck_qkv_split_kv(const uint16_t* qkv, uint16_t* q, uint16_t* k, uint16_t* v, uint16_t* vt, int B, int T, int H,
+                                 int hd, int q_stride, int kv_stride, int vt_stride, const float* rope_cos,
+                                 const float* rope_sin, void* stream) {
+    QkvSplitArgs a{qkv, q, k, vt, B, T, H, hd, q_stride, kv_stride, nullptr, rope_cos, rope_sin, v, vt_stride};
     launch_qkv_split(a, S(stream));
 }
 VCK_EXPORT void vck_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, uint16_t* out, int B, int H,
                               int T, int hd, int q_stride, int kv_stride, int causal, float scale, void* stream) {
     AttnArgs a{q, k, vt, out, B, H, T, hd, q_stride, kv_stride, causal, scale};
     launch_attention(a, S(stream));
-}
-VCK_EXPORT void vck_attention_decode(const uint16_t* q, const uint16_t* k, const uint16_t* vt, uint16_t* out, int B,
-                                     int H, int hd, int kv_stride, const int* ctx_len_dev, float scale, void* stream) {
-    AttnDecodeArgs a{q, k, vt, out, B, H, hd, kv_stride, ctx_len_dev, scale};
-    launch_attention_decode(a, S(stream));
 }
 VCK_EXPORT void vck_splice(const int* row_src, int nrows, const uint16_t* embed, const uint16_t* feats, float* x, int D,
                            void* stream) {

@@ -113,10 +113,12 @@ struct QkvSplitArgs {
     bf16_t* vt;
     int B, T, H, hd;
     int q_stride;   // rows per (b,h) in Q
-    int kv_stride;  // rows (keys) per (b,h) in K / columns in V^T
-    const int* pos0_dev;  // decode append form (T == 1): device scalar holding the position; nullptr -> prefill from 0
+    int kv_stride;  // rows (keys) per (b,h) in K (and V), columns in V^T unless vt_stride is given
+    const int* pos0_dev;  // unused (the decode append is fused into the decode attention kernel); keep nullptr
     const float* rope_cos;  // fp32 [max_pos, hd/2] tables (LlamaRotaryEmbedding); nullptr disables RoPE (ViT)
     const float* rope_sin;
+    bf16_t* v;      // V key-major [B,H,kv_stride,hd] (the KV cache the decode steps stream), or nullptr (ViT)
+    int vt_stride;  // columns per row of V^T (0: kv_stride) — the LLM prefill keeps V^T in a per-call scratch
 };
 void launch_qkv_split(const QkvSplitArgs& a, hipStream_t s);
 
@@ -130,17 +132,18 @@ struct AttnArgs {
     int q_stride, kv_stride;
     int causal;
     float scale;
+    int vt_stride;    // columns per row of V^T (0: kv_stride)
 };
 void launch_attention(const AttnArgs& a, hipStream_t s);
 
 // fused decode attention (K13+K14+K15 for q_len = 1): RoPE of the new q/k, KV-cache append and attention over the cache
-// in ONE launch per layer; the position is read from a device scalar (hipGraph-replayable)
+// in ONE launch per layer; K and V are both key-major; positions come from device memory (hipGraph-replayable)
 struct AttnDecodeFusedArgs {
     const bf16_t* qkv;   // [B, 3*H*hd] fused projection output of the new token
     bf16_t* k;           // [B,H,kv_stride,hd]   (row `pos` is written)
-    bf16_t* vt;          // [B,H,hd,kv_stride]   (column `pos` is written)
+    bf16_t* v;           // [B,H,kv_stride,hd]   (row `pos` is written)
     bf16_t* out;         // [B, H*hd]
-    int B, H, hd, kv_stride;
+    int B, H, hd, kv_stride;   // kv_stride <= 4096 (the scores of a row sit in LDS)
     const int* pos_dev;  // position of the new token == number of keys already cached; row b reads pos_dev[b * pos_stride]
     const float* rope_cos;
     const float* rope_sin;
@@ -149,18 +152,6 @@ struct AttnDecodeFusedArgs {
     const int* active_dev;  // nullptr, or row b is skipped when active_dev[b * pos_stride] == 0
 };
 void launch_attention_decode_fused(const AttnDecodeFusedArgs& a, hipStream_t s);
-
-// decode attention (q_len = 1, K15): ctx length read from a device scalar (hipGraph-replayable)
-struct AttnDecodeArgs {
-    const bf16_t* q;    // [B,H,hd]
-    const bf16_t* k;    // [B,H,kv_stride,hd]
-    const bf16_t* vt;   // [B,H,hd,kv_stride]
-    bf16_t* out;        // [B, H*hd]
-    int B, H, hd, kv_stride;
-    const int* ctx_len_dev;  // number of valid keys (including the token just appended)
-    float scale;
-};
-void launch_attention_decode(const AttnDecodeArgs& a, hipStream_t s);
 
 // ---- splice / embedding (K10) ------------------------------------------------------------------
 // per destination row r of inputs_embeds [B*S, D]: row_src[2r] = kind (0 = token id -> embed_tokens row,

@@ -419,6 +419,11 @@ class HipEngine:
         self._check(self.lib.vc_last_timings(self._model, C.byref(e), C.byref(p), C.byref(d)))
         return {"encode_ms": e.value, "prefill_ms": p.value, "decode_ms": d.value}
 
+    def profile_decode_attention(self, B: int, ctx: int, reps: int = 3):
+        n, us, by = C.c_int(), C.c_double(), C.c_double()
+        self._check(self.lib.vc_profile_decode_attention(self._model, B, ctx, reps, C.byref(n), C.byref(us), C.byref(by)))
+        return {"launches_per_step": n.value, "avg_us": us.value, "avg_bytes": by.value}
+
     def profile_decode_gemv(self, B: int, reps: int = 3):
         n, us, by = C.c_int(), C.c_double(), C.c_double()
         self._check(self.lib.vc_profile_decode_gemv(self._model, B, reps, C.byref(n), C.byref(us), C.byref(by)))
