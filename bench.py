@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0    # dense bf16
+MFMA_FP8_PEAK_TFLOPS = 5000.0  # dense fp8 (K=128 scaled MFMA)
 
 
 def parse_args():
@@ -39,9 +40,10 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=8, help="samples per GPU (BASELINE configs[1]: 8)")
     ap.add_argument("--new-tokens", type=int, default=128)
     ap.add_argument("--model", default="7b", choices=["7b", "13b"])
-    ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"],
-                    help="decoder weight storage: bf16 (BASELINE configs[1], the default metric) or fp8 = W8A16 e4m3 with "
-                         "per-row power-of-two scales (the weight format of BASELINE configs[4])")
+    ap.add_argument("--weights", default="bf16", choices=["bf16", "w8a16", "fp8"],
+                    help="decoder weight storage: bf16 (BASELINE configs[1], the default metric); w8a16 = e4m3 bytes with "
+                         "per-row power-of-two scales, bf16 activations; fp8 = the same weights with the prefill linears on the "
+                         "K=128 scaled fp8 MFMA (W8A8) - BASELINE configs[4]")
     ap.add_argument("--inflight", type=int, default=4,
                     help="batches in flight per GPU: independent generate() calls (own stream + prefill workspaces, shared "
                          "weights) driven by host threads.  1 = strictly one batch at a time")
@@ -167,6 +169,11 @@ def _one_vit_layer(cfg):
     return c1
 
 
+WEIGHTS_DESC = {"bf16": "bf16",
+                "w8a16": "bf16 activations / fp8-e4m3 decoder weights (W8A16)",
+                "fp8": "fp8-e4m3 decoder weights: W8A8 prefill on the K=128 scaled fp8 MFMA, W8A16 decode steps"}
+
+
 def cpu_c1_full(new_tokens: int = 32):
     """BASELINE configs[0] in full on the host cores: VCoder (non-DS) LLaVA-1.5-7b shape, ONE 336x336 RGB+seg pair, prompt
     [1] + 34 text + [IMG, SEG] + 29 text (S = 1216), `new_tokens` greedy tokens through the oracle — the reference's CPU
@@ -234,8 +241,8 @@ def main():
     cfg = vcfg.vicuna_7b("vcoder_ds") if args.model == "7b" else vcfg.vicuna_13b("vcoder_ds")
     eng = HipEngine(cfg, device_index=local)
     eng.load_synthetic(42)
-    if args.weights == "fp8":
-        eng.set_weight_format("fp8")
+    if args.weights != "bf16":
+        eng.set_weight_format(args.weights)
     eng.finalize()
     B, N_new = args.batch, args.new_tokens
     first, _ = shard_range(world * B, rank, world)   # contiguous shard of the global batch
@@ -347,8 +354,11 @@ def main():
         ms_step = dt / args.steps * 1e3
         ach = prof["avg_bytes"] / (prof["avg_us"] * 1e-6) / 1e9
         # composite roofline of ONE batch of B alone: MFMA leg (encode + prefill) + HBM leg (decode)
-        flops, w_bytes, kv_bytes = work_per_sample(cfg, S, N_new, 1.0 if args.weights == "fp8" else 2.0)
+        flops, w_bytes, kv_bytes = work_per_sample(cfg, S, N_new, 1.0 if args.weights != "bf16" else 2.0)
         mfma_ms = B * flops / (MFMA_PEAK_TFLOPS * 1e12) * 1e3
+        if args.weights == "fp8":   # the prefill's decoder linears run on the scaled fp8 MFMA: priced at its dense peak
+            lin = 2 * S * cfg.num_hidden_layers * (4 * cfg.hidden_size ** 2 + 3 * cfg.hidden_size * cfg.intermediate_size)
+            mfma_ms = B * ((flops - lin) / (MFMA_PEAK_TFLOPS * 1e12) + lin / (MFMA_FP8_PEAK_TFLOPS * 1e12)) * 1e3
         hbm_ms = ((N_new - 1) * w_bytes + B * kv_bytes) / (HBM_PEAK_GBS * 1e9) * 1e3
         # with k batches in flight whose decode steps share one weight pass, the HBM leg of a batch shrinks to
         # weights / k + its own KV: the bound of what `value` measures
@@ -385,8 +395,8 @@ def main():
                       else "images/sec (3xViT encode + 128-tok decode), VCoder-DS-13b",
             "value": world * B * args.steps / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"VCoder-DS LLaVA-1.5-{args.model} {'bf16' if args.weights == 'bf16' else 'bf16 activations / fp8-e4m3 decoder weights (W8A16)'}, batch={B}/GPU RGB+seg+depth 336x336, "
+            "vs_baseline": None, "dtype": "bf16" if args.weights != "fp8" else "fp8-e4m3 prefill linears / bf16", "data": "synthetic",
+            "config": {"workload": f"VCoder-DS LLaVA-1.5-{args.model} {WEIGHTS_DESC[args.weights]}, batch={B}/GPU RGB+seg+depth 336x336, "
                                    f"prefill S={S}, {N_new}-token greedy decode", "global_batch": world * B,
                        "parallelism": f"dp{world}", "weights": "seeded synthetic (vcoder_amd/synth.py)",
                        "in_flight_batches_per_gpu": n_sess,
@@ -407,7 +417,7 @@ def main():
                                    "frac_one_batch": (mfma_ms + hbm_ms) / (solo * 1e3),
                                    "hbm_leg_ms_weights_shared": hbm_ms_shared,
                                    "frac_value": (mfma_ms + hbm_ms_shared) / ms_step,
-                                   "peaks": {"mfma_tflops": MFMA_PEAK_TFLOPS, "hbm_gbs": HBM_PEAK_GBS},
+                                   "peaks": {"mfma_tflops": MFMA_PEAK_TFLOPS, "mfma_fp8_tflops": MFMA_FP8_PEAK_TFLOPS, "hbm_gbs": HBM_PEAK_GBS},
                                    "measured_legs_ms": {"mfma": timings["encode_ms"] + timings["prefill_ms"], "hbm": timings["decode_ms"]}},
             "roofline": roofline,
             "decode_step_kernels": kernels,

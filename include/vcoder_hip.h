@@ -90,8 +90,11 @@ int vc_model_set_layer_limit(vc_model* m, int n_layers);
 /* decoder weight storage: 0 = bf16 (default); 1 = W8A16 — the seven linears of every decoder layer are quantised at
  * vc_model_finalize to OCP fp8 e4m3 with one power-of-two scale per output row and streamed as bytes by the decode
  * GEMV (half the HBM traffic of the decode step); the prefill GEMMs read the same dequantised values in bf16, so both
- * phases compute with one set of effective weights.  This is the "fp8 weights" axis of BASELINE.json configs[4]; the
- * reference's counterpart is `load_8bit` (builder.py:31-33, bitsandbytes int8).  Call before vc_model_finalize. */
+ * phases compute with one set of effective weights.  2 = fp8, BASELINE.json configs[4] ("fp8 weights, CDNA4 fp8 MFMA"):
+ * the weights and decode steps of 1, and the prefill's decoder linears quantise their activation rows to e4m3 (one
+ * power-of-two scale per token row) and run e4m3 x e4m3 on v_mfma_scale_f32_16x16x128_f8f6f4 (W8A8, twice the bf16
+ * MFMA rate).  The reference's counterpart is `load_8bit` (builder.py:31-33, bitsandbytes LLM.int8 — also 8-bit
+ * weights x 8-bit activations).  Call before vc_model_finalize. */
 int vc_model_set_weight_format(vc_model* m, int fmt);
 
 /* ---- hot path ------------------------------------------------------------------------------ */

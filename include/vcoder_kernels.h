@@ -41,6 +41,16 @@ void vck_pack_weight(const uint16_t* W, uint16_t* Wp, int N, int K, void* stream
  * k super-tile order; W [N,K] bf16 is overwritten with the dequantised values (what the prefill GEMMs then read).
  * vck_gemv_ex streams the bytes. */
 void vck_quantize_fp8(uint16_t* W, uint8_t* Wq, float* scale, int N, int K, void* stream);
+/* the same, additionally leaving the bytes row-major in Wrow [N,K]: the weight operand of vck_gemm_f8 */
+void vck_quantize_fp8_rows(uint16_t* W, uint8_t* Wq, float* scale, uint8_t* Wrow, int N, int K, void* stream);
+/* W8A8 prefill GEMM (BASELINE config C5, "CDNA4 fp8 MFMA"): token rows of A [M,lda] bf16 -> e4m3 bytes Q [M,K] with a
+ * per-row power-of-two scale (the rule of the weight rows); then
+ *   out = epi( (Q @ Wrow^T) * a_scale[m] * w_scale[n] )
+ * on v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales; twice the bf16 MFMA rate).  K % 128 == 0;
+ * epi 0 bf16, 4 fp32 residual add, 5 SwiGLU.  ws: optional split-K workspace as for vck_gemm_ws. */
+void vck_quant_act_rows(const uint16_t* A, int lda, uint8_t* Q, float* scale, int M, int K, void* stream);
+void vck_gemm_f8(const uint8_t* A, const float* a_scale, const uint8_t* W, const float* w_scale, void* out, int M, int N,
+                 int K, int ldo, int epi, float* ws, size_t ws_bytes, void* stream);
 void vck_interleave_rows(const uint16_t* gate, const uint16_t* up, uint16_t* out, int F, int K, void* stream);
 /* nn.LayerNorm ([HF] clip :370,379) and LlamaRMSNorm ([HF] llama :53-70); fp32 in, bf16 out */
 void vck_layernorm(const float* x, const float* w, const float* b, uint16_t* y, int rows, int D, float eps, void* stream);

@@ -40,14 +40,32 @@ def _bf16(x: torch.Tensor) -> torch.Tensor:
     return x.to(torch.bfloat16).to(torch.float32)
 
 
-class Rounder:
-    """Identity in fp32 mode, bf16 round-trip in emulation mode."""
+def quantize_rows_e4m3(x: torch.Tensor) -> torch.Tensor:
+    """The device's W8A8 activation format (vc_model_set_weight_format(m, 2), csrc/decode.hip quant_act_rows_kernel):
+    every row (last dim) gets the power-of-two scale s = 2^e with the smallest e such that max|row| <= 448 * 2^e, is
+    rounded to OCP e4m3 (RNE) as row / s, and enters the matmul as q * s.  Returns the effective fp32 values."""
+    amax = x.abs().amax(-1, keepdim=True)
+    m, ex = torch.frexp(amax)                       # amax = m * 2^ex, m in [0.5, 1);  448 = 0.875 * 2^9
+    e = torch.where(m <= 0.875, ex - 9, ex - 8)
+    e = torch.where(amax > 0, e, torch.zeros_like(e))
+    s = torch.ldexp(torch.ones_like(amax), e)
+    return (x / s).to(torch.float8_e4m3fn).to(torch.float32) * s
 
-    def __init__(self, emu_bf16: bool):
+
+class Rounder:
+    """Identity in fp32 mode, bf16 round-trip in emulation mode.  act_fp8: additionally the W8A8 prefill format — the
+    inputs of the decoder linears are quantised per token row (`q8`) while the pass is a prefill."""
+
+    def __init__(self, emu_bf16: bool, act_fp8: bool = False):
         self.emu = emu_bf16
+        self.act_fp8 = act_fp8
+        self.prefill = False
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
         return _bf16(x) if self.emu else x
+
+    def q8(self, x: torch.Tensor) -> torch.Tensor:
+        return quantize_rows_e4m3(x) if (self.act_fp8 and self.prefill) else x
 
 
 def as_torch_state(sd: Dict[str, np.ndarray]) -> Dict[str, torch.Tensor]:
@@ -321,7 +339,7 @@ def llama_layer(x, sd, i: int, cfg, cache: KVCache, pos0: int, r: Rounder):
     H = cfg.num_attention_heads
     hd = D // H
     p = f"model.layers.{i}."
-    h = r(rms_norm(x, sd[p + "input_layernorm.weight"], cfg.rms_norm_eps))
+    h = r.q8(r(rms_norm(x, sd[p + "input_layernorm.weight"], cfg.rms_norm_eps)))
     q = r(F.linear(h, sd[p + "self_attn.q_proj.weight"]))
     k = r(F.linear(h, sd[p + "self_attn.k_proj.weight"]))
     v = r(F.linear(h, sd[p + "self_attn.v_proj.weight"]))
@@ -334,21 +352,23 @@ def llama_layer(x, sd, i: int, cfg, cache: KVCache, pos0: int, r: Rounder):
         v = torch.cat([cache.v[i], v], dim=2)
     cache.k[i], cache.v[i] = k, v
     a = softmax_attention(q, k, v, 1.0 / math.sqrt(hd), True, r, q_pos0=pos0)
-    a = a.transpose(1, 2).reshape(B, T, D)
+    a = r.q8(a.transpose(1, 2).reshape(B, T, D))
     x = x + F.linear(a, sd[p + "self_attn.o_proj.weight"])
-    h = r(rms_norm(x, sd[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps))
+    h = r.q8(r(rms_norm(x, sd[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps)))
     g = F.linear(h, sd[p + "mlp.gate_proj.weight"])
     u = F.linear(h, sd[p + "mlp.up_proj.weight"])
-    m = r(F.silu(g) * u)
+    m = r.q8(r(F.silu(g) * u))
     x = x + F.linear(m, sd[p + "mlp.down_proj.weight"])
     return x
 
 
-def llama_forward(x, sd, cfg, cache: KVCache, emu_bf16: bool = False, last_only: bool = False):
+def llama_forward(x, sd, cfg, cache: KVCache, emu_bf16: bool = False, last_only: bool = False, act_fp8: bool = False):
     """LlamaModel.forward :367-418 on inputs_embeds + lm_head (vcoder_ds_llava_llama.py:81-93).
-    position_ids = arange(T) + past_len."""
-    r = Rounder(emu_bf16)
+    position_ids = arange(T) + past_len.  act_fp8: the device's fp8 weight format quantises the decoder linears'
+    activation rows in the PREFILL (a pass that starts an empty cache); cached decode steps keep bf16 activations."""
+    r = Rounder(emu_bf16, act_fp8)
     pos0 = cache.length
+    r.prefill = pos0 == 0
     for i in range(cfg.num_hidden_layers):
         x = llama_layer(x, sd, i, cfg, cache, pos0, r)
     if last_only:
@@ -362,8 +382,9 @@ def llama_forward(x, sd, cfg, cache: KVCache, emu_bf16: bool = False, last_only:
 # =============================================================================================
 
 class OracleModel:
-    def __init__(self, cfg, state_dict: Dict[str, np.ndarray], emu_bf16: bool = False):
+    def __init__(self, cfg, state_dict: Dict[str, np.ndarray], emu_bf16: bool = False, act_fp8: bool = False):
         self.cfg = cfg
+        self.act_fp8 = act_fp8
         self.sd = as_torch_state(state_dict) if not isinstance(next(iter(state_dict.values())), torch.Tensor) else state_dict
         self.emu = emu_bf16
 
@@ -426,12 +447,12 @@ class OracleModel:
         """VCoder[DS]LlavaLlamaForCausalLM.forward (vcoder_ds_llava_llama.py:57-118), prefill."""
         x, _ = self.prepare_inputs(input_ids, images, segs, depths)
         cache = cache if cache is not None else KVCache(self.cfg.num_hidden_layers)
-        logits = llama_forward(x, self.sd, self.cfg, cache, self.emu, last_only)
+        logits = llama_forward(x, self.sd, self.cfg, cache, self.emu, last_only, self.act_fp8)
         return logits, cache
 
     def decode_step(self, tokens: Sequence[int], cache: KVCache):
         x = self.embed_tokens(tokens).unsqueeze(1)
-        return llama_forward(x, self.sd, self.cfg, cache, self.emu, last_only=True)
+        return llama_forward(x, self.sd, self.cfg, cache, self.emu, last_only=True, act_fp8=self.act_fp8)
 
     def generate_greedy(self, input_ids, images, segs=None, depths=None, max_new_tokens: int = 8,
                         eos_token_id: Optional[int] = None, pad_token_id: int = 0, return_logits: bool = False):

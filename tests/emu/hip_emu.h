@@ -195,6 +195,33 @@ inline f32x4 mfma16_f32(float a, float b, f32x4 c) {
     return d;
 }
 
+// v_mfma_scale_f32_16x16x128_f8f6f4, e4m3 x e4m3, unit block scales: A[i][k] in lane i+16*(k/32) byte k%32, B likewise.
+inline float emu_e4m3(uint8_t b) {
+    const int e = (b >> 3) & 15, m = b & 7;
+    const float mag = e == 0 ? (float)m * 0.001953125f : ldexpf(1.f + (float)m * 0.125f, e - 7);
+    return (b & 0x80) ? -mag : mag;
+}
+inline f32x4 mfma16_f8(u32x4 a0, u32x4 a1, u32x4 b0, u32x4 b1, f32x4 c) {
+    auto& w = vc_emu::g_cur->blk->waves[vc_emu::g_cur->wave];
+    const int lane = vc_emu::g_cur->lane;
+    memcpy(w.xchg[lane], &a0, 16);
+    memcpy(w.xchg[lane] + 16, &a1, 16);
+    memcpy(w.xchg[lane] + 32, &b0, 16);
+    memcpy(w.xchg[lane] + 48, &b1, 16);
+    vc_emu::wave_sync();
+    const int j = lane & 15;
+    f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int i = (lane >> 4) * 4 + r;
+        float acc = 0.f;
+        for (int k = 0; k < 128; ++k)
+            acc += emu_e4m3(w.xchg[i + 16 * (k / 32)][k % 32]) * emu_e4m3(w.xchg[j + 16 * (k / 32)][32 + k % 32]);
+        d[r] = c[r] + acc;
+    }
+    vc_emu::wave_sync();
+    return d;
+}
+
 // v_mfma_f32_16x16x32_bf16 under the assumed fragment maps (see vc_device.h header).
 inline f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
     auto& w = vc_emu::g_cur->blk->waves[vc_emu::g_cur->wave];

@@ -255,6 +255,49 @@ def check_gemv_fp8(be, M, N, K, epi, norm=False, seed=0):
     return e
 
 
+def check_gemm_f8(be, M, N, K, epi, seed=0, ws_mb=0):
+    """W8A8 prefill GEMM: the device's activation quantiser equals vcoder_amd/quant.py row for row (bytes + scales), the
+    row-major weight bytes equal quant.quantize_rows, and the e4m3 x e4m3 MFMA GEMM equals A_eff @ W_eff^T (exact
+    products, fp32 accumulation) through the epilogue."""
+    from vcoder_amd import quant
+
+    rng = np.random.RandomState(seed)
+    A = rng.randn(M, K) * np.exp2(rng.randint(-4, 5, size=(M, 1)))
+    A[rng.randint(M)] = 0.0
+    A[rng.randint(M), rng.randint(K)] = 300.0     # a massive activation: the rest of the row loses bits
+    A = bf16_round(A)
+    W = bf16_round(rng.randn(N, K) * 0.05 * np.exp2(rng.randint(-3, 3, size=(N, 1))))
+    qa, sa, a_eff = quant.quantize_rows(A)
+    qw, sw, w_eff = quant.quantize_rows(W)
+    Ad, Q, sad = be.bf16(A), be.zeros((M, K), "u8"), be.zeros((M,), "f32")
+    _call(be, "vck_quant_act_rows", Ad, K, Q, sad, M, K)
+    Wb, Wq, swd, Wrow = be.bf16(W), be.zeros((N * K,), "u8"), be.zeros((N,), "f32"), be.zeros((N, K), "u8")
+    _call(be, "vck_quantize_fp8_rows", Wb, Wq, swd, Wrow, N, K)
+    host = lambda t: np.asarray(t.cpu().numpy() if hasattr(t, "cpu") else t)
+    assert np.array_equal(host(Q), qa), "activation bytes differ from quant.quantize_rows"
+    assert np.array_equal(be.host_f32(sad), sa), "activation row scales differ"
+    assert np.array_equal(host(Wrow), qw), "row-major weight bytes differ from quant.quantize_rows"
+    assert np.array_equal(host(Wq), quant.pack_supertiles(qw))
+    t = torch.from_numpy(a_eff.astype(np.float64) @ w_eff.T.astype(np.float64)).float()
+    if epi == 0:
+        out = be.zeros((M, N), "bf16")
+    elif epi == 4:
+        r0 = rng.randn(M, N).astype(np.float32)
+        out = be.f32(r0.copy())
+        t = t + torch.from_numpy(r0)
+    else:
+        out = be.zeros((M, N // 2), "bf16")
+        t = torch.nn.functional.silu(t[:, 0::2]) * t[:, 1::2]
+    ws = be.zeros((max(ws_mb, 1) << 18,), "f32")
+    be.lib.vck_gemm_f8(be.ptr(Q), be.ptr(sad), be.ptr(Wrow), be.ptr(swd), be.ptr(out), M, N, K, N // 2 if epi == 5 else N, epi,
+                       be.ptr(ws) if ws_mb else None, ctypes.c_size_t(ws_mb << 20), None)
+    be.sync()
+    e = rel_err(be.host_f32(out), t.numpy())
+    tol = 2 ** -8 if epi in (0, 5) else 2e-5
+    assert e < tol, f"gemm_f8 M{M} N{N} K{K} epi{epi}: rel err {e}"
+    return e
+
+
 def check_gemv_splitk(be, M, N, K, ksplit, seed=0):
     """Split-K RESID form (o_proj / down): x += h @ W^T with ssq partials and the xg operand published by the tile's last
     arriver; equal to the unsplit launch up to fp32 summation order, bit-identical across repeated launches, and the

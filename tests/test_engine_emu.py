@@ -35,9 +35,12 @@ def test_device_preprocessing_matches_pil(emu_lib, tmp_path):
     pc.check_against_hf_processor(eng, tmp_path)
 
 
-def test_fp8_weight_format(emu_lib):
-    """W8A16 decoder weights through the emulator: quantise-at-finalize, byte-streaming GEMV, strict + fast paths."""
-    r = e2e_cases.check_fp8_weights("ds_img_only", lib=emu_lib, n_new=4)
+@pytest.mark.parametrize("fmt", ["w8a16", "fp8"])
+def test_fp8_weight_format(emu_lib, fmt):
+    """W8A16 decoder weights through the emulator: quantise-at-finalize, byte-streaming GEMV, strict + fast paths;
+    'fp8' adds the W8A8 prefill (activation rows quantised per token, e4m3 x e4m3 GEMM)."""
+    r = e2e_cases.check_fp8_weights("ds_img_only", lib=emu_lib, n_new=4, fmt=fmt)
+    print(fmt, r)
     assert r["strict_err"] < 1e-4
 
 

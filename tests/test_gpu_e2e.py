@@ -272,7 +272,7 @@ def test_load_pretrained_model_from_hf_layout(tmp_path):
                            eos_token_id=-1)
     eng8 = HipEngine(cfg)
     eng8.load_synthetic(42)
-    eng8.set_weight_format("fp8")
+    eng8.set_weight_format("fp8")   # load_8bit = the fp8 configuration (W8A8 prefill, W8A16 decode steps)
     eng8.finalize()
     ref8 = eng8.generate_greedy(ids, imgs, segs, deps, max_new_tokens=4)
     assert np.array_equal(out8[:, ids.shape[1]:].numpy(), ref8)
@@ -310,16 +310,20 @@ def test_device_preprocessing_matches_pil(tmp_path):
     eng.close()
 
 
-@pytest.mark.parametrize("name", ["ds_img_depth_seg", "vc_img_seg"])
-def test_fp8_weight_format(name):
-    """W8A16 decoder weights (BASELINE configs[4] weight format) on the tiny fixtures: strict + fast paths."""
-    r = e2e_cases.check_fp8_weights(name, n_new=8)
-    print(f"fp8 weights {name}: {r}")
+@pytest.mark.parametrize("name,fmt", [("ds_img_depth_seg", "w8a16"), ("vc_img_seg", "w8a16"), ("ds_img_depth_seg", "fp8"),
+                                      ("vc_img_seg", "fp8")])
+def test_fp8_weight_format(name, fmt):
+    """fp8-e4m3 decoder weights (BASELINE configs[4]) on the tiny fixtures: strict + fast paths; 'fp8' = W8A8 prefill on
+    the K=128 scaled MFMA against the oracle that quantises the same activation rows."""
+    r = e2e_cases.check_fp8_weights(name, n_new=8, fmt=fmt)
+    print(f"{fmt} weights {name}: {r}")
 
 
-def test_fp8_weights_true_dims_against_oracle():
-    """13b geometry (D 5120, F 13824, 2 layers), B=2: the device quantiser + byte-streaming GEMV against the bf16-emulating
-    oracle run on the host-quantised effective weights (vcoder_amd/quant.py)."""
+@pytest.mark.parametrize("fmt", ["w8a16", "fp8"])
+def test_fp8_weights_true_dims_against_oracle(fmt):
+    """13b geometry (D 5120, F 13824, 2 layers), B=1: the device quantisers + byte-streaming GEMV (+ for 'fp8' the
+    e4m3 x e4m3 prefill GEMMs) against the bf16-emulating oracle run on the host-quantised effective weights
+    (vcoder_amd/quant.py) and, for 'fp8', quantising the same activation rows."""
     import torch
     import cpu_ref
     from vcoder_amd import quant
@@ -330,13 +334,13 @@ def test_fp8_weights_true_dims_against_oracle():
     sd = quant.effective_state_dict(synth.synth_state_dict(cfg, 13))
     eng = HipEngine(cfg)
     eng.load_synthetic(13)
-    eng.set_weight_format("fp8")
+    eng.set_weight_format(fmt)
     eng.finalize()
     ids = synth.synth_prompt_ids(cfg.vocab_size, "vcoder_ds", sample=1)[None]
     imgs, segs, deps = synth.synth_batch(1, 336, first=1)
     last, _, S = eng.prefill(ids, imgs, segs, deps)
     lg2, _ = eng.decode_step(np.argmax(last, -1).astype(np.int32))
-    om = cpu_ref.OracleModel(cfg, sd, emu_bf16=True)
+    om = cpu_ref.OracleModel(cfg, sd, emu_bf16=True, act_fp8=(fmt == "fp8"))
     t = torch.from_numpy
     with torch.no_grad():
         o_last, cache = om.forward(ids.tolist(), t(imgs), t(segs), t(deps), last_only=True)
@@ -344,7 +348,7 @@ def test_fp8_weights_true_dims_against_oracle():
     o_last, o_lg2 = o_last[:, -1].numpy(), o_lg2[:, -1].numpy()
     e1, e2 = np.abs(last - o_last).max(), np.abs(lg2 - o_lg2).max()
     scale = np.abs(o_last).max()
-    print(f"fp8 true-dims parity: |logits|max={scale:.3f} prefill err={e1:.4f} decode(fp8 gemv) err={e2:.4f}")
+    print(f"{fmt} true-dims parity: |logits|max={scale:.3f} prefill err={e1 / scale:.2e} decode(fp8 gemv) err={e2 / scale:.2e} (relative)")
     # measured on MI355X: 8.7e-3 (prefill) / 1.23e-2 (decode, fp8 GEMV) relative; tolerance = 2x measured
     assert e1 < 2.5e-2 * scale and e2 < 2.5e-2 * scale
     eng.close()

@@ -36,6 +36,15 @@ def test_gemv_fp8(be, M, N, K, epi, norm):
     kc.check_gemv_fp8(be, M, N, K, epi, norm)
 
 
+@pytest.mark.parametrize("M,N,K,epi,ws", [(1216, 12288, 4096, 0, 0), (1216, 4096, 4096, 4, 0), (1216, 22016, 4096, 5, 0),
+                                          (1216, 4096, 11008, 4, 0), (9728, 4096, 4096, 4, 64), (9728, 12288, 4096, 0, 64),
+                                          (2432, 5120, 13824, 4, 64), (70, 272, 384, 0, 0), (16, 16, 128, 0, 0)])
+def test_gemm_f8(be, M, N, K, epi, ws):
+    """W8A8 prefill GEMM on v_mfma_scale_f32_16x16x128_f8f6f4 at the 7b / 13b decoder shapes (incl. split-K remainder
+    rounds): quantisers bit-identical to vcoder_amd/quant.py, products exact, fp32 accumulation."""
+    kc.check_gemm_f8(be, M, N, K, epi, ws_mb=ws)
+
+
 @pytest.mark.parametrize("M,N,K,ks", [(8, 4096, 4096, 2), (8, 4096, 11008, 3), (16, 5120, 13824, 4), (16, 5120, 5120, 4),
                                       (3, 48, 320, 3)])
 def test_gemv_splitk(be, M, N, K, ks):

@@ -37,6 +37,16 @@ def test_gemv_fp8(be, M, N, K, epi, norm):
     kc.check_gemv_fp8(be, M, N, K, epi, norm)
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(100, 144, 128, 0), (300, 272, 256, 4), (70, 528, 384, 5), (16, 16, 128, 0)])
+def test_gemm_f8(be, M, N, K, epi):
+    kc.check_gemm_f8(be, M, N, K, epi)
+
+
+def test_gemm_f8_splitk_remainder_round(be):
+    """one full round of 256 tiles + 4 remainder tiles cut into K-slices; scales applied by the fix-up launch"""
+    kc.check_gemm_f8(be, 1000 + 24, 16640 - 16, 256, 0, seed=3, ws_mb=4)
+
+
 @pytest.mark.parametrize("M,N,K,ks", [(8, 64, 512, 2), (16, 48, 320, 3), (3, 32, 1024, 4), (8, 32, 64, 4)])
 def test_gemv_splitk(be, M, N, K, ks):
     kc.check_gemv_splitk(be, M, N, K, ks)

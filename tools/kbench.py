@@ -49,6 +49,33 @@ def bench_gemm():
         print(f"gemm+ws {name:9s}                         : {us:9.1f} us  {2 * M * N * K / us / 1e6:7.1f} TFLOP/s", flush=True)
 
 
+def bench_gemm_f8():
+    """W8A8 prefill linears (weight format 2): the activation quantiser and the e4m3 x e4m3 GEMM, next to the bf16 GEMM of the
+    same shape (7b B=8 and 13b B=16 prefill shapes)."""
+    ws = torch.zeros(16 << 20, device=dev)
+    for (M, N, K, epi, name) in [(9728, 12288, 4096, 0, "7b qkv"), (9728, 4096, 4096, 4, "7b o"),
+                                 (9728, 22016, 4096, 5, "7b gate-up"), (9728, 4096, 11008, 4, "7b down"),
+                                 (19456, 15360, 5120, 0, "13b qkv"), (19456, 5120, 5120, 4, "13b o"),
+                                 (19456, 27648, 5120, 5, "13b gate-up"), (19456, 5120, 13824, 4, "13b down")]:
+        A, W = bf16(M, K), bf16(N, K, scale=0.02)
+        out = torch.zeros((M, N), dtype=torch.float32 if epi in (3, 4) else torch.bfloat16, device=dev)
+        ldo = N // 2 if epi == 5 else N
+        us16 = timeit(lambda: lib.vck_gemm_ws(P(A), P(W), None, P(out), M, N, K, K, K, ldo, epi, P(ws), C.c_size_t(64 << 20), None),
+                      iters=10)
+        Q = torch.zeros((M, K), dtype=torch.uint8, device=dev)
+        sa = torch.zeros(M, device=dev)
+        Wq = torch.zeros(N * K, dtype=torch.uint8, device=dev)
+        Wrow = torch.zeros((N, K), dtype=torch.uint8, device=dev)
+        sw = torch.zeros(N, device=dev)
+        lib.vck_quantize_fp8_rows(P(W), P(Wq), P(sw), P(Wrow), N, K, None)
+        usq = timeit(lambda: lib.vck_quant_act_rows(P(A), K, P(Q), P(sa), M, K, None), iters=10)
+        us8 = timeit(lambda: lib.vck_gemm_f8(P(Q), P(sa), P(Wrow), P(sw), P(out), M, N, K, ldo, epi, P(ws), C.c_size_t(64 << 20),
+                                             None), iters=10)
+        fl = 2 * M * N * K / 1e6
+        print(f"gemm_f8 {name:12s} M{M} N{N} K{K}: bf16 {us16:8.1f} us {fl / us16:7.1f} TF | quant {usq:6.1f} us "
+              f"({M * K * 3 / usq / 1e3:6.0f} GB/s) + e4m3 {us8:8.1f} us {fl / us8:7.1f} TF  => x{us16 / (usq + us8):.2f}", flush=True)
+
+
 def bench_gemv():
     M = 8
     for (N, K, epi, name) in [(12288, 4096, 0, "qkv"), (4096, 4096, 2, "o"), (22016, 4096, 3, "gate-up"),
@@ -287,7 +314,9 @@ if __name__ == "__main__":
         bench_gemv_rows()
     if "dattn_rows" in what:
         bench_dattn_rows()
+    if "gemm_f8" in what:
+        bench_gemm_f8()
     for w in what:
         {"gemm": bench_gemm, "gemv": bench_gemv, "attn": bench_attn, "dattn": bench_dattn,
          "gemv_fp8": lambda: None, "gemv13": lambda: None, "gemv_pair": lambda: None, "gemv_rows": lambda: None,
-         "dattn_rows": lambda: None}[w]()
+         "dattn_rows": lambda: None, "gemm_f8": lambda: None}[w]()

@@ -551,7 +551,8 @@ void launch_gemv(const GemvArgs& a0, int epilogue, hipStream_t s) {
 //   s_n = 2^e, e = the smallest integer with absmax_n <= 448 * 2^e     (power of two -> W/s and q*s are exact)
 //   q   = e4m3(W / s_n)  (RNE)  -> packed super-tile layout for gemv_kernel<FP8>
 //   W  <- bf16(q * s_n)  IN PLACE, so the prefill GEMMs (bf16 row-major) see exactly the weights decode sees.
-__global__ __launch_bounds__(256) void quantize_fp8_kernel(bf16_t* W, uint8_t* Wq, float* scale, int N, int K) {
+//   Wrow (optional): the same bytes row-major [N, K] — the weight operand of the e4m3 x e4m3 prefill GEMM.
+__global__ __launch_bounds__(256) void quantize_fp8_kernel(bf16_t* W, uint8_t* Wq, float* scale, int N, int K, uint8_t* Wrow) {
     __shared__ float red[4];
     const int n = blockIdx.x, tid = threadIdx.x;
     bf16_t* row = W + (size_t)n * K;
@@ -588,10 +589,53 @@ __global__ __launch_bounds__(256) void quantize_fp8_kernel(bf16_t* W, uint8_t* W
         st16(row + c * 16 + 8, u32x4{o[4], o[5], o[6], o[7]});
         const int st = c >> 2, lane = (n & 15) + 16 * (c & 3);
         st16(Wq + (((size_t)(n >> 4) * nst + st) * 64 + lane) * 16, u32x4{q[0], q[1], q[2], q[3]});
+        if (Wrow) st16(Wrow + (size_t)n * K + c * 16, u32x4{q[0], q[1], q[2], q[3]});
     }
 }
-void launch_quantize_fp8(bf16_t* W, uint8_t* Wq, float* scale, int N, int K, hipStream_t s) {
-    VC_LAUNCH(quantize_fp8_kernel, dim3((unsigned)N), dim3(256), 0, s, W, Wq, scale, N, K);
+void launch_quantize_fp8(bf16_t* W, uint8_t* Wq, float* scale, int N, int K, hipStream_t s, uint8_t* Wrow) {
+    VC_LAUNCH(quantize_fp8_kernel, dim3((unsigned)N), dim3(256), 0, s, W, Wq, scale, N, K, Wrow);
+}
+
+// Activation operand of the e4m3 x e4m3 prefill GEMM: every token row of A [M, lda] (bf16) gets its own power-of-two
+// scale by the rule of the weight rows (s_m = 2^e, the smallest e with max|A[m]| <= 448 * 2^e; 1 for an all-zero row) and
+// is stored as q = e4m3(A[m] / s_m) in Q [M, K].  Same software encode as the weights, so the host restatement
+// (vcoder_amd/quant.py: quantize_rows) gives identical bytes.
+__global__ __launch_bounds__(256) void quant_act_rows_kernel(const bf16_t* A, int lda, uint8_t* Q, float* scale, int K) {
+    __shared__ float red[4];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const bf16_t* row = A + (size_t)m * lda;
+    float amax = 0.f;
+    for (int c = tid; c < (K >> 3); c += 256) {
+        const u32x4 v = ld16(row + c * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(bf2f_lo(v[e])), fabsf(bf2f_hi(v[e]))));
+    }
+    amax = wave_max(amax);
+    if ((tid & 63) == 0) red[tid >> 6] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    int e = 0;
+    if (amax > 0.f) {
+        const uint32_t u = __builtin_bit_cast(uint32_t, amax);
+        e = (int)(u >> 23) - 127 - ((u & 0x007FFFFFu) <= 0x00600000u ? 8 : 7);
+    }
+    const float inv = __builtin_bit_cast(float, (uint32_t)(127 - e) << 23);
+    if (tid == 0) scale[m] = __builtin_bit_cast(float, (uint32_t)(e + 127) << 23);
+    for (int c = tid; c < (K >> 4); c += 256) {
+        const u32x4 v0 = ld16(row + c * 16), v1 = ld16(row + c * 16 + 8);
+        uint32_t q[4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t pk = j < 4 ? v0[j] : v1[j - 4];
+            const uint32_t a = f2fp8(bf2f_lo(pk) * inv), b = f2fp8(bf2f_hi(pk) * inv);
+            if ((j & 1) == 0) q[j >> 1] = a | (b << 8);
+            else q[j >> 1] |= (a << 16) | (b << 24);
+        }
+        st16(Q + (size_t)m * K + c * 16, u32x4{q[0], q[1], q[2], q[3]});
+    }
+}
+void launch_quant_act_rows(const bf16_t* A, int lda, uint8_t* Q, float* scale, int M, int K, hipStream_t s) {
+    VC_LAUNCH(quant_act_rows_kernel, dim3((unsigned)M), dim3(256), 0, s, A, lda, Q, scale, K);
 }
 
 // W [N,K] row-major -> packed fragment order (done once at weight-load time)

@@ -98,6 +98,7 @@ struct LlmLayer {
     bf16_t *qkv_w, *o_w, *gate_tmp, *up_tmp, *gu_w, *down_w;  // row-major (prefill GEMM)
     bf16_t *qkv_p, *o_p, *gu_p, *down_p;                      // MFMA-fragment packed (decode GEMV); e4m3 bytes if W8A16
     float *qkv_s = nullptr, *o_s = nullptr, *gu_s = nullptr, *down_s = nullptr;  // W8A16 per-output-row scales
+    uint8_t *qkv_q = nullptr, *o_q = nullptr, *gu_q = nullptr, *down_q = nullptr;  // weight format 2: e4m3 bytes, row-major
 };
 struct Projector {
     int depth = 0;
@@ -114,7 +115,8 @@ struct vc_model {
     bool finalized = false;
     bool owns_weights = true;
     int precision = 0;  // 0: bf16 MFMA fast path; 1: strict fp32 path (strict.hip)
-    int weight_format = 0;  // 0: bf16; 1: W8A16 — decoder linears stored as e4m3 + per-row scales for the decode GEMV
+    int weight_format = 0;  // 0: bf16; 1: W8A16 — decoder linears stored as e4m3 + per-row scales for the decode GEMV;
+                            // 2: fp8 — 1 + the prefill GEMMs run e4m3 x e4m3 on the K=128 scaled MFMA (W8A8)
     Buf s_cols, s_patches, s_vx, s_vxn, s_vqkv, s_vq, s_vk, s_vv, s_vattn, s_vh, s_sel, s_mid, s_feats;
     Buf s_xn, s_qkv, s_q, s_attn, s_h, s_kc, s_vc, s_xl;
     Buf pp_src, pp_sq, pp_tmp, pp_out, pp_tab, pp_f32;
@@ -144,6 +146,7 @@ struct vc_model {
     int layer_limit = 0;          // > 0: a prefill evaluates only the first layer_limit decoder layers (vc_model_set_layer_limit)
     // LLM workspace
     Buf x, xn, qkv, q, attn, h, kc, vc, vt_pre, row_src, last_idx, xl, logits_all;
+    Buf a8, a8_scale;             // weight format 2: e4m3 activation rows of the current prefill GEMM + their scales
     int capB = 0, capS = 0;  // KV capacity
     int curB = 0, curS = 0, cur_pos = -1;
     // decode state of this session's own loop (vc_prefill / vc_decode_step, strict mode, generate with the pool off)
@@ -361,6 +364,22 @@ void gemm(vc_model* m, const bf16_t* A, const bf16_t* W, const float* bias, void
         a.ws = m->gemm_ws.as<float>();
         a.ws_bytes = m->gemm_ws.cap;
     }
+    launch_gemm(a, epi, m->st);
+}
+// weight format 2 (W8A8 prefill): the token rows of A are quantised to e4m3 with per-row power-of-two scales, then
+// out = epi((Q @ Wq^T) * a_scale[m] * w_scale[n]) on the K=128 scaled MFMA
+void gemm_f8(vc_model* m, const bf16_t* A, const uint8_t* Wq, const float* wscale, void* out, int M, int N, int K, int ldo,
+             int epi) {
+    launch_quant_act_rows(A, K, m->a8.as<uint8_t>(), m->a8_scale.as<float>(), M, K, m->st);
+    GemmArgs a{reinterpret_cast<const bf16_t*>(m->a8.p), reinterpret_cast<const bf16_t*>(Wq), nullptr, out, M, N, K, K, K, ldo};
+    if ((long)((M + 255) / 256) * ((N + 255) / 256) > 256) {
+        m->gemm_ws.ensure((size_t)64 << 20);
+        a.ws = m->gemm_ws.as<float>();
+        a.ws_bytes = m->gemm_ws.cap;
+    }
+    a.f8 = 1;
+    a.a_scale = m->a8_scale.as<float>();
+    a.w_scale = wscale;
     launch_gemm(a, epi, m->st);
 }
 // Everything one decode step touches besides the weights: the buffers of a session's own loop or of the shared pool.
@@ -789,6 +808,10 @@ void ensure_prefill_ws(vc_model* m, int B, int Scap) {
     m->q.ensure(Mrows * D * 2, true);
     m->attn.ensure(Mrows * D * 2);
     m->h.ensure(Mrows * F * 2);
+    if (m->weight_format == 2) {
+        m->a8.ensure(Mrows * std::max(D, F));
+        m->a8_scale.ensure(Mrows * 4);
+    }
     m->row_src.ensure(Mrows * 8);
     const int Bp = (int)rup(B, 16);
     m->last_idx.ensure(Bp * 4);
@@ -923,10 +946,12 @@ void run_prefill_layers(vc_model* m, const KvTarget& kv, int B, int S) {
     const int nl = m->layer_limit > 0 ? std::min(m->layer_limit, c.layers) : c.layers;
     const int Sr = (int)rup(S, 64);
     m->vt_pre.ensure((size_t)B * H * m->hd * Sr * 2, true);
+    const bool f8 = m->weight_format == 2;
     for (int l = 0; l < nl; ++l) {
         const LlmLayer& L = m->llm[l];
         launch_rmsnorm(m->x.as<float>(), L.in_norm, m->xn.as<bf16_t>(), M, D, c.rms_eps, m->st);
-        gemm(m, m->xn.as<bf16_t>(), L.qkv_w, nullptr, m->qkv.p, M, 3 * D, D, 3 * D, EPI_BF16);
+        if (f8) gemm_f8(m, m->xn.as<bf16_t>(), L.qkv_q, L.qkv_s, m->qkv.p, M, 3 * D, D, 3 * D, EPI_BF16);
+        else gemm(m, m->xn.as<bf16_t>(), L.qkv_w, nullptr, m->qkv.p, M, 3 * D, D, 3 * D, EPI_BF16);
         // K and V rows go to the cache (key-major: what the decode steps stream); the V^T tiles of this layer's flash
         // attention live in a per-call scratch [B,H,hd,Sr]
         QkvSplitArgs qa{m->qkv.as<bf16_t>(), m->q.as<bf16_t>(), kcache(m, kv, l), m->vt_pre.as<bf16_t>(), B, S, H, m->hd, S, kv.capS,
@@ -935,10 +960,16 @@ void run_prefill_layers(vc_model* m, const KvTarget& kv, int B, int S) {
         AttnArgs aa{m->q.as<bf16_t>(), kcache(m, kv, l), m->vt_pre.as<bf16_t>(), m->attn.as<bf16_t>(), B, H, S, m->hd, S, kv.capS, 1,
                     1.0f / sqrtf((float)m->hd), Sr};
         launch_attention(aa, m->st);
-        gemm(m, m->attn.as<bf16_t>(), L.o_w, nullptr, m->x.p, M, D, D, D, EPI_RESID_F32);
+        if (f8) gemm_f8(m, m->attn.as<bf16_t>(), L.o_q, L.o_s, m->x.p, M, D, D, D, EPI_RESID_F32);
+        else gemm(m, m->attn.as<bf16_t>(), L.o_w, nullptr, m->x.p, M, D, D, D, EPI_RESID_F32);
         launch_rmsnorm(m->x.as<float>(), L.post_norm, m->xn.as<bf16_t>(), M, D, c.rms_eps, m->st);
-        gemm(m, m->xn.as<bf16_t>(), L.gu_w, nullptr, m->h.p, M, 2 * F, D, F, EPI_SWIGLU);
-        gemm(m, m->h.as<bf16_t>(), L.down_w, nullptr, m->x.p, M, D, F, D, EPI_RESID_F32);
+        if (f8) {
+            gemm_f8(m, m->xn.as<bf16_t>(), L.gu_q, L.gu_s, m->h.p, M, 2 * F, D, F, EPI_SWIGLU);
+            gemm_f8(m, m->h.as<bf16_t>(), L.down_q, L.down_s, m->x.p, M, D, F, D, EPI_RESID_F32);
+        } else {
+            gemm(m, m->xn.as<bf16_t>(), L.gu_w, nullptr, m->h.p, M, 2 * F, D, F, EPI_SWIGLU);
+            gemm(m, m->h.as<bf16_t>(), L.down_w, nullptr, m->x.p, M, D, F, D, EPI_RESID_F32);
+        }
     }
 }
 
@@ -1445,10 +1476,13 @@ VC_API int vc_model_set_precision(vc_model* m, int mode) {
 }
 
 /* 0: bf16 weights (default).  1: W8A16 — q/k/v/o/gate/up/down of every decoder layer are quantised at finalize to OCP
- * e4m3 with a per-output-row power-of-two scale (BASELINE config C5); embeddings, lm_head, norms, the CLIP tower and the
- * adapters stay bf16/fp32.  Must be called before vc_model_finalize. */
+ * e4m3 with a per-output-row power-of-two scale; embeddings, lm_head, norms, the CLIP tower and the adapters stay
+ * bf16/fp32.  2: fp8 (BASELINE config C5, "CDNA4 fp8 MFMA") — the same weights; the cached decode steps stream the bytes
+ * as in 1 (bf16 activations), and the prefill's decoder linears additionally quantise their activation rows to e4m3
+ * (per-token power-of-two scale) and run e4m3 x e4m3 on v_mfma_scale_f32_16x16x128_f8f6f4 at twice the bf16 MFMA rate.
+ * Must be called before vc_model_finalize. */
 VC_API int vc_model_set_weight_format(vc_model* m, int fmt) {
-    if (!m || (fmt != 0 && fmt != 1)) return VC_ERR_INVALID;
+    if (!m || fmt < 0 || fmt > 2) return VC_ERR_INVALID;
     if (m->finalized) return VC_ERR_STATE;
     m->weight_format = fmt;
     return VC_OK;
@@ -1474,24 +1508,27 @@ VC_API int vc_model_finalize(vc_model* m) {
     const int D = c.hidden, F = c.ffn, V = c.vocab;
     // decode copy of one decoder linear: MFMA-packed bf16, or (W8A16) e4m3 super-tiles + per-row scales — the quantiser
     // also rewrites the row-major bf16 matrix with the dequantised values so prefill and decode share one set of weights
-    auto decode_copy = [&](bf16_t* W, int N, int K, bf16_t*& Wp, float*& Ws) {
-        if (m->weight_format == 1) {
+    auto decode_copy = [&](bf16_t* W, int N, int K, bf16_t*& Wp, float*& Ws, uint8_t*& Wq) {
+        if (m->weight_format >= 1) {
             Wp = reinterpret_cast<bf16_t*>(walloc<uint8_t>(m, (size_t)N * K));
             Ws = walloc<float>(m, N);
-            launch_quantize_fp8(W, reinterpret_cast<uint8_t*>(Wp), Ws, N, K, m->st);
+            Wq = m->weight_format == 2 ? walloc<uint8_t>(m, (size_t)N * K) : nullptr;
+            launch_quantize_fp8(W, reinterpret_cast<uint8_t*>(Wp), Ws, N, K, m->st, Wq);
         } else {
             Wp = walloc<bf16_t>(m, (size_t)N * K);
             launch_pack_weight(W, Wp, N, K, m->st);
         }
     };
-    if (m->weight_format == 1)
+    if (m->weight_format >= 1)
         REQUIRE(D % 64 == 0 && F % 64 == 0, VC_ERR_INVALID, "W8A16 needs hidden and ffn sizes divisible by 64");
+    if (m->weight_format == 2)
+        REQUIRE(D % 128 == 0 && F % 128 == 0, VC_ERR_INVALID, "the fp8 prefill GEMM needs hidden and ffn sizes divisible by 128");
     for (auto& L : m->llm) {
         launch_interleave_rows(L.gate_tmp, L.up_tmp, L.gu_w, F, D, m->st);
-        decode_copy(L.qkv_w, 3 * D, D, L.qkv_p, L.qkv_s);
-        decode_copy(L.o_w, D, D, L.o_p, L.o_s);
-        decode_copy(L.gu_w, 2 * F, D, L.gu_p, L.gu_s);
-        decode_copy(L.down_w, D, F, L.down_p, L.down_s);
+        decode_copy(L.qkv_w, 3 * D, D, L.qkv_p, L.qkv_s, L.qkv_q);
+        decode_copy(L.o_w, D, D, L.o_p, L.o_s, L.o_q);
+        decode_copy(L.gu_w, 2 * F, D, L.gu_p, L.gu_s, L.gu_q);
+        decode_copy(L.down_w, D, F, L.down_p, L.down_s, L.down_q);
     }
     m->lm_head_p = walloc<bf16_t>(m, (size_t)V * D);
     launch_pack_weight(m->lm_head, m->lm_head_p, V, D, m->st);
@@ -2492,7 +2529,7 @@ VC_API int vc_profile_decode_gemv(vc_model* m, int B, int reps, int* launches, d
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, m->ev[0], m->ev[1]));
     const int n = 4 * c.layers + 1;
-    const double wb = m->weight_format == 1 ? 1.0 : 2.0;  // bytes per decoder-linear weight (lm_head stays bf16)
+    const double wb = m->weight_format >= 1 ? 1.0 : 2.0;  // bytes per decoder-linear weight (lm_head stays bf16)
     const double bytes = wb * (double)c.layers * (4.0 * D * D + 3.0 * D * F) + 2.0 * (double)D * c.vocab;
     if (launches) *launches = n;
     if (avg_us) *avg_us = (double)ms * 1e3 / ((double)reps * n);

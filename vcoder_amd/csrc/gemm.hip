@@ -18,6 +18,7 @@
 
 #include "vc_device.h"
 #include <algorithm>
+#include <stdexcept>
 
 #include "kernels.h"
 
@@ -306,9 +307,16 @@ VC_DEV void store_out(const GemmArgs& p, int m, int n, f32x4 v) {
 //     s_setprio 1) overlap the other group's fragment reads + DMA issue; barriers are bare s_barrier.
 // LDS-DMA data is ordered for a ds_read only by the issuing wave's vmcnt wait followed by a barrier the reader passes;
 // the r=3 wait precedes that phase's first barrier and the first read of the retired buffer is a phase later.
-template <int EPI>
+//
+// F8 = true: the same schedule over OCP e4m3 operands (activations quantised per token row, weights per output row, both
+// with power-of-two scales): a 128-byte tile row is now ONE K = 128 step of v_mfma_scale_f32_16x16x128_f8f6f4 (unit
+// block scales; twice the bf16 MFMA rate) instead of two K = 32 bf16 steps — identical bytes, LDS layout, DMA pattern
+// and MFMA cycles per k-tile, half the k-tiles.  The lane's 32 consecutive k are chunks 2*(lane/16), 2*(lane/16)+1 of
+// its row.  The epilogue multiplies the fp32 accumulator by a_scale[m] * w_scale[n] (exact: powers of two).
+template <int EPI, bool F8 = false>
 __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     constexpr int HALF = 128 * 128, TILE = 4 * HALF;  // bytes
+    constexpr int ES = F8 ? 1 : 2;                    // bytes per operand element; a k-tile is 128 bytes of every row
     constexpr int SY0 = 0, SX0 = HALF, SY1 = 2 * HALF, SX1 = 3 * HALF;
     VC_DYNAMIC_SMEM(char, smem);  // [2][Y0 | X0 | Y1 | X1]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -327,7 +335,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     int tm, tn;
     tile_from_pid(pid, tiles_m, tiles_n, tm, tn, p.tile_group);
     const int m0 = tm * 256, n0 = tn * 256;
-    const int nk_all = p.K / BK;
+    const int nk_all = p.K * ES / 128;
     const int kt_first = (int)((long)ks * nk_all / KS);
     // DMA sources: every wave moves pieces {wave, 8 + wave} (8 swizzled rows = 1 KiB each) of every half-tile
     const char* x_src[2][2];
@@ -338,23 +346,23 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
         for (int i = 0; i < 2; ++i) {
             const int row = (i * 8 + wave) * 8 + (lane >> 3);
             const int sw = ((lane & 7) ^ (row & 7)) << 4;
-            x_src[h][i] = reinterpret_cast<const char*>(p.W + (size_t)min(n0 + h * 128 + row, p.N - 1) * p.ldw) + sw +
-                          (size_t)kt_first * (BK * 2);
-            y_src[h][i] = reinterpret_cast<const char*>(p.A + (size_t)min(m0 + h * 128 + row, p.M - 1) * p.lda) + sw +
-                          (size_t)kt_first * (BK * 2);
+            x_src[h][i] = reinterpret_cast<const char*>(p.W) + (size_t)min(n0 + h * 128 + row, p.N - 1) * p.ldw * ES + sw +
+                          (size_t)kt_first * 128;
+            y_src[h][i] = reinterpret_cast<const char*>(p.A) + (size_t)min(m0 + h * 128 + row, p.M - 1) * p.lda * ES + sw +
+                          (size_t)kt_first * 128;
         }
     const int nk = (int)((long)(ks + 1) * nk_all / KS) - kt_first;  // k-tiles of this workgroup
     auto stage_x = [&](int h, int kt) {
         if (kt >= nk) return;
         char* dst = smem + (kt & 1) * TILE + (h ? SX1 : SX0) + wave * 1024;
-        glds16(x_src[h][0] + (size_t)kt * (BK * 2), dst);
-        glds16(x_src[h][1] + (size_t)kt * (BK * 2), dst + 8192);
+        glds16(x_src[h][0] + (size_t)kt * 128, dst);
+        glds16(x_src[h][1] + (size_t)kt * 128, dst + 8192);
     };
     auto stage_y = [&](int h, int kt) {
         if (kt >= nk) return;
         char* dst = smem + (kt & 1) * TILE + (h ? SY1 : SY0) + wave * 1024;
-        glds16(y_src[h][0] + (size_t)kt * (BK * 2), dst);
-        glds16(y_src[h][1] + (size_t)kt * (BK * 2), dst + 8192);
+        glds16(y_src[h][0] + (size_t)kt * 128, dst);
+        glds16(y_src[h][1] + (size_t)kt * 128, dst + 8192);
     };
     f32x4 acc[2][4][2][2];  // [x half][i][y half][j]
 #pragma unroll
@@ -372,22 +380,38 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fx[i][ks] = ld16(base + (h ? SX1 : SX0) + swz(g * 64 + i * 16 + frow, ks * 4 + fchunk));
+            for (int ks = 0; ks < 2; ++ks)
+                fx[i][ks] = ld16(base + (h ? SX1 : SX0) + swz(g * 64 + i * 16 + frow, F8 ? fchunk * 2 + ks : ks * 4 + fchunk));
     };
     auto read_y = [&](const char* base, int h) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fy[h][j][ks] = ld16(base + (h ? SY1 : SY0) + swz(q * 32 + j * 16 + frow, ks * 4 + fchunk));
+            for (int ks = 0; ks < 2; ++ks)
+                fy[h][j][ks] = ld16(base + (h ? SY1 : SY0) + swz(q * 32 + j * 16 + frow, F8 ? fchunk * 2 + ks : ks * 4 + fchunk));
     };
     auto quadrant = [&](int hx, int hy) {
         set_prio<1>();
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        if constexpr (F8) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[hx][i][hy][j] = mfma16(fx[i][ks], fy[hy][j][ks], acc[hx][i][hy][j]);
+                for (int j = 0; j < 2; ++j)
+                    acc[hx][i][hy][j] = mfma16_f8(fx[i][0], fx[i][1], fy[hy][j][0], fy[hy][j][1], acc[hx][i][hy][j]);
+            // the scaled-MFMA intrinsic is sunk by the optimiser (all 32 of a k-tile end up behind the loop's last barrier,
+            // out of their s_setprio brackets) unless its results are pinned here
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) pin_vgprs(acc[hx][i][hy][j]);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[hx][i][hy][j] = mfma16(fx[i][ks], fy[hy][j][ks], acc[hx][i][hy][j]);
+        }
         set_prio<0>();
     };
     // prologue: k-tile 0 complete, the first three half-tiles of k-tile 1 in flight
@@ -456,13 +480,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
             if (n >= p.N) continue;
             f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
             if (p.bias) bv = ld16f(p.bias + n);
+            f32x4 sw = f32x4{1.f, 1.f, 1.f, 1.f};
+            if constexpr (F8) sw = ld16f(p.w_scale + n);
 #pragma unroll
             for (int hy = 0; hy < 2; ++hy)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int m = m0 + hy * 128 + q * 32 + j * 16 + (lane & 15);
                     if (m >= p.M) continue;
-                    store_out<EPI>(p, m, n, acc[hx][i][hy][j] + bv);
+                    if constexpr (F8) store_out<EPI>(p, m, n, acc[hx][i][hy][j] * (sw * p.a_scale[m]) + bv);
+                    else store_out<EPI>(p, m, n, acc[hx][i][hy][j] + bv);
                 }
         }
 }
@@ -481,6 +508,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_fixup_kernel(GemmArgs p) {
     const float* base = p.ws + (size_t)r * p.sk_ks * 65536 + ml * 256 + nl;
     f32x4 v = ld16f(base);
     for (int k = 1; k < p.sk_ks; ++k) v = v + ld16f(base + (size_t)k * 65536);
+    if (p.f8) v = v * (ld16f(p.w_scale + n) * p.a_scale[m]);
     if (p.bias) v = v + ld16f(p.bias + n);
     store_out<EPI>(p, m, n, v);
 }
@@ -492,7 +520,51 @@ static void allow_big_lds_gemm(K kernel, size_t bytes) {
 #endif
 }
 
+// e4m3 x e4m3 (GemmArgs::f8): always the 8-phase kernel, any size (rows are clamped, stores masked)
+static void launch_gemm_f8(const GemmArgs& a, int epilogue, hipStream_t s) {
+    const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+    const size_t sh2 = 2 * (256 * 128 + 256 * 128);
+    static const int sk_on = getenv("VC_GEMM_SPLITK") ? atoi(getenv("VC_GEMM_SPLITK")) : 1;
+    static const int tile_group = getenv("VC_GEMM_GROUP") ? atoi(getenv("VC_GEMM_GROUP")) : 4;
+    static const int xcd_on = getenv("VC_GEMM_XCD") ? atoi(getenv("VC_GEMM_XCD")) : 1;
+    GemmArgs ask = a;
+    ask.tile_group = tile_group;
+    ask.xcd_remap_on = xcd_on;
+    ask.sk_full = (int)t256;
+    ask.sk_ks = 1;
+    const long rem = t256 % 256;
+    if (sk_on && a.ws && t256 > 256 && rem > 0 && rem <= 128) {
+        int ks = (int)std::min<long>(256 / rem, 8);
+        ks = std::min(ks, a.K / 128);
+        while (ks > 1 && (size_t)rem * ks * 65536 * 4 > a.ws_bytes) --ks;
+        if (ks > 1) {
+            ask.sk_full = (int)(t256 - rem);
+            ask.sk_ks = ks;
+        }
+    }
+    const dim3 gsk((unsigned)(ask.sk_ks > 1 ? ask.sk_full + rem * ask.sk_ks : t256)), b2(512);
+#define VC_G8(E)                                                                                       \
+    do {                                                                                               \
+        static bool once = false;                                                                      \
+        if (!once) {                                                                                   \
+            allow_big_lds_gemm(gemm_bf16_8phase_kernel<E, true>, sh2);                                 \
+            once = true;                                                                               \
+        }                                                                                              \
+        VC_LAUNCH((gemm_bf16_8phase_kernel<E, true>), gsk, b2, sh2, s, ask);                           \
+        if (ask.sk_ks > 1)                                                                             \
+            VC_LAUNCH((gemm_splitk_fixup_kernel<E>), dim3((unsigned)(rem * 64)), dim3(256), 0, s, ask); \
+    } while (0)
+    switch (epilogue) {
+        case EPI_BF16: VC_G8(EPI_BF16); break;
+        case EPI_RESID_F32: VC_G8(EPI_RESID_F32); break;
+        case EPI_SWIGLU: VC_G8(EPI_SWIGLU); break;
+        default: throw std::runtime_error("fp8 GEMM: epilogue not instantiated");
+    }
+#undef VC_G8
+}
+
 void launch_gemm(const GemmArgs& a, int epilogue, hipStream_t s) {
+    if (a.f8) return launch_gemm_f8(a, epilogue, s);
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const dim3 grid(tiles), block(256);
     const size_t shmem = 4 * TILE_BYTES;

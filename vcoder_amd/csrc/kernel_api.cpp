@@ -19,6 +19,19 @@ VCK_EXPORT void vck_gemm_ws(const uint16_t* A, const uint16_t* W, const float* b
     a.ws_bytes = ws_bytes;
     launch_gemm(a, epi, S(stream));
 }
+VCK_EXPORT void vck_gemm_f8(const uint8_t* A, const float* a_scale, const uint8_t* W, const float* w_scale, void* out, int M,
+                            int N, int K, int ldo, int epi, float* ws, size_t ws_bytes, void* stream) {
+    GemmArgs a{reinterpret_cast<const bf16_t*>(A), reinterpret_cast<const bf16_t*>(W), nullptr, out, M, N, K, K, K, ldo};
+    a.ws = ws;
+    a.ws_bytes = ws_bytes;
+    a.f8 = 1;
+    a.a_scale = a_scale;
+    a.w_scale = w_scale;
+    launch_gemm(a, epi, S(stream));
+}
+VCK_EXPORT void vck_quant_act_rows(const uint16_t* A, int lda, uint8_t* Q, float* scale, int M, int K, void* stream) {
+    launch_quant_act_rows(A, lda, Q, scale, M, K, S(stream));
+}
 VCK_EXPORT void vck_gemv(const uint16_t* X, const uint16_t* Wp, void* out, int M, int N, int K, int ldo, int epi,
                          void* stream) {
     GemvArgs a{};
@@ -59,6 +72,9 @@ VCK_EXPORT void vck_embed_tokens_ssq(const int* tok, const uint16_t* embed, floa
 }
 VCK_EXPORT void vck_quantize_fp8(uint16_t* W, uint8_t* Wq, float* scale, int N, int K, void* stream) {
     launch_quantize_fp8(W, Wq, scale, N, K, S(stream));
+}
+VCK_EXPORT void vck_quantize_fp8_rows(uint16_t* W, uint8_t* Wq, float* scale, uint8_t* Wrow, int N, int K, void* stream) {
+    launch_quantize_fp8(W, Wq, scale, N, K, S(stream), Wrow);
 }
 VCK_EXPORT void vck_pack_weight(const uint16_t* W, uint16_t* Wp, int N, int K, void* stream) {
     launch_pack_weight(W, Wp, N, K, S(stream));

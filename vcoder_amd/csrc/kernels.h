@@ -37,6 +37,11 @@ struct GemmArgs {
     size_t ws_bytes;
     int sk_full, sk_ks;
     int tile_group, xcd_remap_on;  // tile-order tuning knobs (launch_gemm fills them: VC_GEMM_GROUP / VC_GEMM_XCD)
+    // f8 != 0: A and W point at OCP e4m3 bytes (lda / ldw in elements = bytes, K % 128 == 0) and the accumulator is
+    // multiplied by a_scale[m] * w_scale[n] before bias / epilogue (EPI_BF16, EPI_RESID_F32, EPI_SWIGLU only)
+    int f8;
+    const float* a_scale;  // [M]
+    const float* w_scale;  // [N]
 };
 void launch_gemm(const GemmArgs& a, int epilogue, hipStream_t s);
 
@@ -80,7 +85,9 @@ struct GemvArgs {
 void launch_gemv(const GemvArgs& a, int epilogue, hipStream_t s);
 void launch_pack_weight(const bf16_t* W, bf16_t* Wp, int N, int K, hipStream_t s);
 // W [N,K] bf16 -> e4m3 packed + per-row scales; W is overwritten with the dequantised values (see decode.hip)
-void launch_quantize_fp8(bf16_t* W, uint8_t* Wq, float* scale, int N, int K, hipStream_t s);
+void launch_quantize_fp8(bf16_t* W, uint8_t* Wq, float* scale, int N, int K, hipStream_t s, uint8_t* Wrow = nullptr);
+// token rows of A [M, lda] bf16 -> e4m3 bytes Q [M, K] + per-row power-of-two scales (K % 16 == 0)
+void launch_quant_act_rows(const bf16_t* A, int lda, uint8_t* Q, float* scale, int M, int K, hipStream_t s);
 // interleave gate/up rows: out[2f] = gate[f], out[2f+1] = up[f]
 void launch_interleave_rows(const bf16_t* gate, const bf16_t* up, bf16_t* out, int F, int K, hipStream_t s);
 

@@ -95,6 +95,16 @@ VC_DEV f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
 }
 // v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain): A[i][k]: lane i+16k; B[k][j]: lane j+16k; D as for bf16
 VC_DEV f32x4 mfma16_f32(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+// v_mfma_scale_f32_16x16x128_f8f6f4 with both operands OCP e4m3 and every block scale 2^0 (E8M0 127): the K = 128 fp8
+// form that runs at twice the bf16 MFMA rate (the unscaled 16x16x32 fp8 MFMA runs AT the bf16 rate).  A lane holds 32
+// consecutive k of its row: A[i][k]: lane i + 16*(k/32), byte k%32 (a0 = bytes 0..15, a1 = 16..31); B likewise by
+// column; D as for bf16.  Both operands use the same k map, so the result does not depend on it.
+typedef int i32x8_hw __attribute__((ext_vector_type(8)));
+VC_DEV f32x4 mfma16_f8(u32x4 a0, u32x4 a1, u32x4 b0, u32x4 b1, f32x4 c) {
+    const i32x8_hw a = {(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
+    const i32x8_hw b = {(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b1[0], (int)b1[1], (int)b1[2], (int)b1[3]};
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+}
 VC_DEV int lane_id() { return (int)(threadIdx.x & 63); }
 template <class T> VC_DEV T shfl_xor(T v, int mask) { return __shfl_xor(v, mask, 64); }
 template <class T> VC_DEV T shfl(T v, int src) { return __shfl(v, src, 64); }
@@ -148,7 +158,10 @@ template <int N> VC_DEV void wait_vmcnt() {}
 template <int N> VC_DEV void wait_lgkmcnt() {}
 template <int P> VC_DEV void set_prio() {}
 VC_DEV void sched_fence() {}
+VC_DEV void pin_vgprs(f32x4&) {}
 #else
+// an empty volatile asm that "modifies" v: the instructions producing v cannot be moved past it
+VC_DEV void pin_vgprs(f32x4& v) { asm volatile("" : "+v"(v)); }
 VC_DEV void wg_barrier_raw() { __builtin_amdgcn_s_barrier(); }  // bare s_barrier: no implied vmcnt/lgkmcnt drain
 template <int N> VC_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 template <int N> VC_DEV void wait_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }

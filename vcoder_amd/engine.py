@@ -140,10 +140,13 @@ class HipEngine:
         self._check(self.lib.vc_model_set_precision(self._model, {"bf16": 0, "fast": 0, "strict": 1, "fp32": 1}[mode]))
 
     def set_weight_format(self, fmt: str):
-        """'bf16' (default) or 'fp8' (W8A16: decoder linears as e4m3 + per-row power-of-two scales, quantised at
-        finalize; see vcoder_amd/quant.py for the host restatement).  Before finalize()."""
-        self._check(self.lib.vc_model_set_weight_format(self._model, {"bf16": 0, "fp8": 1, "w8a16": 1}[fmt]))
-        self.weight_format = "fp8" if fmt != "bf16" else "bf16"
+        """'bf16' (default); 'w8a16': decoder linears as e4m3 + per-row power-of-two scales, quantised at finalize and
+        streamed as bytes by the decode steps, bf16 activations everywhere; 'fp8' (BASELINE configs[4]): the same weights,
+        and the prefill's decoder linears also quantise their activation rows to e4m3 and run on the K=128 scaled fp8 MFMA
+        (W8A8).  vcoder_amd/quant.py is the host restatement of both quantisers.  Before finalize()."""
+        code = {"bf16": 0, "w8a16": 1, "fp8": 2}[fmt]
+        self._check(self.lib.vc_model_set_weight_format(self._model, code))
+        self.weight_format = fmt
 
     def set_layer_limit(self, n_layers: int):
         """parity diagnostic: prefills evaluate only the first n decoder layers (0 = all)"""
