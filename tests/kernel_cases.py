@@ -293,7 +293,11 @@ def check_gemm_f8(be, M, N, K, epi, seed=0, ws_mb=0):
                        be.ptr(ws) if ws_mb else None, ctypes.c_size_t(ws_mb << 20), None)
     be.sync()
     e = rel_err(be.host_f32(out), t.numpy())
-    tol = 2 ** -8 if epi in (0, 5) else 2e-5
+    # fp32 outputs: the emulator's MFMA sums the 128 exact products of a step in fp32; the hardware's scaled MFMA aligns them
+    # to the largest and keeps ~13 bits below it (tools/experiments/f8_precision.py: 2e-5 of the row maximum on random
+    # operands, 1e-4 when one product dominates; measured here 3.2e-5 ... 3.9e-5) -> 1e-4
+    tol = 2 ** -8 if epi in (0, 5) else (2e-5 if be.name == "emu" else 1e-4)
+    print(f"gemm_f8 M{M} N{N} K{K} epi{epi}: rel err {e:.3e}")
     assert e < tol, f"gemm_f8 M{M} N{N} K{K} epi{epi}: rel err {e}"
     return e
 

@@ -201,13 +201,19 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
 // 16 lanes of a ds_read_b128 group — 16 rows, one chunk column — hit 16 distinct 16-byte bank slots.
 template <int WAVES, int NT, int R, int EPI, bool FP8, int XP = 2>
 __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
-    constexpr int MG = (XP + 1) / 2;
+#ifndef VC_GEMV_DBG
+#define VC_GEMV_DBG 0
+#endif
+    // timing experiments only (tools/experiments/gemv_rows_ab.sh; results are garbage): 1 = 32-row MFMA / LDS work on ONE
+    // fetched activation piece; 2 = all four pieces fetched, one MFMA row group
+    constexpr int XPL = (VC_GEMV_DBG == 1 && XP == 4) ? 1 : XP;
+    constexpr int MG = (VC_GEMV_DBG == 2 && XP == 4) ? 1 : (XP + 1) / 2;
     constexpr int KSH = FP8 ? 6 : 5;
     // k-tiles per ring slot: a slot always spans 64 k = one 128-byte line of every activation row: a PAIR of 32-wide bf16
     // k-tiles, or one 64-wide W8A16 super-tile
     constexpr int KPI = FP8 ? 1 : 2;
     constexpr int WB = KPI * NT;             // 1-KiB weight blocks per slot
-    constexpr int OPS = WB + XP;             // DMA instructions per slot
+    constexpr int OPS = WB + XPL;            // DMA instructions per slot
     constexpr int SLOT = OPS * 1024;
     static_assert(WAVES * R * SLOT >= WAVES * NT * MG * 1024, "the ring is re-used for the cross-wave reduction");
     static_assert(WAVES >= NT * MG, "one finishing wave per (tile, row group)");
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
             }
         }
 #pragma unroll
-        for (int x = 0; x < XP; ++x) {
+        for (int x = 0; x < XPL; ++x) {
             // the half line at the end of an odd-k-tile row holds only chunks 0..3: the other lanes re-read a valid chunk
             // (their values meet zeroed weights' partner: the consumer zeroes the activation fragment of that k-tile)
             const int c = (half_line && is >= kline_last) ? (xc[x] & 3) : xc[x];
@@ -272,7 +278,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
     auto xoff = [&](int q, int c) {
         const int row = 16 * q + m;
         const int pc = FP8 ? ((c >> 1) | ((c & 1) << 2)) : c;
-        return (WB + (row >> 3)) * 1024 + ((row & 7) * 8 + (pc ^ ((row >> 1) & 7))) * 16;
+        return (WB + (VC_GEMV_DBG == 1 ? 0 : (row >> 3))) * 1024 + ((row & 7) * 8 + (pc ^ ((row >> 1) & 7))) * 16;
     };
     auto consume = [&](int i, int slot) {
         const char* s = my + slot * SLOT;
@@ -437,7 +443,8 @@ template <int WAVES, int NT, int R, bool FP8, int XP>
 static void launch_gemv_dma_x(const GemvArgs& a, int epi, hipStream_t s) {
     const dim3 grid(((a.N / 16 + NT - 1) / NT) * (a.ksplit > 1 ? a.ksplit : 1)), block(WAVES * 64);
     constexpr size_t shmem = (size_t)WAVES * R * ((FP8 ? 1 : 2) * NT + XP) * 1024;
-    static_assert(shmem <= 160 * 1024, "ring exceeds the LDS of a CU");
+    // + the kernel's static ss_part[WAVES][16 * MG] floats
+    static_assert(shmem + WAVES * 16 * ((XP + 1) / 2) * 4 <= 160 * 1024, "ring exceeds the LDS of a CU");
 #define VC_GEMV_DMA(E)                                                                                                  \
     do {                                                                                                                \
         static bool once = false;                                                                                       \
@@ -488,8 +495,16 @@ static void launch_gemv_m32(const GemvArgs& a, int epilogue, hipStream_t s) {
             return;
         }
     }
-    if (tiles <= 256) launch_gemv_dma2<8, 1, FP8 ? 4 : 3, FP8>(a, epilogue, s);
-    else if (tiles <= 512) launch_gemv_dma2<4, 1, 3, FP8>(a, epilogue, s);
+    if (tiles <= 256) {
+        // W8A16 slots are 4 KiB (3 pieces) / 5 KiB (4 pieces): a 4-slot ring of the latter would need all 160 KiB + ss_part
+        if constexpr (FP8) {
+            if (a.M <= 24) {
+                launch_gemv_dma_x<8, 1, 4, true, 3>(a, epilogue, s);
+                return;
+            }
+        }
+        launch_gemv_dma2<8, 1, 3, FP8>(a, epilogue, s);
+    } else if (tiles <= 512) launch_gemv_dma2<4, 1, 3, FP8>(a, epilogue, s);
     else if (tiles <= 768 && !FP8 && geom == 0) launch_gemv_dma2<4, 1, 2, FP8>(a, epilogue, s);
     else launch_gemv_dma2<4, 2, 2, FP8>(a, epilogue, s);
 }

@@ -1855,6 +1855,14 @@ void pool_retire(vc_pool* p, PoolRequest* rq, bool failed, const std::string& er
     rq->cv.notify_all();
 }
 
+void pool_fail_all(vc_pool* p, const std::string& msg) {  // p->mu held
+    for (PoolRequest* rq : p->active) pool_retire(p, rq, true, msg);
+    for (PoolRequest* rq : p->pending) pool_retire(p, rq, true, msg);
+    p->active.clear();
+    p->pending.clear();
+    p->stop = true;
+}
+
 void pool_driver(vc_pool* p) {
     (void)hipSetDevice(p->device);
     t_stream = p->st;
@@ -1940,11 +1948,9 @@ void pool_driver(vc_pool* p) {
             retire_finished();
         }
     } catch (const Fail& f) {
-        for (PoolRequest* rq : p->active) pool_retire(p, rq, true, f.msg);
-        for (PoolRequest* rq : p->pending) pool_retire(p, rq, true, f.msg);
-        p->active.clear();
-        p->pending.clear();
-        p->stop = true;
+        pool_fail_all(p, f.msg);
+    } catch (const std::exception& e) {  // a refused kernel launch
+        pool_fail_all(p, e.what());
     }
 }
 

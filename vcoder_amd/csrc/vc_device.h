@@ -16,8 +16,22 @@
 #else
 #include <hip/hip_runtime.h>
 #define VC_DYNAMIC_SMEM(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
-#define VC_LAUNCH(kernel, grid, block, shmem, stream, ...) \
-    hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__)
+#include <stdexcept>
+#include <string>
+// a refused launch (too much LDS, bad grid ...) must not pass silently: the thread's stale last-error is dropped, the
+// kernel launched, and a fresh error raised as an exception the C entry points turn into a vc_status
+namespace vc {
+inline void check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) throw std::runtime_error(std::string("launch of ") + what + " failed: " + hipGetErrorString(e));
+}
+}
+#define VC_LAUNCH(kernel, grid, block, shmem, stream, ...)                       \
+    do {                                                                         \
+        (void)hipGetLastError();                                                 \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);     \
+        vc::check_launch(#kernel);                                               \
+    } while (0)
 #endif
 
 #define VC_DEV __device__ __forceinline__
