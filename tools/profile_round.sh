@@ -5,7 +5,8 @@
 #   2. SEPARATE rocprofv3 --pmc FETCH_SIZE passes over the two decode-step kernels at the row counts the bench runs them
 #      (tools/kbench.py gemv_rows / dattn_rows; counters and traces are never combined) -> HBM bytes per launch
 #      (tools/pmc_traffic.py, gfx950 x2 correction)
-#   3. SQ counters of the MFMA-bound kernels (GEMM, prefill / ViT attention) in their own pass
+#   3. SQ counters of the MFMA-bound kernels (bf16 and e4m3 GEMM, prefill / ViT attention) in their own pass
+#   4. kernel trace of the fp8 weight format on the 13b geometry (BASELINE configs[4])
 # usage: tools/profile_round.sh <tag>
 set -u
 TAG=${1:-rXX}
@@ -22,12 +23,17 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace1 -o ks -- pyth
 DB=$(find $OUT/${TAG}_trace1 -name "*.db" | head -1)
 python $ROOT/tools/rocpd_summary.py "$DB" $OUT/${TAG}_kernel_stats_one_batch.md > /dev/null 2>> $OUT/${TAG}_trace1.err
 rm -rf $OUT/${TAG}_trace1
+# BASELINE configs[4] weight format on the 13b geometry: W8A8 prefill (scaled fp8 MFMA) + W8A16 decode steps
+timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace8 -o ks -- python $ROOT/bench.py --model 13b --batch 16 --inflight 2 --weights fp8 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_trace8_bench.json 2> $OUT/${TAG}_trace8.err
+DB=$(find $OUT/${TAG}_trace8 -name "*.db" | head -1)
+python $ROOT/tools/rocpd_summary.py "$DB" $OUT/${TAG}_kernel_stats_13b_fp8.md > /dev/null 2>> $OUT/${TAG}_trace8.err
+rm -rf $OUT/${TAG}_trace8
 timeout 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/${TAG}_pmc -o pmc -- python $ROOT/tools/kbench.py gemv_rows dattn_rows > $OUT/${TAG}_pmc_kbench.txt 2> $OUT/${TAG}_pmc.err
 DB2=$(find $OUT/${TAG}_pmc -name "*.db" | head -1)
 python $ROOT/tools/pmc_summary.py "$DB2" > $OUT/${TAG}_pmc_summary.txt 2>> $OUT/${TAG}_pmc.err
 python $ROOT/tools/pmc_traffic.py "$DB2" $OUT/${TAG}_pmc_traffic.json >> $OUT/${TAG}_pmc_summary.txt 2>> $OUT/${TAG}_pmc.err
 rm -rf $OUT/${TAG}_pmc
-timeout 300 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d $OUT/${TAG}_pmcsq -o pmcsq -- python $ROOT/tools/kbench.py gemm attn > $OUT/${TAG}_pmcsq_kbench.txt 2> $OUT/${TAG}_pmcsq.err
+timeout 300 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d $OUT/${TAG}_pmcsq -o pmcsq -- python $ROOT/tools/kbench.py gemm attn gemm_f8 > $OUT/${TAG}_pmcsq_kbench.txt 2> $OUT/${TAG}_pmcsq.err
 DB3=$(find $OUT/${TAG}_pmcsq -name "*.db" | head -1)
 python $ROOT/tools/pmc_summary.py "$DB3" > $OUT/${TAG}_pmc_sq_summary.txt 2>> $OUT/${TAG}_pmcsq.err
 rm -rf $OUT/${TAG}_pmcsq
