@@ -221,7 +221,7 @@ def _device_run(cfg, fmt, ids, imgs, segs, deps, n_new, forced=None):
 # exactness on quantised operands is pinned in test_gpu_kernels.py (GEMM vs float64: 4e-5; quantisers bit-identical to
 # vcoder_amd/quant.py) and test_gpu_e2e.py.  Asserted here: the quantised paths still compute the SAME function (logit
 # vectors correlated with the bf16 path's), and a changed greedy choice is one whose bf16 margin was within the shift.
-MIN_LOGIT_CORRELATION = 0.5
+MIN_LOGIT_CORRELATION = 0.75   # measured: w8a16 min 0.913, fp8 min 0.863 (median 0.92 both)
 
 
 def test_fp8_formats_vs_bf16_full_depth_13b():

@@ -138,35 +138,35 @@ def test_strict_fp32_kernels(be):
 
 
 def test_alternate_kernel_variants():
-    """The non-default template variants (register-staged GEMM, 4x32 attention) stay correct: same cases in a
-    subprocess with the tuning knobs flipped (the library reads them once)."""
+    """The non-default template variants stay correct: the same cases in subprocesses with the tuning knobs flipped (the
+    library reads them once per process); the sweeps run side by side."""
     import os
     import subprocess
     import sys
 
-    env = dict(os.environ, VC_GEMM_VARIANT="0", VC_ATTN_VARIANT="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
-                        "test_gemm or test_attention"], env=env, capture_output=True, text=True)
-    assert r.returncode == 0, r.stdout[-2000:]
-    # tile-order knobs of the GEMM, cacheable weight loads of the GEMV
-    env = dict(os.environ, VC_GEMM_VARIANT="5", VC_GEMM_GROUP="2", VC_GEMM_XCD="0", VC_GEMV_WCACHED="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "test_gemm or test_gemv"],
-                       env=env, capture_output=True, text=True)
-    assert r.returncode == 0, "tile-order / cache-policy knobs: " + r.stdout[-2000:]
-    # deeper load windows of the decode attention
-    env = dict(os.environ, VC_DATTN_UK="16")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "test_fused_decode"],
-                       env=env, capture_output=True, text=True)
-    assert r.returncode == 0, "VC_DATTN_UK=16: " + r.stdout[-2000:]
-    # the register-staged GEMV (the LDS-DMA ring kernel is the default)
-    env = dict(os.environ, VC_GEMV_PATH="0")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
-                        "test_gemv or test_fused_decode"], env=env, capture_output=True, text=True)
-    assert r.returncode == 0, "VC_GEMV_PATH=0: " + r.stdout[-2000:]
-    # 5: the counted-vmcnt 8-phase 256x256 kernel forced onto every (small, ragged, 1-3 k-tile) case;
-    # 2: the one-barrier 256x256 kernel; 4: 256x256 as 4 waves x (128 x 128)
-    for v in ("5", "2", "4"):
-        env = dict(os.environ, VC_GEMM_VARIANT=v)
-        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "test_gemm"],
-                           env=env, capture_output=True, text=True)
-        assert r.returncode == 0, f"VC_GEMM_VARIANT={v}: " + r.stdout[-2000:]
+    plain_gemm = "test_gemm and not f8 and not splitk"
+    sweeps = [
+        # register-staged GEMM, 4 x 32 attention
+        (dict(VC_GEMM_VARIANT="0", VC_ATTN_VARIANT="1"), plain_gemm + " or test_attention"),
+        # 8 x 32 attention
+        (dict(VC_ATTN_VARIANT="2"), "test_attention"),
+        # tile-order knobs of the GEMM (8-phase kernel forced onto every small, ragged, 1-3 k-tile case; split-K rounds
+        # of the bf16 and the e4m3 form), cacheable weight loads of the GEMV
+        (dict(VC_GEMM_VARIANT="5", VC_GEMM_GROUP="2", VC_GEMM_XCD="0", VC_GEMV_WCACHED="1"), "test_gemm or test_gemv"),
+        # deeper load windows of the decode attention
+        (dict(VC_DATTN_UK="16"), "test_fused_decode"),
+        # the register-staged GEMV (the LDS-DMA ring kernel is the default)
+        (dict(VC_GEMV_PATH="0"), "test_gemv or test_fused_decode"),
+        # 2: the one-barrier 256x256 kernel; 4: 256x256 as 4 waves x (128 x 128)
+        (dict(VC_GEMM_VARIANT="2"), plain_gemm),
+        (dict(VC_GEMM_VARIANT="4"), plain_gemm),
+    ]
+    procs = []
+    for knobs, sel in sweeps:
+        env = dict(os.environ, **knobs)
+        procs.append((knobs, subprocess.Popen([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
+                                               f"({sel}) and not alternate"], env=env, stdout=subprocess.PIPE,
+                                              stderr=subprocess.STDOUT, text=True)))
+    for knobs, pr in procs:
+        out, _ = pr.communicate()
+        assert pr.returncode == 0, f"{knobs}: " + out[-2000:]

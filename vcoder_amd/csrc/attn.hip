@@ -268,11 +268,15 @@ void launch_attention(const AttnArgs& a, hipStream_t s) {
     // 8 waves x 16 queries keeps the hd-128 kernel at 128 VGPRs (the 4x32 form needs ~250 -> 1 wave/SIMD); measured on
     // MI355X: prefill (hd 128, T 1216, causal) 288 us vs 378 us; ViT (hd 64, T 577) 97 us vs 117 us.
     static const int variant = getenv("VC_ATTN_VARIANT") ? atoi(getenv("VC_ATTN_VARIANT")) : 0;
+    // variant 2: 8 waves x 32 queries (256 queries per workgroup): every K / V^T fragment read from LDS feeds two MFMAs —
+    // the 8 x 16 form reads 32 KiB of fragments per wave and 64-key tile for 32 MFMAs, i.e. it is bound by LDS bandwidth
     if (a.hd == 128) {
         if (variant == 1) launch_attention_v<128, 4, 2>(a, s);
+        else if (variant == 2) launch_attention_v<128, 8, 2>(a, s);
         else launch_attention_v<128, 8, 1>(a, s);
     } else {
         if (variant == 1) launch_attention_v<64, 4, 2>(a, s);
+        else if (variant == 2) launch_attention_v<64, 8, 2>(a, s);
         else launch_attention_v<64, 8, 1>(a, s);
     }
 }
