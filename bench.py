@@ -314,7 +314,9 @@ def main():
     timed_px = host_px if args.host_pixels else dev_px
     if args.warmup > 0:
         run_steps(max(args.warmup, n_sess), timed_px)  # every session captures its decode graph before the timed region
+    steps0 = eng.pool_step_counts()
     dt, outs = timed(args.steps, timed_px)
+    step_mix = [a - b for a, b in zip(eng.pool_step_counts(), steps0)]   # pooled decode steps of the timed region by 8/16/24/32 rows
     if args.dump_ids and rank == 0:
         np.save(args.dump_ids, outs[-1])
     # ---- transparency legs, outside the timed region -----------------------------------------------------------------
@@ -330,14 +332,21 @@ def main():
     torch.cuda.synchronize()
     solo = (time.perf_counter() - t1) / 2
     timings = sessions[0].last_timings()
-    # the dominant kernel as the timed configuration runs it: the decode GEMV over the rows that share a step (the in-flight
-    # batches' rows in the pool, up to 32), and over one batch alone for reference
-    pooled = os.environ.get("VC_POOL", "1") != "0"
-    rows_step = min(n_sess * B, 32) if pooled else min(B, 16)
-    prof = eng.profile_decode_gemv(rows_step, reps=3)
-    prof_one = eng.profile_decode_gemv(min(B, 16), reps=3) if rows_step != min(B, 16) else prof
+    # The two HBM-bound kernels of a decode step, measured live (HIP events on the engine's stream, real arguments, all
+    # layers) at every row count the timed region ran its steps at: the pool steps over 8 / 16 / 24 / 32 rows as requests
+    # join and leave (step_mix), a private loop over the batch's own rows.
+    pooled = os.environ.get("VC_POOL", "1") != "0" and sum(step_mix) > 0
     S_prompt = 64 + 2 * cfg.num_patches
-    prof_att = eng.profile_decode_attention(rows_step, S_prompt + N_new // 2, reps=3)   # mid-generation context
+    if pooled:
+        mix = {8 * (i + 1): n for i, n in enumerate(step_mix) if n > 0}
+    else:
+        mix = {min(B, 16): args.steps * (N_new - 1)}
+    prof_by_rows, att_by_rows = {}, {}
+    for r_ in sorted(set(mix) | {min(B, 16)}):
+        prof_by_rows[r_] = eng.profile_decode_gemv(r_, reps=3)
+        att_by_rows[r_] = eng.profile_decode_attention(r_, S_prompt + N_new // 2, reps=3)   # mid-generation context
+    rows_step = max(mix, key=lambda r_: mix[r_])          # the row count most steps ran at
+    prof, prof_one, prof_att = prof_by_rows[rows_step], prof_by_rows[min(B, 16)], att_by_rows[rows_step]
 
     if rank == 0:
         traffic = args.pmc_traffic_bytes
@@ -346,13 +355,13 @@ def main():
             f_ = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
             if os.path.exists(f_):
                 with open(f_) as f:
-                    traffic = json.load(f).get("hbm_read_bytes_per_launch_by_rows", {}).get(str(rows_step))
+                    traffic_by_rows = json.load(f).get("hbm_read_bytes_per_launch_by_rows", {})
+                traffic = traffic_by_rows.get(str(rows_step))
             if traffic is None and rows_step == 8 and os.path.exists(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")):
                 with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
                     traffic = json.load(f)["hbm_read_bytes_per_launch"]
         S = 64 + 2 * cfg.num_patches
         ms_step = dt / args.steps * 1e3
-        ach = prof["avg_bytes"] / (prof["avg_us"] * 1e-6) / 1e9
         # composite roofline of ONE batch of B alone: MFMA leg (encode + prefill) + HBM leg (decode)
         flops, w_bytes, kv_bytes = work_per_sample(cfg, S, N_new, 1.0 if args.weights != "bf16" else 2.0)
         mfma_ms = B * flops / (MFMA_PEAK_TFLOPS * 1e12) * 1e3
@@ -362,34 +371,51 @@ def main():
         hbm_ms = ((N_new - 1) * w_bytes + B * kv_bytes) / (HBM_PEAK_GBS * 1e9) * 1e3
         # with k batches in flight whose decode steps share one weight pass, the HBM leg of a batch shrinks to
         # weights / k + its own KV: the bound of what `value` measures
-        share = n_sess if pooled else 1
+        # (rows that shared a weight pass, averaged over the timed region's steps) / B
+        share = sum(n * r_ for r_, n in mix.items()) / sum(mix.values()) / B if pooled else 1
         hbm_ms_shared = ((N_new - 1) * w_bytes / share + B * kv_bytes) / (HBM_PEAK_GBS * 1e9) * 1e3
-        # the two HBM-bound kernels that make up a decode step, each measured live (HIP events) as the timed configuration
-        # runs it; `roofline` is the one that takes more of the step
-        ach_att = prof_att["avg_bytes"] / (prof_att["avg_us"] * 1e-6) / 1e9
-        t_gemv = prof["avg_us"] * prof["launches_per_step"]
-        t_att = prof_att["avg_us"] * prof_att["launches_per_step"]
-        kernels = {
-            "gemv_dma_kernel": {"what": f"decode weight streaming, {prof['launches_per_step']} launches per step, {rows_step} rows per weight pass",
-                                "avg_launch_us": prof["avg_us"], "algorithmic_bytes_per_launch": prof["avg_bytes"],
-                                "achieved": ach, "frac": ach / HBM_PEAK_GBS, "us_per_step": t_gemv, "traffic": traffic,
-                                "one_batch_alone": {"rows": min(B, 16), "avg_launch_us": prof_one["avg_us"],
-                                                    "achieved": prof_one["avg_bytes"] / (prof_one["avg_us"] * 1e-6) / 1e9}},
-            "attention_decode_fused_kernel": {"what": f"KV streaming, {prof_att['launches_per_step']} launches per step, {rows_step} rows, context ~{S_prompt + N_new // 2}",
-                                              "avg_launch_us": prof_att["avg_us"], "algorithmic_bytes_per_launch": prof_att["avg_bytes"],
-                                              "achieved": ach_att, "frac": ach_att / HBM_PEAK_GBS, "us_per_step": t_att, "traffic": None},
-        }
+        # time-weighted over the step mix of the timed region: total kernel time and algorithmic bytes per kernel family;
+        # `roofline` is the family with more time
+        def family(by_rows):
+            steps = sum(mix.values())
+            t_us = sum(mix[r_] * by_rows[r_]["avg_us"] * by_rows[r_]["launches_per_step"] for r_ in mix)
+            byts = sum(mix[r_] * by_rows[r_]["avg_bytes"] * by_rows[r_]["launches_per_step"] for r_ in mix)
+            nl = sum(mix[r_] * by_rows[r_]["launches_per_step"] for r_ in mix)
+            return {"avg_launch_us": t_us / nl, "algorithmic_bytes_per_launch": byts / nl, "achieved": byts / (t_us * 1e-6) / 1e9,
+                    "frac": byts / (t_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "us_per_step": t_us / steps,
+                    "by_rows": {str(r_): {"steps": mix[r_], "avg_launch_us": by_rows[r_]["avg_us"],
+                                          "algorithmic_bytes_per_launch": by_rows[r_]["avg_bytes"],
+                                          "frac": by_rows[r_]["avg_bytes"] / (by_rows[r_]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS}
+                                for r_ in sorted(mix)}}
+        fam_g, fam_a = family(prof_by_rows), family(att_by_rows)
+        t_gemv, t_att = fam_g["us_per_step"], fam_a["us_per_step"]
+        pmc = {}
+        f_ = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        if args.model == "7b" and B == 8 and args.weights == "bf16" and os.path.exists(f_):
+            with open(f_) as f:
+                pmc = json.load(f)
+
+        def traffic_avg(key, by_rows):   # PMC FETCH_SIZE bytes per launch (separate pass, see the file), weighted like the times
+            t = pmc.get(key, {})
+            if not all(str(r_) in t for r_ in mix):
+                return None
+            nl = sum(mix[r_] * by_rows[r_]["launches_per_step"] for r_ in mix)
+            return sum(mix[r_] * by_rows[r_]["launches_per_step"] * t[str(r_)] for r_ in mix) / nl
+        fam_g["traffic"] = traffic if args.pmc_traffic_bytes is not None else traffic_avg("hbm_read_bytes_per_launch_by_rows", prof_by_rows)
+        fam_a["traffic"] = traffic_avg("attention_hbm_read_bytes_per_launch_by_rows", att_by_rows)
+        fam_g["what"] = f"decode weight streaming, {prof['launches_per_step']} launches per step, weights of one step shared by the rows in it"
+        fam_a["what"] = f"KV streaming, {prof_att['launches_per_step']} launches per step, context ~{S_prompt + N_new // 2}"
+        fam_g["one_batch_alone"] = {"rows": min(B, 16), "avg_launch_us": prof_one["avg_us"],
+                                    "achieved": prof_one["avg_bytes"] / (prof_one["avg_us"] * 1e-6) / 1e9}
+        kernels = {"gemv_dma_kernel": fam_g, "attention_decode_fused_kernel": fam_a}
         dom = "attention_decode_fused_kernel" if t_att > t_gemv else "gemv_dma_kernel"
-        if dom == "attention_decode_fused_kernel":
-            f_ = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-            if os.path.exists(f_):
-                with open(f_) as f:
-                    kernels[dom]["traffic"] = json.load(f).get("attention_hbm_read_bytes_per_launch_by_rows", {}).get(str(rows_step))
         k = kernels[dom]
-        roofline = {"bound": "hbm", "kernel": f"{dom} ({k['what']}; {k['us_per_step'] / (t_att + t_gemv) * 100:.0f}% of the decode step's kernel time)",
+        roofline = {"bound": "hbm", "kernel": f"{dom} ({k['what']}; {k['us_per_step'] / (t_att + t_gemv) * 100:.0f}% of the decode steps' "
+                                              f"kernel time; averaged over the timed region's steps: " +
+                                              ", ".join(f"{n} over {r_} rows" for r_, n in sorted(mix.items())) + ")",
                     "achieved": k["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k["frac"], "traffic": k["traffic"],
                     "avg_launch_us": k["avg_launch_us"], "algorithmic_bytes_per_launch": k["algorithmic_bytes_per_launch"],
-                    "rows_per_launch": rows_step}
+                    "rows_per_launch": {str(r_): n for r_, n in sorted(mix.items())}}
         res = {
             "metric": "images/sec (3xViT encode + 128-tok decode), VCoder-DS-7b" if args.model == "7b"
                       else "images/sec (3xViT encode + 128-tok decode), VCoder-DS-13b",

@@ -195,6 +195,9 @@ void vc_comm_destroy(vc_comm* comm);
 /* times `reps` sweeps of every decode GEMV launch of one step (4 per layer + lm_head) over B <= 32 rows with HIP events on
  * the model's stream; returns launches per sweep, average microseconds per launch, algorithmic weight bytes per launch */
 int vc_profile_decode_gemv(vc_model* m, int B, int reps, int* launches, double* avg_us, double* avg_bytes);
+/* cumulative number of pooled decode steps launched over 8 / 16 / 24 / 32 rows since the pool of m's root model was created
+ * (zeros without a pool): weights the per-row-count kernel timings by what a timed run actually executed */
+int vc_pool_step_counts(vc_model* m, unsigned long long* counts4);
 /* the same for the decode attention launches of one step (one per layer) over B rows at context ~ctx: launches per sweep,
  * average microseconds per launch, algorithmic KV bytes per launch (K and V rows of every key, bf16) */
 int vc_profile_decode_attention(vc_model* m, int B, int ctx, int reps, int* launches, double* avg_us, double* avg_bytes);

@@ -36,6 +36,7 @@ def test_concurrent_requests_share_steps_and_keep_their_ids(emu_lib):
     sessions = [root, root.fork(), root.fork()]
     outs = [[None] * 3 for _ in sessions]
     errs = []
+    steps0 = root.pool_step_counts()
 
     def work(si):
         try:
@@ -54,6 +55,11 @@ def test_concurrent_requests_share_steps_and_keep_their_ids(emu_lib):
     for si in range(3):
         for ci, got in outs[si]:
             assert np.array_equal(got, refs[ci]), f"session {si} case {names[ci]}: pooled ids differ from the session loop"
+    # the pool's step histogram (what bench.py weights its kernel timings by): nine requests of 6 cached steps each ran
+    # in FEWER than 54 steps because they shared them; all of them over the first 8-row span (at most 4 rows in flight)
+    steps = [a - b for a, b in zip(root.pool_step_counts(), steps0)]
+    assert steps[1:] == [0, 0, 0] and 6 <= steps[0] < 54, steps
+    assert sessions[1].pool_step_counts() == root.pool_step_counts()
     for s in sessions[1:]:
         s.close()
 

@@ -1821,6 +1821,7 @@ struct vc_pool {
     std::thread driver;
     hipEvent_t step_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     unsigned long steps_run = 0;
+    unsigned long long steps_by_span[VC_POOL_ROWS / 8] = {};  // steps launched over 8 / 16 / 24 / 32 rows (vc_pool_step_counts)
 };
 
 namespace {
@@ -1926,6 +1927,7 @@ void pool_driver(vc_pool* p) {
             HIPCHK(hipGraphLaunch(p->graph[gi], p->st));
             HIPCHK(hipEventRecord(p->step_ev[n % 4], p->st));
             p->steps_run = n + 1;
+            p->steps_by_span[gi] += 1;
             for (PoolRequest* rq : p->active) {
                 rq->steps_left -= 1;
                 rq->produced += 1;
@@ -2503,6 +2505,19 @@ VC_API int vc_profile_decode_attention(vc_model* m, int B, int ctx, int reps, in
     HIPCHK(hipStreamSynchronize(m->st));
     m->cur_pos = -1;
     GUARD_END(m->ctx)
+}
+
+/* cumulative number of pooled decode steps launched over 8, 16, 24 and 32 rows since the pool of m's root model was
+ * created (zeros if it has none): lets bench.py weight the per-row-count kernel timings by what the timed run executed */
+VC_API int vc_pool_step_counts(vc_model* m, unsigned long long* counts4) {
+    if (!m || !counts4) return VC_ERR_INVALID;
+    vc_model* root = m->root ? m->root : m;
+    for (int i = 0; i < 4; ++i) counts4[i] = 0;
+    if (root->pool) {
+        std::lock_guard<std::mutex> lk(root->pool->mu);
+        for (int i = 0; i < 4 && i < VC_POOL_ROWS / 8; ++i) counts4[i] = root->pool->steps_by_span[i];
+    }
+    return VC_OK;
 }
 
 VC_API int vc_profile_decode_gemv(vc_model* m, int B, int reps, int* launches, double* avg_us, double* avg_bytes) {

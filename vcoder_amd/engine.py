@@ -427,6 +427,12 @@ class HipEngine:
         self._check(self.lib.vc_profile_decode_attention(self._model, B, ctx, reps, C.byref(n), C.byref(us), C.byref(by)))
         return {"launches_per_step": n.value, "avg_us": us.value, "avg_bytes": by.value}
 
+    def pool_step_counts(self):
+        """cumulative pooled decode steps launched over 8 / 16 / 24 / 32 rows (zeros when generate() never used the pool)"""
+        c = (C.c_ulonglong * 4)()
+        self._check(self.lib.vc_pool_step_counts(self._model, c))
+        return [int(x) for x in c]
+
     def profile_decode_gemv(self, B: int, reps: int = 3):
         n, us, by = C.c_int(), C.c_double(), C.c_double()
         self._check(self.lib.vc_profile_decode_gemv(self._model, B, reps, C.byref(n), C.byref(us), C.byref(by)))
