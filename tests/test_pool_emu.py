@@ -32,7 +32,7 @@ def test_concurrent_requests_share_steps_and_keep_their_ids(emu_lib):
     for n in names:
         g, cfg, ids, imgs, segs, deps = e2e_cases.fixture_inputs(n)
         cases.append((ids, imgs, segs, deps))
-        refs.append(session_loop_ids(root, ids, imgs, segs, deps, 7))
+        refs.append(session_loop_ids(root, ids, imgs, segs, deps, 6))
     sessions = [root, root.fork(), root.fork()]
     outs = [[None] * 3 for _ in sessions]
     errs = []
@@ -42,7 +42,7 @@ def test_concurrent_requests_share_steps_and_keep_their_ids(emu_lib):
         try:
             for j in range(3):
                 ci = (si + j) % 3                                          # every session meets every case
-                outs[si][j] = (ci, sessions[si].generate_greedy(*cases[ci], max_new_tokens=7))
+                outs[si][j] = (ci, sessions[si].generate_greedy(*cases[ci], max_new_tokens=6))
         except BaseException as e:
             errs.append(e)
 
@@ -55,10 +55,10 @@ def test_concurrent_requests_share_steps_and_keep_their_ids(emu_lib):
     for si in range(3):
         for ci, got in outs[si]:
             assert np.array_equal(got, refs[ci]), f"session {si} case {names[ci]}: pooled ids differ from the session loop"
-    # the pool's step histogram (what bench.py weights its kernel timings by): nine requests of 6 cached steps each ran
-    # in FEWER than 54 steps because they shared them; all of them over the first 8-row span (at most 4 rows in flight)
+    # the pool's step histogram (what bench.py weights its kernel timings by): nine requests of 5 cached steps each ran
+    # in FEWER than 45 steps because they shared them; all of them over the first 8-row span (at most 4 rows in flight)
     steps = [a - b for a, b in zip(root.pool_step_counts(), steps0)]
-    assert steps[1:] == [0, 0, 0] and 6 <= steps[0] < 54, steps
+    assert steps[1:] == [0, 0, 0] and 5 <= steps[0] < 45, steps
     assert sessions[1].pool_step_counts() == root.pool_step_counts()
     for s in sessions[1:]:
         s.close()
@@ -69,16 +69,16 @@ def test_pool_mixes_eos_stops_and_sampling(emu_lib):
     sampled request and a plain greedy one, all in flight together; each equals its lone run."""
     root = e2e_cases.engine_for("vcoder_ds", emu_lib)
     g, cfg, ids, imgs, segs, deps = e2e_cases.fixture_inputs("ds_img_depth_seg")
-    base = root.generate_greedy(ids, imgs, segs, deps, max_new_tokens=10)
+    base = root.generate_greedy(ids, imgs, segs, deps, max_new_tokens=8)
     eos = int(base[0, 2])
     kws = [
-        dict(max_new_tokens=10),
-        dict(max_new_tokens=10, eos_token_id=eos, pad_token_id=0),
-        dict(max_new_tokens=10, stop_sequences=[[int(base[1, 3])]], pad_token_id=0),
-        dict(max_new_tokens=10, do_sample=True, temperature=0.9, top_k=20, top_p=0.95, seed=11),
+        dict(max_new_tokens=8),
+        dict(max_new_tokens=8, eos_token_id=eos, pad_token_id=0),
+        dict(max_new_tokens=8, stop_sequences=[[int(base[1, 3])]], pad_token_id=0),
+        dict(max_new_tokens=8, do_sample=True, temperature=0.9, top_k=20, top_p=0.95, seed=11),
     ]
     lone = [root.generate(ids, imgs, segs, deps, **kw) for kw in kws]
-    assert lone[1].shape[1] <= 10 and (lone[1][0, 3:] == 0).all()           # row 0 pads after its EOS
+    assert lone[1].shape[1] <= 8 and (lone[1][0, 3:] == 0).all()            # row 0 pads after its EOS
     sessions = [root] + [root.fork() for _ in range(3)]
     outs, errs = [None] * 4, []
 
