@@ -1,4 +1,5 @@
-// decode.hip — weight-streaming skinny GEMM for the decode steps (M = batch <= 16 tokens).
+// decode.hip — weight-streaming skinny GEMM for the decode steps (M <= 32 token rows per weight pass: a session's batch
+// or the rows of the shared decode pool), the fp8 quantisers of the W8A16 / W8A8 formats, weight packing.
 //
 //   out[m][n] = epilogue( sum_k X[m][k] * W[n][k] )        (Llama linears have no bias)
 //

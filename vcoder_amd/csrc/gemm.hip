@@ -311,8 +311,10 @@ VC_DEV void store_out(const GemmArgs& p, int m, int n, f32x4 v) {
 // F8 = true: the same schedule over OCP e4m3 operands (activations quantised per token row, weights per output row, both
 // with power-of-two scales): a 128-byte tile row is now ONE K = 128 step of v_mfma_scale_f32_16x16x128_f8f6f4 (unit
 // block scales; twice the bf16 MFMA rate) instead of two K = 32 bf16 steps — identical bytes, LDS layout, DMA pattern
-// and MFMA cycles per k-tile, half the k-tiles.  The lane's 32 consecutive k are chunks 2*(lane/16), 2*(lane/16)+1 of
-// its row.  The epilogue multiplies the fp32 accumulator by a_scale[m] * w_scale[n] (exact: powers of two).
+// and MFMA cycles per k-tile, half the k-tiles.  A lane feeds the instruction chunks g and 4+g of its row (g = lane/16) —
+// the fragment reads of the bf16 form, which are bank-conflict free; reading the "natural" chunks 2g, 2g+1 measured 50 %
+// conflict cycles.  Which 32 of the row's 128 k a lane contributes is free as long as both operands agree: the
+// instruction sums over all of them.  The epilogue multiplies the fp32 accumulator by a_scale[m] * w_scale[n] (exact: powers of two).
 template <int EPI, bool F8 = false>
 __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     constexpr int HALF = 128 * 128, TILE = 4 * HALF;  // bytes
@@ -381,14 +383,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
-                fx[i][ks] = ld16(base + (h ? SX1 : SX0) + swz(g * 64 + i * 16 + frow, F8 ? fchunk * 2 + ks : ks * 4 + fchunk));
+                fx[i][ks] = ld16(base + (h ? SX1 : SX0) + swz(g * 64 + i * 16 + frow, ks * 4 + fchunk));
     };
     auto read_y = [&](const char* base, int h) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
-                fy[h][j][ks] = ld16(base + (h ? SY1 : SY0) + swz(q * 32 + j * 16 + frow, F8 ? fchunk * 2 + ks : ks * 4 + fchunk));
+                fy[h][j][ks] = ld16(base + (h ? SY1 : SY0) + swz(q * 32 + j * 16 + frow, ks * 4 + fchunk));
     };
     auto quadrant = [&](int hx, int hy) {
         set_prio<1>();

@@ -45,7 +45,7 @@ struct GemmArgs {
 };
 void launch_gemm(const GemmArgs& a, int epilogue, hipStream_t s);
 
-// Skinny GEMM for decode (M <= 16): weights pre-packed in MFMA-fragment order, streamed once.  K12/K16/K17/K18.
+// Skinny GEMM for decode (M <= VC_GEMV_MAX_M token rows per weight pass): weights pre-packed in MFMA-fragment order, streamed once.  K12/K16/K17/K18.
 // packed W layout: [N/16][K/32][64 lanes][8 bf16]; lane l of tile (nt,kt) holds W[nt*16+(l&15)][kt*32+(l>>4)*8 + e].
 enum GemvEpilogue : int {
     GEMV_BF16 = 0,       // out bf16 [M, N]
@@ -232,8 +232,6 @@ struct SelectArgs {
                           // that join a running loop are selected from their prefill's own logits buffer
 };
 void launch_select_embed(const SelectArgs& a, hipStream_t s);
-// rows[row0 .. row0+nrows) <- src[0 .. nrows) (whole records), stream-ordered
-void launch_rows_write(int* rows, const int* src, int row0, int nrows, hipStream_t s);
 // embedding + sum-of-squares partials for tokens supplied by the host (vc_decode_step with explicit tokens)
 void launch_embed_tokens_ssq(const int* tok, const bf16_t* embed, float* x, float* ssq, const float* xg_w, bf16_t* xg, int B, int D, int npart,
                              hipStream_t s);

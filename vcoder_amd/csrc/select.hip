@@ -262,14 +262,4 @@ void launch_embed_tokens_ssq(const int* tok, const bf16_t* embed, float* x, floa
     VC_LAUNCH(embed_tokens_ssq_kernel, dim3((B + 3) / 4), dim3(256), 0, s, tok, embed, x, ssq, xg_w, xg, B, D, npart);
 }
 
-// host-written row records: one launch copies `n` ints per row from a staging table into the live RowState array of the
-// decode loop, stream-ordered between two decode steps (rows join a running loop without a host synchronisation)
-__global__ __launch_bounds__(128) void rows_write_kernel(int* rows, const int* src, int row0) {
-    rows[(size_t)(row0 + blockIdx.x) * RS_STRIDE + threadIdx.x] = src[(size_t)blockIdx.x * RS_STRIDE + threadIdx.x];
-}
-void launch_rows_write(int* rows, const int* src, int row0, int nrows, hipStream_t s) {
-    static_assert(RS_STRIDE == 128, "one thread per record word");
-    VC_LAUNCH(rows_write_kernel, dim3(nrows), dim3(RS_STRIDE), 0, s, rows, src, row0);
-}
-
 }  // namespace vc
