@@ -99,14 +99,14 @@ template <int HD> VC_DEV int swz_k(int row, int chunk) {  // K tile [64][HD] bf1
 VC_DEV int swz_v(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }  // V^T tile [HD][64]
 
 template <int HD, bool CAUSAL, int WAVES, int QS>
-__global__ __launch_bounds__(WAVES * 64) void attention_kernel(AttnArgs p) {
+__global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && QS == 1) ? 4 : 1) void attention_kernel(AttnArgs p) {  // 8 x 16: two workgroups per CU (<= 128 VGPRs)
     constexpr int NTH = WAVES * 64;       // threads per workgroup
     constexpr int QB = WAVES * QS * 16;   // queries per workgroup
     constexpr int KS = HD / 32;        // k-steps of the QK^T contraction
     constexpr int DT = HD / 16;        // 16-wide d tiles of the output
     constexpr int KCH = HD / 8;        // 16-B chunks per K row
-    __shared__ __attribute__((aligned(16))) char k_lds[64 * HD * 2];
-    __shared__ __attribute__((aligned(16))) char v_lds[HD * 128];
+    constexpr int KB_ = 64 * HD * 2, VB_ = HD * 128;   // bytes of a K tile [64 keys][HD] and a V^T tile [HD][64 keys]
+    __shared__ __attribute__((aligned(16))) char lds[2][KB_ + VB_];   // double-buffered: the LDS-DMA of tile t+1 lands under tile t
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, j = lane & 15;
     const int q0 = blockIdx.x * QB, h = blockIdx.y, b = blockIdx.z;
@@ -133,40 +133,44 @@ __global__ __launch_bounds__(WAVES * 64) void attention_kernel(AttnArgs p) {
 #pragma unroll
     for (int qs = 0; qs < QS; ++qs) { m_run[qs] = -INFINITY; l_run[qs] = 0.f; }
 
+    const float c2 = p.scale * 1.4426950408889634f;   // scale * log2(e): exp(scale * x) = exp2(c2 * x)
     const int kv_end = CAUSAL ? min(p.T, q0 + QB) : p.T;
     const int nkt = (kv_end + 63) / 64;
-    constexpr int KLD = (64 * KCH) / NTH, VLD = (HD * 8) / NTH;  // staged 16-B chunks per thread
-    u32x4 rk[KLD], rv[VLD];
-    auto load_tile = [&](int kt) {
+    // K / V^T tiles go global -> LDS by DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass), 1-KiB pieces =
+    // 64 lanes x 16 B written linearly; the XOR swizzles of swz_k / swz_v are applied on the SOURCE side: the lane that
+    // fills slot s of row r fetches chunk s ^ f(r) of that row.
+    constexpr int KROWS = 1024 / (HD * 2);      // K rows per piece (4 at hd 128, 8 at hd 64)
+    constexpr int KPIECES = KB_ / 1024 / WAVES, VPIECES = VB_ / 1024 / WAVES;
+    static_assert(KPIECES >= 1 && VPIECES >= 1 && KB_ % (1024 * WAVES) == 0 && VB_ % (1024 * WAVES) == 0, "pieces per wave");
+    const char* ksrc[KPIECES];
+    const char* vsrc[VPIECES];
 #pragma unroll
-        for (int i = 0; i < KLD; ++i) {
-            const int c = tid + i * NTH, row = c / KCH, ch = c % KCH;
-            rk[i] = ld16(kbase + (size_t)(kt * 64 + row) * HD + ch * 8);
-        }
+    for (int i = 0; i < KPIECES; ++i) {
+        const int piece = i * WAVES + wave, row = piece * KROWS + lane / KCH, slot = lane % KCH;
+        const int ch = HD == 128 ? (slot ^ (row & 15)) : (slot ^ (row & 7));
+        ksrc[i] = reinterpret_cast<const char*>(kbase + (size_t)row * HD + ch * 8);
+    }
 #pragma unroll
-        for (int i = 0; i < VLD; ++i) {
-            const int c = tid + i * NTH, row = c >> 3, ch = c & 7;
-            rv[i] = ld16(vbase + (size_t)row * vts + kt * 64 + ch * 8);
-        }
-    };
-    auto store_tile = [&]() {
+    for (int i = 0; i < VPIECES; ++i) {
+        const int piece = i * WAVES + wave, row = piece * 8 + (lane >> 3), slot = lane & 7;
+        vsrc[i] = reinterpret_cast<const char*>(vbase + (size_t)row * vts + ((slot ^ ((row >> 1) & 7)) * 8));
+    }
+    auto issue_tile = [&](int kt, int buf) {
 #pragma unroll
-        for (int i = 0; i < KLD; ++i) {
-            const int c = tid + i * NTH;
-            st16(k_lds + swz_k<HD>(c / KCH, c % KCH), rk[i]);
-        }
+        for (int i = 0; i < KPIECES; ++i) glds16(ksrc[i] + (size_t)kt * (64 * HD * 2), lds[buf] + (i * WAVES + wave) * 1024);
 #pragma unroll
-        for (int i = 0; i < VLD; ++i) {
-            const int c = tid + i * NTH;
-            st16(v_lds + swz_v(c >> 3, c & 7), rv[i]);
-        }
+        for (int i = 0; i < VPIECES; ++i) glds16(vsrc[i] + (size_t)kt * 128, lds[buf] + KB_ + (i * WAVES + wave) * 1024);
     };
 
-    load_tile(0);
+    issue_tile(0, 0);
     for (int kt = 0; kt < nkt; ++kt) {
-        store_tile();
+        // tile kt has landed for every wave (own vmcnt wait + barrier) and every wave is done with tile kt-1, whose buffer
+        // the next DMA overwrites
+        wait_vmcnt<0>();
         __syncthreads();
-        if (kt + 1 < nkt) load_tile(kt + 1);
+        if (kt + 1 < nkt) issue_tile(kt + 1, (kt + 1) & 1);
+        const char* k_lds = lds[kt & 1];
+        const char* v_lds = lds[kt & 1] + KB_;
         const int k0 = kt * 64;
         // ---- S^T = K Q^T
         f32x4 sacc[QS][4];
@@ -182,33 +186,42 @@ __global__ __launch_bounds__(WAVES * 64) void attention_kernel(AttnArgs p) {
 #pragma unroll
                 for (int qs = 0; qs < QS; ++qs) sacc[qs][sub] = mfma16(kf, qf[qs][ks], sacc[qs][sub]);
             }
-        // ---- online softmax (lane owns query j of each q-subtile; keys spread over regs and the 4 lane groups)
+        // ---- online softmax (lane owns query j of each q-subtile; keys spread over regs and the 4 lane groups).  The
+        // kernel is bound by these VALU / transcendental instructions, not by its MFMAs (per query-key pair: 256 MACs =
+        // 0.25 MFMA cycles against one v_exp_f32 and the arithmetic around it), so the per-element work is the minimum:
+        // the running maximum is kept on the RAW scores (scale > 0 commutes with max), scale * log2(e) is folded into the
+        // one FMA that feeds v_exp_f32, and the key mask is only evaluated in tiles that contain a masked key (the
+        // diagonal tiles of a causal pass, the ragged last tile) — a wave-uniform branch.
         u32x4 pb[QS][2];
 #pragma unroll
         for (int qs = 0; qs < QS; ++qs) {
-            const int query = q0 + wave * (QS * 16) + qs * 16 + j;
-            float mx = -INFINITY;
+            const int qfirst = q0 + wave * (QS * 16) + qs * 16;     // smallest query of this sub-tile
+            const int query = qfirst + j;
+            if ((CAUSAL && k0 + 63 > qfirst) || k0 + 64 > p.T) {
 #pragma unroll
-            for (int sub = 0; sub < 4; ++sub)
+                for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = k0 + sub * 16 + g * 4 + r;
-                    float v = sacc[qs][sub][r] * p.scale;
-                    if (key >= p.T || (CAUSAL && key > query)) v = -INFINITY;
-                    sacc[qs][sub][r] = v;
-                    mx = fmaxf(mx, v);
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = k0 + sub * 16 + g * 4 + r;
+                        if (key >= p.T || (CAUSAL && key > query)) sacc[qs][sub][r] = -INFINITY;
+                    }
+            }
+            float mx = fmaxf(fmaxf(sacc[qs][0][0], sacc[qs][0][1]), fmaxf(sacc[qs][0][2], sacc[qs][0][3]));
+#pragma unroll
+            for (int sub = 1; sub < 4; ++sub)
+                mx = fmaxf(mx, fmaxf(fmaxf(sacc[qs][sub][0], sacc[qs][sub][1]), fmaxf(sacc[qs][sub][2], sacc[qs][sub][3])));
             mx = fmaxf(mx, shfl_xor(mx, 16));
             mx = fmaxf(mx, shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run[qs], mx);
-            const float alpha = __expf(m_run[qs] - m_new);  // first tile: exp(-inf) = 0
+            const float m_new = fmaxf(m_run[qs], mx);               // raw-score units; finite from the first tile on (key 0)
+            const float alpha = fast_exp2((m_run[qs] - m_new) * c2);  // first tile: exp2(-inf) = 0
             m_run[qs] = m_new;
+            const float mc = m_new * c2;
             float rs = 0.f;
 #pragma unroll
             for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float e = __expf(sacc[qs][sub][r] - m_new);
+                    const float e = fast_exp2(fmaf(sacc[qs][sub][r], c2, -mc));   // = exp(scale * (s - m)); masked: 0
                     sacc[qs][sub][r] = e;
                     rs += e;
                 }
@@ -235,7 +248,6 @@ __global__ __launch_bounds__(WAVES * 64) void attention_kernel(AttnArgs p) {
 #pragma unroll
                 for (int qs = 0; qs < QS; ++qs) o[qs][dt] = mfma16(vf, pb[qs][kh], o[qs][dt]);
             }
-        __syncthreads();
     }
     // ---- normalise and store: lane holds out[query j][d = dt*16 + g*4 .. +4]
 #pragma unroll

@@ -230,6 +230,12 @@ VC_DEV unsigned atomic_inc_agent(unsigned* p) { return __hip_atomic_fetch_add(p,
 #endif
 
 // ---- activations (fp32) --------------------------------------------------------------------
+// v_exp_f32 (2^x, no range reduction or denormal handling: the softmax arguments are <= 0)
+#ifdef VC_EMU
+VC_DEV float fast_exp2(float x) { return exp2f(x); }
+#else
+VC_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+#endif
 VC_DEV float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }   // x*sigmoid(1.702x)
 VC_DEV float erf_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 VC_DEV float silu(float x) { return x / (1.0f + __expf(-x)); }
