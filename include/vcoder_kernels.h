@@ -48,6 +48,8 @@ void vck_quantize_fp8_rows(uint16_t* W, uint8_t* Wq, float* scale, uint8_t* Wrow
  *   out = epi( (Q @ Wrow^T) * a_scale[m] * w_scale[n] )
  * on v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales; twice the bf16 MFMA rate).  K % 128 == 0;
  * epi 0 bf16, 4 fp32 residual add, 5 SwiGLU.  ws: optional split-K workspace as for vck_gemm_ws. */
+/* RMSNorm straight into that operand: the bytes / scales of vck_rmsnorm followed by vck_quant_act_rows, in one pass */
+void vck_rmsnorm_q8(const float* x, const float* w, uint8_t* q, float* scale, int rows, int D, float eps, void* stream);
 void vck_quant_act_rows(const uint16_t* A, int lda, uint8_t* Q, float* scale, int M, int K, void* stream);
 void vck_gemm_f8(const uint8_t* A, const float* a_scale, const uint8_t* W, const float* w_scale, void* out, int M, int N,
                  int K, int ldo, int epi, float* ws, size_t ws_bytes, void* stream);

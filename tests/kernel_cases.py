@@ -363,6 +363,28 @@ def check_rmsnorm(be, rows, D, gather=False, seed=0):
     assert e < 2 ** -8, f"rmsnorm rel err {e}"
 
 
+def check_rmsnorm_q8(be, rows, D, seed=0):
+    """RMSNorm straight into the e4m3 operand: bit-identical to vck_rmsnorm followed by vck_quant_act_rows, and to
+    vcoder_amd/quant.py on the kernel's own bf16 row."""
+    from vcoder_amd import quant
+
+    rng = np.random.RandomState(seed)
+    x = (rng.randn(rows, D) * np.exp2(rng.randint(-3, 4, size=(rows, 1)))).astype(np.float32)
+    x[rng.randint(rows), rng.randint(D)] = 500.0
+    w = (rng.rand(D) + 0.5).astype(np.float32)
+    xd, wd = be.f32(x), be.f32(w)
+    y = be.zeros((rows, D), "bf16")
+    _call(be, "vck_rmsnorm", xd, None, wd, y, rows, D, 1e-5)
+    q2, s2 = be.zeros((rows, D), "u8"), be.zeros((rows,), "f32")
+    _call(be, "vck_quant_act_rows", y, D, q2, s2, rows, D)
+    q1, s1 = be.zeros((rows, D), "u8"), be.zeros((rows,), "f32")
+    _call(be, "vck_rmsnorm_q8", xd, wd, q1, s1, rows, D, 1e-5)
+    host = lambda t: np.asarray(t.cpu().numpy() if hasattr(t, "cpu") else t)
+    assert np.array_equal(host(q1), host(q2)) and np.array_equal(be.host_f32(s1), be.host_f32(s2)), "fused != two passes"
+    qa, sa, _ = quant.quantize_rows(be.host_f32(y))
+    assert np.array_equal(host(q1), qa) and np.array_equal(be.host_f32(s1), sa)
+
+
 class _VitCfg:
     def __init__(self, image, patch):
         self.vit_image_size, self.vit_patch_size = image, patch

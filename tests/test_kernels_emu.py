@@ -78,6 +78,11 @@ def test_rmsnorm(be, rows, D, gather):
     kc.check_rmsnorm(be, rows, D, gather)
 
 
+@pytest.mark.parametrize("rows,D", [(9, 256), (5, 1280), (3, 5120)])
+def test_rmsnorm_q8(be, rows, D):
+    kc.check_rmsnorm_q8(be, rows, D)
+
+
 def test_vit_front(be):
     kc.check_im2col(be, 2, 56, 14, 640)
     kc.check_vit_embed_ln(be, 2, 17, 128)

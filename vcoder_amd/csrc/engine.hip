@@ -368,9 +368,10 @@ void gemm(vc_model* m, const bf16_t* A, const bf16_t* W, const float* bias, void
 }
 // weight format 2 (W8A8 prefill): the token rows of A are quantised to e4m3 with per-row power-of-two scales, then
 // out = epi((Q @ Wq^T) * a_scale[m] * w_scale[n]) on the K=128 scaled MFMA
+// A == nullptr: the e4m3 rows and scales are already in m->a8 / m->a8_scale (launch_rmsnorm_q8)
 void gemm_f8(vc_model* m, const bf16_t* A, const uint8_t* Wq, const float* wscale, void* out, int M, int N, int K, int ldo,
              int epi) {
-    launch_quant_act_rows(A, K, m->a8.as<uint8_t>(), m->a8_scale.as<float>(), M, K, m->st);
+    if (A) launch_quant_act_rows(A, K, m->a8.as<uint8_t>(), m->a8_scale.as<float>(), M, K, m->st);
     GemmArgs a{reinterpret_cast<const bf16_t*>(m->a8.p), reinterpret_cast<const bf16_t*>(Wq), nullptr, out, M, N, K, K, K, ldo};
     if ((long)((M + 255) / 256) * ((N + 255) / 256) > 256) {
         m->gemm_ws.ensure((size_t)64 << 20);
@@ -949,9 +950,13 @@ void run_prefill_layers(vc_model* m, const KvTarget& kv, int B, int S) {
     const bool f8 = m->weight_format == 2;
     for (int l = 0; l < nl; ++l) {
         const LlmLayer& L = m->llm[l];
-        launch_rmsnorm(m->x.as<float>(), L.in_norm, m->xn.as<bf16_t>(), M, D, c.rms_eps, m->st);
-        if (f8) gemm_f8(m, m->xn.as<bf16_t>(), L.qkv_q, L.qkv_s, m->qkv.p, M, 3 * D, D, 3 * D, EPI_BF16);
-        else gemm(m, m->xn.as<bf16_t>(), L.qkv_w, nullptr, m->qkv.p, M, 3 * D, D, 3 * D, EPI_BF16);
+        if (f8) {  // RMSNorm writes the e4m3 operand of the QKV GEMM directly
+            launch_rmsnorm_q8(m->x.as<float>(), L.in_norm, m->a8.as<uint8_t>(), m->a8_scale.as<float>(), M, D, c.rms_eps, m->st);
+            gemm_f8(m, nullptr, L.qkv_q, L.qkv_s, m->qkv.p, M, 3 * D, D, 3 * D, EPI_BF16);
+        } else {
+            launch_rmsnorm(m->x.as<float>(), L.in_norm, m->xn.as<bf16_t>(), M, D, c.rms_eps, m->st);
+            gemm(m, m->xn.as<bf16_t>(), L.qkv_w, nullptr, m->qkv.p, M, 3 * D, D, 3 * D, EPI_BF16);
+        }
         // K and V rows go to the cache (key-major: what the decode steps stream); the V^T tiles of this layer's flash
         // attention live in a per-call scratch [B,H,hd,Sr]
         QkvSplitArgs qa{m->qkv.as<bf16_t>(), m->q.as<bf16_t>(), kcache(m, kv, l), m->vt_pre.as<bf16_t>(), B, S, H, m->hd, S, kv.capS,
@@ -962,9 +967,10 @@ void run_prefill_layers(vc_model* m, const KvTarget& kv, int B, int S) {
         launch_attention(aa, m->st);
         if (f8) gemm_f8(m, m->attn.as<bf16_t>(), L.o_q, L.o_s, m->x.p, M, D, D, D, EPI_RESID_F32);
         else gemm(m, m->attn.as<bf16_t>(), L.o_w, nullptr, m->x.p, M, D, D, D, EPI_RESID_F32);
-        launch_rmsnorm(m->x.as<float>(), L.post_norm, m->xn.as<bf16_t>(), M, D, c.rms_eps, m->st);
+        if (f8) launch_rmsnorm_q8(m->x.as<float>(), L.post_norm, m->a8.as<uint8_t>(), m->a8_scale.as<float>(), M, D, c.rms_eps, m->st);
+        else launch_rmsnorm(m->x.as<float>(), L.post_norm, m->xn.as<bf16_t>(), M, D, c.rms_eps, m->st);
         if (f8) {
-            gemm_f8(m, m->xn.as<bf16_t>(), L.gu_q, L.gu_s, m->h.p, M, 2 * F, D, F, EPI_SWIGLU);
+            gemm_f8(m, nullptr, L.gu_q, L.gu_s, m->h.p, M, 2 * F, D, F, EPI_SWIGLU);
             gemm_f8(m, m->h.as<bf16_t>(), L.down_q, L.down_s, m->x.p, M, D, F, D, EPI_RESID_F32);
         } else {
             gemm(m, m->xn.as<bf16_t>(), L.gu_w, nullptr, m->h.p, M, 2 * F, D, F, EPI_SWIGLU);

@@ -91,6 +91,9 @@ VCK_EXPORT void vck_rmsnorm(const float* x, const int* row_idx, const float* w, 
     if (row_idx) launch_rmsnorm_rows(x, row_idx, w, y, rows, D, eps, S(stream));
     else launch_rmsnorm(x, w, y, rows, D, eps, S(stream));
 }
+VCK_EXPORT void vck_rmsnorm_q8(const float* x, const float* w, uint8_t* q, float* scale, int rows, int D, float eps, void* stream) {
+    launch_rmsnorm_q8(x, w, q, scale, rows, D, eps, S(stream));
+}
 VCK_EXPORT void vck_im2col(const float* pixels, uint16_t* cols, int n_img, int image, int patch, int Kpad, void* stream) {
     launch_im2col(pixels, cols, n_img, image, patch, Kpad, S(stream));
 }

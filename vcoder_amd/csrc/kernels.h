@@ -97,6 +97,8 @@ void launch_layernorm(const float* x, const float* w, const float* b, bf16_t* y,
                       hipStream_t s);
 void launch_rmsnorm(const float* x, const float* w, bf16_t* y, int rows, int D, float eps, hipStream_t s);
 // rows gathered through an index (final norm over the last token of each sample): row r reads x[idx[r]]
+// RMSNorm + per-row e4m3 quantisation in one pass: q [rows, D] bytes + scale [rows] (= launch_rmsnorm then launch_quant_act_rows)
+void launch_rmsnorm_q8(const float* x, const float* w, uint8_t* q, float* scale, int rows, int D, float eps, hipStream_t s);
 void launch_rmsnorm_rows(const float* x, const int* row_idx, const float* w, bf16_t* y, int rows, int D, float eps,
                          hipStream_t s);
 

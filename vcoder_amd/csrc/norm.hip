@@ -124,6 +124,67 @@ void launch_rmsnorm_rows(const float* x, const int* row_idx, const float* w, bf1
     launch_norm<true>(x, row_idx, w, nullptr, y, rows, D, eps, s);
 }
 
+// ---- RMSNorm straight into the e4m3 activation operand of the fp8 prefill GEMM (weight format 2) -------------------------
+// One wave per row: y = bf16(x * rstd * w) exactly as norm_row computes it, then the row's power-of-two scale and the e4m3
+// bytes by the rule of quant_act_rows_kernel (decode.hip) — the same bytes that kernel would produce from the bf16 row,
+// without writing and re-reading it.
+template <int MAXV>
+__global__ __launch_bounds__(256) void rmsnorm_q8_kernel(const float* x, const float* w, uint8_t* q, float* scale, int rows,
+                                                         int D, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;  // wave-uniform
+    const int lane = lane_id();
+    const int nch = D >> 2;
+    const float* xr = x + (size_t)row * D;
+    f32x4 v[MAXV];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        v[i] = c < nch ? ld16f(xr + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ss += v[i][e] * v[i][e];
+    }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)D + eps);
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+            const f32x4 wv = ld16f(w + c * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[i][e] = bf2f(f2bf(v[i][e] * rstd * wv[e]));
+                amax = fmaxf(amax, fabsf(v[i][e]));
+            }
+        }
+    }
+    amax = wave_max(amax);
+    int ex = 0;
+    if (amax > 0.f) {
+        const uint32_t u = __builtin_bit_cast(uint32_t, amax);
+        ex = (int)(u >> 23) - 127 - ((u & 0x007FFFFFu) <= 0x00600000u ? 8 : 7);  // 448 = 1.75 * 2^8
+    }
+    const float inv = __builtin_bit_cast(float, (uint32_t)(127 - ex) << 23);
+    if (lane == 0) scale[row] = __builtin_bit_cast(float, (uint32_t)(ex + 127) << 23);
+    uint8_t* qr = q + (size_t)row * D;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+            const uint32_t pk = (uint32_t)f2fp8(v[i][0] * inv) | ((uint32_t)f2fp8(v[i][1] * inv) << 8) |
+                                ((uint32_t)f2fp8(v[i][2] * inv) << 16) | ((uint32_t)f2fp8(v[i][3] * inv) << 24);
+            *reinterpret_cast<uint32_t*>(qr + c * 4) = pk;
+        }
+    }
+}
+void launch_rmsnorm_q8(const float* x, const float* w, uint8_t* q, float* scale, int rows, int D, float eps, hipStream_t s) {
+    const dim3 grid((rows + 3) / 4), block(256);
+    if (D <= 1024) VC_LAUNCH((rmsnorm_q8_kernel<4>), grid, block, 0, s, x, w, q, scale, rows, D, eps);
+    else if (D <= 4096) VC_LAUNCH((rmsnorm_q8_kernel<16>), grid, block, 0, s, x, w, q, scale, rows, D, eps);
+    else VC_LAUNCH((rmsnorm_q8_kernel<32>), grid, block, 0, s, x, w, q, scale, rows, D, eps);
+}
+
 // ---- K2: CLS concat + position embedding + pre-LayerNorm -> fp32 residual stream ----------------------
 template <int MAXV>
 __global__ __launch_bounds__(256) void vit_embed_ln_kernel(const float* patches, const float* cls, const float* pos,
