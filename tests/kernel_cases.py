@@ -737,7 +737,7 @@ def sample_reference_probs(lg, temperature, top_k, top_p):
     return p / p.sum()
 
 
-def check_gemv_rows_agree_across_variants(be, N, K, epi, norm=True, ksplit=0, seed=0):
+def check_gemv_rows_agree_across_variants(be, N, K, epi, norm=True, ksplit=0, seed=0, fp8=False):
     """The decode pool's promise: a row gets bit-for-bit the same result from a 32-row pass (two MFMA row groups) as from a
     16-row pass — rows 0..15 and 16..31 of an M = 29 launch against two launches of 16 and 13 rows."""
     rng = np.random.RandomState(seed)
@@ -745,8 +745,14 @@ def check_gemv_rows_agree_across_variants(be, N, K, epi, norm=True, ksplit=0, se
     npart = (K // 16 + 15) // 16 * 16
     X = bf16_round(rng.randn(32, K))
     W = bf16_round(rng.randn(N, K) * 0.05)
-    Wd, Wp = be.bf16(W), be.zeros((N * K,), "bf16")
-    _call(be, "vck_pack_weight", Wd, Wp, N, K)
+    wsc = None
+    if fp8:   # W8A16: e4m3 super-tiles + row scales; the reference uses the dequantised matrix the quantiser leaves behind
+        Wd, Wp, wsc = be.bf16(W), be.zeros((N * K,), "u8"), be.zeros((N,), "f32")
+        _call(be, "vck_quantize_fp8", Wd, Wp, wsc, N, K)
+        W = be.host_f32(Wd)
+    else:
+        Wd, Wp = be.bf16(W), be.zeros((N * K,), "bf16")
+        _call(be, "vck_pack_weight", Wd, Wp, N, K)
     ssq = np.zeros((32, npart), np.float32)
     ssq[:, : K // 16] = rng.rand(32, K // 16).astype(np.float32) + 0.5
     ssqd = be.f32(ssq) if norm else None
@@ -759,14 +765,14 @@ def check_gemv_rows_agree_across_variants(be, N, K, epi, norm=True, ksplit=0, se
         sk = (be.zeros((ksplit * (N // 16) * 2 * 256,), "f32"), be.zeros((N // 16 * 2,), "i32"))
     Xd = be.bf16(X)
     big = mk()
-    _gemv_ex(be, Xd, Wp, None, big, ssqd, None, None, None, npart, M, N, K, No, epi, sk=sk, ksplit=ksplit)
+    _gemv_ex(be, Xd, Wp, wsc, big, ssqd, None, None, None, npart, M, N, K, No, epi, sk=sk, ksplit=ksplit)
     be.sync()
     lo, hi = mk(), mk()
-    _gemv_ex(be, Xd, Wp, None, lo, ssqd, None, None, None, npart, 16, N, K, No, epi, sk=sk, ksplit=ksplit)
+    _gemv_ex(be, Xd, Wp, wsc, lo, ssqd, None, None, None, npart, 16, N, K, No, epi, sk=sk, ksplit=ksplit)
     be.sync()
     Xh = be.bf16(X[16:])
     ssqh = be.f32(ssq[16:]) if norm else None
-    _gemv_ex(be, Xh, Wp, None, hi, ssqh, None, None, None, npart, M - 16, N, K, No, epi, sk=sk, ksplit=ksplit)
+    _gemv_ex(be, Xh, Wp, wsc, hi, ssqh, None, None, None, npart, M - 16, N, K, No, epi, sk=sk, ksplit=ksplit)
     be.sync()
     b, l = be.host_f32(big), be.host_f32(lo)
     # bit equality holds for the default (LDS-DMA) kernels, whose K partition is the same for both row counts; the

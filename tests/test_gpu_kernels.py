@@ -104,6 +104,16 @@ def test_fused_decode_kernels(be):
     kc.check_select_embed(be, 8, 32000, 4096)
 
 
+@pytest.mark.parametrize("N,K,epi,norm,fp8", [(12288, 4096, 0, True, False), (22016, 4096, 3, True, False),
+                                              (4096, 11008, 2, False, False), (22016, 4096, 3, True, True),
+                                              (27648, 5120, 3, True, True), (15360, 5120, 0, True, True),
+                                              (5120, 13824, 2, False, True)])
+def test_gemv_rows_agree_between_pool_and_session_passes(be, N, K, epi, norm, fp8):
+    """a row gets bit-for-bit the same result from a 29-row pass (the decode pool) as from a <= 16-row pass, bf16 and e4m3
+    weights, at the 7b / 13b decoder shapes (W8A16 gate/up: the 4-tiles-per-workgroup geometry)"""
+    kc.check_gemv_rows_agree_across_variants(be, N, K, epi, norm, fp8=fp8)
+
+
 def test_strict_fp32_kernels(be):
     kc.check_gemm_f32(be, 1216, 12288, 4096, 3, bias=False)
     kc.check_gemm_f32(be, 577, 4096, 1024, 1)

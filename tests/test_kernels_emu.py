@@ -59,6 +59,13 @@ def test_gemv_32_rows(be, N, K, epi, norm, ks):
     kc.check_gemv_rows_agree_across_variants(be, N, K, epi, norm, ks)
 
 
+@pytest.mark.parametrize("N,K,epi,norm", [(24576, 128, 3, True), (64, 256, 0, True), (4096, 192, 2, False)])
+def test_gemv_32_rows_w8a16(be, N, K, epi, norm):
+    """the same promise with e4m3 weights; N = 24576 (1536 tiles) takes the 4-tiles-per-workgroup geometry, whose
+    finishing stage gives every wave two (tile, row group) units"""
+    kc.check_gemv_rows_agree_across_variants(be, N, K, epi, norm, fp8=True)
+
+
 def test_gemv_chain_24_rows(be):
     kc.check_gemv_norm_chain(be, 24, 256, 64, seed=7)
     kc.check_gemv_norm_chain(be, 32, 512, 96, seed=8)

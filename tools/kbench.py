@@ -150,6 +150,33 @@ def bench_gemv_rows():
               f"(geom {os.environ.get('VC_GEMV2_GEOM', 'default')})", flush=True)
 
 
+def bench_gemv_rows8():
+    """W8A16 weights at 17..32 rows: gate/up (7b, 13b) and qkv, consumer form (VC_GEMV8_NT4=0/1 switches the gate/up geometry)"""
+    for M in (16, 24, 32):
+        for (N, K, epi, name) in [(22016, 4096, 3, "7b gate-up"), (27648, 5120, 3, "13b gate-up"), (12288, 4096, 0, "7b qkv")]:
+            X = bf16(32, K)
+            Ws = []
+            sc = torch.zeros(N, device=dev)
+            for _ in range(6):
+                W = bf16(N, K, scale=0.02)
+                Wq = torch.zeros(N * K, dtype=torch.uint8, device=dev)
+                lib.vck_quantize_fp8(P(W), P(Wq), P(sc), N, K, None)
+                Ws.append(Wq)
+            torch.cuda.synchronize()
+            out = torch.zeros((32, N), dtype=torch.bfloat16, device=dev)
+            ldo = N // 2 if epi == 3 else N
+            npart = (K // 16 + 15) // 16 * 16
+            ssq = torch.rand(32, npart, device=dev)
+            it = [0]
+
+            def f():
+                it[0] += 1
+                lib.vck_gemv_ex(P(X), P(Ws[it[0] % 6]), P(sc), P(out), P(ssq), None, None, None, npart, C.c_float(1e-5),
+                                None, None, 0, M, N, K, ldo, epi, None)
+            us = timeit(f, iters=40)
+            print(f"gemv_rows8 M{M:2d} {name:12s} N{N} K{K}: {us:7.1f} us  {N * K / us / 1e3:7.1f} GB/s", flush=True)
+
+
 def bench_dattn_rows():
     """decode attention over B rows with per-row positions (the pool's form), ctx ~1280"""
     H, hd, S = 32, 128, 2048
@@ -316,7 +343,9 @@ if __name__ == "__main__":
         bench_dattn_rows()
     if "gemm_f8" in what:
         bench_gemm_f8()
+    if "gemv_rows8" in what:
+        bench_gemv_rows8()
     for w in what:
         {"gemm": bench_gemm, "gemv": bench_gemv, "attn": bench_attn, "dattn": bench_dattn,
          "gemv_fp8": lambda: None, "gemv13": lambda: None, "gemv_pair": lambda: None, "gemv_rows": lambda: None,
-         "dattn_rows": lambda: None, "gemm_f8": lambda: None}[w]()
+         "dattn_rows": lambda: None, "gemm_f8": lambda: None, "gemv_rows8": lambda: None}[w]()

@@ -217,7 +217,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
     constexpr int OPS = WB + XPL;            // DMA instructions per slot
     constexpr int SLOT = OPS * 1024;
     static_assert(WAVES * R * SLOT >= WAVES * NT * MG * 1024, "the ring is re-used for the cross-wave reduction");
-    static_assert(WAVES >= NT * MG, "one finishing wave per (tile, row group)");
     VC_DYNAMIC_SMEM(char, ring);             // [WAVES][R][SLOT]
     __shared__ float ss_part[WAVES][16 * MG];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -388,10 +387,14 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
 #pragma unroll
         for (int q = 0; q < MG; ++q) st16f(red + (((wave * NT + t) * MG + q) * 64 + lane) * 4, acc[t][q]);
     __syncthreads();
-    if (wave >= NT * MG) return;
-    const int ft = wave % NT, fq = wave / NT;  // this wave finishes tile ft for row group fq
+    // one finishing wave per (tile, row group) unit; with more units than waves (NT * MG > WAVES) a wave takes several
+#pragma unroll
+    for (int u0 = 0; u0 < (NT * MG + WAVES - 1) / WAVES; ++u0) {
+    const int unit_w = u0 * WAVES + wave;
+    if (unit_w >= NT * MG) continue;
+    const int ft = unit_w % NT, fq = unit_w / NT;  // this wave finishes tile ft for row group fq
     const int nt = nt0 + ft;
-    if (nt >= ntiles) return;
+    if (nt >= ntiles) continue;
     f32x4 v = ld16f(red + (((0 * NT + ft) * MG + fq) * 64 + lane) * 4);
 #pragma unroll
     for (int w = 1; w < WAVES; ++w) v = v + ld16f(red + (((w * NT + ft) * MG + fq) * 64 + lane) * 4);
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
         unsigned arrived = 0;
         if (lane == 0) arrived = atomic_inc_agent(&p.sk_counters[unit]);
         arrived = shfl(arrived, 0);
-        if (arrived != (unsigned)(KS - 1)) return;
+        if (arrived != (unsigned)(KS - 1)) continue;
         v = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int k = 0; k < KS; ++k) {
             const float* q = p.sk_scratch + (((size_t)k * ntiles * 2 + unit) * 64 + lane) * 4;
@@ -419,6 +422,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
         if (lane == 0) st_agent_u32(&p.sk_counters[unit], 0u);  // re-armed for the next launch (stream order)
     }
     gemv_epilogue<WAVES, EPI, FP8, 16 * MG>(p, v, &ss_part[0][0], nt, m + 16 * fq, g, mvalid[fq]);
+    }
 }
 
 template <class K>
@@ -507,7 +511,20 @@ static void launch_gemv_m32(const GemvArgs& a, int epilogue, hipStream_t s) {
         launch_gemv_dma2<8, 1, 3, FP8>(a, epilogue, s);
     } else if (tiles <= 512) launch_gemv_dma2<4, 1, 3, FP8>(a, epilogue, s);
     else if (tiles <= 768 && !FP8 && geom == 0) launch_gemv_dma2<4, 1, 2, FP8>(a, epilogue, s);
-    else launch_gemv_dma2<4, 2, 2, FP8>(a, epilogue, s);
+    else {
+        // W8A16, the widest matrices (13b gate/up: 1728 tiles): 4 tiles per workgroup halve the activation bytes per weight
+        // byte — the bound of this kernel at 17..32 rows, DESIGN.md section 9.2 — same K partition (4 waves).  Measured at 32
+        // rows: 45.2 -> 35.3 us; with 1376 tiles (7b gate/up) the 344 single-resident workgroups balance badly over 256 CUs
+        // and it loses (26.2 -> 27.9 us), hence the threshold.  VC_GEMV8_NT4=0 switches it off.
+        static const int nt4 = getenv("VC_GEMV8_NT4") ? atoi(getenv("VC_GEMV8_NT4")) : 1;
+        if constexpr (FP8) {
+            if (nt4 && tiles >= 1536) {
+                launch_gemv_dma2<4, 4, 2, true>(a, epilogue, s);
+                return;
+            }
+        }
+        launch_gemv_dma2<4, 2, 2, FP8>(a, epilogue, s);
+    }
 }
 
 template <bool FP8>
