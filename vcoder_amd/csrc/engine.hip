@@ -34,6 +34,10 @@ static const int IMAGE_TOKEN_INDEX = -200;  // vcoder_llava/constants.py:5
 static const int SEG_TOKEN_INDEX = -300;    // constants.py:8
 static const int DEPTH_TOKEN_INDEX = -400;  // constants.py:11
 static const int VC_MAX_ROWS = 16;          // sequences one prefill / one session loop handles
+// The prefill's RMSNorm output rows are padded by 64 elements: with both GEMM operands at a row stride of exactly 2^13
+// bytes (K = 4096 bf16) the 9728 x 12288 QKV GEMM of the 7b model ran 19 % slower (915 vs 770 us; address aliasing
+// between the concurrently fetched panels — tools/experiments/gemm_rounds.py); no other shape cares.
+static const int XN_PAD = 64;
 static const int VC_POOL_ROWS = 32;         // rows of the shared decode pool (two MFMA token-slot groups)
 
 #include "engine_ctx.h"
@@ -357,8 +361,8 @@ int place_tensor(vc_model* m, const std::string& raw_key, const void* src, int d
 // ------------------------------------------------------------------------------------------------
 // GEMM helpers
 void gemm(vc_model* m, const bf16_t* A, const bf16_t* W, const float* bias, void* out, int M, int N, int K, int ldo,
-          int epi) {
-    GemmArgs a{A, W, bias, out, M, N, K, K, K, ldo};
+          int epi, int lda = 0) {
+    GemmArgs a{A, W, bias, out, M, N, K, lda > 0 ? lda : K, K, ldo};
     if ((long)((M + 255) / 256) * ((N + 255) / 256) > 256) {  // only problems with more than one round of tiles can use it
         m->gemm_ws.ensure((size_t)64 << 20);
         a.ws = m->gemm_ws.as<float>();
@@ -804,7 +808,7 @@ void ensure_prefill_ws(vc_model* m, int B, int Scap) {
     const int D = c.hidden, F = c.ffn;
     const size_t Mrows = (size_t)B * Scap;
     m->x.ensure(Mrows * D * 4);
-    m->xn.ensure(Mrows * D * 2);
+    m->xn.ensure(Mrows * (D + XN_PAD) * 2);
     m->qkv.ensure(Mrows * 3 * D * 2);
     m->q.ensure(Mrows * D * 2, true);
     m->attn.ensure(Mrows * D * 2);
@@ -954,8 +958,8 @@ void run_prefill_layers(vc_model* m, const KvTarget& kv, int B, int S) {
             launch_rmsnorm_q8(m->x.as<float>(), L.in_norm, m->a8.as<uint8_t>(), m->a8_scale.as<float>(), M, D, c.rms_eps, m->st);
             gemm_f8(m, nullptr, L.qkv_q, L.qkv_s, m->qkv.p, M, 3 * D, D, 3 * D, EPI_BF16);
         } else {
-            launch_rmsnorm(m->x.as<float>(), L.in_norm, m->xn.as<bf16_t>(), M, D, c.rms_eps, m->st);
-            gemm(m, m->xn.as<bf16_t>(), L.qkv_w, nullptr, m->qkv.p, M, 3 * D, D, 3 * D, EPI_BF16);
+            launch_rmsnorm(m->x.as<float>(), L.in_norm, m->xn.as<bf16_t>(), M, D, c.rms_eps, m->st, D + XN_PAD);
+            gemm(m, m->xn.as<bf16_t>(), L.qkv_w, nullptr, m->qkv.p, M, 3 * D, D, 3 * D, EPI_BF16, D + XN_PAD);
         }
         // K and V rows go to the cache (key-major: what the decode steps stream); the V^T tiles of this layer's flash
         // attention live in a per-call scratch [B,H,hd,Sr]
@@ -968,12 +972,12 @@ void run_prefill_layers(vc_model* m, const KvTarget& kv, int B, int S) {
         if (f8) gemm_f8(m, m->attn.as<bf16_t>(), L.o_q, L.o_s, m->x.p, M, D, D, D, EPI_RESID_F32);
         else gemm(m, m->attn.as<bf16_t>(), L.o_w, nullptr, m->x.p, M, D, D, D, EPI_RESID_F32);
         if (f8) launch_rmsnorm_q8(m->x.as<float>(), L.post_norm, m->a8.as<uint8_t>(), m->a8_scale.as<float>(), M, D, c.rms_eps, m->st);
-        else launch_rmsnorm(m->x.as<float>(), L.post_norm, m->xn.as<bf16_t>(), M, D, c.rms_eps, m->st);
+        else launch_rmsnorm(m->x.as<float>(), L.post_norm, m->xn.as<bf16_t>(), M, D, c.rms_eps, m->st, D + XN_PAD);
         if (f8) {
             gemm_f8(m, nullptr, L.gu_q, L.gu_s, m->h.p, M, 2 * F, D, F, EPI_SWIGLU);
             gemm_f8(m, m->h.as<bf16_t>(), L.down_q, L.down_s, m->x.p, M, D, F, D, EPI_RESID_F32);
         } else {
-            gemm(m, m->xn.as<bf16_t>(), L.gu_w, nullptr, m->h.p, M, 2 * F, D, F, EPI_SWIGLU);
+            gemm(m, m->xn.as<bf16_t>(), L.gu_w, nullptr, m->h.p, M, 2 * F, D, F, EPI_SWIGLU, D + XN_PAD);
             gemm(m, m->h.as<bf16_t>(), L.down_w, nullptr, m->x.p, M, D, F, D, EPI_RESID_F32);
         }
     }

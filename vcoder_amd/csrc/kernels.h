@@ -95,7 +95,8 @@ void launch_interleave_rows(const bf16_t* gate, const bf16_t* up, bf16_t* out, i
 // K3: LayerNorm(D) fp32 in -> bf16 out.  K11: RMSNorm.
 void launch_layernorm(const float* x, const float* w, const float* b, bf16_t* y, int rows, int D, float eps,
                       hipStream_t s);
-void launch_rmsnorm(const float* x, const float* w, bf16_t* y, int rows, int D, float eps, hipStream_t s);
+// ldy: row stride of y in elements (0 = D)
+void launch_rmsnorm(const float* x, const float* w, bf16_t* y, int rows, int D, float eps, hipStream_t s, int ldy = 0);
 // rows gathered through an index (final norm over the last token of each sample): row r reads x[idx[r]]
 // RMSNorm + per-row e4m3 quantisation in one pass: q [rows, D] bytes + scale [rows] (= launch_rmsnorm then launch_quant_act_rows)
 void launch_rmsnorm_q8(const float* x, const float* w, uint8_t* q, float* scale, int rows, int D, float eps, hipStream_t s);

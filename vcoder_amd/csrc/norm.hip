@@ -70,11 +70,11 @@ VC_DEV void norm_row(const float* __restrict__ x, const float* __restrict__ w, c
 
 template <int MAXV, bool RMS>
 __global__ __launch_bounds__(256) void norm_kernel(const float* x, const int* row_idx, const float* w, const float* b,
-                                                   bf16_t* y, int rows, int D, float eps) {
+                                                   bf16_t* y, int rows, int D, float eps, int ldy) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;  // wave-uniform
     const int src = row_idx ? row_idx[row] : row;
-    norm_row<MAXV, RMS, false>(x + (size_t)src * D, w, b, y + (size_t)row * D, D, eps, nullptr, nullptr);
+    norm_row<MAXV, RMS, false>(x + (size_t)src * D, w, b, y + (size_t)row * ldy, D, eps, nullptr, nullptr);
 }
 
 // fp32-out form for the strict path
@@ -105,19 +105,20 @@ void launch_rmsnorm_f32(const float* x, const int* row_idx, const float* w, floa
 
 template <bool RMS>
 static void launch_norm(const float* x, const int* idx, const float* w, const float* b, bf16_t* y, int rows, int D,
-                        float eps, hipStream_t s) {
+                        float eps, hipStream_t s, int ldy = 0) {
     const dim3 grid((rows + 3) / 4), block(256);
-    if (D <= 1024) VC_LAUNCH((norm_kernel<4, RMS>), grid, block, 0, s, x, idx, w, b, y, rows, D, eps);
-    else if (D <= 4096) VC_LAUNCH((norm_kernel<16, RMS>), grid, block, 0, s, x, idx, w, b, y, rows, D, eps);
-    else VC_LAUNCH((norm_kernel<32, RMS>), grid, block, 0, s, x, idx, w, b, y, rows, D, eps);
+    if (ldy <= 0) ldy = D;
+    if (D <= 1024) VC_LAUNCH((norm_kernel<4, RMS>), grid, block, 0, s, x, idx, w, b, y, rows, D, eps, ldy);
+    else if (D <= 4096) VC_LAUNCH((norm_kernel<16, RMS>), grid, block, 0, s, x, idx, w, b, y, rows, D, eps, ldy);
+    else VC_LAUNCH((norm_kernel<32, RMS>), grid, block, 0, s, x, idx, w, b, y, rows, D, eps, ldy);
 }
 
 void launch_layernorm(const float* x, const float* w, const float* b, bf16_t* y, int rows, int D, float eps,
                       hipStream_t s) {
     launch_norm<false>(x, nullptr, w, b, y, rows, D, eps, s);
 }
-void launch_rmsnorm(const float* x, const float* w, bf16_t* y, int rows, int D, float eps, hipStream_t s) {
-    launch_norm<true>(x, nullptr, w, nullptr, y, rows, D, eps, s);
+void launch_rmsnorm(const float* x, const float* w, bf16_t* y, int rows, int D, float eps, hipStream_t s, int ldy) {
+    launch_norm<true>(x, nullptr, w, nullptr, y, rows, D, eps, s, ldy);
 }
 void launch_rmsnorm_rows(const float* x, const int* row_idx, const float* w, bf16_t* y, int rows, int D, float eps,
                          hipStream_t s) {
