@@ -57,6 +57,11 @@ def parse_args():
                     help="all-gather of the token ids: torch.distributed (backend nccl = RCCL) or the library's own "
                          "vc_allgather_tokens (RCCL called through the C ABI)")
     ap.add_argument("--dump-ids", default=None, help="write the gathered ids of the last timed step to this .npy (tests)")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the compact legs the default single-GPU run appends outside the timed region: parity_mode "
+                         "(images/s of the precision modes that meet the 1e-3 / bit-exact-ids bar), BASELINE configs[2] "
+                         "(13b bf16, batch 16) and the per-GPU slice of configs[4] (13b fp8, batch 16)")
+    ap.add_argument("--extra-steps", type=int, default=2, help="steps of each compact leg")
     ap.add_argument("--pmc-traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass "
                          "(default: the committed FETCH_SIZE pass of this kernel under profiles/)")
@@ -202,6 +207,124 @@ def cpu_c1_full(new_tokens: int = 32):
             "seconds": dt, "images_per_s": 1.0 / dt, "cores": torch.get_num_threads(), "first_ids": out[0, :8].tolist()}
 
 
+def run_leg(eng, cfg, ids, px, n_new, steps, inflight, check_against=None, precision=None):
+    """`steps` complete hot-path passes over one batch (ids, px) with `inflight` generate() calls in flight (sessions forked
+    from `eng`), one untimed warm-up pass per session first.  -> images/s, ms per step, the ids of the last step, and whether
+    every step's ids equal `check_against` (default: the first warm-up pass, a batch generated alone)."""
+    import threading
+
+    import numpy as np
+    import torch
+
+    n_sess = max(1, min(inflight, steps))
+    sessions = [eng] + [eng.fork() for _ in range(n_sess - 1)]
+    if precision is not None:
+        for s_ in sessions:
+            s_.set_precision(precision)   # the arithmetic mode is a property of the session
+    lone = eng.generate_greedy(ids, *px, max_new_tokens=n_new, eos_token_id=None)
+    want = lone if check_against is None else check_against
+
+    def sweep(k):
+        outs, errs = [None] * k, []
+
+        def worker(si):
+            try:
+                for j in range(si, k, n_sess):
+                    outs[j] = sessions[si].generate_greedy(ids, *px, max_new_tokens=n_new, eos_token_id=None)
+            except BaseException as e:
+                errs.append(e)
+
+        ths = [threading.Thread(target=worker, args=(si,)) for si in range(n_sess)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        if errs:
+            raise errs[0]
+        return outs
+
+    if n_sess > 1:
+        sweep(n_sess)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outs = sweep(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    solo_ids = eng.generate_greedy(ids, *px, max_new_tokens=n_new, eos_token_id=None)
+    torch.cuda.synchronize()
+    solo = time.perf_counter() - t0
+    timings = eng.last_timings()
+    ok = all(np.array_equal(o, want) for o in outs + [solo_ids])
+    for s_ in sessions[1:]:
+        s_.close()
+    B = ids.shape[0]
+    return {"value": B * steps / dt, "unit": "images/s", "steps": steps, "ms_per_step": dt / steps * 1e3,
+            "in_flight_batches": n_sess, "one_batch_at_a_time": {"value": B / solo, "ms_per_step": solo * 1e3, **timings},
+            "ids_checked": bool(ok)}, lone
+
+
+def extra_legs(args, eng7, cfg7, ids7, dev_px7, lone_ids7, fast_value, n_new):
+    """The compact legs of the default single-GPU run (outside the timed region): parity_mode on the benchmark model, then —
+    the 7b engine released — BASELINE configs[2] and the per-GPU slice of configs[4] on a 13b model."""
+    import numpy as np
+    import torch
+
+    from vcoder_amd import config as vcfg, synth
+    from vcoder_amd.engine import HipEngine
+
+    out = {}
+    # ---- parity_mode: the precision modes that meet BASELINE.json's "logits within 1e-3, greedy ids bit-exact" bar
+    # (tests/test_gpu_e2e.py, tests/test_gpu_fulldepth.py), timed on the SAME batch as `value`
+    pm = {"bar": "logits within 1e-3 of the fp32 CPU reference, greedy ids bit-exact (tests: test_fixture_strict_mode, "
+                 "test_fixture_split_mode, test_gpu_fulldepth)", "fast_path_value": fast_value}
+    strict_ids = None
+    for mode, steps, inflight in (("strict", 1, 1), ("split", args.extra_steps, args.inflight)):
+        try:
+            eng7.set_precision(mode)
+        except (KeyError, ValueError) as e:
+            pm[mode] = {"error": "mode not available: %r" % (e,)}
+            continue
+        try:
+            leg, ids_ = run_leg(eng7, cfg7, ids7, dev_px7, n_new, steps, inflight, precision=mode)
+            leg["frac_of_fast_path"] = leg["value"] / fast_value
+            leg["ids_equal_fast_path"] = float((ids_ == lone_ids7).mean())
+            if mode == "strict":
+                strict_ids = ids_
+                leg["what"] = "fp32 activations end to end on v_mfma_f32_16x16x4_f32 (csrc/strict.hip)"
+            else:
+                leg["what"] = ("fp32 activations in HBM, every MFMA operand split into bf16 hi + lo fragments on the fast kernels "
+                               "(2 MFMAs per weight k-step, 3 per attention product)")
+                if strict_ids is not None:
+                    leg["ids_equal_strict"] = bool(np.array_equal(ids_, strict_ids))
+            pm[mode] = leg
+        finally:
+            eng7.set_precision("bf16")
+    out["parity_mode"] = pm
+    eng7.close()
+    torch.cuda.empty_cache()
+    # ---- BASELINE configs[2] (13b bf16, batch 16, one GPU) and the per-GPU slice of configs[4] (13b fp8 weights, batch 16)
+    cfg13 = vcfg.vicuna_13b("vcoder_ds")
+    B13 = 16
+    ids13 = np.stack([synth.synth_prompt_ids(cfg13.vocab_size, "vcoder_ds", sample=b) for b in range(B13)])
+    px13 = tuple(torch.from_numpy(a).cuda() for a in synth.synth_batch(B13, cfg13.vit_image_size))
+    for key, weights, desc in (("c3_13b_bf16_b16", "bf16", "BASELINE configs[2]: VCoder-DS LLaVA-1.5-13b bf16, batch=16, 128-tok decode on one MI355X"),
+                               ("c5_slice_13b_fp8_b16", "fp8", "per-GPU slice of BASELINE configs[4]: VCoder-DS LLaVA-1.5-13b fp8-e4m3 weights "
+                                                               "(W8A8 prefill on the K=128 scaled fp8 MFMA, W8A16 decode), batch=16 per GPU")):
+        e13 = HipEngine(cfg13)
+        e13.load_synthetic(42)
+        if weights != "bf16":
+            e13.set_weight_format(weights)
+        e13.finalize()
+        leg, _ = run_leg(e13, cfg13, ids13, px13, n_new, args.extra_steps, 2)
+        leg["config"] = desc
+        leg["dtype"] = "bf16" if weights == "bf16" else "fp8-e4m3 prefill linears / bf16"
+        out[key] = leg
+        e13.close()
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -312,23 +435,32 @@ def main():
         return dt, outs
 
     timed_px = host_px if args.host_pixels else dev_px
+    # what every step must produce: the ids of this rank's batch generated ALONE (one generate() call, nothing else in
+    # flight).  Every timed step feeds the same inputs, so each of its outputs has to equal this, whoever shared its decode
+    # steps in the pool — checked below for every step of the timed region (`ids_checked`), the run fails on a mismatch.
+    lone_ids = sessions[0].generate_greedy(ids, *dev_px, max_new_tokens=N_new, eos_token_id=None)
+    lone_gathered = gather(lone_ids)
     if args.warmup > 0:
         run_steps(max(args.warmup, n_sess), timed_px)  # every session captures its decode graph before the timed region
     steps0 = eng.pool_step_counts()
     dt, outs = timed(args.steps, timed_px)
     step_mix = [a - b for a, b in zip(eng.pool_step_counts(), steps0)]   # pooled decode steps of the timed region by 8/16/24/32 rows
+    bad_steps = [j for j, o in enumerate(outs) if not np.array_equal(np.asarray(o), np.asarray(lone_gathered))]
+    ids_checked = len(bad_steps) == 0 and all(np.asarray(o).shape == (world * B, N_new) for o in outs)
     if args.dump_ids and rank == 0:
         np.save(args.dump_ids, outs[-1])
     # ---- transparency legs, outside the timed region -----------------------------------------------------------------
     # (a) the other residency of the inputs (PCIe-inclusive when `value` is resident, and vice versa)
     k_side = max(n_sess, min(args.steps, 2 * n_sess))
     other_px = dev_px if args.host_pixels else host_px
-    dt_other, _ = timed(k_side, other_px)
+    dt_other, outs_other = timed(k_side, other_px)
+    ids_checked = ids_checked and all(np.array_equal(np.asarray(o), np.asarray(lone_gathered)) for o in outs_other)
     # (b) the same step strictly one batch at a time on this rank
     fence()
     t1 = time.perf_counter()
     for _ in range(2):
-        sessions[0].generate_greedy(ids, *dev_px, max_new_tokens=N_new, eos_token_id=None)
+        o_ = sessions[0].generate_greedy(ids, *dev_px, max_new_tokens=N_new, eos_token_id=None)
+        ids_checked = ids_checked and np.array_equal(o_, lone_ids)
     torch.cuda.synchronize()
     solo = (time.perf_counter() - t1) / 2
     timings = sessions[0].last_timings()
@@ -433,8 +565,13 @@ def main():
                        "inputs": "host buffers (PCIe inclusive)" if args.host_pixels else "resident in HBM",
                        "token_gather": "vc_allgather_tokens (RCCL via the C ABI)" if comm is not None else
                                        ("torch.distributed all_gather_into_tensor (%s)" % backend if world > 1 else "none (1 GPU)")},
+            "ids_checked": bool(ids_checked),
+            "ids_check": {"what": "ids of EVERY step of the timed region (and of the side legs) == ids of the same batch generated "
+                                  "alone, bit for bit", "steps_checked": args.steps + k_side + 2, "mismatching_timed_steps": bad_steps},
             "phase_ms_one_session": timings,  # encode / prefill / decode wall time of one batch run alone
-            "one_batch_at_a_time": {"value": B / solo, "unit": "images/s per GPU", "ms_per_step": solo * 1e3},
+            "one_batch_at_a_time": {"value": B / solo, "unit": "images/s per GPU", "ms_per_step": solo * 1e3,
+                                    "label": "c2_as_written" if (args.model == "7b" and B == 8 and args.weights == "bf16") else "one generate() call at a time",
+                                    "what": "BASELINE configs[1] as written: ONE batch of %d in the GPU at a time" % B},
             ("resident_inputs" if args.host_pixels else "pcie_inclusive"): {
                 "value": world * B * k_side / dt_other, "unit": "images/s", "ms_per_step": dt_other / k_side * 1e3, "steps": k_side,
                 "note": "same loop, pixels %s" % ("resident in HBM" if args.host_pixels else
@@ -452,12 +589,19 @@ def main():
             res["cpu_baseline"] = cpu_baseline(cfg, N_new)
         if args.cpu_c1 and world == 1:
             res["cpu_c1"] = cpu_c1_full()
+        if world == 1 and not args.no_extra_legs and args.model == "7b" and args.weights == "bf16":
+            for s_ in sessions[1:]:
+                s_.close()
+            res.update(extra_legs(args, eng, cfg, ids, dev_px, lone_ids, res["value"], N_new))
         print(json.dumps(res), flush=True)
     if comm is not None:
         comm.close()
     if world > 1:
         fence()
         dist.destroy_process_group()
+    if not ids_checked:
+        raise SystemExit("bench.py: the ids of the timed region differ from the ids of the same batch generated alone "
+                         "(steps %s) - the measurement is void" % bad_steps)
 
 
 if __name__ == "__main__":

@@ -100,6 +100,9 @@ void vck_select_embed(const float* logits, int ldl, int* rows, int* next_tok, in
                       float* ssq, const float* xg_w, uint16_t* xg, int D, int npart, int V, int nrows, int advance,
                       void* stream);
 int vck_row_state_stride(void);
+/* test hook of the sampler: u[i] = the uniform in (0,1) the Gumbel-max draw derives from 32-bit hash h[i] (strictly
+ * inside the interval for EVERY h, so the Gumbel term -log(-log(u)) written to gumbel[i] is finite) */
+void vck_uniform_probe(const uint32_t* h, float* u, float* gumbel, int n, void* stream);
 void vck_embed_tokens_ssq(const int* tok, const uint16_t* embed, float* x, float* ssq, const float* xg_w, uint16_t* xg, int B,
                           int D, int npart, void* stream);
 void vck_advance(int* step_dev, int* pos_dev, int* ctx_dev, void* stream);

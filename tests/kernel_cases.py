@@ -737,6 +737,24 @@ def sample_reference_probs(lg, temperature, top_k, top_p):
     return p / p.sum()
 
 
+def check_uniform_extremes(be):
+    """the sampler's hash -> uniform map stays strictly inside (0, 1) for every 32-bit hash — including the extremes
+    (with 24 random bits, 16777215.5 rounded to 2^24 and u == 1.0 made the Gumbel term +inf: a uniformly random token)"""
+    h = np.array([0, 1, 0x1FF, 0x200, 0x7FFFFFFF, 0x80000000, 0xFFFFFE00, 0xFFFFFF00, 0xFFFFFFFE, 0xFFFFFFFF] +
+                 list(np.random.RandomState(3).randint(0, 2 ** 32, size=246, dtype=np.uint64)), dtype=np.uint32)
+    n = h.shape[0]
+    hd = be.i32(h.view(np.int32))
+    u, g = be.zeros((n,), "f32"), be.zeros((n,), "f32")
+    _call(be, "vck_uniform_probe", hd, u, g, n)
+    be.sync()
+    u, g = be.host_f32(u), be.host_f32(g)
+    assert (u > 0).all() and (u < 1).all(), f"uniform left (0,1): min {u.min()} max {u.max()}"
+    assert np.isfinite(g).all(), "Gumbel term not finite"
+    exp = ((h >> 9).astype(np.float64) + 0.5) / 8388608.0
+    assert np.array_equal(u, exp.astype(np.float32))
+    assert u[9] == np.float32(1.0 - 2.0 ** -24) and u[0] == np.float32(2.0 ** -24)
+
+
 def check_gemv_rows_agree_across_variants(be, N, K, epi, norm=True, ksplit=0, seed=0, fp8=False):
     """The decode pool's promise: a row gets bit-for-bit the same result from a 32-row pass (two MFMA row groups) as from a
     16-row pass — rows 0..15 and 16..31 of an M = 29 launch against two launches of 16 and 13 rows."""

@@ -416,6 +416,7 @@ def test_sampling_on_device_true_vocab():
     print("TV T=1.0 p=0.7:", kc.check_sampling(be, 32000, 1.0, 0, 0.7, draws=4096))
     print("TV T=0.7 k=20 p=0.9:", kc.check_sampling(be, 32000, 0.7, 20, 0.9, draws=2048))
     kc.check_select_embed(be, 8, 32000, 4096)
+    kc.check_uniform_extremes(be)
 
 
 def test_cost_harness_batched_equals_per_sample(tmp_path):

@@ -134,6 +134,7 @@ def test_device_sampling(be):
     kc.check_sampling(be, 64, 0.2, 5, 1.0, draws=256)        # serve/cli.py: temperature 0.2 (+ HF's default top_k)
     kc.check_sampling(be, 96, 1.0, 0, 0.6, draws=512)        # serve/chat.py: top_p
     kc.check_sampling(be, 64, 1.3, 12, 0.8, draws=512)
+    kc.check_uniform_extremes(be)
 
 
 def test_strict_fp32_kernels(be):

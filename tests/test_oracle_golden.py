@@ -180,3 +180,30 @@ def test_reference_tokenizers_live():
             fn_r = ref_mm.tokenizer_depth_seg_token if "<seg>" in prompt else ref_mm.tokenizer_image_token
             fn_o = mm_utils.tokenizer_depth_seg_token if "<seg>" in prompt else mm_utils.tokenizer_image_token
             assert list(fn_r(prompt, tk)) == list(fn_o(prompt, tk)), (type(tk).__name__, prompt)
+
+
+def test_sampling_oracle_equals_hf_warpers():
+    """tests/kernel_cases.py:sample_reference_probs (the fp64 restatement every device-sampling test is judged against)
+    equals HF's own TemperatureLogitsWarper -> TopKLogitsWarper -> TopPLogitsWarper chain followed by softmax — the
+    processors GenerationMixin._sample applies ([HF] generation/logits_process.py).  transformers is
+    third-party (installed in the build container and on the GPU box), not part of the reference tree."""
+    lp = pytest.importorskip("transformers.generation.logits_process")
+    import kernel_cases as kc
+
+    rng = np.random.RandomState(11)
+    for V, t, k, p in [(64, 0.7, 0, 1.0), (64, 0.2, 5, 1.0), (96, 1.0, 0, 0.6), (64, 1.3, 12, 0.8), (32000, 0.2, 50, 1.0),
+                       (32000, 1.0, 0, 0.7), (32000, 0.7, 20, 0.9), (50, 1.0, 50, 1.0), (40, 0.5, 3, 0.05)]:
+        lg = (rng.randn(V) * 1.5).astype(np.float32)
+        if V == 64:
+            lg[7] = lg[9]   # a tie inside the distribution
+        z = torch.from_numpy(lg)[None].double()
+        ids = torch.zeros((1, 1), dtype=torch.long)
+        z = lp.TemperatureLogitsWarper(float(t))(ids, z)
+        if k and k > 0:
+            z = lp.TopKLogitsWarper(top_k=int(k))(ids, z)
+        if p < 1.0:
+            z = lp.TopPLogitsWarper(top_p=float(p))(ids, z)
+        want = torch.softmax(z, -1)[0].numpy()
+        got = kc.sample_reference_probs(lg, t, k, p)
+        assert np.array_equal(got > 0, want > 0), f"support differs at V={V} T={t} k={k} p={p}"
+        assert np.abs(got - want).max() < 1e-12, (V, t, k, p, np.abs(got - want).max())

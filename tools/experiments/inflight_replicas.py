@@ -1,12 +1,12 @@
 #!/usr/bin/env python
 """Experiment: N independent engine replicas on ONE GPU, each on its own HIP stream / host thread, generating
-concurrently (prefill of one batch overlaps decode of another).  usage: python tools/inflight_test.py [n_inflight] [steps]"""
+concurrently (prefill of one batch overlaps decode of another).  usage: python tools/experiments/inflight_replicas.py [n_inflight] [steps]"""
 import os
 import sys
 import threading
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

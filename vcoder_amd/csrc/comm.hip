@@ -9,6 +9,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 
 #include "../../include/vcoder_hip.h"
@@ -33,21 +34,20 @@ struct Rccl {
 };
 constexpr int kNcclInt32 = 2;  // ncclDataType_t::ncclInt32
 
-Rccl& rccl() {
-    static Rccl r;
-    static bool tried = false;
-    if (tried) return r;
-    tried = true;
+void rccl_bind(Rccl& r) {
 #ifdef VC_EMU
     r.why = "the CPU emulator build has no RCCL";
 #else
+    std::string errs;
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
         r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         if (r.handle) break;
+        const char* e = dlerror();  // one call: it returns the message AND clears it
+        errs += std::string(errs.empty() ? "" : "; ") + (e ? e : "?");
     }
     if (!r.handle) {
-        r.why = std::string("librccl.so could not be loaded: ") + (dlerror() ? dlerror() : "?");
-        return r;
+        r.why = "librccl.so could not be loaded: " + errs;
+        return;
     }
     r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.handle, "ncclGetUniqueId"));
     r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.handle, "ncclCommInitRank"));
@@ -59,6 +59,12 @@ Rccl& rccl() {
         r.handle = nullptr;
     }
 #endif
+}
+
+Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] { rccl_bind(r); });
     return r;
 }
 

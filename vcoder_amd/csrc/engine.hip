@@ -70,6 +70,35 @@ inline size_t rup(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // invalidate the graph capture of) other sessions' streams
 thread_local hipStream_t t_stream = nullptr;
 
+// Stream creation with an optional CU mask (experiment knob): `env` = "first:count" restricts the stream to
+// `count` compute units starting at mask bit `first`.  On gfx942/gfx950 the KFD deals mask bits round-robin over the XCDs
+// (bit i -> XCD i % 8), so a contiguous bit range is an equal share of every XCD.  VC_POOL_CU_RANGE masks the decode pool's
+// stream (HBM-bound steps), VC_SESSION_CU_RANGE the sessions' streams (MFMA-bound encode + prefill): disjoint ranges let the
+// two phases run side by side on separate CUs instead of time-sharing all of them.
+hipStream_t make_stream(const char* env) {
+    hipStream_t st = nullptr;
+    const char* v = env ? getenv(env) : nullptr;
+    int first = 0, count = 0;
+#ifndef VC_EMU
+    if (v && sscanf(v, "%d:%d", &first, &count) == 2 && count > 0 && first >= 0) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        HIPCHK(hipGetDevice(&dev));
+        HIPCHK(hipGetDeviceProperties(&prop, dev));
+        const int ncu = prop.multiProcessorCount;
+        REQUIRE(first + count <= ncu, VC_ERR_INVALID, "%s=%s: the device has %d compute units", env, v, ncu);
+        std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+        for (int i = first; i < first + count; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
+        HIPCHK(hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()));
+        return st;
+    }
+#endif
+    (void)v; (void)first; (void)count;
+    // non-blocking: no implicit synchronisation with the legacy NULL stream (torch's default stream, other sessions)
+    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    return st;
+}
+
 struct Buf {  // grow-only device buffer
     void* p = nullptr;
     size_t cap = 0;
@@ -1286,8 +1315,7 @@ VC_API int vc_init(int device_id, vc_ctx** out) {
     REQUIRE(n > 0 && device_id >= 0 && device_id < n, VC_ERR_HIP, "no HIP device %d (found %d)", device_id, n);
     HIPCHK(hipSetDevice(device_id));
     ctx->device = device_id;
-    // non-blocking: no implicit synchronisation with the legacy NULL stream (torch's default stream, other sessions)
-    HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->stream = make_stream("VC_SESSION_CU_RANGE");
     *out = ctx;
     GUARD_END(ctx)
 }
@@ -1975,7 +2003,7 @@ void pool_destroy(vc_pool* p) {
     p->cv_driver.notify_all();
     if (p->driver.joinable()) p->driver.join();
     (void)hipSetDevice(p->device);
-    (void)hipStreamSynchronize(p->st);
+    if (p->st) (void)hipStreamSynchronize(p->st);
     for (auto& g : p->graph)
         if (g) (void)hipGraphExecDestroy(g);
     for (Buf* b : {&p->kc, &p->vc, &p->rows, &p->x_dec, &p->xg_dec, &p->qkv_dec, &p->attn_dec, &p->h_dec, &p->logits,
@@ -1989,52 +2017,70 @@ void pool_destroy(vc_pool* p) {
 
 std::mutex g_pool_create;
 
-// the root model's pool with room for `need_S` positions and `need_out` ids per row; an idle pool that is too small is
-// rebuilt, a busy one makes the caller wait for it to drain
+// the root model's pool with room for `need_S` positions and `need_out` ids per row; an idle pool that is too small (or that
+// stopped after an error) is rebuilt, a busy one makes the caller wait for it to drain.  The pool is returned ACQUIRED:
+// p->users was incremented while g_pool_create was still held, so no concurrent pool_for can find it idle and destroy it
+// before the caller has registered (callers release with pool_release).
 vc_pool* pool_for(vc_model* m, int need_S, int need_out) {
     vc_model* root = m->root ? m->root : m;
     const vc_model_cfg& c = root->c;
     std::unique_lock<std::mutex> create(g_pool_create);
     vc_pool* p = root->pool;
-    if (p && (p->capS < need_S || p->out_stride < need_out)) {
+    if (p) {
         std::unique_lock<std::mutex> lk(p->mu);
-        p->cv_rows.wait(lk, [&] { return p->users == 0; });
-        lk.unlock();
-        pool_destroy(p);
-        root->pool = p = nullptr;
+        if (p->capS < need_S || p->out_stride < need_out || p->stop) {
+            p->cv_rows.wait(lk, [&] { return p->users == 0; });
+            lk.unlock();
+            pool_destroy(p);
+            root->pool = p = nullptr;
+        } else {
+            p->users += 1;
+            return p;
+        }
     }
-    if (p) return p;
     p = new vc_pool();
-    p->root = root;
-    p->device = root->ctx->device;
-    const int D = c.hidden, F = c.ffn, H = c.heads, R = p->R;
-    p->capS = std::min((int)rup(std::max(need_S, 2048), 64), c.max_positions / 64 * 64);
-    p->out_stride = std::max(need_out, p->capS);
-    REQUIRE(p->capS >= need_S, VC_ERR_INVALID, "sequence %d exceeds max_position_embeddings=%d", need_S, c.max_positions);
-    HIPCHK(hipStreamCreateWithFlags(&p->st, hipStreamNonBlocking));
-    t_stream = p->st;  // zero-fills of the new buffers
-    const size_t kvb = (size_t)c.layers * R * H * p->capS * root->hd * 2;
-    p->kc.ensure(kvb, true);
-    p->vc.ensure(kvb, true);
-    p->rows.ensure((size_t)R * RS_STRIDE * 4, true);
-    p->x_dec.ensure((size_t)R * D * 4, true);
-    p->xg_dec.ensure((size_t)R * D * 2, true);
-    p->qkv_dec.ensure((size_t)R * 3 * D * 2, true);
-    p->attn_dec.ensure((size_t)R * D * 2, true);
-    p->h_dec.ensure((size_t)R * F * 2, true);
-    p->logits.ensure((size_t)R * c.vocab * 4, true);
-    p->next_tok.ensure(R * 4, true);
-    p->out_ids.ensure((size_t)R * p->out_stride * 4, true);
-    p->ssq.ensure((size_t)R * root->npart * 4, true);
-    p->sk_scratch.ensure((size_t)4 * 512 * 2 * 256 * 4);   // [ksplit <= 4][tiles <= 512][2 row groups][256]
-    p->sk_counters.ensure(512 * 2 * 4, true);
-    t_stream = m->st;
-    for (auto& e : p->step_ev) HIPCHK(hipEventCreate(&e));
-    const LoopView v = pool_view(p);
-    for (int i = 0; i < R / 8; ++i) p->graph[i] = capture_step(root, v, 8 * (i + 1));
-    p->driver = std::thread(pool_driver, p);
+    try {
+        p->root = root;
+        p->device = root->ctx->device;
+        const int D = c.hidden, F = c.ffn, H = c.heads, R = p->R;
+        p->capS = std::min((int)rup(std::max(need_S, 2048), 64), c.max_positions / 64 * 64);
+        p->out_stride = std::max(need_out, p->capS);
+        REQUIRE(p->capS >= need_S, VC_ERR_INVALID, "sequence %d exceeds max_position_embeddings=%d", need_S, c.max_positions);
+        p->st = make_stream("VC_POOL_CU_RANGE");
+        t_stream = p->st;  // zero-fills of the new buffers
+        const size_t kvb = (size_t)c.layers * R * H * p->capS * root->hd * 2;
+        p->kc.ensure(kvb, true);
+        p->vc.ensure(kvb, true);
+        p->rows.ensure((size_t)R * RS_STRIDE * 4, true);
+        p->x_dec.ensure((size_t)R * D * 4, true);
+        p->xg_dec.ensure((size_t)R * D * 2, true);
+        p->qkv_dec.ensure((size_t)R * 3 * D * 2, true);
+        p->attn_dec.ensure((size_t)R * D * 2, true);
+        p->h_dec.ensure((size_t)R * F * 2, true);
+        p->logits.ensure((size_t)R * c.vocab * 4, true);
+        p->next_tok.ensure(R * 4, true);
+        p->out_ids.ensure((size_t)R * p->out_stride * 4, true);
+        p->ssq.ensure((size_t)R * root->npart * 4, true);
+        p->sk_scratch.ensure((size_t)4 * 512 * 2 * 256 * 4);   // [ksplit <= 4][tiles <= 512][2 row groups][256]
+        p->sk_counters.ensure(512 * 2 * 4, true);
+        t_stream = m->st;
+        for (auto& e : p->step_ev) HIPCHK(hipEventCreate(&e));
+        const LoopView v = pool_view(p);
+        for (int i = 0; i < R / 8; ++i) p->graph[i] = capture_step(root, v, 8 * (i + 1));
+        p->driver = std::thread(pool_driver, p);
+    } catch (...) {  // a failed allocation / capture must not leak the half-built pool or leave t_stream on its stream
+        t_stream = m->st;
+        pool_destroy(p);
+        throw;
+    }
+    p->users = 1;
     root->pool = p;
     return p;
+}
+void pool_release(vc_pool* p) {
+    std::lock_guard<std::mutex> lk(p->mu);
+    p->users -= 1;
+    p->cv_rows.notify_all();
 }
 
 // generate() through the pool: prefill on the session's stream into pool rows, decode steps shared with whoever else is in
@@ -2052,13 +2098,17 @@ void generate_on_pool(vc_model* m, const int64_t* ids, int B, int T, const float
                       int cb_every, int32_t* out_ids, int* n_generated) {
     const vc_model_cfg& c = m->c;
     const int max_new = g.max_new;
-    // the spliced length is only known after the splice plan; an upper bound sizes the pool: every placeholder could
-    // expand to a feature block
-    int n_ph = 0;
-    for (int t = 0; t < T; ++t) n_ph += ids[t] < 0;
-    const int R_img = m->Tv;
-    const int S_bound = std::min(c.max_positions, T + std::max(n_ph, 1) * 3 * R_img);
-    vc_pool* p = pool_for(m, std::min(S_bound + max_new, c.max_positions / 64 * 64), max_new);
+    // the spliced length is only known after the splice plan; an upper bound sizes the pool: the text rows plus one
+    // feature block per image the sample owns (vc_set_image_counts: the list / 5-D form gives a sample several images per
+    // modality; otherwise one per modality), over the sample with the most images
+    int n_img_max = 3;
+    for (int b = 0; b < B; ++b) {
+        int n_b = 0;
+        for (int k = 0; k < 3; ++k) n_b += m->img_counts[k].empty() ? 1 : ((int)m->img_counts[k].size() == B ? m->img_counts[k][b] : 1);
+        n_img_max = std::max(n_img_max, n_b);
+    }
+    const int S_bound = std::min(c.max_positions, T + n_img_max * m->Tv);
+    vc_pool* p = pool_for(m, std::min(S_bound + max_new, c.max_positions / 64 * 64), max_new);  // acquired: users counted
     PoolRequest rq;
     rq.sess = m;
     rq.B = B;
@@ -2070,7 +2120,6 @@ void generate_on_pool(vc_model* m, const int64_t* ids, int B, int T, const float
     // ---- rows: first fit of B contiguous free rows; blocks while the pool is full
     {
         std::unique_lock<std::mutex> lk(p->mu);
-        p->users += 1;
         int row0 = -1;
         p->cv_rows.wait(lk, [&] {
             for (int r0 = 0; r0 + B <= p->R; ++r0) {
@@ -2475,6 +2524,7 @@ VC_API int vc_profile_decode_attention(vc_model* m, int B, int ctx, int reps, in
         v = session_view(m);
     } else {
         vc_pool* p = pool_for(m, ctx + 64, 1);
+        pool_release(p);  // measurement hook: the caller guarantees that no generate() runs meanwhile
         {
             std::lock_guard<std::mutex> lk(p->mu);
             REQUIRE(p->users == 0 && p->active.empty() && p->pending.empty(), VC_ERR_STATE, "the decode pool is busy");
@@ -2543,6 +2593,7 @@ VC_API int vc_profile_decode_gemv(vc_model* m, int B, int reps, int* launches, d
         v = session_view(m);
     } else {  // 17..32 rows: the decode pool's buffers (it must be idle), launches on this session's stream
         vc_pool* p = pool_for(m, 64, 1);
+        pool_release(p);  // measurement hook: the caller guarantees that no generate() runs meanwhile
         {
             std::lock_guard<std::mutex> lk(p->mu);
             REQUIRE(p->users == 0 && p->active.empty() && p->pending.empty(), VC_ERR_STATE, "the decode pool is busy");

@@ -66,6 +66,9 @@ VCK_EXPORT void vck_select_embed(const float* logits, int ldl, int* rows, int* n
     launch_select_embed(a, S(stream));
 }
 VCK_EXPORT int vck_row_state_stride() { return RS_STRIDE; }
+VCK_EXPORT void vck_uniform_probe(const uint32_t* h, float* u, float* gumbel, int n, void* stream) {
+    launch_uniform_probe(h, u, gumbel, n, S(stream));
+}
 VCK_EXPORT void vck_embed_tokens_ssq(const int* tok, const uint16_t* embed, float* x, float* ssq, const float* xg_w,
                                      uint16_t* xg, int B, int D, int npart, void* stream) {
     launch_embed_tokens_ssq(tok, embed, x, ssq, xg_w, xg, B, D, npart, S(stream));

@@ -239,6 +239,8 @@ void launch_select_embed(const SelectArgs& a, hipStream_t s);
 void launch_embed_tokens_ssq(const int* tok, const bf16_t* embed, float* x, float* ssq, const float* xg_w, bf16_t* xg, int B, int D, int npart,
                              hipStream_t s);
 void launch_advance(int* step_dev, int* pos_dev, int* ctx_dev, hipStream_t s);
+// test hook: u[i] = the sampler's uniform for hash value h[i], gumbel[i] = -log(-log(u[i]))
+void launch_uniform_probe(const uint32_t* h, float* u, float* gumbel, int n, hipStream_t s);
 
 // ---- strict (fp32-faithful) path: see strict.hip -------------------------------------------------------------------
 struct GemmF32Args {

@@ -36,11 +36,14 @@ VC_DEV uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
     return x;
 }
-// uniform in (0,1) from (seed, step, index): 24 random bits, never 0 or 1
+// uniform strictly inside (0,1) from a 32-bit hash: 23 random bits, so that (h >> 9) + 0.5 is exact in fp32 and the
+// largest value is 1 - 2^-24 (with 24 bits, 16777215.5 rounds to 2^24 and u == 1 makes the Gumbel term +inf)
+VC_DEV float uniform_open01(uint32_t h) { return ((float)(h >> 9) + 0.5f) * (1.0f / 8388608.0f); }
+// uniform in (0,1) from (seed, step, index), never 0 or 1
 VC_DEV float sample_uniform(uint32_t seed_lo, uint32_t seed_hi, uint32_t step, uint32_t idx) {
     uint32_t h = mix32(idx * 0x9E3779B1u + seed_lo);
     h = mix32(h ^ (step * 0x85EBCA6Bu + seed_hi));
-    return ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    return uniform_open01(h);
 }
 
 struct BlockRed {  // cross-wave scratch of the 1024-thread workgroup
@@ -247,6 +250,17 @@ void launch_select_embed(const SelectArgs& a0, hipStream_t s) {
     }
 #endif
     VC_LAUNCH(select_embed_kernel, dim3(a.nrows), dim3(1024), lds, s, a);
+}
+
+// test hook: the sampler's hash -> uniform map on explicit hash values (the extreme h = 0xFFFFFFFF must stay below 1)
+__global__ __launch_bounds__(64) void uniform_probe_kernel(const uint32_t* h, float* u, float* gumbel, int n) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    u[i] = uniform_open01(h[i]);
+    gumbel[i] = -__logf(-__logf(u[i]));
+}
+void launch_uniform_probe(const uint32_t* h, float* u, float* gumbel, int n, hipStream_t s) {
+    VC_LAUNCH(uniform_probe_kernel, dim3((n + 63) / 64), dim3(64), 0, s, h, u, gumbel, n);
 }
 
 // embedding + sum-of-squares partials for tokens supplied by the host (vc_decode_step with explicit tokens)

@@ -218,6 +218,8 @@ class HipEngine:
         """-> ([img, seg, depth] concatenated pixel blocks, keep-alive counts arrays); announces per-sample image counts
         to the library (one-shot, consumed by the next prefill / generate call)."""
         blocks, counts = zip(*(self._image_block(a, B) for a in (images, segs, depths)))
+        # images one placeholder can expand to: the largest per-sample image group of any modality (1 in the 4-D form)
+        self._max_images_per_block = max([1] + [max(c) for c in counts if c is not None])
         if any(c is not None for c in counts):
             arrs = [None if blk is None else np.ascontiguousarray(c if c is not None else [1] * B, dtype=np.int32)
                     for blk, c in zip(blocks, counts)]
@@ -253,7 +255,7 @@ class HipEngine:
         # first call sizes the output; lengths are only known after the splice plan, so run twice is avoided by
         # allocating for the worst case: every placeholder expands to a feature block
         rows = self.cfg.num_patches + (1 if self.cfg.mm_vision_select_feature == "cls_patch" else 0)
-        worst = T + rows * self._max_feature_blocks(ids, keep)
+        worst = T + rows * self._max_feature_blocks(ids)
         out = np.empty((B * worst * self.cfg.hidden_size,), dtype=np.float32)
         self._check(self.lib.vc_prefill_embeds_only(self._model, ids.ctypes.data_as(C.c_void_p), B, T, pi, ps, pd, on_dev,
                                                     int(has_attention_mask), out.ctypes.data_as(C.c_void_p), C.byref(S)))
@@ -279,7 +281,7 @@ class HipEngine:
             self._cur_batch = B
             return last, None, S.value
         rows = self.cfg.num_patches + (1 if self.cfg.mm_vision_select_feature == "cls_patch" else 0)
-        worst = T + rows * self._max_feature_blocks(ids, keep)
+        worst = T + rows * self._max_feature_blocks(ids)
         full = np.empty((B * worst * V,), dtype=np.float32)
         self._check(self.lib.vc_prefill(self._model, ids.ctypes.data_as(C.c_void_p), B, T, pi, ps, pd, on_dev,
                                         int(has_attention_mask), last.ctypes.data_as(C.c_void_p),
@@ -288,12 +290,13 @@ class HipEngine:
         self._cur_batch = B
         return last, full[: B * S.value * V].reshape(B, S.value, V).copy(), S.value
 
-    @staticmethod
-    def _max_feature_blocks(ids, pixel_blocks) -> int:
-        """upper bound of the image blocks (of `rows` feature rows) one sample can splice: every placeholder could expand
-        to all images of a modality"""
-        n_images = sum(int(b.shape[0]) for b in pixel_blocks)
-        return max(1, int((ids < 0).sum(axis=1).max())) * max(1, n_images)
+    _max_images_per_block = 1
+
+    def _max_feature_blocks(self, ids) -> int:
+        """upper bound of the image blocks (of `rows` feature rows) ONE sample can splice: each of its placeholders expands
+        to the images of one per-sample group (bounded by the largest group of the call) — per sample, not multiplied by
+        the batch: the host buffers sized from it are B * (T + rows * this) rows"""
+        return max(1, int((ids < 0).sum(axis=1).max())) * self._max_images_per_block
 
     def vision_tower_forward(self, pixels) -> np.ndarray:
         """CLIPVisionTower.forward (clip_encoder.py:39-51): [N,3,S,S] -> un-projected features [N, R, mm_hidden_size]."""
