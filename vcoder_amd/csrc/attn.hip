@@ -83,6 +83,102 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(QkvSplitArgs p) {
     }
 }
 
+// ---- precision mode "split": fp32 projection output -> RoPE in fp32 -> (i) the fp32 K / V cache rows the decode steps read,
+// (ii) bf16 hi / lo planes of Q, K and V^T for the MFMA flash kernel of THIS prefill / ViT layer (x = hi + lo to ~16 bits)
+VC_DEV void split8(const float* v, u32x4& hi, u32x4& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        hi[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+        lo[e] = pack_bf2(v[2 * e] - bf2f_lo(hi[e]), v[2 * e + 1] - bf2f_hi(hi[e]));
+    }
+}
+template <int HD>
+__global__ __launch_bounds__(256) void qkv_split32_kernel(QkvSplit32Args p) {
+    const float* __restrict__ rope_cos = p.rope_cos;
+    const float* __restrict__ rope_sin = p.rope_sin;
+    __shared__ __attribute__((aligned(16))) bf16_t vt_tile[2][64][HD + 8];  // [hi / lo][token][d]
+    const int t0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x;
+    const int D = p.H * HD;
+    constexpr int CPT = HD / 16;  // rope work items per token: chunk c pairs d0 = 8c with d0 + HD/2
+    const bool rope = rope_cos != nullptr;
+    const size_t bh = (size_t)b * p.H + h;
+    for (int w = tid; w < 64 * CPT; w += 256) {
+        const int tl = w / CPT, c = w % CPT, t = t0 + tl;
+        if (t >= p.T) continue;
+        const float* row = p.qkv + ((size_t)b * p.T + t) * (3 * D) + h * HD;
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {  // 0 = q, 1 = k
+            const float* src = row + which * D;
+            float x[8], y[8], ox[8], oy[8];
+            *reinterpret_cast<f32x4*>(x) = ld16f(src + c * 8);
+            *reinterpret_cast<f32x4*>(x + 4) = ld16f(src + c * 8 + 4);
+            *reinterpret_cast<f32x4*>(y) = ld16f(src + HD / 2 + c * 8);
+            *reinterpret_cast<f32x4*>(y + 4) = ld16f(src + HD / 2 + c * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float cs = 1.f, sn = 0.f;
+                if (rope) {
+                    cs = rope_cos[(size_t)t * (HD / 2) + c * 8 + e];
+                    sn = rope_sin[(size_t)t * (HD / 2) + c * 8 + e];
+                }
+                ox[e] = x[e] * cs - y[e] * sn;   // out[d] = x*cos - y*sin ; out[d+hd/2] = y*cos + x*sin
+                oy[e] = y[e] * cs + x[e] * sn;
+            }
+            u32x4 xh, xl, yh, yl;
+            split8(ox, xh, xl);
+            split8(oy, yh, yl);
+            const size_t off = which == 0 ? (bh * p.q_stride + t) * HD : (bh * p.ks_stride + t) * HD;
+            bf16_t* dh = (which == 0 ? p.q_hi : p.k_hi) + off;
+            bf16_t* dl = (which == 0 ? p.q_lo : p.k_lo) + off;
+            st16(dh + c * 8, xh);
+            st16(dl + c * 8, xl);
+            st16(dh + HD / 2 + c * 8, yh);
+            st16(dl + HD / 2 + c * 8, yl);
+            if (which == 1 && p.k32 != nullptr) {
+                float* kc = p.k32 + (bh * p.kv_stride + t) * HD;
+                st16f(kc + c * 8, *reinterpret_cast<f32x4*>(ox));
+                st16f(kc + c * 8 + 4, *reinterpret_cast<f32x4*>(ox + 4));
+                st16f(kc + HD / 2 + c * 8, *reinterpret_cast<f32x4*>(oy));
+                st16f(kc + HD / 2 + c * 8 + 4, *reinterpret_cast<f32x4*>(oy + 4));
+            }
+        }
+    }
+    for (int w = tid; w < 64 * (HD / 8); w += 256) {
+        const int tl = w / (HD / 8), c = w % (HD / 8), t = t0 + tl;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (t < p.T) {
+            const float* src = p.qkv + ((size_t)b * p.T + t) * (3 * D) + 2 * D + h * HD + c * 8;
+            *reinterpret_cast<f32x4*>(v) = ld16f(src);
+            *reinterpret_cast<f32x4*>(v + 4) = ld16f(src + 4);
+            if (p.v32 != nullptr) {
+                float* vc = p.v32 + (bh * p.kv_stride + t) * HD + c * 8;
+                st16f(vc, *reinterpret_cast<f32x4*>(v));
+                st16f(vc + 4, *reinterpret_cast<f32x4*>(v + 4));
+            }
+        }
+        u32x4 vh, vl;
+        split8(v, vh, vl);
+        st16(&vt_tile[0][tl][c * 8], vh);
+        st16(&vt_tile[1][tl][c * 8], vl);
+    }
+    __syncthreads();
+    for (int w = tid; w < 2 * HD * 8; w += 256) {
+        const int pl = w / (HD * 8), d = (w >> 3) % HD, tc = w & 7;
+        if (t0 + tc * 8 >= p.T) continue;
+        uint32_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            o[e] = (uint32_t)vt_tile[pl][tc * 8 + 2 * e][d] | ((uint32_t)vt_tile[pl][tc * 8 + 2 * e + 1][d] << 16);
+        st16((pl ? p.vt_lo : p.vt_hi) + (bh * HD + d) * p.vt_stride + t0 + tc * 8, u32x4{o[0], o[1], o[2], o[3]});
+    }
+}
+void launch_qkv_split32(const QkvSplit32Args& a, hipStream_t s) {
+    const dim3 grid((a.T + 63) / 64, a.H, a.B), block(256);
+    if (a.hd == 128) VC_LAUNCH((qkv_split32_kernel<128>), grid, block, 0, s, a);
+    else VC_LAUNCH((qkv_split32_kernel<64>), grid, block, 0, s, a);
+}
+
 void launch_qkv_split(const QkvSplitArgs& a, hipStream_t s) {
     const dim3 grid((a.T + 63) / 64, a.H, a.B), block(256);
     if (a.hd == 128) VC_LAUNCH((qkv_split_kernel<128>), grid, block, 0, s, a);
@@ -98,15 +194,28 @@ template <int HD> VC_DEV int swz_k(int row, int chunk) {  // K tile [64][HD] bf1
 }
 VC_DEV int swz_v(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }  // V^T tile [HD][64]
 
-template <int HD, bool CAUSAL, int WAVES, int QS>
-__global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && QS == 1) ? 4 : 1) void attention_kernel(AttnArgs p) {  // 8 x 16: two workgroups per CU (<= 128 VGPRs)
+// SPLIT (precision mode "split"): every operand comes as two bf16 planes (x = hi + lo, ~16 mantissa bits): S^T = Kh Qh + Kh Ql
+// + Kl Qh, the softmax numerators are split the same way in registers, O^T += Vh Ph + Vh Pl + Vl Ph (the lo x lo terms are
+// below 2^-18 relative), and the output row is written as [hi | lo] at columns h*HD and lo_off + h*HD of a row of ldo
+// elements.  Twice the LDS per stage (dynamic shared memory: 128 KiB at hd 128, one workgroup per CU).
+template <int HD, bool CAUSAL, int WAVES, int QS, bool SPLIT = false>
+__global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && QS == 1 && !SPLIT) ? 4 : 1) void attention_kernel(AttnArgs p) {  // 8 x 16: two workgroups per CU (<= 128 VGPRs)
     constexpr int NTH = WAVES * 64;       // threads per workgroup
     constexpr int QB = WAVES * QS * 16;   // queries per workgroup
     constexpr int KS = HD / 32;        // k-steps of the QK^T contraction
     constexpr int DT = HD / 16;        // 16-wide d tiles of the output
     constexpr int KCH = HD / 8;        // 16-B chunks per K row
     constexpr int KB_ = 64 * HD * 2, VB_ = HD * 128;   // bytes of a K tile [64 keys][HD] and a V^T tile [HD][64 keys]
-    __shared__ __attribute__((aligned(16))) char lds[2][KB_ + VB_];   // double-buffered: the LDS-DMA of tile t+1 lands under tile t
+    constexpr int PL = SPLIT ? 2 : 1;                  // operand planes
+    constexpr int STAGE = PL * (KB_ + VB_);            // [K hi | K lo | V^T hi | V^T lo]
+    char* lds0;                                        // [2][STAGE], double-buffered: the LDS-DMA of tile t+1 lands under tile t
+    if constexpr (SPLIT) {
+        VC_DYNAMIC_SMEM(char, lds_dyn);
+        lds0 = lds_dyn;
+    } else {
+        __shared__ __attribute__((aligned(16))) char lds_st[2 * STAGE];
+        lds0 = lds_st;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, j = lane & 15;
     const int q0 = blockIdx.x * QB, h = blockIdx.y, b = blockIdx.z;
@@ -115,14 +224,20 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && QS == 1) ? 4 : 1) void a
     const bf16_t* kbase = p.k + bh * p.kv_stride * HD;
     const int vts = p.vt_stride > 0 ? p.vt_stride : p.kv_stride;
     const bf16_t* vbase = p.vt + bh * HD * (size_t)vts;
+    const bf16_t* qbase_lo = SPLIT ? p.q_lo + bh * p.q_stride * HD : nullptr;
+    const bf16_t* kbase_lo = SPLIT ? p.k_lo + bh * p.kv_stride * HD : nullptr;
+    const bf16_t* vbase_lo = SPLIT ? p.vt_lo + bh * HD * (size_t)vts : nullptr;
 
     // Q fragments (MFMA B operand): lane holds Q[query j][d = ks*32 + g*8 .. +8]
-    u32x4 qf[QS][KS];
+    u32x4 qf[QS][KS], qfl[SPLIT ? QS : 1][SPLIT ? KS : 1];
 #pragma unroll
     for (int qs = 0; qs < QS; ++qs) {
         const int qrow = min(q0 + wave * (QS * 16) + qs * 16 + j, p.T - 1);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[qs][ks] = ld16(qbase + (size_t)qrow * HD + ks * 32 + g * 8);
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[qs][ks] = ld16(qbase + (size_t)qrow * HD + ks * 32 + g * 8);
+            if constexpr (SPLIT) qfl[qs][ks] = ld16(qbase_lo + (size_t)qrow * HD + ks * 32 + g * 8);
+        }
     }
     f32x4 o[QS][DT];
 #pragma unroll
@@ -144,22 +259,35 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && QS == 1) ? 4 : 1) void a
     static_assert(KPIECES >= 1 && VPIECES >= 1 && KB_ % (1024 * WAVES) == 0 && VB_ % (1024 * WAVES) == 0, "pieces per wave");
     const char* ksrc[KPIECES];
     const char* vsrc[VPIECES];
+    size_t koff[KPIECES], voff[VPIECES];   // element offsets inside a (b,h) plane: the lo planes share them
 #pragma unroll
     for (int i = 0; i < KPIECES; ++i) {
         const int piece = i * WAVES + wave, row = piece * KROWS + lane / KCH, slot = lane % KCH;
         const int ch = HD == 128 ? (slot ^ (row & 15)) : (slot ^ (row & 7));
-        ksrc[i] = reinterpret_cast<const char*>(kbase + (size_t)row * HD + ch * 8);
+        koff[i] = (size_t)row * HD + ch * 8;
+        ksrc[i] = reinterpret_cast<const char*>(kbase + koff[i]);
     }
 #pragma unroll
     for (int i = 0; i < VPIECES; ++i) {
         const int piece = i * WAVES + wave, row = piece * 8 + (lane >> 3), slot = lane & 7;
-        vsrc[i] = reinterpret_cast<const char*>(vbase + (size_t)row * vts + ((slot ^ ((row >> 1) & 7)) * 8));
+        voff[i] = (size_t)row * vts + ((slot ^ ((row >> 1) & 7)) * 8);
+        vsrc[i] = reinterpret_cast<const char*>(vbase + voff[i]);
     }
+    // stage layout: K hi at 0, [K lo at KB_,] V^T hi at PL*KB_, [V^T lo at PL*KB_ + VB_]
     auto issue_tile = [&](int kt, int buf) {
+        char* st = lds0 + buf * STAGE;
 #pragma unroll
-        for (int i = 0; i < KPIECES; ++i) glds16(ksrc[i] + (size_t)kt * (64 * HD * 2), lds[buf] + (i * WAVES + wave) * 1024);
+        for (int i = 0; i < KPIECES; ++i) {
+            glds16(ksrc[i] + (size_t)kt * (64 * HD * 2), st + (i * WAVES + wave) * 1024);
+            if constexpr (SPLIT)
+                glds16(reinterpret_cast<const char*>(kbase_lo + koff[i]) + (size_t)kt * (64 * HD * 2), st + KB_ + (i * WAVES + wave) * 1024);
+        }
 #pragma unroll
-        for (int i = 0; i < VPIECES; ++i) glds16(vsrc[i] + (size_t)kt * 128, lds[buf] + KB_ + (i * WAVES + wave) * 1024);
+        for (int i = 0; i < VPIECES; ++i) {
+            glds16(vsrc[i] + (size_t)kt * 128, st + PL * KB_ + (i * WAVES + wave) * 1024);
+            if constexpr (SPLIT)
+                glds16(reinterpret_cast<const char*>(vbase_lo + voff[i]) + (size_t)kt * 128, st + PL * KB_ + VB_ + (i * WAVES + wave) * 1024);
+        }
     };
 
     issue_tile(0, 0);
@@ -169,8 +297,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && QS == 1) ? 4 : 1) void a
         wait_vmcnt<0>();
         __syncthreads();
         if (kt + 1 < nkt) issue_tile(kt + 1, (kt + 1) & 1);
-        const char* k_lds = lds[kt & 1];
-        const char* v_lds = lds[kt & 1] + KB_;
+        const char* k_lds = lds0 + (kt & 1) * STAGE;
+        const char* v_lds = k_lds + PL * KB_;
         const int k0 = kt * 64;
         // ---- S^T = K Q^T
         f32x4 sacc[QS][4];
@@ -185,6 +313,14 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && QS == 1) ? 4 : 1) void a
                 const u32x4 kf = ld16(k_lds + swz_k<HD>(sub * 16 + j, ks * 4 + g));
 #pragma unroll
                 for (int qs = 0; qs < QS; ++qs) sacc[qs][sub] = mfma16(kf, qf[qs][ks], sacc[qs][sub]);
+                if constexpr (SPLIT) {
+                    const u32x4 kl = ld16(k_lds + KB_ + swz_k<HD>(sub * 16 + j, ks * 4 + g));
+#pragma unroll
+                    for (int qs = 0; qs < QS; ++qs) {
+                        sacc[qs][sub] = mfma16(kf, qfl[qs][ks], sacc[qs][sub]);
+                        sacc[qs][sub] = mfma16(kl, qf[qs][ks], sacc[qs][sub]);
+                    }
+                }
             }
         // ---- online softmax (lane owns query j of each q-subtile; keys spread over regs and the 4 lane groups).  The
         // kernel is bound by these VALU / transcendental instructions, not by its MFMAs (per query-key pair: 256 MACs =
@@ -192,7 +328,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && QS == 1) ? 4 : 1) void a
         // the running maximum is kept on the RAW scores (scale > 0 commutes with max), scale * log2(e) is folded into the
         // one FMA that feeds v_exp_f32, and the key mask is only evaluated in tiles that contain a masked key (the
         // diagonal tiles of a causal pass, the ragged last tile) — a wave-uniform branch.
-        u32x4 pb[QS][2];
+        u32x4 pb[QS][2], pbl[SPLIT ? QS : 1][2];
 #pragma unroll
         for (int qs = 0; qs < QS; ++qs) {
             const int qfirst = q0 + wave * (QS * 16) + qs * 16;     // smallest query of this sub-tile
@@ -234,6 +370,16 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && QS == 1) ? 4 : 1) void a
                                    pack_bf2(sacc[qs][2 * kh][2], sacc[qs][2 * kh][3]),
                                    pack_bf2(sacc[qs][2 * kh + 1][0], sacc[qs][2 * kh + 1][1]),
                                    pack_bf2(sacc[qs][2 * kh + 1][2], sacc[qs][2 * kh + 1][3])};
+            if constexpr (SPLIT) {
+#pragma unroll
+                for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const f32x4& sv = sacc[qs][2 * kh + (e >> 1)];
+                        const uint32_t hi = pb[qs][kh][e];
+                        pbl[qs][kh][e] = pack_bf2(sv[2 * (e & 1)] - bf2f_lo(hi), sv[2 * (e & 1) + 1] - bf2f_hi(hi));
+                    }
+            }
         }
         // ---- O^T += V^T P^T   (contraction slot (g,e) <-> key kh*32 + (e>>2)*16 + 4g + (e&3) on both operands)
 #pragma unroll
@@ -247,6 +393,16 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && QS == 1) ? 4 : 1) void a
                 const u32x4 vf = {lo[0], lo[1], hi[0], hi[1]};
 #pragma unroll
                 for (int qs = 0; qs < QS; ++qs) o[qs][dt] = mfma16(vf, pb[qs][kh], o[qs][dt]);
+                if constexpr (SPLIT) {
+                    const u32x2 llo = ld8(v_lds + VB_ + swz_v(row, c0) + within);
+                    const u32x2 lhi = ld8(v_lds + VB_ + swz_v(row, c0 + 2) + within);
+                    const u32x4 vl = {llo[0], llo[1], lhi[0], lhi[1]};
+#pragma unroll
+                    for (int qs = 0; qs < QS; ++qs) {
+                        o[qs][dt] = mfma16(vf, pbl[qs][kh], o[qs][dt]);
+                        o[qs][dt] = mfma16(vl, pb[qs][kh], o[qs][dt]);
+                    }
+                }
             }
     }
     // ---- normalise and store: lane holds out[query j][d = dt*16 + g*4 .. +4]
@@ -258,11 +414,16 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && QS == 1) ? 4 : 1) void a
         const float inv = 1.0f / l;
         const int query = q0 + wave * (QS * 16) + qs * 16 + j;
         if (query < p.T) {
-            bf16_t* dst = p.out + ((size_t)b * p.T + query) * ((size_t)p.H * HD) + h * HD + g * 4;
+            const size_t ldo = SPLIT ? (size_t)p.ldo : (size_t)p.H * HD;
+            bf16_t* dst = p.out + ((size_t)b * p.T + query) * ldo + h * HD + g * 4;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 const f32x4 v = o[qs][dt] * inv;
-                st8(dst + dt * 16, u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])});
+                const u32x2 hi = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                st8(dst + dt * 16, hi);
+                if constexpr (SPLIT)
+                    st8(dst + p.lo_off + dt * 16, u32x2{pack_bf2(v[0] - bf2f_lo(hi[0]), v[1] - bf2f_hi(hi[0])),
+                                                        pack_bf2(v[2] - bf2f_lo(hi[1]), v[3] - bf2f_hi(hi[1]))});
             }
         }
     }
@@ -276,7 +437,30 @@ static void launch_attention_v(const AttnArgs& a, hipStream_t s) {
     else VC_LAUNCH((attention_kernel<HD, false, WAVES, QS>), grid, block, 0, s, a);
 }
 
+template <int HD>
+static void launch_attention_split(const AttnArgs& a, hipStream_t s) {
+    const dim3 grid((a.T + 127) / 128, a.H, a.B), block(512);
+    constexpr size_t shmem = 2 * 2 * (64 * HD * 2 + HD * 128);   // [2 stages][K hi | K lo | V^T hi | V^T lo]
+#ifndef VC_EMU
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<HD, true, 8, 1, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<HD, false, 8, 1, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        once = true;
+    }
+#endif
+    if (a.causal) VC_LAUNCH((attention_kernel<HD, true, 8, 1, true>), grid, block, shmem, s, a);
+    else VC_LAUNCH((attention_kernel<HD, false, 8, 1, true>), grid, block, shmem, s, a);
+}
+
 void launch_attention(const AttnArgs& a, hipStream_t s) {
+    if (a.q_lo != nullptr) {  // precision mode "split": hi / lo operand planes
+        if (a.hd == 128) launch_attention_split<128>(a, s);
+        else launch_attention_split<64>(a, s);
+        return;
+    }
     // 8 waves x 16 queries keeps the hd-128 kernel at 128 VGPRs (the 4x32 form needs ~250 -> 1 wave/SIMD); measured on
     // MI355X: prefill (hd 128, T 1216, causal) 288 us vs 378 us; ViT (hd 64, T 577) 97 us vs 117 us.
     static const int variant = getenv("VC_ATTN_VARIANT") ? atoi(getenv("VC_ATTN_VARIANT")) : 0;
@@ -308,9 +492,13 @@ void launch_attention(const AttnArgs& a, hipStream_t s) {
 // =============================================================================================
 constexpr int DEC_MAX_CTX = 4096;
 
-template <int HD, int UK>               // UK = independent row loads in flight per lane
+// KV32 (precision mode "split"): the projection output and the K / V cache are fp32 (4 dims per 16-byte load, HD / 4 lanes
+// per key row), q is not rounded, and the output row is written as bf16 hi / lo rows of a stacked group layout (out_G)
+template <int HD, int UK, bool KV32 = false>               // UK = independent row loads in flight per lane
 __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeFusedArgs p) {
-    constexpr int LPK = HD / 8;           // lanes per key row (each lane owns 8 dims = 16 bytes)
+    constexpr int EPL = KV32 ? 4 : 8;     // elements per lane = one 16-byte load
+    constexpr int ESZ = KV32 ? 4 : 2;     // bytes per cache element
+    constexpr int LPK = HD / EPL;         // lanes per key row
     constexpr int KPW = 64 / LPK;         // key rows per wave-instruction
     constexpr int BATCH = 8 * KPW * UK;   // keys one round of the 8 waves covers
     __shared__ __attribute__((aligned(16))) float sc[DEC_MAX_CTX + BATCH];  // scores, padded to whole rounds
@@ -324,47 +512,71 @@ __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeF
     const int pos = p.pos_dev[(size_t)b * p.pos_stride];
     const int ctx = pos + 1;
     const int D = p.H * HD;
-    bf16_t* kbase = p.k + bh * p.kv_stride * HD;
-    bf16_t* vbase = p.v + bh * p.kv_stride * HD;
+    char* kbase = reinterpret_cast<char*>(p.k) + bh * p.kv_stride * HD * ESZ;
+    char* vbase = reinterpret_cast<char*>(p.v) + bh * p.kv_stride * HD * ESZ;
     // ---- phase 0: rotate q,k of the new token, append k / v to the cache (global) and keep q in LDS
     if (tid < HD / 2) {
         const int d = tid;
-        const bf16_t* row = p.qkv + (size_t)b * (3 * D) + h * HD;
         const float c = p.rope_cos[(size_t)pos * (HD / 2) + d], s = p.rope_sin[(size_t)pos * (HD / 2) + d];
-        const float q0 = bf2f(row[d]), q1 = bf2f(row[d + HD / 2]);
-        const float k0 = bf2f(row[D + d]), k1 = bf2f(row[D + d + HD / 2]);
-        q_s[d] = bf2f(f2bf(q0 * c - q1 * s));            // q is rounded to bf16 exactly like the unfused path
-        q_s[d + HD / 2] = bf2f(f2bf(q1 * c + q0 * s));
-        bf16_t* ko = kbase + (size_t)pos * HD;
-        ko[d] = f2bf(k0 * c - k1 * s);
-        ko[d + HD / 2] = f2bf(k1 * c + k0 * s);
-        bf16_t* vo = vbase + (size_t)pos * HD;
-        vo[d] = row[2 * D + d];
-        vo[d + HD / 2] = row[2 * D + d + HD / 2];
+        if constexpr (KV32) {
+            const float* row = reinterpret_cast<const float*>(p.qkv) + (size_t)b * (3 * D) + h * HD;
+            const float q0 = row[d], q1 = row[d + HD / 2];
+            const float k0 = row[D + d], k1 = row[D + d + HD / 2];
+            q_s[d] = q0 * c - q1 * s;
+            q_s[d + HD / 2] = q1 * c + q0 * s;
+            float* ko = reinterpret_cast<float*>(kbase) + (size_t)pos * HD;
+            ko[d] = k0 * c - k1 * s;
+            ko[d + HD / 2] = k1 * c + k0 * s;
+            float* vo = reinterpret_cast<float*>(vbase) + (size_t)pos * HD;
+            vo[d] = row[2 * D + d];
+            vo[d + HD / 2] = row[2 * D + d + HD / 2];
+        } else {
+            const bf16_t* row = p.qkv + (size_t)b * (3 * D) + h * HD;
+            const float q0 = bf2f(row[d]), q1 = bf2f(row[d + HD / 2]);
+            const float k0 = bf2f(row[D + d]), k1 = bf2f(row[D + d + HD / 2]);
+            q_s[d] = bf2f(f2bf(q0 * c - q1 * s));            // q is rounded to bf16 exactly like the unfused path
+            q_s[d + HD / 2] = bf2f(f2bf(q1 * c + q0 * s));
+            bf16_t* ko = reinterpret_cast<bf16_t*>(kbase) + (size_t)pos * HD;
+            ko[d] = f2bf(k0 * c - k1 * s);
+            ko[d + HD / 2] = f2bf(k1 * c + k0 * s);
+            bf16_t* vo = reinterpret_cast<bf16_t*>(vbase) + (size_t)pos * HD;
+            vo[d] = row[2 * D + d];
+            vo[d + HD / 2] = row[2 * D + d + HD / 2];
+        }
     }
     __syncthreads();  // workgroup-scope release/acquire: the appended K / V rows are visible to this block
     // ---- phase 1: scores
-    float qv[8];
+    float qv[EPL];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) qv[e] = q_s[(lane % LPK) * 8 + e];
+    for (int e = 0; e < EPL; ++e) qv[e] = q_s[(lane % LPK) * EPL + e];
     const int ctx_pad = (ctx + BATCH - 1) / BATCH * BATCH;
-    const int krow = lane / LPK, kcol = (lane % LPK) * 8;
+    const int krow = lane / LPK, kcol = (lane % LPK) * EPL;
     // Both streams run as a ROLLING window of UK loads per lane: a register is re-requested for the next batch as soon as
     // its row has been consumed, so UK rows stay in flight with UK registers (no second set).  Rows past the context are
     // clamped to the last valid row (one cached line, p = 0 / score masked): no branch around the loads.
     // wave-uniform base + one 32-bit byte offset per lane (the scalar-base addressing form: half the address VGPRs)
-    auto row_off = [&](int key) { return (uint32_t)(min(key, ctx - 1) * HD + kcol) * 2u; };
+    auto row_off = [&](int key) { return (uint32_t)(min(key, ctx - 1) * HD + kcol) * (uint32_t)ESZ; };
+    auto dot = [&](const u32x4& r) {
+        float s = 0.f;
+        if constexpr (KV32) {
+            const f32x4 f = __builtin_bit_cast(f32x4, r);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s += qv[e] * f[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s += qv[2 * e] * bf2f_lo(r[e]) + qv[2 * e + 1] * bf2f_hi(r[e]);
+        }
+        return s;
+    };
     u32x4 kv[UK];
 #pragma unroll
-    for (int u = 0; u < UK; ++u) kv[u] = ld16_stream(reinterpret_cast<const char*>(kbase) + row_off(wave * KPW * UK + u * KPW + krow));
+    for (int u = 0; u < UK; ++u) kv[u] = ld16_stream(kbase + row_off(wave * KPW * UK + u * KPW + krow));
     for (int kb = wave * KPW * UK; kb < ctx_pad; kb += BATCH) {
 #pragma unroll
         for (int u = 0; u < UK; ++u) {
             const int key = kb + u * KPW + krow;
-            float s = 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) s += qv[2 * e] * bf2f_lo(kv[u][e]) + qv[2 * e + 1] * bf2f_hi(kv[u][e]);
-            kv[u] = ld16_stream(reinterpret_cast<const char*>(kbase) + row_off(key + BATCH));
+            float s = dot(kv[u]);
+            kv[u] = ld16_stream(kbase + row_off(key + BATCH));
 #pragma unroll
             for (int mk = 1; mk < LPK; mk <<= 1) s += shfl_xor(s, mk);
             if ((lane % LPK) == 0) sc[key] = key < ctx ? s * p.scale : -INFINITY;
@@ -374,7 +586,7 @@ __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeF
     // LDS-only softmax below
     u32x4 vv[UK];
 #pragma unroll
-    for (int u = 0; u < UK; ++u) vv[u] = ld16_stream(reinterpret_cast<const char*>(vbase) + row_off(wave * KPW * UK + u * KPW + krow));
+    for (int u = 0; u < UK; ++u) vv[u] = ld16_stream(vbase + row_off(wave * KPW * UK + u * KPW + krow));
     __syncthreads();
     // ---- phase 2: softmax over sc[0..ctx_pad)
     float mx = -INFINITY;
@@ -399,27 +611,33 @@ __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeF
 #pragma unroll
     for (int w = 0; w < 8; ++w) sum += red[w];
     const float inv = 1.0f / sum;
-    // ---- phase 3: out[d] = sum_key p[key] * V[key][d]; a lane accumulates its 8 dims over the key rows it loads (keys
+    // ---- phase 3: out[d] = sum_key p[key] * V[key][d]; a lane accumulates its dims over the key rows it loads (keys
     // past the context carry p = 0 and re-read the last valid row)
-    float acc[8];
+    float acc[EPL];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
     for (int kb = wave * KPW * UK; kb < ctx_pad; kb += BATCH) {
 #pragma unroll
         for (int u = 0; u < UK; ++u) {
             const int key = kb + u * KPW + krow;
             const float pk = sc[key];
             const u32x4 v = vv[u];
-            vv[u] = ld16_stream(reinterpret_cast<const char*>(vbase) + row_off(key + BATCH));
+            vv[u] = ld16_stream(vbase + row_off(key + BATCH));
+            if constexpr (KV32) {
+                const f32x4 f = __builtin_bit_cast(f32x4, v);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[2 * e] += pk * bf2f_lo(v[e]);
-                acc[2 * e + 1] += pk * bf2f_hi(v[e]);
+                for (int e = 0; e < 4; ++e) acc[e] += pk * f[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[2 * e] += pk * bf2f_lo(v[e]);
+                    acc[2 * e + 1] += pk * bf2f_hi(v[e]);
+                }
             }
         }
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < EPL; ++e) {
         float a = acc[e];
 #pragma unroll
         for (int mk = LPK; mk < 64; mk <<= 1) a += shfl_xor(a, mk);  // over the KPW key rows of the wave-instruction
@@ -427,14 +645,23 @@ __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeF
     }
     if (lane < LPK) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) part[wave][lane * 8 + e] = acc[e];
+        for (int e = 0; e < EPL; ++e) part[wave][lane * EPL + e] = acc[e];
     }
     __syncthreads();
     if (tid < HD) {
         float a = 0.f;
 #pragma unroll
         for (int w = 0; w < 8; ++w) a += part[w][tid];
-        p.out[(size_t)b * D + h * HD + tid] = f2bf(a * inv);
+        a *= inv;
+        if constexpr (KV32) {  // stacked hi / lo row groups of the split decode GEMV: row b -> group b / G, slot b % G
+            const int G = p.out_G;
+            const size_t orow = (size_t)(b / G) * 2 * G + b % G;
+            const bf16_t hi = f2bf(a);
+            p.out[orow * D + h * HD + tid] = hi;
+            p.out[(orow + G) * D + h * HD + tid] = f2bf(a - bf2f(hi));
+        } else {
+            p.out[(size_t)b * D + h * HD + tid] = f2bf(a);
+        }
     }
 }
 
@@ -442,6 +669,11 @@ void launch_attention_decode_fused(const AttnDecodeFusedArgs& a, hipStream_t s) 
     const dim3 grid(a.H, a.B), block(512);
     // VC_DATTN_UK: row loads in flight per lane (tuning knob; 8 = 8 KiB per wave, two workgroups per CU)
     static const int uk = getenv("VC_DATTN_UK") ? atoi(getenv("VC_DATTN_UK")) : 8;
+    if (a.kv32) {  // precision mode "split"
+        if (a.hd == 128) VC_LAUNCH((attention_decode_fused_kernel<128, 8, true>), grid, block, 0, s, a);
+        else VC_LAUNCH((attention_decode_fused_kernel<64, 8, true>), grid, block, 0, s, a);
+        return;
+    }
     if (a.hd == 128) {
         if (uk == 12) VC_LAUNCH((attention_decode_fused_kernel<128, 12>), grid, block, 0, s, a);
         else if (uk == 16) VC_LAUNCH((attention_decode_fused_kernel<128, 16>), grid, block, 0, s, a);

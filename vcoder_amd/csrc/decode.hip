@@ -13,6 +13,8 @@
 // waves of a workgroup and reduced through LDS; epilogues (fp32 residual add, SwiGLU) are fused.
 #include <stdlib.h>
 
+#include <stdexcept>
+
 #include "vc_device.h"
 #include "kernels.h"
 
@@ -38,7 +40,12 @@ VC_DEV void gemv_epilogue(const GemvArgs& p, f32x4 v, const float* ss_part /*[WA
             st16f(o, v);
             if (p.xg_out) {  // the consumer's operand: bf16(x * g) of the updated residual values
                 const f32x4 gw = ld16f(p.xg_w + n);
-                st8(p.xg_out + (size_t)m * p.N + n, u32x2{pack_bf2(v[0] * gw[0], v[1] * gw[1]), pack_bf2(v[2] * gw[2], v[3] * gw[3])});
+                const f32x4 t = {v[0] * gw[0], v[1] * gw[1], v[2] * gw[2], v[3] * gw[3]};
+                const u32x2 hi = {pack_bf2(t[0], t[1]), pack_bf2(t[2], t[3])};
+                st8(p.xg_out + (size_t)m * p.N + n, hi);
+                if (p.split_rows)  // split mode: the lo row of the stacked group, bf16(t - hi)
+                    st8(p.xg_out + (size_t)(m + p.split_rows) * p.N + n,
+                        u32x2{pack_bf2(t[0] - bf2f_lo(hi[0]), t[1] - bf2f_hi(hi[0])), pack_bf2(t[2] - bf2f_lo(hi[1]), t[3] - bf2f_hi(hi[1]))});
             }
         }
         if (p.ssq_out) {  // sum of squares of this tile's 16 new residual values of token m (fixed order)
@@ -51,12 +58,20 @@ VC_DEV void gemv_epilogue(const GemvArgs& p, f32x4 v, const float* ss_part /*[WA
     }
     if (!mvalid) return;
     if constexpr (EPI == GEMV_BF16) {
-        st8(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo + n, u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])});
+        const u32x2 hi = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        st8(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo + n, hi);
+        if (p.split_rows)
+            st8(reinterpret_cast<bf16_t*>(p.out) + (size_t)(m + p.split_rows) * p.ldo + n,
+                u32x2{pack_bf2(v[0] - bf2f_lo(hi[0]), v[1] - bf2f_hi(hi[0])), pack_bf2(v[2] - bf2f_lo(hi[1]), v[3] - bf2f_hi(hi[1]))});
     } else if constexpr (EPI == GEMV_F32) {
         st16f(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n, v);
     } else if constexpr (EPI == GEMV_SWIGLU) {
-        *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo + (n >> 1)) =
-            pack_bf2(silu(v[0]) * v[1], silu(v[2]) * v[3]);
+        const float h0 = silu(v[0]) * v[1], h1 = silu(v[2]) * v[3];
+        const uint32_t hi = pack_bf2(h0, h1);
+        *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo + (n >> 1)) = hi;
+        if (p.split_rows)
+            *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)(m + p.split_rows) * p.ldo + (n >> 1)) =
+                pack_bf2(h0 - bf2f_lo(hi), h1 - bf2f_hi(hi));
     }
 }
 
@@ -228,9 +243,17 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
     const int nit = (nkt + KPI - 1) / KPI;   // slots' worth of k-tiles in the matrix
     const int it0 = (int)((long)ks * nit / KS), it1 = (int)((long)(ks + 1) * nit / KS);  // this workgroup's share of K
     const int m = lane & 15, g = lane >> 4;
-    bool mvalid[MG];
+    // precision mode "split" (p.split_rows = G in {8, 16}): X holds G + M rows — rows [0, M) the bf16 hi parts of the M
+    // activation rows, rows [G, G + M) their lo parts (x = hi + lo) — and the two partial products of a row meet in the
+    // epilogue: token slots m and m + 8 of one MFMA row group (G = 8), or the two row groups (G = 16)
+    const int SR = p.split_rows;
+    const int Mx = SR ? SR + p.M : p.M;      // rows of X
+    bool mvalid[MG], ovalid[MG];             // slot holds a row of X / slot is a row of the OUTPUT (norm partials, stores)
 #pragma unroll
-    for (int q = 0; q < MG; ++q) mvalid[q] = m + 16 * q < p.M;
+    for (int q = 0; q < MG; ++q) {
+        mvalid[q] = m + 16 * q < Mx;
+        ovalid[q] = m + 16 * q < p.M;
+    }
     char* my = ring + wave * (R * SLOT);
     const char* wsrc[NT];
 #pragma unroll
@@ -245,7 +268,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
         const int row = 8 * x + xr;
         const int pc = xs ^ ((row >> 1) & 7);                               // physical chunk held by slot s of this row
         xc[x] = FP8 ? (((pc & 3) << 1) | (pc >> 2)) : pc;                   // W8A16: physical p = logical (c >> 1) | ((c & 1) << 2)
-        xsrc[x] = reinterpret_cast<const char*>(p.X + (size_t)(row < p.M ? row : 0) * p.K);
+        xsrc[x] = reinterpret_cast<const char*>(p.X + (size_t)(row < Mx ? row : 0) * p.K);
     }
     const int kline_last = (p.K * 2 + 127) / 128 - 1;                        // last (possibly half) 128-byte line of a row
     const bool half_line = (p.K * 2) % 128 != 0;                             // bf16, odd k-tile count: 64 valid bytes in it
@@ -332,7 +355,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
     if (p.ssq_in != nullptr) {
 #pragma unroll
         for (int q = 0; q < MG; ++q) {
-            const float* sp = p.ssq_in + (size_t)(mvalid[q] ? m + 16 * q : 0) * p.npart;
+            const float* sp = p.ssq_in + (size_t)(ovalid[q] ? m + 16 * q : 0) * p.npart;
 #pragma unroll
             for (int j = 0; j < SQ; ++j) {
                 const int qi = wave * 4 + g + j * WAVES * 4;
@@ -352,7 +375,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
                 s1 += (sq[q][j + 1][0] + sq[q][j + 1][1]) + (sq[q][j + 1][2] + sq[q][j + 1][3]);
             }
             float ss = s0 + s1;
-            const float* sp = p.ssq_in + (size_t)(mvalid[q] ? m + 16 * q : 0) * p.npart;
+            const float* sp = p.ssq_in + (size_t)(ovalid[q] ? m + 16 * q : 0) * p.npart;
             for (int qi = wave * 4 + g + SQ * WAVES * 4; qi < nq; qi += WAVES * 4) {  // rows wider than 16*SQ*WAVES*... (rare)
                 const f32x4 v = ld16f(sp + qi * 4);
                 ss += (v[0] + v[1]) + (v[2] + v[3]);
@@ -395,9 +418,26 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
     const int ft = unit_w % NT, fq = unit_w / NT;  // this wave finishes tile ft for row group fq
     const int nt = nt0 + ft;
     if (nt >= ntiles) continue;
+    if (SR == 16 && fq > 0) continue;              // split mode: row group 1 holds the lo parts of group 0's rows
     f32x4 v = ld16f(red + (((0 * NT + ft) * MG + fq) * 64 + lane) * 4);
 #pragma unroll
     for (int w = 1; w < WAVES; ++w) v = v + ld16f(red + (((w * NT + ft) * MG + fq) * 64 + lane) * 4);
+    if (SR) {  // hi . W + lo . W, each summed over the waves in the fixed order above: the same bits whichever form ran
+        if constexpr (MG > 1) {
+            if (SR == 16) {
+                f32x4 u = ld16f(red + (((0 * NT + ft) * MG + 1) * 64 + lane) * 4);
+#pragma unroll
+                for (int w = 1; w < WAVES; ++w) u = u + ld16f(red + (((w * NT + ft) * MG + 1) * 64 + lane) * 4);
+                v = v + u;
+            }
+        }
+        if (SR == 8) {
+            f32x4 u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) u[e] = shfl_xor(v[e], 8);   // token slot m + 8 (same output features)
+            v = v + u;
+        }
+    }
     if (KS > 1) {
         // hand the partial to whoever finishes this (tile, row group) last; it adds the KS partials in k order.  Write-through
         // (sc1) stores, drained, then a relaxed agent-scope arrival count; the finisher reads with cache-bypassing (sc1)
@@ -421,7 +461,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
         }
         if (lane == 0) st_agent_u32(&p.sk_counters[unit], 0u);  // re-armed for the next launch (stream order)
     }
-    gemv_epilogue<WAVES, EPI, FP8, 16 * MG>(p, v, &ss_part[0][0], nt, m + 16 * fq, g, mvalid[fq]);
+    gemv_epilogue<WAVES, EPI, FP8, 16 * MG>(p, v, &ss_part[0][0], nt, m + 16 * fq, g, ovalid[fq]);
     }
 }
 
@@ -468,16 +508,19 @@ static void launch_gemv_dma_x(const GemvArgs& a, int epi, hipStream_t s) {
 #undef VC_GEMV_DMA
 }
 
-// M <= 16: one MFMA row group, one (M <= 8) or two 8-row activation pieces per slot
+// rows of the activation operand X: M, or split_rows + M in precision mode "split" (hi rows, then lo rows)
+static int x_rows(const GemvArgs& a) { return a.split_rows ? a.split_rows + a.M : a.M; }
+
+// X rows <= 16: one MFMA row group, one (<= 8 rows) or two 8-row activation pieces per slot
 template <int WAVES, int NT, int R, bool FP8>
 static void launch_gemv_dma(const GemvArgs& a, int epi, hipStream_t s) {
-    if (a.M <= 8) launch_gemv_dma_x<WAVES, NT, R, FP8, 1>(a, epi, s);
+    if (x_rows(a) <= 8) launch_gemv_dma_x<WAVES, NT, R, FP8, 1>(a, epi, s);
     else launch_gemv_dma_x<WAVES, NT, R, FP8, 2>(a, epi, s);
 }
-// M in 17..32: two row groups, three or four pieces
+// X rows in 17..32: two row groups, three or four pieces
 template <int WAVES, int NT, int R, bool FP8>
 static void launch_gemv_dma2(const GemvArgs& a, int epi, hipStream_t s) {
-    if (a.M <= 24) launch_gemv_dma_x<WAVES, NT, R, FP8, 3>(a, epi, s);
+    if (x_rows(a) <= 24) launch_gemv_dma_x<WAVES, NT, R, FP8, 3>(a, epi, s);
     else launch_gemv_dma_x<WAVES, NT, R, FP8, 4>(a, epi, s);
 }
 
@@ -503,7 +546,7 @@ static void launch_gemv_m32(const GemvArgs& a, int epilogue, hipStream_t s) {
     if (tiles <= 256) {
         // W8A16 slots are 4 KiB (3 pieces) / 5 KiB (4 pieces): a 4-slot ring of the latter would need all 160 KiB + ss_part
         if constexpr (FP8) {
-            if (a.M <= 24) {
+            if (x_rows(a) <= 24) {
                 launch_gemv_dma_x<8, 1, 4, true, 3>(a, epilogue, s);
                 return;
             }
@@ -535,11 +578,11 @@ static void launch_gemv_f(const GemvArgs& a, int epilogue, hipStream_t s) {
     // form measured: bf16 -4...-10 % with pairs, W8A16 +20 % — there the activation fragments are twice the weight bytes
     static const int nt2 = getenv("VC_GEMV_NT") ? atoi(getenv("VC_GEMV_NT")) == 2 : 0;
     const int tiles = a.N / 16;
-    if (a.M > 16) {  // the decode pool's 17..32 rows: LDS-DMA form only
+    if (x_rows(a) > 16) {  // the decode pool's 17..32 rows (split mode: 9..16 rows + their lo parts): LDS-DMA form only
         launch_gemv_m32<FP8>(a, epilogue, s);
         return;
     }
-    if (path == 1) {
+    if (path == 1 || a.split_rows) {
         // Geometry by tile count, so that (where possible) every workgroup of the launch is resident at once — a tail of
         // late workgroups cannot keep enough bytes in flight to use the HBM (13b o_proj/down: 320 tiles at one
         // 128-KiB workgroup per CU ran a 64-workgroup second round at a third of the rate):
@@ -576,6 +619,15 @@ void launch_gemv(const GemvArgs& a0, int epilogue, hipStream_t s) {
     static const int w_cached = getenv("VC_GEMV_WCACHED") ? atoi(getenv("VC_GEMV_WCACHED")) : 0;
     GemvArgs a = a0;
     a.w_cached = w_cached;
+    if (a.split_rows) {
+        // hi rows [0, M) + lo rows [G, G + M) of X; the two MFMA forms that combine them: G = 8 inside one 16-slot row group
+        // (M <= 8), G = 16 across the two row groups (M <= 16).  No split-K hand-off in this mode.
+        if (!((a.split_rows == 8 && a.M <= 8) || (a.split_rows == 16 && a.M <= 16)))
+            throw std::runtime_error("split GEMV: rows per pass must fit the group (G = 8: M <= 8, G = 16: M <= 16)");
+        a.sk_scratch = nullptr;
+        a.sk_counters = nullptr;
+        a.ksplit = 0;
+    }
     if (a.wscale) launch_gemv_f<true>(a, epilogue, s);
     else launch_gemv_f<false>(a, epilogue, s);
 }

@@ -147,7 +147,9 @@ struct vc_model {
     hipStream_t st;
     bool finalized = false;
     bool owns_weights = true;
-    int precision = 0;  // 0: bf16 MFMA fast path; 1: strict fp32 path (strict.hip)
+    int precision = 0;  // 0: bf16 MFMA fast path; 1: strict fp32 path (strict.hip); 2: split — fp32 activations in HBM,
+                        // every MFMA operand as bf16 hi + lo fragments on the fast kernels
+    int kv_es = 2;      // bytes per element of this session's own KV cache (kc / vc): 2 bf16, 4 fp32 (precision 2)
     int weight_format = 0;  // 0: bf16; 1: W8A16 — decoder linears stored as e4m3 + per-row scales for the decode GEMV;
                             // 2: fp8 — 1 + the prefill GEMMs run e4m3 x e4m3 on the K=128 scaled MFMA (W8A8)
     Buf s_cols, s_patches, s_vx, s_vxn, s_vqkv, s_vq, s_vk, s_vv, s_vattn, s_vh, s_sel, s_mid, s_feats;
@@ -419,7 +421,10 @@ void gemm_f8(vc_model* m, const bf16_t* A, const uint8_t* Wq, const float* wscal
 // Everything one decode step touches besides the weights: the buffers of a session's own loop or of the shared pool.
 struct LoopView {
     hipStream_t st;
-    bf16_t *kc, *vc;   // [L][capR][H][capS][hd]: K and V, both key-major
+    bf16_t *kc, *vc;   // [L][capR][H][capS][hd]: K and V, both key-major (fp32 elements when es == 4)
+    int es;            // bytes per cache element: 2 (bf16) or 4 (fp32: precision mode "split")
+    int split_G;       // 0: bf16 decode step.  G = 8 / 16: split decode step — xg_dec / attn_dec / h_dec hold stacked groups of
+                       // G bf16 hi rows + G lo rows (row r -> group r / G), qkv_dec is fp32
     int capR, capS;
     int* rows;         // RowState records
     float* x_dec;
@@ -433,25 +438,32 @@ struct LoopView {
 // decode-time linear over `X` (bf16 [M, K]).  use_rstd: X is the xg operand (bf16(x * g)) and the output is scaled by the
 // rows' 1/rms from the ssq partials; next_norm_w (RESID epilogue only): publish the ssq partials of the updated residual
 // rows and the next consumer's xg operand
+// split decode step (v.split_G = G): X and every bf16-valued output are stacked groups of G hi rows + G lo rows, one
+// weight pass serves one group (G rows: hi + lo fill the kernel's 16 / 32 token slots)
 void gemv(vc_model* m, const LoopView& v, const bf16_t* X, const bf16_t* Wp, const float* wscale, void* out, int M, int N, int K,
           int ldo, int epi, bool use_rstd = false, const float* next_norm_w = nullptr) {
-    const size_t esz = (epi == GEMV_F32 || epi == GEMV_RESID_F32) ? 4 : 2;
+    const bool f32out = epi == GEMV_F32 || epi == GEMV_RESID_F32;
+    const size_t esz = f32out ? 4 : 2;
     const int np = m->npart;
-    for (int m0 = 0; m0 < M; m0 += VC_GEMV_MAX_M) {  // the skinny kernel holds VC_GEMV_MAX_M token slots per weight pass
+    const int G = v.split_G;
+    const int pass = G ? G : VC_GEMV_MAX_M;
+    for (int m0 = 0; m0 < M; m0 += pass) {  // the skinny kernel holds VC_GEMV_MAX_M token slots per weight pass
+        const size_t xrow0 = G ? (size_t)(m0 / G) * 2 * G : (size_t)m0;   // first row of the pass in a stacked bf16 buffer
         GemvArgs a{};
-        a.X = X + (size_t)m0 * K;
+        a.X = X + xrow0 * K;
         a.Wp = Wp;
         a.wscale = wscale;
-        a.out = reinterpret_cast<char*>(out) + (size_t)m0 * ldo * esz;
-        a.M = std::min(VC_GEMV_MAX_M, M - m0);
+        a.out = reinterpret_cast<char*>(out) + (f32out ? (size_t)m0 : xrow0) * ldo * esz;
+        a.M = std::min(pass, M - m0);
         a.N = N;
         a.K = K;
         a.ldo = ldo;
+        a.split_rows = G;
         a.ssq_in = use_rstd ? v.ssq + (size_t)m0 * np : nullptr;
         if (next_norm_w) {
             a.ssq_out = v.ssq + (size_t)m0 * np;
             a.xg_w = next_norm_w;
-            a.xg_out = v.xg_dec + (size_t)m0 * N;
+            a.xg_out = v.xg_dec + xrow0 * N;
         }
         a.npart = np;
         a.eps = m->c.rms_eps;
@@ -472,7 +484,7 @@ void decode_linears(vc_model* m, const LoopView& v, int M, F&& between) {
     for (int l = 0; l < c.layers; ++l) {
         const LlmLayer& L = m->llm[l];
         const float* next_in = l + 1 < c.layers ? m->llm[l + 1].in_norm : m->final_norm;
-        gemv(m, v, xg, L.qkv_p, L.qkv_s, v.qkv_dec, M, 3 * D, D, 3 * D, GEMV_BF16, true);                      // K11+K12
+        gemv(m, v, xg, L.qkv_p, L.qkv_s, v.qkv_dec, M, 3 * D, D, 3 * D, v.split_G ? GEMV_F32 : GEMV_BF16, true);  // K11+K12
         between(l);                                                                                          // K13-K15
         gemv(m, v, v.attn_dec, L.o_p, L.o_s, v.x_dec, M, D, D, D, GEMV_RESID_F32, false, L.post_norm);          // K16
         gemv(m, v, xg, L.gu_p, L.gu_s, v.h_dec, M, 2 * Fd, D, Fd, GEMV_SWIGLU, true);                          // K11+K17
@@ -865,26 +877,29 @@ void ensure_llm(vc_model* m, int B, int S_total) {
     REQUIRE(B <= VC_MAX_ROWS, VC_ERR_INVALID, "batch %d: at most %d sequences per GPU replica (shard larger batches over ranks)",
             B, VC_MAX_ROWS);
     REQUIRE(Scap <= c.max_positions, VC_ERR_INVALID, "sequence %d exceeds max_position_embeddings=%d", Scap, c.max_positions);
-    if (B != m->capB || Scap > m->capS) {
-        const int newS = std::max(Scap, m->capB == B ? m->capS : 0);
+    const int es = m->precision == 2 ? 4 : 2;   // split mode keeps fp32 keys / values
+    if (B != m->capB || Scap > m->capS || es != m->kv_es) {
+        const int newS = std::max(Scap, (m->capB == B && es == m->kv_es) ? m->capS : 0);
         const size_t per_layer = (size_t)B * H * newS * m->hd;
         m->kc.release();
         m->vc.release();
-        m->kc.ensure(per_layer * c.layers * 2, true);
-        m->vc.ensure(per_layer * c.layers * 2, true);
+        m->kc.ensure(per_layer * c.layers * es, true);
+        m->vc.ensure(per_layer * c.layers * es, true);
         m->capB = B;
         m->capS = newS;
+        m->kv_es = es;
         drop_graph(m);
     }
     const void* before[] = {m->x_dec.p, m->xg_dec.p, m->qkv_dec.p, m->attn_dec.p, m->h_dec.p, m->next_tok.p, m->rows.p, m->ssq.p,
                             m->logits.p};
     ensure_prefill_ws(m, B, Scap);
     const int Bp = (int)rup(B, 16);
+    // (sized for the split step as well: hi + lo row groups double the bf16 operands, qkv_dec is fp32 there)
     m->x_dec.ensure((size_t)Bp * D * 4, true);
-    m->xg_dec.ensure((size_t)Bp * D * 2, true);
-    m->qkv_dec.ensure((size_t)Bp * 3 * D * 2, true);
-    m->attn_dec.ensure((size_t)Bp * D * 2, true);
-    m->h_dec.ensure((size_t)Bp * F * 2, true);
+    m->xg_dec.ensure((size_t)2 * Bp * D * 2, true);
+    m->qkv_dec.ensure((size_t)Bp * 3 * D * 4, true);
+    m->attn_dec.ensure((size_t)2 * Bp * D * 2, true);
+    m->h_dec.ensure((size_t)2 * Bp * F * 2, true);
     m->next_tok.ensure(Bp * 4, true);
     m->rows.ensure((size_t)Bp * RS_STRIDE * 4, true);
     m->ssq.ensure((size_t)Bp * m->npart * 4, true);
@@ -901,6 +916,8 @@ LoopView session_view(vc_model* m) {
     v.st = m->st;
     v.kc = m->kc.as<bf16_t>();
     v.vc = m->vc.as<bf16_t>();
+    v.es = m->kv_es;
+    v.split_G = m->precision == 2 ? (m->capB <= 8 ? 8 : 16) : 0;
     v.capR = m->capB;
     v.capS = m->capS;
     v.rows = m->rows.as<int>();
@@ -922,16 +939,23 @@ LoopView session_view(vc_model* m) {
 struct KvTarget {
     bf16_t *kc, *vc;
     int capR, capS, row0;
+    int es;  // bytes per element: 2 (bf16), 4 (fp32 — precision mode "split")
 };
+// layer l of a cache whose elements are `es` bytes (the pointer type is nominal for es == 4)
+bf16_t* kv_layer(bf16_t* base, int es, size_t elems) { return reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(base) + elems * es); }
 bf16_t* kcache(const vc_model* m, const KvTarget& t, int l) {
-    return t.kc + ((size_t)l * t.capR + t.row0) * m->c.heads * t.capS * m->hd;
+    return kv_layer(t.kc, t.es, ((size_t)l * t.capR + t.row0) * m->c.heads * t.capS * m->hd);
 }
 bf16_t* vcache(const vc_model* m, const KvTarget& t, int l) {
-    return t.vc + ((size_t)l * t.capR + t.row0) * m->c.heads * t.capS * m->hd;
+    return kv_layer(t.vc, t.es, ((size_t)l * t.capR + t.row0) * m->c.heads * t.capS * m->hd);
 }
-KvTarget session_kv(vc_model* m) { return KvTarget{m->kc.as<bf16_t>(), m->vc.as<bf16_t>(), m->capB, m->capS, 0}; }
-bf16_t* kcache(const LoopView& v, const vc_model* m, int l) { return v.kc + (size_t)l * v.capR * m->c.heads * v.capS * m->hd; }
-bf16_t* vcache(const LoopView& v, const vc_model* m, int l) { return v.vc + (size_t)l * v.capR * m->c.heads * v.capS * m->hd; }
+KvTarget session_kv(vc_model* m) { return KvTarget{m->kc.as<bf16_t>(), m->vc.as<bf16_t>(), m->capB, m->capS, 0, m->kv_es}; }
+bf16_t* kcache(const LoopView& v, const vc_model* m, int l) {
+    return kv_layer(v.kc, v.es, (size_t)l * v.capR * m->c.heads * v.capS * m->hd);
+}
+bf16_t* vcache(const LoopView& v, const vc_model* m, int l) {
+    return kv_layer(v.vc, v.es, (size_t)l * v.capR * m->c.heads * v.capS * m->hd);
+}
 
 // The decode loop outran the cache (a host-driven vc_decode_step loop past the reserve of its prefill): re-allocate with
 // room for `need` positions and move the live prefix — K and V rows are contiguous per (layer, sample, head), so each is
@@ -944,18 +968,19 @@ void grow_kv(vc_model* m, int need) {
     REQUIRE(newS >= need, VC_ERR_STATE, "KV cache full: position %d exceeds max_position_embeddings=%d", need, c.max_positions);
     const size_t heads = (size_t)c.layers * m->capB * c.heads;
     Buf nk, nv;
-    nk.ensure(heads * newS * m->hd * 2, true);
-    nv.ensure(heads * newS * m->hd * 2, true);
-    HIPCHK(hipMemcpy2DAsync(nk.p, (size_t)newS * m->hd * 2, m->kc.p, (size_t)oldS * m->hd * 2, (size_t)live * m->hd * 2, heads,
+    const size_t es = (size_t)m->kv_es;
+    nk.ensure(heads * newS * m->hd * es, true);
+    nv.ensure(heads * newS * m->hd * es, true);
+    HIPCHK(hipMemcpy2DAsync(nk.p, (size_t)newS * m->hd * es, m->kc.p, (size_t)oldS * m->hd * es, (size_t)live * m->hd * es, heads,
                             hipMemcpyDeviceToDevice, m->st));
-    HIPCHK(hipMemcpy2DAsync(nv.p, (size_t)newS * m->hd * 2, m->vc.p, (size_t)oldS * m->hd * 2, (size_t)live * m->hd * 2, heads,
+    HIPCHK(hipMemcpy2DAsync(nv.p, (size_t)newS * m->hd * es, m->vc.p, (size_t)oldS * m->hd * es, (size_t)live * m->hd * es, heads,
                             hipMemcpyDeviceToDevice, m->st));
     HIPCHK(hipStreamSynchronize(m->st));
     m->kc.release();
     m->vc.release();
     m->kc = nk;
     m->vc = nv;
-    if (m->precision && m->s_capS == oldS && m->s_capB == m->capB) {  // the strict path's fp32 caches (K and V key-major)
+    if (m->precision == 1 && m->s_capS == oldS && m->s_capB == m->capB) {  // the strict path's fp32 caches (K and V key-major)
         Buf sk, sv;
         sk.ensure(heads * newS * m->hd * 4, true);
         sv.ensure(heads * newS * m->hd * 4, true);

@@ -49,6 +49,47 @@ VC_DEV void tile_coords(int bid, int nblk, int tiles_m, int tiles_n, int& tm, in
     tile_from_pid(xcd_remap(bid, nblk), tiles_m, tiles_n, tm, tn);
 }
 
+// epilogue store of out[m][n..n+3] (shared by all kernels).  p.split_out != 0 (precision mode "split"):
+// a bf16 output becomes TWO bf16 planes, hi = bf16(v) at column n and lo = bf16(v - hi) at column split_out + n of the same
+// row — the K-concatenated [hi | lo] operand of the next GEMM, which contracts it against the weight matrix twice
+// (GemmArgs::kwrap), i.e. with ~16 mantissa bits of the activation instead of 8.
+VC_DEV u32x2 pack_bf4(f32x4 v) { return u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])}; }
+VC_DEV f32x4 bf4_residual(f32x4 v, u32x2 hi) {
+    return f32x4{v[0] - bf2f_lo(hi[0]), v[1] - bf2f_hi(hi[0]), v[2] - bf2f_lo(hi[1]), v[3] - bf2f_hi(hi[1])};
+}
+template <int EPI>
+VC_DEV void store_out(const GemmArgs& p, int m, int n, f32x4 v) {
+    if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_QGELU || EPI == EPI_BF16_GELU) {
+        if constexpr (EPI == EPI_BF16_QGELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+        }
+        if constexpr (EPI == EPI_BF16_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = erf_gelu(v[e]);
+        }
+        const u32x2 o = pack_bf4(v);
+        bf16_t* dst = reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo + n;
+        st8(dst, o);
+        if (p.split_out) st8(dst + p.split_out, pack_bf4(bf4_residual(v, o)));
+    } else if constexpr (EPI == EPI_F32) {
+        st16f(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n, v);
+    } else if constexpr (EPI == EPI_RESID_F32) {
+        float* o = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n;
+        st16f(o, ld16f(o) + v);
+    } else {  // EPI_SWIGLU: (g0,u0,g1,u1) -> 2 outputs
+        const float h0 = silu(v[0]) * v[1], h1 = silu(v[2]) * v[3];
+        const uint32_t o = pack_bf2(h0, h1);
+        bf16_t* dst = reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo + (n >> 1);
+        *reinterpret_cast<uint32_t*>(dst) = o;
+        if (p.split_out) *reinterpret_cast<uint32_t*>(dst + p.split_out) = pack_bf2(h0 - bf2f_lo(o), h1 - bf2f_hi(o));
+    }
+}
+
+// k-tile of the WEIGHT operand for k-tile `kt` of the contraction: with GemmArgs::kwrap = K_w / BK the weight matrix is
+// contracted against both halves of a K-concatenated [hi | lo] activation row (K = 2 K_w), i.e. its k index wraps
+VC_DEV int wrap_kt(int kt, int kwrap) { return (kwrap > 0 && kt >= kwrap) ? kt - kwrap : kt; }
+
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     VC_DYNAMIC_SMEM(char, smem);  // [2 stages][W tile | A tile]
@@ -75,7 +116,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     auto load_tile = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            rw[i] = ld16(w_src[i] + (size_t)kt * (BK * 2));
+            rw[i] = ld16(w_src[i] + (size_t)wrap_kt(kt, p.kwrap) * (BK * 2));
             ra[i] = ld16(a_src[i] + (size_t)kt * (BK * 2));
         }
     };
@@ -133,27 +174,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
         for (int j = 0; j < 4; ++j) {
             const int m = m0 + wm * 64 + j * 16 + (lane & 15);
             if (m >= p.M) continue;
-            f32x4 v = acc[i][j] + bv;
-            if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_QGELU || EPI == EPI_BF16_GELU) {
-                if constexpr (EPI == EPI_BF16_QGELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
-                }
-                if constexpr (EPI == EPI_BF16_GELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = erf_gelu(v[e]);
-                }
-                u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-                st8(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo + n, o);
-            } else if constexpr (EPI == EPI_F32) {
-                st16f(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n, v);
-            } else if constexpr (EPI == EPI_RESID_F32) {
-                float* o = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n;
-                st16f(o, ld16f(o) + v);
-            } else {  // EPI_SWIGLU: (g0,u0,g1,u1) -> 2 outputs
-                const uint32_t o = pack_bf2(silu(v[0]) * v[1], silu(v[2]) * v[3]);
-                *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo + (n >> 1)) = o;
-            }
+            store_out<EPI>(p, m, n, acc[i][j] + bv);
         }
     }
 }
@@ -198,7 +219,7 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_bf16_dma_kernel(GemmArgs p)
         char* ws = smem + stage * STAGE;
         char* as = ws + W_BYTES;
 #pragma unroll
-        for (int i = 0; i < WP; ++i) glds16(w_src[i] + (size_t)kt * (BK * 2), ws + (i * NW + wave) * 1024);
+        for (int i = 0; i < WP; ++i) glds16(w_src[i] + (size_t)wrap_kt(kt, p.kwrap) * (BK * 2), ws + (i * NW + wave) * 1024);
 #pragma unroll
         for (int i = 0; i < AP; ++i) glds16(a_src[i] + (size_t)kt * (BK * 2), as + (i * NW + wave) * 1024);
     };
@@ -241,56 +262,11 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_bf16_dma_kernel(GemmArgs p)
         for (int j = 0; j < FJ; ++j) {
             const int m = m0 + wm * (FJ * 16) + j * 16 + (lane & 15);
             if (m >= p.M) continue;
-            f32x4 v = acc[i][j] + bv;
-            if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_QGELU || EPI == EPI_BF16_GELU) {
-                if constexpr (EPI == EPI_BF16_QGELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
-                }
-                if constexpr (EPI == EPI_BF16_GELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = erf_gelu(v[e]);
-                }
-                u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-                st8(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo + n, o);
-            } else if constexpr (EPI == EPI_F32) {
-                st16f(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n, v);
-            } else if constexpr (EPI == EPI_RESID_F32) {
-                float* o = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n;
-                st16f(o, ld16f(o) + v);
-            } else {  // EPI_SWIGLU: (g0,u0,g1,u1) -> 2 outputs
-                const uint32_t o = pack_bf2(silu(v[0]) * v[1], silu(v[2]) * v[3]);
-                *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo + (n >> 1)) = o;
-            }
+            store_out<EPI>(p, m, n, acc[i][j] + bv);
         }
     }
 }
 
-
-// epilogue store of out[m][n..n+3] (shared by the DMA kernels)
-template <int EPI>
-VC_DEV void store_out(const GemmArgs& p, int m, int n, f32x4 v) {
-    if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_QGELU || EPI == EPI_BF16_GELU) {
-        if constexpr (EPI == EPI_BF16_QGELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
-        }
-        if constexpr (EPI == EPI_BF16_GELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = erf_gelu(v[e]);
-        }
-        u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-        st8(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo + n, o);
-    } else if constexpr (EPI == EPI_F32) {
-        st16f(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n, v);
-    } else if constexpr (EPI == EPI_RESID_F32) {
-        float* o = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n;
-        st16f(o, ld16f(o) + v);
-    } else {  // EPI_SWIGLU: (g0,u0,g1,u1) -> 2 outputs
-        const uint32_t o = pack_bf2(silu(v[0]) * v[1], silu(v[2]) * v[3]);
-        *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo + (n >> 1)) = o;
-    }
-}
 
 // ---- 256 x 256 tile, 8 waves, counted-vmcnt "8-phase" schedule ----------------------------------------------------------
 // The one-barrier loop above drains the LDS-DMA queue (vmcnt(0)) at every k-tile barrier, so HBM/L2 latency is exposed
@@ -348,8 +324,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
         for (int i = 0; i < 2; ++i) {
             const int row = (i * 8 + wave) * 8 + (lane >> 3);
             const int sw = ((lane & 7) ^ (row & 7)) << 4;
-            x_src[h][i] = reinterpret_cast<const char*>(p.W) + (size_t)min(n0 + h * 128 + row, p.N - 1) * p.ldw * ES + sw +
-                          (size_t)kt_first * 128;
+            x_src[h][i] = reinterpret_cast<const char*>(p.W) + (size_t)min(n0 + h * 128 + row, p.N - 1) * p.ldw * ES + sw;
             y_src[h][i] = reinterpret_cast<const char*>(p.A) + (size_t)min(m0 + h * 128 + row, p.M - 1) * p.lda * ES + sw +
                           (size_t)kt_first * 128;
         }
@@ -357,8 +332,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     auto stage_x = [&](int h, int kt) {
         if (kt >= nk) return;
         char* dst = smem + (kt & 1) * TILE + (h ? SX1 : SX0) + wave * 1024;
-        glds16(x_src[h][0] + (size_t)kt * 128, dst);
-        glds16(x_src[h][1] + (size_t)kt * 128, dst + 8192);
+        const size_t wk = (size_t)wrap_kt(kt_first + kt, p.kwrap) * 128;
+        glds16(x_src[h][0] + wk, dst);
+        glds16(x_src[h][1] + wk, dst + 8192);
     };
     auto stage_y = [&](int h, int kt) {
         if (kt >= nk) return;

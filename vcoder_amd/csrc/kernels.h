@@ -42,6 +42,11 @@ struct GemmArgs {
     int f8;
     const float* a_scale;  // [M]
     const float* w_scale;  // [N]
+    // precision mode "split": kwrap > 0 — the activation rows are K-concatenated [hi | lo] bf16 planes (K = 2 * kwrap * 64)
+    // and the weight's k index wraps after kwrap k-tiles of 64 (W is [N, K / 2]); split_out > 0 — bf16 epilogues write
+    // hi at column n and lo = bf16(v - hi) at column split_out + n (EPI_SWIGLU: at n / 2)
+    int kwrap;
+    int split_out;
 };
 void launch_gemm(const GemmArgs& a, int epilogue, hipStream_t s);
 
@@ -81,6 +86,10 @@ struct GemvArgs {
     unsigned* sk_counters;   // [N/16][2 row groups], zero between launches
     int ksplit;              // 0/1 = off (launcher decides when the two buffers are given)
     int w_cached;            // 1: stream the weights with the default cache policy instead of non-temporal (VC_GEMV_WCACHED)
+    // precision mode "split" (0 = off; G = 8 for M <= 8, G = 16 for M <= 16): X is [G + M, K] — rows [0, M) the bf16 hi parts
+    // of the activation rows, rows [G, G + M) the lo parts (x = hi + lo, ~16 mantissa bits) — and out[m] = (hi[m] + lo[m]) . W.
+    // bf16-valued outputs (GEMV_BF16, GEMV_SWIGLU, xg_out) are written the same way: hi at row m, lo at row G + m.
+    int split_rows;
 };
 void launch_gemv(const GemvArgs& a, int epilogue, hipStream_t s);
 void launch_pack_weight(const bf16_t* W, bf16_t* Wp, int N, int K, hipStream_t s);
@@ -102,16 +111,25 @@ void launch_rmsnorm(const float* x, const float* w, bf16_t* y, int rows, int D, 
 void launch_rmsnorm_q8(const float* x, const float* w, uint8_t* q, float* scale, int rows, int D, float eps, hipStream_t s);
 void launch_rmsnorm_rows(const float* x, const int* row_idx, const float* w, bf16_t* y, int rows, int D, float eps,
                          hipStream_t s);
+// precision mode "split": the normalised row as two bf16 planes, hi = bf16(o) at y + r * ldy and lo = bf16(o - hi) at
+// y + r * ldy + lo_off (lo_off = D with ldy >= 2 D: the K-concatenated operand of a kwrap GEMM; lo_off = G * D with ldy = D:
+// the stacked hi / lo row groups of a split decode GEMV)
+void launch_layernorm_split(const float* x, const float* w, const float* b, bf16_t* y, int rows, int D, float eps, int ldy,
+                            size_t lo_off, hipStream_t s);
+void launch_rmsnorm_split(const float* x, const int* row_idx, const float* w, bf16_t* y, int rows, int D, float eps, int ldy,
+                          size_t lo_off, hipStream_t s);
 
 // ---- ViT front end ---------------------------------------------------------------------------
 // K1 (im2col half): pixels fp32 [N,3,S,S] -> cols bf16 [N*g*g, Kpad] (zero padded from 3*P*P to Kpad)
-void launch_im2col(const float* pixels, bf16_t* cols, int n_img, int image, int patch, int Kpad, hipStream_t s);
+// split: cols is [N*g*g, 2 * Kpad], columns [0, Kpad) = bf16(pixel), [Kpad, 2 Kpad) = bf16(pixel - hi)
+void launch_im2col(const float* pixels, bf16_t* cols, int n_img, int image, int patch, int Kpad, hipStream_t s, bool split = false);
 // K2: x[n][0] = cls + pos[0]; x[n][1+p] = patches[n*g2+p] + pos[1+p]; then pre-LayerNorm, fp32 out [N,T,D]
 void launch_vit_embed_ln(const float* patches, const float* cls, const float* pos, const float* w, const float* b,
                          float* x, int n_img, int T, int D, float eps, hipStream_t s);
 
 // K8 feature_select: x fp32 [N,T,D] -> y bf16 [N*(T-skip), D] dropping the first `skip` rows (CLS) of each image
-void launch_select_rows_bf16(const float* x, bf16_t* y, int n_img, int T, int skip, int D, hipStream_t s);
+// split: y is [N*(T-skip), 2 * D] = [hi | lo]
+void launch_select_rows_bf16(const float* x, bf16_t* y, int n_img, int T, int skip, int D, hipStream_t s, bool split = false);
 
 // ---- attention -------------------------------------------------------------------------------
 // qkv split (+RoPE for the LLM, K13/K14): qkv bf16 [B*T, 3*D] -> Q [B,H,Tq_stride,hd], K [B,H,S_stride,hd] at pos0..,
@@ -143,8 +161,27 @@ struct AttnArgs {
     int causal;
     float scale;
     int vt_stride;    // columns per row of V^T (0: kv_stride)
+    // precision mode "split" (q_lo != nullptr): q / k / vt are the hi planes and these the lo planes of the same layouts
+    // (x = hi + lo); the output row is [hi | lo]: row stride ldo elements, lo plane at column lo_off
+    const bf16_t* q_lo;
+    const bf16_t* k_lo;
+    const bf16_t* vt_lo;
+    int ldo, lo_off;
 };
 void launch_attention(const AttnArgs& a, hipStream_t s);
+
+// precision mode "split": fp32 fused-QKV rows -> RoPE (fp32) -> fp32 K / V cache rows + bf16 hi / lo planes of Q, K, V^T
+struct QkvSplit32Args {
+    const float* qkv;        // [B*T, 3*H*hd] fp32
+    bf16_t *q_hi, *q_lo;     // [B,H,q_stride,hd]
+    bf16_t *k_hi, *k_lo;     // [B,H,ks_stride,hd]   per-call scratch of the flash kernel
+    bf16_t *vt_hi, *vt_lo;   // [B,H,hd,vt_stride]
+    float *k32, *v32;        // fp32 caches [B,H,kv_stride,hd], rows 0..T-1 written; nullptr: none (ViT)
+    int B, T, H, hd, q_stride, ks_stride, vt_stride, kv_stride;
+    const float* rope_cos;   // nullptr disables RoPE (ViT)
+    const float* rope_sin;
+};
+void launch_qkv_split32(const QkvSplit32Args& a, hipStream_t s);
 
 // fused decode attention (K13+K14+K15 for q_len = 1): RoPE of the new q/k, KV-cache append and attention over the cache
 // in ONE launch per layer; K and V are both key-major; positions come from device memory (hipGraph-replayable)
@@ -160,6 +197,10 @@ struct AttnDecodeFusedArgs {
     float scale;
     int pos_stride;         // 0: one position for every row
     const int* active_dev;  // nullptr, or row b is skipped when active_dev[b * pos_stride] == 0
+    // precision mode "split" (kv32 != 0): qkv is fp32 [B, 3*H*hd], k / v are fp32 caches, and the output is written as
+    // bf16 hi / lo rows in stacked groups of out_G rows: row b -> hi at row (b / G) * 2G + b % G, lo G rows further
+    int kv32;
+    int out_G;
 };
 void launch_attention_decode_fused(const AttnDecodeFusedArgs& a, hipStream_t s);
 
@@ -233,11 +274,12 @@ struct SelectArgs {
     int lds_floats;       // filled by the launcher: floats of LDS staging available to the sampler
     int row0;             // workgroup i handles state row row0 + i (rows / next_tok / x / ssq / xg) with logits row i: rows
                           // that join a running loop are selected from their prefill's own logits buffer
+    int xg_G;             // precision mode "split" (0 = off): xg holds stacked groups of G hi rows + G lo rows
 };
 void launch_select_embed(const SelectArgs& a, hipStream_t s);
 // embedding + sum-of-squares partials for tokens supplied by the host (vc_decode_step with explicit tokens)
 void launch_embed_tokens_ssq(const int* tok, const bf16_t* embed, float* x, float* ssq, const float* xg_w, bf16_t* xg, int B, int D, int npart,
-                             hipStream_t s);
+                             hipStream_t s, int xg_G = 0);
 void launch_advance(int* step_dev, int* pos_dev, int* ctx_dev, hipStream_t s);
 // test hook: u[i] = the sampler's uniform for hash value h[i], gumbel[i] = -log(-log(u[i]))
 void launch_uniform_probe(const uint32_t* h, float* u, float* gumbel, int n, hipStream_t s);

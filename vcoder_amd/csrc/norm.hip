@@ -14,10 +14,12 @@
 namespace vc {
 
 // MAXV float4 per lane -> rows up to MAXV*256 columns
-template <int MAXV, bool RMS, bool OUT_F32>
+// OUT: 0 = bf16, 1 = fp32, 2 = split: bf16 hi = bf16(o) at y and lo = bf16(o - hi) at y + lo_off (precision mode "split":
+// the K-concatenated [hi | lo] operand of a kwrap GEMM, or the stacked hi / lo rows of a split decode GEMV)
+template <int MAXV, bool RMS, int OUT>
 VC_DEV void norm_row(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
                      void* __restrict__ y, int D, float eps, const float* __restrict__ add0,
-                     const float* __restrict__ add1) {
+                     const float* __restrict__ add1, size_t lo_off = 0) {
     const int lane = lane_id();
     const int nch = D >> 2;
     f32x4 v[MAXV];
@@ -58,11 +60,16 @@ VC_DEV void norm_row(const float* __restrict__ x, const float* __restrict__ w, c
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * wv[e];
             if (!RMS) o = o + ld16f(b + c * 4);
-            if (OUT_F32) {
+            if constexpr (OUT == 1) {
                 st16f(reinterpret_cast<float*>(y) + c * 4, o);
             } else {
                 u32x2 pk = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
                 st8(reinterpret_cast<bf16_t*>(y) + c * 4, pk);
+                if constexpr (OUT == 2) {
+                    const u32x2 lo = {pack_bf2(o[0] - bf2f_lo(pk[0]), o[1] - bf2f_hi(pk[0])),
+                                      pack_bf2(o[2] - bf2f_lo(pk[1]), o[3] - bf2f_hi(pk[1]))};
+                    st8(reinterpret_cast<bf16_t*>(y) + lo_off + c * 4, lo);
+                }
             }
         }
     }
@@ -74,7 +81,7 @@ __global__ __launch_bounds__(256) void norm_kernel(const float* x, const int* ro
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;  // wave-uniform
     const int src = row_idx ? row_idx[row] : row;
-    norm_row<MAXV, RMS, false>(x + (size_t)src * D, w, b, y + (size_t)row * ldy, D, eps, nullptr, nullptr);
+    norm_row<MAXV, RMS, 0>(x + (size_t)src * D, w, b, y + (size_t)row * ldy, D, eps, nullptr, nullptr);
 }
 
 // fp32-out form for the strict path
@@ -84,7 +91,7 @@ __global__ __launch_bounds__(256) void norm_f32_kernel(const float* x, const int
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int src = row_idx ? row_idx[row] : row;
-    norm_row<MAXV, RMS, true>(x + (size_t)src * D, w, b, y + (size_t)row * D, D, eps, nullptr, nullptr);
+    norm_row<MAXV, RMS, 1>(x + (size_t)src * D, w, b, y + (size_t)row * D, D, eps, nullptr, nullptr);
 }
 template <bool RMS>
 static void launch_norm_f32(const float* x, const int* idx, const float* w, const float* b, float* y, int rows, int D,
@@ -101,6 +108,32 @@ void launch_layernorm_f32(const float* x, const float* w, const float* b, float*
 void launch_rmsnorm_f32(const float* x, const int* row_idx, const float* w, float* y, int rows, int D, float eps,
                         hipStream_t s) {
     launch_norm_f32<true>(x, row_idx, w, nullptr, y, rows, D, eps, s);
+}
+
+// split-out form: row r -> hi at y + r * ldy, lo at y + r * ldy + lo_off
+template <int MAXV, bool RMS>
+__global__ __launch_bounds__(256) void norm_split_kernel(const float* x, const int* row_idx, const float* w, const float* b,
+                                                         bf16_t* y, int rows, int D, float eps, int ldy, size_t lo_off) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;  // wave-uniform
+    const int src = row_idx ? row_idx[row] : row;
+    norm_row<MAXV, RMS, 2>(x + (size_t)src * D, w, b, y + (size_t)row * ldy, D, eps, nullptr, nullptr, lo_off);
+}
+template <bool RMS>
+static void launch_norm_split(const float* x, const int* idx, const float* w, const float* b, bf16_t* y, int rows, int D,
+                              float eps, int ldy, size_t lo_off, hipStream_t s) {
+    const dim3 grid((rows + 3) / 4), block(256);
+    if (D <= 1024) VC_LAUNCH((norm_split_kernel<4, RMS>), grid, block, 0, s, x, idx, w, b, y, rows, D, eps, ldy, lo_off);
+    else if (D <= 4096) VC_LAUNCH((norm_split_kernel<16, RMS>), grid, block, 0, s, x, idx, w, b, y, rows, D, eps, ldy, lo_off);
+    else VC_LAUNCH((norm_split_kernel<32, RMS>), grid, block, 0, s, x, idx, w, b, y, rows, D, eps, ldy, lo_off);
+}
+void launch_layernorm_split(const float* x, const float* w, const float* b, bf16_t* y, int rows, int D, float eps, int ldy,
+                            size_t lo_off, hipStream_t s) {
+    launch_norm_split<false>(x, nullptr, w, b, y, rows, D, eps, ldy, lo_off, s);
+}
+void launch_rmsnorm_split(const float* x, const int* row_idx, const float* w, bf16_t* y, int rows, int D, float eps, int ldy,
+                          size_t lo_off, hipStream_t s) {
+    launch_norm_split<true>(x, row_idx, w, nullptr, y, rows, D, eps, ldy, lo_off, s);
 }
 
 template <bool RMS>
@@ -195,7 +228,7 @@ __global__ __launch_bounds__(256) void vit_embed_ln_kernel(const float* patches,
     if (row >= n_img * T) return;
     const int n = row / T, t = row % T;
     const float* src = t == 0 ? cls : patches + ((size_t)n * (T - 1) + (t - 1)) * D;
-    norm_row<MAXV, false, true>(src, w, b, x + (size_t)row * D, D, eps, pos + (size_t)t * D, nullptr);
+    norm_row<MAXV, false, 1>(src, w, b, x + (size_t)row * D, D, eps, pos + (size_t)t * D, nullptr);
 }
 void launch_vit_embed_ln(const float* patches, const float* cls, const float* pos, const float* w, const float* b,
                          float* x, int n_img, int T, int D, float eps, hipStream_t s) {
@@ -205,8 +238,9 @@ void launch_vit_embed_ln(const float* patches, const float* cls, const float* po
 }
 
 // ---- K1: im2col (pixels fp32 NCHW -> bf16 [N*g*g, Kpad]); column = c*P*P + py*P + px ---------------------
+// ldc = row stride of cols (Kpad, or 2 * Kpad with lo_off = Kpad for the split [hi | lo] form)
 __global__ __launch_bounds__(256) void im2col_kernel(const float* pixels, bf16_t* cols, int n_img, int S, int P,
-                                                     int Kpad) {
+                                                     int Kpad, int ldc, int lo_off) {
     const int g = S / P, chunks = Kpad >> 3;
     const size_t total = (size_t)n_img * g * g * chunks;
     const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -227,18 +261,24 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* pixels, bf16_t
         }
     }
     u32x4 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
-    st16(cols + row * Kpad + ch * 8, o);
+    st16(cols + row * ldc + ch * 8, o);
+    if (lo_off) {
+        u32x4 l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) l[e] = pack_bf2(v[2 * e] - bf2f_lo(o[e]), v[2 * e + 1] - bf2f_hi(o[e]));
+        st16(cols + row * ldc + lo_off + ch * 8, l);
+    }
 }
-void launch_im2col(const float* pixels, bf16_t* cols, int n_img, int image, int patch, int Kpad, hipStream_t s) {
+void launch_im2col(const float* pixels, bf16_t* cols, int n_img, int image, int patch, int Kpad, hipStream_t s, bool split) {
     const int g = image / patch;
     const size_t total = (size_t)n_img * g * g * (Kpad / 8);
     VC_LAUNCH(im2col_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, pixels, cols, n_img, image, patch,
-              Kpad);
+              Kpad, split ? 2 * Kpad : Kpad, split ? Kpad : 0);
 }
 
 // ---- K8: feature_select — drop the first `skip` rows of every image, fp32 -> bf16 ----------------------
 __global__ __launch_bounds__(256) void select_rows_kernel(const float* x, bf16_t* y, int n_img, int T, int skip,
-                                                          int D) {
+                                                          int D, int ldy, int lo_off) {
     const int chunks = D >> 3;
     const size_t total = (size_t)n_img * (T - skip) * chunks;
     const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -249,11 +289,17 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const float* x, bf16_t
     const float* src = x + (n * T + t) * D + ch * 8;
     const f32x4 a = ld16f(src), b = ld16f(src + 4);
     u32x4 o = {pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3]), pack_bf2(b[0], b[1]), pack_bf2(b[2], b[3])};
-    st16(y + orow * D + ch * 8, o);
+    st16(y + orow * ldy + ch * 8, o);
+    if (lo_off) {
+        const u32x4 l = {pack_bf2(a[0] - bf2f_lo(o[0]), a[1] - bf2f_hi(o[0])), pack_bf2(a[2] - bf2f_lo(o[1]), a[3] - bf2f_hi(o[1])),
+                         pack_bf2(b[0] - bf2f_lo(o[2]), b[1] - bf2f_hi(o[2])), pack_bf2(b[2] - bf2f_lo(o[3]), b[3] - bf2f_hi(o[3]))};
+        st16(y + orow * ldy + lo_off + ch * 8, l);
+    }
 }
-void launch_select_rows_bf16(const float* x, bf16_t* y, int n_img, int T, int skip, int D, hipStream_t s) {
+void launch_select_rows_bf16(const float* x, bf16_t* y, int n_img, int T, int skip, int D, hipStream_t s, bool split) {
     const size_t total = (size_t)n_img * (T - skip) * (D / 8);
-    VC_LAUNCH(select_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, y, n_img, T, skip, D);
+    VC_LAUNCH(select_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, y, n_img, T, skip, D,
+              split ? 2 * D : D, split ? D : 0);
 }
 
 }  // namespace vc

@@ -89,8 +89,9 @@ VC_DEV void block_argmax(float& v, int& i, BlockRed& r, int lane, int wave) {
 }
 
 // bf16 embedding row -> fp32 residual row + sum-of-squares partials + xg = bf16(x * g) (the first GEMV's operand)
+// xg_lo != nullptr (precision mode "split"): additionally the lo row bf16(x * g - xg) of the stacked hi / lo group
 VC_DEV void embed_row_ssq(const bf16_t* sp, float* dp, float* ssq_row, const float* gw, bf16_t* xg, int D, int npart,
-                          int lane) {
+                          int lane, bf16_t* xg_lo = nullptr) {
     float ss = 0.f;
     for (int c = lane; c < D / 8; c += 64) {
         const u32x4 v = ld16(sp + c * 8);
@@ -99,8 +100,15 @@ VC_DEV void embed_row_ssq(const bf16_t* sp, float* dp, float* ssq_row, const flo
         st16f(dp + c * 8, a);
         st16f(dp + c * 8 + 4, b);
         const f32x4 g0 = ld16f(gw + c * 8), g1 = ld16f(gw + c * 8 + 4);
-        st16(xg + c * 8, u32x4{pack_bf2(a[0] * g0[0], a[1] * g0[1]), pack_bf2(a[2] * g0[2], a[3] * g0[3]),
-                               pack_bf2(b[0] * g1[0], b[1] * g1[1]), pack_bf2(b[2] * g1[2], b[3] * g1[3])});
+        const f32x4 ta = {a[0] * g0[0], a[1] * g0[1], a[2] * g0[2], a[3] * g0[3]};
+        const f32x4 tb = {b[0] * g1[0], b[1] * g1[1], b[2] * g1[2], b[3] * g1[3]};
+        const u32x4 hi = {pack_bf2(ta[0], ta[1]), pack_bf2(ta[2], ta[3]), pack_bf2(tb[0], tb[1]), pack_bf2(tb[2], tb[3])};
+        st16(xg + c * 8, hi);
+        if (xg_lo != nullptr)
+            st16(xg_lo + c * 8, u32x4{pack_bf2(ta[0] - bf2f_lo(hi[0]), ta[1] - bf2f_hi(hi[0])),
+                                      pack_bf2(ta[2] - bf2f_lo(hi[1]), ta[3] - bf2f_hi(hi[1])),
+                                      pack_bf2(tb[0] - bf2f_lo(hi[2]), tb[1] - bf2f_hi(hi[2])),
+                                      pack_bf2(tb[2] - bf2f_lo(hi[3]), tb[3] - bf2f_hi(hi[3]))});
         ss += ((a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3])) +
               ((b[0] * b[0] + b[1] * b[1]) + (b[2] * b[2] + b[3] * b[3]));
     }
@@ -230,8 +238,10 @@ __global__ __launch_bounds__(1024) void select_embed_kernel(SelectArgs p) {
     __syncthreads();
     if (wave == 0 && p.embed != nullptr) {
         const int tok = tok_s;
+        const int G = p.xg_G;  // split mode: row r -> hi at row (r / G) * 2G + r % G of xg, lo G rows further
+        const size_t xrow = G ? (size_t)(r / G) * 2 * G + r % G : (size_t)r;
         embed_row_ssq(p.embed + (size_t)tok * p.D, p.x + (size_t)r * p.D, p.ssq + (size_t)r * p.npart, p.xg_w,
-                      p.xg + (size_t)r * p.D, p.D, p.npart, lane);
+                      p.xg + xrow * p.D, p.D, p.npart, lane, G ? p.xg + (xrow + G) * p.D : nullptr);
     }
 }
 
@@ -265,15 +275,16 @@ void launch_uniform_probe(const uint32_t* h, float* u, float* gumbel, int n, hip
 
 // embedding + sum-of-squares partials for tokens supplied by the host (vc_decode_step with explicit tokens)
 __global__ __launch_bounds__(256) void embed_tokens_ssq_kernel(const int* tok, const bf16_t* embed, float* x, float* ssq,
-                                                               const float* xg_w, bf16_t* xg, int B, int D, int npart) {
+                                                               const float* xg_w, bf16_t* xg, int B, int D, int npart, int G) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B) return;
-    embed_row_ssq(embed + (size_t)tok[row] * D, x + (size_t)row * D, ssq + (size_t)row * npart, xg_w, xg + (size_t)row * D, D,
-                  npart, threadIdx.x & 63);
+    const size_t xrow = G ? (size_t)(row / G) * 2 * G + row % G : (size_t)row;
+    embed_row_ssq(embed + (size_t)tok[row] * D, x + (size_t)row * D, ssq + (size_t)row * npart, xg_w, xg + xrow * D, D,
+                  npart, threadIdx.x & 63, G ? xg + (xrow + G) * D : nullptr);
 }
 void launch_embed_tokens_ssq(const int* tok, const bf16_t* embed, float* x, float* ssq, const float* xg_w, bf16_t* xg, int B,
-                             int D, int npart, hipStream_t s) {
-    VC_LAUNCH(embed_tokens_ssq_kernel, dim3((B + 3) / 4), dim3(256), 0, s, tok, embed, x, ssq, xg_w, xg, B, D, npart);
+                             int D, int npart, hipStream_t s, int xg_G) {
+    VC_LAUNCH(embed_tokens_ssq_kernel, dim3((B + 3) / 4), dim3(256), 0, s, tok, embed, x, ssq, xg_w, xg, B, D, npart, xg_G);
 }
 
 }  // namespace vc
