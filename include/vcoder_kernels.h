@@ -114,6 +114,38 @@ void vck_attention_f32(const float* q, const float* k, const float* v, float* ou
                        int kv_stride, int causal, int Tk, const int* pos0_dev, float scale, void* stream);
 void vck_qkv_rope_f32(const float* qkv, float* q, float* k, float* v, int B, int T, int H, int hd, int q_stride, int kv_stride,
                       const int* pos0_dev, const float* rope_cos, const float* rope_sin, void* stream);
+/* ---- precision mode "split" behind vc_model_set_precision(m, 2): the FAST kernels with every MFMA operand carried as two bf16
+ * values, x = hi + lo (hi = bf16(x), lo = bf16(x - hi): ~16 mantissa bits; weights are exactly bf16), fp32 everywhere between
+ * two MFMAs.  Meets the "logits within 1e-3, greedy ids bit-exact" bar of BASELINE.json at ~half the fast path's MFMA rate.
+ * vck_gemm_split: A is [M, lda] with columns [0, Kw) = hi and [Kw, 2 Kw) = lo of the activation row; W [N, Kw] is contracted
+ *   against both halves (its k index wraps); epi as vck_gemm; split_out > 0: bf16-valued epilogues write [hi | lo] again, the lo
+ *   plane split_out columns to the right of the hi value.
+ * vck_gemv_split: X is [G + M, K] — rows [0, M) hi, rows [G, G + M) lo (G = 8 for M <= 8, 16 for M <= 16); bf16-valued outputs
+ *   (epi 0 / 3, xg_out) come back as hi row m + lo row G + m.
+ * vck_*norm_split: normalised row r -> hi at y + r * ldy, lo at y + r * ldy + lo_off.
+ * vck_qkv_split32: fp32 fused-QKV rows -> RoPE in fp32 -> fp32 K / V cache rows (k32 / v32, may be NULL) + bf16 hi / lo planes
+ *   of Q [B,H,q_stride,hd], K [B,H,ks_stride,hd] and V^T [B,H,hd,vt_stride].
+ * vck_attention_split: flash attention over those planes (3 MFMAs per product), output rows [hi | lo]: stride ldo, lo at lo_off.
+ * vck_attention_decode_kv32: the fused decode attention over fp32 qkv / fp32 K, V caches; output as stacked groups of G hi rows
+ *   + G lo rows (row b -> hi at row (b / G) * 2G + b % G). */
+void vck_gemm_split(const uint16_t* A, const uint16_t* W, const float* bias, void* out, int M, int N, int Kw, int lda, int ldo,
+                    int epi, int split_out, float* ws, size_t ws_bytes, void* stream);
+void vck_gemv_split(const uint16_t* X, const void* Wp, const float* wscale, void* out, const float* ssq_in, float* ssq_out,
+                    const float* xg_w, uint16_t* xg_out, int npart, float eps, int M, int N, int K, int ldo, int epi, int G,
+                    void* stream);
+void vck_rmsnorm_split(const float* x, const int* row_idx, const float* w, uint16_t* y, int rows, int D, float eps, int ldy,
+                       uint64_t lo_off, void* stream);
+void vck_layernorm_split(const float* x, const float* w, const float* b, uint16_t* y, int rows, int D, float eps, int ldy,
+                         uint64_t lo_off, void* stream);
+void vck_qkv_split32(const float* qkv, uint16_t* q_hi, uint16_t* q_lo, uint16_t* k_hi, uint16_t* k_lo, uint16_t* vt_hi,
+                     uint16_t* vt_lo, float* k32, float* v32, int B, int T, int H, int hd, int q_stride, int ks_stride, int vt_stride,
+                     int kv_stride, const float* rope_cos, const float* rope_sin, void* stream);
+void vck_attention_split(const uint16_t* q_hi, const uint16_t* q_lo, const uint16_t* k_hi, const uint16_t* k_lo,
+                         const uint16_t* vt_hi, const uint16_t* vt_lo, uint16_t* out, int B, int H, int T, int hd, int q_stride,
+                         int kv_stride, int causal, float scale, int ldo, int lo_off, void* stream);
+void vck_attention_decode_kv32(const float* qkv, float* k, float* v, uint16_t* out, int B, int H, int hd, int kv_stride,
+                               const int* pos_rows, int pos_stride, const int* active_rows, const float* rope_cos,
+                               const float* rope_sin, float scale, int G, void* stream);
 /* deterministic synthetic tensors (vcoder_amd/synth.py) and dtype converts */
 void vck_synth_bf16(uint16_t* out, uint64_t n, uint32_t tseed, float offset, float halfwidth, void* stream);
 void vck_synth_f32(float* out, uint64_t n, uint32_t tseed, float offset, float halfwidth, void* stream);

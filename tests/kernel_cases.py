@@ -912,3 +912,266 @@ def check_qkv_rope_f32(be, B, T, H, hd, pos0):
     assert np.abs(be.host_f32(q) - rq).max() < 1e-5
     gk, gv = be.host_f32(k), be.host_f32(v)
     assert np.abs(gk[:, :, pos0:pos0 + T] - rk).max() < 1e-5 and np.array_equal(gv[:, :, pos0:pos0 + T], t[2].numpy())
+
+
+# ---- precision mode "split": every MFMA operand as bf16 hi + lo ---------------------------------------------------------
+def split_hi_lo(x):
+    """x (fp32) -> (hi, lo) fp32 arrays holding bf16 values: hi = bf16(x), lo = bf16(x - hi); x - (hi + lo) ~ 2^-17 |x|"""
+    x = np.asarray(x, dtype=np.float32)
+    hi = bf16_round(x)
+    lo = bf16_round(x - hi)
+    return hi, lo
+
+
+def _split_value(be, out, N):
+    """[M, >= 2N] device bf16 buffer holding [hi | lo] planes -> fp32 hi + lo"""
+    o = be.host_f32(out)
+    return o[:, :N].astype(np.float64) + o[:, N:2 * N].astype(np.float64)
+
+
+def check_gemm_split(be, M, N, K, epi, bias=True, seed=0, ws_mb=0, pad=64):
+    """vck_gemm_split: A = [hi | lo] of an fp32 matrix (row stride 2K + pad), W bf16; against the float64 product of the
+    fp32 activations.  fp32 outputs: the split's own error (2^-17 relative per operand) — tolerance 3e-5 of the largest
+    output; bf16-valued outputs come back as [hi | lo] and are compared the same way."""
+    rng = np.random.RandomState(seed)
+    A = rng.randn(M, K).astype(np.float32)
+    W = bf16_round(rng.randn(N, K) * 0.05)
+    b = rng.randn(N).astype(np.float32) * 0.1 if bias else None
+    hi, lo = split_hi_lo(A)
+    lda = 2 * K + pad
+    Acat = np.zeros((M, lda), np.float32)
+    Acat[:, :K], Acat[:, K:2 * K] = hi, lo
+    t = torch.from_numpy(A.astype(np.float64) @ W.T.astype(np.float64) + (b if bias else 0.0))
+    No = N // 2 if epi == 5 else N
+    if epi == 1:
+        t = t * torch.sigmoid(1.702 * t)
+    elif epi == 2:
+        t = torch.nn.functional.gelu(t)
+    elif epi == 5:
+        t = torch.nn.functional.silu(t[:, 0::2]) * t[:, 1::2]
+    if epi in (0, 1, 2, 5):
+        ldo = 2 * No + pad
+        out = be.zeros((M, ldo), "bf16")
+        split_out = No
+    elif epi == 3:
+        ldo, split_out, out = N, 0, be.zeros((M, N), "f32")
+    else:
+        r0 = rng.randn(M, N).astype(np.float32)
+        ldo, split_out, out = N, 0, be.f32(r0.copy())
+        t = t + torch.from_numpy(r0).double()
+    Ad, Wd, bd = be.bf16(Acat), be.bf16(W), (be.f32(b) if bias else None)
+    ws = be.zeros((max(ws_mb, 1) << 18,), "f32")
+    be.lib.vck_gemm_split(be.ptr(Ad), be.ptr(Wd), be.ptr(bd), be.ptr(out), M, N, K, lda, ldo, epi, split_out,
+                          be.ptr(ws) if ws_mb else None, ctypes.c_size_t((ws_mb << 20) if ws_mb else 0), None)
+    be.sync()
+    got = _split_value(be, out, No) if split_out else be.host_f32(out).astype(np.float64)
+    e = rel_err(got, t.numpy())
+    assert e < 3e-5, f"gemm_split M{M} N{N} K{K} epi{epi}: rel err {e}"
+    return e
+
+
+def check_gemv_split(be, M, N, K, epi, norm=True, seed=0, fp8=False):
+    """vck_gemv_split at M rows (G = 8 for M <= 8, else 16): stacked hi / lo rows of X against the float64 product of the
+    fp32 rows; RMSNorm folding (ssq_in -> rstd, RESID epilogue -> ssq_out + stacked xg_out) as in the bf16 kernel."""
+    rng = np.random.RandomState(seed)
+    G = 8 if M <= 8 else 16
+    npart = (max(K, N) // 16 + 15) // 16 * 16
+    Xf = rng.randn(M, K).astype(np.float32)
+    hi, lo = split_hi_lo(Xf)
+    X = np.zeros((2 * G, K), np.float32)
+    X[:M], X[G:G + M] = hi, lo
+    X[M:G] = 7.0   # rows of the group beyond M must not be read into any result
+    W = bf16_round(rng.randn(N, K) * 0.05)
+    wsc = None
+    if fp8:
+        Wd, Wp, wsc = be.bf16(W), be.zeros((N * K,), "u8"), be.zeros((N,), "f32")
+        _call(be, "vck_quantize_fp8", Wd, Wp, wsc, N, K)
+        W = be.host_f32(Wd)
+    else:
+        Wd, Wp = be.bf16(W), be.zeros((N * K,), "bf16")
+        _call(be, "vck_pack_weight", Wd, Wp, N, K)
+    ssq = np.zeros((16, npart), np.float32)
+    ssq[:, : K // 16] = rng.rand(16, K // 16).astype(np.float32) + 0.5
+    ref = Xf.astype(np.float64) @ W.T.astype(np.float64)
+    if norm:
+        ref = ref / np.sqrt(ssq[:M, : K // 16].astype(np.float64).sum(-1, keepdims=True) / K + 1e-5)
+    No = N // 2 if epi == 3 else N
+    gw = (rng.rand(N).astype(np.float32) + 0.5) if epi == 2 else None
+    if epi == 3:
+        t = torch.from_numpy(ref)
+        ref = (torch.nn.functional.silu(t[:, 0::2]) * t[:, 1::2]).numpy()
+    r0 = rng.randn(16, No).astype(np.float32)
+    if epi == 2:
+        ref = ref + r0[:M]
+        out = be.f32(r0.copy())
+    elif epi == 1:
+        out = be.zeros((16, No), "f32")
+    else:
+        out = be.zeros((2 * G, No), "bf16")
+    xg_out = be.zeros((2 * G, N), "bf16") if epi == 2 else None
+    ssq_out = be.zeros((16, npart), "f32") if epi == 2 else None
+    Xd, ssqd, gwd = be.bf16(X), (be.f32(ssq) if norm else None), (be.f32(gw) if gw is not None else None)
+    be.lib.vck_gemv_split(be.ptr(Xd), be.ptr(Wp), be.ptr(wsc), be.ptr(out), be.ptr(ssqd), be.ptr(ssq_out), be.ptr(gwd),
+                          be.ptr(xg_out), ctypes.c_int(npart), ctypes.c_float(1e-5), M, N, K, No, epi, G, None)
+    be.sync()
+    o = be.host_f32(out).astype(np.float64)
+    got = (o[:M] + o[G:G + M]) if epi in (0, 3) else o[:M]
+    e = rel_err(got, ref)
+    assert e < 3e-5, f"gemv_split M{M} N{N} K{K} epi{epi} fp8{fp8}: rel err {e}"
+    if epi == 2:
+        xg = be.host_f32(xg_out).astype(np.float64)
+        e2 = rel_err(xg[:M] + xg[G:G + M], got * gw)
+        assert e2 < 2e-5, f"gemv_split xg_out: {e2}"
+        so = be.host_f32(ssq_out)[:M, : N // 16].astype(np.float64).sum(-1)
+        assert np.abs(so / (got ** 2).sum(-1) - 1).max() < 1e-5
+        assert np.array_equal(o[M:], r0[M:].astype(np.float64)), "residual rows beyond M were touched"
+    return e
+
+
+def check_gemv_split_groups_agree(be, N, K, epi, seed=0):
+    """a row gets the same bits from the G = 8 form (hi / lo share one MFMA row group) as from the G = 16 form (two row
+    groups): what lets a request decode in the pool (G = 16) or on its own loop (G = 8 for <= 8 rows) with identical ids"""
+    rng = np.random.RandomState(seed)
+    M = 5
+    Xf = rng.randn(M, K).astype(np.float32)
+    hi, lo = split_hi_lo(Xf)
+    W = bf16_round(rng.randn(N, K) * 0.05)
+    Wd, Wp = be.bf16(W), be.zeros((N * K,), "bf16")
+    _call(be, "vck_pack_weight", Wd, Wp, N, K)
+    No = N // 2 if epi == 3 else N
+    outs = []
+    for G in (8, 16):
+        X = np.zeros((2 * G, K), np.float32)
+        X[:M], X[G:G + M] = hi, lo
+        out = be.zeros((2 * G, No), "bf16") if epi in (0, 3) else be.zeros((16, No), "f32")
+        Xd = be.bf16(X)
+        be.lib.vck_gemv_split(be.ptr(Xd), be.ptr(Wp), None, be.ptr(out), None, None, None, None, ctypes.c_int(16),
+                              ctypes.c_float(1e-5), M, N, K, No, epi, G, None)
+        be.sync()
+        o = be.host_f32(out)
+        outs.append((o[:M], o[G:G + M]) if epi in (0, 3) else (o[:M],))
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b), "the G = 8 and G = 16 forms of the split GEMV disagree"
+
+
+def check_norm_split(be, rows, D, rms=True, seed=0):
+    rng = np.random.RandomState(seed)
+    x = (rng.randn(rows, D) * 2).astype(np.float32)
+    w = (rng.rand(D) + 0.5).astype(np.float32)
+    b = (rng.randn(D) * 0.1).astype(np.float32)
+    x64 = x.astype(np.float64)
+    if rms:
+        ref = x64 / np.sqrt((x64 ** 2).mean(-1, keepdims=True) + 1e-5) * w
+    else:
+        mu = x64.mean(-1, keepdims=True)
+        ref = (x64 - mu) / np.sqrt(((x64 - mu) ** 2).mean(-1, keepdims=True) + 1e-5) * w + b
+    ld = 2 * D + 64
+    y = be.zeros((rows, ld), "bf16")
+    xd, wd, bd = be.f32(x), be.f32(w), be.f32(b)
+    if rms:
+        be.lib.vck_rmsnorm_split(be.ptr(xd), None, be.ptr(wd), be.ptr(y), rows, D, ctypes.c_float(1e-5), ld, ctypes.c_uint64(D), None)
+    else:
+        be.lib.vck_layernorm_split(be.ptr(xd), be.ptr(wd), be.ptr(bd), be.ptr(y), rows, D, ctypes.c_float(1e-5), ld, ctypes.c_uint64(D), None)
+    be.sync()
+    e = rel_err(_split_value(be, y, D), ref)
+    assert e < 2e-5, f"norm_split rows{rows} D{D} rms{rms}: {e}"
+
+
+def check_qkv_split32_and_attention_split(be, B, H, T, hd, causal, rope=True, seed=0, spike=False):
+    """vck_qkv_split32 + vck_attention_split as the split prefill chains them: fp32 fused-QKV rows -> RoPE -> hi / lo planes
+    (+ fp32 cache rows) -> flash attention with 3 MFMAs per product, against the fp32 oracle (no rounding points)."""
+    rng = np.random.RandomState(seed)
+    D = H * hd
+    Ts = (T + 63) // 64 * 64
+    S_cap = Ts + 64
+    qkv = rng.randn(B * T, 3 * D).astype(np.float32)
+    if spike:
+        qkv.reshape(B, T, 3, H, hd)[:, T - 3, 1] = qkv.reshape(B, T, 3, H, hd)[:, T - 1, 0] * 4
+    cos, sin = rope_tables(S_cap, hd)
+    planes = lambda *shape: [be.zeros(shape, "bf16") for _ in range(2)]
+    (qh, ql), (kh, kl), (vh, vl) = planes(B, H, Ts, hd), planes(B, H, Ts, hd), planes(B, H, hd, Ts)
+    k32, v32 = be.zeros((B, H, S_cap, hd), "f32"), be.zeros((B, H, S_cap, hd), "f32")
+    qd, cd, sd = be.f32(qkv), be.f32(cos), be.f32(sin)
+    be.lib.vck_qkv_split32(be.ptr(qd), be.ptr(qh), be.ptr(ql), be.ptr(kh), be.ptr(kl), be.ptr(vh), be.ptr(vl), be.ptr(k32),
+                           be.ptr(v32), B, T, H, hd, Ts, Ts, Ts, S_cap, be.ptr(cd) if rope else None, be.ptr(sd) if rope else None,
+                           None)
+    be.sync()
+    x = torch.from_numpy(qkv).view(B, T, 3, H, hd).permute(2, 0, 3, 1, 4).contiguous()   # [3,B,H,T,hd]
+    q, k, v = x[0], x[1], x[2]
+    if rope:
+        c, s_ = torch.from_numpy(cos[:T]), torch.from_numpy(sin[:T])
+        def rot(t):
+            a, b_ = t[..., : hd // 2], t[..., hd // 2:]
+            return torch.cat([a * c - b_ * s_, b_ * c + a * s_], -1)
+        q, k = rot(q), rot(k)
+    gk32, gv32 = be.host_f32(k32), be.host_f32(v32)
+    assert np.abs(gk32[:, :, :T] - k.numpy()).max() < 1e-5 and np.array_equal(gv32[:, :, :T], v.numpy())
+    assert not gk32[:, :, T:].any() and not gv32[:, :, T:].any()
+    for (h_, l_), ref_ in (((qh, ql), q), ((kh, kl), k)):
+        g_ = be.host_f32(h_)[:, :, :T].astype(np.float64) + be.host_f32(l_)[:, :, :T].astype(np.float64)
+        assert np.abs(g_ - ref_.numpy()).max() < 2e-5 * max(1.0, float(ref_.abs().max()))
+    gvt = be.host_f32(vh)[..., :T].astype(np.float64) + be.host_f32(vl)[..., :T].astype(np.float64)
+    assert np.abs(gvt - v.numpy().transpose(0, 1, 3, 2)).max() < 2e-5 * float(v.abs().max())
+    scale = 1.0 / math.sqrt(hd)
+    ldo = 2 * D + 64
+    out = be.zeros((B * T, ldo), "bf16")
+    be.lib.vck_attention_split(be.ptr(qh), be.ptr(ql), be.ptr(kh), be.ptr(kl), be.ptr(vh), be.ptr(vl), be.ptr(out), B, H, T, hd,
+                               Ts, Ts, int(causal), ctypes.c_float(scale), ldo, D, None)
+    be.sync()
+    ref = cpu_ref.softmax_attention(q, k, v, scale, causal, cpu_ref.Rounder(False))
+    ref = ref.transpose(1, 2).reshape(B * T, D).numpy()
+    err = np.abs(_split_value(be, out, D) - ref).max()
+    assert err < 3e-5 * max(1.0, np.abs(ref).max()), f"attention_split B{B} H{H} T{T} hd{hd} causal{causal}: abs err {err}"
+    return err
+
+
+def check_attention_decode_kv32(be, B, H, hd, pos, seed=0):
+    """fused decode attention over fp32 qkv / fp32 caches (split mode), a position per row, one row inactive; output as
+    stacked hi / lo row groups"""
+    rng = np.random.RandomState(seed)
+    D = H * hd
+    G = 8 if B <= 8 else 16
+    poss = [max(1, pos - 13 * b) for b in range(B)]
+    S = (pos + 1 + 63) // 64 * 64 + 64
+    qkv = rng.randn(B, 3 * D).astype(np.float32)
+    k_old, v_old = rng.randn(B, H, S, hd).astype(np.float32), rng.randn(B, H, S, hd).astype(np.float32)
+    kd, vd = be.f32(k_old), be.f32(v_old)
+    nrows_out = ((B + G - 1) // G) * 2 * G
+    out = be.zeros((nrows_out, D), "bf16")
+    cos, sin = rope_tables(S, hd)
+    scale = 1.0 / math.sqrt(hd)
+    qd, cd, sd = be.f32(qkv), be.f32(cos), be.f32(sin)
+    inactive = B - 1 if B > 1 else -1
+    rows = np.zeros((B, 4), np.int32)
+    rows[:, 0] = 1
+    rows[:, 1] = poss
+    if inactive >= 0:
+        rows[inactive, 0] = 0
+    rd = be.i32(rows)
+    base = rd.ctypes.data if isinstance(rd, np.ndarray) else rd.data_ptr()
+    be.lib.vck_attention_decode_kv32(be.ptr(qd), be.ptr(kd), be.ptr(vd), be.ptr(out), B, H, hd, S, c_p(base + 4), 4, c_p(base),
+                                     be.ptr(cd), be.ptr(sd), ctypes.c_float(scale), G, None)
+    be.sync()
+    gk, gv, go = be.host_f32(kd), be.host_f32(vd), be.host_f32(out).astype(np.float64)
+    for b in range(B):
+        pb = poss[b]
+        orow = (b // G) * 2 * G + b % G
+        if b == inactive:
+            assert np.array_equal(gk[b], k_old[b]) and np.array_equal(gv[b], v_old[b]) and not go[orow].any()
+            continue
+        x = torch.from_numpy(qkv[b]).view(3, H, 1, hd)
+        c, s_ = torch.from_numpy(cos[pb]), torch.from_numpy(sin[pb])
+        def rot(t):
+            a, b_ = t[..., : hd // 2], t[..., hd // 2:]
+            return torch.cat([a * c - b_ * s_, b_ * c + a * s_], -1)
+        q, kn, vn = rot(x[0]), rot(x[1]), x[2]
+        assert np.abs(gk[b, :, pb] - kn[:, 0].numpy()).max() < 1e-5 and np.array_equal(gv[b, :, pb], vn[:, 0].numpy())
+        keep = np.ones(S, bool)
+        keep[pb] = False
+        assert np.array_equal(gk[b][:, keep], k_old[b][:, keep]) and np.array_equal(gv[b][:, keep], v_old[b][:, keep])
+        k_all = torch.cat([torch.from_numpy(k_old[b, :, :pb]), kn], 1)[None]
+        v_all = torch.cat([torch.from_numpy(v_old[b, :, :pb]), vn], 1)[None]
+        ref = cpu_ref.softmax_attention(q[None], k_all, v_all, scale, False, cpu_ref.Rounder(False))
+        ref = ref.transpose(1, 2).reshape(D).numpy()
+        err = np.abs(go[orow] + go[orow + G] - ref).max()
+        assert err < 3e-5 * max(1.0, np.abs(ref).max()), f"decode attention kv32 row {b}: {err}"

@@ -150,6 +150,9 @@ def test_full_depth_parity_logic_on_the_tiny_model(emu_lib):
     import test_gpu_fulldepth as fd
     from vcoder_amd import config as vcfg
 
-    r = fd.run_case(vcfg.tiny("vcoder_ds"), B=2, n_new=6, seed=42, emu_rows=1, checkpoints=(1, 2), strict_tokens=3,
-                    lib=emu_lib)
+    r = fd.run_case(vcfg.tiny("vcoder_ds"), B=3, n_new=6, seed=42, oracle_rows=(0, 2), checkpoints=(1, 2), strict_tokens=3,
+                    pooled_calls=2, lib=emu_lib)
+    assert r["e_strict"] < 1e-4 and r["e_split"] < 1e-4 and r["err32"].max() < e2e_cases.TOL_VS_FP32_REF
+    r = fd.run_case(vcfg.tiny("vcoder_ds"), B=2, n_new=4, seed=42, oracle_rows=(0, 1), checkpoints=(2,), strict_tokens=2,
+                    split=False, pooled_calls=1, lib=emu_lib)
     assert r["e_strict"] < 1e-4 and r["err32"].max() < e2e_cases.TOL_VS_FP32_REF

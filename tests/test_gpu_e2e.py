@@ -189,6 +189,52 @@ def test_fixture_strict_mode(name):
     print(name, e2e_cases.check_fixture_strict(name))
 
 
+@pytest.mark.parametrize("name", FIXTURES)
+def test_fixture_split_mode(name):
+    """The BASELINE.json bar on the FAST kernels (vc_model_set_precision = split: every MFMA operand as bf16 hi + lo): logits
+    within 1e-3 absolute of the reference's fp32 CPU outputs at every position and decode step, greedy ids bit-exact with no
+    margin criterion; generate() runs through the decode pool (stacked groups of 16), the step-by-step check on the
+    session's loop (groups of 8)."""
+    print(name, e2e_cases.check_fixture_strict(name, mode="split"))
+
+
+def test_true_dims_split_against_fp32_oracle():
+    """True 7b / ViT-L dims (2+2 layers, B = 2 and a 13b-geometry variant), split mode vs the fp32 oracle: 1e-3 absolute, ids
+    equal; and the bf16 path on the same inputs for scale."""
+    import torch
+    import cpu_ref
+
+    for mk, seed in ((vcfg.vicuna_7b, 11), (vcfg.vicuna_13b, 12)):
+        cfg = mk("vcoder_ds")
+        cfg.num_hidden_layers = 2
+        cfg.vit_num_layers = 3
+        sd = synth.synth_state_dict(cfg, seed)
+        eng = HipEngine(cfg)
+        eng.load_synthetic(seed)
+        eng.finalize()
+        B = 2
+        ids = np.stack([synth.synth_prompt_ids(cfg.vocab_size, "vcoder_ds", sample=3 + b) for b in range(B)])
+        imgs, segs, deps = synth.synth_batch(B, 336, first=3)
+        fast_last, _, _ = eng.prefill(ids, imgs, segs, deps)
+        eng.set_precision("split")
+        last, _, S = eng.prefill(ids, imgs, segs, deps)
+        tok = np.argmax(last, -1).astype(np.int32)
+        lg2, _ = eng.decode_step(tok)
+        om = cpu_ref.OracleModel(cfg, sd, emu_bf16=False)
+        t = torch.from_numpy
+        with torch.no_grad():
+            o_last, cache = om.forward(ids.tolist(), t(imgs), t(segs), t(deps), last_only=True)
+            o_lg2 = om.decode_step(tok.tolist(), cache)
+        e1 = np.abs(last - o_last[:, -1].numpy()).max()
+        e2 = np.abs(lg2 - o_lg2[:, -1].numpy()).max()
+        ef = np.abs(fast_last - o_last[:, -1].numpy()).max()
+        print(f"true-dims SPLIT parity (D={cfg.hidden_size}): prefill err={e1:.2e} decode err={e2:.2e}  (bf16 path: {ef:.2e})")
+        assert e1 < 1e-3 and e2 < 1e-3
+        assert np.array_equal(tok, np.argmax(o_last[:, -1].numpy(), -1))
+        assert np.array_equal(np.argmax(lg2, -1), np.argmax(o_lg2[:, -1].numpy(), -1))
+        eng.close()
+
+
 def test_true_dims_strict_against_fp32_oracle():
     """True 7b / ViT-L dims (2+2 layers), strict mode vs the fp32 oracle (= the reference's CPU path): 1e-3."""
     import torch

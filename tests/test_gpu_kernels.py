@@ -127,6 +127,43 @@ def test_strict_fp32_kernels(be):
     kc.check_qkv_rope_f32(be, 8, 1, 32, 128, 1216)
 
 
+# ---- precision mode "split": the fast kernels with every MFMA operand as bf16 hi + lo, at the true shapes ---------------
+@pytest.mark.parametrize("M,N,K,epi,bias,ws", [
+    (1216, 12288, 4096, 3, False, 0), (1216, 4096, 4096, 4, False, 0), (1216, 22016, 4096, 5, False, 0),
+    (1216, 4096, 11008, 4, False, 0), (9728, 12288, 4096, 3, False, 64), (9728, 4096, 11008, 4, False, 64),
+    (1154, 3072, 1024, 3, True, 0), (1154, 4096, 1024, 1, True, 0), (1154, 1024, 4096, 4, True, 0),
+    (1152, 1024, 640, 3, False, 0), (1152, 4096, 4096, 2, True, 0), (1216, 32000, 4096, 3, False, 0),
+    (70, 264, 192, 0, True, 0), (300, 320, 256, 5, False, 0)])
+def test_gemm_split(be, M, N, K, epi, bias, ws):
+    """[hi | lo] activation rows against a wrapped bf16 weight (2 MFMAs per weight k-step) vs float64: 3e-5 of max|out|"""
+    kc.check_gemm_split(be, M, N, K, epi, bias, ws_mb=ws)
+
+
+@pytest.mark.parametrize("M,N,K,epi,norm", [(8, 12288, 4096, 1, True), (8, 4096, 4096, 2, False), (8, 22016, 4096, 3, True),
+                                            (8, 4096, 11008, 2, False), (8, 32000, 4096, 1, True), (16, 15360, 5120, 1, True),
+                                            (16, 5120, 13824, 2, False), (13, 27648, 5120, 3, True), (3, 48, 288, 1, False)])
+def test_gemv_split(be, M, N, K, epi, norm):
+    kc.check_gemv_split(be, M, N, K, epi, norm)
+
+
+def test_split_small_and_attention_kernels(be):
+    for (N, K, epi) in [(12288, 4096, 1), (22016, 4096, 3), (32000, 4096, 1)]:
+        kc.check_gemv_split_groups_agree(be, N, K, epi)
+    kc.check_gemv_split(be, 8, 4096, 4096, 1, True, fp8=True)
+    kc.check_norm_split(be, 9728, 4096, rms=True)
+    kc.check_norm_split(be, 37, 5120, rms=True)
+    kc.check_norm_split(be, 1154, 1024, rms=False)
+    kc.check_qkv_split32_and_attention_split(be, 2, 8, 1216, 128, True)
+    kc.check_qkv_split32_and_attention_split(be, 1, 2, 1216, 128, True, seed=1, spike=True)
+    kc.check_qkv_split32_and_attention_split(be, 2, 16, 577, 64, False, rope=False, seed=2)
+    kc.check_qkv_split32_and_attention_split(be, 1, 1, 17, 64, False, rope=False, seed=3)
+    kc.check_attention_decode_kv32(be, 8, 32, 128, 1216)
+    kc.check_attention_decode_kv32(be, 16, 4, 128, 1343, seed=1)
+    kc.check_attention_decode_kv32(be, 24, 8, 128, 1300, seed=2)     # the pool's span: two groups of 16
+    kc.check_attention_decode_kv32(be, 2, 4, 128, 4000, seed=3)
+    kc.check_attention_decode_kv32(be, 1, 2, 64, 5, seed=4)
+
+
 def test_dma_kernels_are_race_free_and_bit_reproducible(be):
     """The counted-vmcnt schedules (8-phase GEMM, LDS-DMA ring GEMV) order LDS-DMA writes against ds_reads by hand; a
     misplaced wait shows up as rare wrong tiles that depend on timing.  Screen: many back-to-back launches of the true

@@ -418,6 +418,24 @@ void gemm_f8(vc_model* m, const bf16_t* A, const uint8_t* Wq, const float* wscal
     a.w_scale = wscale;
     launch_gemm(a, epi, m->st);
 }
+// precision mode "split": A is the K-concatenated [hi | lo] bf16 image of an fp32 activation matrix (row stride lda >= 2 Kw),
+// W [N, Kw] is contracted against both halves (kwrap); split_out > 0: a bf16-valued epilogue writes [hi | lo] again, the lo
+// plane split_out columns to the right
+void gemm_split(vc_model* m, const bf16_t* A, const bf16_t* W, const float* bias, void* out, int M, int N, int Kw, int ldo,
+                int epi, int lda, int split_out = 0) {
+    GemmArgs a{A, W, bias, out, M, N, 2 * Kw, lda, Kw, ldo};
+    a.kwrap = Kw / 64;
+    a.split_out = split_out;
+    if ((long)((M + 255) / 256) * ((N + 255) / 256) > 256) {
+        m->gemm_ws.ensure((size_t)64 << 20);
+        a.ws = m->gemm_ws.as<float>();
+        a.ws_bytes = m->gemm_ws.cap;
+    }
+    launch_gemm(a, epi, m->st);
+}
+// row stride of a [hi | lo] operand of width K: padded like XN_PAD (2 K bf16 is a power-of-two stride at K = 4096)
+inline int split_ld(int K) { return 2 * K + XN_PAD; }
+
 // Everything one decode step touches besides the weights: the buffers of a session's own loop or of the shared pool.
 struct LoopView {
     hipStream_t st;
@@ -597,6 +615,116 @@ void run_vit_and_adapters(vc_model* m, const PixSet& in, int pixels_on_device) {
             gemm(m, cur, pj.w[l], pj.b[l], dst, rows, D, K, D, last ? EPI_BF16 : EPI_BF16_GELU);
             cur = dst;
             K = D;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// SPLIT path (precision 2): the fast path's kernels and sequence of operations with every MFMA operand carried as bf16
+// hi + lo (x = hi + lo to ~16 mantissa bits; weights are exactly bf16): GEMMs contract the [hi | lo] rows against the weight
+// twice, attention uses three MFMAs per product, and everything between two MFMAs stays fp32.  Leaves the fp32 residual
+// stream of all N images in v_x [N*Tv, Dv].
+int run_vit_tower_split(vc_model* m, const PixSet& in, int pixels_on_device, int order[3], int first_img[3]) {
+    const vc_model_cfg& c = m->c;
+    const int Dv = c.vit_hidden, Fv = c.vit_ffn, H = c.vit_heads, Tv = m->Tv, P = m->P;
+    int nmod = 0, N = 0;
+    for (int k = 0; k < 3; ++k) {
+        first_img[k] = 0;
+        if (in.p[k] && in.n[k] > 0) {
+            order[nmod++] = k;
+            first_img[k] = N;
+            N += in.n[k];
+        }
+    }
+    REQUIRE(N > 0, VC_ERR_INVALID, "no images");
+    const size_t img_elems = (size_t)3 * c.vit_image * c.vit_image;
+    m->v_pixels.ensure((size_t)N * img_elems * 4);
+    for (int i = 0; i < nmod; ++i) {
+        const int k = order[i];
+        HIPCHK(hipMemcpyAsync(m->v_pixels.as<float>() + (size_t)first_img[k] * img_elems, in.p[k],
+                              (size_t)in.n[k] * img_elems * 4,
+                              pixels_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, m->st));
+    }
+    const int M = N * Tv, Mp = N * P;
+    const int Ts = (int)rup(Tv, 64);
+    const int ldx = split_ld(Dv), ldh = split_ld(Fv);
+    m->v_cols.ensure((size_t)Mp * 2 * m->Kpad * 2);
+    m->v_patches.ensure((size_t)Mp * Dv * 4);
+    m->v_x.ensure((size_t)M * Dv * 4);
+    m->v_xn.ensure((size_t)M * ldx * 2);
+    m->s_vqkv.ensure((size_t)M * 3 * Dv * 4);
+    const size_t plane = (size_t)N * H * Ts * m->vhd;   // one bf16 plane of Q / K / V^T
+    m->v_q.ensure(2 * plane * 2, true);
+    m->v_k.ensure(2 * plane * 2, true);
+    m->v_vt.ensure(2 * plane * 2, true);
+    m->v_attn.ensure((size_t)M * ldx * 2);
+    m->v_h.ensure((size_t)M * ldh * 2);
+    launch_im2col(m->v_pixels.as<float>(), m->v_cols.as<bf16_t>(), N, c.vit_image, c.vit_patch, m->Kpad, m->st, true);
+    gemm_split(m, m->v_cols.as<bf16_t>(), m->vit_patch_w, nullptr, m->v_patches.p, Mp, Dv, m->Kpad, Dv, EPI_F32, 2 * m->Kpad);
+    launch_vit_embed_ln(m->v_patches.as<float>(), m->vit_cls, m->vit_pos, m->vit_pre_w, m->vit_pre_b, m->v_x.as<float>(),
+                        N, Tv, Dv, c.vit_ln_eps, m->st);
+    bf16_t *qh = m->v_q.as<bf16_t>(), *kh = m->v_k.as<bf16_t>(), *vh = m->v_vt.as<bf16_t>();
+    for (int j = 0; j < c.vit_layers_used; ++j) {
+        const VitLayer& L = m->vit[j];
+        launch_layernorm_split(m->v_x.as<float>(), L.ln1_w, L.ln1_b, m->v_xn.as<bf16_t>(), M, Dv, c.vit_ln_eps, ldx, Dv, m->st);
+        gemm_split(m, m->v_xn.as<bf16_t>(), L.qkv_w, L.qkv_b, m->s_vqkv.p, M, 3 * Dv, Dv, 3 * Dv, EPI_F32, ldx);
+        QkvSplit32Args qa{m->s_vqkv.as<float>(), qh, qh + plane, kh, kh + plane, vh, vh + plane, nullptr, nullptr,
+                          N, Tv, H, m->vhd, Ts, Ts, Ts, 0, nullptr, nullptr};
+        launch_qkv_split32(qa, m->st);
+        AttnArgs aa{qh, kh, vh, m->v_attn.as<bf16_t>(), N, H, Tv, m->vhd, Ts, Ts, 0, 1.0f / sqrtf((float)m->vhd), 0,
+                    qh + plane, kh + plane, vh + plane, ldx, Dv};
+        launch_attention(aa, m->st);
+        gemm_split(m, m->v_attn.as<bf16_t>(), L.out_w, L.out_b, m->v_x.p, M, Dv, Dv, Dv, EPI_RESID_F32, ldx);
+        launch_layernorm_split(m->v_x.as<float>(), L.ln2_w, L.ln2_b, m->v_xn.as<bf16_t>(), M, Dv, c.vit_ln_eps, ldx, Dv, m->st);
+        gemm_split(m, m->v_xn.as<bf16_t>(), L.fc1_w, L.fc1_b, m->v_h.p, M, Fv, Dv, ldh, EPI_BF16_QGELU, ldx, Fv);
+        gemm_split(m, m->v_h.as<bf16_t>(), L.fc2_w, L.fc2_b, m->v_x.p, M, Dv, Fv, Dv, EPI_RESID_F32, ldh);
+    }
+    return N;
+}
+
+// feature_select + adapters of the split path: projected features fp32 in s_feats (what the fp32 splice reads)
+void run_vit_and_adapters_split(vc_model* m, const PixSet& in, int pixels_on_device) {
+    const vc_model_cfg& c = m->c;
+    const int Dv = c.vit_hidden, D = c.hidden;
+    int order[3], first_img[3];
+    const int N = run_vit_tower_split(m, in, pixels_on_device, order, first_img);
+    const int skip = c.vit_keep_cls ? 0 : 1;
+    const int R = m->Tv - skip;  // feature rows per image
+    const int ldv = 2 * Dv, ldd = split_ld(D);
+    m->v_sel.ensure((size_t)N * R * ldv * 2);
+    launch_select_rows_bf16(m->v_x.as<float>(), m->v_sel.as<bf16_t>(), N, m->Tv, skip, Dv, m->st, true);
+    m->s_feats.ensure((size_t)N * R * D * 4);
+    m->v_mid.ensure((size_t)N * R * ldd * 2);
+    for (int k = 0; k < 3; ++k) m->feat_rows[k] = 0;
+    for (int mod = 0; mod < 3; ++mod) {
+        if (!(in.p[mod] && in.n[mod] > 0)) continue;
+        const Projector& pj = mod == VC_MOD_IMAGE ? m->mm : m->seg;  // quirk 1: depth -> seg_mm_projector
+        const int rows = in.n[mod] * R;
+        float* out = m->s_feats.as<float>() + (size_t)first_img[mod] * R * D;
+        m->feat_off[mod] = first_img[mod] * R;
+        m->feat_rows[mod] = rows;
+        if (pj.depth == 0) {  // identity: the fp32 rows of hidden_states[select_layer]
+            REQUIRE(Dv == D, VC_ERR_INVALID, "identity projector needs mm_hidden_size == hidden_size");
+            m->s_sel.ensure((size_t)N * R * Dv * 4);
+            launch_select_rows_f32(m->v_x.as<float>(), m->s_sel.as<float>(), N, m->Tv, skip, Dv, m->st);
+            HIPCHK(hipMemcpyAsync(out, m->s_sel.as<float>() + (size_t)first_img[mod] * R * Dv, (size_t)rows * D * 4,
+                                  hipMemcpyDeviceToDevice, m->st));
+            continue;
+        }
+        const bf16_t* cur = m->v_sel.as<bf16_t>() + (size_t)first_img[mod] * R * ldv;
+        int K = Dv, lda = ldv;
+        for (int l = 0; l < pj.depth; ++l) {
+            const bool last = l == pj.depth - 1;
+            if (!last && l % 2 == 1) m->v_h.ensure((size_t)rows * ldd * 2);
+            if (last) {
+                gemm_split(m, cur, pj.w[l], pj.b[l], out, rows, D, K, D, EPI_F32, lda);
+            } else {
+                bf16_t* dst = l % 2 == 0 ? m->v_mid.as<bf16_t>() : m->v_h.as<bf16_t>();
+                gemm_split(m, cur, pj.w[l], pj.b[l], dst, rows, D, K, ldd, EPI_BF16_GELU, lda, D);
+                cur = dst;
+                K = D;
+                lda = ldd;
+            }
         }
     }
 }
@@ -1037,6 +1165,41 @@ void run_prefill_layers(vc_model* m, const KvTarget& kv, int B, int S) {
     }
 }
 
+// the decoder stack of a prefill in precision mode "split": fp32 keys / values go to `kv` (es == 4), the bf16 hi / lo
+// planes the flash kernel needs live in per-call scratch
+void run_prefill_layers_split(vc_model* m, const KvTarget& kv, int B, int S) {
+    const vc_model_cfg& c = m->c;
+    const int D = c.hidden, F = c.ffn, H = c.heads, M = B * S;
+    const int nl = m->layer_limit > 0 ? std::min(m->layer_limit, c.layers) : c.layers;
+    const int Sr = (int)rup(S, 64);
+    const int ldx = split_ld(D), ldh = split_ld(F);
+    REQUIRE(kv.es == 4, VC_ERR_STATE, "split mode needs an fp32 KV cache");
+    const size_t qplane = (size_t)B * H * S * m->hd, kplane = (size_t)B * H * Sr * m->hd;
+    m->xn.ensure((size_t)M * ldx * 2);
+    m->s_qkv.ensure((size_t)M * 3 * D * 4);
+    m->q.ensure(2 * qplane * 2, true);
+    m->vt_pre.ensure(4 * kplane * 2, true);   // K hi | K lo | V^T hi | V^T lo
+    m->attn.ensure((size_t)M * ldx * 2);
+    m->h.ensure((size_t)M * ldh * 2);
+    bf16_t *qh = m->q.as<bf16_t>(), *kh = m->vt_pre.as<bf16_t>(), *vh = kh + 2 * kplane;
+    for (int l = 0; l < nl; ++l) {
+        const LlmLayer& L = m->llm[l];
+        launch_rmsnorm_split(m->x.as<float>(), nullptr, L.in_norm, m->xn.as<bf16_t>(), M, D, c.rms_eps, ldx, D, m->st);
+        gemm_split(m, m->xn.as<bf16_t>(), L.qkv_w, nullptr, m->s_qkv.p, M, 3 * D, D, 3 * D, EPI_F32, ldx);
+        QkvSplit32Args qa{m->s_qkv.as<float>(), qh, qh + qplane, kh, kh + kplane, vh, vh + kplane,
+                          reinterpret_cast<float*>(kcache(m, kv, l)), reinterpret_cast<float*>(vcache(m, kv, l)),
+                          B, S, H, m->hd, S, Sr, Sr, kv.capS, m->rope_cos, m->rope_sin};
+        launch_qkv_split32(qa, m->st);
+        AttnArgs aa{qh, kh, vh, m->attn.as<bf16_t>(), B, H, S, m->hd, S, Sr, 1, 1.0f / sqrtf((float)m->hd), Sr,
+                    qh + qplane, kh + kplane, vh + kplane, ldx, D};
+        launch_attention(aa, m->st);
+        gemm_split(m, m->attn.as<bf16_t>(), L.o_w, nullptr, m->x.p, M, D, D, D, EPI_RESID_F32, ldx);
+        launch_rmsnorm_split(m->x.as<float>(), nullptr, L.post_norm, m->xn.as<bf16_t>(), M, D, c.rms_eps, ldx, D, m->st);
+        gemm_split(m, m->xn.as<bf16_t>(), L.gu_w, nullptr, m->h.p, M, 2 * F, D, ldh, EPI_SWIGLU, ldx, F);
+        gemm_split(m, m->h.as<bf16_t>(), L.down_w, nullptr, m->x.p, M, D, F, D, EPI_RESID_F32, ldh);
+    }
+}
+
 // ---- one cached decode step over the first `nrows` rows of a loop (captured into a hipGraph): 5 launches per layer + 2.
 // x_dec (fp32 residual rows of the new tokens), their sum-of-squares partials and xg are prepared by the previous step's
 // select kernel (or by embed_tokens_ssq when the host supplies the tokens).  Positions, step counts and every
@@ -1058,6 +1221,7 @@ SelectArgs select_args(vc_model* m, const LoopView& v, const float* logits, int 
     a.V = m->c.vocab;
     a.nrows = nrows;
     a.advance = advance;
+    a.xg_G = v.split_G;
     return a;
 }
 
@@ -1065,7 +1229,7 @@ void enqueue_decode_step(vc_model* m, const LoopView& v, int nrows) {
     decode_linears(m, v, nrows, [&](int l) {
         AttnDecodeFusedArgs da{v.qkv_dec, kcache(v, m, l), vcache(v, m, l), v.attn_dec, nrows, m->c.heads, m->hd, v.capS,
                                v.rows + RS_POS, m->rope_cos, m->rope_sin, 1.0f / sqrtf((float)m->hd), RS_STRIDE,
-                               v.rows + RS_ACTIVE};
+                               v.rows + RS_ACTIVE, v.split_G ? 1 : 0, v.split_G};
         launch_attention_decode_fused(da, v.st);
     });
     launch_select_embed(select_args(m, v, v.logits, nrows, 3), v.st);                                        // K19/K20+K10
@@ -1185,7 +1349,8 @@ void do_prefill(vc_model* m, const int64_t* ids, int B, int T, const float* img,
     }
     for (auto& v : m->img_counts) v.clear();  // one-shot
     if (m->ev[0]) HIPCHK(hipEventRecord(m->ev[0], m->st));
-    if (m->precision) run_vit_and_adapters_strict(m, pix, on_dev);
+    if (m->precision == 1) run_vit_and_adapters_strict(m, pix, on_dev);
+    else if (m->precision == 2) run_vit_and_adapters_split(m, pix, on_dev);
     else run_vit_and_adapters(m, pix, on_dev);
     const int R = m->Tv - (c.vit_keep_cls ? 0 : 1);
     std::vector<bool> dz;
@@ -1236,9 +1401,11 @@ void do_prefill(vc_model* m, const int64_t* ids, int B, int T, const float* img,
             flat[((size_t)b * S + s) * 2 + 1] = r.src;
         }
     HIPCHK(hipMemcpyAsync(m->row_src.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, m->st));
-    if (m->precision) {
-        REQUIRE(own_kv, VC_ERR_STATE, "strict mode runs on the session's own decode loop");
-        ensure_strict(m, B, m->capS);
+    if (m->precision) {  // strict and split: the projected features are fp32
+        if (m->precision == 1) {
+            REQUIRE(own_kv, VC_ERR_STATE, "strict mode runs on the session's own decode loop");
+            ensure_strict(m, B, m->capS);
+        }
         launch_splice_f32(m->row_src.as<int>(), (int)(B * S), m->embed, m->s_feats.as<float>(), m->x.as<float>(), c.hidden,
                           m->st);
     } else {
@@ -1257,9 +1424,20 @@ void finish_prefill(vc_model* m, const KvTarget& kv, float* logits_all_host) {
     std::vector<int> idx(B);
     for (int b = 0; b < B; ++b) idx[b] = b * S + S - 1;
     HIPCHK(hipMemcpyAsync(m->last_idx.p, idx.data(), B * 4, hipMemcpyHostToDevice, m->st));
-    if (m->precision) {
+    if (m->precision == 1) {
         run_llm_layers_strict(m, m->x.as<float>(), B, S, nullptr);
         logits_strict(m, m->x.as<float>(), m->last_idx.as<int>(), B);
+    } else if (m->precision == 2) {
+        run_prefill_layers_split(m, kv, B, S);
+        // final norm of the last rows as one stacked hi / lo group of the split GEMV, then lm_head
+        const int G = B <= 8 ? 8 : 16;
+        m->xl.ensure((size_t)2 * 16 * D * 2, true);
+        launch_rmsnorm_split(m->x.as<float>(), m->last_idx.as<int>(), m->final_norm, m->xl.as<bf16_t>(), B, D, c.rms_eps, D,
+                             (size_t)G * D, m->st);
+        LoopView lv{};
+        lv.st = m->st;
+        lv.split_G = G;
+        gemv(m, lv, m->xl.as<bf16_t>(), m->lm_head_p, nullptr, m->logits.p, B, c.vocab, D, c.vocab, GEMV_F32);
     } else {
         run_prefill_layers(m, kv, B, S);
         launch_rmsnorm_rows(m->x.as<float>(), m->last_idx.as<int>(), m->final_norm, m->xl.as<bf16_t>(), B, D, c.rms_eps, m->st);
@@ -1270,10 +1448,15 @@ void finish_prefill(vc_model* m, const KvTarget& kv, float* logits_all_host) {
     if (logits_all_host) {  // lm_head over ALL S positions, as the reference's forward returns (:93)
         const size_t Mr = (size_t)B * S;
         m->logits_all.ensure(Mr * c.vocab * 4);
-        if (m->precision) {
+        if (m->precision == 1) {
             launch_rmsnorm_f32(m->x.as<float>(), nullptr, m->final_norm, m->s_xn.as<float>(), (int)Mr, D, c.rms_eps, m->st);
             gemm32(m, m->s_xn.as<float>(), m->lm_head, nullptr, m->logits_all.as<float>(), (int)Mr, c.vocab, D, D, D, c.vocab,
                    EPI_F32);
+        } else if (m->precision == 2) {
+            const int ldx = split_ld(D);
+            m->xn.ensure(Mr * ldx * 2);
+            launch_rmsnorm_split(m->x.as<float>(), nullptr, m->final_norm, m->xn.as<bf16_t>(), (int)Mr, D, c.rms_eps, ldx, D, m->st);
+            gemm_split(m, m->xn.as<bf16_t>(), m->lm_head, nullptr, m->logits_all.p, (int)Mr, c.vocab, D, c.vocab, EPI_F32, ldx);
         } else {
             launch_rmsnorm(m->x.as<float>(), m->final_norm, m->xn.as<bf16_t>(), (int)Mr, D, c.rms_eps, m->st);
             gemm(m, m->xn.as<bf16_t>(), m->lm_head, nullptr, m->logits_all.p, (int)Mr, c.vocab, D, c.vocab, EPI_F32);
@@ -1532,7 +1715,12 @@ VC_API int vc_model_synth_tensor(vc_model* m, const char* hf_key, const int64_t*
 /* 0: bf16 MFMA path (default, benchmarked); 1: strict fp32 path (fp32 activations + fp32 MFMA, ~1e-6 from the fp32 CPU
  * reference; slow).  Takes effect at the next prefill. */
 VC_API int vc_model_set_precision(vc_model* m, int mode) {
-    if (!m || (mode != 0 && mode != 1)) return VC_ERR_INVALID;
+    if (!m || mode < 0 || mode > 2) return VC_ERR_INVALID;
+    if (mode != m->precision) {  // the decode graph bakes the step's kernels and buffers in
+        (void)hipSetDevice(m->ctx->device);
+        (void)hipStreamSynchronize(m->st);
+        drop_graph(m);
+    }
     m->precision = mode;
     m->cur_pos = -1;
     return VC_OK;
@@ -1637,7 +1825,8 @@ VC_API int vc_encode(vc_model* m, int modality, const float* pixels, int pixels_
     PixSet pix{{nullptr, nullptr, nullptr}, {0, 0, 0}};
     pix.p[modality] = pixels;
     pix.n[modality] = B;
-    if (m->precision) run_vit_and_adapters_strict(m, pix, pixels_on_device);
+    if (m->precision == 1) run_vit_and_adapters_strict(m, pix, pixels_on_device);
+    else if (m->precision == 2) run_vit_and_adapters_split(m, pix, pixels_on_device);
     else run_vit_and_adapters(m, pix, pixels_on_device);
     if (out) {
         const size_t n = (size_t)m->feat_rows[modality] * m->c.hidden;
@@ -1668,8 +1857,13 @@ VC_API int vc_vision_tower_forward(vc_model* m, const float* pixels, int pixels_
     int order[3], first[3];
     const int R = m->Tv - (m->c.vit_keep_cls ? 0 : 1);
     const size_t n = (size_t)N * R * m->c.vit_hidden;
-    if (m->precision) {
+    if (m->precision == 1) {
         run_vit_tower_strict(m, pix, pixels_on_device, order, first);
+        HIPCHK(hipMemcpyAsync(out, m->s_sel.p, n * 4, hipMemcpyDeviceToHost, m->st));
+    } else if (m->precision == 2) {
+        run_vit_tower_split(m, pix, pixels_on_device, order, first);
+        m->s_sel.ensure(n * 4);
+        launch_select_rows_f32(m->v_x.as<float>(), m->s_sel.as<float>(), N, m->Tv, m->c.vit_keep_cls ? 0 : 1, m->c.vit_hidden, m->st);
         HIPCHK(hipMemcpyAsync(out, m->s_sel.p, n * 4, hipMemcpyDeviceToHost, m->st));
     } else {
         run_vit_tower(m, pix, pixels_on_device, order, first);
@@ -1764,9 +1958,9 @@ VC_API int vc_decode_step(vc_model* m, const int32_t* tok, float* logits, int32_
             REQUIRE(tok[b] >= 0 && tok[b] < m->c.vocab, VC_ERR_INDEX, "index out of range in self (token id %d)", tok[b]);
         HIPCHK(hipMemcpyAsync(m->next_tok.p, tok, B * 4, hipMemcpyHostToDevice, m->st));
         launch_embed_tokens_ssq(m->next_tok.as<int>(), m->embed, m->x_dec.as<float>(), m->ssq.as<float>(), m->llm[0].in_norm,
-                                m->xg_dec.as<bf16_t>(), B, m->c.hidden, m->npart, m->st);
+                                m->xg_dec.as<bf16_t>(), B, m->c.hidden, m->npart, m->st, session_view(m).split_G);
     }
-    if (m->precision) {
+    if (m->precision == 1) {
         enqueue_decode_step_strict(m, B);
     } else {
         ensure_graph(m, B);
@@ -1872,6 +2066,7 @@ struct vc_pool {
     int device = 0;
     hipStream_t st = nullptr;
     int R = VC_POOL_ROWS, capS = 0, out_stride = 0;
+    bool split = false;               // built for precision mode "split": fp32 KV, stacked hi / lo step operands (G = 16)
     Buf kc, vc, rows, x_dec, xg_dec, qkv_dec, attn_dec, h_dec, logits, next_tok, out_ids, ssq, sk_scratch, sk_counters;
     hipGraphExec_t graph[VC_POOL_ROWS / 8] = {};    // one decode step over rows [0, 8 * (i + 1))
     std::mutex mu;
@@ -1894,6 +2089,8 @@ LoopView pool_view(vc_pool* p) {
     v.st = p->st;
     v.kc = p->kc.as<bf16_t>();
     v.vc = p->vc.as<bf16_t>();
+    v.es = p->split ? 4 : 2;
+    v.split_G = p->split ? 16 : 0;   // one layout whatever rows a step spans: a row keeps its slot between steps
     v.capR = p->R;
     v.capS = p->capS;
     v.rows = p->rows.as<int>();
@@ -2051,9 +2248,10 @@ vc_pool* pool_for(vc_model* m, int need_S, int need_out) {
     const vc_model_cfg& c = root->c;
     std::unique_lock<std::mutex> create(g_pool_create);
     vc_pool* p = root->pool;
+    const bool want_split = m->precision == 2;
     if (p) {
         std::unique_lock<std::mutex> lk(p->mu);
-        if (p->capS < need_S || p->out_stride < need_out || p->stop) {
+        if (p->capS < need_S || p->out_stride < need_out || p->stop || p->split != want_split) {
             p->cv_rows.wait(lk, [&] { return p->users == 0; });
             lk.unlock();
             pool_destroy(p);
@@ -2067,21 +2265,23 @@ vc_pool* pool_for(vc_model* m, int need_S, int need_out) {
     try {
         p->root = root;
         p->device = root->ctx->device;
+        p->split = want_split;
         const int D = c.hidden, F = c.ffn, H = c.heads, R = p->R;
+        const size_t es = want_split ? 4 : 2, two = want_split ? 2 : 1;
         p->capS = std::min((int)rup(std::max(need_S, 2048), 64), c.max_positions / 64 * 64);
         p->out_stride = std::max(need_out, p->capS);
         REQUIRE(p->capS >= need_S, VC_ERR_INVALID, "sequence %d exceeds max_position_embeddings=%d", need_S, c.max_positions);
         p->st = make_stream("VC_POOL_CU_RANGE");
         t_stream = p->st;  // zero-fills of the new buffers
-        const size_t kvb = (size_t)c.layers * R * H * p->capS * root->hd * 2;
+        const size_t kvb = (size_t)c.layers * R * H * p->capS * root->hd * es;
         p->kc.ensure(kvb, true);
         p->vc.ensure(kvb, true);
         p->rows.ensure((size_t)R * RS_STRIDE * 4, true);
         p->x_dec.ensure((size_t)R * D * 4, true);
-        p->xg_dec.ensure((size_t)R * D * 2, true);
-        p->qkv_dec.ensure((size_t)R * 3 * D * 2, true);
-        p->attn_dec.ensure((size_t)R * D * 2, true);
-        p->h_dec.ensure((size_t)R * F * 2, true);
+        p->xg_dec.ensure(two * R * D * 2, true);
+        p->qkv_dec.ensure((size_t)R * 3 * D * es, true);
+        p->attn_dec.ensure(two * R * D * 2, true);
+        p->h_dec.ensure(two * R * F * 2, true);
         p->logits.ensure((size_t)R * c.vocab * 4, true);
         p->next_tok.ensure(R * 4, true);
         p->out_ids.ensure((size_t)R * p->out_stride * 4, true);
@@ -2186,7 +2386,7 @@ void generate_on_pool(vc_model* m, const int64_t* ids, int B, int T, const float
         m->last_S = S;
         REQUIRE(S + max_new <= p->capS, VC_ERR_INVALID, "prompt %d + max_new %d exceeds the pool's KV capacity %d", S, max_new,
                 p->capS);
-        finish_prefill(m, KvTarget{p->kc.as<bf16_t>(), p->vc.as<bf16_t>(), p->R, p->capS, rq.row0}, nullptr);
+        finish_prefill(m, KvTarget{p->kc.as<bf16_t>(), p->vc.as<bf16_t>(), p->R, p->capS, rq.row0, p->split ? 4 : 2}, nullptr);
         if (m->ev[2]) HIPCHK(hipEventRecord(m->ev[2], m->st));
         HIPCHK(hipEventRecord(rq.prefill_done, m->st));
         DBG_HIP("finish_prefill");
@@ -2314,9 +2514,9 @@ void generate_on_session(vc_model* m, const int64_t* ids, int B, int T, const fl
     const int every = cb ? std::max(cb_every, 1) : 8;
     if (cb && every == 1) report(1);
     if (max_new > 1 && !all_finished()) {
-        if (!m->precision) ensure_graph(m, B);
+        if (m->precision != 1) ensure_graph(m, B);
         for (int step = 1; step < max_new; ++step) {
-            if (m->precision) enqueue_decode_step_strict(m, B);
+            if (m->precision == 1) enqueue_decode_step_strict(m, B);
             else HIPCHK(hipGraphLaunch(m->graph, m->st));
             m->cur_pos += 1;
             produced = step + 1;
@@ -2391,7 +2591,7 @@ VC_API int vc_generate(vc_model* m, const int64_t* ids, int B, int T, const floa
     // concurrent generate() calls share their decode steps in the root model's pool (VC_POOL=0: every call on its own
     // loop); strict mode keeps fp32 caches of its own
     static const bool use_pool = !(getenv("VC_POOL") && atoi(getenv("VC_POOL")) == 0);
-    if (use_pool && !m->precision)
+    if (use_pool && m->precision != 1)
         generate_on_pool(m, ids, B, T, img, seg, depth, pixels_on_device, g, tail, cb, cb_user, cb_every, out_ids, n_generated);
     else
         generate_on_session(m, ids, B, T, img, seg, depth, pixels_on_device, g, tail, cb, cb_user, cb_every, out_ids,
@@ -2542,6 +2742,7 @@ VC_API int vc_profile_decode_attention(vc_model* m, int B, int ctx, int reps, in
     GUARD_BEGIN
     USE_DEVICE(m->ctx);
     REQUIRE(m->finalized && B >= 1 && B <= VC_POOL_ROWS && reps >= 1 && ctx >= 64, VC_ERR_INVALID, "bad profile arguments");
+    REQUIRE(m->precision == 0, VC_ERR_STATE, "the profile hooks time the bf16 path's kernels");
     const vc_model_cfg& c = m->c;
     LoopView v;
     if (B <= VC_MAX_ROWS) {
@@ -2610,6 +2811,7 @@ VC_API int vc_profile_decode_gemv(vc_model* m, int B, int reps, int* launches, d
     GUARD_BEGIN
     USE_DEVICE(m->ctx);
     REQUIRE(m->finalized && B >= 1 && B <= VC_POOL_ROWS && reps >= 1, VC_ERR_INVALID, "bad profile arguments");
+    REQUIRE(m->precision == 0, VC_ERR_STATE, "the profile hooks time the bf16 path's kernels");
     const vc_model_cfg& c = m->c;
     const int D = c.hidden, F = c.ffn;
     LoopView v;

@@ -171,3 +171,52 @@ VCK_EXPORT void vck_qkv_rope_f32(const float* qkv, float* q, float* k, float* v,
     QkvF32Args a{qkv, q, k, v, B, T, H, hd, q_stride, kv_stride, pos0_dev, rope_cos, rope_sin};
     launch_qkv_rope_f32(a, S(stream));
 }
+
+// ---- precision mode "split" (DESIGN.md section 5b): every MFMA operand as bf16 hi + lo -------------------------------------
+VCK_EXPORT void vck_gemm_split(const uint16_t* A, const uint16_t* W, const float* bias, void* out, int M, int N, int Kw, int lda,
+                               int ldo, int epi, int split_out, float* ws, size_t ws_bytes, void* stream) {
+    GemmArgs a{A, W, bias, out, M, N, 2 * Kw, lda, Kw, ldo};
+    a.kwrap = Kw / 64;
+    a.split_out = split_out;
+    a.ws = ws;
+    a.ws_bytes = ws_bytes;
+    launch_gemm(a, epi, S(stream));
+}
+VCK_EXPORT void vck_gemv_split(const uint16_t* X, const void* Wp, const float* wscale, void* out, const float* ssq_in,
+                               float* ssq_out, const float* xg_w, uint16_t* xg_out, int npart, float eps, int M, int N, int K,
+                               int ldo, int epi, int G, void* stream) {
+    GemvArgs a{};
+    a.X = X; a.Wp = reinterpret_cast<const uint16_t*>(Wp); a.wscale = wscale; a.out = out; a.M = M; a.N = N; a.K = K; a.ldo = ldo;
+    a.ssq_in = ssq_in; a.ssq_out = ssq_out; a.xg_w = xg_w; a.xg_out = xg_out; a.npart = npart; a.eps = eps;
+    a.split_rows = G;
+    launch_gemv(a, epi, S(stream));
+}
+VCK_EXPORT void vck_rmsnorm_split(const float* x, const int* row_idx, const float* w, uint16_t* y, int rows, int D, float eps,
+                                  int ldy, uint64_t lo_off, void* stream) {
+    launch_rmsnorm_split(x, row_idx, w, y, rows, D, eps, ldy, (size_t)lo_off, S(stream));
+}
+VCK_EXPORT void vck_layernorm_split(const float* x, const float* w, const float* b, uint16_t* y, int rows, int D, float eps,
+                                    int ldy, uint64_t lo_off, void* stream) {
+    launch_layernorm_split(x, w, b, y, rows, D, eps, ldy, (size_t)lo_off, S(stream));
+}
+VCK_EXPORT void vck_qkv_split32(const float* qkv, uint16_t* q_hi, uint16_t* q_lo, uint16_t* k_hi, uint16_t* k_lo, uint16_t* vt_hi,
+                                uint16_t* vt_lo, float* k32, float* v32, int B, int T, int H, int hd, int q_stride, int ks_stride,
+                                int vt_stride, int kv_stride, const float* rope_cos, const float* rope_sin, void* stream) {
+    QkvSplit32Args a{qkv, q_hi, q_lo, k_hi, k_lo, vt_hi, vt_lo, k32, v32, B, T, H, hd, q_stride, ks_stride, vt_stride, kv_stride,
+                     rope_cos, rope_sin};
+    launch_qkv_split32(a, S(stream));
+}
+VCK_EXPORT void vck_attention_split(const uint16_t* q_hi, const uint16_t* q_lo, const uint16_t* k_hi, const uint16_t* k_lo,
+                                    const uint16_t* vt_hi, const uint16_t* vt_lo, uint16_t* out, int B, int H, int T, int hd,
+                                    int q_stride, int kv_stride, int causal, float scale, int ldo, int lo_off, void* stream) {
+    AttnArgs a{q_hi, k_hi, vt_hi, out, B, H, T, hd, q_stride, kv_stride, causal, scale, 0, q_lo, k_lo, vt_lo, ldo, lo_off};
+    launch_attention(a, S(stream));
+}
+VCK_EXPORT void vck_attention_decode_kv32(const float* qkv, float* k, float* v, uint16_t* out, int B, int H, int hd, int kv_stride,
+                                          const int* pos_rows, int pos_stride, const int* active_rows, const float* rope_cos,
+                                          const float* rope_sin, float scale, int G, void* stream) {
+    AttnDecodeFusedArgs a{reinterpret_cast<const uint16_t*>(qkv), reinterpret_cast<uint16_t*>(k), reinterpret_cast<uint16_t*>(v), out,
+                          B, H, hd, kv_stride, pos_rows, rope_cos, rope_sin, scale, pos_stride, active_rows, 1, G};
+    launch_attention_decode_fused(a, S(stream));
+}
+

@@ -135,9 +135,10 @@ class HipEngine:
                                                        C.c_float(hw)))
 
     def set_precision(self, mode: str):
-        """'bf16' (default: bf16 MFMA operands, what the benchmark runs) or 'strict' (fp32 activations on fp32 MFMA —
-        fp32-faithful to the reference's CPU path, slow)."""
-        self._check(self.lib.vc_model_set_precision(self._model, {"bf16": 0, "fast": 0, "strict": 1, "fp32": 1}[mode]))
+        """'bf16' (default: bf16 MFMA operands, what the benchmark runs); 'strict' (fp32 activations on fp32 MFMA —
+        fp32-faithful to the reference's CPU path, slow); 'split' (fp32 activations in HBM, every MFMA operand as bf16 hi + lo
+        fragments on the FAST kernels: the same 1e-3 / bit-exact-ids bar at about half the fast path's MFMA rate)."""
+        self._check(self.lib.vc_model_set_precision(self._model, {"bf16": 0, "fast": 0, "strict": 1, "fp32": 1, "split": 2}[mode]))
 
     def set_weight_format(self, fmt: str):
         """'bf16' (default); 'w8a16': decoder linears as e4m3 + per-row power-of-two scales, quantised at finalize and
