@@ -116,7 +116,8 @@ def top2_margin(lg):
     return s[..., -1] - s[..., -2]
 
 
-def run_case(model, oracle, cfg, name, ids_list, use_seg=True, use_depth=True, n_new=8, B=None, zero_depth=False):
+def run_case(model, oracle, cfg, name, ids_list, use_seg=True, use_depth=True, n_new=8, B=None, zero_depth=False,
+             cfg_overrides=None):
     B = len(ids_list)
     size = cfg.vit_image_size
     imgs, segs, deps = synth.synth_batch(B, size)
@@ -149,7 +150,8 @@ def run_case(model, oracle, cfg, name, ids_list, use_seg=True, use_depth=True, n
                         spliced_len=emb.shape[1], embeds_rowsum=emb.sum(-1).astype(np.float32),
                         embeds_sample=emb[:, ::7, ::16].astype(np.float32),
                         prefill_logits=full.astype(np.float32), greedy_ids=toks.astype(np.int64),
-                        step_logits=lg.astype(np.float32), top2_margin=top2_margin(lg).astype(np.float32))
+                        step_logits=lg.astype(np.float32), top2_margin=top2_margin(lg).astype(np.float32),
+                        cfg_overrides=json.dumps(cfg_overrides or {}))
 
 
 def run_list_case(model, oracle, cfg, name, ids_list, counts):
@@ -313,6 +315,37 @@ def main_round2():
     print("round-2 fixtures written to", GOLD)
 
 
+def main_round3():
+    """Fixtures added in round 3 (`python oracle/gen_golden.py --round3`): the other projector types of the plugin factories
+    (multimodal_projector/builder.py:33-51) through the live reference — 'linear' for <image>, 'mlp3x_gelu' for <seg> / <depth>;
+    and 'identity' (mm_hidden_size == hidden_size) for <image> with the usual mlp2x_gelu seg adapter."""
+    os.makedirs(GOLD, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    I, S, D = synth.IMAGE_TOKEN_INDEX, synth.SEG_TOKEN_INDEX, synth.DEPTH_TOKEN_INDEX
+    cases = [("ds_proj_linear_mlp3x", dict(mm_projector_type="linear", seg_mm_projector_type="mlp3x_gelu",
+                                           depth_mm_projector_type="mlp3x_gelu")),
+             ("ds_proj_identity", dict(mm_projector_type="identity", mm_hidden_size=256, seg_mm_hidden_size=256,
+                                       depth_mm_hidden_size=256, vit_num_heads=4))]
+    for name, ov in cases:
+        with tempfile.TemporaryDirectory() as tmp:
+            cfg = vcfg.tiny("vcoder_ds")
+            for k, v in ov.items():
+                setattr(cfg, k, v)
+            cfg.validate()
+            clip_dir = os.path.join(tmp, "clip")
+            make_clip_dir(cfg, clip_dir)
+            sd = synth.synth_state_dict(cfg, SEED)
+            model = build_reference_model(cfg, sd, clip_dir)
+            oracle = cpu_ref.OracleModel(cfg, sd)
+            V = cfg.vocab_size
+            p = lambda s_, ph: np.concatenate([[1], synth.synth_prompt_ids(V, "llava", 5, 4, s_)[1:6], ph,
+                                               synth.synth_prompt_ids(V, "llava", 5, 4, s_)[7:]]).astype(np.int64)
+            run_case(model, oracle, cfg, name, [p(0, [I, S, D]), p(1, [I, S, D])], cfg_overrides=ov)
+            del model
+    print("round-3 fixtures written to", GOLD)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
@@ -387,6 +420,9 @@ def main():
 if __name__ == "__main__":
     if "--round2" in sys.argv:
         main_round2()
+    elif "--round3" in sys.argv:
+        main_round3()
     else:
         main()
         main_round2()
+        main_round3()

@@ -27,6 +27,16 @@ def test_strict_mode_meets_north_star_bar(emu_lib, name):
     assert r["logits_err"] < 1e-4 and r["decode_logits_err"] < 1e-4
 
 
+def test_other_projector_types_fixture(emu_lib):
+    """'linear' <image> adapter + 'mlp3x_gelu' <seg> / <depth> adapter, fixture of the live reference (round 3): fast path
+    within the bf16 tolerance, strict and split modes within 1e-3 with bit-exact ids ('identity': under -m gpu)."""
+    r = e2e_cases.check_fixture("ds_proj_linear_mlp3x", lib=emu_lib, check_generate=True, check_emu_oracle=False)
+    assert r["ids_equal"]
+    for mode in ("strict", "split"):
+        r = e2e_cases.check_fixture_strict("ds_proj_linear_mlp3x", lib=emu_lib, mode=mode)
+        assert r["logits_err"] < 1e-4
+
+
 def test_device_preprocessing_matches_pil(emu_lib, tmp_path):
     import preprocess_cases as pc
 

@@ -10,7 +10,7 @@ from vcoder_amd.engine import HipEngine
 pytestmark = pytest.mark.gpu
 
 FIXTURES = ["ds_img_depth_seg", "ds_img_seg_depth", "ds_img_seg", "ds_img_only", "ds_zero_depth", "ds_img_text_seg",
-            "vc_img_seg", "vc_img_text_seg", "llava_img"]
+            "vc_img_seg", "vc_img_text_seg", "llava_img", "ds_proj_linear_mlp3x", "ds_proj_identity"]
 
 
 @pytest.mark.parametrize("name", FIXTURES)
@@ -298,6 +298,21 @@ def test_load_pretrained_model_from_hf_layout(tmp_path):
     assert np.array_equal(out[:, ids.shape[1]:].cpu().numpy(), g["greedy_ids"])
     with pytest.raises(RuntimeError):
         tok("hello")   # no tokenizer files in a synthetic checkpoint: the error surfaces lazily, not at load
+    # the plugin modules are LOADED modules after load_pretrained_model (vcoder_ds_llava_arch.py:34-49): standalone forward ==
+    # the oracle's projector, and == what vc_encode applies to the tower's features inside the model
+    import cpu_ref
+    sd_t = cpu_ref.as_torch_state(sd)
+    gm = model.get_model()
+    feats = t(model.engine.vision_tower_forward(imgs)).cuda()                 # CLIPVisionTower.forward output [B, 16, 128]
+    for name, mod_name in (("mm_projector", "img"), ("seg_mm_projector", "seg"), ("depth_mm_projector", None), ("mm2_projector", None)):
+        mod = getattr(gm, name)
+        assert mod.is_loaded(), name
+        got = mod(feats).float().cpu().numpy()
+        ref = cpu_ref.projector_forward(feats.float().cpu(), sd_t, f"model.{name}", mod.projector_type, emu_bf16=True).numpy()
+        assert np.abs(got - ref).max() < 2 ** -7 * max(1.0, np.abs(ref).max()), name
+        if mod_name == "img":
+            enc = model.engine.encode(imgs, "img")
+            assert np.abs(enc - got).max() < 2 ** -7 * max(1.0, np.abs(got).max()), "vc_encode != tower forward + mm_projector module"
     model.engine.close()
     # (a) tower embedded in the VCoder checkpoint; non-DS name dispatch
     cfg2 = vcfg.tiny("vcoder")
@@ -324,6 +339,33 @@ def test_load_pretrained_model_from_hf_layout(tmp_path):
     assert np.array_equal(out8[:, ids.shape[1]:].numpy(), ref8)
     model8.engine.close()
     eng8.close()
+
+
+def test_projector_types_standalone():
+    """build_vision_projector / build_seg_projector / build_depth_projector for every type string the reference accepts
+    (multimodal_projector/builder.py:33-51): 'linear', 'mlp2x_gelu', 'mlp3x_gelu', 'identity' — the module's device forward
+    against oracle/cpu_ref.projector_forward at the true adapter dims (1024 -> 4096)."""
+    import torch
+    import cpu_ref
+    from vcoder_amd.model import build_depth_projector, build_seg_projector, build_vision_projector
+
+    rng = np.random.RandomState(1)
+    for fn, ptype in ((build_vision_projector, "linear"), (build_seg_projector, "mlp2x_gelu"), (build_depth_projector, "mlp3x_gelu"),
+                      (build_vision_projector, "identity")):
+        c = vcfg.vicuna_7b("vcoder_ds")
+        c.mm_projector_type = c.seg_mm_projector_type = c.depth_mm_projector_type = ptype
+        if ptype == "identity":
+            c.mm_hidden_size = c.hidden_size
+        mod = fn(c)
+        sdp = {k: torch.from_numpy(synth.round_to_bf16((rng.randn(*mod.shape_of(k)) * 0.03).astype(np.float32))) for k in mod.keys()}
+        mod.load_state_dict(sdp)
+        x = torch.from_numpy(synth.round_to_bf16(rng.randn(2, 576, mod.in_features).astype(np.float32)))
+        got = mod(x.cuda()).float().cpu().numpy()
+        ref = cpu_ref.projector_forward(x, {"p." + k: v for k, v in sdp.items()}, "p", ptype, emu_bf16=True).numpy()
+        assert got.shape == ref.shape == (2, 576, c.hidden_size)
+        e = np.abs(got - ref).max() / max(1.0, np.abs(ref).max())
+        print(f"projector {ptype}: rel err {e:.2e}")
+        assert e < 2 ** -7, ptype
 
 
 def test_device_preprocessing_matches_pil(tmp_path):

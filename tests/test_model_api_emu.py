@@ -26,7 +26,7 @@ def model(tmp_path_factory):
     m = lm.VCoderDSLlavaLlamaForCausalLM(cfg2, device="cuda", _lib_override=lib)
     used = dead = 0
     for k, v in checkpoint.iter_checkpoint_tensors(d):   # what from_pretrained does
-        if m.engine.load_tensor(k, v):
+        if m._load_tensor(k, v):
             used += 1
         else:
             dead += 1
@@ -119,6 +119,44 @@ def test_projector_factories():
     cfg.mm_vision_tower = "nonexistent/tower"
     with pytest.raises(ValueError, match="Unknown vision tower"):
         build_vision_tower(cfg)
+
+
+def test_plugin_modules_hold_their_weights_and_run(model):
+    """get_model().mm_projector / seg_mm_projector / depth_mm_projector are LOADED modules after the checkpoint load (the
+    reference: nn.Modules filled by from_pretrained, vcoder_ds_llava_arch.py:34-49) and their standalone forward equals the
+    oracle's projector_forward — for the model's mlp2x_gelu modules and, built through the factories, for every other
+    projector type the reference accepts (multimodal_projector/builder.py:33-51)."""
+    import cpu_ref
+
+    lib = kc.EmuBackend().lib
+    cfg = model.config
+    sd = cpu_ref.as_torch_state(synth.synth_state_dict(cfg, 42))
+    gm = model.get_model()
+    rng = np.random.RandomState(0)
+    x = torch.from_numpy(synth.round_to_bf16(rng.randn(2, 5, cfg.mm_hidden_size).astype(np.float32)))
+    for name in ("mm_projector", "seg_mm_projector", "depth_mm_projector", "mm2_projector"):
+        mod = getattr(gm, name)
+        assert mod.is_loaded(), f"{name} has no weights after the checkpoint load"
+        for k, v in mod.state_dict().items():     # bf16 checkpoint values, exactly
+            assert np.array_equal(v, sd[f"model.{name}.{k}"].numpy()), (name, k)
+        got = mod(x, lib=lib).numpy()
+        ref = cpu_ref.projector_forward(x, sd, f"model.{name}", mod.projector_type, emu_bf16=True).numpy()
+        assert np.abs(got - ref).max() < 2 ** -7 * max(1.0, np.abs(ref).max()), name
+    # the other types, through the factories
+    for ptype in ("linear", "mlp3x_gelu", "identity"):
+        c2 = vcfg.tiny("vcoder_ds")
+        c2.mm_projector_type = ptype
+        if ptype == "identity":
+            c2.mm_hidden_size = c2.hidden_size
+        mod = build_vision_projector(c2)
+        sd2 = {k: torch.from_numpy(synth.round_to_bf16((rng.randn(*mod.shape_of(k)) * 0.05).astype(np.float32))) for k in mod.keys()}
+        mod.load_state_dict(sd2)
+        xin = torch.from_numpy(synth.round_to_bf16(rng.randn(3, 7, c2.mm_hidden_size).astype(np.float32)))
+        got = mod(xin, lib=lib).numpy()
+        ref = cpu_ref.projector_forward(xin, {"p." + k: v for k, v in sd2.items()}, "p", ptype, emu_bf16=True).numpy()
+        assert got.shape == ref.shape and np.abs(got - ref).max() < 2 ** -7 * max(1.0, np.abs(ref).max()), ptype
+    with pytest.raises(RuntimeError, match="has no weights"):
+        build_vision_projector(vcfg.tiny("vcoder_ds"))(x, lib=lib)
 
 
 def test_dropin_module_aliases():

@@ -138,8 +138,26 @@ class _HipCausalLMBase:
         return iter(())
 
     # ---- weights ----------------------------------------------------------------------------------------
+    _PLUGINS = ("mm_projector", "seg_mm_projector", "depth_mm_projector", "mm2_projector")
+
+    def _load_tensor(self, key: str, value) -> bool:
+        """one checkpoint tensor: into the engine's inference layout AND — for the adapter plugins — into the module object
+        get_model() hands out, so that `get_model().mm_projector` is a loaded, callable module as in the reference
+        (vcoder_ds_llava_arch.py:34-49; depth_mm_projector / mm2_projector are dead in forward but still state-dict
+        complete).  -> False when the engine ignores the key (dead at inference)."""
+        for name in self._PLUGINS:
+            pre = f"model.{name}."
+            if key.startswith(pre) and hasattr(self.model, name):
+                getattr(self.model, name).load_state_dict({key[len(pre):]: value}, strict=False)
+        return self.engine.load_tensor(key, value)
+
     def load_state_dict(self, sd, strict: bool = True):
-        used, dead = self.engine.load_state_dict(sd)
+        used = dead = 0
+        for k, v in sd.items():
+            if self._load_tensor(k, v):
+                used += 1
+            else:
+                dead += 1
         return SimpleNamespace(missing_keys=[], unexpected_keys=[], used=used, dead=dead)
 
     def finalize_weights(self):
@@ -164,7 +182,7 @@ class _HipCausalLMBase:
         saw_tower = False
         for k, v in checkpoint.iter_checkpoint_tensors(model_path):
             saw_tower |= "vision_tower" in k
-            model.engine.load_tensor(k, v)
+            model._load_tensor(k, v)
         if not saw_tower:
             model.get_vision_tower().load_model(engine=model.engine)
         if weight_format != "bf16":

@@ -69,27 +69,52 @@ class HipProjector:
     def state_dict(self):
         return dict(self._state)
 
-    def forward(self, x):
-        """x: torch CUDA tensor [..., in_features] -> [..., out_features] (bf16 MFMA GEMMs, fp32 accumulate)."""
+    def is_loaded(self) -> bool:
+        return all(k in self._state for k in self.keys())
+
+    def _device_weights(self, device):
+        """bf16 weights / fp32 biases on `device`, uploaded once per loaded state"""
+        import torch
+
+        stamp = (str(device), tuple(id(self._state[k]) for k in self.keys()))
+        if getattr(self, "_dev_stamp", None) != stamp:
+            self._dev = {k: torch.from_numpy(v).to(device, torch.bfloat16 if k.endswith("weight") else torch.float32).contiguous()
+                         for k, v in self._state.items()}
+            self._dev_stamp = stamp
+        return self._dev
+
+    def forward(self, x, lib=None):
+        """x: torch CUDA tensor [..., in_features] -> [..., out_features]: the module's own forward on the library's MFMA
+        GEMM (bf16 operands, fp32 accumulate, bias / erf-GELU epilogues) — the arithmetic vc_encode applies to the tower
+        features inside the model.  The K dimension is zero-padded to the GEMM's 64-element k-tile."""
         import torch
         from .. import _lib
 
         if self.depth == 0:
             return x
-        lib = _lib.load()
+        missing = [k for k in self.keys() if k not in self._state]
+        if missing:
+            raise RuntimeError(f"{self.role}_projector ({self.projector_type}) has no weights for {missing}: load a state dict "
+                               f"(load_pretrained_model / load_state_dict fill the plugin modules)")
+        lib = lib if lib is not None else _lib.load()
+        dev = self._device_weights(x.device)
         lead = x.shape[:-1]
         cur = x.reshape(-1, x.shape[-1]).to(torch.bfloat16).contiguous()
         M = cur.shape[0]
         for j in range(self.depth):
             wk, bk = ("weight", "bias") if self.depth == 1 else (f"{2 * j}.weight", f"{2 * j}.bias")
-            w = torch.from_numpy(self._state[wk]).to(x.device, torch.bfloat16).contiguous()
-            b = torch.from_numpy(self._state[bk]).to(x.device, torch.float32).contiguous()
+            w, b = dev[wk], dev[bk]
             N, K = w.shape
+            Kp = (K + 63) // 64 * 64
+            if Kp != K:
+                w = torch.nn.functional.pad(w, (0, Kp - K)).contiguous()
+                cur = torch.nn.functional.pad(cur, (0, Kp - K)).contiguous()
             out = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
             epi = 0 if j == self.depth - 1 else 2  # EPI_BF16 | EPI_BF16_GELU
             lib.vck_gemm(C.c_void_p(cur.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()),
-                         C.c_void_p(out.data_ptr()), M, N, K, K, K, N, epi, None)
-            torch.cuda.synchronize()
+                         C.c_void_p(out.data_ptr()), M, N, Kp, Kp, Kp, N, epi, None)
+            if x.is_cuda:
+                torch.cuda.synchronize()
             cur = out
         return cur.reshape(*lead, self.out_features).to(x.dtype)
 
