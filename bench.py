@@ -279,7 +279,7 @@ def extra_legs(args, eng7, cfg7, ids7, dev_px7, lone_ids7, fast_value, n_new):
     pm = {"bar": "logits within 1e-3 of the fp32 CPU reference, greedy ids bit-exact (tests: test_fixture_strict_mode, "
                  "test_fixture_split_mode, test_gpu_fulldepth)", "fast_path_value": fast_value}
     strict_ids = None
-    for mode, steps, inflight in (("strict", 1, 1), ("split", args.extra_steps, args.inflight)):
+    for mode, steps, inflight in (("strict", 1, 1), ("split", max(args.extra_steps, args.inflight), args.inflight)):
         try:
             eng7.set_precision(mode)
         except (KeyError, ValueError) as e:

@@ -341,6 +341,28 @@ def test_load_pretrained_model_from_hf_layout(tmp_path):
     eng8.close()
 
 
+def test_auto_model_for_causal_lm_reaches_this_backend(tmp_path):
+    """AutoModelForCausalLM.from_pretrained(<vcoder_ds_llava checkpoint>) after vcoder_amd.hf_register.register() — what the
+    reference's AutoConfig.register / AutoModelForCausalLM.register provide (vcoder_ds_llava_llama.py:144-145): the loaded model
+    is this backend's class and generates the reference fixture's ids."""
+    pytest.importorskip("transformers")
+    import torch
+    from transformers import AutoModelForCausalLM
+    from vcoder_amd import checkpoint, hf_register
+
+    hf_register.register()
+    cfg = vcfg.tiny("vcoder_ds")
+    d = str(tmp_path / "vcoder_ds_llava-v1.5-tiny")
+    checkpoint.save_checkpoint(d, cfg.to_hf_dict(), synth.synth_state_dict(cfg, 42))
+    model = AutoModelForCausalLM.from_pretrained(d)
+    assert type(model).__name__ == "VCoderDSLlavaLlamaForCausalLM" and model.get_model().mm_projector.is_loaded()
+    g, _, ids, imgs, segs, deps = e2e_cases.fixture_inputs("ds_img_depth_seg")
+    t = torch.from_numpy
+    out = model.generate(t(ids), images=t(imgs), segs=t(segs), depths=t(deps), do_sample=False, max_new_tokens=8, eos_token_id=-1)
+    assert np.array_equal(out[:, ids.shape[1]:].numpy(), g["greedy_ids"])
+    model.engine.close()
+
+
 def test_projector_types_standalone():
     """build_vision_projector / build_seg_projector / build_depth_projector for every type string the reference accepts
     (multimodal_projector/builder.py:33-51): 'linear', 'mlp2x_gelu', 'mlp3x_gelu', 'identity' — the module's device forward

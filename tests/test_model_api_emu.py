@@ -57,6 +57,29 @@ def test_forward_and_cached_decode(model):
     assert np.abs(out2.logits[:, 0].numpy() - g["step_logits"][:, 1]).max() < e2e_cases.TOL_VS_FP32_REF
 
 
+def test_text_only_forward_and_dead_inputs_embeds(model):
+    """images=None: the reference's prepare_inputs_labels_for_multimodal returns early (vcoder_ds_llava_arch.py:129-133) and
+    forward is a plain Llama pass over the text ids; a caller's inputs_embeds is overwritten there (vcoder_ds_llava_llama.py:79):
+    ignored next to input_ids, and without input_ids the call fails like LlamaModel does."""
+    import cpu_ref
+
+    cfg = model.config
+    rng = np.random.RandomState(4)
+    ids = rng.randint(3, cfg.vocab_size, size=(2, 11)).astype(np.int64)
+    out = model(input_ids=torch.from_numpy(ids), inputs_embeds=torch.zeros(2, 11, cfg.hidden_size))
+    sd = cpu_ref.as_torch_state(synth.synth_state_dict(cfg, 42))
+    x = torch.stack([cpu_ref.OracleModel(cfg, sd).embed_tokens(r.tolist()) for r in ids], 0)
+    ref = cpu_ref.llama_forward(x, sd, cfg, cpu_ref.KVCache(cfg.num_hidden_layers), False, False).numpy()
+    assert tuple(out.logits.shape) == ref.shape == (2, 11, cfg.vocab_size)
+    assert np.abs(out.logits.numpy() - ref).max() < e2e_cases.TOL_VS_FP32_REF
+    with pytest.raises(ValueError, match="exactly one of input_ids or inputs_embeds"):
+        model(inputs_embeds=torch.zeros(2, 11, cfg.hidden_size))
+    bad = ids.copy()
+    bad[1, 3] = -200   # a placeholder id without images reaches the embedding lookup
+    with pytest.raises(IndexError):
+        model(input_ids=torch.from_numpy(bad))
+
+
 def test_generate_variants(model):
     g, cfg, ids, imgs, segs, deps = _fx()
     t = torch.from_numpy
@@ -157,6 +180,37 @@ def test_plugin_modules_hold_their_weights_and_run(model):
         assert got.shape == ref.shape and np.abs(got - ref).max() < 2 ** -7 * max(1.0, np.abs(ref).max()), ptype
     with pytest.raises(RuntimeError, match="has no weights"):
         build_vision_projector(vcfg.tiny("vcoder_ds"))(x, lib=lib)
+
+
+def test_hf_auto_class_registration(tmp_path, monkeypatch):
+    """vcoder_amd.hf_register: the counterpart of the reference's AutoConfig.register / AutoModelForCausalLM.register
+    (vcoder_ds_llava_llama.py:144-145) — a checkpoint's model_type resolves to this backend's model class, whose
+    from_pretrained receives the HF config and converts it (the real load runs under -m gpu)."""
+    pytest.importorskip("transformers")
+    from transformers import AutoConfig, AutoModelForCausalLM
+    from vcoder_amd import hf_register
+
+    reg = hf_register.register()
+    assert {"vcoder_ds_llava", "vcoder_llava"} <= set(reg)
+    for variant, cls_name in (("vcoder_ds", "VCoderDSLlavaLlamaForCausalLM"), ("vcoder", "VCoderLlavaLlamaForCausalLM")):
+        cfg = vcfg.tiny(variant)
+        cfg.mm_projector_type = "linear"
+        d = str(tmp_path / f"{cfg.model_type}-tiny")
+        checkpoint.save_checkpoint(d, cfg.to_hf_dict(), dict(list(synth.synth_state_dict(cfg, 42).items())[:2]), bf16=True)
+        hf_cfg = AutoConfig.from_pretrained(d)
+        assert hf_cfg.model_type == cfg.model_type and hf_cfg.mm_projector_type == "linear"
+        assert AutoModelForCausalLM._model_mapping[type(hf_cfg)].__name__ == cls_name
+        seen = {}
+
+        def fake_from_pretrained(cls, model_path, *a, config=None, **k):
+            seen["cls"], seen["cfg"] = cls.__name__, vcfg.VCoderConfig.from_hf_dict(config.to_dict(), os.path.basename(model_path))
+            return "model"
+
+        monkeypatch.setattr(lm._HipCausalLMBase, "from_pretrained", classmethod(fake_from_pretrained))
+        assert AutoModelForCausalLM.from_pretrained(d) == "model"
+        back = seen["cfg"]
+        assert seen["cls"] == cls_name and back.variant == variant and back.mm_projector_type == "linear"
+        assert (back.hidden_size, back.vit_num_layers, back.mm_hidden_size, back.vit_image_size) == (256, 3, 128, 56)
 
 
 def test_dropin_module_aliases():

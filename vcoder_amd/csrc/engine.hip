@@ -1330,8 +1330,10 @@ void do_prefill(vc_model* m, const int64_t* ids, int B, int T, const float* img,
     REQUIRE(B >= 1 && T >= 1 && ids, VC_ERR_INVALID, "bad ids/B/T");
     REQUIRE(B <= VC_MAX_ROWS, VC_ERR_INVALID, "batch %d: at most %d sequences per prefill (larger batches run in pieces)", B,
             VC_MAX_ROWS);
-    REQUIRE(img, VC_ERR_INVALID, "images is required for a multimodal forward");
-    if (c.variant == VC_VARIANT_LLAVA) seg = depth = nullptr;
+    // images == NULL: the reference's prepare_inputs_labels_for_multimodal returns early (vcoder_ds_llava_arch.py:129-133) and
+    // the call is a plain LlamaForCausalLM forward over the text ids (every id must be a vocabulary id)
+    const bool text_only = img == nullptr;
+    if (text_only || c.variant == VC_VARIANT_LLAVA) seg = depth = nullptr;
     if (c.variant != VC_VARIANT_VCODER_DS) depth = nullptr;
     PixSet pix{{img, seg, depth}, {0, 0, 0}};
     for (int k = 0; k < 3; ++k) {
@@ -1349,7 +1351,11 @@ void do_prefill(vc_model* m, const int64_t* ids, int B, int T, const float* img,
     }
     for (auto& v : m->img_counts) v.clear();  // one-shot
     if (m->ev[0]) HIPCHK(hipEventRecord(m->ev[0], m->st));
-    if (m->precision == 1) run_vit_and_adapters_strict(m, pix, on_dev);
+    if (text_only) {
+        for (int k = 0; k < 3; ++k) m->feat_rows[k] = 0;
+        if (m->precision) m->s_feats.ensure(256);   // the fp32 splice takes a feature base pointer (no row refers to it)
+        else m->feats.ensure(256);
+    } else if (m->precision == 1) run_vit_and_adapters_strict(m, pix, on_dev);
     else if (m->precision == 2) run_vit_and_adapters_split(m, pix, on_dev);
     else run_vit_and_adapters(m, pix, on_dev);
     const int R = m->Tv - (c.vit_keep_cls ? 0 : 1);
@@ -1376,7 +1382,18 @@ void do_prefill(vc_model* m, const int64_t* ids, int B, int T, const float* img,
     }
     if (m->ev[1]) HIPCHK(hipEventRecord(m->ev[1], m->st));
     std::vector<std::vector<RowSrc>> rows;
-    plan_rows(m, ids, B, T, seg != nullptr, depth ? &dz : nullptr, R, rows);
+    if (text_only) {
+        rows.assign(B, {});
+        for (int b = 0; b < B; ++b)
+            for (int t = 0; t < T; ++t) {
+                const int64_t id = ids[(size_t)b * T + t];
+                REQUIRE(id >= 0 && id < c.vocab, VC_ERR_INDEX, "index out of range in self (id %lld reached the embedding lookup)",
+                        (long long)id);
+                rows[b].push_back({0, (int)id});
+            }
+    } else {
+        plan_rows(m, ids, B, T, seg != nullptr, depth ? &dz : nullptr, R, rows);
+    }
     size_t S = 0;
     bool unequal = false;
     for (auto& r : rows) {

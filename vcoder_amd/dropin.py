@@ -92,6 +92,15 @@ def install(reference_root: Optional[str] = None) -> types.ModuleType:
     for cls in ("LlavaLlamaForCausalLM", "VCoderLlavaLlamaForCausalLM", "VCoderDSLlavaLlamaForCausalLM"):
         setattr(pkg, cls, getattr(language_model, cls))
 
+    # the import side effect of the reference's model modules: AutoConfig / AutoModelForCausalLM know the VCoder model types
+    # (vcoder_ds_llava_llama.py:144-145).  Optional glue: skipped when Transformers is not installed.
+    try:
+        from . import hf_register
+
+        hf_register.register()
+    except ImportError:
+        pass
+
     # ---- pure-Python glue: the reference's own files when present, ours otherwise
     if ref is None:
         sys.modules["vcoder_llava.constants"] = constants

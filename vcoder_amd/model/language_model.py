@@ -177,6 +177,9 @@ class _HipCausalLMBase:
 
         from .. import checkpoint
 
+        if config is not None and not isinstance(config, VCoderConfig):
+            # an HF PretrainedConfig handed over by AutoModelForCausalLM.from_pretrained (vcoder_amd/hf_register.py)
+            config = VCoderConfig.from_hf_dict(config.to_dict(), os.path.basename(os.path.normpath(str(model_path))))
         cfg = config if config is not None else VCoderConfig.from_pretrained(model_path, os.path.basename(model_path))
         model = cls(cfg, device=device)
         saw_tower = False
@@ -198,8 +201,12 @@ class _HipCausalLMBase:
 
         if labels is not None:
             raise NotImplementedError("training loss is outside the inference hot path (SURVEY.md §8: train/* out of scope)")
-        if inputs_embeds is not None:
-            raise NotImplementedError("inputs_embeds entry is not used by any inference caller of the reference")
+        # The reference OVERWRITES a caller's inputs_embeds with what prepare_inputs_labels_for_multimodal returns
+        # (vcoder_ds_llava_llama.py:79: the spliced embeddings, or None) — the argument is dead; without input_ids the call
+        # then dies in LlamaModel ("You must specify exactly one of input_ids or inputs_embeds").  Same here.
+        if input_ids is None:
+            raise ValueError("You must specify exactly one of input_ids or inputs_embeds (the reference discards a caller's "
+                             "inputs_embeds: vcoder_ds_llava_llama.py:79)")
         if output_attentions or output_hidden_states:
             raise NotImplementedError("attention maps / hidden states are not materialised by the fused kernels")
         ids = input_ids
@@ -217,10 +224,10 @@ class _HipCausalLMBase:
         else:
             if past_key_values is not None:
                 raise NotImplementedError("multi-token continuation of a cached sequence is not on the reference's path")
-            if images is None:
-                raise ValueError("images is required (text-only forward is not part of the VCoder hot path)")
-            _, full, S = self.engine.prefill(ids, images, segs if self.variant != "llava" else None,
-                                             depths if self.variant == "vcoder_ds" else None,
+            # images None: prepare_inputs_labels_for_multimodal returns early (vcoder_ds_llava_arch.py:129-133) and the
+            # call is a plain Llama forward over the text ids
+            _, full, S = self.engine.prefill(ids, images, (segs if self.variant != "llava" else None) if images is not None else None,
+                                             (depths if self.variant == "vcoder_ds" else None) if images is not None else None,
                                              has_attention_mask=attention_mask is not None, all_logits=True,
                                              reserve=self._decode_reserve)
             self._generation += 1
