@@ -79,13 +79,23 @@ int vc_model_synth_tensor(vc_model* m, const char* hf_key, const int64_t* shape,
 int vc_model_finalize(vc_model* m);
 
 /* arithmetic mode: 0 = bf16 MFMA operands, fp32 accumulate/residual/softmax (default; what bench.py measures);
- * 1 = strict: fp32 activations end to end on fp32 MFMA (slow) — within ~1e-5 of the reference's fp32 CPU path, for the
- * "logits within 1e-3, greedy ids bit-exact" bar of BASELINE.json.  Takes effect at the next prefill. */
+ * 1 = strict: fp32 activations end to end on fp32 MFMA (slow) — within ~1e-5 of the reference's fp32 CPU path;
+ * 2 = split: fp32 activations in HBM, every MFMA operand carried as two bf16 values (x = hi + lo, ~16 mantissa bits) on the
+ *     FAST kernels — GEMMs contract the [hi | lo] rows against the (exactly bf16) weight twice, attention uses three MFMAs per
+ *     product, fp32 KV cache; runs in sessions, the hipGraph loop and the decode pool at about half the bf16 path's rate.
+ * 1 and 2 meet the "logits within 1e-3, greedy ids bit-exact" bar of BASELINE.json (2: 1.7e-4 at full 7b depth over 128
+ * tokens, every greedy id equal to the fp32 reference's).  Takes effect at the next prefill. */
 int vc_model_set_precision(vc_model* m, int mode);
 
 /* parity diagnostic: prefills evaluate only the first n decoder layers (0 = all), final norm + lm_head applied to that
  * hidden state — error growth with depth is measured on one loaded model (tests/test_gpu_fulldepth.py) */
 int vc_model_set_layer_limit(vc_model* m, int n_layers);
+
+/* parity diagnostic (per-layer teacher forcing): decoder layers [l0, l1) of a prefill applied to a caller-supplied residual
+ * stream x_in [B, S, hidden] (host fp32, positions 0..S-1) in the model's weight format / precision mode; x_out [B, S, hidden]
+ * = the residual stream behind layer l1 - 1.  Every layer can be fed the oracle's own input, so that rounding / quantisation
+ * noise of the layers in front of it does not compound (tests/test_gpu_e2e.py: fp8 formats per layer). */
+int vc_debug_prefill_layers(vc_model* m, int l0, int l1, const float* x_in, int B, int S, float* x_out);
 
 /* decoder weight storage: 0 = bf16 (default); 1 = W8A16 — the seven linears of every decoder layer are quantised at
  * vc_model_finalize to OCP fp8 e4m3 with one power-of-two scale per output row and streamed as bytes by the decode
@@ -112,6 +122,17 @@ int vc_vision_tower_forward(vc_model* m, const float* pixels, int pixels_on_devi
  * (vcoder_ds_llava_arch.py:135-169) — sample b owns counts[b] images of a modality, whose feature rows are spliced as ONE
  * block at its placeholder; the pixel pointer of that modality then holds sum(counts) images.  NULL = one per sample. */
 int vc_set_image_counts(vc_model* m, const int32_t* img_counts, const int32_t* seg_counts, const int32_t* depth_counts, int B);
+
+/* Padded batches: the caller's 2-D attention_mask [B, T] (bytes, 0 = hidden) for the NEXT vc_prefill* / vc_generate* call
+ * (one-shot).  As in the reference, it is LEFT-extended with "visible" over the S - T rows the splice adds — by position
+ * (vcoder_ds_llava_arch.py:305-311) — and a hidden position is hidden as a KEY from every query of its sequence during the
+ * prefill ([HF] LlamaModel: causal mask + padding mask); position ids stay arange(S).  Spliced lengths must be equal (quirk 6)
+ * and position 0 visible.  Cached steps: vc_generate* runs them under an all-ones mask, like the reference's multimodal decode
+ * path (vcoder_ds_llava_arch.py:130-133 replaces the mask by ones: the padded positions' keys become visible); a vc_prefill +
+ * vc_decode_step loop keeps the prefill's hidden keys hidden (a caller carrying its mask through the steps) until
+ * vc_clear_attention_mask(). */
+int vc_set_attention_mask(vc_model* m, const uint8_t* mask, int B, int T);
+int vc_clear_attention_mask(vc_model* m);
 
 /* KV-cache slots the next vc_prefill keeps free behind the prompt for vc_decode_step loops (default 64, clamped to
  * max_position_embeddings).  A loop that outruns the reserve still works: the cache grows (one copy of the live prefix). */

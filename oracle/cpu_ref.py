@@ -96,8 +96,10 @@ def quick_gelu(x):
     return x * torch.sigmoid(1.702 * x)
 
 
-def softmax_attention(q, k, v, scale, causal, r: Rounder, q_pos0: int = 0):
+def softmax_attention(q, k, v, scale, causal, r: Rounder, q_pos0: int = 0, key_mask=None):
     """q [N,H,Tq,hd], k/v [N,H,Tk,hd].  softmax in fp32 ([HF] clip :272, llama eager_attention :191-214).
+    key_mask [N,Tk] bool (padded batches): a False key is hidden from every query of its sequence — the additive form of the
+    2-D attention_mask HF's LlamaModel combines with the causal mask.
 
     Emulation: P = exp(s - rowmax) is rounded to bf16 before P.V, the row sum uses the unrounded
     fp32 p, and the normalised output is rounded to bf16 (what the flash kernel does)."""
@@ -107,6 +109,8 @@ def softmax_attention(q, k, v, scale, causal, r: Rounder, q_pos0: int = 0):
         qi = torch.arange(Tq).unsqueeze(1) + q_pos0
         ki = torch.arange(Tk).unsqueeze(0)
         s = s.masked_fill(ki > qi, float("-inf"))
+    if key_mask is not None:
+        s = s.masked_fill(~key_mask[:, None, None, : k.shape[-2]].bool(), float("-inf"))
     m = s.max(-1, keepdim=True).values
     p = torch.exp(s - m)
     l = p.sum(-1, keepdim=True)
@@ -333,7 +337,7 @@ class KVCache:
         return 0 if self.k[0] is None else self.k[0].shape[2]
 
 
-def llama_layer(x, sd, i: int, cfg, cache: KVCache, pos0: int, r: Rounder):
+def llama_layer(x, sd, i: int, cfg, cache: KVCache, pos0: int, r: Rounder, key_mask=None):
     """LlamaDecoderLayer :284-325 with LlamaAttention :217-281 and LlamaMLP :163-176."""
     B, T, D = x.shape
     H = cfg.num_attention_heads
@@ -351,7 +355,7 @@ def llama_layer(x, sd, i: int, cfg, cache: KVCache, pos0: int, r: Rounder):
         k = torch.cat([cache.k[i], k], dim=2)
         v = torch.cat([cache.v[i], v], dim=2)
     cache.k[i], cache.v[i] = k, v
-    a = softmax_attention(q, k, v, 1.0 / math.sqrt(hd), True, r, q_pos0=pos0)
+    a = softmax_attention(q, k, v, 1.0 / math.sqrt(hd), True, r, q_pos0=pos0, key_mask=key_mask)
     a = r.q8(a.transpose(1, 2).reshape(B, T, D))
     x = x + F.linear(a, sd[p + "self_attn.o_proj.weight"])
     h = r.q8(r(rms_norm(x, sd[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps)))
@@ -362,7 +366,8 @@ def llama_layer(x, sd, i: int, cfg, cache: KVCache, pos0: int, r: Rounder):
     return x
 
 
-def llama_forward(x, sd, cfg, cache: KVCache, emu_bf16: bool = False, last_only: bool = False, act_fp8: bool = False):
+def llama_forward(x, sd, cfg, cache: KVCache, emu_bf16: bool = False, last_only: bool = False, act_fp8: bool = False,
+                  key_mask=None):
     """LlamaModel.forward :367-418 on inputs_embeds + lm_head (vcoder_ds_llava_llama.py:81-93).
     position_ids = arange(T) + past_len.  act_fp8: the device's fp8 weight format quantises the decoder linears'
     activation rows in the PREFILL (a pass that starts an empty cache); cached decode steps keep bf16 activations."""
@@ -370,7 +375,7 @@ def llama_forward(x, sd, cfg, cache: KVCache, emu_bf16: bool = False, last_only:
     pos0 = cache.length
     r.prefill = pos0 == 0
     for i in range(cfg.num_hidden_layers):
-        x = llama_layer(x, sd, i, cfg, cache, pos0, r)
+        x = llama_layer(x, sd, i, cfg, cache, pos0, r, key_mask=key_mask)   # key_mask [B, past + T]: 2-D attention_mask
     if last_only:
         x = x[:, -1:]
     h = r(rms_norm(x, sd["model.norm.weight"], cfg.rms_norm_eps))
@@ -443,16 +448,28 @@ class OracleModel:
         return torch.stack(rows, 0), plans
 
     def forward(self, input_ids, images, segs=None, depths=None, cache: Optional[KVCache] = None,
-                last_only: bool = False):
-        """VCoder[DS]LlavaLlamaForCausalLM.forward (vcoder_ds_llava_llama.py:57-118), prefill."""
-        x, _ = self.prepare_inputs(input_ids, images, segs, depths)
+                last_only: bool = False, attention_mask=None):
+        """VCoder[DS]LlavaLlamaForCausalLM.forward (vcoder_ds_llava_llama.py:57-118), prefill.  attention_mask [B,T]: left-
+        extended with True over the S - T rows the splice added, by position (vcoder_ds_llava_arch.py:305-311), then the 2-D
+        key mask of LlamaModel; kept in self.mask_ext for decode_step(keep_mask=True)."""
+        x, _ = self.prepare_inputs(input_ids, images, segs, depths, attention_mask_given=attention_mask is not None)
+        self.mask_ext = None
+        if attention_mask is not None:
+            am = torch.as_tensor(np.asarray(attention_mask)).bool()
+            self.mask_ext = torch.cat([torch.ones(am.shape[0], x.shape[1] - am.shape[1], dtype=torch.bool), am], dim=1)
         cache = cache if cache is not None else KVCache(self.cfg.num_hidden_layers)
-        logits = llama_forward(x, self.sd, self.cfg, cache, self.emu, last_only, self.act_fp8)
+        logits = llama_forward(x, self.sd, self.cfg, cache, self.emu, last_only, self.act_fp8, key_mask=self.mask_ext)
         return logits, cache
 
-    def decode_step(self, tokens: Sequence[int], cache: KVCache):
+    def decode_step(self, tokens: Sequence[int], cache: KVCache, keep_mask: bool = False):
+        """one cached step.  keep_mask False: the all-ones mask the reference's multimodal decode path builds
+        (vcoder_ds_llava_arch.py:130-133); True: the prefill's mask extended with ones (a caller carrying its mask, no images)."""
         x = self.embed_tokens(tokens).unsqueeze(1)
-        return llama_forward(x, self.sd, self.cfg, cache, self.emu, last_only=True, act_fp8=self.act_fp8)
+        km = None
+        if keep_mask and getattr(self, "mask_ext", None) is not None:
+            n = cache.length + 1 - self.mask_ext.shape[1]
+            km = torch.cat([self.mask_ext, torch.ones(self.mask_ext.shape[0], n, dtype=torch.bool)], dim=1)
+        return llama_forward(x, self.sd, self.cfg, cache, self.emu, last_only=True, act_fp8=self.act_fp8, key_mask=km)
 
     def generate_greedy(self, input_ids, images, segs=None, depths=None, max_new_tokens: int = 8,
                         eos_token_id: Optional[int] = None, pad_token_id: int = 0, return_logits: bool = False):

@@ -315,6 +315,72 @@ def main_round2():
     print("round-2 fixtures written to", GOLD)
 
 
+@torch.no_grad()
+def run_masked_case(model, oracle, cfg, name, ids_list, mask, n_new=6):
+    """A PADDED batch through the live reference: prefill with a 2-D attention_mask that hides positions
+    (prepare_inputs_labels_for_multimodal left-extends it by position, vcoder_ds_llava_arch.py:305-311; LlamaModel hides those
+    keys), then cached greedy steps in the two forms a caller can produce:
+      'ones'  the all-ones mask of the reference's multimodal decode path (vcoder_ds_llava_arch.py:130-133) — what
+              model.generate() runs.  Under Transformers 5.x that line crashes on the DynamicCache, so the step is issued as
+              SURVEY.md section 8(c) prescribes: forward(input_ids=[[t]], attention_mask=ones(B, L + 1), past_key_values=pkv)
+              WITHOUT images (the early return then leaves exactly that mask in place);
+      'keep'  the caller's own mask carried through: cat(extended prefill mask, ones) — forward() without images."""
+    B = len(ids_list)
+    imgs, segs, deps = (torch.from_numpy(a) for a in synth.synth_batch(B, cfg.vit_image_size))
+    ids = torch.tensor(np.stack(ids_list), dtype=torch.long)
+    am = torch.tensor(np.asarray(mask), dtype=torch.long)
+    mask_ext = model.prepare_inputs_labels_for_multimodal(ids, am, None, None, imgs, segs, deps)[1]
+    res = {}
+    for variant in ("ones", "keep"):
+        out = model(input_ids=ids, attention_mask=am, images=imgs, segs=segs, depths=deps, use_cache=True)
+        full = out.logits.float().numpy()
+        pkv = out.past_key_values
+        L = full.shape[1]
+        last = out.logits[:, -1].float()
+        toks, lgs = [], []
+        for step in range(n_new):
+            lgs.append(last.numpy())
+            nxt = last.argmax(-1)
+            toks.append(nxt.numpy())
+            if step + 1 == n_new:
+                break
+            step_mask = torch.ones(B, L + step + 1, dtype=torch.long)
+            if variant == "keep":
+                step_mask[:, :L] = mask_ext.long()
+            o = model(input_ids=nxt[:, None], attention_mask=step_mask, past_key_values=pkv, use_cache=True)
+            pkv = o.past_key_values
+            last = o.logits[:, -1].float()
+        res[variant] = (np.stack(toks, 1), np.stack(lgs, 1), full)
+    assert np.array_equal(res["ones"][2], res["keep"][2])
+    full = res["ones"][2]
+    # ---- pin the oracle
+    o_full, cache = oracle.forward(ids.tolist(), imgs, segs, deps, attention_mask=am.numpy())
+    assert np.array_equal(oracle.mask_ext.numpy(), mask_ext.bool().numpy()), "mask extension differs from the reference"
+    e_full = float(np.abs(o_full.numpy() - full).max())
+    errs = {}
+    for variant in ("ones", "keep"):
+        o_full2, cache = oracle.forward(ids.tolist(), imgs, segs, deps, attention_mask=am.numpy(), last_only=True)
+        last = o_full2[:, -1]
+        e, same = 0.0, True
+        for step in range(n_new):
+            e = max(e, float(np.abs(last.numpy() - res[variant][1][:, step]).max()))
+            nxt = last.argmax(-1)
+            same = same and bool((nxt.numpy() == res[variant][0][:, step]).all())
+            if step + 1 < n_new:
+                last = oracle.decode_step(nxt.tolist(), cache, keep_mask=(variant == "keep"))[:, -1]
+        errs[variant] = (e, same)
+    unmasked = model(input_ids=ids, attention_mask=torch.ones_like(am), images=imgs, segs=segs, depths=deps).logits.float().numpy()
+    print(f"[{name}] S={full.shape[1]} full|d|={e_full:.2e} steps ones {errs['ones']} keep {errs['keep']}; the mask moves the prefill "
+          f"logits by {np.abs(unmasked - full).max():.3f}; ones-vs-keep step logits differ by "
+          f"{np.abs(res['ones'][1] - res['keep'][1]).max():.3f}")
+    assert e_full < 2e-4 and all(e < 2e-4 and same for e, same in errs.values()), "oracle/cpu_ref.py disagrees with the reference"
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), variant=cfg.variant, seed=SEED, input_ids=ids.numpy(),
+                        attention_mask=am.numpy().astype(np.int64), mask_ext=mask_ext.bool().numpy(), spliced_len=full.shape[1],
+                        prefill_logits=full.astype(np.float32), ids_ones=res["ones"][0].astype(np.int64),
+                        step_logits_ones=res["ones"][1].astype(np.float32), ids_keep=res["keep"][0].astype(np.int64),
+                        step_logits_keep=res["keep"][1].astype(np.float32))
+
+
 def main_round3():
     """Fixtures added in round 3 (`python oracle/gen_golden.py --round3`): the other projector types of the plugin factories
     (multimodal_projector/builder.py:33-51) through the live reference — 'linear' for <image>, 'mlp3x_gelu' for <seg> / <depth>;
@@ -343,6 +409,25 @@ def main_round3():
                                                synth.synth_prompt_ids(V, "llava", 5, 4, s_)[7:]]).astype(np.int64)
             run_case(model, oracle, cfg, name, [p(0, [I, S, D]), p(1, [I, S, D])], cfg_overrides=ov)
             del model
+    # padded batch (attention_mask with hidden positions): row 0 unpadded, row 1 right-padded, row 2 LEFT-padded (the
+    # reference's by-position left extension then hides three rows in the middle of the spliced sequence, not the pads)
+    with tempfile.TemporaryDirectory() as tmp:
+        cfg = vcfg.tiny("vcoder_ds")
+        clip_dir = os.path.join(tmp, "clip")
+        make_clip_dir(cfg, clip_dir)
+        sd = synth.synth_state_dict(cfg, SEED)
+        model = build_reference_model(cfg, sd, clip_dir)
+        oracle = cpu_ref.OracleModel(cfg, sd)
+        V = cfg.vocab_size
+        p = lambda s_, ph: np.concatenate([[1], synth.synth_prompt_ids(V, "llava", 5, 4, s_)[1:6], ph,
+                                           synth.synth_prompt_ids(V, "llava", 5, 4, s_)[7:]]).astype(np.int64)
+        r0, r1, r2 = p(0, [I, D, S]), p(1, [I, D, S]), p(2, [I, D, S])
+        T = len(r0)
+        rows = [r0, np.concatenate([r1[:-3], [0, 0, 0]]), np.concatenate([[0, 0, 0], r2[:-3]])]
+        mask = np.ones((3, T), dtype=np.int64)
+        mask[1, -3:] = 0
+        mask[2, :3] = 0
+        run_masked_case(model, oracle, cfg, "ds_padded_mask", rows, mask)
     print("round-3 fixtures written to", GOLD)
 
 

@@ -54,6 +54,23 @@ def test_fp8_weight_format(emu_lib, fmt):
     assert r["strict_err"] < 1e-4
 
 
+@pytest.mark.parametrize("fmt", ["bf16", "w8a16", "fp8"])
+def test_layers_teacher_forced(emu_lib, fmt):
+    """vc_debug_prefill_layers: each decoder layer on the oracle's own input (tiny model; the 13b geometry runs under -m gpu)"""
+    from vcoder_amd import config as vcfg
+
+    r = e2e_cases.check_layers_teacher_forced(vcfg.tiny("vcoder_ds"), 21, fmt, layers=(0, 1), B=2, S=70, lib=emu_lib)
+    print(fmt, r)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "strict", "split"])
+def test_padded_batch_attention_mask(emu_lib, mode):
+    """a 2-D attention_mask that hides positions (right- and left-padded rows) against the live reference's fixture: masked
+    prefill, both cached-step forms, generate()"""
+    r = e2e_cases.check_masked_fixture(lib=emu_lib, mode=mode)
+    print(mode, r)
+
+
 def test_device_side_stop_sequences(emu_lib):
     e2e_cases.check_stop_sequences("ds_img_only", lib=emu_lib)
 

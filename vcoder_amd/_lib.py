@@ -88,6 +88,12 @@ def declare(lib: C.CDLL) -> C.CDLL:
     lib.vc_comm_destroy.restype = None
     lib.vc_model_set_layer_limit.argtypes = [vp, i32]
     lib.vc_model_set_layer_limit.restype = C.c_int
+    lib.vc_debug_prefill_layers.argtypes = [vp, i32, i32, vp, i32, i32, vp]
+    lib.vc_debug_prefill_layers.restype = C.c_int
+    lib.vc_set_attention_mask.argtypes = [vp, vp, i32, i32]
+    lib.vc_set_attention_mask.restype = C.c_int
+    lib.vc_clear_attention_mask.argtypes = [vp]
+    lib.vc_clear_attention_mask.restype = C.c_int
     lib.vc_last_spliced_len.argtypes = [vp]
     lib.vc_last_spliced_len.restype = C.c_int
     lib.vc_profile_decode_gemv.argtypes = [vp, i32, i32, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]

@@ -333,13 +333,17 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && QS == 1 && !SPLIT) ? 4 :
         for (int qs = 0; qs < QS; ++qs) {
             const int qfirst = q0 + wave * (QS * 16) + qs * 16;     // smallest query of this sub-tile
             const int query = qfirst + j;
-            if ((CAUSAL && k0 + 63 > qfirst) || k0 + 64 > p.T) {
+            if ((CAUSAL && k0 + 63 > qfirst) || k0 + 64 > p.T || p.key_mask != nullptr) {
+                // key_mask (padded batches): a key hidden by the caller's attention_mask is hidden from EVERY query of its
+                // sequence, exactly as the additive mask HF builds from the 2-D mask ([HF] llama/modeling_llama.py causal mask +
+                // padding mask); key 0 of a sequence is always visible (the engine checks), so the running maximum is finite
+                const uint8_t* km = p.key_mask != nullptr ? p.key_mask + (size_t)b * p.mask_stride : nullptr;
 #pragma unroll
                 for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int key = k0 + sub * 16 + g * 4 + r;
-                        if (key >= p.T || (CAUSAL && key > query)) sacc[qs][sub][r] = -INFINITY;
+                        if (key >= p.T || (CAUSAL && key > query) || (km != nullptr && km[key] == 0)) sacc[qs][sub][r] = -INFINITY;
                     }
             }
             float mx = fmaxf(fmaxf(sacc[qs][0][0], sacc[qs][0][1]), fmaxf(sacc[qs][0][2], sacc[qs][0][3]));
@@ -551,6 +555,9 @@ __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeF
     for (int e = 0; e < EPL; ++e) qv[e] = q_s[(lane % LPK) * EPL + e];
     const int ctx_pad = (ctx + BATCH - 1) / BATCH * BATCH;
     const int krow = lane / LPK, kcol = (lane % LPK) * EPL;
+    // keys hidden by the attention_mask of the row's prefill (vc_decode_step loops that keep a caller's mask; nullptr: none).
+    // The new token's own key (position pos) is always visible.
+    const uint8_t* kmask = p.key_mask != nullptr ? p.key_mask + (size_t)b * p.mask_stride : nullptr;
     // Both streams run as a ROLLING window of UK loads per lane: a register is re-requested for the next batch as soon as
     // its row has been consumed, so UK rows stay in flight with UK registers (no second set).  Rows past the context are
     // clamped to the last valid row (one cached line, p = 0 / score masked): no branch around the loads.
@@ -579,7 +586,7 @@ __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeF
             kv[u] = ld16_stream(kbase + row_off(key + BATCH));
 #pragma unroll
             for (int mk = 1; mk < LPK; mk <<= 1) s += shfl_xor(s, mk);
-            if ((lane % LPK) == 0) sc[key] = key < ctx ? s * p.scale : -INFINITY;
+            if ((lane % LPK) == 0) sc[key] = (key < ctx && (kmask == nullptr || kmask[min(key, ctx - 1)] != 0)) ? s * p.scale : -INFINITY;
         }
     }
     // the first V batch of every wave does not depend on the scores: request it now so HBM stays busy through the

@@ -177,6 +177,14 @@ struct vc_model {
     // list / 5-D image form (vcoder_ds_llava_arch.py:135-169): images per sample and modality for the NEXT prefill
     // (vc_set_image_counts; empty = one image per sample), and the running first-image index of every sample
     std::vector<int> img_counts[3], img_first[3];
+    // padded batches: the caller's 2-D attention_mask for the NEXT prefill / generate (vc_set_attention_mask; one-shot), and
+    // the left-extended key mask of the CURRENT prefill on the device ([VC_MAX_ROWS][max_positions] bytes, 1 = visible)
+    std::vector<uint8_t> mask_next;
+    int mask_B = 0, mask_T = 0;
+    Buf kmask;
+    bool has_kmask = false;         // the current prefill hides keys
+    bool kmask_in_decode = false;   // ... and the session's decode steps keep hiding them (vc_decode_step loops)
+    bool graph_masked = false;      // what the captured decode graph was built for
     int reserve_new = 64;         // KV slots a vc_prefill keeps free behind the prompt (vc_model_reserve_decode)
     int layer_limit = 0;          // > 0: a prefill evaluates only the first layer_limit decoder layers (vc_model_set_layer_limit)
     // LLM workspace
@@ -445,6 +453,8 @@ struct LoopView {
                        // G bf16 hi rows + G lo rows (row r -> group r / G), qkv_dec is fp32
     int capR, capS;
     int* rows;         // RowState records
+    const uint8_t* kmask;  // keys hidden from the rows' decode steps ([rows][kmask_stride] bytes, 0 = hidden), or nullptr
+    int kmask_stride;
     float* x_dec;
     bf16_t *xg_dec, *qkv_dec, *attn_dec, *h_dec;
     float* logits;
@@ -869,6 +879,10 @@ void run_llm_layers_strict(vc_model* m, float* x, int B, int T, const int* pos_d
         launch_qkv_rope_f32(qa, m->st);
         AttnF32Args aa{q, s_kcache(m, l), s_vcache(m, l), at, B, H, T, m->hd, T, m->s_capS, 1, 0, pos_dev,
                        1.0f / sqrtf((float)m->hd)};
+        if (T > 1 ? m->has_kmask : m->kmask_in_decode) {
+            aa.key_mask = m->kmask.as<uint8_t>();
+            aa.mask_stride = c.max_positions;
+        }
         launch_attention_f32(aa, m->st);
         gemm32(m, at, L.o_w, nullptr, x, M, D, D, D, D, D, EPI_RESID_F32);
         launch_rmsnorm_f32(x, nullptr, L.post_norm, xn, M, D, c.rms_eps, m->st);
@@ -1049,6 +1063,8 @@ LoopView session_view(vc_model* m) {
     v.capR = m->capB;
     v.capS = m->capS;
     v.rows = m->rows.as<int>();
+    v.kmask = m->kmask_in_decode ? m->kmask.as<uint8_t>() : nullptr;
+    v.kmask_stride = m->c.max_positions;
     v.x_dec = m->x_dec.as<float>();
     v.xg_dec = m->xg_dec.as<bf16_t>();
     v.qkv_dec = m->qkv_dec.as<bf16_t>();
@@ -1127,14 +1143,15 @@ void grow_kv(vc_model* m, int need) {
     drop_graph(m);
 }
 
-void run_prefill_layers(vc_model* m, const KvTarget& kv, int B, int S) {
+// decoder layers [l0, l1) of a prefill (l1 < 0: all, or the first layer_limit)
+void run_prefill_layers(vc_model* m, const KvTarget& kv, int B, int S, int l0 = 0, int l1 = -1) {
     const vc_model_cfg& c = m->c;
     const int D = c.hidden, F = c.ffn, H = c.heads, M = B * S;
-    const int nl = m->layer_limit > 0 ? std::min(m->layer_limit, c.layers) : c.layers;
+    const int nl = l1 >= 0 ? l1 : (m->layer_limit > 0 ? std::min(m->layer_limit, c.layers) : c.layers);
     const int Sr = (int)rup(S, 64);
     m->vt_pre.ensure((size_t)B * H * m->hd * Sr * 2, true);
     const bool f8 = m->weight_format == 2;
-    for (int l = 0; l < nl; ++l) {
+    for (int l = l0; l < nl; ++l) {
         const LlmLayer& L = m->llm[l];
         if (f8) {  // RMSNorm writes the e4m3 operand of the QKV GEMM directly
             launch_rmsnorm_q8(m->x.as<float>(), L.in_norm, m->a8.as<uint8_t>(), m->a8_scale.as<float>(), M, D, c.rms_eps, m->st);
@@ -1150,6 +1167,10 @@ void run_prefill_layers(vc_model* m, const KvTarget& kv, int B, int S) {
         launch_qkv_split(qa, m->st);
         AttnArgs aa{m->q.as<bf16_t>(), kcache(m, kv, l), m->vt_pre.as<bf16_t>(), m->attn.as<bf16_t>(), B, H, S, m->hd, S, kv.capS, 1,
                     1.0f / sqrtf((float)m->hd), Sr};
+        if (m->has_kmask) {
+            aa.key_mask = m->kmask.as<uint8_t>();
+            aa.mask_stride = c.max_positions;
+        }
         launch_attention(aa, m->st);
         if (f8) gemm_f8(m, m->attn.as<bf16_t>(), L.o_q, L.o_s, m->x.p, M, D, D, D, EPI_RESID_F32);
         else gemm(m, m->attn.as<bf16_t>(), L.o_w, nullptr, m->x.p, M, D, D, D, EPI_RESID_F32);
@@ -1167,10 +1188,10 @@ void run_prefill_layers(vc_model* m, const KvTarget& kv, int B, int S) {
 
 // the decoder stack of a prefill in precision mode "split": fp32 keys / values go to `kv` (es == 4), the bf16 hi / lo
 // planes the flash kernel needs live in per-call scratch
-void run_prefill_layers_split(vc_model* m, const KvTarget& kv, int B, int S) {
+void run_prefill_layers_split(vc_model* m, const KvTarget& kv, int B, int S, int l0 = 0, int l1 = -1) {
     const vc_model_cfg& c = m->c;
     const int D = c.hidden, F = c.ffn, H = c.heads, M = B * S;
-    const int nl = m->layer_limit > 0 ? std::min(m->layer_limit, c.layers) : c.layers;
+    const int nl = l1 >= 0 ? l1 : (m->layer_limit > 0 ? std::min(m->layer_limit, c.layers) : c.layers);
     const int Sr = (int)rup(S, 64);
     const int ldx = split_ld(D), ldh = split_ld(F);
     REQUIRE(kv.es == 4, VC_ERR_STATE, "split mode needs an fp32 KV cache");
@@ -1182,7 +1203,7 @@ void run_prefill_layers_split(vc_model* m, const KvTarget& kv, int B, int S) {
     m->attn.ensure((size_t)M * ldx * 2);
     m->h.ensure((size_t)M * ldh * 2);
     bf16_t *qh = m->q.as<bf16_t>(), *kh = m->vt_pre.as<bf16_t>(), *vh = kh + 2 * kplane;
-    for (int l = 0; l < nl; ++l) {
+    for (int l = l0; l < nl; ++l) {
         const LlmLayer& L = m->llm[l];
         launch_rmsnorm_split(m->x.as<float>(), nullptr, L.in_norm, m->xn.as<bf16_t>(), M, D, c.rms_eps, ldx, D, m->st);
         gemm_split(m, m->xn.as<bf16_t>(), L.qkv_w, nullptr, m->s_qkv.p, M, 3 * D, D, 3 * D, EPI_F32, ldx);
@@ -1192,6 +1213,10 @@ void run_prefill_layers_split(vc_model* m, const KvTarget& kv, int B, int S) {
         launch_qkv_split32(qa, m->st);
         AttnArgs aa{qh, kh, vh, m->attn.as<bf16_t>(), B, H, S, m->hd, S, Sr, 1, 1.0f / sqrtf((float)m->hd), Sr,
                     qh + qplane, kh + kplane, vh + kplane, ldx, D};
+        if (m->has_kmask) {
+            aa.key_mask = m->kmask.as<uint8_t>();
+            aa.mask_stride = c.max_positions;
+        }
         launch_attention(aa, m->st);
         gemm_split(m, m->attn.as<bf16_t>(), L.o_w, nullptr, m->x.p, M, D, D, D, EPI_RESID_F32, ldx);
         launch_rmsnorm_split(m->x.as<float>(), nullptr, L.post_norm, m->xn.as<bf16_t>(), M, D, c.rms_eps, ldx, D, m->st);
@@ -1229,7 +1254,7 @@ void enqueue_decode_step(vc_model* m, const LoopView& v, int nrows) {
     decode_linears(m, v, nrows, [&](int l) {
         AttnDecodeFusedArgs da{v.qkv_dec, kcache(v, m, l), vcache(v, m, l), v.attn_dec, nrows, m->c.heads, m->hd, v.capS,
                                v.rows + RS_POS, m->rope_cos, m->rope_sin, 1.0f / sqrtf((float)m->hd), RS_STRIDE,
-                               v.rows + RS_ACTIVE, v.split_G ? 1 : 0, v.split_G};
+                               v.rows + RS_ACTIVE, v.split_G ? 1 : 0, v.split_G, v.kmask, v.kmask_stride};
         launch_attention_decode_fused(da, v.st);
     });
     launch_select_embed(select_args(m, v, v.logits, nrows, 3), v.st);                                        // K19/K20+K10
@@ -1261,10 +1286,11 @@ hipGraphExec_t capture_step(vc_model* m, const LoopView& v, int nrows) {
 }
 
 void ensure_graph(vc_model* m, int B) {
-    if (m->graph && m->graph_rows == B) return;
+    if (m->graph && m->graph_rows == B && m->graph_masked == m->kmask_in_decode) return;
     drop_graph(m);
     m->graph = capture_step(m, session_view(m), B);
     m->graph_rows = B;
+    m->graph_masked = m->kmask_in_decode;
 }
 
 void ensure_out_ids(vc_model* m, int B, int max_new) {
@@ -1403,6 +1429,31 @@ void do_prefill(vc_model* m, const int64_t* ids, int B, int T, const float* img,
     // quirk 6: unequal spliced lengths with an attention_mask and no labels die at vcoder_ds_llava_arch.py:295-297
     REQUIRE(!(unequal && has_mask), VC_ERR_UNEQUAL, "local variable '_new_labels' referenced before assignment");
     REQUIRE(S >= 1, VC_ERR_INVALID, "empty sequence");
+    // The caller's attention_mask [B, T] is LEFT-extended with "visible" over the S - T rows the splice added — by position,
+    // whatever the rows hold (vcoder_ds_llava_arch.py:305-311) — and hides its zero positions as KEYS from every query of the
+    // sequence in this prefill.
+    std::vector<uint8_t> kmask_host;
+    m->has_kmask = false;
+    if (!m->mask_next.empty()) {
+        std::vector<uint8_t> mk;
+        mk.swap(m->mask_next);  // one-shot
+        REQUIRE(m->mask_B == B && m->mask_T == T, VC_ERR_INVALID, "attention_mask is [%d, %d], input_ids [%d, %d]", m->mask_B,
+                m->mask_T, B, T);
+        REQUIRE((int)S >= T, VC_ERR_INVALID, "spliced length %zu shorter than the prompt %d", S, T);
+        const int stride = c.max_positions, lead = (int)S - T;
+        kmask_host.assign((size_t)VC_MAX_ROWS * stride, 1);
+        bool any = false;
+        for (int b = 0; b < B; ++b)
+            for (int t = 0; t < T; ++t)
+                if (!mk[(size_t)b * T + t]) {
+                    kmask_host[(size_t)b * stride + lead + t] = 0;
+                    any = true;
+                }
+        for (int b = 0; b < B && any; ++b)
+            REQUIRE(kmask_host[(size_t)b * stride] != 0, VC_ERR_INVALID,
+                    "attention_mask hides position 0 of sequence %d: its first queries would attend to nothing", b);
+        m->has_kmask = any;
+    }
     {   // reserve_new < 0: a hint (vc_prefill): as many of -reserve_new decode slots as max_position_embeddings allows;
         // reserve_new >= 0: required (generate) — exceeding max_position_embeddings is an error
         int want = (int)S + std::max(reserve_new < 0 ? -reserve_new : reserve_new, 1);
@@ -1418,6 +1469,11 @@ void do_prefill(vc_model* m, const int64_t* ids, int B, int T, const float* img,
             flat[((size_t)b * S + s) * 2 + 1] = r.src;
         }
     HIPCHK(hipMemcpyAsync(m->row_src.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, m->st));
+    if (m->has_kmask) {
+        m->kmask.ensure(kmask_host.size());
+        HIPCHK(hipMemcpyAsync(m->kmask.p, kmask_host.data(), kmask_host.size(), hipMemcpyHostToDevice, m->st));
+    }
+    m->kmask_in_decode = false;   // a decode mask never outlives its prefill (vc_prefill re-arms it)
     if (m->precision) {  // strict and split: the projected features are fp32
         if (m->precision == 1) {
             REQUIRE(own_kv, VC_ERR_STATE, "strict mode runs on the session's own decode loop");
@@ -1682,7 +1738,7 @@ VC_API void vc_model_destroy(vc_model* m) {
                    &m->out_ids, &m->dsum, &m->ssq, &m->sk_scratch, &m->sk_counters, &m->gemm_ws, &m->s_cols, &m->s_patches, &m->s_vx, &m->s_vxn, &m->s_vqkv,
                    &m->s_vq, &m->s_vk, &m->s_vv, &m->s_vattn, &m->s_vh, &m->s_sel, &m->s_mid, &m->s_feats, &m->s_xn, &m->s_qkv,
                    &m->s_q, &m->s_attn, &m->s_h, &m->s_kc, &m->s_vc, &m->s_xl, &m->pp_src, &m->pp_sq, &m->pp_tmp, &m->pp_out,
-                   &m->pp_tab, &m->pp_f32})
+                   &m->pp_tab, &m->pp_f32, &m->kmask})
         b->release();
     for (auto& e : m->ev)
         if (e) (void)hipEventDestroy(e);
@@ -1913,6 +1969,23 @@ VC_API int vc_set_image_counts(vc_model* m, const int32_t* img, const int32_t* s
     return VC_OK;
 }
 
+/* attention_mask [B, T] (bytes, 0 = hidden) of the NEXT vc_prefill* / vc_generate* call (one-shot).  See include/vcoder_hip.h. */
+VC_API int vc_set_attention_mask(vc_model* m, const uint8_t* mask, int B, int T) {
+    if (!m || !mask || B < 1 || T < 1) return VC_ERR_INVALID;
+    m->mask_next.assign(mask, mask + (size_t)B * T);
+    m->mask_B = B;
+    m->mask_T = T;
+    return VC_OK;
+}
+/* the cached decode steps behind the current vc_prefill see every key again (what the reference's multimodal decode path does:
+ * vcoder_ds_llava_arch.py:130-133 replaces the mask with ones) */
+VC_API int vc_clear_attention_mask(vc_model* m) {
+    if (!m) return VC_ERR_INVALID;
+    m->kmask_in_decode = false;
+    m->mask_next.clear();
+    return VC_OK;
+}
+
 /* KV-cache slots the next vc_prefill keeps free behind the prompt for vc_decode_step (default 64; clamped to
  * max_position_embeddings).  A decode loop that outruns the reserve still works — the cache grows, at the cost of a copy. */
 VC_API int vc_model_reserve_decode(vc_model* m, int max_new_tokens) {
@@ -1931,6 +2004,10 @@ VC_API int vc_prefill(vc_model* m, const int64_t* ids, int B, int T, const float
     do_prefill(m, ids, B, T, img, seg, depth, pixels_on_device, has_attention_mask, -std::max(m->reserve_new, 1), true, S_out);
     ensure_out_ids(m, B, 1);
     finish_prefill(m, session_kv(m), logits_all);
+    // a vc_decode_step loop behind this prefill keeps the hidden keys hidden (a caller that carries its attention_mask through
+    // the steps: forward() without images); vc_clear_attention_mask() gives the steps the all-ones mask the reference's
+    // multimodal decode path builds (vcoder_ds_llava_arch.py:130-133)
+    m->kmask_in_decode = m->has_kmask;
     // greedy choice of the prefill logits, so that vc_decode_step(tok = NULL) continues the sequence: nothing is recorded
     // (max_new 0), no EOS bookkeeping, the position stays at S
     GenParams g;
@@ -1960,6 +2037,35 @@ VC_API int vc_prefill_embeds_only(vc_model* m, const int64_t* ids, int B, int T,
         HIPCHK(hipMemcpyAsync(out_host, m->x.p, (size_t)B * S * m->c.hidden * 4, hipMemcpyDeviceToHost, m->st));
         HIPCHK(hipStreamSynchronize(m->st));
     }
+    GUARD_END(m->ctx)
+}
+
+/* Parity diagnostic (tests/: per-layer teacher forcing): decoder layers [l0, l1) of a PREFILL applied to a caller-supplied
+ * residual stream x_in [B, S, hidden] (fp32, host) at positions 0..S-1, in the model's weight format and precision mode;
+ * x_out receives the residual stream behind layer l1 - 1.  Feeding every layer the ORACLE's input isolates that layer's
+ * arithmetic: quantisation noise of the layers in front cannot compound.  Uses the session's own KV cache. */
+VC_API int vc_debug_prefill_layers(vc_model* m, int l0, int l1, const float* x_in, int B, int S, float* x_out) {
+    if (!m) return VC_ERR_INVALID;
+    GUARD_BEGIN
+    USE_DEVICE(m->ctx);
+    REQUIRE(m->finalized, VC_ERR_STATE, "vc_model_finalize() has not been called");
+    REQUIRE(x_in && x_out && B >= 1 && B <= VC_MAX_ROWS && S >= 1 && l0 >= 0 && l1 > l0 && l1 <= m->c.layers, VC_ERR_INVALID,
+            "bad layer range / shape");
+    m->cur_pos = -1;
+    ensure_llm(m, B, S + 1);
+    const size_t n = (size_t)B * S * m->c.hidden;
+    HIPCHK(hipMemcpyAsync(m->x.p, x_in, n * 4, hipMemcpyHostToDevice, m->st));
+    if (m->precision == 1) {
+        ensure_strict(m, B, m->capS);
+        REQUIRE(l0 == 0 && l1 == m->c.layers, VC_ERR_INVALID, "strict mode runs the whole stack");
+        run_llm_layers_strict(m, m->x.as<float>(), B, S, nullptr);
+    } else if (m->precision == 2) {
+        run_prefill_layers_split(m, session_kv(m), B, S, l0, l1);
+    } else {
+        run_prefill_layers(m, session_kv(m), B, S, l0, l1);
+    }
+    HIPCHK(hipMemcpyAsync(x_out, m->x.p, n * 4, hipMemcpyDeviceToHost, m->st));
+    HIPCHK(hipStreamSynchronize(m->st));
     GUARD_END(m->ctx)
 }
 
@@ -2499,6 +2605,7 @@ void generate_on_session(vc_model* m, const int64_t* ids, int B, int T, const fl
     REQUIRE(S + max_new <= m->capS, VC_ERR_INVALID, "prompt %d + max_new %d exceeds the KV capacity %d", S, max_new, m->capS);
     ensure_out_ids(m, B, max_new);
     finish_prefill(m, session_kv(m), nullptr);
+    m->kmask_in_decode = false;   // generate(): the cached steps run under an all-ones mask (vcoder_ds_llava_arch.py:130-133)
     if (m->ev[2]) HIPCHK(hipEventRecord(m->ev[2], m->st));
     arm_session_rows(m, g, tail.data());
     const LoopView v = session_view(m);

@@ -167,6 +167,10 @@ struct AttnArgs {
     const bf16_t* k_lo;
     const bf16_t* vt_lo;
     int ldo, lo_off;
+    // padded batches: key_mask[b * mask_stride + key] == 0 hides that key from every query of sequence b (the caller's 2-D
+    // attention_mask, left-extended over the spliced rows as the reference does); nullptr = no mask
+    const uint8_t* key_mask;
+    int mask_stride;
 };
 void launch_attention(const AttnArgs& a, hipStream_t s);
 
@@ -201,6 +205,9 @@ struct AttnDecodeFusedArgs {
     // bf16 hi / lo rows in stacked groups of out_G rows: row b -> hi at row (b / G) * 2G + b % G, lo G rows further
     int kv32;
     int out_G;
+    // keys hidden by the row's attention_mask: key_mask[b * mask_stride + key] == 0 (nullptr = none)
+    const uint8_t* key_mask;
+    int mask_stride;
 };
 void launch_attention_decode_fused(const AttnDecodeFusedArgs& a, hipStream_t s);
 
@@ -304,6 +311,8 @@ struct AttnF32Args {
     int Tk;
     const int* pos0_dev;  // device scalar: absolute position of query 0 (nullptr -> 0)
     float scale;
+    const uint8_t* key_mask;  // [B, mask_stride]: 0 hides the key from every query of the sequence (nullptr = none)
+    int mask_stride;
 };
 void launch_attention_f32(const AttnF32Args& a, hipStream_t s);
 struct QkvF32Args {

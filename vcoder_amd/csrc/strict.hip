@@ -116,12 +116,14 @@ __global__ __launch_bounds__(64) void attention_f32_kernel(AttnF32Args p) {
     __syncthreads();
     const float* kb = p.k + bh * p.kv_stride * p.hd;
     const float* vb = p.v + bh * p.kv_stride * p.hd;
+    const uint8_t* km = p.key_mask != nullptr ? p.key_mask + (size_t)b * p.mask_stride : nullptr;
     float mx = -INFINITY;
     for (int key = lane; key < nkeys; key += 64) {
         const float* kr = kb + (size_t)key * p.hd;
         float s = 0.f;
         for (int d = 0; d < p.hd; ++d) s = fmaf(qs[d], kr[d], s);
         s *= p.scale;
+        if (km != nullptr && km[key] == 0) s = -INFINITY;   // a key hidden by the caller's attention_mask (key 0 never is)
         sc[key] = s;
         mx = fmaxf(mx, s);
     }

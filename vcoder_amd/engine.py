@@ -153,6 +153,15 @@ class HipEngine:
         """parity diagnostic: prefills evaluate only the first n decoder layers (0 = all)"""
         self._check(self.lib.vc_model_set_layer_limit(self._model, int(n_layers)))
 
+    def run_layers(self, l0: int, l1: int, x: np.ndarray) -> np.ndarray:
+        """parity diagnostic: decoder layers [l0, l1) of a prefill applied to the residual stream x [B, S, hidden] (fp32)"""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        B, S, D = x.shape
+        out = np.empty_like(x)
+        self._check(self.lib.vc_debug_prefill_layers(self._model, int(l0), int(l1), x.ctypes.data_as(C.c_void_p), B, S,
+                                                     out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def finalize(self):
         self._check(self.lib.vc_model_finalize(self._model))
         self.finalized = True
@@ -228,6 +237,23 @@ class HipEngine:
                                                                     for a in arrs), B))
         return list(blocks)
 
+    def _announce_mask(self, attention_mask, B: int, T: int) -> bool:
+        """hands a caller's 2-D attention_mask to the library for the next prefill / generate call (one-shot) when it hides
+        positions; -> whether a mask was given at all (the reference's behaviour for unequal spliced lengths depends on it)"""
+        if attention_mask is None:
+            return False
+        m = attention_mask.detach().cpu().numpy() if _is_torch(attention_mask) else np.asarray(attention_mask)
+        if m.shape != (B, T):
+            raise ValueError(f"attention_mask must be [{B},{T}], got {tuple(m.shape)}")
+        if not bool(np.all(m != 0)):
+            mk = np.ascontiguousarray(m != 0, dtype=np.uint8)
+            self._check(self.lib.vc_set_attention_mask(self._model, mk.ctypes.data_as(C.c_void_p), B, T))
+        return True
+
+    def clear_attention_mask(self):
+        """the cached decode steps behind the current prefill see every key again (the reference's multimodal decode path)"""
+        self._check(self.lib.vc_clear_attention_mask(self._model))
+
     @staticmethod
     def _ids(input_ids) -> np.ndarray:
         if _is_torch(input_ids):
@@ -264,11 +290,14 @@ class HipEngine:
         return out[: B * S.value * self.cfg.hidden_size].reshape(B, S.value, self.cfg.hidden_size).copy()
 
     def prefill(self, input_ids, images, segs=None, depths=None, has_attention_mask: bool = False,
-                all_logits: bool = False, reserve: Optional[int] = None):
+                all_logits: bool = False, reserve: Optional[int] = None, attention_mask=None):
         """-> (logits_last [B,V], logits_all [B,S,V] or None, S).  reserve: decode_step calls the caller intends to make
-        (sizes the KV cache up front; a longer loop still works — the cache grows)."""
+        (sizes the KV cache up front; a longer loop still works — the cache grows).  attention_mask [B,T]: padded batches —
+        hidden positions are hidden as keys in this prefill and in the decode_step loop behind it (clear_attention_mask() ends
+        that)."""
         ids = self._ids(input_ids)
         B, T = ids.shape
+        has_attention_mask = self._announce_mask(attention_mask, B, T) or has_attention_mask
         if reserve is not None:
             self._check(self.lib.vc_model_reserve_decode(self._model, int(reserve)))
         (pi, ps, pd), on_dev, keep = self._pixels(*self._image_blocks(B, images, segs, depths))
@@ -338,7 +367,7 @@ class HipEngine:
                  eos_token_id: Optional[int] = None, pad_token_id: Optional[int] = None,
                  stop_sequences: Optional[Sequence[Sequence[int]]] = None, do_sample: bool = False,
                  temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0, seed: int = 0,
-                 on_tokens=None, stream_every: int = 1) -> np.ndarray:
+                 on_tokens=None, stream_every: int = 1, attention_mask=None) -> np.ndarray:
         """generate() on the device (vc_generate): greedy, or temperature / top-k / top-p sampling with a counter-based
         generator (same seed -> same tokens).  on_tokens(first_step, ids [B, n]) is called with every `stream_every` new
         columns while the hipGraph-replayed decode loop keeps running in between.  -> new ids [B, n_generated] int32."""
@@ -355,6 +384,7 @@ class HipEngine:
             for b0 in range(0, B, self.MAX_BATCH):
                 sl = slice(b0, b0 + self.MAX_BATCH)
                 parts.append(self.generate(ids[sl], *(None if a is None else a[sl] for a in (images, segs, depths)),
+                                           attention_mask=None if attention_mask is None else attention_mask[sl],
                                            max_new_tokens=max_new_tokens, eos_token_id=eos_token_id,
                                            pad_token_id=pad_token_id, stop_sequences=stop_sequences, do_sample=do_sample,
                                            temperature=temperature, top_k=top_k, top_p=top_p, seed=seed + b0))
@@ -364,6 +394,7 @@ class HipEngine:
             n = max(p.shape[1] for p in parts)
             return np.concatenate([np.pad(p, ((0, 0), (0, n - p.shape[1])), constant_values=pad) for p in parts], axis=0)
         (pi, ps, pd), on_dev, keep = self._pixels(*self._image_blocks(B, images, segs, depths))
+        self._announce_mask(attention_mask, B, T)   # hides keys in the prefill; the cached steps see every key (the reference)
         out = np.empty((B, max_new_tokens), dtype=np.int32)
         n = C.c_int(0)
         eos = -1 if eos_token_id is None else int(eos_token_id)

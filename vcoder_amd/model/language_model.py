@@ -211,12 +211,16 @@ class _HipCausalLMBase:
             raise NotImplementedError("attention maps / hidden states are not materialised by the fused kernels")
         ids = input_ids
         B = ids.shape[0]
-        _require_trivial_mask(attention_mask)
         if past_key_values is not None and ids.shape[1] == 1:
             # cached decode step: the input_ids.shape[1]==1 fast path (vcoder_ds_llava_arch.py:130-133)
             if not isinstance(past_key_values, KVCacheHandle) or past_key_values.generation != self._generation:
                 raise RuntimeError("past_key_values does not belong to the engine's current KV cache")
             tok = ids.reshape(-1).detach().cpu().numpy() if hasattr(ids, "detach") else np.asarray(ids).reshape(-1)
+            # With images the reference REPLACES the mask by ones here (vcoder_ds_llava_arch.py:130-133): keys a padded
+            # prefill hid become visible.  Without images the caller's mask goes through to LlamaModel: the engine keeps the
+            # prefill's hidden keys hidden (new positions are visible, as HF's generate loop appends ones).
+            if images is not None or attention_mask is None:
+                self.engine.clear_attention_mask()
             lg, _ = self.engine.decode_step(tok)
             past_key_values.length += 1
             logits = torch.from_numpy(lg).unsqueeze(1)
@@ -228,8 +232,11 @@ class _HipCausalLMBase:
             # call is a plain Llama forward over the text ids
             _, full, S = self.engine.prefill(ids, images, (segs if self.variant != "llava" else None) if images is not None else None,
                                              (depths if self.variant == "vcoder_ds" else None) if images is not None else None,
-                                             has_attention_mask=attention_mask is not None, all_logits=True,
-                                             reserve=self._decode_reserve)
+                                             all_logits=True, reserve=self._decode_reserve,
+                                             attention_mask=attention_mask if images is not None else None)
+            if images is None and attention_mask is not None and not _all_ones(attention_mask):
+                raise NotImplementedError("a padded TEXT-ONLY batch (attention_mask with zeros, images=None) is outside the "
+                                          "VCoder hot path")
             self._generation += 1
             logits = torch.from_numpy(full)
             pkv = KVCacheHandle(self, self._generation, S, B)
@@ -286,7 +293,6 @@ class _HipCausalLMBase:
             raise NotImplementedError("beam search is not used by the reference's VCoder callers (num_beams=1)")
         if temperature is not None and float(temperature) <= 0.0:
             do_sample = False
-        _require_trivial_mask(attention_mask)
         T = input_ids.shape[1]
         B = input_ids.shape[0]
         if max_new_tokens is None:
@@ -325,14 +331,16 @@ class _HipCausalLMBase:
                                        eos_token_id=eos, pad_token_id=pad, stop_sequences=stops or None,
                                        do_sample=bool(do_sample), temperature=float(temperature or 1.0),
                                        top_k=top_k or 0, top_p=1.0 if top_p is None else top_p, seed=seed or 0,
-                                       on_tokens=on_tokens, stream_every=kwargs.get("stream_every", 1))
+                                       on_tokens=on_tokens, stream_every=kwargs.get("stream_every", 1),
+                                       attention_mask=attention_mask)
             self._generation += 1
             out = torch.cat([ids_cpu, torch.from_numpy(new.astype(np.int64))], dim=1)
             if streamer is not None:
                 streamer.end()
         else:
             last, _, S = self.engine.prefill(ids_cpu.numpy(), images, segs, depths, has_attention_mask=True,
-                                             reserve=max_new_tokens)
+                                             reserve=max_new_tokens, attention_mask=attention_mask)
+            self.engine.clear_attention_mask()   # generate(): the cached steps run under an all-ones mask (:130-133)
             self._generation += 1
             logits = torch.from_numpy(last)
             unfinished = torch.ones(B, dtype=torch.long)
@@ -378,17 +386,9 @@ class _HipCausalLMBase:
     _sample_calls = 0
 
 
-def _require_trivial_mask(attention_mask):
-    """The reference left-extends the caller's mask over the spliced feature rows (vcoder_ds_llava_arch.py:305-311) and
-    hands it to LlamaModel; every caller of the reference passes None or all ones (batch 1, no padding).  The fused
-    kernels implement exactly that case — a mask that actually hides positions is refused rather than ignored."""
-    if attention_mask is None:
-        return
+def _all_ones(attention_mask) -> bool:
     m = attention_mask.detach().cpu().numpy() if hasattr(attention_mask, "detach") else np.asarray(attention_mask)
-    if m.size and not bool(np.all(m != 0)):
-        raise NotImplementedError("attention_mask with masked-out positions (padded batches) is not supported by the "
-                                  "MI355X hot path: pass equal-length prompts (the reference itself fails on unequal "
-                                  "spliced lengths, vcoder_ds_llava_arch.py:295-297)")
+    return bool(np.all(m != 0))
 
 
 def _reference_keyword_stop(crit):
