@@ -123,6 +123,12 @@ int vc_vision_tower_forward(vc_model* m, const float* pixels, int pixels_on_devi
  * block at its placeholder; the pixel pointer of that modality then holds sum(counts) images.  NULL = one per sample. */
 int vc_set_image_counts(vc_model* m, const int32_t* img_counts, const int32_t* seg_counts, const int32_t* depth_counts, int B);
 
+/* output_hidden_states for the NEXT vc_prefill (one-shot): out (host, cap_floats floats) receives [(layers + 1), B, S, hidden]
+ * fp32 — inputs_embeds, the residual stream behind every decoder layer, the last entry after the final RMSNorm: the tuple
+ * [HF] LlamaModel.forward returns as hidden_states (vcoder_ds_llava_llama.py:81-90,117).  out must stay valid until that
+ * vc_prefill returns; NULL cancels. */
+int vc_request_hidden_states(vc_model* m, float* out, size_t cap_floats);
+
 /* Padded batches: the caller's 2-D attention_mask [B, T] (bytes, 0 = hidden) for the NEXT vc_prefill* / vc_generate* call
  * (one-shot).  As in the reference, it is LEFT-extended with "visible" over the S - T rows the splice adds — by position
  * (vcoder_ds_llava_arch.py:305-311) — and a hidden position is hidden as a KEY from every query of its sequence during the

@@ -367,15 +367,21 @@ def llama_layer(x, sd, i: int, cfg, cache: KVCache, pos0: int, r: Rounder, key_m
 
 
 def llama_forward(x, sd, cfg, cache: KVCache, emu_bf16: bool = False, last_only: bool = False, act_fp8: bool = False,
-                  key_mask=None):
+                  key_mask=None, hidden_out: Optional[list] = None):
     """LlamaModel.forward :367-418 on inputs_embeds + lm_head (vcoder_ds_llava_llama.py:81-93).
     position_ids = arange(T) + past_len.  act_fp8: the device's fp8 weight format quantises the decoder linears'
     activation rows in the PREFILL (a pass that starts an empty cache); cached decode steps keep bf16 activations."""
     r = Rounder(emu_bf16, act_fp8)
     pos0 = cache.length
     r.prefill = pos0 == 0
+    # hidden_out (a list): receives LlamaModel's all_hidden_states ([HF] llama/modeling_llama.py: inputs_embeds, every layer's
+    # output, the last entry AFTER the final norm)
     for i in range(cfg.num_hidden_layers):
+        if hidden_out is not None:
+            hidden_out.append(x.clone())
         x = llama_layer(x, sd, i, cfg, cache, pos0, r, key_mask=key_mask)   # key_mask [B, past + T]: 2-D attention_mask
+    if hidden_out is not None:
+        hidden_out.append(rms_norm(x, sd["model.norm.weight"], cfg.rms_norm_eps))
     if last_only:
         x = x[:, -1:]
     h = r(rms_norm(x, sd["model.norm.weight"], cfg.rms_norm_eps))
@@ -448,7 +454,7 @@ class OracleModel:
         return torch.stack(rows, 0), plans
 
     def forward(self, input_ids, images, segs=None, depths=None, cache: Optional[KVCache] = None,
-                last_only: bool = False, attention_mask=None):
+                last_only: bool = False, attention_mask=None, hidden_out: Optional[list] = None):
         """VCoder[DS]LlavaLlamaForCausalLM.forward (vcoder_ds_llava_llama.py:57-118), prefill.  attention_mask [B,T]: left-
         extended with True over the S - T rows the splice added, by position (vcoder_ds_llava_arch.py:305-311), then the 2-D
         key mask of LlamaModel; kept in self.mask_ext for decode_step(keep_mask=True)."""
@@ -458,7 +464,8 @@ class OracleModel:
             am = torch.as_tensor(np.asarray(attention_mask)).bool()
             self.mask_ext = torch.cat([torch.ones(am.shape[0], x.shape[1] - am.shape[1], dtype=torch.bool), am], dim=1)
         cache = cache if cache is not None else KVCache(self.cfg.num_hidden_layers)
-        logits = llama_forward(x, self.sd, self.cfg, cache, self.emu, last_only, self.act_fp8, key_mask=self.mask_ext)
+        logits = llama_forward(x, self.sd, self.cfg, cache, self.emu, last_only, self.act_fp8, key_mask=self.mask_ext,
+                               hidden_out=hidden_out)
         return logits, cache
 
     def decode_step(self, tokens: Sequence[int], cache: KVCache, keep_mask: bool = False):

@@ -428,6 +428,21 @@ def main_round3():
         mask[1, -3:] = 0
         mask[2, :3] = 0
         run_masked_case(model, oracle, cfg, "ds_padded_mask", rows, mask)
+        # output_hidden_states of the prefill forward (vcoder_ds_llava_llama.py:81-90,117): LlamaModel's tuple of L + 1 tensors
+        ids = torch.tensor(np.stack([r0, r1]), dtype=torch.long)
+        imgs, segs, deps = (torch.from_numpy(a) for a in synth.synth_batch(2, cfg.vit_image_size))
+        with torch.no_grad():
+            out = model(input_ids=ids, images=imgs, segs=segs, depths=deps, output_hidden_states=True, use_cache=False)
+        hs = torch.stack([h.float() for h in out.hidden_states], 0).numpy()           # [L + 1, B, S, D]
+        assert hs.shape[0] == cfg.num_hidden_layers + 1
+        ho = []
+        oracle.forward(ids.tolist(), imgs, segs, deps, hidden_out=ho)
+        e = float(np.abs(torch.stack(ho, 0).numpy() - hs).max())
+        print(f"[ds_hidden_states] {hs.shape} oracle|d|={e:.2e} |h|max={np.abs(hs).max():.2f}")
+        assert e < 2e-5 * max(1.0, float(np.abs(hs).max()))
+        np.savez_compressed(os.path.join(GOLD, "ds_hidden_states.npz"), variant=cfg.variant, seed=SEED, input_ids=ids.numpy(),
+                            hidden_sample=hs[:, :, ::3, ::8].astype(np.float32), hidden_rowsum=hs.sum(-1).astype(np.float32),
+                            logits_last=out.logits[:, -1].float().numpy())
     print("round-3 fixtures written to", GOLD)
 
 

@@ -71,6 +71,11 @@ def test_padded_batch_attention_mask(emu_lib, mode):
     print(mode, r)
 
 
+@pytest.mark.parametrize("mode", ["bf16", "strict", "split"])
+def test_output_hidden_states(emu_lib, mode):
+    print(mode, e2e_cases.check_hidden_states(lib=emu_lib, mode=mode))
+
+
 def test_device_side_stop_sequences(emu_lib):
     e2e_cases.check_stop_sequences("ds_img_only", lib=emu_lib)
 

@@ -485,6 +485,12 @@ def test_padded_batch_attention_mask(mode):
     print(mode, e2e_cases.check_masked_fixture(mode=mode))
 
 
+@pytest.mark.parametrize("mode", ["bf16", "strict", "split"])
+def test_output_hidden_states(mode):
+    """forward(output_hidden_states=True): the L + 1 hidden states of the prefill vs the live reference's tuple"""
+    print(mode, e2e_cases.check_hidden_states(mode=mode))
+
+
 def test_padded_batch_true_dims():
     """the key mask at the true 7b head geometry (S = 1216, hd 128, 2 layers): a right-padded row against the fp32 oracle in
     split mode (1e-3) — ragged masked tiles in the flash kernel, the fp32-KV decode attention with hidden keys"""

@@ -80,6 +80,20 @@ def test_text_only_forward_and_dead_inputs_embeds(model):
         model(input_ids=torch.from_numpy(bad))
 
 
+def test_forward_output_hidden_states(model):
+    g = np.load(os.path.join(e2e_cases.GOLD, "ds_hidden_states.npz"))
+    ids = g["input_ids"]
+    imgs, segs, deps = synth.synth_batch(ids.shape[0], model.config.vit_image_size)
+    t = torch.from_numpy
+    out = model(input_ids=t(ids), images=t(imgs), segs=t(segs), depths=t(deps), output_hidden_states=True)
+    assert isinstance(out.hidden_states, tuple) and len(out.hidden_states) == model.config.num_hidden_layers + 1
+    hs = torch.stack(out.hidden_states, 0).numpy()
+    assert np.abs(hs[:, :, ::3, ::8] - g["hidden_sample"]).max() < 2.0 ** -6 * np.abs(g["hidden_sample"]).max()
+    assert model(input_ids=t(ids), images=t(imgs), segs=t(segs), depths=t(deps)).hidden_states is None
+    with pytest.raises(NotImplementedError):
+        model(input_ids=t(ids), images=t(imgs), segs=t(segs), depths=t(deps), output_attentions=True)
+
+
 def test_generate_variants(model):
     g, cfg, ids, imgs, segs, deps = _fx()
     t = torch.from_numpy

@@ -185,6 +185,10 @@ struct vc_model {
     bool has_kmask = false;         // the current prefill hides keys
     bool kmask_in_decode = false;   // ... and the session's decode steps keep hiding them (vc_decode_step loops)
     bool graph_masked = false;      // what the captured decode graph was built for
+    // output_hidden_states of the NEXT vc_prefill (vc_request_hidden_states; one-shot): host buffer [(L + 1), B, S, hidden]
+    float* hidden_out = nullptr;
+    size_t hidden_cap = 0;        // floats
+    Buf hidden_tmp;
     int reserve_new = 64;         // KV slots a vc_prefill keeps free behind the prompt (vc_model_reserve_decode)
     int layer_limit = 0;          // > 0: a prefill evaluates only the first layer_limit decoder layers (vc_model_set_layer_limit)
     // LLM workspace
@@ -396,6 +400,8 @@ int place_tensor(vc_model* m, const std::string& raw_key, const void* src, int d
     HIPCHK(hipStreamSynchronize(m->st));  // staging buffers are reused by the next call
     return VC_OK;
 }
+
+void emit_hidden(vc_model* m, int idx, int B, int S);  // output_hidden_states hook (defined with the prefill layers)
 
 // ------------------------------------------------------------------------------------------------
 // GEMM helpers
@@ -888,6 +894,7 @@ void run_llm_layers_strict(vc_model* m, float* x, int B, int T, const int* pos_d
         launch_rmsnorm_f32(x, nullptr, L.post_norm, xn, M, D, c.rms_eps, m->st);
         gemm32(m, xn, L.gu_w, nullptr, h, M, 2 * F, D, D, D, F, EPI_SWIGLU);
         gemm32(m, h, L.down_w, nullptr, x, M, D, F, F, F, D, EPI_RESID_F32);
+        if (T > 1 && x == m->x.as<float>()) emit_hidden(m, l + 1, B, T);
     }
 }
 
@@ -1143,6 +1150,24 @@ void grow_kv(vc_model* m, int need) {
     drop_graph(m);
 }
 
+// output_hidden_states ([HF] LlamaModel.forward: the tuple (inputs_embeds, layer 1 output, ..., layer L-1 output,
+// norm(layer L output))): entry `idx` of the caller's host buffer <- the fp32 residual stream (idx == layers: after the final
+// RMSNorm).  No-op unless requested for this prefill.
+void emit_hidden(vc_model* m, int idx, int B, int S) {
+    if (!m->hidden_out) return;
+    const vc_model_cfg& c = m->c;
+    const size_t n = (size_t)B * S * c.hidden;
+    REQUIRE((size_t)(idx + 1) * n <= m->hidden_cap, VC_ERR_INVALID, "hidden-state buffer too small: %zu floats for entry %d of %zu",
+            m->hidden_cap, idx, n);
+    const float* src = m->x.as<float>();
+    if (idx == c.layers) {
+        m->hidden_tmp.ensure(n * 4);
+        launch_rmsnorm_f32(m->x.as<float>(), nullptr, m->final_norm, m->hidden_tmp.as<float>(), B * S, c.hidden, c.rms_eps, m->st);
+        src = m->hidden_tmp.as<float>();
+    }
+    HIPCHK(hipMemcpyAsync(m->hidden_out + (size_t)idx * n, src, n * 4, hipMemcpyDeviceToHost, m->st));
+}
+
 // decoder layers [l0, l1) of a prefill (l1 < 0: all, or the first layer_limit)
 void run_prefill_layers(vc_model* m, const KvTarget& kv, int B, int S, int l0 = 0, int l1 = -1) {
     const vc_model_cfg& c = m->c;
@@ -1183,6 +1208,7 @@ void run_prefill_layers(vc_model* m, const KvTarget& kv, int B, int S, int l0 = 
             gemm(m, m->xn.as<bf16_t>(), L.gu_w, nullptr, m->h.p, M, 2 * F, D, F, EPI_SWIGLU, D + XN_PAD);
             gemm(m, m->h.as<bf16_t>(), L.down_w, nullptr, m->x.p, M, D, F, D, EPI_RESID_F32);
         }
+        emit_hidden(m, l + 1, B, S);
     }
 }
 
@@ -1222,6 +1248,7 @@ void run_prefill_layers_split(vc_model* m, const KvTarget& kv, int B, int S, int
         launch_rmsnorm_split(m->x.as<float>(), nullptr, L.post_norm, m->xn.as<bf16_t>(), M, D, c.rms_eps, ldx, D, m->st);
         gemm_split(m, m->xn.as<bf16_t>(), L.gu_w, nullptr, m->h.p, M, 2 * F, D, ldh, EPI_SWIGLU, ldx, F);
         gemm_split(m, m->h.as<bf16_t>(), L.down_w, nullptr, m->x.p, M, D, F, D, EPI_RESID_F32, ldh);
+        emit_hidden(m, l + 1, B, S);
     }
 }
 
@@ -1497,6 +1524,7 @@ void finish_prefill(vc_model* m, const KvTarget& kv, float* logits_all_host) {
     std::vector<int> idx(B);
     for (int b = 0; b < B; ++b) idx[b] = b * S + S - 1;
     HIPCHK(hipMemcpyAsync(m->last_idx.p, idx.data(), B * 4, hipMemcpyHostToDevice, m->st));
+    emit_hidden(m, 0, B, S);   // inputs_embeds
     if (m->precision == 1) {
         run_llm_layers_strict(m, m->x.as<float>(), B, S, nullptr);
         logits_strict(m, m->x.as<float>(), m->last_idx.as<int>(), B);
@@ -1537,6 +1565,7 @@ void finish_prefill(vc_model* m, const KvTarget& kv, float* logits_all_host) {
         HIPCHK(hipMemcpyAsync(logits_all_host, m->logits_all.p, Mr * c.vocab * 4, hipMemcpyDeviceToHost, m->st));
     }
     HIPCHK(hipStreamSynchronize(m->st));  // `idx` is host memory
+    m->hidden_out = nullptr;               // one-shot
 }
 
 // arm the session's own loop for the B rows just prefilled: every row at position S, step 0
@@ -1738,7 +1767,7 @@ VC_API void vc_model_destroy(vc_model* m) {
                    &m->out_ids, &m->dsum, &m->ssq, &m->sk_scratch, &m->sk_counters, &m->gemm_ws, &m->s_cols, &m->s_patches, &m->s_vx, &m->s_vxn, &m->s_vqkv,
                    &m->s_vq, &m->s_vk, &m->s_vv, &m->s_vattn, &m->s_vh, &m->s_sel, &m->s_mid, &m->s_feats, &m->s_xn, &m->s_qkv,
                    &m->s_q, &m->s_attn, &m->s_h, &m->s_kc, &m->s_vc, &m->s_xl, &m->pp_src, &m->pp_sq, &m->pp_tmp, &m->pp_out,
-                   &m->pp_tab, &m->pp_f32, &m->kmask})
+                   &m->pp_tab, &m->pp_f32, &m->kmask, &m->hidden_tmp})
         b->release();
     for (auto& e : m->ev)
         if (e) (void)hipEventDestroy(e);
@@ -1966,6 +1995,16 @@ VC_API int vc_set_image_counts(vc_model* m, const int32_t* img, const int32_t* s
             m->img_counts[k].push_back(src[k][b]);
         }
     }
+    return VC_OK;
+}
+
+/* output_hidden_states for the NEXT vc_prefill (one-shot): `out` (host, cap_floats floats) receives [(layers + 1), B, S, hidden]
+ * fp32 — inputs_embeds, the residual stream behind every decoder layer, the last one after the final RMSNorm
+ * ([HF] LlamaModel.forward all_hidden_states).  The buffer must stay valid until that vc_prefill returns. */
+VC_API int vc_request_hidden_states(vc_model* m, float* out, size_t cap_floats) {
+    if (!m) return VC_ERR_INVALID;
+    m->hidden_out = out;
+    m->hidden_cap = out ? cap_floats : 0;
     return VC_OK;
 }
 

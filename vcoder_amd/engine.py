@@ -290,7 +290,7 @@ class HipEngine:
         return out[: B * S.value * self.cfg.hidden_size].reshape(B, S.value, self.cfg.hidden_size).copy()
 
     def prefill(self, input_ids, images, segs=None, depths=None, has_attention_mask: bool = False,
-                all_logits: bool = False, reserve: Optional[int] = None, attention_mask=None):
+                all_logits: bool = False, reserve: Optional[int] = None, attention_mask=None, hidden_states: bool = False):
         """-> (logits_last [B,V], logits_all [B,S,V] or None, S).  reserve: decode_step calls the caller intends to make
         (sizes the KV cache up front; a longer loop still works — the cache grows).  attention_mask [B,T]: padded batches —
         hidden positions are hidden as keys in this prefill and in the decode_step loop behind it (clear_attention_mask() ends
@@ -304,11 +304,19 @@ class HipEngine:
         V = self.cfg.vocab_size
         last = np.empty((B, V), dtype=np.float32)
         S = C.c_int(0)
+        self.last_hidden_states = None
+        hid = None
+        if hidden_states:   # [(L + 1), B, S, D] for the worst-case S; trimmed below
+            rows_ = self.cfg.num_patches + (1 if self.cfg.mm_vision_select_feature == "cls_patch" else 0)
+            worst_ = T + rows_ * self._max_feature_blocks(ids)
+            hid = np.empty(((self.cfg.num_hidden_layers + 1) * B * worst_ * self.cfg.hidden_size,), dtype=np.float32)
+            self._check(self.lib.vc_request_hidden_states(self._model, hid.ctypes.data_as(C.c_void_p), C.c_size_t(hid.size)))
         if not all_logits:
             self._check(self.lib.vc_prefill(self._model, ids.ctypes.data_as(C.c_void_p), B, T, pi, ps, pd, on_dev,
                                             int(has_attention_mask), last.ctypes.data_as(C.c_void_p), None, C.byref(S)))
             self.last_S = S.value
             self._cur_batch = B
+            self._keep_hidden(hid, B, S.value)
             return last, None, S.value
         rows = self.cfg.num_patches + (1 if self.cfg.mm_vision_select_feature == "cls_patch" else 0)
         worst = T + rows * self._max_feature_blocks(ids)
@@ -318,7 +326,14 @@ class HipEngine:
                                         full.ctypes.data_as(C.c_void_p), C.byref(S)))
         self.last_S = S.value
         self._cur_batch = B
+        self._keep_hidden(hid, B, S.value)
         return last, full[: B * S.value * V].reshape(B, S.value, V).copy(), S.value
+
+    def _keep_hidden(self, hid, B, S):
+        """hidden states of the last prefill(hidden_states=True): [(L + 1), B, S, D] (the device packs them for the true S)"""
+        if hid is not None:
+            L1, D = self.cfg.num_hidden_layers + 1, self.cfg.hidden_size
+            self.last_hidden_states = hid[: L1 * B * S * D].reshape(L1, B, S, D).copy()
 
     _max_images_per_block = 1
 
@@ -354,6 +369,7 @@ class HipEngine:
         return lg, nxt
 
     _cur_batch = 0
+    last_hidden_states = None
 
     def generate_greedy(self, input_ids, images, segs=None, depths=None, max_new_tokens: int = 128,
                         eos_token_id: Optional[int] = None, pad_token_id: Optional[int] = None,

@@ -207,8 +207,8 @@ class _HipCausalLMBase:
         if input_ids is None:
             raise ValueError("You must specify exactly one of input_ids or inputs_embeds (the reference discards a caller's "
                              "inputs_embeds: vcoder_ds_llava_llama.py:79)")
-        if output_attentions or output_hidden_states:
-            raise NotImplementedError("attention maps / hidden states are not materialised by the fused kernels")
+        if output_attentions:
+            raise NotImplementedError("attention maps are not materialised by the flash kernels")
         ids = input_ids
         B = ids.shape[0]
         if past_key_values is not None and ids.shape[1] == 1:
@@ -219,6 +219,9 @@ class _HipCausalLMBase:
             # With images the reference REPLACES the mask by ones here (vcoder_ds_llava_arch.py:130-133): keys a padded
             # prefill hid become visible.  Without images the caller's mask goes through to LlamaModel: the engine keeps the
             # prefill's hidden keys hidden (new positions are visible, as HF's generate loop appends ones).
+            if output_hidden_states:
+                raise NotImplementedError("hidden states of a cached decode step are not materialised by the fused step kernels "
+                                          "(prefill forward() returns them)")
             if images is not None or attention_mask is None:
                 self.engine.clear_attention_mask()
             lg, _ = self.engine.decode_step(tok)
@@ -233,7 +236,8 @@ class _HipCausalLMBase:
             _, full, S = self.engine.prefill(ids, images, (segs if self.variant != "llava" else None) if images is not None else None,
                                              (depths if self.variant == "vcoder_ds" else None) if images is not None else None,
                                              all_logits=True, reserve=self._decode_reserve,
-                                             attention_mask=attention_mask if images is not None else None)
+                                             attention_mask=attention_mask if images is not None else None,
+                                             hidden_states=bool(output_hidden_states))
             if images is None and attention_mask is not None and not _all_ones(attention_mask):
                 raise NotImplementedError("a padded TEXT-ONLY batch (attention_mask with zeros, images=None) is outside the "
                                           "VCoder hot path")
@@ -242,7 +246,12 @@ class _HipCausalLMBase:
             pkv = KVCacheHandle(self, self._generation, S, B)
         if hasattr(ids, "device") and getattr(ids, "is_cuda", False):
             logits = logits.to(ids.device)
-        out = CausalLMOutputWithPast(loss=None, logits=logits, past_key_values=pkv if use_cache is not False else None)
+        hs = None
+        if output_hidden_states and self.engine.last_hidden_states is not None:
+            # the tuple LlamaModel.forward returns: inputs_embeds, every layer's output, the last one after the final norm
+            hs = tuple(torch.from_numpy(h) for h in self.engine.last_hidden_states)
+        out = CausalLMOutputWithPast(loss=None, logits=logits, past_key_values=pkv if use_cache is not False else None,
+                                     hidden_states=hs)
         if return_dict is False:
             return (out.logits,) + ((out.past_key_values,) if out.past_key_values is not None else ())
         return out
