@@ -537,13 +537,14 @@ def test_padded_batch_true_dims():
 def test_fp8_formats_per_layer_teacher_forced(fmt):
     """13b geometry (D 5120, F 13824, 40 heads; 3 layers), the C2 prompt length S = 1216, B = 2: every layer fed the ORACLE's
     own layer input (vc_debug_prefill_layers), output compared with the oracle's for that input — the quantisation noise of
-    the layers in front cannot compound, so the bound is tight: <= 2e-2 of max|x_out| and <= 6e-2 of the layer's own update
-    (BASELINE configs[4]'s arithmetic: e4m3 weights; 'fp8' adds e4m3 activation rows on the K=128 scaled MFMA)."""
+    the layers in front cannot compound, so the bound is tight: rms <= 2e-3 and max <= 2e-2 of max|x_out| (max <= 8e-2 with e4m3
+    activation rows: one row-scale flip re-rounds a whole row; see check_layers_teacher_forced).  BASELINE configs[4]'s
+    arithmetic: e4m3 weights; 'fp8' adds e4m3 activation rows on the K=128 scaled MFMA."""
     cfg = vcfg.vicuna_13b("vcoder_ds")
     cfg.num_hidden_layers = 3
     cfg.vit_num_layers = 2
     r = e2e_cases.check_layers_teacher_forced(cfg, 17, fmt, layers=(0, 1, 2), B=2)
-    print(fmt, "per-layer relative deviation (of |x_out|max, of |update|max):", {l: (f"{a:.2e}", f"{b:.2e}") for l, (a, b) in r.items()})
+    print(fmt, "per-layer deviation relative to |x_out|max (max, rms):", {l: (f"{a:.2e}", f"{b:.2e}") for l, (a, b) in r.items()})
 
 
 @pytest.mark.parametrize("name", ["ds_img_depth_seg", "vc_img_seg"])
