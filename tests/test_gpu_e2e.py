@@ -363,6 +363,35 @@ def test_auto_model_for_causal_lm_reaches_this_backend(tmp_path):
     model.engine.close()
 
 
+def test_load_pretrained_model_lora_and_projector_only(tmp_path):
+    """load_pretrained_model(model_path, model_base, name) on the reference's two overlay layouts (builder.py:42-92): a peft
+    LoRA checkpoint ('lora' in the name) merged into the base LLM, and a projector-only checkpoint; both are plain LLaVA
+    models; generate() ids equal the fp32 oracle's on the merged weights in split mode."""
+    import torch
+    import cpu_ref
+    from test_model_api_emu import _write_lora_family
+    from vcoder_amd.model import load_pretrained_model
+
+    cfg = vcfg.tiny("llava")
+    sd = synth.synth_state_dict(cfg, 42)
+    paths, merged = _write_lora_family(tmp_path, cfg, sd, np.random.RandomState(5))
+    g, _, ids, imgs, _, _ = e2e_cases.fixture_inputs("llava_img")
+    t = torch.from_numpy
+    for path, name, want in ((paths["lora"], "llava-v1.5-tiny-lora", merged), (paths["ponly"], "llava-v1.5-tiny-pretrain", sd)):
+        tok, model, ip, sip, dip, ctx = load_pretrained_model(path, paths["base"], name)
+        assert type(model).__name__ == "LlavaLlamaForCausalLM" and sip is None and dip is None
+        model.engine.set_precision("split")
+        out = model.generate(t(ids), images=t(imgs), do_sample=False, max_new_tokens=6, eos_token_id=-1)
+        ref, _ = cpu_ref.OracleModel(model.config, want).generate_greedy(ids.tolist(), t(imgs), max_new_tokens=6, return_logits=True)
+        assert np.array_equal(out[:, ids.shape[1]:].numpy(), ref.numpy()), name
+        model.engine.close()
+    with pytest.warns(UserWarning, match="no `model_base`"):
+        try:
+            load_pretrained_model(paths["lora"], None, "llava-v1.5-tiny-lora")   # the reference warns, then loads it as a full model
+        except FileNotFoundError:
+            pass                                                                  # ... which a LoRA directory is not
+
+
 def test_projector_types_standalone():
     """build_vision_projector / build_seg_projector / build_depth_projector for every type string the reference accepts
     (multimodal_projector/builder.py:33-51): 'linear', 'mlp2x_gelu', 'mlp3x_gelu', 'identity' — the module's device forward

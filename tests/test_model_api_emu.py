@@ -425,3 +425,82 @@ def test_loader_refuses_vcoder_it(tmp_path):
 
     with pytest.raises(NotImplementedError, match="vcoder_it"):
         load_pretrained_model(str(tmp_path), None, "vcoder_it_llava-v1.5-7b")
+
+
+def _write_lora_family(tmp_path, cfg, sd, rng):
+    """a base LLM directory, a CLIP directory, a peft-style LoRA checkpoint and a projector-only checkpoint built from the
+    synthetic llava checkpoint `sd`; -> (paths, merged state dict the loaders must reproduce)"""
+    import json
+    from safetensors.torch import save_file
+
+    t = torch.from_numpy
+    vt = "model.vision_tower.vision_tower."
+    clip_dir = str(tmp_path / "clip-tiny")
+    checkpoint.save_checkpoint(clip_dir, {"model_type": "clip_vision_model"}, {k[len(vt):]: v for k, v in sd.items() if k.startswith(vt)})
+    cfg.mm_vision_tower = clip_dir
+    base = str(tmp_path / "vicuna-tiny")
+    llm = {k: v for k, v in sd.items() if not k.startswith(vt) and "mm_projector" not in k}
+    checkpoint.save_checkpoint(base, {"model_type": "llama"}, llm)
+    proj = {k: v for k, v in sd.items() if "mm_projector" in k}
+    # --- LoRA checkpoint (peft layout)
+    lora = str(tmp_path / "llava-tiny-lora")
+    os.makedirs(lora)
+    with open(os.path.join(lora, "config.json"), "w") as f:
+        json.dump(cfg.to_hf_dict(), f)
+    r, alpha = 4, 8
+    with open(os.path.join(lora, "adapter_config.json"), "w") as f:
+        json.dump({"peft_type": "LORA", "r": r, "lora_alpha": alpha, "target_modules": ["q_proj", "v_proj", "down_proj"],
+                   "fan_in_fan_out": False}, f)
+    adapter, merged = {}, dict(sd)
+    for l in range(cfg.num_hidden_layers):
+        for mod in ("self_attn.q_proj", "self_attn.v_proj", "mlp.down_proj"):
+            key = f"model.layers.{l}.{mod}.weight"
+            out_f, in_f = sd[key].shape
+            A = synth.round_to_bf16((rng.randn(r, in_f) * 0.05).astype(np.float32))
+            Bm = synth.round_to_bf16((rng.randn(out_f, r) * 0.05).astype(np.float32))
+            adapter[f"base_model.model.model.layers.{l}.{mod}.lora_A.weight"] = t(A)
+            adapter[f"base_model.model.model.layers.{l}.{mod}.lora_B.weight"] = t(Bm)
+            merged[key] = synth.round_to_bf16(sd[key] + (alpha / r) * (Bm @ A))     # the loader rounds to bf16 once, like this
+    save_file(adapter, os.path.join(lora, "adapter_model.safetensors"))
+    torch.save({"base_model.model." + k: t(v) for k, v in proj.items()}, os.path.join(lora, "non_lora_trainables.bin"))
+    # --- projector-only checkpoint
+    ponly = str(tmp_path / "llava-tiny-pretrain")
+    os.makedirs(ponly)
+    with open(os.path.join(ponly, "config.json"), "w") as f:
+        json.dump(cfg.to_hf_dict(), f)
+    torch.save({k: t(v) for k, v in proj.items()}, os.path.join(ponly, "mm_projector.bin"))
+    return dict(base=base, lora=lora, ponly=ponly, clip=clip_dir), merged
+
+
+def test_lora_and_projector_only_checkpoints(tmp_path):
+    """builder.py:42-92: `model_base` + a LoRA checkpoint (adapter merged on the host: W + alpha / r * B A, what
+    PeftModel.merge_and_unload computes, plus non_lora_trainables.bin) and `model_base` + mm_projector.bin — both load as
+    LlavaLlamaForCausalLM; logits equal the oracle's on the merged / overlaid state dict."""
+    import cpu_ref
+
+    lib = kc.EmuBackend().lib
+    cfg = vcfg.tiny("llava")
+    sd = synth.synth_state_dict(cfg, 42)
+    rng = np.random.RandomState(5)
+    paths, merged = _write_lora_family(tmp_path, cfg, sd, rng)
+    g, _, ids, imgs, _, _ = e2e_cases.fixture_inputs("llava_img")
+    t = torch.from_numpy
+    for kind, it, want in (("lora", checkpoint.iter_lora_merged(paths["base"], paths["lora"]), merged),
+                           ("projector-only", checkpoint.iter_base_with_projector(paths["base"], paths["ponly"]), sd)):
+        c2 = vcfg.VCoderConfig.from_pretrained(paths["lora"] if kind == "lora" else paths["ponly"], "llava")
+        m = lm.LlavaLlamaForCausalLM.from_tensors(c2, it, _lib_override=lib)
+        assert m.get_model().mm_projector.is_loaded()
+        out = m(input_ids=t(ids), images=t(imgs))
+        om = cpu_ref.OracleModel(c2, want)
+        ref, _ = om.forward(ids.tolist(), t(imgs))
+        assert np.abs(out.logits.numpy() - ref.numpy()).max() < e2e_cases.TOL_VS_FP32_REF, kind
+        if kind == "lora":   # the adapter matters: the un-merged weights give other logits
+            ref0, _ = cpu_ref.OracleModel(c2, sd).forward(ids.tolist(), t(imgs))
+            assert np.abs(ref.numpy() - ref0.numpy()).max() > 5 * e2e_cases.TOL_VS_FP32_REF
+        m.engine.close()
+    # error paths of the overlay readers
+    pairs, scale, fifo = checkpoint.load_lora_adapter(paths["lora"])
+    assert scale == 2.0 and not fifo and len(pairs) == 3 * cfg.num_hidden_layers
+    os.remove(os.path.join(paths["lora"], "non_lora_trainables.bin"))
+    with pytest.raises(FileNotFoundError):
+        list(checkpoint.iter_lora_merged(paths["base"], paths["lora"]))

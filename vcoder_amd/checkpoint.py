@@ -50,3 +50,77 @@ def save_checkpoint(path: str, config_dict: dict, state: Dict[str, np.ndarray], 
     if bf16:
         tens = {k: v.to(torch.bfloat16) for k, v in tens.items()}
     save_file(tens, os.path.join(path, "model.safetensors"))
+
+
+# ---- the reference loader's overlay paths (vcoder_llava/model/builder.py:42-92) -----------------------------------------------
+def _torch_load(path):
+    import torch
+
+    return torch.load(path, map_location="cpu", weights_only=True)
+
+
+def _strip_peft_prefixes(sd: dict) -> dict:
+    """builder.py:66-68: drop a leading 'base_model.' and, if keys then start with 'model.model.', one 'model.'"""
+    sd = {(k[11:] if k.startswith("base_model.") else k): v for k, v in sd.items()}
+    if any(k.startswith("model.model.") for k in sd):
+        sd = {(k[6:] if k.startswith("model.") else k): v for k, v in sd.items()}
+    return sd
+
+
+def load_lora_adapter(path: str):
+    """adapter_config.json + adapter_model.{safetensors,bin} of a peft LoRA checkpoint ->
+    ({target state-dict key: (A [r, in], B [out, r])}, scale = lora_alpha / r, fan_in_fan_out)"""
+    with open(os.path.join(path, "adapter_config.json")) as f:
+        ac = json.load(f)
+    if ac.get("peft_type", "LORA") != "LORA":
+        raise ValueError(f"unsupported peft_type {ac.get('peft_type')}")
+    st = os.path.join(path, "adapter_model.safetensors")
+    if os.path.exists(st):
+        from safetensors import safe_open
+
+        with safe_open(st, framework="pt", device="cpu") as sf:
+            raw = {k: sf.get_tensor(k) for k in sf.keys()}
+    else:
+        raw = _torch_load(os.path.join(path, "adapter_model.bin"))
+    pairs = {}
+    for k, v in raw.items():
+        for tag, idx in ((".lora_A.", 0), (".lora_B.", 1)):
+            if tag in k:
+                base = k.split(tag)[0] + ".weight"                       # ...q_proj.lora_A[.default].weight -> ...q_proj.weight
+                base = base[len("base_model.model."):] if base.startswith("base_model.model.") else base
+                pairs.setdefault(base, [None, None])[idx] = v.float()
+    missing = [k for k, (a, b) in pairs.items() if a is None or b is None]
+    if missing:
+        raise ValueError(f"LoRA adapter lacks a lora_A / lora_B partner for {missing[:3]}")
+    return {k: (a, b) for k, (a, b) in pairs.items()}, float(ac["lora_alpha"]) / float(ac["r"]), bool(ac.get("fan_in_fan_out", False))
+
+
+def iter_lora_merged(model_base: str, model_path: str) -> Iterator[Tuple[str, object]]:
+    """builder.py:42-77: the base LLM's tensors with the LoRA deltas merged in (W + alpha / r * B @ A — what
+    PeftModel.merge_and_unload computes), then the non-LoRA trainables (projector etc.) of the LoRA checkpoint."""
+    pairs, scale, fifo = load_lora_adapter(model_path)
+    used = set()
+    for k, v in iter_checkpoint_tensors(model_base):
+        if k in pairs:
+            a, b = pairs[k]
+            delta = (b @ a) * scale
+            v = v.float() + (delta.t() if fifo else delta)
+            used.add(k)
+        yield k, v
+    left = set(pairs) - used
+    if left:
+        raise KeyError(f"LoRA targets not found in the base checkpoint: {sorted(left)[:3]}")
+    nl = os.path.join(model_path, "non_lora_trainables.bin")
+    if not os.path.exists(nl):
+        raise FileNotFoundError(f"{nl} (no network here: the reference would download it from the hub)")
+    for k, v in _strip_peft_prefixes(_torch_load(nl)).items():
+        yield k, v
+
+
+def iter_base_with_projector(model_base: str, model_path: str) -> Iterator[Tuple[str, object]]:
+    """builder.py:78-88: the base LLM's tensors, then the projector weights of a projector-only checkpoint"""
+    for k, v in iter_checkpoint_tensors(model_base):
+        yield k, v
+    for k, v in _torch_load(os.path.join(model_path, "mm_projector.bin")).items():
+        yield k, v
+

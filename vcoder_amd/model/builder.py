@@ -3,8 +3,9 @@
 Same signature and 6-tuple; same name-substring dispatch ('vcoder_ds_llava' / 'vcoder_llava' / else llava,
 builder.py:93-108), same processor aliasing (:145-151) and context_len rule (:133-136).  `load_8bit=True` (the
 reference: bitsandbytes LLM.int8, builder.py:31-33) selects this build's 8-bit weight format instead: W8A16, decoder
-linears as fp8-e4m3 with per-row power-of-two scales (vcoder_amd/quant.py).  4-bit (NF4) and the LoRA-merge paths are not
-part of the MI355X hot path and raise."""
+linears as fp8-e4m3 with per-row power-of-two scales (vcoder_amd/quant.py).  `model_base` selects the reference's two
+overlay paths (builder.py:42-92): LoRA adapters are merged on the host (W + alpha / r * B A, what peft's merge_and_unload
+computes), projector-only checkpoints overlay `mm_projector.bin`.  4-bit (NF4) raises."""
 from __future__ import annotations
 
 from .language_model import LlavaLlamaForCausalLM, VCoderDSLlavaLlamaForCausalLM, VCoderLlavaLlamaForCausalLM
@@ -23,22 +24,38 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, l
     if "llava" not in name:
         raise ValueError(f"'{model_name}': only LLaVA-family checkpoints (llava / vcoder_llava / vcoder_ds_llava) are "
                          "on the hot path")
-    if "lora" in name or model_base is not None:
-        raise NotImplementedError("LoRA / projector-only checkpoints: merge with the reference's "
-                                  "scripts/merge_lora_weights.py first")
     if "vcoder_it" in name:
         # the reference dispatches these names to VCoderITLlavaLlamaForCausalLM (builder.py:93), an unreleased variant that
         # is not on the hot path — refuse rather than load it as a plain LLaVA
         raise NotImplementedError("vcoder_it_llava checkpoints (VCoderITLlavaLlamaForCausalLM) are outside the MI355X hot path")
-    tokenizer = _load_tokenizer(model_path)
-    if "vcoder_ds_llava" in name:
-        cls = VCoderDSLlavaLlamaForCausalLM
-    elif "vcoder_llava" in name:
-        cls = VCoderLlavaLlamaForCausalLM
+    fmt = weight_format or ("w8a16" if load_8bit else "bf16")
+    if model_base is not None:
+        # builder.py:42-92: a LoRA checkpoint ('lora' in the name: base LLM + non_lora_trainables.bin + the adapter, merged) or
+        # a projector-only checkpoint (base LLM + mm_projector.bin).  Both build a plain LlavaLlamaForCausalLM in the
+        # reference, whatever else the name says; the tokenizer comes from the base.
+        from ..config import VCoderConfig
+        from .. import checkpoint
+
+        tokenizer = _load_tokenizer(model_base)
+        cfg = VCoderConfig.from_pretrained(model_path, "llava")
+        cfg.variant = "llava"
+        tensors = (checkpoint.iter_lora_merged(model_base, model_path) if "lora" in name
+                   else checkpoint.iter_base_with_projector(model_base, model_path))
+        model = LlavaLlamaForCausalLM.from_tensors(cfg, tensors, device=device, weight_format=fmt)
     else:
-        cls = LlavaLlamaForCausalLM
-    model = cls.from_pretrained(model_path, low_cpu_mem_usage=True, device=device,
-                                weight_format=weight_format or ("w8a16" if load_8bit else "bf16"))
+        if "lora" in name:
+            import warnings
+
+            warnings.warn("There is `lora` in model name but no `model_base` is provided. If you are loading a LoRA model, please "
+                          "provide the `model_base` argument.")   # builder.py:41-42: the reference warns and loads it as a full model
+        tokenizer = _load_tokenizer(model_path)
+        if "vcoder_ds_llava" in name:
+            cls = VCoderDSLlavaLlamaForCausalLM
+        elif "vcoder_llava" in name:
+            cls = VCoderLlavaLlamaForCausalLM
+        else:
+            cls = LlavaLlamaForCausalLM
+        model = cls.from_pretrained(model_path, low_cpu_mem_usage=True, device=device, weight_format=fmt)
     context_len = model.config.max_sequence_length if getattr(model.config, "max_sequence_length", None) else 2048
     vision_tower = model.get_vision_tower()
     if not vision_tower.is_loaded or vision_tower.image_processor is None:

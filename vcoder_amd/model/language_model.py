@@ -181,9 +181,16 @@ class _HipCausalLMBase:
             # an HF PretrainedConfig handed over by AutoModelForCausalLM.from_pretrained (vcoder_amd/hf_register.py)
             config = VCoderConfig.from_hf_dict(config.to_dict(), os.path.basename(os.path.normpath(str(model_path))))
         cfg = config if config is not None else VCoderConfig.from_pretrained(model_path, os.path.basename(model_path))
-        model = cls(cfg, device=device)
+        return cls.from_tensors(cfg, checkpoint.iter_checkpoint_tensors(model_path), device=device, weight_format=weight_format)
+
+    @classmethod
+    def from_tensors(cls, cfg: VCoderConfig, tensors, device="cuda", weight_format="bf16", _lib_override=None):
+        """A model from an iterator of (HF state-dict key, tensor) pairs — one checkpoint, or a base checkpoint overlaid with
+        merged LoRA deltas / projector weights (model/builder.py).  The CLIP tower comes from the stream when it carries
+        `vision_tower` keys, else from the local directory `config.mm_vision_tower`."""
+        model = cls(cfg, device=device, _lib_override=_lib_override)
         saw_tower = False
-        for k, v in checkpoint.iter_checkpoint_tensors(model_path):
+        for k, v in tensors:
             saw_tower |= "vision_tower" in k
             model._load_tensor(k, v)
         if not saw_tower:
