@@ -160,6 +160,11 @@ int vc_prefill_embeds_only(vc_model* m, const int64_t* ids, int B, int T, const 
  * next_tok [B] host (greedy argmax, lowest index on ties) or NULL. */
 int vc_decode_step(vc_model* m, const int32_t* tok, float* logits, int32_t* next_tok);
 
+/* beam search support: the KV rows of the current vc_prefill / vc_decode_step loop are permuted, row r <- old row src_rows[r] —
+ * `past_key_values` reordered by beam_idx after a beam step ([HF] generation/utils.py beam_search; the reference's eval loaders
+ * forward num_beams: eval/model_seg_loader.py:129-139) */
+int vc_reorder_cache(vc_model* m, const int32_t* src_rows, int B);
+
 /* greedy generate(): encode + splice + prefill + (max_new-1) hipGraph-replayed decode steps, HF semantics
  * (SURVEY.md Appendix C): eos_id < 0 disables EOS; finished rows emit pad_id; stops when all rows finished.
  * generate() always carries an attention_mask, so unequal spliced lengths fail with VC_ERR_UNEQUAL (quirk 6).

@@ -90,6 +90,8 @@ def declare(lib: C.CDLL) -> C.CDLL:
     lib.vc_model_set_layer_limit.restype = C.c_int
     lib.vc_debug_prefill_layers.argtypes = [vp, i32, i32, vp, i32, i32, vp]
     lib.vc_debug_prefill_layers.restype = C.c_int
+    lib.vc_reorder_cache.argtypes = [vp, vp, i32]
+    lib.vc_reorder_cache.restype = C.c_int
     lib.vc_request_hidden_states.argtypes = [vp, vp, C.c_size_t]
     lib.vc_request_hidden_states.restype = C.c_int
     lib.vc_set_attention_mask.argtypes = [vp, vp, i32, i32]

@@ -2108,6 +2108,41 @@ VC_API int vc_debug_prefill_layers(vc_model* m, int l0, int l1, const float* x_i
     GUARD_END(m->ctx)
 }
 
+/* Beam search support: the KV rows of the session's current loop are permuted, row r <- old row src_rows[r] (live prefix only) —
+ * `past_key_values` reordered by beam_idx ([HF] generation/utils.py: _reorder_cache after every beam step). */
+VC_API int vc_reorder_cache(vc_model* m, const int32_t* src_rows, int B) {
+    if (!m) return VC_ERR_INVALID;
+    GUARD_BEGIN
+    USE_DEVICE(m->ctx);
+    REQUIRE(m->cur_pos >= 0, VC_ERR_STATE, "vc_reorder_cache before vc_prefill");
+    REQUIRE(src_rows && B == m->curB, VC_ERR_INVALID, "beam_idx must have one entry per row of the current batch (%d)", m->curB);
+    bool identity = true;
+    for (int b = 0; b < B; ++b) {
+        REQUIRE(src_rows[b] >= 0 && src_rows[b] < B, VC_ERR_INDEX, "beam index %d out of range", src_rows[b]);
+        identity = identity && src_rows[b] == b;
+    }
+    if (!identity) {
+        const vc_model_cfg& c = m->c;
+        const int live = m->cur_pos, H = c.heads;
+        const bool strict = m->precision == 1;
+        const size_t es = strict ? 4 : (size_t)m->kv_es;
+        const int capS = strict ? m->s_capS : m->capS, capB = strict ? m->s_capB : m->capB;
+        const size_t cap_row = (size_t)capS * m->hd * es, live_row = (size_t)live * m->hd * es;
+        m->stage.ensure((size_t)B * H * live_row);
+        m->stage2.ensure((size_t)B * 4);
+        HIPCHK(hipMemcpyAsync(m->stage2.p, src_rows, (size_t)B * 4, hipMemcpyHostToDevice, m->st));
+        char* kb = reinterpret_cast<char*>(strict ? m->s_kc.p : m->kc.p);
+        char* vb = reinterpret_cast<char*>(strict ? m->s_vc.p : m->vc.p);
+        for (int l = 0; l < c.layers; ++l) {
+            const size_t off = (size_t)l * capB * H * cap_row;
+            launch_kv_permute(kb + off, m->stage.p, m->stage2.as<int>(), B, H, cap_row, live_row, m->st);
+            launch_kv_permute(vb + off, m->stage.p, m->stage2.as<int>(), B, H, cap_row, live_row, m->st);
+        }
+        HIPCHK(hipStreamSynchronize(m->st));
+    }
+    GUARD_END(m->ctx)
+}
+
 VC_API int vc_decode_step(vc_model* m, const int32_t* tok, float* logits, int32_t* next_tok) {
     if (!m) return VC_ERR_INVALID;
     GUARD_BEGIN

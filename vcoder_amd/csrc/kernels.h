@@ -346,6 +346,9 @@ void launch_synth_bf16(bf16_t* out, size_t n, uint32_t tseed, float offset, floa
 void launch_synth_f32(float* out, size_t n, uint32_t tseed, float offset, float halfwidth, hipStream_t s);
 constexpr int ROW_SUM_PARTS = 32;  // out: [rows][ROW_SUM_PARTS] partial sums
 void launch_row_sum(const float* x, size_t n_per_row, int rows, float* out, hipStream_t s);
+// rows of one layer's K or V cache permuted in place through `tmp`: row r <- old row perm[r], live prefix only (beam search)
+void launch_kv_permute(void* cache, void* tmp, const int* perm, int rows, int H, size_t cap_row_bytes, size_t live_row_bytes,
+                       hipStream_t s);
 void launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
 void launch_bf16_to_f32(const bf16_t* in, float* out, size_t n, hipStream_t s);
 

@@ -139,6 +139,32 @@ void launch_row_sum(const float* x, size_t n_per_row, int rows, float* out, hipS
     VC_LAUNCH(row_sum_kernel, dim3(rows, ROW_SUM_PARTS), dim3(256), 0, s, x, n_per_row, out);
 }
 
+// ---- KV-cache row permutation (beam search: `past_key_values` reordered by beam_idx, [HF] generation/utils.py _reorder_cache)
+// cache [rows][H][capS][hd] (elements of es bytes); phase 0: tmp[r][h][s] = cache[perm[r]][h][s] for s < live; phase 1:
+// cache[r][h][s] = tmp[r][h][s].  One thread = 16 bytes.
+__global__ __launch_bounds__(256) void kv_permute_kernel(char* cache, char* tmp, const int* perm, int rows, int H, size_t cap_row_bytes,
+                                                         size_t live_row_bytes, int phase) {
+    const size_t chunks = live_row_bytes / 16;                 // per (row, head)
+    const size_t total = (size_t)rows * H * chunks;
+    for (size_t id = (size_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (size_t)gridDim.x * 256) {
+        const size_t c = id % chunks, rh = id / chunks;
+        const int h = (int)(rh % H), r = (int)(rh / H);
+        char* t = tmp + ((size_t)r * H + h) * live_row_bytes + c * 16;
+        if (phase == 0) st16(t, ld16(cache + ((size_t)perm[r] * H + h) * cap_row_bytes + c * 16));
+        else st16(cache + ((size_t)r * H + h) * cap_row_bytes + c * 16, ld16(t));
+    }
+}
+void launch_kv_permute(void* cache, void* tmp, const int* perm, int rows, int H, size_t cap_row_bytes, size_t live_row_bytes,
+                       hipStream_t s) {
+    const size_t total = (size_t)rows * H * (live_row_bytes / 16);
+    if (total == 0) return;
+    const unsigned grid = (unsigned)min((size_t)4096, (total + 255) / 256);
+    VC_LAUNCH(kv_permute_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<char*>(cache), reinterpret_cast<char*>(tmp), perm, rows, H,
+              cap_row_bytes, live_row_bytes, 0);
+    VC_LAUNCH(kv_permute_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<char*>(cache), reinterpret_cast<char*>(tmp), perm, rows, H,
+              cap_row_bytes, live_row_bytes, 1);
+}
+
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* in, bf16_t* out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = f2bf(in[i]);
 }

@@ -250,6 +250,11 @@ class HipEngine:
             self._check(self.lib.vc_set_attention_mask(self._model, mk.ctypes.data_as(C.c_void_p), B, T))
         return True
 
+    def reorder_cache(self, beam_idx):
+        """KV rows of the current prefill / decode_step loop permuted: row r <- old row beam_idx[r] (beam search)"""
+        idx = np.ascontiguousarray(np.asarray(beam_idx).reshape(-1), dtype=np.int32)
+        self._check(self.lib.vc_reorder_cache(self._model, idx.ctypes.data_as(C.c_void_p), int(idx.shape[0])))
+
     def clear_attention_mask(self):
         """the cached decode steps behind the current prefill see every key again (the reference's multimodal decode path)"""
         self._check(self.lib.vc_clear_attention_mask(self._model))

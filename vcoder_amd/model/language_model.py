@@ -305,10 +305,18 @@ class _HipCausalLMBase:
 
         if input_ids is None:
             input_ids = inputs
-        if num_beams != 1:
-            raise NotImplementedError("beam search is not used by the reference's VCoder callers (num_beams=1)")
         if temperature is not None and float(temperature) <= 0.0:
             do_sample = False
+        if num_beams != 1:
+            if do_sample:
+                raise NotImplementedError("beam-sample (num_beams > 1 with do_sample=True) is not implemented; the reference's "
+                                          "eval loaders use num_beams with greedy scoring or num_beams=1")
+            if streamer is not None:
+                raise ValueError("`streamer` cannot be used with beam search")   # HF's own check
+            return self._beam_search(input_ids, images, segs, depths, int(num_beams), max_new_tokens, max_length, eos_token_id,
+                                     pad_token_id, attention_mask, stopping_criteria,
+                                     float(kwargs.get("length_penalty", 1.0)), kwargs.get("early_stopping", False),
+                                     kwargs.get("_beam_len_counts_prompt", True))
         T = input_ids.shape[1]
         B = input_ids.shape[0]
         if max_new_tokens is None:
@@ -400,6 +408,141 @@ class _HipCausalLMBase:
         return out
 
     _sample_calls = 0
+
+    # ---- beam search (HF GenerationMixin.beam_search + BeamSearchScorer of the reference's pinned Transformers 4.31) -----------
+    def _beam_search(self, input_ids, images, segs, depths, num_beams, max_new_tokens, max_length, eos_token_id, pad_token_id,
+                     attention_mask, stopping_criteria, length_penalty, early_stopping, len_counts_prompt):
+        """`generate(num_beams=n)` as the reference's eval loaders can ask for it (eval/model_seg_loader.py:129-139 forwards
+        args.num_beams): every sequence is expanded to n beams (rows b*n .. b*n+n-1, as `_expand_inputs_for_generation`), the
+        prefill and one cached decode step per token run on the engine, scoring is HF's — log-softmax of the fp32 logits plus
+        the running beam score, the 2n best continuations per sequence, BeamSearchScorer.process / finalize (hypotheses
+        scored by sum_logprobs / len ** length_penalty; 4.31 counts the PROMPT ids in len) — and the KV rows are reordered by
+        beam_idx after every step (vc_reorder_cache).  Returns [B, T + n_new] int64, shorter rows padded with pad_token_id
+        (after one EOS), like HF."""
+        import torch
+
+        ids_cpu = input_ids.detach().cpu() if hasattr(input_ids, "detach") else torch.as_tensor(np.asarray(input_ids))
+        B, T = ids_cpu.shape
+        nb = num_beams
+        if B * nb > self.engine.MAX_BATCH:
+            raise ValueError(f"batch {B} x num_beams {nb} exceeds the {self.engine.MAX_BATCH} rows a replica decodes at a time")
+        if max_new_tokens is None:
+            max_new_tokens = (max_length - T) if max_length is not None else 20
+        eos = self.config.eos_token_id if eos_token_id is None else eos_token_id
+        eos = None if (eos is not None and int(eos) < 0) else eos
+        pad = pad_token_id if pad_token_id is not None else (self.config.pad_token_id if self.config.pad_token_id is not None else eos)
+        segs = segs if self.variant != "llava" else None
+        depths = depths if self.variant == "vcoder_ds" else None
+        rep = np.repeat(np.arange(B), nb)
+
+        def expand(a):
+            if a is None:
+                return None
+            if isinstance(a, (list, tuple)):
+                return [a[i] for i in rep]
+            return a[torch.as_tensor(rep, device=a.device)] if hasattr(a, "detach") else np.asarray(a)[rep]
+
+        ids_x = ids_cpu[torch.as_tensor(rep)]
+        mask_x = expand(attention_mask)
+        last, _, S = self.engine.prefill(ids_x.numpy(), expand(images), expand(segs), expand(depths), has_attention_mask=True,
+                                         reserve=max_new_tokens, attention_mask=mask_x)
+        self.engine.clear_attention_mask()          # cached steps under the all-ones mask (vcoder_ds_llava_arch.py:130-133)
+        self._generation += 1
+        V = last.shape[-1]
+        seqs = ids_x.clone()                                                  # [B*nb, T + generated]
+        beam_scores = torch.zeros(B, nb)
+        beam_scores[:, 1:] = -1e9
+        beam_scores = beam_scores.view(-1)
+        hyps = [[] for _ in range(B)]                                         # per sequence: (score, ids), at most nb kept
+        worst = [1e9] * B
+        done = [False] * B
+
+        def hyp_len(n_ids):                                                    # 4.31: the whole id row; >= 4.38: generated part only
+            return n_ids if len_counts_prompt else n_ids - T
+
+        def add_hyp(b, ids_row, sum_logprobs):
+            score = sum_logprobs / (max(hyp_len(ids_row.shape[-1]), 1) ** length_penalty)
+            if len(hyps[b]) < nb or score > worst[b]:
+                hyps[b].append((score, ids_row))
+                if len(hyps[b]) > nb:
+                    srt = sorted((s_, i) for i, (s_, _) in enumerate(hyps[b]))
+                    del hyps[b][srt[0][1]]
+                    worst[b] = srt[1][0]
+                else:
+                    worst[b] = min(score, worst[b])
+
+        def is_done(b, best_sum_logprobs, cur_len):
+            if len(hyps[b]) < nb:
+                return False
+            if early_stopping is True:
+                return True
+            if early_stopping is False:
+                return worst[b] >= best_sum_logprobs / (max(hyp_len(cur_len), 1) ** length_penalty)
+            # "never"
+            hl = hyp_len(cur_len) if length_penalty <= 0.0 else hyp_len(T + max_new_tokens)
+            return worst[b] >= best_sum_logprobs / (max(hl, 1) ** length_penalty)
+
+        logits = torch.from_numpy(last).float()
+        n_steps = 0
+        for step in range(max_new_tokens):
+            scores = torch.log_softmax(logits, dim=-1) + beam_scores[:, None]
+            top_s, top_i = torch.topk(scores.view(B, nb * V), 2 * nb, dim=1, largest=True, sorted=True)
+            next_idx, next_tok = top_i // V, top_i % V
+            nscore, ntok, nsrc = torch.zeros(B, nb), torch.zeros(B, nb, dtype=torch.long), torch.zeros(B, nb, dtype=torch.long)
+            cur_len = seqs.shape[1]
+            for b in range(B):
+                if done[b]:
+                    ntok[b] = pad if pad is not None else 0
+                    continue
+                k = 0
+                for rank in range(2 * nb):
+                    tok, sc, src = int(next_tok[b, rank]), float(top_s[b, rank]), b * nb + int(next_idx[b, rank])
+                    if eos is not None and tok == int(eos):
+                        if rank >= nb:
+                            continue
+                        add_hyp(b, seqs[src].clone(), sc)
+                    else:
+                        nscore[b, k], ntok[b, k], nsrc[b, k] = sc, tok, src
+                        k += 1
+                    if k == nb:
+                        break
+                if k < nb:
+                    raise ValueError(f"At most {nb} tokens in {next_tok[b].tolist()} can be equal to `eos_token_id: {eos}`.")
+                done[b] = done[b] or is_done(b, float(top_s[b].max()), cur_len)
+            beam_scores = nscore.view(-1)
+            beam_idx = nsrc.view(-1)
+            seqs = torch.cat([seqs[beam_idx], ntok.view(-1, 1)], dim=1)
+            n_steps = step + 1
+            stop = all(done)
+            if stopping_criteria:
+                for crit in stopping_criteria:
+                    r = crit(seqs, scores)
+                    stop = stop or bool(r.all() if hasattr(r, "all") else r)
+            if stop or step + 1 == max_new_tokens:
+                break
+            self.engine.reorder_cache(beam_idx.numpy())
+            lg, _ = self.engine.decode_step(ntok.view(-1).numpy().astype(np.int32))
+            logits = torch.from_numpy(lg).float()
+        # finalize: open beams become hypotheses, the best one per sequence is returned
+        out_rows = []
+        for b in range(B):
+            if not done[b]:
+                for j in range(nb):
+                    add_hyp(b, seqs[b * nb + j], float(beam_scores[b * nb + j]))
+            out_rows.append(max(hyps[b], key=lambda t_: t_[0])[1])
+        L = max(r.shape[0] for r in out_rows)
+        max_len = T + max_new_tokens
+        L_out = min(L + 1, max_len)            # BeamSearchScorer.finalize: room for the EOS a finished hypothesis does not carry
+        if any(r.shape[0] < L_out for r in out_rows) and pad is None:
+            raise ValueError("`pad_token_id` has to be defined")
+        out = torch.full((B, L_out), int(pad) if pad is not None else 0, dtype=torch.long)
+        for b, r in enumerate(out_rows):
+            out[b, : r.shape[0]] = r
+            if r.shape[0] < L_out and eos is not None:
+                out[b, r.shape[0]] = int(eos)
+        if hasattr(input_ids, "device"):
+            out = out.to(input_ids.device)
+        return out
 
 
 def _all_ones(attention_mask) -> bool:
