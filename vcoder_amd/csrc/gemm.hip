@@ -291,7 +291,9 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_bf16_dma_kernel(GemmArgs p)
 // the fragment reads of the bf16 form, which are bank-conflict free; reading the "natural" chunks 2g, 2g+1 measured 50 %
 // conflict cycles.  Which 32 of the row's 128 k a lane contributes is free as long as both operands agree: the
 // instruction sums over all of them.  The epilogue multiplies the fp32 accumulator by a_scale[m] * w_scale[n] (exact: powers of two).
-template <int EPI, bool F8 = false>
+// KWRAP (precision mode "split"): the weight's k-tile index wraps after p.kwrap tiles (compile-time flag: the default
+// instantiation keeps the weight source a plain `base + kt * 128`, exactly the round-2 loop)
+template <int EPI, bool F8 = false, bool KWRAP = false>
 __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     constexpr int HALF = 128 * 128, TILE = 4 * HALF;  // bytes
     constexpr int ES = F8 ? 1 : 2;                    // bytes per operand element; a k-tile is 128 bytes of every row
@@ -324,7 +326,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
         for (int i = 0; i < 2; ++i) {
             const int row = (i * 8 + wave) * 8 + (lane >> 3);
             const int sw = ((lane & 7) ^ (row & 7)) << 4;
-            x_src[h][i] = reinterpret_cast<const char*>(p.W) + (size_t)min(n0 + h * 128 + row, p.N - 1) * p.ldw * ES + sw;
+            x_src[h][i] = reinterpret_cast<const char*>(p.W) + (size_t)min(n0 + h * 128 + row, p.N - 1) * p.ldw * ES + sw +
+                          (KWRAP ? (size_t)0 : (size_t)kt_first * 128);
             y_src[h][i] = reinterpret_cast<const char*>(p.A) + (size_t)min(m0 + h * 128 + row, p.M - 1) * p.lda * ES + sw +
                           (size_t)kt_first * 128;
         }
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     auto stage_x = [&](int h, int kt) {
         if (kt >= nk) return;
         char* dst = smem + (kt & 1) * TILE + (h ? SX1 : SX0) + wave * 1024;
-        const size_t wk = (size_t)wrap_kt(kt_first + kt, p.kwrap) * 128;
+        const size_t wk = KWRAP ? (size_t)wrap_kt(kt_first + kt, p.kwrap) * 128 : (size_t)kt * 128;
         glds16(x_src[h][0] + wk, dst);
         glds16(x_src[h][1] + wk, dst + 8192);
     };
@@ -588,9 +591,14 @@ void launch_gemm(const GemmArgs& a, int epilogue, hipStream_t s) {
             allow_big_lds_gemm(gemm_bf16_dma_kernel<E, 2, 4, 8, 4>, sh2);                                  \
             allow_big_lds_gemm(gemm_bf16_dma_kernel<E, 2, 2, 8, 8>, sh2);                                  \
             allow_big_lds_gemm(gemm_bf16_8phase_kernel<E>, sh2);                                           \
+            allow_big_lds_gemm(gemm_bf16_8phase_kernel<E, false, true>, sh2);                              \
             once = true;                                                                                   \
         }                                                                                                  \
-        if (phased) {                                                                                      \
+        if (phased && ask.kwrap > 0) {                                                                     \
+            VC_LAUNCH((gemm_bf16_8phase_kernel<E, false, true>), gsk, b2, sh2, s, ask);                    \
+            if (ask.sk_ks > 1)                                                                             \
+                VC_LAUNCH((gemm_splitk_fixup_kernel<E>), dim3((unsigned)(rem * 64)), dim3(256), 0, s, ask); \
+        } else if (phased) {                                                                               \
             VC_LAUNCH((gemm_bf16_8phase_kernel<E>), gsk, b2, sh2, s, ask);                                 \
             if (ask.sk_ks > 1)                                                                             \
                 VC_LAUNCH((gemm_splitk_fixup_kernel<E>), dim3((unsigned)(rem * 64)), dim3(256), 0, s, ask); \
