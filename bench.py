@@ -164,6 +164,15 @@ def cpu_baseline(cfg, n_new: int, decode_steps: int = 8):
                        f"{n_new - 1} steps")}
 
 
+def _pmc_traffic_file():
+    """the newest committed PMC FETCH_SIZE pass of the decode-step kernels (profiles/rNN_pmc_traffic.json; tools/profile_round.sh)"""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+    files = [f for f in files if "hbm_read_bytes_per_launch_by_rows" in open(f).read()]
+    return files[-1] if files else None
+
+
 def _one_vit_layer(cfg):
     class C1:
         pass
@@ -484,8 +493,8 @@ def main():
         traffic = args.pmc_traffic_bytes
         if traffic is None and args.model == "7b" and B == 8 and args.weights == "bf16":
             # separate --pmc FETCH_SIZE pass of this kernel at this row count (gfx950 x2 correction applied, see the file)
-            f_ = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-            if os.path.exists(f_):
+            f_ = _pmc_traffic_file()
+            if f_ and os.path.exists(f_):
                 with open(f_) as f:
                     traffic_by_rows = json.load(f).get("hbm_read_bytes_per_launch_by_rows", {})
                 traffic = traffic_by_rows.get(str(rows_step))
@@ -522,8 +531,8 @@ def main():
         fam_g, fam_a = family(prof_by_rows), family(att_by_rows)
         t_gemv, t_att = fam_g["us_per_step"], fam_a["us_per_step"]
         pmc = {}
-        f_ = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-        if args.model == "7b" and B == 8 and args.weights == "bf16" and os.path.exists(f_):
+        f_ = _pmc_traffic_file()
+        if args.model == "7b" and B == 8 and args.weights == "bf16" and f_ and os.path.exists(f_):
             with open(f_) as f:
                 pmc = json.load(f)
 

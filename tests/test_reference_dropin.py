@@ -140,3 +140,47 @@ def test_reference_cli_runs_one_turn(dropin_env, monkeypatch, capsys):
     assert torch.equal(out[:, :ids.shape[1]], ids)
     assert "ASSISTANT: " in printed and "t" in printed.split("ASSISTANT: ")[1], "the TextStreamer printed generated tokens"
     assert "exit..." in printed
+
+
+def test_reference_chat_worker_streams_a_reply(dropin_env):
+    """The reference's model worker (vcoder_llava/serve/chat.py, unmodified): Chat(...) loads through load_pretrained_model and
+    Chat.generate_stream(params) — base64 images -> process_images -> tokenizer_depth_seg_token -> KeywordsStoppingCriteria +
+    TextIteratorStreamer -> model.generate(inputs=..., do_sample=True, temperature, top_p, max_new_tokens, streamer=,
+    stopping_criteria=, use_cache=True, images=, segs=, depths=) (chat.py:141-151) — yields JSON chunks of growing text."""
+    import base64
+    import logging
+
+    import vcoder_llava.serve.chat as chat          # the reference's file
+
+    assert chat.__file__.startswith(ref_shim.REFERENCE_ROOT)
+    worker = chat.Chat(dropin_env.ckpt + "/", None, None, False, False, "cpu", logging.getLogger("test"))
+    assert worker.model_name == "vcoder_ds_llava-v1.5-tiny" and worker.is_multimodal and worker.is_seg and worker.is_depth
+    assert type(worker.model).__name__ == "VCoderDSLlavaLlamaForCausalLM" and worker.depth_image_processor is worker.image_processor
+    b64 = [base64.b64encode(open(f, "rb").read()).decode() for f in dropin_env.files]
+    seen = {}
+    gen = worker.model.generate
+
+    def spy(**kw):
+        seen.update({k: kw[k] for k in ("do_sample", "temperature", "top_p", "max_new_tokens", "use_cache")})
+        seen["ids"] = kw["inputs"].clone()
+        seen["pix_dtype"] = (kw["images"].dtype, kw["segs"].dtype, kw["depths"].dtype)
+        out = gen(**kw)
+        seen["out"] = out
+        return out
+
+    worker.model.generate = spy
+    params = {"prompt": "A chat. USER: <depth>\n<seg>\n<image>\nWhat is there? ASSISTANT:", "images": b64[:1], "segs": b64[1:2],
+              "depths": b64[2:3], "temperature": 0.7, "top_p": 0.9, "max_new_tokens": 10, "stop": "</s>"}
+    chunks = [json.loads(c.decode().rstrip("\0")) for c in worker.generate_stream_gate(params)]
+    assert chunks and all(c["error_code"] == 0 for c in chunks), chunks
+    texts = [c["text"] for c in chunks]
+    assert all(t.startswith(params["prompt"]) for t in texts) and len(texts[-1]) > len(params["prompt"])
+    assert all(len(a) <= len(b) for a, b in zip(texts, texts[1:])), "the streamed text grows"
+    assert [int(t) for t in seen["ids"][0] if int(t) < 0] == [-200, -400, -300]
+    assert seen["do_sample"] is True and seen["max_new_tokens"] == 10 and seen["pix_dtype"] == (torch.float16,) * 3
+    out = seen["out"]
+    assert out.shape[0] == 1 and torch.equal(out[:, : seen["ids"].shape[1]], seen["ids"])
+    # the worker's own error path: a prompt whose <image> count does not match the images -> its ValueError handler
+    bad = dict(params, images=b64[:1] + b64[:1])
+    err = [json.loads(c.decode().rstrip("\0")) for c in worker.generate_stream_gate(bad)]
+    assert err[-1]["error_code"] == 1

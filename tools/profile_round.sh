@@ -15,14 +15,19 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o ks -- python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_trace_bench.json 2> $OUT/${TAG}_trace.err
+timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o ks -- python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extra-legs > $OUT/${TAG}_trace_bench.json 2> $OUT/${TAG}_trace.err
 DB=$(find $OUT/${TAG}_trace -name "*.db" | head -1)
 python $ROOT/tools/rocpd_summary.py "$DB" $OUT/${TAG}_kernel_stats_pooled.md > /dev/null 2>> $OUT/${TAG}_trace.err
 rm -rf $OUT/${TAG}_trace
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace1 -o ks -- python $ROOT/bench.py --steps 1 --warmup 1 --inflight 1 --no-cpu-baseline > $OUT/${TAG}_trace1_bench.json 2> $OUT/${TAG}_trace1.err
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace1 -o ks -- python $ROOT/bench.py --steps 1 --warmup 1 --inflight 1 --no-cpu-baseline --no-extra-legs > $OUT/${TAG}_trace1_bench.json 2> $OUT/${TAG}_trace1.err
 DB=$(find $OUT/${TAG}_trace1 -name "*.db" | head -1)
 python $ROOT/tools/rocpd_summary.py "$DB" $OUT/${TAG}_kernel_stats_one_batch.md > /dev/null 2>> $OUT/${TAG}_trace1.err
 rm -rf $OUT/${TAG}_trace1
+# precision mode "split": one batch of configs[1] (the split kernels' durations)
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_traceS -o ks -- python $ROOT/tools/experiments/split_mode_one_batch.py 2 > $OUT/${TAG}_traceS.txt 2> $OUT/${TAG}_traceS.err
+DB=$(find $OUT/${TAG}_traceS -name "*.db" | head -1)
+python $ROOT/tools/rocpd_summary.py "$DB" $OUT/${TAG}_kernel_stats_split_one_batch.md > /dev/null 2>> $OUT/${TAG}_traceS.err
+rm -rf $OUT/${TAG}_traceS
 # BASELINE configs[4] weight format on the 13b geometry: W8A8 prefill (scaled fp8 MFMA) + W8A16 decode steps
 timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace8 -o ks -- python $ROOT/bench.py --model 13b --batch 16 --inflight 2 --weights fp8 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_trace8_bench.json 2> $OUT/${TAG}_trace8.err
 DB=$(find $OUT/${TAG}_trace8 -name "*.db" | head -1)
