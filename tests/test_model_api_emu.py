@@ -400,6 +400,10 @@ def test_attention_mask_of_a_padded_batch_is_honoured(model):
     bad[1, np.where(ids[1] == -300)[0][0]] = 5
     with pytest.raises(UnboundLocalError):
         model(input_ids=t(bad), attention_mask=t(mask), **kw)
+    # the failed call must not leave its mask behind for the next one (one-shot requests die with their call)
+    g2, _, ids2, imgs2, segs2, deps2 = _fx()
+    out2 = model(input_ids=t(ids2), images=t(imgs2), segs=t(segs2), depths=t(deps2))
+    assert np.abs(out2.logits.numpy() - g2["prefill_logits"]).max() < tol
 
 
 def test_vision_tower_forward_and_feature_select(model):

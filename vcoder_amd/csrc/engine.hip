@@ -1581,6 +1581,19 @@ void arm_session_rows(vc_model* m, const GenParams& g, const int* tail) {
 
 }  // namespace
 
+// the one-shot requests of the NEXT prefill / generate call (vc_set_image_counts, vc_set_attention_mask,
+// vc_request_hidden_states) never outlive that call — also not when it fails half-way (a stale mask would be applied to,
+// and a stale host pointer written by, some later call)
+struct OneShotReset {
+    vc_model* m;
+    ~OneShotReset() {
+        for (auto& v : m->img_counts) v.clear();
+        m->mask_next.clear();
+        m->hidden_out = nullptr;
+        m->hidden_cap = 0;
+    }
+};
+
 // =================================================================================================
 // C ABI
 // =================================================================================================
@@ -2037,6 +2050,7 @@ VC_API int vc_prefill(vc_model* m, const int64_t* ids, int B, int T, const float
                       const float* depth, int pixels_on_device, int has_attention_mask, float* logits_last,
                       float* logits_all, int* S_out) {
     if (!m) return VC_ERR_INVALID;
+    OneShotReset one_shot{m};
     GUARD_BEGIN
     USE_DEVICE(m->ctx);
     m->cur_pos = -1;
@@ -2066,6 +2080,7 @@ VC_API int vc_prefill_embeds_only(vc_model* m, const int64_t* ids, int B, int T,
                                   const float* depth, int pixels_on_device, int has_attention_mask, float* out_host,
                                   int* S_out) {
     if (!m) return VC_ERR_INVALID;
+    OneShotReset one_shot{m};
     GUARD_BEGIN
     USE_DEVICE(m->ctx);
     m->cur_pos = -1;
@@ -2753,6 +2768,7 @@ VC_API int vc_generate(vc_model* m, const int64_t* ids, int B, int T, const floa
                        const int32_t* stop_lens, int n_stop, const vc_sampling* samp, vc_token_cb cb, void* cb_user,
                        int cb_every, int32_t* out_ids, int* n_generated) {
     if (!m) return VC_ERR_INVALID;
+    OneShotReset one_shot{m};
     GUARD_BEGIN
     USE_DEVICE(m->ctx);
     REQUIRE(max_new >= 1 && out_ids, VC_ERR_INVALID, "bad max_new/out_ids");
