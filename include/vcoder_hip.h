@@ -129,6 +129,12 @@ int vc_set_image_counts(vc_model* m, const int32_t* img_counts, const int32_t* s
  * vc_prefill returns; NULL cancels. */
 int vc_request_hidden_states(vc_model* m, float* out, size_t cap_floats);
 
+/* output_attentions for the NEXT vc_prefill (one-shot): out (host, cap_floats floats) receives [layers, B, heads, S, S] fp32 — the
+ * attention probabilities HF's eager attention returns as `attentions` (vcoder_ds_llava_llama.py:81-90,118; [HF]
+ * llama/modeling_llama.py eager_attention_forward): softmax(q k^T / sqrt(hd) + causal mask + padding mask), recomputed per layer
+ * from that layer's q / k by a diagnostic kernel (the flash kernels never materialise them).  S <= 4096. */
+int vc_request_attentions(vc_model* m, float* out, size_t cap_floats);
+
 /* Padded batches: the caller's 2-D attention_mask [B, T] (bytes, 0 = hidden) for the NEXT vc_prefill* / vc_generate* call
  * (one-shot).  As in the reference, it is LEFT-extended with "visible" over the S - T rows the splice adds — by position
  * (vcoder_ds_llava_arch.py:305-311) — and a hidden position is hidden as a KEY from every query of its sequence during the

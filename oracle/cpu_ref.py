@@ -96,7 +96,7 @@ def quick_gelu(x):
     return x * torch.sigmoid(1.702 * x)
 
 
-def softmax_attention(q, k, v, scale, causal, r: Rounder, q_pos0: int = 0, key_mask=None):
+def softmax_attention(q, k, v, scale, causal, r: Rounder, q_pos0: int = 0, key_mask=None, probs_out: Optional[list] = None):
     """q [N,H,Tq,hd], k/v [N,H,Tk,hd].  softmax in fp32 ([HF] clip :272, llama eager_attention :191-214).
     key_mask [N,Tk] bool (padded batches): a False key is hidden from every query of its sequence — the additive form of the
     2-D attention_mask HF's LlamaModel combines with the causal mask.
@@ -114,6 +114,8 @@ def softmax_attention(q, k, v, scale, causal, r: Rounder, q_pos0: int = 0, key_m
     m = s.max(-1, keepdim=True).values
     p = torch.exp(s - m)
     l = p.sum(-1, keepdim=True)
+    if probs_out is not None:   # attn_weights of the eager attention ([HF] llama eager_attention_forward: softmax in fp32)
+        probs_out.append(p / l)
     o = torch.matmul(r(p), v) / l
     return r(o)
 
@@ -337,7 +339,7 @@ class KVCache:
         return 0 if self.k[0] is None else self.k[0].shape[2]
 
 
-def llama_layer(x, sd, i: int, cfg, cache: KVCache, pos0: int, r: Rounder, key_mask=None):
+def llama_layer(x, sd, i: int, cfg, cache: KVCache, pos0: int, r: Rounder, key_mask=None, probs_out: Optional[list] = None):
     """LlamaDecoderLayer :284-325 with LlamaAttention :217-281 and LlamaMLP :163-176."""
     B, T, D = x.shape
     H = cfg.num_attention_heads
@@ -355,7 +357,7 @@ def llama_layer(x, sd, i: int, cfg, cache: KVCache, pos0: int, r: Rounder, key_m
         k = torch.cat([cache.k[i], k], dim=2)
         v = torch.cat([cache.v[i], v], dim=2)
     cache.k[i], cache.v[i] = k, v
-    a = softmax_attention(q, k, v, 1.0 / math.sqrt(hd), True, r, q_pos0=pos0, key_mask=key_mask)
+    a = softmax_attention(q, k, v, 1.0 / math.sqrt(hd), True, r, q_pos0=pos0, key_mask=key_mask, probs_out=probs_out)
     a = r.q8(a.transpose(1, 2).reshape(B, T, D))
     x = x + F.linear(a, sd[p + "self_attn.o_proj.weight"])
     h = r.q8(r(rms_norm(x, sd[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps)))
@@ -367,7 +369,7 @@ def llama_layer(x, sd, i: int, cfg, cache: KVCache, pos0: int, r: Rounder, key_m
 
 
 def llama_forward(x, sd, cfg, cache: KVCache, emu_bf16: bool = False, last_only: bool = False, act_fp8: bool = False,
-                  key_mask=None, hidden_out: Optional[list] = None):
+                  key_mask=None, hidden_out: Optional[list] = None, attn_out: Optional[list] = None):
     """LlamaModel.forward :367-418 on inputs_embeds + lm_head (vcoder_ds_llava_llama.py:81-93).
     position_ids = arange(T) + past_len.  act_fp8: the device's fp8 weight format quantises the decoder linears'
     activation rows in the PREFILL (a pass that starts an empty cache); cached decode steps keep bf16 activations."""
@@ -375,11 +377,11 @@ def llama_forward(x, sd, cfg, cache: KVCache, emu_bf16: bool = False, last_only:
     pos0 = cache.length
     r.prefill = pos0 == 0
     # hidden_out (a list): receives LlamaModel's all_hidden_states ([HF] llama/modeling_llama.py: inputs_embeds, every layer's
-    # output, the last entry AFTER the final norm)
+    # output, the last entry AFTER the final norm); attn_out (a list): all_self_attns, one [B, H, T, past + T] per layer
     for i in range(cfg.num_hidden_layers):
         if hidden_out is not None:
             hidden_out.append(x.clone())
-        x = llama_layer(x, sd, i, cfg, cache, pos0, r, key_mask=key_mask)   # key_mask [B, past + T]: 2-D attention_mask
+        x = llama_layer(x, sd, i, cfg, cache, pos0, r, key_mask=key_mask, probs_out=attn_out)   # key_mask [B, past + T]: 2-D attention_mask
     if hidden_out is not None:
         hidden_out.append(rms_norm(x, sd["model.norm.weight"], cfg.rms_norm_eps))
     if last_only:
@@ -454,7 +456,8 @@ class OracleModel:
         return torch.stack(rows, 0), plans
 
     def forward(self, input_ids, images, segs=None, depths=None, cache: Optional[KVCache] = None,
-                last_only: bool = False, attention_mask=None, hidden_out: Optional[list] = None):
+                last_only: bool = False, attention_mask=None, hidden_out: Optional[list] = None,
+                attn_out: Optional[list] = None):
         """VCoder[DS]LlavaLlamaForCausalLM.forward (vcoder_ds_llava_llama.py:57-118), prefill.  attention_mask [B,T]: left-
         extended with True over the S - T rows the splice added, by position (vcoder_ds_llava_arch.py:305-311), then the 2-D
         key mask of LlamaModel; kept in self.mask_ext for decode_step(keep_mask=True)."""
@@ -465,7 +468,7 @@ class OracleModel:
             self.mask_ext = torch.cat([torch.ones(am.shape[0], x.shape[1] - am.shape[1], dtype=torch.bool), am], dim=1)
         cache = cache if cache is not None else KVCache(self.cfg.num_hidden_layers)
         logits = llama_forward(x, self.sd, self.cfg, cache, self.emu, last_only, self.act_fp8, key_mask=self.mask_ext,
-                               hidden_out=hidden_out)
+                               hidden_out=hidden_out, attn_out=attn_out)
         return logits, cache
 
     def decode_step(self, tokens: Sequence[int], cache: KVCache, keep_mask: bool = False):

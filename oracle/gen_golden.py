@@ -432,17 +432,23 @@ def main_round3():
         ids = torch.tensor(np.stack([r0, r1]), dtype=torch.long)
         imgs, segs, deps = (torch.from_numpy(a) for a in synth.synth_batch(2, cfg.vit_image_size))
         with torch.no_grad():
-            out = model(input_ids=ids, images=imgs, segs=segs, depths=deps, output_hidden_states=True, use_cache=False)
+            out = model(input_ids=ids, images=imgs, segs=segs, depths=deps, output_hidden_states=True, output_attentions=True,
+                        use_cache=False)
         hs = torch.stack([h.float() for h in out.hidden_states], 0).numpy()           # [L + 1, B, S, D]
         assert hs.shape[0] == cfg.num_hidden_layers + 1
-        ho = []
-        oracle.forward(ids.tolist(), imgs, segs, deps, hidden_out=ho)
+        ho, ao = [], []
+        oracle.forward(ids.tolist(), imgs, segs, deps, hidden_out=ho, attn_out=ao)
         e = float(np.abs(torch.stack(ho, 0).numpy() - hs).max())
         print(f"[ds_hidden_states] {hs.shape} oracle|d|={e:.2e} |h|max={np.abs(hs).max():.2f}")
         assert e < 2e-5 * max(1.0, float(np.abs(hs).max()))
+        at = torch.stack([a.float() for a in out.attentions], 0).numpy()               # [L, B, H, S, S] (eager attention)
+        assert at.shape == (cfg.num_hidden_layers, 2, cfg.num_attention_heads, hs.shape[2], hs.shape[2])
+        e_at = float(np.abs(torch.stack(ao, 0).numpy() - at).max())
+        print(f"[ds_hidden_states] attentions {at.shape} oracle|d|={e_at:.2e}")
+        assert e_at < 1e-6
         np.savez_compressed(os.path.join(GOLD, "ds_hidden_states.npz"), variant=cfg.variant, seed=SEED, input_ids=ids.numpy(),
                             hidden_sample=hs[:, :, ::3, ::8].astype(np.float32), hidden_rowsum=hs.sum(-1).astype(np.float32),
-                            logits_last=out.logits[:, -1].float().numpy())
+                            logits_last=out.logits[:, -1].float().numpy(), attentions=at.astype(np.float32))
     print("round-3 fixtures written to", GOLD)
 
 

@@ -90,8 +90,11 @@ def test_forward_output_hidden_states(model):
     hs = torch.stack(out.hidden_states, 0).numpy()
     assert np.abs(hs[:, :, ::3, ::8] - g["hidden_sample"]).max() < 2.0 ** -6 * np.abs(g["hidden_sample"]).max()
     assert model(input_ids=t(ids), images=t(imgs), segs=t(segs), depths=t(deps)).hidden_states is None
-    with pytest.raises(NotImplementedError):
-        model(input_ids=t(ids), images=t(imgs), segs=t(segs), depths=t(deps), output_attentions=True)
+    out = model(input_ids=t(ids), images=t(imgs), segs=t(segs), depths=t(deps), output_attentions=True, use_cache=True)
+    assert isinstance(out.attentions, tuple) and len(out.attentions) == model.config.num_hidden_layers
+    assert np.abs(torch.stack(out.attentions, 0).numpy() - g["attentions"]).max() < 2.0 ** -7
+    with pytest.raises(NotImplementedError):   # a cached decode step keeps neither
+        model(input_ids=t(ids[:, :1]), past_key_values=out.past_key_values, images=t(imgs), output_attentions=True)
 
 
 def test_generate_variants(model):

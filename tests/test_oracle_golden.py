@@ -38,6 +38,23 @@ def _inputs(g, cfg):
     return t(imgs), (t(segs) if bool(g["use_seg"]) else None), (t(deps) if bool(g["use_depth"]) else None)
 
 
+def test_oracle_hidden_states_and_attentions():
+    """LlamaModel's all_hidden_states / all_self_attns of the prefill: the oracle's against the live reference's
+    (tests/golden/ds_hidden_states.npz, oracle/gen_golden.py --round3)."""
+    g = np.load(os.path.join(GOLD, "ds_hidden_states.npz"))
+    om = oracle_for(str(g["variant"]))
+    ids = g["input_ids"]
+    imgs, segs, deps = (torch.from_numpy(a) for a in synth.synth_batch(ids.shape[0], om.cfg.vit_image_size))
+    ho, ao = [], []
+    logits, _ = om.forward(ids.tolist(), imgs, segs, deps, hidden_out=ho, attn_out=ao)
+    hs = torch.stack(ho, 0).numpy()
+    scale = max(1.0, float(np.abs(g["hidden_sample"]).max()))
+    assert np.abs(hs[:, :, ::3, ::8] - g["hidden_sample"]).max() < 2e-5 * scale
+    assert np.abs(hs.sum(-1) - g["hidden_rowsum"]).max() < 1e-3 * scale
+    assert np.abs(torch.stack(ao, 0).numpy() - g["attentions"]).max() < 1e-6
+    assert np.abs(logits[:, -1].numpy() - g["logits_last"]).max() < 1e-4
+
+
 @pytest.mark.parametrize("name", FIXTURES)
 def test_oracle_matches_reference_fixture(name):
     import json

@@ -92,6 +92,8 @@ def declare(lib: C.CDLL) -> C.CDLL:
     lib.vc_debug_prefill_layers.restype = C.c_int
     lib.vc_reorder_cache.argtypes = [vp, vp, i32]
     lib.vc_reorder_cache.restype = C.c_int
+    lib.vc_request_attentions.argtypes = [vp, vp, C.c_size_t]
+    lib.vc_request_attentions.restype = C.c_int
     lib.vc_request_hidden_states.argtypes = [vp, vp, C.c_size_t]
     lib.vc_request_hidden_states.restype = C.c_int
     lib.vc_set_attention_mask.argtypes = [vp, vp, i32, i32]

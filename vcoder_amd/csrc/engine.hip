@@ -189,6 +189,9 @@ struct vc_model {
     float* hidden_out = nullptr;
     size_t hidden_cap = 0;        // floats
     Buf hidden_tmp;
+    // output_attentions of the NEXT vc_prefill (vc_request_attentions; one-shot): host buffer [L, B, H, S, S]
+    float* attn_out = nullptr;
+    size_t attn_cap = 0;
     int reserve_new = 64;         // KV slots a vc_prefill keeps free behind the prompt (vc_model_reserve_decode)
     int layer_limit = 0;          // > 0: a prefill evaluates only the first layer_limit decoder layers (vc_model_set_layer_limit)
     // LLM workspace
@@ -402,6 +405,28 @@ int place_tensor(vc_model* m, const std::string& raw_key, const void* src, int d
 }
 
 void emit_hidden(vc_model* m, int idx, int B, int S);  // output_hidden_states hook (defined with the prefill layers)
+// output_attentions hook: the probabilities of decoder layer l from its q / k in the precision mode's own form
+void emit_attentions(vc_model* m, int l, int B, int S, AttnProbsArgs a) {
+    if (!m->attn_out) return;
+    const size_t n = (size_t)B * m->c.heads * S * S;
+    REQUIRE((size_t)(l + 1) * n <= m->attn_cap, VC_ERR_INVALID, "attention buffer too small: %zu floats for layer %d of %zu", m->attn_cap,
+            l, n);
+    REQUIRE(S <= 4096, VC_ERR_INVALID, "output_attentions: at most 4096 positions");
+    m->hidden_tmp.ensure(n * 4);
+    a.out = m->hidden_tmp.as<float>();
+    a.B = B;
+    a.H = m->c.heads;
+    a.T = S;
+    a.hd = m->hd;
+    a.scale = 1.0f / sqrtf((float)m->hd);
+    if (m->has_kmask) {
+        a.key_mask = m->kmask.as<uint8_t>();
+        a.mask_stride = m->c.max_positions;
+    }
+    launch_attn_probs(a, m->st);
+    HIPCHK(hipMemcpyAsync(m->attn_out + (size_t)l * n, a.out, n * 4, hipMemcpyDeviceToHost, m->st));
+    HIPCHK(hipStreamSynchronize(m->st));   // hidden_tmp is shared with the hidden-state hook
+}
 
 // ------------------------------------------------------------------------------------------------
 // GEMM helpers
@@ -890,6 +915,14 @@ void run_llm_layers_strict(vc_model* m, float* x, int B, int T, const int* pos_d
             aa.mask_stride = c.max_positions;
         }
         launch_attention_f32(aa, m->st);
+        if (T > 1 && x == m->x.as<float>()) {
+            AttnProbsArgs pa{};
+            pa.q32 = q;
+            pa.k32 = s_kcache(m, l);
+            pa.q_stride = T;
+            pa.kv_stride = m->s_capS;
+            emit_attentions(m, l, B, T, pa);
+        }
         gemm32(m, at, L.o_w, nullptr, x, M, D, D, D, D, D, EPI_RESID_F32);
         launch_rmsnorm_f32(x, nullptr, L.post_norm, xn, M, D, c.rms_eps, m->st);
         gemm32(m, xn, L.gu_w, nullptr, h, M, 2 * F, D, D, D, F, EPI_SWIGLU);
@@ -1197,6 +1230,14 @@ void run_prefill_layers(vc_model* m, const KvTarget& kv, int B, int S, int l0 = 
             aa.mask_stride = c.max_positions;
         }
         launch_attention(aa, m->st);
+        if (m->attn_out) {
+            AttnProbsArgs pa{};
+            pa.q_hi = m->q.as<bf16_t>();
+            pa.k_hi = kcache(m, kv, l);
+            pa.q_stride = S;
+            pa.kv_stride = kv.capS;
+            emit_attentions(m, l, B, S, pa);
+        }
         if (f8) gemm_f8(m, m->attn.as<bf16_t>(), L.o_q, L.o_s, m->x.p, M, D, D, D, EPI_RESID_F32);
         else gemm(m, m->attn.as<bf16_t>(), L.o_w, nullptr, m->x.p, M, D, D, D, EPI_RESID_F32);
         if (f8) launch_rmsnorm_q8(m->x.as<float>(), L.post_norm, m->a8.as<uint8_t>(), m->a8_scale.as<float>(), M, D, c.rms_eps, m->st);
@@ -1244,6 +1285,16 @@ void run_prefill_layers_split(vc_model* m, const KvTarget& kv, int B, int S, int
             aa.mask_stride = c.max_positions;
         }
         launch_attention(aa, m->st);
+        if (m->attn_out) {
+            AttnProbsArgs pa{};
+            pa.q_hi = qh;
+            pa.q_lo = qh + qplane;
+            pa.k_hi = kh;
+            pa.k_lo = kh + kplane;
+            pa.q_stride = S;
+            pa.kv_stride = Sr;
+            emit_attentions(m, l, B, S, pa);
+        }
         gemm_split(m, m->attn.as<bf16_t>(), L.o_w, nullptr, m->x.p, M, D, D, D, EPI_RESID_F32, ldx);
         launch_rmsnorm_split(m->x.as<float>(), nullptr, L.post_norm, m->xn.as<bf16_t>(), M, D, c.rms_eps, ldx, D, m->st);
         gemm_split(m, m->xn.as<bf16_t>(), L.gu_w, nullptr, m->h.p, M, 2 * F, D, ldh, EPI_SWIGLU, ldx, F);
@@ -1566,6 +1617,7 @@ void finish_prefill(vc_model* m, const KvTarget& kv, float* logits_all_host) {
     }
     HIPCHK(hipStreamSynchronize(m->st));  // `idx` is host memory
     m->hidden_out = nullptr;               // one-shot
+    m->attn_out = nullptr;
 }
 
 // arm the session's own loop for the B rows just prefilled: every row at position S, step 0
@@ -1591,6 +1643,8 @@ struct OneShotReset {
         m->mask_next.clear();
         m->hidden_out = nullptr;
         m->hidden_cap = 0;
+        m->attn_out = nullptr;
+        m->attn_cap = 0;
     }
 };
 
@@ -2018,6 +2072,15 @@ VC_API int vc_request_hidden_states(vc_model* m, float* out, size_t cap_floats) 
     if (!m) return VC_ERR_INVALID;
     m->hidden_out = out;
     m->hidden_cap = out ? cap_floats : 0;
+    return VC_OK;
+}
+
+/* output_attentions for the NEXT vc_prefill (one-shot): `out` (host, cap_floats floats) receives [layers, B, heads, S, S] fp32,
+ * the attention probabilities of every decoder layer (zeros above the diagonal and at hidden keys) */
+VC_API int vc_request_attentions(vc_model* m, float* out, size_t cap_floats) {
+    if (!m) return VC_ERR_INVALID;
+    m->attn_out = out;
+    m->attn_cap = out ? cap_floats : 0;
     return VC_OK;
 }
 

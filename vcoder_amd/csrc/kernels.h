@@ -315,6 +315,22 @@ struct AttnF32Args {
     int mask_stride;
 };
 void launch_attention_f32(const AttnF32Args& a, hipStream_t s);
+// output_attentions (diagnostic): probabilities [B, H, T, T] fp32 of a causal prefill layer from its q / k — fp32 (q32 / k32),
+// bf16 (q_hi / k_hi) or bf16 hi + lo planes
+struct AttnProbsArgs {
+    const float* q32;      // [B,H,q_stride,hd] or nullptr
+    const bf16_t* q_hi;    // used when q32 == nullptr
+    const bf16_t* q_lo;    // nullptr: none
+    const float* k32;      // [B,H,kv_stride,hd] or nullptr
+    const bf16_t* k_hi;
+    const bf16_t* k_lo;
+    float* out;            // [B,H,T,T]
+    int B, H, T, hd, q_stride, kv_stride;   // T <= 4096
+    float scale;
+    const uint8_t* key_mask;
+    int mask_stride;
+};
+void launch_attn_probs(const AttnProbsArgs& a, hipStream_t s);
 struct QkvF32Args {
     const float* qkv;  // [B*T, 3*H*hd]
     float* q;          // [B,H,q_stride,hd]

@@ -148,6 +148,59 @@ void launch_attention_f32(const AttnF32Args& a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// output_attentions: the attention PROBABILITIES of one decoder layer, [B, H, T, T] fp32 — softmax(q k^T * scale + causal
+// mask + key mask), what HF's eager attention returns as `attn_weights` ([HF] llama/modeling_llama.py eager_attention_forward
+// :191-214).  The flash kernels never materialise them; this diagnostic kernel recomputes them from the layer's q / k in
+// whatever form the precision mode keeps them: fp32, bf16, or bf16 hi + lo planes.  One wave per query row.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void attn_probs_kernel(AttnProbsArgs p) {
+    __shared__ float sc[STRICT_MAX_KEYS];
+    __shared__ float qs[128];
+    const int lane = threadIdx.x;
+    const int t = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const size_t bh = (size_t)b * p.H + h;
+    const size_t qo = (bh * p.q_stride + t) * p.hd;
+    for (int d = lane; d < p.hd; d += 64) {
+        float v;
+        if (p.q32) v = p.q32[qo + d];
+        else v = bf2f(p.q_hi[qo + d]) + (p.q_lo ? bf2f(p.q_lo[qo + d]) : 0.f);
+        qs[d] = v;
+    }
+    __syncthreads();
+    const uint8_t* km = p.key_mask != nullptr ? p.key_mask + (size_t)b * p.mask_stride : nullptr;
+    const int nkeys = t + 1;   // causal prefill from position 0
+    float mx = -INFINITY;
+    for (int key = lane; key < nkeys; key += 64) {
+        const size_t ko = (bh * p.kv_stride + key) * p.hd;
+        float s = 0.f;
+        if (p.k32) {
+            for (int d = 0; d < p.hd; ++d) s = fmaf(qs[d], p.k32[ko + d], s);
+        } else {
+            for (int d = 0; d < p.hd; ++d) s = fmaf(qs[d], bf2f(p.k_hi[ko + d]) + (p.k_lo ? bf2f(p.k_lo[ko + d]) : 0.f), s);
+        }
+        s *= p.scale;
+        if (km != nullptr && km[key] == 0) s = -INFINITY;
+        sc[key] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int key = lane; key < nkeys; key += 64) {
+        const float e = expf(sc[key] - mx);
+        sc[key] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    __syncthreads();
+    float* o = p.out + (bh * p.T + t) * (size_t)p.T;
+    const float inv = 1.0f / sum;
+    for (int key = lane; key < p.T; key += 64) o[key] = key < nkeys ? sc[key] * inv : 0.f;
+}
+void launch_attn_probs(const AttnProbsArgs& a, hipStream_t s) {
+    VC_LAUNCH(attn_probs_kernel, dim3(a.T, a.H, a.B), dim3(64), 0, s, a);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // head split + RoPE + cache write, fp32: qkv [B*T, 3D] -> q [B,H,q_stride,hd], k/v caches [B,H,kv_stride,hd] at pos0+t
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void qkv_rope_f32_kernel(QkvF32Args p) {

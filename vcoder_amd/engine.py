@@ -295,13 +295,17 @@ class HipEngine:
         return out[: B * S.value * self.cfg.hidden_size].reshape(B, S.value, self.cfg.hidden_size).copy()
 
     def prefill(self, input_ids, images, segs=None, depths=None, has_attention_mask: bool = False,
-                all_logits: bool = False, reserve: Optional[int] = None, attention_mask=None, hidden_states: bool = False):
+                all_logits: bool = False, reserve: Optional[int] = None, attention_mask=None, hidden_states: bool = False,
+                attentions: bool = False):
         """-> (logits_last [B,V], logits_all [B,S,V] or None, S).  reserve: decode_step calls the caller intends to make
         (sizes the KV cache up front; a longer loop still works — the cache grows).  attention_mask [B,T]: padded batches —
         hidden positions are hidden as keys in this prefill and in the decode_step loop behind it (clear_attention_mask() ends
         that)."""
         ids = self._ids(input_ids)
         B, T = ids.shape
+        # output_attentions is sized exactly: the spliced length comes from a splice-only pass (before any one-shot request of
+        # THIS call is announced — that pass would consume them)
+        S_att = self.inputs_embeds(ids, images, segs, depths).shape[1] if attentions else 0
         has_attention_mask = self._announce_mask(attention_mask, B, T) or has_attention_mask
         if reserve is not None:
             self._check(self.lib.vc_model_reserve_decode(self._model, int(reserve)))
@@ -309,8 +313,11 @@ class HipEngine:
         V = self.cfg.vocab_size
         last = np.empty((B, V), dtype=np.float32)
         S = C.c_int(0)
-        self.last_hidden_states = None
-        hid = None
+        self.last_hidden_states = self.last_attentions = None
+        hid = att = None
+        if attentions:      # [L, B, H, S, S]
+            att = np.empty((self.cfg.num_hidden_layers, B, self.cfg.num_attention_heads, S_att, S_att), dtype=np.float32)
+            self._check(self.lib.vc_request_attentions(self._model, att.ctypes.data_as(C.c_void_p), C.c_size_t(att.size)))
         if hidden_states:   # [(L + 1), B, S, D] for the worst-case S; trimmed below
             rows_ = self.cfg.num_patches + (1 if self.cfg.mm_vision_select_feature == "cls_patch" else 0)
             worst_ = T + rows_ * self._max_feature_blocks(ids)
@@ -322,6 +329,7 @@ class HipEngine:
             self.last_S = S.value
             self._cur_batch = B
             self._keep_hidden(hid, B, S.value)
+            self.last_attentions = att
             return last, None, S.value
         rows = self.cfg.num_patches + (1 if self.cfg.mm_vision_select_feature == "cls_patch" else 0)
         worst = T + rows * self._max_feature_blocks(ids)
@@ -332,7 +340,10 @@ class HipEngine:
         self.last_S = S.value
         self._cur_batch = B
         self._keep_hidden(hid, B, S.value)
+        self.last_attentions = att
         return last, full[: B * S.value * V].reshape(B, S.value, V).copy(), S.value
+
+    last_attentions = None
 
     def _keep_hidden(self, hid, B, S):
         """hidden states of the last prefill(hidden_states=True): [(L + 1), B, S, D] (the device packs them for the true S)"""

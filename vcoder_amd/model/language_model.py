@@ -214,8 +214,6 @@ class _HipCausalLMBase:
         if input_ids is None:
             raise ValueError("You must specify exactly one of input_ids or inputs_embeds (the reference discards a caller's "
                              "inputs_embeds: vcoder_ds_llava_llama.py:79)")
-        if output_attentions:
-            raise NotImplementedError("attention maps are not materialised by the flash kernels")
         ids = input_ids
         B = ids.shape[0]
         if past_key_values is not None and ids.shape[1] == 1:
@@ -226,9 +224,9 @@ class _HipCausalLMBase:
             # With images the reference REPLACES the mask by ones here (vcoder_ds_llava_arch.py:130-133): keys a padded
             # prefill hid become visible.  Without images the caller's mask goes through to LlamaModel: the engine keeps the
             # prefill's hidden keys hidden (new positions are visible, as HF's generate loop appends ones).
-            if output_hidden_states:
-                raise NotImplementedError("hidden states of a cached decode step are not materialised by the fused step kernels "
-                                          "(prefill forward() returns them)")
+            if output_hidden_states or output_attentions:
+                raise NotImplementedError("hidden states / attention maps of a cached decode step are not materialised by the "
+                                          "fused step kernels (the prefill forward() returns them)")
             if images is not None or attention_mask is None:
                 self.engine.clear_attention_mask()
             lg, _ = self.engine.decode_step(tok)
@@ -244,7 +242,7 @@ class _HipCausalLMBase:
                                              (depths if self.variant == "vcoder_ds" else None) if images is not None else None,
                                              all_logits=True, reserve=self._decode_reserve,
                                              attention_mask=attention_mask if images is not None else None,
-                                             hidden_states=bool(output_hidden_states))
+                                             hidden_states=bool(output_hidden_states), attentions=bool(output_attentions))
             if images is None and attention_mask is not None and not _all_ones(attention_mask):
                 raise NotImplementedError("a padded TEXT-ONLY batch (attention_mask with zeros, images=None) is outside the "
                                           "VCoder hot path")
@@ -257,8 +255,11 @@ class _HipCausalLMBase:
         if output_hidden_states and self.engine.last_hidden_states is not None:
             # the tuple LlamaModel.forward returns: inputs_embeds, every layer's output, the last one after the final norm
             hs = tuple(torch.from_numpy(h) for h in self.engine.last_hidden_states)
+        at = None
+        if output_attentions and self.engine.last_attentions is not None:
+            at = tuple(torch.from_numpy(a) for a in self.engine.last_attentions)     # L tensors [B, H, S, S]
         out = CausalLMOutputWithPast(loss=None, logits=logits, past_key_values=pkv if use_cache is not False else None,
-                                     hidden_states=hs)
+                                     hidden_states=hs, attentions=at)
         if return_dict is False:
             return (out.logits,) + ((out.past_key_values,) if out.past_key_values is not None else ())
         return out
