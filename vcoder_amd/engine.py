@@ -315,33 +315,30 @@ class HipEngine:
         S = C.c_int(0)
         self.last_hidden_states = self.last_attentions = None
         hid = att = None
-        if attentions:      # [L, B, H, S, S]
-            att = np.empty((self.cfg.num_hidden_layers, B, self.cfg.num_attention_heads, S_att, S_att), dtype=np.float32)
-            self._check(self.lib.vc_request_attentions(self._model, att.ctypes.data_as(C.c_void_p), C.c_size_t(att.size)))
-        if hidden_states:   # [(L + 1), B, S, D] for the worst-case S; trimmed below
-            rows_ = self.cfg.num_patches + (1 if self.cfg.mm_vision_select_feature == "cls_patch" else 0)
-            worst_ = T + rows_ * self._max_feature_blocks(ids)
-            hid = np.empty(((self.cfg.num_hidden_layers + 1) * B * worst_ * self.cfg.hidden_size,), dtype=np.float32)
-            self._check(self.lib.vc_request_hidden_states(self._model, hid.ctypes.data_as(C.c_void_p), C.c_size_t(hid.size)))
-        if not all_logits:
-            self._check(self.lib.vc_prefill(self._model, ids.ctypes.data_as(C.c_void_p), B, T, pi, ps, pd, on_dev,
-                                            int(has_attention_mask), last.ctypes.data_as(C.c_void_p), None, C.byref(S)))
-            self.last_S = S.value
-            self._cur_batch = B
-            self._keep_hidden(hid, B, S.value)
-            self.last_attentions = att
-            return last, None, S.value
         rows = self.cfg.num_patches + (1 if self.cfg.mm_vision_select_feature == "cls_patch" else 0)
         worst = T + rows * self._max_feature_blocks(ids)
-        full = np.empty((B * worst * V,), dtype=np.float32)
-        self._check(self.lib.vc_prefill(self._model, ids.ctypes.data_as(C.c_void_p), B, T, pi, ps, pd, on_dev,
-                                        int(has_attention_mask), last.ctypes.data_as(C.c_void_p),
-                                        full.ctypes.data_as(C.c_void_p), C.byref(S)))
+        full = np.empty((B * worst * V,), dtype=np.float32) if all_logits else None
+        try:
+            if attentions:      # [L, B, H, S, S]
+                att = np.empty((self.cfg.num_hidden_layers, B, self.cfg.num_attention_heads, S_att, S_att), dtype=np.float32)
+                self._check(self.lib.vc_request_attentions(self._model, att.ctypes.data_as(C.c_void_p), C.c_size_t(att.size)))
+            if hidden_states:   # [(L + 1), B, S, D] for the worst-case S; trimmed below
+                hid = np.empty(((self.cfg.num_hidden_layers + 1) * B * worst * self.cfg.hidden_size,), dtype=np.float32)
+                self._check(self.lib.vc_request_hidden_states(self._model, hid.ctypes.data_as(C.c_void_p), C.c_size_t(hid.size)))
+            self._check(self.lib.vc_prefill(self._model, ids.ctypes.data_as(C.c_void_p), B, T, pi, ps, pd, on_dev,
+                                            int(has_attention_mask), last.ctypes.data_as(C.c_void_p),
+                                            full.ctypes.data_as(C.c_void_p) if all_logits else None, C.byref(S)))
+        except BaseException:
+            # the library forgets its one-shot requests when vc_prefill returns (error or not); a failure BEFORE that call must
+            # not leave it holding pointers into buffers that are about to be freed
+            self.lib.vc_request_attentions(self._model, None, C.c_size_t(0))
+            self.lib.vc_request_hidden_states(self._model, None, C.c_size_t(0))
+            raise
         self.last_S = S.value
         self._cur_batch = B
         self._keep_hidden(hid, B, S.value)
         self.last_attentions = att
-        return last, full[: B * S.value * V].reshape(B, S.value, V).copy(), S.value
+        return last, (full[: B * S.value * V].reshape(B, S.value, V).copy() if all_logits else None), S.value
 
     last_attentions = None
 
