@@ -440,6 +440,14 @@ def _split_ref(qkv, B, T, H, hd, rope, pos0=0):
     return bf16_round(q.numpy()), bf16_round(k.numpy()), v.numpy()
 
 
+def vt_key_pos(Ts):
+    """key order of the flash kernel's V^T scratch (csrc/attn.hip vt_chunk_key0): stored[..., p] = natural[..., vt_key_pos(Ts)[p]];
+    inside every aligned 32-key block position 8c + e holds key 4c + (e & 3) + 16 (e >> 2)."""
+    pos = np.arange(Ts)
+    c, e = (pos % 32) // 8, pos % 8
+    return (pos // 32) * 32 + 4 * c + (e & 3) + 16 * (e >> 2)
+
+
 def check_qkv_split(be, B, T, H, hd, rope):
     rng = np.random.RandomState(6)
     D = H * hd
@@ -455,8 +463,10 @@ def check_qkv_split(be, B, T, H, hd, rope):
     assert np.abs(gk[:, :, :T] - rk).max() <= 2 ** -7 * np.abs(rk).max()
     if not rope:
         assert np.array_equal(gq[:, :, :T], rq) and np.array_equal(gk[:, :, :T], rk)
-    assert np.array_equal(gv[:, :, :, :T], rv.transpose(0, 1, 3, 2))
-    assert not gv[:, :, :, T:].any() and not gq[:, :, T:].any()
+    rvt = np.zeros_like(gv)
+    rvt[:, :, :, :T] = rv.transpose(0, 1, 3, 2)
+    assert np.array_equal(gv, rvt[..., vt_key_pos(Ts)])              # the scratch's key order; zeros behind T
+    assert not gq[:, :, T:].any()
     # the LLM prefill form: K and V rows into a cache of S_cap keys, V^T into a scratch of its own stride
     S_cap = Ts + 64
     k2, v2 = be.zeros((B, H, S_cap, hd), "bf16"), be.zeros((B, H, S_cap, hd), "bf16")
@@ -483,6 +493,7 @@ def check_attention(be, B, H, T, hd, causal, seed=0, spike=False):
     qp[:, :, :T], kp[:, :, :T], vtp[:, :, :, :T] = q, k, v.transpose(0, 1, 3, 2)
     out = be.zeros((B * T, H * hd), "bf16")
     scale = 1.0 / math.sqrt(hd)
+    vtp = vtp[..., vt_key_pos(Ts)]
     _call(be, "vck_attention", be.bf16(qp), be.bf16(kp), be.bf16(vtp), out, B, H, T, hd, Ts, Ts, int(causal), scale)
     ref = cpu_ref.softmax_attention(torch.from_numpy(q), torch.from_numpy(k), torch.from_numpy(v), scale, causal,
                                     cpu_ref.Rounder(True))
@@ -1110,8 +1121,10 @@ def check_qkv_split32_and_attention_split(be, B, H, T, hd, causal, rope=True, se
     for (h_, l_), ref_ in (((qh, ql), q), ((kh, kl), k)):
         g_ = be.host_f32(h_)[:, :, :T].astype(np.float64) + be.host_f32(l_)[:, :, :T].astype(np.float64)
         assert np.abs(g_ - ref_.numpy()).max() < 2e-5 * max(1.0, float(ref_.abs().max()))
-    gvt = be.host_f32(vh)[..., :T].astype(np.float64) + be.host_f32(vl)[..., :T].astype(np.float64)
-    assert np.abs(gvt - v.numpy().transpose(0, 1, 3, 2)).max() < 2e-5 * float(v.abs().max())
+    gvt = be.host_f32(vh).astype(np.float64) + be.host_f32(vl).astype(np.float64)     # the scratch's key order (vt_key_pos)
+    rvt = np.zeros_like(gvt)
+    rvt[..., :T] = v.numpy().transpose(0, 1, 3, 2)
+    assert np.abs(gvt - rvt[..., vt_key_pos(Ts)]).max() < 2e-5 * float(v.abs().max())
     scale = 1.0 / math.sqrt(hd)
     ldo = 2 * D + 64
     out = be.zeros((B * T, ldo), "bf16")

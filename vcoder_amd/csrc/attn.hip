@@ -1,6 +1,7 @@
 // attn.hip — attention for the VCoder hot path on gfx950.
 //
-//   qkv_split   : fused-QKV GEMM output -> Q [B,H,Tq,hd], K cache [B,H,S,hd], V^T cache [B,H,hd,S] (+RoPE)
+//   qkv_split   : fused-QKV GEMM output -> Q [B,H,Tq,hd], K cache [B,H,S,hd], V^T scratch [B,H,hd,S] in the flash kernel's
+//                 key order (vt_chunk_key0 below) (+RoPE)
 //                 RoPE = rotate_half form of [HF] llama/modeling_llama.py:113-160 (cos/sin fp32 table)      K13/K14
 //   attention   : flash-style softmax(Q K^T * scale [+causal]) V, fp32 online softmax, MFMA 16x16x32 bf16
 //                 ViT: [HF] clip/modeling_clip.py:259-277,320-330 (non-causal, hd 64, T 577)              K5
@@ -18,6 +19,13 @@
 #include "kernels.h"
 
 namespace vc {
+
+// Key order of the V^T scratch (the flash kernel's A operand of O^T = V^T P^T).  Inside every aligned block of 32 keys the
+// 16-byte chunk c (0..3) of a row holds keys {4c..4c+3, 16+4c..16+4c+3}: position 8c + e <-> key 4c + (e & 3) + 16 (e >> 2)
+// (vt_key_pos in tests/kernel_cases.py).  That is the order in which the S^T accumulators of a lane (MFMA C layout: sub-tile
+// `sub`, lane group g, register r <-> key 16 sub + 4g + r) are packed into the P operand, so a lane's 8 contraction values of
+// a 32-key half are one contiguous chunk.  The scratch is written and read only by the kernels of this file.
+VC_DEV int vt_chunk_key0(int chunk_in_tile) { return (chunk_in_tile >> 2) * 32 + (chunk_in_tile & 3) * 4; }
 
 // =============================================================================================
 // qkv split (+RoPE), prefill form: one workgroup = (64-token tile, head, batch)
@@ -74,11 +82,14 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(QkvSplitArgs p) {
     __syncthreads();
     for (int w = tid; w < HD * 8; w += 256) {
         const int d = w >> 3, tc = w & 7;
-        if (t0 + tc * 8 >= p.T) continue;
+        const int k0 = vt_chunk_key0(tc);      // chunk tc of the tile holds keys k0..k0+3 and k0+16..k0+19 (vt_key_pos)
+        if (t0 + k0 >= p.T) continue;
         uint32_t o[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            o[e] = (uint32_t)vt_tile[tc * 8 + 2 * e][d] | ((uint32_t)vt_tile[tc * 8 + 2 * e + 1][d] << 16);
+        for (int e = 0; e < 4; ++e) {
+            const int key = k0 + (e >> 1) * 16 + (e & 1) * 2;
+            o[e] = (uint32_t)vt_tile[key][d] | ((uint32_t)vt_tile[key + 1][d] << 16);
+        }
         st16(p.vt + (((size_t)b * p.H + h) * HD + d) * vts + t0 + tc * 8, u32x4{o[0], o[1], o[2], o[3]});
     }
 }
@@ -165,11 +176,14 @@ __global__ __launch_bounds__(256) void qkv_split32_kernel(QkvSplit32Args p) {
     __syncthreads();
     for (int w = tid; w < 2 * HD * 8; w += 256) {
         const int pl = w / (HD * 8), d = (w >> 3) % HD, tc = w & 7;
-        if (t0 + tc * 8 >= p.T) continue;
+        const int k0 = vt_chunk_key0(tc);
+        if (t0 + k0 >= p.T) continue;
         uint32_t o[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            o[e] = (uint32_t)vt_tile[pl][tc * 8 + 2 * e][d] | ((uint32_t)vt_tile[pl][tc * 8 + 2 * e + 1][d] << 16);
+        for (int e = 0; e < 4; ++e) {
+            const int key = k0 + (e >> 1) * 16 + (e & 1) * 2;
+            o[e] = (uint32_t)vt_tile[pl][key][d] | ((uint32_t)vt_tile[pl][key + 1][d] << 16);
+        }
         st16((pl ? p.vt_lo : p.vt_hi) + (bh * HD + d) * p.vt_stride + t0 + tc * 8, u32x4{o[0], o[1], o[2], o[3]});
     }
 }
@@ -350,10 +364,12 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && QS == 1 && !SPLIT) ? 4 :
 #pragma unroll
             for (int sub = 1; sub < 4; ++sub)
                 mx = fmaxf(mx, fmaxf(fmaxf(sacc[qs][sub][0], sacc[qs][sub][1]), fmaxf(sacc[qs][sub][2], sacc[qs][sub][3])));
-            mx = fmaxf(mx, shfl_xor(mx, 16));
-            mx = fmaxf(mx, shfl_xor(mx, 32));
+            mx = rows_max(mx);
             const float m_new = fmaxf(m_run[qs], mx);               // raw-score units; finite from the first tile on (key 0)
-            const float alpha = fast_exp2((m_run[qs] - m_new) * c2);  // first tile: exp2(-inf) = 0
+            // the running maximum of a query settles after a few tiles; when no query of the sub-tile raised it, alpha is
+            // exactly 1 and the rescale of O and l is skipped (a wave-uniform branch; the result is the same bits)
+            const bool grew = wave_any(m_new > m_run[qs]);
+            const float alpha = grew ? fast_exp2((m_run[qs] - m_new) * c2) : 1.0f;  // first tile: exp2(-inf) = 0
             m_run[qs] = m_new;
             const float mc = m_new * c2;
             float rs = 0.f;
@@ -365,9 +381,12 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && QS == 1 && !SPLIT) ? 4 :
                     sacc[qs][sub][r] = e;
                     rs += e;
                 }
-            l_run[qs] = l_run[qs] * alpha + rs;
+            if (grew) {
+                l_run[qs] = l_run[qs] * alpha;
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) o[qs][dt] = o[qs][dt] * alpha;
+                for (int dt = 0; dt < DT; ++dt) o[qs][dt] = o[qs][dt] * alpha;
+            }
+            l_run[qs] += rs;
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh)
                 pb[qs][kh] = u32x4{pack_bf2(sacc[qs][2 * kh][0], sacc[qs][2 * kh][1]),
@@ -385,22 +404,20 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && QS == 1 && !SPLIT) ? 4 :
                     }
             }
         }
-        // ---- O^T += V^T P^T   (contraction slot (g,e) <-> key kh*32 + (e>>2)*16 + 4g + (e&3) on both operands)
+        // ---- O^T += V^T P^T   (contraction slot (g,e) <-> key kh*32 + (e>>2)*16 + 4g + (e&3) on both operands: the V^T scratch
+        // stores the keys of every 32-key block in exactly that order, so a lane's 8 contraction values are ONE 16-byte chunk —
+        // one conflict-free ds_read_b128 per MFMA.  Two 8-byte reads of a key-ordered tile were merged by the compiler into
+        // ds_read2st64_b64, which banks mod 32 in contiguous 16-lane groups: 39 % of the kernel's LDS cycles were conflicts)
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh) {
                 const int row = dt * 16 + j;
-                const int c0 = kh * 4 + (g >> 1), within = (g & 1) * 8;
-                const u32x2 lo = ld8(v_lds + swz_v(row, c0) + within);
-                const u32x2 hi = ld8(v_lds + swz_v(row, c0 + 2) + within);
-                const u32x4 vf = {lo[0], lo[1], hi[0], hi[1]};
+                const u32x4 vf = ld16(v_lds + swz_v(row, kh * 4 + g));   // keys 32 kh + {4g..4g+3, 16+4g..16+4g+3}: vt_key_pos
 #pragma unroll
                 for (int qs = 0; qs < QS; ++qs) o[qs][dt] = mfma16(vf, pb[qs][kh], o[qs][dt]);
                 if constexpr (SPLIT) {
-                    const u32x2 llo = ld8(v_lds + VB_ + swz_v(row, c0) + within);
-                    const u32x2 lhi = ld8(v_lds + VB_ + swz_v(row, c0 + 2) + within);
-                    const u32x4 vl = {llo[0], llo[1], lhi[0], lhi[1]};
+                    const u32x4 vl = ld16(v_lds + VB_ + swz_v(row, kh * 4 + g));
 #pragma unroll
                     for (int qs = 0; qs < QS; ++qs) {
                         o[qs][dt] = mfma16(vf, pbl[qs][kh], o[qs][dt]);

@@ -136,6 +136,34 @@ VC_DEV float wave_max(float v) {
     return v;
 }
 
+// All-reduce (max) over the four 16-lane rows of a wave — lanes l, l^16, l^32, l^48 — which is how the 16x16 MFMA accumulator
+// layouts spread one matrix column.  gfx950's v_permlane16_swap / v_permlane32_swap exchange rows inside the VALU: with both
+// operands holding v, the pair afterwards holds (row 2k, row 2k+1) resp. (half 0, half 1) of v in every lane, so the maximum of
+// the pair is the reduction — no ds_bpermute round trip through the LDS pipe (two of them sat on the flash kernel's per-tile
+// critical path).  wave_any: a wave-uniform "does any lane ...".
+#ifdef VC_EMU
+VC_DEV float rows_max(float v) {
+    v = fmaxf(v, shfl_xor(v, 16));
+    return fmaxf(v, shfl_xor(v, 32));
+}
+VC_DEV bool wave_any(bool pred) {
+    int x = pred ? 1 : 0;
+    for (int m = 32; m >= 1; m >>= 1) x |= shfl_xor(x, m);
+    return x != 0;
+}
+#else
+VC_DEV float rows_max(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    asm("v_max_f32 %0, %1, %2" : "=v"(a) : "v"(a), "v"(b));
+    b = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    asm("v_max_f32 %0, %1, %2" : "=v"(a) : "v"(a), "v"(b));
+    return a;
+}
+VC_DEV bool wave_any(bool pred) { return __builtin_amdgcn_ballot_w64(pred) != 0; }
+#endif
+
 // 16-byte global/LDS accessors on raw pointers
 VC_DEV u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 VC_DEV void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
