@@ -103,7 +103,8 @@ def test_qkv_split(be, B, T, H, hd, rope):
 
 
 @pytest.mark.parametrize("B,H,T,hd,causal,spike", [(1, 1, 17, 64, False, False), (1, 2, 150, 64, False, True),
-                                                   (1, 1, 70, 128, True, False), (1, 1, 200, 128, True, True)])
+                                                   (1, 1, 70, 128, True, False), (1, 1, 200, 128, True, True),
+                                                   (2, 4, 300, 128, True, True), (4, 2, 150, 64, False, False)])  # B H % 8 == 0: XCD-grouped order
 def test_attention(be, B, H, T, hd, causal, spike):
     kc.check_attention(be, B, H, T, hd, causal, spike=spike)
 

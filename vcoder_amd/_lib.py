@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libvcoder_hip.so")
+# VCODER_HIP_LIB: another build of the same library (kernel A/B experiments, tools/experiments/); default = the in-tree build
+LIB_PATH = os.environ.get("VCODER_HIP_LIB") or os.path.join(HERE, "lib", "libvcoder_hip.so")
 
 VC_OK, VC_IGNORED = 0, 1
 VC_ERR_INVALID, VC_ERR_HIP, VC_ERR_STATE, VC_ERR_INDEX, VC_ERR_UNEQUAL = -1, -2, -3, -4, -5

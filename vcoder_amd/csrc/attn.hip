@@ -232,7 +232,28 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && QS == 1 && !SPLIT) ? 4 :
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, j = lane & 15;
-    const int q0 = blockIdx.x * QB, h = blockIdx.y, b = blockIdx.z;
+    // Workgroup order.  sched 0: the 3-D grid as launched (query block fastest).  Otherwise a 1-D grid whose linear id — the
+    // hardware hands consecutive ids to consecutive XCDs — is mapped so that (1, 3) every XCD owns a contiguous range of
+    // (b, h) pairs: the query blocks of a head run on ONE XCD and its K / V^T tiles are fetched into that L2 once, not into
+    // eight; and (1, 2) the query blocks of a causal pass are taken heaviest first (block i has ~2 (i + 1) KV tiles), so the
+    // launch ends on the light ones instead of a few 19-tile stragglers.
+    int qb_ = blockIdx.x, h_ = blockIdx.y, b_ = blockIdx.z;
+    if (p.sched != 0) {
+        const int lin = blockIdx.x, BH = p.B * p.H;
+        int head, qr;
+        if (p.sched == 2) {
+            head = lin % BH;
+            qr = lin / BH;
+        } else {
+            const int xcd = lin & 7, r = lin >> 3, per = BH >> 3;   // the launcher checks BH % 8 == 0
+            head = xcd * per + r / p.nqb;
+            qr = r % p.nqb;
+        }
+        qb_ = (CAUSAL && p.sched != 3) ? p.nqb - 1 - qr : qr;
+        h_ = head % p.H;
+        b_ = head / p.H;
+    }
+    const int q0 = qb_ * QB, h = h_, b = b_;
     const size_t bh = (size_t)b * p.H + h;
     const bf16_t* qbase = p.q + bh * p.q_stride * HD;
     const bf16_t* kbase = p.k + bh * p.kv_stride * HD;
@@ -352,23 +373,43 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && QS == 1 && !SPLIT) ? 4 :
                 // sequence, exactly as the additive mask HF builds from the 2-D mask ([HF] llama/modeling_llama.py causal mask +
                 // padding mask); key 0 of a sequence is always visible (the engine checks), so the running maximum is finite
                 const uint8_t* km = p.key_mask != nullptr ? p.key_mask + (size_t)b * p.mask_stride : nullptr;
+                if (km == nullptr) {   // the common case: sixteen selects, no branches
 #pragma unroll
-                for (int sub = 0; sub < 4; ++sub)
+                    for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = k0 + sub * 16 + g * 4 + r;
-                        if (key >= p.T || (CAUSAL && key > query) || (km != nullptr && km[key] == 0)) sacc[qs][sub][r] = -INFINITY;
-                    }
+                        for (int r = 0; r < 4; ++r) {
+                            const int key = k0 + sub * 16 + g * 4 + r;
+                            const bool hide = key >= p.T || (CAUSAL && key > query);
+                            sacc[qs][sub][r] = hide ? -INFINITY : sacc[qs][sub][r];
+                        }
+                } else {
+#pragma unroll
+                    for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int key = k0 + sub * 16 + g * 4 + r;
+                            if (key >= p.T || (CAUSAL && key > query) || km[key] == 0) sacc[qs][sub][r] = -INFINITY;
+                        }
+                }
             }
-            float mx = fmaxf(fmaxf(sacc[qs][0][0], sacc[qs][0][1]), fmaxf(sacc[qs][0][2], sacc[qs][0][3]));
-#pragma unroll
-            for (int sub = 1; sub < 4; ++sub)
-                mx = fmaxf(mx, fmaxf(fmaxf(sacc[qs][sub][0], sacc[qs][sub][1]), fmaxf(sacc[qs][sub][2], sacc[qs][sub][3])));
+            // v_max3 on the raw accumulators (fmaxf would canonicalise every MFMA output first: 16 extra VALU per tile)
+            float mx = vmax3(sacc[qs][0][0], sacc[qs][0][1], sacc[qs][0][2]);
+            mx = vmax3(mx, sacc[qs][0][3], sacc[qs][1][0]);
+            mx = vmax3(mx, sacc[qs][1][1], sacc[qs][1][2]);
+            mx = vmax3(mx, sacc[qs][1][3], sacc[qs][2][0]);
+            mx = vmax3(mx, sacc[qs][2][1], sacc[qs][2][2]);
+            mx = vmax3(mx, sacc[qs][2][3], sacc[qs][3][0]);
+            mx = vmax3(mx, sacc[qs][3][1], sacc[qs][3][2]);
+            mx = vmax2(mx, sacc[qs][3][3]);
             mx = rows_max(mx);
-            const float m_new = fmaxf(m_run[qs], mx);               // raw-score units; finite from the first tile on (key 0)
-            // the running maximum of a query settles after a few tiles; when no query of the sub-tile raised it, alpha is
-            // exactly 1 and the rescale of O and l is skipped (a wave-uniform branch; the result is the same bits)
-            const bool grew = wave_any(m_new > m_run[qs]);
+            // Deferred maximum: the reference point m of exp(scale * (s - m)) only has to keep the exponentials in range, it
+            // need not BE the maximum.  It moves (and O, l are rescaled) only when some query of the sub-tile exceeds it by more
+            // than DEFER — a wave-uniform branch that is rarely taken once the first tiles are done; in between P <= e^8, exact
+            // in fp32 and with the same relative bf16 rounding.  Precision mode "split" keeps the threshold at 0: the reference
+            // point is then the running maximum itself and skipping the no-op rescale (alpha == 1) changes no bit.
+            constexpr float DEFER = SPLIT ? 0.f : 11.5f;            // in log2 units: e^8
+            const bool grew = wave_any((mx - m_run[qs]) * c2 > DEFER);   // first tile: m_run = -inf
+            const float m_new = grew ? vmax2(m_run[qs], mx) : m_run[qs];   // raw-score units; finite from the first tile on (key 0)
             const float alpha = grew ? fast_exp2((m_run[qs] - m_new) * c2) : 1.0f;  // first tile: exp2(-inf) = 0
             m_run[qs] = m_new;
             const float mc = m_new * c2;
@@ -450,17 +491,31 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && QS == 1 && !SPLIT) ? 4 :
     }
 }
 
+// VC_ATTN_SCHED (see attention_kernel): 0 = plain 3-D grid, 1 = XCD-grouped heads + heaviest query block first, 2 = heaviest
+// first only, 3 = XCD-grouped only; unset = by shape
+static dim3 attention_grid(AttnArgs& a, int QB) {
+    // measured (profiles/r03_l_*): causal prefill shape 2 < 3 < 0 = 1 (165-175 / 179-187 / 186-200 us); ViT shape 3 < 0 < 2
+    // (78-85 / 85-92 / 88-94 us) — the default is 2 for a causal pass, 3 otherwise
+    static const int sched_env = getenv("VC_ATTN_SCHED") ? atoi(getenv("VC_ATTN_SCHED")) : -1;
+    a.nqb = (a.T + QB - 1) / QB;
+    a.sched = sched_env >= 0 ? sched_env : (a.causal ? 2 : 3);
+    if ((a.sched == 1 || a.sched == 3) && (a.B * a.H) % 8 != 0) a.sched = a.sched == 1 ? 2 : 0;
+    return a.sched ? dim3(a.nqb * a.H * a.B) : dim3(a.nqb, a.H, a.B);
+}
+
 template <int HD, int WAVES, int QS>
-static void launch_attention_v(const AttnArgs& a, hipStream_t s) {
+static void launch_attention_v(const AttnArgs& a0, hipStream_t s) {
     const int QB = WAVES * QS * 16;
-    const dim3 grid((a.T + QB - 1) / QB, a.H, a.B), block(WAVES * 64);
+    AttnArgs a = a0;
+    const dim3 grid = attention_grid(a, QB), block(WAVES * 64);
     if (a.causal) VC_LAUNCH((attention_kernel<HD, true, WAVES, QS>), grid, block, 0, s, a);
     else VC_LAUNCH((attention_kernel<HD, false, WAVES, QS>), grid, block, 0, s, a);
 }
 
 template <int HD>
-static void launch_attention_split(const AttnArgs& a, hipStream_t s) {
-    const dim3 grid((a.T + 127) / 128, a.H, a.B), block(512);
+static void launch_attention_split(const AttnArgs& a0, hipStream_t s) {
+    AttnArgs a = a0;
+    const dim3 grid = attention_grid(a, 128), block(512);
     constexpr size_t shmem = 2 * 2 * (64 * HD * 2 + HD * 128);   // [2 stages][K hi | K lo | V^T hi | V^T lo]
 #ifndef VC_EMU
     static bool once = false;

@@ -171,6 +171,8 @@ struct AttnArgs {
     // attention_mask, left-extended over the spliced rows as the reference does); nullptr = no mask
     const uint8_t* key_mask;
     int mask_stride;
+    // set by the launcher: workgroup order (0 = 3-D grid as is; see attention_kernel) and query blocks per (b, h)
+    int sched, nqb;
 };
 void launch_attention(const AttnArgs& a, hipStream_t s);
 

@@ -59,7 +59,16 @@ VC_DEV bf16_t f2bf(float f) {
 #else
 VC_DEV bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }  // v_cvt_pk_bf16_f32 (RNE)
 #endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifdef VC_EMU
 VC_DEV uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+#else
+// ONE v_cvt_pk_bf16_f32 (two scalar conversions are not merged by hipcc 7.2: cvt, cvt, shift, or — 4 VALU per pair)
+typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
+VC_DEV uint32_t pack_bf2(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2_hw));
+}
+#endif
 
 // ---- fp8 (OCP e4m3fn: 1-4-3, bias 7, max 448, no inf) ----------------------------------------
 // Encode is software on both builds (load-time only; round-to-nearest-even, saturating) so the device, the emulator
@@ -141,6 +150,22 @@ VC_DEV float wave_max(float v) {
 // operands holding v, the pair afterwards holds (row 2k, row 2k+1) resp. (half 0, half 1) of v in every lane, so the maximum of
 // the pair is the reduction — no ds_bpermute round trip through the LDS pipe (two of them sat on the flash kernel's per-tile
 // critical path).  wave_any: a wave-uniform "does any lane ...".
+// max of three without the canonicalising v_max x, x hipcc puts in front of every fmaxf operand it cannot prove quiet
+#ifdef VC_EMU
+VC_DEV float vmax3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+VC_DEV float vmax2(float a, float b) { return fmaxf(a, b); }
+#else
+VC_DEV float vmax2(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+VC_DEV float vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+#endif
 #ifdef VC_EMU
 VC_DEV float rows_max(float v) {
     v = fmaxf(v, shfl_xor(v, 16));
