@@ -656,8 +656,7 @@ __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeF
             const int key = kb + u * KPW + krow;
             float s = dot(kv[u]);
             kv[u] = ld16_stream(kbase + row_off(key + BATCH));
-#pragma unroll
-            for (int mk = 1; mk < LPK; mk <<= 1) s += shfl_xor(s, mk);
+            s = lanes_sum<LPK>(s);
             if ((lane % LPK) == 0) sc[key] = (key < ctx && (kmask == nullptr || kmask[min(key, ctx - 1)] != 0)) ? s * p.scale : -INFINITY;
         }
     }

@@ -150,6 +150,31 @@ VC_DEV float wave_max(float v) {
 // operands holding v, the pair afterwards holds (row 2k, row 2k+1) resp. (half 0, half 1) of v in every lane, so the maximum of
 // the pair is the reduction — no ds_bpermute round trip through the LDS pipe (two of them sat on the flash kernel's per-tile
 // critical path).  wave_any: a wave-uniform "does any lane ...".
+// Sum over the N (4, 8, 16, 32) adjacent lanes of an aligned lane group, result in every lane.  DPP operand modifiers inside
+// the VALU adds — quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror — instead of ds_bpermute round trips
+// through the LDS pipe (what hipcc makes of __shfl_xor).  After each step all lanes of the sub-group hold the same value, so
+// taking lane 7 - i / 15 - i instead of i ^ 4 / i ^ 8 adds the same two numbers: bit-identical to the xor butterfly.
+#ifdef VC_EMU
+template <int N> VC_DEV float lanes_sum(float s) {
+#pragma unroll
+    for (int mk = 1; mk < N; mk <<= 1) s += shfl_xor(s, mk);
+    return s;
+}
+#else
+template <int CTRL> VC_DEV float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <int N> VC_DEV float lanes_sum(float s) {
+    static_assert(N == 4 || N == 8 || N == 16 || N == 32, "lane group");
+    s += dpp_f32<0xB1>(s);
+    s += dpp_f32<0x4E>(s);
+    if constexpr (N >= 8) s += dpp_f32<0x141>(s);
+    if constexpr (N >= 16) s += dpp_f32<0x140>(s);
+    if constexpr (N >= 32) s += shfl_xor(s, 16);
+    return s;
+}
+#endif
+
 // max of three without the canonicalising v_max x, x hipcc puts in front of every fmaxf operand it cannot prove quiet
 #ifdef VC_EMU
 VC_DEV float vmax3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
