@@ -188,3 +188,35 @@ def test_full_depth_parity_logic_on_the_tiny_model(emu_lib):
     r = fd.run_case(vcfg.tiny("vcoder_ds"), B=2, n_new=4, seed=42, oracle_rows=(0, 1), checkpoints=(2,), strict_tokens=2,
                     split=False, pooled_calls=1, lib=emu_lib)
     assert r["e_strict"] < 1e-4 and r["err32"].max() < e2e_cases.TOL_VS_FP32_REF
+
+
+def test_context_limit_is_a_clean_error(emu_lib):
+    """Maximum sizes: a sequence may fill the context (max_position_embeddings) to the last slot and then generation stops with
+    an error that names the limit — not a write past the KV cache; a prompt whose spliced length exceeds it is refused up front.
+    (HF's LlamaRotaryEmbedding re-sizes its table instead; the engine's cap is documented in include/vcoder_hip.h.)"""
+    import numpy as np
+    import pytest as _pt
+
+    g, cfg, ids, imgs, segs, deps = e2e_cases.fixture_inputs("ds_img_only")
+    ref_eng = e2e_cases.engine_for(cfg.variant, emu_lib)
+    eng = e2e_cases.engine_for(cfg.variant, emu_lib, overrides={"max_position_embeddings": 64})
+    _, _, S = eng.prefill(ids, imgs, segs, deps)
+    assert S < 64
+    n_fit = 64 - S              # prompt + new tokens <= max_position_embeddings
+    want = ref_eng.generate_greedy(ids, imgs, segs, deps, max_new_tokens=n_fit)
+    got = eng.generate_greedy(ids, imgs, segs, deps, max_new_tokens=n_fit)
+    assert np.array_equal(got, want)
+    with _pt.raises((RuntimeError, ValueError), match="max_position_embeddings"):
+        eng.generate_greedy(ids, imgs, segs, deps, max_new_tokens=n_fit + 8)
+    # a host-driven decode_step loop runs into the same wall
+    last, _, S = eng.prefill(ids, imgs, segs, deps, reserve=4)
+    tok = np.argmax(last, -1).astype(np.int32)
+    for _ in range(64 - S):     # the step that caches position 63 is the last one that fits
+        _, tok = eng.decode_step(tok, want_logits=False)
+    with _pt.raises((RuntimeError, ValueError), match="max_position_embeddings"):
+        eng.decode_step(tok, want_logits=False)
+    # the engine is usable afterwards
+    assert np.array_equal(eng.generate_greedy(ids, imgs, segs, deps, max_new_tokens=4), want[:, :4])
+    long_ids = np.concatenate([ids, np.full((ids.shape[0], 64), 5, dtype=ids.dtype)], axis=1)
+    with _pt.raises((RuntimeError, ValueError), match="max_position_embeddings"):
+        eng.prefill(long_ids, imgs, segs, deps)

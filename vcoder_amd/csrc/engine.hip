@@ -2659,8 +2659,9 @@ void generate_on_pool(vc_model* m, const int64_t* ids, int B, int T, const float
         do_prefill(m, ids, B, T, img, seg, depth, on_dev, 1, max_new, false, &S);
         DBG_HIP("do_prefill");
         m->last_S = S;
-        REQUIRE(S + max_new <= p->capS, VC_ERR_INVALID, "prompt %d + max_new %d exceeds the pool's KV capacity %d", S, max_new,
-                p->capS);
+        REQUIRE(S + max_new <= p->capS, VC_ERR_INVALID,
+                "prompt %d + max_new %d exceeds the context: max_position_embeddings=%d (KV capacity %d)", S, max_new,
+                m->c.max_positions, p->capS);
         finish_prefill(m, KvTarget{p->kc.as<bf16_t>(), p->vc.as<bf16_t>(), p->R, p->capS, rq.row0, p->split ? 4 : 2}, nullptr);
         if (m->ev[2]) HIPCHK(hipEventRecord(m->ev[2], m->st));
         HIPCHK(hipEventRecord(rq.prefill_done, m->st));
