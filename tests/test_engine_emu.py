@@ -220,3 +220,19 @@ def test_context_limit_is_a_clean_error(emu_lib):
     long_ids = np.concatenate([ids, np.full((ids.shape[0], 64), 5, dtype=ids.dtype)], axis=1)
     with _pt.raises((RuntimeError, ValueError), match="max_position_embeddings"):
         eng.prefill(long_ids, imgs, segs, deps)
+
+
+def test_empty_inputs_are_refused(emu_lib):
+    """Empty batches, empty prompts and max_new_tokens = 0 are errors (HF's generate validates max_new_tokens > 0 the same way),
+    not launches over zero rows."""
+    import pytest as _pt
+
+    g, cfg, ids, imgs, segs, deps = e2e_cases.fixture_inputs("ds_img_only")
+    eng = e2e_cases.engine_for(cfg.variant, emu_lib)
+    with _pt.raises(ValueError):
+        eng.generate_greedy(ids, imgs, segs, deps, max_new_tokens=0)
+    with _pt.raises(ValueError):
+        eng.generate_greedy(ids[:0], imgs[:0], None, None, max_new_tokens=2)
+    with _pt.raises(ValueError):
+        eng.prefill(ids[:, :0], imgs, segs, deps)
+    assert eng.generate_greedy(ids, imgs, segs, deps, max_new_tokens=1).shape == (ids.shape[0], 1)
