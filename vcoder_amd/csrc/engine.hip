@@ -94,6 +94,17 @@ hipStream_t make_stream(const char* env) {
     }
 #endif
     (void)v; (void)first; (void)count;
+#ifndef VC_EMU
+    // <env>_PRIO = high | low (experiment knob): queue priority of the stream
+    const std::string pe = env ? std::string(env) + "_PRIO" : std::string();
+    const char* pv = env ? getenv(pe.c_str()) : nullptr;
+    if (pv && (pv[0] == 'h' || pv[0] == 'l')) {
+        int least = 0, greatest = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPCHK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, pv[0] == 'h' ? greatest : least));
+        return st;
+    }
+#endif
     // non-blocking: no implicit synchronisation with the legacy NULL stream (torch's default stream, other sessions)
     HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     return st;
