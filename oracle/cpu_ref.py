@@ -429,6 +429,13 @@ class OracleModel:
         right-padded with zero rows when no attention_mask was passed (:278-285) and raise when one was
         (quirk 6: the reference dies with UnboundLocalError at :297)."""
         cfg = self.cfg
+        if images is None:
+            # the early return of prepare_inputs_labels_for_multimodal (vcoder_ds_llava_arch.py:129-133 and siblings): the ids go
+            # to LlamaModel's embed_tokens as they are — a placeholder id (negative) is then torch's embedding IndexError
+            rows = [list(map(int, r)) for r in input_ids]
+            if any(t < 0 or t >= cfg.vocab_size for r in rows for t in r):
+                raise IndexError("index out of range in self")
+            return torch.stack([self.embed_tokens(r) for r in rows], 0), None
         img_f = self._encode_any(images, "img")
         seg_f = self._encode_any(segs, "seg") if (segs is not None and cfg.variant != "llava") else None
         dep_f, dz = None, None

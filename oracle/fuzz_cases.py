@@ -1,0 +1,56 @@
+"""TEST INFRASTRUCTURE — generator of random prompt STRUCTURES for the differential checks (oracle/fuzz_vs_reference.py:
+oracle against the live reference, build container only; tests/test_fuzz_emu.py: the engine against the oracle): placeholder
+multisets and orders, text between placeholders, modalities present or None, batches with unequal spliced lengths, with and
+without an attention_mask.  No reference import here."""
+from __future__ import annotations
+
+import numpy as np
+
+from vcoder_amd import synth
+
+I, S, D = synth.IMAGE_TOKEN_INDEX, synth.SEG_TOKEN_INDEX, synth.DEPTH_TOKEN_INDEX
+
+
+def random_row(rng, T, vocab, allowed):
+    """[bos] + text with placeholders at random positions, exactly T ids: each allowed placeholder once (86 %), never (8 %) or
+    twice (6 % — one more than the sample has images: the reference's IndexError)"""
+    ph = []
+    for t in allowed:
+        r = rng.rand()
+        ph += [t] * (1 if r < 0.86 else (0 if r < 0.94 else 2))
+    ph = ph[: T - 1]
+    row = [int(rng.randint(3, vocab)) for _ in range(T - 1)]
+    order = list(rng.permutation(ph)) if ph else []
+    if rng.rand() < 0.7:     # <image> first, as every prompt the reference's own tokenizer helpers emit; the rest in any order
+        order.sort(key=lambda t: t != I)
+    for pos, t in zip(sorted(rng.choice(T - 1, size=len(ph), replace=False)), order):
+        row[int(pos)] = int(t)
+    return [1] + row
+
+
+def random_case(rng, cfg):
+    B = int(rng.randint(1, 4))
+    T = int(rng.randint(3, 12))
+    use_img = rng.rand() < 0.95
+    use_seg = cfg.variant != "llava" and rng.rand() < 0.8
+    use_depth = cfg.variant == "vcoder_ds" and rng.rand() < 0.8
+    if rng.rand() < 0.75:    # placeholders of the modalities that are there (any order: most orders are valid splices)
+        allowed = ([I] if use_img else []) + ([S] if use_seg else []) + ([D] if use_depth and rng.rand() < 0.8 else [])
+    else:                    # any subset, whether or not its tensors were passed
+        allowed_sets = {"vcoder_ds": [[I], [I, S], [I, S, D], [I, D], [S, D], []],
+                        "vcoder": [[I], [I, S], [S], []],
+                        "llava": [[I], []]}[cfg.variant]
+        allowed = allowed_sets[int(rng.randint(len(allowed_sets)))]
+    same_structure = rng.rand() < 0.5
+    rows = [random_row(rng, T, cfg.vocab_size, allowed)]
+    for _ in range(B - 1):
+        if same_structure:   # same placeholder positions, other text: equal spliced lengths
+            rows.append([t if t in (I, S, D) else int(rng.randint(3, cfg.vocab_size)) for t in rows[0]])
+            rows[-1][0] = 1
+        else:
+            rows.append(random_row(rng, T, cfg.vocab_size, allowed))
+    imgs, segs, deps = synth.synth_batch(B, cfg.vit_image_size, int(rng.randint(0, 1000)))
+    if use_depth and rng.rand() < 0.15:
+        deps = np.zeros_like(deps)      # the reference's "no depth" sentinel (vcoder_ds_llava_arch.py:161)
+    with_mask = rng.rand() < 0.5
+    return rows, (imgs if use_img else None), (segs if use_seg else None), (deps if use_depth else None), with_mask

@@ -1,0 +1,105 @@
+"""TEST INFRASTRUCTURE (build container only) — randomised differential check of oracle/cpu_ref.py against the LIVE reference
+(/root/reference through oracle/ref_shim.py) on prompt STRUCTURES: random placeholder multisets and orders, text between
+placeholders, modalities present or None, batches with unequal spliced lengths, with and without an attention_mask.
+
+For every case both sides either raise (the exception class names must agree — the oracle restates the reference's quirks,
+e.g. the UnboundLocalError of vcoder_ds_llava_arch.py:297) or return inputs_embeds / prefill logits that agree to fp32
+round-off.  Nothing is written to tests/golden: the fixtures there are the committed vectors; this script is the wider net
+that says the restatement of the splice (vcoder_ds_llava_arch.py:120-327 and its two siblings) has no untested corner.
+
+    python oracle/fuzz_vs_reference.py [--cases 300] [--seed 0] [--variants vcoder_ds vcoder llava]
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import cpu_ref  # noqa: E402
+import gen_golden  # noqa: E402
+from vcoder_amd import config as vcfg  # noqa: E402
+from vcoder_amd import synth  # noqa: E402
+
+from fuzz_cases import random_case  # noqa: E402
+
+
+def run_reference(model, cfg, rows, imgs, segs, deps, with_mask):
+    ids = torch.tensor(rows, dtype=torch.long)
+    t = lambda a: None if a is None else torch.from_numpy(a)
+    kw = {"images": t(imgs)}
+    if cfg.variant != "llava":
+        kw["segs"] = t(segs)
+    if cfg.variant == "vcoder_ds":
+        kw["depths"] = t(deps)
+    with torch.no_grad():
+        out = model(input_ids=ids, attention_mask=torch.ones_like(ids) if with_mask else None, use_cache=False, **kw)
+    return out.logits.float().numpy()
+
+
+def run_oracle(oracle, rows, imgs, segs, deps, with_mask):
+    t = lambda a: None if a is None else torch.from_numpy(a)
+    mask = np.ones((len(rows), len(rows[0])), dtype=np.int64) if with_mask else None
+    lg, _ = oracle.forward(rows, t(imgs), t(segs), t(deps), attention_mask=mask)
+    return lg.numpy()
+
+
+def outcome(fn):
+    try:
+        return "ok", fn()
+    except Exception as e:   # noqa: BLE001 — the class of the failure is the datum
+        return type(e).__name__, str(e)[:100]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=300)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--variants", nargs="+", default=["vcoder_ds", "vcoder", "llava"])
+    args = ap.parse_args()
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    bad = 0
+    with tempfile.TemporaryDirectory() as tmp:
+        for variant in args.variants:
+            cfg = vcfg.tiny(variant)
+            clip_dir = os.path.join(tmp, "clip_" + variant)
+            gen_golden.make_clip_dir(cfg, clip_dir)
+            sd = synth.synth_state_dict(cfg, gen_golden.SEED)
+            model = gen_golden.build_reference_model(cfg, sd, clip_dir)
+            oracle = cpu_ref.OracleModel(cfg, sd)
+            rng = np.random.RandomState(args.seed + hash(variant) % 1000)
+            stats = {}
+            for c in range(args.cases):
+                rows, imgs, segs, deps, with_mask = random_case(rng, cfg)
+                k_ref, v_ref = outcome(lambda: run_reference(model, cfg, rows, imgs, segs, deps, with_mask))
+                k_or, v_or = outcome(lambda: run_oracle(oracle, rows, imgs, segs, deps, with_mask))
+                key = k_ref if k_ref == k_or else f"MISMATCH ref={k_ref} oracle={k_or}"
+                if k_ref == k_or == "ok":
+                    if v_ref.shape != v_or.shape:
+                        key = f"MISMATCH shapes ref={v_ref.shape} oracle={v_or.shape}"
+                    else:
+                        err = float(np.abs(v_ref - v_or).max())
+                        if not err < 2e-4:
+                            key = f"MISMATCH logits |d|={err:.2e}"
+                stats[key] = stats.get(key, 0) + 1
+                if key.startswith("MISMATCH"):
+                    bad += 1
+                    print(f"[{variant} #{c}] {key}\n   rows={rows} img={imgs is not None} seg={segs is not None} "
+                          f"depth={deps is not None}{' (zero)' if deps is not None and not deps.any() else ''} mask={with_mask}\n"
+                          f"   ref: {v_ref if k_ref != 'ok' else 'ok'}\n   oracle: {v_or if k_or != 'ok' else 'ok'}", flush=True)
+            print(f"[{variant}] {args.cases} cases:", dict(sorted(stats.items())), flush=True)
+    print("fuzz_vs_reference:", "ALL AGREE" if bad == 0 else f"{bad} MISMATCHES")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
