@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE — generator of random prompt STRUCTURES for the differential checks (oracle/fuzz_vs_reference.py:
 oracle against the live reference, build container only; tests/test_fuzz_emu.py: the engine against the oracle): placeholder
 multisets and orders, text between placeholders, modalities present or None, batches with unequal spliced lengths, with and
-without an attention_mask.  No reference import here."""
+without an attention_mask (ones, right padding or holes).  No reference import here."""
 from __future__ import annotations
 
 import numpy as np
@@ -52,5 +52,28 @@ def random_case(rng, cfg):
     imgs, segs, deps = synth.synth_batch(B, cfg.vit_image_size, int(rng.randint(0, 1000)))
     if use_depth and rng.rand() < 0.15:
         deps = np.zeros_like(deps)      # the reference's "no depth" sentinel (vcoder_ds_llava_arch.py:161)
-    with_mask = rng.rand() < 0.5
-    return rows, (imgs if use_img else None), (segs if use_seg else None), (deps if use_depth else None), with_mask
+    if rng.rand() < 0.2:     # the list form (vcoder_ds_llava_arch.py:135-169): sample b owns 1-2 images per modality, spliced as
+        # ONE block at its placeholder — equal counts keep the lengths equal, unequal ones pad / raise like any other batch
+        def as_list(a, seed_off):
+            n = [int(rng.randint(1, 3)) for _ in range(B)] if rng.rand() < 0.5 else [int(rng.randint(1, 3))] * B
+            pool = synth.synth_batch(sum(n), cfg.vit_image_size, 2000 + seed_off)[0]
+            out, o = [], 0
+            for k in n:
+                out.append(pool[o:o + k])
+                o += k
+            return out
+        imgs, segs = as_list(imgs, 0), as_list(segs, 1)
+        if deps.any():
+            deps = as_list(deps, 2)
+        else:
+            deps = [np.zeros((1,) + deps.shape[1:], deps.dtype) for _ in range(B)]
+    mask = None
+    if rng.rand() < 0.5:     # attention_mask [B, T]: all ones, right padding, or holes (column 0 stays visible)
+        mask = np.ones((B, T), dtype=np.int64)
+        for b in range(B):
+            r = rng.rand()
+            if r < 0.25 and T > 2:
+                mask[b, T - int(rng.randint(1, T - 1)):] = 0
+            elif r < 0.4:
+                mask[b, 1:] = (rng.rand(T - 1) < 0.7).astype(np.int64)
+    return rows, (imgs if use_img else None), (segs if use_seg else None), (deps if use_depth else None), mask

@@ -32,22 +32,21 @@ from vcoder_amd import synth  # noqa: E402
 from fuzz_cases import random_case  # noqa: E402
 
 
-def run_reference(model, cfg, rows, imgs, segs, deps, with_mask):
+def run_reference(model, cfg, rows, imgs, segs, deps, mask):
     ids = torch.tensor(rows, dtype=torch.long)
-    t = lambda a: None if a is None else torch.from_numpy(a)
+    t = lambda a: None if a is None else ([torch.from_numpy(x) for x in a] if isinstance(a, list) else torch.from_numpy(a))
     kw = {"images": t(imgs)}
     if cfg.variant != "llava":
         kw["segs"] = t(segs)
     if cfg.variant == "vcoder_ds":
         kw["depths"] = t(deps)
     with torch.no_grad():
-        out = model(input_ids=ids, attention_mask=torch.ones_like(ids) if with_mask else None, use_cache=False, **kw)
+        out = model(input_ids=ids, attention_mask=None if mask is None else torch.from_numpy(mask), use_cache=False, **kw)
     return out.logits.float().numpy()
 
 
-def run_oracle(oracle, rows, imgs, segs, deps, with_mask):
-    t = lambda a: None if a is None else torch.from_numpy(a)
-    mask = np.ones((len(rows), len(rows[0])), dtype=np.int64) if with_mask else None
+def run_oracle(oracle, rows, imgs, segs, deps, mask):
+    t = lambda a: None if a is None else ([torch.from_numpy(x) for x in a] if isinstance(a, list) else torch.from_numpy(a))
     lg, _ = oracle.forward(rows, t(imgs), t(segs), t(deps), attention_mask=mask)
     return lg.numpy()
 
@@ -79,9 +78,9 @@ def main():
             rng = np.random.RandomState(args.seed + hash(variant) % 1000)
             stats = {}
             for c in range(args.cases):
-                rows, imgs, segs, deps, with_mask = random_case(rng, cfg)
-                k_ref, v_ref = outcome(lambda: run_reference(model, cfg, rows, imgs, segs, deps, with_mask))
-                k_or, v_or = outcome(lambda: run_oracle(oracle, rows, imgs, segs, deps, with_mask))
+                rows, imgs, segs, deps, mask = random_case(rng, cfg)
+                k_ref, v_ref = outcome(lambda: run_reference(model, cfg, rows, imgs, segs, deps, mask))
+                k_or, v_or = outcome(lambda: run_oracle(oracle, rows, imgs, segs, deps, mask))
                 key = k_ref if k_ref == k_or else f"MISMATCH ref={k_ref} oracle={k_or}"
                 if k_ref == k_or == "ok":
                     if v_ref.shape != v_or.shape:
@@ -94,7 +93,7 @@ def main():
                 if key.startswith("MISMATCH"):
                     bad += 1
                     print(f"[{variant} #{c}] {key}\n   rows={rows} img={imgs is not None} seg={segs is not None} "
-                          f"depth={deps is not None}{' (zero)' if deps is not None and not deps.any() else ''} mask={with_mask}\n"
+                          f"depth={deps is not None} list={isinstance(imgs, list) or isinstance(segs, list)} mask={None if mask is None else mask.tolist()}\n"
                           f"   ref: {v_ref if k_ref != 'ok' else 'ok'}\n   oracle: {v_or if k_or != 'ok' else 'ok'}", flush=True)
             print(f"[{variant}] {args.cases} cases:", dict(sorted(stats.items())), flush=True)
     print("fuzz_vs_reference:", "ALL AGREE" if bad == 0 else f"{bad} MISMATCHES")

@@ -39,16 +39,15 @@ def test_random_prompt_structures(emu_lib, variant, n_cases, seed):
     om = cpu_ref.OracleModel(cfg, synth.synth_state_dict(cfg, 42))
     eng.set_precision("strict")
     rng = np.random.RandomState(seed)
-    t = lambda a: None if a is None else torch.from_numpy(a)
+    t = lambda a: None if a is None else ([torch.from_numpy(x) for x in a] if isinstance(a, list) else torch.from_numpy(a))
     stats = {}
     try:
         for c in range(n_cases):
-            rows, imgs, segs, deps, with_mask = fuzz_cases.random_case(rng, cfg)
+            rows, imgs, segs, deps, mask = fuzz_cases.random_case(rng, cfg)
             ids = np.asarray(rows, dtype=np.int64)
-            mask = np.ones_like(ids) if with_mask else None
             k_or, v_or = _outcome(lambda: om.forward(rows, t(imgs), t(segs), t(deps), attention_mask=mask)[0].numpy())
             k_en, v_en = _outcome(lambda: eng.prefill(ids, imgs, segs, deps, all_logits=True, attention_mask=mask)[1])
-            what = f"case {c}: rows={rows} img={imgs is not None} seg={segs is not None} depth={deps is not None} mask={with_mask}"
+            what = f"case {c}: rows={rows} img={imgs is not None} seg={segs is not None} depth={deps is not None} list={isinstance(imgs, list) or isinstance(segs, list)} mask={None if mask is None else mask.tolist()}"
             assert k_en == k_or, f"{what}: engine {k_en} ({v_en if k_en != 'ok' else ''}) vs oracle {k_or} ({v_or if k_or != 'ok' else ''})"
             if k_or == "ok":
                 assert v_en.shape == v_or.shape, f"{what}: shapes {v_en.shape} vs {v_or.shape}"
@@ -64,7 +63,13 @@ def test_random_prompt_structures(emu_lib, variant, n_cases, seed):
                     if unequal != "ok":
                         assert k_gen == unequal == "UnboundLocalError", f"{what}: generate -> {k_gen}, oracle -> {unequal}"
                     else:
-                        want = om.generate_greedy(rows, t(imgs), t(segs), t(deps), max_new_tokens=4).numpy()
+                        # the reference's generate(): the caller's mask hides keys in the prefill; its cached multimodal steps
+                        # rebuild a mask of ones (vcoder_ds_llava_arch.py:130-133)
+                        lg, cache = om.forward(rows, t(imgs), t(segs), t(deps), attention_mask=mask)
+                        toks = [lg[:, -1].argmax(-1)]
+                        for _ in range(3):
+                            toks.append(om.decode_step(toks[-1].tolist(), cache)[:, -1].argmax(-1))
+                        want = torch.stack(toks, 1).numpy()
                         assert k_gen == "ok" and np.array_equal(got, want), f"{what}: greedy ids {got} vs {want.tolist()}"
             stats[k_or] = stats.get(k_or, 0) + 1
     finally:
