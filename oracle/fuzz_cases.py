@@ -77,3 +77,25 @@ def random_case(rng, cfg):
             elif r < 0.4:
                 mask[b, 1:] = (rng.rand(T - 1) < 0.7).astype(np.int64)
     return rows, (imgs if use_img else None), (segs if use_seg else None), (deps if use_depth else None), mask
+
+
+def random_overrides(rng, variant: str) -> dict:
+    """a random variation of vcfg.tiny(variant): config attributes -> values (vision feature selection, projector types, head
+    dims 64 / 128 on both sides, depths, image grid, norm epsilon)"""
+    o = {}
+    if rng.rand() < 0.5:
+        o["mm_vision_select_feature"] = "cls_patch"
+    o["mm_vision_select_layer"] = int(rng.choice([-2, -1, -3, 1]))
+    proj = ["mlp2x_gelu", "linear", "mlp3x_gelu"]
+    o["mm_projector_type"] = str(rng.choice(proj))
+    if variant != "llava":
+        o["seg_mm_projector_type"] = str(rng.choice(proj))
+    if variant == "vcoder_ds":
+        o["depth_mm_projector_type"] = str(rng.choice(proj))
+    o["num_attention_heads"] = int(rng.choice([2, 4]))          # head dim 128 / 64
+    o["vit_num_heads"] = int(rng.choice([2, 1]))                # head dim 64 / 128
+    o["num_hidden_layers"] = int(rng.choice([1, 2, 3]))
+    o["vit_image_size"] = int(rng.choice([28, 42, 56]))         # 4 / 9 / 16 patches
+    o["rms_norm_eps"] = float(rng.choice([1e-5, 1e-6]))
+    o["intermediate_size"] = int(rng.choice([384, 320, 512]))
+    return o

@@ -29,7 +29,7 @@ import gen_golden  # noqa: E402
 from vcoder_amd import config as vcfg  # noqa: E402
 from vcoder_amd import synth  # noqa: E402
 
-from fuzz_cases import random_case  # noqa: E402
+from fuzz_cases import random_case, random_overrides  # noqa: E402
 
 
 def run_reference(model, cfg, rows, imgs, segs, deps, mask):
@@ -63,21 +63,27 @@ def main():
     ap.add_argument("--cases", type=int, default=300)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--variants", nargs="+", default=["vcoder_ds", "vcoder", "llava"])
+    ap.add_argument("--configs", type=int, default=0, help="random config variations per variant, after the tiny config itself")
     args = ap.parse_args()
     torch.manual_seed(0)
     torch.set_num_threads(8)
     bad = 0
     with tempfile.TemporaryDirectory() as tmp:
-        for variant in args.variants:
+        for vi, variant in enumerate(v_ for v_ in args.variants for _ in range(1 + args.configs)):
+            rng = np.random.RandomState(args.seed + 1000 * vi)
             cfg = vcfg.tiny(variant)
-            clip_dir = os.path.join(tmp, "clip_" + variant)
+            over = random_overrides(rng, variant) if vi % (1 + args.configs) else {}   # the tiny config itself, then variations
+            for k_, v_ in over.items():
+                setattr(cfg, k_, v_)
+            clip_dir = os.path.join(tmp, "clip_%d" % vi)
             gen_golden.make_clip_dir(cfg, clip_dir)
             sd = synth.synth_state_dict(cfg, gen_golden.SEED)
             model = gen_golden.build_reference_model(cfg, sd, clip_dir)
             oracle = cpu_ref.OracleModel(cfg, sd)
-            rng = np.random.RandomState(args.seed + hash(variant) % 1000)
             stats = {}
-            for c in range(args.cases):
+            if over:
+                print(f"[{variant}] config {over}", flush=True)
+            for c in range(args.cases if not over else max(8, args.cases // 6)):
                 rows, imgs, segs, deps, mask = random_case(rng, cfg)
                 k_ref, v_ref = outcome(lambda: run_reference(model, cfg, rows, imgs, segs, deps, mask))
                 k_or, v_or = outcome(lambda: run_oracle(oracle, rows, imgs, segs, deps, mask))
@@ -95,7 +101,7 @@ def main():
                     print(f"[{variant} #{c}] {key}\n   rows={rows} img={imgs is not None} seg={segs is not None} "
                           f"depth={deps is not None} list={isinstance(imgs, list) or isinstance(segs, list)} mask={None if mask is None else mask.tolist()}\n"
                           f"   ref: {v_ref if k_ref != 'ok' else 'ok'}\n   oracle: {v_or if k_or != 'ok' else 'ok'}", flush=True)
-            print(f"[{variant}] {args.cases} cases:", dict(sorted(stats.items())), flush=True)
+            print(f"[{variant}] {sum(stats.values())} cases:", dict(sorted(stats.items())), flush=True)
     print("fuzz_vs_reference:", "ALL AGREE" if bad == 0 else f"{bad} MISMATCHES")
     return 1 if bad else 0
 

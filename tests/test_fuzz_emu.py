@@ -1,4 +1,4 @@
-"""Randomised differential test: the engine (HIP sources on the lane emulator, precision mode "strict") against the oracle on
+"""Randomised differential test: the engine (HIP sources on the lane emulator, precision modes "strict" and "split") against the oracle on
 random prompt STRUCTURES — placeholder multisets / orders, text in between, modalities present or None, zero-depth sentinel,
 unequal spliced lengths, with and without an attention_mask (oracle/fuzz_cases.py).  The same generator pins the oracle to the
 LIVE reference in the build container (oracle/fuzz_vs_reference.py: 1200 cases, all agree), so this closes the chain
@@ -32,13 +32,10 @@ def _outcome(fn):
         return type(e).__name__, str(e)
 
 
-@pytest.mark.parametrize("variant,n_cases,seed", [("vcoder_ds", 36, 11), ("vcoder", 24, 12), ("llava", 16, 13)])
-def test_random_prompt_structures(emu_lib, variant, n_cases, seed):
-    eng = e2e_cases.engine_for(variant, emu_lib)
+def _run_cases(eng, n_cases, rng, mode="strict"):
     cfg = eng.cfg
     om = cpu_ref.OracleModel(cfg, synth.synth_state_dict(cfg, 42))
-    eng.set_precision("strict")
-    rng = np.random.RandomState(seed)
+    eng.set_precision(mode)
     t = lambda a: None if a is None else ([torch.from_numpy(x) for x in a] if isinstance(a, list) else torch.from_numpy(a))
     stats = {}
     try:
@@ -74,5 +71,33 @@ def test_random_prompt_structures(emu_lib, variant, n_cases, seed):
             stats[k_or] = stats.get(k_or, 0) + 1
     finally:
         eng.set_precision("bf16")
+    return stats
+
+
+@pytest.mark.parametrize("variant,n_cases,seed", [("vcoder_ds", 36, 11), ("vcoder", 24, 12), ("llava", 16, 13)])
+def test_random_prompt_structures(emu_lib, variant, n_cases, seed):
+    stats = _run_cases(e2e_cases.engine_for(variant, emu_lib), n_cases, np.random.RandomState(seed))
     assert stats.get("ok", 0) >= n_cases // 4, stats     # the generator keeps a healthy share of valid prompts
     print(variant, stats)
+
+
+@pytest.mark.parametrize("variant,seed,mode", [("vcoder_ds", 21, "strict"), ("vcoder_ds", 22, "split"), ("vcoder_ds", 23, "strict"),
+                                               ("vcoder", 24, "split"), ("vcoder", 25, "strict"), ("llava", 26, "split"),
+                                               ("llava", 27, "strict")])
+def test_random_configs(emu_lib, variant, seed, mode):
+    """the same check on random variations of the tiny architecture: feature selection (patch / cls_patch, any layer), projector
+    types per modality, head dims 64 / 128 on both sides, depths, image grids, norm epsilon (oracle/fuzz_cases.random_overrides —
+    the oracle is pinned to the live reference on such variations by oracle/fuzz_vs_reference.py --configs N)"""
+    from vcoder_amd.engine import HipEngine
+
+    rng = np.random.RandomState(seed)
+    over = fuzz_cases.random_overrides(rng, variant)
+    cfg = e2e_cases.tiny_cfg(variant, over)
+    eng = HipEngine(cfg, lib=emu_lib)
+    try:
+        eng.load_synthetic(42)
+        eng.finalize()
+        stats = _run_cases(eng, 8, rng, mode)
+    finally:
+        eng.close()
+    print(variant, mode, over, stats)
