@@ -820,3 +820,23 @@ def test_decode_pool_true_dims():
     for s in sessions[1:]:
         s.close()
     root.close()
+
+
+@pytest.mark.parametrize("variant,seed,mode", [("vcoder_ds", 31, "split"), ("vcoder_ds", 32, "strict"), ("vcoder", 33, "split"),
+                                               ("llava", 34, "split")])
+def test_random_prompt_structures_and_configs(variant, seed, mode):
+    """The randomised differential check of tests/test_fuzz_emu.py on the device: random prompt structures (placeholder orders,
+    missing modalities, list-form images, masks with holes, unequal lengths) on the tiny architecture and on a random variation
+    of it, engine against the fp32 oracle — same outcome class, all-position logits within 1e-3, greedy ids equal."""
+    import test_fuzz_emu as fz
+
+    rng = np.random.RandomState(seed)
+    print(variant, mode, fz._run_cases(e2e_cases.engine_for(variant), 24, rng, mode))
+    over = fz.fuzz_cases.random_overrides(rng, variant)
+    eng = HipEngine(e2e_cases.tiny_cfg(variant, over))
+    try:
+        eng.load_synthetic(42)
+        eng.finalize()
+        print(variant, mode, over, fz._run_cases(eng, 16, rng, mode))
+    finally:
+        eng.close()
