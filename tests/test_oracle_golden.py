@@ -206,6 +206,62 @@ def test_reference_tokenizers_live():
             assert list(fn_r(prompt, tk)) == list(fn_o(prompt, tk)), (type(tk).__name__, prompt)
 
 
+@pytest.mark.reference
+@pytest.mark.skipif(not ref_shim.reference_available(), reason="needs /root/reference (build container only)")
+def test_reference_prompt_glue_random_live():
+    """f1 (prompt -> ids glue) against the live reference on random prompts: the three tokenizer helpers on random mixes of words,
+    <image> / <seg> / <depth> tags (any count, any order, with and without the newline), both tokenizer kinds, list and 'pt'
+    returns — same ids or the same exception class; get_model_name_from_path and expand2square on random inputs."""
+    ref_shim.load_reference()
+    from PIL import Image
+    from vcoder_llava import mm_utils as ref_mm
+
+    class Fake:
+        bos_token_id = 1
+
+        def __call__(self, text):
+            class R:
+                pass
+            r = R()
+            r.input_ids = [1] + [3 + (ord(c) % 50) for c in text]
+            return r
+
+    class NoBos(Fake):
+        def __call__(self, text):
+            r = Fake.__call__(self, text)
+            r.input_ids = r.input_ids[1:]
+            return r
+
+    def outcome(fn):
+        try:
+            out = fn()
+            return "ok", (out.tolist() if hasattr(out, "tolist") else list(out))
+        except Exception as e:  # noqa: BLE001
+            return type(e).__name__, None
+
+    rng = np.random.RandomState(5)
+    words = ["USER:", "what", "is", "there?", "ASSISTANT:", "a", "", "\n", "count the objects"]
+    tags = ["<image>", "<seg>", "<depth>", "<image>\n", "<seg>\n", "<depth>\n"]
+    n_ok = 0
+    for c in range(400):
+        parts = [str(rng.choice(tags)) if rng.rand() < 0.35 else str(rng.choice(words)) for _ in range(int(rng.randint(1, 9)))]
+        prompt = (" " if rng.rand() < 0.7 else "").join(parts)
+        tk = Fake() if rng.rand() < 0.6 else NoBos()
+        rt = "pt" if rng.rand() < 0.2 else None
+        for name in ("tokenizer_image_token", "tokenizer_seg_token", "tokenizer_depth_seg_token"):
+            a = outcome(lambda: getattr(ref_mm, name)(prompt, tk, return_tensors=rt))
+            b = outcome(lambda: getattr(mm_utils, name)(prompt, tk, return_tensors=rt))
+            assert a == b, (name, type(tk).__name__, repr(prompt), a, b)
+            n_ok += a[0] == "ok"
+    assert n_ok > 600
+    for path in ("a/b/llava-v1.5-7b", "x/vcoder_ds_llava-v1.5-13b/", "/m/checkpoint-100", "org/model/checkpoint-5/", "single"):
+        assert ref_mm.get_model_name_from_path(path) == mm_utils.get_model_name_from_path(path), path
+    for (w, h) in ((7, 7), (9, 4), (3, 10), (1, 6)):
+        img = Image.fromarray(rng.randint(0, 255, size=(h, w, 3)).astype(np.uint8))
+        a, b = ref_mm.expand2square(img, (10, 20, 30)), mm_utils.expand2square(img, (10, 20, 30))
+        assert a.size == b.size and np.array_equal(np.asarray(a), np.asarray(b)), (w, h)
+
+
 def test_sampling_oracle_equals_hf_warpers():
     """tests/kernel_cases.py:sample_reference_probs (the fp64 restatement every device-sampling test is judged against)
     equals HF's own TemperatureLogitsWarper -> TopKLogitsWarper -> TopPLogitsWarper chain followed by softmax — the
