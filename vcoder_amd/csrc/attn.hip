@@ -325,6 +325,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && QS == 1 && !SPLIT) ? 4 :
         }
     };
 
+    const int w_first = q0 + wave * (QS * 16);   // smallest query of this wave
     issue_tile(0, 0);
     for (int kt = 0; kt < nkt; ++kt) {
         // tile kt has landed for every wave (own vmcnt wait + barrier) and every wave is done with tile kt-1, whose buffer
@@ -335,6 +336,11 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && QS == 1 && !SPLIT) ? 4 :
         const char* k_lds = lds0 + (kt & 1) * STAGE;
         const char* v_lds = k_lds + PL * KB_;
         const int k0 = kt * 64;
+        // Tiles this wave has nothing to do in (it still takes part in the DMA and the barrier above): every key of the tile
+        // lies in the future of all its queries — the last tile of a causal block for the lower half of its waves — or all
+        // its queries lie behind the sequence (the ragged last block: S = 1216 leaves waves 4..7 of block 9, the 19-tile one,
+        // without a row).  Together 13 % of the wave-tiles of the prefill shape; the skipped work contributed exact zeros.
+        if (w_first >= p.T || (CAUSAL && k0 > w_first + QS * 16 - 1)) continue;
         // ---- S^T = K Q^T
         f32x4 sacc[QS][4];
 #pragma unroll
