@@ -64,7 +64,11 @@ void vck_vit_embed_ln(const float* patches, const float* cls, const float* pos, 
 /* feature_select (multimodal_encoder/clip_encoder.py:29-37) */
 void vck_select_rows_bf16(const float* x, uint16_t* y, int n_img, int T, int skip, int D, void* stream);
 /* head split + rotate_half RoPE ([HF] llama :113-160,259-262): qkv bf16 [B*T, 3*H*hd] -> Q [B,H,q_stride,hd],
- * K [B,H,kv_stride,hd], V^T [B,H,hd,kv_stride] (the MFMA A operand of the flash kernel's P.V).  pos0_dev is unused. */
+ * K [B,H,kv_stride,hd], V^T [B,H,hd,kv_stride] (the MFMA A operand of the flash kernel's P.V).  pos0_dev is unused.
+ * V^T is a scratch between this kernel and vck_attention and uses the flash kernel's KEY ORDER: inside every aligned block of 32
+ * keys, position 8c + e (c = 0..3, e = 0..7) holds key 4c + (e & 3) + 16 (e >> 2) (csrc/attn.hip vt_chunk_key0) — the order in
+ * which a lane's softmax numerators are packed into the P operand, so one 16-byte LDS read is a whole MFMA fragment.  A caller
+ * that fills V^T itself (vck_attention's vt) must use the same order; strides are multiples of 64. */
 void vck_qkv_split(const uint16_t* qkv, uint16_t* q, uint16_t* k, uint16_t* vt, int B, int T, int H, int hd, int q_stride,
                    int kv_stride, const int* pos0_dev, const float* rope_cos, const float* rope_sin, void* stream);
 /* the LLM prefill form: K and V rows into the key-major KV cache (kv_stride keys per (b,h)) — what the decode steps stream —
@@ -124,7 +128,7 @@ void vck_qkv_rope_f32(const float* qkv, float* q, float* k, float* v, int B, int
  *   (epi 0 / 3, xg_out) come back as hi row m + lo row G + m.
  * vck_*norm_split: normalised row r -> hi at y + r * ldy, lo at y + r * ldy + lo_off.
  * vck_qkv_split32: fp32 fused-QKV rows -> RoPE in fp32 -> fp32 K / V cache rows (k32 / v32, may be NULL) + bf16 hi / lo planes
- *   of Q [B,H,q_stride,hd], K [B,H,ks_stride,hd] and V^T [B,H,hd,vt_stride].
+ *   of Q [B,H,q_stride,hd], K [B,H,ks_stride,hd] and V^T [B,H,hd,vt_stride] (key order of vck_qkv_split's V^T).
  * vck_attention_split: flash attention over those planes (3 MFMAs per product), output rows [hi | lo]: stride ldo, lo at lo_off.
  * vck_attention_decode_kv32: the fused decode attention over fp32 qkv / fp32 K, V caches; output as stacked groups of G hi rows
  *   + G lo rows (row b -> hi at row (b / G) * 2G + b % G). */
