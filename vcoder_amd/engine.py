@@ -3,7 +3,7 @@ this file only marshals pointers, shapes and errors."""
 from __future__ import annotations
 
 import ctypes as C
-from typing import Sequence, Dict, Iterable, Optional, Tuple
+from typing import Sequence, Dict, Optional, Tuple
 
 import numpy as np
 

@@ -11,7 +11,7 @@ No torch.nn / HF Transformers module is involved: forward/generate marshal to li
 from __future__ import annotations
 
 from types import SimpleNamespace
-from typing import List, Optional
+from typing import Optional
 
 import numpy as np
 

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import re
-from typing import Dict, List, Optional
+from typing import Dict, List
 
 import numpy as np
 
