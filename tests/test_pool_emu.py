@@ -130,3 +130,81 @@ def test_pool_queues_requests_beyond_its_rows(emu_lib):
         assert np.array_equal(o, ref)
     for s in sessions[1:]:
         s.close()
+
+
+def test_pool_random_schedule_stress(emu_lib):
+    """A randomised schedule: five sessions, each issuing three generate() calls with random case, length, EOS / stop-sequence /
+    sampling parameters, padded masks and start delays — more rows wanted than the pool's first span holds at times, requests
+    joining and leaving mid-flight, one call failing on purpose (unequal lengths).  Every call's ids equal the ids of the same
+    call made alone afterwards, and the failing call fails the same way without disturbing the others."""
+    import time
+
+    rng = np.random.RandomState(2024)
+    root = e2e_cases.engine_for("vcoder_ds", emu_lib)
+    names = ["ds_img_depth_seg", "ds_img_only", "ds_img_seg"]
+    cases = []
+    for n in names:
+        g, cfg, ids, imgs, segs, deps = e2e_cases.fixture_inputs(n)
+        cases.append((ids, imgs, segs, deps))
+    probe = root.generate_greedy(*cases[0], max_new_tokens=10)
+    sessions = [root] + [root.fork() for _ in range(4)]
+    plans = []
+    for si in range(len(sessions)):
+        calls = []
+        for j in range(3):
+            ci = int(rng.randint(3))
+            kw = dict(max_new_tokens=int(rng.randint(2, 11)))
+            r = rng.rand()
+            if r < 0.25:
+                kw.update(eos_token_id=int(probe[0, int(rng.randint(1, 6))]), pad_token_id=0)
+            elif r < 0.45:
+                kw.update(stop_sequences=[[int(probe[-1, int(rng.randint(1, 6))])]], pad_token_id=0)
+            elif r < 0.7:
+                kw.update(do_sample=True, temperature=float(rng.choice([0.7, 1.0, 1.3])), top_k=int(rng.choice([0, 10, 40])),
+                          top_p=float(rng.choice([1.0, 0.9])), seed=int(rng.randint(1 << 30)))
+            if rng.rand() < 0.3:        # a padded prompt: right padding hidden by the mask
+                ids = cases[ci][0]
+                mask = np.ones_like(ids)
+                mask[:, -1] = 0
+                kw["attention_mask"] = mask
+            calls.append((ci, kw, float(rng.rand() * 0.05)))
+        plans.append(calls)
+    bad_ids = np.concatenate([cases[0][0][:1], np.where(cases[0][0][:1] < 0, 5, cases[0][0][:1])], 0)   # row 1 lost its placeholders
+    plans[2][1] = ("bad", dict(max_new_tokens=4), 0.0)
+    outs = [[None] * 3 for _ in sessions]
+    errs = []
+
+    def run(eng, ci, kw):
+        if ci == "bad":
+            imgs, segs, deps = cases[0][1:]
+            return eng.generate(bad_ids, imgs, segs, deps, **kw)
+        return eng.generate(*cases[ci], **kw)
+
+    def work(si):
+        try:
+            for j, (ci, kw, delay) in enumerate(plans[si]):
+                time.sleep(delay)
+                try:
+                    outs[si][j] = ("ok", run(sessions[si], ci, kw))
+                except UnboundLocalError as e:
+                    outs[si][j] = ("UnboundLocalError", str(e))
+        except BaseException as e:
+            errs.append((si, e))
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(len(sessions))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    assert outs[2][1][0] == "UnboundLocalError"
+    for si in range(len(sessions)):
+        for j, (ci, kw, _) in enumerate(plans[si]):
+            if ci == "bad":
+                continue
+            kind, got = outs[si][j]
+            want = run(root, ci, kw)                         # the same call, alone
+            assert kind == "ok" and got.shape == want.shape and np.array_equal(got, want), \
+                f"session {si} call {j} ({names[ci]}, {kw}): pooled ids differ from the lone call"
+    for s in sessions[1:]:
+        s.close()
