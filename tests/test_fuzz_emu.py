@@ -68,6 +68,17 @@ def _run_cases(eng, n_cases, rng, mode="strict"):
                             toks.append(om.decode_step(toks[-1].tolist(), cache)[:, -1].argmax(-1))
                         want = torch.stack(toks, 1).numpy()
                         assert k_gen == "ok" and np.array_equal(got, want), f"{what}: greedy ids {got} vs {want.tolist()}"
+                        # a host-driven decode_step loop keeps the caller's mask (forward() without images carries it)
+                        lg, cache = om.forward(rows, t(imgs), t(segs), t(deps), attention_mask=mask)
+                        last, _, _ = eng.prefill(ids, imgs, segs, deps, attention_mask=mask)
+                        assert np.abs(last - lg[:, -1].numpy()).max() < 1e-3
+                        tok_o = lg[:, -1].argmax(-1)
+                        for _ in range(3):
+                            lo = om.decode_step(tok_o.tolist(), cache, keep_mask=True)[:, -1]
+                            le, _ = eng.decode_step(tok_o.numpy().astype(np.int32))
+                            assert np.abs(le - lo.numpy()).max() < 1e-3, f"{what}: cached step with the carried mask"
+                            tok_o = lo.argmax(-1)
+                        eng.clear_attention_mask()
             stats[k_or] = stats.get(k_or, 0) + 1
     finally:
         eng.set_precision("bf16")
