@@ -85,7 +85,7 @@ def _run_cases(eng, n_cases, rng, mode="strict"):
     return stats
 
 
-@pytest.mark.parametrize("variant,n_cases,seed", [("vcoder_ds", 36, 11), ("vcoder", 24, 12), ("llava", 16, 13)])
+@pytest.mark.parametrize("variant,n_cases,seed", [("vcoder_ds", 27, 11), ("vcoder", 18, 12), ("llava", 12, 13)])
 def test_random_prompt_structures(emu_lib, variant, n_cases, seed):
     stats = _run_cases(e2e_cases.engine_for(variant, emu_lib), n_cases, np.random.RandomState(seed))
     assert stats.get("ok", 0) >= n_cases // 4, stats     # the generator keeps a healthy share of valid prompts
