@@ -128,7 +128,7 @@ def test_kv_cache_grows_under_a_long_decode_loop(emu_lib):
 
     g, cfg, ids, imgs, segs, deps = e2e_cases.fixture_inputs("ds_img_only")
     eng = e2e_cases.engine_for(cfg.variant, emu_lib)
-    n = 200
+    n = 112                                                                     # S + n crosses the 64- and the 128-key capacities
     ref = eng.generate_greedy(ids, imgs, segs, deps, max_new_tokens=n + 1)      # sized for n up front
     last, _, S = eng.prefill(ids, imgs, segs, deps, reserve=8)                   # tiny reserve: forces two growths
     tok = np.argmax(last, -1).astype(np.int32)
