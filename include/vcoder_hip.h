@@ -126,13 +126,15 @@ int vc_set_image_counts(vc_model* m, const int32_t* img_counts, const int32_t* s
 /* output_hidden_states for the NEXT vc_prefill (one-shot): out (host, cap_floats floats) receives [(layers + 1), B, S, hidden]
  * fp32 — inputs_embeds, the residual stream behind every decoder layer, the last entry after the final RMSNorm: the tuple
  * [HF] LlamaModel.forward returns as hidden_states (vcoder_ds_llava_llama.py:81-90,117).  out must stay valid until that
- * vc_prefill returns; NULL cancels. */
+ * vc_prefill returns; NULL cancels.  Requested before a vc_decode_step instead, it is that cached step's tuple:
+ * [(layers + 1), B, 1, hidden] (the step then runs eagerly, outside its hipGraph). */
 int vc_request_hidden_states(vc_model* m, float* out, size_t cap_floats);
 
 /* output_attentions for the NEXT vc_prefill (one-shot): out (host, cap_floats floats) receives [layers, B, heads, S, S] fp32 — the
  * attention probabilities HF's eager attention returns as `attentions` (vcoder_ds_llava_llama.py:81-90,118; [HF]
  * llama/modeling_llama.py eager_attention_forward): softmax(q k^T / sqrt(hd) + causal mask + padding mask), recomputed per layer
- * from that layer's q / k by a diagnostic kernel (the flash kernels never materialise them).  S <= 4096. */
+ * from that layer's q / k by a diagnostic kernel (the flash kernels never materialise them).  S <= 4096.  Requested before a
+ * vc_decode_step: [layers, B, heads, 1, pos + 1] — the new token's query over every cached key and itself. */
 int vc_request_attentions(vc_model* m, float* out, size_t cap_floats);
 
 /* Padded batches: the caller's 2-D attention_mask [B, T] (bytes, 0 = hidden) for the NEXT vc_prefill* / vc_generate* call

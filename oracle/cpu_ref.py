@@ -478,7 +478,8 @@ class OracleModel:
                                hidden_out=hidden_out, attn_out=attn_out)
         return logits, cache
 
-    def decode_step(self, tokens: Sequence[int], cache: KVCache, keep_mask: bool = False):
+    def decode_step(self, tokens: Sequence[int], cache: KVCache, keep_mask: bool = False, hidden_out: Optional[list] = None,
+                    attn_out: Optional[list] = None):
         """one cached step.  keep_mask False: the all-ones mask the reference's multimodal decode path builds
         (vcoder_ds_llava_arch.py:130-133); True: the prefill's mask extended with ones (a caller carrying its mask, no images)."""
         x = self.embed_tokens(tokens).unsqueeze(1)
@@ -486,7 +487,8 @@ class OracleModel:
         if keep_mask and getattr(self, "mask_ext", None) is not None:
             n = cache.length + 1 - self.mask_ext.shape[1]
             km = torch.cat([self.mask_ext, torch.ones(self.mask_ext.shape[0], n, dtype=torch.bool)], dim=1)
-        return llama_forward(x, self.sd, self.cfg, cache, self.emu, last_only=True, act_fp8=self.act_fp8, key_mask=km)
+        return llama_forward(x, self.sd, self.cfg, cache, self.emu, last_only=True, act_fp8=self.act_fp8, key_mask=km,
+                             hidden_out=hidden_out, attn_out=attn_out)
 
     def generate_greedy(self, input_ids, images, segs=None, depths=None, max_new_tokens: int = 8,
                         eos_token_id: Optional[int] = None, pad_token_id: int = 0, return_logits: bool = False):

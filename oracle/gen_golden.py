@@ -446,9 +446,35 @@ def main_round3():
         e_at = float(np.abs(torch.stack(ao, 0).numpy() - at).max())
         print(f"[ds_hidden_states] attentions {at.shape} oracle|d|={e_at:.2e}")
         assert e_at < 1e-6
+        # ... and of a CACHED decode step behind it (form B of SURVEY.md section 8(c): no images, a mask of ones over past + 1).
+        # On a FRESH reference model: under Transformers 5.15 a forward with output_attentions=True leaves the model in a state
+        # in which later use_cache=True forwards differ (by 6e-2 here) from the same call on a fresh model and from its own
+        # use_cache=False forward — third-party state, not the reference's arithmetic.
+        model2 = build_reference_model(cfg, sd, clip_dir)
+        with torch.no_grad():
+            pre = model2(input_ids=ids, images=imgs, segs=segs, depths=deps, use_cache=True)
+            assert float((pre.logits - out.logits).abs().max()) < 1e-5, "cached prefill differs from the no-cache forward"
+            nxt = pre.logits[:, -1].float().argmax(-1)
+            L_ = pre.logits.shape[1]
+            st = model2(input_ids=nxt[:, None], attention_mask=torch.ones(2, L_ + 1, dtype=torch.long),
+                        past_key_values=pre.past_key_values, use_cache=True, output_hidden_states=True, output_attentions=True)
+        step_hs = torch.stack([h.float() for h in st.hidden_states], 0).numpy()        # [L + 1, B, 1, D]
+        step_at = torch.stack([a.float() for a in st.attentions], 0).numpy()           # [L, B, H, 1, S + 1]
+        assert step_hs.shape == (cfg.num_hidden_layers + 1, 2, 1, cfg.hidden_size)
+        assert step_at.shape == (cfg.num_hidden_layers, 2, cfg.num_attention_heads, 1, L_ + 1)
+        _, cache = oracle.forward(ids.tolist(), imgs, segs, deps, last_only=True)
+        sh, sa = [], []
+        o_step = oracle.decode_step(nxt.tolist(), cache, hidden_out=sh, attn_out=sa)
+        e_sh = float(np.abs(torch.stack(sh, 0).numpy() - step_hs).max())
+        e_sa = float(np.abs(torch.stack(sa, 0).numpy() - step_at).max())
+        e_sl = float(np.abs(o_step[:, -1].numpy() - st.logits[:, -1].float().numpy()).max())
+        print(f"[ds_hidden_states] cached step: hidden oracle|d|={e_sh:.2e} attentions oracle|d|={e_sa:.2e} logits|d|={e_sl:.2e}")
+        assert e_sh < 2e-5 * max(1.0, float(np.abs(step_hs).max())) and e_sa < 1e-6 and e_sl < 2e-4
         np.savez_compressed(os.path.join(GOLD, "ds_hidden_states.npz"), variant=cfg.variant, seed=SEED, input_ids=ids.numpy(),
                             hidden_sample=hs[:, :, ::3, ::8].astype(np.float32), hidden_rowsum=hs.sum(-1).astype(np.float32),
-                            logits_last=out.logits[:, -1].float().numpy(), attentions=at.astype(np.float32))
+                            logits_last=out.logits[:, -1].float().numpy(), attentions=at.astype(np.float32),
+                            step_token=nxt.numpy().astype(np.int64), step_hidden=step_hs.astype(np.float32),
+                            step_attentions=step_at.astype(np.float32), step_logits=st.logits[:, -1].float().numpy())
     print("round-3 fixtures written to", GOLD)
 
 

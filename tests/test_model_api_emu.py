@@ -93,8 +93,13 @@ def test_forward_output_hidden_states(model):
     out = model(input_ids=t(ids), images=t(imgs), segs=t(segs), depths=t(deps), output_attentions=True, use_cache=True)
     assert isinstance(out.attentions, tuple) and len(out.attentions) == model.config.num_hidden_layers
     assert np.abs(torch.stack(out.attentions, 0).numpy() - g["attentions"]).max() < 2.0 ** -7
-    with pytest.raises(NotImplementedError):   # a cached decode step keeps neither
-        model(input_ids=t(ids[:, :1]), past_key_values=out.past_key_values, images=t(imgs), output_attentions=True)
+    # a cached decode step behind it: [B, 1, D] per entry, [B, H, 1, past + 1] per layer
+    st = model(input_ids=t(g["step_token"][:, None]), past_key_values=out.past_key_values, images=t(imgs), segs=t(segs), depths=t(deps),
+               output_hidden_states=True, output_attentions=True)
+    assert len(st.hidden_states) == model.config.num_hidden_layers + 1 and tuple(st.hidden_states[0].shape) == (ids.shape[0], 1, model.config.hidden_size)
+    assert np.abs(torch.stack(st.attentions, 0).numpy() - g["step_attentions"]).max() < 2.0 ** -7
+    assert np.abs(torch.stack(st.hidden_states, 0).numpy() - g["step_hidden"]).max() < 2.0 ** -6 * float(np.abs(g["step_hidden"]).max())
+    assert np.abs(st.logits[:, -1].numpy() - g["step_logits"]).max() < e2e_cases.TOL_VS_FP32_REF
 
 
 def test_generate_variants(model):

@@ -53,6 +53,13 @@ def test_oracle_hidden_states_and_attentions():
     assert np.abs(hs.sum(-1) - g["hidden_rowsum"]).max() < 1e-3 * scale
     assert np.abs(torch.stack(ao, 0).numpy() - g["attentions"]).max() < 1e-6
     assert np.abs(logits[:, -1].numpy() - g["logits_last"]).max() < 1e-4
+    # ... and of a cached decode step behind that prefill
+    _, cache = om.forward(ids.tolist(), imgs, segs, deps, last_only=True)
+    sh, sa = [], []
+    step = om.decode_step(g["step_token"].tolist(), cache, hidden_out=sh, attn_out=sa)
+    assert np.abs(torch.stack(sh, 0).numpy() - g["step_hidden"]).max() < 2e-5 * scale
+    assert np.abs(torch.stack(sa, 0).numpy() - g["step_attentions"]).max() < 1e-6
+    assert np.abs(step[:, -1].numpy() - g["step_logits"]).max() < 1e-4
 
 
 @pytest.mark.parametrize("name", FIXTURES)

@@ -203,6 +203,7 @@ struct vc_model {
     // output_attentions of the NEXT vc_prefill (vc_request_attentions; one-shot): host buffer [L, B, H, S, S]
     float* attn_out = nullptr;
     size_t attn_cap = 0;
+    Buf attn_q;                   // roped q of a decode step with output_attentions
     int reserve_new = 64;         // KV slots a vc_prefill keeps free behind the prompt (vc_model_reserve_decode)
     int layer_limit = 0;          // > 0: a prefill evaluates only the first layer_limit decoder layers (vc_model_set_layer_limit)
     // LLM workspace
@@ -415,22 +416,27 @@ int place_tensor(vc_model* m, const std::string& raw_key, const void* src, int d
     return VC_OK;
 }
 
-void emit_hidden(vc_model* m, int idx, int B, int S);  // output_hidden_states hook (defined with the prefill layers)
-// output_attentions hook: the probabilities of decoder layer l from its q / k in the precision mode's own form
-void emit_attentions(vc_model* m, int l, int B, int S, AttnProbsArgs a) {
+// output_hidden_states hook (defined with the prefill layers); x_src: the residual rows to copy (default: the prefill's m->x)
+void emit_hidden(vc_model* m, int idx, int B, int S, const float* x_src = nullptr);
+// output_attentions hook: the probabilities of decoder layer l from its q / k in the precision mode's own form.  S queries
+// starting at position q_pos0 against Tk keys (0: S — a prefill; a cached decode step: S = 1, Tk = its position + 1)
+void emit_attentions(vc_model* m, int l, int B, int S, AttnProbsArgs a, int Tk = 0, int q_pos0 = 0) {
     if (!m->attn_out) return;
-    const size_t n = (size_t)B * m->c.heads * S * S;
+    const int keys = Tk > 0 ? Tk : S;
+    const size_t n = (size_t)B * m->c.heads * S * keys;
     REQUIRE((size_t)(l + 1) * n <= m->attn_cap, VC_ERR_INVALID, "attention buffer too small: %zu floats for layer %d of %zu", m->attn_cap,
             l, n);
-    REQUIRE(S <= 4096, VC_ERR_INVALID, "output_attentions: at most 4096 positions");
+    REQUIRE(keys <= 4096, VC_ERR_INVALID, "output_attentions: at most 4096 positions");
     m->hidden_tmp.ensure(n * 4);
     a.out = m->hidden_tmp.as<float>();
     a.B = B;
     a.H = m->c.heads;
     a.T = S;
+    a.Tk = Tk;
+    a.q_pos0 = q_pos0;
     a.hd = m->hd;
     a.scale = 1.0f / sqrtf((float)m->hd);
-    if (m->has_kmask) {
+    if (Tk > 0 ? m->kmask_in_decode : m->has_kmask) {
         a.key_mask = m->kmask.as<uint8_t>();
         a.mask_stride = m->c.max_positions;
     }
@@ -546,8 +552,8 @@ void gemv(vc_model* m, const LoopView& v, const bf16_t* X, const bf16_t* Wp, con
 }
 
 // the GEMVs of one decode step over the first M rows; `between(l)` runs after the qkv projection of layer l (the attention)
-template <class F>
-void decode_linears(vc_model* m, const LoopView& v, int M, F&& between) {
+template <class F, class G>
+void decode_linears(vc_model* m, const LoopView& v, int M, F&& between, G&& after_layer) {
     const vc_model_cfg& c = m->c;
     const int D = c.hidden, Fd = c.ffn;
     const bf16_t* xg = v.xg_dec;
@@ -559,8 +565,13 @@ void decode_linears(vc_model* m, const LoopView& v, int M, F&& between) {
         gemv(m, v, v.attn_dec, L.o_p, L.o_s, v.x_dec, M, D, D, D, GEMV_RESID_F32, false, L.post_norm);          // K16
         gemv(m, v, xg, L.gu_p, L.gu_s, v.h_dec, M, 2 * Fd, D, Fd, GEMV_SWIGLU, true);                          // K11+K17
         gemv(m, v, v.h_dec, L.down_p, L.down_s, v.x_dec, M, D, Fd, D, GEMV_RESID_F32, false, next_in);          // K17
+        after_layer(l);
     }
     gemv(m, v, xg, m->lm_head_p, nullptr, v.logits, M, c.vocab, D, c.vocab, GEMV_F32, true);                    // K11+K18
+}
+template <class F>
+void decode_linears(vc_model* m, const LoopView& v, int M, F&& between) {
+    decode_linears(m, v, M, between, [](int) {});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -926,19 +937,22 @@ void run_llm_layers_strict(vc_model* m, float* x, int B, int T, const int* pos_d
             aa.mask_stride = c.max_positions;
         }
         launch_attention_f32(aa, m->st);
-        if (T > 1 && x == m->x.as<float>()) {
+        const bool step = T == 1 && x == m->x_dec.as<float>();   // a session's cached decode step (m->cur_pos = its position)
+        if ((T > 1 && x == m->x.as<float>()) || step) {
             AttnProbsArgs pa{};
             pa.q32 = q;
             pa.k32 = s_kcache(m, l);
             pa.q_stride = T;
             pa.kv_stride = m->s_capS;
-            emit_attentions(m, l, B, T, pa);
+            if (step) emit_attentions(m, l, B, 1, pa, m->cur_pos + 1, m->cur_pos);
+            else emit_attentions(m, l, B, T, pa);
         }
         gemm32(m, at, L.o_w, nullptr, x, M, D, D, D, D, D, EPI_RESID_F32);
         launch_rmsnorm_f32(x, nullptr, L.post_norm, xn, M, D, c.rms_eps, m->st);
         gemm32(m, xn, L.gu_w, nullptr, h, M, 2 * F, D, D, D, F, EPI_SWIGLU);
         gemm32(m, h, L.down_w, nullptr, x, M, D, F, F, F, D, EPI_RESID_F32);
         if (T > 1 && x == m->x.as<float>()) emit_hidden(m, l + 1, B, T);
+        else if (step) emit_hidden(m, l + 1, B, 1, x);
     }
 }
 
@@ -1197,16 +1211,16 @@ void grow_kv(vc_model* m, int need) {
 // output_hidden_states ([HF] LlamaModel.forward: the tuple (inputs_embeds, layer 1 output, ..., layer L-1 output,
 // norm(layer L output))): entry `idx` of the caller's host buffer <- the fp32 residual stream (idx == layers: after the final
 // RMSNorm).  No-op unless requested for this prefill.
-void emit_hidden(vc_model* m, int idx, int B, int S) {
+void emit_hidden(vc_model* m, int idx, int B, int S, const float* x_src) {
     if (!m->hidden_out) return;
     const vc_model_cfg& c = m->c;
     const size_t n = (size_t)B * S * c.hidden;
     REQUIRE((size_t)(idx + 1) * n <= m->hidden_cap, VC_ERR_INVALID, "hidden-state buffer too small: %zu floats for entry %d of %zu",
             m->hidden_cap, idx, n);
-    const float* src = m->x.as<float>();
+    const float* src = x_src ? x_src : m->x.as<float>();
     if (idx == c.layers) {
         m->hidden_tmp.ensure(n * 4);
-        launch_rmsnorm_f32(m->x.as<float>(), nullptr, m->final_norm, m->hidden_tmp.as<float>(), B * S, c.hidden, c.rms_eps, m->st);
+        launch_rmsnorm_f32(src, nullptr, m->final_norm, m->hidden_tmp.as<float>(), B * S, c.hidden, c.rms_eps, m->st);
         src = m->hidden_tmp.as<float>();
     }
     HIPCHK(hipMemcpyAsync(m->hidden_out + (size_t)idx * n, src, n * 4, hipMemcpyDeviceToHost, m->st));
@@ -1349,9 +1363,41 @@ void enqueue_decode_step(vc_model* m, const LoopView& v, int nrows) {
     launch_select_embed(select_args(m, v, v.logits, nrows, 3), v.st);                                        // K19/K20+K10
 }
 
+// The same step run eagerly with the output_hidden_states / output_attentions hooks of a cached decode step
+// (vc_request_hidden_states / vc_request_attentions before vc_decode_step): inputs_embeds row, every layer's residual row, the
+// final norm; and per layer the probabilities of the new token's query over the pos + 1 keys, recomputed from the step's own
+// roped q (rounded as the fused kernel rounds it) and the K cache — the fused decode attention keeps only unnormalised scores.
+void enqueue_decode_step_diag(vc_model* m, const LoopView& v, int nrows, int pos) {
+    const vc_model_cfg& c = m->c;
+    emit_hidden(m, 0, nrows, 1, v.x_dec);
+    decode_linears(
+        m, v, nrows,
+        [&](int l) {
+            AttnDecodeFusedArgs da{v.qkv_dec, kcache(v, m, l), vcache(v, m, l), v.attn_dec, nrows, c.heads, m->hd, v.capS,
+                                   v.rows + RS_POS, m->rope_cos, m->rope_sin, 1.0f / sqrtf((float)m->hd), RS_STRIDE,
+                                   v.rows + RS_ACTIVE, v.split_G ? 1 : 0, v.split_G, v.kmask, v.kmask_stride};
+            launch_attention_decode_fused(da, v.st);
+            if (m->attn_out) {
+                m->attn_q.ensure((size_t)nrows * c.hidden * 4);
+                launch_rope_q_decode(v.qkv_dec, v.split_G != 0, m->attn_q.as<float>(), nrows, c.heads, m->hd, pos, m->rope_cos, m->rope_sin,
+                                     v.split_G == 0, v.st);
+                AttnProbsArgs pa{};
+                pa.q32 = m->attn_q.as<float>();
+                if (v.split_G) pa.k32 = reinterpret_cast<const float*>(kcache(v, m, l));
+                else pa.k_hi = kcache(v, m, l);
+                pa.q_stride = 1;
+                pa.kv_stride = v.capS;
+                emit_attentions(m, l, nrows, 1, pa, pos + 1, pos);
+            }
+        },
+        [&](int l) { emit_hidden(m, l + 1, nrows, 1, v.x_dec); });
+    launch_select_embed(select_args(m, v, v.logits, nrows, 3), v.st);
+}
+
 // strict mode: the rows of a session advance in lockstep, so row 0's position serves every row of the fp32 kernels
 void enqueue_decode_step_strict(vc_model* m, int B) {
     const LoopView v = session_view(m);
+    emit_hidden(m, 0, B, 1, m->x_dec.as<float>());
     run_llm_layers_strict(m, m->x_dec.as<float>(), B, 1, v.rows + RS_POS);
     logits_strict(m, m->x_dec.as<float>(), nullptr, B);
     launch_select_embed(select_args(m, v, v.logits, B, 3), v.st);
@@ -1845,7 +1891,7 @@ VC_API void vc_model_destroy(vc_model* m) {
                    &m->out_ids, &m->dsum, &m->ssq, &m->sk_scratch, &m->sk_counters, &m->gemm_ws, &m->s_cols, &m->s_patches, &m->s_vx, &m->s_vxn, &m->s_vqkv,
                    &m->s_vq, &m->s_vk, &m->s_vv, &m->s_vattn, &m->s_vh, &m->s_sel, &m->s_mid, &m->s_feats, &m->s_xn, &m->s_qkv,
                    &m->s_q, &m->s_attn, &m->s_h, &m->s_kc, &m->s_vc, &m->s_xl, &m->pp_src, &m->pp_sq, &m->pp_tmp, &m->pp_out,
-                   &m->pp_tab, &m->pp_f32, &m->kmask, &m->hidden_tmp})
+                   &m->pp_tab, &m->pp_f32, &m->kmask, &m->hidden_tmp, &m->attn_q})
         b->release();
     for (auto& e : m->ev)
         if (e) (void)hipEventDestroy(e);
@@ -2246,8 +2292,18 @@ VC_API int vc_decode_step(vc_model* m, const int32_t* tok, float* logits, int32_
         launch_embed_tokens_ssq(m->next_tok.as<int>(), m->embed, m->x_dec.as<float>(), m->ssq.as<float>(), m->llm[0].in_norm,
                                 m->xg_dec.as<bf16_t>(), B, m->c.hidden, m->npart, m->st, session_view(m).split_G);
     }
+    struct StepRequests {   // one-shot, also when the step fails
+        vc_model* m;
+        ~StepRequests() {
+            m->hidden_out = nullptr;
+            m->attn_out = nullptr;
+            m->hidden_cap = m->attn_cap = 0;
+        }
+    } step_requests{m};
     if (m->precision == 1) {
         enqueue_decode_step_strict(m, B);
+    } else if (m->hidden_out || m->attn_out) {
+        enqueue_decode_step_diag(m, session_view(m), B, m->cur_pos);
     } else {
         ensure_graph(m, B);
         HIPCHK(hipGraphLaunch(m->graph, m->st));

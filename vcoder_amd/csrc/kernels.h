@@ -326,13 +326,19 @@ struct AttnProbsArgs {
     const float* k32;      // [B,H,kv_stride,hd] or nullptr
     const bf16_t* k_hi;
     const bf16_t* k_lo;
-    float* out;            // [B,H,T,T]
-    int B, H, T, hd, q_stride, kv_stride;   // T <= 4096
+    float* out;            // [B,H,T,Tk]
+    int B, H, T, hd, q_stride, kv_stride;   // T queries; keys <= 4096
     float scale;
     const uint8_t* key_mask;
     int mask_stride;
+    int Tk;                // key columns of an output row (0: T — the prefill form)
+    int q_pos0;            // position of query 0: query t sees keys 0 .. q_pos0 + t (a cached decode step: T = 1, q_pos0 = its position)
 };
 void launch_attn_probs(const AttnProbsArgs& a, hipStream_t s);
+// q of ONE new token per row, rotated to position `pos`, for launch_attn_probs on a cached decode step: qkv rows [B, 3 H hd] (bf16, or
+// fp32 when qkv_f32) -> q [B,H,1,hd] fp32; round_bf16: the values the fused decode attention uses (q rounded to bf16 after RoPE)
+void launch_rope_q_decode(const void* qkv, bool qkv_f32, float* q, int B, int H, int hd, int pos, const float* rope_cos,
+                          const float* rope_sin, bool round_bf16, hipStream_t s);
 struct QkvF32Args {
     const float* qkv;  // [B*T, 3*H*hd]
     float* q;          // [B,H,q_stride,hd]

@@ -168,7 +168,8 @@ __global__ __launch_bounds__(64) void attn_probs_kernel(AttnProbsArgs p) {
     }
     __syncthreads();
     const uint8_t* km = p.key_mask != nullptr ? p.key_mask + (size_t)b * p.mask_stride : nullptr;
-    const int nkeys = t + 1;   // causal prefill from position 0
+    const int Tk = p.Tk > 0 ? p.Tk : p.T;
+    const int nkeys = min(p.q_pos0 + t + 1, Tk);   // causal: query t sits at position q_pos0 + t
     float mx = -INFINITY;
     for (int key = lane; key < nkeys; key += 64) {
         const size_t ko = (bh * p.kv_stride + key) * p.hd;
@@ -192,12 +193,40 @@ __global__ __launch_bounds__(64) void attn_probs_kernel(AttnProbsArgs p) {
     }
     sum = wave_sum(sum);
     __syncthreads();
-    float* o = p.out + (bh * p.T + t) * (size_t)p.T;
+    float* o = p.out + (bh * p.T + t) * (size_t)Tk;
     const float inv = 1.0f / sum;
-    for (int key = lane; key < p.T; key += 64) o[key] = key < nkeys ? sc[key] * inv : 0.f;
+    for (int key = lane; key < Tk; key += 64) o[key] = key < nkeys ? sc[key] * inv : 0.f;
 }
 void launch_attn_probs(const AttnProbsArgs& a, hipStream_t s) {
     VC_LAUNCH(attn_probs_kernel, dim3(a.T, a.H, a.B), dim3(64), 0, s, a);
+}
+
+__global__ __launch_bounds__(64) void rope_q_decode_kernel(const void* qkv, int qkv_f32, float* q, int H, int hd, int pos,
+                                                           const float* rope_cos, const float* rope_sin, int round_bf16) {
+    const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x, half = hd / 2;
+    if (d >= half) return;
+    const size_t ro = (size_t)b * (3 * H * hd) + (size_t)h * hd;
+    float q0, q1;
+    if (qkv_f32) {
+        q0 = reinterpret_cast<const float*>(qkv)[ro + d];
+        q1 = reinterpret_cast<const float*>(qkv)[ro + d + half];
+    } else {
+        q0 = bf2f(reinterpret_cast<const bf16_t*>(qkv)[ro + d]);
+        q1 = bf2f(reinterpret_cast<const bf16_t*>(qkv)[ro + d + half]);
+    }
+    const float c = rope_cos[(size_t)pos * half + d], s = rope_sin[(size_t)pos * half + d];
+    float o0 = q0 * c - q1 * s, o1 = q1 * c + q0 * s;
+    if (round_bf16) {
+        o0 = bf2f(f2bf(o0));
+        o1 = bf2f(f2bf(o1));
+    }
+    float* qo = q + ((size_t)b * H + h) * hd;
+    qo[d] = o0;
+    qo[d + half] = o1;
+}
+void launch_rope_q_decode(const void* qkv, bool qkv_f32, float* q, int B, int H, int hd, int pos, const float* rope_cos,
+                          const float* rope_sin, bool round_bf16, hipStream_t s) {
+    VC_LAUNCH(rope_q_decode_kernel, dim3(H, B), dim3(64), 0, s, qkv, (int)qkv_f32, q, H, hd, pos, rope_cos, rope_sin, (int)round_bf16);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

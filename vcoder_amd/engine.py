@@ -334,7 +334,7 @@ class HipEngine:
             self.lib.vc_request_attentions(self._model, None, C.c_size_t(0))
             self.lib.vc_request_hidden_states(self._model, None, C.c_size_t(0))
             raise
-        self.last_S = S.value
+        self.last_S = self._step_pos = S.value
         self._cur_batch = B
         self._keep_hidden(hid, B, S.value)
         self.last_attentions = att
@@ -366,9 +366,12 @@ class HipEngine:
         self._check(self.lib.vc_vision_tower_forward(self._model, p, on_dev, N, out.ctypes.data_as(C.c_void_p)))
         return out
 
-    def decode_step(self, tokens=None, want_logits: bool = True):
-        """-> (logits [B,V] or None, next_tok [B] int32)"""
+    def decode_step(self, tokens=None, want_logits: bool = True, hidden_states: bool = False, attentions: bool = False):
+        """-> (logits [B,V] or None, next_tok [B] int32).  hidden_states / attentions: this cached step's output_hidden_states
+        [(L + 1), B, 1, D] / output_attentions [L, B, H, 1, pos + 1] in last_hidden_states / last_attentions (the step then runs
+        outside its hipGraph)."""
         B = self._cur_batch
+        self.last_hidden_states = self.last_attentions = None
         tok_p = None
         if tokens is not None:
             tk = np.ascontiguousarray(np.asarray(tokens).reshape(-1), dtype=np.int32)
@@ -377,9 +380,25 @@ class HipEngine:
             tok_p = tk.ctypes.data_as(C.c_void_p)
         lg = np.empty((B, self.cfg.vocab_size), dtype=np.float32) if want_logits else None
         nxt = np.empty((B,), dtype=np.int32)
-        self._check(self.lib.vc_decode_step(self._model, tok_p, lg.ctypes.data_as(C.c_void_p) if want_logits else None,
-                                            nxt.ctypes.data_as(C.c_void_p)))
+        hid = att = None
+        try:
+            if hidden_states:
+                hid = np.empty((self.cfg.num_hidden_layers + 1, B, 1, self.cfg.hidden_size), dtype=np.float32)
+                self._check(self.lib.vc_request_hidden_states(self._model, hid.ctypes.data_as(C.c_void_p), C.c_size_t(hid.size)))
+            if attentions:
+                att = np.empty((self.cfg.num_hidden_layers, B, self.cfg.num_attention_heads, 1, self._step_pos + 1), dtype=np.float32)
+                self._check(self.lib.vc_request_attentions(self._model, att.ctypes.data_as(C.c_void_p), C.c_size_t(att.size)))
+            self._check(self.lib.vc_decode_step(self._model, tok_p, lg.ctypes.data_as(C.c_void_p) if want_logits else None,
+                                                nxt.ctypes.data_as(C.c_void_p)))
+        except BaseException:
+            self.lib.vc_request_attentions(self._model, None, C.c_size_t(0))
+            self.lib.vc_request_hidden_states(self._model, None, C.c_size_t(0))
+            raise
+        self._step_pos += 1
+        self.last_hidden_states, self.last_attentions = hid, att
         return lg, nxt
+
+    _step_pos = 0   # position of the token the next decode_step processes (prefill: S)
 
     _cur_batch = 0
     last_hidden_states = None

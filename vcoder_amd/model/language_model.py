@@ -224,12 +224,10 @@ class _HipCausalLMBase:
             # With images the reference REPLACES the mask by ones here (vcoder_ds_llava_arch.py:130-133): keys a padded
             # prefill hid become visible.  Without images the caller's mask goes through to LlamaModel: the engine keeps the
             # prefill's hidden keys hidden (new positions are visible, as HF's generate loop appends ones).
-            if output_hidden_states or output_attentions:
-                raise NotImplementedError("hidden states / attention maps of a cached decode step are not materialised by the "
-                                          "fused step kernels (the prefill forward() returns them)")
             if images is not None or attention_mask is None:
                 self.engine.clear_attention_mask()
-            lg, _ = self.engine.decode_step(tok)
+            # output_hidden_states / output_attentions of a cached step: [B, 1, D] per entry, [B, H, 1, past + 1] per layer
+            lg, _ = self.engine.decode_step(tok, hidden_states=bool(output_hidden_states), attentions=bool(output_attentions))
             past_key_values.length += 1
             logits = torch.from_numpy(lg).unsqueeze(1)
             pkv = past_key_values
