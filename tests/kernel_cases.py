@@ -34,7 +34,8 @@ class EmuBackend:
     name = "emu"
 
     def __init__(self):
-        path = os.path.join(ROOT, "tests", "emu", "libvcoder_emu.so")
+        # VC_EMU_LIB: another build of the emulator library (e.g. with the host engine under AddressSanitizer, tools/emu_asan.sh)
+        path = os.environ.get("VC_EMU_LIB") or os.path.join(ROOT, "tests", "emu", "libvcoder_emu.so")
         if not os.path.exists(path):
             import subprocess
 
