@@ -19,6 +19,9 @@
 #include <thread>
 #include <vector>
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <sys/mman.h>
 
 struct dim3 {
     unsigned x, y, z;
@@ -78,9 +81,46 @@ static const hipError_t hipSuccess = 0;
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
 enum hipStreamCaptureMode { hipStreamCaptureModeGlobal, hipStreamCaptureModeThreadLocal };
 inline const char* hipGetErrorString(hipError_t) { return "emu"; }
-inline hipError_t hipMalloc(void** p, size_t n) { *p = aligned_alloc(256, (n + 255) / 256 * 256 + 256); return *p ? 0 : 1; }
+// Guard pages (default; VC_EMU_GUARD=0 switches to plain padded allocations): every device allocation ends (to 16 bytes) at an
+// inaccessible page, so a kernel that reads or writes past its buffer faults instead of silently touching the allocator's slack —
+// what a 256-byte padding, or the page granularity of a real hipMalloc, would hide.
+struct EmuGuardTable {
+    std::mutex mu;
+    std::map<void*, std::pair<void*, size_t>> live;   // user pointer -> (mapping base, mapping bytes)
+};
+inline EmuGuardTable& emu_guard_table() {
+    static EmuGuardTable t;
+    return t;
+}
+inline bool emu_guard_on() {
+    static const bool on = !(getenv("VC_EMU_GUARD") && atoi(getenv("VC_EMU_GUARD")) == 0);
+    return on;
+}
+inline void* emu_alloc(size_t n) {
+    if (!emu_guard_on()) return aligned_alloc(256, (n + 255) / 256 * 256 + 256);
+    const size_t page = 4096, need = ((n ? n : 1) + 15) / 16 * 16, total = (need + page - 1) / page * page + page;
+    char* base = (char*)mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (base == (char*)MAP_FAILED) return nullptr;
+    mprotect(base + total - page, page, PROT_NONE);
+    void* user = base + (total - page) - need;
+    EmuGuardTable& t = emu_guard_table();
+    std::lock_guard<std::mutex> lk(t.mu);
+    t.live[user] = {base, total};
+    return user;
+}
+inline void emu_free(void* p) {
+    if (!p) return;
+    if (!emu_guard_on()) return free(p);
+    EmuGuardTable& t = emu_guard_table();
+    std::lock_guard<std::mutex> lk(t.mu);
+    auto it = t.live.find(p);
+    if (it == t.live.end()) return;
+    munmap(it->second.first, it->second.second);
+    t.live.erase(it);
+}
+inline hipError_t hipMalloc(void** p, size_t n) { *p = emu_alloc(n); return *p ? 0 : 1; }
 template <class T> inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
-inline hipError_t hipFree(void* p) { free(p); return 0; }
+inline hipError_t hipFree(void* p) { emu_free(p); return 0; }
 inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return 0; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return 0; }

@@ -42,18 +42,37 @@ class EmuBackend:
             subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build_emu.sh")])
         self.lib = ctypes.CDLL(path)
 
+    # every array handed to a kernel ends (to 16 bytes) at an inaccessible page — an out-of-bounds access faults (VC_EMU_GUARD=0:
+    # plain numpy arrays); the emulator's hipMalloc does the same for the engine's device buffers (tests/emu/hip_emu.h)
+    @staticmethod
+    def _guard(a):
+        if os.environ.get("VC_EMU_GUARD", "1") == "0":
+            return a
+        import mmap
+
+        a = np.ascontiguousarray(a)
+        page, need = 4096, (max(a.nbytes, 1) + 15) // 16 * 16
+        total = (need + page - 1) // page * page + page
+        buf = mmap.mmap(-1, total)
+        addr = ctypes.addressof(ctypes.c_char.from_buffer(buf))
+        if ctypes.CDLL(None, use_errno=True).mprotect(ctypes.c_void_p(addr + total - page), ctypes.c_size_t(page), 0) != 0:
+            raise OSError("mprotect failed")
+        g = np.frombuffer(buf, dtype=a.dtype, count=a.size, offset=total - page - need).reshape(a.shape)
+        g[...] = a
+        return g
+
     # arrays are numpy; bf16 arrays are uint16 bit patterns
     def f32(self, a):
-        return np.ascontiguousarray(a, dtype=np.float32)
+        return self._guard(np.ascontiguousarray(a, dtype=np.float32))
 
     def bf16(self, a):
-        return synth.to_bf16_bits(np.asarray(a, dtype=np.float32)).reshape(np.shape(a))
+        return self._guard(synth.to_bf16_bits(np.asarray(a, dtype=np.float32)).reshape(np.shape(a)))
 
     def i32(self, a):
-        return np.ascontiguousarray(a, dtype=np.int32)
+        return self._guard(np.ascontiguousarray(a, dtype=np.int32))
 
     def zeros(self, shape, kind):
-        return np.zeros(shape, dtype={"f32": np.float32, "bf16": np.uint16, "i32": np.int32, "u8": np.uint8}[kind])
+        return self._guard(np.zeros(shape, dtype={"f32": np.float32, "bf16": np.uint16, "i32": np.int32, "u8": np.uint8}[kind]))
 
     def ptr(self, a):
         return None if a is None else a.ctypes.data_as(c_p)
