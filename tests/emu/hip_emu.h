@@ -98,11 +98,13 @@ inline bool emu_guard_on() {
 }
 inline void* emu_alloc(size_t n) {
     if (!emu_guard_on()) return aligned_alloc(256, (n + 255) / 256 * 256 + 256);
+    // VC_EMU_GUARD=2: the mirror image — the buffer STARTS right behind an inaccessible page (underruns fault)
+    static const bool front = getenv("VC_EMU_GUARD") && atoi(getenv("VC_EMU_GUARD")) == 2;
     const size_t page = 4096, need = ((n ? n : 1) + 15) / 16 * 16, total = (need + page - 1) / page * page + page;
     char* base = (char*)mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
     if (base == (char*)MAP_FAILED) return nullptr;
-    mprotect(base + total - page, page, PROT_NONE);
-    void* user = base + (total - page) - need;
+    mprotect(front ? base : base + total - page, page, PROT_NONE);
+    void* user = front ? base + page : base + (total - page) - need;
     EmuGuardTable& t = emu_guard_table();
     std::lock_guard<std::mutex> lk(t.mu);
     t.live[user] = {base, total};

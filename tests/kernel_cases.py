@@ -55,9 +55,10 @@ class EmuBackend:
         total = (need + page - 1) // page * page + page
         buf = mmap.mmap(-1, total)
         addr = ctypes.addressof(ctypes.c_char.from_buffer(buf))
-        if ctypes.CDLL(None, use_errno=True).mprotect(ctypes.c_void_p(addr + total - page), ctypes.c_size_t(page), 0) != 0:
+        front = os.environ.get("VC_EMU_GUARD") == "2"     # the mirror image: the array starts right behind the dead page
+        if ctypes.CDLL(None, use_errno=True).mprotect(ctypes.c_void_p(addr + (0 if front else total - page)), ctypes.c_size_t(page), 0) != 0:
             raise OSError("mprotect failed")
-        g = np.frombuffer(buf, dtype=a.dtype, count=a.size, offset=total - page - need).reshape(a.shape)
+        g = np.frombuffer(buf, dtype=a.dtype, count=a.size, offset=page if front else total - page - need).reshape(a.shape)
         g[...] = a
         return g
 
