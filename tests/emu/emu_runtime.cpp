@@ -167,12 +167,12 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
         b->bdim = block;
         b->gdim = grid;
         b->body = &body;
-        b->dyn_smem = (char*)aligned_alloc(256, (shmem + 255) / 256 * 256 + 256);
+        b->dyn_smem = (char*)emu_alloc(shmem);   // dynamic LDS of the launch: guard page behind it like every device buffer
         for (size_t i = wid; i < nblocks; i += workers) {
             b->bidx = dim3((unsigned)(i % grid.x), (unsigned)((i / grid.x) % grid.y), (unsigned)(i / ((size_t)grid.x * grid.y)));
             run_block(b, fibers);
         }
-        free(b->dyn_smem);
+        emu_free(b->dyn_smem);
         delete b;
         munmap(stacks, STACK_BYTES * nthreads);
     };
