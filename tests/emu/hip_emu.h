@@ -105,6 +105,10 @@ inline void* emu_alloc(size_t n) {
     if (base == (char*)MAP_FAILED) return nullptr;
     mprotect(front ? base : base + total - page, page, PROT_NONE);
     void* user = front ? base + page : base + (total - page) - need;
+    // fresh device memory is garbage, not zeros: 0xFF bytes are NaNs in fp32 and bf16 and -1 as an index, so a kernel that reads
+    // what nobody wrote poisons its output instead of passing on the mapping's zero fill (VC_EMU_POISON=0: leave the zeros)
+    static const bool poison = !(getenv("VC_EMU_POISON") && atoi(getenv("VC_EMU_POISON")) == 0);
+    if (poison) memset(user, 0xFF, need);
     EmuGuardTable& t = emu_guard_table();
     std::lock_guard<std::mutex> lk(t.mu);
     t.live[user] = {base, total};
