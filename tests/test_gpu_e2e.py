@@ -840,3 +840,14 @@ def test_random_prompt_structures_and_configs(variant, seed, mode):
         print(variant, mode, over, fz._run_cases(eng, 16, rng, mode))
     finally:
         eng.close()
+
+
+def test_pool_random_schedule_and_limits_on_the_device():
+    """The CPU suite's randomised pool schedule (five sessions, random EOS / stop / sampling / masks / delays, one failing call),
+    the context-limit wall and the empty-input refusals, on the real device: same assertions, true concurrency."""
+    import test_engine_emu as te
+    import test_pool_emu as tp
+
+    tp.test_pool_random_schedule_stress(None)
+    te.test_context_limit_is_a_clean_error(None)
+    te.test_empty_inputs_are_refused(None)
