@@ -848,6 +848,7 @@ def test_pool_random_schedule_and_limits_on_the_device():
     import test_engine_emu as te
     import test_pool_emu as tp
 
-    tp.test_pool_random_schedule_stress(None)
+    for seed in (2024, 7, 77, 777, 7777, 77777):      # a second on the device each
+        tp.test_pool_random_schedule_stress(None, seed)
     te.test_context_limit_is_a_clean_error(None)
     te.test_empty_inputs_are_refused(None)

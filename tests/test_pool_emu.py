@@ -132,14 +132,14 @@ def test_pool_queues_requests_beyond_its_rows(emu_lib):
         s.close()
 
 
-def test_pool_random_schedule_stress(emu_lib):
+def test_pool_random_schedule_stress(emu_lib, seed: int = 2024):
     """A randomised schedule: five sessions, each issuing two generate() calls with random case, length, EOS / stop-sequence /
     sampling parameters, padded masks and start delays — more rows wanted than the pool's first span holds at times, requests
     joining and leaving mid-flight, one call failing on purpose (unequal lengths).  Every call's ids equal the ids of the same
     call made alone afterwards, and the failing call fails the same way without disturbing the others."""
     import time
 
-    rng = np.random.RandomState(2024)
+    rng = np.random.RandomState(seed)
     root = e2e_cases.engine_for("vcoder_ds", emu_lib)
     names = ["ds_img_depth_seg", "ds_img_only", "ds_img_seg"]
     cases = []
