@@ -68,6 +68,31 @@ void wave_sync() {
     while (w.gen == gen) yield_to_scheduler();
 }
 
+static bool dma_deferred() {
+    static const bool on = !(getenv("VC_EMU_DMA") && atoi(getenv("VC_EMU_DMA")) == 0);
+    return on;
+}
+void dma_issue(const void* src, void* dst) {
+    Fiber* f = g_cur;
+    if (!f || !dma_deferred()) {
+        memcpy(dst, src, 16);
+        return;
+    }
+    if (f->dma_tail - f->dma_head >= 128) {   // cannot happen with a sane schedule: land the oldest
+        const PendingDma& d = f->dma[f->dma_head++ % 128];
+        memcpy(d.dst, d.src, 16);
+    }
+    f->dma[f->dma_tail++ % 128] = PendingDma{src, dst};
+}
+void dma_wait(int keep_newest) {
+    Fiber* f = g_cur;
+    if (!f) return;
+    while ((int)(f->dma_tail - f->dma_head) > keep_newest) {
+        const PendingDma& d = f->dma[f->dma_head++ % 128];
+        memcpy(d.dst, d.src, 16);
+    }
+}
+
 static void fiber_finished(Fiber* f) {
     BlockCtx* b = f->blk;
     f->done = true;
@@ -106,6 +131,7 @@ static void run_block(BlockCtx* b, std::vector<Fiber>& fibers) {
     for (int t = 0; t < n; ++t) {
         Fiber& f = fibers[t];
         f.done = false;
+        f.dma_head = f.dma_tail = 0;
         f.blk = b;
         f.lane = t & 63;
         f.wave = t >> 6;

@@ -46,6 +46,12 @@ struct WaveCtx {
     alignas(16) unsigned char xchg[64][64];
 };
 struct BlockCtx;
+// A lane's LDS-DMAs in flight (global_load_lds): issued in program order, LANDED only when the lane waits for them — the
+// vmcnt model below.  128 entries = far more than any kernel keeps outstanding.
+struct PendingDma {
+    const void* src;
+    void* dst;
+};
 struct Fiber {
     void* sp = nullptr;
     char* stack = nullptr;
@@ -53,6 +59,8 @@ struct Fiber {
     int lane = 0, wave = 0;
     dim3 tidx;
     BlockCtx* blk = nullptr;
+    PendingDma dma[128];
+    unsigned dma_head = 0, dma_tail = 0;   // ring: [head, tail) pending, oldest first
 };
 struct BlockCtx {
     int nthreads = 0, alive = 0;
@@ -68,6 +76,13 @@ struct BlockCtx {
 };
 extern thread_local Fiber* g_cur;
 void yield_to_scheduler();
+// vmcnt model (VC_EMU_DMA=0: DMAs land at once, waits are no-ops): an LDS-DMA is queued at issue and its 16 bytes are copied
+// when the issuing lane executes a wait that no longer allows it to be outstanding — wait_vmcnt<N> lands all but the newest N,
+// __syncthreads() all (hipcc drains vmcnt before the barrier), a bare s_barrier none.  Register loads and stores, which also
+// count on the hardware, are not queued: they can only make the hardware land MORE DMAs at a wait than the model does, so a
+// schedule that is correct here is correct there; one that reads a slot too early reads stale bytes here every time.
+void dma_issue(const void* src, void* dst);
+void dma_wait(int keep_newest);
 void block_barrier();
 void wave_sync();
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
@@ -180,7 +195,10 @@ inline hipError_t hipGraphLaunch(hipGraphExec_t g, hipStream_t) { for (auto& f :
 #define blockDim (vc_emu::g_cur->blk->bdim)
 #define gridDim (vc_emu::g_cur->blk->gdim)
 
-inline void __syncthreads() { vc_emu::block_barrier(); }
+inline void __syncthreads() {
+    vc_emu::dma_wait(0);
+    vc_emu::block_barrier();
+}
 inline float __expf(float x) { return expf(x); }
 inline float __logf(float x) { return logf(x); }
 inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }

@@ -233,8 +233,8 @@ VC_DEV u32x4 ld16_stream(const void* p) { return __builtin_nontemporal_load(rein
 // The LDS destination is WAVE-UNIFORM base + lane*16; the global source is per lane (so LDS swizzles are applied to
 // the source address).  Completion is tracked by vmcnt; hipcc waits vmcnt(0) before the next __syncthreads().
 #ifdef VC_EMU
-VC_DEV void glds16(const void* gsrc_lane, void* lds_wave_base) {
-    memcpy(reinterpret_cast<char*>(lds_wave_base) + lane_id() * 16, gsrc_lane, 16);
+VC_DEV void glds16(const void* gsrc_lane, void* lds_wave_base) {   // lands when the lane's vmcnt wait says so (hip_emu.h)
+    vc_emu::dma_issue(gsrc_lane, reinterpret_cast<char*>(lds_wave_base) + lane_id() * 16);
 }
 #else
 VC_DEV void glds16(const void* gsrc_lane, void* lds_wave_base) {
@@ -245,8 +245,8 @@ VC_DEV void glds16(const void* gsrc_lane, void* lds_wave_base) {
 
 // ---- hand-placed synchronisation for the counted-vmcnt GEMM schedule (gemm.hip, 8-phase kernel) ---------------
 #ifdef VC_EMU
-VC_DEV void wg_barrier_raw() { __syncthreads(); }
-template <int N> VC_DEV void wait_vmcnt() {}
+VC_DEV void wg_barrier_raw() { vc_emu::block_barrier(); }   // bare s_barrier: no implied vmcnt drain
+template <int N> VC_DEV void wait_vmcnt() { vc_emu::dma_wait(N); }
 template <int N> VC_DEV void wait_lgkmcnt() {}
 template <int P> VC_DEV void set_prio() {}
 VC_DEV void sched_fence() {}
@@ -264,7 +264,7 @@ VC_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // non-temporal LDS-DMA for streams read exactly once (decode weights): measured 6.8 vs 6.0 TB/s on a pure stream
 #ifdef VC_EMU
 VC_DEV void glds16_nt(const void* gsrc_lane, void* lds_wave_base) { glds16(gsrc_lane, lds_wave_base); }
-VC_DEV void wait_vmcnt_n(int) {}
+VC_DEV void wait_vmcnt_n(int n) { vc_emu::dma_wait(n); }
 #else
 VC_DEV void glds16_nt(const void* gsrc_lane, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
