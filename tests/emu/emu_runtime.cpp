@@ -143,14 +143,34 @@ static void run_block(BlockCtx* b, std::vector<Fiber>& fibers) {
         for (int i = 0; i < 6; ++i) *--sp = nullptr;
         f.sp = sp;
     }
+    // VC_EMU_ORDER: the order in which the scheduler visits the waves of a block in each pass — 0 ascending (default), 1 descending,
+    // >= 2 a pseudo-random permutation per pass (seed).  Fibers yield only at barriers and wave collectives, so the wave order IS
+    // the interleaving: a kernel that relies on a barrier it does not have computes differently under another order.
+    static const int order_mode = getenv("VC_EMU_ORDER") ? atoi(getenv("VC_EMU_ORDER")) : 0;
+    const int nw = n / 64;
+    int worder[16];
+    for (int w = 0; w < nw; ++w) worder[w] = w;
+    unsigned long lcg = 0x9E3779B97F4A7C15ul * (unsigned long)(order_mode + 1) + b->bidx.x * 131ul + b->bidx.y * 7919ul + b->bidx.z;
     while (b->alive > 0) {
         const unsigned long before = b->progress;
-        for (int t = 0; t < n; ++t) {
-            Fiber& f = fibers[t];
-            if (f.done) continue;
-            g_cur = &f;
-            vc_emu_switch(&b->sched_sp, f.sp);
+        if (order_mode == 1) {
+            for (int w = 0; w < nw; ++w) worder[w] = nw - 1 - w;
+        } else if (order_mode >= 2) {
+            for (int w = nw - 1; w > 0; --w) {   // Fisher-Yates
+                lcg = lcg * 6364136223846793005ul + 1442695040888963407ul;
+                const int j = (int)((lcg >> 33) % (unsigned long)(w + 1));
+                const int tmp = worder[w];
+                worder[w] = worder[j];
+                worder[j] = tmp;
+            }
         }
+        for (int wi = 0; wi < nw; ++wi)
+            for (int l = 0; l < 64; ++l) {
+                Fiber& f = fibers[worder[wi] * 64 + l];
+                if (f.done) continue;
+                g_cur = &f;
+                vc_emu_switch(&b->sched_sp, f.sp);
+            }
         if (b->progress == before && b->alive > 0) {
             fprintf(stderr, "emu: deadlock in block (%u,%u,%u): %d threads alive, barrier %d arrived\n", b->bidx.x,
                     b->bidx.y, b->bidx.z, b->alive, b->bar_arrived);

@@ -1,0 +1,21 @@
+"""The kernel tests once more under another wave interleaving: the emulator's scheduler visits the waves of a block in
+descending / pseudo-random order (VC_EMU_ORDER, tests/emu/emu_runtime.cpp; read once per process, hence the subprocess).  Fibers
+yield only at barriers and wave collectives, so the order IS the interleaving: a kernel that leans on a barrier or a vmcnt wait
+it does not have computes differently under one of them (dropping the per-tile barrier of the flash kernel fails 5 of 6 attention
+cases; loosening the GEMV's counted wait by one fails at once)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("order", ["11"])   # descending = "1"; any other number seeds a random order
+def test_kernels_under_another_wave_order(order):
+    env = dict(os.environ, VC_EMU_ORDER=order)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_kernels_emu.py"), "-x", "-q", "-p",
+                        "no:cacheprovider", "-k", "attention or gemm or gemv or qkv or decode"], env=env, capture_output=True,
+                       text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
