@@ -72,8 +72,21 @@ static bool dma_deferred() {
     static const bool on = !(getenv("VC_EMU_DMA") && atoi(getenv("VC_EMU_DMA")) == 0);
     return on;
 }
-void dma_issue(const void* src, void* dst) {
+void dma_issue(const void* src, void* dst, const void* wave_base) {
     Fiber* f = g_cur;
+    if (f) {   // the LDS base comes from M0 on the hardware: it has to be wave-uniform
+        WaveCtx& w = f->blk->waves[f->wave];
+        const unsigned seq = ++f->dma_seq, slot = seq % 256;
+        if (w.dma_base_seq[slot] != seq) {
+            w.dma_base_seq[slot] = seq;
+            w.dma_base[slot] = wave_base;
+        } else if (w.dma_base[slot] != wave_base) {
+            fprintf(stderr, "emu: LDS-DMA %u of wave %d in block (%u,%u,%u): lane %d passes LDS base %p, an earlier lane %p — the base "
+                            "is taken from M0 and must be wave-uniform\n", seq, f->wave, f->blk->bidx.x, f->blk->bidx.y, f->blk->bidx.z,
+                    f->lane, wave_base, w.dma_base[slot]);
+            abort();
+        }
+    }
     if (!f || !dma_deferred()) {
         memcpy(dst, src, 16);
         return;
@@ -127,11 +140,13 @@ static void run_block(BlockCtx* b, std::vector<Fiber>& fibers) {
     for (int w = 0; w < n / 64; ++w) {
         b->wave_alive[w] = 64;
         b->waves[w].arrived = 0;
+        memset(b->waves[w].dma_base_seq, 0, sizeof(b->waves[w].dma_base_seq));
     }
     for (int t = 0; t < n; ++t) {
         Fiber& f = fibers[t];
         f.done = false;
         f.dma_head = f.dma_tail = 0;
+        f.dma_seq = 0;
         f.blk = b;
         f.lane = t & 63;
         f.wave = t >> 6;

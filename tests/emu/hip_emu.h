@@ -44,6 +44,10 @@ struct WaveCtx {
     int arrived = 0;
     unsigned gen = 0;
     alignas(16) unsigned char xchg[64][64];
+    // LDS base of the wave's k-th DMA as the first lane to issue it passed it: the hardware takes the base from M0 (a scalar), so
+    // every lane must pass the same one — a lane-dependent base would work here (each lane copies to its own) and not there
+    const void* dma_base[256];
+    unsigned dma_base_seq[256];
 };
 struct BlockCtx;
 // A lane's LDS-DMAs in flight (global_load_lds): issued in program order, LANDED only when the lane waits for them — the
@@ -61,6 +65,7 @@ struct Fiber {
     BlockCtx* blk = nullptr;
     PendingDma dma[128];
     unsigned dma_head = 0, dma_tail = 0;   // ring: [head, tail) pending, oldest first
+    unsigned dma_seq = 0;                  // DMAs this lane has issued in the block (wave-uniform control flow: the same for all lanes)
 };
 struct BlockCtx {
     int nthreads = 0, alive = 0;
@@ -81,7 +86,7 @@ void yield_to_scheduler();
 // __syncthreads() all (hipcc drains vmcnt before the barrier), a bare s_barrier none.  Register loads and stores, which also
 // count on the hardware, are not queued: they can only make the hardware land MORE DMAs at a wait than the model does, so a
 // schedule that is correct here is correct there; one that reads a slot too early reads stale bytes here every time.
-void dma_issue(const void* src, void* dst);
+void dma_issue(const void* src, void* dst, const void* wave_base);
 void dma_wait(int keep_newest);
 void block_barrier();
 void wave_sync();

@@ -234,7 +234,7 @@ VC_DEV u32x4 ld16_stream(const void* p) { return __builtin_nontemporal_load(rein
 // the source address).  Completion is tracked by vmcnt; hipcc waits vmcnt(0) before the next __syncthreads().
 #ifdef VC_EMU
 VC_DEV void glds16(const void* gsrc_lane, void* lds_wave_base) {   // lands when the lane's vmcnt wait says so (hip_emu.h)
-    vc_emu::dma_issue(gsrc_lane, reinterpret_cast<char*>(lds_wave_base) + lane_id() * 16);
+    vc_emu::dma_issue(gsrc_lane, reinterpret_cast<char*>(lds_wave_base) + lane_id() * 16, lds_wave_base);
 }
 #else
 VC_DEV void glds16(const void* gsrc_lane, void* lds_wave_base) {
