@@ -68,6 +68,53 @@ void wave_sync() {
     while (w.gen == gen) yield_to_scheduler();
 }
 
+static bool race_on() {
+    static const bool on = getenv("VC_EMU_RACE") && atoi(getenv("VC_EMU_RACE")) != 0;
+    return on;
+}
+static LdsShadow* shadow_of(Fiber* f, const void* p) {
+    BlockCtx* b = f->blk;
+    if (!b->shadow) return nullptr;
+    const size_t off = (size_t)((const char*)p - b->dyn_smem);
+    if ((const char*)p < b->dyn_smem || off >= b->dyn_bytes) return nullptr;
+    return b->shadow + off / 16;
+}
+static void race_abort(Fiber* f, const void* p, const char* what, int other) {
+    BlockCtx* b = f->blk;
+    fprintf(stderr, "emu: LDS race in block (%u,%u,%u): %s — wave %d lane %d vs wave %d, dynamic LDS offset %zu, barrier epoch %u\n",
+            b->bidx.x, b->bidx.y, b->bidx.z, what, f->wave, f->lane, other, (size_t)((const char*)p - b->dyn_smem), b->bar_gen);
+    abort();
+}
+void lds_read(const void* p) {
+    Fiber* f = g_cur;
+    if (!f || !f->blk->shadow) return;
+    LdsShadow* s = shadow_of(f, p);
+    if (!s) return;
+    const unsigned e = f->blk->bar_gen + 1;   // epochs count from 1: 0 = never
+    if (s->w_epoch == e && s->w_wave >= 0 && s->w_wave != f->wave) race_abort(f, p, "read of bytes another wave wrote since the last barrier", s->w_wave);
+    if (s->r_epoch != e) {
+        s->r_epoch = e;
+        s->r_wave = (short)f->wave;
+    } else if (s->r_wave != f->wave) {
+        s->r_wave = -2;
+    }
+}
+void lds_write(const void* p, bool dma_issue_only) {
+    Fiber* f = g_cur;
+    if (!f || !f->blk->shadow) return;
+    LdsShadow* s = shadow_of(f, p);
+    if (!s) return;
+    const unsigned e = f->blk->bar_gen + 1;
+    if (s->r_epoch == e && s->r_wave != -1 && s->r_wave != f->wave)
+        race_abort(f, p, dma_issue_only ? "DMA issued over bytes another wave read since the last barrier" : "write over bytes another wave read since the last barrier", s->r_wave);
+    if (s->w_epoch == e && s->w_wave >= 0 && s->w_wave != f->wave)
+        race_abort(f, p, dma_issue_only ? "DMA issued over bytes another wave wrote since the last barrier" : "write over bytes another wave wrote since the last barrier", s->w_wave);
+    if (!dma_issue_only) {
+        s->w_epoch = e;
+        s->w_wave = (short)f->wave;
+    }
+}
+
 static bool dma_deferred() {
     static const bool on = !(getenv("VC_EMU_DMA") && atoi(getenv("VC_EMU_DMA")) == 0);
     return on;
@@ -87,13 +134,16 @@ void dma_issue(const void* src, void* dst, const void* wave_base) {
             abort();
         }
     }
+    lds_write(dst, true);
     if (!f || !dma_deferred()) {
         memcpy(dst, src, 16);
+        lds_write(dst, false);
         return;
     }
     if (f->dma_tail - f->dma_head >= 128) {   // cannot happen with a sane schedule: land the oldest
         const PendingDma& d = f->dma[f->dma_head++ % 128];
         memcpy(d.dst, d.src, 16);
+        lds_write(d.dst, false);
     }
     f->dma[f->dma_tail++ % 128] = PendingDma{src, dst};
 }
@@ -103,6 +153,7 @@ void dma_wait(int keep_newest) {
     while ((int)(f->dma_tail - f->dma_head) > keep_newest) {
         const PendingDma& d = f->dma[f->dma_head++ % 128];
         memcpy(d.dst, d.src, 16);
+        lds_write(d.dst, false);
     }
 }
 
@@ -137,6 +188,8 @@ static void run_block(BlockCtx* b, std::vector<Fiber>& fibers) {
     const int n = b->nthreads;
     b->alive = n;
     b->bar_arrived = 0;
+    if (b->shadow)
+        for (size_t i = 0; i <= b->dyn_bytes / 16; ++i) b->shadow[i] = LdsShadow{0u, 0u, (short)-1, (short)-1};
     for (int w = 0; w < n / 64; ++w) {
         b->wave_alive[w] = 64;
         b->waves[w].arrived = 0;
@@ -229,11 +282,14 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
         b->gdim = grid;
         b->body = &body;
         b->dyn_smem = (char*)emu_alloc(shmem);   // dynamic LDS of the launch: guard page behind it like every device buffer
+        b->dyn_bytes = shmem;
+        b->shadow = (race_on() && shmem > 0) ? (LdsShadow*)malloc((shmem / 16 + 1) * sizeof(LdsShadow)) : nullptr;
         for (size_t i = wid; i < nblocks; i += workers) {
             b->bidx = dim3((unsigned)(i % grid.x), (unsigned)((i / grid.x) % grid.y), (unsigned)(i / ((size_t)grid.x * grid.y)));
             run_block(b, fibers);
         }
         emu_free(b->dyn_smem);
+        free(b->shadow);
         delete b;
         munmap(stacks, STACK_BYTES * nthreads);
     };

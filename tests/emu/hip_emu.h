@@ -67,7 +67,14 @@ struct Fiber {
     unsigned dma_head = 0, dma_tail = 0;   // ring: [head, tail) pending, oldest first
     unsigned dma_seq = 0;                  // DMAs this lane has issued in the block (wave-uniform control flow: the same for all lanes)
 };
+// One entry per 16 bytes of a launch's dynamic LDS (VC_EMU_RACE=1): who wrote / read it last and in which barrier epoch
+struct LdsShadow {
+    unsigned w_epoch, r_epoch;
+    short w_wave, r_wave;   // -1: nobody yet; r_wave -2: several waves read it in r_epoch
+};
 struct BlockCtx {
+    size_t dyn_bytes = 0;
+    LdsShadow* shadow = nullptr;
     int nthreads = 0, alive = 0;
     int bar_arrived = 0;
     unsigned bar_gen = 0;
@@ -86,6 +93,12 @@ void yield_to_scheduler();
 // __syncthreads() all (hipcc drains vmcnt before the barrier), a bare s_barrier none.  Register loads and stores, which also
 // count on the hardware, are not queued: they can only make the hardware land MORE DMAs at a wait than the model does, so a
 // schedule that is correct here is correct there; one that reads a slot too early reads stale bytes here every time.
+// LDS race check (VC_EMU_RACE=1; dynamic LDS only): two waves may touch the same 16 bytes in one barrier epoch only if both
+// read.  A read of bytes another wave wrote (or DMA-landed) since the last barrier, a write or a DMA ISSUE over bytes another wave
+// read or wrote since the last barrier -> the emulator aborts with the block, the waves and the LDS offset.  Accesses of one wave
+// are ordered by its own instruction stream and vmcnt waits (the model above); barriers are __syncthreads() and the bare s_barrier.
+void lds_read(const void* p);
+void lds_write(const void* p, bool dma_issue_only);
 void dma_issue(const void* src, void* dst, const void* wave_base);
 void dma_wait(int keep_newest);
 void block_barrier();

@@ -2,7 +2,9 @@
 descending / pseudo-random order (VC_EMU_ORDER, tests/emu/emu_runtime.cpp; read once per process, hence the subprocess).  Fibers
 yield only at barriers and wave collectives, so the order IS the interleaving: a kernel that leans on a barrier or a vmcnt wait
 it does not have computes differently under one of them (dropping the per-tile barrier of the flash kernel fails 5 of 6 attention
-cases; loosening the GEMV's counted wait by one fails at once)."""
+cases; loosening the GEMV's counted wait by one fails at once).  The same run has the emulator's LDS race check on (VC_EMU_RACE=1):
+two waves touching the same 16 bytes of dynamic LDS inside one barrier epoch, unless both read, abort the run with the block, the
+waves and the offset."""
 import os
 import subprocess
 import sys
@@ -14,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("order", ["11"])   # descending = "1"; any other number seeds a random order
 def test_kernels_under_another_wave_order(order):
-    env = dict(os.environ, VC_EMU_ORDER=order)
+    env = dict(os.environ, VC_EMU_ORDER=order, VC_EMU_RACE="1")   # ... and with the dynamic-LDS race check on (hip_emu.h)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_kernels_emu.py"), "-x", "-q", "-p",
                         "no:cacheprovider", "-k", "attention or gemm or gemv or qkv or decode"], env=env, capture_output=True,
                        text=True, timeout=1500)

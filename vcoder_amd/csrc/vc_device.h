@@ -214,13 +214,20 @@ VC_DEV float rows_max(float v) {
 VC_DEV bool wave_any(bool pred) { return __builtin_amdgcn_ballot_w64(pred) != 0; }
 #endif
 
-// 16-byte global/LDS accessors on raw pointers
-VC_DEV u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
-VC_DEV void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
-VC_DEV u32x2 ld8(const void* p) { return *reinterpret_cast<const u32x2*>(p); }
-VC_DEV void st8(void* p, u32x2 v) { *reinterpret_cast<u32x2*>(p) = v; }
-VC_DEV f32x4 ld16f(const void* p) { return *reinterpret_cast<const f32x4*>(p); }
-VC_DEV void st16f(void* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+// 16-byte global/LDS accessors on raw pointers (the emulator's LDS race check hooks in here: tests/emu/hip_emu.h)
+#ifdef VC_EMU
+#define VC_LDS_R(p) vc_emu::lds_read(p)
+#define VC_LDS_W(p) vc_emu::lds_write(p, false)
+#else
+#define VC_LDS_R(p) ((void)0)
+#define VC_LDS_W(p) ((void)0)
+#endif
+VC_DEV u32x4 ld16(const void* p) { VC_LDS_R(p); return *reinterpret_cast<const u32x4*>(p); }
+VC_DEV void st16(void* p, u32x4 v) { VC_LDS_W(p); *reinterpret_cast<u32x4*>(p) = v; }
+VC_DEV u32x2 ld8(const void* p) { VC_LDS_R(p); return *reinterpret_cast<const u32x2*>(p); }
+VC_DEV void st8(void* p, u32x2 v) { VC_LDS_W(p); *reinterpret_cast<u32x2*>(p) = v; }
+VC_DEV f32x4 ld16f(const void* p) { VC_LDS_R(p); return *reinterpret_cast<const f32x4*>(p); }
+VC_DEV void st16f(void* p, f32x4 v) { VC_LDS_W(p); *reinterpret_cast<f32x4*>(p) = v; }
 
 // non-temporal 16-byte load for streams that are read once per launch (decode weights, KV cache rows)
 #ifdef VC_EMU
