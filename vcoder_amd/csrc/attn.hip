@@ -223,6 +223,10 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && QS == 1 && !SPLIT) ? 4 :
     constexpr int PL = SPLIT ? 2 : 1;                  // operand planes
     constexpr int STAGE = PL * (KB_ + VB_);            // [K hi | K lo | V^T hi | V^T lo]
     char* lds0;                                        // [2][STAGE], double-buffered: the LDS-DMA of tile t+1 lands under tile t
+#ifdef VC_EMU   // the emulator's guard page, NaN poison and race check cover DYNAMIC LDS: the test build takes both forms from it
+    VC_DYNAMIC_SMEM(char, lds_dyn);
+    lds0 = lds_dyn;
+#else
     if constexpr (SPLIT) {
         VC_DYNAMIC_SMEM(char, lds_dyn);
         lds0 = lds_dyn;
@@ -230,6 +234,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && QS == 1 && !SPLIT) ? 4 :
         __shared__ __attribute__((aligned(16))) char lds_st[2 * STAGE];
         lds0 = lds_st;
     }
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, j = lane & 15;
     // Workgroup order.  sched 0: the 3-D grid as launched (query block fastest).  Otherwise a 1-D grid whose linear id — the
@@ -514,8 +519,13 @@ static void launch_attention_v(const AttnArgs& a0, hipStream_t s) {
     const int QB = WAVES * QS * 16;
     AttnArgs a = a0;
     const dim3 grid = attention_grid(a, QB), block(WAVES * 64);
-    if (a.causal) VC_LAUNCH((attention_kernel<HD, true, WAVES, QS>), grid, block, 0, s, a);
-    else VC_LAUNCH((attention_kernel<HD, false, WAVES, QS>), grid, block, 0, s, a);
+#ifdef VC_EMU
+    constexpr size_t shmem = 2 * (64 * HD * 2 + HD * 128);   // the two stages the product build holds in static LDS
+#else
+    constexpr size_t shmem = 0;
+#endif
+    if (a.causal) VC_LAUNCH((attention_kernel<HD, true, WAVES, QS>), grid, block, shmem, s, a);
+    else VC_LAUNCH((attention_kernel<HD, false, WAVES, QS>), grid, block, shmem, s, a);
 }
 
 template <int HD>
