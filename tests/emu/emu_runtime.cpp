@@ -85,11 +85,18 @@ static void race_abort(Fiber* f, const void* p, const char* what, int other) {
             b->bidx.x, b->bidx.y, b->bidx.z, what, f->wave, f->lane, other, (size_t)((const char*)p - b->dyn_smem), b->bar_gen);
     abort();
 }
+void lgkm_wait(int keep_newest) {
+    Fiber* f = g_cur;
+    if (!f) return;
+    if ((int)(f->lds_rd_tail - f->lds_rd_head) > keep_newest) f->lds_rd_head = f->lds_rd_tail - (unsigned)keep_newest;
+}
 void lds_read(const void* p) {
     Fiber* f = g_cur;
     if (!f || !f->blk->shadow) return;
     LdsShadow* s = shadow_of(f, p);
     if (!s) return;
+    if (f->lds_rd_tail - f->lds_rd_head >= 64) ++f->lds_rd_head;
+    f->lds_rd[f->lds_rd_tail++ % 64] = (const void*)((uintptr_t)p & ~(uintptr_t)15);
     const unsigned e = f->blk->bar_gen + 1;   // epochs count from 1: 0 = never
     if (s->w_epoch == e && s->w_wave >= 0 && s->w_wave != f->wave) race_abort(f, p, "read of bytes another wave wrote since the last barrier", s->w_wave);
     if (s->r_epoch != e) {
@@ -135,6 +142,14 @@ void dma_issue(const void* src, void* dst, const void* wave_base) {
         }
     }
     lds_write(dst, true);
+    if (f && f->blk->shadow)
+        for (unsigned i = f->lds_rd_head; i != f->lds_rd_tail; ++i)
+            if (f->lds_rd[i % 64] == (const void*)((uintptr_t)dst & ~(uintptr_t)15)) {
+                fprintf(stderr, "emu: block (%u,%u,%u) wave %d lane %d: DMA issued into dynamic LDS offset %zu that this lane read without an "
+                                "lgkmcnt wait in between\n", f->blk->bidx.x, f->blk->bidx.y, f->blk->bidx.z, f->wave, f->lane,
+                        (size_t)((const char*)dst - f->blk->dyn_smem));
+                abort();
+            }
     if (!f || !dma_deferred()) {
         memcpy(dst, src, 16);
         lds_write(dst, false);
@@ -200,6 +215,7 @@ static void run_block(BlockCtx* b, std::vector<Fiber>& fibers) {
         f.done = false;
         f.dma_head = f.dma_tail = 0;
         f.dma_seq = 0;
+        f.lds_rd_head = f.lds_rd_tail = 0;
         f.blk = b;
         f.lane = t & 63;
         f.wave = t >> 6;

@@ -66,6 +66,8 @@ struct Fiber {
     PendingDma dma[128];
     unsigned dma_head = 0, dma_tail = 0;   // ring: [head, tail) pending, oldest first
     unsigned dma_seq = 0;                  // DMAs this lane has issued in the block (wave-uniform control flow: the same for all lanes)
+    const void* lds_rd[64];                // dynamic-LDS addresses this lane read since its last lgkmcnt wait (ring, newest last)
+    unsigned lds_rd_head = 0, lds_rd_tail = 0;
 };
 // One entry per 16 bytes of a launch's dynamic LDS (VC_EMU_RACE=1): who wrote / read it last and in which barrier epoch
 struct LdsShadow {
@@ -97,6 +99,10 @@ void yield_to_scheduler();
 // read.  A read of bytes another wave wrote (or DMA-landed) since the last barrier, a write or a DMA ISSUE over bytes another wave
 // read or wrote since the last barrier -> the emulator aborts with the block, the waves and the LDS offset.  Accesses of one wave
 // are ordered by its own instruction stream and vmcnt waits (the model above); barriers are __syncthreads() and the bare s_barrier.
+// Same-wave write-after-read (VC_EMU_RACE=1): a DMA issued into bytes this lane has read without an lgkmcnt wait (explicit, or the
+// one hipcc puts in front of __syncthreads()) in between — the read may still sit in the LDS queue when the DMA's data arrives.
+// Conservative: a read whose VALUE was already consumed has completed too, which the emulator cannot see.
+void lgkm_wait(int keep_newest);
 void lds_read(const void* p);
 void lds_write(const void* p, bool dma_issue_only);
 void dma_issue(const void* src, void* dst, const void* wave_base);
@@ -215,6 +221,7 @@ inline hipError_t hipGraphLaunch(hipGraphExec_t g, hipStream_t) { for (auto& f :
 
 inline void __syncthreads() {
     vc_emu::dma_wait(0);
+    vc_emu::lgkm_wait(0);
     vc_emu::block_barrier();
 }
 inline float __expf(float x) { return expf(x); }

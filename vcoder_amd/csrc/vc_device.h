@@ -254,7 +254,7 @@ VC_DEV void glds16(const void* gsrc_lane, void* lds_wave_base) {
 #ifdef VC_EMU
 VC_DEV void wg_barrier_raw() { vc_emu::block_barrier(); }   // bare s_barrier: no implied vmcnt drain
 template <int N> VC_DEV void wait_vmcnt() { vc_emu::dma_wait(N); }
-template <int N> VC_DEV void wait_lgkmcnt() {}
+template <int N> VC_DEV void wait_lgkmcnt() { vc_emu::lgkm_wait(N); }
 template <int P> VC_DEV void set_prio() {}
 VC_DEV void sched_fence() {}
 VC_DEV void pin_vgprs(f32x4&) {}
