@@ -43,7 +43,15 @@ class HipEngine:
             self._check(self.lib.vc_model_create_shared(self._ctx, _parent._model, C.byref(self._model)))
             self.finalized = True
             return
-        c = _lib.ModelCfg(
+        c = self._model_cfg(cfg)
+        self._check(self.lib.vc_model_create(self._ctx, C.byref(c), C.byref(self._model)))
+        self.finalized = False
+        self.last_S = 0
+
+    @staticmethod
+    def _model_cfg(cfg: VCoderConfig) -> "_lib.ModelCfg":
+        """the vc_model_cfg of a configuration (include/vcoder_hip.h)"""
+        return _lib.ModelCfg(
             variant=_lib.VARIANTS[cfg.variant], vit_hidden=cfg.mm_hidden_size, vit_heads=cfg.vit_num_heads,
             vit_ffn=cfg.vit_intermediate_size, vit_layers=cfg.vit_num_layers, vit_layers_used=cfg.vit_layers_used,
             vit_image=cfg.vit_image_size, vit_patch=cfg.vit_patch_size,
@@ -54,9 +62,6 @@ class HipEngine:
             rope_theta=cfg.rope_theta, mm_proj_depth=synth.projector_depth(cfg.mm_projector_type),
             seg_proj_depth=synth.projector_depth(cfg.seg_mm_projector_type) if cfg.variant != "llava" else 0,
             pad_token_id=int(cfg.pad_token_id or 0))
-        self._check(self.lib.vc_model_create(self._ctx, C.byref(c), C.byref(self._model)))
-        self.finalized = False
-        self.last_S = 0
 
     def fork(self) -> "HipEngine":
         """A new session on the same (finalized) weights: own HIP stream, KV cache and hipGraph.  Sessions can be
