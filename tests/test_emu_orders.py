@@ -21,8 +21,9 @@ def test_kernels_under_another_wave_order(order):
            "-k", "attention or gemm or gemv or qkv or decode"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
     if r.returncode != 0:
-        # one unexplained failure in ~40 runs was seen while this test was written (not reproduced since): keep its output and
-        # require the repeat to pass, so that a reproducible failure still fails and a one-off leaves a trace instead of a red run
+        # (a one-in-40 failure seen while this test was written turned out to be the EMULATOR's own arrival counter — a plain
+        # increment shared by workgroups on different OS threads; fixed in vc_device.h.)  Keep the output of a failing run and
+        # require the repeat to pass: a reproducible failure still fails, a one-off leaves a trace instead of a red run
         import warnings
 
         first = r.stdout[-3000:] + r.stderr[-2000:]

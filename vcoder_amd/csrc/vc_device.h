@@ -303,10 +303,15 @@ VC_DEV void wave_lds_fence() { __builtin_amdgcn_wave_barrier(); }
 // drains them (vmcnt(0)) before it counts its arrival.  No agent-scope FENCE: on this multi-XCD part a release/acquire
 // fence writes back / invalidates the XCD's whole L2 (measured: 4-8x slower launches).
 #ifdef VC_EMU
-VC_DEV void st_agent(float* p, float v) { *p = v; }
-VC_DEV float ld_agent(const float* p) { return *p; }
-VC_DEV void st_agent_u32(unsigned* p, unsigned v) { *p = v; }
-VC_DEV unsigned atomic_inc_agent(unsigned* p) { return (*p)++; }  // emulated workgroups run one after another
+// the emulator runs workgroups on several OS threads at once: real atomics.  The arrival count carries acquire / release here —
+// what the drained write-through stores and cache-bypassing loads provide on the device (a plain `(*p)++` lost an arrival about
+// once in 40 runs of the split-K test: two workgroups read the same count and nobody finished the tile)
+VC_DEV void st_agent(float* p, float v) { __atomic_store_n(reinterpret_cast<unsigned*>(p), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED); }
+VC_DEV float ld_agent(const float* p) {
+    return __builtin_bit_cast(float, __atomic_load_n(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED));
+}
+VC_DEV void st_agent_u32(unsigned* p, unsigned v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+VC_DEV unsigned atomic_inc_agent(unsigned* p) { return __atomic_fetch_add(p, 1u, __ATOMIC_ACQ_REL); }
 #else
 VC_DEV void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 VC_DEV float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
