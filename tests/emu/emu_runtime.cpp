@@ -68,10 +68,8 @@ void wave_sync() {
     while (w.gen == gen) yield_to_scheduler();
 }
 
-static bool race_on() {
-    static const bool on = getenv("VC_EMU_RACE") && atoi(getenv("VC_EMU_RACE")) != 0;
-    return on;
-}
+bool g_race = getenv("VC_EMU_RACE") && atoi(getenv("VC_EMU_RACE")) != 0;
+static bool race_on() { return g_race; }
 static LdsShadow* shadow_of(Fiber* f, const void* p) {
     BlockCtx* b = f->blk;
     if (!b->shadow) return nullptr;
@@ -85,12 +83,12 @@ static void race_abort(Fiber* f, const void* p, const char* what, int other) {
             b->bidx.x, b->bidx.y, b->bidx.z, what, f->wave, f->lane, other, (size_t)((const char*)p - b->dyn_smem), b->bar_gen);
     abort();
 }
-void lgkm_wait(int keep_newest) {
+void lgkm_wait_slow(int keep_newest) {
     Fiber* f = g_cur;
     if (!f) return;
     if ((int)(f->lds_rd_tail - f->lds_rd_head) > keep_newest) f->lds_rd_head = f->lds_rd_tail - (unsigned)keep_newest;
 }
-void lds_read(const void* p) {
+void lds_read_slow(const void* p) {
     Fiber* f = g_cur;
     if (!f || !f->blk->shadow) return;
     LdsShadow* s = shadow_of(f, p);
@@ -106,7 +104,7 @@ void lds_read(const void* p) {
         s->r_wave = -2;
     }
 }
-void lds_write(const void* p, bool dma_issue_only) {
+void lds_write_slow(const void* p, bool dma_issue_only) {
     Fiber* f = g_cur;
     if (!f || !f->blk->shadow) return;
     LdsShadow* s = shadow_of(f, p);

@@ -102,9 +102,13 @@ void yield_to_scheduler();
 // Same-wave write-after-read (VC_EMU_RACE=1): a DMA issued into bytes this lane has read without an lgkmcnt wait (explicit, or the
 // one hipcc puts in front of __syncthreads()) in between — the read may still sit in the LDS queue when the DMA's data arrives.
 // Conservative: a read whose VALUE was already consumed has completed too, which the emulator cannot see.
-void lgkm_wait(int keep_newest);
-void lds_read(const void* p);
-void lds_write(const void* p, bool dma_issue_only);
+extern bool g_race;   // VC_EMU_RACE != 0, read once: the hooks below cost one predictable branch when it is off
+void lgkm_wait_slow(int keep_newest);
+void lds_read_slow(const void* p);
+void lds_write_slow(const void* p, bool dma_issue_only);
+inline void lgkm_wait(int keep_newest) { if (g_race) lgkm_wait_slow(keep_newest); }
+inline void lds_read(const void* p) { if (g_race) lds_read_slow(p); }
+inline void lds_write(const void* p, bool dma_issue_only) { if (g_race) lds_write_slow(p, dma_issue_only); }
 void dma_issue(const void* src, void* dst, const void* wave_base);
 void dma_wait(int keep_newest);
 void block_barrier();
