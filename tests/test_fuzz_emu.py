@@ -85,16 +85,15 @@ def _run_cases(eng, n_cases, rng, mode="strict"):
     return stats
 
 
-@pytest.mark.parametrize("variant,n_cases,seed", [("vcoder_ds", 27, 11), ("vcoder", 18, 12), ("llava", 12, 13)])
+@pytest.mark.parametrize("variant,n_cases,seed", [("vcoder_ds", 20, 11), ("vcoder", 14, 12), ("llava", 10, 13)])
 def test_random_prompt_structures(emu_lib, variant, n_cases, seed):
     stats = _run_cases(e2e_cases.engine_for(variant, emu_lib), n_cases, np.random.RandomState(seed))
     assert stats.get("ok", 0) >= n_cases // 4, stats     # the generator keeps a healthy share of valid prompts
     print(variant, stats)
 
 
-@pytest.mark.parametrize("variant,seed,mode", [("vcoder_ds", 21, "strict"), ("vcoder_ds", 22, "split"), ("vcoder_ds", 23, "strict"),
-                                               ("vcoder", 24, "split"), ("vcoder", 25, "strict"), ("llava", 26, "split"),
-                                               ("llava", 27, "strict")])
+@pytest.mark.parametrize("variant,seed,mode", [("vcoder_ds", 21, "strict"), ("vcoder_ds", 22, "split"), ("vcoder", 24, "split"),
+                                               ("vcoder", 25, "strict"), ("llava", 26, "split")])
 def test_random_configs(emu_lib, variant, seed, mode):
     """the same check on random variations of the tiny architecture: feature selection (patch / cls_patch, any layer), projector
     types per modality, head dims 64 / 128 on both sides, depths, image grids, norm epsilon (oracle/fuzz_cases.random_overrides —
