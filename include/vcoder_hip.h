@@ -162,6 +162,12 @@ int vc_prefill(vc_model* m, const int64_t* ids, int B, int T, const float* img, 
 int vc_prefill_embeds_only(vc_model* m, const int64_t* ids, int B, int T, const float* img, const float* seg,
                            const float* depth, int pixels_on_device, int has_attention_mask, float* out_host,
                            int* S_out);
+/* the spliced length S the same arguments would give a vc_prefill / vc_generate call — the splice plan of
+ * prepare_inputs_labels_for_multimodal (vcoder_ds_llava_arch.py:175-276) alone: no tower pass, no KV / mask state touched;
+ * img / seg only say whether the modality is present, the depth pixels are read for is_depth_zero (:161).  Same plan errors
+ * (VC_ERR_INDEX, VC_ERR_UNEQUAL) as the real call. */
+int vc_plan_spliced_len(vc_model* m, const int64_t* ids, int B, int T, const float* img, const float* seg, const float* depth,
+                        int pixels_on_device, int has_attention_mask, int* S_out);
 
 /* one cached decode step (input_ids.shape[1]==1 fast path, vcoder_ds_llava_arch.py:130-133).
  * tok [B] host (NULL: use the token the previous step selected on device); logits [B,V] host or NULL;

@@ -65,6 +65,7 @@ def declare(lib: C.CDLL) -> C.CDLL:
     lib.vc_encode.argtypes = [vp, i32, vp, i32, i32, vp]
     lib.vc_prefill.argtypes = [vp, vp, i32, i32, vp, vp, vp, i32, i32, vp, vp, C.POINTER(C.c_int)]
     lib.vc_prefill_embeds_only.argtypes = [vp, vp, i32, i32, vp, vp, vp, i32, i32, vp, C.POINTER(C.c_int)]
+    lib.vc_plan_spliced_len.argtypes = [vp, vp, i32, i32, vp, vp, vp, i32, i32, C.POINTER(C.c_int)]
     lib.vc_decode_step.argtypes = [vp, vp, vp, vp]
     lib.vc_generate_greedy.argtypes = [vp, vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, vp, C.POINTER(C.c_int)]
     lib.vc_generate_greedy_stop.argtypes = [vp, vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, vp,
@@ -112,7 +113,7 @@ def declare(lib: C.CDLL) -> C.CDLL:
     lib.vc_preprocess_image.argtypes = [vp, vp, i32, i32, i32, f32p, f32p, vp, i32]
     lib.vc_preprocess_image.restype = C.c_int
     for name in ("vc_init", "vc_synchronize", "vc_model_create", "vc_model_load_tensor", "vc_model_synth_tensor",
-                 "vc_model_finalize", "vc_encode", "vc_prefill", "vc_prefill_embeds_only", "vc_decode_step",
+                 "vc_model_finalize", "vc_encode", "vc_prefill", "vc_prefill_embeds_only", "vc_plan_spliced_len", "vc_decode_step",
                  "vc_generate_greedy", "vc_profile_decode_gemv", "vc_last_timings"):
         getattr(lib, name).restype = C.c_int
     return lib

@@ -69,11 +69,22 @@ def _strip_peft_prefixes(sd: dict) -> dict:
 
 def load_lora_adapter(path: str):
     """adapter_config.json + adapter_model.{safetensors,bin} of a peft LoRA checkpoint ->
-    ({target state-dict key: (A [r, in], B [out, r])}, scale = lora_alpha / r, fan_in_fan_out)"""
+    ({target state-dict key: (A [r, in], B [out, r])}, scale = lora_alpha / r, fan_in_fan_out).
+
+    Plain LoRA only: anything that would change what `PeftModel.merge_and_unload` computes (rsLoRA scaling, DoRA magnitudes,
+    per-module rank / alpha patterns, saved extra modules, LoRA on embeddings) is refused instead of being merged wrongly."""
     with open(os.path.join(path, "adapter_config.json")) as f:
         ac = json.load(f)
     if ac.get("peft_type", "LORA") != "LORA":
         raise ValueError(f"unsupported peft_type {ac.get('peft_type')}")
+    for flag in ("use_rslora", "use_dora"):
+        if ac.get(flag):
+            raise NotImplementedError(f"LoRA adapter with {flag}=true: merged weights would differ from peft's (not supported)")
+    for pat in ("rank_pattern", "alpha_pattern"):
+        if ac.get(pat):
+            raise NotImplementedError(f"LoRA adapter with a non-empty {pat}: per-module scales are not supported")
+    if ac.get("modules_to_save"):
+        raise NotImplementedError(f"LoRA adapter with modules_to_save={ac['modules_to_save']}: saved modules are not supported")
     st = os.path.join(path, "adapter_model.safetensors")
     if os.path.exists(st):
         from safetensors import safe_open
@@ -82,13 +93,18 @@ def load_lora_adapter(path: str):
             raw = {k: sf.get_tensor(k) for k in sf.keys()}
     else:
         raw = _torch_load(os.path.join(path, "adapter_model.bin"))
-    pairs = {}
+    pairs, unknown = {}, []
     for k, v in raw.items():
         for tag, idx in ((".lora_A.", 0), (".lora_B.", 1)):
             if tag in k:
                 base = k.split(tag)[0] + ".weight"                       # ...q_proj.lora_A[.default].weight -> ...q_proj.weight
                 base = base[len("base_model.model."):] if base.startswith("base_model.model.") else base
                 pairs.setdefault(base, [None, None])[idx] = v.float()
+                break
+        else:
+            unknown.append(k)   # lora_embedding_A/B, lora_magnitude_vector, modules_to_save copies, ...
+    if unknown:
+        raise NotImplementedError(f"LoRA adapter holds tensors that are not lora_A / lora_B matrices: {sorted(unknown)[:3]}")
     missing = [k for k, (a, b) in pairs.items() if a is None or b is None]
     if missing:
         raise ValueError(f"LoRA adapter lacks a lora_A / lora_B partner for {missing[:3]}")
@@ -96,25 +112,34 @@ def load_lora_adapter(path: str):
 
 
 def iter_lora_merged(model_base: str, model_path: str) -> Iterator[Tuple[str, object]]:
-    """builder.py:42-77: the base LLM's tensors with the LoRA deltas merged in (W + alpha / r * B @ A — what
-    PeftModel.merge_and_unload computes), then the non-LoRA trainables (projector etc.) of the LoRA checkpoint."""
+    """builder.py:42-77 in the reference's order: the base LLM's tensors, overridden by the non-LoRA trainables of the LoRA
+    checkpoint (`load_state_dict(non_lora_trainables, strict=False)`, :72 — projector etc., and embed_tokens / lm_head when the
+    fine-tune saved them, possibly with another vocabulary size: the model is built from the LoRA checkpoint's config), THEN
+    the LoRA deltas merged in (W + alpha / r * B @ A — what PeftModel.merge_and_unload computes, :74-77)."""
     pairs, scale, fifo = load_lora_adapter(model_path)
+    nl = os.path.join(model_path, "non_lora_trainables.bin")
+    if not os.path.exists(nl):
+        raise FileNotFoundError(f"{nl} (no network here: the reference would download it from the hub)")
+    over = _strip_peft_prefixes(_torch_load(nl))
     used = set()
-    for k, v in iter_checkpoint_tensors(model_base):
+
+    def merged(k, v):
         if k in pairs:
             a, b = pairs[k]
             delta = (b @ a) * scale
             v = v.float() + (delta.t() if fifo else delta)
             used.add(k)
-        yield k, v
+        return v
+
+    for k, v in iter_checkpoint_tensors(model_base):
+        if k in over:
+            continue   # the checkpoint's own copy wins (yielded below; its shape follows the LoRA checkpoint's config)
+        yield k, merged(k, v)
+    for k, v in over.items():
+        yield k, merged(k, v)
     left = set(pairs) - used
     if left:
         raise KeyError(f"LoRA targets not found in the base checkpoint: {sorted(left)[:3]}")
-    nl = os.path.join(model_path, "non_lora_trainables.bin")
-    if not os.path.exists(nl):
-        raise FileNotFoundError(f"{nl} (no network here: the reference would download it from the hub)")
-    for k, v in _strip_peft_prefixes(_torch_load(nl)).items():
-        yield k, v
 
 
 def iter_base_with_projector(model_base: str, model_path: str) -> Iterator[Tuple[str, object]]:

@@ -204,6 +204,7 @@ struct vc_model {
     float* attn_out = nullptr;
     size_t attn_cap = 0;
     Buf attn_q;                   // roped q of a decode step with output_attentions
+    bool plan_only = false;       // do_prefill stops behind the splice plan (vc_plan_spliced_len): no tower pass, no state change
     int reserve_new = 64;         // KV slots a vc_prefill keeps free behind the prompt (vc_model_reserve_decode)
     int layer_limit = 0;          // > 0: a prefill evaluates only the first layer_limit decoder layers (vc_model_set_layer_limit)
     // LLM workspace
@@ -917,13 +918,14 @@ void ensure_strict(vc_model* m, int B, int Scap) {
 float* s_kcache(vc_model* m, int l) { return m->s_kc.as<float>() + (size_t)l * m->s_capB * m->c.heads * m->s_capS * m->hd; }
 float* s_vcache(vc_model* m, int l) { return m->s_vc.as<float>() + (size_t)l * m->s_capB * m->c.heads * m->s_capS * m->hd; }
 
-// one decoder stack pass over `T` new tokens per sample starting at the device-scalar position (prefill: pos 0)
-void run_llm_layers_strict(vc_model* m, float* x, int B, int T, const int* pos_dev) {
+// one decoder stack pass over `T` new tokens per sample starting at the device-scalar position (prefill: pos 0).
+// is_prefill says which of the two the pass is — a text-only prefill of ONE token has T == 1 too
+void run_llm_layers_strict(vc_model* m, float* x, int B, int T, const int* pos_dev, bool is_prefill) {
     const vc_model_cfg& c = m->c;
     const int D = c.hidden, F = c.ffn, H = c.heads, M = B * T;
     float *xn = m->s_xn.as<float>(), *qkv = m->s_qkv.as<float>(), *q = m->s_q.as<float>(), *at = m->s_attn.as<float>(),
           *h = m->s_h.as<float>();
-    const int nl = (m->layer_limit > 0 && T > 1) ? std::min(m->layer_limit, c.layers) : c.layers;
+    const int nl = (m->layer_limit > 0 && is_prefill) ? std::min(m->layer_limit, c.layers) : c.layers;
     for (int l = 0; l < nl; ++l) {
         const LlmLayer& L = m->llm[l];
         launch_rmsnorm_f32(x, nullptr, L.in_norm, xn, M, D, c.rms_eps, m->st);
@@ -932,13 +934,14 @@ void run_llm_layers_strict(vc_model* m, float* x, int B, int T, const int* pos_d
         launch_qkv_rope_f32(qa, m->st);
         AttnF32Args aa{q, s_kcache(m, l), s_vcache(m, l), at, B, H, T, m->hd, T, m->s_capS, 1, 0, pos_dev,
                        1.0f / sqrtf((float)m->hd)};
-        if (T > 1 ? m->has_kmask : m->kmask_in_decode) {
+        if (is_prefill ? m->has_kmask : m->kmask_in_decode) {
             aa.key_mask = m->kmask.as<uint8_t>();
             aa.mask_stride = c.max_positions;
         }
         launch_attention_f32(aa, m->st);
-        const bool step = T == 1 && x == m->x_dec.as<float>();   // a session's cached decode step (m->cur_pos = its position)
-        if ((T > 1 && x == m->x.as<float>()) || step) {
+        const bool step = !is_prefill && x == m->x_dec.as<float>();   // a session's cached decode step (m->cur_pos = its position)
+        const bool pre = is_prefill && x == m->x.as<float>();
+        if (pre || step) {
             AttnProbsArgs pa{};
             pa.q32 = q;
             pa.k32 = s_kcache(m, l);
@@ -951,7 +954,7 @@ void run_llm_layers_strict(vc_model* m, float* x, int B, int T, const int* pos_d
         launch_rmsnorm_f32(x, nullptr, L.post_norm, xn, M, D, c.rms_eps, m->st);
         gemm32(m, xn, L.gu_w, nullptr, h, M, 2 * F, D, D, D, F, EPI_SWIGLU);
         gemm32(m, h, L.down_w, nullptr, x, M, D, F, F, F, D, EPI_RESID_F32);
-        if (T > 1 && x == m->x.as<float>()) emit_hidden(m, l + 1, B, T);
+        if (pre) emit_hidden(m, l + 1, B, T);
         else if (step) emit_hidden(m, l + 1, B, 1, x);
     }
 }
@@ -1398,7 +1401,7 @@ void enqueue_decode_step_diag(vc_model* m, const LoopView& v, int nrows, int pos
 void enqueue_decode_step_strict(vc_model* m, int B) {
     const LoopView v = session_view(m);
     emit_hidden(m, 0, B, 1, m->x_dec.as<float>());
-    run_llm_layers_strict(m, m->x_dec.as<float>(), B, 1, v.rows + RS_POS);
+    run_llm_layers_strict(m, m->x_dec.as<float>(), B, 1, v.rows + RS_POS, false);
     logits_strict(m, m->x_dec.as<float>(), nullptr, B);
     launch_select_embed(select_args(m, v, v.logits, B, 3), v.st);
 }
@@ -1516,6 +1519,22 @@ void do_prefill(vc_model* m, const int64_t* ids, int B, int T, const float* img,
         for (int k = 0; k < 3; ++k) m->feat_rows[k] = 0;
         if (m->precision) m->s_feats.ensure(256);   // the fp32 splice takes a feature base pointer (no row refers to it)
         else m->feats.ensure(256);
+    } else if (m->plan_only) {
+        // the plan needs the feature-row COUNTS of every modality and the depth pixels (is_depth_zero), not the features
+        const int Rp = m->Tv - (c.vit_keep_cls ? 0 : 1);
+        const size_t img_elems = (size_t)3 * c.vit_image * c.vit_image;
+        int first = 0;
+        for (int k = 0; k < 3; ++k) {
+            m->feat_off[k] = first * Rp;
+            m->feat_rows[k] = pix.p[k] ? pix.n[k] * Rp : 0;
+            if (pix.p[k]) first += pix.n[k];
+        }
+        REQUIRE(first > 0, VC_ERR_INVALID, "no images");
+        m->v_pixels.ensure((size_t)first * img_elems * 4);
+        if (depth)
+            HIPCHK(hipMemcpyAsync(m->v_pixels.as<float>() + (size_t)(first - pix.n[VC_MOD_DEPTH]) * img_elems, depth,
+                                  (size_t)pix.n[VC_MOD_DEPTH] * img_elems * 4, on_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                                  m->st));
     } else if (m->precision == 1) run_vit_and_adapters_strict(m, pix, on_dev);
     else if (m->precision == 2) run_vit_and_adapters_split(m, pix, on_dev);
     else run_vit_and_adapters(m, pix, on_dev);
@@ -1564,6 +1583,10 @@ void do_prefill(vc_model* m, const int64_t* ids, int B, int T, const float* img,
     // quirk 6: unequal spliced lengths with an attention_mask and no labels die at vcoder_ds_llava_arch.py:295-297
     REQUIRE(!(unequal && has_mask), VC_ERR_UNEQUAL, "local variable '_new_labels' referenced before assignment");
     REQUIRE(S >= 1, VC_ERR_INVALID, "empty sequence");
+    if (m->plan_only) {
+        if (S_out) *S_out = (int)S;
+        return;
+    }
     // The caller's attention_mask [B, T] is LEFT-extended with "visible" over the S - T rows the splice added — by position,
     // whatever the rows hold (vcoder_ds_llava_arch.py:305-311) — and hides its zero positions as KEYS from every query of the
     // sequence in this prefill.
@@ -1634,7 +1657,7 @@ void finish_prefill(vc_model* m, const KvTarget& kv, float* logits_all_host) {
     HIPCHK(hipMemcpyAsync(m->last_idx.p, idx.data(), B * 4, hipMemcpyHostToDevice, m->st));
     emit_hidden(m, 0, B, S);   // inputs_embeds
     if (m->precision == 1) {
-        run_llm_layers_strict(m, m->x.as<float>(), B, S, nullptr);
+        run_llm_layers_strict(m, m->x.as<float>(), B, S, nullptr, true);
         logits_strict(m, m->x.as<float>(), m->last_idx.as<int>(), B);
     } else if (m->precision == 2) {
         run_prefill_layers_split(m, kv, B, S);
@@ -2214,6 +2237,26 @@ VC_API int vc_prefill_embeds_only(vc_model* m, const int64_t* ids, int B, int T,
     GUARD_END(m->ctx)
 }
 
+/* The spliced length S a vc_prefill* / vc_generate* call with these arguments would produce — the splice plan alone (ids,
+ * which modalities are present, the per-sample image counts of vc_set_image_counts, is_depth_zero of the depth pixels): no
+ * tower pass, no cache or mask state touched.  Same errors as the real call's plan (IndexError / quirk 6). */
+VC_API int vc_plan_spliced_len(vc_model* m, const int64_t* ids, int B, int T, const float* img, const float* seg,
+                               const float* depth, int pixels_on_device, int has_attention_mask, int* S_out) {
+    if (!m) return VC_ERR_INVALID;
+    struct Reset {
+        vc_model* m;
+        ~Reset() {
+            m->plan_only = false;
+            for (auto& v : m->img_counts) v.clear();
+        }
+    } reset{m};
+    GUARD_BEGIN
+    USE_DEVICE(m->ctx);
+    m->plan_only = true;
+    do_prefill(m, ids, B, T, img, seg, depth, pixels_on_device, has_attention_mask, -1, false, S_out);
+    GUARD_END(m->ctx)
+}
+
 /* Parity diagnostic (tests/: per-layer teacher forcing): decoder layers [l0, l1) of a PREFILL applied to a caller-supplied
  * residual stream x_in [B, S, hidden] (fp32, host) at positions 0..S-1, in the model's weight format and precision mode;
  * x_out receives the residual stream behind layer l1 - 1.  Feeding every layer the ORACLE's input isolates that layer's
@@ -2226,13 +2269,14 @@ VC_API int vc_debug_prefill_layers(vc_model* m, int l0, int l1, const float* x_i
     REQUIRE(x_in && x_out && B >= 1 && B <= VC_MAX_ROWS && S >= 1 && l0 >= 0 && l1 > l0 && l1 <= m->c.layers, VC_ERR_INVALID,
             "bad layer range / shape");
     m->cur_pos = -1;
+    m->has_kmask = m->kmask_in_decode = false;   // a diagnostic pass over caller-supplied rows: no key mask of an earlier prefill
     ensure_llm(m, B, S + 1);
     const size_t n = (size_t)B * S * m->c.hidden;
     HIPCHK(hipMemcpyAsync(m->x.p, x_in, n * 4, hipMemcpyHostToDevice, m->st));
     if (m->precision == 1) {
         ensure_strict(m, B, m->capS);
         REQUIRE(l0 == 0 && l1 == m->c.layers, VC_ERR_INVALID, "strict mode runs the whole stack");
-        run_llm_layers_strict(m, m->x.as<float>(), B, S, nullptr);
+        run_llm_layers_strict(m, m->x.as<float>(), B, S, nullptr, true);
     } else if (m->precision == 2) {
         run_prefill_layers_split(m, session_kv(m), B, S, l0, l1);
     } else {

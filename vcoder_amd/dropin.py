@@ -98,7 +98,7 @@ def install(reference_root: Optional[str] = None) -> types.ModuleType:
         from . import hf_register
 
         hf_register.register()
-    except ImportError:
+    except (ImportError, TypeError, ValueError):   # optional glue: an absent or older Transformers must not break the install
         pass
 
     # ---- pure-Python glue: the reference's own files when present, ours otherwise

@@ -299,6 +299,17 @@ class HipEngine:
         self.last_S = S.value
         return out[: B * S.value * self.cfg.hidden_size].reshape(B, S.value, self.cfg.hidden_size).copy()
 
+    def planned_len(self, input_ids, images, segs=None, depths=None, has_attention_mask: bool = False) -> int:
+        """spliced length S of a prefill / generate call with these arguments — the splice plan alone (vc_plan_spliced_len):
+        no tower pass, no KV / mask state touched; raises what the real call's plan would raise"""
+        ids = self._ids(input_ids)
+        B, T = ids.shape
+        (pi, ps, pd), on_dev, keep = self._pixels(*self._image_blocks(B, images, segs, depths))
+        S = C.c_int(0)
+        self._check(self.lib.vc_plan_spliced_len(self._model, ids.ctypes.data_as(C.c_void_p), B, T, pi, ps, pd, on_dev,
+                                                 int(has_attention_mask), C.byref(S)))
+        return S.value
+
     def prefill(self, input_ids, images, segs=None, depths=None, has_attention_mask: bool = False,
                 all_logits: bool = False, reserve: Optional[int] = None, attention_mask=None, hidden_states: bool = False,
                 attentions: bool = False):
@@ -308,13 +319,14 @@ class HipEngine:
         that)."""
         ids = self._ids(input_ids)
         B, T = ids.shape
-        # output_attentions is sized exactly: the spliced length comes from a splice-only pass (before any one-shot request of
-        # THIS call is announced — that pass would consume them)
-        S_att = self.inputs_embeds(ids, images, segs, depths).shape[1] if attentions else 0
-        has_attention_mask = self._announce_mask(attention_mask, B, T) or has_attention_mask
+        # output_attentions is sized exactly: the spliced length comes from the splice plan alone (no tower pass), asked with
+        # the mask-or-not of the real call so that an unequal-length batch takes the same error path in both
+        S_att = self.planned_len(ids, images, segs, depths, has_attention_mask or attention_mask is not None) if attentions else 0
         if reserve is not None:
             self._check(self.lib.vc_model_reserve_decode(self._model, int(reserve)))
         (pi, ps, pd), on_dev, keep = self._pixels(*self._image_blocks(B, images, segs, depths))
+        # the mask is announced LAST: anything above may raise, and an armed one-shot mask would hit the next call
+        has_attention_mask = self._announce_mask(attention_mask, B, T) or has_attention_mask
         V = self.cfg.vocab_size
         last = np.empty((B, V), dtype=np.float32)
         S = C.c_int(0)
@@ -335,9 +347,10 @@ class HipEngine:
                                             full.ctypes.data_as(C.c_void_p) if all_logits else None, C.byref(S)))
         except BaseException:
             # the library forgets its one-shot requests when vc_prefill returns (error or not); a failure BEFORE that call must
-            # not leave it holding pointers into buffers that are about to be freed
+            # not leave it holding pointers into buffers that are about to be freed — or an armed mask
             self.lib.vc_request_attentions(self._model, None, C.c_size_t(0))
             self.lib.vc_request_hidden_states(self._model, None, C.c_size_t(0))
+            self.lib.vc_clear_attention_mask(self._model)
             raise
         self.last_S = self._step_pos = S.value
         self._cur_batch = B
@@ -447,7 +460,6 @@ class HipEngine:
             n = max(p.shape[1] for p in parts)
             return np.concatenate([np.pad(p, ((0, 0), (0, n - p.shape[1])), constant_values=pad) for p in parts], axis=0)
         (pi, ps, pd), on_dev, keep = self._pixels(*self._image_blocks(B, images, segs, depths))
-        self._announce_mask(attention_mask, B, T)   # hides keys in the prefill; the cached steps see every key (the reference)
         out = np.empty((B, max_new_tokens), dtype=np.int32)
         n = C.c_int(0)
         eos = -1 if eos_token_id is None else int(eos_token_id)
@@ -467,6 +479,9 @@ class HipEngine:
                 errs.append(e)
 
         cb = _lib.TOKEN_CB(_cb) if on_tokens is not None else _lib.TOKEN_CB()
+        # hides keys in the prefill; the cached steps see every key (the reference).  Announced last: the one-shot mask is
+        # consumed by the call right below, nothing in between can raise and leave it armed
+        self._announce_mask(attention_mask, B, T)
         self._check(self.lib.vc_generate(self._model, ids.ctypes.data_as(C.c_void_p), B, T, pi, ps, pd, on_dev,
                                          int(max_new_tokens), eos, pad,
                                          flat.ctypes.data_as(C.c_void_p) if stops else None,

@@ -22,8 +22,18 @@ def register(exist_ok: bool = True):
     """-> {model_type: (hf config class, model class)} of what is registered with AutoConfig / AutoModelForCausalLM"""
     if _registered:
         return dict(_registered)
+    import inspect
+
     from transformers import AutoConfig, AutoModelForCausalLM, PretrainedConfig
     from transformers.models.auto.configuration_auto import CONFIG_MAPPING
+
+    # `exist_ok` only exists from Transformers 4.32 on; the reference pins 4.31 (pyproject.toml:23), whose register()
+    # takes (model_type, config) / (config_class, model_class) and raises ValueError for a key it already has
+    def _kw(fn):
+        try:
+            return {"exist_ok": exist_ok} if "exist_ok" in inspect.signature(fn).parameters else {}
+        except (TypeError, ValueError):
+            return {}
 
     from .model import language_model as lm
 
@@ -39,8 +49,13 @@ def register(exist_ok: bool = True):
         if model_type == "llava" and model_type in CONFIG_MAPPING:
             continue   # Transformers' own Llava: not ours to replace
         cfg_cls = make(model_type, name)
-        AutoConfig.register(model_type, cfg_cls, exist_ok=exist_ok)
+        kw = _kw(AutoConfig.register)
+        if not kw and model_type in CONFIG_MAPPING:
+            if not exist_ok:
+                raise ValueError(f"'{model_type}' is already used by a Transformers config")
+            continue   # pre-4.32: no way to replace an entry; whoever registered it first keeps it
+        AutoConfig.register(model_type, cfg_cls, **kw)
         model_cls.config_class = cfg_cls
-        AutoModelForCausalLM.register(cfg_cls, model_cls, exist_ok=exist_ok)
+        AutoModelForCausalLM.register(cfg_cls, model_cls, **_kw(AutoModelForCausalLM.register))
         _registered[model_type] = (cfg_cls, model_cls)
     return dict(_registered)

@@ -236,14 +236,15 @@ class _HipCausalLMBase:
                 raise NotImplementedError("multi-token continuation of a cached sequence is not on the reference's path")
             # images None: prepare_inputs_labels_for_multimodal returns early (vcoder_ds_llava_arch.py:129-133) and the
             # call is a plain Llama forward over the text ids
+            if images is None and attention_mask is not None and not _all_ones(attention_mask):
+                # (before the prefill: a refused call must leave the engine's cache and the live KVCacheHandles as they were)
+                raise NotImplementedError("a padded TEXT-ONLY batch (attention_mask with zeros, images=None) is outside the "
+                                          "VCoder hot path")
             _, full, S = self.engine.prefill(ids, images, (segs if self.variant != "llava" else None) if images is not None else None,
                                              (depths if self.variant == "vcoder_ds" else None) if images is not None else None,
                                              all_logits=True, reserve=self._decode_reserve,
                                              attention_mask=attention_mask if images is not None else None,
                                              hidden_states=bool(output_hidden_states), attentions=bool(output_attentions))
-            if images is None and attention_mask is not None and not _all_ones(attention_mask):
-                raise NotImplementedError("a padded TEXT-ONLY batch (attention_mask with zeros, images=None) is outside the "
-                                          "VCoder hot path")
             self._generation += 1
             logits = torch.from_numpy(full)
             pkv = KVCacheHandle(self, self._generation, S, B)
