@@ -83,3 +83,13 @@ def test_prompt_equals_reference_template():
         conv.append_message(conv.roles[0], q)
         conv.append_message(conv.roles[1], None)
         assert ce.build_prompt(q, mode) == conv.get_prompt()
+
+
+def test_answers_equal_reference_loaders(tmp_path):
+    """The committed answers files are what the REFERENCE'S loaders wrote (oracle/gen_cost_golden.py); the batched harness
+    reproduces them byte for byte (emulator, split mode; all six runs also under -m gpu)."""
+    import e2e_cases
+
+    done = e2e_cases.check_cost_answers(str(tmp_path), lib=kc.EmuBackend().lib, mode="split", pixels_on_device=False,
+                                        runs=["semantic_1_0", "depth_2_0", "depth_noseg_1_0", "panoptic_2_1"])
+    assert done == {"semantic_1_0": 6, "depth_2_0": 3, "depth_noseg_1_0": 6, "panoptic_2_1": 3}

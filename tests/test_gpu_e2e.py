@@ -716,6 +716,18 @@ def test_cost_harness_batched_equals_per_sample(tmp_path):
     model.engine.close()
 
 
+def test_cost_answers_equal_reference_loaders(tmp_path):
+    """SURVEY §8(f) row 3 pinned to the reference: eval_task (batched, device preprocessing, device greedy loop) writes byte for
+    byte the answers files the REFERENCE'S model_seg_loader.eval_model / model_depth_loader.eval_model wrote for the same
+    folder / checkpoint / tokenizer / question seed (tests/golden/cost <- oracle/gen_cost_golden.py), in split mode (the mode
+    that meets the 1e-3 bar) and in strict mode; batch sizes 4 and 1 agree."""
+    done = e2e_cases.check_cost_answers(str(tmp_path / "split"), mode="split")
+    assert done == {"semantic_1_0": 6, "panoptic_2_1": 3, "semantic_noseg_1_0": 6, "depth_1_0": 6, "depth_2_0": 3,
+                    "depth_noseg_1_0": 6}
+    e2e_cases.check_cost_answers(str(tmp_path / "strict"), mode="strict", runs=["depth_1_0", "semantic_noseg_1_0"])
+    e2e_cases.check_cost_answers(str(tmp_path / "b1"), mode="split", runs=["depth_1_0"], batch_size=1)
+
+
 def test_bench_two_ranks_self_launched(tmp_path):
     """`python bench.py --gpus 2` with WORLD_SIZE unset starts its own two ranks (torch.distributed.run on 127.0.0.1), shards
     the global batch contiguously, and the gathered token stream equals the single-process one.  On this 1-GPU box both

@@ -31,10 +31,15 @@ _SYSTEM = {
                  "The assistant gives helpful, detailed, and polite answers to the user's questions.",
 }
 STOP_STR = "</s>"
-# appended to the question when a sample has no segmentation map (model_seg_loader.py:72 / model_depth_loader.py)
+# appended to the question when a sample has no segmentation map (model_seg_loader.py:73) ...
 PARAGRAPH_INSTRUCTION = (" Return the answer in the paragraph format: 'The objects present in the image are: ...' and then "
                          "list the objects with their count in word format (if greater than 1) in front of them, like "
                          "'two people'.")
+# ... and by the depth loader when it runs without --use_depth_seg (model_depth_loader.py:90)
+DEPTH_PARAGRAPH_INSTRUCTION = (' Return answer in the paragraph format: "The depth order for the objects present in the image '
+                               'is: ..." and then list the objects with their order number (if greater than 1) separated by a '
+                               'hyphen like "person-2". For example, an acceptable response is "The depth order for objects '
+                               'present in the image is: bicycle, bicycle-2, bicycle-3, pavement, road, bus, tree, sky, building."')
 
 
 def build_prompt(question: str, conv_mode: str = "llava_v1") -> str:
@@ -94,9 +99,18 @@ def _load_rgb(path: str):
     return Image.open(path).convert("RGB")
 
 
+def _eos_ids(tokenizer, model) -> List[int]:
+    """EOS id(s) of the run: the tokenizer's, else the config's; HF's GenerationConfig takes one id or a list"""
+    eos = getattr(tokenizer, "eos_token_id", None)
+    eos = model.config.eos_token_id if eos is None else eos
+    return [int(e) for e in (eos if isinstance(eos, (list, tuple)) else [eos])]
+
+
 def generate_answers(model, tokenizer, samples: Sequence[Sample], batch_size: int = 8, max_new_tokens: int = 512,
-                     conv_mode: str = "llava_v1", load_image: Callable = _load_rgb, pixels_on_device: bool = True) -> List[str]:
-    """Greedy answers for `samples`, in order.  Buckets by prompt so every batch splices to equal lengths."""
+                     conv_mode: str = "llava_v1", load_image: Callable = _load_rgb, pixels_on_device: bool = True,
+                     task: str = "semantic") -> List[str]:
+    """Greedy answers for `samples`, in order.  Buckets by prompt so every batch splices to equal lengths.  task == "depth":
+    the depth loader's wording for samples without maps (model_depth_loader.py:90)."""
     engine = model.engine
     buckets: Dict[str, List[int]] = {}
     prompts = []
@@ -107,13 +121,15 @@ def generate_answers(model, tokenizer, samples: Sequence[Sample], batch_size: in
             if s.depth_file is not None:
                 q = DEFAULT_DEPTH_TOKEN + "\n" + q
         else:
-            q = DEFAULT_IMAGE_TOKEN + "\n" + q + PARAGRAPH_INSTRUCTION   # model_seg_loader.py:70-72
+            q = DEFAULT_IMAGE_TOKEN + "\n" + q + (DEPTH_PARAGRAPH_INSTRUCTION if task == "depth" else PARAGRAPH_INSTRUCTION)
         p = build_prompt(q, conv_mode)
         prompts.append(p)
         buckets.setdefault(p, []).append(i)
     answers: List[Optional[str]] = [None] * len(samples)
-    eos = getattr(tokenizer, "eos_token_id", None)
-    eos = model.config.eos_token_id if eos is None else eos
+    eos_ids = _eos_ids(tokenizer, model)
+    # one EOS id goes to the device loop as such; further ids of an EOS list end a row the same way as single-token stop
+    # sequences (the token is kept, the row pads afterwards — what HF's generate does for every id of the list)
+    eos, more = eos_ids[0], [[e] for e in eos_ids[1:]]
     for prompt, idxs in buckets.items():
         if "<seg>" in prompt:
             ids = mm_utils.tokenizer_depth_seg_token(prompt, tokenizer)
@@ -130,7 +146,7 @@ def generate_answers(model, tokenizer, samples: Sequence[Sample], batch_size: in
             if samples[group[0]].depth_file is not None:
                 deps = mm_utils.process_images_device([load_image(samples[i].depth_file) for i in group], model, to_device=pixels_on_device)
             new = engine.generate_greedy(np.tile(ids, (B, 1)), imgs, segs, deps, max_new_tokens=max_new_tokens,
-                                         eos_token_id=eos, pad_token_id=model.config.pad_token_id)
+                                         eos_token_id=eos, pad_token_id=model.config.pad_token_id, stop_sequences=more or None)
             texts = tokenizer.batch_decode(new.tolist(), skip_special_tokens=True)
             for i, t in zip(group, texts):
                 t = t.strip()
@@ -157,13 +173,26 @@ def eval_task(model, tokenizer, task: str, image_folder: str, seg_image_folder: 
               depth_image_folder: Optional[str] = None, num_chunks: int = 1, chunk_idx: int = 0, batch_size: int = 8,
               questions: Optional[Sequence[str]] = None, conv_mode: str = "llava_v1", max_new_tokens: int = 512,
               seed: Optional[int] = None, pixels_on_device: bool = True) -> str:
-    """One COST task for this rank's chunk; returns the answers file (`{output}_{task}_{num_chunks}_{chunk_idx}.txt`)."""
+    """One COST task for this rank's chunk; returns the answers file.
+
+    task in {"semantic", "instance", "panoptic"}: model_seg_loader.py:99-166 — maps from `{seg_image_folder}/{task}_inference`,
+    file `{output}_{task}_{num_chunks}_{chunk_idx}.txt`.  task == "depth": model_depth_loader.py:116-185 — maps from
+    `{seg_image_folder}/panoptic_inference` + `depth_image_folder` (both or neither, :54), file
+    `{output}_{num_chunks}_{chunk_idx}.txt`.  seg_image_folder None = the loaders without --use_seg / --use_depth_seg."""
     questions = list(questions) if questions is not None else load_questions(task)
-    seg_folder = os.path.join(seg_image_folder, f"{task}_inference") if seg_image_folder else None
-    samples = build_samples(image_folder, seg_folder, depth_image_folder, questions, num_chunks, chunk_idx, seed)
+    if task == "depth":
+        if seg_image_folder and not depth_image_folder:
+            raise ValueError("Depth image folder must be provided if seg image folder is provided")
+        seg_folder = os.path.join(seg_image_folder, "panoptic_inference") if seg_image_folder else None
+        depth_folder = depth_image_folder if seg_image_folder else None
+        out = os.path.expanduser(output_file) + f"_{num_chunks}_{chunk_idx}.txt"
+    else:
+        seg_folder = os.path.join(seg_image_folder, f"{task}_inference") if seg_image_folder else None
+        depth_folder = None   # the seg loader passes depths=None (model_seg_loader.py:133)
+        out = os.path.expanduser(output_file) + f"_{task}_{num_chunks}_{chunk_idx}.txt"
+    samples = build_samples(image_folder, seg_folder, depth_folder, questions, num_chunks, chunk_idx, seed)
     answers = generate_answers(model, tokenizer, samples, batch_size, max_new_tokens, conv_mode,
-                               pixels_on_device=pixels_on_device)
-    out = os.path.expanduser(output_file) + f"_{task}_{num_chunks}_{chunk_idx}.txt"
+                               pixels_on_device=pixels_on_device, task=task)
     if os.path.exists(out):
         os.remove(out)
     write_answers(out, samples, answers)
