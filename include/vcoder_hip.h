@@ -233,6 +233,9 @@ int vc_preprocess_image(vc_model* m, const uint8_t* rgb, int h, int w, int pad_t
 typedef struct vc_comm vc_comm;
 int vc_comm_unique_id(vc_ctx* ctx, void* out128);
 int vc_comm_create(vc_ctx* ctx, int rank, int world, const void* unique_id128, vc_comm** out);
+/* 1 when the communicator's gathers run through RCCL: world > 1, or a SINGLE rank created with VC_COMM_FORCE_RCCL=1 in the
+ * environment (a one-rank ncclCommInitRank + ncclAllGather on the stream: the multi-GPU code path on a one-GPU box) */
+int vc_comm_uses_rccl(vc_comm* comm);
 /* global[r * n + i] = rank r's local[i]; host buffers (n int32 per rank) */
 int vc_allgather_tokens(vc_comm* comm, const int32_t* local, int n, int32_t* global);
 void vc_comm_destroy(vc_comm* comm);

@@ -767,6 +767,39 @@ def test_bench_two_ranks_self_launched(tmp_path):
     assert np.array_equal(got, ref), "gathered ids of the 2-rank run differ from the single-process ids"
 
 
+@pytest.mark.parametrize("gather", ["torch", "cabi"])
+def test_bench_force_dist_one_gpu(tmp_path, gather):
+    """`bench.py --gpus 1 --force-dist`: the multi-GPU code path on ONE GPU with the REAL backend — init_process_group("nccl",
+    world_size = 1) (= RCCL), the per-step id all-gather (all_gather_into_tensor on the device, or the library's one-rank RCCL
+    communicator with --gather cabi), barrier(device_ids=...) fences and the MAX all-reduce of the timing — so that the
+    driver's 8-GPU run is not the first execution of this code.  The gathered ids equal the plain single-process ids."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dump = str(tmp_path / "ids.npy")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "VC_COMM_FORCE_RCCL")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--gather", gather, "--steps",
+                        "2", "--warmup", "1", "--batch", "2", "--new-tokens", "6", "--inflight", "2", "--no-cpu-baseline",
+                        "--dump-ids", dump], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["n_gpus"] == 1 and res["config"]["force_dist"] is True and res["ids_checked"] is True
+    assert ("RCCL via the C ABI)" in res["config"]["token_gather"]) if gather == "cabi" else ("(nccl)" in res["config"]["token_gather"])
+    got = np.load(dump)
+    cfg = vcfg.vicuna_7b("vcoder_ds")
+    eng = HipEngine(cfg)
+    eng.load_synthetic(42)
+    eng.finalize()
+    ids = np.stack([synth.synth_prompt_ids(cfg.vocab_size, "vcoder_ds", sample=b) for b in range(2)])
+    imgs, segs, deps = synth.synth_batch(2, 336)
+    ref = eng.generate_greedy(ids, imgs, segs, deps, max_new_tokens=6)
+    eng.close()
+    assert np.array_equal(got, ref)
+
+
 def test_token_comm_c_abi_world1():
     """vc_comm_create / vc_allgather_tokens at world 1 (identity, no RCCL needed); the multi-rank form needs one GPU per
     rank and runs in the driver's multi-GPU bench (`bench.py --gather cabi`)."""
@@ -776,6 +809,43 @@ def test_token_comm_c_abi_world1():
     c = TokenComm(eng, 0, 1)
     x = np.arange(24, dtype=np.int32).reshape(3, 8)
     assert np.array_equal(c.allgather(x), x)
+    c.close()
+
+
+def test_token_comm_rccl_forced_world1(monkeypatch):
+    """VC_COMM_FORCE_RCCL=1: a communicator of ONE rank that still dlopens librccl, takes a unique id (by-value ncclUniqueId
+    ABI), runs ncclCommInitRank(nranks = 1) and serves vc_allgather_tokens with ncclAllGather on the engine's stream — the code
+    the multi-GPU run executes (scripts/v1_5/eval/cost_depth.sh:10-34 is the reference's counterpart), exercised here on one
+    GPU, interleaved with kernels on the same stream, including a buffer growth and the explicit-unique-id form."""
+    import ctypes as C
+
+    from vcoder_amd.parallel import TokenComm
+
+    monkeypatch.setenv("VC_COMM_FORCE_RCCL", "1")
+    eng = e2e_cases.engine_for("vcoder_ds")
+    g, cfg, ids, imgs, segs, deps = e2e_cases.fixture_inputs("ds_img_depth_seg")
+    c = TokenComm(eng, 0, 1)
+    assert c.uses_rccl
+    new = eng.generate_greedy(ids, imgs, segs, deps, max_new_tokens=8)       # kernels on the stream the gather uses
+    assert np.array_equal(c.allgather(new), new)
+    big = np.arange(5 * 4096, dtype=np.int32).reshape(5, 4096)              # grows the device buffers
+    assert np.array_equal(c.allgather(big), big)
+    assert np.array_equal(c.allgather(new), new)
+    c.close()
+    # the explicit unique-id form the ranks of a real world use (rank 0: vc_comm_unique_id -> vc_comm_create)
+    uid = C.create_string_buffer(128)
+    eng._check(eng.lib.vc_comm_unique_id(eng._ctx, uid))
+    assert any(uid.raw)
+    comm = C.c_void_p()
+    eng._check(eng.lib.vc_comm_create(eng._ctx, 0, 1, uid, C.byref(comm)))
+    assert eng.lib.vc_comm_uses_rccl(comm) == 1
+    out = np.empty_like(new)
+    eng._check(eng.lib.vc_allgather_tokens(comm, new.ctypes.data_as(C.c_void_p), int(new.size), out.ctypes.data_as(C.c_void_p)))
+    assert np.array_equal(out, new)
+    eng.lib.vc_comm_destroy(comm)
+    monkeypatch.delenv("VC_COMM_FORCE_RCCL")
+    c = TokenComm(eng, 0, 1)
+    assert not c.uses_rccl and np.array_equal(c.allgather(new), new)         # default: no RCCL in a world of one
     c.close()
 
 

@@ -89,6 +89,18 @@ def _loop(eng, ids, imgs, segs, deps, n_new, keep_rows):
     return np.stack(steps, 1), np.stack(toks, 1), S
 
 
+def _loop_forced(eng, ids, imgs, segs, deps, forced):
+    """the session's cached loop TEACHER-FORCED with `forced` [B, n]: the logits of every step [B, n, V] (step t sees the prompt
+    and forced[:, :t])"""
+    n = forced.shape[1]
+    last, _, _ = eng.prefill(ids, imgs, segs, deps, reserve=n)
+    steps = [last]
+    for t in range(n - 1):
+        lg, _ = eng.decode_step(np.ascontiguousarray(forced[:, t], dtype=np.int32))
+        steps.append(lg)
+    return np.stack(steps, 1)
+
+
 def _concurrent(root, n_calls, fn):
     import threading
 
@@ -109,7 +121,8 @@ def _concurrent(root, n_calls, fn):
     return sessions, outs, errs
 
 
-def run_case(cfg, B, n_new, seed, oracle_rows, checkpoints, strict_tokens, split=True, pooled_calls=4, lib=None):
+def run_case(cfg, B, n_new, seed, oracle_rows, checkpoints, strict_tokens, split=True, pooled_calls=4, lib=None,
+             fast_vs="oracle"):
     """The FULL-SIZE call of a BASELINE configuration (B sequences of the C2 prompt, n_new greedy tokens, every layer) on the
     device in its precision modes, checked against ONE teacher-forced fp32 oracle pass over the rows `oracle_rows`:
 
@@ -121,7 +134,13 @@ def run_case(cfg, B, n_new, seed, oracle_rows, checkpoints, strict_tokens, split
                          sequence IS the fp32 reference's; generate() through the pool == the session loop
       strict mode        the first `strict_tokens` steps of row 0: 1e-3 absolute, ids identical
 
+    fast_vs = "split" (needs split=True): the reference the bf16 path is measured against is the SPLIT path on the device,
+    teacher-forced with the bf16 path's ids (row oracle_rows[0], batch 1) — the same test proves the split path to be within 1e-3
+    ABSOLUTE of the fp32 oracle with identical ids, which is 100x below the bf16 path's tolerance; it saves the oracle a third
+    row (60-70 s of host time per case).
+
     lib: test-only injection of the CPU emulator build (tests/test_engine_emu.py runs this logic on the tiny model)."""
+    assert fast_vs in ("oracle", "split") and (split or fast_vs == "oracle")
     t0 = time.time()
     eng = HipEngine(cfg, lib=lib)
     eng.load_synthetic(seed)
@@ -155,6 +174,9 @@ def run_case(cfg, B, n_new, seed, oracle_rows, checkpoints, strict_tokens, split
         assert S2 == S
         assert np.array_equal(eng.generate_greedy(ids, imgs, segs, deps, max_new_tokens=n_new), split_ids), \
             "split mode: generate() through the decode pool differs from the session loop"
+        if fast_vs == "split":
+            r0 = rows[0]
+            split_forced_fast = _loop_forced(eng, ids[r0:r0 + 1], imgs[r0:r0 + 1], segs[r0:r0 + 1], deps[r0:r0 + 1], fast_ids[r0:r0 + 1])
     # ---- strict (fp32) path
     eng.set_precision("strict")
     s_last, _, _ = eng.prefill(ids[:1], imgs[:1], segs[:1], deps[:1], reserve=strict_tokens)
@@ -172,18 +194,21 @@ def run_case(cfg, B, n_new, seed, oracle_rows, checkpoints, strict_tokens, split
     # ---- ONE fp32 oracle pass (= the reference's CPU path): the oracle rows forced with the split ids, then oracle_rows[0]
     # forced with the fast path's ids
     om32 = cpu_ref.OracleModel(cfg, sd, emu_bf16=False)
-    sel = (rows if split else []) + [rows[0]] + ([] if split else rows[1:])
-    forced = np.stack(([split_ids[r] for r in rows] if split else []) + [fast_ids[rows[0]]] +
+    with_fast = fast_vs == "oracle"
+    sel = (rows if split else []) + ([rows[0]] if with_fast else []) + ([] if split else rows[1:])
+    forced = np.stack(([split_ids[r] for r in rows] if split else []) + ([fast_ids[rows[0]]] if with_fast else []) +
                       ([] if split else [fast_ids[r] for r in rows[1:]]), 0)
     S_o, o32, cut32 = oracle_teacher_forced(om32, ids[sel], imgs[sel], segs[sel], deps[sel], forced, checkpoints)
     assert S_o == S == ids.shape[1] - 3 + 2 * cfg.num_patches
     t_o32 = time.time() - t0 - t_dev - t_sd
     scale = float(np.abs(o32).max())
     n_split = len(rows) if split else 0
-    o_fast = o32[n_split:]                                            # rows forced with the fast path's ids
+    # the reference rows forced with the fast path's ids: the oracle's, or the split path's own (fast_vs == "split")
+    o_fast = o32[n_split:] if with_fast else split_forced_fast
     f_rows = [0] if split else list(range(len(rows)))                # index into fast_logits (which holds oracle_rows)
     err32 = np.abs(fast_logits[f_rows] - o_fast).max(-1)              # [rows, n] max |dlogit| per step
-    print(f"[{cfg.num_hidden_layers}L D{cfg.hidden_size}] S={S} B={B} n={n_new} |logits|max={scale:.3f}  bf16 path vs fp32 oracle "
+    print(f"[{cfg.num_hidden_layers}L D{cfg.hidden_size}] S={S} B={B} n={n_new} |logits|max={scale:.3f}  bf16 path vs "
+          f"{'fp32 oracle' if with_fast else 'the split path forced with its ids (itself checked against the fp32 oracle below)'} "
           f"(rows {[rows[i] for i in f_rows]}): prefill {err32[:, 0].max():.4f}, decode steps max {err32[:, 1:].max():.4f} "
           f"(rel {err32.max() / scale:.2e}); times: device {t_dev:.0f}s weights {t_sd:.0f}s oracle-fp32 {t_o32:.0f}s")
     for L in checkpoints:
@@ -246,18 +271,21 @@ def test_full_size_7b_c2():
     lone call, 4 concurrent calls through the decode pool (what bench.py's `value` measures), split mode, strict mode; fp32
     oracle teacher-forced on rows {0, 7}."""
     cfg = vcfg.vicuna_7b("vcoder_ds")
-    r = run_case(cfg, B=8, n_new=128, seed=42, oracle_rows=(0, 7), checkpoints=(2, 8, 16, 32), strict_tokens=8)
+    r = run_case(cfg, B=8, n_new=128, seed=42, oracle_rows=(0, 7), checkpoints=(2, 8, 16, 32), strict_tokens=8, fast_vs="split")
     assert r["err32"].max() < REL_TOL_VS_FP32 * max(1.0, r["scale"])
     assert r["e_split"] < 1e-3
 
 
 def test_full_size_13b_c3():
     """BASELINE configs[2] AS WRITTEN: VCoder-DS 13b (D 5120, 40 layers, 40 heads, F 13824), B = 16, 128 greedy tokens; 2
-    concurrent calls through the pool; fp32 oracle teacher-forced on rows {0, 15} with the bf16 path's ids."""
+    concurrent calls through the pool; SPLIT mode against the fp32 oracle teacher-forced on rows {0, 15} (1e-3 absolute,
+    256 / 256 ids, no near-tie criterion — BASELINE.json's bar at this size); strict mode on 4 tokens; the bf16 path against
+    the split path."""
     cfg = vcfg.vicuna_13b("vcoder_ds")
-    r = run_case(cfg, B=16, n_new=128, seed=42, oracle_rows=(0, 15), checkpoints=(40,), strict_tokens=4, split=False,
-                 pooled_calls=2)
+    r = run_case(cfg, B=16, n_new=128, seed=42, oracle_rows=(0, 15), checkpoints=(40,), strict_tokens=4, split=True,
+                 pooled_calls=2, fast_vs="split")
     assert r["err32"].max() < REL_TOL_VS_FP32 * max(1.0, r["scale"])
+    assert r["e_split"] < 1e-3
 
 
 def _device_run(cfg, fmt, ids, imgs, segs, deps, n_new, forced=None):

@@ -86,6 +86,8 @@ def declare(lib: C.CDLL) -> C.CDLL:
     lib.vc_comm_create.restype = C.c_int
     lib.vc_allgather_tokens.argtypes = [vp, vp, i32, vp]
     lib.vc_allgather_tokens.restype = C.c_int
+    lib.vc_comm_uses_rccl.argtypes = [vp]
+    lib.vc_comm_uses_rccl.restype = C.c_int
     lib.vc_comm_destroy.argtypes = [vp]
     lib.vc_comm_destroy.restype = None
     lib.vc_model_set_layer_limit.argtypes = [vp, i32]

@@ -7,6 +7,7 @@
 // bandwidth is irrelevant, so there is nothing to bucket or overlap.
 #include <dlfcn.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -83,6 +84,9 @@ static int fail(vc_ctx* ctx, int code, const std::string& msg) {
     return code;
 }
 
+/* 1 when this communicator's gathers run through RCCL (world > 1, or a single rank created under VC_COMM_FORCE_RCCL=1) */
+VC_API int vc_comm_uses_rccl(vc_comm* c) { return c && c->nccl ? 1 : 0; }
+
 /* rank 0 creates the 128-byte RCCL unique id and hands it to the other ranks through any side channel (bench.py: the
  * torch.distributed store); world 1 needs none */
 VC_API int vc_comm_unique_id(vc_ctx* ctx, void* out128) {
@@ -103,9 +107,15 @@ VC_API int vc_comm_create(vc_ctx* ctx, int rank, int world, const void* unique_i
     c->ctx = ctx;
     c->rank = rank;
     c->world = world;
-    if (world > 1) {
+    // VC_COMM_FORCE_RCCL=1: a single rank still binds librccl, creates a communicator of ONE rank and runs its gathers as
+    // ncclAllGather on the stream — so that symbol binding, the by-value ncclUniqueId ABI and the stream ordering of the
+    // multi-GPU path execute on a one-GPU box (tests/test_gpu_e2e.py::test_token_comm_rccl_forced_world1) before the first
+    // 8-GPU run does.  Read per call, not cached: a test sets it for one communicator.
+    const char* force_env = getenv("VC_COMM_FORCE_RCCL");
+    const bool force = world == 1 && force_env && force_env[0] == '1';
+    if (world > 1 || force) {
         Rccl& r = rccl();
-        if (!r.handle || !unique_id128) {
+        if (!r.handle || (!unique_id128 && !force)) {
             delete c;
             return fail(ctx, VC_ERR_STATE, r.handle ? "a unique id is required for world > 1" : r.why);
         }
@@ -114,7 +124,15 @@ VC_API int vc_comm_create(vc_ctx* ctx, int rank, int world, const void* unique_i
             return fail(ctx, VC_ERR_HIP, "hipSetDevice failed");
         }
         Uid id;
-        memcpy(&id, unique_id128, sizeof id);
+        if (unique_id128) {
+            memcpy(&id, unique_id128, sizeof id);
+        } else {   // forced single rank: nobody to exchange an id with
+            const int rc = r.GetUniqueId(&id);
+            if (rc != 0) {
+                delete c;
+                return fail(ctx, VC_ERR_HIP, std::string("ncclGetUniqueId: ") + (r.GetErrorString ? r.GetErrorString(rc) : "?"));
+            }
+        }
         const int rc = r.CommInitRank(&c->nccl, world, id, rank);
         if (rc != 0) {
             delete c;
@@ -130,7 +148,7 @@ VC_API int vc_comm_create(vc_ctx* ctx, int rank, int world, const void* unique_i
 VC_API int vc_allgather_tokens(vc_comm* c, const int32_t* local, int n, int32_t* global) {
     if (!c || !local || !global || n < 0) return VC_ERR_INVALID;
     if (n == 0) return VC_OK;
-    if (c->world == 1) {
+    if (c->world == 1 && !c->nccl) {
         memmove(global, local, (size_t)n * 4);
         return VC_OK;
     }

@@ -17,10 +17,11 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, min(lo + per, n_items)
 
 
-def gather_token_ids(local_ids: np.ndarray, dist=None, device=None) -> np.ndarray:
+def gather_token_ids(local_ids: np.ndarray, dist=None, device=None, force: bool = False) -> np.ndarray:
     """all-gather int32 [B_local, N] -> [world*B_local, N] (equal shard sizes).  `dist` = torch.distributed (already
-    initialised) or None for a single process."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    initialised) or None for a single process.  force: run the collective even in a world of one (bench.py --force-dist: the
+    multi-GPU code path on a one-GPU box)."""
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return np.ascontiguousarray(local_ids, dtype=np.int32)
     import torch
 
@@ -52,6 +53,10 @@ class TokenComm:
                 raise ValueError("world > 1 needs an `exchange` to distribute the RCCL unique id")
             uid = C.create_string_buffer(exchange(buf.raw if rank == 0 else b""), 128)
         engine._check(self.lib.vc_comm_create(engine._ctx, rank, world, uid, C.byref(self._comm)))
+
+    @property
+    def uses_rccl(self) -> bool:
+        return bool(self.lib.vc_comm_uses_rccl(self._comm))
 
     def allgather(self, local_ids: np.ndarray) -> np.ndarray:
         """int32 [B_local, N] -> [world * B_local, N]"""
