@@ -137,6 +137,16 @@ void vck_gemm_split(const uint16_t* A, const uint16_t* W, const float* bias, voi
 void vck_gemv_split(const uint16_t* X, const void* Wp, const float* wscale, void* out, const float* ssq_in, float* ssq_out,
                     const float* xg_w, uint16_t* xg_out, int npart, float eps, int M, int N, int K, int ldo, int epi, int G,
                     void* stream);
+/* the decode GEMV with every argument: G = split rows (0: bf16 step; 8 / 16 / 32: X holds hi rows [0, M) and lo rows [G, G + M)),
+ * the split-K buffers and their capacity (floats / counters; 0 = the historical [4][512][2][256] / [512][2]) */
+void vck_gemv_full(const uint16_t* X, const void* Wp, const float* wscale, void* out, const float* ssq_in, float* ssq_out,
+                   const float* xg_w, uint16_t* xg_out, int npart, float eps, float* sk_scratch, unsigned long long sk_scratch_floats,
+                   unsigned* sk_counters, int sk_counters_n, int ksplit, int M, int N, int K, int ldo, int epi, int G, void* stream);
+/* which kernel serves the decode GEMV over bf16 weights: 0 = per-wave rings (gemv_dma_kernel), 1 = workgroup-shared activation
+ * chunks (gemv_wg_kernel), -1 = the process default (environment VC_GEMV_WG) */
+void vck_set_gemv_variant(int v);
+void vck_set_gemv_wg_geom(const char* spec, int deep);   /* tuning: "ntiles:K:ntw:ks,..." per matrix shape; deep: -1 default */
+unsigned long long vck_gemv_wg_launches(void);   /* launches the workgroup-shared form has served (tests) */
 void vck_rmsnorm_split(const float* x, const int* row_idx, const float* w, uint16_t* y, int rows, int D, float eps, int ldy,
                        uint64_t lo_off, void* stream);
 void vck_layernorm_split(const float* x, const float* w, const float* b, uint16_t* y, int rows, int D, float eps, int ldy,

@@ -1209,3 +1209,125 @@ def check_attention_decode_kv32(be, B, H, hd, pos, seed=0):
         ref = ref.transpose(1, 2).reshape(D).numpy()
         err = np.abs(go[orow] + go[orow + G] - ref).max()
         assert err < 3e-5 * max(1.0, np.abs(ref).max()), f"decode attention kv32 row {b}: {err}"
+
+
+# ---- the workgroup-shared-activation decode GEMV (gemv_wg_kernel; vck_set_gemv_variant(1)) -------------------------------------
+def _gemv_full(be, X, Wp, out, ssq_in, ssq_out, xg_w, xg_out, npart, M, N, K, ldo, epi, G=0, ksplit=0, sk=None):
+    """vck_gemv_full through raw pointers (bf16 weights); sk = (scratch f32, counters i32) with their true capacities"""
+    be.lib.vck_gemv_full(be.ptr(X), be.ptr(Wp), None, be.ptr(out), be.ptr(ssq_in), be.ptr(ssq_out), be.ptr(xg_w), be.ptr(xg_out),
+                         ctypes.c_int(npart), ctypes.c_float(1e-5), be.ptr(sk[0]) if sk else None,
+                         ctypes.c_ulonglong(sk[2] if sk else 0), be.ptr(sk[1]) if sk else None, ctypes.c_int(sk[3] if sk else 0),
+                         ctypes.c_int(ksplit), M, N, K, ldo, epi, G, None)
+    be.sync()
+
+
+def _wg_case(be, rng, rows, N, K, epi, norm, G):
+    """inputs of a wg-GEMV case over `rows` activation rows; G > 0: the stacked hi / lo form of precision mode split"""
+    npart = (max(K, N) // 16 + 15) // 16 * 16
+    Xf = rng.randn(rows, K).astype(np.float32)
+    if G:
+        hi, lo = split_hi_lo(Xf)
+    else:
+        Xf = bf16_round(Xf)
+        hi, lo = Xf, None
+    W = bf16_round(rng.randn(N, K) * 0.05)
+    Wd, Wp = be.bf16(W), be.zeros((N * K,), "bf16")
+    _call(be, "vck_pack_weight", Wd, Wp, N, K)
+    ssq = np.zeros((32, npart), np.float32)
+    ssq[:, : K // 16] = rng.rand(32, K // 16).astype(np.float32) + 0.5
+    ref = Xf.astype(np.float64) @ W.T.astype(np.float64)
+    if norm:
+        ref = ref / np.sqrt(ssq[:rows, : K // 16].astype(np.float64).sum(-1, keepdims=True) / K + 1e-5)
+    No = N // 2 if epi == 3 else N
+    if epi == 3:
+        t = torch.from_numpy(ref)
+        ref = (torch.nn.functional.silu(t[:, 0::2]) * t[:, 1::2]).numpy()
+    gw = (rng.rand(N).astype(np.float32) + 0.5) if epi == 2 else None
+    r0 = rng.randn(32, No).astype(np.float32)
+    if epi == 2:
+        ref = ref + r0[:rows]
+    sk = (be.zeros((8 * (N // 16) * 2 * 256,), "f32"), be.zeros((N // 16 * 2,), "i32"), 8 * (N // 16) * 2 * 256, N // 16 * 2)
+    return dict(npart=npart, hi=hi, lo=lo, Wp=Wp, Wd=Wd, ssq=ssq, ref=ref, No=No, gw=gw, r0=r0, sk=sk, N=N, K=K, epi=epi, norm=norm)
+
+
+def _wg_run(be, c, M, G, ksplit=0, row0=0):
+    """one launch over rows [row0, row0 + M) of the case -> (values [M, No] float64 (hi + lo summed for bf16-valued outputs in
+    split form), raw outputs for bit comparisons)"""
+    N, K, epi, No = c["N"], c["K"], c["epi"], c["No"]
+    if G:
+        X = np.full((2 * G, K), 7.0, np.float32)     # rows of the group beyond M must not reach any result
+        X[:M], X[G:G + M] = c["hi"][row0:row0 + M], c["lo"][row0:row0 + M]
+    else:
+        X = np.full((32, K), 7.0, np.float32)
+        X[:M] = c["hi"][row0:row0 + M]
+    rows_out = 2 * G if (G and epi in (0, 3)) else 32
+    if epi == 2:
+        out = be.f32(c["r0"][row0:].copy() if row0 else c["r0"].copy())
+        if row0:
+            pad = np.zeros((32, No), np.float32)
+            pad[: 32 - row0] = c["r0"][row0:]
+            out = be.f32(pad)
+    elif epi == 1:
+        out = be.zeros((32, No), "f32")
+    else:
+        out = be.zeros((rows_out, No), "bf16")
+    xg_out = be.zeros((2 * G if G else 32, N), "bf16") if epi == 2 else None
+    ssq_out = be.zeros((32, c["npart"]), "f32") if epi == 2 else None
+    ssq = np.zeros_like(c["ssq"])
+    ssq[:M] = c["ssq"][row0:row0 + M]
+    Xd, ssqd, gwd = be.bf16(X), (be.f32(ssq) if c["norm"] else None), (be.f32(c["gw"]) if c["gw"] is not None else None)
+    _gemv_full(be, Xd, c["Wp"], out, ssqd, ssq_out, gwd, xg_out, c["npart"], M, N, K, No, epi, G=G, ksplit=ksplit, sk=c["sk"])
+    o = be.host_f32(out)
+    assert not be.host_i32(c["sk"][1]).any(), "arrival counters must be re-armed"
+    if G and epi in (0, 3):
+        val, raw = o[:M].astype(np.float64) + o[G:G + M].astype(np.float64), (o[:M].copy(), o[G:G + M].copy())
+    else:
+        val, raw = o[:M].astype(np.float64), (o[:M].copy(),)
+    extra = None
+    if epi == 2:
+        xg = be.host_f32(xg_out)
+        extra = dict(xg=(xg[:M].copy(), xg[G:G + M].copy()) if G else (xg[:M].copy(),), ssq=be.host_f32(ssq_out)[:M, : N // 16].copy(),
+                     untouched=o[M:].copy())
+    return val, raw, extra
+
+
+def check_gemv_wg(be, M, N, K, epi, norm=True, G=0, ksplit=0, seed=0):
+    """gemv_wg_kernel against the float64 product: every epilogue, RMSNorm folding on both sides, the split form (hi / lo rows,
+    one weight pass), explicit K-slices with the cross-workgroup hand-off"""
+    be.lib.vck_set_gemv_variant(1)
+    be.lib.vck_gemv_wg_launches.restype = ctypes.c_ulonglong
+    n0 = be.lib.vck_gemv_wg_launches()
+    try:
+        rng = np.random.RandomState(seed)
+        c = _wg_case(be, rng, M, N, K, epi, norm, G)
+        val, raw, extra = _wg_run(be, c, M, G, ksplit)
+        assert be.lib.vck_gemv_wg_launches() == n0 + 1, "the call was not served by gemv_wg_kernel"
+        e = rel_err(val, c["ref"])
+        tol = 3e-5 if G else (2 ** -8 if epi in (0, 3) else 2e-5)
+        assert e < tol, f"gemv_wg M{M} N{N} K{K} epi{epi} G{G} ks{ksplit}: rel err {e}"
+        if epi == 2:
+            xg = sum(x.astype(np.float64) for x in extra["xg"])
+            assert rel_err(xg, val * c["gw"]) < (2e-5 if G else 2 ** -8)
+            assert np.abs(extra["ssq"].astype(np.float64).sum(-1) / (val ** 2).sum(-1) - 1).max() < 1e-5
+            assert np.array_equal(extra["untouched"], c["r0"][M:]), "residual rows beyond M were touched"
+        return e
+    finally:
+        be.lib.vck_set_gemv_variant(-1)
+
+
+def check_gemv_wg_rows_agree(be, N, K, epi, norm=True, G=False, ksplit=0, seed=0):
+    """the pool's promise for the wg form: a row gets the same BITS from a 29-row pass as from the 8-row (5-row) pass and the
+    13-row pass that hold it — the k order of a sum is a function of the matrix alone; in split form G = 32 vs G = 8 / 16"""
+    be.lib.vck_set_gemv_variant(1)
+    try:
+        rng = np.random.RandomState(seed)
+        c = _wg_case(be, rng, 29, N, K, epi, norm, 32 if G else 0)
+        _, big, _ = _wg_run(be, c, 29, 32 if G else 0, ksplit)
+        for row0, M, Gs in ((0, 5, 8), (0, 8, 8), (16, 13, 16), (8, 16, 16)):
+            _, small, _ = _wg_run(be, c, M, Gs if G else 0, ksplit, row0=row0)
+            if epi == 2 and row0:
+                continue   # (the in-place residual form adds into the rows the buffer holds: only row0 == 0 lines up)
+            for a, b in zip(big, small):
+                assert np.array_equal(a[row0:row0 + M], b), f"rows {row0}..{row0 + M - 1} differ between the 29-row and the {M}-row pass"
+    finally:
+        be.lib.vck_set_gemv_variant(-1)

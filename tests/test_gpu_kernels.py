@@ -1,5 +1,7 @@
 """`-m gpu`: every HIP kernel at the TRUE shapes of VCoder-DS LLaVA-1.5-7b / CLIP ViT-L/14@336, called through
 the C ABI of libvcoder_hip.so (include/vcoder_kernels.h) and compared with the oracle."""
+import ctypes
+
 import pytest
 
 import kernel_cases as kc
@@ -196,3 +198,49 @@ def test_dma_kernels_are_race_free_and_bit_reproducible(be):
         be.sync()
         for o in outs[1:]:
             assert torch.equal(o, outs[0]), f"gemv M{M} N{N} K{K}: launches differ"
+
+
+@pytest.mark.parametrize("M,N,K,epi,norm,G,ks", [
+    (8, 12288, 4096, 0, True, 0, 0), (32, 12288, 4096, 0, True, 0, 0), (24, 4096, 4096, 2, False, 0, 0), (32, 22016, 4096, 3, True, 0, 0),
+    (29, 4096, 11008, 2, False, 0, 0), (32, 32000, 4096, 1, True, 0, 0), (16, 15360, 5120, 0, True, 0, 0), (32, 5120, 13824, 2, False, 0, 0),
+    (8, 12288, 4096, 1, True, 8, 0), (16, 22016, 4096, 3, True, 16, 0), (32, 12288, 4096, 1, True, 32, 0), (32, 4096, 11008, 2, False, 32, 0),
+    (32, 22016, 4096, 3, True, 32, 0), (3, 48, 320, 1, True, 0, 0)])
+def test_gemv_wg(be, M, N, K, epi, norm, G, ks):
+    """gemv_wg_kernel (workgroup-shared activation chunks) at the true 7b / 13b decode shapes, 8..32 rows, every epilogue, the
+    split form with both planes in one weight pass (G = 32: 64 operand rows), the default K-slice geometry of each matrix"""
+    kc.check_gemv_wg(be, M, N, K, epi, norm, G, ks)
+
+
+@pytest.mark.parametrize("N,K,epi,G", [(12288, 4096, 0, False), (22016, 4096, 3, False), (4096, 11008, 2, False), (32000, 4096, 1, False),
+                                       (12288, 4096, 1, True), (22016, 4096, 3, True), (4096, 4096, 2, True)])
+def test_gemv_wg_rows_agree(be, N, K, epi, G):
+    """the pool's promise for the wg form at true shapes: identical bits for a row from 5 / 8 / 13 / 16 / 29-row passes"""
+    kc.check_gemv_wg_rows_agree(be, N, K, epi, True, G)
+
+
+def test_gemv_wg_is_race_free_and_bit_reproducible(be):
+    """hand-placed counted vmcnt waits + one bare barrier per chunk: back-to-back launches must all give the first launch's bits"""
+    import numpy as np
+    import torch
+
+    be.lib.vck_set_gemv_variant(1)
+    try:
+        rng = np.random.RandomState(4)
+        for (M, N, K, epi) in [(8, 12288, 4096, 0), (32, 22016, 4096, 3), (32, 4096, 11008, 1), (24, 5120, 13824, 1), (29, 32000, 4096, 1)]:
+            X = be.bf16(kc.bf16_round(rng.randn(32, K)))
+            Wb = be.bf16(kc.bf16_round(rng.randn(N, K) * 0.05))
+            Wp = be.zeros((N * K,), "bf16")
+            kc._call(be, "vck_pack_weight", Wb, Wp, N, K)
+            scratch, counters = be.zeros((8 * (N // 16) * 2 * 256,), "f32"), be.zeros((N // 16 * 2,), "i32")
+            outs = []
+            for it in range(24):
+                out = be.zeros((32, N // 2 if epi == 3 else N), "f32" if epi == 1 else "bf16")
+                be.lib.vck_gemv_full(be.ptr(X), be.ptr(Wp), None, be.ptr(out), None, None, None, None, 16, ctypes.c_float(1e-5),
+                                     be.ptr(scratch), ctypes.c_ulonglong(8 * (N // 16) * 2 * 256), be.ptr(counters), N // 16 * 2, 0,
+                                     M, N, K, N // 2 if epi == 3 else N, epi, 0, None)
+                outs.append(out)
+            be.sync()
+            for o in outs[1:]:
+                assert torch.equal(o, outs[0]), f"gemv_wg M{M} N{N} K{K}: launches differ"
+    finally:
+        be.lib.vck_set_gemv_variant(-1)

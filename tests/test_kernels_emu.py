@@ -189,3 +189,20 @@ def test_alternate_kernel_variants():
             r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
                                 f"({sel}) and not alternate"], env=dict(os.environ, **knobs), capture_output=True, text=True)
             assert r.returncode == 0, f"{knobs}: first run:\n{out[-1500:]}\nrepeated alone:\n{r.stdout[-1500:]}"
+
+
+@pytest.mark.parametrize("M,N,K,epi,norm,G,ks", [
+    (8, 64, 256, 0, True, 0, 0), (3, 32, 1024, 1, True, 0, 0), (16, 48, 320, 2, False, 0, 0), (8, 64, 256, 3, True, 0, 0),
+    (1, 16, 64, 1, False, 0, 0), (29, 96, 576, 0, True, 0, 0), (24, 64, 512, 2, True, 0, 2), (32, 160, 1024, 3, True, 0, 3),
+    (5, 64, 256, 0, True, 8, 0), (13, 48, 320, 2, True, 16, 0), (29, 96, 576, 3, True, 32, 0), (32, 64, 1024, 1, True, 32, 4),
+    (21, 80, 384, 2, True, 24, 2), (8, 8192, 128, 0, False, 0, 0)])
+def test_gemv_wg(be, M, N, K, epi, norm, G, ks):
+    """the workgroup-shared-activation decode GEMV: all row counts (1..4 activation pieces), epilogues, the split form with
+    both planes in one weight pass, K-slices over workgroups; N = 8192 (512 tiles) takes tile pairs per wave"""
+    kc.check_gemv_wg(be, M, N, K, epi, norm, G, ks)
+
+
+@pytest.mark.parametrize("N,K,epi,G,ks", [(64, 512, 0, False, 0), (48, 320, 1, False, 2), (96, 1024, 3, False, 3), (32, 512, 2, False, 0),
+                                          (64, 512, 0, True, 0), (48, 1024, 1, True, 4), (64, 256, 3, True, 0)])
+def test_gemv_wg_rows_agree(be, N, K, epi, G, ks):
+    kc.check_gemv_wg_rows_agree(be, N, K, epi, True, G, ks)

@@ -150,6 +150,80 @@ def bench_gemv_rows():
               f"(geom {os.environ.get('VC_GEMV2_GEOM', 'default')})", flush=True)
 
 
+def bench_gemv_wg():
+    """The workgroup-shared-activation GEMV (gemv_wg_kernel) next to the per-wave-ring form on the five 7b decode shapes, at
+    8 / 16 / 24 / 32 rows and — split form — 8 / 16 / 32 rows with both planes in one weight pass; then a geometry sweep
+    (tiles per wave x K-slices) per shape at 32 rows."""
+    shapes = [(12288, 4096, 0, "qkv", 32), (4096, 4096, 2, "o", 32), (22016, 4096, 3, "gate-up", 32), (4096, 11008, 2, "down", 32),
+              (32000, 4096, 1, "lm_head", 1)]
+    bufs = {}
+    for (N, K, epi, name, cnt) in shapes:
+        npart = (4096 // 16 + 15) // 16 * 16
+        bufs[name] = dict(X=bf16(64, K), Ws=[bf16(N * K, scale=0.02) for _ in range(6)],
+                          out=torch.zeros((64, N), dtype=torch.float32 if epi in (1, 2) else torch.bfloat16, device=dev),
+                          ssq=torch.rand(32, npart, device=dev), gw=torch.rand(N, device=dev) + 0.5,
+                          xg=torch.zeros((64, N), dtype=torch.bfloat16, device=dev),
+                          scratch=torch.zeros(8 * (N // 16) * 2 * 256, device=dev),
+                          counters=torch.zeros(N // 16 * 2, dtype=torch.int32, device=dev), npart=npart)
+
+    def run(name, N, K, epi, M, G, iters=30):
+        b = bufs[name]
+        ldo = N // 2 if epi == 3 else N
+        it = [0]
+        f32e = epi in (1, 2) or (G and epi == 0)   # the split step's qkv leaves fp32
+        e = 1 if (G and epi == 0) else epi
+        out = b["out"] if (b["out"].dtype == torch.float32) == bool(e in (1, 2)) else torch.zeros((64, N), dtype=torch.float32 if e in (1, 2) else torch.bfloat16, device=dev)
+
+        def f():
+            it[0] += 1
+            W = b["Ws"][it[0] % 6]
+            if e == 2:
+                lib.vck_gemv_full(P(b["X"]), P(W), None, P(out), None, P(b["ssq"]), P(b["gw"]), P(b["xg"]), b["npart"], C.c_float(1e-5),
+                                  P(b["scratch"]), C.c_ulonglong(b["scratch"].numel()), P(b["counters"]), b["counters"].numel(), 0,
+                                  M, N, K, ldo, e, G, None)
+            else:
+                lib.vck_gemv_full(P(b["X"]), P(W), None, P(out), P(b["ssq"]), None, None, None, b["npart"], C.c_float(1e-5),
+                                  P(b["scratch"]), C.c_ulonglong(b["scratch"].numel()), P(b["counters"]), b["counters"].numel(), 0,
+                                  M, N, K, ldo, e, G, None)
+        return timeit(f, iters=iters)
+
+    lib.vck_set_gemv_wg_geom.argtypes = [C.c_char_p, C.c_int]
+    for variant in (0, 1):
+        lib.vck_set_gemv_variant(variant)
+        for M in (8, 16, 24, 32):
+            tot = 0.0
+            for (N, K, epi, name, cnt) in shapes:
+                us = run(name, N, K, epi, M, 0)
+                tot += us * cnt
+                print(f"gemv_wg v{variant} M{M:2d} {name:8s}: {us:7.1f} us  {2 * N * K / us / 1e3:7.1f} GB/s", flush=True)
+            print(f"gemv_wg v{variant} M{M:2d} all GEMVs of a 7b decode step: {tot / 1e3:6.3f} ms", flush=True)
+    # split form: the ring kernel serves G = 8 (M <= 8) / 16 (M <= 16); the wg form also G = 32
+    for variant, cases in ((0, ((8, 8), (16, 16))), (1, ((8, 8), (16, 16), (32, 32)))):
+        lib.vck_set_gemv_variant(variant)
+        for M, G in cases:
+            tot = 0.0
+            for (N, K, epi, name, cnt) in shapes:
+                us = run(name, N, K, epi, M, G)
+                tot += us * cnt
+                print(f"gemv_wg split v{variant} M{M:2d} G{G:2d} {name:8s}: {us:7.1f} us  {2 * N * K / us / 1e3:7.1f} GB/s", flush=True)
+            print(f"gemv_wg split v{variant} M{M:2d} G{G:2d} all GEMVs of a 7b decode step: {tot / 1e3:6.3f} ms", flush=True)
+    # geometry sweep at 32 rows (and 8 rows): tiles per wave x K-slices, deep = chunk / ring trade at 25..32 rows
+    lib.vck_set_gemv_variant(1)
+    for (N, K, epi, name, cnt) in shapes:
+        for ntw in (1, 2):
+            for ks in (1, 2, 3, 4, 6, 8):
+                groups = (N // 16 + 4 * ntw - 1) // (4 * ntw)
+                if groups * ks > 1100 or groups * ks < 128 or (K // 64) // ks < 4:
+                    continue
+                res = []
+                for M, deep in ((8, 0), (32, 0), (32, 1)):
+                    lib.vck_set_gemv_wg_geom(f"{N // 16}:{K}:{ntw}:{ks}".encode(), deep)
+                    res.append(run(name, N, K, epi, M, 0, iters=20))
+                print(f"gemv_wg geom {name:8s} ntw{ntw} ks{ks} ({groups * ks:4d} wgs): M8 {res[0]:6.1f}  M32 {res[1]:6.1f}  M32deep {res[2]:6.1f} us", flush=True)
+    lib.vck_set_gemv_wg_geom(b"", -1)
+    lib.vck_set_gemv_variant(-1)
+
+
 def bench_gemv_rows8():
     """W8A16 weights at 17..32 rows: gate/up (7b, 13b) and qkv, consumer form (VC_GEMV8_NT4=0/1 switches the gate/up geometry)"""
     for M in (16, 24, 32):
@@ -345,7 +419,9 @@ if __name__ == "__main__":
         bench_gemm_f8()
     if "gemv_rows8" in what:
         bench_gemv_rows8()
+    if "gemv_wg" in what:
+        bench_gemv_wg()
     for w in what:
         {"gemm": bench_gemm, "gemv": bench_gemv, "attn": bench_attn, "dattn": bench_dattn,
          "gemv_fp8": lambda: None, "gemv13": lambda: None, "gemv_pair": lambda: None, "gemv_rows": lambda: None,
-         "dattn_rows": lambda: None, "gemm_f8": lambda: None, "gemv_rows8": lambda: None}[w]()
+         "dattn_rows": lambda: None, "gemm_f8": lambda: None, "gemv_rows8": lambda: None, "gemv_wg": lambda: None}[w]()

@@ -11,9 +11,11 @@
 // contiguous 1 KiB block with non-temporal loads, and a v_mfma_f32_16x16x32_bf16 per block does the
 // 16 outputs x 16 token-slots x 32 k dot products (tokens >= M are fed zeros).  K is split across the
 // waves of a workgroup and reduced through LDS; epilogues (fp32 residual add, SwiGLU) are fused.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <stdexcept>
+#include <string>
 
 #include "vc_device.h"
 #include "kernels.h"
@@ -449,6 +451,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) st_agent(mine + e, v[e]);
         wait_vmcnt<0>();  // the write-through stores have been acknowledged before the arrival is counted
+        wave_lds_fence(); // (a wave issues as one on the hardware; the emulator's lane fibers must all have stored before lane 0 counts)
         unsigned arrived = 0;
         if (lane == 0) arrived = atomic_inc_agent(&p.sk_counters[unit]);
         arrived = shfl(arrived, 0);
@@ -462,6 +465,223 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
         if (lane == 0) st_agent_u32(&p.sk_counters[unit], 0u);  // re-armed for the next launch (stream order)
     }
     gemv_epilogue<WAVES, EPI, FP8, 16 * MG>(p, v, &ss_part[0][0], nt, m + 16 * fq, g, ovalid[fq]);
+    }
+}
+
+// ---- workgroup-shared activation form ("wg"; bf16 weights, K % 64 == 0) ------------------------------------------------------
+// gemv_dma_kernel lets the waves of a workgroup split K, so every workgroup re-reads ALL of X [M, K] from L2: M / (16 NT) bytes
+// of it per weight byte — 2.0 at 32 rows, which (not HBM) bounds the pooled decode step, and twice that
+// again with the hi / lo rows of precision mode "split".  Here the four waves of a workgroup own different OUTPUT TILES (NTW
+// each) over the same K-slice, and the activation rows of that slice come through ONE shared, double-buffered LDS chunk ring
+// (CL lines of 64 k per chunk, fetched cooperatively, a quarter per wave): M / (64 NTW) activation bytes per weight byte — 8x
+// (NTW = 2) less L2 -> LDS traffic.  The weight stream is unchanged: a private ring of R one-line slots per wave, non-temporal
+// LDS-DMA, counted vmcnt waits — the activation DMAs sit in the same in-order queue, so a slot's wait counts the chunk fetch
+// issued behind it.  One bare s_barrier per chunk publishes the next chunk (each wave first waits for its own share to land).
+//
+// K is split over KS workgroups per tile group (the launcher picks KS from the matrix alone); a wave owns its tiles' sums over
+// the slice, so there is no cross-wave reduction, only the deterministic cross-workgroup hand-off of the split-K form above
+// (sc1 partials, arrival counter, the last arriver adds the slices in k order).  The k order of every sum depends on the matrix
+// only — never on M, NTW, CL or R — so a row gets the same bits from an 8-row and a 32-row pass.
+//
+// KH = 2 (precision mode "split"): X holds the hi rows [0, M) and the lo rows [G, G + M); both planes of a line are staged and
+// every weight fragment feeds hi and lo MFMAs of the SAME accumulator (the [hi | lo] K-concatenation of the prefill GEMM) —
+// one weight pass for up to 32 rows (64 operand rows), no combine step.
+template <int NTW, int XP, int KH, int CL, int R, int EPI>
+__global__ __launch_bounds__(256) void gemv_wg_kernel(GemvArgs p) {
+    constexpr int WAVES = 4;
+    constexpr int MG = (XP + 1) / 2;          // MFMA row groups of 16 token rows
+    constexpr int P = XP * KH;                // 1-KiB activation pieces (8 rows x 128 B) per line
+    constexpr int WO = 2 * NTW;               // weight DMA instructions per line (2 k-tiles x NTW tiles)
+    constexpr int XO = CL * P / WAVES;        // activation DMA instructions per wave and chunk
+    static_assert((CL * P) % WAVES == 0, "the chunk's pieces are dealt evenly to the four waves");
+    constexpr int XBUF = CL * P * 1024;       // one activation chunk
+    constexpr int SLOT = WO * 1024;
+    VC_DYNAMIC_SMEM(char, lds);               // [2][XBUF] activation chunks | [WAVES][R][SLOT] weight rings
+    __shared__ float ss_part[WAVES][16 * MG];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntiles = p.N >> 4;
+    const int KS = p.ksplit > 1 ? p.ksplit : 1;
+    const int ks = (int)blockIdx.x % KS, grp = (int)blockIdx.x / KS;
+    const int nlines = p.K >> 6;
+    const int l0 = (int)((long)ks * nlines / KS), l1 = (int)((long)(ks + 1) * nlines / KS);
+    const int nl = l1 - l0, nchunk = (nl + CL - 1) / CL;
+    const int m = lane & 15, g = lane >> 4;
+    const int G = p.split_rows;
+    char* xb = lds;
+    char* my = lds + 2 * XBUF + wave * (R * SLOT);
+    const int tile0 = (grp * WAVES + wave) * NTW;
+    const char* wsrc[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+        wsrc[t] = reinterpret_cast<const char*>(p.Wp) + ((size_t)min(tile0 + t, ntiles - 1) * (nlines * 2) * 64 + lane) * 16;
+    bool ovalid[MG];
+#pragma unroll
+    for (int q = 0; q < MG; ++q) ovalid[q] = m + 16 * q < p.M;
+    // activation pieces: lane = (row xr of the piece, 16-byte slot xs of the line); swizzled on the source side as in gemv_dma_kernel
+    const int xr = lane >> 3, xs = lane & 7;
+    auto issue_x = [&](int c) {   // this wave's share of chunk c -> buffer c & 1
+        char* dst = xb + (c & 1) * XBUF;
+#pragma unroll
+        for (int o = 0; o < XO; ++o) {
+            const int op = o * WAVES + wave;              // piece `pi` of line `j` of the chunk
+            const int j = op / P, pi = op % P;
+            const int part = pi / XP, x = pi % XP;
+            const int row = 8 * x + xr;
+            const int pc = xs ^ ((row >> 1) & 7);
+            const int line = min(l0 + c * CL + j, nlines - 1);
+            const size_t grow = (size_t)(row < p.M ? row : 0) + (part ? (size_t)G : 0);
+            glds16(reinterpret_cast<const char*>(p.X) + (grow * p.K + (size_t)line * 64) * 2 + pc * 16, dst + (j * P + pi) * 1024);
+        }
+    };
+    auto issue_w = [&](int i, int slot) {
+        char* dst = my + slot * SLOT;
+        const size_t line = (size_t)(l0 + i);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                if (p.w_cached) glds16(wsrc[t] + (line * 2 + kk) * 1024, dst + (kk * NTW + t) * 1024);
+                else glds16_nt(wsrc[t] + (line * 2 + kk) * 1024, dst + (kk * NTW + t) * 1024);
+            }
+    };
+    f32x4 acc[NTW][MG];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int q = 0; q < MG; ++q) acc[t][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // LDS offset of logical chunk c16 (16 bytes = 8 k) of local row `row` inside piece area `part` of line j
+    auto xoff = [&](int j, int part, int row, int c16) {
+        return (j * P + part * XP + (row >> 3)) * 1024 + ((row & 7) * 8 + (c16 ^ ((row >> 1) & 7))) * 16;
+    };
+    auto consume = [&](int c, int j, int slot) {
+        const char* xs_ = xb + (c & 1) * XBUF;
+        const char* sl = my + slot * SLOT + lane * 16;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            u32x4 w[NTW];
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) w[t] = ld16(sl + (kk * NTW + t) * 1024);
+#pragma unroll
+            for (int h = 0; h < KH; ++h) {
+                u32x4 x[MG];
+#pragma unroll
+                for (int q = 0; q < MG; ++q) {
+                    const int row = 16 * q + m;
+                    x[q] = u32x4{0u, 0u, 0u, 0u};
+                    if (2 * q + (m >> 3) < XP) x[q] = ld16(xs_ + xoff(j, h, row, kk * 4 + g));
+                    if (row >= p.M) x[q] = u32x4{0u, 0u, 0u, 0u};
+                }
+#pragma unroll
+                for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                    for (int q = 0; q < MG; ++q) acc[t][q] = mfma16(w[t], x[q], acc[t][q]);
+            }
+        }
+        wait_lgkmcnt<0>();  // the slot's fragment reads have retired before it is re-armed
+    };
+    // 1/rms partials: register loads issued BEFORE any DMA, so the compiler's wait at their use leaves the DMAs in flight
+    constexpr int SQ = 6;
+    f32x4 sq[MG][SQ];
+    const int nq = p.npart >> 2;
+    if (p.ssq_in != nullptr) {
+#pragma unroll
+        for (int q = 0; q < MG; ++q) {
+            const float* sp = p.ssq_in + (size_t)(ovalid[q] ? m + 16 * q : 0) * p.npart;
+#pragma unroll
+            for (int j = 0; j < SQ; ++j) {
+                const int qi = wave * 4 + g + j * WAVES * 4;
+                sq[q][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (qi < nq) sq[q][j] = ld16f(sp + qi * 4);
+            }
+        }
+    }
+    const int primed = min(nl, R);
+    if (nl > 0) issue_x(0);
+    for (int r = 0; r < primed; ++r) issue_w(r, r);
+    if (p.ssq_in != nullptr) {
+#pragma unroll
+        for (int q = 0; q < MG; ++q) {
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < SQ; j += 2) {
+                s0 += (sq[q][j][0] + sq[q][j][1]) + (sq[q][j][2] + sq[q][j][3]);
+                s1 += (sq[q][j + 1][0] + sq[q][j + 1][1]) + (sq[q][j + 1][2] + sq[q][j + 1][3]);
+            }
+            float ss = s0 + s1;
+            const float* sp = p.ssq_in + (size_t)(ovalid[q] ? m + 16 * q : 0) * p.npart;
+            for (int qi = wave * 4 + g + SQ * WAVES * 4; qi < nq; qi += WAVES * 4) {
+                const f32x4 v = ld16f(sp + qi * 4);
+                ss += (v[0] + v[1]) + (v[2] + v[3]);
+            }
+            ss += shfl_xor(ss, 16);
+            ss += shfl_xor(ss, 32);
+            if (g == 0) ss_part[wave][16 * q + m] = ss;
+        }
+    }
+    // chunk 0 of every wave has landed (everything issued behind it: the primed weight slots) and is published
+    wait_vmcnt_n(primed * WO);
+    wg_barrier_raw();
+    int slot = 0;
+    for (int c = 0; c < nchunk; ++c) {
+        const bool more = c + 1 < nchunk;
+        if (more) issue_x(c + 1);   // into the buffer whose last reads (chunk c - 1) every wave finished before the last barrier
+        int rearmed = 0;
+#pragma unroll
+        for (int j = 0; j < CL; ++j) {
+            const int i = c * CL + j;
+            if (i < nl) {
+                // DMAs issued behind slot i: the slots i+1 .. min(i+R, nl)-1, and chunk c+1's share when slot i went out before it
+                const int behind = (min(i + R, nl) - i - 1) * WO + ((more && j < R) ? XO : 0);
+                if (i + R <= nl) {
+                    if (more && j < R) wait_vmcnt<(R - 1) * WO + XO>();
+                    else wait_vmcnt<(R - 1) * WO>();
+                } else {
+                    wait_vmcnt_n(behind);
+                }
+                consume(c, j, slot);
+                if (i + R < nl) {
+                    issue_w(i + R, slot);
+                    ++rearmed;
+                }
+                slot = slot + 1 == R ? 0 : slot + 1;
+            }
+        }
+        if (more) {
+            wait_vmcnt_n(rearmed * WO);   // this wave's share of chunk c+1 has landed (only the re-armed slots are younger)
+            wg_barrier_raw();             // ... and so has everyone's; nobody still reads chunk c's buffer's predecessor
+        }
+    }
+    __syncthreads();   // ss_part is complete (and, with KS > 1, nothing of the rings is live any more)
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const int nt = tile0 + t;
+        if (nt >= ntiles) continue;
+#pragma unroll
+        for (int q = 0; q < MG; ++q) {
+            f32x4 v = acc[t][q];
+            if (KS > 1) {
+                // the split-K hand-off of gemv_dma_kernel: write-through partial, drained, arrival count; the last arriver adds the
+                // KS partials in k order with cache-bypassing loads and re-arms the counter
+                const size_t unit = (size_t)nt * 2 + q;
+                float* mine = p.sk_scratch + (((size_t)ks * ntiles * 2 + unit) * 64 + lane) * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) st_agent(mine + e, v[e]);
+                wait_vmcnt<0>();
+                wave_lds_fence();   // (the emulator's lane fibers must all have stored before lane 0 counts the arrival)
+                unsigned arrived = 0;
+                if (lane == 0) arrived = atomic_inc_agent(&p.sk_counters[unit]);
+                arrived = shfl(arrived, 0);
+                if (arrived != (unsigned)(KS - 1)) continue;
+                v = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int k = 0; k < KS; ++k) {
+                    const float* qp = p.sk_scratch + (((size_t)k * ntiles * 2 + unit) * 64 + lane) * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += ld_agent(qp + e);
+                }
+                if (lane == 0) st_agent_u32(&p.sk_counters[unit], 0u);
+            }
+            gemv_epilogue<WAVES, EPI, false, 16 * MG>(p, v, &ss_part[0][0], nt, m + 16 * q, g, ovalid[q]);
+        }
     }
 }
 
@@ -615,10 +835,133 @@ static void launch_gemv_f(const GemvArgs& a, int epilogue, hipStream_t s) {
     else if (tiles <= 512) launch_gemv_w<8, 1, FP8>(a, epilogue, s);
     else launch_gemv_w<4, 1, FP8>(a, epilogue, s);
 }
+// ---- launcher of the workgroup-shared form ----------------------------------------------------------------------------------
+struct WgGeom {
+    int ntw, ks;
+};
+// Tiles per wave and K-slices per tile group: a function of the MATRIX alone (so that every row count sums in the same order).
+// Default: tile pairs per wave from 512 tiles on; as many K-slices as keep the launch at <= ~2.5 workgroups per CU with >= 8
+// lines (512 k) per slice.  VC_GEMV_WG_GEOM="ntiles:K:ntw:ks,..." overrides single shapes (tuning).
+static std::string g_wg_geom_override;   // set_gemv_wg_geom: tools/kbench.py sweeps geometries inside one process
+static int g_wg_deep = -1;
+void set_gemv_wg_geom(const char* spec, int deep) {
+    g_wg_geom_override = spec ? spec : "";
+    g_wg_deep = deep;
+}
+static WgGeom wg_geometry(int ntiles, int K) {
+    static const char* env = getenv("VC_GEMV_WG_GEOM");
+    const char* q = !g_wg_geom_override.empty() ? g_wg_geom_override.c_str() : env;
+    if (q) {
+        while (*q) {
+            int t = 0, k = 0, ntw = 0, ks = 0, used = 0;
+            if (sscanf(q, "%d:%d:%d:%d%n", &t, &k, &ntw, &ks, &used) == 4 && used > 0) {
+                if (t == ntiles && k == K && (ntw == 1 || ntw == 2) && ks >= 1 && ks <= 8) return WgGeom{ntw, ks};
+                q += used;
+            } else {
+                ++q;
+            }
+            while (*q == ',' || *q == ' ') ++q;
+        }
+    }
+    const int ntw = ntiles >= 512 ? 2 : 1;
+    const int groups = (ntiles + 4 * ntw - 1) / (4 * ntw), lines = K / 64;
+    int ks = 1;
+    for (int c = 2; c <= 8; ++c)
+        if ((long)groups * c <= 640 && lines / c >= 8) ks = c;
+    return WgGeom{ntw, ks};
+}
+
+template <int NTW, int XP, int KH, int CL, int R>
+static void launch_gemv_wg_e(const GemvArgs& a, int epi, hipStream_t s) {
+    const int groups = (a.N / 16 + 4 * NTW - 1) / (4 * NTW);
+    const dim3 grid((unsigned)(groups * (a.ksplit > 1 ? a.ksplit : 1))), block(256);
+    constexpr size_t shmem = (size_t)(2 * CL * XP * KH + 4 * R * 2 * NTW) * 1024;
+    static_assert(shmem + 4 * 16 * ((XP + 1) / 2) * 4 <= 160 * 1024, "exceeds the LDS of a CU");
+#define VC_GEMV_WG(E)                                                                                                   \
+    do {                                                                                                                \
+        static bool once = false;                                                                                       \
+        if (!once) {                                                                                                    \
+            allow_big_lds(gemv_wg_kernel<NTW, XP, KH, CL, R, E>, shmem);                                                \
+            once = true;                                                                                                \
+        }                                                                                                               \
+        VC_LAUNCH((gemv_wg_kernel<NTW, XP, KH, CL, R, E>), grid, block, shmem, s, a);                                   \
+    } while (0)
+    switch (epi) {
+        case GEMV_BF16: VC_GEMV_WG(GEMV_BF16); break;
+        case GEMV_F32: VC_GEMV_WG(GEMV_F32); break;
+        case GEMV_RESID_F32: VC_GEMV_WG(GEMV_RESID_F32); break;
+        default: VC_GEMV_WG(GEMV_SWIGLU); break;
+    }
+#undef VC_GEMV_WG
+}
+
+// chunk length / ring depth by the activation pieces per line, so that two workgroups fit a CU (64 - 72 KiB each at NTW = 2)
+template <int NTW>
+static void launch_gemv_wg_n(const GemvArgs& a, int epi, hipStream_t s) {
+    // VC_GEMV_WG_DEEP=1 (tuning): at 25..32 rows, 4-line chunks with a 2-slot ring instead of 2-line chunks with a 3-slot ring
+    static const int deep_env = getenv("VC_GEMV_WG_DEEP") ? atoi(getenv("VC_GEMV_WG_DEEP")) : 0;
+    const int deep = g_wg_deep >= 0 ? g_wg_deep : deep_env;
+    const int xp = (a.M + 7) / 8;
+    if (a.split_rows) {
+        switch (xp) {
+            case 1: launch_gemv_wg_e<NTW, 1, 2, 4, 3>(a, epi, s); break;
+            case 2: launch_gemv_wg_e<NTW, 2, 2, 4, 2>(a, epi, s); break;
+            case 3: launch_gemv_wg_e<NTW, 3, 2, 2, 2>(a, epi, s); break;
+            default: launch_gemv_wg_e<NTW, 4, 2, 2, 2>(a, epi, s); break;
+        }
+        return;
+    }
+    switch (xp) {
+        case 1: launch_gemv_wg_e<NTW, 1, 1, 4, 4>(a, epi, s); break;
+        case 2: launch_gemv_wg_e<NTW, 2, 1, 4, 3>(a, epi, s); break;
+        case 3: launch_gemv_wg_e<NTW, 3, 1, 4, 3>(a, epi, s); break;
+        default:
+            if (deep) launch_gemv_wg_e<NTW, 4, 1, 4, 2>(a, epi, s);
+            else launch_gemv_wg_e<NTW, 4, 1, 2, 3>(a, epi, s);
+            break;
+    }
+}
+
+static int g_gemv_variant = -1;
+static unsigned long g_gemv_wg_launches = 0;
+void set_gemv_variant(int v) { g_gemv_variant = v; }
+unsigned long gemv_wg_launches() { return g_gemv_wg_launches; }
+static int gemv_variant_now() {
+    static const int wg_env = getenv("VC_GEMV_WG") ? atoi(getenv("VC_GEMV_WG")) : 0;
+    return g_gemv_variant >= 0 ? g_gemv_variant : wg_env;
+}
+bool gemv_wg_enabled() { return gemv_variant_now() == 1; }
+
+// true when the workgroup-shared form can serve the call
+static bool gemv_wg_applies(const GemvArgs& a) {
+    if (a.wscale || a.K % 64 != 0 || a.M < 1 || a.M > 32) return false;
+    if (a.split_rows && !(a.split_rows >= a.M && a.split_rows <= 32 && a.split_rows % 8 == 0)) return false;
+    return true;
+}
+
+static void launch_gemv_wg(const GemvArgs& a0, int epi, hipStream_t s) {
+    GemvArgs a = a0;
+    const int ntiles = a.N / 16;
+    WgGeom gm = wg_geometry(ntiles, a.K);
+    if (a.ksplit > 1) gm.ks = a.ksplit;   // an explicit request (tests) is honoured
+    const size_t cap = a.sk_scratch_floats ? a.sk_scratch_floats : (size_t)4 * 512 * 2 * 256;
+    const int ncnt = a.sk_counters_n ? a.sk_counters_n : 512 * 2;
+    // the split-K buffers bound the slices (a geometry decision of the matrix: the buffers are sized once per model)
+    while (gm.ks > 1 && (!a.sk_scratch || !a.sk_counters || (size_t)gm.ks * ntiles * 2 * 256 > cap || ntiles * 2 > ncnt)) --gm.ks;
+    a.ksplit = gm.ks;
+    ++g_gemv_wg_launches;
+    if (gm.ntw == 2) launch_gemv_wg_n<2>(a, epi, s);
+    else launch_gemv_wg_n<1>(a, epi, s);
+}
+
 void launch_gemv(const GemvArgs& a0, int epilogue, hipStream_t s) {
     static const int w_cached = getenv("VC_GEMV_WCACHED") ? atoi(getenv("VC_GEMV_WCACHED")) : 0;
     GemvArgs a = a0;
     a.w_cached = w_cached;
+    if (gemv_variant_now() == 1 && gemv_wg_applies(a)) {
+        launch_gemv_wg(a, epilogue, s);
+        return;
+    }
     if (a.split_rows) {
         // hi rows [0, M) + lo rows [G, G + M) of X; the two MFMA forms that combine them: G = 8 inside one 16-slot row group
         // (M <= 8), G = 16 across the two row groups (M <= 16).  No split-K hand-off in this mode.

@@ -493,6 +493,14 @@ void gemm_split(vc_model* m, const bf16_t* A, const bf16_t* W, const float* bias
 // row stride of a [hi | lo] operand of width K: padded like XN_PAD (2 K bf16 is a power-of-two stride at K = 4096)
 inline int split_ld(int K) { return 2 * K + XN_PAD; }
 
+// split-K buffers of the decode GEMVs: the widest [K-slices][output tiles] product of the model's matrices (the workgroup-shared
+// form slices qkv / gate-up / lm_head as well: at most 8 slices, decode.hip wg_geometry), two row groups of 256 floats each
+inline size_t sk_floats(const vc_model_cfg& c) {
+    const size_t tiles = (size_t)std::max(std::max(3 * c.hidden, 2 * c.ffn), c.vocab) / 16 + 1;
+    return std::max((size_t)4 * 512, (size_t)8 * tiles) * 2 * 256;
+}
+inline int sk_counters_n(const vc_model_cfg& c) { return (int)((size_t)std::max(std::max(3 * c.hidden, 2 * c.ffn), c.vocab) / 16 + 1) * 2; }
+
 // Everything one decode step touches besides the weights: the buffers of a session's own loop or of the shared pool.
 struct LoopView {
     hipStream_t st;
@@ -544,10 +552,12 @@ void gemv(vc_model* m, const LoopView& v, const bf16_t* X, const bf16_t* Wp, con
         }
         a.npart = np;
         a.eps = m->c.rms_eps;
-        if (N / 16 <= 512) {  // o_proj / down: the launcher may split K over several workgroups per tile
-            a.sk_scratch = v.sk_scratch;
-            a.sk_counters = v.sk_counters;
-        }
+        // the launcher may split K over several workgroups per tile (per-wave rings: o_proj / down only; the workgroup-shared
+        // form: any matrix)
+        a.sk_scratch = v.sk_scratch;
+        a.sk_counters = v.sk_counters;
+        a.sk_scratch_floats = sk_floats(m->c);
+        a.sk_counters_n = sk_counters_n(m->c);
         launch_gemv(a, epi, v.st);
     }
 }
@@ -1113,8 +1123,8 @@ void ensure_llm(vc_model* m, int B, int S_total) {
     m->next_tok.ensure(Bp * 4, true);
     m->rows.ensure((size_t)Bp * RS_STRIDE * 4, true);
     m->ssq.ensure((size_t)Bp * m->npart * 4, true);
-    m->sk_scratch.ensure((size_t)4 * 512 * 2 * 256 * 4);   // [ksplit <= 4][tiles <= 512][2 row groups][256]
-    m->sk_counters.ensure(512 * 2 * 4, true);
+    m->sk_scratch.ensure(sk_floats(c) * 4);   // [K-slices][tiles][2 row groups][256]
+    m->sk_counters.ensure((size_t)sk_counters_n(c) * 4, true);
     const void* after[] = {m->x_dec.p, m->xg_dec.p, m->qkv_dec.p, m->attn_dec.p, m->h_dec.p, m->next_tok.p, m->rows.p, m->ssq.p,
                            m->logits.p};
     for (size_t i = 0; i < sizeof(before) / sizeof(before[0]); ++i)
@@ -2452,7 +2462,9 @@ struct vc_pool {
     int device = 0;
     hipStream_t st = nullptr;
     int R = VC_POOL_ROWS, capS = 0, out_stride = 0;
-    bool split = false;               // built for precision mode "split": fp32 KV, stacked hi / lo step operands (G = 16)
+    bool split = false;               // built for precision mode "split": fp32 KV, stacked hi / lo step operands
+    int split_G = 16;                 // rows per stacked hi / lo group: 16 (per-wave-ring GEMV: two weight passes per 32-row step)
+                                      // or 32 (workgroup-shared GEMV: one)
     Buf kc, vc, rows, x_dec, xg_dec, qkv_dec, attn_dec, h_dec, logits, next_tok, out_ids, ssq, sk_scratch, sk_counters;
     hipGraphExec_t graph[VC_POOL_ROWS / 8] = {};    // one decode step over rows [0, 8 * (i + 1))
     std::mutex mu;
@@ -2476,7 +2488,9 @@ LoopView pool_view(vc_pool* p) {
     v.kc = p->kc.as<bf16_t>();
     v.vc = p->vc.as<bf16_t>();
     v.es = p->split ? 4 : 2;
-    v.split_G = p->split ? 16 : 0;   // one layout whatever rows a step spans: a row keeps its slot between steps
+    // one layout whatever rows a step spans: a row keeps its slot between steps.  The workgroup-shared GEMV takes all 32 rows
+    // (hi + lo planes) in ONE weight pass; the per-wave-ring form two passes of 16
+    v.split_G = p->split ? p->split_G : 0;
     v.capR = p->R;
     v.capS = p->capS;
     v.rows = p->rows.as<int>();
@@ -2652,6 +2666,7 @@ vc_pool* pool_for(vc_model* m, int need_S, int need_out) {
         p->root = root;
         p->device = root->ctx->device;
         p->split = want_split;
+        p->split_G = (gemv_wg_enabled() && root->weight_format == 0) ? 32 : 16;
         const int D = c.hidden, F = c.ffn, H = c.heads, R = p->R;
         const size_t es = want_split ? 4 : 2, two = want_split ? 2 : 1;
         p->capS = std::min((int)rup(std::max(need_S, 2048), 64), c.max_positions / 64 * 64);
@@ -2672,8 +2687,8 @@ vc_pool* pool_for(vc_model* m, int need_S, int need_out) {
         p->next_tok.ensure(R * 4, true);
         p->out_ids.ensure((size_t)R * p->out_stride * 4, true);
         p->ssq.ensure((size_t)R * root->npart * 4, true);
-        p->sk_scratch.ensure((size_t)4 * 512 * 2 * 256 * 4);   // [ksplit <= 4][tiles <= 512][2 row groups][256]
-        p->sk_counters.ensure(512 * 2 * 4, true);
+        p->sk_scratch.ensure(sk_floats(c) * 4);   // [K-slices][tiles][2 row groups][256]
+        p->sk_counters.ensure((size_t)sk_counters_n(c) * 4, true);
         t_stream = m->st;
         for (auto& e : p->step_ev) HIPCHK(hipEventCreate(&e));
         const LoopView v = pool_view(p);

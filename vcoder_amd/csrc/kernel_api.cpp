@@ -191,6 +191,23 @@ VCK_EXPORT void vck_gemv_split(const uint16_t* X, const void* Wp, const float* w
     a.split_rows = G;
     launch_gemv(a, epi, S(stream));
 }
+/* the decode GEMV with every argument (tests / tools): split rows G (0 = bf16 step), split-K buffers with their capacity */
+VCK_EXPORT void vck_gemv_full(const uint16_t* X, const void* Wp, const float* wscale, void* out, const float* ssq_in,
+                              float* ssq_out, const float* xg_w, uint16_t* xg_out, int npart, float eps, float* sk_scratch,
+                              unsigned long long sk_scratch_floats, unsigned* sk_counters, int sk_counters_n, int ksplit, int M,
+                              int N, int K, int ldo, int epi, int G, void* stream) {
+    GemvArgs a{};
+    a.X = X; a.Wp = reinterpret_cast<const uint16_t*>(Wp); a.wscale = wscale; a.out = out; a.M = M; a.N = N; a.K = K; a.ldo = ldo;
+    a.ssq_in = ssq_in; a.ssq_out = ssq_out; a.xg_w = xg_w; a.xg_out = xg_out; a.npart = npart; a.eps = eps;
+    a.sk_scratch = sk_scratch; a.sk_counters = sk_counters; a.ksplit = ksplit;
+    a.sk_scratch_floats = (size_t)sk_scratch_floats; a.sk_counters_n = sk_counters_n;
+    a.split_rows = G;
+    launch_gemv(a, epi, S(stream));
+}
+/* 0 = per-wave rings, 1 = workgroup-shared activation chunks, -1 = the process default (VC_GEMV_WG) */
+VCK_EXPORT void vck_set_gemv_variant(int v) { set_gemv_variant(v); }
+VCK_EXPORT void vck_set_gemv_wg_geom(const char* spec, int deep) { set_gemv_wg_geom(spec, deep); }
+VCK_EXPORT unsigned long long vck_gemv_wg_launches() { return gemv_wg_launches(); }
 VCK_EXPORT void vck_rmsnorm_split(const float* x, const int* row_idx, const float* w, uint16_t* y, int rows, int D, float eps,
                                   int ldy, uint64_t lo_off, void* stream) {
     launch_rmsnorm_split(x, row_idx, w, y, rows, D, eps, ldy, (size_t)lo_off, S(stream));

@@ -90,8 +90,17 @@ struct GemvArgs {
     // of the activation rows, rows [G, G + M) the lo parts (x = hi + lo, ~16 mantissa bits) — and out[m] = (hi[m] + lo[m]) . W.
     // bf16-valued outputs (GEMV_BF16, GEMV_SWIGLU, xg_out) are written the same way: hi at row m, lo at row G + m.
     int split_rows;
+    // capacity of the split-K buffers (0 = the historical [4][512][2][256] floats / [512][2] counters)
+    size_t sk_scratch_floats;
+    int sk_counters_n;
 };
 void launch_gemv(const GemvArgs& a, int epilogue, hipStream_t s);
+// which decode GEMV serves bf16 weights: 0 = per-wave rings (gemv_dma_kernel), 1 = workgroup-shared activation chunks
+// (gemv_wg_kernel); -1 = the process default (environment VC_GEMV_WG, read once).  Tests and tools/kbench.py switch it.
+void set_gemv_variant(int v);
+void set_gemv_wg_geom(const char* spec, int deep);   // tuning: "ntiles:K:ntw:ks,..." (empty = default), deep = -1 / 0 / 1
+bool gemv_wg_enabled();             // the workgroup-shared form serves bf16-weight GEMVs (variant 1)
+unsigned long gemv_wg_launches();   // launches served by the workgroup-shared form so far (tests)
 void launch_pack_weight(const bf16_t* W, bf16_t* Wp, int N, int K, hipStream_t s);
 // W [N,K] bf16 -> e4m3 packed + per-row scales; W is overwritten with the dequantised values (see decode.hip)
 void launch_quantize_fp8(bf16_t* W, uint8_t* Wq, float* scale, int N, int K, hipStream_t s, uint8_t* Wrow = nullptr);

@@ -282,8 +282,9 @@ VC_DEV void wait_vmcnt_n(int n) {
     switch (n) {
 #define VC_VMCASE(N) case N: wait_vmcnt<N>(); break;
         VC_VMCASE(1) VC_VMCASE(2) VC_VMCASE(3) VC_VMCASE(4) VC_VMCASE(5) VC_VMCASE(6) VC_VMCASE(7) VC_VMCASE(8) VC_VMCASE(9)
-        VC_VMCASE(10) VC_VMCASE(11) VC_VMCASE(12) VC_VMCASE(13) VC_VMCASE(14) VC_VMCASE(15) VC_VMCASE(16) VC_VMCASE(18)
-        VC_VMCASE(20) VC_VMCASE(21) VC_VMCASE(24) VC_VMCASE(28) VC_VMCASE(32)
+        VC_VMCASE(10) VC_VMCASE(11) VC_VMCASE(12) VC_VMCASE(13) VC_VMCASE(14) VC_VMCASE(15) VC_VMCASE(16) VC_VMCASE(17)
+        VC_VMCASE(18) VC_VMCASE(19) VC_VMCASE(20) VC_VMCASE(21) VC_VMCASE(22) VC_VMCASE(23) VC_VMCASE(24) VC_VMCASE(25)
+        VC_VMCASE(26) VC_VMCASE(27) VC_VMCASE(28) VC_VMCASE(29) VC_VMCASE(30) VC_VMCASE(31) VC_VMCASE(32)
 #undef VC_VMCASE
         default: wait_vmcnt<0>(); break;
     }
