@@ -160,6 +160,14 @@ void vck_attention_split(const uint16_t* q_hi, const uint16_t* q_lo, const uint1
 void vck_attention_decode_kv32(const float* qkv, float* k, float* v, uint16_t* out, int B, int H, int hd, int kv_stride,
                                const int* pos_rows, int pos_stride, const int* active_rows, const float* rope_cos,
                                const float* rope_sin, float scale, int G, void* stream);
+/* fp24 KV caches of precision mode "split" (rows of hd x u16 | hd x u8: the top 24 bits of the fp32 values, RNE — 0.75 of the fp32
+ * bytes at 2^-17 relative precision): the writer of a prefill and the fused decode attention over them */
+void vck_qkv_split24(const float* qkv, uint16_t* q_hi, uint16_t* q_lo, uint16_t* k_hi, uint16_t* k_lo, uint16_t* vt_hi,
+                     uint16_t* vt_lo, void* k24, void* v24, int B, int T, int H, int hd, int q_stride, int ks_stride, int vt_stride,
+                     int kv_stride, const float* rope_cos, const float* rope_sin, void* stream);
+void vck_attention_decode_kv24(const float* qkv, void* k, void* v, uint16_t* out, int B, int H, int hd, int kv_stride,
+                               const int* pos_rows, int pos_stride, const int* active_rows, const float* rope_cos,
+                               const float* rope_sin, float scale, int G, void* stream);
 /* deterministic synthetic tensors (vcoder_amd/synth.py) and dtype converts */
 void vck_synth_bf16(uint16_t* out, uint64_t n, uint32_t tseed, float offset, float halfwidth, void* stream);
 void vck_synth_f32(float* out, uint64_t n, uint32_t tseed, float offset, float halfwidth, void* stream);

@@ -1331,3 +1331,111 @@ def check_gemv_wg_rows_agree(be, N, K, epi, norm=True, G=False, ksplit=0, seed=0
                 assert np.array_equal(a[row0:row0 + M], b), f"rows {row0}..{row0 + M - 1} differ between the 29-row and the {M}-row pass"
     finally:
         be.lib.vck_set_gemv_variant(-1)
+
+
+# ---- fp24 KV caches of precision mode "split" (rows of hd x u16 | hd x u8: the top 24 bits of fp32, RNE) ------------------------
+def f24_round(x):
+    """fp32 -> the nearest fp24 value (round to nearest even on bit 8), as float32"""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7F + ((u >> 8) & 1)) & 0xFFFFFF00
+    return u.astype(np.uint32).view(np.float32).reshape(np.shape(x))
+
+
+def f24_pack(x):
+    """[..., S, hd] float32 -> uint8 rows [..., S, 3 * hd] in the cache layout"""
+    r = f24_round(x).view(np.uint32)
+    hi = (r >> 16).astype(np.uint16)
+    lo = ((r >> 8) & 0xFF).astype(np.uint8)
+    return np.concatenate([hi.view(np.uint8).reshape(*hi.shape[:-1], -1), lo], axis=-1)
+
+
+def f24_unpack(rows, hd):
+    """uint8 rows [..., 3 * hd] -> float32 [..., hd]"""
+    hi = np.ascontiguousarray(rows[..., : 2 * hd]).view(np.uint16).astype(np.uint32)
+    lo = rows[..., 2 * hd:].astype(np.uint32)
+    return ((hi << 16) | (lo << 8)).view(np.float32)
+
+
+def _u8_dev(be, a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if be.name == "hip":
+        return torch.from_numpy(a).to(be.dev)
+    z = be.zeros(a.shape, "u8")
+    z[...] = a
+    return z
+
+
+def _u8_host(be, a):
+    return a.cpu().numpy() if be.name == "hip" else np.array(a)
+
+
+def check_kv24(be, B, H, hd, pos, T_prefill=70, seed=0):
+    """the fp24 cache end to end at kernel level: vck_qkv_split24 writes rows that decode to fp24(RoPE(k)) / fp24(v) exactly
+    (RNE), and vck_attention_decode_kv24 — positions per row, one row inactive, append of the new row — equals the fp32 oracle
+    on the fp24-rounded cache to 3e-5."""
+    rng = np.random.RandomState(seed)
+    D = H * hd
+    # ---- prefill writer
+    T = T_prefill
+    Ts = (T + 63) // 64 * 64
+    S_cap = Ts + 64
+    qkv = rng.randn(B * T, 3 * D).astype(np.float32)
+    cos, sin = rope_tables(max(S_cap, pos + 130), hd)
+    planes = lambda *shape: [be.zeros(shape, "bf16") for _ in range(2)]
+    (qh, ql), (kh, kl), (vh, vl) = planes(B, H, Ts, hd), planes(B, H, Ts, hd), planes(B, H, hd, Ts)
+    k24, v24 = be.zeros((B, H, S_cap, 3 * hd), "u8"), be.zeros((B, H, S_cap, 3 * hd), "u8")
+    qd, cd, sd = be.f32(qkv), be.f32(cos), be.f32(sin)
+    be.lib.vck_qkv_split24(be.ptr(qd), be.ptr(qh), be.ptr(ql), be.ptr(kh), be.ptr(kl), be.ptr(vh), be.ptr(vl), be.ptr(k24),
+                           be.ptr(v24), B, T, H, hd, Ts, Ts, Ts, S_cap, be.ptr(cd), be.ptr(sd), None)
+    be.sync()
+    x = torch.from_numpy(qkv).view(B, T, 3, H, hd).permute(2, 0, 3, 1, 4).contiguous()
+    c, s_ = torch.from_numpy(cos[:T]), torch.from_numpy(sin[:T])
+    rot = lambda t, c=c, s_=s_: torch.cat([t[..., : hd // 2] * c - t[..., hd // 2:] * s_, t[..., hd // 2:] * c + t[..., : hd // 2] * s_], -1)
+    gk, gv = f24_unpack(_u8_host(be, k24), hd), f24_unpack(_u8_host(be, v24), hd)
+    kr = rot(x[1]).numpy()
+    # the device rotates in fp32 with fma contraction possible: allow one fp24 step around the reference rounding
+    assert np.abs(gk[:, :, :T] - kr).max() <= 2.0 ** -16 * np.abs(kr).max() and np.array_equal(gv[:, :, :T], f24_round(x[2].numpy()))
+    assert not _u8_host(be, k24)[:, :, T:].any() and not _u8_host(be, v24)[:, :, T:].any()
+    # ---- decode attention over fp24 caches
+    G = 8 if B <= 8 else (16 if B <= 16 else 32)
+    poss = [max(1, pos - 13 * b) for b in range(B)]
+    S = (pos + 1 + 63) // 64 * 64 + 64
+    q1 = rng.randn(B, 3 * D).astype(np.float32)
+    k_old, v_old = f24_round(rng.randn(B, H, S, hd).astype(np.float32)), f24_round(rng.randn(B, H, S, hd).astype(np.float32))
+    kd, vd = _u8_dev(be, f24_pack(k_old)), _u8_dev(be, f24_pack(v_old))
+    nrows_out = ((B + G - 1) // G) * 2 * G
+    out = be.zeros((nrows_out, D), "bf16")
+    scale = 1.0 / math.sqrt(hd)
+    q1d = be.f32(q1)
+    inactive = B - 1 if B > 1 else -1
+    rows = np.zeros((B, 4), np.int32)
+    rows[:, 0] = 1
+    rows[:, 1] = poss
+    if inactive >= 0:
+        rows[inactive, 0] = 0
+    rd = be.i32(rows)
+    base = rd.ctypes.data if isinstance(rd, np.ndarray) else rd.data_ptr()
+    be.lib.vck_attention_decode_kv24(be.ptr(q1d), be.ptr(kd), be.ptr(vd), be.ptr(out), B, H, hd, S, c_p(base + 4), 4, c_p(base),
+                                     be.ptr(cd), be.ptr(sd), ctypes.c_float(scale), G, None)
+    be.sync()
+    gk, gv, go = f24_unpack(_u8_host(be, kd), hd), f24_unpack(_u8_host(be, vd), hd), be.host_f32(out).astype(np.float64)
+    for b in range(B):
+        pb = poss[b]
+        orow = (b // G) * 2 * G + b % G
+        if b == inactive:
+            assert np.array_equal(gk[b], k_old[b]) and np.array_equal(gv[b], v_old[b]) and not go[orow].any()
+            continue
+        xx = torch.from_numpy(q1[b]).view(3, H, 1, hd)
+        cb, sb = torch.from_numpy(cos[pb]), torch.from_numpy(sin[pb])
+        q, kn, vn = rot(xx[0], cb, sb), rot(xx[1], cb, sb), xx[2]
+        assert np.abs(gk[b, :, pb] - kn[:, 0].numpy()).max() <= 2.0 ** -16 * np.abs(kn.numpy()).max()
+        assert np.array_equal(gv[b, :, pb], f24_round(vn[:, 0].numpy()))
+        keep = np.ones(S, bool)
+        keep[pb] = False
+        assert np.array_equal(gk[b][:, keep], k_old[b][:, keep]) and np.array_equal(gv[b][:, keep], v_old[b][:, keep])
+        k_all = torch.cat([torch.from_numpy(k_old[b, :, :pb]), torch.from_numpy(gk[b, :, pb:pb + 1])], 1)[None]
+        v_all = torch.cat([torch.from_numpy(v_old[b, :, :pb]), torch.from_numpy(gv[b, :, pb:pb + 1])], 1)[None]
+        ref = cpu_ref.softmax_attention(q[None], k_all, v_all, scale, False, cpu_ref.Rounder(False))
+        ref = ref.transpose(1, 2).reshape(D).numpy()
+        err = np.abs(go[orow] + go[orow + G] - ref).max()
+        assert err < 3e-5 * max(1.0, np.abs(ref).max()), f"decode attention kv24 row {b}: {err}"

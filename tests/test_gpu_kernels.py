@@ -164,6 +164,11 @@ def test_split_small_and_attention_kernels(be):
     kc.check_attention_decode_kv32(be, 24, 8, 128, 1300, seed=2)     # the pool's span: two groups of 16
     kc.check_attention_decode_kv32(be, 2, 4, 128, 4000, seed=3)
     kc.check_attention_decode_kv32(be, 1, 2, 64, 5, seed=4)
+    # the fp24 caches (the split mode's default KV format): writer + decode step at the true head shapes
+    kc.check_kv24(be, 8, 32, 128, 1216, T_prefill=130)
+    kc.check_kv24(be, 32, 4, 128, 1343, T_prefill=64, seed=1)
+    kc.check_kv24(be, 2, 4, 128, 4000, T_prefill=70, seed=3)
+    kc.check_kv24(be, 1, 2, 64, 5, T_prefill=3, seed=4)
 
 
 def test_dma_kernels_are_race_free_and_bit_reproducible(be):

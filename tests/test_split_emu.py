@@ -44,6 +44,13 @@ def test_split_attention_kernels(be):
     kc.check_attention_decode_kv32(be, 10, 1, 64, 70, seed=1)                                  # two groups of G = 16? no: one group, G = 16
 
 
+def test_fp24_kv_cache_kernels(be):
+    """the split mode's KV format (3 bytes per element): writer of the prefill, append + attention of the decode step"""
+    kc.check_kv24(be, 3, 2, 128, 140)
+    kc.check_kv24(be, 10, 1, 64, 70, T_prefill=33, seed=1)
+    kc.check_kv24(be, 19, 1, 128, 90, T_prefill=5, seed=2)    # 17..32 rows: one stacked group of G = 32
+
+
 @pytest.mark.parametrize("name", ["ds_img_depth_seg", "vc_img_text_seg", "llava_img"])
 def test_split_mode_meets_north_star_bar(be, name):
     r = e2e_cases.check_fixture_strict(name, lib=be.lib, mode="split")

@@ -207,9 +207,9 @@ def bench_gemv_wg():
                 tot += us * cnt
                 print(f"gemv_wg split v{variant} M{M:2d} G{G:2d} {name:8s}: {us:7.1f} us  {2 * N * K / us / 1e3:7.1f} GB/s", flush=True)
             print(f"gemv_wg split v{variant} M{M:2d} G{G:2d} all GEMVs of a 7b decode step: {tot / 1e3:6.3f} ms", flush=True)
-    # geometry sweep at 32 rows (and 8 rows): tiles per wave x K-slices, deep = chunk / ring trade at 25..32 rows
+    # geometry sweep at 32 rows (and 8 rows): tiles per wave x K-slices, deep = chunk / ring trade at 25..32 rows (KB_WG_SWEEP=1)
     lib.vck_set_gemv_variant(1)
-    for (N, K, epi, name, cnt) in shapes:
+    for (N, K, epi, name, cnt) in (shapes if os.environ.get("KB_WG_SWEEP") == "1" else []):
         for ntw in (1, 2):
             for ks in (1, 2, 3, 4, 6, 8):
                 groups = (N // 16 + 4 * ntw - 1) // (4 * ntw)
@@ -272,6 +272,34 @@ def bench_dattn_rows():
         us = timeit(f, iters=40)
         byts = 4.0 * float((pos + 1).sum().item()) * D
         print(f"decode attention rows B={B:2d} ctx~1280: {us:7.1f} us  {byts / us / 1e3:7.1f} GB/s", flush=True)
+
+
+def bench_dattn_split():
+    """decode attention of precision mode split: fp32 caches vs fp24 caches (3 bytes per element), rows as the pool spans them"""
+    H, hd, S = 32, 128, 2048
+    D = H * hd
+    cos, sin = torch.rand(S, hd // 2, device=dev), torch.rand(S, hd // 2, device=dev)
+    for B in (8, 16, 32):
+        G = 8 if B <= 8 else (16 if B <= 16 else 32)
+        qkv = torch.randn(B, 3 * D, device=dev)
+        out = torch.zeros((2 * G, D), dtype=torch.bfloat16, device=dev)
+        pos = torch.tensor([1216 + (7 * b) % 128 for b in range(B)], dtype=torch.int32, device=dev)
+        act = torch.ones(B, dtype=torch.int32, device=dev)
+        keys = float((pos + 1).sum().item())
+        for name, es, fn in (("fp32", 4, lib.vck_attention_decode_kv32), ("fp24", 3, lib.vck_attention_decode_kv24)):
+            ks = [torch.randint(0, 255, (B, H, S, hd * es), dtype=torch.uint8, device=dev) for _ in range(2)]
+            vs = [torch.randint(0, 255, (B, H, S, hd * es), dtype=torch.uint8, device=dev) for _ in range(2)]
+            for t in ks + vs:   # keep exponents sane: clear the top exponent bits of every element's high byte
+                t.view(B, H, S, -1)[...] &= 0x3F
+            it = [0]
+
+            def f():
+                it[0] += 1
+                fn(P(qkv), P(ks[it[0] % 2]), P(vs[it[0] % 2]), P(out), B, H, hd, S, P(pos), 1, P(act), P(cos), P(sin),
+                   C.c_float(1 / math.sqrt(hd)), G, None)
+            us = timeit(f, iters=30)
+            byts = 2.0 * keys * D * es
+            print(f"decode attention split {name} B={B:2d} ctx~1280: {us:7.1f} us  {byts / us / 1e3:7.1f} GB/s", flush=True)
 
 
 def bench_gemv_pair():
@@ -421,7 +449,9 @@ if __name__ == "__main__":
         bench_gemv_rows8()
     if "gemv_wg" in what:
         bench_gemv_wg()
+    if "dattn_split" in what:
+        bench_dattn_split()
     for w in what:
         {"gemm": bench_gemm, "gemv": bench_gemv, "attn": bench_attn, "dattn": bench_dattn,
          "gemv_fp8": lambda: None, "gemv13": lambda: None, "gemv_pair": lambda: None, "gemv_rows": lambda: None,
-         "dattn_rows": lambda: None, "gemm_f8": lambda: None, "gemv_rows8": lambda: None, "gemv_wg": lambda: None}[w]()
+         "dattn_rows": lambda: None, "gemm_f8": lambda: None, "gemv_rows8": lambda: None, "gemv_wg": lambda: None, "dattn_split": lambda: None}[w]()

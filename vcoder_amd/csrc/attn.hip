@@ -147,11 +147,23 @@ __global__ __launch_bounds__(256) void qkv_split32_kernel(QkvSplit32Args p) {
             st16(dh + HD / 2 + c * 8, yh);
             st16(dl + HD / 2 + c * 8, yl);
             if (which == 1 && p.k32 != nullptr) {
-                float* kc = p.k32 + (bh * p.kv_stride + t) * HD;
-                st16f(kc + c * 8, *reinterpret_cast<f32x4*>(ox));
-                st16f(kc + c * 8 + 4, *reinterpret_cast<f32x4*>(ox + 4));
-                st16f(kc + HD / 2 + c * 8, *reinterpret_cast<f32x4*>(oy));
-                st16f(kc + HD / 2 + c * 8 + 4, *reinterpret_cast<f32x4*>(oy + 4));
+                if (p.kv24) {   // fp24 cache row: hd x u16 hi plane | hd x u8 lo plane
+                    char* kc = reinterpret_cast<char*>(p.k32) + (bh * p.kv_stride + t) * (size_t)(3 * HD);
+                    u32x4 h8;
+                    u32x2 l8;
+                    pack_f24x8(ox, h8, l8);
+                    st16(kc + c * 16, h8);
+                    st8(kc + 2 * HD + c * 8, l8);
+                    pack_f24x8(oy, h8, l8);
+                    st16(kc + HD + c * 16, h8);
+                    st8(kc + 2 * HD + HD / 2 + c * 8, l8);
+                } else {
+                    float* kc = p.k32 + (bh * p.kv_stride + t) * HD;
+                    st16f(kc + c * 8, *reinterpret_cast<f32x4*>(ox));
+                    st16f(kc + c * 8 + 4, *reinterpret_cast<f32x4*>(ox + 4));
+                    st16f(kc + HD / 2 + c * 8, *reinterpret_cast<f32x4*>(oy));
+                    st16f(kc + HD / 2 + c * 8 + 4, *reinterpret_cast<f32x4*>(oy + 4));
+                }
             }
         }
     }
@@ -163,9 +175,18 @@ __global__ __launch_bounds__(256) void qkv_split32_kernel(QkvSplit32Args p) {
             *reinterpret_cast<f32x4*>(v) = ld16f(src);
             *reinterpret_cast<f32x4*>(v + 4) = ld16f(src + 4);
             if (p.v32 != nullptr) {
-                float* vc = p.v32 + (bh * p.kv_stride + t) * HD + c * 8;
-                st16f(vc, *reinterpret_cast<f32x4*>(v));
-                st16f(vc + 4, *reinterpret_cast<f32x4*>(v + 4));
+                if (p.kv24) {
+                    char* vc = reinterpret_cast<char*>(p.v32) + (bh * p.kv_stride + t) * (size_t)(3 * HD);
+                    u32x4 h8;
+                    u32x2 l8;
+                    pack_f24x8(v, h8, l8);
+                    st16(vc + c * 16, h8);
+                    st8(vc + 2 * HD + c * 8, l8);
+                } else {
+                    float* vc = p.v32 + (bh * p.kv_stride + t) * HD + c * 8;
+                    st16f(vc, *reinterpret_cast<f32x4*>(v));
+                    st16f(vc + 4, *reinterpret_cast<f32x4*>(v + 4));
+                }
             }
         }
         u32x4 vh, vl;
@@ -586,10 +607,15 @@ constexpr int DEC_MAX_CTX = 4096;
 
 // KV32 (precision mode "split"): the projection output and the K / V cache are fp32 (4 dims per 16-byte load, HD / 4 lanes
 // per key row), q is not rounded, and the output row is written as bf16 hi / lo rows of a stacked group layout (out_G)
-template <int HD, int UK, bool KV32 = false>               // UK = independent row loads in flight per lane
+// KVF == 2: fp24 caches (rows of hd x u16 | hd x u8; 8 elements per lane = one 16-byte + one 8-byte load) — 3 bytes per element
+// at 2^-17 relative precision: the split step's attention streams 0.75 of the fp32 bytes
+template <int HD, int UK, int KVF = 0>               // UK = independent row loads in flight per lane; KVF: 0 bf16, 1 fp32, 2 fp24
 __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeFusedArgs p) {
-    constexpr int EPL = KV32 ? 4 : 8;     // elements per lane = one 16-byte load
-    constexpr int ESZ = KV32 ? 4 : 2;     // bytes per cache element
+    constexpr bool KV32 = KVF != 0;       // the split step's operand forms (fp32 projection rows, unrounded q, hi / lo output rows)
+    constexpr bool F24 = KVF == 2;
+    constexpr int EPL = KVF == 1 ? 4 : 8; // elements per lane
+    constexpr int ESZ = KVF == 1 ? 4 : 2; // bytes per element of the (hi) plane
+    constexpr int ROWB = F24 ? 3 * HD : HD * ESZ;   // bytes per cache row
     constexpr int LPK = HD / EPL;         // lanes per key row
     constexpr int KPW = 64 / LPK;         // key rows per wave-instruction
     constexpr int BATCH = 8 * KPW * UK;   // keys one round of the 8 waves covers
@@ -604,8 +630,8 @@ __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeF
     const int pos = p.pos_dev[(size_t)b * p.pos_stride];
     const int ctx = pos + 1;
     const int D = p.H * HD;
-    char* kbase = reinterpret_cast<char*>(p.k) + bh * p.kv_stride * HD * ESZ;
-    char* vbase = reinterpret_cast<char*>(p.v) + bh * p.kv_stride * HD * ESZ;
+    char* kbase = reinterpret_cast<char*>(p.k) + bh * p.kv_stride * ROWB;
+    char* vbase = reinterpret_cast<char*>(p.v) + bh * p.kv_stride * ROWB;
     // ---- phase 0: rotate q,k of the new token, append k / v to the cache (global) and keep q in LDS
     if (tid < HD / 2) {
         const int d = tid;
@@ -616,12 +642,26 @@ __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeF
             const float k0 = row[D + d], k1 = row[D + d + HD / 2];
             q_s[d] = q0 * c - q1 * s;
             q_s[d + HD / 2] = q1 * c + q0 * s;
-            float* ko = reinterpret_cast<float*>(kbase) + (size_t)pos * HD;
-            ko[d] = k0 * c - k1 * s;
-            ko[d + HD / 2] = k1 * c + k0 * s;
-            float* vo = reinterpret_cast<float*>(vbase) + (size_t)pos * HD;
-            vo[d] = row[2 * D + d];
-            vo[d + HD / 2] = row[2 * D + d + HD / 2];
+            if constexpr (F24) {
+                auto put = [&](char* rowp, int dd, float val) {
+                    const uint32_t code = f32_to_f24(val);
+                    reinterpret_cast<uint16_t*>(rowp)[dd] = (uint16_t)(code >> 8);
+                    reinterpret_cast<uint8_t*>(rowp + 2 * HD)[dd] = (uint8_t)(code & 0xFFu);
+                };
+                char* ko = kbase + (size_t)pos * ROWB;
+                put(ko, d, k0 * c - k1 * s);
+                put(ko, d + HD / 2, k1 * c + k0 * s);
+                char* vo = vbase + (size_t)pos * ROWB;
+                put(vo, d, row[2 * D + d]);
+                put(vo, d + HD / 2, row[2 * D + d + HD / 2]);
+            } else {
+                float* ko = reinterpret_cast<float*>(kbase) + (size_t)pos * HD;
+                ko[d] = k0 * c - k1 * s;
+                ko[d + HD / 2] = k1 * c + k0 * s;
+                float* vo = reinterpret_cast<float*>(vbase) + (size_t)pos * HD;
+                vo[d] = row[2 * D + d];
+                vo[d + HD / 2] = row[2 * D + d + HD / 2];
+            }
         } else {
             const bf16_t* row = p.qkv + (size_t)b * (3 * D) + h * HD;
             const float q0 = bf2f(row[d]), q1 = bf2f(row[d + HD / 2]);
@@ -650,10 +690,15 @@ __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeF
     // its row has been consumed, so UK rows stay in flight with UK registers (no second set).  Rows past the context are
     // clamped to the last valid row (one cached line, p = 0 / score masked): no branch around the loads.
     // wave-uniform base + one 32-bit byte offset per lane (the scalar-base addressing form: half the address VGPRs)
-    auto row_off = [&](int key) { return (uint32_t)(min(key, ctx - 1) * HD + kcol) * (uint32_t)ESZ; };
-    auto dot = [&](const u32x4& r) {
+    auto row_off = [&](int key) { return (uint32_t)(min(key, ctx - 1) * ROWB) + (uint32_t)(kcol * ESZ); };
+    // fp24: the lo plane of the row, 8 bytes per lane
+    auto lo_off = [&](int key) { return (uint32_t)(min(key, ctx - 1) * ROWB) + (uint32_t)(2 * HD + kcol); };
+    auto dot = [&](const u32x4& r, const u32x2& rl) {
         float s = 0.f;
-        if constexpr (KV32) {
+        if constexpr (F24) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += qv[e] * f24_elem(r, rl, e);
+        } else if constexpr (KV32) {
             const f32x4 f = __builtin_bit_cast(f32x4, r);
 #pragma unroll
             for (int e = 0; e < 4; ++e) s += qv[e] * f[e];
@@ -664,14 +709,19 @@ __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeF
         return s;
     };
     u32x4 kv[UK];
+    u32x2 kl[F24 ? UK : 1];
 #pragma unroll
-    for (int u = 0; u < UK; ++u) kv[u] = ld16_stream(kbase + row_off(wave * KPW * UK + u * KPW + krow));
+    for (int u = 0; u < UK; ++u) {
+        kv[u] = ld16_stream(kbase + row_off(wave * KPW * UK + u * KPW + krow));
+        if constexpr (F24) kl[u] = ld8_stream(kbase + lo_off(wave * KPW * UK + u * KPW + krow));
+    }
     for (int kb = wave * KPW * UK; kb < ctx_pad; kb += BATCH) {
 #pragma unroll
         for (int u = 0; u < UK; ++u) {
             const int key = kb + u * KPW + krow;
-            float s = dot(kv[u]);
+            float s = dot(kv[u], kl[F24 ? u : 0]);
             kv[u] = ld16_stream(kbase + row_off(key + BATCH));
+            if constexpr (F24) kl[u] = ld8_stream(kbase + lo_off(key + BATCH));
             s = lanes_sum<LPK>(s);
             if ((lane % LPK) == 0) sc[key] = (key < ctx && (kmask == nullptr || kmask[min(key, ctx - 1)] != 0)) ? s * p.scale : -INFINITY;
         }
@@ -679,8 +729,12 @@ __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeF
     // the first V batch of every wave does not depend on the scores: request it now so HBM stays busy through the
     // LDS-only softmax below
     u32x4 vv[UK];
+    u32x2 vl[F24 ? UK : 1];
 #pragma unroll
-    for (int u = 0; u < UK; ++u) vv[u] = ld16_stream(vbase + row_off(wave * KPW * UK + u * KPW + krow));
+    for (int u = 0; u < UK; ++u) {
+        vv[u] = ld16_stream(vbase + row_off(wave * KPW * UK + u * KPW + krow));
+        if constexpr (F24) vl[u] = ld8_stream(vbase + lo_off(wave * KPW * UK + u * KPW + krow));
+    }
     __syncthreads();
     // ---- phase 2: softmax over sc[0..ctx_pad)
     float mx = -INFINITY;
@@ -716,8 +770,13 @@ __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeF
             const int key = kb + u * KPW + krow;
             const float pk = sc[key];
             const u32x4 v = vv[u];
+            const u32x2 vlo = vl[F24 ? u : 0];
             vv[u] = ld16_stream(vbase + row_off(key + BATCH));
-            if constexpr (KV32) {
+            if constexpr (F24) {
+                vl[u] = ld8_stream(vbase + lo_off(key + BATCH));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += pk * f24_elem(v, vlo, e);
+            } else if constexpr (KV32) {
                 const f32x4 f = __builtin_bit_cast(f32x4, v);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[e] += pk * f[e];
@@ -763,9 +822,15 @@ void launch_attention_decode_fused(const AttnDecodeFusedArgs& a, hipStream_t s) 
     const dim3 grid(a.H, a.B), block(512);
     // VC_DATTN_UK: row loads in flight per lane (tuning knob; 8 = 8 KiB per wave, two workgroups per CU)
     static const int uk = getenv("VC_DATTN_UK") ? atoi(getenv("VC_DATTN_UK")) : 8;
-    if (a.kv32) {  // precision mode "split"
-        if (a.hd == 128) VC_LAUNCH((attention_decode_fused_kernel<128, 8, true>), grid, block, 0, s, a);
-        else VC_LAUNCH((attention_decode_fused_kernel<64, 8, true>), grid, block, 0, s, a);
+    if (a.kv32 == 2) {  // precision mode "split", fp24 caches
+        // 6 rows x 24 B in flight per lane (the bf16 kernel's 8 x 16 B take 114 VGPRs, 8 rows of fp24 171: one workgroup per CU)
+        if (a.hd == 128) VC_LAUNCH((attention_decode_fused_kernel<128, 6, 2>), grid, block, 0, s, a);
+        else VC_LAUNCH((attention_decode_fused_kernel<64, 6, 2>), grid, block, 0, s, a);
+        return;
+    }
+    if (a.kv32) {  // precision mode "split", fp32 caches
+        if (a.hd == 128) VC_LAUNCH((attention_decode_fused_kernel<128, 8, 1>), grid, block, 0, s, a);
+        else VC_LAUNCH((attention_decode_fused_kernel<64, 8, 1>), grid, block, 0, s, a);
         return;
     }
     if (a.hd == 128) {

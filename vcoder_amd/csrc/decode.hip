@@ -863,12 +863,13 @@ static WgGeom wg_geometry(int ntiles, int K) {
             while (*q == ',' || *q == ' ') ++q;
         }
     }
-    const int ntw = ntiles >= 512 ? 2 : 1;
-    const int groups = (ntiles + 4 * ntw - 1) / (4 * ntw), lines = K / 64;
-    int ks = 1;
-    for (int c = 2; c <= 8; ++c)
-        if ((long)groups * c <= 640 && lines / c >= 8) ks = c;
-    return WgGeom{ntw, ks};
+    // measured on MI355X at the 7b shapes, 8 and 32 rows (profiles/r04_b_kbench_gemv_wg.txt): one tile per wave beats tile pairs
+    // everywhere (twice the workgroups), and every extra K-slice costs (the cross-workgroup hand-off) — so only as many slices as
+    // it takes to put >= 256 workgroups on the chip: qkv (768 tiles) 2, o / down (256) 4, gate-up / lm_head 1
+    const int groups = (ntiles + 3) / 4, lines = K / 64;
+    int ks = groups >= 256 ? 1 : groups >= 128 ? 2 : 4;
+    while (ks > 1 && lines / ks < 8) --ks;
+    return WgGeom{1, ks};
 }
 
 template <int NTW, int XP, int KH, int CL, int R>
@@ -895,29 +896,31 @@ static void launch_gemv_wg_e(const GemvArgs& a, int epi, hipStream_t s) {
 #undef VC_GEMV_WG
 }
 
-// chunk length / ring depth by the activation pieces per line, so that two workgroups fit a CU (64 - 72 KiB each at NTW = 2)
+// chunk length / ring depth by the activation pieces per line, so that two workgroups fit a CU (<= 72 KiB each); a one-tile
+// wave has 2-KiB slots and takes a ring twice as deep for the same LDS
 template <int NTW>
 static void launch_gemv_wg_n(const GemvArgs& a, int epi, hipStream_t s) {
-    // VC_GEMV_WG_DEEP=1 (tuning): at 25..32 rows, 4-line chunks with a 2-slot ring instead of 2-line chunks with a 3-slot ring
+    // VC_GEMV_WG_DEEP=1 (tuning): at 25..32 rows, 4-line chunks with a shallower ring instead of 2-line chunks
     static const int deep_env = getenv("VC_GEMV_WG_DEEP") ? atoi(getenv("VC_GEMV_WG_DEEP")) : 0;
     const int deep = g_wg_deep >= 0 ? g_wg_deep : deep_env;
     const int xp = (a.M + 7) / 8;
+    constexpr int RX = NTW == 1 ? 2 : 1;   // ring depth factor
     if (a.split_rows) {
         switch (xp) {
-            case 1: launch_gemv_wg_e<NTW, 1, 2, 4, 3>(a, epi, s); break;
-            case 2: launch_gemv_wg_e<NTW, 2, 2, 4, 2>(a, epi, s); break;
-            case 3: launch_gemv_wg_e<NTW, 3, 2, 2, 2>(a, epi, s); break;
-            default: launch_gemv_wg_e<NTW, 4, 2, 2, 2>(a, epi, s); break;
+            case 1: launch_gemv_wg_e<NTW, 1, 2, 4, NTW == 1 ? 4 : 3>(a, epi, s); break;
+            case 2: launch_gemv_wg_e<NTW, 2, 2, 4, 2 * RX>(a, epi, s); break;
+            case 3: launch_gemv_wg_e<NTW, 3, 2, 2, 2 * RX>(a, epi, s); break;
+            default: launch_gemv_wg_e<NTW, 4, 2, 2, 2 * RX>(a, epi, s); break;
         }
         return;
     }
     switch (xp) {
-        case 1: launch_gemv_wg_e<NTW, 1, 1, 4, 4>(a, epi, s); break;
-        case 2: launch_gemv_wg_e<NTW, 2, 1, 4, 3>(a, epi, s); break;
-        case 3: launch_gemv_wg_e<NTW, 3, 1, 4, 3>(a, epi, s); break;
+        case 1: launch_gemv_wg_e<NTW, 1, 1, 4, NTW == 1 ? 6 : 4>(a, epi, s); break;
+        case 2: launch_gemv_wg_e<NTW, 2, 1, 4, NTW == 1 ? 5 : 3>(a, epi, s); break;
+        case 3: launch_gemv_wg_e<NTW, 3, 1, 4, NTW == 1 ? 5 : 3>(a, epi, s); break;
         default:
-            if (deep) launch_gemv_wg_e<NTW, 4, 1, 4, 2>(a, epi, s);
-            else launch_gemv_wg_e<NTW, 4, 1, 2, 3>(a, epi, s);
+            if (deep) launch_gemv_wg_e<NTW, 4, 1, 4, 2 * RX>(a, epi, s);
+            else launch_gemv_wg_e<NTW, 4, 1, 2, NTW == 1 ? 5 : 3>(a, epi, s);
             break;
     }
 }
@@ -926,11 +929,16 @@ static int g_gemv_variant = -1;
 static unsigned long g_gemv_wg_launches = 0;
 void set_gemv_variant(int v) { g_gemv_variant = v; }
 unsigned long gemv_wg_launches() { return g_gemv_wg_launches; }
+// VC_GEMV_WG / set_gemv_variant: 0 = the per-wave-ring kernel everywhere; 1 = the workgroup-shared form everywhere it applies;
+// 2 (default) = the workgroup-shared form for precision mode "split" only.  Measured (profiles/r04_b_kbench_gemv_wg.txt): for the
+// bf16 step the ring kernel is faster at every row count (3.13 vs 3.57 ms at 32 rows with the best geometry found) — fewer,
+// larger DMA slots in flight per wave and no barrier in its loop outweigh the activation traffic it repeats; for the split step
+// one weight pass over 32 rows' hi + lo planes beats its two passes of 16 (6.27 ms).
 static int gemv_variant_now() {
-    static const int wg_env = getenv("VC_GEMV_WG") ? atoi(getenv("VC_GEMV_WG")) : 0;
+    static const int wg_env = getenv("VC_GEMV_WG") ? atoi(getenv("VC_GEMV_WG")) : 2;
     return g_gemv_variant >= 0 ? g_gemv_variant : wg_env;
 }
-bool gemv_wg_enabled() { return gemv_variant_now() == 1; }
+bool gemv_wg_enabled() { return gemv_variant_now() >= 1; }
 
 // true when the workgroup-shared form can serve the call
 static bool gemv_wg_applies(const GemvArgs& a) {
@@ -958,7 +966,7 @@ void launch_gemv(const GemvArgs& a0, int epilogue, hipStream_t s) {
     static const int w_cached = getenv("VC_GEMV_WCACHED") ? atoi(getenv("VC_GEMV_WCACHED")) : 0;
     GemvArgs a = a0;
     a.w_cached = w_cached;
-    if (gemv_variant_now() == 1 && gemv_wg_applies(a)) {
+    if ((gemv_variant_now() == 1 || (gemv_variant_now() == 2 && a.split_rows)) && gemv_wg_applies(a)) {
         launch_gemv_wg(a, epilogue, s);
         return;
     }

@@ -209,6 +209,7 @@ struct vc_model {
     int layer_limit = 0;          // > 0: a prefill evaluates only the first layer_limit decoder layers (vc_model_set_layer_limit)
     // LLM workspace
     Buf x, xn, qkv, q, attn, h, kc, vc, vt_pre, row_src, last_idx, xl, logits_all;
+    Buf p_ssq, p_rstd;            // prefill: sum-of-squares partials [B*S, npart] and 1/rms [B*S] of the folded RMSNorm
     Buf a8, a8_scale;             // weight format 2: e4m3 activation rows of the current prefill GEMM + their scales
     int capB = 0, capS = 0;  // KV capacity
     int curB = 0, curS = 0, cur_pos = -1;
@@ -448,9 +449,28 @@ void emit_attentions(vc_model* m, int l, int B, int S, AttnProbsArgs a, int Tk =
 
 // ------------------------------------------------------------------------------------------------
 // GEMM helpers
+// folded RMSNorm of a prefill (GemmArgs::row_scale / xg_out): what a GEMM consumes and what it hands to the next one
+struct NormFold {
+    const float* row_scale = nullptr;   // consumer: 1/rms per row
+    bf16_t* xg_out = nullptr;           // producer (EPI_RESID_F32): the next GEMM's operand rows ...
+    const float* xg_w = nullptr;        // ... = bf16(x * xg_w)
+    float* ssq_out = nullptr;
+    int ld_xg = 0, xg_lo = 0, npart = 0;
+};
+static void apply_fold(GemmArgs& a, const NormFold* f) {
+    if (!f) return;
+    a.row_scale = f->row_scale;
+    a.xg_out = f->xg_out;
+    a.xg_w = f->xg_w;
+    a.ssq_out = f->ssq_out;
+    a.ld_xg = f->ld_xg;
+    a.xg_lo = f->xg_lo;
+    a.npart = f->npart;
+}
 void gemm(vc_model* m, const bf16_t* A, const bf16_t* W, const float* bias, void* out, int M, int N, int K, int ldo,
-          int epi, int lda = 0) {
+          int epi, int lda = 0, const NormFold* fold = nullptr) {
     GemmArgs a{A, W, bias, out, M, N, K, lda > 0 ? lda : K, K, ldo};
+    apply_fold(a, fold);
     if ((long)((M + 255) / 256) * ((N + 255) / 256) > 256) {  // only problems with more than one round of tiles can use it
         m->gemm_ws.ensure((size_t)64 << 20);
         a.ws = m->gemm_ws.as<float>();
@@ -479,10 +499,11 @@ void gemm_f8(vc_model* m, const bf16_t* A, const uint8_t* Wq, const float* wscal
 // W [N, Kw] is contracted against both halves (kwrap); split_out > 0: a bf16-valued epilogue writes [hi | lo] again, the lo
 // plane split_out columns to the right
 void gemm_split(vc_model* m, const bf16_t* A, const bf16_t* W, const float* bias, void* out, int M, int N, int Kw, int ldo,
-                int epi, int lda, int split_out = 0) {
+                int epi, int lda, int split_out = 0, const NormFold* fold = nullptr) {
     GemmArgs a{A, W, bias, out, M, N, 2 * Kw, lda, Kw, ldo};
     a.kwrap = Kw / 64;
     a.split_out = split_out;
+    apply_fold(a, fold);
     if ((long)((M + 255) / 256) * ((N + 255) / 256) > 256) {
         m->gemm_ws.ensure((size_t)64 << 20);
         a.ws = m->gemm_ws.as<float>();
@@ -501,11 +522,18 @@ inline size_t sk_floats(const vc_model_cfg& c) {
 }
 inline int sk_counters_n(const vc_model_cfg& c) { return (int)((size_t)std::max(std::max(3 * c.hidden, 2 * c.ffn), c.vocab) / 16 + 1) * 2; }
 
+// bytes per KV-cache element of precision mode "split": 3 = fp24 (default: hd x u16 | hd x u8 per row, 2^-17 relative, 0.75 of the
+// fp32 bytes the decode attention streams), 4 = fp32 (VC_SPLIT_KV=32: regression / A-B)
+inline int split_kv_es() {
+    static const int es = (getenv("VC_SPLIT_KV") && atoi(getenv("VC_SPLIT_KV")) == 32) ? 4 : 3;
+    return es;
+}
+
 // Everything one decode step touches besides the weights: the buffers of a session's own loop or of the shared pool.
 struct LoopView {
     hipStream_t st;
     bf16_t *kc, *vc;   // [L][capR][H][capS][hd]: K and V, both key-major (fp32 elements when es == 4)
-    int es;            // bytes per cache element: 2 (bf16) or 4 (fp32: precision mode "split")
+    int es;            // bytes per cache element: 2 (bf16); precision mode "split": 3 (fp24) or 4 (fp32)
     int split_G;       // 0: bf16 decode step.  G = 8 / 16: split decode step — xg_dec / attn_dec / h_dec hold stacked groups of
                        // G bf16 hi rows + G lo rows (row r -> group r / G), qkv_dec is fp32
     int capR, capS;
@@ -1079,6 +1107,8 @@ void ensure_prefill_ws(vc_model* m, int B, int Scap) {
         m->a8_scale.ensure(Mrows * 4);
     }
     m->row_src.ensure(Mrows * 8);
+    m->p_ssq.ensure(Mrows * (size_t)m->npart * 4);   // folded RMSNorm of the prefill: sum-of-squares partials + row scales
+    m->p_rstd.ensure(Mrows * 4);
     const int Bp = (int)rup(B, 16);
     m->last_idx.ensure(Bp * 4);
     m->xl.ensure((size_t)Bp * D * 2, true);
@@ -1097,7 +1127,7 @@ void ensure_llm(vc_model* m, int B, int S_total) {
     REQUIRE(B <= VC_MAX_ROWS, VC_ERR_INVALID, "batch %d: at most %d sequences per GPU replica (shard larger batches over ranks)",
             B, VC_MAX_ROWS);
     REQUIRE(Scap <= c.max_positions, VC_ERR_INVALID, "sequence %d exceeds max_position_embeddings=%d", Scap, c.max_positions);
-    const int es = m->precision == 2 ? 4 : 2;   // split mode keeps fp32 keys / values
+    const int es = m->precision == 2 ? split_kv_es() : 2;   // split mode keeps fp24 (or fp32) keys / values
     if (B != m->capB || Scap > m->capS || es != m->kv_es) {
         const int newS = std::max(Scap, (m->capB == B && es == m->kv_es) ? m->capS : 0);
         const size_t per_layer = (size_t)B * H * newS * m->hd;
@@ -1161,7 +1191,7 @@ LoopView session_view(vc_model* m) {
 struct KvTarget {
     bf16_t *kc, *vc;
     int capR, capS, row0;
-    int es;  // bytes per element: 2 (bf16), 4 (fp32 — precision mode "split")
+    int es;  // bytes per element: 2 (bf16); precision mode "split": 3 (fp24) or 4 (fp32)
 };
 // layer l of a cache whose elements are `es` bytes (the pointer type is nominal for es == 4)
 bf16_t* kv_layer(bf16_t* base, int es, size_t elems) { return reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(base) + elems * es); }
@@ -1247,14 +1277,24 @@ void run_prefill_layers(vc_model* m, const KvTarget& kv, int B, int S, int l0 = 
     const int Sr = (int)rup(S, 64);
     m->vt_pre.ensure((size_t)B * H * m->hd * Sr * 2, true);
     const bool f8 = m->weight_format == 2;
+    // RMSNorm never runs as a pass behind the first layer (VC_PREFILL_FOLD=0 restores the passes): the GEMM that writes a
+    // residual row (o_proj, down) also writes xg = bf16(x * g) for the next GEMM and the row's sum-of-squares partials, a
+    // one-wave-per-row launch turns them into 1/rms, and the consuming GEMM (gate/up, the next layer's QKV) scales its
+    // accumulator by it — the decode steps' form.  The e4m3 format keeps its fused norm + quantiser.
+    static const int fold_on = getenv("VC_PREFILL_FOLD") ? atoi(getenv("VC_PREFILL_FOLD")) : 1;
+    const bool fold = fold_on && !f8;
+    float* rstd = m->p_rstd.as<float>();
+    NormFold prod{nullptr, m->xn.as<bf16_t>(), nullptr, m->p_ssq.as<float>(), D + XN_PAD, 0, m->npart};
+    const NormFold cons{rstd};
+    bool have_xg = false;   // xn holds bf16(x * g) of the CURRENT x for the norm about to be consumed, rstd its row scales
     for (int l = l0; l < nl; ++l) {
         const LlmLayer& L = m->llm[l];
         if (f8) {  // RMSNorm writes the e4m3 operand of the QKV GEMM directly
             launch_rmsnorm_q8(m->x.as<float>(), L.in_norm, m->a8.as<uint8_t>(), m->a8_scale.as<float>(), M, D, c.rms_eps, m->st);
             gemm_f8(m, nullptr, L.qkv_q, L.qkv_s, m->qkv.p, M, 3 * D, D, 3 * D, EPI_BF16);
         } else {
-            launch_rmsnorm(m->x.as<float>(), L.in_norm, m->xn.as<bf16_t>(), M, D, c.rms_eps, m->st, D + XN_PAD);
-            gemm(m, m->xn.as<bf16_t>(), L.qkv_w, nullptr, m->qkv.p, M, 3 * D, D, 3 * D, EPI_BF16, D + XN_PAD);
+            if (!have_xg) launch_rmsnorm(m->x.as<float>(), L.in_norm, m->xn.as<bf16_t>(), M, D, c.rms_eps, m->st, D + XN_PAD);
+            gemm(m, m->xn.as<bf16_t>(), L.qkv_w, nullptr, m->qkv.p, M, 3 * D, D, 3 * D, EPI_BF16, D + XN_PAD, have_xg ? &cons : nullptr);
         }
         // K and V rows go to the cache (key-major: what the decode steps stream); the V^T tiles of this layer's flash
         // attention live in a per-call scratch [B,H,hd,Sr]
@@ -1276,14 +1316,23 @@ void run_prefill_layers(vc_model* m, const KvTarget& kv, int B, int S, int l0 = 
             pa.kv_stride = kv.capS;
             emit_attentions(m, l, B, S, pa);
         }
-        if (f8) gemm_f8(m, m->attn.as<bf16_t>(), L.o_q, L.o_s, m->x.p, M, D, D, D, EPI_RESID_F32);
-        else gemm(m, m->attn.as<bf16_t>(), L.o_w, nullptr, m->x.p, M, D, D, D, EPI_RESID_F32);
-        if (f8) launch_rmsnorm_q8(m->x.as<float>(), L.post_norm, m->a8.as<uint8_t>(), m->a8_scale.as<float>(), M, D, c.rms_eps, m->st);
-        else launch_rmsnorm(m->x.as<float>(), L.post_norm, m->xn.as<bf16_t>(), M, D, c.rms_eps, m->st, D + XN_PAD);
         if (f8) {
+            gemm_f8(m, m->attn.as<bf16_t>(), L.o_q, L.o_s, m->x.p, M, D, D, D, EPI_RESID_F32);
+            launch_rmsnorm_q8(m->x.as<float>(), L.post_norm, m->a8.as<uint8_t>(), m->a8_scale.as<float>(), M, D, c.rms_eps, m->st);
             gemm_f8(m, nullptr, L.gu_q, L.gu_s, m->h.p, M, 2 * F, D, F, EPI_SWIGLU);
             gemm_f8(m, m->h.as<bf16_t>(), L.down_q, L.down_s, m->x.p, M, D, F, D, EPI_RESID_F32);
+        } else if (fold) {
+            prod.xg_w = L.post_norm;
+            gemm(m, m->attn.as<bf16_t>(), L.o_w, nullptr, m->x.p, M, D, D, D, EPI_RESID_F32, 0, &prod);
+            launch_rstd_from_partials(prod.ssq_out, m->npart, D / 16, rstd, M, D, c.rms_eps, m->st);
+            gemm(m, m->xn.as<bf16_t>(), L.gu_w, nullptr, m->h.p, M, 2 * F, D, F, EPI_SWIGLU, D + XN_PAD, &cons);
+            have_xg = l + 1 < nl;   // the last layer's output meets the final norm on its gathered rows only
+            prod.xg_w = have_xg ? m->llm[l + 1].in_norm : nullptr;
+            gemm(m, m->h.as<bf16_t>(), L.down_w, nullptr, m->x.p, M, D, F, D, EPI_RESID_F32, 0, have_xg ? &prod : nullptr);
+            if (have_xg) launch_rstd_from_partials(prod.ssq_out, m->npart, D / 16, rstd, M, D, c.rms_eps, m->st);
         } else {
+            gemm(m, m->attn.as<bf16_t>(), L.o_w, nullptr, m->x.p, M, D, D, D, EPI_RESID_F32);
+            launch_rmsnorm(m->x.as<float>(), L.post_norm, m->xn.as<bf16_t>(), M, D, c.rms_eps, m->st, D + XN_PAD);
             gemm(m, m->xn.as<bf16_t>(), L.gu_w, nullptr, m->h.p, M, 2 * F, D, F, EPI_SWIGLU, D + XN_PAD);
             gemm(m, m->h.as<bf16_t>(), L.down_w, nullptr, m->x.p, M, D, F, D, EPI_RESID_F32);
         }
@@ -1299,7 +1348,7 @@ void run_prefill_layers_split(vc_model* m, const KvTarget& kv, int B, int S, int
     const int nl = l1 >= 0 ? l1 : (m->layer_limit > 0 ? std::min(m->layer_limit, c.layers) : c.layers);
     const int Sr = (int)rup(S, 64);
     const int ldx = split_ld(D), ldh = split_ld(F);
-    REQUIRE(kv.es == 4, VC_ERR_STATE, "split mode needs an fp32 KV cache");
+    REQUIRE(kv.es == 3 || kv.es == 4, VC_ERR_STATE, "split mode needs an fp24 / fp32 KV cache");
     const size_t qplane = (size_t)B * H * S * m->hd, kplane = (size_t)B * H * Sr * m->hd;
     m->xn.ensure((size_t)M * ldx * 2);
     m->s_qkv.ensure((size_t)M * 3 * D * 4);
@@ -1308,13 +1357,19 @@ void run_prefill_layers_split(vc_model* m, const KvTarget& kv, int B, int S, int
     m->attn.ensure((size_t)M * ldx * 2);
     m->h.ensure((size_t)M * ldh * 2);
     bf16_t *qh = m->q.as<bf16_t>(), *kh = m->vt_pre.as<bf16_t>(), *vh = kh + 2 * kplane;
+    // folded RMSNorm as in run_prefill_layers: the producer writes both planes of xg ([hi | lo], the lo plane D columns right)
+    static const int fold_on = getenv("VC_PREFILL_FOLD") ? atoi(getenv("VC_PREFILL_FOLD")) : 1;
+    float* rstd = m->p_rstd.as<float>();
+    NormFold prod{nullptr, m->xn.as<bf16_t>(), nullptr, m->p_ssq.as<float>(), ldx, D, m->npart};
+    const NormFold cons{rstd};
+    bool have_xg = false;
     for (int l = l0; l < nl; ++l) {
         const LlmLayer& L = m->llm[l];
-        launch_rmsnorm_split(m->x.as<float>(), nullptr, L.in_norm, m->xn.as<bf16_t>(), M, D, c.rms_eps, ldx, D, m->st);
-        gemm_split(m, m->xn.as<bf16_t>(), L.qkv_w, nullptr, m->s_qkv.p, M, 3 * D, D, 3 * D, EPI_F32, ldx);
+        if (!have_xg) launch_rmsnorm_split(m->x.as<float>(), nullptr, L.in_norm, m->xn.as<bf16_t>(), M, D, c.rms_eps, ldx, D, m->st);
+        gemm_split(m, m->xn.as<bf16_t>(), L.qkv_w, nullptr, m->s_qkv.p, M, 3 * D, D, 3 * D, EPI_F32, ldx, 0, have_xg ? &cons : nullptr);
         QkvSplit32Args qa{m->s_qkv.as<float>(), qh, qh + qplane, kh, kh + kplane, vh, vh + kplane,
                           reinterpret_cast<float*>(kcache(m, kv, l)), reinterpret_cast<float*>(vcache(m, kv, l)),
-                          B, S, H, m->hd, S, Sr, Sr, kv.capS, m->rope_cos, m->rope_sin};
+                          B, S, H, m->hd, S, Sr, Sr, kv.capS, m->rope_cos, m->rope_sin, kv.es == 3};
         launch_qkv_split32(qa, m->st);
         AttnArgs aa{qh, kh, vh, m->attn.as<bf16_t>(), B, H, S, m->hd, S, Sr, 1, 1.0f / sqrtf((float)m->hd), Sr,
                     qh + qplane, kh + kplane, vh + kplane, ldx, D};
@@ -1333,10 +1388,21 @@ void run_prefill_layers_split(vc_model* m, const KvTarget& kv, int B, int S, int
             pa.kv_stride = Sr;
             emit_attentions(m, l, B, S, pa);
         }
-        gemm_split(m, m->attn.as<bf16_t>(), L.o_w, nullptr, m->x.p, M, D, D, D, EPI_RESID_F32, ldx);
-        launch_rmsnorm_split(m->x.as<float>(), nullptr, L.post_norm, m->xn.as<bf16_t>(), M, D, c.rms_eps, ldx, D, m->st);
-        gemm_split(m, m->xn.as<bf16_t>(), L.gu_w, nullptr, m->h.p, M, 2 * F, D, ldh, EPI_SWIGLU, ldx, F);
-        gemm_split(m, m->h.as<bf16_t>(), L.down_w, nullptr, m->x.p, M, D, F, D, EPI_RESID_F32, ldh);
+        if (fold_on) {
+            prod.xg_w = L.post_norm;
+            gemm_split(m, m->attn.as<bf16_t>(), L.o_w, nullptr, m->x.p, M, D, D, D, EPI_RESID_F32, ldx, 0, &prod);
+            launch_rstd_from_partials(prod.ssq_out, m->npart, D / 16, rstd, M, D, c.rms_eps, m->st);
+            gemm_split(m, m->xn.as<bf16_t>(), L.gu_w, nullptr, m->h.p, M, 2 * F, D, ldh, EPI_SWIGLU, ldx, F, &cons);
+            have_xg = l + 1 < nl;
+            prod.xg_w = have_xg ? m->llm[l + 1].in_norm : nullptr;
+            gemm_split(m, m->h.as<bf16_t>(), L.down_w, nullptr, m->x.p, M, D, F, D, EPI_RESID_F32, ldh, 0, have_xg ? &prod : nullptr);
+            if (have_xg) launch_rstd_from_partials(prod.ssq_out, m->npart, D / 16, rstd, M, D, c.rms_eps, m->st);
+        } else {
+            gemm_split(m, m->attn.as<bf16_t>(), L.o_w, nullptr, m->x.p, M, D, D, D, EPI_RESID_F32, ldx);
+            launch_rmsnorm_split(m->x.as<float>(), nullptr, L.post_norm, m->xn.as<bf16_t>(), M, D, c.rms_eps, ldx, D, m->st);
+            gemm_split(m, m->xn.as<bf16_t>(), L.gu_w, nullptr, m->h.p, M, 2 * F, D, ldh, EPI_SWIGLU, ldx, F);
+            gemm_split(m, m->h.as<bf16_t>(), L.down_w, nullptr, m->x.p, M, D, F, D, EPI_RESID_F32, ldh);
+        }
         emit_hidden(m, l + 1, B, S);
     }
 }
@@ -1370,7 +1436,7 @@ void enqueue_decode_step(vc_model* m, const LoopView& v, int nrows) {
     decode_linears(m, v, nrows, [&](int l) {
         AttnDecodeFusedArgs da{v.qkv_dec, kcache(v, m, l), vcache(v, m, l), v.attn_dec, nrows, m->c.heads, m->hd, v.capS,
                                v.rows + RS_POS, m->rope_cos, m->rope_sin, 1.0f / sqrtf((float)m->hd), RS_STRIDE,
-                               v.rows + RS_ACTIVE, v.split_G ? 1 : 0, v.split_G, v.kmask, v.kmask_stride};
+                               v.rows + RS_ACTIVE, v.split_G ? (v.es == 3 ? 2 : 1) : 0, v.split_G, v.kmask, v.kmask_stride};
         launch_attention_decode_fused(da, v.st);
     });
     launch_select_embed(select_args(m, v, v.logits, nrows, 3), v.st);                                        // K19/K20+K10
@@ -1388,7 +1454,7 @@ void enqueue_decode_step_diag(vc_model* m, const LoopView& v, int nrows, int pos
         [&](int l) {
             AttnDecodeFusedArgs da{v.qkv_dec, kcache(v, m, l), vcache(v, m, l), v.attn_dec, nrows, c.heads, m->hd, v.capS,
                                    v.rows + RS_POS, m->rope_cos, m->rope_sin, 1.0f / sqrtf((float)m->hd), RS_STRIDE,
-                                   v.rows + RS_ACTIVE, v.split_G ? 1 : 0, v.split_G, v.kmask, v.kmask_stride};
+                                   v.rows + RS_ACTIVE, v.split_G ? (v.es == 3 ? 2 : 1) : 0, v.split_G, v.kmask, v.kmask_stride};
             launch_attention_decode_fused(da, v.st);
             if (m->attn_out) {
                 m->attn_q.ensure((size_t)nrows * c.hidden * 4);
@@ -1396,7 +1462,8 @@ void enqueue_decode_step_diag(vc_model* m, const LoopView& v, int nrows, int pos
                                      v.split_G == 0, v.st);
                 AttnProbsArgs pa{};
                 pa.q32 = m->attn_q.as<float>();
-                if (v.split_G) pa.k32 = reinterpret_cast<const float*>(kcache(v, m, l));
+                if (v.split_G && v.es == 3) pa.k24 = kcache(v, m, l);
+                else if (v.split_G) pa.k32 = reinterpret_cast<const float*>(kcache(v, m, l));
                 else pa.k_hi = kcache(v, m, l);
                 pa.q_stride = 1;
                 pa.kv_stride = v.capS;
@@ -1924,7 +1991,7 @@ VC_API void vc_model_destroy(vc_model* m) {
                    &m->out_ids, &m->dsum, &m->ssq, &m->sk_scratch, &m->sk_counters, &m->gemm_ws, &m->s_cols, &m->s_patches, &m->s_vx, &m->s_vxn, &m->s_vqkv,
                    &m->s_vq, &m->s_vk, &m->s_vv, &m->s_vattn, &m->s_vh, &m->s_sel, &m->s_mid, &m->s_feats, &m->s_xn, &m->s_qkv,
                    &m->s_q, &m->s_attn, &m->s_h, &m->s_kc, &m->s_vc, &m->s_xl, &m->pp_src, &m->pp_sq, &m->pp_tmp, &m->pp_out,
-                   &m->pp_tab, &m->pp_f32, &m->kmask, &m->hidden_tmp, &m->attn_q})
+                   &m->pp_tab, &m->pp_f32, &m->kmask, &m->hidden_tmp, &m->attn_q, &m->a8, &m->a8_scale, &m->p_ssq, &m->p_rstd})
         b->release();
     for (auto& e : m->ev)
         if (e) (void)hipEventDestroy(e);
@@ -2487,7 +2554,7 @@ LoopView pool_view(vc_pool* p) {
     v.st = p->st;
     v.kc = p->kc.as<bf16_t>();
     v.vc = p->vc.as<bf16_t>();
-    v.es = p->split ? 4 : 2;
+    v.es = p->split ? split_kv_es() : 2;
     // one layout whatever rows a step spans: a row keeps its slot between steps.  The workgroup-shared GEMV takes all 32 rows
     // (hi + lo planes) in ONE weight pass; the per-wave-ring form two passes of 16
     v.split_G = p->split ? p->split_G : 0;
@@ -2668,7 +2735,7 @@ vc_pool* pool_for(vc_model* m, int need_S, int need_out) {
         p->split = want_split;
         p->split_G = (gemv_wg_enabled() && root->weight_format == 0) ? 32 : 16;
         const int D = c.hidden, F = c.ffn, H = c.heads, R = p->R;
-        const size_t es = want_split ? 4 : 2, two = want_split ? 2 : 1;
+        const size_t es = want_split ? (size_t)split_kv_es() : 2, two = want_split ? 2 : 1;
         p->capS = std::min((int)rup(std::max(need_S, 2048), 64), c.max_positions / 64 * 64);
         p->out_stride = std::max(need_out, p->capS);
         REQUIRE(p->capS >= need_S, VC_ERR_INVALID, "sequence %d exceeds max_position_embeddings=%d", need_S, c.max_positions);
@@ -2680,7 +2747,7 @@ vc_pool* pool_for(vc_model* m, int need_S, int need_out) {
         p->rows.ensure((size_t)R * RS_STRIDE * 4, true);
         p->x_dec.ensure((size_t)R * D * 4, true);
         p->xg_dec.ensure(two * R * D * 2, true);
-        p->qkv_dec.ensure((size_t)R * 3 * D * es, true);
+        p->qkv_dec.ensure((size_t)R * 3 * D * (want_split ? 4 : 2), true);   // the split step's projection rows are fp32
         p->attn_dec.ensure(two * R * D * 2, true);
         p->h_dec.ensure(two * R * F * 2, true);
         p->logits.ensure((size_t)R * c.vocab * 4, true);
@@ -2788,7 +2855,7 @@ void generate_on_pool(vc_model* m, const int64_t* ids, int B, int T, const float
         REQUIRE(S + max_new <= p->capS, VC_ERR_INVALID,
                 "prompt %d + max_new %d exceeds the context: max_position_embeddings=%d (KV capacity %d)", S, max_new,
                 m->c.max_positions, p->capS);
-        finish_prefill(m, KvTarget{p->kc.as<bf16_t>(), p->vc.as<bf16_t>(), p->R, p->capS, rq.row0, p->split ? 4 : 2}, nullptr);
+        finish_prefill(m, KvTarget{p->kc.as<bf16_t>(), p->vc.as<bf16_t>(), p->R, p->capS, rq.row0, p->split ? split_kv_es() : 2}, nullptr);
         if (m->ev[2]) HIPCHK(hipEventRecord(m->ev[2], m->st));
         HIPCHK(hipEventRecord(rq.prefill_done, m->st));
         DBG_HIP("finish_prefill");

@@ -57,8 +57,11 @@ VC_DEV u32x2 pack_bf4(f32x4 v) { return u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2
 VC_DEV f32x4 bf4_residual(f32x4 v, u32x2 hi) {
     return f32x4{v[0] - bf2f_lo(hi[0]), v[1] - bf2f_hi(hi[0]), v[2] - bf2f_lo(hi[1]), v[3] - bf2f_hi(hi[1])};
 }
-template <int EPI>
+// FIX: the caller is the split-K fix-up kernel (a wave = one output row, 4 adjacent lanes = one 16-column tile) instead of an
+// MFMA accumulator layout (lanes l, l ^ 16, l ^ 32, l ^ 48 = the 16 columns of one token)
+template <int EPI, bool FIX = false>
 VC_DEV void store_out(const GemmArgs& p, int m, int n, f32x4 v) {
+    if (p.row_scale) v = v * p.row_scale[m];   // folded RMSNorm, consumer side
     if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_QGELU || EPI == EPI_BF16_GELU) {
         if constexpr (EPI == EPI_BF16_QGELU) {
 #pragma unroll
@@ -76,7 +79,20 @@ VC_DEV void store_out(const GemmArgs& p, int m, int n, f32x4 v) {
         st16f(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n, v);
     } else if constexpr (EPI == EPI_RESID_F32) {
         float* o = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n;
-        st16f(o, ld16f(o) + v);
+        v = ld16f(o) + v;
+        st16f(o, v);
+        if (p.xg_out) {   // folded RMSNorm, producer side: the next GEMM's operand and the row's sum-of-squares partial
+            const f32x4 t = v * ld16f(p.xg_w + n);
+            const u32x2 hi = pack_bf4(t);
+            bf16_t* d = p.xg_out + (size_t)m * p.ld_xg + n;
+            st8(d, hi);
+            if (p.xg_lo) st8(d + p.xg_lo, pack_bf4(bf4_residual(t, hi)));
+            float sq = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            // the 16 columns of the tile sit in 4 lanes that share this lane's m (so they are all here: N % 16 == 0)
+            sq += shfl_xor(sq, FIX ? 1 : 16);
+            sq += shfl_xor(sq, FIX ? 2 : 32);
+            if (FIX ? (lane_id() & 3) == 0 : lane_id() < 16) p.ssq_out[(size_t)m * p.npart + (n >> 4)] = sq;
+        }
     } else {  // EPI_SWIGLU: (g0,u0,g1,u1) -> 2 outputs
         const float h0 = silu(v[0]) * v[1], h1 = silu(v[2]) * v[3];
         const uint32_t o = pack_bf2(h0, h1);
@@ -491,7 +507,21 @@ __global__ __launch_bounds__(256) void gemm_splitk_fixup_kernel(GemmArgs p) {
     for (int k = 1; k < p.sk_ks; ++k) v = v + ld16f(base + (size_t)k * 65536);
     if (p.f8) v = v * (ld16f(p.w_scale + n) * p.a_scale[m]);
     if (p.bias) v = v + ld16f(p.bias + n);
-    store_out<EPI>(p, m, n, v);
+    store_out<EPI, true>(p, m, n, v);
+}
+
+// rstd of every row from the sum-of-squares partials a RESID epilogue published (one wave per row, fixed order)
+__global__ __launch_bounds__(256) void rstd_from_partials_kernel(const float* ssq, int npart, int nparts, float* rstd, int rows, int D,
+                                                                 float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int i = lane; i < nparts; i += 64) s += ssq[(size_t)row * npart + i];
+    s = wave_sum(s);
+    if (lane == 0) rstd[row] = rsqrtf(s / (float)D + eps);
+}
+void launch_rstd_from_partials(const float* ssq, int npart, int nparts, float* rstd, int rows, int D, float eps, hipStream_t s) {
+    VC_LAUNCH(rstd_from_partials_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, ssq, npart, nparts, rstd, rows, D, eps);
 }
 
 template <class K>
@@ -545,6 +575,8 @@ static void launch_gemm_f8(const GemmArgs& a, int epilogue, hipStream_t s) {
 }
 
 void launch_gemm(const GemmArgs& a, int epilogue, hipStream_t s) {
+    if (a.xg_out && (epilogue != EPI_RESID_F32 || a.N % 16 != 0 || !a.xg_w || !a.ssq_out || a.npart < a.N / 16))
+        throw std::runtime_error("gemm: the folded-RMSNorm producer needs EPI_RESID_F32, N % 16 == 0, xg_w, ssq_out, npart >= N / 16");
     if (a.f8) return launch_gemm_f8(a, epilogue, s);
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const dim3 grid(tiles), block(256);

@@ -223,6 +223,14 @@ VCK_EXPORT void vck_qkv_split32(const float* qkv, uint16_t* q_hi, uint16_t* q_lo
                      rope_cos, rope_sin};
     launch_qkv_split32(a, S(stream));
 }
+/* the same with fp24 cache rows (k24 / v24: [B,H,kv_stride] x 3*hd bytes: hd x u16 | hd x u8) */
+VCK_EXPORT void vck_qkv_split24(const float* qkv, uint16_t* q_hi, uint16_t* q_lo, uint16_t* k_hi, uint16_t* k_lo, uint16_t* vt_hi,
+                                uint16_t* vt_lo, void* k24, void* v24, int B, int T, int H, int hd, int q_stride, int ks_stride,
+                                int vt_stride, int kv_stride, const float* rope_cos, const float* rope_sin, void* stream) {
+    QkvSplit32Args a{qkv, q_hi, q_lo, k_hi, k_lo, vt_hi, vt_lo, reinterpret_cast<float*>(k24), reinterpret_cast<float*>(v24), B, T, H, hd,
+                     q_stride, ks_stride, vt_stride, kv_stride, rope_cos, rope_sin, 1};
+    launch_qkv_split32(a, S(stream));
+}
 VCK_EXPORT void vck_attention_split(const uint16_t* q_hi, const uint16_t* q_lo, const uint16_t* k_hi, const uint16_t* k_lo,
                                     const uint16_t* vt_hi, const uint16_t* vt_lo, uint16_t* out, int B, int H, int T, int hd,
                                     int q_stride, int kv_stride, int causal, float scale, int ldo, int lo_off, void* stream) {
@@ -234,6 +242,14 @@ VCK_EXPORT void vck_attention_decode_kv32(const float* qkv, float* k, float* v, 
                                           const float* rope_sin, float scale, int G, void* stream) {
     AttnDecodeFusedArgs a{reinterpret_cast<const uint16_t*>(qkv), reinterpret_cast<uint16_t*>(k), reinterpret_cast<uint16_t*>(v), out,
                           B, H, hd, kv_stride, pos_rows, rope_cos, rope_sin, scale, pos_stride, active_rows, 1, G};
+    launch_attention_decode_fused(a, S(stream));
+}
+/* the same over fp24 caches */
+VCK_EXPORT void vck_attention_decode_kv24(const float* qkv, void* k, void* v, uint16_t* out, int B, int H, int hd, int kv_stride,
+                                          const int* pos_rows, int pos_stride, const int* active_rows, const float* rope_cos,
+                                          const float* rope_sin, float scale, int G, void* stream) {
+    AttnDecodeFusedArgs a{reinterpret_cast<const uint16_t*>(qkv), reinterpret_cast<uint16_t*>(k), reinterpret_cast<uint16_t*>(v), out,
+                          B, H, hd, kv_stride, pos_rows, rope_cos, rope_sin, scale, pos_stride, active_rows, 2, G};
     launch_attention_decode_fused(a, S(stream));
 }
 

@@ -47,8 +47,21 @@ struct GemmArgs {
     // hi at column n and lo = bf16(v - hi) at column split_out + n (EPI_SWIGLU: at n / 2)
     int kwrap;
     int split_out;
+    // RMSNorm folded across two GEMMs of a prefill, as in the decode steps (rmsnorm(x) . W^T = rstd * ((x * g) . W^T)):
+    //  consumer: row_scale[m] (= rstd of row m; launch_rstd_from_partials) multiplies the accumulator before the epilogue; A is
+    //            then the producer's xg rows;
+    //  producer (EPI_RESID_F32 only, N % 16 == 0): next to the updated fp32 residual rows it writes the NEXT GEMM's operand
+    //            xg_out[m][n] = bf16(x * xg_w[n]) (row stride ld_xg; xg_lo > 0: the lo plane bf16(t - hi) xg_lo columns to the
+    //            right — precision mode "split") and ssq_out[m * npart + n / 16] = sum of the 16 new residual values squared.
+    const float* row_scale;
+    bf16_t* xg_out;
+    const float* xg_w;
+    float* ssq_out;
+    int ld_xg, xg_lo, npart;
 };
 void launch_gemm(const GemmArgs& a, int epilogue, hipStream_t s);
+// rstd[m] = rsqrt(sum_{p < nparts} ssq[m * npart + p] / D + eps): the row scales of the consumer of a folded RMSNorm
+void launch_rstd_from_partials(const float* ssq, int npart, int nparts, float* rstd, int rows, int D, float eps, hipStream_t s);
 
 // Skinny GEMM for decode (M <= VC_GEMV_MAX_M token rows per weight pass): weights pre-packed in MFMA-fragment order, streamed once.  K12/K16/K17/K18.
 // packed W layout: [N/16][K/32][64 lanes][8 bf16]; lane l of tile (nt,kt) holds W[nt*16+(l&15)][kt*32+(l>>4)*8 + e].
@@ -195,6 +208,7 @@ struct QkvSplit32Args {
     int B, T, H, hd, q_stride, ks_stride, vt_stride, kv_stride;
     const float* rope_cos;   // nullptr disables RoPE (ViT)
     const float* rope_sin;
+    int kv24;                // != 0: k32 / v32 point at fp24 caches (3 * hd bytes per row: hd x u16 hi plane | hd x u8 lo plane)
 };
 void launch_qkv_split32(const QkvSplit32Args& a, hipStream_t s);
 
@@ -212,8 +226,9 @@ struct AttnDecodeFusedArgs {
     float scale;
     int pos_stride;         // 0: one position for every row
     const int* active_dev;  // nullptr, or row b is skipped when active_dev[b * pos_stride] == 0
-    // precision mode "split" (kv32 != 0): qkv is fp32 [B, 3*H*hd], k / v are fp32 caches, and the output is written as
-    // bf16 hi / lo rows in stacked groups of out_G rows: row b -> hi at row (b / G) * 2G + b % G, lo G rows further
+    // precision mode "split" (kv32 != 0): qkv is fp32 [B, 3*H*hd], k / v are fp32 caches (kv32 == 1) or fp24 caches (kv32 == 2:
+    // rows of hd x u16 | hd x u8, vc_device.h), and the output is written as bf16 hi / lo rows in stacked groups of out_G rows:
+    // row b -> hi at row (b / G) * 2G + b % G, lo G rows further
     int kv32;
     int out_G;
     // keys hidden by the row's attention_mask: key_mask[b * mask_stride + key] == 0 (nullptr = none)
@@ -335,6 +350,7 @@ struct AttnProbsArgs {
     const float* k32;      // [B,H,kv_stride,hd] or nullptr
     const bf16_t* k_hi;
     const bf16_t* k_lo;
+    const void* k24;       // fp24 cache rows [B,H,kv_stride] x (hd x u16 | hd x u8), used when k32 == nullptr and k_hi == nullptr
     float* out;            // [B,H,T,Tk]
     int B, H, T, hd, q_stride, kv_stride;   // T queries; keys <= 4096
     float scale;

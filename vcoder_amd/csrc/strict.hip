@@ -176,6 +176,11 @@ __global__ __launch_bounds__(64) void attn_probs_kernel(AttnProbsArgs p) {
         float s = 0.f;
         if (p.k32) {
             for (int d = 0; d < p.hd; ++d) s = fmaf(qs[d], p.k32[ko + d], s);
+        } else if (p.k_hi == nullptr && p.k24 != nullptr) {
+            const char* row = reinterpret_cast<const char*>(p.k24) + (bh * p.kv_stride + key) * (size_t)(3 * p.hd);
+            const uint16_t* hi = reinterpret_cast<const uint16_t*>(row);
+            const uint8_t* lo = reinterpret_cast<const uint8_t*>(row + 2 * p.hd);
+            for (int d = 0; d < p.hd; ++d) s = fmaf(qs[d], f24_to_f32(hi[d], lo[d]), s);
         } else {
             for (int d = 0; d < p.hd; ++d) s = fmaf(qs[d], bf2f(p.k_hi[ko + d]) + (p.k_lo ? bf2f(p.k_lo[ko + d]) : 0.f), s);
         }

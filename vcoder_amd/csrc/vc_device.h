@@ -70,6 +70,35 @@ VC_DEV uint32_t pack_bf2(float lo, float hi) {
 }
 #endif
 
+// ---- fp24: the top 24 bits of an fp32 (sign, 8 exponent, 15 mantissa bits; round to nearest even) -----------------------------
+// The KV-cache element of precision mode "split": |x - fp24(x)| <= 2^-17 |x| (bf16: 2^-9; the bf16 hi + lo pair the MFMA operands
+// carry: ~2^-18) at 3 bytes instead of fp32's 4.  A cache row of hd elements is stored as two planes — hd x u16 (bits 31..16: what a
+// truncated bf16 would hold) followed by hd x u8 (bits 15..8) — so both planes are read with aligned vector loads.
+VC_DEV uint32_t f32_to_f24(float f) {   // -> the 24-bit code in bits 23..0
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    if ((u & 0x7F800000u) != 0x7F800000u) u += 0x7Fu + ((u >> 8) & 1u);   // RNE on bit 8 (inf / nan pass through)
+    return u >> 8;
+}
+VC_DEV float f24_to_f32(uint32_t hi16, uint32_t lo8) { return __builtin_bit_cast(float, (hi16 << 16) | (lo8 << 8)); }
+// 8 values -> their hi plane (8 x u16) and lo plane (8 x u8)
+VC_DEV void pack_f24x8(const float* v, u32x4& hi, u32x2& lo) {
+    uint32_t c[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) c[e] = f32_to_f24(v[e]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) hi[i] = (c[2 * i] >> 8) | ((c[2 * i + 1] >> 8) << 16);
+    lo[0] = (c[0] & 0xFFu) | ((c[1] & 0xFFu) << 8) | ((c[2] & 0xFFu) << 16) | ((c[3] & 0xFFu) << 24);
+    lo[1] = (c[4] & 0xFFu) | ((c[5] & 0xFFu) << 8) | ((c[6] & 0xFFu) << 16) | ((c[7] & 0xFFu) << 24);
+}
+// element e (0..7) of a lane's 8-element group from its hi words (4 x 2 u16) and lo bytes (2 x 4 u8)
+VC_DEV float f24_elem(const u32x4& hi, const u32x2& lo, int e) {
+    const uint32_t w = hi[e >> 1], l = lo[e >> 2];
+    const uint32_t h = (e & 1) ? (w & 0xFFFF0000u) : (w << 16);
+    const int sh = 8 * (e & 3);
+    const uint32_t b = sh >= 8 ? ((l >> (sh - 8)) & 0xFF00u) : ((l << 8) & 0xFF00u);
+    return __builtin_bit_cast(float, h | b);
+}
+
 // ---- fp8 (OCP e4m3fn: 1-4-3, bias 7, max 448, no inf) ----------------------------------------
 // Encode is software on both builds (load-time only; round-to-nearest-even, saturating) so the device, the emulator
 // and vcoder_amd/quant.py produce identical bytes.  Every e4m3 value is exactly representable in bf16, so the
@@ -232,8 +261,10 @@ VC_DEV void st16f(void* p, f32x4 v) { VC_LDS_W(p); *reinterpret_cast<f32x4*>(p) 
 // non-temporal 16-byte load for streams that are read once per launch (decode weights, KV cache rows)
 #ifdef VC_EMU
 VC_DEV u32x4 ld16_stream(const void* p) { return ld16(p); }
+VC_DEV u32x2 ld8_stream(const void* p) { return ld8(p); }
 #else
 VC_DEV u32x4 ld16_stream(const void* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); }
+VC_DEV u32x2 ld8_stream(const void* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p)); }
 #endif
 
 // ---- LDS-DMA: 16 bytes per lane, global -> LDS without passing through VGPRs (global_load_lds_dwordx4).
