@@ -240,3 +240,26 @@ def test_empty_inputs_are_refused(emu_lib):
     with _pt.raises(ValueError):
         eng.prefill(ids[:, :0], imgs, segs, deps)
     assert eng.generate_greedy(ids, imgs, segs, deps, max_new_tokens=1).shape == (ids.shape[0], 1)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "split"])
+def test_prefill_with_folded_rmsnorm(emu_lib, mode, monkeypatch):
+    """VC_PREFILL_FOLD=1 (opt-in): the residual-writing GEMMs of a prefill hand xg = bf16(x * g) and
+    sum-of-squares partials to the next GEMM, which scales its accumulator by 1/rms — no RMSNorm pass behind layer 0.  The logits
+    stay within the mode's tolerance of the reference fixture (split: 1e-3 absolute, ids exact) and of the unfolded prefill."""
+    import numpy as np
+
+    g, cfg, ids, imgs, segs, deps = e2e_cases.fixture_inputs("ds_img_depth_seg")
+    eng = e2e_cases.engine_for("vcoder_ds", emu_lib)
+    if mode != "bf16":
+        eng.set_precision(mode)
+    base, base_all, _ = eng.prefill(ids, imgs, segs, deps, all_logits=True)
+    monkeypatch.setenv("VC_PREFILL_FOLD", "1")
+    fold, fold_all, _ = eng.prefill(ids, imgs, segs, deps, all_logits=True)
+    monkeypatch.delenv("VC_PREFILL_FOLD")
+    assert not np.array_equal(fold_all, base_all)   # the other rounding order really ran
+    ref = g["prefill_logits"]
+    tol = 1e-3 if mode == "split" else e2e_cases.TOL_VS_FP32_REF * float(np.abs(ref).max())
+    assert np.abs(fold_all - ref).max() < tol and np.abs(base_all - ref).max() < tol
+    assert np.array_equal(fold.argmax(-1), g["greedy_ids"][:, 0])
+    eng.set_precision("bf16")   # (engine_for caches its engines)

@@ -449,6 +449,10 @@ void emit_attentions(vc_model* m, int l, int B, int S, AttnProbsArgs a, int Tk =
 
 // ------------------------------------------------------------------------------------------------
 // GEMM helpers
+inline bool prefill_fold_on() {
+    const char* e = getenv("VC_PREFILL_FOLD");
+    return e && atoi(e) != 0;
+}
 // folded RMSNorm of a prefill (GemmArgs::row_scale / xg_out): what a GEMM consumes and what it hands to the next one
 struct NormFold {
     const float* row_scale = nullptr;   // consumer: 1/rms per row
@@ -1277,12 +1281,13 @@ void run_prefill_layers(vc_model* m, const KvTarget& kv, int B, int S, int l0 = 
     const int Sr = (int)rup(S, 64);
     m->vt_pre.ensure((size_t)B * H * m->hd * Sr * 2, true);
     const bool f8 = m->weight_format == 2;
-    // RMSNorm never runs as a pass behind the first layer (VC_PREFILL_FOLD=0 restores the passes): the GEMM that writes a
-    // residual row (o_proj, down) also writes xg = bf16(x * g) for the next GEMM and the row's sum-of-squares partials, a
-    // one-wave-per-row launch turns them into 1/rms, and the consuming GEMM (gate/up, the next layer's QKV) scales its
-    // accumulator by it — the decode steps' form.  The e4m3 format keeps its fused norm + quantiser.
-    static const int fold_on = getenv("VC_PREFILL_FOLD") ? atoi(getenv("VC_PREFILL_FOLD")) : 1;
-    const bool fold = fold_on && !f8;
+    // VC_PREFILL_FOLD=1 (opt-in; read per call so that tests can switch it): RMSNorm never runs as a pass behind the first
+    // layer — the GEMM that writes a residual row (o_proj, down) also writes xg = bf16(x * g) for the next GEMM and the row's
+    // sum-of-squares partials, a one-wave-per-row launch turns them into 1/rms, and the consuming GEMM (gate/up, the next
+    // layer's QKV) scales its accumulator by it: the decode steps' form.  Measured on MI355X (7b, B = 8,
+    // profiles/r04_d_*): 112.9 ms per prefill against 111.6 with the 63 passes — the residual GEMMs' epilogue (8-byte bf16
+    // stores in 32-byte segments, partials) costs more than the 45-us passes it removes — so the passes stay the default.
+    const bool fold = prefill_fold_on() && !f8;
     float* rstd = m->p_rstd.as<float>();
     NormFold prod{nullptr, m->xn.as<bf16_t>(), nullptr, m->p_ssq.as<float>(), D + XN_PAD, 0, m->npart};
     const NormFold cons{rstd};
@@ -1357,8 +1362,8 @@ void run_prefill_layers_split(vc_model* m, const KvTarget& kv, int B, int S, int
     m->attn.ensure((size_t)M * ldx * 2);
     m->h.ensure((size_t)M * ldh * 2);
     bf16_t *qh = m->q.as<bf16_t>(), *kh = m->vt_pre.as<bf16_t>(), *vh = kh + 2 * kplane;
-    // folded RMSNorm as in run_prefill_layers: the producer writes both planes of xg ([hi | lo], the lo plane D columns right)
-    static const int fold_on = getenv("VC_PREFILL_FOLD") ? atoi(getenv("VC_PREFILL_FOLD")) : 1;
+    // folded RMSNorm as in run_prefill_layers (opt-in): the producer writes both planes of xg ([hi | lo], the lo plane D columns right)
+    const bool fold_on = prefill_fold_on();
     float* rstd = m->p_rstd.as<float>();
     NormFold prod{nullptr, m->xn.as<bf16_t>(), nullptr, m->p_ssq.as<float>(), ldx, D, m->npart};
     const NormFold cons{rstd};

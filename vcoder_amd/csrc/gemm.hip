@@ -59,9 +59,10 @@ VC_DEV f32x4 bf4_residual(f32x4 v, u32x2 hi) {
 }
 // FIX: the caller is the split-K fix-up kernel (a wave = one output row, 4 adjacent lanes = one 16-column tile) instead of an
 // MFMA accumulator layout (lanes l, l ^ 16, l ^ 32, l ^ 48 = the 16 columns of one token)
+// (the consumer side of the folded RMSNorm — GemmArgs::row_scale — is applied by the callers, which hold a row's scale in a
+// register across the columns they store)
 template <int EPI, bool FIX = false>
 VC_DEV void store_out(const GemmArgs& p, int m, int n, f32x4 v) {
-    if (p.row_scale) v = v * p.row_scale[m];   // folded RMSNorm, consumer side
     if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_QGELU || EPI == EPI_BF16_GELU) {
         if constexpr (EPI == EPI_BF16_QGELU) {
 #pragma unroll
@@ -89,8 +90,12 @@ VC_DEV void store_out(const GemmArgs& p, int m, int n, f32x4 v) {
             if (p.xg_lo) st8(d + p.xg_lo, pack_bf4(bf4_residual(t, hi)));
             float sq = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
             // the 16 columns of the tile sit in 4 lanes that share this lane's m (so they are all here: N % 16 == 0)
-            sq += shfl_xor(sq, FIX ? 1 : 16);
-            sq += shfl_xor(sq, FIX ? 2 : 32);
+            if constexpr (FIX) {
+                sq += shfl_xor(sq, 1);
+                sq += shfl_xor(sq, 2);
+            } else {
+                sq = rows_sum(sq);
+            }
             if (FIX ? (lane_id() & 3) == 0 : lane_id() < 16) p.ssq_out[(size_t)m * p.npart + (n >> 4)] = sq;
         }
     } else {  // EPI_SWIGLU: (g0,u0,g1,u1) -> 2 outputs
@@ -190,7 +195,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
         for (int j = 0; j < 4; ++j) {
             const int m = m0 + wm * 64 + j * 16 + (lane & 15);
             if (m >= p.M) continue;
-            store_out<EPI>(p, m, n, acc[i][j] + bv);
+            store_out<EPI>(p, m, n, (p.row_scale ? acc[i][j] * p.row_scale[m] : acc[i][j]) + bv);
         }
     }
 }
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_bf16_dma_kernel(GemmArgs p)
         for (int j = 0; j < FJ; ++j) {
             const int m = m0 + wm * (FJ * 16) + j * 16 + (lane & 15);
             if (m >= p.M) continue;
-            store_out<EPI>(p, m, n, acc[i][j] + bv);
+            store_out<EPI>(p, m, n, (p.row_scale ? acc[i][j] * p.row_scale[m] : acc[i][j]) + bv);
         }
     }
 }
@@ -469,6 +474,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
         return;
     }
     // ---- epilogue: lane holds out[m][n..n+3]
+    float rsc[2][2] = {{1.f, 1.f}, {1.f, 1.f}};   // folded RMSNorm, consumer side: the row scales of this lane's four token rows
+    if (p.row_scale) {
+#pragma unroll
+        for (int hy = 0; hy < 2; ++hy)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) rsc[hy][j] = p.row_scale[min(m0 + hy * 128 + q * 32 + j * 16 + (lane & 15), p.M - 1)];
+    }
 #pragma unroll
     for (int hx = 0; hx < 2; ++hx)
 #pragma unroll
@@ -486,7 +498,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
                     const int m = m0 + hy * 128 + q * 32 + j * 16 + (lane & 15);
                     if (m >= p.M) continue;
                     if constexpr (F8) store_out<EPI>(p, m, n, acc[hx][i][hy][j] * (sw * p.a_scale[m]) + bv);
-                    else store_out<EPI>(p, m, n, acc[hx][i][hy][j] + bv);
+                    else store_out<EPI>(p, m, n, acc[hx][i][hy][j] * rsc[hy][j] + bv);
                 }
         }
 }
@@ -506,6 +518,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_fixup_kernel(GemmArgs p) {
     f32x4 v = ld16f(base);
     for (int k = 1; k < p.sk_ks; ++k) v = v + ld16f(base + (size_t)k * 65536);
     if (p.f8) v = v * (ld16f(p.w_scale + n) * p.a_scale[m]);
+    if (p.row_scale) v = v * p.row_scale[m];
     if (p.bias) v = v + ld16f(p.bias + n);
     store_out<EPI, true>(p, m, n, v);
 }

@@ -242,6 +242,23 @@ VC_DEV float rows_max(float v) {
 }
 VC_DEV bool wave_any(bool pred) { return __builtin_amdgcn_ballot_w64(pred) != 0; }
 #endif
+// sum over the four 16-lane rows (lanes l, l ^ 16, l ^ 32, l ^ 48), result in every lane: the order ((r0 + r1) + (r2 + r3)) of the
+// shfl_xor(16), shfl_xor(32) butterfly, in the VALU (permlane swaps) on the device
+#ifdef VC_EMU
+VC_DEV float rows_sum(float v) {
+    v += shfl_xor(v, 16);
+    return v + shfl_xor(v, 32);
+}
+#else
+VC_DEV float rows_sum(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    a = a + b;
+    b = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+#endif
 
 // 16-byte global/LDS accessors on raw pointers (the emulator's LDS race check hooks in here: tests/emu/hip_emu.h)
 #ifdef VC_EMU
