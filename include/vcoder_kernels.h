@@ -168,6 +168,14 @@ void vck_qkv_split24(const float* qkv, uint16_t* q_hi, uint16_t* q_lo, uint16_t*
 void vck_attention_decode_kv24(const float* qkv, void* k, void* v, uint16_t* out, int B, int H, int hd, int kv_stride,
                                const int* pos_rows, int pos_stride, const int* active_rows, const float* rope_cos,
                                const float* rope_sin, float scale, int G, void* stream);
+/* e4m3 KV caches of the fp8 weight format (rows of hd bytes, no scale, saturating at 448): the prefill's writer (the bf16 K rows go to
+ * a per-call scratch for the flash kernel) and the bf16 decode step's fused attention over them */
+void vck_qkv_split_kv8(const uint16_t* qkv, uint16_t* q, uint16_t* k, uint8_t* k8, uint8_t* v8, uint16_t* vt, int B, int T, int H, int hd,
+                       int q_stride, int kv_stride, int vt_stride, int kv8_stride, const float* rope_cos, const float* rope_sin,
+                       void* stream);
+void vck_attention_decode_kv8(const uint16_t* qkv, uint8_t* k, uint8_t* v, uint16_t* out, int B, int H, int hd, int kv_stride,
+                              const int* pos_rows, int pos_stride, const int* active_rows, const float* rope_cos,
+                              const float* rope_sin, float scale, void* stream);
 /* deterministic synthetic tensors (vcoder_amd/synth.py) and dtype converts */
 void vck_synth_bf16(uint16_t* out, uint64_t n, uint32_t tseed, float offset, float halfwidth, void* stream);
 void vck_synth_f32(float* out, uint64_t n, uint32_t tseed, float offset, float halfwidth, void* stream);

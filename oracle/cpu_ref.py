@@ -52,9 +52,15 @@ def quantize_rows_e4m3(x: torch.Tensor) -> torch.Tensor:
     return (x / s).to(torch.float8_e4m3fn).to(torch.float32) * s
 
 
+def quantize_e4m3(x: torch.Tensor) -> torch.Tensor:
+    """OCP e4m3fn without a scale, saturating at +-448 (the device's f2fp8): the KV-cache element of the fp8 weight format"""
+    return x.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32)
+
+
 class Rounder:
-    """Identity in fp32 mode, bf16 round-trip in emulation mode.  act_fp8: additionally the W8A8 prefill format — the
-    inputs of the decoder linears are quantised per token row (`q8`) while the pass is a prefill."""
+    """Identity in fp32 mode, bf16 round-trip in emulation mode.  act_fp8: additionally the device's `fp8` weight format — the
+    inputs of the decoder linears are quantised per token row (`q8`) while the pass is a prefill (W8A8), and the KV cache the
+    cached decode steps read holds e4m3 values (llama_layer)."""
 
     def __init__(self, emu_bf16: bool, act_fp8: bool = False):
         self.emu = emu_bf16
@@ -353,10 +359,21 @@ def llama_layer(x, sd, i: int, cfg, cache: KVCache, pos0: int, r: Rounder, key_m
     cos, sin = rope_cos_sin(torch.arange(pos0, pos0 + T), hd, cfg.rope_theta)
     q = r(apply_rope(q, cos, sin))
     k = r(apply_rope(k, cos, sin))
-    if cache.k[i] is not None:
-        k = torch.cat([cache.k[i], k], dim=2)
-        v = torch.cat([cache.v[i], v], dim=2)
-    cache.k[i], cache.v[i] = k, v
+    if r.act_fp8:
+        # the fp8 weight format keeps its KV cache in e4m3 (no scale, saturating): a cached decode step reads the cache — its own
+        # new row included, appended before the attention — while the flash attention of a PREFILL reads this pass's bf16 rows
+        kq, vq = quantize_e4m3(k), quantize_e4m3(v)
+        if cache.k[i] is not None:
+            k = torch.cat([cache.k[i], kq], dim=2)
+            v = torch.cat([cache.v[i], vq], dim=2)
+            cache.k[i], cache.v[i] = k, v
+        else:
+            cache.k[i], cache.v[i] = kq, vq
+    else:
+        if cache.k[i] is not None:
+            k = torch.cat([cache.k[i], k], dim=2)
+            v = torch.cat([cache.v[i], v], dim=2)
+        cache.k[i], cache.v[i] = k, v
     a = softmax_attention(q, k, v, 1.0 / math.sqrt(hd), True, r, q_pos0=pos0, key_mask=key_mask, probs_out=probs_out)
     a = r.q8(a.transpose(1, 2).reshape(B, T, D))
     x = x + F.linear(a, sd[p + "self_attn.o_proj.weight"])

@@ -1439,3 +1439,80 @@ def check_kv24(be, B, H, hd, pos, T_prefill=70, seed=0):
         ref = ref.transpose(1, 2).reshape(D).numpy()
         err = np.abs(go[orow] + go[orow + G] - ref).max()
         assert err < 3e-5 * max(1.0, np.abs(ref).max()), f"decode attention kv24 row {b}: {err}"
+
+
+# ---- e4m3 KV caches of the fp8 weight format -------------------------------------------------------------------------------------
+def e4m3_round(x):
+    """nearest OCP e4m3fn value (saturating at +-448), float32 — torch's cast, which the device's software encode equals"""
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float().numpy()
+
+
+def e4m3_bytes(x):
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+
+
+def e4m3_from_bytes(b):
+    return torch.from_numpy(np.ascontiguousarray(b, dtype=np.uint8)).view(torch.float8_e4m3fn).float().numpy()
+
+
+def check_kv8(be, B, H, hd, pos, T_prefill=70, seed=0):
+    """the e4m3 KV cache at kernel level: vck_qkv_split_kv8 writes bytes equal to torch's e4m3 cast of the bf16 K (after RoPE) /
+    V rows (and the bf16 K scratch + V^T the flash kernel reads, as before); vck_attention_decode_kv8 — a position per row, one
+    row inactive, the new row appended in e4m3 — equals the fp32 oracle on the dequantised cache to one bf16 output rounding."""
+    rng = np.random.RandomState(seed)
+    D = H * hd
+    T = T_prefill
+    Ts = (T + 63) // 64 * 64
+    S_cap = Ts + 64
+    qkv = bf16_round(rng.randn(B * T, 3 * D))
+    cos, sin = rope_tables(max(S_cap, pos + 130), hd)
+    q, k, vt = be.zeros((B, H, Ts, hd), "bf16"), be.zeros((B, H, Ts, hd), "bf16"), be.zeros((B, H, hd, Ts), "bf16")
+    k8, v8 = be.zeros((B, H, S_cap, hd), "u8"), be.zeros((B, H, S_cap, hd), "u8")
+    qd, cd, sd = be.bf16(qkv), be.f32(cos), be.f32(sin)
+    be.lib.vck_qkv_split_kv8(be.ptr(qd), be.ptr(q), be.ptr(k), be.ptr(k8), be.ptr(v8), be.ptr(vt), B, T, H, hd, Ts, Ts, Ts, S_cap,
+                             be.ptr(cd), be.ptr(sd), None)
+    be.sync()
+    gk = be.host_f32(k)[:, :, :T]                       # the bf16 rows (checked against the oracle by check_qkv_split)
+    x = qkv.reshape(B, T, 3, H, hd).transpose(2, 0, 3, 1, 4)
+    assert np.array_equal(_u8_host(be, k8)[:, :, :T], e4m3_bytes(gk)), "K cache bytes != e4m3(bf16 K rows)"
+    assert np.array_equal(_u8_host(be, v8)[:, :, :T], e4m3_bytes(x[2])), "V cache bytes != e4m3(V rows)"
+    assert not _u8_host(be, k8)[:, :, T:].any() and not _u8_host(be, v8)[:, :, T:].any()
+    # ---- decode step over e4m3 caches
+    poss = [max(1, pos - 13 * b) for b in range(B)]
+    S = (pos + 1 + 63) // 64 * 64 + 64
+    q1 = bf16_round(rng.randn(B, 3 * D))
+    k_old, v_old = e4m3_round(rng.randn(B, H, S, hd) * 1.5), e4m3_round(rng.randn(B, H, S, hd) * 1.5)
+    kd, vd = _u8_dev(be, e4m3_bytes(k_old)), _u8_dev(be, e4m3_bytes(v_old))
+    out = be.zeros((B, D), "bf16")
+    scale = 1.0 / math.sqrt(hd)
+    q1d = be.bf16(q1)
+    inactive = B - 1 if B > 1 else -1
+    rows = np.zeros((B, 4), np.int32)
+    rows[:, 0] = 1
+    rows[:, 1] = poss
+    if inactive >= 0:
+        rows[inactive, 0] = 0
+    rd = be.i32(rows)
+    base = rd.ctypes.data if isinstance(rd, np.ndarray) else rd.data_ptr()
+    be.lib.vck_attention_decode_kv8(be.ptr(q1d), be.ptr(kd), be.ptr(vd), be.ptr(out), B, H, hd, S, c_p(base + 4), 4, c_p(base),
+                                    be.ptr(cd), be.ptr(sd), ctypes.c_float(scale), None)
+    be.sync()
+    gk8, gv8, got = e4m3_from_bytes(_u8_host(be, kd)), e4m3_from_bytes(_u8_host(be, vd)), be.host_f32(out)
+    for b in range(B):
+        pb = poss[b]
+        if b == inactive:
+            assert np.array_equal(gk8[b], k_old[b]) and np.array_equal(gv8[b], v_old[b]) and not got[b].any()
+            continue
+        rq, rk, rv = _split_ref(q1[b:b + 1], 1, 1, H, hd, True, pos0=pb)   # roped + bf16-rounded q, k and raw v of the new token
+        # the appended rows: e4m3 of the bf16 values (the device's fp32 RoPE may land one bf16 step off the reference rounding)
+        assert np.abs(gk8[b, :, pb] - rk[0, :, 0]).max() <= 2 ** -3 * np.abs(rk).max() and np.array_equal(gv8[b, :, pb], e4m3_round(rv[0, :, 0]))
+        keep = np.ones(S, bool)
+        keep[pb] = False
+        assert np.array_equal(gk8[b][:, keep], k_old[b][:, keep]) and np.array_equal(gv8[b][:, keep], v_old[b][:, keep])
+        k_all = np.concatenate([k_old[b:b + 1, :, :pb], gk8[b:b + 1, :, pb:pb + 1]], 2)
+        v_all = np.concatenate([v_old[b:b + 1, :, :pb], gv8[b:b + 1, :, pb:pb + 1]], 2)
+        ref = cpu_ref.softmax_attention(torch.from_numpy(rq), torch.from_numpy(k_all), torch.from_numpy(v_all), scale, False,
+                                        cpu_ref.Rounder(False))
+        ref = ref.transpose(1, 2).reshape(D).numpy()
+        err = np.abs(got[b] - ref).max()
+        assert err < 2 ** -7 * max(1.0, np.abs(ref).max()), f"decode attention kv8 row {b} pos {pb}: abs err {err}"

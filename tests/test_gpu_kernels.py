@@ -169,6 +169,10 @@ def test_split_small_and_attention_kernels(be):
     kc.check_kv24(be, 32, 4, 128, 1343, T_prefill=64, seed=1)
     kc.check_kv24(be, 2, 4, 128, 4000, T_prefill=70, seed=3)
     kc.check_kv24(be, 1, 2, 64, 5, T_prefill=3, seed=4)
+    # the e4m3 caches of the fp8 weight format
+    kc.check_kv8(be, 8, 40, 128, 1216, T_prefill=130)
+    kc.check_kv8(be, 32, 4, 128, 1343, T_prefill=64, seed=1)
+    kc.check_kv8(be, 1, 2, 64, 5, T_prefill=3, seed=4)
 
 
 def test_dma_kernels_are_race_free_and_bit_reproducible(be):

@@ -115,6 +115,12 @@ def test_splice_greedy_synth(be):
     kc.check_synth(be)
 
 
+def test_e4m3_kv_cache_kernels(be):
+    """the fp8 weight format's KV cache (1 byte per element): the prefill's writer and the bf16 step's decode attention"""
+    kc.check_kv8(be, 3, 2, 128, 140)
+    kc.check_kv8(be, 10, 1, 64, 70, T_prefill=33, seed=1)
+
+
 def test_fused_decode_kernels(be):
     kc.check_gemv_norm_chain(be, 8, 256, 64)
     kc.check_gemv_norm_chain(be, 3, 512, 96, seed=1)

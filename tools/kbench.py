@@ -302,6 +302,31 @@ def bench_dattn_split():
             print(f"decode attention split {name} B={B:2d} ctx~1280: {us:7.1f} us  {byts / us / 1e3:7.1f} GB/s", flush=True)
 
 
+def bench_dattn_kv8():
+    """decode attention of the bf16 step: bf16 caches vs the e4m3 caches of the fp8 weight format, 13b heads (40 x 128)"""
+    H, hd, S = 40, 128, 2048
+    D = H * hd
+    cos, sin = torch.rand(S, hd // 2, device=dev), torch.rand(S, hd // 2, device=dev)
+    for B in (8, 16, 32):
+        qkv = bf16(B, 3 * D)
+        out = torch.zeros((B, D), dtype=torch.bfloat16, device=dev)
+        pos = torch.tensor([1216 + (7 * b) % 128 for b in range(B)], dtype=torch.int32, device=dev)
+        act = torch.ones(B, dtype=torch.int32, device=dev)
+        keys = float((pos + 1).sum().item())
+        for name, es, fn in (("bf16", 2, lib.vck_attention_decode_rows), ("e4m3", 1, lib.vck_attention_decode_kv8)):
+            ks = [torch.randint(0, 120, (B, H, S, hd * es), dtype=torch.uint8, device=dev) for _ in range(2)]
+            vs = [torch.randint(0, 120, (B, H, S, hd * es), dtype=torch.uint8, device=dev) for _ in range(2)]
+            it = [0]
+
+            def f():
+                it[0] += 1
+                fn(P(qkv), P(ks[it[0] % 2]), P(vs[it[0] % 2]), P(out), B, H, hd, S, P(pos), 1, P(act), P(cos), P(sin),
+                   C.c_float(1 / math.sqrt(hd)), None)
+            us = timeit(f, iters=30)
+            byts = 2.0 * keys * D * es
+            print(f"decode attention 13b heads {name} B={B:2d} ctx~1280: {us:7.1f} us  {byts / us / 1e3:7.1f} GB/s", flush=True)
+
+
 def bench_gemv_pair():
     """Two streams run the SAME GEMV (same weights, different activations / outputs) at the same time: does the second
     reader hit the Infinity Cache / merge with the first?  pair time ~ single time => yes."""
@@ -451,7 +476,9 @@ if __name__ == "__main__":
         bench_gemv_wg()
     if "dattn_split" in what:
         bench_dattn_split()
+    if "dattn_kv8" in what:
+        bench_dattn_kv8()
     for w in what:
         {"gemm": bench_gemm, "gemv": bench_gemv, "attn": bench_attn, "dattn": bench_dattn,
          "gemv_fp8": lambda: None, "gemv13": lambda: None, "gemv_pair": lambda: None, "gemv_rows": lambda: None,
-         "dattn_rows": lambda: None, "gemm_f8": lambda: None, "gemv_rows8": lambda: None, "gemv_wg": lambda: None, "dattn_split": lambda: None}[w]()
+         "dattn_rows": lambda: None, "gemm_f8": lambda: None, "gemv_rows8": lambda: None, "gemv_wg": lambda: None, "dattn_split": lambda: None, "dattn_kv8": lambda: None}[w]()

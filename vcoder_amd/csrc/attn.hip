@@ -65,6 +65,13 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(QkvSplitArgs p) {
                                      : p.k + (((size_t)b * p.H + h) * p.kv_stride + t) * HD;
             st16(dst + c * 8, olo);
             st16(dst + HD / 2 + c * 8, ohi);
+            if (which == 1 && p.k8 != nullptr) {   // e4m3 cache row: the bf16 values above, re-rounded
+                uint8_t* d8 = p.k8 + (((size_t)b * p.H + h) * p.kv8_stride + t) * HD;
+                st8(d8 + c * 8, u32x2{f32x4_to_fp8x4(bf2f_lo(olo[0]), bf2f_hi(olo[0]), bf2f_lo(olo[1]), bf2f_hi(olo[1])),
+                                      f32x4_to_fp8x4(bf2f_lo(olo[2]), bf2f_hi(olo[2]), bf2f_lo(olo[3]), bf2f_hi(olo[3]))});
+                st8(d8 + HD / 2 + c * 8, u32x2{f32x4_to_fp8x4(bf2f_lo(ohi[0]), bf2f_hi(ohi[0]), bf2f_lo(ohi[1]), bf2f_hi(ohi[1])),
+                                               f32x4_to_fp8x4(bf2f_lo(ohi[2]), bf2f_hi(ohi[2]), bf2f_lo(ohi[3]), bf2f_hi(ohi[3]))});
+            }
         }
     }
     // V: rows as they are into the cache (key-major, what the decode steps stream); and a staged [token][d] tile written
@@ -76,6 +83,10 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(QkvSplitArgs p) {
         if (t < p.T) {
             v = ld16(p.qkv + ((size_t)b * p.T + t) * (3 * D) + 2 * D + h * HD + c * 8);
             if (p.v != nullptr) st16(p.v + (((size_t)b * p.H + h) * p.kv_stride + t) * HD + c * 8, v);
+            if (p.v8 != nullptr)
+                st8(p.v8 + (((size_t)b * p.H + h) * p.kv8_stride + t) * HD + c * 8,
+                    u32x2{f32x4_to_fp8x4(bf2f_lo(v[0]), bf2f_hi(v[0]), bf2f_lo(v[1]), bf2f_hi(v[1])),
+                          f32x4_to_fp8x4(bf2f_lo(v[2]), bf2f_hi(v[2]), bf2f_lo(v[3]), bf2f_hi(v[3]))});
         }
         st16(&vt_tile[tl][c * 8], v);
     }
@@ -609,12 +620,14 @@ constexpr int DEC_MAX_CTX = 4096;
 // per key row), q is not rounded, and the output row is written as bf16 hi / lo rows of a stacked group layout (out_G)
 // KVF == 2: fp24 caches (rows of hd x u16 | hd x u8; 8 elements per lane = one 16-byte + one 8-byte load) — 3 bytes per element
 // at 2^-17 relative precision: the split step's attention streams 0.75 of the fp32 bytes
-template <int HD, int UK, int KVF = 0>               // UK = independent row loads in flight per lane; KVF: 0 bf16, 1 fp32, 2 fp24
+// KVF == 3: e4m3 caches (rows of hd bytes) under the bf16 step — the fp8 weight format's KV: half the bf16 bytes
+template <int HD, int UK, int KVF = 0>               // UK = independent row loads in flight per lane; KVF: 0 bf16, 1 fp32, 2 fp24, 3 e4m3
 __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeFusedArgs p) {
-    constexpr bool KV32 = KVF != 0;       // the split step's operand forms (fp32 projection rows, unrounded q, hi / lo output rows)
+    constexpr bool KV32 = KVF == 1 || KVF == 2;   // the split step's operand forms (fp32 projection rows, unrounded q, hi / lo output rows)
     constexpr bool F24 = KVF == 2;
-    constexpr int EPL = KVF == 1 ? 4 : 8; // elements per lane
-    constexpr int ESZ = KVF == 1 ? 4 : 2; // bytes per element of the (hi) plane
+    constexpr bool F8 = KVF == 3;         // e4m3 caches under the bf16 step (the fp8 weight format): 16 elements per 16-byte load
+    constexpr int EPL = KVF == 1 ? 4 : (F8 ? 16 : 8);   // elements per lane
+    constexpr int ESZ = KVF == 1 ? 4 : (F8 ? 1 : 2);    // bytes per element of the (hi) plane
     constexpr int ROWB = F24 ? 3 * HD : HD * ESZ;   // bytes per cache row
     constexpr int LPK = HD / EPL;         // lanes per key row
     constexpr int KPW = 64 / LPK;         // key rows per wave-instruction
@@ -668,12 +681,21 @@ __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeF
             const float k0 = bf2f(row[D + d]), k1 = bf2f(row[D + d + HD / 2]);
             q_s[d] = bf2f(f2bf(q0 * c - q1 * s));            // q is rounded to bf16 exactly like the unfused path
             q_s[d + HD / 2] = bf2f(f2bf(q1 * c + q0 * s));
-            bf16_t* ko = reinterpret_cast<bf16_t*>(kbase) + (size_t)pos * HD;
-            ko[d] = f2bf(k0 * c - k1 * s);
-            ko[d + HD / 2] = f2bf(k1 * c + k0 * s);
-            bf16_t* vo = reinterpret_cast<bf16_t*>(vbase) + (size_t)pos * HD;
-            vo[d] = row[2 * D + d];
-            vo[d + HD / 2] = row[2 * D + d + HD / 2];
+            if constexpr (F8) {   // e4m3 rows: the bf16 values the bf16 cache would hold, re-rounded (as the prefill's writer does)
+                uint8_t* ko = reinterpret_cast<uint8_t*>(kbase) + (size_t)pos * HD;
+                ko[d] = f2fp8(bf2f(f2bf(k0 * c - k1 * s)));
+                ko[d + HD / 2] = f2fp8(bf2f(f2bf(k1 * c + k0 * s)));
+                uint8_t* vo = reinterpret_cast<uint8_t*>(vbase) + (size_t)pos * HD;
+                vo[d] = f2fp8(bf2f(row[2 * D + d]));
+                vo[d + HD / 2] = f2fp8(bf2f(row[2 * D + d + HD / 2]));
+            } else {
+                bf16_t* ko = reinterpret_cast<bf16_t*>(kbase) + (size_t)pos * HD;
+                ko[d] = f2bf(k0 * c - k1 * s);
+                ko[d + HD / 2] = f2bf(k1 * c + k0 * s);
+                bf16_t* vo = reinterpret_cast<bf16_t*>(vbase) + (size_t)pos * HD;
+                vo[d] = row[2 * D + d];
+                vo[d + HD / 2] = row[2 * D + d + HD / 2];
+            }
         }
     }
     __syncthreads();  // workgroup-scope release/acquire: the appended K / V rows are visible to this block
@@ -698,6 +720,13 @@ __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeF
         if constexpr (F24) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) s += qv[e] * f24_elem(r, rl, e);
+        } else if constexpr (F8) {
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) {
+                const f32x4 f = fp8x4_to_f32x4(r[w4]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s += qv[4 * w4 + e] * f[e];
+            }
         } else if constexpr (KV32) {
             const f32x4 f = __builtin_bit_cast(f32x4, r);
 #pragma unroll
@@ -776,6 +805,13 @@ __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeF
                 vl[u] = ld8_stream(vbase + lo_off(key + BATCH));
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[e] += pk * f24_elem(v, vlo, e);
+            } else if constexpr (F8) {
+#pragma unroll
+                for (int w4 = 0; w4 < 4; ++w4) {
+                    const f32x4 f = fp8x4_to_f32x4(v[w4]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[4 * w4 + e] += pk * f[e];
+                }
             } else if constexpr (KV32) {
                 const f32x4 f = __builtin_bit_cast(f32x4, v);
 #pragma unroll
@@ -822,6 +858,18 @@ void launch_attention_decode_fused(const AttnDecodeFusedArgs& a, hipStream_t s) 
     const dim3 grid(a.H, a.B), block(512);
     // VC_DATTN_UK: row loads in flight per lane (tuning knob; 8 = 8 KiB per wave, two workgroups per CU)
     static const int uk = getenv("VC_DATTN_UK") ? atoi(getenv("VC_DATTN_UK")) : 8;
+    if (a.kv32 == 3) {  // bf16 step over e4m3 caches (the fp8 weight format)
+        // rows in flight per lane: 16 elements per load cost 16 + 16 query / accumulator registers; 8 rows took 156 VGPRs (one
+        // workgroup per CU).  VC_DATTN8_UK = 4 (tuning; default 6)
+        static const int uk8 = getenv("VC_DATTN8_UK") ? atoi(getenv("VC_DATTN8_UK")) : 6;
+        if (a.hd == 128) {
+            if (uk8 == 4) VC_LAUNCH((attention_decode_fused_kernel<128, 4, 3>), grid, block, 0, s, a);
+            else VC_LAUNCH((attention_decode_fused_kernel<128, 6, 3>), grid, block, 0, s, a);   // 124 VGPRs: two workgroups per CU
+        } else {
+            VC_LAUNCH((attention_decode_fused_kernel<64, 4, 3>), grid, block, 0, s, a);
+        }
+        return;
+    }
     if (a.kv32 == 2) {  // precision mode "split", fp24 caches
         // 6 rows x 24 B in flight per lane (the bf16 kernel's 8 x 16 B take 114 VGPRs, 8 rows of fp24 171: one workgroup per CU)
         if (a.hd == 128) VC_LAUNCH((attention_decode_fused_kernel<128, 6, 2>), grid, block, 0, s, a);

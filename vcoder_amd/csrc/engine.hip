@@ -209,6 +209,7 @@ struct vc_model {
     int layer_limit = 0;          // > 0: a prefill evaluates only the first layer_limit decoder layers (vc_model_set_layer_limit)
     // LLM workspace
     Buf x, xn, qkv, q, attn, h, kc, vc, vt_pre, row_src, last_idx, xl, logits_all;
+    Buf k_pre;                    // bf16 K rows of the current prefill layer when the cache holds e4m3 rows (fp8 format)
     Buf p_ssq, p_rstd;            // prefill: sum-of-squares partials [B*S, npart] and 1/rms [B*S] of the folded RMSNorm
     Buf a8, a8_scale;             // weight format 2: e4m3 activation rows of the current prefill GEMM + their scales
     int capB = 0, capS = 0;  // KV capacity
@@ -532,6 +533,15 @@ inline int split_kv_es() {
     static const int es = (getenv("VC_SPLIT_KV") && atoi(getenv("VC_SPLIT_KV")) == 32) ? 4 : 3;
     return es;
 }
+
+// the fp8 weight format (2) keeps its KV cache in e4m3 as well (1 byte per element: at 13b the pooled decode attention reads 2.6x
+// the bytes of the e4m3 weights otherwise); VC_FP8_KV=0 keeps bf16 rows
+inline bool fp8_kv_on() {
+    static const bool on = !(getenv("VC_FP8_KV") && atoi(getenv("VC_FP8_KV")) == 0);
+    return on;
+}
+// bytes per KV element of the bf16-step modes (precision 0) of a model
+inline int step_kv_es(const vc_model* m) { return (m->weight_format == 2 && fp8_kv_on()) ? 1 : 2; }
 
 // Everything one decode step touches besides the weights: the buffers of a session's own loop or of the shared pool.
 struct LoopView {
@@ -1131,7 +1141,8 @@ void ensure_llm(vc_model* m, int B, int S_total) {
     REQUIRE(B <= VC_MAX_ROWS, VC_ERR_INVALID, "batch %d: at most %d sequences per GPU replica (shard larger batches over ranks)",
             B, VC_MAX_ROWS);
     REQUIRE(Scap <= c.max_positions, VC_ERR_INVALID, "sequence %d exceeds max_position_embeddings=%d", Scap, c.max_positions);
-    const int es = m->precision == 2 ? split_kv_es() : 2;   // split mode keeps fp24 (or fp32) keys / values
+    // split mode keeps fp24 (or fp32) keys / values; the fp8 weight format e4m3 ones
+    const int es = m->precision == 2 ? split_kv_es() : (m->precision == 0 ? step_kv_es(m) : 2);
     if (B != m->capB || Scap > m->capS || es != m->kv_es) {
         const int newS = std::max(Scap, (m->capB == B && es == m->kv_es) ? m->capS : 0);
         const size_t per_layer = (size_t)B * H * newS * m->hd;
@@ -1280,6 +1291,7 @@ void run_prefill_layers(vc_model* m, const KvTarget& kv, int B, int S, int l0 = 
     const int nl = l1 >= 0 ? l1 : (m->layer_limit > 0 ? std::min(m->layer_limit, c.layers) : c.layers);
     const int Sr = (int)rup(S, 64);
     m->vt_pre.ensure((size_t)B * H * m->hd * Sr * 2, true);
+    if (kv.es == 1) m->k_pre.ensure((size_t)B * H * Sr * m->hd * 2, true);
     const bool f8 = m->weight_format == 2;
     // VC_PREFILL_FOLD=1 (opt-in; read per call so that tests can switch it): RMSNorm never runs as a pass behind the first
     // layer — the GEMM that writes a residual row (o_proj, down) also writes xg = bf16(x * g) for the next GEMM and the row's
@@ -1303,10 +1315,17 @@ void run_prefill_layers(vc_model* m, const KvTarget& kv, int B, int S, int l0 = 
         }
         // K and V rows go to the cache (key-major: what the decode steps stream); the V^T tiles of this layer's flash
         // attention live in a per-call scratch [B,H,hd,Sr]
-        QkvSplitArgs qa{m->qkv.as<bf16_t>(), m->q.as<bf16_t>(), kcache(m, kv, l), m->vt_pre.as<bf16_t>(), B, S, H, m->hd, S, kv.capS,
-                        nullptr, m->rope_cos, m->rope_sin, vcache(m, kv, l), Sr};
+        // (kv.es == 1, the e4m3 cache of the fp8 format: the flash kernel of THIS prefill reads bf16 K rows from a per-call
+        // scratch, the cache receives e4m3 rows)
+        const bool kv8 = kv.es == 1;
+        bf16_t* kflash = kv8 ? m->k_pre.as<bf16_t>() : kcache(m, kv, l);
+        const int kflash_stride = kv8 ? Sr : kv.capS;
+        QkvSplitArgs qa{m->qkv.as<bf16_t>(), m->q.as<bf16_t>(), kflash, m->vt_pre.as<bf16_t>(), B, S, H, m->hd, S, kflash_stride,
+                        nullptr, m->rope_cos, m->rope_sin, kv8 ? nullptr : vcache(m, kv, l), Sr,
+                        kv8 ? reinterpret_cast<uint8_t*>(kcache(m, kv, l)) : nullptr,
+                        kv8 ? reinterpret_cast<uint8_t*>(vcache(m, kv, l)) : nullptr, kv.capS};
         launch_qkv_split(qa, m->st);
-        AttnArgs aa{m->q.as<bf16_t>(), kcache(m, kv, l), m->vt_pre.as<bf16_t>(), m->attn.as<bf16_t>(), B, H, S, m->hd, S, kv.capS, 1,
+        AttnArgs aa{m->q.as<bf16_t>(), kflash, m->vt_pre.as<bf16_t>(), m->attn.as<bf16_t>(), B, H, S, m->hd, S, kflash_stride, 1,
                     1.0f / sqrtf((float)m->hd), Sr};
         if (m->has_kmask) {
             aa.key_mask = m->kmask.as<uint8_t>();
@@ -1316,9 +1335,9 @@ void run_prefill_layers(vc_model* m, const KvTarget& kv, int B, int S, int l0 = 
         if (m->attn_out) {
             AttnProbsArgs pa{};
             pa.q_hi = m->q.as<bf16_t>();
-            pa.k_hi = kcache(m, kv, l);
+            pa.k_hi = kflash;
             pa.q_stride = S;
-            pa.kv_stride = kv.capS;
+            pa.kv_stride = kflash_stride;
             emit_attentions(m, l, B, S, pa);
         }
         if (f8) {
@@ -1441,7 +1460,7 @@ void enqueue_decode_step(vc_model* m, const LoopView& v, int nrows) {
     decode_linears(m, v, nrows, [&](int l) {
         AttnDecodeFusedArgs da{v.qkv_dec, kcache(v, m, l), vcache(v, m, l), v.attn_dec, nrows, m->c.heads, m->hd, v.capS,
                                v.rows + RS_POS, m->rope_cos, m->rope_sin, 1.0f / sqrtf((float)m->hd), RS_STRIDE,
-                               v.rows + RS_ACTIVE, v.split_G ? (v.es == 3 ? 2 : 1) : 0, v.split_G, v.kmask, v.kmask_stride};
+                               v.rows + RS_ACTIVE, v.split_G ? (v.es == 3 ? 2 : 1) : (v.es == 1 ? 3 : 0), v.split_G, v.kmask, v.kmask_stride};
         launch_attention_decode_fused(da, v.st);
     });
     launch_select_embed(select_args(m, v, v.logits, nrows, 3), v.st);                                        // K19/K20+K10
@@ -1459,9 +1478,11 @@ void enqueue_decode_step_diag(vc_model* m, const LoopView& v, int nrows, int pos
         [&](int l) {
             AttnDecodeFusedArgs da{v.qkv_dec, kcache(v, m, l), vcache(v, m, l), v.attn_dec, nrows, c.heads, m->hd, v.capS,
                                    v.rows + RS_POS, m->rope_cos, m->rope_sin, 1.0f / sqrtf((float)m->hd), RS_STRIDE,
-                                   v.rows + RS_ACTIVE, v.split_G ? (v.es == 3 ? 2 : 1) : 0, v.split_G, v.kmask, v.kmask_stride};
+                                   v.rows + RS_ACTIVE, v.split_G ? (v.es == 3 ? 2 : 1) : (v.es == 1 ? 3 : 0), v.split_G, v.kmask, v.kmask_stride};
             launch_attention_decode_fused(da, v.st);
             if (m->attn_out) {
+                REQUIRE(v.es != 1, VC_ERR_INVALID, "output_attentions of a cached decode step is not available with the e4m3 KV cache "
+                        "of the fp8 weight format (VC_FP8_KV=0 keeps bf16 rows)");
                 m->attn_q.ensure((size_t)nrows * c.hidden * 4);
                 launch_rope_q_decode(v.qkv_dec, v.split_G != 0, m->attn_q.as<float>(), nrows, c.heads, m->hd, pos, m->rope_cos, m->rope_sin,
                                      v.split_G == 0, v.st);
@@ -1996,7 +2017,7 @@ VC_API void vc_model_destroy(vc_model* m) {
                    &m->out_ids, &m->dsum, &m->ssq, &m->sk_scratch, &m->sk_counters, &m->gemm_ws, &m->s_cols, &m->s_patches, &m->s_vx, &m->s_vxn, &m->s_vqkv,
                    &m->s_vq, &m->s_vk, &m->s_vv, &m->s_vattn, &m->s_vh, &m->s_sel, &m->s_mid, &m->s_feats, &m->s_xn, &m->s_qkv,
                    &m->s_q, &m->s_attn, &m->s_h, &m->s_kc, &m->s_vc, &m->s_xl, &m->pp_src, &m->pp_sq, &m->pp_tmp, &m->pp_out,
-                   &m->pp_tab, &m->pp_f32, &m->kmask, &m->hidden_tmp, &m->attn_q, &m->a8, &m->a8_scale, &m->p_ssq, &m->p_rstd})
+                   &m->pp_tab, &m->pp_f32, &m->kmask, &m->hidden_tmp, &m->attn_q, &m->a8, &m->a8_scale, &m->p_ssq, &m->p_rstd, &m->k_pre})
         b->release();
     for (auto& e : m->ev)
         if (e) (void)hipEventDestroy(e);
@@ -2535,6 +2556,7 @@ struct vc_pool {
     hipStream_t st = nullptr;
     int R = VC_POOL_ROWS, capS = 0, out_stride = 0;
     bool split = false;               // built for precision mode "split": fp32 KV, stacked hi / lo step operands
+    int kv_es = 2;                    // bytes per cache element: 2 bf16, 1 e4m3 (fp8 weight format), 3 / 4 fp24 / fp32 (split)
     int split_G = 16;                 // rows per stacked hi / lo group: 16 (per-wave-ring GEMV: two weight passes per 32-row step)
                                       // or 32 (workgroup-shared GEMV: one)
     Buf kc, vc, rows, x_dec, xg_dec, qkv_dec, attn_dec, h_dec, logits, next_tok, out_ids, ssq, sk_scratch, sk_counters;
@@ -2559,7 +2581,7 @@ LoopView pool_view(vc_pool* p) {
     v.st = p->st;
     v.kc = p->kc.as<bf16_t>();
     v.vc = p->vc.as<bf16_t>();
-    v.es = p->split ? split_kv_es() : 2;
+    v.es = p->kv_es;
     // one layout whatever rows a step spans: a row keeps its slot between steps.  The workgroup-shared GEMV takes all 32 rows
     // (hi + lo planes) in ONE weight pass; the per-wave-ring form two passes of 16
     v.split_G = p->split ? p->split_G : 0;
@@ -2740,7 +2762,8 @@ vc_pool* pool_for(vc_model* m, int need_S, int need_out) {
         p->split = want_split;
         p->split_G = (gemv_wg_enabled() && root->weight_format == 0) ? 32 : 16;
         const int D = c.hidden, F = c.ffn, H = c.heads, R = p->R;
-        const size_t es = want_split ? (size_t)split_kv_es() : 2, two = want_split ? 2 : 1;
+        const size_t es = want_split ? (size_t)split_kv_es() : (size_t)step_kv_es(root), two = want_split ? 2 : 1;
+        p->kv_es = (int)es;
         p->capS = std::min((int)rup(std::max(need_S, 2048), 64), c.max_positions / 64 * 64);
         p->out_stride = std::max(need_out, p->capS);
         REQUIRE(p->capS >= need_S, VC_ERR_INVALID, "sequence %d exceeds max_position_embeddings=%d", need_S, c.max_positions);
@@ -2860,7 +2883,7 @@ void generate_on_pool(vc_model* m, const int64_t* ids, int B, int T, const float
         REQUIRE(S + max_new <= p->capS, VC_ERR_INVALID,
                 "prompt %d + max_new %d exceeds the context: max_position_embeddings=%d (KV capacity %d)", S, max_new,
                 m->c.max_positions, p->capS);
-        finish_prefill(m, KvTarget{p->kc.as<bf16_t>(), p->vc.as<bf16_t>(), p->R, p->capS, rq.row0, p->split ? split_kv_es() : 2}, nullptr);
+        finish_prefill(m, KvTarget{p->kc.as<bf16_t>(), p->vc.as<bf16_t>(), p->R, p->capS, rq.row0, p->kv_es}, nullptr);
         if (m->ev[2]) HIPCHK(hipEventRecord(m->ev[2], m->st));
         HIPCHK(hipEventRecord(rq.prefill_done, m->st));
         DBG_HIP("finish_prefill");
@@ -3249,7 +3272,7 @@ VC_API int vc_profile_decode_attention(vc_model* m, int B, int ctx, int reps, in
         for (int l = 0; l < c.layers; ++l) {
             AttnDecodeFusedArgs da{v.qkv_dec, kcache(v, m, l), vcache(v, m, l), v.attn_dec, B, c.heads, m->hd, v.capS,
                                    v.rows + RS_POS, m->rope_cos, m->rope_sin, 1.0f / sqrtf((float)m->hd), RS_STRIDE,
-                                   v.rows + RS_ACTIVE};
+                                   v.rows + RS_ACTIVE, v.es == 1 ? 3 : 0};
             launch_attention_decode_fused(da, m->st);
         }
     };
@@ -3262,7 +3285,7 @@ VC_API int vc_profile_decode_attention(vc_model* m, int B, int ctx, int reps, in
     HIPCHK(hipEventElapsedTime(&ms, m->ev[0], m->ev[1]));
     if (launches) *launches = c.layers;
     if (avg_us) *avg_us = (double)ms * 1e3 / ((double)reps * c.layers);
-    if (avg_bytes) *avg_bytes = 4.0 * keys * (double)c.hidden;
+    if (avg_bytes) *avg_bytes = 2.0 * (double)v.es * keys * (double)c.hidden;   // K + V rows of `es` bytes per element
     HIPCHK(hipMemsetAsync(v.rows, 0, (size_t)B * RS_STRIDE * 4, m->st));
     HIPCHK(hipStreamSynchronize(m->st));
     m->cur_pos = -1;

@@ -120,6 +120,22 @@ VCK_EXPORT void vck_qkv_split_kv(const uint16_t* qkv, uint16_t* q, uint16_t* k, 
     QkvSplitArgs a{qkv, q, k, vt, B, T, H, hd, q_stride, kv_stride, nullptr, rope_cos, rope_sin, v, vt_stride};
     launch_qkv_split(a, S(stream));
 }
+/* the prefill's split + RoPE writing an e4m3 KV cache (k8 / v8 [B,H,kv8_stride,hd] bytes; the fp8 weight format): K bf16 rows go
+ * to the per-call scratch `k` (stride kv_stride) the flash kernel reads */
+VCK_EXPORT void vck_qkv_split_kv8(const uint16_t* qkv, uint16_t* q, uint16_t* k, uint8_t* k8, uint8_t* v8, uint16_t* vt, int B, int T,
+                                  int H, int hd, int q_stride, int kv_stride, int vt_stride, int kv8_stride, const float* rope_cos,
+                                  const float* rope_sin, void* stream) {
+    QkvSplitArgs a{qkv, q, k, vt, B, T, H, hd, q_stride, kv_stride, nullptr, rope_cos, rope_sin, nullptr, vt_stride, k8, v8, kv8_stride};
+    launch_qkv_split(a, S(stream));
+}
+/* the fused decode attention of the bf16 step over e4m3 caches */
+VCK_EXPORT void vck_attention_decode_kv8(const uint16_t* qkv, uint8_t* k, uint8_t* v, uint16_t* out, int B, int H, int hd, int kv_stride,
+                                         const int* pos_rows, int pos_stride, const int* active_rows, const float* rope_cos,
+                                         const float* rope_sin, float scale, void* stream) {
+    AttnDecodeFusedArgs a{qkv, reinterpret_cast<uint16_t*>(k), reinterpret_cast<uint16_t*>(v), out, B, H, hd, kv_stride, pos_rows,
+                          rope_cos, rope_sin, scale, pos_stride, active_rows, 3};
+    launch_attention_decode_fused(a, S(stream));
+}
 VCK_EXPORT void vck_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, uint16_t* out, int B, int H,
                               int T, int hd, int q_stride, int kv_stride, int causal, float scale, void* stream) {
     AttnArgs a{q, k, vt, out, B, H, T, hd, q_stride, kv_stride, causal, scale};

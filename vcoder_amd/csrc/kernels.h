@@ -169,6 +169,11 @@ struct QkvSplitArgs {
     const float* rope_sin;
     bf16_t* v;      // V key-major [B,H,kv_stride,hd] (the KV cache the decode steps stream), or nullptr (ViT)
     int vt_stride;  // columns per row of V^T (0: kv_stride) — the LLM prefill keeps V^T in a per-call scratch
+    // e4m3 KV cache of the fp8 weight format: k8 / v8 [B,H,kv8_stride,hd] bytes receive e4m3(bf16 K after RoPE) / e4m3(V) — what
+    // the decode steps stream (half the bf16 bytes); `k` is then a per-call bf16 scratch for THIS prefill's flash kernel
+    uint8_t* k8;
+    uint8_t* v8;
+    int kv8_stride;
 };
 void launch_qkv_split(const QkvSplitArgs& a, hipStream_t s);
 
@@ -228,7 +233,8 @@ struct AttnDecodeFusedArgs {
     const int* active_dev;  // nullptr, or row b is skipped when active_dev[b * pos_stride] == 0
     // precision mode "split" (kv32 != 0): qkv is fp32 [B, 3*H*hd], k / v are fp32 caches (kv32 == 1) or fp24 caches (kv32 == 2:
     // rows of hd x u16 | hd x u8, vc_device.h), and the output is written as bf16 hi / lo rows in stacked groups of out_G rows:
-    // row b -> hi at row (b / G) * 2G + b % G, lo G rows further
+    // row b -> hi at row (b / G) * 2G + b % G, lo G rows further.
+    // kv32 == 3: the bf16 step over e4m3 caches (rows of hd bytes; the fp8 weight format): qkv / q / out as for kv32 == 0
     int kv32;
     int out_G;
     // keys hidden by the row's attention_mask: key_mask[b * mask_stride + key] == 0 (nullptr = none)

@@ -138,6 +138,22 @@ VC_DEV u32x2 fp8x4_to_bf16x4(uint32_t v) {
 }
 #endif
 
+// 4 packed e4m3 -> 4 floats (exact)
+#ifdef VC_EMU
+VC_DEV f32x4 fp8x4_to_f32x4(uint32_t v) {
+    return f32x4{fp82f_sw(v & 0xFF), fp82f_sw((v >> 8) & 0xFF), fp82f_sw((v >> 16) & 0xFF), fp82f_sw(v >> 24)};
+}
+#else
+VC_DEV f32x4 fp8x4_to_f32x4(uint32_t v) {
+    const f32x2_hw lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)v, false), hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)v, true);
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+#endif
+// 4 floats -> 4 packed e4m3 (software encode: the same bytes on the device, in the emulator and in vcoder_amd/quant.py)
+VC_DEV uint32_t f32x4_to_fp8x4(float a, float b, float c, float d) {
+    return (uint32_t)f2fp8(a) | ((uint32_t)f2fp8(b) << 8) | ((uint32_t)f2fp8(c) << 16) | ((uint32_t)f2fp8(d) << 24);
+}
+
 // ---- MFMA ----------------------------------------------------------------------------------
 #ifndef VC_EMU
 typedef __bf16 bf16x8_hw __attribute__((ext_vector_type(8)));
