@@ -189,7 +189,7 @@ def _one_vit_layer(cfg):
 
 WEIGHTS_DESC = {"bf16": "bf16",
                 "w8a16": "bf16 activations / fp8-e4m3 decoder weights (W8A16)",
-                "fp8": "fp8-e4m3 decoder weights: W8A8 prefill on the K=128 scaled fp8 MFMA, W8A16 decode steps"}
+                "fp8": "fp8-e4m3 decoder weights: W8A8 prefill on the K=128 scaled fp8 MFMA, W8A16 decode steps, e4m3 KV cache"}
 
 
 def cpu_c1_full(new_tokens: int = 32):
@@ -326,7 +326,7 @@ def extra_legs(args, eng7, cfg7, ids7, dev_px7, lone_ids7, fast_value, n_new):
     px13 = tuple(torch.from_numpy(a).cuda() for a in synth.synth_batch(B13, cfg13.vit_image_size))
     for key, weights, desc in (("c3_13b_bf16_b16", "bf16", "BASELINE configs[2]: VCoder-DS LLaVA-1.5-13b bf16, batch=16, 128-tok decode on one MI355X"),
                                ("c5_slice_13b_fp8_b16", "fp8", "per-GPU slice of BASELINE configs[4]: VCoder-DS LLaVA-1.5-13b fp8-e4m3 weights "
-                                                               "(W8A8 prefill on the K=128 scaled fp8 MFMA, W8A16 decode), batch=16 per GPU")):
+                                                               "(W8A8 prefill on the K=128 scaled fp8 MFMA, W8A16 decode, e4m3 KV cache), batch=16 per GPU")):
         e13 = HipEngine(cfg13)
         e13.load_synthetic(42)
         if weights != "bf16":
@@ -354,6 +354,9 @@ def extra_legs(args, eng7, cfg7, ids7, dev_px7, lone_ids7, fast_value, n_new):
                              "per_layer_vs_oracle_of_max_abs_x": {"w8a16": {"rms": 6.1e-4, "max": 3.6e-3}, "fp8": {"rms": 7.0e-3, "max": 3.8e-2}},
                              "tolerances_in_test": {"w8a16": {"rms": 2e-3, "max": 2e-2}, "fp8": {"rms": 1.5e-2, "max": 8e-2}},
                              "quantiser_bytes_and_scales_vs_torch_float8_e4m3fn": "bit-exact",
+                             "kv_cache": "e4m3 rows (no scale): bytes == torch's e4m3 cast of the bf16 rows, decode attention == the fp32 "
+                                         "oracle on the dequantised cache to one bf16 rounding (tests/kernel_cases.py::check_kv8); the "
+                                         "oracle's fp8 mode models the cache in the fixtures' cached steps",
                              "e4m3_gemm_vs_fp64_of_same_operands": "<= 3.9e-5 rel"}
         out[key] = leg
         e13.close()
