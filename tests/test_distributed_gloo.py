@@ -63,3 +63,27 @@ def test_two_rank_gather_equals_single_process(tmp_path):
     imgs, segs, deps = synth.synth_batch(4, cfg.vit_image_size)
     ref = eng.generate_greedy(ids, imgs, segs, deps, max_new_tokens=3)
     assert got.shape == (4, 3) and np.array_equal(got, ref)
+
+
+def test_forced_gather_in_a_world_of_one(tmp_path):
+    """gather_token_ids(force=True) — what `bench.py --gpus 1 --force-dist` uses to run the multi-GPU gather on one GPU — really
+    runs the collective in a world of one (gloo here, nccl = RCCL under -m gpu) and returns the local rows unchanged"""
+    script = tmp_path / "w1.py"
+    script.write_text(r'''
+import os, sys, numpy as np
+sys.path.insert(0, %r)
+import torch.distributed as dist
+from vcoder_amd.parallel import gather_token_ids
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29623")
+dist.init_process_group("gloo", rank=0, world_size=1)
+calls = []
+orig = dist.all_gather_into_tensor
+dist.all_gather_into_tensor = lambda out, t, *a, **k: (calls.append(1), orig(out, t, *a, **k))[1]
+x = np.arange(24, dtype=np.int32).reshape(3, 8)
+assert np.array_equal(gather_token_ids(x, dist), x) and not calls            # default: no collective in a world of one
+assert np.array_equal(gather_token_ids(x, dist, force=True), x) and calls == [1]
+dist.destroy_process_group()
+print("ok")
+''' % ROOT)
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
