@@ -103,6 +103,8 @@ def _eos_ids(tokenizer, model) -> List[int]:
     """EOS id(s) of the run: the tokenizer's, else the config's; HF's GenerationConfig takes one id or a list"""
     eos = getattr(tokenizer, "eos_token_id", None)
     eos = model.config.eos_token_id if eos is None else eos
+    if eos is None:
+        return []
     return [int(e) for e in (eos if isinstance(eos, (list, tuple)) else [eos])]
 
 
@@ -129,7 +131,7 @@ def generate_answers(model, tokenizer, samples: Sequence[Sample], batch_size: in
     eos_ids = _eos_ids(tokenizer, model)
     # one EOS id goes to the device loop as such; further ids of an EOS list end a row the same way as single-token stop
     # sequences (the token is kept, the row pads afterwards — what HF's generate does for every id of the list)
-    eos, more = eos_ids[0], [[e] for e in eos_ids[1:]]
+    eos, more = (eos_ids[0] if eos_ids else None), [[e] for e in eos_ids[1:]]
     for prompt, idxs in buckets.items():
         if "<seg>" in prompt:
             ids = mm_utils.tokenizer_depth_seg_token(prompt, tokenizer)
