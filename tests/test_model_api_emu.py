@@ -241,6 +241,34 @@ def test_plugin_modules_hold_their_weights_and_run(model):
         build_vision_projector(vcfg.tiny("vcoder_ds"))(x, lib=lib)
 
 
+def test_generate_with_an_eos_id_list(model):
+    """eos_token_id may be a LIST (HF GenerationConfig): a row finishes at the first of its ids — the device loop (first id as EOS,
+    the others as single-token stops) and the host-driven loop (a stopping criterion that needs host code) agree with the
+    greedy ids cut at the first listed token and padded behind it."""
+    g, cfg, ids, imgs, segs, deps = _fx()
+    t = torch.from_numpy
+    T = ids.shape[1]
+    ref = g["greedy_ids"][:, :8]
+    eos_list = [int(ref[0, 2]), int(ref[1, 4])]          # row 0 ends at step 2 (or earlier if it emits the other id), row 1 by step 4
+    want = ref.copy()
+    for b in range(2):
+        hit = next((i for i, v in enumerate(ref[b]) if int(v) in eos_list), None)
+        if hit is not None:
+            want[b, hit + 1:] = 0
+    n = max(next((i for i, v in enumerate(ref[b]) if int(v) in eos_list), 7) for b in range(2)) + 1
+    out = model.generate(t(ids), images=t(imgs), segs=t(segs), depths=t(deps), do_sample=False, max_new_tokens=8,
+                         eos_token_id=eos_list, pad_token_id=0)
+    assert np.array_equal(out[:, T:].numpy(), want[:, :n])
+
+    class NeedsHost:   # forces the decode_step loop on the host
+        def __call__(self, output_ids, scores, **kw):
+            return False
+
+    out2 = model.generate(t(ids), images=t(imgs), segs=t(segs), depths=t(deps), do_sample=False, max_new_tokens=8,
+                          eos_token_id=eos_list, pad_token_id=0, stopping_criteria=[NeedsHost()])
+    assert np.array_equal(out2[:, T:].numpy(), want[:, :n])
+
+
 def test_hf_auto_class_registration(tmp_path, monkeypatch):
     """vcoder_amd.hf_register: the counterpart of the reference's AutoConfig.register / AutoModelForCausalLM.register
     (vcoder_ds_llava_llama.py:144-145) — a checkpoint's model_type resolves to this backend's model class, whose

@@ -322,6 +322,12 @@ class _HipCausalLMBase:
         if max_new_tokens is None:
             max_new_tokens = (max_length - T) if max_length is not None else 20
         eos = self.config.eos_token_id if eos_token_id is None else eos_token_id
+        # HF's GenerationConfig takes one EOS id or a list: any of them finishes a row.  The first is the device loop's EOS, the
+        # others end a row the same way as single-token stop sequences (token kept, pads afterwards)
+        eos_more = []
+        if isinstance(eos, (list, tuple)):
+            eos_more = [int(e) for e in eos[1:]]
+            eos = int(eos[0]) if len(eos) else None
         pad = pad_token_id if pad_token_id is not None else (self.config.pad_token_id if self.config.pad_token_id is not None else eos)
         segs = segs if self.variant != "llava" else None
         depths = depths if self.variant == "vcoder_ds" else None
@@ -342,6 +348,8 @@ class _HipCausalLMBase:
                 stops = None
                 break
             stops += seqs
+        if stops is not None:
+            stops = stops + [[e] for e in eos_more]
         on_device = stops is not None and len(stops) <= 8
         if streamer is not None:
             streamer.put(ids_cpu)
@@ -390,7 +398,7 @@ class _HipCausalLMBase:
                 if streamer is not None:
                     streamer.put(nxt.cpu())
                 if eos is not None:
-                    unfinished = unfinished * (nxt != eos).long()
+                    unfinished = unfinished * (~torch.isin(nxt, torch.tensor([eos] + eos_more))).long()
                 stop = bool(unfinished.max() == 0) if eos is not None else False
                 if stopping_criteria:
                     for crit in stopping_criteria:
