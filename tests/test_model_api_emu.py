@@ -172,8 +172,9 @@ def test_generate_variants(model):
     out3 = model.generate(t(ids[:1]), images=t(imgs[:1]), segs=t(segs[:1]), depths=t(deps[:1]), do_sample=True,
                           temperature=0.2, top_p=0.9, max_new_tokens=3, generator=gen, eos_token_id=-1)
     assert tuple(out3.shape) == (1, T + 3) and int(out3[0, T:].min()) >= 0
-    with pytest.raises(NotImplementedError):
-        model.generate(t(ids), images=t(imgs), num_beams=2, do_sample=True, max_new_tokens=2)   # beam-sample is not built
+    out4 = model.generate(t(ids), images=t(imgs), segs=t(segs), depths=t(deps), num_beams=2, do_sample=True, max_new_tokens=2,
+                          eos_token_id=-1, seed=1)   # beam-sample (test_beam_search_equals_hf_generate pins it)
+    assert tuple(out4.shape) == (2, T + 2)
 
 
 def test_model_surface(model):
@@ -687,5 +688,45 @@ def test_beam_search_equals_hf_generate(model):
         assert tuple(out.shape) == (2, mids.shape[1] + 4) and torch.equal(out[:, : mids.shape[1]], t(mids))
         with pytest.raises(ValueError, match="streamer"):
             model.generate(ids, images=None, num_beams=2, max_new_tokens=2, streamer=object())
+        # ---- beam-sample (num_beams > 1, do_sample=True): Transformers 4.31's `beam_sample` — the 2n candidates are DRAWN from
+        # softmax(warpers(log-softmax + beam score)).  Checked against the same published algorithm run on HF's own
+        # LlamaForCausalLM (full forwards, no cache) with the same torch generator: equal ids mean the engine's logits of the
+        # SAMPLED (not the top) continuations and its cache reorder by their beam_idx are right.
+        def hf_beam_sample(nb, n_new, seed, temperature, top_k, top_p):
+            gen = torch.Generator().manual_seed(seed)
+            B = ids.shape[0]
+            seqs = ids.repeat_interleave(nb, 0)
+            beam = torch.zeros(B, nb)
+            beam[:, 1:] = -1e9
+            beam = beam.view(-1)
+            V = hc.vocab_size
+            for _ in range(n_new):
+                with torch.no_grad():
+                    lg = hf(seqs).logits[:, -1].float()
+                w = (torch.log_softmax(lg, -1) + beam[:, None]) / temperature
+                if 0 < top_k < V:
+                    w = w.masked_fill(w < torch.topk(w, top_k)[0][..., -1, None], float("-inf"))
+                if top_p < 1.0:
+                    w = lm._top_p_filter(w, top_p)
+                flat = w.view(B, nb * V)
+                draw = torch.multinomial(torch.softmax(flat, -1), 2 * nb, generator=gen)
+                sc, order = torch.sort(torch.gather(flat, -1, draw), descending=True, dim=1)
+                tok = torch.gather(draw, -1, order)[:, :nb]          # no EOS: the n best draws continue
+                src = (torch.arange(B)[:, None] * nb + tok // V).view(-1)
+                beam = sc[:, :nb].reshape(-1)
+                seqs = torch.cat([seqs[src], (tok % V).view(-1, 1)], 1)
+            best = beam.view(B, nb).argmax(1)
+            return seqs.view(B, nb, -1)[torch.arange(B), best]
+
+        for (nb, temp, tk, tp, seed) in ((2, 1.0, 0, 1.0, 3), (3, 0.7, 20, 0.9, 11)):
+            want = hf_beam_sample(nb, 5, seed, temp, tk, tp)
+            got = model.generate(ids, images=None, num_beams=nb, do_sample=True, temperature=temp, top_k=tk, top_p=tp,
+                                 max_new_tokens=5, eos_token_id=-1, generator=torch.Generator().manual_seed(seed),
+                                 length_penalty=0.0)
+            assert torch.equal(got, want), (nb, temp, got.tolist(), want.tolist())
+        a = model.generate(ids, images=None, num_beams=2, do_sample=True, max_new_tokens=5, eos_token_id=-1, seed=5)
+        b = model.generate(ids, images=None, num_beams=2, do_sample=True, max_new_tokens=5, eos_token_id=-1, seed=5)
+        c = model.generate(ids, images=None, num_beams=2, do_sample=True, max_new_tokens=5, eos_token_id=-1, seed=6)
+        assert torch.equal(a, b) and not torch.equal(a, c)
     finally:
         model.engine.set_precision("bf16")

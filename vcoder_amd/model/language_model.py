@@ -308,15 +308,18 @@ class _HipCausalLMBase:
         if temperature is not None and float(temperature) <= 0.0:
             do_sample = False
         if num_beams != 1:
-            if do_sample:
-                raise NotImplementedError("beam-sample (num_beams > 1 with do_sample=True) is not implemented; the reference's "
-                                          "eval loaders use num_beams with greedy scoring or num_beams=1")
             if streamer is not None:
                 raise ValueError("`streamer` cannot be used with beam search")   # HF's own check
+            sample = None
+            if do_sample:   # beam-sample (the eval loaders forward --temperature and --num_beams independently)
+                if generator is None:
+                    generator = torch.Generator().manual_seed(int(seed if seed is not None else torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF)
+                sample = dict(temperature=float(temperature or 1.0), top_k=50 if top_k is None else int(top_k),
+                              top_p=1.0 if top_p is None else float(top_p), generator=generator)
             return self._beam_search(input_ids, images, segs, depths, int(num_beams), max_new_tokens, max_length, eos_token_id,
                                      pad_token_id, attention_mask, stopping_criteria,
                                      float(kwargs.get("length_penalty", 1.0)), kwargs.get("early_stopping", False),
-                                     kwargs.get("_beam_len_counts_prompt", True))
+                                     kwargs.get("_beam_len_counts_prompt", True), sample)
         T = input_ids.shape[1]
         B = input_ids.shape[0]
         if max_new_tokens is None:
@@ -419,14 +422,21 @@ class _HipCausalLMBase:
 
     # ---- beam search (HF GenerationMixin.beam_search + BeamSearchScorer of the reference's pinned Transformers 4.31) -----------
     def _beam_search(self, input_ids, images, segs, depths, num_beams, max_new_tokens, max_length, eos_token_id, pad_token_id,
-                     attention_mask, stopping_criteria, length_penalty, early_stopping, len_counts_prompt):
+                     attention_mask, stopping_criteria, length_penalty, early_stopping, len_counts_prompt, sample=None):
         """`generate(num_beams=n)` as the reference's eval loaders can ask for it (eval/model_seg_loader.py:129-139 forwards
         args.num_beams): every sequence is expanded to n beams (rows b*n .. b*n+n-1, as `_expand_inputs_for_generation`), the
         prefill and one cached decode step per token run on the engine, scoring is HF's — log-softmax of the fp32 logits plus
         the running beam score, the 2n best continuations per sequence, BeamSearchScorer.process / finalize (hypotheses
         scored by sum_logprobs / len ** length_penalty; 4.31 counts the PROMPT ids in len) — and the KV rows are reordered by
         beam_idx after every step (vc_reorder_cache).  Returns [B, T + n_new] int64, shorter rows padded with pad_token_id
-        (after one EOS), like HF."""
+        (after one EOS), like HF.
+
+        sample (do_sample=True: `beam_sample` of Transformers 4.31, generation/utils.py): the 2n candidates per sequence are DRAWN
+        instead of taken — the warpers (temperature -> top-k -> top-p) act on log-softmax + running beam score, as 4.31 applies
+        them, `torch.multinomial(softmax(.), 2n)` over the n * V continuations, the draws sorted by score — everything behind it
+        (EOS handling, hypotheses, cache reorder) is the beam search's.  The draws come from the caller's torch generator
+        (or `seed`), so a seed reproduces them; bit-equality with a given HF version's stream is not defined (its warper
+        order changed after 4.31)."""
         import torch
 
         ids_cpu = input_ids.detach().cpu() if hasattr(input_ids, "detach") else torch.as_tensor(np.asarray(input_ids))
@@ -494,7 +504,20 @@ class _HipCausalLMBase:
         n_steps = 0
         for step in range(max_new_tokens):
             scores = torch.log_softmax(logits, dim=-1) + beam_scores[:, None]
-            top_s, top_i = torch.topk(scores.view(B, nb * V), 2 * nb, dim=1, largest=True, sorted=True)
+            if sample is not None:
+                w = scores / sample["temperature"]
+                if 0 < sample["top_k"] < V:
+                    kth = torch.topk(w, sample["top_k"])[0][..., -1, None]
+                    w = w.masked_fill(w < kth, float("-inf"))
+                if sample["top_p"] < 1.0:
+                    w = _top_p_filter(w, sample["top_p"])
+                flat = w.view(B, nb * V)
+                draw = torch.multinomial(torch.softmax(flat, dim=-1), 2 * nb, generator=sample["generator"])
+                top_s, order = torch.sort(torch.gather(flat, -1, draw), descending=True, dim=1)
+                top_i = torch.gather(draw, -1, order)
+                scores = w
+            else:
+                top_s, top_i = torch.topk(scores.view(B, nb * V), 2 * nb, dim=1, largest=True, sorted=True)
             next_idx, next_tok = top_i // V, top_i % V
             nscore, ntok, nsrc = torch.zeros(B, nb), torch.zeros(B, nb, dtype=torch.long), torch.zeros(B, nb, dtype=torch.long)
             cur_len = seqs.shape[1]
