@@ -82,9 +82,10 @@ int vc_model_finalize(vc_model* m);
  * 1 = strict: fp32 activations end to end on fp32 MFMA (slow) — within ~1e-5 of the reference's fp32 CPU path;
  * 2 = split: fp32 activations in HBM, every MFMA operand carried as two bf16 values (x = hi + lo, ~16 mantissa bits) on the
  *     FAST kernels — GEMMs contract the [hi | lo] rows against the (exactly bf16) weight twice, attention uses three MFMAs per
- *     product, fp32 KV cache; runs in sessions, the hipGraph loop and the decode pool at about half the bf16 path's rate.
- * 1 and 2 meet the "logits within 1e-3, greedy ids bit-exact" bar of BASELINE.json (2: 1.7e-4 at full 7b depth over 128
- * tokens, every greedy id equal to the fp32 reference's).  Takes effect at the next prefill. */
+ *     product, fp24 KV cache (the top 24 bits of the fp32 values; VC_SPLIT_KV=32: fp32), one weight pass per 32-row pooled
+ *     decode step; runs in sessions, the hipGraph loop and the decode pool at 0.60 of the bf16 path's rate.
+ * 1 and 2 meet the "logits within 1e-3, greedy ids bit-exact" bar of BASELINE.json (2: 1.9e-4 at full 7b depth over 128
+ * tokens, every greedy id equal to the fp32 reference's; the same at 13b, B = 16).  Takes effect at the next prefill. */
 int vc_model_set_precision(vc_model* m, int mode);
 
 /* parity diagnostic: prefills evaluate only the first n decoder layers (0 = all), final norm + lm_head applied to that
@@ -103,7 +104,8 @@ int vc_debug_prefill_layers(vc_model* m, int l0, int l1, const float* x_in, int 
  * phases compute with one set of effective weights.  2 = fp8, BASELINE.json configs[4] ("fp8 weights, CDNA4 fp8 MFMA"):
  * the weights and decode steps of 1, and the prefill's decoder linears quantise their activation rows to e4m3 (one
  * power-of-two scale per token row) and run e4m3 x e4m3 on v_mfma_scale_f32_16x16x128_f8f6f4 (W8A8, twice the bf16
- * MFMA rate).  The reference's counterpart is `load_8bit` (builder.py:31-33, bitsandbytes LLM.int8 — also 8-bit
+ * MFMA rate), and the KV cache holds e4m3 rows (no scale, saturating; VC_FP8_KV=0: bf16 rows) — half the bytes of the stream
+ * that dominates the pooled 13b decode step.  The reference's counterpart is `load_8bit` (builder.py:31-33, bitsandbytes LLM.int8 — also 8-bit
  * weights x 8-bit activations).  Call before vc_model_finalize. */
 int vc_model_set_weight_format(vc_model* m, int fmt);
 
