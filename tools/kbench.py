@@ -35,7 +35,8 @@ def bf16(*shape, scale=1.0):
 
 def bench_gemm():
     for (M, N, K, epi, name) in [(9728, 12288, 4096, 0, "llm qkv"), (9728, 4096, 4096, 4, "llm o"),
-                                 (9728, 22016, 4096, 5, "llm gate-up"), (9728, 4096, 11008, 4, "llm down"),
+                                 (9728, 22016, 4096, 5, "llm gate-up"), (9728, 22016, 4096, 0, "gate-up/bf16"),
+                                 (9728, 22016, 4096, 3, "gate-up/f32"), (9728, 4096, 11008, 4, "llm down"),
                                  (13848, 3072, 1024, 0, "vit qkv"), (13848, 4096, 1024, 1, "vit fc1"),
                                  (13848, 1024, 4096, 4, "vit fc2"), (13824, 4096, 4096, 0, "adapter 2")]:
         A, W = bf16(M, K), bf16(N, K, scale=0.02)
