@@ -110,7 +110,8 @@ def cpu_baseline(cfg, n_new: int, decode_steps: int = 8):
     import torch
     import cpu_ref
 
-    cores = torch.get_num_threads()
+    pool = torch.get_num_threads()
+    cores = cpu_ref.fit_threads()      # the cgroup CPU quota, not the machine: an oversubscribed pool is throttled (r04_o)
     D, F, V, L = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size, cfg.num_hidden_layers
     Dv, Fv = cfg.mm_hidden_size, cfg.vit_intermediate_size
     fill = lambda *s: torch.empty(*s).fill_(0.01)
@@ -161,11 +162,13 @@ def cpu_baseline(cfg, n_new: int, decode_steps: int = 8):
             step_t.append(time.perf_counter() - t0)
         t_dec = sorted(step_t)[len(step_t) // 2]   # median: one step stalled by the host does not move the estimate
     per_sample = t_enc + t_pre + (n_new - 1) * t_dec
+    torch.set_num_threads(pool)
     return {"value": 1.0 / per_sample, "unit": "images/s", "cores": cores, "kind": "port",
             "sample": (f"oracle/cpu_ref.py fp32 at true {cfg.hidden_size}-wide dims, B=1, every layer: 3 modalities x "
                        f"{cfg.vit_layers_used} ViT layers + adapters ({t_enc:.2f}s), {L}-layer prefill S={S} ({t_pre:.1f}s), "
                        f"{decode_steps} full cached decode steps (median {t_dec * 1e3:.0f}ms) extrapolated linearly to "
-                       f"{n_new - 1} steps")}
+                       f"{n_new - 1} steps; {cores} torch threads = the CPUs this process may use "
+                       f"(affinity and cgroup quota; the machine has {os.cpu_count()})")}
 
 
 def _pmc_traffic_file():
@@ -212,6 +215,7 @@ def cpu_c1_full(new_tokens: int = 32):
     ids = synth.synth_prompt_ids(cfg.vocab_size, "vcoder")[None]
     imgs, segs, _ = synth.synth_batch(1, cfg.vit_image_size)
     om = cpu_ref.OracleModel(cfg, sd)
+    cpu_ref.fit_threads()
     t0 = time.perf_counter()
     with torch.no_grad():
         out = om.generate_greedy(ids.tolist(), torch.from_numpy(imgs), torch.from_numpy(segs), None, max_new_tokens=new_tokens)

@@ -74,6 +74,42 @@ class Rounder:
         return quantize_rows_e4m3(x) if (self.act_fp8 and self.prefill) else x
 
 
+def usable_cpus() -> int:
+    """CPUs this process can actually keep busy: its affinity mask capped by the cgroup CPU quota (cgroup v2 `cpu.max`, v1
+    `cpu.cfs_quota_us / cpu.cfs_period_us`).  torch sizes its pool from the machine (128 threads on the 2 x 64-core MI355X
+    hosts), but the GPU boxes run under a 16-CPU quota: 128 threads there are throttled to HALF the fp32 matmul rate of 16
+    (profiles/r04_o_host_matmul.txt: 0.84 vs 1.61 TFLOP/s)."""
+    import os
+
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = int(q) / int(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = min(n, max(1, math.ceil(quota)))
+    return n
+
+
+def fit_threads() -> int:
+    """torch's intra-op pool never wider than usable_cpus(); -> the thread count now in effect (what a timing reports as `cores`)"""
+    n = min(torch.get_num_threads(), usable_cpus())
+    torch.set_num_threads(n)
+    return n
+
+
 def as_torch_state(sd: Dict[str, np.ndarray]) -> Dict[str, torch.Tensor]:
     return {k: torch.from_numpy(np.ascontiguousarray(v)).float() for k, v in sd.items()}
 

@@ -10,5 +10,8 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
 
 
 def pytest_configure(config):
+    import cpu_ref
+
+    cpu_ref.fit_threads()   # the oracle passes of the suite: torch's pool capped by the cgroup CPU quota (r04_o_host_matmul.txt)
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "reference: needs /root/reference (build container only)")
