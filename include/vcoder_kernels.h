@@ -145,6 +145,11 @@ void vck_gemv_full(const uint16_t* X, const void* Wp, const float* wscale, void*
 /* which kernel serves the decode GEMV over bf16 weights: 0 = per-wave rings (gemv_dma_kernel), 1 = workgroup-shared activation
  * chunks (gemv_wg_kernel), -1 = the process default (environment VC_GEMV_WG) */
 void vck_set_gemv_variant(int v);
+/* tuning of the 17..32-row bf16 GEMV: three tiles per workgroup where the triples balance over the CUs — bit 0: 385..512 triples
+ * (two resident per CU), bit 1: 193..256 triples (one per CU, deeper ring); -1 = the process default (environment VC_GEMV2_NT3,
+ * default 3).  Results are bit-identical whichever is set. */
+void vck_set_gemv_m32_nt3(int v);
+unsigned long long vck_gemv_m32_nt3_launches(void);   /* launches the three-tile form has served (tests) */
 void vck_set_gemv_wg_geom(const char* spec, int deep);   /* tuning: "ntiles:K:ntw:ks,..." per matrix shape; deep: -1 default */
 unsigned long long vck_gemv_wg_launches(void);   /* launches the workgroup-shared form has served (tests) */
 void vck_rmsnorm_split(const float* x, const int* row_idx, const float* w, uint16_t* y, int rows, int D, float eps, int ldy,

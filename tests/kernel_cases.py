@@ -1333,6 +1333,58 @@ def check_gemv_wg_rows_agree(be, N, K, epi, norm=True, G=False, ksplit=0, seed=0
         be.lib.vck_set_gemv_variant(-1)
 
 
+def check_gemv_m32_nt3(be, N, K, epi, norm=True, rows=(19, 29, 32), seed=0):
+    """the three-tiles-per-workgroup form of the 17..32-row ring kernel (vck_set_gemv_m32_nt3; launch_gemv_m32): against the
+    float64 product, and bit for bit what the default geometry gives every row (same K partition: 4 waves, no K-slices) — the
+    ragged last workgroup (a tile count that is not a multiple of 3) included"""
+    triples = (N // 16 + 2) // 3
+    assert 192 < triples <= 256 or 384 < triples <= 512, "not a tile count the three-tile geometry serves (launch_gemv_m32)"
+    be.lib.vck_set_gemv_variant(0)
+    try:
+        rng = np.random.RandomState(seed)
+        c = _wg_case(be, rng, 32, N, K, epi, norm, 0)
+        c["sk"] = None      # no split-K buffers: the launcher's own geometry classes
+        worst = 0.0
+        for M in rows:
+            be.lib.vck_set_gemv_m32_nt3(0)
+            _, raw0, ex0 = _wg_run_plain(be, c, M)
+            be.lib.vck_set_gemv_m32_nt3(3)
+            be.lib.vck_gemv_m32_nt3_launches.restype = ctypes.c_ulonglong
+            n0 = be.lib.vck_gemv_m32_nt3_launches()
+            val, raw1, ex1 = _wg_run_plain(be, c, M)
+            assert be.lib.vck_gemv_m32_nt3_launches() == n0 + 1, "the call was not served by the three-tile form"
+            assert np.array_equal(raw0, raw1), f"M{M} N{N} K{K} epi{epi}: three tiles per workgroup changed the bits"
+            if epi == 2:
+                assert np.array_equal(ex0["xg"], ex1["xg"]) and np.array_equal(ex0["ssq"], ex1["ssq"])
+                assert np.array_equal(ex1["untouched"], c["r0"][M:]), "residual rows beyond M were touched"
+            e = rel_err(val, c["ref"][:M])
+            assert e < (2 ** -8 if epi in (0, 3) else 2e-5), f"gemv m32 nt3 M{M} N{N} K{K} epi{epi}: rel err {e}"
+            worst = max(worst, e)
+        return worst
+    finally:
+        be.lib.vck_set_gemv_m32_nt3(-1)
+        be.lib.vck_set_gemv_variant(-1)
+
+
+def _wg_run_plain(be, c, M):
+    """one bf16 launch over the first M rows of a _wg_case without split-K buffers -> (float64 values, raw output, extras)"""
+    N, K, epi, No = c["N"], c["K"], c["epi"], c["No"]
+    X = np.full((32, K), 7.0, np.float32)
+    X[:M] = c["hi"][:M]
+    out = be.f32(c["r0"].copy()) if epi == 2 else be.zeros((32, No), "f32" if epi == 1 else "bf16")
+    xg_out = be.zeros((32, N), "bf16") if epi == 2 else None
+    ssq_out = be.zeros((32, c["npart"]), "f32") if epi == 2 else None
+    ssq = np.zeros_like(c["ssq"])
+    ssq[:M] = c["ssq"][:M]
+    Xd, ssqd, gwd = be.bf16(X), (be.f32(ssq) if c["norm"] else None), (be.f32(c["gw"]) if c["gw"] is not None else None)
+    _gemv_full(be, Xd, c["Wp"], out, ssqd, ssq_out, gwd, xg_out, c["npart"], M, N, K, No, epi)
+    o = be.host_f32(out)
+    extra = None
+    if epi == 2:
+        extra = dict(xg=be.host_f32(xg_out)[:M].copy(), ssq=be.host_f32(ssq_out)[:M, : N // 16].copy(), untouched=o[M:].copy())
+    return o[:M].astype(np.float64), o[:M].copy(), extra
+
+
 # ---- fp24 KV caches of precision mode "split" (rows of hd x u16 | hd x u8: the top 24 bits of fp32, RNE) ------------------------
 def f24_round(x):
     """fp32 -> the nearest fp24 value (round to nearest even on bit 8), as float32"""

@@ -227,6 +227,13 @@ def test_gemv_wg_rows_agree(be, N, K, epi, G):
     kc.check_gemv_wg_rows_agree(be, N, K, epi, True, G)
 
 
+@pytest.mark.parametrize("N,K,epi", [(12288, 4096, 0), (22016, 4096, 3), (16 * 767, 4096, 2), (16 * 1154, 5120, 1)])
+def test_gemv_m32_three_tiles_per_workgroup(be, N, K, epi):
+    """VC_GEMV2_NT3 / vck_set_gemv_m32_nt3 at the 7b qkv and gate/up shapes (+ ragged 767- and 1154-tile matrices, the other
+    epilogues): three tiles per workgroup give every row of a 19 / 29 / 32-row step the bits of the pair geometry"""
+    kc.check_gemv_m32_nt3(be, N, K, epi)
+
+
 def test_gemv_wg_is_race_free_and_bit_reproducible(be):
     """hand-placed counted vmcnt waits + one bare barrier per chunk: back-to-back launches must all give the first launch's bits"""
     import numpy as np

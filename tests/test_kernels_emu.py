@@ -208,6 +208,13 @@ def test_gemv_wg(be, M, N, K, epi, norm, G, ks):
     kc.check_gemv_wg(be, M, N, K, epi, norm, G, ks)
 
 
+@pytest.mark.parametrize("N,K,epi", [(16 * 600, 64, 1), (16 * 767, 128, 0), (16 * 1154, 128, 3), (16 * 1376, 64, 2)])
+def test_gemv_m32_three_tiles_per_workgroup(be, N, K, epi):
+    """three tiles per workgroup in the pooled (17..32-row) bf16 GEMV (both tile-count classes that take it): the bits of the
+    pair geometry, ragged last workgroup included"""
+    kc.check_gemv_m32_nt3(be, N, K, epi)
+
+
 @pytest.mark.parametrize("N,K,epi,G,ks", [(64, 512, 0, False, 0), (48, 320, 1, False, 2), (96, 1024, 3, False, 3), (32, 512, 2, False, 0),
                                           (64, 512, 0, True, 0), (48, 1024, 1, True, 4), (64, 256, 3, True, 0)])
 def test_gemv_wg_rows_agree(be, N, K, epi, G, ks):

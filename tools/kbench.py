@@ -225,6 +225,36 @@ def bench_gemv_wg():
     lib.vck_set_gemv_variant(-1)
 
 
+def bench_gemv_nt3():
+    """17..32-row bf16 GEMV: two (default) vs three tiles per workgroup (vck_set_gemv_m32_nt3) on the 7b qkv / gate-up shapes and the
+    13b qkv, with the engine's operands; also checks that the two geometries give the same bits"""
+    for (N, K, epi, name) in [(12288, 4096, 0, "qkv"), (22016, 4096, 3, "gate-up"), (15360, 5120, 0, "13b qkv")]:
+        X = bf16(32, K)
+        Ws = [bf16(N * K, scale=0.02) for _ in range(8)]
+        ldo = N // 2 if epi == 3 else N
+        npart = (K // 16 + 15) // 16 * 16
+        ssq = torch.rand(32, npart, device=dev)
+        it = [0]
+        for M in (24, 32):
+            outs = {}
+            for nt3 in (0, 3):
+                lib.vck_set_gemv_m32_nt3(nt3)
+                out = torch.zeros((32, ldo), dtype=torch.bfloat16, device=dev)
+
+                def f():
+                    it[0] += 1
+                    lib.vck_gemv_ex(P(X), P(Ws[it[0] % 8]), None, P(out), P(ssq), None, None, None, npart, C.c_float(1e-5),
+                                    None, None, 0, M, N, K, ldo, epi, None)
+                us = timeit(f, iters=40)
+                it[0] = 7
+                f()
+                torch.cuda.synchronize()
+                outs[nt3] = out.clone()
+                print(f"gemv_nt3 M{M} {name:8s} nt3={nt3}: {us:7.1f} us  {2 * N * K / us / 1e3:7.1f} GB/s", flush=True)
+            print(f"gemv_nt3 M{M} {name:8s} same bits: {bool(torch.equal(outs[0].view(torch.int16), outs[3].view(torch.int16)))}", flush=True)
+    lib.vck_set_gemv_m32_nt3(-1)
+
+
 def bench_gemv_rows8():
     """W8A16 weights at 17..32 rows: gate/up (7b, 13b) and qkv, consumer form (VC_GEMV8_NT4=0/1 switches the gate/up geometry)"""
     for M in (16, 24, 32):
@@ -475,6 +505,8 @@ if __name__ == "__main__":
         bench_gemv_rows8()
     if "gemv_wg" in what:
         bench_gemv_wg()
+    if "gemv_nt3" in what:
+        bench_gemv_nt3()
     if "dattn_split" in what:
         bench_dattn_split()
     if "dattn_kv8" in what:
@@ -482,4 +514,4 @@ if __name__ == "__main__":
     for w in what:
         {"gemm": bench_gemm, "gemv": bench_gemv, "attn": bench_attn, "dattn": bench_dattn,
          "gemv_fp8": lambda: None, "gemv13": lambda: None, "gemv_pair": lambda: None, "gemv_rows": lambda: None,
-         "dattn_rows": lambda: None, "gemm_f8": lambda: None, "gemv_rows8": lambda: None, "gemv_wg": lambda: None, "dattn_split": lambda: None, "dattn_kv8": lambda: None}[w]()
+         "dattn_rows": lambda: None, "gemm_f8": lambda: None, "gemv_rows8": lambda: None, "gemv_wg": lambda: None, "gemv_nt3": lambda: None, "dattn_split": lambda: None, "dattn_kv8": lambda: None}[w]()

@@ -747,9 +747,45 @@ static void launch_gemv_dma2(const GemvArgs& a, int epi, hipStream_t s) {
 // M in 17..32 (the decode pool): two row groups per weight pass.  The K partition (waves per workgroup, K-slices) of every
 // tile-count class equals the 16-row launcher's below, so a row's result does not depend on which variant served it; only
 // the tiles per workgroup and the ring depth are re-balanced for the larger slots (LDS: all workgroups resident).
+// VC_GEMV2_NT3 / set_gemv_m32_nt3 (bf16 weights, 17..32 rows; default 3 = both classes on, 0 = off): THREE tiles per
+// workgroup.  The ring of a 32-row slot is half activation pieces at two tiles per workgroup (4 KiB of weights + 4 KiB of X per
+// slot), which caps the weight bytes a CU keeps in flight at 64 KiB; three tiles make a slot 6 + 4 KiB (0.67 activation bytes
+// per weight byte instead of 1.0).  It pays exactly where the triples also BALANCE over the 256 CUs:
+//   bit 1: triples that fit ONE per CU (193..256 workgroups; 7b qkv: 768 tiles -> 256) with a 3-slot ring — 72 KiB in flight on
+//          every CU, where the default's 384 pair-workgroups sit two on half the CUs and one on the other half:
+//          25.0 -> 20.2 us at 32 rows, 23.4 -> 20.3 at 24 (profiles/r04_q_kbench_gemv_nt3.txt);
+//   bit 0: triples all resident two per CU (385..512 workgroups of 80 KiB; 7b gate/up: 1376 tiles -> 459), 96 KiB in flight per
+//          CU: 37.6 -> 36.9 us at 32 rows, 36.9 -> 33.6 at 24.
+// Anything else keeps pairs: the 13b qkv (960 tiles -> 320 triples, 2 per CU on 160 CUs) measured 32.7 -> 40.8 us.
+// Same K partition (4 waves, no K-slices), so every row's bits are those of the other variants (checked on the device, same file).
+static int g_m32_nt3 = -1;
+static unsigned long g_m32_nt3_launches = 0;
+void set_gemv_m32_nt3(int v) { g_m32_nt3 = v; }
+unsigned long gemv_m32_nt3_launches() { return g_m32_nt3_launches; }
+static int gemv_m32_nt3_now() {
+    static const int env = getenv("VC_GEMV2_NT3") ? atoi(getenv("VC_GEMV2_NT3")) : 3;
+    return g_m32_nt3 >= 0 ? g_m32_nt3 : env;
+}
+
 template <bool FP8>
 static void launch_gemv_m32(const GemvArgs& a, int epilogue, hipStream_t s) {
     const int tiles = a.N / 16;
+    if constexpr (!FP8) {
+        const int nt3 = gemv_m32_nt3_now();
+        if (nt3 && a.ksplit <= 1) {
+            const int triples = (tiles + 2) / 3;
+            if ((nt3 & 2) && tiles > 512 && triples > 192 && triples <= 256) {
+                ++g_m32_nt3_launches;
+                launch_gemv_dma2<4, 3, 3, false>(a, epilogue, s);
+                return;
+            }
+            if ((nt3 & 1) && tiles > 512 && triples > 384 && triples <= 512) {
+                ++g_m32_nt3_launches;
+                launch_gemv_dma2<4, 3, 2, false>(a, epilogue, s);
+                return;
+            }
+        }
+    }
     static const int ks_env = getenv("VC_GEMV_KS") ? atoi(getenv("VC_GEMV_KS")) : -1;
     // VC_GEMV2_GEOM: tuning knob for the 513..768-tile class (7b qkv): 0 = 4 waves x 1 tile, 2-slot ring (3 workgroups/CU),
     // 1 = 4 waves x 2 tiles, 2-slot ring (2/CU, the pair shares the activation pieces; measured 28.3 vs 33.9 us at M = 24)

@@ -111,6 +111,8 @@ void launch_gemv(const GemvArgs& a, int epilogue, hipStream_t s);
 // which decode GEMV serves bf16 weights: 0 = per-wave rings (gemv_dma_kernel), 1 = workgroup-shared activation chunks
 // (gemv_wg_kernel); -1 = the process default (environment VC_GEMV_WG, read once).  Tests and tools/kbench.py switch it.
 void set_gemv_variant(int v);
+void set_gemv_m32_nt3(int v);   // -1 = VC_GEMV2_NT3 (default 3); see launch_gemv_m32
+unsigned long gemv_m32_nt3_launches();   // launches served by the three-tile form so far (tests)
 void set_gemv_wg_geom(const char* spec, int deep);   // tuning: "ntiles:K:ntw:ks,..." (empty = default), deep = -1 / 0 / 1
 bool gemv_wg_enabled();             // the workgroup-shared form serves bf16-weight GEMVs (variant 1)
 unsigned long gemv_wg_launches();   // launches served by the workgroup-shared form so far (tests)
