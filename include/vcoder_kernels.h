@@ -150,6 +150,11 @@ void vck_set_gemv_variant(int v);
  * default 3).  Results are bit-identical whichever is set. */
 void vck_set_gemv_m32_nt3(int v);
 unsigned long long vck_gemv_m32_nt3_launches(void);   /* launches the three-tile form has served (tests) */
+/* 17..32-row bf16 GEMV over 129..256-tile matrices (o_proj / down) as "virtual waves": 1 = 2 slices x 4 waves with tile pairs,
+ * 2 = 4 slices x 2 waves with tile quads, 0 = the 8-wave single-tile workgroup; -1 = the process default (environment
+ * VC_GEMV2_KVIRT).  Results are bit-identical whichever is set. */
+void vck_set_gemv_m32_kvirt(int v);
+unsigned long long vck_gemv_m32_kvirt_launches(void);
 void vck_set_gemv_wg_geom(const char* spec, int deep);   /* tuning: "ntiles:K:ntw:ks,..." per matrix shape; deep: -1 default */
 unsigned long long vck_gemv_wg_launches(void);   /* launches the workgroup-shared form has served (tests) */
 void vck_rmsnorm_split(const float* x, const int* row_idx, const float* w, uint16_t* y, int rows, int D, float eps, int ldy,

@@ -1366,8 +1366,41 @@ def check_gemv_m32_nt3(be, N, K, epi, norm=True, rows=(19, 29, 32), seed=0):
         be.lib.vck_set_gemv_variant(-1)
 
 
-def _wg_run_plain(be, c, M):
-    """one bf16 launch over the first M rows of a _wg_case without split-K buffers -> (float64 values, raw output, extras)"""
+def check_gemv_m32_kvirt(be, N, K, epi, rows=(19, 29, 32), seed=0):
+    """"virtual waves" (GemvArgs::kvirt; vck_set_gemv_m32_kvirt) for the 129..256-tile matrices of a 17..32-row step: 2 slices x 4
+    waves with tile pairs and 4 slices x 2 waves with tile quads must give the BITS of the 8-wave single-tile workgroup (the
+    finisher adds the hand-over partials in that workgroup's wave order), against float64, counters re-armed"""
+    assert 128 < N // 16 <= 256
+    be.lib.vck_set_gemv_variant(0)
+    be.lib.vck_gemv_m32_kvirt_launches.restype = ctypes.c_ulonglong
+    try:
+        rng = np.random.RandomState(seed)
+        c = _wg_case(be, rng, 32, N, K, epi, False, 0)
+        worst = 0.0
+        for M in rows:
+            be.lib.vck_set_gemv_m32_kvirt(0)
+            _, raw0, ex0 = _wg_run_plain(be, c, M, sk=c["sk"])
+            for mode in (1, 2):
+                be.lib.vck_set_gemv_m32_kvirt(mode)
+                n0 = be.lib.vck_gemv_m32_kvirt_launches()
+                val, raw1, ex1 = _wg_run_plain(be, c, M, sk=c["sk"])
+                assert be.lib.vck_gemv_m32_kvirt_launches() == n0 + 1, "the call was not served by the virtual-wave form"
+                assert not be.host_i32(c["sk"][1]).any(), "arrival counters must be re-armed"
+                assert np.array_equal(raw0, raw1), f"M{M} N{N} K{K} epi{epi} kvirt mode {mode}: bits differ from the 8-wave workgroup's"
+                if epi == 2:
+                    assert np.array_equal(ex0["xg"], ex1["xg"]) and np.array_equal(ex0["ssq"], ex1["ssq"])
+                    assert np.array_equal(ex1["untouched"], c["r0"][M:]), "residual rows beyond M were touched"
+                e = rel_err(val, c["ref"][:M])
+                assert e < (2 ** -8 if epi in (0, 3) else 2e-5), f"gemv m32 kvirt {mode} M{M} N{N} K{K} epi{epi}: rel err {e}"
+                worst = max(worst, e)
+        return worst
+    finally:
+        be.lib.vck_set_gemv_m32_kvirt(-1)
+        be.lib.vck_set_gemv_variant(-1)
+
+
+def _wg_run_plain(be, c, M, sk=None):
+    """one bf16 launch over the first M rows of a _wg_case (sk: the split-K buffers, or none) -> (float64 values, raw output, extras)"""
     N, K, epi, No = c["N"], c["K"], c["epi"], c["No"]
     X = np.full((32, K), 7.0, np.float32)
     X[:M] = c["hi"][:M]
@@ -1377,7 +1410,7 @@ def _wg_run_plain(be, c, M):
     ssq = np.zeros_like(c["ssq"])
     ssq[:M] = c["ssq"][:M]
     Xd, ssqd, gwd = be.bf16(X), (be.f32(ssq) if c["norm"] else None), (be.f32(c["gw"]) if c["gw"] is not None else None)
-    _gemv_full(be, Xd, c["Wp"], out, ssqd, ssq_out, gwd, xg_out, c["npart"], M, N, K, No, epi)
+    _gemv_full(be, Xd, c["Wp"], out, ssqd, ssq_out, gwd, xg_out, c["npart"], M, N, K, No, epi, sk=sk)
     o = be.host_f32(out)
     extra = None
     if epi == 2:

@@ -234,6 +234,13 @@ def test_gemv_m32_three_tiles_per_workgroup(be, N, K, epi):
     kc.check_gemv_m32_nt3(be, N, K, epi)
 
 
+@pytest.mark.parametrize("N,K,epi", [(4096, 4096, 2), (4096, 11008, 2), (16 * 131, 4096, 1)])
+def test_gemv_m32_virtual_waves(be, N, K, epi):
+    """VC_GEMV2_KVIRT / vck_set_gemv_m32_kvirt (opt-in, measured slower: profiles/r04_s_kbench_gemv_kvirt.txt) at the 7b o_proj /
+    down shapes: the cross-workgroup hand-over reproduces the 8-wave workgroup's bits on the device"""
+    kc.check_gemv_m32_kvirt(be, N, K, epi)
+
+
 def test_gemv_wg_is_race_free_and_bit_reproducible(be):
     """hand-placed counted vmcnt waits + one bare barrier per chunk: back-to-back launches must all give the first launch's bits"""
     import numpy as np

@@ -215,6 +215,13 @@ def test_gemv_m32_three_tiles_per_workgroup(be, N, K, epi):
     kc.check_gemv_m32_nt3(be, N, K, epi)
 
 
+@pytest.mark.parametrize("N,K,epi", [(4096, 704, 2), (16 * 131, 192, 2), (16 * 200, 1024, 1), (16 * 254, 320, 0)])
+def test_gemv_m32_virtual_waves(be, N, K, epi):
+    """GemvArgs::kvirt (opt-in): 2 x 4 and 4 x 2 waves over tile pairs / quads hand their partials over so that the finisher
+    adds them in the 8-wave workgroup's order — its bits, ragged tile groups, waves without a k-line and half lines included"""
+    kc.check_gemv_m32_kvirt(be, N, K, epi)
+
+
 @pytest.mark.parametrize("N,K,epi,G,ks", [(64, 512, 0, False, 0), (48, 320, 1, False, 2), (96, 1024, 3, False, 3), (32, 512, 2, False, 0),
                                           (64, 512, 0, True, 0), (48, 1024, 1, True, 4), (64, 256, 3, True, 0)])
 def test_gemv_wg_rows_agree(be, N, K, epi, G, ks):

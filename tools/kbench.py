@@ -255,6 +255,46 @@ def bench_gemv_nt3():
     lib.vck_set_gemv_m32_nt3(-1)
 
 
+def bench_gemv_kvirt():
+    """17..32-row bf16 GEMV over the 256-tile matrices (7b o_proj / down, the engine's residual epilogue with the next norm folded):
+    the 8-wave single-tile workgroup vs "virtual waves" (vck_set_gemv_m32_kvirt 1: tile pairs, 2: tile quads); same bits?"""
+    for (N, K, name) in [(4096, 4096, "o"), (4096, 11008, "down")]:
+        X = bf16(32, K)
+        Ws = [bf16(N * K, scale=0.02) for _ in range(8)]
+        npart = (4096 // 16 + 15) // 16 * 16
+        ssq = torch.zeros(32, npart, device=dev)
+        gw = torch.rand(N, device=dev) + 0.5
+        xg = torch.zeros((32, N), dtype=torch.bfloat16, device=dev)
+        nsk = 8 * (N // 16) * 2 * 256
+        scratch = torch.zeros(nsk, device=dev)
+        counters = torch.zeros(N // 16 * 2, dtype=torch.int32, device=dev)
+        r0 = torch.randn(32, N, device=dev)
+        out = r0.clone()
+        it = [0]
+
+        def f():
+            it[0] += 1
+            lib.vck_gemv_full(P(X), P(Ws[it[0] % 8]), None, P(out), None, P(ssq), P(gw), P(xg), npart, C.c_float(1e-5), P(scratch),
+                              C.c_ulonglong(nsk), P(counters), N // 16 * 2, 0, M, N, K, N, 2, 0, None)
+        for M in (24, 32):
+            res = {}
+            for mode in (0, 1, 2):
+                lib.vck_set_gemv_m32_kvirt(mode)
+                us = timeit(f, iters=40)
+                out.copy_(r0)
+                it[0] = 7
+                f()
+                torch.cuda.synchronize()
+                res[mode] = (out.clone(), xg.clone(), ssq.clone())
+                print(f"gemv_kvirt M{M} {name:5s} mode {mode}: {us:7.1f} us  {2 * N * K / us / 1e3:7.1f} GB/s", flush=True)
+            same = [all(torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a.view(torch.int16),
+                                    b.view(torch.int32) if b.dtype == torch.float32 else b.view(torch.int16))
+                        for a, b in zip(res[0], res[m_])) for m_ in (1, 2)]
+            print(f"gemv_kvirt M{M} {name:5s} same bits as the 8-wave workgroup: pairs {same[0]}, quads {same[1]}; counters re-armed: "
+                  f"{not bool(counters.any())}", flush=True)
+    lib.vck_set_gemv_m32_kvirt(-1)
+
+
 def bench_gemv_rows8():
     """W8A16 weights at 17..32 rows: gate/up (7b, 13b) and qkv, consumer form (VC_GEMV8_NT4=0/1 switches the gate/up geometry)"""
     for M in (16, 24, 32):
@@ -507,6 +547,8 @@ if __name__ == "__main__":
         bench_gemv_wg()
     if "gemv_nt3" in what:
         bench_gemv_nt3()
+    if "gemv_kvirt" in what:
+        bench_gemv_kvirt()
     if "dattn_split" in what:
         bench_dattn_split()
     if "dattn_kv8" in what:
@@ -514,4 +556,4 @@ if __name__ == "__main__":
     for w in what:
         {"gemm": bench_gemm, "gemv": bench_gemv, "attn": bench_attn, "dattn": bench_dattn,
          "gemv_fp8": lambda: None, "gemv13": lambda: None, "gemv_pair": lambda: None, "gemv_rows": lambda: None,
-         "dattn_rows": lambda: None, "gemm_f8": lambda: None, "gemv_rows8": lambda: None, "gemv_wg": lambda: None, "gemv_nt3": lambda: None, "dattn_split": lambda: None, "dattn_kv8": lambda: None}[w]()
+         "dattn_rows": lambda: None, "gemm_f8": lambda: None, "gemv_rows8": lambda: None, "gemv_wg": lambda: None, "gemv_nt3": lambda: None, "gemv_kvirt": lambda: None, "dattn_split": lambda: None, "dattn_kv8": lambda: None}[w]()

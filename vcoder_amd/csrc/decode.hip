@@ -238,12 +238,16 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
     __shared__ float ss_part[WAVES][16 * MG];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntiles = p.N >> 4;
-    const int KS = p.ksplit > 1 ? p.ksplit : 1;
+    const int KV = p.kvirt > 1 ? p.kvirt : 1;   // virtual-wave slices (GemvArgs::kvirt)
+    const int KS = KV > 1 ? KV : (p.ksplit > 1 ? p.ksplit : 1);
     const int ks = (int)blockIdx.x % KS;
     const int nt0 = ((int)blockIdx.x / KS) * NT;
     const int nkt = p.K >> KSH;
     const int nit = (nkt + KPI - 1) / KPI;   // slots' worth of k-tiles in the matrix
-    const int it0 = (int)((long)ks * nit / KS), it1 = (int)((long)(ks + 1) * nit / KS);  // this workgroup's share of K
+    // this workgroup's share of K: a contiguous slice (ksplit), or — virtual waves — all of K at the stride of WAVES * KV waves
+    const int it0 = KV > 1 ? 0 : (int)((long)ks * nit / KS), it1 = KV > 1 ? nit : (int)((long)(ks + 1) * nit / KS);
+    const int vwave = KV > 1 ? wave + WAVES * ks : wave;   // this wave's place among the waves that interleave K
+    const int vstride = WAVES * KV;
     const int m = lane & 15, g = lane >> 4;
     // precision mode "split" (p.split_rows = G in {8, 16}): X holds G + M rows — rows [0, M) the bf16 hi parts of the M
     // activation rows, rows [G, G + M) their lo parts (x = hi + lo) — and the two partial products of a row meet in the
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
     const bool half_line = (p.K * 2) % 128 != 0;                             // bf16, odd k-tile count: 64 valid bytes in it
     auto issue = [&](int i, int slot) {
         char* dst = my + slot * SLOT;
-        const int is = it0 + wave + i * WAVES;                               // slot index along K = line index of X
+        const int is = it0 + vwave + i * vstride;                            // slot index along K = line index of X
 #pragma unroll
         for (int kk = 0; kk < KPI; ++kk) {
             const size_t kt = (size_t)min(is * KPI + kk, nkt - 1);           // an odd tail re-reads the last tile
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
             u32x4 w[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) w[t] = ld16(sl + (kk * NT + t) * 1024);
-            const bool tail = KPI > 1 && (it0 + wave + i * WAVES) * KPI + kk >= nkt;
+            const bool tail = KPI > 1 && (it0 + vwave + i * vstride) * KPI + kk >= nkt;
             u32x4 x0[MG], x1[MG];
 #pragma unroll
             for (int q = 0; q < MG; ++q) {
@@ -347,7 +351,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
         wait_lgkmcnt<0>();  // the slot's fragment reads have retired before it is re-armed
         wave_lds_fence();
     };
-    const int cnt = max(0, (it1 - it0 - wave + WAVES - 1) / WAVES);  // slots of this wave (wave-uniform)
+    const int cnt = max(0, (it1 - it0 - vwave + vstride - 1) / vstride);  // slots of this wave (wave-uniform)
     const int primed = min(cnt, R);
     // 1/rms of the rows from the producer's partials: the register loads are issued BEFORE the ring is primed, so the wait
     // the compiler places at their first use leaves every DMA in flight (vmcnt counts in order)
@@ -447,20 +451,42 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
         // MI355X_MICROARCH.md "valid forms") — an agent-scope fence here writes back / invalidates the XCD's whole L2 and
         // measured 4-8x slower launches.  The scratch is laid out for two row groups whatever MG is.
         const size_t unit = (size_t)nt * 2 + fq;
-        float* mine = p.sk_scratch + (((size_t)ks * ntiles * 2 + unit) * 64 + lane) * 4;
+        auto entry = [&](int e) { return p.sk_scratch + (((size_t)e * ntiles * 2 + unit) * 64 + lane) * 4; };
+        if (KV > 1 && ks > 0) {
+            // virtual waves: slices behind the first hand over every wave's partial UNSUMMED (entries 1 + (ks-1)*WAVES + w)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) st_agent(mine + e, v[e]);
+            for (int w = 0; w < WAVES; ++w) {
+                const f32x4 pw = ld16f(red + (((w * NT + ft) * MG + fq) * 64 + lane) * 4);
+                float* mine = entry(1 + (ks - 1) * WAVES + w);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) st_agent(mine + e, pw[e]);
+            }
+        } else {
+            float* mine = entry(ks);   // (virtual waves, slice 0: entry 0 = its waves summed in order, the head of the sequence)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st_agent(mine + e, v[e]);
+        }
         wait_vmcnt<0>();  // the write-through stores have been acknowledged before the arrival is counted
         wave_lds_fence(); // (a wave issues as one on the hardware; the emulator's lane fibers must all have stored before lane 0 counts)
         unsigned arrived = 0;
         if (lane == 0) arrived = atomic_inc_agent(&p.sk_counters[unit]);
         arrived = shfl(arrived, 0);
         if (arrived != (unsigned)(KS - 1)) continue;
-        v = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < KS; ++k) {
-            const float* q = p.sk_scratch + (((size_t)k * ntiles * 2 + unit) * 64 + lane) * 4;
+        if (KV > 1) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += ld_agent(q + e);
+            for (int e = 0; e < 4; ++e) v[e] = ld_agent(entry(0) + e);
+            for (int k = 1; k < 1 + (KV - 1) * WAVES; ++k) {
+                const float* q = entry(k);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += ld_agent(q + e);
+            }
+        } else {
+            v = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < KS; ++k) {
+                const float* q = entry(k);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += ld_agent(q + e);
+            }
         }
         if (lane == 0) st_agent_u32(&p.sk_counters[unit], 0u);  // re-armed for the next launch (stream order)
     }
@@ -706,7 +732,7 @@ static void launch_gemv_w(const GemvArgs& a, int epi, hipStream_t s) {
 
 template <int WAVES, int NT, int R, bool FP8, int XP>
 static void launch_gemv_dma_x(const GemvArgs& a, int epi, hipStream_t s) {
-    const dim3 grid(((a.N / 16 + NT - 1) / NT) * (a.ksplit > 1 ? a.ksplit : 1)), block(WAVES * 64);
+    const dim3 grid(((a.N / 16 + NT - 1) / NT) * (a.kvirt > 1 ? a.kvirt : a.ksplit > 1 ? a.ksplit : 1)), block(WAVES * 64);
     constexpr size_t shmem = (size_t)WAVES * R * ((FP8 ? 1 : 2) * NT + XP) * 1024;
     // + the kernel's static ss_part[WAVES][16 * MG] floats
     static_assert(shmem + WAVES * 16 * ((XP + 1) / 2) * 4 <= 160 * 1024, "ring exceeds the LDS of a CU");
@@ -767,9 +793,41 @@ static int gemv_m32_nt3_now() {
     return g_m32_nt3 >= 0 ? g_m32_nt3 : env;
 }
 
+// VC_GEMV2_KVIRT / set_gemv_m32_kvirt (bf16 weights, 17..32 rows, 129..256 tiles: 7b o_proj / down; default 0 = off): the
+// 8-wave workgroup of that class (one tile, 2 activation bytes per weight byte, 48 KiB of weights in flight per CU) as "virtual
+// waves" — GemvArgs::kvirt — so that tiles can be grouped without leaving CUs idle and without changing a bit:
+//   1: 2 slices x 4 waves, tile PAIRS  (256 workgroups, 4-slot rings: 64 KiB in flight, 1.0 activation bytes per weight byte)
+//   2: 4 slices x 2 waves, tile QUADS  (256 workgroups, 5-slot rings: 80 KiB in flight, 0.5)
+static int g_m32_kvirt = -1;
+static unsigned long g_m32_kvirt_launches = 0;
+void set_gemv_m32_kvirt(int v) { g_m32_kvirt = v; }
+unsigned long gemv_m32_kvirt_launches() { return g_m32_kvirt_launches; }
+static int gemv_m32_kvirt_now() {
+    static const int env = getenv("VC_GEMV2_KVIRT") ? atoi(getenv("VC_GEMV2_KVIRT")) : 0;
+    return g_m32_kvirt >= 0 ? g_m32_kvirt : env;
+}
+
 template <bool FP8>
 static void launch_gemv_m32(const GemvArgs& a, int epilogue, hipStream_t s) {
     const int tiles = a.N / 16;
+    if constexpr (!FP8) {
+        const int kvm = gemv_m32_kvirt_now();
+        if (kvm && tiles > 128 && tiles <= 256 && a.ksplit <= 1 && !a.split_rows && !a.ssq_in && a.sk_scratch && a.sk_counters) {
+            // only with buffers of DECLARED capacity (the entry count differs from the K-slice forms the historical size assumes)
+            const size_t cap = a.sk_scratch_floats;
+            const int ncnt = a.sk_counters_n;
+            const int kv = kvm == 2 ? 4 : 2, wv = 8 / kv;
+            if ((size_t)(1 + (kv - 1) * wv) * tiles * 2 * 256 <= cap && tiles * 2 <= ncnt) {
+                GemvArgs b = a;
+                b.kvirt = kv;
+                b.ksplit = 0;
+                ++g_m32_kvirt_launches;
+                if (kvm == 2) launch_gemv_dma2<2, 4, 5, false>(b, epilogue, s);
+                else launch_gemv_dma2<4, 2, 4, false>(b, epilogue, s);
+                return;
+            }
+        }
+    }
     if constexpr (!FP8) {
         const int nt3 = gemv_m32_nt3_now();
         if (nt3 && a.ksplit <= 1) {

@@ -98,6 +98,11 @@ struct GemvArgs {
     float* sk_scratch;       // [ksplit][N/16][2 row groups][256] or nullptr
     unsigned* sk_counters;   // [N/16][2 row groups], zero between launches
     int ksplit;              // 0/1 = off (launcher decides when the two buffers are given)
+    // "virtual waves" (set by the launcher only; 0/1 = off): `kvirt` workgroups of W waves share a tile group and take the k-lines
+    // that waves s*W .. s*W+W-1 of ONE workgroup of kvirt*W waves would take, and the finisher adds the partials in exactly that
+    // workgroup's order (slice 0's waves pre-summed — the head of the sequence — then every further wave's partial one by one):
+    // the bits of the kvirt*W-wave geometry from workgroups small enough to pair tiles.  sk_scratch: [1 + (kvirt-1)*W] entries.
+    int kvirt;
     int w_cached;            // 1: stream the weights with the default cache policy instead of non-temporal (VC_GEMV_WCACHED)
     // precision mode "split" (0 = off; G = 8 for M <= 8, G = 16 for M <= 16): X is [G + M, K] — rows [0, M) the bf16 hi parts
     // of the activation rows, rows [G, G + M) the lo parts (x = hi + lo, ~16 mantissa bits) — and out[m] = (hi[m] + lo[m]) . W.
@@ -113,6 +118,8 @@ void launch_gemv(const GemvArgs& a, int epilogue, hipStream_t s);
 void set_gemv_variant(int v);
 void set_gemv_m32_nt3(int v);   // -1 = VC_GEMV2_NT3 (default 3); see launch_gemv_m32
 unsigned long gemv_m32_nt3_launches();   // launches served by the three-tile form so far (tests)
+void set_gemv_m32_kvirt(int v);  // -1 = VC_GEMV2_KVIRT (default 0); see launch_gemv_m32
+unsigned long gemv_m32_kvirt_launches();
 void set_gemv_wg_geom(const char* spec, int deep);   // tuning: "ntiles:K:ntw:ks,..." (empty = default), deep = -1 / 0 / 1
 bool gemv_wg_enabled();             // the workgroup-shared form serves bf16-weight GEMVs (variant 1)
 unsigned long gemv_wg_launches();   // launches served by the workgroup-shared form so far (tests)
