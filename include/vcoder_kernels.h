@@ -154,6 +154,11 @@ unsigned long long vck_gemv_m32_nt3_launches(void);   /* launches the three-tile
  * 2 = 4 slices x 2 waves with tile quads, 0 = the 8-wave single-tile workgroup; -1 = the process default (environment
  * VC_GEMV2_KVIRT).  Results are bit-identical whichever is set. */
 void vck_set_gemv_m32_kvirt(int v);
+/* experiment: NT = ceil(tiles / 256) tiles per workgroup for bf16 matrices of more than 512 tiles, one deep-ringed workgroup per
+ * CU; bit NT of the mask enables the class (NT in 3, 4, 6, 7, 8); -1 = the process default (environment VC_GEMV_WIDE, default 0).
+ * Results are bit-identical whichever is set. */
+void vck_set_gemv_wide(int v);
+unsigned long long vck_gemv_wide_launches(void);
 unsigned long long vck_gemv_m32_kvirt_launches(void);
 void vck_set_gemv_wg_geom(const char* spec, int deep);   /* tuning: "ntiles:K:ntw:ks,..." per matrix shape; deep: -1 default */
 unsigned long long vck_gemv_wg_launches(void);   /* launches the workgroup-shared form has served (tests) */

@@ -1366,6 +1366,32 @@ def check_gemv_m32_nt3(be, N, K, epi, norm=True, rows=(19, 29, 32), seed=0):
         be.lib.vck_set_gemv_variant(-1)
 
 
+def check_gemv_wide(be, N, K, epi, rows, seed=0):
+    """the "wide" geometry experiment (vck_set_gemv_wide: ceil(tiles / 256) tiles per 4-wave workgroup, deep ring): bit for bit
+    the default geometry's result at every row count, and within tolerance of float64"""
+    be.lib.vck_set_gemv_variant(0)
+    be.lib.vck_gemv_wide_launches.restype = ctypes.c_ulonglong
+    try:
+        rng = np.random.RandomState(seed)
+        c = _wg_case(be, rng, 32, N, K, epi, True, 0)
+        worst = 0.0
+        for M in rows:
+            be.lib.vck_set_gemv_wide(0)
+            _, raw0, _ = _wg_run_plain(be, c, M)
+            be.lib.vck_set_gemv_wide(0x1d8)
+            n0 = be.lib.vck_gemv_wide_launches()
+            val, raw1, _ = _wg_run_plain(be, c, M)
+            assert be.lib.vck_gemv_wide_launches() == n0 + 1, f"M{M} N{N} epi{epi}: not served by the wide geometry"
+            assert np.array_equal(raw0, raw1), f"M{M} N{N} K{K} epi{epi}: the wide geometry changed the bits"
+            e = rel_err(val, c["ref"][:M])
+            assert e < (2 ** -8 if epi in (0, 3) else 2e-5), f"gemv wide M{M} N{N} K{K} epi{epi}: rel err {e}"
+            worst = max(worst, e)
+        return worst
+    finally:
+        be.lib.vck_set_gemv_wide(-1)
+        be.lib.vck_set_gemv_variant(-1)
+
+
 def check_gemv_m32_kvirt(be, N, K, epi, rows=(19, 29, 32), seed=0):
     """"virtual waves" (GemvArgs::kvirt; vck_set_gemv_m32_kvirt) for the 129..256-tile matrices of a 17..32-row step: 2 slices x 4
     waves with tile pairs and 4 slices x 2 waves with tile quads must give the BITS of the 8-wave single-tile workgroup (the

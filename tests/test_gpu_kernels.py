@@ -234,6 +234,13 @@ def test_gemv_m32_three_tiles_per_workgroup(be, N, K, epi):
     kc.check_gemv_m32_nt3(be, N, K, epi)
 
 
+@pytest.mark.parametrize("N,K,epi,rows", [(12288, 4096, 0, (8, 16)), (15360, 5120, 0, (8, 16, 24, 32)), (22016, 4096, 3, (8, 16, 24, 32)),
+                                          (27648, 5120, 3, (8, 16, 32)), (32000, 4096, 1, (8, 16, 24))])
+def test_gemv_wide_geometry(be, N, K, epi, rows):
+    """VC_GEMV_WIDE (opt-in experiment) at the true 7b / 13b shapes: ceil(tiles / 256) tiles per workgroup, the default's bits"""
+    kc.check_gemv_wide(be, N, K, epi, rows)
+
+
 @pytest.mark.parametrize("N,K,epi", [(4096, 4096, 2), (4096, 11008, 2), (16 * 131, 4096, 1)])
 def test_gemv_m32_virtual_waves(be, N, K, epi):
     """VC_GEMV2_KVIRT / vck_set_gemv_m32_kvirt (opt-in, measured slower: profiles/r04_s_kbench_gemv_kvirt.txt) at the 7b o_proj /

@@ -215,6 +215,14 @@ def test_gemv_m32_three_tiles_per_workgroup(be, N, K, epi):
     kc.check_gemv_m32_nt3(be, N, K, epi)
 
 
+@pytest.mark.parametrize("N,K,epi,rows", [(16 * 700, 192, 0, (5, 13)), (16 * 900, 128, 0, (8, 16, 19, 32)),
+                                          (16 * 1376, 128, 3, (3, 16, 24, 29)), (16 * 1727, 64, 3, (8, 9, 17, 32)),
+                                          (32000, 128, 1, (8, 12, 20))])
+def test_gemv_wide_geometry(be, N, K, epi, rows):
+    """the opt-in one-workgroup-per-CU geometries (3 / 4 / 6 / 7 / 8 tiles per workgroup) give the default geometry's bits"""
+    kc.check_gemv_wide(be, N, K, epi, rows)
+
+
 @pytest.mark.parametrize("N,K,epi", [(4096, 704, 2), (16 * 131, 192, 2), (16 * 200, 1024, 1), (16 * 254, 320, 0)])
 def test_gemv_m32_virtual_waves(be, N, K, epi):
     """GemvArgs::kvirt (opt-in): 2 x 4 and 4 x 2 waves over tile pairs / quads hand their partials over so that the finisher

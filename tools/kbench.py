@@ -255,6 +255,38 @@ def bench_gemv_nt3():
     lib.vck_set_gemv_m32_nt3(-1)
 
 
+def bench_gemv_wide():
+    """ring-kernel GEMV, default geometry vs the "wide" one (vck_set_gemv_wide 0x1d8: ceil(tiles / 256) tiles per workgroup, one deep
+    ring per CU) on every > 512-tile matrix of the 7b and 13b models at 8 / 16 / 24 / 32 rows; same bits?"""
+    for (N, K, epi, name) in [(12288, 4096, 0, "7b qkv"), (22016, 4096, 3, "7b gate-up"), (32000, 4096, 1, "7b lm_head"),
+                              (15360, 5120, 0, "13b qkv"), (27648, 5120, 3, "13b gate-up")]:
+        X = bf16(32, K)
+        Ws = [bf16(N * K, scale=0.02) for _ in range(6)]
+        ldo = N // 2 if epi == 3 else N
+        npart = (K // 16 + 15) // 16 * 16
+        ssq = torch.rand(32, npart, device=dev)
+        it = [0]
+        for M in (8, 16, 24, 32):
+            outs, t = {}, {}
+            for wide in (0, 0x1d8):
+                lib.vck_set_gemv_wide(wide)
+                out = torch.zeros((32, ldo), dtype=torch.float32 if epi == 1 else torch.bfloat16, device=dev)
+
+                def f():
+                    it[0] += 1
+                    lib.vck_gemv_ex(P(X), P(Ws[it[0] % 6]), None, P(out), P(ssq), None, None, None, npart, C.c_float(1e-5),
+                                    None, None, 0, M, N, K, ldo, epi, None)
+                t[wide] = timeit(f, iters=40)
+                it[0] = 5
+                f()
+                torch.cuda.synchronize()
+                outs[wide] = out.clone()
+            same = torch.equal(outs[0].view(torch.int32 if epi == 1 else torch.int16), outs[0x1d8].view(torch.int32 if epi == 1 else torch.int16))
+            print(f"gemv_wide M{M:2d} {name:12s}: default {t[0]:6.1f} us ({2 * N * K / t[0] / 1e3:6.0f} GB/s)  wide {t[0x1d8]:6.1f} us "
+                  f"({2 * N * K / t[0x1d8] / 1e3:6.0f} GB/s)  same bits {same}", flush=True)
+    lib.vck_set_gemv_wide(-1)
+
+
 def bench_gemv_kvirt():
     """17..32-row bf16 GEMV over the 256-tile matrices (7b o_proj / down, the engine's residual epilogue with the next norm folded):
     the 8-wave single-tile workgroup vs "virtual waves" (vck_set_gemv_m32_kvirt 1: tile pairs, 2: tile quads); same bits?"""
@@ -549,6 +581,8 @@ if __name__ == "__main__":
         bench_gemv_nt3()
     if "gemv_kvirt" in what:
         bench_gemv_kvirt()
+    if "gemv_wide" in what:
+        bench_gemv_wide()
     if "dattn_split" in what:
         bench_dattn_split()
     if "dattn_kv8" in what:
@@ -556,4 +590,4 @@ if __name__ == "__main__":
     for w in what:
         {"gemm": bench_gemm, "gemv": bench_gemv, "attn": bench_attn, "dattn": bench_dattn,
          "gemv_fp8": lambda: None, "gemv13": lambda: None, "gemv_pair": lambda: None, "gemv_rows": lambda: None,
-         "dattn_rows": lambda: None, "gemm_f8": lambda: None, "gemv_rows8": lambda: None, "gemv_wg": lambda: None, "gemv_nt3": lambda: None, "gemv_kvirt": lambda: None, "dattn_split": lambda: None, "dattn_kv8": lambda: None}[w]()
+         "dattn_rows": lambda: None, "gemm_f8": lambda: None, "gemv_rows8": lambda: None, "gemv_wg": lambda: None, "gemv_nt3": lambda: None, "gemv_kvirt": lambda: None, "gemv_wide": lambda: None, "dattn_split": lambda: None, "dattn_kv8": lambda: None}[w]()

@@ -1056,6 +1056,59 @@ static void launch_gemv_wg(const GemvArgs& a0, int epi, hipStream_t s) {
     else launch_gemv_wg_n<1>(a, epi, s);
 }
 
+// ---- "wide" geometry of the ring kernel (experiment, off by default: VC_GEMV_WIDE / set_gemv_wide) -------------------------------
+// What the three-tile form taught (profiles/r04_q_kbench_gemv_nt3.txt): ONE deep-ringed workgroup per CU, all 256 CUs holding
+// exactly one, beat every geometry with more, unevenly spread workgroups.  This generalises it to the matrices with more than 512
+// tiles: NT = ceil(tiles / 256) tiles per 4-wave workgroup (>= 218 workgroups, i.e. >= 85 % of the CUs), the ring as deep as
+// 160 KiB allow.  The K partition stays 4 waves without K-slices, so the bits are those of the default geometry.  Bit NT of the
+// knob enables the class (0x1d8 = all of 3, 4, 6, 7, 8):
+//   NT 3: 7b qkv (768 tiles -> 256 workgroups), <= 16 rows (17..32 rows take it through VC_GEMV2_NT3 already)
+//   NT 4: 13b qkv (960 -> 240)        NT 6: 7b gate/up (1376 -> 230)        NT 7: 13b gate/up (1728 -> 247)
+//   NT 8: lm_head (2000 -> 250), <= 24 rows (a 32-row slot of 8 tiles does not fit twice)
+static int g_gemv_wide = -1;
+static unsigned long g_gemv_wide_launches = 0;
+void set_gemv_wide(int v) { g_gemv_wide = v; }
+unsigned long gemv_wide_launches() { return g_gemv_wide_launches; }
+static int gemv_wide_now() {
+    static const int env = getenv("VC_GEMV_WIDE") ? (int)strtol(getenv("VC_GEMV_WIDE"), nullptr, 0) : 0;
+    return g_gemv_wide >= 0 ? g_gemv_wide : env;
+}
+template <int NT, int R, int XP, int EPI>
+static void launch_gemv_wide1(const GemvArgs& a, hipStream_t s) {
+    constexpr int WAVES = 4;
+    const dim3 grid((a.N / 16 + NT - 1) / NT), block(WAVES * 64);
+    constexpr size_t shmem = (size_t)WAVES * R * (2 * NT + XP) * 1024;
+    static_assert(shmem + WAVES * 16 * ((XP + 1) / 2) * 4 <= 160 * 1024, "ring exceeds the LDS of a CU");
+    static bool once = false;
+    if (!once) {
+        allow_big_lds(gemv_dma_kernel<WAVES, NT, R, EPI, false, XP>, shmem);
+        once = true;
+    }
+    VC_LAUNCH((gemv_dma_kernel<WAVES, NT, R, EPI, false, XP>), grid, block, shmem, s, a);
+}
+static bool launch_gemv_wide(const GemvArgs& a, int epi, hipStream_t s) {
+    const int wide = gemv_wide_now();
+    if (!wide || a.wscale || a.ksplit > 1 || a.kvirt > 1 || a.split_rows) return false;
+    const int tiles = a.N / 16;
+    if (tiles <= 512) return false;
+    const int nt = (tiles + 255) / 256;
+    if (nt > 8 || !((wide >> nt) & 1) || (tiles + nt - 1) / nt < 218) return false;
+    const int xr = x_rows(a), xp = xr <= 8 ? 1 : xr <= 16 ? 2 : xr <= 24 ? 3 : 4;
+#define VC_WIDE(NT_, R_, XP_, E_)                      \
+    if (nt == NT_ && xp == XP_ && epi == E_) {         \
+        launch_gemv_wide1<NT_, R_, XP_, E_>(a, s);     \
+        ++g_gemv_wide_launches;                        \
+        return true;                                   \
+    }
+    VC_WIDE(3, 5, 1, GEMV_BF16) VC_WIDE(3, 4, 2, GEMV_BF16)
+    VC_WIDE(4, 4, 1, GEMV_BF16) VC_WIDE(4, 3, 2, GEMV_BF16) VC_WIDE(4, 3, 3, GEMV_BF16) VC_WIDE(4, 3, 4, GEMV_BF16)
+    VC_WIDE(6, 3, 1, GEMV_SWIGLU) VC_WIDE(6, 2, 2, GEMV_SWIGLU) VC_WIDE(6, 2, 3, GEMV_SWIGLU) VC_WIDE(6, 2, 4, GEMV_SWIGLU)
+    VC_WIDE(7, 2, 1, GEMV_SWIGLU) VC_WIDE(7, 2, 2, GEMV_SWIGLU) VC_WIDE(7, 2, 3, GEMV_SWIGLU) VC_WIDE(7, 2, 4, GEMV_SWIGLU)
+    VC_WIDE(8, 2, 1, GEMV_F32) VC_WIDE(8, 2, 2, GEMV_F32) VC_WIDE(8, 2, 3, GEMV_F32)
+#undef VC_WIDE
+    return false;
+}
+
 void launch_gemv(const GemvArgs& a0, int epilogue, hipStream_t s) {
     static const int w_cached = getenv("VC_GEMV_WCACHED") ? atoi(getenv("VC_GEMV_WCACHED")) : 0;
     GemvArgs a = a0;
@@ -1073,6 +1126,7 @@ void launch_gemv(const GemvArgs& a0, int epilogue, hipStream_t s) {
         a.sk_counters = nullptr;
         a.ksplit = 0;
     }
+    if (launch_gemv_wide(a, epilogue, s)) return;
     if (a.wscale) launch_gemv_f<true>(a, epilogue, s);
     else launch_gemv_f<false>(a, epilogue, s);
 }

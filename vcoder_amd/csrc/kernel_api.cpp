@@ -225,6 +225,8 @@ VCK_EXPORT void vck_set_gemv_variant(int v) { set_gemv_variant(v); }
 VCK_EXPORT void vck_set_gemv_m32_nt3(int v) { set_gemv_m32_nt3(v); }
 VCK_EXPORT unsigned long long vck_gemv_m32_nt3_launches() { return gemv_m32_nt3_launches(); }
 VCK_EXPORT void vck_set_gemv_m32_kvirt(int v) { set_gemv_m32_kvirt(v); }
+VCK_EXPORT void vck_set_gemv_wide(int v) { set_gemv_wide(v); }
+VCK_EXPORT unsigned long long vck_gemv_wide_launches() { return gemv_wide_launches(); }
 VCK_EXPORT unsigned long long vck_gemv_m32_kvirt_launches() { return gemv_m32_kvirt_launches(); }
 VCK_EXPORT void vck_set_gemv_wg_geom(const char* spec, int deep) { set_gemv_wg_geom(spec, deep); }
 VCK_EXPORT unsigned long long vck_gemv_wg_launches() { return gemv_wg_launches(); }

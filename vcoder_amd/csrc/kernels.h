@@ -118,6 +118,8 @@ void launch_gemv(const GemvArgs& a, int epilogue, hipStream_t s);
 void set_gemv_variant(int v);
 void set_gemv_m32_nt3(int v);   // -1 = VC_GEMV2_NT3 (default 3); see launch_gemv_m32
 unsigned long gemv_m32_nt3_launches();   // launches served by the three-tile form so far (tests)
+void set_gemv_wide(int v);       // -1 = VC_GEMV_WIDE (default 0); bit NT enables the NT-tiles-per-workgroup class (launch_gemv_wide)
+unsigned long gemv_wide_launches();
 void set_gemv_m32_kvirt(int v);  // -1 = VC_GEMV2_KVIRT (default 0); see launch_gemv_m32
 unsigned long gemv_m32_kvirt_launches();
 void set_gemv_wg_geom(const char* spec, int deep);   // tuning: "ntiles:K:ntw:ks,..." (empty = default), deep = -1 / 0 / 1
