@@ -1,6 +1,7 @@
 """`-m gpu`: every HIP kernel at the TRUE shapes of VCoder-DS LLaVA-1.5-7b / CLIP ViT-L/14@336, called through
 the C ABI of libvcoder_hip.so (include/vcoder_kernels.h) and compared with the oracle."""
 import ctypes
+import os
 
 import pytest
 
@@ -234,6 +235,14 @@ def test_gemv_m32_three_tiles_per_workgroup(be, N, K, epi):
     kc.check_gemv_m32_nt3(be, N, K, epi)
 
 
+# Kernel forms that are OFF by default and have not been through a device run of this suite yet (built after the round's GPU
+# budget was spent; emulator-checked): their device tests run when VC_TEST_EXPERIMENTS=1 (tools/gpu/r05_a.sh sets it), so that an
+# experiment cannot stop the driver's `-x` run of the product's tests.
+experiment = pytest.mark.skipif(os.environ.get("VC_TEST_EXPERIMENTS", "0") != "1",
+                                reason="opt-in kernel experiment: set VC_TEST_EXPERIMENTS=1 (tools/gpu/r05_a.sh)")
+
+
+@experiment
 @pytest.mark.parametrize("N,K,epi,rows", [(12288, 4096, 0, (8, 16)), (15360, 5120, 0, (8, 16, 24, 32)), (22016, 4096, 3, (8, 16, 24, 32)),
                                           (27648, 5120, 3, (8, 16, 32)), (32000, 4096, 1, (8, 16, 24))])
 def test_gemv_wide_geometry(be, N, K, epi, rows):
@@ -241,6 +250,7 @@ def test_gemv_wide_geometry(be, N, K, epi, rows):
     kc.check_gemv_wide(be, N, K, epi, rows)
 
 
+@experiment
 @pytest.mark.parametrize("N,K,epi", [(4096, 4096, 2), (4096, 11008, 2), (16 * 131, 4096, 1)])
 def test_gemv_m32_virtual_waves(be, N, K, epi):
     """VC_GEMV2_KVIRT / vck_set_gemv_m32_kvirt (opt-in, measured slower: profiles/r04_s_kbench_gemv_kvirt.txt) at the 7b o_proj /
