@@ -830,7 +830,7 @@ static void launch_gemv_m32(const GemvArgs& a, int epilogue, hipStream_t s) {
     }
     if constexpr (!FP8) {
         const int nt3 = gemv_m32_nt3_now();
-        if (nt3 && a.ksplit <= 1) {
+        if (nt3 && a.ksplit <= 1 && !a.split_rows) {   // (hi / lo operand rows keep the pair geometry they were validated on)
             const int triples = (tiles + 2) / 3;
             if ((nt3 & 2) && tiles > 512 && triples > 192 && triples <= 256) {
                 ++g_m32_nt3_launches;
