@@ -217,7 +217,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
 // fragment-shaped gather (16 rows x 64 B per instruction).  The LDS image of a piece is lane-linear [8 rows][8 chunks of
 // 16 B]; the chunk a lane fetches is XOR-swizzled by (row >> 1) & 7 on the SOURCE side (the DMA writes linearly), so the
 // 16 lanes of a ds_read_b128 group — 16 rows, one chunk column — hit 16 distinct 16-byte bank slots.
-template <int WAVES, int NT, int R, int EPI, bool FP8, int XP = 2>
+// KVT > 1: the "virtual waves" form (GemvArgs::kvirt == KVT; a template parameter so that the default kernels carry none of it)
+template <int WAVES, int NT, int R, int EPI, bool FP8, int XP = 2, int KVT = 1>
 __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
 #ifndef VC_GEMV_DBG
 #define VC_GEMV_DBG 0
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
     __shared__ float ss_part[WAVES][16 * MG];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntiles = p.N >> 4;
-    const int KV = p.kvirt > 1 ? p.kvirt : 1;   // virtual-wave slices (GemvArgs::kvirt)
+    constexpr int KV = KVT;                      // virtual-wave slices (GemvArgs::kvirt)
     const int KS = KV > 1 ? KV : (p.ksplit > 1 ? p.ksplit : 1);
     const int ks = (int)blockIdx.x % KS;
     const int nt0 = ((int)blockIdx.x / KS) * NT;
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
     // this workgroup's share of K: a contiguous slice (ksplit), or — virtual waves — all of K at the stride of WAVES * KV waves
     const int it0 = KV > 1 ? 0 : (int)((long)ks * nit / KS), it1 = KV > 1 ? nit : (int)((long)(ks + 1) * nit / KS);
     const int vwave = KV > 1 ? wave + WAVES * ks : wave;   // this wave's place among the waves that interleave K
-    const int vstride = WAVES * KV;
+    constexpr int vstride = WAVES * KV;
     const int m = lane & 15, g = lane >> 4;
     // precision mode "split" (p.split_rows = G in {8, 16}): X holds G + M rows — rows [0, M) the bf16 hi parts of the M
     // activation rows, rows [G, G + M) their lo parts (x = hi + lo) — and the two partial products of a row meet in the
@@ -732,7 +733,7 @@ static void launch_gemv_w(const GemvArgs& a, int epi, hipStream_t s) {
 
 template <int WAVES, int NT, int R, bool FP8, int XP>
 static void launch_gemv_dma_x(const GemvArgs& a, int epi, hipStream_t s) {
-    const dim3 grid(((a.N / 16 + NT - 1) / NT) * (a.kvirt > 1 ? a.kvirt : a.ksplit > 1 ? a.ksplit : 1)), block(WAVES * 64);
+    const dim3 grid(((a.N / 16 + NT - 1) / NT) * (a.ksplit > 1 ? a.ksplit : 1)), block(WAVES * 64);
     constexpr size_t shmem = (size_t)WAVES * R * ((FP8 ? 1 : 2) * NT + XP) * 1024;
     // + the kernel's static ss_part[WAVES][16 * MG] floats
     static_assert(shmem + WAVES * 16 * ((XP + 1) / 2) * 4 <= 160 * 1024, "ring exceeds the LDS of a CU");
@@ -807,6 +808,19 @@ static int gemv_m32_kvirt_now() {
     return g_m32_kvirt >= 0 ? g_m32_kvirt : env;
 }
 
+template <int WAVES, int NT, int R, int EPI, int XP, int KVT>
+static void launch_gemv_kvirt1(const GemvArgs& a, hipStream_t s) {
+    const dim3 grid(((a.N / 16 + NT - 1) / NT) * KVT), block(WAVES * 64);
+    constexpr size_t shmem = (size_t)WAVES * R * (2 * NT + XP) * 1024;
+    static_assert(shmem + WAVES * 16 * ((XP + 1) / 2) * 4 <= 160 * 1024, "ring exceeds the LDS of a CU");
+    static bool once = false;
+    if (!once) {
+        allow_big_lds(gemv_dma_kernel<WAVES, NT, R, EPI, false, XP, KVT>, shmem);
+        once = true;
+    }
+    VC_LAUNCH((gemv_dma_kernel<WAVES, NT, R, EPI, false, XP, KVT>), grid, block, shmem, s, a);
+}
+
 template <bool FP8>
 static void launch_gemv_m32(const GemvArgs& a, int epilogue, hipStream_t s) {
     const int tiles = a.N / 16;
@@ -822,8 +836,19 @@ static void launch_gemv_m32(const GemvArgs& a, int epilogue, hipStream_t s) {
                 b.kvirt = kv;
                 b.ksplit = 0;
                 ++g_m32_kvirt_launches;
-                if (kvm == 2) launch_gemv_dma2<2, 4, 5, false>(b, epilogue, s);
-                else launch_gemv_dma2<4, 2, 4, false>(b, epilogue, s);
+                const bool x3 = x_rows(a) <= 24;
+#define VC_KVIRT(E)                                                                                       \
+    do {                                                                                                  \
+        if (kvm == 2) x3 ? launch_gemv_kvirt1<2, 4, 5, E, 3, 4>(b, s) : launch_gemv_kvirt1<2, 4, 5, E, 4, 4>(b, s); \
+        else x3 ? launch_gemv_kvirt1<4, 2, 4, E, 3, 2>(b, s) : launch_gemv_kvirt1<4, 2, 4, E, 4, 2>(b, s);          \
+    } while (0)
+                switch (epilogue) {
+                    case GEMV_BF16: VC_KVIRT(GEMV_BF16); break;
+                    case GEMV_F32: VC_KVIRT(GEMV_F32); break;
+                    case GEMV_RESID_F32: VC_KVIRT(GEMV_RESID_F32); break;
+                    default: VC_KVIRT(GEMV_SWIGLU); break;
+                }
+#undef VC_KVIRT
                 return;
             }
         }
