@@ -1381,7 +1381,10 @@ def check_gemv_wide(be, N, K, epi, rows, seed=0):
             be.lib.vck_set_gemv_wide(0x1d8)
             n0 = be.lib.vck_gemv_wide_launches()
             val, raw1, _ = _wg_run_plain(be, c, M)
-            assert be.lib.vck_gemv_wide_launches() == n0 + 1, f"M{M} N{N} epi{epi}: not served by the wide geometry"
+            if os.environ.get("VC_GEMV_PATH", "1") != "1" and M <= 16:
+                assert be.lib.vck_gemv_wide_launches() == n0, "the register-staged path (VC_GEMV_PATH=0) must not be overridden"
+            else:
+                assert be.lib.vck_gemv_wide_launches() == n0 + 1, f"M{M} N{N} epi{epi}: not served by the wide geometry"
             assert np.array_equal(raw0, raw1), f"M{M} N{N} K{K} epi{epi}: the wide geometry changed the bits"
             e = rel_err(val, c["ref"][:M])
             assert e < (2 ** -8 if epi in (0, 3) else 2e-5), f"gemv wide M{M} N{N} K{K} epi{epi}: rel err {e}"

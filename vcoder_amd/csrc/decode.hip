@@ -1119,6 +1119,9 @@ static bool launch_gemv_wide(const GemvArgs& a, int epi, hipStream_t s) {
     const int nt = (tiles + 255) / 256;
     if (nt > 8 || !((wide >> nt) & 1) || (tiles + nt - 1) / nt < 218) return false;
     const int xr = x_rows(a), xp = xr <= 8 ? 1 : xr <= 16 ? 2 : xr <= 24 ? 3 : 4;
+    // VC_GEMV_PATH=0 serves <= 16 rows with the register-staged kernel, whose k order is another: the wide ring stays out of it
+    static const int path = getenv("VC_GEMV_PATH") ? atoi(getenv("VC_GEMV_PATH")) : 1;
+    if (path != 1 && xr <= 16) return false;
 #define VC_WIDE(NT_, R_, XP_, E_)                      \
     if (nt == NT_ && xp == XP_ && epi == E_) {         \
         launch_gemv_wide1<NT_, R_, XP_, E_>(a, s);     \
