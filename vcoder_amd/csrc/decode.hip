@@ -14,6 +14,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <atomic>
 #include <stdexcept>
 #include <string>
 
@@ -786,9 +787,9 @@ static void launch_gemv_dma2(const GemvArgs& a, int epi, hipStream_t s) {
 // Anything else keeps pairs: the 13b qkv (960 tiles -> 320 triples, 2 per CU on 160 CUs) measured 32.7 -> 40.8 us.
 // Same K partition (4 waves, no K-slices), so every row's bits are those of the other variants (checked on the device, same file).
 static int g_m32_nt3 = -1;
-static unsigned long g_m32_nt3_launches = 0;
+static std::atomic<unsigned long> g_m32_nt3_launches{0};   // sessions launch from their own threads
 void set_gemv_m32_nt3(int v) { g_m32_nt3 = v; }
-unsigned long gemv_m32_nt3_launches() { return g_m32_nt3_launches; }
+unsigned long gemv_m32_nt3_launches() { return g_m32_nt3_launches.load(std::memory_order_relaxed); }
 static int gemv_m32_nt3_now() {
     static const int env = getenv("VC_GEMV2_NT3") ? atoi(getenv("VC_GEMV2_NT3")) : 3;
     return g_m32_nt3 >= 0 ? g_m32_nt3 : env;
@@ -800,9 +801,9 @@ static int gemv_m32_nt3_now() {
 //   1: 2 slices x 4 waves, tile PAIRS  (256 workgroups, 4-slot rings: 64 KiB in flight, 1.0 activation bytes per weight byte)
 //   2: 4 slices x 2 waves, tile QUADS  (256 workgroups, 5-slot rings: 80 KiB in flight, 0.5)
 static int g_m32_kvirt = -1;
-static unsigned long g_m32_kvirt_launches = 0;
+static std::atomic<unsigned long> g_m32_kvirt_launches{0};   // sessions launch from their own threads
 void set_gemv_m32_kvirt(int v) { g_m32_kvirt = v; }
-unsigned long gemv_m32_kvirt_launches() { return g_m32_kvirt_launches; }
+unsigned long gemv_m32_kvirt_launches() { return g_m32_kvirt_launches.load(std::memory_order_relaxed); }
 static int gemv_m32_kvirt_now() {
     static const int env = getenv("VC_GEMV2_KVIRT") ? atoi(getenv("VC_GEMV2_KVIRT")) : 0;
     return g_m32_kvirt >= 0 ? g_m32_kvirt : env;
@@ -835,7 +836,7 @@ static void launch_gemv_m32(const GemvArgs& a, int epilogue, hipStream_t s) {
                 GemvArgs b = a;
                 b.kvirt = kv;
                 b.ksplit = 0;
-                ++g_m32_kvirt_launches;
+                g_m32_kvirt_launches.fetch_add(1, std::memory_order_relaxed);
                 const bool x3 = x_rows(a) <= 24;
 #define VC_KVIRT(E)                                                                                       \
     do {                                                                                                  \
@@ -858,12 +859,12 @@ static void launch_gemv_m32(const GemvArgs& a, int epilogue, hipStream_t s) {
         if (nt3 && a.ksplit <= 1 && !a.split_rows) {   // (hi / lo operand rows keep the pair geometry they were validated on)
             const int triples = (tiles + 2) / 3;
             if ((nt3 & 2) && tiles > 512 && triples > 192 && triples <= 256) {
-                ++g_m32_nt3_launches;
+                g_m32_nt3_launches.fetch_add(1, std::memory_order_relaxed);
                 launch_gemv_dma2<4, 3, 3, false>(a, epilogue, s);
                 return;
             }
             if ((nt3 & 1) && tiles > 512 && triples > 384 && triples <= 512) {
-                ++g_m32_nt3_launches;
+                g_m32_nt3_launches.fetch_add(1, std::memory_order_relaxed);
                 launch_gemv_dma2<4, 3, 2, false>(a, epilogue, s);
                 return;
             }
@@ -1045,9 +1046,9 @@ static void launch_gemv_wg_n(const GemvArgs& a, int epi, hipStream_t s) {
 }
 
 static int g_gemv_variant = -1;
-static unsigned long g_gemv_wg_launches = 0;
+static std::atomic<unsigned long> g_gemv_wg_launches{0};   // sessions launch from their own threads
 void set_gemv_variant(int v) { g_gemv_variant = v; }
-unsigned long gemv_wg_launches() { return g_gemv_wg_launches; }
+unsigned long gemv_wg_launches() { return g_gemv_wg_launches.load(std::memory_order_relaxed); }
 // VC_GEMV_WG / set_gemv_variant: 0 = the per-wave-ring kernel everywhere; 1 = the workgroup-shared form everywhere it applies;
 // 2 (default) = the workgroup-shared form for precision mode "split" only.  Measured (profiles/r04_b_kbench_gemv_wg.txt): for the
 // bf16 step the ring kernel is faster at every row count (3.13 vs 3.57 ms at 32 rows with the best geometry found) — fewer,
@@ -1076,7 +1077,7 @@ static void launch_gemv_wg(const GemvArgs& a0, int epi, hipStream_t s) {
     // the split-K buffers bound the slices (a geometry decision of the matrix: the buffers are sized once per model)
     while (gm.ks > 1 && (!a.sk_scratch || !a.sk_counters || (size_t)gm.ks * ntiles * 2 * 256 > cap || ntiles * 2 > ncnt)) --gm.ks;
     a.ksplit = gm.ks;
-    ++g_gemv_wg_launches;
+    g_gemv_wg_launches.fetch_add(1, std::memory_order_relaxed);
     if (gm.ntw == 2) launch_gemv_wg_n<2>(a, epi, s);
     else launch_gemv_wg_n<1>(a, epi, s);
 }
@@ -1091,9 +1092,9 @@ static void launch_gemv_wg(const GemvArgs& a0, int epi, hipStream_t s) {
 //   NT 4: 13b qkv (960 -> 240)        NT 6: 7b gate/up (1376 -> 230)        NT 7: 13b gate/up (1728 -> 247)
 //   NT 8: lm_head (2000 -> 250), <= 24 rows (a 32-row slot of 8 tiles does not fit twice)
 static int g_gemv_wide = -1;
-static unsigned long g_gemv_wide_launches = 0;
+static std::atomic<unsigned long> g_gemv_wide_launches{0};   // sessions launch from their own threads
 void set_gemv_wide(int v) { g_gemv_wide = v; }
-unsigned long gemv_wide_launches() { return g_gemv_wide_launches; }
+unsigned long gemv_wide_launches() { return g_gemv_wide_launches.load(std::memory_order_relaxed); }
 static int gemv_wide_now() {
     static const int env = getenv("VC_GEMV_WIDE") ? (int)strtol(getenv("VC_GEMV_WIDE"), nullptr, 0) : 0;
     return g_gemv_wide >= 0 ? g_gemv_wide : env;
@@ -1125,7 +1126,7 @@ static bool launch_gemv_wide(const GemvArgs& a, int epi, hipStream_t s) {
 #define VC_WIDE(NT_, R_, XP_, E_)                      \
     if (nt == NT_ && xp == XP_ && epi == E_) {         \
         launch_gemv_wide1<NT_, R_, XP_, E_>(a, s);     \
-        ++g_gemv_wide_launches;                        \
+        g_gemv_wide_launches.fetch_add(1, std::memory_order_relaxed);                        \
         return true;                                   \
     }
     VC_WIDE(3, 5, 1, GEMV_BF16) VC_WIDE(3, 4, 2, GEMV_BF16)
