@@ -1,10 +1,12 @@
-"""The N>1 path on CPU: 2 processes (gloo), contiguous batch shards, one all-gather of the generated ids, no other
-collective — gathered stream == the single-process stream for the same global batch."""
+"""The N>1 path on CPU: 2 and 8 processes (gloo), contiguous batch shards, one all-gather of the generated ids, no other
+collective — gathered stream == the single-process stream for the same global batch.  8 ranks is the world
+the driver's scaling run uses (BASELINE configs[3] / [4])."""
 import os
 import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 from vcoder_amd.parallel import shard_range
 
@@ -23,7 +25,7 @@ rank, world = dist.get_rank(), dist.get_world_size()
 cfg = vcfg.tiny("vcoder_ds")
 eng = HipEngine(cfg, lib=kc.EmuBackend().lib)          # emulator injection: CPU test only
 eng.load_synthetic(42); eng.finalize()
-GB = 4
+GB = %(gb)d
 lo, hi = shard_range(GB, rank, world)
 ids = np.stack([synth.synth_prompt_ids(cfg.vocab_size, "vcoder_ds", 5, 4, sample=s) for s in range(lo, hi)])
 imgs, segs, deps = synth.synth_batch(hi - lo, cfg.vit_image_size, first=lo)
@@ -41,13 +43,14 @@ def test_shard_range():
     assert shard_range(2, 3, 4) == (2, 2)
 
 
-def test_two_rank_gather_equals_single_process(tmp_path):
+@pytest.mark.parametrize("world,gb,port", [(2, 4, 29617), (8, 16, 29631)])
+def test_gather_equals_single_process(tmp_path, world, gb, port):
     out = str(tmp_path / "gathered.npy")
     script = tmp_path / "worker.py"
-    script.write_text(WORKER % {"root": ROOT, "out": out})
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", VC_EMU_WORKERS="2")
-    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                           "--master-addr", "127.0.0.1", "--master-port", "29617", str(script)], env=env, timeout=600)
+    script.write_text(WORKER % {"root": ROOT, "out": out, "gb": gb})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", VC_EMU_WORKERS="2" if world == 2 else "1", OMP_NUM_THREADS="1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)], env=env, timeout=900)
     got = np.load(out)
     # single process over the whole global batch
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -59,10 +62,10 @@ def test_two_rank_gather_equals_single_process(tmp_path):
     eng = HipEngine(cfg, lib=kc.EmuBackend().lib)
     eng.load_synthetic(42)
     eng.finalize()
-    ids = np.stack([synth.synth_prompt_ids(cfg.vocab_size, "vcoder_ds", 5, 4, sample=s) for s in range(4)])
-    imgs, segs, deps = synth.synth_batch(4, cfg.vit_image_size)
+    ids = np.stack([synth.synth_prompt_ids(cfg.vocab_size, "vcoder_ds", 5, 4, sample=s) for s in range(gb)])
+    imgs, segs, deps = synth.synth_batch(gb, cfg.vit_image_size)
     ref = eng.generate_greedy(ids, imgs, segs, deps, max_new_tokens=3)
-    assert got.shape == (4, 3) and np.array_equal(got, ref)
+    assert got.shape == (gb, 3) and np.array_equal(got, ref)
 
 
 def test_forced_gather_in_a_world_of_one(tmp_path):
