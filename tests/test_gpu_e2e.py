@@ -508,12 +508,11 @@ def test_fp8_weights_true_dims_against_oracle(fmt):
     (vcoder_amd/quant.py) and, for 'fp8', quantising the same activation rows."""
     import torch
     import cpu_ref
-    from vcoder_amd import quant
 
     cfg = vcfg.vicuna_13b("vcoder_ds")
     cfg.num_hidden_layers = 2
     cfg.vit_num_layers = 2
-    sd = quant.effective_state_dict(synth.synth_state_dict(cfg, 13))
+    sd = e2e_cases.host_state(cfg, 13, effective=True)   # shared by the two parametrisations
     eng = HipEngine(cfg)
     eng.load_synthetic(13)
     eng.set_weight_format(fmt)
