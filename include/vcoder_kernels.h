@@ -142,25 +142,14 @@ void vck_gemv_split(const uint16_t* X, const void* Wp, const float* wscale, void
 void vck_gemv_full(const uint16_t* X, const void* Wp, const float* wscale, void* out, const float* ssq_in, float* ssq_out,
                    const float* xg_w, uint16_t* xg_out, int npart, float eps, float* sk_scratch, unsigned long long sk_scratch_floats,
                    unsigned* sk_counters, int sk_counters_n, int ksplit, int M, int N, int K, int ldo, int epi, int G, void* stream);
-/* which kernel serves the decode GEMV over bf16 weights: 0 = per-wave rings (gemv_dma_kernel), 1 = workgroup-shared activation
- * chunks (gemv_wg_kernel), -1 = the process default (environment VC_GEMV_WG) */
+/* which kernel serves the decode GEMV of precision mode "split": 0 = per-wave rings (gemv_dma_kernel; two weight passes of 16
+ * rows per 32-row step), 1 / -1 (default) = workgroup-shared activation chunks (gemv_wg_kernel; hi + lo planes in one pass) */
 void vck_set_gemv_variant(int v);
-/* tuning of the 17..32-row bf16 GEMV: three tiles per workgroup where the triples balance over the CUs — bit 0: 385..512 triples
- * (two resident per CU), bit 1: 193..256 triples (one per CU, deeper ring); -1 = the process default (environment VC_GEMV2_NT3,
- * default 3).  Results are bit-identical whichever is set. */
-void vck_set_gemv_m32_nt3(int v);
-unsigned long long vck_gemv_m32_nt3_launches(void);   /* launches the three-tile form has served (tests) */
-/* 17..32-row bf16 GEMV over 129..256-tile matrices (o_proj / down) as "virtual waves": 1 = 2 slices x 4 waves with tile pairs,
- * 2 = 4 slices x 2 waves with tile quads, 0 = the 8-wave single-tile workgroup; -1 = the process default (environment
- * VC_GEMV2_KVIRT).  Results are bit-identical whichever is set. */
-void vck_set_gemv_m32_kvirt(int v);
-/* experiment: NT = ceil(tiles / 256) tiles per workgroup for bf16 matrices of more than 512 tiles, one deep-ringed workgroup per
- * CU; bit NT of the mask enables the class (NT in 3, 4, 6, 7, 8); -1 = the process default (environment VC_GEMV_WIDE, default 0).
- * Results are bit-identical whichever is set. */
+/* NT = ceil(tiles / 256) tiles per workgroup for bf16 matrices of more than 512 tiles, one deep-ringed workgroup per CU (NT in
+ * 3, 4, 6, 7): -1 / 1 = the classes that measured faster (default), 0 = off, 2 = every class.  Results are bit-identical
+ * whichever is set. */
 void vck_set_gemv_wide(int v);
 unsigned long long vck_gemv_wide_launches(void);
-unsigned long long vck_gemv_m32_kvirt_launches(void);
-void vck_set_gemv_wg_geom(const char* spec, int deep);   /* tuning: "ntiles:K:ntw:ks,..." per matrix shape; deep: -1 default */
 unsigned long long vck_gemv_wg_launches(void);   /* launches the workgroup-shared form has served (tests) */
 void vck_rmsnorm_split(const float* x, const int* row_idx, const float* w, uint16_t* y, int rows, int D, float eps, int ldy,
                        uint64_t lo_off, void* stream);

@@ -119,6 +119,10 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
 
 // ---- minimal HIP runtime shims so that the host engine (engine.hip) also runs under the emulator ----------
 #include <chrono>
+// the device's constant-rate wall clock (vc_device.h vc_wall_clock): 100 MHz ticks of the host's steady clock
+inline unsigned long long vc_emu_wall_clock() {
+    return (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10;
+}
 typedef int hipError_t;
 static const hipError_t hipSuccess = 0;
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };

@@ -825,9 +825,7 @@ def check_gemv_rows_agree_across_variants(be, N, K, epi, norm=True, ksplit=0, se
     _gemv_ex(be, Xh, Wp, wsc, hi, ssqh, None, None, None, npart, M - 16, N, K, No, epi, sk=sk, ksplit=ksplit)
     be.sync()
     b, l = be.host_f32(big), be.host_f32(lo)
-    # bit equality holds for the default (LDS-DMA) kernels, whose K partition is the same for both row counts; the
-    # register-staged regression variant (VC_GEMV_PATH=0) serves only the 16-row pass and sums in another order
-    same = np.array_equal if os.environ.get("VC_GEMV_PATH", "1") != "0" else (lambda u, v: rel_err(u, v) < 2 ** -7)
+    same = np.array_equal   # the K partition is the same for both row counts
     assert same(b[:16], l[:16]), "rows 0..15 differ between the 32-row and the 16-row pass"
     if epi != 2:   # (the in-place residual form adds into whatever rows the buffer holds: only rows 0..15 line up)
         assert same(b[16:M], be.host_f32(hi)[: M - 16]), "rows 16..28 differ between the 32-row and the 16-row pass"
@@ -1211,7 +1209,7 @@ def check_attention_decode_kv32(be, B, H, hd, pos, seed=0):
         assert err < 3e-5 * max(1.0, np.abs(ref).max()), f"decode attention kv32 row {b}: {err}"
 
 
-# ---- the workgroup-shared-activation decode GEMV (gemv_wg_kernel; vck_set_gemv_variant(1)) -------------------------------------
+# ---- the workgroup-shared-activation decode GEMV of precision mode "split" (gemv_wg_kernel) -------------------------------------
 def _gemv_full(be, X, Wp, out, ssq_in, ssq_out, xg_w, xg_out, npart, M, N, K, ldo, epi, G=0, ksplit=0, sk=None):
     """vck_gemv_full through raw pointers (bf16 weights); sk = (scratch f32, counters i32) with their true capacities"""
     be.lib.vck_gemv_full(be.ptr(X), be.ptr(Wp), None, be.ptr(out), be.ptr(ssq_in), be.ptr(ssq_out), be.ptr(xg_w), be.ptr(xg_out),
@@ -1291,9 +1289,10 @@ def _wg_run(be, c, M, G, ksplit=0, row0=0):
     return val, raw, extra
 
 
-def check_gemv_wg(be, M, N, K, epi, norm=True, G=0, ksplit=0, seed=0):
-    """gemv_wg_kernel against the float64 product: every epilogue, RMSNorm folding on both sides, the split form (hi / lo rows,
-    one weight pass), explicit K-slices with the cross-workgroup hand-off"""
+def check_gemv_wg(be, M, N, K, epi, norm=True, G=8, ksplit=0, seed=0):
+    """gemv_wg_kernel (the GEMV of precision mode "split": hi / lo rows, one weight pass) against the float64 product: every
+    epilogue, RMSNorm folding on both sides, explicit K-slices with the cross-workgroup hand-off"""
+    assert G > 0, "the workgroup-shared form serves the split step only (its bf16 form was removed in round 5)"
     be.lib.vck_set_gemv_variant(1)
     be.lib.vck_gemv_wg_launches.restype = ctypes.c_ulonglong
     n0 = be.lib.vck_gemv_wg_launches()
@@ -1315,7 +1314,7 @@ def check_gemv_wg(be, M, N, K, epi, norm=True, G=0, ksplit=0, seed=0):
         be.lib.vck_set_gemv_variant(-1)
 
 
-def check_gemv_wg_rows_agree(be, N, K, epi, norm=True, G=False, ksplit=0, seed=0):
+def check_gemv_wg_rows_agree(be, N, K, epi, norm=True, G=True, ksplit=0, seed=0):
     """the pool's promise for the wg form: a row gets the same BITS from a 29-row pass as from the 8-row (5-row) pass and the
     13-row pass that hold it — the k order of a sum is a function of the matrix alone; in split form G = 32 vs G = 8 / 16"""
     be.lib.vck_set_gemv_variant(1)
@@ -1333,58 +1332,22 @@ def check_gemv_wg_rows_agree(be, N, K, epi, norm=True, G=False, ksplit=0, seed=0
         be.lib.vck_set_gemv_variant(-1)
 
 
-def check_gemv_m32_nt3(be, N, K, epi, norm=True, rows=(19, 29, 32), seed=0):
-    """the three-tiles-per-workgroup form of the 17..32-row ring kernel (vck_set_gemv_m32_nt3; launch_gemv_m32): against the
-    float64 product, and bit for bit what the default geometry gives every row (same K partition: 4 waves, no K-slices) — the
-    ragged last workgroup (a tile count that is not a multiple of 3) included"""
-    triples = (N // 16 + 2) // 3
-    assert 192 < triples <= 256 or 384 < triples <= 512, "not a tile count the three-tile geometry serves (launch_gemv_m32)"
-    be.lib.vck_set_gemv_variant(0)
-    try:
-        rng = np.random.RandomState(seed)
-        c = _wg_case(be, rng, 32, N, K, epi, norm, 0)
-        c["sk"] = None      # no split-K buffers: the launcher's own geometry classes
-        worst = 0.0
-        for M in rows:
-            be.lib.vck_set_gemv_m32_nt3(0)
-            _, raw0, ex0 = _wg_run_plain(be, c, M)
-            be.lib.vck_set_gemv_m32_nt3(3)
-            be.lib.vck_gemv_m32_nt3_launches.restype = ctypes.c_ulonglong
-            n0 = be.lib.vck_gemv_m32_nt3_launches()
-            val, raw1, ex1 = _wg_run_plain(be, c, M)
-            assert be.lib.vck_gemv_m32_nt3_launches() == n0 + 1, "the call was not served by the three-tile form"
-            assert np.array_equal(raw0, raw1), f"M{M} N{N} K{K} epi{epi}: three tiles per workgroup changed the bits"
-            if epi == 2:
-                assert np.array_equal(ex0["xg"], ex1["xg"]) and np.array_equal(ex0["ssq"], ex1["ssq"])
-                assert np.array_equal(ex1["untouched"], c["r0"][M:]), "residual rows beyond M were touched"
-            e = rel_err(val, c["ref"][:M])
-            assert e < (2 ** -8 if epi in (0, 3) else 2e-5), f"gemv m32 nt3 M{M} N{N} K{K} epi{epi}: rel err {e}"
-            worst = max(worst, e)
-        return worst
-    finally:
-        be.lib.vck_set_gemv_m32_nt3(-1)
-        be.lib.vck_set_gemv_variant(-1)
-
-
-def check_gemv_wide(be, N, K, epi, rows, seed=0):
-    """the "wide" geometry experiment (vck_set_gemv_wide: ceil(tiles / 256) tiles per 4-wave workgroup, deep ring): bit for bit
-    the default geometry's result at every row count, and within tolerance of float64"""
-    be.lib.vck_set_gemv_variant(0)
+def check_gemv_wide(be, N, K, epi, rows, norm=True, seed=0):
+    """the "wide" geometry of the ring kernel (vck_set_gemv_wide: ceil(tiles / 256) tiles per 4-wave workgroup, deep ring; on by
+    default for the classes that measured faster, 2 = every class): bit for bit the pair geometry's result at every row count
+    (ragged last workgroup included), and within tolerance of float64"""
     be.lib.vck_gemv_wide_launches.restype = ctypes.c_ulonglong
     try:
         rng = np.random.RandomState(seed)
-        c = _wg_case(be, rng, 32, N, K, epi, True, 0)
+        c = _wg_case(be, rng, 32, N, K, epi, norm, 0)
         worst = 0.0
         for M in rows:
             be.lib.vck_set_gemv_wide(0)
-            _, raw0, _ = _wg_run_plain(be, c, M)
-            be.lib.vck_set_gemv_wide(0x1d8)
+            _, raw0, ex0 = _wg_run_plain(be, c, M)
+            be.lib.vck_set_gemv_wide(2)
             n0 = be.lib.vck_gemv_wide_launches()
-            val, raw1, _ = _wg_run_plain(be, c, M)
-            if os.environ.get("VC_GEMV_PATH", "1") != "1" and M <= 16:
-                assert be.lib.vck_gemv_wide_launches() == n0, "the register-staged path (VC_GEMV_PATH=0) must not be overridden"
-            else:
-                assert be.lib.vck_gemv_wide_launches() == n0 + 1, f"M{M} N{N} epi{epi}: not served by the wide geometry"
+            val, raw1, ex1 = _wg_run_plain(be, c, M)
+            assert be.lib.vck_gemv_wide_launches() == n0 + 1, f"M{M} N{N} epi{epi}: not served by the wide geometry"
             assert np.array_equal(raw0, raw1), f"M{M} N{N} K{K} epi{epi}: the wide geometry changed the bits"
             e = rel_err(val, c["ref"][:M])
             assert e < (2 ** -8 if epi in (0, 3) else 2e-5), f"gemv wide M{M} N{N} K{K} epi{epi}: rel err {e}"
@@ -1392,40 +1355,6 @@ def check_gemv_wide(be, N, K, epi, rows, seed=0):
         return worst
     finally:
         be.lib.vck_set_gemv_wide(-1)
-        be.lib.vck_set_gemv_variant(-1)
-
-
-def check_gemv_m32_kvirt(be, N, K, epi, rows=(19, 29, 32), seed=0):
-    """"virtual waves" (GemvArgs::kvirt; vck_set_gemv_m32_kvirt) for the 129..256-tile matrices of a 17..32-row step: 2 slices x 4
-    waves with tile pairs and 4 slices x 2 waves with tile quads must give the BITS of the 8-wave single-tile workgroup (the
-    finisher adds the hand-over partials in that workgroup's wave order), against float64, counters re-armed"""
-    assert 128 < N // 16 <= 256
-    be.lib.vck_set_gemv_variant(0)
-    be.lib.vck_gemv_m32_kvirt_launches.restype = ctypes.c_ulonglong
-    try:
-        rng = np.random.RandomState(seed)
-        c = _wg_case(be, rng, 32, N, K, epi, False, 0)
-        worst = 0.0
-        for M in rows:
-            be.lib.vck_set_gemv_m32_kvirt(0)
-            _, raw0, ex0 = _wg_run_plain(be, c, M, sk=c["sk"])
-            for mode in (1, 2):
-                be.lib.vck_set_gemv_m32_kvirt(mode)
-                n0 = be.lib.vck_gemv_m32_kvirt_launches()
-                val, raw1, ex1 = _wg_run_plain(be, c, M, sk=c["sk"])
-                assert be.lib.vck_gemv_m32_kvirt_launches() == n0 + 1, "the call was not served by the virtual-wave form"
-                assert not be.host_i32(c["sk"][1]).any(), "arrival counters must be re-armed"
-                assert np.array_equal(raw0, raw1), f"M{M} N{N} K{K} epi{epi} kvirt mode {mode}: bits differ from the 8-wave workgroup's"
-                if epi == 2:
-                    assert np.array_equal(ex0["xg"], ex1["xg"]) and np.array_equal(ex0["ssq"], ex1["ssq"])
-                    assert np.array_equal(ex1["untouched"], c["r0"][M:]), "residual rows beyond M were touched"
-                e = rel_err(val, c["ref"][:M])
-                assert e < (2 ** -8 if epi in (0, 3) else 2e-5), f"gemv m32 kvirt {mode} M{M} N{N} K{K} epi{epi}: rel err {e}"
-                worst = max(worst, e)
-        return worst
-    finally:
-        be.lib.vck_set_gemv_m32_kvirt(-1)
-        be.lib.vck_set_gemv_variant(-1)
 
 
 def _wg_run_plain(be, c, M, sk=None):

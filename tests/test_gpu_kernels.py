@@ -211,51 +211,28 @@ def test_dma_kernels_are_race_free_and_bit_reproducible(be):
 
 
 @pytest.mark.parametrize("M,N,K,epi,norm,G,ks", [
-    (8, 12288, 4096, 0, True, 0, 0), (32, 12288, 4096, 0, True, 0, 0), (24, 4096, 4096, 2, False, 0, 0), (32, 22016, 4096, 3, True, 0, 0),
-    (29, 4096, 11008, 2, False, 0, 0), (32, 32000, 4096, 1, True, 0, 0), (16, 15360, 5120, 0, True, 0, 0), (32, 5120, 13824, 2, False, 0, 0),
     (8, 12288, 4096, 1, True, 8, 0), (16, 22016, 4096, 3, True, 16, 0), (32, 12288, 4096, 1, True, 32, 0), (32, 4096, 11008, 2, False, 32, 0),
-    (32, 22016, 4096, 3, True, 32, 0), (3, 48, 320, 1, True, 0, 0)])
+    (32, 22016, 4096, 3, True, 32, 0), (24, 4096, 4096, 2, False, 24, 0), (29, 32000, 4096, 1, True, 32, 0), (16, 15360, 5120, 1, True, 16, 0),
+    (32, 5120, 13824, 2, False, 32, 0), (3, 48, 320, 1, True, 8, 0)])
 def test_gemv_wg(be, M, N, K, epi, norm, G, ks):
-    """gemv_wg_kernel (workgroup-shared activation chunks) at the true 7b / 13b decode shapes, 8..32 rows, every epilogue, the
-    split form with both planes in one weight pass (G = 32: 64 operand rows), the default K-slice geometry of each matrix"""
+    """gemv_wg_kernel (workgroup-shared activation chunks; the GEMV of precision mode "split") at the true 7b / 13b decode shapes,
+    8..32 rows, every epilogue, both planes in one weight pass (G = 32: 64 operand rows), the default K-slice geometry of each matrix"""
     kc.check_gemv_wg(be, M, N, K, epi, norm, G, ks)
 
 
-@pytest.mark.parametrize("N,K,epi,G", [(12288, 4096, 0, False), (22016, 4096, 3, False), (4096, 11008, 2, False), (32000, 4096, 1, False),
-                                       (12288, 4096, 1, True), (22016, 4096, 3, True), (4096, 4096, 2, True)])
+@pytest.mark.parametrize("N,K,epi,G", [(12288, 4096, 1, True), (22016, 4096, 3, True), (4096, 4096, 2, True), (4096, 11008, 2, True),
+                                       (32000, 4096, 1, True)])
 def test_gemv_wg_rows_agree(be, N, K, epi, G):
     """the pool's promise for the wg form at true shapes: identical bits for a row from 5 / 8 / 13 / 16 / 29-row passes"""
     kc.check_gemv_wg_rows_agree(be, N, K, epi, True, G)
 
 
-@pytest.mark.parametrize("N,K,epi", [(12288, 4096, 0), (22016, 4096, 3), (16 * 767, 4096, 2), (16 * 1154, 5120, 1)])
-def test_gemv_m32_three_tiles_per_workgroup(be, N, K, epi):
-    """VC_GEMV2_NT3 / vck_set_gemv_m32_nt3 at the 7b qkv and gate/up shapes (+ ragged 767- and 1154-tile matrices, the other
-    epilogues): three tiles per workgroup give every row of a 19 / 29 / 32-row step the bits of the pair geometry"""
-    kc.check_gemv_m32_nt3(be, N, K, epi)
-
-
-# Kernel forms that are OFF by default and have not been through a device run of this suite yet (built after the round's GPU
-# budget was spent; emulator-checked): their device tests run when VC_TEST_EXPERIMENTS=1 (tools/gpu/r05_a.sh sets it), so that an
-# experiment cannot stop the driver's `-x` run of the product's tests.
-experiment = pytest.mark.skipif(os.environ.get("VC_TEST_EXPERIMENTS", "0") != "1",
-                                reason="opt-in kernel experiment: set VC_TEST_EXPERIMENTS=1 (tools/gpu/r05_a.sh)")
-
-
-@experiment
-@pytest.mark.parametrize("N,K,epi,rows", [(12288, 4096, 0, (8, 16)), (15360, 5120, 0, (8, 16, 24, 32)), (22016, 4096, 3, (8, 16, 24, 32)),
-                                          (27648, 5120, 3, (8, 16, 32)), (32000, 4096, 1, (8, 16, 24))])
+@pytest.mark.parametrize("N,K,epi,rows", [(12288, 4096, 0, (8, 16, 19, 29, 32)), (16 * 767, 4096, 0, (13, 32)), (15360, 5120, 0, (8, 16, 24, 32)),
+                                          (22016, 4096, 3, (8, 16, 24, 32)), (27648, 5120, 3, (8, 16, 32))])
 def test_gemv_wide_geometry(be, N, K, epi, rows):
-    """VC_GEMV_WIDE (opt-in experiment) at the true 7b / 13b shapes: ceil(tiles / 256) tiles per workgroup, the default's bits"""
+    """the one-workgroup-per-CU geometries at the true 7b / 13b shapes (+ a ragged 767-tile matrix): ceil(tiles / 256) tiles per
+    workgroup give every row the bits of the pair geometry (measured: profiles/r05_a_kbench_gemv_wide.txt)"""
     kc.check_gemv_wide(be, N, K, epi, rows)
-
-
-@experiment
-@pytest.mark.parametrize("N,K,epi", [(4096, 4096, 2), (4096, 11008, 2), (16 * 131, 4096, 1)])
-def test_gemv_m32_virtual_waves(be, N, K, epi):
-    """VC_GEMV2_KVIRT / vck_set_gemv_m32_kvirt (opt-in, measured slower: profiles/r04_s_kbench_gemv_kvirt.txt) at the 7b o_proj /
-    down shapes: the cross-workgroup hand-over reproduces the 8-wave workgroup's bits on the device"""
-    kc.check_gemv_m32_kvirt(be, N, K, epi)
 
 
 def test_gemv_wg_is_race_free_and_bit_reproducible(be):
@@ -267,17 +244,17 @@ def test_gemv_wg_is_race_free_and_bit_reproducible(be):
     try:
         rng = np.random.RandomState(4)
         for (M, N, K, epi) in [(8, 12288, 4096, 0), (32, 22016, 4096, 3), (32, 4096, 11008, 1), (24, 5120, 13824, 1), (29, 32000, 4096, 1)]:
-            X = be.bf16(kc.bf16_round(rng.randn(32, K)))
+            X = be.bf16(kc.bf16_round(rng.randn(64, K)))   # hi rows [0, M), lo rows [32, 32 + M)
             Wb = be.bf16(kc.bf16_round(rng.randn(N, K) * 0.05))
             Wp = be.zeros((N * K,), "bf16")
             kc._call(be, "vck_pack_weight", Wb, Wp, N, K)
             scratch, counters = be.zeros((8 * (N // 16) * 2 * 256,), "f32"), be.zeros((N // 16 * 2,), "i32")
             outs = []
             for it in range(24):
-                out = be.zeros((32, N // 2 if epi == 3 else N), "f32" if epi == 1 else "bf16")
+                out = be.zeros((64, N // 2 if epi == 3 else N), "f32" if epi == 1 else "bf16")
                 be.lib.vck_gemv_full(be.ptr(X), be.ptr(Wp), None, be.ptr(out), None, None, None, None, 16, ctypes.c_float(1e-5),
                                      be.ptr(scratch), ctypes.c_ulonglong(8 * (N // 16) * 2 * 256), be.ptr(counters), N // 16 * 2, 0,
-                                     M, N, K, N // 2 if epi == 3 else N, epi, 0, None)
+                                     M, N, K, N // 2 if epi == 3 else N, epi, 32, None)
                 outs.append(out)
             be.sync()
             for o in outs[1:]:

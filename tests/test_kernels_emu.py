@@ -171,12 +171,10 @@ def test_alternate_kernel_variants():
         # 8 x 32 attention
         (dict(VC_ATTN_VARIANT="2"), "test_attention"),
         # tile-order knobs of the GEMM (8-phase kernel forced onto every small, ragged, 1-3 k-tile case; split-K rounds
-        # of the bf16 and the e4m3 form), cacheable weight loads of the GEMV
-        (dict(VC_GEMM_VARIANT="5", VC_GEMM_GROUP="2", VC_GEMM_XCD="0", VC_GEMV_WCACHED="1"), "test_gemm or test_gemv"),
+        # of the bf16 and the e4m3 form)
+        (dict(VC_GEMM_VARIANT="5", VC_GEMM_GROUP="2", VC_GEMM_XCD="0"), "test_gemm"),
         # deeper load windows of the decode attention
         (dict(VC_DATTN_UK="16"), "test_fused_decode"),
-        # the register-staged GEMV (the LDS-DMA ring kernel is the default)
-        (dict(VC_GEMV_PATH="0"), "test_gemv or test_fused_decode"),
         # 2: the one-barrier 256x256 kernel; 4: 256x256 as 4 waves x (128 x 128)
         (dict(VC_GEMM_VARIANT="2"), plain_gemm),
         (dict(VC_GEMM_VARIANT="4"), plain_gemm),
@@ -198,39 +196,23 @@ def test_alternate_kernel_variants():
 
 
 @pytest.mark.parametrize("M,N,K,epi,norm,G,ks", [
-    (8, 64, 256, 0, True, 0, 0), (3, 32, 1024, 1, True, 0, 0), (16, 48, 320, 2, False, 0, 0), (8, 64, 256, 3, True, 0, 0),
-    (1, 16, 64, 1, False, 0, 0), (29, 96, 576, 0, True, 0, 0), (24, 64, 512, 2, True, 0, 2), (32, 160, 1024, 3, True, 0, 3),
     (5, 64, 256, 0, True, 8, 0), (13, 48, 320, 2, True, 16, 0), (29, 96, 576, 3, True, 32, 0), (32, 64, 1024, 1, True, 32, 4),
-    (21, 80, 384, 2, True, 24, 2), (8, 8192, 128, 0, False, 0, 0)])
+    (21, 80, 384, 2, True, 24, 2), (8, 64, 256, 3, True, 8, 0), (1, 16, 64, 1, False, 8, 0), (16, 48, 320, 2, False, 16, 0),
+    (24, 64, 512, 0, False, 24, 3)])
 def test_gemv_wg(be, M, N, K, epi, norm, G, ks):
-    """the workgroup-shared-activation decode GEMV: all row counts (1..4 activation pieces), epilogues, the split form with
-    both planes in one weight pass, K-slices over workgroups; N = 8192 (512 tiles) takes tile pairs per wave"""
+    """the workgroup-shared-activation decode GEMV of precision mode "split": all row counts (1..4 activation pieces), epilogues,
+    both planes in one weight pass, K-slices over workgroups"""
     kc.check_gemv_wg(be, M, N, K, epi, norm, G, ks)
 
 
-@pytest.mark.parametrize("N,K,epi", [(16 * 600, 64, 1), (16 * 767, 128, 0), (16 * 1154, 128, 3), (16 * 1376, 64, 2)])
-def test_gemv_m32_three_tiles_per_workgroup(be, N, K, epi):
-    """three tiles per workgroup in the pooled (17..32-row) bf16 GEMV (both tile-count classes that take it): the bits of the
-    pair geometry, ragged last workgroup included"""
-    kc.check_gemv_m32_nt3(be, N, K, epi)
+@pytest.mark.parametrize("N,K,epi,norm,rows", [(16 * 700, 192, 0, True, (5, 13, 19, 32)), (16 * 767, 128, 0, True, (8, 29)),
+                                               (16 * 900, 128, 0, False, (8, 16, 19, 32)), (16 * 1376, 128, 3, True, (3, 16, 24, 29)),
+                                               (16 * 1727, 64, 3, True, (8, 9, 17, 32))])
+def test_gemv_wide_geometry(be, N, K, epi, norm, rows):
+    """the one-workgroup-per-CU geometries (3 / 4 / 6 / 7 tiles per workgroup) give the pair geometry's bits"""
+    kc.check_gemv_wide(be, N, K, epi, rows, norm)
 
 
-@pytest.mark.parametrize("N,K,epi,rows", [(16 * 700, 192, 0, (5, 13)), (16 * 900, 128, 0, (8, 16, 19, 32)),
-                                          (16 * 1376, 128, 3, (3, 16, 24, 29)), (16 * 1727, 64, 3, (8, 9, 17, 32)),
-                                          (32000, 128, 1, (8, 12, 20))])
-def test_gemv_wide_geometry(be, N, K, epi, rows):
-    """the opt-in one-workgroup-per-CU geometries (3 / 4 / 6 / 7 / 8 tiles per workgroup) give the default geometry's bits"""
-    kc.check_gemv_wide(be, N, K, epi, rows)
-
-
-@pytest.mark.parametrize("N,K,epi", [(4096, 704, 2), (16 * 131, 192, 2), (16 * 200, 1024, 1), (16 * 254, 320, 0)])
-def test_gemv_m32_virtual_waves(be, N, K, epi):
-    """GemvArgs::kvirt (opt-in): 2 x 4 and 4 x 2 waves over tile pairs / quads hand their partials over so that the finisher
-    adds them in the 8-wave workgroup's order — its bits, ragged tile groups, waves without a k-line and half lines included"""
-    kc.check_gemv_m32_kvirt(be, N, K, epi)
-
-
-@pytest.mark.parametrize("N,K,epi,G,ks", [(64, 512, 0, False, 0), (48, 320, 1, False, 2), (96, 1024, 3, False, 3), (32, 512, 2, False, 0),
-                                          (64, 512, 0, True, 0), (48, 1024, 1, True, 4), (64, 256, 3, True, 0)])
+@pytest.mark.parametrize("N,K,epi,G,ks", [(64, 512, 0, True, 0), (48, 1024, 1, True, 4), (64, 256, 3, True, 0), (32, 512, 2, True, 2)])
 def test_gemv_wg_rows_agree(be, N, K, epi, G, ks):
     kc.check_gemv_wg_rows_agree(be, N, K, epi, True, G, ks)

@@ -65,6 +65,47 @@ def test_concurrent_requests_share_steps_and_keep_their_ids(emu_lib):
         s.close()
 
 
+def test_pool_profile_counts_every_launch_and_changes_no_id(emu_lib):
+    """vc_pool_profile: the step graphs re-captured with timing slots give the same ids, and the per-(span, kind) sums hold exactly
+    one launch per kind and layer for every pool step (lm_head: one per step) with non-zero durations"""
+    root = e2e_cases.engine_for("vcoder_ds", emu_lib)
+    g, cfg, ids, imgs, segs, deps = e2e_cases.fixture_inputs("ds_img_depth_seg")
+    plain = root.generate_greedy(ids, imgs, segs, deps, max_new_tokens=6)
+    assert all(v["launches"] == 0 for v in root.pool_profile_read()[8].values()), "profiling is off by default"
+    root.pool_profile(True)
+    try:
+        other = root.fork()
+        outs, errs = [None, None], []
+
+        def work(i, eng):
+            try:
+                outs[i] = eng.generate_greedy(ids, imgs, segs, deps, max_new_tokens=6)
+            except BaseException as e:
+                errs.append(e)
+
+        ths = [threading.Thread(target=work, args=(i, e)) for i, e in enumerate((root, other))]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        assert not errs, errs
+        assert np.array_equal(outs[0], plain) and np.array_equal(outs[1], plain)
+        steps = root.pool_step_counts()   # (the pool was rebuilt for the slots: its histogram starts at zero)
+        prof = root.pool_profile_read()
+        L = root.cfg.num_hidden_layers
+        for s_, rows in enumerate((8, 16, 24, 32)):
+            for kind, v in prof[rows].items():
+                want = steps[s_] * (1 if kind == "lm_head" else L)
+                assert v["launches"] == want, (rows, kind, v, steps)
+                assert (v["us"] > 0) == (want > 0), (rows, kind, v)
+        assert sum(steps) >= 5
+        assert all(v["launches"] == 0 for r in root.pool_profile_read().values() for v in r.values()), "read(reset=True) zeroes the sums"
+        other.close()
+    finally:
+        root.pool_profile(False)
+    assert np.array_equal(root.generate_greedy(ids, imgs, segs, deps, max_new_tokens=6), plain)   # rebuilt without the slots
+
+
 def test_pool_mixes_eos_stops_and_sampling(emu_lib):
     """Rows of one step with different generation parameters: an EOS request that ends early, a keyword-stop request, a
     sampled request and a plain greedy one, all in flight together; each equals its lone run."""

@@ -8,4 +8,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 timeout 120 python tools/kbench.py gemv_wide 2>&1 | grep gemv_wide > gpurun_out/r05_a_kbench_gemv_wide.txt
 cat gpurun_out/r05_a_kbench_gemv_wide.txt
+timeout 90 python tools/kbench.py gemm_chunk 2>&1 | grep gemm_chunk > gpurun_out/r05_a_kbench_gemm_chunk.txt
+VC_GEMM_VARIANT=5 timeout 90 python tools/kbench.py gemm_chunk 2>&1 | grep gemm_chunk | sed 's/^/8phase /' >> gpurun_out/r05_a_kbench_gemm_chunk.txt
+cat gpurun_out/r05_a_kbench_gemm_chunk.txt
 VC_TEST_EXPERIMENTS=1 timeout 200 python -m pytest tests/test_gpu_kernels.py -q -x -m gpu -k "wide_geometry or three_tiles or virtual_waves" 2>&1 | tail -5 | tee gpurun_out/r05_a_pytest.txt

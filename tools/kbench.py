@@ -147,119 +147,14 @@ def bench_gemv_rows():
             us = timeit(f, iters=40)
             tot += us * cnt
             print(f"gemv_rows M{M:2d} {name:8s} N{N} K{K}: {us:7.1f} us  {2 * N * K / us / 1e3:7.1f} GB/s", flush=True)
-        print(f"gemv_rows M{M:2d} all GEMVs of a 7b decode step: {tot / 1e3:6.3f} ms = {tot / 1e3 / M:6.4f} ms per row "
-              f"(geom {os.environ.get('VC_GEMV2_GEOM', 'default')})", flush=True)
-
-
-def bench_gemv_wg():
-    """The workgroup-shared-activation GEMV (gemv_wg_kernel) next to the per-wave-ring form on the five 7b decode shapes, at
-    8 / 16 / 24 / 32 rows and — split form — 8 / 16 / 32 rows with both planes in one weight pass; then a geometry sweep
-    (tiles per wave x K-slices) per shape at 32 rows."""
-    shapes = [(12288, 4096, 0, "qkv", 32), (4096, 4096, 2, "o", 32), (22016, 4096, 3, "gate-up", 32), (4096, 11008, 2, "down", 32),
-              (32000, 4096, 1, "lm_head", 1)]
-    bufs = {}
-    for (N, K, epi, name, cnt) in shapes:
-        npart = (4096 // 16 + 15) // 16 * 16
-        bufs[name] = dict(X=bf16(64, K), Ws=[bf16(N * K, scale=0.02) for _ in range(6)],
-                          out=torch.zeros((64, N), dtype=torch.float32 if epi in (1, 2) else torch.bfloat16, device=dev),
-                          ssq=torch.rand(32, npart, device=dev), gw=torch.rand(N, device=dev) + 0.5,
-                          xg=torch.zeros((64, N), dtype=torch.bfloat16, device=dev),
-                          scratch=torch.zeros(8 * (N // 16) * 2 * 256, device=dev),
-                          counters=torch.zeros(N // 16 * 2, dtype=torch.int32, device=dev), npart=npart)
-
-    def run(name, N, K, epi, M, G, iters=30):
-        b = bufs[name]
-        ldo = N // 2 if epi == 3 else N
-        it = [0]
-        f32e = epi in (1, 2) or (G and epi == 0)   # the split step's qkv leaves fp32
-        e = 1 if (G and epi == 0) else epi
-        out = b["out"] if (b["out"].dtype == torch.float32) == bool(e in (1, 2)) else torch.zeros((64, N), dtype=torch.float32 if e in (1, 2) else torch.bfloat16, device=dev)
-
-        def f():
-            it[0] += 1
-            W = b["Ws"][it[0] % 6]
-            if e == 2:
-                lib.vck_gemv_full(P(b["X"]), P(W), None, P(out), None, P(b["ssq"]), P(b["gw"]), P(b["xg"]), b["npart"], C.c_float(1e-5),
-                                  P(b["scratch"]), C.c_ulonglong(b["scratch"].numel()), P(b["counters"]), b["counters"].numel(), 0,
-                                  M, N, K, ldo, e, G, None)
-            else:
-                lib.vck_gemv_full(P(b["X"]), P(W), None, P(out), P(b["ssq"]), None, None, None, b["npart"], C.c_float(1e-5),
-                                  P(b["scratch"]), C.c_ulonglong(b["scratch"].numel()), P(b["counters"]), b["counters"].numel(), 0,
-                                  M, N, K, ldo, e, G, None)
-        return timeit(f, iters=iters)
-
-    lib.vck_set_gemv_wg_geom.argtypes = [C.c_char_p, C.c_int]
-    for variant in (0, 1):
-        lib.vck_set_gemv_variant(variant)
-        for M in (8, 16, 24, 32):
-            tot = 0.0
-            for (N, K, epi, name, cnt) in shapes:
-                us = run(name, N, K, epi, M, 0)
-                tot += us * cnt
-                print(f"gemv_wg v{variant} M{M:2d} {name:8s}: {us:7.1f} us  {2 * N * K / us / 1e3:7.1f} GB/s", flush=True)
-            print(f"gemv_wg v{variant} M{M:2d} all GEMVs of a 7b decode step: {tot / 1e3:6.3f} ms", flush=True)
-    # split form: the ring kernel serves G = 8 (M <= 8) / 16 (M <= 16); the wg form also G = 32
-    for variant, cases in ((0, ((8, 8), (16, 16))), (1, ((8, 8), (16, 16), (32, 32)))):
-        lib.vck_set_gemv_variant(variant)
-        for M, G in cases:
-            tot = 0.0
-            for (N, K, epi, name, cnt) in shapes:
-                us = run(name, N, K, epi, M, G)
-                tot += us * cnt
-                print(f"gemv_wg split v{variant} M{M:2d} G{G:2d} {name:8s}: {us:7.1f} us  {2 * N * K / us / 1e3:7.1f} GB/s", flush=True)
-            print(f"gemv_wg split v{variant} M{M:2d} G{G:2d} all GEMVs of a 7b decode step: {tot / 1e3:6.3f} ms", flush=True)
-    # geometry sweep at 32 rows (and 8 rows): tiles per wave x K-slices, deep = chunk / ring trade at 25..32 rows (KB_WG_SWEEP=1)
-    lib.vck_set_gemv_variant(1)
-    for (N, K, epi, name, cnt) in (shapes if os.environ.get("KB_WG_SWEEP") == "1" else []):
-        for ntw in (1, 2):
-            for ks in (1, 2, 3, 4, 6, 8):
-                groups = (N // 16 + 4 * ntw - 1) // (4 * ntw)
-                if groups * ks > 1100 or groups * ks < 128 or (K // 64) // ks < 4:
-                    continue
-                res = []
-                for M, deep in ((8, 0), (32, 0), (32, 1)):
-                    lib.vck_set_gemv_wg_geom(f"{N // 16}:{K}:{ntw}:{ks}".encode(), deep)
-                    res.append(run(name, N, K, epi, M, 0, iters=20))
-                print(f"gemv_wg geom {name:8s} ntw{ntw} ks{ks} ({groups * ks:4d} wgs): M8 {res[0]:6.1f}  M32 {res[1]:6.1f}  M32deep {res[2]:6.1f} us", flush=True)
-    lib.vck_set_gemv_wg_geom(b"", -1)
-    lib.vck_set_gemv_variant(-1)
-
-
-def bench_gemv_nt3():
-    """17..32-row bf16 GEMV: two (default) vs three tiles per workgroup (vck_set_gemv_m32_nt3) on the 7b qkv / gate-up shapes and the
-    13b qkv, with the engine's operands; also checks that the two geometries give the same bits"""
-    for (N, K, epi, name) in [(12288, 4096, 0, "qkv"), (22016, 4096, 3, "gate-up"), (15360, 5120, 0, "13b qkv")]:
-        X = bf16(32, K)
-        Ws = [bf16(N * K, scale=0.02) for _ in range(8)]
-        ldo = N // 2 if epi == 3 else N
-        npart = (K // 16 + 15) // 16 * 16
-        ssq = torch.rand(32, npart, device=dev)
-        it = [0]
-        for M in (24, 32):
-            outs = {}
-            for nt3 in (0, 3):
-                lib.vck_set_gemv_m32_nt3(nt3)
-                out = torch.zeros((32, ldo), dtype=torch.bfloat16, device=dev)
-
-                def f():
-                    it[0] += 1
-                    lib.vck_gemv_ex(P(X), P(Ws[it[0] % 8]), None, P(out), P(ssq), None, None, None, npart, C.c_float(1e-5),
-                                    None, None, 0, M, N, K, ldo, epi, None)
-                us = timeit(f, iters=40)
-                it[0] = 7
-                f()
-                torch.cuda.synchronize()
-                outs[nt3] = out.clone()
-                print(f"gemv_nt3 M{M} {name:8s} nt3={nt3}: {us:7.1f} us  {2 * N * K / us / 1e3:7.1f} GB/s", flush=True)
-            print(f"gemv_nt3 M{M} {name:8s} same bits: {bool(torch.equal(outs[0].view(torch.int16), outs[3].view(torch.int16)))}", flush=True)
-    lib.vck_set_gemv_m32_nt3(-1)
+        print(f"gemv_rows M{M:2d} all GEMVs of a 7b decode step: {tot / 1e3:6.3f} ms = {tot / 1e3 / M:6.4f} ms per row", flush=True)
 
 
 def bench_gemv_wide():
-    """ring-kernel GEMV, default geometry vs the "wide" one (vck_set_gemv_wide 0x1d8: ceil(tiles / 256) tiles per workgroup, one deep
-    ring per CU) on every > 512-tile matrix of the 7b and 13b models at 8 / 16 / 24 / 32 rows; same bits?"""
-    for (N, K, epi, name) in [(12288, 4096, 0, "7b qkv"), (22016, 4096, 3, "7b gate-up"), (32000, 4096, 1, "7b lm_head"),
-                              (15360, 5120, 0, "13b qkv"), (27648, 5120, 3, "13b gate-up")]:
+    """ring-kernel GEMV, pair geometry (vck_set_gemv_wide 0) vs the "wide" one (2: ceil(tiles / 256) tiles per workgroup, one deep
+    ring per CU, every class) on every > 512-tile matrix of the 7b and 13b models at 8 / 16 / 24 / 32 rows; same bits?"""
+    for (N, K, epi, name) in [(12288, 4096, 0, "7b qkv"), (22016, 4096, 3, "7b gate-up"), (15360, 5120, 0, "13b qkv"),
+                              (27648, 5120, 3, "13b gate-up")]:
         X = bf16(32, K)
         Ws = [bf16(N * K, scale=0.02) for _ in range(6)]
         ldo = N // 2 if epi == 3 else N
@@ -268,7 +163,7 @@ def bench_gemv_wide():
         it = [0]
         for M in (8, 16, 24, 32):
             outs, t = {}, {}
-            for wide in (0, 0x1d8):
+            for wide in (0, 2):
                 lib.vck_set_gemv_wide(wide)
                 out = torch.zeros((32, ldo), dtype=torch.float32 if epi == 1 else torch.bfloat16, device=dev)
 
@@ -281,50 +176,32 @@ def bench_gemv_wide():
                 f()
                 torch.cuda.synchronize()
                 outs[wide] = out.clone()
-            same = torch.equal(outs[0].view(torch.int32 if epi == 1 else torch.int16), outs[0x1d8].view(torch.int32 if epi == 1 else torch.int16))
-            print(f"gemv_wide M{M:2d} {name:12s}: default {t[0]:6.1f} us ({2 * N * K / t[0] / 1e3:6.0f} GB/s)  wide {t[0x1d8]:6.1f} us "
-                  f"({2 * N * K / t[0x1d8] / 1e3:6.0f} GB/s)  same bits {same}", flush=True)
+            same = torch.equal(outs[0].view(torch.int32 if epi == 1 else torch.int16), outs[2].view(torch.int32 if epi == 1 else torch.int16))
+            print(f"gemv_wide M{M:2d} {name:12s}: default {t[0]:6.1f} us ({2 * N * K / t[0] / 1e3:6.0f} GB/s)  wide {t[2]:6.1f} us "
+                  f"({2 * N * K / t[2] / 1e3:6.0f} GB/s)  same bits {same}", flush=True)
     lib.vck_set_gemv_wide(-1)
 
 
-def bench_gemv_kvirt():
-    """17..32-row bf16 GEMV over the 256-tile matrices (7b o_proj / down, the engine's residual epilogue with the next norm folded):
-    the 8-wave single-tile workgroup vs "virtual waves" (vck_set_gemv_m32_kvirt 1: tile pairs, 2: tile quads); same bits?"""
-    for (N, K, name) in [(4096, 4096, "o"), (4096, 11008, "down")]:
-        X = bf16(32, K)
-        Ws = [bf16(N * K, scale=0.02) for _ in range(8)]
-        npart = (4096 // 16 + 15) // 16 * 16
-        ssq = torch.zeros(32, npart, device=dev)
-        gw = torch.rand(N, device=dev) + 0.5
-        xg = torch.zeros((32, N), dtype=torch.bfloat16, device=dev)
-        nsk = 8 * (N // 16) * 2 * 256
-        scratch = torch.zeros(nsk, device=dev)
-        counters = torch.zeros(N // 16 * 2, dtype=torch.int32, device=dev)
-        r0 = torch.randn(32, N, device=dev)
-        out = r0.clone()
-        it = [0]
+def bench_gemm_chunk():
+    """go / no-go of the chunked-prefill idea: the decoder GEMMs at M = 288 / 320 / 384 rows (a prefill chunk plus
+    the pool's 32 decode rows) with the weights streamed from HBM (4 rotating copies); the sum per layer against 150 us."""
+    for M in (288, 320, 384, 512):
+        tot = 0.0
+        for (N, K, epi, name) in [(12288, 4096, 0, "qkv"), (4096, 4096, 4, "o"), (22016, 4096, 5, "gate-up"), (4096, 11008, 4, "down")]:
+            A = bf16(M, K)
+            Ws = [bf16(N, K, scale=0.02) for _ in range(4)]
+            out = torch.zeros((M, N), dtype=torch.float32 if epi in (3, 4) else torch.bfloat16, device=dev)
+            ldo = N // 2 if epi == 5 else N
+            ws = torch.zeros(16 << 20, device=dev)
+            it = [0]
 
-        def f():
-            it[0] += 1
-            lib.vck_gemv_full(P(X), P(Ws[it[0] % 8]), None, P(out), None, P(ssq), P(gw), P(xg), npart, C.c_float(1e-5), P(scratch),
-                              C.c_ulonglong(nsk), P(counters), N // 16 * 2, 0, M, N, K, N, 2, 0, None)
-        for M in (24, 32):
-            res = {}
-            for mode in (0, 1, 2):
-                lib.vck_set_gemv_m32_kvirt(mode)
-                us = timeit(f, iters=40)
-                out.copy_(r0)
-                it[0] = 7
-                f()
-                torch.cuda.synchronize()
-                res[mode] = (out.clone(), xg.clone(), ssq.clone())
-                print(f"gemv_kvirt M{M} {name:5s} mode {mode}: {us:7.1f} us  {2 * N * K / us / 1e3:7.1f} GB/s", flush=True)
-            same = [all(torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a.view(torch.int16),
-                                    b.view(torch.int32) if b.dtype == torch.float32 else b.view(torch.int16))
-                        for a, b in zip(res[0], res[m_])) for m_ in (1, 2)]
-            print(f"gemv_kvirt M{M} {name:5s} same bits as the 8-wave workgroup: pairs {same[0]}, quads {same[1]}; counters re-armed: "
-                  f"{not bool(counters.any())}", flush=True)
-    lib.vck_set_gemv_m32_kvirt(-1)
+            def f():
+                it[0] += 1
+                lib.vck_gemm_ws(P(A), P(Ws[it[0] % 4]), None, P(out), M, N, K, K, K, ldo, epi, P(ws), C.c_size_t(64 << 20), None)
+            us = timeit(f, iters=20)
+            tot += us
+            print(f"gemm_chunk M{M} {name:8s}: {us:7.1f} us  {2 * M * N * K / us / 1e6:7.1f} TFLOP/s  weights {2 * N * K / us / 1e3:6.0f} GB/s", flush=True)
+        print(f"gemm_chunk M{M} layer sum: {tot:7.1f} us (go if <= 150)", flush=True)
 
 
 def bench_gemv_rows8():
@@ -561,33 +438,9 @@ def bench_dattn():
 
 if __name__ == "__main__":
     what = sys.argv[1:] or ["gemm", "gemv", "attn", "dattn"]
-    if "gemv_fp8" in what:
-        bench_gemv_fp8()
-    if "gemv13" in what:
-        bench_gemv13()
-    if "gemv_pair" in what:
-        bench_gemv_pair()
-    if "gemv_rows" in what:
-        bench_gemv_rows()
-    if "dattn_rows" in what:
-        bench_dattn_rows()
-    if "gemm_f8" in what:
-        bench_gemm_f8()
-    if "gemv_rows8" in what:
-        bench_gemv_rows8()
-    if "gemv_wg" in what:
-        bench_gemv_wg()
-    if "gemv_nt3" in what:
-        bench_gemv_nt3()
-    if "gemv_kvirt" in what:
-        bench_gemv_kvirt()
-    if "gemv_wide" in what:
-        bench_gemv_wide()
-    if "dattn_split" in what:
-        bench_dattn_split()
-    if "dattn_kv8" in what:
-        bench_dattn_kv8()
+    table = {"gemm": bench_gemm, "gemv": bench_gemv, "attn": bench_attn, "dattn": bench_dattn, "gemv_fp8": bench_gemv_fp8,
+             "gemv13": bench_gemv13, "gemv_pair": bench_gemv_pair, "gemv_rows": bench_gemv_rows, "dattn_rows": bench_dattn_rows,
+             "gemm_f8": bench_gemm_f8, "gemv_rows8": bench_gemv_rows8, "gemv_wide": bench_gemv_wide, "gemm_chunk": bench_gemm_chunk,
+             "dattn_split": bench_dattn_split, "dattn_kv8": bench_dattn_kv8}
     for w in what:
-        {"gemm": bench_gemm, "gemv": bench_gemv, "attn": bench_attn, "dattn": bench_dattn,
-         "gemv_fp8": lambda: None, "gemv13": lambda: None, "gemv_pair": lambda: None, "gemv_rows": lambda: None,
-         "dattn_rows": lambda: None, "gemm_f8": lambda: None, "gemv_rows8": lambda: None, "gemv_wg": lambda: None, "gemv_nt3": lambda: None, "gemv_kvirt": lambda: None, "gemv_wide": lambda: None, "dattn_split": lambda: None, "dattn_kv8": lambda: None}[w]()
+        table[w]()

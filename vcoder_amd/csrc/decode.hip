@@ -78,13 +78,8 @@ VC_DEV void gemv_epilogue(const GemvArgs& p, f32x4 v, const float* ss_part /*[WA
     }
 }
 
-// WAVES waves split K (k-tiles interleaved: wave w takes tiles w, w + WAVES, ... so the workgroup reads the packed
-// stream in contiguous 1-KiB x WAVES runs and every wave's share differs by at most one tile); a workgroup owns NT
-// consecutive 16-output tiles so one activation fragment feeds NT weight tiles.  Activation fragments come straight
-// from L2 (bf16 [M, K], at most 16 x K x 2 B per launch).
-//
 // RMSNorm is folded WITHOUT a prologue: out = rstd[m] * sum_k (x[m][k] * g[k]) * W[n][k], so the kernel that produces
-// the residual row also writes xg = bf16(x * g) for its consumer (RESID epilogue below / the embedding kernels) together
+// the residual row also writes xg = bf16(x * g) for its consumer (RESID epilogue above / the embedding kernels) together
 // with deterministic sum-of-squares partials, and the consumer multiplies its fp32 accumulator by
 // rstd[m] = rsqrt(sum_p ssq[m][p] / K + eps) in the epilogue ([HF] llama/modeling_llama.py:62-67 with the scalar factor
 // moved out of the dot product).  The partials are fetched while the weights stream.
@@ -93,112 +88,10 @@ VC_DEV void gemv_epilogue(const GemvArgs& p, f32x4 v, const float* ss_part /*[WA
 // 64-wide k "super tile" per wave-instruction ([N/16][K/64][64 lanes][16 B]; lane = n%16 + 16*((k%64)/16)).  The bytes
 // are widened to bf16 fragments in registers (exact) and fed to two MFMAs whose activation fragments use the same k
 // assignment; the per-output-row power-of-two scale multiplies the fp32 accumulator in the epilogue (exact).
-template <int WAVES, int NT, int EPI, bool FP8>
-__global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
-    constexpr int KT = FP8 ? 64 : 32;   // k columns per 16-byte weight load
-    constexpr int KSH = FP8 ? 6 : 5;
-    constexpr int GK = KT / 4;          // k columns per lane group
-    __shared__ __attribute__((aligned(16))) float red[WAVES * NT * 64 * 4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ntiles = p.N >> 4;
-    const int nt0 = blockIdx.x * NT;
-    const int nkt = p.K >> KSH;
-    const int m = lane & 15, g = lane >> 4;
-    const bool mvalid = m < p.M;
-    const bf16_t* wp[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) wp[t] = p.Wp + ((size_t)min(nt0 + t, ntiles - 1) * nkt * 64 + lane) * 8;
-    const bf16_t* xp = p.X + (size_t)(mvalid ? m : 0) * p.K + g * GK;
-    f32x4 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // K loop, software-pipelined over batches of U k-tiles with two register sets: the weight loads of batch b+1 are in
-    // flight while the MFMAs of batch b run.  Tiles past the end re-read the last tile against zero activations, so
-    // there is no unpipelined tail.
-    constexpr int U = 8 / NT;
-    const int cnt = (nkt - wave + WAVES - 1) / WAVES;  // k-tiles of this wave (wave-uniform)
-    const int nb = (cnt + U - 1) / U;
-    u32x4 wa[NT][U], wb[NT][U];
-    auto load_w = [&](u32x4 (&w)[NT][U], int b) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int kt = min(wave + (b * U + u) * WAVES, nkt - 1);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) w[t][u] = ld16_stream(wp[t] + (size_t)kt * 512);
-        }
-    };
-    if (nb > 0) load_w(wa, 0);
-    // 1/rms of row m from the producer's partials: every wave sums a slice (independent loads issued behind the first
-    // weight batch), the slices meet in LDS at the barrier that also ends the K loop; fixed order -> bit-reproducible
-    __shared__ float ss_part[WAVES][16];
-    if (p.ssq_in != nullptr) {
-        const float* sp = p.ssq_in + (size_t)m * p.npart;
-        float s0 = 0.f, s1 = 0.f;
-        const int nq = p.npart >> 2;
-        for (int q = wave * 4 + g; q < nq; q += WAVES * 8) {
-            const f32x4 v = ld16f(sp + q * 4);
-            f32x4 u = {0.f, 0.f, 0.f, 0.f};
-            if (q + WAVES * 4 < nq) u = ld16f(sp + (q + WAVES * 4) * 4);
-            s0 += (v[0] + v[1]) + (v[2] + v[3]);
-            s1 += (u[0] + u[1]) + (u[2] + u[3]);
-        }
-        float ss = s0 + s1;
-        ss += shfl_xor(ss, 16);
-        ss += shfl_xor(ss, 32);
-        if (g == 0) ss_part[wave][m] = ss;
-    }
-    auto fma_tile = [&](f32x4& a, const u32x4& w, const u32x4& x0, const u32x4& x1) {
-        if constexpr (FP8) {
-            const u32x2 b0 = fp8x4_to_bf16x4(w[0]), b1 = fp8x4_to_bf16x4(w[1]);
-            const u32x2 b2 = fp8x4_to_bf16x4(w[2]), b3 = fp8x4_to_bf16x4(w[3]);
-            a = mfma16(u32x4{b0[0], b0[1], b1[0], b1[1]}, x0, a);
-            a = mfma16(u32x4{b2[0], b2[1], b3[0], b3[1]}, x1, a);
-        } else {
-            a = mfma16(w, x0, a);
-        }
-    };
-    auto compute = [&](u32x4 (&w)[NT][U], int b) {
-        u32x4 xv[U], xw[FP8 ? U : 1];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int kt = wave + (b * U + u) * WAVES;
-            const bool ok = mvalid && kt < nkt;
-            const bf16_t* xq = xp + (size_t)min(kt, nkt - 1) * KT;
-            const u32x4 z = {0u, 0u, 0u, 0u};
-            xv[u] = ld16(xq);
-            if (!ok) xv[u] = z;
-            if constexpr (FP8) {
-                xw[u] = ld16(xq + 8);
-                if (!ok) xw[u] = z;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) fma_tile(acc[t], w[t][u], xv[u], xw[FP8 ? u : 0]);
-    };
-    for (int b = 0; b < nb; b += 2) {
-        if (b + 1 < nb) load_w(wb, b + 1);
-        compute(wa, b);
-        if (b + 1 < nb) {
-            if (b + 2 < nb) load_w(wa, b + 2);
-            compute(wb, b + 1);
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) st16f(red + ((wave * NT + t) * 64 + lane) * 4, acc[t]);
-    __syncthreads();
-    if (wave >= NT) return;
-    const int nt = nt0 + wave;  // wave t finishes tile t
-    if (nt >= ntiles) return;
-    f32x4 v = ld16f(red + ((0 * NT + wave) * 64 + lane) * 4);
-#pragma unroll
-    for (int w = 1; w < WAVES; ++w) v = v + ld16f(red + ((w * NT + wave) * 64 + lane) * 4);
-    gemv_epilogue<WAVES, EPI, FP8>(p, v, &ss_part[0][0], nt, m, g, mvalid);
-}
-
-// ---- LDS-DMA form (default) ----------------------------------------------------------------------------------------------
-// Same arithmetic and epilogues as gemv_kernel, but nothing of the stream ever sits in VGPRs: every wave owns a private
+//
+// ---- the per-wave-ring kernel (LDS-DMA) ----------------------------------------------------------------------------------
+// WAVES waves split K (k-lines interleaved: wave w takes lines w, w + WAVES, ...); a workgroup owns NT consecutive 16-output
+// tiles so one activation fragment feeds NT weight tiles.  Nothing of the stream ever sits in VGPRs: every wave owns a private
 // ring of R slots in LDS; one slot = the NT packed 1-KiB weight blocks of a k-tile (non-temporal global_load_lds) plus the
 // matching activation fragment piece(s) (one 16-byte gather per lane, default cache policy: every workgroup re-reads
 // them from L2).  All vector-memory operations of the loop are DMAs issued in program order, OPS per k-tile, so the
@@ -206,7 +99,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
 // read back with ds_read_b128 (lane-linear, conflict-free), fed to the MFMAs and re-armed for k-tile i+R.  A wave only
 // ever reads LDS bytes that it DMA'd itself, so its own vmcnt wait is the only ordering needed (no barrier in the loop).
 // ~40 VGPRs per wave: occupancy is set by the ring size alone.  A pure stream of this shape measures 5.8-6.1 TB/s at the
-// qkv / gate-up launch sizes (tools/experiments/corun.hip) against 5.0-5.3 for the register-staged loop above.
+// qkv / gate-up launch sizes (tools/experiments/corun.hip) against 5.0-5.3 for a register-staged loop (rounds 1-4 kept one as a
+// regression variant; removed in round 5).
 // XP = 8-row pieces of the activation operand per ring slot (1..4: M <= 8 / 16 / 24 / 32); MG = (XP + 1) / 2 MFMA row groups
 // of 16 token rows, each weight block read from LDS feeding MG MFMAs.  The assignment of k-tiles to waves and K-slices does
 // not depend on XP (nor on NT / R), so a row's sum is formed in the same order whichever variant serves it: the decode
@@ -218,38 +112,29 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs p) {
 // fragment-shaped gather (16 rows x 64 B per instruction).  The LDS image of a piece is lane-linear [8 rows][8 chunks of
 // 16 B]; the chunk a lane fetches is XOR-swizzled by (row >> 1) & 7 on the SOURCE side (the DMA writes linearly), so the
 // 16 lanes of a ds_read_b128 group — 16 rows, one chunk column — hit 16 distinct 16-byte bank slots.
-// KVT > 1: the "virtual waves" form (GemvArgs::kvirt == KVT; a template parameter so that the default kernels carry none of it)
-template <int WAVES, int NT, int R, int EPI, bool FP8, int XP = 2, int KVT = 1>
+template <int WAVES, int NT, int R, int EPI, bool FP8, int XP = 2>
 __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
-#ifndef VC_GEMV_DBG
-#define VC_GEMV_DBG 0
-#endif
-    // timing experiments only (tools/experiments/gemv_rows_ab.sh; results are garbage): 1 = 32-row MFMA / LDS work on ONE
-    // fetched activation piece; 2 = all four pieces fetched, one MFMA row group
-    constexpr int XPL = (VC_GEMV_DBG == 1 && XP == 4) ? 1 : XP;
-    constexpr int MG = (VC_GEMV_DBG == 2 && XP == 4) ? 1 : (XP + 1) / 2;
+    constexpr int MG = (XP + 1) / 2;
     constexpr int KSH = FP8 ? 6 : 5;
     // k-tiles per ring slot: a slot always spans 64 k = one 128-byte line of every activation row: a PAIR of 32-wide bf16
     // k-tiles, or one 64-wide W8A16 super-tile
     constexpr int KPI = FP8 ? 1 : 2;
     constexpr int WB = KPI * NT;             // 1-KiB weight blocks per slot
-    constexpr int OPS = WB + XPL;            // DMA instructions per slot
+    constexpr int OPS = WB + XP;            // DMA instructions per slot
     constexpr int SLOT = OPS * 1024;
     static_assert(WAVES * R * SLOT >= WAVES * NT * MG * 1024, "the ring is re-used for the cross-wave reduction");
+    stamp_begin(p.stamp);
     VC_DYNAMIC_SMEM(char, ring);             // [WAVES][R][SLOT]
     __shared__ float ss_part[WAVES][16 * MG];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntiles = p.N >> 4;
-    constexpr int KV = KVT;                      // virtual-wave slices (GemvArgs::kvirt)
-    const int KS = KV > 1 ? KV : (p.ksplit > 1 ? p.ksplit : 1);
+    const int KS = p.ksplit > 1 ? p.ksplit : 1;
     const int ks = (int)blockIdx.x % KS;
     const int nt0 = ((int)blockIdx.x / KS) * NT;
     const int nkt = p.K >> KSH;
     const int nit = (nkt + KPI - 1) / KPI;   // slots' worth of k-tiles in the matrix
-    // this workgroup's share of K: a contiguous slice (ksplit), or — virtual waves — all of K at the stride of WAVES * KV waves
-    const int it0 = KV > 1 ? 0 : (int)((long)ks * nit / KS), it1 = KV > 1 ? nit : (int)((long)(ks + 1) * nit / KS);
-    const int vwave = KV > 1 ? wave + WAVES * ks : wave;   // this wave's place among the waves that interleave K
-    constexpr int vstride = WAVES * KV;
+    // this workgroup's share of K: a contiguous slice (ksplit)
+    const int it0 = (int)((long)ks * nit / KS), it1 = (int)((long)(ks + 1) * nit / KS);
     const int m = lane & 15, g = lane >> 4;
     // precision mode "split" (p.split_rows = G in {8, 16}): X holds G + M rows — rows [0, M) the bf16 hi parts of the M
     // activation rows, rows [G, G + M) their lo parts (x = hi + lo) — and the two partial products of a row meet in the
@@ -282,18 +167,17 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
     const bool half_line = (p.K * 2) % 128 != 0;                             // bf16, odd k-tile count: 64 valid bytes in it
     auto issue = [&](int i, int slot) {
         char* dst = my + slot * SLOT;
-        const int is = it0 + vwave + i * vstride;                            // slot index along K = line index of X
+        const int is = it0 + wave + i * WAVES;                            // slot index along K = line index of X
 #pragma unroll
         for (int kk = 0; kk < KPI; ++kk) {
             const size_t kt = (size_t)min(is * KPI + kk, nkt - 1);           // an odd tail re-reads the last tile
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                if (p.w_cached) glds16(wsrc[t] + kt * 1024, dst + (kk * NT + t) * 1024);
-                else glds16_nt(wsrc[t] + kt * 1024, dst + (kk * NT + t) * 1024);
+                glds16_nt(wsrc[t] + kt * 1024, dst + (kk * NT + t) * 1024);
             }
         }
 #pragma unroll
-        for (int x = 0; x < XPL; ++x) {
+        for (int x = 0; x < XP; ++x) {
             // the half line at the end of an odd-k-tile row holds only chunks 0..3: the other lanes re-read a valid chunk
             // (their values meet zeroed weights' partner: the consumer zeroes the activation fragment of that k-tile)
             const int c = (half_line && is >= kline_last) ? (xc[x] & 3) : xc[x];
@@ -309,7 +193,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
     auto xoff = [&](int q, int c) {
         const int row = 16 * q + m;
         const int pc = FP8 ? ((c >> 1) | ((c & 1) << 2)) : c;
-        return (WB + (VC_GEMV_DBG == 1 ? 0 : (row >> 3))) * 1024 + ((row & 7) * 8 + (pc ^ ((row >> 1) & 7))) * 16;
+        return (WB + (row >> 3)) * 1024 + ((row & 7) * 8 + (pc ^ ((row >> 1) & 7))) * 16;
     };
     auto consume = [&](int i, int slot) {
         const char* s = my + slot * SLOT;
@@ -322,7 +206,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
             u32x4 w[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) w[t] = ld16(sl + (kk * NT + t) * 1024);
-            const bool tail = KPI > 1 && (it0 + vwave + i * vstride) * KPI + kk >= nkt;
+            const bool tail = KPI > 1 && (it0 + wave + i * WAVES) * KPI + kk >= nkt;
             u32x4 x0[MG], x1[MG];
 #pragma unroll
             for (int q = 0; q < MG; ++q) {
@@ -353,7 +237,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
         wait_lgkmcnt<0>();  // the slot's fragment reads have retired before it is re-armed
         wave_lds_fence();
     };
-    const int cnt = max(0, (it1 - it0 - vwave + vstride - 1) / vstride);  // slots of this wave (wave-uniform)
+    const int cnt = max(0, (it1 - it0 - wave + WAVES - 1) / WAVES);  // slots of this wave (wave-uniform)
     const int primed = min(cnt, R);
     // 1/rms of the rows from the producer's partials: the register loads are issued BEFORE the ring is primed, so the wait
     // the compiler places at their first use leaves every DMA in flight (vmcnt counts in order)
@@ -454,46 +338,26 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
         // measured 4-8x slower launches.  The scratch is laid out for two row groups whatever MG is.
         const size_t unit = (size_t)nt * 2 + fq;
         auto entry = [&](int e) { return p.sk_scratch + (((size_t)e * ntiles * 2 + unit) * 64 + lane) * 4; };
-        if (KV > 1 && ks > 0) {
-            // virtual waves: slices behind the first hand over every wave's partial UNSUMMED (entries 1 + (ks-1)*WAVES + w)
+        float* mine = entry(ks);
 #pragma unroll
-            for (int w = 0; w < WAVES; ++w) {
-                const f32x4 pw = ld16f(red + (((w * NT + ft) * MG + fq) * 64 + lane) * 4);
-                float* mine = entry(1 + (ks - 1) * WAVES + w);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) st_agent(mine + e, pw[e]);
-            }
-        } else {
-            float* mine = entry(ks);   // (virtual waves, slice 0: entry 0 = its waves summed in order, the head of the sequence)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) st_agent(mine + e, v[e]);
-        }
+        for (int e = 0; e < 4; ++e) st_agent(mine + e, v[e]);
         wait_vmcnt<0>();  // the write-through stores have been acknowledged before the arrival is counted
         wave_lds_fence(); // (a wave issues as one on the hardware; the emulator's lane fibers must all have stored before lane 0 counts)
         unsigned arrived = 0;
         if (lane == 0) arrived = atomic_inc_agent(&p.sk_counters[unit]);
         arrived = shfl(arrived, 0);
         if (arrived != (unsigned)(KS - 1)) continue;
-        if (KV > 1) {
+        v = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < KS; ++k) {
+            const float* q = entry(k);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = ld_agent(entry(0) + e);
-            for (int k = 1; k < 1 + (KV - 1) * WAVES; ++k) {
-                const float* q = entry(k);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += ld_agent(q + e);
-            }
-        } else {
-            v = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int k = 0; k < KS; ++k) {
-                const float* q = entry(k);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += ld_agent(q + e);
-            }
+            for (int e = 0; e < 4; ++e) v[e] += ld_agent(q + e);
         }
         if (lane == 0) st_agent_u32(&p.sk_counters[unit], 0u);  // re-armed for the next launch (stream order)
     }
     gemv_epilogue<WAVES, EPI, FP8, 16 * MG>(p, v, &ss_part[0][0], nt, m + 16 * fq, g, ovalid[fq]);
     }
+    stamp_end(p.stamp);
 }
 
 // ---- workgroup-shared activation form ("wg"; bf16 weights, K % 64 == 0) ------------------------------------------------------
@@ -524,6 +388,7 @@ __global__ __launch_bounds__(256) void gemv_wg_kernel(GemvArgs p) {
     static_assert((CL * P) % WAVES == 0, "the chunk's pieces are dealt evenly to the four waves");
     constexpr int XBUF = CL * P * 1024;       // one activation chunk
     constexpr int SLOT = WO * 1024;
+    stamp_begin(p.stamp);
     VC_DYNAMIC_SMEM(char, lds);               // [2][XBUF] activation chunks | [WAVES][R][SLOT] weight rings
     __shared__ float ss_part[WAVES][16 * MG];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -568,8 +433,7 @@ __global__ __launch_bounds__(256) void gemv_wg_kernel(GemvArgs p) {
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
-                if (p.w_cached) glds16(wsrc[t] + (line * 2 + kk) * 1024, dst + (kk * NTW + t) * 1024);
-                else glds16_nt(wsrc[t] + (line * 2 + kk) * 1024, dst + (kk * NTW + t) * 1024);
+                glds16_nt(wsrc[t] + (line * 2 + kk) * 1024, dst + (kk * NTW + t) * 1024);
             }
     };
     f32x4 acc[NTW][MG];
@@ -711,6 +575,7 @@ __global__ __launch_bounds__(256) void gemv_wg_kernel(GemvArgs p) {
             gemv_epilogue<WAVES, EPI, false, 16 * MG>(p, v, &ss_part[0][0], nt, m + 16 * q, g, ovalid[q]);
         }
     }
+    stamp_end(p.stamp);
 }
 
 template <class K>
@@ -719,17 +584,6 @@ static void allow_big_lds(K kernel, size_t bytes) {
     if (bytes > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 #endif
-}
-
-template <int WAVES, int NT, bool FP8>
-static void launch_gemv_w(const GemvArgs& a, int epi, hipStream_t s) {
-    const dim3 grid((a.N / 16 + NT - 1) / NT), block(WAVES * 64);
-    switch (epi) {
-        case GEMV_BF16: VC_LAUNCH((gemv_kernel<WAVES, NT, GEMV_BF16, FP8>), grid, block, 0, s, a); break;
-        case GEMV_F32: VC_LAUNCH((gemv_kernel<WAVES, NT, GEMV_F32, FP8>), grid, block, 0, s, a); break;
-        case GEMV_RESID_F32: VC_LAUNCH((gemv_kernel<WAVES, NT, GEMV_RESID_F32, FP8>), grid, block, 0, s, a); break;
-        default: VC_LAUNCH((gemv_kernel<WAVES, NT, GEMV_SWIGLU, FP8>), grid, block, 0, s, a); break;
-    }
 }
 
 template <int WAVES, int NT, int R, bool FP8, int XP>
@@ -772,116 +626,24 @@ static void launch_gemv_dma2(const GemvArgs& a, int epi, hipStream_t s) {
     else launch_gemv_dma_x<WAVES, NT, R, FP8, 4>(a, epi, s);
 }
 
+// K-slices of the 257..512-tile class (13b o_proj / down: 320 tiles neither fill the chip one-per-CU nor balance two-per-CU):
+// with the split-K buffers, pairs of tiles x 3 K-slices = 480 workgroups, all resident (2/CU), activation fragments shared by
+// the pair (measured M = 16: down 43.0 -> 30.2 us, o_proj 20.1 -> 14.9; for <= 256 tiles every split loses: 8.5 -> 10 us).
+// An explicit a.ksplit is honoured.
+constexpr int KS_MID = 3;
+
 // M in 17..32 (the decode pool): two row groups per weight pass.  The K partition (waves per workgroup, K-slices) of every
 // tile-count class equals the 16-row launcher's below, so a row's result does not depend on which variant served it; only
 // the tiles per workgroup and the ring depth are re-balanced for the larger slots (LDS: all workgroups resident).
-// VC_GEMV2_NT3 / set_gemv_m32_nt3 (bf16 weights, 17..32 rows; default 3 = both classes on, 0 = off): THREE tiles per
-// workgroup.  The ring of a 32-row slot is half activation pieces at two tiles per workgroup (4 KiB of weights + 4 KiB of X per
-// slot), which caps the weight bytes a CU keeps in flight at 64 KiB; three tiles make a slot 6 + 4 KiB (0.67 activation bytes
-// per weight byte instead of 1.0).  It pays exactly where the triples also BALANCE over the 256 CUs:
-//   bit 1: triples that fit ONE per CU (193..256 workgroups; 7b qkv: 768 tiles -> 256) with a 3-slot ring — 72 KiB in flight on
-//          every CU, where the default's 384 pair-workgroups sit two on half the CUs and one on the other half:
-//          25.0 -> 20.2 us at 32 rows, 23.4 -> 20.3 at 24 (profiles/r04_q_kbench_gemv_nt3.txt);
-//   bit 0: triples all resident two per CU (385..512 workgroups of 80 KiB; 7b gate/up: 1376 tiles -> 459), 96 KiB in flight per
-//          CU: 37.6 -> 36.9 us at 32 rows, 36.9 -> 33.6 at 24.
-// Anything else keeps pairs: the 13b qkv (960 tiles -> 320 triples, 2 per CU on 160 CUs) measured 32.7 -> 40.8 us.
-// Same K partition (4 waves, no K-slices), so every row's bits are those of the other variants (checked on the device, same file).
-static int g_m32_nt3 = -1;
-static std::atomic<unsigned long> g_m32_nt3_launches{0};   // sessions launch from their own threads
-void set_gemv_m32_nt3(int v) { g_m32_nt3 = v; }
-unsigned long gemv_m32_nt3_launches() { return g_m32_nt3_launches.load(std::memory_order_relaxed); }
-static int gemv_m32_nt3_now() {
-    static const int env = getenv("VC_GEMV2_NT3") ? atoi(getenv("VC_GEMV2_NT3")) : 3;
-    return g_m32_nt3 >= 0 ? g_m32_nt3 : env;
-}
-
-// VC_GEMV2_KVIRT / set_gemv_m32_kvirt (bf16 weights, 17..32 rows, 129..256 tiles: 7b o_proj / down; default 0 = off): the
-// 8-wave workgroup of that class (one tile, 2 activation bytes per weight byte, 48 KiB of weights in flight per CU) as "virtual
-// waves" — GemvArgs::kvirt — so that tiles can be grouped without leaving CUs idle and without changing a bit:
-//   1: 2 slices x 4 waves, tile PAIRS  (256 workgroups, 4-slot rings: 64 KiB in flight, 1.0 activation bytes per weight byte)
-//   2: 4 slices x 2 waves, tile QUADS  (256 workgroups, 5-slot rings: 80 KiB in flight, 0.5)
-static int g_m32_kvirt = -1;
-static std::atomic<unsigned long> g_m32_kvirt_launches{0};   // sessions launch from their own threads
-void set_gemv_m32_kvirt(int v) { g_m32_kvirt = v; }
-unsigned long gemv_m32_kvirt_launches() { return g_m32_kvirt_launches.load(std::memory_order_relaxed); }
-static int gemv_m32_kvirt_now() {
-    static const int env = getenv("VC_GEMV2_KVIRT") ? atoi(getenv("VC_GEMV2_KVIRT")) : 0;
-    return g_m32_kvirt >= 0 ? g_m32_kvirt : env;
-}
-
-template <int WAVES, int NT, int R, int EPI, int XP, int KVT>
-static void launch_gemv_kvirt1(const GemvArgs& a, hipStream_t s) {
-    const dim3 grid(((a.N / 16 + NT - 1) / NT) * KVT), block(WAVES * 64);
-    constexpr size_t shmem = (size_t)WAVES * R * (2 * NT + XP) * 1024;
-    static_assert(shmem + WAVES * 16 * ((XP + 1) / 2) * 4 <= 160 * 1024, "ring exceeds the LDS of a CU");
-    static bool once = false;
-    if (!once) {
-        allow_big_lds(gemv_dma_kernel<WAVES, NT, R, EPI, false, XP, KVT>, shmem);
-        once = true;
-    }
-    VC_LAUNCH((gemv_dma_kernel<WAVES, NT, R, EPI, false, XP, KVT>), grid, block, shmem, s, a);
-}
-
 template <bool FP8>
 static void launch_gemv_m32(const GemvArgs& a, int epilogue, hipStream_t s) {
     const int tiles = a.N / 16;
-    if constexpr (!FP8) {
-        const int kvm = gemv_m32_kvirt_now();
-        if (kvm && tiles > 128 && tiles <= 256 && a.ksplit <= 1 && !a.split_rows && !a.ssq_in && a.sk_scratch && a.sk_counters) {
-            // only with buffers of DECLARED capacity (the entry count differs from the K-slice forms the historical size assumes)
-            const size_t cap = a.sk_scratch_floats;
-            const int ncnt = a.sk_counters_n;
-            const int kv = kvm == 2 ? 4 : 2, wv = 8 / kv;
-            if ((size_t)(1 + (kv - 1) * wv) * tiles * 2 * 256 <= cap && tiles * 2 <= ncnt) {
-                GemvArgs b = a;
-                b.kvirt = kv;
-                b.ksplit = 0;
-                g_m32_kvirt_launches.fetch_add(1, std::memory_order_relaxed);
-                const bool x3 = x_rows(a) <= 24;
-#define VC_KVIRT(E)                                                                                       \
-    do {                                                                                                  \
-        if (kvm == 2) x3 ? launch_gemv_kvirt1<2, 4, 5, E, 3, 4>(b, s) : launch_gemv_kvirt1<2, 4, 5, E, 4, 4>(b, s); \
-        else x3 ? launch_gemv_kvirt1<4, 2, 4, E, 3, 2>(b, s) : launch_gemv_kvirt1<4, 2, 4, E, 4, 2>(b, s);          \
-    } while (0)
-                switch (epilogue) {
-                    case GEMV_BF16: VC_KVIRT(GEMV_BF16); break;
-                    case GEMV_F32: VC_KVIRT(GEMV_F32); break;
-                    case GEMV_RESID_F32: VC_KVIRT(GEMV_RESID_F32); break;
-                    default: VC_KVIRT(GEMV_SWIGLU); break;
-                }
-#undef VC_KVIRT
-                return;
-            }
-        }
-    }
-    if constexpr (!FP8) {
-        const int nt3 = gemv_m32_nt3_now();
-        if (nt3 && a.ksplit <= 1 && !a.split_rows) {   // (hi / lo operand rows keep the pair geometry they were validated on)
-            const int triples = (tiles + 2) / 3;
-            if ((nt3 & 2) && tiles > 512 && triples > 192 && triples <= 256) {
-                g_m32_nt3_launches.fetch_add(1, std::memory_order_relaxed);
-                launch_gemv_dma2<4, 3, 3, false>(a, epilogue, s);
-                return;
-            }
-            if ((nt3 & 1) && tiles > 512 && triples > 384 && triples <= 512) {
-                g_m32_nt3_launches.fetch_add(1, std::memory_order_relaxed);
-                launch_gemv_dma2<4, 3, 2, false>(a, epilogue, s);
-                return;
-            }
-        }
-    }
-    static const int ks_env = getenv("VC_GEMV_KS") ? atoi(getenv("VC_GEMV_KS")) : -1;
-    // VC_GEMV2_GEOM: tuning knob for the 513..768-tile class (7b qkv): 0 = 4 waves x 1 tile, 2-slot ring (3 workgroups/CU),
-    // 1 = 4 waves x 2 tiles, 2-slot ring (2/CU, the pair shares the activation pieces; measured 28.3 vs 33.9 us at M = 24)
-    static const int geom = getenv("VC_GEMV2_GEOM") ? atoi(getenv("VC_GEMV2_GEOM")) : 1;
     if (a.ksplit > 1 || (a.sk_scratch && a.sk_counters && a.ksplit == 0 && tiles > 256 && tiles <= 512)) {
         GemvArgs b = a;
-        if (b.ksplit <= 1) b.ksplit = ks_env >= 0 ? ks_env : 3;
-        if (b.ksplit > 1) {
-            if (a.ksplit > 1 && tiles <= 256) launch_gemv_dma2<4, 1, 2, FP8>(b, epilogue, s);
-            else launch_gemv_dma2<4, 2, 2, FP8>(b, epilogue, s);
-            return;
-        }
+        if (b.ksplit <= 1) b.ksplit = KS_MID;
+        if (a.ksplit > 1 && tiles <= 256) launch_gemv_dma2<4, 1, 2, FP8>(b, epilogue, s);
+        else launch_gemv_dma2<4, 2, 2, FP8>(b, epilogue, s);
+        return;
     }
     if (tiles <= 256) {
         // W8A16 slots are 4 KiB (3 pieces) / 5 KiB (4 pieces): a 4-slot ring of the latter would need all 160 KiB + ss_part
@@ -893,107 +655,65 @@ static void launch_gemv_m32(const GemvArgs& a, int epilogue, hipStream_t s) {
         }
         launch_gemv_dma2<8, 1, 3, FP8>(a, epilogue, s);
     } else if (tiles <= 512) launch_gemv_dma2<4, 1, 3, FP8>(a, epilogue, s);
-    else if (tiles <= 768 && !FP8 && geom == 0) launch_gemv_dma2<4, 1, 2, FP8>(a, epilogue, s);
     else {
         // W8A16, the widest matrices (13b gate/up: 1728 tiles): 4 tiles per workgroup halve the activation bytes per weight
         // byte — the bound of this kernel at 17..32 rows, DESIGN.md section 9.2 — same K partition (4 waves).  Measured at 32
         // rows: 45.2 -> 35.3 us; with 1376 tiles (7b gate/up) the 344 single-resident workgroups balance badly over 256 CUs
-        // and it loses (26.2 -> 27.9 us), hence the threshold.  VC_GEMV8_NT4=0 switches it off.
-        static const int nt4 = getenv("VC_GEMV8_NT4") ? atoi(getenv("VC_GEMV8_NT4")) : 1;
+        // and it loses (26.2 -> 27.9 us), hence the threshold.
         if constexpr (FP8) {
-            if (nt4 && tiles >= 1536) {
+            if (tiles >= 1536) {
                 launch_gemv_dma2<4, 4, 2, true>(a, epilogue, s);
                 return;
             }
         }
+        // 513..768 tiles as pairs too (2 workgroups/CU, the pair shares the activation pieces; 28.3 vs 33.9 us at M = 24 for
+        // one tile per workgroup)
         launch_gemv_dma2<4, 2, 2, FP8>(a, epilogue, s);
     }
 }
 
 template <bool FP8>
 static void launch_gemv_f(const GemvArgs& a, int epilogue, hipStream_t s) {
-    // VC_GEMV_PATH=0: the register-staged kernel; default 1: the LDS-DMA ring kernel
-    static const int path = getenv("VC_GEMV_PATH") ? atoi(getenv("VC_GEMV_PATH")) : 1;
-    // VC_GEMV_NT=2 pairs output tiles per workgroup (halves the L2 traffic of the activation operand).  Register-staged
-    // form measured: bf16 -4...-10 % with pairs, W8A16 +20 % — there the activation fragments are twice the weight bytes
-    static const int nt2 = getenv("VC_GEMV_NT") ? atoi(getenv("VC_GEMV_NT")) == 2 : 0;
     const int tiles = a.N / 16;
-    if (x_rows(a) > 16) {  // the decode pool's 17..32 rows (split mode: 9..16 rows + their lo parts): LDS-DMA form only
+    if (x_rows(a) > 16) {  // the decode pool's 17..32 rows (split mode, ring form: 9..16 rows + their lo parts)
         launch_gemv_m32<FP8>(a, epilogue, s);
         return;
     }
-    if (path == 1 || a.split_rows) {
-        // Geometry by tile count, so that (where possible) every workgroup of the launch is resident at once — a tail of
-        // late workgroups cannot keep enough bytes in flight to use the HBM (13b o_proj/down: 320 tiles at one
-        // 128-KiB workgroup per CU ran a 64-workgroup second round at a third of the rate):
-        //   <= 256 tiles: 8 waves, deep ring (1 workgroup/CU);  <= 512: 4 waves, 5-slot ring (2 workgroups/CU);
-        //   <= 768: 4 waves x 1 tile (3/CU);  wider: 4 waves x 2 tiles (pairs share the activation fragments:
-        //   gate/up 30.0 vs 33.1 us, lm_head 40.6 vs 45.5; 4 tiles per workgroup measured slower: W8A16 gate/up 23.2 vs
-        //   19.7 us).  bf16 slots hold a k-tile pair, W8A16 slots one super-tile.
-        // 257..512 tiles (13b o_proj / down: 320) neither fill the chip one-per-CU nor balance two-per-CU: with the
-        // split-K buffers, pairs of tiles x 3 K-slices = 480 workgroups, all resident (2/CU), activation fragments
-        // shared by the pair (measured M=16: down 43.0 -> 30.2 us, o_proj 20.1 -> 14.9; for <= 256 tiles every split
-        // loses: 8.5 -> 10 us).  VC_GEMV_KS overrides the slice count (1 = off); an explicit a.ksplit is honoured.
-        static const int ks_env = getenv("VC_GEMV_KS") ? atoi(getenv("VC_GEMV_KS")) : -1;
-        if (a.ksplit > 1 || (a.sk_scratch && a.sk_counters && a.ksplit == 0 && tiles > 256 && tiles <= 512)) {
-            GemvArgs b = a;
-            if (b.ksplit <= 1) b.ksplit = ks_env >= 0 ? ks_env : 3;
-            if (b.ksplit > 1) {
-                if (a.ksplit > 1 && !nt2 && tiles <= 256) launch_gemv_dma<4, 1, 3, FP8>(b, epilogue, s);
-                else launch_gemv_dma<4, 2, 3, FP8>(b, epilogue, s);
-                return;
-            }
-        }
-        if (tiles <= 256) launch_gemv_dma<8, 1, FP8 ? 5 : 4, FP8>(a, epilogue, s);
-        else if (tiles <= 512) launch_gemv_dma<4, 1, 5, FP8>(a, epilogue, s);
-        else if (tiles <= 768 && !nt2 && !FP8) launch_gemv_dma<4, 1, 3, FP8>(a, epilogue, s);  // W8A16: always pairs (X is 2x W)
-        else launch_gemv_dma<4, 2, 3, FP8>(a, epilogue, s);
+    // Geometry by tile count, so that (where possible) every workgroup of the launch is resident at once — a tail of
+    // late workgroups cannot keep enough bytes in flight to use the HBM (13b o_proj/down: 320 tiles at one
+    // 128-KiB workgroup per CU ran a 64-workgroup second round at a third of the rate):
+    //   <= 256 tiles: 8 waves, deep ring (1 workgroup/CU);  <= 512: 4 waves, 5-slot ring (2 workgroups/CU);
+    //   <= 768: 4 waves x 1 tile (3/CU);  wider: 4 waves x 2 tiles (pairs share the activation fragments:
+    //   gate/up 30.0 vs 33.1 us, lm_head 40.6 vs 45.5; 4 tiles per workgroup measured slower: W8A16 gate/up 23.2 vs
+    //   19.7 us).  bf16 slots hold a k-tile pair, W8A16 slots one super-tile.
+    if (a.ksplit > 1 || (a.sk_scratch && a.sk_counters && a.ksplit == 0 && tiles > 256 && tiles <= 512)) {
+        GemvArgs b = a;
+        if (b.ksplit <= 1) b.ksplit = KS_MID;
+        if (a.ksplit > 1 && tiles <= 256) launch_gemv_dma<4, 1, 3, FP8>(b, epilogue, s);
+        else launch_gemv_dma<4, 2, 3, FP8>(b, epilogue, s);
         return;
     }
-    // >= ~2048 waves in flight: few output tiles -> more K-splitting waves per workgroup
-    if (nt2 && tiles > 512) launch_gemv_w<8, 2, FP8>(a, epilogue, s);
-    else if (tiles <= 512) launch_gemv_w<8, 1, FP8>(a, epilogue, s);
-    else launch_gemv_w<4, 1, FP8>(a, epilogue, s);
+    if (tiles <= 256) launch_gemv_dma<8, 1, FP8 ? 5 : 4, FP8>(a, epilogue, s);
+    else if (tiles <= 512) launch_gemv_dma<4, 1, 5, FP8>(a, epilogue, s);
+    else if (tiles <= 768 && !FP8) launch_gemv_dma<4, 1, 3, FP8>(a, epilogue, s);  // W8A16: always pairs (X is 2x W)
+    else launch_gemv_dma<4, 2, 3, FP8>(a, epilogue, s);
 }
-// ---- launcher of the workgroup-shared form ----------------------------------------------------------------------------------
-struct WgGeom {
-    int ntw, ks;
-};
-// Tiles per wave and K-slices per tile group: a function of the MATRIX alone (so that every row count sums in the same order).
-// Default: tile pairs per wave from 512 tiles on; as many K-slices as keep the launch at <= ~2.5 workgroups per CU with >= 8
-// lines (512 k) per slice.  VC_GEMV_WG_GEOM="ntiles:K:ntw:ks,..." overrides single shapes (tuning).
-static std::string g_wg_geom_override;   // set_gemv_wg_geom: tools/kbench.py sweeps geometries inside one process
-static int g_wg_deep = -1;
-void set_gemv_wg_geom(const char* spec, int deep) {
-    g_wg_geom_override = spec ? spec : "";
-    g_wg_deep = deep;
-}
-static WgGeom wg_geometry(int ntiles, int K) {
-    static const char* env = getenv("VC_GEMV_WG_GEOM");
-    const char* q = !g_wg_geom_override.empty() ? g_wg_geom_override.c_str() : env;
-    if (q) {
-        while (*q) {
-            int t = 0, k = 0, ntw = 0, ks = 0, used = 0;
-            if (sscanf(q, "%d:%d:%d:%d%n", &t, &k, &ntw, &ks, &used) == 4 && used > 0) {
-                if (t == ntiles && k == K && (ntw == 1 || ntw == 2) && ks >= 1 && ks <= 8) return WgGeom{ntw, ks};
-                q += used;
-            } else {
-                ++q;
-            }
-            while (*q == ',' || *q == ' ') ++q;
-        }
-    }
-    // measured on MI355X at the 7b shapes, 8 and 32 rows (profiles/r04_b_kbench_gemv_wg.txt): one tile per wave beats tile pairs
-    // everywhere (twice the workgroups), and every extra K-slice costs (the cross-workgroup hand-off) — so only as many slices as
-    // it takes to put >= 256 workgroups on the chip: qkv (768 tiles) 2, o / down (256) 4, gate-up / lm_head 1
+
+// ---- launcher of the workgroup-shared form (precision mode "split" only) -----------------------------------------------------
+// K-slices per tile group: a function of the MATRIX alone (so that every row count sums in the same order).  Measured on MI355X at
+// the 7b shapes, 8 and 32 rows (profiles/r04_b_kbench_gemv_wg.txt): one tile per wave beats tile pairs everywhere (twice the
+// workgroups), and every extra K-slice costs (the cross-workgroup hand-off) — so only as many slices as it takes to put >= 256
+// workgroups on the chip: qkv (768 tiles) 2, o / down (256) 4, gate-up / lm_head 1.
+static int wg_kslices(int ntiles, int K) {
     const int groups = (ntiles + 3) / 4, lines = K / 64;
     int ks = groups >= 256 ? 1 : groups >= 128 ? 2 : 4;
     while (ks > 1 && lines / ks < 8) --ks;
-    return WgGeom{1, ks};
+    return ks;
 }
 
-template <int NTW, int XP, int KH, int CL, int R>
+template <int XP, int CL, int R>
 static void launch_gemv_wg_e(const GemvArgs& a, int epi, hipStream_t s) {
+    constexpr int NTW = 1, KH = 2;
     const int groups = (a.N / 16 + 4 * NTW - 1) / (4 * NTW);
     const dim3 grid((unsigned)(groups * (a.ksplit > 1 ? a.ksplit : 1))), block(256);
     constexpr size_t shmem = (size_t)(2 * CL * XP * KH + 4 * R * 2 * NTW) * 1024;
@@ -1016,89 +736,61 @@ static void launch_gemv_wg_e(const GemvArgs& a, int epi, hipStream_t s) {
 #undef VC_GEMV_WG
 }
 
-// chunk length / ring depth by the activation pieces per line, so that two workgroups fit a CU (<= 72 KiB each); a one-tile
-// wave has 2-KiB slots and takes a ring twice as deep for the same LDS
-template <int NTW>
-static void launch_gemv_wg_n(const GemvArgs& a, int epi, hipStream_t s) {
-    // VC_GEMV_WG_DEEP=1 (tuning): at 25..32 rows, 4-line chunks with a shallower ring instead of 2-line chunks
-    static const int deep_env = getenv("VC_GEMV_WG_DEEP") ? atoi(getenv("VC_GEMV_WG_DEEP")) : 0;
-    const int deep = g_wg_deep >= 0 ? g_wg_deep : deep_env;
-    const int xp = (a.M + 7) / 8;
-    constexpr int RX = NTW == 1 ? 2 : 1;   // ring depth factor
-    if (a.split_rows) {
-        switch (xp) {
-            case 1: launch_gemv_wg_e<NTW, 1, 2, 4, NTW == 1 ? 4 : 3>(a, epi, s); break;
-            case 2: launch_gemv_wg_e<NTW, 2, 2, 4, 2 * RX>(a, epi, s); break;
-            case 3: launch_gemv_wg_e<NTW, 3, 2, 2, 2 * RX>(a, epi, s); break;
-            default: launch_gemv_wg_e<NTW, 4, 2, 2, 2 * RX>(a, epi, s); break;
-        }
-        return;
-    }
-    switch (xp) {
-        case 1: launch_gemv_wg_e<NTW, 1, 1, 4, NTW == 1 ? 6 : 4>(a, epi, s); break;
-        case 2: launch_gemv_wg_e<NTW, 2, 1, 4, NTW == 1 ? 5 : 3>(a, epi, s); break;
-        case 3: launch_gemv_wg_e<NTW, 3, 1, 4, NTW == 1 ? 5 : 3>(a, epi, s); break;
-        default:
-            if (deep) launch_gemv_wg_e<NTW, 4, 1, 4, 2 * RX>(a, epi, s);
-            else launch_gemv_wg_e<NTW, 4, 1, 2, NTW == 1 ? 5 : 3>(a, epi, s);
-            break;
-    }
-}
-
 static int g_gemv_variant = -1;
 static std::atomic<unsigned long> g_gemv_wg_launches{0};   // sessions launch from their own threads
 void set_gemv_variant(int v) { g_gemv_variant = v; }
 unsigned long gemv_wg_launches() { return g_gemv_wg_launches.load(std::memory_order_relaxed); }
-// VC_GEMV_WG / set_gemv_variant: 0 = the per-wave-ring kernel everywhere; 1 = the workgroup-shared form everywhere it applies;
-// 2 (default) = the workgroup-shared form for precision mode "split" only.  Measured (profiles/r04_b_kbench_gemv_wg.txt): for the
-// bf16 step the ring kernel is faster at every row count (3.13 vs 3.57 ms at 32 rows with the best geometry found) — fewer,
-// larger DMA slots in flight per wave and no barrier in its loop outweigh the activation traffic it repeats; for the split step
-// one weight pass over 32 rows' hi + lo planes beats its two passes of 16 (6.27 ms).
-static int gemv_variant_now() {
-    static const int wg_env = getenv("VC_GEMV_WG") ? atoi(getenv("VC_GEMV_WG")) : 2;
-    return g_gemv_variant >= 0 ? g_gemv_variant : wg_env;
-}
-bool gemv_wg_enabled() { return gemv_variant_now() >= 1; }
+// set_gemv_variant: 0 = the per-wave-ring kernel for everything (a split step then takes two weight passes of 16 rows); -1 / 1
+// (default) = the workgroup-shared form for precision mode "split".  Measured (profiles/r04_b_kbench_gemv_wg.txt): for the bf16
+// step the ring kernel is faster at every row count (3.13 vs 3.57 ms at 32 rows with the best geometry found — fewer, larger DMA
+// slots in flight per wave and no barrier in its loop outweigh the activation traffic it repeats), so the bf16 form of the
+// workgroup-shared kernel was removed in round 5; for the split step one weight pass over 32 rows' hi + lo planes beats the ring
+// kernel's two passes of 16 (6.27 ms).
+bool gemv_wg_enabled() { return g_gemv_variant != 0; }
 
 // true when the workgroup-shared form can serve the call
+bool gemv_wg_applies(int K, bool fp8_weights) { return !fp8_weights && K % 64 == 0; }
 static bool gemv_wg_applies(const GemvArgs& a) {
-    if (a.wscale || a.K % 64 != 0 || a.M < 1 || a.M > 32) return false;
-    if (a.split_rows && !(a.split_rows >= a.M && a.split_rows <= 32 && a.split_rows % 8 == 0)) return false;
-    return true;
+    if (!a.split_rows || !gemv_wg_applies(a.K, a.wscale != nullptr) || a.M < 1 || a.M > 32) return false;
+    return a.split_rows >= a.M && a.split_rows <= 32 && a.split_rows % 8 == 0;
 }
 
 static void launch_gemv_wg(const GemvArgs& a0, int epi, hipStream_t s) {
     GemvArgs a = a0;
     const int ntiles = a.N / 16;
-    WgGeom gm = wg_geometry(ntiles, a.K);
-    if (a.ksplit > 1) gm.ks = a.ksplit;   // an explicit request (tests) is honoured
+    int ks = a.ksplit > 1 ? a.ksplit : wg_kslices(ntiles, a.K);   // an explicit request (tests) is honoured
     const size_t cap = a.sk_scratch_floats ? a.sk_scratch_floats : (size_t)4 * 512 * 2 * 256;
     const int ncnt = a.sk_counters_n ? a.sk_counters_n : 512 * 2;
     // the split-K buffers bound the slices (a geometry decision of the matrix: the buffers are sized once per model)
-    while (gm.ks > 1 && (!a.sk_scratch || !a.sk_counters || (size_t)gm.ks * ntiles * 2 * 256 > cap || ntiles * 2 > ncnt)) --gm.ks;
-    a.ksplit = gm.ks;
+    while (ks > 1 && (!a.sk_scratch || !a.sk_counters || (size_t)ks * ntiles * 2 * 256 > cap || ntiles * 2 > ncnt)) --ks;
+    a.ksplit = ks;
     g_gemv_wg_launches.fetch_add(1, std::memory_order_relaxed);
-    if (gm.ntw == 2) launch_gemv_wg_n<2>(a, epi, s);
-    else launch_gemv_wg_n<1>(a, epi, s);
+    // chunk length / ring depth by the activation pieces per line, so that two workgroups fit a CU (<= 72 KiB each)
+    switch ((a.M + 7) / 8) {
+        case 1: launch_gemv_wg_e<1, 4, 4>(a, epi, s); break;
+        case 2: launch_gemv_wg_e<2, 4, 4>(a, epi, s); break;
+        case 3: launch_gemv_wg_e<3, 2, 4>(a, epi, s); break;
+        default: launch_gemv_wg_e<4, 2, 4>(a, epi, s); break;
+    }
 }
 
-// ---- "wide" geometry of the ring kernel (experiment, off by default: VC_GEMV_WIDE / set_gemv_wide) -------------------------------
-// What the three-tile form taught (profiles/r04_q_kbench_gemv_nt3.txt): ONE deep-ringed workgroup per CU, all 256 CUs holding
-// exactly one, beat every geometry with more, unevenly spread workgroups.  This generalises it to the matrices with more than 512
-// tiles: NT = ceil(tiles / 256) tiles per 4-wave workgroup (>= 218 workgroups, i.e. >= 85 % of the CUs), the ring as deep as
-// 160 KiB allow.  The K partition stays 4 waves without K-slices, so the bits are those of the default geometry.  Bit NT of the
-// knob enables the class (0x1d8 = all of 3, 4, 6, 7, 8):
-//   NT 3: 7b qkv (768 tiles -> 256 workgroups), <= 16 rows (17..32 rows take it through VC_GEMV2_NT3 already)
-//   NT 4: 13b qkv (960 -> 240)        NT 6: 7b gate/up (1376 -> 230)        NT 7: 13b gate/up (1728 -> 247)
-//   NT 8: lm_head (2000 -> 250), <= 24 rows (a 32-row slot of 8 tiles does not fit twice)
+// ---- "wide" geometry of the ring kernel (set_gemv_wide: -1 / 1 = the measured classes below, 0 = off, 2 = every class) ----------
+// ONE deep-ringed workgroup per CU, all 256 CUs holding exactly one, beats every geometry with more, unevenly spread workgroups
+// (profiles/r04_q_kbench_gemv_nt3.txt: 7b qkv at 32 rows as 256 triples with a 3-slot ring, 72 KiB of weights in flight on every
+// CU, 25.0 -> 20.2 us against 384 pair-workgroups sitting two on half the CUs and one on the other half).  For the matrices with
+// more than 512 tiles: NT = ceil(tiles / 256) tiles per 4-wave workgroup (>= 218 workgroups, i.e. >= 85 % of the CUs), the ring as
+// deep as 160 KiB allow.  The K partition stays 4 waves without K-slices, so the bits are those of the default geometry (checked on
+// the device for every class and row count).  Measured on MI355X (profiles/r05_a_kbench_gemv_wide.txt, us, default -> wide at
+// 8 / 16 / 24 / 32 rows), which is what the default table below encodes:
+//   NT 3: 7b qkv (768 tiles -> 256 workgroups)      18.7 -> 18.2 | 20.2 -> 18.7 | 23.4 -> 20.3 | 25.0 -> 20.2   => always
+//   NT 4: 13b qkv (960 -> 240)                      26.0 -> 26.5 | 27.7 -> 26.7 | 30.5 -> 28.6 | 32.6 -> 29.2   => from 9 rows on
+//   NT 6: 7b gate/up (1376 -> 230)                  30.6 -> 30.9 | 31.4 -> 30.9 | 33.0 -> 33.0 | 36.7 -> 33.4   => from 9 rows on
+//   NT 7: 13b gate/up (1728 -> 247)                 47.1 -> 46.9 | 50.4 -> 46.8 | 56.5 -> 48.9 | 61.4 -> 49.5   => always
+// (NT 8, lm_head 2000 -> 250, lost at every row count — 41.9 -> 47.5 us at 8 rows — and was removed.)
 static int g_gemv_wide = -1;
 static std::atomic<unsigned long> g_gemv_wide_launches{0};   // sessions launch from their own threads
 void set_gemv_wide(int v) { g_gemv_wide = v; }
 unsigned long gemv_wide_launches() { return g_gemv_wide_launches.load(std::memory_order_relaxed); }
-static int gemv_wide_now() {
-    static const int env = getenv("VC_GEMV_WIDE") ? (int)strtol(getenv("VC_GEMV_WIDE"), nullptr, 0) : 0;
-    return g_gemv_wide >= 0 ? g_gemv_wide : env;
-}
 template <int NT, int R, int XP, int EPI>
 static void launch_gemv_wide1(const GemvArgs& a, hipStream_t s) {
     constexpr int WAVES = 4;
@@ -1113,36 +805,30 @@ static void launch_gemv_wide1(const GemvArgs& a, hipStream_t s) {
     VC_LAUNCH((gemv_dma_kernel<WAVES, NT, R, EPI, false, XP>), grid, block, shmem, s, a);
 }
 static bool launch_gemv_wide(const GemvArgs& a, int epi, hipStream_t s) {
-    const int wide = gemv_wide_now();
-    if (!wide || a.wscale || a.ksplit > 1 || a.kvirt > 1 || a.split_rows) return false;
+    const int wide = g_gemv_wide < 0 ? 1 : g_gemv_wide;
+    if (!wide || a.wscale || a.ksplit > 1 || a.split_rows) return false;
     const int tiles = a.N / 16;
     if (tiles <= 512) return false;
     const int nt = (tiles + 255) / 256;
-    if (nt > 8 || !((wide >> nt) & 1) || (tiles + nt - 1) / nt < 218) return false;
+    if (nt > 7 || (tiles + nt - 1) / nt < 218) return false;
     const int xr = x_rows(a), xp = xr <= 8 ? 1 : xr <= 16 ? 2 : xr <= 24 ? 3 : 4;
-    // VC_GEMV_PATH=0 serves <= 16 rows with the register-staged kernel, whose k order is another: the wide ring stays out of it
-    static const int path = getenv("VC_GEMV_PATH") ? atoi(getenv("VC_GEMV_PATH")) : 1;
-    if (path != 1 && xr <= 16) return false;
-#define VC_WIDE(NT_, R_, XP_, E_)                      \
-    if (nt == NT_ && xp == XP_ && epi == E_) {         \
-        launch_gemv_wide1<NT_, R_, XP_, E_>(a, s);     \
-        g_gemv_wide_launches.fetch_add(1, std::memory_order_relaxed);                        \
-        return true;                                   \
+    if (wide == 1 && xp == 1 && (nt == 4 || nt == 6)) return false;   // the two classes that lose at <= 8 rows (table above)
+#define VC_WIDE(NT_, R_, XP_, E_)                                          \
+    if (nt == NT_ && xp == XP_ && epi == E_) {                             \
+        launch_gemv_wide1<NT_, R_, XP_, E_>(a, s);                         \
+        g_gemv_wide_launches.fetch_add(1, std::memory_order_relaxed);      \
+        return true;                                                       \
     }
-    VC_WIDE(3, 5, 1, GEMV_BF16) VC_WIDE(3, 4, 2, GEMV_BF16)
+    VC_WIDE(3, 5, 1, GEMV_BF16) VC_WIDE(3, 4, 2, GEMV_BF16) VC_WIDE(3, 3, 3, GEMV_BF16) VC_WIDE(3, 3, 4, GEMV_BF16)
     VC_WIDE(4, 4, 1, GEMV_BF16) VC_WIDE(4, 3, 2, GEMV_BF16) VC_WIDE(4, 3, 3, GEMV_BF16) VC_WIDE(4, 3, 4, GEMV_BF16)
     VC_WIDE(6, 3, 1, GEMV_SWIGLU) VC_WIDE(6, 2, 2, GEMV_SWIGLU) VC_WIDE(6, 2, 3, GEMV_SWIGLU) VC_WIDE(6, 2, 4, GEMV_SWIGLU)
     VC_WIDE(7, 2, 1, GEMV_SWIGLU) VC_WIDE(7, 2, 2, GEMV_SWIGLU) VC_WIDE(7, 2, 3, GEMV_SWIGLU) VC_WIDE(7, 2, 4, GEMV_SWIGLU)
-    VC_WIDE(8, 2, 1, GEMV_F32) VC_WIDE(8, 2, 2, GEMV_F32) VC_WIDE(8, 2, 3, GEMV_F32)
 #undef VC_WIDE
     return false;
 }
 
-void launch_gemv(const GemvArgs& a0, int epilogue, hipStream_t s) {
-    static const int w_cached = getenv("VC_GEMV_WCACHED") ? atoi(getenv("VC_GEMV_WCACHED")) : 0;
-    GemvArgs a = a0;
-    a.w_cached = w_cached;
-    if ((gemv_variant_now() == 1 || (gemv_variant_now() == 2 && a.split_rows)) && gemv_wg_applies(a)) {
+void launch_gemv(const GemvArgs& a, int epilogue, hipStream_t s) {
+    if (gemv_wg_enabled() && gemv_wg_applies(a)) {
         launch_gemv_wg(a, epilogue, s);
         return;
     }
@@ -1151,9 +837,13 @@ void launch_gemv(const GemvArgs& a0, int epilogue, hipStream_t s) {
         // (M <= 8), G = 16 across the two row groups (M <= 16).  No split-K hand-off in this mode.
         if (!((a.split_rows == 8 && a.M <= 8) || (a.split_rows == 16 && a.M <= 16)))
             throw std::runtime_error("split GEMV: rows per pass must fit the group (G = 8: M <= 8, G = 16: M <= 16)");
-        a.sk_scratch = nullptr;
-        a.sk_counters = nullptr;
-        a.ksplit = 0;
+        GemvArgs b = a;
+        b.sk_scratch = nullptr;
+        b.sk_counters = nullptr;
+        b.ksplit = 0;
+        if (b.wscale) launch_gemv_f<true>(b, epilogue, s);
+        else launch_gemv_f<false>(b, epilogue, s);
+        return;
     }
     if (launch_gemv_wide(a, epilogue, s)) return;
     if (a.wscale) launch_gemv_f<true>(a, epilogue, s);

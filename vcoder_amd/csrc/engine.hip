@@ -223,6 +223,7 @@ struct vc_model {
     hipGraphExec_t graph = nullptr;  // one decode step over graph_rows rows (parameters live in the RowState records)
     int graph_rows = 0;
     struct vc_pool* pool = nullptr;  // the root model's shared decode pool (created on first use; sessions point at it)
+    bool pool_profile = false;       // root model: the pool's step graphs carry in-situ timing stamps (vc_pool_profile)
     vc_model* root = nullptr;        // the model that owns the weights (itself for a root)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float t_encode = 0, t_prefill = 0, t_decode = 0;
@@ -560,7 +561,18 @@ struct LoopView {
     int *next_tok, *out_ids;
     float *ssq, *sk_scratch;
     unsigned* sk_counters;
+    // in-situ timing (vc_pool_profile): slot s of the step = stamps[2 s], stamps[2 s + 1]; *stamp_next = the next free slot while the
+    // step is being enqueued; prof_acc = this span's accumulators.  All nullptr when off.
+    unsigned long long* stamps;
+    int* stamp_next;
+    unsigned long long* prof_acc;
 };
+
+// the next timing slot of the step being enqueued (nullptr: profiling off)
+inline unsigned long long* next_stamp(const LoopView& v) {
+    if (!v.stamps || !v.stamp_next) return nullptr;
+    return v.stamps + 2 * (size_t)(*v.stamp_next)++;
+}
 
 // decode-time linear over `X` (bf16 [M, K]).  use_rstd: X is the xg operand (bf16(x * g)) and the output is scaled by the
 // rows' 1/rms from the ssq partials; next_norm_w (RESID epilogue only): publish the ssq partials of the updated residual
@@ -600,6 +612,7 @@ void gemv(vc_model* m, const LoopView& v, const bf16_t* X, const bf16_t* Wp, con
         a.sk_counters = v.sk_counters;
         a.sk_scratch_floats = sk_floats(m->c);
         a.sk_counters_n = sk_counters_n(m->c);
+        a.stamp = next_stamp(v);
         launch_gemv(a, epi, v.st);
     }
 }
@@ -1461,9 +1474,12 @@ void enqueue_decode_step(vc_model* m, const LoopView& v, int nrows) {
         AttnDecodeFusedArgs da{v.qkv_dec, kcache(v, m, l), vcache(v, m, l), v.attn_dec, nrows, m->c.heads, m->hd, v.capS,
                                v.rows + RS_POS, m->rope_cos, m->rope_sin, 1.0f / sqrtf((float)m->hd), RS_STRIDE,
                                v.rows + RS_ACTIVE, v.split_G ? (v.es == 3 ? 2 : 1) : (v.es == 1 ? 3 : 0), v.split_G, v.kmask, v.kmask_stride};
+        da.stamp = next_stamp(v);
         launch_attention_decode_fused(da, v.st);
     });
     launch_select_embed(select_args(m, v, v.logits, nrows, 3), v.st);                                        // K19/K20+K10
+    // in-situ timing: fold the step's slots (5 per layer: qkv, attention, o, gate/up, down; then lm_head) into the span's sums
+    if (v.stamps && v.stamp_next && v.prof_acc) launch_stamp_accumulate(v.stamps, *v.stamp_next, m->c.layers, v.prof_acc, v.st);
 }
 
 // The same step run eagerly with the output_hidden_states / output_attentions hooks of a cached decode step
@@ -2572,6 +2588,9 @@ struct vc_pool {
     hipEvent_t step_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     unsigned long steps_run = 0;
     unsigned long long steps_by_span[VC_POOL_ROWS / 8] = {};  // steps launched over 8 / 16 / 24 / 32 rows (vc_pool_step_counts)
+    // in-situ timing (vc_pool_profile): the step graphs were captured with stamp slots; prof_acc[span][kind] = {ticks, launches}
+    bool prof = false;
+    Buf stamps, prof_acc;
 };
 
 namespace {
@@ -2599,6 +2618,7 @@ LoopView pool_view(vc_pool* p) {
     v.ssq = p->ssq.as<float>();
     v.sk_scratch = p->sk_scratch.as<float>();
     v.sk_counters = p->sk_counters.as<unsigned>();
+    v.stamps = p->prof ? p->stamps.as<unsigned long long>() : nullptr;
     return v;
 }
 
@@ -2723,7 +2743,7 @@ void pool_destroy(vc_pool* p) {
     for (auto& g : p->graph)
         if (g) (void)hipGraphExecDestroy(g);
     for (Buf* b : {&p->kc, &p->vc, &p->rows, &p->x_dec, &p->xg_dec, &p->qkv_dec, &p->attn_dec, &p->h_dec, &p->logits,
-                   &p->next_tok, &p->out_ids, &p->ssq, &p->sk_scratch, &p->sk_counters})
+                   &p->next_tok, &p->out_ids, &p->ssq, &p->sk_scratch, &p->sk_counters, &p->stamps, &p->prof_acc})
         b->release();
     for (auto& e : p->step_ev)
         if (e) (void)hipEventDestroy(e);
@@ -2732,6 +2752,14 @@ void pool_destroy(vc_pool* p) {
 }
 
 std::mutex g_pool_create;
+
+// rows per stacked hi / lo group of a split pool: 32 when the workgroup-shared GEMV (one weight pass over the 32 rows' two planes)
+// can serve EVERY matrix of the model, else the per-wave-ring form's two passes of 16
+int pool_split_G(const vc_model* root) {
+    const vc_model_cfg& c = root->c;
+    const bool fp8w = root->weight_format != 0;
+    return (gemv_wg_enabled() && gemv_wg_applies(c.hidden, fp8w) && gemv_wg_applies(c.ffn, fp8w)) ? 32 : 16;
+}
 
 // the root model's pool with room for `need_S` positions and `need_out` ids per row; an idle pool that is too small (or that
 // stopped after an error) is rebuilt, a busy one makes the caller wait for it to drain.  The pool is returned ACQUIRED:
@@ -2745,7 +2773,9 @@ vc_pool* pool_for(vc_model* m, int need_S, int need_out) {
     const bool want_split = m->precision == 2;
     if (p) {
         std::unique_lock<std::mutex> lk(p->mu);
-        if (p->capS < need_S || p->out_stride < need_out || p->stop || p->split != want_split) {
+        // (a split pool laid out for the other GEMV form — set_gemv_variant switched since it was built — is rebuilt as well)
+        if (p->capS < need_S || p->out_stride < need_out || p->stop || p->split != want_split ||
+            (want_split && p->split_G != pool_split_G(root)) || p->prof != (root->pool_profile && !want_split)) {
             p->cv_rows.wait(lk, [&] { return p->users == 0; });
             lk.unlock();
             pool_destroy(p);
@@ -2760,7 +2790,7 @@ vc_pool* pool_for(vc_model* m, int need_S, int need_out) {
         p->root = root;
         p->device = root->ctx->device;
         p->split = want_split;
-        p->split_G = (gemv_wg_enabled() && root->weight_format == 0) ? 32 : 16;
+        p->split_G = pool_split_G(root);
         const int D = c.hidden, F = c.ffn, H = c.heads, R = p->R;
         const size_t es = want_split ? (size_t)split_kv_es() : (size_t)step_kv_es(root), two = want_split ? 2 : 1;
         p->kv_es = (int)es;
@@ -2786,8 +2816,23 @@ vc_pool* pool_for(vc_model* m, int need_S, int need_out) {
         p->sk_counters.ensure((size_t)sk_counters_n(c) * 4, true);
         t_stream = m->st;
         for (auto& e : p->step_ev) HIPCHK(hipEventCreate(&e));
-        const LoopView v = pool_view(p);
-        for (int i = 0; i < R / 8; ++i) p->graph[i] = capture_step(root, v, 8 * (i + 1));
+        p->prof = root->pool_profile && !want_split;   // (a split step's GEMVs may take two passes: the slot layout assumes one)
+        if (p->prof) {
+            const size_t nslots = (size_t)5 * c.layers + 1;
+            p->stamps.ensure(nslots * 2 * 8);
+            p->prof_acc.ensure((size_t)(R / 8) * PROF_KINDS * 2 * 8, true);
+            launch_stamp_reset(p->stamps.as<unsigned long long>(), (int)nslots, m->st);
+            HIPCHK(hipStreamSynchronize(m->st));
+        }
+        LoopView v = pool_view(p);
+        for (int i = 0; i < R / 8; ++i) {
+            int slot = 0;
+            if (p->prof) {
+                v.stamp_next = &slot;
+                v.prof_acc = p->prof_acc.as<unsigned long long>() + (size_t)i * PROF_KINDS * 2;
+            }
+            p->graph[i] = capture_step(root, v, 8 * (i + 1));
+        }
         p->driver = std::thread(pool_driver, p);
     } catch (...) {  // a failed allocation / capture must not leak the half-built pool or leave t_stream on its stream
         t_stream = m->st;
@@ -3303,6 +3348,54 @@ VC_API int vc_pool_step_counts(vc_model* m, unsigned long long* counts4) {
         for (int i = 0; i < 4 && i < VC_POOL_ROWS / 8; ++i) counts4[i] = root->pool->steps_by_span[i];
     }
     return VC_OK;
+}
+
+/* In-situ timing of the pool's decode-step kernels.  on != 0: the pool's step graphs are (re)captured with a timing slot per launch
+ * — the first thread of every workgroup stamps {earliest start, latest end} with the device's constant-rate wall clock — and one
+ * tiny launch per step folds the slots into per-(span, kind) sums, so that a measurement covers every launch of a timed region as
+ * it ran there (beside whatever the other sessions had on the GPU), not a replay.  Takes effect when the pool is next (re)built,
+ * i.e. while it is idle.  bf16 path only (the split step keeps its graphs). */
+VC_API int vc_pool_profile(vc_model* m, int on) {
+    if (!m) return VC_ERR_INVALID;
+    vc_model* root = m->root ? m->root : m;
+    root->pool_profile = on != 0;
+    return VC_OK;
+}
+
+/* sums since the last reset: for span s (8 (s + 1) rows) and kind k (0 qkv, 1 decode attention, 2 o_proj, 3 gate/up, 4 down,
+ * 5 lm_head): total microseconds between the earliest workgroup start and the latest workgroup end of the launches, and their
+ * number.  us / launches are [4][6].  reset != 0 zeroes the sums.  The pool must be idle (no generate() in flight). */
+VC_API int vc_pool_profile_read(vc_model* m, double* us, unsigned long long* launches, int reset) {
+    if (!m || !us || !launches) return VC_ERR_INVALID;
+    GUARD_BEGIN
+    USE_DEVICE(m->ctx);
+    vc_model* root = m->root ? m->root : m;
+    const int nspan = VC_POOL_ROWS / 8;
+    for (int i = 0; i < nspan * PROF_KINDS; ++i) {
+        us[i] = 0;
+        launches[i] = 0;
+    }
+    vc_pool* p = root->pool;
+    if (p && p->prof) {
+        {
+            std::lock_guard<std::mutex> lk(p->mu);
+            REQUIRE(p->users == 0 && p->active.empty() && p->pending.empty(), VC_ERR_STATE, "the decode pool is busy");
+        }
+        HIPCHK(hipStreamSynchronize(p->st));
+        std::vector<unsigned long long> h((size_t)nspan * PROF_KINDS * 2);
+        HIPCHK(hipMemcpy(h.data(), p->prof_acc.p, h.size() * 8, hipMemcpyDeviceToHost));
+        int khz = 100000;   // the constant-rate wall clock: 100 MHz on gfx9
+#ifndef VC_EMU
+        (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, root->ctx->device);
+        if (khz <= 0) khz = 100000;
+#endif
+        for (int i = 0; i < nspan * PROF_KINDS; ++i) {
+            us[i] = (double)h[2 * i] * 1e3 / (double)khz;
+            launches[i] = h[2 * i + 1];
+        }
+        if (reset) HIPCHK(hipMemset(p->prof_acc.p, 0, h.size() * 8));
+    }
+    GUARD_END(m->ctx)
 }
 
 VC_API int vc_profile_decode_gemv(vc_model* m, int B, int reps, int* launches, double* avg_us, double* avg_bytes) {

@@ -220,15 +220,10 @@ VCK_EXPORT void vck_gemv_full(const uint16_t* X, const void* Wp, const float* ws
     a.split_rows = G;
     launch_gemv(a, epi, S(stream));
 }
-/* 0 = per-wave rings, 1 = workgroup-shared activation chunks, -1 = the process default (VC_GEMV_WG) */
+/* split-mode GEMV: 0 = per-wave rings, 1 / -1 = workgroup-shared activation chunks (default) */
 VCK_EXPORT void vck_set_gemv_variant(int v) { set_gemv_variant(v); }
-VCK_EXPORT void vck_set_gemv_m32_nt3(int v) { set_gemv_m32_nt3(v); }
-VCK_EXPORT unsigned long long vck_gemv_m32_nt3_launches() { return gemv_m32_nt3_launches(); }
-VCK_EXPORT void vck_set_gemv_m32_kvirt(int v) { set_gemv_m32_kvirt(v); }
 VCK_EXPORT void vck_set_gemv_wide(int v) { set_gemv_wide(v); }
 VCK_EXPORT unsigned long long vck_gemv_wide_launches() { return gemv_wide_launches(); }
-VCK_EXPORT unsigned long long vck_gemv_m32_kvirt_launches() { return gemv_m32_kvirt_launches(); }
-VCK_EXPORT void vck_set_gemv_wg_geom(const char* spec, int deep) { set_gemv_wg_geom(spec, deep); }
 VCK_EXPORT unsigned long long vck_gemv_wg_launches() { return gemv_wg_launches(); }
 VCK_EXPORT void vck_rmsnorm_split(const float* x, const int* row_idx, const float* w, uint16_t* y, int rows, int D, float eps,
                                   int ldy, uint64_t lo_off, void* stream) {

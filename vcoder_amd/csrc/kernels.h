@@ -98,12 +98,6 @@ struct GemvArgs {
     float* sk_scratch;       // [ksplit][N/16][2 row groups][256] or nullptr
     unsigned* sk_counters;   // [N/16][2 row groups], zero between launches
     int ksplit;              // 0/1 = off (launcher decides when the two buffers are given)
-    // "virtual waves" (set by the launcher only; 0/1 = off): `kvirt` workgroups of W waves share a tile group and take the k-lines
-    // that waves s*W .. s*W+W-1 of ONE workgroup of kvirt*W waves would take, and the finisher adds the partials in exactly that
-    // workgroup's order (slice 0's waves pre-summed — the head of the sequence — then every further wave's partial one by one):
-    // the bits of the kvirt*W-wave geometry from workgroups small enough to pair tiles.  sk_scratch: [1 + (kvirt-1)*W] entries.
-    int kvirt;
-    int w_cached;            // 1: stream the weights with the default cache policy instead of non-temporal (VC_GEMV_WCACHED)
     // precision mode "split" (0 = off; G = 8 for M <= 8, G = 16 for M <= 16): X is [G + M, K] — rows [0, M) the bf16 hi parts
     // of the activation rows, rows [G, G + M) the lo parts (x = hi + lo, ~16 mantissa bits) — and out[m] = (hi[m] + lo[m]) . W.
     // bf16-valued outputs (GEMV_BF16, GEMV_SWIGLU, xg_out) are written the same way: hi at row m, lo at row G + m.
@@ -111,19 +105,16 @@ struct GemvArgs {
     // capacity of the split-K buffers (0 = the historical [4][512][2][256] floats / [512][2] counters)
     size_t sk_scratch_floats;
     int sk_counters_n;
+    // in-situ timing slot {earliest workgroup start, latest workgroup end} in wall-clock ticks, or nullptr (vc_device.h stamp_begin)
+    unsigned long long* stamp;
 };
 void launch_gemv(const GemvArgs& a, int epilogue, hipStream_t s);
-// which decode GEMV serves bf16 weights: 0 = per-wave rings (gemv_dma_kernel), 1 = workgroup-shared activation chunks
-// (gemv_wg_kernel); -1 = the process default (environment VC_GEMV_WG, read once).  Tests and tools/kbench.py switch it.
+// the decode GEMV of precision mode "split": 0 = per-wave rings (two weight passes of 16 rows), -1 / 1 = the workgroup-shared form
 void set_gemv_variant(int v);
-void set_gemv_m32_nt3(int v);   // -1 = VC_GEMV2_NT3 (default 3); see launch_gemv_m32
-unsigned long gemv_m32_nt3_launches();   // launches served by the three-tile form so far (tests)
-void set_gemv_wide(int v);       // -1 = VC_GEMV_WIDE (default 0); bit NT enables the NT-tiles-per-workgroup class (launch_gemv_wide)
+void set_gemv_wide(int v);       // -1 / 1 = the measured classes (default), 0 = off, 2 = every class (launch_gemv_wide)
 unsigned long gemv_wide_launches();
-void set_gemv_m32_kvirt(int v);  // -1 = VC_GEMV2_KVIRT (default 0); see launch_gemv_m32
-unsigned long gemv_m32_kvirt_launches();
-void set_gemv_wg_geom(const char* spec, int deep);   // tuning: "ntiles:K:ntw:ks,..." (empty = default), deep = -1 / 0 / 1
-bool gemv_wg_enabled();             // the workgroup-shared form serves bf16-weight GEMVs (variant 1)
+bool gemv_wg_enabled();                          // the workgroup-shared form serves the split step's GEMVs
+bool gemv_wg_applies(int K, bool fp8_weights);   // ... for a matrix with this K / weight format
 unsigned long gemv_wg_launches();   // launches served by the workgroup-shared form so far (tests)
 void launch_pack_weight(const bf16_t* W, bf16_t* Wp, int N, int K, hipStream_t s);
 // W [N,K] bf16 -> e4m3 packed + per-row scales; W is overwritten with the dequantised values (see decode.hip)
@@ -251,6 +242,7 @@ struct AttnDecodeFusedArgs {
     // keys hidden by the row's attention_mask: key_mask[b * mask_stride + key] == 0 (nullptr = none)
     const uint8_t* key_mask;
     int mask_stride;
+    unsigned long long* stamp;   // in-situ timing slot, or nullptr (GemvArgs::stamp)
 };
 void launch_attention_decode_fused(const AttnDecodeFusedArgs& a, hipStream_t s);
 
@@ -327,6 +319,11 @@ struct SelectArgs {
     int xg_G;             // precision mode "split" (0 = off): xg holds stacked groups of G hi rows + G lo rows
 };
 void launch_select_embed(const SelectArgs& a, hipStream_t s);
+// in-situ timing of the decode-step launches (GemvArgs::stamp): slot j = {min start, max end}; `n` slots laid out 5 per layer
+// (qkv, attention, o, gate/up, down) + lm_head; acc[kind] = {sum of (end - start) ticks, launches}, kinds as in vc_pool_profile_read
+constexpr int PROF_KINDS = 6;
+void launch_stamp_reset(unsigned long long* stamps, int n, hipStream_t s);
+void launch_stamp_accumulate(unsigned long long* stamps, int n, int layers, unsigned long long* acc, hipStream_t s);
 // embedding + sum-of-squares partials for tokens supplied by the host (vc_decode_step with explicit tokens)
 void launch_embed_tokens_ssq(const int* tok, const bf16_t* embed, float* x, float* ssq, const float* xg_w, bf16_t* xg, int B, int D, int npart,
                              hipStream_t s, int xg_G = 0);

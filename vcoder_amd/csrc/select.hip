@@ -245,6 +245,64 @@ __global__ __launch_bounds__(1024) void select_embed_kernel(SelectArgs p) {
     }
 }
 
+// ---- in-situ timing slots (vc_device.h stamp_begin / stamp_end; engine.hip vc_pool_profile) ------------------------------------
+// The slots are written with agent-scope atomics by the timed kernels, so every access here is agent-scope too (the "same scope on
+// both sides" rule of the cross-workgroup hand-offs in decode.hip).
+VC_DEV unsigned long long ld_agent_u64(const unsigned long long* p) {
+#ifdef VC_EMU
+    return __atomic_load_n(p, __ATOMIC_RELAXED);
+#else
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+VC_DEV void st_agent_u64(unsigned long long* p, unsigned long long v) {
+#ifdef VC_EMU
+    __atomic_store_n(p, v, __ATOMIC_RELAXED);
+#else
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__global__ __launch_bounds__(256) void stamp_reset_kernel(unsigned long long* stamps, int n) {
+    for (int j = threadIdx.x; j < n; j += 256) {
+        st_agent_u64(stamps + 2 * j, ~0ull);
+        st_agent_u64(stamps + 2 * j + 1, 0ull);
+    }
+}
+// one workgroup: slot j -> kind (5 per layer: qkv 0, attention 1, o 2, gate/up 3, down 4; the last slot: lm_head 5); a slot no
+// workgroup stamped (an attention launch over free rows only) is skipped; every slot is re-armed
+__global__ __launch_bounds__(256) void stamp_accumulate_kernel(unsigned long long* stamps, int n, int layers, unsigned long long* acc) {
+    __shared__ unsigned long long sum[PROF_KINDS], cnt[PROF_KINDS];
+    const int tid = threadIdx.x;
+    if (tid < PROF_KINDS) sum[tid] = cnt[tid] = 0;
+    __syncthreads();
+    for (int j = tid; j < n; j += 256) {
+        const unsigned long long t0 = ld_agent_u64(stamps + 2 * j), t1 = ld_agent_u64(stamps + 2 * j + 1);
+        if (t1 != 0 && t0 != ~0ull && t1 >= t0) {
+            const int kind = j < 5 * layers ? j % 5 : 5;
+#ifdef VC_EMU
+            __atomic_fetch_add(&sum[kind], t1 - t0, __ATOMIC_RELAXED);
+            __atomic_fetch_add(&cnt[kind], 1ull, __ATOMIC_RELAXED);
+#else
+            atomicAdd(&sum[kind], t1 - t0);
+            atomicAdd(&cnt[kind], 1ull);
+#endif
+        }
+        st_agent_u64(stamps + 2 * j, ~0ull);
+        st_agent_u64(stamps + 2 * j + 1, 0ull);
+    }
+    __syncthreads();
+    if (tid < PROF_KINDS) {
+        st_agent_u64(acc + 2 * tid, ld_agent_u64(acc + 2 * tid) + sum[tid]);
+        st_agent_u64(acc + 2 * tid + 1, ld_agent_u64(acc + 2 * tid + 1) + cnt[tid]);
+    }
+}
+void launch_stamp_reset(unsigned long long* stamps, int n, hipStream_t s) {
+    VC_LAUNCH(stamp_reset_kernel, dim3(1), dim3(256), 0, s, stamps, n);
+}
+void launch_stamp_accumulate(unsigned long long* stamps, int n, int layers, unsigned long long* acc, hipStream_t s) {
+    VC_LAUNCH(stamp_accumulate_kernel, dim3(1), dim3(256), 0, s, stamps, n, layers, acc);
+}
+
 void launch_select_embed(const SelectArgs& a0, hipStream_t s) {
     SelectArgs a = a0;
     // the row's scaled logits are staged in LDS when they fit (sampling only reads them ~70 times)

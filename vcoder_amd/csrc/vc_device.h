@@ -384,6 +384,32 @@ VC_DEV void st_agent_u32(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __A
 VC_DEV unsigned atomic_inc_agent(unsigned* p) { return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #endif
 
+// ---- in-situ launch timing (vc_pool_profile; bench.py `roofline`): the first thread of every workgroup stamps the launch's slot
+// {earliest start, latest end} with the constant-rate wall clock as its first and its last instruction.  Agent-scope atomics
+// (performed memory-side: the XCDs' L2s are not coherent with each other), no return value -> nothing waits for them.
+#ifdef VC_EMU
+VC_DEV unsigned long long vc_wall_clock() { return vc_emu_wall_clock(); }
+VC_DEV void stamp_min(unsigned long long* p, unsigned long long v) {
+    unsigned long long cur = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (v < cur && !__atomic_compare_exchange_n(p, &cur, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+}
+VC_DEV void stamp_max(unsigned long long* p, unsigned long long v) {
+    unsigned long long cur = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (v > cur && !__atomic_compare_exchange_n(p, &cur, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+}
+#else
+VC_DEV unsigned long long vc_wall_clock() { return (unsigned long long)wall_clock64(); }
+VC_DEV void stamp_min(unsigned long long* p, unsigned long long v) { (void)__hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+VC_DEV void stamp_max(unsigned long long* p, unsigned long long v) { (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
+// `stamp` = the launch's slot (nullptr: off, the default)
+VC_DEV void stamp_begin(unsigned long long* stamp) {
+    if (stamp != nullptr && threadIdx.x == 0) stamp_min(stamp, vc_wall_clock());
+}
+VC_DEV void stamp_end(unsigned long long* stamp) {
+    if (stamp != nullptr && threadIdx.x == 0) stamp_max(stamp + 1, vc_wall_clock());
+}
+
 // ---- activations (fp32) --------------------------------------------------------------------
 // v_exp_f32 (2^x, no range reduction or denormal handling: the softmax arguments are <= 0)
 #ifdef VC_EMU

@@ -536,6 +536,19 @@ class HipEngine:
         self._check(self.lib.vc_pool_step_counts(self._model, c))
         return [int(x) for x in c]
 
+    PROFILE_KINDS = ("qkv", "attention", "o_proj", "gate_up", "down", "lm_head")
+
+    def pool_profile(self, on: bool = True):
+        """in-situ timing of the pool's decode-step launches (vc_pool_profile): takes effect when the pool is next (re)built"""
+        self._check(self.lib.vc_pool_profile(self._model, 1 if on else 0))
+
+    def pool_profile_read(self, reset: bool = True):
+        """{rows: {kind: {"us": total microseconds, "launches": n}}} since the last reset, rows in (8, 16, 24, 32); the pool must be idle"""
+        us, n = (C.c_double * 24)(), (C.c_ulonglong * 24)()
+        self._check(self.lib.vc_pool_profile_read(self._model, us, n, 1 if reset else 0))
+        return {8 * (s + 1): {k: {"us": us[s * 6 + i], "launches": int(n[s * 6 + i])} for i, k in enumerate(self.PROFILE_KINDS)}
+                for s in range(4)}
+
     def profile_decode_gemv(self, B: int, reps: int = 3):
         n, us, by = C.c_int(), C.c_double(), C.c_double()
         self._check(self.lib.vc_profile_decode_gemv(self._model, B, reps, C.byref(n), C.byref(us), C.byref(by)))
