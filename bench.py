@@ -61,6 +61,8 @@ def parse_args():
                          "per-step id all-gather, the device barriers and the MAX all-reduce of the timing (and with --gather cabi "
                          "a one-rank RCCL communicator inside the library): the multi-GPU code path on a one-GPU box")
     ap.add_argument("--dump-ids", default=None, help="write the gathered ids of the last timed step to this .npy (tests)")
+    ap.add_argument("--no-insitu", action="store_true",
+                    help="do not stamp the pool's decode-step launches (roofline then reports the isolated replay); A/B of the stamps' cost")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the compact legs the default single-GPU run appends outside the timed region: parity_mode "
                          "(images/s of the precision modes that meet the 1e-3 / bit-exact-ids bar), BASELINE configs[2] "
@@ -442,6 +444,11 @@ def main():
     import threading
 
     n_sess = max(1, min(args.inflight, args.steps))
+    # in-situ timing of the pool's decode-step kernels (vc_pool_profile): every launch of the timed region stamps its earliest
+    # workgroup start / latest workgroup end with the device's wall clock; `roofline` is computed from those sums
+    insitu_on = not args.no_insitu and os.environ.get("VC_POOL", "1") != "0"
+    if insitu_on:
+        eng.pool_profile(True)
     sessions = [eng] + [eng.fork() for _ in range(n_sess - 1)]
 
     def run_steps(k: int, px):
@@ -496,8 +503,12 @@ def main():
     if args.warmup > 0:
         run_steps(max(args.warmup, n_sess), timed_px)  # every session captures its decode graph before the timed region
     steps0 = eng.pool_step_counts()
+    if insitu_on:
+        torch.cuda.synchronize()
+        eng.pool_profile_read(reset=True)      # drop the warm-up's launches
     dt, outs = timed(args.steps, timed_px)
     step_mix = [a - b for a, b in zip(eng.pool_step_counts(), steps0)]   # pooled decode steps of the timed region by 8/16/24/32 rows
+    insitu = eng.pool_profile_read(reset=True) if insitu_on else None    # every decode-step launch of the timed region, as it ran
     bad_steps = [j for j, o in enumerate(outs) if not np.array_equal(np.asarray(o), np.asarray(lone_gathered))]
     ids_checked = len(bad_steps) == 0 and all(np.asarray(o).shape == (world * B, N_new) for o in outs)
     if args.dump_ids and rank == 0:
@@ -593,14 +604,67 @@ def main():
         fam_g["one_batch_alone"] = {"rows": min(B, 16), "avg_launch_us": prof_one["avg_us"],
                                     "achieved": prof_one["avg_bytes"] / (prof_one["avg_us"] * 1e-6) / 1e9}
         kernels = {"gemv_dma_kernel": fam_g, "attention_decode_fused_kernel": fam_a}
+        for f_ in (fam_g, fam_a):
+            f_["measured"] = ("isolated replay AFTER the timed region: HIP events around back-to-back sweeps of this kernel alone, real arguments, "
+                              "all layers (vc_profile_decode_gemv / _attention)")
+        how = fam_g["measured"]
+        if insitu is not None and sum(v["launches"] for r_ in insitu.values() for v in r_.values()) > 0:
+            # ---- IN SITU: every launch of the timed region as it ran there (beside whatever the other sessions had on the GPU) ----
+            L_, D_, F_, V_ = cfg.num_hidden_layers, cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size
+            wb = 2.0 if args.weights == "bf16" else 1.0
+            kind_bytes = {"qkv": wb * 3 * D_ * D_, "o_proj": wb * D_ * D_, "gate_up": wb * 2 * F_ * D_, "down": wb * D_ * F_, "lm_head": 2.0 * V_ * D_}
+
+            def situ(kinds, total_bytes=None):
+                rows_ = [r_ for r_ in sorted(insitu) if sum(insitu[r_][k_]["launches"] for k_ in kinds) > 0]
+                us = sum(insitu[r_][k_]["us"] for r_ in rows_ for k_ in kinds)
+                nl = sum(insitu[r_][k_]["launches"] for r_ in rows_ for k_ in kinds)
+                byts = total_bytes if total_bytes is not None else sum(insitu[r_][k_]["launches"] * kind_bytes[k_] for r_ in rows_ for k_ in kinds)
+                by_rows = {}
+                for r_ in rows_:
+                    u_ = sum(insitu[r_][k_]["us"] for k_ in kinds)
+                    n_ = sum(insitu[r_][k_]["launches"] for k_ in kinds)
+                    e_ = {"launches": n_, "avg_launch_us": u_ / n_,
+                          "avg_exec_us": sum(insitu[r_][k_]["exec_us"] for k_ in kinds) / n_,
+                          "by_kind_avg_us": {k_: insitu[r_][k_]["us"] / max(insitu[r_][k_]["launches"], 1) for k_ in kinds}}
+                    if total_bytes is None:
+                        b_ = sum(insitu[r_][k_]["launches"] * kind_bytes[k_] for k_ in kinds)
+                        e_["frac"] = b_ / (u_ * 1e-6) / 1e9 / HBM_PEAK_GBS
+                        e_["us_per_layer"] = sum(insitu[r_][k_]["us"] / max(insitu[r_][k_]["launches"], 1) for k_ in kinds if k_ != "lm_head")
+                    by_rows[str(r_)] = e_
+                ex_ = sum(insitu[r_][k_]["exec_us"] for r_ in rows_ for k_ in kinds)
+                return {"launches": nl, "total_ms": us / 1e3, "avg_launch_us": us / nl, "algorithmic_bytes_per_launch": byts / nl,
+                        "avg_exec_us": ex_ / nl, "frac_exec_only": byts / (ex_ * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                        "achieved": byts / (us * 1e-6) / 1e9, "frac": byts / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "by_rows": by_rows}
+            n_steps_pool = sum(step_mix)
+            sum_ctx = (N_new - 1) * (S_prompt + 1) + (N_new - 1) * (N_new - 2) / 2.0     # keys read by one row over its cached steps
+            kv_es = 1.0 if args.weights == "fp8" and os.environ.get("VC_FP8_KV", "1") != "0" else 2.0
+            att_bytes = args.steps * B * 2.0 * kv_es * D_ * sum_ctx * L_                 # every request of the timed region, all layers
+            sg = situ(("qkv", "o_proj", "gate_up", "down", "lm_head"))
+            sa = situ(("attention",), att_bytes)
+            consistent = sa["launches"] == n_steps_pool * L_ and sg["launches"] == n_steps_pool * (4 * L_ + 1)
+            for f_, s_ in ((fam_g, sg), (fam_a, sa)):
+                f_["isolated_replay"] = {k_: f_[k_] for k_ in ("avg_launch_us", "algorithmic_bytes_per_launch", "achieved", "frac", "us_per_step", "by_rows")}
+                f_.update({k_: s_[k_] for k_ in ("avg_launch_us", "algorithmic_bytes_per_launch", "achieved", "frac", "by_rows", "avg_exec_us", "frac_exec_only")})
+                f_["us_per_step"] = s_["total_ms"] * 1e3 / max(n_steps_pool, 1)
+                f_["launches_in_timed_region"] = s_["launches"]
+                f_["measured"] = ("IN SITU: every launch of the timed region on the device's 100-MHz wall clock (vc_pool_profile), beside whatever "
+                                  "the other in-flight calls had on the GPU.  avg_launch_us / achieved / frac use the launch PERIOD = latest "
+                                  "workgroup end of the previous launch of the step -> latest workgroup end of this one (dispatch, drain and the "
+                                  "inter-kernel gap included; rocprofv3's per-kernel duration is <= it); *_exec* = earliest workgroup start -> "
+                                  "latest workgroup end only (<= rocprofv3's)")
+            fam_a["algorithmic_bytes"] = "K + V rows of every cached key of every request of the timed region (context %d..%d), all layers" % (S_prompt + 1, S_prompt + N_new - 1)
+            t_gemv, t_att = fam_g["us_per_step"], fam_a["us_per_step"]
+            how = fam_g["measured"] + ("" if consistent else " [WARNING: launch counts differ from the pool's step histogram]")
         dom = "attention_decode_fused_kernel" if t_att > t_gemv else "gemv_dma_kernel"
         k = kernels[dom]
         roofline = {"bound": "hbm", "kernel": f"{dom} ({k['what']}; {k['us_per_step'] / (t_att + t_gemv) * 100:.0f}% of the decode steps' "
-                                              f"kernel time; averaged over the timed region's steps: " +
+                                              f"kernel time; over the timed region's pool steps: " +
                                               ", ".join(f"{n} over {r_} rows" for r_, n in sorted(mix.items())) + ")",
                     "achieved": k["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k["frac"], "traffic": k["traffic"],
                     "avg_launch_us": k["avg_launch_us"], "algorithmic_bytes_per_launch": k["algorithmic_bytes_per_launch"],
-                    "rows_per_launch": {str(r_): n for r_, n in sorted(mix.items())}}
+                    "measured": how, "rows_per_launch": {str(r_): n for r_, n in sorted(mix.items())}}
+        if "isolated_replay" in k:
+            roofline["isolated_replay"] = {"frac": k["isolated_replay"]["frac"], "avg_launch_us": k["isolated_replay"]["avg_launch_us"]}
         res = {
             "metric": "images/sec (3xViT encode + 128-tok decode), VCoder-DS-7b" if args.model == "7b"
                       else "images/sec (3xViT encode + 128-tok decode), VCoder-DS-13b",

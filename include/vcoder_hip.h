@@ -251,14 +251,15 @@ int vc_profile_decode_gemv(vc_model* m, int B, int reps, int* launches, double* 
 int vc_pool_step_counts(vc_model* m, unsigned long long* counts4);
 /* In-situ timing of the pool's decode-step kernels (bench.py `roofline`: the dominant kernel AS IT RAN in the timed region, beside
  * whatever the other sessions had on the GPU — not a replay).  on != 0: the pool's step graphs are (re)captured with one timing slot
- * per launch; the first thread of every workgroup stamps {earliest start, latest end} with the device's constant-rate wall clock,
- * and one tiny launch per step folds the slots into per-(span, kind) sums.  Takes effect when the pool is next (re)built, i.e. while
+ * per launch; the first thread of every workgroup writes its own {start, end} on the device's constant-rate wall clock (plain
+ * stores, no atomics), and one small launch per step folds the slots into per-(span, kind) sums of (latest end - earliest start).  Takes effect when the pool is next (re)built, i.e. while
  * no generate() is in flight.  bf16 path only.  No reference counterpart (the reference has no timing code). */
 int vc_pool_profile(vc_model* m, int on);
-/* sums since the last reset, [4 spans: 8 / 16 / 24 / 32 rows][6 kinds: qkv, decode attention, o_proj, gate/up, down, lm_head]:
- * total microseconds (earliest workgroup start -> latest workgroup end) and number of launches.  reset != 0 zeroes them.
- * The pool must be idle. */
-int vc_pool_profile_read(vc_model* m, double* us, unsigned long long* launches, int reset);
+/* sums since the last reset, each [4 spans: 8 / 16 / 24 / 32 rows][6 kinds: qkv, decode attention, o_proj, gate/up, down, lm_head]:
+ * exec_us = earliest workgroup start -> latest workgroup end of the launches; period_us = latest end of the previous launch of the
+ * step -> latest end of this one (dispatch, drain and inter-kernel gap included: what the step's dependency chain pays per launch;
+ * rocprofv3's per-kernel duration lies between the two); launches.  reset != 0 zeroes them.  The pool must be idle. */
+int vc_pool_profile_read(vc_model* m, double* exec_us, double* period_us, unsigned long long* launches, int reset);
 /* the same for the decode attention launches of one step (one per layer) over B rows at context ~ctx: launches per sweep,
  * average microseconds per launch, algorithmic KV bytes per launch (K and V rows of every key, bf16) */
 int vc_profile_decode_attention(vc_model* m, int B, int ctx, int reps, int* launches, double* avg_us, double* avg_bytes);

@@ -97,7 +97,7 @@ def test_pool_profile_counts_every_launch_and_changes_no_id(emu_lib):
             for kind, v in prof[rows].items():
                 want = steps[s_] * (1 if kind == "lm_head" else L)
                 assert v["launches"] == want, (rows, kind, v, steps)
-                assert (v["us"] > 0) == (want > 0), (rows, kind, v)
+                assert (v["us"] > 0) == (want > 0) and (v["exec_us"] > 0) == (want > 0), (rows, kind, v)
         assert sum(steps) >= 5
         assert all(v["launches"] == 0 for r in root.pool_profile_read().values() for v in r.values()), "read(reset=True) zeroes the sums"
         other.close()

@@ -113,7 +113,7 @@ def declare(lib: C.CDLL) -> C.CDLL:
     lib.vc_pool_step_counts.restype = C.c_int
     lib.vc_pool_profile.argtypes = [vp, i32]
     lib.vc_pool_profile.restype = C.c_int
-    lib.vc_pool_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_ulonglong), i32]
+    lib.vc_pool_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_ulonglong), i32]
     lib.vc_pool_profile_read.restype = C.c_int
     lib.vc_last_timings.argtypes = [vp, f32p, f32p, f32p]
     lib.vc_preprocess_image.argtypes = [vp, vp, i32, i32, i32, f32p, f32p, vp, i32]

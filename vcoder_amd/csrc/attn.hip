@@ -640,7 +640,7 @@ __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeF
     const int h = blockIdx.x, b = blockIdx.y;
     const size_t bh = (size_t)b * p.H + h;
     if (p.active_dev != nullptr && p.active_dev[(size_t)b * p.pos_stride] == 0) return;  // a free row of the decode pool
-    stamp_begin(p.stamp);
+    stamp_begin(p.stamp, blockIdx.y * gridDim.x + blockIdx.x);
     const int pos = p.pos_dev[(size_t)b * p.pos_stride];
     const int ctx = pos + 1;
     const int D = p.H * HD;
@@ -853,7 +853,7 @@ __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeF
             p.out[(size_t)b * D + h * HD + tid] = f2bf(a);
         }
     }
-    stamp_end(p.stamp);
+    stamp_end(p.stamp, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 void launch_attention_decode_fused(const AttnDecodeFusedArgs& a, hipStream_t s) {

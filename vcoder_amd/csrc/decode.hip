@@ -123,7 +123,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
     constexpr int OPS = WB + XP;            // DMA instructions per slot
     constexpr int SLOT = OPS * 1024;
     static_assert(WAVES * R * SLOT >= WAVES * NT * MG * 1024, "the ring is re-used for the cross-wave reduction");
-    stamp_begin(p.stamp);
+    stamp_begin(p.stamp, blockIdx.x);
     VC_DYNAMIC_SMEM(char, ring);             // [WAVES][R][SLOT]
     __shared__ float ss_part[WAVES][16 * MG];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
     }
     gemv_epilogue<WAVES, EPI, FP8, 16 * MG>(p, v, &ss_part[0][0], nt, m + 16 * fq, g, ovalid[fq]);
     }
-    stamp_end(p.stamp);
+    stamp_end(p.stamp, blockIdx.x);
 }
 
 // ---- workgroup-shared activation form ("wg"; bf16 weights, K % 64 == 0) ------------------------------------------------------
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void gemv_wg_kernel(GemvArgs p) {
     static_assert((CL * P) % WAVES == 0, "the chunk's pieces are dealt evenly to the four waves");
     constexpr int XBUF = CL * P * 1024;       // one activation chunk
     constexpr int SLOT = WO * 1024;
-    stamp_begin(p.stamp);
+    stamp_begin(p.stamp, blockIdx.x);
     VC_DYNAMIC_SMEM(char, lds);               // [2][XBUF] activation chunks | [WAVES][R][SLOT] weight rings
     __shared__ float ss_part[WAVES][16 * MG];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(256) void gemv_wg_kernel(GemvArgs p) {
             gemv_epilogue<WAVES, EPI, false, 16 * MG>(p, v, &ss_part[0][0], nt, m + 16 * q, g, ovalid[q]);
         }
     }
-    stamp_end(p.stamp);
+    stamp_end(p.stamp, blockIdx.x);
 }
 
 template <class K>

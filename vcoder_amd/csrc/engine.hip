@@ -561,17 +561,18 @@ struct LoopView {
     int *next_tok, *out_ids;
     float *ssq, *sk_scratch;
     unsigned* sk_counters;
-    // in-situ timing (vc_pool_profile): slot s of the step = stamps[2 s], stamps[2 s + 1]; *stamp_next = the next free slot while the
-    // step is being enqueued; prof_acc = this span's accumulators.  All nullptr when off.
-    unsigned long long* stamps;
+    // in-situ timing (vc_pool_profile): slot s of the step = stamps + s * STAMP_SLOT_WORDS; *stamp_next = the next free slot while
+    // the step is being enqueued; prof_acc = this span's accumulators.  All nullptr when off.
+    unsigned* stamps;
     int* stamp_next;
     unsigned long long* prof_acc;
+    unsigned* stamp_scratch;
 };
 
 // the next timing slot of the step being enqueued (nullptr: profiling off)
-inline unsigned long long* next_stamp(const LoopView& v) {
+inline unsigned* next_stamp(const LoopView& v) {
     if (!v.stamps || !v.stamp_next) return nullptr;
-    return v.stamps + 2 * (size_t)(*v.stamp_next)++;
+    return v.stamps + STAMP_SLOT_WORDS * (size_t)(*v.stamp_next)++;
 }
 
 // decode-time linear over `X` (bf16 [M, K]).  use_rstd: X is the xg operand (bf16(x * g)) and the output is scaled by the
@@ -1479,7 +1480,8 @@ void enqueue_decode_step(vc_model* m, const LoopView& v, int nrows) {
     });
     launch_select_embed(select_args(m, v, v.logits, nrows, 3), v.st);                                        // K19/K20+K10
     // in-situ timing: fold the step's slots (5 per layer: qkv, attention, o, gate/up, down; then lm_head) into the span's sums
-    if (v.stamps && v.stamp_next && v.prof_acc) launch_stamp_accumulate(v.stamps, *v.stamp_next, m->c.layers, v.prof_acc, v.st);
+    if (v.stamps && v.stamp_next && v.prof_acc)
+        launch_stamp_accumulate(v.stamps, *v.stamp_next, m->c.layers, v.prof_acc, v.stamp_scratch, v.st);
 }
 
 // The same step run eagerly with the output_hidden_states / output_attentions hooks of a cached decode step
@@ -2588,9 +2590,10 @@ struct vc_pool {
     hipEvent_t step_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     unsigned long steps_run = 0;
     unsigned long long steps_by_span[VC_POOL_ROWS / 8] = {};  // steps launched over 8 / 16 / 24 / 32 rows (vc_pool_step_counts)
-    // in-situ timing (vc_pool_profile): the step graphs were captured with stamp slots; prof_acc[span][kind] = {ticks, launches}
+    // in-situ timing (vc_pool_profile): the step graphs were captured with stamp slots; prof_acc[span][kind] = {exec ticks,
+    // period ticks, launches}
     bool prof = false;
-    Buf stamps, prof_acc;
+    Buf stamps, prof_acc, stamp_scratch;
 };
 
 namespace {
@@ -2618,7 +2621,8 @@ LoopView pool_view(vc_pool* p) {
     v.ssq = p->ssq.as<float>();
     v.sk_scratch = p->sk_scratch.as<float>();
     v.sk_counters = p->sk_counters.as<unsigned>();
-    v.stamps = p->prof ? p->stamps.as<unsigned long long>() : nullptr;
+    v.stamps = p->prof ? p->stamps.as<unsigned>() : nullptr;
+    v.stamp_scratch = p->prof ? p->stamp_scratch.as<unsigned>() : nullptr;
     return v;
 }
 
@@ -2743,7 +2747,7 @@ void pool_destroy(vc_pool* p) {
     for (auto& g : p->graph)
         if (g) (void)hipGraphExecDestroy(g);
     for (Buf* b : {&p->kc, &p->vc, &p->rows, &p->x_dec, &p->xg_dec, &p->qkv_dec, &p->attn_dec, &p->h_dec, &p->logits,
-                   &p->next_tok, &p->out_ids, &p->ssq, &p->sk_scratch, &p->sk_counters, &p->stamps, &p->prof_acc})
+                   &p->next_tok, &p->out_ids, &p->ssq, &p->sk_scratch, &p->sk_counters, &p->stamps, &p->prof_acc, &p->stamp_scratch})
         b->release();
     for (auto& e : p->step_ev)
         if (e) (void)hipEventDestroy(e);
@@ -2819,9 +2823,9 @@ vc_pool* pool_for(vc_model* m, int need_S, int need_out) {
         p->prof = root->pool_profile && !want_split;   // (a split step's GEMVs may take two passes: the slot layout assumes one)
         if (p->prof) {
             const size_t nslots = (size_t)5 * c.layers + 1;
-            p->stamps.ensure(nslots * 2 * 8);
-            p->prof_acc.ensure((size_t)(R / 8) * PROF_KINDS * 2 * 8, true);
-            launch_stamp_reset(p->stamps.as<unsigned long long>(), (int)nslots, m->st);
+            p->stamps.ensure(nslots * STAMP_SLOT_WORDS * 4, true);
+            p->prof_acc.ensure((size_t)(R / 8) * PROF_KINDS * 3 * 8, true);
+            p->stamp_scratch.ensure((1 + 2 * nslots) * 4, true);
             HIPCHK(hipStreamSynchronize(m->st));
         }
         LoopView v = pool_view(p);
@@ -2829,7 +2833,7 @@ vc_pool* pool_for(vc_model* m, int need_S, int need_out) {
             int slot = 0;
             if (p->prof) {
                 v.stamp_next = &slot;
-                v.prof_acc = p->prof_acc.as<unsigned long long>() + (size_t)i * PROF_KINDS * 2;
+                v.prof_acc = p->prof_acc.as<unsigned long long>() + (size_t)i * PROF_KINDS * 3;
             }
             p->graph[i] = capture_step(root, v, 8 * (i + 1));
         }
@@ -3362,17 +3366,18 @@ VC_API int vc_pool_profile(vc_model* m, int on) {
     return VC_OK;
 }
 
-/* sums since the last reset: for span s (8 (s + 1) rows) and kind k (0 qkv, 1 decode attention, 2 o_proj, 3 gate/up, 4 down,
- * 5 lm_head): total microseconds between the earliest workgroup start and the latest workgroup end of the launches, and their
- * number.  us / launches are [4][6].  reset != 0 zeroes the sums.  The pool must be idle (no generate() in flight). */
-VC_API int vc_pool_profile_read(vc_model* m, double* us, unsigned long long* launches, int reset) {
-    if (!m || !us || !launches) return VC_ERR_INVALID;
+/* sums since the last reset, for span s (8 (s + 1) rows) and kind k (0 qkv, 1 decode attention, 2 o_proj, 3 gate/up, 4 down,
+ * 5 lm_head), each [4][6]: exec_us = earliest workgroup start -> latest workgroup end of the launches; period_us = latest end of
+ * the previous launch of the step -> latest end of this one (dispatch, drain and the inter-kernel gap included: what the step's
+ * dependency chain pays per launch); launches.  reset != 0 zeroes the sums.  The pool must be idle (no generate() in flight). */
+VC_API int vc_pool_profile_read(vc_model* m, double* exec_us, double* period_us, unsigned long long* launches, int reset) {
+    if (!m || !exec_us || !period_us || !launches) return VC_ERR_INVALID;
     GUARD_BEGIN
     USE_DEVICE(m->ctx);
     vc_model* root = m->root ? m->root : m;
     const int nspan = VC_POOL_ROWS / 8;
     for (int i = 0; i < nspan * PROF_KINDS; ++i) {
-        us[i] = 0;
+        exec_us[i] = period_us[i] = 0;
         launches[i] = 0;
     }
     vc_pool* p = root->pool;
@@ -3382,7 +3387,7 @@ VC_API int vc_pool_profile_read(vc_model* m, double* us, unsigned long long* lau
             REQUIRE(p->users == 0 && p->active.empty() && p->pending.empty(), VC_ERR_STATE, "the decode pool is busy");
         }
         HIPCHK(hipStreamSynchronize(p->st));
-        std::vector<unsigned long long> h((size_t)nspan * PROF_KINDS * 2);
+        std::vector<unsigned long long> h((size_t)nspan * PROF_KINDS * 3);
         HIPCHK(hipMemcpy(h.data(), p->prof_acc.p, h.size() * 8, hipMemcpyDeviceToHost));
         int khz = 100000;   // the constant-rate wall clock: 100 MHz on gfx9
 #ifndef VC_EMU
@@ -3390,8 +3395,9 @@ VC_API int vc_pool_profile_read(vc_model* m, double* us, unsigned long long* lau
         if (khz <= 0) khz = 100000;
 #endif
         for (int i = 0; i < nspan * PROF_KINDS; ++i) {
-            us[i] = (double)h[2 * i] * 1e3 / (double)khz;
-            launches[i] = h[2 * i + 1];
+            exec_us[i] = (double)h[3 * i] * 1e3 / (double)khz;
+            period_us[i] = (double)h[3 * i + 1] * 1e3 / (double)khz;
+            launches[i] = h[3 * i + 2];
         }
         if (reset) HIPCHK(hipMemset(p->prof_acc.p, 0, h.size() * 8));
     }

@@ -105,8 +105,8 @@ struct GemvArgs {
     // capacity of the split-K buffers (0 = the historical [4][512][2][256] floats / [512][2] counters)
     size_t sk_scratch_floats;
     int sk_counters_n;
-    // in-situ timing slot {earliest workgroup start, latest workgroup end} in wall-clock ticks, or nullptr (vc_device.h stamp_begin)
-    unsigned long long* stamp;
+    // in-situ timing slot ([STAMP_WGS] x {start, end} wall-clock ticks, one entry per workgroup), or nullptr (vc_device.h stamp_begin)
+    unsigned* stamp;
 };
 void launch_gemv(const GemvArgs& a, int epilogue, hipStream_t s);
 // the decode GEMV of precision mode "split": 0 = per-wave rings (two weight passes of 16 rows), -1 / 1 = the workgroup-shared form
@@ -242,7 +242,7 @@ struct AttnDecodeFusedArgs {
     // keys hidden by the row's attention_mask: key_mask[b * mask_stride + key] == 0 (nullptr = none)
     const uint8_t* key_mask;
     int mask_stride;
-    unsigned long long* stamp;   // in-situ timing slot, or nullptr (GemvArgs::stamp)
+    unsigned* stamp;   // in-situ timing slot, or nullptr (GemvArgs::stamp)
 };
 void launch_attention_decode_fused(const AttnDecodeFusedArgs& a, hipStream_t s);
 
@@ -319,11 +319,13 @@ struct SelectArgs {
     int xg_G;             // precision mode "split" (0 = off): xg holds stacked groups of G hi rows + G lo rows
 };
 void launch_select_embed(const SelectArgs& a, hipStream_t s);
-// in-situ timing of the decode-step launches (GemvArgs::stamp): slot j = {min start, max end}; `n` slots laid out 5 per layer
-// (qkv, attention, o, gate/up, down) + lm_head; acc[kind] = {sum of (end - start) ticks, launches}, kinds as in vc_pool_profile_read
+// in-situ timing of the decode-step launches (GemvArgs::stamp): slot j = [STAMP_WGS] x {start, end} u32 ticks (zero = not stamped);
+// `n` slots laid out 5 per layer (qkv, attention, o, gate/up, down) + lm_head; acc[kind] = {exec ticks (latest end - earliest
+// start), period ticks (latest end - the previous launch's latest end), launches}, kinds as in vc_pool_profile_read.  The slots
+// and `scratch` ([1 + 2 n] words) must be zero before the first step (the kernel re-zeroes / re-arms them).
 constexpr int PROF_KINDS = 6;
-void launch_stamp_reset(unsigned long long* stamps, int n, hipStream_t s);
-void launch_stamp_accumulate(unsigned long long* stamps, int n, int layers, unsigned long long* acc, hipStream_t s);
+constexpr size_t STAMP_SLOT_WORDS = 2 * 2048;   // == 2 * STAMP_WGS (vc_device.h)
+void launch_stamp_accumulate(unsigned* stamps, int n, int layers, unsigned long long* acc, unsigned* scratch, hipStream_t s);
 // embedding + sum-of-squares partials for tokens supplied by the host (vc_decode_step with explicit tokens)
 void launch_embed_tokens_ssq(const int* tok, const bf16_t* embed, float* x, float* ssq, const float* xg_w, bf16_t* xg, int B, int D, int npart,
                              hipStream_t s, int xg_G = 0);

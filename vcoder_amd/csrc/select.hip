@@ -246,61 +246,92 @@ __global__ __launch_bounds__(1024) void select_embed_kernel(SelectArgs p) {
 }
 
 // ---- in-situ timing slots (vc_device.h stamp_begin / stamp_end; engine.hip vc_pool_profile) ------------------------------------
-// The slots are written with agent-scope atomics by the timed kernels, so every access here is agent-scope too (the "same scope on
-// both sides" rule of the cross-workgroup hand-offs in decode.hip).
-VC_DEV unsigned long long ld_agent_u64(const unsigned long long* p) {
-#ifdef VC_EMU
-    return __atomic_load_n(p, __ATOMIC_RELAXED);
-#else
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-}
-VC_DEV void st_agent_u64(unsigned long long* p, unsigned long long v) {
-#ifdef VC_EMU
-    __atomic_store_n(p, v, __ATOMIC_RELAXED);
-#else
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-}
-__global__ __launch_bounds__(256) void stamp_reset_kernel(unsigned long long* stamps, int n) {
-    for (int j = threadIdx.x; j < n; j += 256) {
-        st_agent_u64(stamps + 2 * j, ~0ull);
-        st_agent_u64(stamps + 2 * j + 1, 0ull);
+// One workgroup per launch slot: earliest start / latest end over the slot's workgroup entries (32-bit ticks: compared relative to
+// one valid entry, so a wrap of the low word inside a launch does not matter), the slot re-zeroed.  The workgroup that finishes
+// last (agent-scope hand-off as in decode.hip's split-K: sc1 stores, arrival counter, sc1 loads) walks the slots in launch order
+// and adds, for the slot's kind — 5 slots per layer (qkv 0, attention 1, o 2, gate/up 3, down 4), the last slot lm_head (5) —
+//   exec   = latest end - earliest start of the launch's workgroups, and
+//   period = latest end - latest end of the PREVIOUS stamped launch of the step (the first launch: its exec): the launch as the
+//            step's dependency chain pays for it, dispatch / drain / inter-kernel gap included — what bench.py's `roofline` uses
+// to acc[kind] = {exec ticks, period ticks, launches}.  A slot nobody stamped (a decode attention over free rows only) is skipped.
+static_assert(STAMP_SLOT_WORDS == 2 * (size_t)STAMP_WGS, "slot size");
+__global__ __launch_bounds__(256) void stamp_accumulate_kernel(unsigned* stamps, int n, int layers, unsigned long long* acc,
+                                                               unsigned* scratch /*[1 + 2 n]: arrival counter, {start, end} per slot*/) {
+    __shared__ unsigned ref;
+    __shared__ int lo, hi;
+    __shared__ unsigned last;
+    const int tid = threadIdx.x, j = blockIdx.x;
+    unsigned* slot = stamps + (size_t)j * STAMP_SLOT_WORDS;
+    if (tid == 0) {
+        ref = 0;
+        lo = 0x7fffffff;
+        hi = -0x7fffffff;
     }
-}
-// one workgroup: slot j -> kind (5 per layer: qkv 0, attention 1, o 2, gate/up 3, down 4; the last slot: lm_head 5); a slot no
-// workgroup stamped (an attention launch over free rows only) is skipped; every slot is re-armed
-__global__ __launch_bounds__(256) void stamp_accumulate_kernel(unsigned long long* stamps, int n, int layers, unsigned long long* acc) {
-    __shared__ unsigned long long sum[PROF_KINDS], cnt[PROF_KINDS];
-    const int tid = threadIdx.x;
-    if (tid < PROF_KINDS) sum[tid] = cnt[tid] = 0;
     __syncthreads();
-    for (int j = tid; j < n; j += 256) {
-        const unsigned long long t0 = ld_agent_u64(stamps + 2 * j), t1 = ld_agent_u64(stamps + 2 * j + 1);
-        if (t1 != 0 && t0 != ~0ull && t1 >= t0) {
-            const int kind = j < 5 * layers ? j % 5 : 5;
-#ifdef VC_EMU
-            __atomic_fetch_add(&sum[kind], t1 - t0, __ATOMIC_RELAXED);
-            __atomic_fetch_add(&cnt[kind], 1ull, __ATOMIC_RELAXED);
-#else
-            atomicAdd(&sum[kind], t1 - t0);
-            atomicAdd(&cnt[kind], 1ull);
-#endif
+    unsigned t0[STAMP_WGS / 256], t1[STAMP_WGS / 256];
+#pragma unroll
+    for (int i = 0; i < STAMP_WGS / 256; ++i) {
+        const int w = i * 256 + tid;
+        t0[i] = slot[2 * w];
+        t1[i] = slot[2 * w + 1];
+        if (t0[i] | t1[i]) {
+            slot[2 * w] = 0;
+            slot[2 * w + 1] = 0;
         }
-        st_agent_u64(stamps + 2 * j, ~0ull);
-        st_agent_u64(stamps + 2 * j + 1, 0ull);
+        if (t0[i] != 0 && t1[i] != 0) ref = t0[i];   // any valid entry serves as the reference (benign race: all are valid)
     }
     __syncthreads();
-    if (tid < PROF_KINDS) {
-        st_agent_u64(acc + 2 * tid, ld_agent_u64(acc + 2 * tid) + sum[tid]);
-        st_agent_u64(acc + 2 * tid + 1, ld_agent_u64(acc + 2 * tid + 1) + cnt[tid]);
+    const unsigned r = ref;
+    int mylo = 0x7fffffff, myhi = -0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < STAMP_WGS / 256; ++i)
+        if (r != 0 && t0[i] != 0 && t1[i] != 0) {
+            mylo = min(mylo, (int)(t0[i] - r));
+            myhi = max(myhi, (int)(t1[i] - r));
+        }
+    if (myhi >= mylo) {
+#ifdef VC_EMU
+        __atomic_fetch_min(&lo, mylo, __ATOMIC_RELAXED);
+        __atomic_fetch_max(&hi, myhi, __ATOMIC_RELAXED);
+#else
+        atomicMin(&lo, mylo);
+        atomicMax(&hi, myhi);
+#endif
     }
+    __syncthreads();
+    if (tid == 0) {
+        const bool ok = r != 0 && hi >= lo;
+        // {0, 0} = not stamped (a stamped end is odd: | 1 survives r + hi only by luck, so validity travels in the start word's bit 0)
+        st_agent_u32(scratch + 1 + 2 * j, ok ? ((r + (unsigned)lo) | 1u) : 0u);
+        st_agent_u32(scratch + 2 + 2 * j, ok ? r + (unsigned)hi : 0u);
+        wait_vmcnt<0>();
+        last = atomic_inc_agent(scratch) == (unsigned)(n - 1) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!last || tid != 0) return;
+    unsigned prev_end = 0;
+    bool have_prev = false;
+    unsigned long long ex[PROF_KINDS] = {}, pe[PROF_KINDS] = {}, cn[PROF_KINDS] = {};
+    for (int s_ = 0; s_ < n; ++s_) {
+        const unsigned st = ld_agent_u32(scratch + 1 + 2 * s_), en = ld_agent_u32(scratch + 2 + 2 * s_);
+        if (!(st & 1u)) continue;
+        const int kind = s_ < 5 * layers ? s_ % 5 : 5;
+        const unsigned e_ = en - (st & ~1u);
+        ex[kind] += e_;
+        pe[kind] += have_prev ? (unsigned)(en - prev_end) : e_;
+        cn[kind] += 1;
+        prev_end = en;
+        have_prev = true;
+    }
+    for (int k = 0; k < PROF_KINDS; ++k) {   // only this thread of this launch touches acc; launches are stream-ordered
+        acc[3 * k] += ex[k];
+        acc[3 * k + 1] += pe[k];
+        acc[3 * k + 2] += cn[k];
+    }
+    st_agent_u32(scratch, 0u);   // re-armed for the next step
 }
-void launch_stamp_reset(unsigned long long* stamps, int n, hipStream_t s) {
-    VC_LAUNCH(stamp_reset_kernel, dim3(1), dim3(256), 0, s, stamps, n);
-}
-void launch_stamp_accumulate(unsigned long long* stamps, int n, int layers, unsigned long long* acc, hipStream_t s) {
-    VC_LAUNCH(stamp_accumulate_kernel, dim3(1), dim3(256), 0, s, stamps, n, layers, acc);
+void launch_stamp_accumulate(unsigned* stamps, int n, int layers, unsigned long long* acc, unsigned* scratch, hipStream_t s) {
+    VC_LAUNCH(stamp_accumulate_kernel, dim3((unsigned)n), dim3(256), 0, s, stamps, n, layers, acc, scratch);
 }
 
 void launch_select_embed(const SelectArgs& a0, hipStream_t s) {

@@ -377,37 +377,32 @@ VC_DEV float ld_agent(const float* p) {
 }
 VC_DEV void st_agent_u32(unsigned* p, unsigned v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
 VC_DEV unsigned atomic_inc_agent(unsigned* p) { return __atomic_fetch_add(p, 1u, __ATOMIC_ACQ_REL); }
+VC_DEV unsigned ld_agent_u32(const unsigned* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
 #else
 VC_DEV void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 VC_DEV float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 VC_DEV void st_agent_u32(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 VC_DEV unsigned atomic_inc_agent(unsigned* p) { return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+VC_DEV unsigned ld_agent_u32(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #endif
 
-// ---- in-situ launch timing (vc_pool_profile; bench.py `roofline`): the first thread of every workgroup stamps the launch's slot
-// {earliest start, latest end} with the constant-rate wall clock as its first and its last instruction.  Agent-scope atomics
-// (performed memory-side: the XCDs' L2s are not coherent with each other), no return value -> nothing waits for them.
+// ---- in-situ launch timing (vc_pool_profile; bench.py `roofline`): the first thread of every workgroup writes the low 32 bits of
+// the constant-rate wall clock (| 1: zero means "not stamped") as its first and as its last instruction into the workgroup's own
+// entry of the launch's slot — plain 4-byte stores, no atomics, nothing shared between workgroups (a same-address agent-scope
+// atomic per workgroup measured +3 us per launch; this form is not measurable).  stamp_accumulate_kernel (select.hip) takes the
+// minimum start / maximum end of a slot after the step and re-zeroes it.
+constexpr int STAMP_WGS = 2048;   // workgroup entries per launch slot ({start, end} x u32 each); workgroups beyond do not stamp
 #ifdef VC_EMU
-VC_DEV unsigned long long vc_wall_clock() { return vc_emu_wall_clock(); }
-VC_DEV void stamp_min(unsigned long long* p, unsigned long long v) {
-    unsigned long long cur = __atomic_load_n(p, __ATOMIC_RELAXED);
-    while (v < cur && !__atomic_compare_exchange_n(p, &cur, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
-}
-VC_DEV void stamp_max(unsigned long long* p, unsigned long long v) {
-    unsigned long long cur = __atomic_load_n(p, __ATOMIC_RELAXED);
-    while (v > cur && !__atomic_compare_exchange_n(p, &cur, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
-}
+VC_DEV unsigned vc_wall_clock32() { return (unsigned)vc_emu_wall_clock(); }
 #else
-VC_DEV unsigned long long vc_wall_clock() { return (unsigned long long)wall_clock64(); }
-VC_DEV void stamp_min(unsigned long long* p, unsigned long long v) { (void)__hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-VC_DEV void stamp_max(unsigned long long* p, unsigned long long v) { (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+VC_DEV unsigned vc_wall_clock32() { return (unsigned)wall_clock64(); }
 #endif
-// `stamp` = the launch's slot (nullptr: off, the default)
-VC_DEV void stamp_begin(unsigned long long* stamp) {
-    if (stamp != nullptr && threadIdx.x == 0) stamp_min(stamp, vc_wall_clock());
+// `stamp` = the launch's slot (nullptr: off, the default); wg = the workgroup's linear index in the grid
+VC_DEV void stamp_begin(unsigned* stamp, unsigned wg) {
+    if (stamp != nullptr && threadIdx.x == 0 && wg < (unsigned)STAMP_WGS) stamp[2 * wg] = vc_wall_clock32() | 1u;
 }
-VC_DEV void stamp_end(unsigned long long* stamp) {
-    if (stamp != nullptr && threadIdx.x == 0) stamp_max(stamp + 1, vc_wall_clock());
+VC_DEV void stamp_end(unsigned* stamp, unsigned wg) {
+    if (stamp != nullptr && threadIdx.x == 0 && wg < (unsigned)STAMP_WGS) stamp[2 * wg + 1] = vc_wall_clock32() | 1u;
 }
 
 // ---- activations (fp32) --------------------------------------------------------------------

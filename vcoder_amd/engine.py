@@ -543,11 +543,13 @@ class HipEngine:
         self._check(self.lib.vc_pool_profile(self._model, 1 if on else 0))
 
     def pool_profile_read(self, reset: bool = True):
-        """{rows: {kind: {"us": total microseconds, "launches": n}}} since the last reset, rows in (8, 16, 24, 32); the pool must be idle"""
-        us, n = (C.c_double * 24)(), (C.c_ulonglong * 24)()
-        self._check(self.lib.vc_pool_profile_read(self._model, us, n, 1 if reset else 0))
-        return {8 * (s + 1): {k: {"us": us[s * 6 + i], "launches": int(n[s * 6 + i])} for i, k in enumerate(self.PROFILE_KINDS)}
-                for s in range(4)}
+        """{rows: {kind: {"us": period microseconds, "exec_us": ..., "launches": n}}} since the last reset, rows in (8, 16, 24, 32).
+        "us" = latest workgroup end of the previous launch of the step -> latest end of this one (what the dependency chain pays per
+        launch); "exec_us" = earliest start -> latest end of the launch's own workgroups.  The pool must be idle."""
+        ex, pe, n = (C.c_double * 24)(), (C.c_double * 24)(), (C.c_ulonglong * 24)()
+        self._check(self.lib.vc_pool_profile_read(self._model, ex, pe, n, 1 if reset else 0))
+        return {8 * (s + 1): {k: {"us": pe[s * 6 + i], "exec_us": ex[s * 6 + i], "launches": int(n[s * 6 + i])}
+                              for i, k in enumerate(self.PROFILE_KINDS)} for s in range(4)}
 
     def profile_decode_gemv(self, B: int, reps: int = 3):
         n, us, by = C.c_int(), C.c_double(), C.c_double()
