@@ -77,6 +77,12 @@ int vc_model_synth_tensor(vc_model* m, const char* hf_key, const int64_t* shape,
                           float offset, float halfwidth);
 /* after the last tensor: fuses QKV / interleaves gate-up / packs decode copies; fails listing a missing key */
 int vc_model_finalize(vc_model* m);
+/* Number of loaded tensors whose fp32 source held values bf16 cannot represent — the reference's own checkpoints: an fp16 LLM
+ * (model/builder.py:25-40, torch_dtype=float16) and an fp32 CLIP hub checkpoint (multimodal_encoder/clip_encoder.py:22-27).  Every
+ * such matrix keeps a second bf16 plane lo = bf16(w - bf16(w)); precision modes "strict" and "split" contract against hi + lo (the
+ * checkpoint's values to ~16 mantissa bits; exact for fp16 values), the bf16 fast path uses the bf16-rounded weights alone.
+ * 0 for a bf16 checkpoint.  >= 0, or a negative vc_status. */
+int vc_model_inexact_tensors(vc_model* m);
 
 /* arithmetic mode: 0 = bf16 MFMA operands, fp32 accumulate/residual/softmax (default; what bench.py measures);
  * 1 = strict: fp32 activations end to end on fp32 MFMA (slow) — within ~1e-5 of the reference's fp32 CPU path;

@@ -142,6 +142,19 @@ void vck_gemv_split(const uint16_t* X, const void* Wp, const float* wscale, void
 void vck_gemv_full(const uint16_t* X, const void* Wp, const float* wscale, void* out, const float* ssq_in, float* ssq_out,
                    const float* xg_w, uint16_t* xg_out, int npart, float eps, float* sk_scratch, unsigned long long sk_scratch_floats,
                    unsigned* sk_counters, int sk_counters_n, int ksplit, int M, int N, int K, int ldo, int epi, int G, void* stream);
+/* Inexact checkpoints (fp16 / fp32 values bf16 cannot hold; vc_model_inexact_tensors): w = bf16 hi + bf16 lo.
+ *  vck_f32_to_bf16_planes: hi = bf16(in), lo = bf16(in - hi) (lo may be NULL), *inexact = 1 if any in != hi
+ *  vck_gemm_f32_wlo:   the strict GEMM over W + W_lo
+ *  vck_gemm_split_wlo: the split prefill GEMM with a third K segment a_hi . w_lo (W_lo [N, Kw] like W; NULL = vck_gemm_split)
+ *  vck_gemv_split_wlo: the split decode GEMV (G > 0, workgroup-shared form) with the packed lo plane */
+void vck_f32_to_bf16_planes(const float* in, uint16_t* hi, uint16_t* lo, uint64_t n, unsigned* inexact, void* stream);
+void vck_gemm_f32_wlo(const float* A, const uint16_t* W, const uint16_t* W_lo, const float* bias, float* out, int M, int N, int K,
+                      int lda, int ldw, int ldo, int epi, void* stream);
+void vck_gemm_split_wlo(const uint16_t* A, const uint16_t* W, const uint16_t* W_lo, const float* bias, void* out, int M, int N, int Kw,
+                        int lda, int ldo, int epi, int split_out, float* ws, size_t ws_bytes, void* stream);
+void vck_gemv_split_wlo(const uint16_t* X, const void* Wp, const void* Wp_lo, void* out, const float* ssq_in, float* ssq_out,
+                        const float* xg_w, uint16_t* xg_out, int npart, float eps, float* sk_scratch, unsigned long long sk_scratch_floats,
+                        unsigned* sk_counters, int sk_counters_n, int ksplit, int M, int N, int K, int ldo, int epi, int G, void* stream);
 /* which kernel serves the decode GEMV of precision mode "split": 0 = per-wave rings (gemv_dma_kernel; two weight passes of 16
  * rows per 32-row step), 1 / -1 (default) = workgroup-shared activation chunks (gemv_wg_kernel; hi + lo planes in one pass) */
 void vck_set_gemv_variant(int v);

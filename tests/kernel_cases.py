@@ -959,13 +959,19 @@ def _split_value(be, out, N):
     return o[:, :N].astype(np.float64) + o[:, N:2 * N].astype(np.float64)
 
 
-def check_gemm_split(be, M, N, K, epi, bias=True, seed=0, ws_mb=0, pad=64):
+def fp16_valued(x):
+    """values an fp16 checkpoint holds (11 significant bits: bf16 hi + bf16 lo exactly), as fp32"""
+    return np.asarray(x, dtype=np.float32).astype(np.float16).astype(np.float32)
+
+
+def check_gemm_split(be, M, N, K, epi, bias=True, seed=0, ws_mb=0, pad=64, wlo=False):
     """vck_gemm_split: A = [hi | lo] of an fp32 matrix (row stride 2K + pad), W bf16; against the float64 product of the
     fp32 activations.  fp32 outputs: the split's own error (2^-17 relative per operand) — tolerance 3e-5 of the largest
-    output; bf16-valued outputs come back as [hi | lo] and are compared the same way."""
+    output; bf16-valued outputs come back as [hi | lo] and are compared the same way.
+    wlo: W is fp16-valued (an inexact checkpoint) and goes in as bf16 hi + lo planes (vck_gemm_split_wlo: a third K segment)."""
     rng = np.random.RandomState(seed)
     A = rng.randn(M, K).astype(np.float32)
-    W = bf16_round(rng.randn(N, K) * 0.05)
+    W = fp16_valued(rng.randn(N, K) * 0.05) if wlo else bf16_round(rng.randn(N, K) * 0.05)
     b = rng.randn(N).astype(np.float32) * 0.1 if bias else None
     hi, lo = split_hi_lo(A)
     lda = 2 * K + pad
@@ -989,15 +995,76 @@ def check_gemm_split(be, M, N, K, epi, bias=True, seed=0, ws_mb=0, pad=64):
         r0 = rng.randn(M, N).astype(np.float32)
         ldo, split_out, out = N, 0, be.f32(r0.copy())
         t = t + torch.from_numpy(r0).double()
-    Ad, Wd, bd = be.bf16(Acat), be.bf16(W), (be.f32(b) if bias else None)
+    Wh = bf16_round(W)
+    Ad, Wd, bd = be.bf16(Acat), be.bf16(Wh), (be.f32(b) if bias else None)
     ws = be.zeros((max(ws_mb, 1) << 18,), "f32")
-    be.lib.vck_gemm_split(be.ptr(Ad), be.ptr(Wd), be.ptr(bd), be.ptr(out), M, N, K, lda, ldo, epi, split_out,
-                          be.ptr(ws) if ws_mb else None, ctypes.c_size_t((ws_mb << 20) if ws_mb else 0), None)
+    if wlo:
+        Wl = W - Wh
+        assert np.array_equal(bf16_round(Wl), Wl) and np.abs(Wl).max() > 0, "an fp16 value is bf16 hi + bf16 lo exactly"
+        Wld = be.bf16(Wl)
+        be.lib.vck_gemm_split_wlo(be.ptr(Ad), be.ptr(Wd), be.ptr(Wld), be.ptr(bd), be.ptr(out), M, N, K, lda, ldo, epi, split_out,
+                                  be.ptr(ws) if ws_mb else None, ctypes.c_size_t((ws_mb << 20) if ws_mb else 0), None)
+    else:
+        be.lib.vck_gemm_split(be.ptr(Ad), be.ptr(Wd), be.ptr(bd), be.ptr(out), M, N, K, lda, ldo, epi, split_out,
+                              be.ptr(ws) if ws_mb else None, ctypes.c_size_t((ws_mb << 20) if ws_mb else 0), None)
     be.sync()
     got = _split_value(be, out, No) if split_out else be.host_f32(out).astype(np.float64)
     e = rel_err(got, t.numpy())
-    assert e < 3e-5, f"gemm_split M{M} N{N} K{K} epi{epi}: rel err {e}"
+    assert e < 3e-5, f"gemm_split M{M} N{N} K{K} epi{epi} wlo{wlo}: rel err {e}"
     return e
+
+
+def check_gemm_split_wlo(be, M, N, K, epi, seed=0):
+    return check_gemm_split(be, M, N, K, epi, bias=epi != 5, seed=seed, wlo=True)
+
+
+def check_weight_planes(be, n=5000, seed=0):
+    """vck_f32_to_bf16_planes: hi = bf16(x), lo = bf16(x - hi), the inexact flag; fp16 values come back exactly as hi + lo"""
+    rng = np.random.RandomState(seed)
+    for vals, inexact in ((fp16_valued(rng.randn(n) * 0.05), 1), (bf16_round(rng.randn(n) * 0.05), 0), (rng.randn(n).astype(np.float32), 1)):
+        x, hi, lo, flag = be.f32(vals), be.zeros((n,), "bf16"), be.zeros((n,), "bf16"), be.zeros((1,), "i32")
+        be.lib.vck_f32_to_bf16_planes(be.ptr(x), be.ptr(hi), be.ptr(lo), ctypes.c_uint64(n), be.ptr(flag), None)
+        be.sync()
+        h, l = be.host_f32(hi), be.host_f32(lo)
+        assert np.array_equal(h, bf16_round(vals)) and np.array_equal(l, bf16_round(vals - h))
+        assert int(be.host_i32(flag)[0]) == inexact
+        if inexact and np.array_equal(fp16_valued(vals), vals):
+            assert np.array_equal(h + l, vals), "fp16 values are bf16 hi + bf16 lo exactly"
+        else:
+            assert np.abs(h.astype(np.float64) + l - vals).max() <= 2.0 ** -16 * np.abs(vals).max()
+
+
+def check_gemm_f32_wlo(be, M, N, K, epi, seed=0):
+    """the strict GEMM over W + W_lo against float64 on the fp16-valued weights"""
+    rng = np.random.RandomState(seed)
+    A = rng.randn(M, K).astype(np.float32)
+    W = fp16_valued(rng.randn(N, K) * 0.05)
+    Wh = bf16_round(W)
+    out = be.zeros((M, N), "f32")
+    Ad, Whd, Wld = be.f32(A), be.bf16(Wh), be.bf16(W - Wh)   # (held until the launch has finished)
+    be.lib.vck_gemm_f32_wlo(be.ptr(Ad), be.ptr(Whd), be.ptr(Wld), None, be.ptr(out), M, N, K, K, K, N, epi, None)
+    be.sync()
+    e = rel_err(be.host_f32(out).astype(np.float64), A.astype(np.float64) @ W.T.astype(np.float64))
+    assert e < 2e-5, f"gemm_f32_wlo M{M} N{N} K{K}: rel err {e}"
+    return e
+
+
+def check_gemv_split_wlo(be, M, N, K, epi, G, ksplit=0, seed=0):
+    """the split decode GEMV (workgroup-shared form) over the packed hi + lo planes of an fp16-valued weight: against float64 on
+    the original values, and clearly better than the hi plane alone"""
+    be.lib.vck_set_gemv_variant(1)
+    try:
+        rng = np.random.RandomState(seed)
+        c = _wg_case(be, rng, M, N, K, epi, True, G, w16=True)
+        val, _, _ = _wg_run(be, c, M, G, ksplit, wlo=True)
+        e = rel_err(val, c["ref"])
+        assert e < 3e-5, f"gemv_split_wlo M{M} N{N} K{K} epi{epi} G{G} ks{ksplit}: rel err {e}"
+        val0, _, _ = _wg_run(be, c, M, G, ksplit)
+        e0 = rel_err(val0, c["ref"])
+        assert e0 > 4 * e, f"the hi plane alone should miss the fp16 values: {e0} vs {e}"
+        return e
+    finally:
+        be.lib.vck_set_gemv_variant(-1)
 
 
 def check_gemv_split(be, M, N, K, epi, norm=True, seed=0, fp8=False):
@@ -1219,8 +1286,9 @@ def _gemv_full(be, X, Wp, out, ssq_in, ssq_out, xg_w, xg_out, npart, M, N, K, ld
     be.sync()
 
 
-def _wg_case(be, rng, rows, N, K, epi, norm, G):
-    """inputs of a wg-GEMV case over `rows` activation rows; G > 0: the stacked hi / lo form of precision mode split"""
+def _wg_case(be, rng, rows, N, K, epi, norm, G, w16=False):
+    """inputs of a wg-GEMV case over `rows` activation rows; G > 0: the stacked hi / lo form of precision mode split; w16: an
+    fp16-valued weight (packed hi and lo planes)"""
     npart = (max(K, N) // 16 + 15) // 16 * 16
     Xf = rng.randn(rows, K).astype(np.float32)
     if G:
@@ -1228,9 +1296,14 @@ def _wg_case(be, rng, rows, N, K, epi, norm, G):
     else:
         Xf = bf16_round(Xf)
         hi, lo = Xf, None
-    W = bf16_round(rng.randn(N, K) * 0.05)
-    Wd, Wp = be.bf16(W), be.zeros((N * K,), "bf16")
+    W = fp16_valued(rng.randn(N, K) * 0.05) if w16 else bf16_round(rng.randn(N, K) * 0.05)
+    Wd, Wp = be.bf16(bf16_round(W)), be.zeros((N * K,), "bf16")
     _call(be, "vck_pack_weight", Wd, Wp, N, K)
+    Wp_lo = None
+    if w16:
+        Wp_lo, Wl_d = be.zeros((N * K,), "bf16"), be.bf16(W - bf16_round(W))
+        _call(be, "vck_pack_weight", Wl_d, Wp_lo, N, K)
+        be.sync()
     ssq = np.zeros((32, npart), np.float32)
     ssq[:, : K // 16] = rng.rand(32, K // 16).astype(np.float32) + 0.5
     ref = Xf.astype(np.float64) @ W.T.astype(np.float64)
@@ -1245,10 +1318,10 @@ def _wg_case(be, rng, rows, N, K, epi, norm, G):
     if epi == 2:
         ref = ref + r0[:rows]
     sk = (be.zeros((8 * (N // 16) * 2 * 256,), "f32"), be.zeros((N // 16 * 2,), "i32"), 8 * (N // 16) * 2 * 256, N // 16 * 2)
-    return dict(npart=npart, hi=hi, lo=lo, Wp=Wp, Wd=Wd, ssq=ssq, ref=ref, No=No, gw=gw, r0=r0, sk=sk, N=N, K=K, epi=epi, norm=norm)
+    return dict(npart=npart, hi=hi, lo=lo, Wp=Wp, Wp_lo=Wp_lo, Wd=Wd, ssq=ssq, ref=ref, No=No, gw=gw, r0=r0, sk=sk, N=N, K=K, epi=epi, norm=norm)
 
 
-def _wg_run(be, c, M, G, ksplit=0, row0=0):
+def _wg_run(be, c, M, G, ksplit=0, row0=0, wlo=False):
     """one launch over rows [row0, row0 + M) of the case -> (values [M, No] float64 (hi + lo summed for bf16-valued outputs in
     split form), raw outputs for bit comparisons)"""
     N, K, epi, No = c["N"], c["K"], c["epi"], c["No"]
@@ -1274,7 +1347,14 @@ def _wg_run(be, c, M, G, ksplit=0, row0=0):
     ssq = np.zeros_like(c["ssq"])
     ssq[:M] = c["ssq"][row0:row0 + M]
     Xd, ssqd, gwd = be.bf16(X), (be.f32(ssq) if c["norm"] else None), (be.f32(c["gw"]) if c["gw"] is not None else None)
-    _gemv_full(be, Xd, c["Wp"], out, ssqd, ssq_out, gwd, xg_out, c["npart"], M, N, K, No, epi, G=G, ksplit=ksplit, sk=c["sk"])
+    if wlo:
+        sk = c["sk"]
+        be.lib.vck_gemv_split_wlo(be.ptr(Xd), be.ptr(c["Wp"]), be.ptr(c["Wp_lo"]), be.ptr(out), be.ptr(ssqd), be.ptr(ssq_out), be.ptr(gwd),
+                                  be.ptr(xg_out), ctypes.c_int(c["npart"]), ctypes.c_float(1e-5), be.ptr(sk[0]), ctypes.c_ulonglong(sk[2]),
+                                  be.ptr(sk[1]), ctypes.c_int(sk[3]), ctypes.c_int(ksplit), M, N, K, No, epi, G, None)
+        be.sync()
+    else:
+        _gemv_full(be, Xd, c["Wp"], out, ssqd, ssq_out, gwd, xg_out, c["npart"], M, N, K, No, epi, G=G, ksplit=ksplit, sk=c["sk"])
     o = be.host_f32(out)
     assert not be.host_i32(c["sk"][1]).any(), "arrival counters must be re-armed"
     if G and epi in (0, 3):

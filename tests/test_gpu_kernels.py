@@ -235,6 +235,20 @@ def test_gemv_wide_geometry(be, N, K, epi, rows):
     kc.check_gemv_wide(be, N, K, epi, rows)
 
 
+def test_weight_lo_plane_kernels(be):
+    """inexact checkpoints (w = bf16 hi + bf16 lo): the loader's plane kernel, the split prefill GEMM's third K segment on the
+    8-phase and the 128^2 kernels at true shapes, the strict GEMM, the lo-plane form of the workgroup-shared decode GEMV"""
+    kc.check_weight_planes(be, n=100003)
+    kc.check_gemm_split_wlo(be, 1216, 12288, 4096, 3, seed=1)       # 7b qkv, one sample's prefill rows: 8-phase kernel, 192 k-tiles
+    kc.check_gemm_split_wlo(be, 2432, 4096, 11008, 4, seed=2)       # down: RESID, odd tile count
+    kc.check_gemm_split_wlo(be, 1216, 22016, 4096, 5, seed=3)       # gate/up: SwiGLU with stacked hi / lo output
+    kc.check_gemm_split_wlo(be, 577, 1024, 1024, 3, seed=4)         # ViT shape (128^2 DMA kernel)
+    kc.check_gemm_f32_wlo(be, 70, 512, 1024, 3)
+    for (M, N, K, epi, G, ks) in [(8, 12288, 4096, 1, 8, 0), (16, 22016, 4096, 3, 16, 0), (32, 4096, 11008, 2, 32, 0),
+                                  (29, 32000, 4096, 1, 32, 0), (24, 4096, 4096, 2, 24, 0)]:
+        kc.check_gemv_split_wlo(be, M, N, K, epi, G, ks)
+
+
 def test_gemv_wg_is_race_free_and_bit_reproducible(be):
     """hand-placed counted vmcnt waits + one bare barrier per chunk: back-to-back launches must all give the first launch's bits"""
     import numpy as np

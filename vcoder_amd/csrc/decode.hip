@@ -378,12 +378,16 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
 // KH = 2 (precision mode "split"): X holds the hi rows [0, M) and the lo rows [G, G + M); both planes of a line are staged and
 // every weight fragment feeds hi and lo MFMAs of the SAME accumulator (the [hi | lo] K-concatenation of the prefill GEMM) —
 // one weight pass for up to 32 rows (64 operand rows), no combine step.
-template <int NTW, int XP, int KH, int CL, int R, int EPI>
+//
+// WL (an inexact checkpoint: w = bf16 hi + bf16 lo, GemvArgs::Wp_lo): the slot also carries the lo plane's blocks of the line, and
+// every lo fragment feeds one more MFMA against the activation HI plane — x.w = x_hi.w_hi + x_lo.w_hi + x_hi.w_lo, the prefill GEMM's
+// third K segment (gemm.hip w_koff); twice the weight bytes per step.
+template <int NTW, int XP, int KH, int CL, int R, int EPI, bool WL = false>
 __global__ __launch_bounds__(256) void gemv_wg_kernel(GemvArgs p) {
     constexpr int WAVES = 4;
     constexpr int MG = (XP + 1) / 2;          // MFMA row groups of 16 token rows
     constexpr int P = XP * KH;                // 1-KiB activation pieces (8 rows x 128 B) per line
-    constexpr int WO = 2 * NTW;               // weight DMA instructions per line (2 k-tiles x NTW tiles)
+    constexpr int WO = 2 * NTW * (WL ? 2 : 1);   // weight DMA instructions per line (2 k-tiles x NTW tiles [x hi, lo planes])
     constexpr int XO = CL * P / WAVES;        // activation DMA instructions per wave and chunk
     static_assert((CL * P) % WAVES == 0, "the chunk's pieces are dealt evenly to the four waves");
     constexpr int XBUF = CL * P * 1024;       // one activation chunk
@@ -404,6 +408,8 @@ __global__ __launch_bounds__(256) void gemv_wg_kernel(GemvArgs p) {
     char* my = lds + 2 * XBUF + wave * (R * SLOT);
     const int tile0 = (grp * WAVES + wave) * NTW;
     const char* wsrc[NTW];
+    long long lo_delta = 0;   // bytes from a hi block to the lo plane's block of the same (tile, k-tile)
+    if constexpr (WL) lo_delta = reinterpret_cast<const char*>(p.Wp_lo) - reinterpret_cast<const char*>(p.Wp);
 #pragma unroll
     for (int t = 0; t < NTW; ++t)
         wsrc[t] = reinterpret_cast<const char*>(p.Wp) + ((size_t)min(tile0 + t, ntiles - 1) * (nlines * 2) * 64 + lane) * 16;
@@ -434,6 +440,7 @@ __global__ __launch_bounds__(256) void gemv_wg_kernel(GemvArgs p) {
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
                 glds16_nt(wsrc[t] + (line * 2 + kk) * 1024, dst + (kk * NTW + t) * 1024);
+                if constexpr (WL) glds16_nt(wsrc[t] + lo_delta + (line * 2 + kk) * 1024, dst + ((2 + kk) * NTW + t) * 1024);
             }
     };
     f32x4 acc[NTW][MG];
@@ -450,9 +457,12 @@ __global__ __launch_bounds__(256) void gemv_wg_kernel(GemvArgs p) {
         const char* sl = my + slot * SLOT + lane * 16;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            u32x4 w[NTW];
+            u32x4 w[NTW], wl[WL ? NTW : 1];
 #pragma unroll
-            for (int t = 0; t < NTW; ++t) w[t] = ld16(sl + (kk * NTW + t) * 1024);
+            for (int t = 0; t < NTW; ++t) {
+                w[t] = ld16(sl + (kk * NTW + t) * 1024);
+                if constexpr (WL) wl[t] = ld16(sl + ((2 + kk) * NTW + t) * 1024);
+            }
 #pragma unroll
             for (int h = 0; h < KH; ++h) {
                 u32x4 x[MG];
@@ -466,7 +476,11 @@ __global__ __launch_bounds__(256) void gemv_wg_kernel(GemvArgs p) {
 #pragma unroll
                 for (int t = 0; t < NTW; ++t)
 #pragma unroll
-                    for (int q = 0; q < MG; ++q) acc[t][q] = mfma16(w[t], x[q], acc[t][q]);
+                    for (int q = 0; q < MG; ++q) {
+                        acc[t][q] = mfma16(w[t], x[q], acc[t][q]);
+                        if constexpr (WL)
+                            if (h == 0) acc[t][q] = mfma16(wl[t], x[q], acc[t][q]);   // the weight's lo plane against the activation's hi plane
+                    }
             }
         }
         wait_lgkmcnt<0>();  // the slot's fragment reads have retired before it is re-armed
@@ -711,21 +725,21 @@ static int wg_kslices(int ntiles, int K) {
     return ks;
 }
 
-template <int XP, int CL, int R>
+template <int XP, int CL, int R, bool WL>
 static void launch_gemv_wg_e(const GemvArgs& a, int epi, hipStream_t s) {
     constexpr int NTW = 1, KH = 2;
     const int groups = (a.N / 16 + 4 * NTW - 1) / (4 * NTW);
     const dim3 grid((unsigned)(groups * (a.ksplit > 1 ? a.ksplit : 1))), block(256);
-    constexpr size_t shmem = (size_t)(2 * CL * XP * KH + 4 * R * 2 * NTW) * 1024;
+    constexpr size_t shmem = (size_t)(2 * CL * XP * KH + 4 * R * 2 * NTW * (WL ? 2 : 1)) * 1024;
     static_assert(shmem + 4 * 16 * ((XP + 1) / 2) * 4 <= 160 * 1024, "exceeds the LDS of a CU");
 #define VC_GEMV_WG(E)                                                                                                   \
     do {                                                                                                                \
         static bool once = false;                                                                                       \
         if (!once) {                                                                                                    \
-            allow_big_lds(gemv_wg_kernel<NTW, XP, KH, CL, R, E>, shmem);                                                \
+            allow_big_lds(gemv_wg_kernel<NTW, XP, KH, CL, R, E, WL>, shmem);                                            \
             once = true;                                                                                                \
         }                                                                                                               \
-        VC_LAUNCH((gemv_wg_kernel<NTW, XP, KH, CL, R, E>), grid, block, shmem, s, a);                                   \
+        VC_LAUNCH((gemv_wg_kernel<NTW, XP, KH, CL, R, E, WL>), grid, block, shmem, s, a);                               \
     } while (0)
     switch (epi) {
         case GEMV_BF16: VC_GEMV_WG(GEMV_BF16); break;
@@ -765,12 +779,22 @@ static void launch_gemv_wg(const GemvArgs& a0, int epi, hipStream_t s) {
     while (ks > 1 && (!a.sk_scratch || !a.sk_counters || (size_t)ks * ntiles * 2 * 256 > cap || ntiles * 2 > ncnt)) --ks;
     a.ksplit = ks;
     g_gemv_wg_launches.fetch_add(1, std::memory_order_relaxed);
-    // chunk length / ring depth by the activation pieces per line, so that two workgroups fit a CU (<= 72 KiB each)
+    // chunk length / ring depth by the activation pieces per line, so that two workgroups fit a CU (<= 72 KiB each); with the
+    // weight's lo plane (an inexact checkpoint) the slots are twice as large: one workgroup per CU (80 - 96 KiB)
+    if (a.Wp_lo != nullptr) {
+        switch ((a.M + 7) / 8) {
+            case 1: launch_gemv_wg_e<1, 4, 4, true>(a, epi, s); break;
+            case 2: launch_gemv_wg_e<2, 4, 4, true>(a, epi, s); break;
+            case 3: launch_gemv_wg_e<3, 2, 4, true>(a, epi, s); break;
+            default: launch_gemv_wg_e<4, 2, 4, true>(a, epi, s); break;
+        }
+        return;
+    }
     switch ((a.M + 7) / 8) {
-        case 1: launch_gemv_wg_e<1, 4, 4>(a, epi, s); break;
-        case 2: launch_gemv_wg_e<2, 4, 4>(a, epi, s); break;
-        case 3: launch_gemv_wg_e<3, 2, 4>(a, epi, s); break;
-        default: launch_gemv_wg_e<4, 2, 4>(a, epi, s); break;
+        case 1: launch_gemv_wg_e<1, 4, 4, false>(a, epi, s); break;
+        case 2: launch_gemv_wg_e<2, 4, 4, false>(a, epi, s); break;
+        case 3: launch_gemv_wg_e<3, 2, 4, false>(a, epi, s); break;
+        default: launch_gemv_wg_e<4, 2, 4, false>(a, epi, s); break;
     }
 }
 
@@ -832,6 +856,9 @@ void launch_gemv(const GemvArgs& a, int epilogue, hipStream_t s) {
         launch_gemv_wg(a, epilogue, s);
         return;
     }
+    if (a.Wp_lo != nullptr)
+        throw std::runtime_error("decode GEMV: the weight lo plane of an inexact checkpoint is served by the workgroup-shared split form only "
+                                 "(precision mode split, bf16 weights, K % 64 == 0, set_gemv_variant != 0)");
     if (a.split_rows) {
         // hi rows [0, M) + lo rows [G, G + M) of X; the two MFMA forms that combine them: G = 8 inside one 16-slot row group
         // (M <= 8), G = 16 across the two row groups (M <= 16).  No split-K hand-off in this mode.

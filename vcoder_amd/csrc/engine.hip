@@ -170,6 +170,15 @@ struct vc_model {
     // derived
     int P, Tv, Kpatch, Kpad, hd, vhd, npart;
     std::vector<void*> owned;  // every weight allocation
+    // Checkpoints bf16 cannot hold (the reference's: an fp16 LLM, builder.py:25-40, and an fp32 CLIP hub checkpoint cast to fp16,
+    // clip_encoder.py:22-27): every matrix whose fp32 source had a value != bf16(value) keeps a second bf16 plane lo = bf16(w - hi)
+    // of the same layout.  lo_of maps a hi plane (row-major, or the decode steps' packed copy) to it.  Precision modes "strict" and
+    // "split" contract against hi + lo (w to ~16 mantissa bits; exact for fp16 values); the bf16 fast path uses hi alone.
+    // Written while loading / finalizing only; sessions read their root's map.
+    std::map<const void*, bf16_t*> lo_of;
+    int inexact_tensors = 0;   // loaded tensors that needed a lo plane (vc_model_inexact_tensors)
+    bf16_t* embed_lo = nullptr;
+    unsigned* inexact_flag = nullptr;   // device word for the loader's check
     std::map<std::string, bool> need;
     // weights
     float *vit_cls = nullptr, *vit_pos = nullptr, *vit_pre_w = nullptr, *vit_pre_b = nullptr;
@@ -301,10 +310,38 @@ std::string canon_key(const std::string& k) {
     return k;
 }
 
-void to_bf16(vc_model* m, bf16_t* dst, const void* src, int dtype, size_t n) {
-    if (dtype == VC_BF16) HIPCHK(hipMemcpyAsync(dst, src, n * 2, hipMemcpyDeviceToDevice, m->st));
-    else launch_f32_to_bf16(reinterpret_cast<const float*>(src), dst, n, m->st);
+// the lo plane of a weight (hi-plane pointer as loaded / packed), or nullptr: exact checkpoint, or none kept for it
+const bf16_t* lo_plane(const vc_model* m, const void* hi) {
+    const vc_model* r = m->root ? m->root : m;
+    auto it = r->lo_of.find(hi);
+    return it == r->lo_of.end() ? nullptr : it->second;
 }
+
+// `n` elements of `src` -> elements [off, off + n) of the matrix at `base` (base_elems elements in all: q / k / v land in one
+// matrix).  fp32 sources that bf16 cannot hold exactly get (and from then on fill) the matrix's lo plane.
+void to_bf16(vc_model* m, bf16_t* base, size_t off, size_t base_elems, const void* src, int dtype, size_t n) {
+    bf16_t* dst = base + off;
+    if (dtype == VC_BF16) {
+        HIPCHK(hipMemcpyAsync(dst, src, n * 2, hipMemcpyDeviceToDevice, m->st));
+        return;
+    }
+    if (!m->inexact_flag) m->inexact_flag = walloc<unsigned>(m, 64, true);
+    auto it = m->lo_of.find(base);
+    bf16_t* lo = it == m->lo_of.end() ? nullptr : it->second;
+    HIPCHK(hipMemsetAsync(m->inexact_flag, 0, 4, m->st));
+    launch_f32_to_bf16_planes(reinterpret_cast<const float*>(src), dst, lo ? lo + off : nullptr, n, m->inexact_flag, m->st);
+    unsigned flag = 0;
+    HIPCHK(hipMemcpyAsync(&flag, m->inexact_flag, 4, hipMemcpyDeviceToHost, m->st));
+    HIPCHK(hipStreamSynchronize(m->st));
+    if (!flag) return;
+    m->inexact_tensors += 1;
+    if (!lo) {
+        lo = walloc<bf16_t>(m, base_elems, true);   // zero: the parts of the matrix loaded from exact data
+        m->lo_of[base] = lo;
+        launch_f32_to_bf16_planes(reinterpret_cast<const float*>(src), dst, lo + off, n, nullptr, m->st);
+    }
+}
+void to_bf16(vc_model* m, bf16_t* dst, const void* src, int dtype, size_t n) { to_bf16(m, dst, 0, n, src, dtype, n); }
 void to_f32(vc_model* m, float* dst, const void* src, int dtype, size_t n) {
     if (dtype == VC_F32) HIPCHK(hipMemcpyAsync(dst, src, n * 4, hipMemcpyDeviceToDevice, m->st));
     else launch_bf16_to_f32(reinterpret_cast<const bf16_t*>(src), dst, n, m->st);
@@ -361,9 +398,9 @@ int place_tensor(vc_model* m, const std::string& raw_key, const void* src, int d
         const std::string r = rest;
         if (r == "input_layernorm.weight") { expect({D}); to_f32(m, L.in_norm, src, dtype, numel); }
         else if (r == "post_attention_layernorm.weight") { expect({D}); to_f32(m, L.post_norm, src, dtype, numel); }
-        else if (r == "self_attn.q_proj.weight") { expect({D, D}); to_bf16(m, L.qkv_w, src, dtype, numel); }
-        else if (r == "self_attn.k_proj.weight") { expect({D, D}); to_bf16(m, L.qkv_w + (size_t)D * D, src, dtype, numel); }
-        else if (r == "self_attn.v_proj.weight") { expect({D, D}); to_bf16(m, L.qkv_w + (size_t)2 * D * D, src, dtype, numel); }
+        else if (r == "self_attn.q_proj.weight") { expect({D, D}); to_bf16(m, L.qkv_w, 0, (size_t)3 * D * D, src, dtype, numel); }
+        else if (r == "self_attn.k_proj.weight") { expect({D, D}); to_bf16(m, L.qkv_w, (size_t)D * D, (size_t)3 * D * D, src, dtype, numel); }
+        else if (r == "self_attn.v_proj.weight") { expect({D, D}); to_bf16(m, L.qkv_w, (size_t)2 * D * D, (size_t)3 * D * D, src, dtype, numel); }
         else if (r == "self_attn.o_proj.weight") { expect({D, D}); to_bf16(m, L.o_w, src, dtype, numel); }
         else if (r == "mlp.gate_proj.weight") { expect({F, D}); to_bf16(m, L.gate_tmp, src, dtype, numel); }
         else if (r == "mlp.up_proj.weight") { expect({F, D}); to_bf16(m, L.up_tmp, src, dtype, numel); }
@@ -386,9 +423,17 @@ int place_tensor(vc_model* m, const std::string& raw_key, const void* src, int d
     else if (key == "vit.embeddings.patch_embedding.weight") {
         expect({Dv, m->Kpatch});
         m->stage2.ensure(numel * 2);
+        m->lo_of.erase(m->stage2.p);
         to_bf16(m, m->stage2.as<bf16_t>(), src, dtype, numel);
         HIPCHK(hipMemcpy2DAsync(m->vit_patch_w, (size_t)m->Kpad * 2, m->stage2.p, (size_t)m->Kpatch * 2,
                                 (size_t)m->Kpatch * 2, Dv, hipMemcpyDeviceToDevice, m->st));
+        if (auto it2 = m->lo_of.find(m->stage2.p); it2 != m->lo_of.end()) {   // the staged lo plane -> the padded [Dv, Kpad] layout
+            bf16_t* lo_pad = walloc<bf16_t>(m, (size_t)Dv * m->Kpad, true);
+            HIPCHK(hipMemcpy2DAsync(lo_pad, (size_t)m->Kpad * 2, it2->second, (size_t)m->Kpatch * 2, (size_t)m->Kpatch * 2, Dv,
+                                    hipMemcpyDeviceToDevice, m->st));
+            m->lo_of.erase(it2);
+            m->lo_of[m->vit_patch_w] = lo_pad;
+        }
     } else if (key == "vit.pre_layrnorm.weight") { expect({Dv}); to_f32(m, m->vit_pre_w, src, dtype, numel); }
     else if (key == "vit.pre_layrnorm.bias") { expect({Dv}); to_f32(m, m->vit_pre_b, src, dtype, numel); }
     else if (sscanf(key.c_str(), "vit.encoder.layers.%d.%127s", &layer, rest) == 2) {
@@ -399,9 +444,9 @@ int place_tensor(vc_model* m, const std::string& raw_key, const void* src, int d
         else if (r == "layer_norm1.bias") { expect({Dv}); to_f32(m, L.ln1_b, src, dtype, numel); }
         else if (r == "layer_norm2.weight") { expect({Dv}); to_f32(m, L.ln2_w, src, dtype, numel); }
         else if (r == "layer_norm2.bias") { expect({Dv}); to_f32(m, L.ln2_b, src, dtype, numel); }
-        else if (r == "self_attn.q_proj.weight") { expect({Dv, Dv}); to_bf16(m, L.qkv_w, src, dtype, numel); }
-        else if (r == "self_attn.k_proj.weight") { expect({Dv, Dv}); to_bf16(m, L.qkv_w + DD, src, dtype, numel); }
-        else if (r == "self_attn.v_proj.weight") { expect({Dv, Dv}); to_bf16(m, L.qkv_w + 2 * DD, src, dtype, numel); }
+        else if (r == "self_attn.q_proj.weight") { expect({Dv, Dv}); to_bf16(m, L.qkv_w, 0, 3 * DD, src, dtype, numel); }
+        else if (r == "self_attn.k_proj.weight") { expect({Dv, Dv}); to_bf16(m, L.qkv_w, DD, 3 * DD, src, dtype, numel); }
+        else if (r == "self_attn.v_proj.weight") { expect({Dv, Dv}); to_bf16(m, L.qkv_w, 2 * DD, 3 * DD, src, dtype, numel); }
         else if (r == "self_attn.q_proj.bias") { expect({Dv}); to_f32(m, L.qkv_b, src, dtype, numel); }
         else if (r == "self_attn.k_proj.bias") { expect({Dv}); to_f32(m, L.qkv_b + Dv, src, dtype, numel); }
         else if (r == "self_attn.v_proj.bias") { expect({Dv}); to_f32(m, L.qkv_b + 2 * Dv, src, dtype, numel); }
@@ -509,6 +554,10 @@ void gemm_split(vc_model* m, const bf16_t* A, const bf16_t* W, const float* bias
     GemmArgs a{A, W, bias, out, M, N, 2 * Kw, lda, Kw, ldo};
     a.kwrap = Kw / 64;
     a.split_out = split_out;
+    if (const bf16_t* Wl = lo_plane(m, W)) {   // an inexact checkpoint: a third K segment, a_hi . w_lo (gemm.hip w_koff)
+        a.K = 3 * Kw;
+        a.w_lo_off = (long long)(reinterpret_cast<const char*>(Wl) - reinterpret_cast<const char*>(W));
+    }
     apply_fold(a, fold);
     if ((long)((M + 255) / 256) * ((N + 255) / 256) > 256) {
         m->gemm_ws.ensure((size_t)64 << 20);
@@ -614,6 +663,7 @@ void gemv(vc_model* m, const LoopView& v, const bf16_t* X, const bf16_t* Wp, con
         a.sk_scratch_floats = sk_floats(m->c);
         a.sk_counters_n = sk_counters_n(m->c);
         a.stamp = next_stamp(v);
+        if (G) a.Wp_lo = lo_plane(m, Wp);   // split mode on an inexact checkpoint
         launch_gemv(a, epi, v.st);
     }
 }
@@ -864,6 +914,7 @@ void run_vit_and_adapters_split(vc_model* m, const PixSet& in, int pixels_on_dev
 void gemm32(vc_model* m, const float* A, const bf16_t* W, const float* bias, float* out, int M, int N, int K, int lda,
             int ldw, int ldo, int epi) {
     GemmF32Args a{A, W, bias, out, M, N, K, lda, ldw, ldo};
+    a.W_lo = lo_plane(m, W);
     launch_gemm_f32(a, epi, m->st);
 }
 
@@ -1457,6 +1508,7 @@ SelectArgs select_args(vc_model* m, const LoopView& v, const float* logits, int 
     a.next_tok = v.next_tok;
     a.out_ids = v.out_ids;
     a.embed = m->embed;
+    a.embed_lo = (m->precision || v.split_G) ? lo_plane(m, m->embed) : nullptr;   // strict / split on an inexact checkpoint: x = hi + lo
     a.x = v.x_dec;
     a.ssq = v.ssq;
     a.xg_w = m->llm[0].in_norm;
@@ -1759,7 +1811,7 @@ void do_prefill(vc_model* m, const int64_t* ids, int B, int T, const float* img,
             ensure_strict(m, B, m->capS);
         }
         launch_splice_f32(m->row_src.as<int>(), (int)(B * S), m->embed, m->s_feats.as<float>(), m->x.as<float>(), c.hidden,
-                          m->st);
+                          m->st, lo_plane(m, m->embed));
     } else {
         launch_splice(m->row_src.as<int>(), (int)(B * S), m->embed, m->feats.as<bf16_t>(), m->x.as<float>(), c.hidden, m->st);
     }
@@ -2119,6 +2171,15 @@ VC_API int vc_model_set_layer_limit(vc_model* m, int n_layers) {
     return VC_OK;
 }
 
+/* Number of loaded tensors whose fp32 source held values bf16 cannot represent (an fp16 / fp32 checkpoint; 0 for a bf16 one).
+ * Each keeps a bf16 lo plane: precision modes "strict" and "split" compute with hi + lo (the checkpoint's values to ~16 mantissa
+ * bits, exact for fp16), the bf16 fast path with the bf16-rounded weights alone. */
+VC_API int vc_model_inexact_tensors(vc_model* m) {
+    if (!m) return VC_ERR_INVALID;
+    const vc_model* r = m->root ? m->root : m;
+    return r->inexact_tensors;
+}
+
 VC_API int vc_model_finalize(vc_model* m) {
     if (!m) return VC_ERR_INVALID;
     GUARD_BEGIN
@@ -2144,21 +2205,56 @@ VC_API int vc_model_finalize(vc_model* m) {
         REQUIRE(D % 64 == 0 && F % 64 == 0, VC_ERR_INVALID, "W8A16 needs hidden and ffn sizes divisible by 64");
     if (m->weight_format == 2)
         REQUIRE(D % 128 == 0 && F % 128 == 0, VC_ERR_INVALID, "the fp8 prefill GEMM needs hidden and ffn sizes divisible by 128");
+    // lo planes of an inexact checkpoint (m->lo_of): interleaved / packed like their hi planes; the e4m3 weight formats re-round
+    // the decoder linears anyway, so those drop theirs
+    auto free_owned = [&](void* p) {
+        for (auto& o : m->owned)
+            if (o == p) { (void)hipFree(o); o = nullptr; }
+    };
+    auto drop_lo = [&](const void* hi) {
+        auto it = m->lo_of.find(hi);
+        if (it == m->lo_of.end()) return;
+        free_owned(it->second);
+        m->lo_of.erase(it);
+    };
+    auto pack_lo = [&](const bf16_t* W, const bf16_t* Wp, int N, int K) {   // the decode steps' packed copy of W's lo plane
+        auto it = m->lo_of.find(W);
+        if (it == m->lo_of.end()) return;
+        bf16_t* lp = walloc<bf16_t>(m, (size_t)N * K);
+        launch_pack_weight(it->second, lp, N, K, m->st);
+        m->lo_of[Wp] = lp;
+    };
     for (auto& L : m->llm) {
         launch_interleave_rows(L.gate_tmp, L.up_tmp, L.gu_w, F, D, m->st);
+        if (m->lo_of.count(L.gate_tmp) || m->lo_of.count(L.up_tmp)) {
+            for (bf16_t* t : {L.gate_tmp, L.up_tmp})
+                if (!m->lo_of.count(t)) m->lo_of[t] = walloc<bf16_t>(m, (size_t)F * D, true);
+            bf16_t* gu_lo = walloc<bf16_t>(m, (size_t)2 * F * D);
+            launch_interleave_rows(m->lo_of[L.gate_tmp], m->lo_of[L.up_tmp], gu_lo, F, D, m->st);
+            m->lo_of[L.gu_w] = gu_lo;
+        }
+        if (m->weight_format >= 1)
+            for (const bf16_t* w : {L.qkv_w, L.o_w, L.gu_w, L.down_w}) drop_lo(w);
         decode_copy(L.qkv_w, 3 * D, D, L.qkv_p, L.qkv_s, L.qkv_q);
         decode_copy(L.o_w, D, D, L.o_p, L.o_s, L.o_q);
         decode_copy(L.gu_w, 2 * F, D, L.gu_p, L.gu_s, L.gu_q);
         decode_copy(L.down_w, D, F, L.down_p, L.down_s, L.down_q);
+        if (m->weight_format == 0) {
+            pack_lo(L.qkv_w, L.qkv_p, 3 * D, D);
+            pack_lo(L.o_w, L.o_p, D, D);
+            pack_lo(L.gu_w, L.gu_p, 2 * F, D);
+            pack_lo(L.down_w, L.down_p, D, F);
+        }
     }
     m->lm_head_p = walloc<bf16_t>(m, (size_t)V * D);
     launch_pack_weight(m->lm_head, m->lm_head_p, V, D, m->st);
+    pack_lo(m->lm_head, m->lm_head_p, V, D);
     HIPCHK(hipStreamSynchronize(m->st));
-    // gate/up staging copies are no longer needed
+    // gate/up staging copies (and their lo planes) are no longer needed
     for (auto& L : m->llm) {
         for (bf16_t** t : {&L.gate_tmp, &L.up_tmp}) {
-            for (auto& o : m->owned)
-                if (o == *t) { (void)hipFree(o); o = nullptr; }
+            drop_lo(*t);
+            free_owned(*t);
             *t = nullptr;
         }
     }
@@ -2455,7 +2551,8 @@ VC_API int vc_decode_step(vc_model* m, const int32_t* tok, float* logits, int32_
             REQUIRE(tok[b] >= 0 && tok[b] < m->c.vocab, VC_ERR_INDEX, "index out of range in self (token id %d)", tok[b]);
         HIPCHK(hipMemcpyAsync(m->next_tok.p, tok, B * 4, hipMemcpyHostToDevice, m->st));
         launch_embed_tokens_ssq(m->next_tok.as<int>(), m->embed, m->x_dec.as<float>(), m->ssq.as<float>(), m->llm[0].in_norm,
-                                m->xg_dec.as<bf16_t>(), B, m->c.hidden, m->npart, m->st, session_view(m).split_G);
+                                m->xg_dec.as<bf16_t>(), B, m->c.hidden, m->npart, m->st, session_view(m).split_G,
+                                m->precision ? lo_plane(m, m->embed) : nullptr);
     }
     struct StepRequests {   // one-shot, also when the step fails
         vc_model* m;

@@ -107,9 +107,18 @@ VC_DEV void store_out(const GemmArgs& p, int m, int n, f32x4 v) {
     }
 }
 
-// k-tile of the WEIGHT operand for k-tile `kt` of the contraction: with GemmArgs::kwrap = K_w / BK the weight matrix is
-// contracted against both halves of a K-concatenated [hi | lo] activation row (K = 2 K_w), i.e. its k index wraps
-VC_DEV int wrap_kt(int kt, int kwrap) { return (kwrap > 0 && kt >= kwrap) ? kt - kwrap : kt; }
+// byte offset of the WEIGHT operand's k-tile (128 bytes = 64 bf16) for k-tile `kt` of the contraction: with GemmArgs::kwrap =
+// K_w / BK the weight matrix is contracted against both halves of a K-concatenated [hi | lo] activation row (K = 2 K_w), i.e. its
+// k index wraps; with GemmArgs::w_lo_off a third segment (k-tiles [2 kwrap, 3 kwrap)) takes the weight's lo plane against the
+// activation's hi plane (a_koff: the activation's k index wraps back to 0 there)
+VC_DEV long long w_koff(int kt, const GemmArgs& p) {
+    if (p.kwrap <= 0 || kt < p.kwrap) return (long long)kt * 128;
+    if (kt < 2 * p.kwrap) return (long long)(kt - p.kwrap) * 128;
+    return p.w_lo_off + (long long)(kt - 2 * p.kwrap) * 128;
+}
+VC_DEV long long a_koff(int kt, const GemmArgs& p) {
+    return (long long)((p.kwrap > 0 && kt >= 2 * p.kwrap) ? kt - 2 * p.kwrap : kt) * 128;
+}
 
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
@@ -137,8 +146,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     auto load_tile = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            rw[i] = ld16(w_src[i] + (size_t)wrap_kt(kt, p.kwrap) * (BK * 2));
-            ra[i] = ld16(a_src[i] + (size_t)kt * (BK * 2));
+            rw[i] = ld16(w_src[i] + w_koff(kt, p));
+            ra[i] = ld16(a_src[i] + a_koff(kt, p));
         }
     };
     auto store_tile = [&](int stage) {
@@ -240,9 +249,9 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_bf16_dma_kernel(GemmArgs p)
         char* ws = smem + stage * STAGE;
         char* as = ws + W_BYTES;
 #pragma unroll
-        for (int i = 0; i < WP; ++i) glds16(w_src[i] + (size_t)wrap_kt(kt, p.kwrap) * (BK * 2), ws + (i * NW + wave) * 1024);
+        for (int i = 0; i < WP; ++i) glds16(w_src[i] + w_koff(kt, p), ws + (i * NW + wave) * 1024);
 #pragma unroll
-        for (int i = 0; i < AP; ++i) glds16(a_src[i] + (size_t)kt * (BK * 2), as + (i * NW + wave) * 1024);
+        for (int i = 0; i < AP; ++i) glds16(a_src[i] + a_koff(kt, p), as + (i * NW + wave) * 1024);
     };
     f32x4 acc[FI][FJ];
 #pragma unroll
@@ -350,21 +359,22 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
             x_src[h][i] = reinterpret_cast<const char*>(p.W) + (size_t)min(n0 + h * 128 + row, p.N - 1) * p.ldw * ES + sw +
                           (KWRAP ? (size_t)0 : (size_t)kt_first * 128);
             y_src[h][i] = reinterpret_cast<const char*>(p.A) + (size_t)min(m0 + h * 128 + row, p.M - 1) * p.lda * ES + sw +
-                          (size_t)kt_first * 128;
+                          (KWRAP ? (size_t)0 : (size_t)kt_first * 128);
         }
     const int nk = (int)((long)(ks + 1) * nk_all / KS) - kt_first;  // k-tiles of this workgroup
     auto stage_x = [&](int h, int kt) {
         if (kt >= nk) return;
         char* dst = smem + (kt & 1) * TILE + (h ? SX1 : SX0) + wave * 1024;
-        const size_t wk = KWRAP ? (size_t)wrap_kt(kt_first + kt, p.kwrap) * 128 : (size_t)kt * 128;
+        const long long wk = KWRAP ? w_koff(kt_first + kt, p) : (long long)kt * 128;
         glds16(x_src[h][0] + wk, dst);
         glds16(x_src[h][1] + wk, dst + 8192);
     };
     auto stage_y = [&](int h, int kt) {
         if (kt >= nk) return;
         char* dst = smem + (kt & 1) * TILE + (h ? SY1 : SY0) + wave * 1024;
-        glds16(y_src[h][0] + (size_t)kt * 128, dst);
-        glds16(y_src[h][1] + (size_t)kt * 128, dst + 8192);
+        const long long ak = KWRAP ? a_koff(kt_first + kt, p) : (long long)kt * 128;
+        glds16(y_src[h][0] + ak, dst);
+        glds16(y_src[h][1] + ak, dst + 8192);
     };
     f32x4 acc[2][4][2][2];  // [x half][i][y half][j]
 #pragma unroll

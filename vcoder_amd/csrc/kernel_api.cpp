@@ -175,6 +175,16 @@ VCK_EXPORT void vck_gemm_f32(const float* A, const uint16_t* W, const float* bia
     GemmF32Args a{A, W, bias, out, M, N, K, lda, ldw, ldo};
     launch_gemm_f32(a, epi, S(stream));
 }
+/* ... with the lo plane of an inexact checkpoint's weight: w = W + W_lo */
+VCK_EXPORT void vck_gemm_f32_wlo(const float* A, const uint16_t* W, const uint16_t* W_lo, const float* bias, float* out, int M, int N,
+                                 int K, int lda, int ldw, int ldo, int epi, void* stream) {
+    GemmF32Args a{A, W, bias, out, M, N, K, lda, ldw, ldo};
+    a.W_lo = W_lo;
+    launch_gemm_f32(a, epi, S(stream));
+}
+VCK_EXPORT void vck_f32_to_bf16_planes(const float* in, uint16_t* hi, uint16_t* lo, uint64_t n, unsigned* inexact, void* stream) {
+    launch_f32_to_bf16_planes(in, hi, lo, (size_t)n, inexact, S(stream));
+}
 VCK_EXPORT void vck_attention_f32(const float* q, const float* k, const float* v, float* out, int B, int H, int Tq, int hd,
                                   int q_stride, int kv_stride, int causal, int Tk, const int* pos0_dev, float scale,
                                   void* stream) {
@@ -204,6 +214,31 @@ VCK_EXPORT void vck_gemv_split(const uint16_t* X, const void* Wp, const float* w
     GemvArgs a{};
     a.X = X; a.Wp = reinterpret_cast<const uint16_t*>(Wp); a.wscale = wscale; a.out = out; a.M = M; a.N = N; a.K = K; a.ldo = ldo;
     a.ssq_in = ssq_in; a.ssq_out = ssq_out; a.xg_w = xg_w; a.xg_out = xg_out; a.npart = npart; a.eps = eps;
+    a.split_rows = G;
+    launch_gemv(a, epi, S(stream));
+}
+/* ... with the lo plane of an inexact checkpoint's weight ([N, Kw] like W): a third K segment a_hi . w_lo (K = 3 Kw) */
+VCK_EXPORT void vck_gemm_split_wlo(const uint16_t* A, const uint16_t* W, const uint16_t* W_lo, const float* bias, void* out, int M,
+                                   int N, int Kw, int lda, int ldo, int epi, int split_out, float* ws, size_t ws_bytes, void* stream) {
+    GemmArgs a{A, W, bias, out, M, N, (W_lo ? 3 : 2) * Kw, lda, Kw, ldo};
+    a.kwrap = Kw / 64;
+    a.split_out = split_out;
+    if (W_lo) a.w_lo_off = (long long)(reinterpret_cast<const char*>(W_lo) - reinterpret_cast<const char*>(W));
+    a.ws = ws;
+    a.ws_bytes = ws_bytes;
+    launch_gemm(a, epi, S(stream));
+}
+/* the split decode GEMV (G > 0) with the packed lo plane of an inexact checkpoint's weight */
+VCK_EXPORT void vck_gemv_split_wlo(const uint16_t* X, const void* Wp, const void* Wp_lo, void* out, const float* ssq_in, float* ssq_out,
+                                   const float* xg_w, uint16_t* xg_out, int npart, float eps, float* sk_scratch,
+                                   unsigned long long sk_scratch_floats, unsigned* sk_counters, int sk_counters_n, int ksplit, int M,
+                                   int N, int K, int ldo, int epi, int G, void* stream) {
+    GemvArgs a{};
+    a.X = X; a.Wp = reinterpret_cast<const uint16_t*>(Wp); a.Wp_lo = reinterpret_cast<const uint16_t*>(Wp_lo); a.out = out;
+    a.M = M; a.N = N; a.K = K; a.ldo = ldo;
+    a.ssq_in = ssq_in; a.ssq_out = ssq_out; a.xg_w = xg_w; a.xg_out = xg_out; a.npart = npart; a.eps = eps;
+    a.sk_scratch = sk_scratch; a.sk_counters = sk_counters; a.ksplit = ksplit;
+    a.sk_scratch_floats = (size_t)sk_scratch_floats; a.sk_counters_n = sk_counters_n;
     a.split_rows = G;
     launch_gemv(a, epi, S(stream));
 }

@@ -47,6 +47,10 @@ struct GemmArgs {
     // hi at column n and lo = bf16(v - hi) at column split_out + n (EPI_SWIGLU: at n / 2)
     int kwrap;
     int split_out;
+    // ... with the lo plane of an inexact checkpoint's weight (w = bf16 hi + bf16 lo): w_lo_off != 0 is the BYTE offset from W to
+    // a second [N, ldw] plane and K = 3 * kwrap * 64 — a third K segment contracts the activation HI plane (the A k index wraps
+    // back to 0 there) against W_lo: a.w = a_hi.w_hi + a_lo.w_hi + a_hi.w_lo (the a_lo.w_lo term, 2^-16 of the product, is dropped)
+    long long w_lo_off;
     // RMSNorm folded across two GEMMs of a prefill, as in the decode steps (rmsnorm(x) . W^T = rstd * ((x * g) . W^T)):
     //  consumer: row_scale[m] (= rstd of row m; launch_rstd_from_partials) multiplies the accumulator before the epilogue; A is
     //            then the producer's xg rows;
@@ -107,6 +111,9 @@ struct GemvArgs {
     int sk_counters_n;
     // in-situ timing slot ([STAMP_WGS] x {start, end} wall-clock ticks, one entry per workgroup), or nullptr (vc_device.h stamp_begin)
     unsigned* stamp;
+    // the packed lo plane of an inexact checkpoint's weight (w = bf16 hi + bf16 lo; same layout as Wp), or nullptr.  Precision mode
+    // "split" on the workgroup-shared kernel only: out[m] = x_hi.w_hi + x_lo.w_hi + x_hi.w_lo
+    const bf16_t* Wp_lo;
 };
 void launch_gemv(const GemvArgs& a, int epilogue, hipStream_t s);
 // the decode GEMV of precision mode "split": 0 = per-wave rings (two weight passes of 16 rows), -1 / 1 = the workgroup-shared form
@@ -252,7 +259,8 @@ void launch_attention_decode_fused(const AttnDecodeFusedArgs& a, hipStream_t s);
 // The table is the host-side splice plan of prepare_inputs_labels_for_multimodal (vcoder_ds_llava_arch.py:175-305).
 void launch_splice(const int* row_src, int nrows, const bf16_t* embed, const bf16_t* feats, float* x, int D,
                    hipStream_t s);
-void launch_embed_tokens(const int* tok, const bf16_t* embed, float* x, int B, int D, hipStream_t s);
+// embed_lo (here and below): the lo plane of an inexact checkpoint's table (x = hi + lo), or nullptr
+void launch_embed_tokens(const int* tok, const bf16_t* embed, float* x, int B, int D, hipStream_t s, const bf16_t* embed_lo = nullptr);
 
 // ---- greedy select (K19) ----------------------------------------------------------------------
 // logits fp32 [B,V] -> next token (lowest index on ties); EOS/pad bookkeeping; appends to out_ids[b*max_new+step]
@@ -317,6 +325,7 @@ struct SelectArgs {
     int row0;             // workgroup i handles state row row0 + i (rows / next_tok / x / ssq / xg) with logits row i: rows
                           // that join a running loop are selected from their prefill's own logits buffer
     int xg_G;             // precision mode "split" (0 = off): xg holds stacked groups of G hi rows + G lo rows
+    const bf16_t* embed_lo;  // lo plane of an inexact checkpoint's embedding table (strict / split: x = hi + lo), or nullptr
 };
 void launch_select_embed(const SelectArgs& a, hipStream_t s);
 // in-situ timing of the decode-step launches (GemvArgs::stamp): slot j = [STAMP_WGS] x {start, end} u32 ticks (zero = not stamped);
@@ -328,7 +337,7 @@ constexpr size_t STAMP_SLOT_WORDS = 2 * 2048;   // == 2 * STAMP_WGS (vc_device.h
 void launch_stamp_accumulate(unsigned* stamps, int n, int layers, unsigned long long* acc, unsigned* scratch, hipStream_t s);
 // embedding + sum-of-squares partials for tokens supplied by the host (vc_decode_step with explicit tokens)
 void launch_embed_tokens_ssq(const int* tok, const bf16_t* embed, float* x, float* ssq, const float* xg_w, bf16_t* xg, int B, int D, int npart,
-                             hipStream_t s, int xg_G = 0);
+                             hipStream_t s, int xg_G = 0, const bf16_t* embed_lo = nullptr);
 void launch_advance(int* step_dev, int* pos_dev, int* ctx_dev, hipStream_t s);
 // test hook: u[i] = the sampler's uniform for hash value h[i], gumbel[i] = -log(-log(u[i]))
 void launch_uniform_probe(const uint32_t* h, float* u, float* gumbel, int n, hipStream_t s);
@@ -341,6 +350,7 @@ struct GemmF32Args {
     float* out;         // fp32; epilogue ids reuse GemmEpilogue: EPI_F32 (also for EPI_BF16), *_QGELU, *_GELU, RESID, SWIGLU
     int M, N, K;
     int lda, ldw, ldo;
+    const bf16_t* W_lo; // [N, ldw] lo plane of an inexact checkpoint (w = bf16 hi + bf16 lo), or nullptr
 };
 void launch_gemm_f32(const GemmF32Args& a, int epilogue, hipStream_t s);
 struct AttnF32Args {
@@ -396,7 +406,8 @@ void launch_rmsnorm_f32(const float* x, const int* row_idx, const float* w, floa
                         hipStream_t s);
 void launch_im2col_f32(const float* pixels, float* cols, int n_img, int image, int patch, hipStream_t s);
 void launch_select_rows_f32(const float* x, float* y, int n_img, int T, int skip, int D, hipStream_t s);
-void launch_splice_f32(const int* row_src, int nrows, const bf16_t* embed, const float* feats, float* x, int D, hipStream_t s);
+void launch_splice_f32(const int* row_src, int nrows, const bf16_t* embed, const float* feats, float* x, int D, hipStream_t s,
+                       const bf16_t* embed_lo = nullptr);
 
 // ---- device-side image preprocessing (preprocess.hip) --------------------------------------------------------------
 void launch_pad_square(const uint8_t* src, int h, int w, uint8_t* dst, int side, int ox, int oy, const int fill[3],
@@ -415,6 +426,9 @@ void launch_row_sum(const float* x, size_t n_per_row, int rows, float* out, hipS
 void launch_kv_permute(void* cache, void* tmp, const int* perm, int rows, int H, size_t cap_row_bytes, size_t live_row_bytes,
                        hipStream_t s);
 void launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
+// hi = bf16(in), lo = bf16(in - hi) (nullptr: skipped), *inexact = 1 if any in != hi (checkpoints bf16 cannot hold: the weight lo
+// planes of the strict / split precision modes)
+void launch_f32_to_bf16_planes(const float* in, bf16_t* hi, bf16_t* lo, size_t n, unsigned* inexact, hipStream_t s);
 void launch_bf16_to_f32(const bf16_t* in, float* out, size_t n, hipStream_t s);
 
 }  // namespace vc

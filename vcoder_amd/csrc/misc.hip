@@ -31,7 +31,8 @@ void launch_splice(const int* row_src, int nrows, const bf16_t* embed, const bf1
     VC_LAUNCH(splice_kernel, dim3((nrows + 3) / 4), dim3(256), 0, s, row_src, nrows, embed, feats, x, D);
 }
 
-__global__ __launch_bounds__(256) void embed_tokens_kernel(const int* tok, const bf16_t* embed, float* x, int B, int D) {
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const int* tok, const bf16_t* embed, float* x, int B, int D,
+                                                           const bf16_t* embed_lo) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B) return;
     const int lane = threadIdx.x & 63;
@@ -39,12 +40,19 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(const int* tok, const
     float* dp = x + (size_t)row * D;
     for (int c = lane; c < D / 8; c += 64) {
         const u32x4 v = ld16(sp + c * 8);
-        st16f(dp + c * 8, f32x4{bf2f_lo(v[0]), bf2f_hi(v[0]), bf2f_lo(v[1]), bf2f_hi(v[1])});
-        st16f(dp + c * 8 + 4, f32x4{bf2f_lo(v[2]), bf2f_hi(v[2]), bf2f_lo(v[3]), bf2f_hi(v[3])});
+        f32x4 a = {bf2f_lo(v[0]), bf2f_hi(v[0]), bf2f_lo(v[1]), bf2f_hi(v[1])};
+        f32x4 b = {bf2f_lo(v[2]), bf2f_hi(v[2]), bf2f_lo(v[3]), bf2f_hi(v[3])};
+        if (embed_lo != nullptr) {   // the lo plane of an inexact checkpoint (strict / split modes)
+            const u32x4 w = ld16(embed_lo + (size_t)tok[row] * D + c * 8);
+            a = a + f32x4{bf2f_lo(w[0]), bf2f_hi(w[0]), bf2f_lo(w[1]), bf2f_hi(w[1])};
+            b = b + f32x4{bf2f_lo(w[2]), bf2f_hi(w[2]), bf2f_lo(w[3]), bf2f_hi(w[3])};
+        }
+        st16f(dp + c * 8, a);
+        st16f(dp + c * 8 + 4, b);
     }
 }
-void launch_embed_tokens(const int* tok, const bf16_t* embed, float* x, int B, int D, hipStream_t s) {
-    VC_LAUNCH(embed_tokens_kernel, dim3((B + 3) / 4), dim3(256), 0, s, tok, embed, x, B, D);
+void launch_embed_tokens(const int* tok, const bf16_t* embed, float* x, int B, int D, hipStream_t s, const bf16_t* embed_lo) {
+    VC_LAUNCH(embed_tokens_kernel, dim3((B + 3) / 4), dim3(256), 0, s, tok, embed, x, B, D, embed_lo);
 }
 
 // ---- greedy select: one workgroup per batch row ------------------------------------------------------
@@ -170,6 +178,23 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* in, bf16_
 }
 __global__ __launch_bounds__(256) void bf16_to_f32_kernel(const bf16_t* in, float* out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = bf2f(in[i]);
+}
+// checkpoint values that bf16 cannot hold (an fp16 / fp32 checkpoint): hi = bf16(x), lo = bf16(x - hi) (x = hi + lo to ~16 mantissa
+// bits; exact for fp16 values), *inexact |= any x != hi.  lo == nullptr: hi and the flag only.
+__global__ __launch_bounds__(256) void f32_to_bf16_planes_kernel(const float* in, bf16_t* hi, bf16_t* lo, size_t n, unsigned* inexact) {
+    bool any = false;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float x = in[i];
+        const bf16_t h = f2bf(x);
+        const float r = x - bf2f(h);
+        hi[i] = h;
+        if (lo != nullptr) lo[i] = f2bf(r);
+        any = any || r != 0.f;
+    }
+    if (any && inexact != nullptr) *inexact = 1u;   // (every writer stores the same value)
+}
+void launch_f32_to_bf16_planes(const float* in, bf16_t* hi, bf16_t* lo, size_t n, unsigned* inexact, hipStream_t s) {
+    VC_LAUNCH(f32_to_bf16_planes_kernel, dim3(grid_for(n)), dim3(256), 0, s, in, hi, lo, n, inexact);
 }
 void launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s) {
     VC_LAUNCH(f32_to_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, s, in, out, n);

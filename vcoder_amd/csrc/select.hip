@@ -90,13 +90,19 @@ VC_DEV void block_argmax(float& v, int& i, BlockRed& r, int lane, int wave) {
 
 // bf16 embedding row -> fp32 residual row + sum-of-squares partials + xg = bf16(x * g) (the first GEMV's operand)
 // xg_lo != nullptr (precision mode "split"): additionally the lo row bf16(x * g - xg) of the stacked hi / lo group
+// sp_lo != nullptr: the lo plane of an inexact checkpoint's table row (x = hi + lo; split mode)
 VC_DEV void embed_row_ssq(const bf16_t* sp, float* dp, float* ssq_row, const float* gw, bf16_t* xg, int D, int npart,
-                          int lane, bf16_t* xg_lo = nullptr) {
+                          int lane, bf16_t* xg_lo = nullptr, const bf16_t* sp_lo = nullptr) {
     float ss = 0.f;
     for (int c = lane; c < D / 8; c += 64) {
         const u32x4 v = ld16(sp + c * 8);
-        const f32x4 a = {bf2f_lo(v[0]), bf2f_hi(v[0]), bf2f_lo(v[1]), bf2f_hi(v[1])};
-        const f32x4 b = {bf2f_lo(v[2]), bf2f_hi(v[2]), bf2f_lo(v[3]), bf2f_hi(v[3])};
+        f32x4 a = {bf2f_lo(v[0]), bf2f_hi(v[0]), bf2f_lo(v[1]), bf2f_hi(v[1])};
+        f32x4 b = {bf2f_lo(v[2]), bf2f_hi(v[2]), bf2f_lo(v[3]), bf2f_hi(v[3])};
+        if (sp_lo != nullptr) {
+            const u32x4 w = ld16(sp_lo + c * 8);
+            a = a + f32x4{bf2f_lo(w[0]), bf2f_hi(w[0]), bf2f_lo(w[1]), bf2f_hi(w[1])};
+            b = b + f32x4{bf2f_lo(w[2]), bf2f_hi(w[2]), bf2f_lo(w[3]), bf2f_hi(w[3])};
+        }
         st16f(dp + c * 8, a);
         st16f(dp + c * 8 + 4, b);
         const f32x4 g0 = ld16f(gw + c * 8), g1 = ld16f(gw + c * 8 + 4);
@@ -241,7 +247,8 @@ __global__ __launch_bounds__(1024) void select_embed_kernel(SelectArgs p) {
         const int G = p.xg_G;  // split mode: row r -> hi at row (r / G) * 2G + r % G of xg, lo G rows further
         const size_t xrow = G ? (size_t)(r / G) * 2 * G + r % G : (size_t)r;
         embed_row_ssq(p.embed + (size_t)tok * p.D, p.x + (size_t)r * p.D, p.ssq + (size_t)r * p.npart, p.xg_w,
-                      p.xg + xrow * p.D, p.D, p.npart, lane, G ? p.xg + (xrow + G) * p.D : nullptr);
+                      p.xg + xrow * p.D, p.D, p.npart, lane, G ? p.xg + (xrow + G) * p.D : nullptr,
+                      p.embed_lo ? p.embed_lo + (size_t)tok * p.D : nullptr);
     }
 }
 
@@ -364,16 +371,17 @@ void launch_uniform_probe(const uint32_t* h, float* u, float* gumbel, int n, hip
 
 // embedding + sum-of-squares partials for tokens supplied by the host (vc_decode_step with explicit tokens)
 __global__ __launch_bounds__(256) void embed_tokens_ssq_kernel(const int* tok, const bf16_t* embed, float* x, float* ssq,
-                                                               const float* xg_w, bf16_t* xg, int B, int D, int npart, int G) {
+                                                               const float* xg_w, bf16_t* xg, int B, int D, int npart, int G,
+                                                               const bf16_t* embed_lo) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B) return;
     const size_t xrow = G ? (size_t)(row / G) * 2 * G + row % G : (size_t)row;
     embed_row_ssq(embed + (size_t)tok[row] * D, x + (size_t)row * D, ssq + (size_t)row * npart, xg_w, xg + xrow * D, D,
-                  npart, threadIdx.x & 63, G ? xg + (xrow + G) * D : nullptr);
+                  npart, threadIdx.x & 63, G ? xg + (xrow + G) * D : nullptr, embed_lo ? embed_lo + (size_t)tok[row] * D : nullptr);
 }
 void launch_embed_tokens_ssq(const int* tok, const bf16_t* embed, float* x, float* ssq, const float* xg_w, bf16_t* xg, int B,
-                             int D, int npart, hipStream_t s, int xg_G) {
-    VC_LAUNCH(embed_tokens_ssq_kernel, dim3((B + 3) / 4), dim3(256), 0, s, tok, embed, x, ssq, xg_w, xg, B, D, npart, xg_G);
+                             int D, int npart, hipStream_t s, int xg_G, const bf16_t* embed_lo) {
+    VC_LAUNCH(embed_tokens_ssq_kernel, dim3((B + 3) / 4), dim3(256), 0, s, tok, embed, x, ssq, xg_w, xg, B, D, npart, xg_G, embed_lo);
 }
 
 }  // namespace vc

@@ -36,7 +36,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int k = k0 + lc + e;
-            ws[lr][lc + e] = k < p.K ? bf2f(p.W[(size_t)wr * p.ldw + k]) : 0.f;
+            float w = k < p.K ? bf2f(p.W[(size_t)wr * p.ldw + k]) : 0.f;
+            if (p.W_lo != nullptr && k < p.K) w += bf2f(p.W_lo[(size_t)wr * p.ldw + k]);   // inexact checkpoint: w = hi + lo
+            ws[lr][lc + e] = w;
             as[lr][lc + e] = k < p.K ? p.A[(size_t)ar * p.lda + k] : 0.f;
         }
         __syncthreads();
@@ -302,18 +304,21 @@ void launch_select_rows_f32(const float* x, float* y, int n_img, int T, int skip
 
 // splice for the strict path: feature rows are fp32
 __global__ __launch_bounds__(256) void splice_f32_kernel(const int* row_src, int nrows, const bf16_t* embed, const float* feats,
-                                                         float* x, int D) {
+                                                         float* x, int D, const bf16_t* embed_lo) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= nrows) return;
     const int lane = threadIdx.x & 63;
     const int kind = row_src[2 * row], src = row_src[2 * row + 1];
     float* dp = x + (size_t)row * D;
-    for (int c = lane; c < D; c += 64)
-        dp[c] = kind == 0 ? bf2f(embed[(size_t)src * D + c]) : kind == 1 ? feats[(size_t)src * D + c] : 0.f;
+    for (int c = lane; c < D; c += 64) {
+        float v = kind == 0 ? bf2f(embed[(size_t)src * D + c]) : kind == 1 ? feats[(size_t)src * D + c] : 0.f;
+        if (kind == 0 && embed_lo != nullptr) v += bf2f(embed_lo[(size_t)src * D + c]);
+        dp[c] = v;
+    }
 }
 void launch_splice_f32(const int* row_src, int nrows, const bf16_t* embed, const float* feats, float* x, int D,
-                       hipStream_t s) {
-    VC_LAUNCH(splice_f32_kernel, dim3((nrows + 3) / 4), dim3(256), 0, s, row_src, nrows, embed, feats, x, D);
+                       hipStream_t s, const bf16_t* embed_lo) {
+    VC_LAUNCH(splice_f32_kernel, dim3((nrows + 3) / 4), dim3(256), 0, s, row_src, nrows, embed, feats, x, D, embed_lo);
 }
 
 }  // namespace vc

@@ -167,6 +167,11 @@ class HipEngine:
                                                      out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def inexact_tensors(self) -> int:
+        """loaded tensors whose values bf16 cannot hold (an fp16 / fp32 checkpoint): each keeps a bf16 lo plane that the 'strict' and
+        'split' precision modes add back (w = hi + lo); the bf16 fast path runs on the rounded weights (vc_model_inexact_tensors)"""
+        return self._check(self.lib.vc_model_inexact_tensors(self._model))
+
     def finalize(self):
         self._check(self.lib.vc_model_finalize(self._model))
         self.finalized = True

@@ -162,6 +162,15 @@ class _HipCausalLMBase:
 
     def finalize_weights(self):
         self.engine.finalize()
+        # tensors whose checkpoint values bf16 cannot hold (an fp16 LLM / fp32 CLIP tower, the reference's own dtypes): the engine
+        # kept a lo plane for each; the bf16 fast path computes with the rounded weights, 'strict' / 'split' with hi + lo
+        self.inexact_tensors = self.engine.inexact_tensors()
+        if self.inexact_tensors:
+            import logging
+
+            logging.getLogger("vcoder_amd").info(
+                "%d checkpoint tensors are not bf16-representable: the bf16 fast path rounds them to bf16; precision modes "
+                "'split' / 'strict' compute with bf16 hi + lo planes (the checkpoint's values to ~16 mantissa bits)", self.inexact_tensors)
         tower = self.get_vision_tower()
         if tower is not None:
             tower.is_loaded = True

@@ -74,11 +74,14 @@ def from_bf16_bits(b: np.ndarray) -> np.ndarray:
     return (b.astype(np.uint32) << np.uint32(16)).view(np.float32)
 
 
-def synth_tensor(name: str, shape: Tuple[int, ...], seed: int, offset: float, halfwidth: float) -> np.ndarray:
+def synth_tensor(name: str, shape: Tuple[int, ...], seed: int, offset: float, halfwidth: float, rounding: str = "bf16") -> np.ndarray:
     """value[i] = bf16( offset + (u24[i] - 8388607.5) * (halfwidth / 8388608) ), fp32 array.
 
     (u24 - 8388607.5) is exact in fp32; the product and the sum are one IEEE fp32 op each, computed
     without contraction both here and in the device kernel (which uses __fmul_rn / __fadd_rn).
+
+    rounding: "bf16" (default: what the device-side generator produces), "fp16" (the value an fp16 checkpoint holds: 11
+    significant bits, NOT bf16-representable in general) or "fp32" (unrounded) — see synth_state_dict(dtypes="reference").
     """
     n = int(np.prod(shape)) if len(shape) else 1
     idx = np.arange(n, dtype=np.uint32)
@@ -86,6 +89,10 @@ def synth_tensor(name: str, shape: Tuple[int, ...], seed: int, offset: float, ha
     v = (u - np.float32(8388607.5)) * np.float32(halfwidth / 8388608.0)
     if offset != 0.0:
         v = v + np.float32(offset)
+    if rounding == "fp32":
+        return v.reshape(shape)
+    if rounding == "fp16":
+        return v.astype(np.float16).astype(np.float32).reshape(shape)
     return round_to_bf16(v).reshape(shape)
 
 
@@ -181,12 +188,20 @@ def projector_depth(ptype: str) -> int:
     raise ValueError(f"Unknown projector type: {ptype}")
 
 
-def synth_state_dict(cfg, seed: int = 42, only_prefix: str | None = None) -> Dict[str, np.ndarray]:
+def synth_state_dict(cfg, seed: int = 42, only_prefix: str | None = None, dtypes: str = "bf16") -> Dict[str, np.ndarray]:
+    """dtypes="bf16": every value bf16-representable (the default checkpoint of the tests and the benchmark).
+    dtypes="reference": the value classes of the reference's own checkpoints — the LLM, its head, embeddings and the projectors
+    fp16-valued (model/builder.py:25-40 loads them with torch_dtype=float16), the CLIP tower fp32-valued (the hub checkpoint,
+    multimodal_encoder/clip_encoder.py:22-27) — which bf16 cannot hold: vc_model_inexact_tensors() > 0, and the strict / split
+    precision modes must add the lo planes back to stay within 1e-3 of an fp32 oracle run on THESE values."""
     out = {}
     for key, shape, off, hw in tensor_specs(cfg):
         if only_prefix is not None and not key.startswith(only_prefix):
             continue
-        out[key] = synth_tensor(key, shape, seed, off, hw)
+        rounding = "bf16"
+        if dtypes == "reference":
+            rounding = "fp32" if "vision_tower" in key else "fp16"
+        out[key] = synth_tensor(key, shape, seed, off, hw, rounding)
     return out
 
 
