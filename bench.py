@@ -637,7 +637,7 @@ def main():
                         "achieved": byts / (us * 1e-6) / 1e9, "frac": byts / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "by_rows": by_rows}
             n_steps_pool = sum(step_mix)
             sum_ctx = (N_new - 1) * (S_prompt + 1) + (N_new - 1) * (N_new - 2) / 2.0     # keys read by one row over its cached steps
-            kv_es = 1.0 if args.weights == "fp8" and os.environ.get("VC_FP8_KV", "1") != "0" else 2.0
+            kv_es = 1.0 if args.weights == "fp8" and getattr(eng, "fp8_kv", True) else 2.0
             att_bytes = args.steps * B * 2.0 * kv_es * D_ * sum_ctx * L_                 # every request of the timed region, all layers
             sg = situ(("qkv", "o_proj", "gate_up", "down", "lm_head"))
             sa = situ(("attention",), att_bytes)

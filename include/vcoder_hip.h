@@ -76,6 +76,8 @@ int vc_model_load_tensor(vc_model* m, const char* hf_key, const void* host_ptr, 
 int vc_model_synth_tensor(vc_model* m, const char* hf_key, const int64_t* shape, int ndim, uint32_t tensor_seed,
                           float offset, float halfwidth);
 /* after the last tensor: fuses QKV / interleaves gate-up / packs decode copies; fails listing a missing key */
+/* weight format 2 ("fp8"): KV cache of the decode steps in e4m3 (default 1) or bf16 (0).  Before vc_model_finalize. */
+int vc_model_set_fp8_kv(vc_model* m, int on);
 int vc_model_finalize(vc_model* m);
 /* Number of loaded tensors whose fp32 source held values bf16 cannot represent — the reference's own checkpoints: an fp16 LLM
  * (model/builder.py:25-40, torch_dtype=float16) and an fp32 CLIP hub checkpoint (multimodal_encoder/clip_encoder.py:22-27).  Every

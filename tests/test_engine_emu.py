@@ -63,6 +63,17 @@ def test_layers_teacher_forced(emu_lib, fmt):
     print(fmt, r)
 
 
+@pytest.mark.parametrize("fmt", ["w8a16", "fp8"])
+def test_layers_teacher_forced_with_massive_activation_channels(emu_lib, fmt):
+    """the same with three hidden channels of the residual stream 300 x the rest (what trained LLaMA-family checkpoints carry):
+    a token row's e4m3 scale is then set by channels without information; device vs the oracle quantising the same rows, relative
+    to the layer's update"""
+    from vcoder_amd import config as vcfg
+
+    r = e2e_cases.check_layers_teacher_forced(vcfg.tiny("vcoder_ds"), 23, fmt, layers=(0, 1), B=2, S=70, lib=emu_lib, outlier_gain=300.0)
+    print(fmt, r)
+
+
 @pytest.mark.parametrize("mode", ["bf16", "strict", "split"])
 def test_padded_batch_attention_mask(emu_lib, mode):
     """a 2-D attention_mask that hides positions (right- and left-padded rows) against the live reference's fixture: masked

@@ -707,7 +707,7 @@ def test_beam_search_equals_hf_generate(model):
                 if 0 < top_k < V:
                     w = w.masked_fill(w < torch.topk(w, top_k)[0][..., -1, None], float("-inf"))
                 if top_p < 1.0:
-                    w = lm._top_p_filter(w, top_p)
+                    w = lm._top_p_filter(w, top_p, min_tokens_to_keep=2)   # 4.31: TopPLogitsWarper(min_tokens_to_keep=2) for beams
                 flat = w.view(B, nb * V)
                 draw = torch.multinomial(torch.softmax(flat, -1), 2 * nb, generator=gen)
                 sc, order = torch.sort(torch.gather(flat, -1, draw), descending=True, dim=1)
@@ -724,6 +724,21 @@ def test_beam_search_equals_hf_generate(model):
                                  max_new_tokens=5, eos_token_id=-1, generator=torch.Generator().manual_seed(seed),
                                  length_penalty=0.0)
             assert torch.equal(got, want), (nb, temp, got.tolist(), want.tolist())
+        # a list of EOS ids (HF accepts int or list; BeamSearchScorer tests membership): same result as the single id when the
+        # second id never occurs, and both ids terminate
+        one = model.generate(ids, images=None, num_beams=3, eos_token_id=eos_tok, **kw)
+        two = model.generate(ids, images=None, num_beams=3, eos_token_id=[eos_tok, cfg.vocab_size - 1], **kw)
+        assert torch.equal(one, two)
+        other = int(free[1, T + 1])
+        both = model.generate(ids, images=None, num_beams=3, eos_token_id=[eos_tok, other], **kw)
+        for row in both[:, T:].tolist():
+            hits = [i for i, v in enumerate(row) if v in (eos_tok, other)]
+            # a finished hypothesis is closed with eos_token_id[0] (HF's finalize), whichever id ended it; pads behind it
+            assert not hits or all(v == 0 for v in row[hits[0] + 1:]), row
+        # a top_p so tight that fewer than 2n continuations survive at step 0 (only beam 0 is alive): must not raise
+        tight = model.generate(ids, images=None, num_beams=3, do_sample=True, top_p=0.01, temperature=0.1, max_new_tokens=4,
+                               eos_token_id=-1, seed=2)
+        assert tuple(tight.shape) == (2, T + 4)
         a = model.generate(ids, images=None, num_beams=2, do_sample=True, max_new_tokens=5, eos_token_id=-1, seed=5)
         b = model.generate(ids, images=None, num_beams=2, do_sample=True, max_new_tokens=5, eos_token_id=-1, seed=5)
         c = model.generate(ids, images=None, num_beams=2, do_sample=True, max_new_tokens=5, eos_token_id=-1, seed=6)

@@ -233,6 +233,7 @@ struct vc_model {
     int graph_rows = 0;
     struct vc_pool* pool = nullptr;  // the root model's shared decode pool (created on first use; sessions point at it)
     bool pool_profile = false;       // root model: the pool's step graphs carry in-situ timing stamps (vc_pool_profile)
+    bool fp8_kv = true;              // weight format 2: the KV cache of the bf16-step modes in e4m3 (vc_model_set_fp8_kv)
     vc_model* root = nullptr;        // the model that owns the weights (itself for a root)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float t_encode = 0, t_prefill = 0, t_decode = 0;
@@ -585,13 +586,12 @@ inline int split_kv_es() {
 }
 
 // the fp8 weight format (2) keeps its KV cache in e4m3 as well (1 byte per element: at 13b the pooled decode attention reads 2.6x
-// the bytes of the e4m3 weights otherwise); VC_FP8_KV=0 keeps bf16 rows
-inline bool fp8_kv_on() {
-    static const bool on = !(getenv("VC_FP8_KV") && atoi(getenv("VC_FP8_KV")) == 0);
-    return on;
-}
+// the bytes of the e4m3 weights otherwise); vc_model_set_fp8_kv(m, 0) keeps bf16 rows (root model's setting, before finalize)
 // bytes per KV element of the bf16-step modes (precision 0) of a model
-inline int step_kv_es(const vc_model* m) { return (m->weight_format == 2 && fp8_kv_on()) ? 1 : 2; }
+inline int step_kv_es(const vc_model* m) {
+    const vc_model* r = m->root ? m->root : m;
+    return (r->weight_format == 2 && r->fp8_kv) ? 1 : 2;
+}
 
 // Everything one decode step touches besides the weights: the buffers of a session's own loop or of the shared pool.
 struct LoopView {
@@ -1551,8 +1551,6 @@ void enqueue_decode_step_diag(vc_model* m, const LoopView& v, int nrows, int pos
                                    v.rows + RS_ACTIVE, v.split_G ? (v.es == 3 ? 2 : 1) : (v.es == 1 ? 3 : 0), v.split_G, v.kmask, v.kmask_stride};
             launch_attention_decode_fused(da, v.st);
             if (m->attn_out) {
-                REQUIRE(v.es != 1, VC_ERR_INVALID, "output_attentions of a cached decode step is not available with the e4m3 KV cache "
-                        "of the fp8 weight format (VC_FP8_KV=0 keeps bf16 rows)");
                 m->attn_q.ensure((size_t)nrows * c.hidden * 4);
                 launch_rope_q_decode(v.qkv_dec, v.split_G != 0, m->attn_q.as<float>(), nrows, c.heads, m->hd, pos, m->rope_cos, m->rope_sin,
                                      v.split_G == 0, v.st);
@@ -1560,6 +1558,7 @@ void enqueue_decode_step_diag(vc_model* m, const LoopView& v, int nrows, int pos
                 pa.q32 = m->attn_q.as<float>();
                 if (v.split_G && v.es == 3) pa.k24 = kcache(v, m, l);
                 else if (v.split_G) pa.k32 = reinterpret_cast<const float*>(kcache(v, m, l));
+                else if (v.es == 1) pa.k8 = reinterpret_cast<const uint8_t*>(kcache(v, m, l));   // the fp8 weight format's e4m3 rows
                 else pa.k_hi = kcache(v, m, l);
                 pa.q_stride = 1;
                 pa.kv_stride = v.capS;
@@ -2158,6 +2157,15 @@ VC_API int vc_model_set_weight_format(vc_model* m, int fmt) {
     if (!m || fmt < 0 || fmt > 2) return VC_ERR_INVALID;
     if (m->finalized) return VC_ERR_STATE;
     m->weight_format = fmt;
+    return VC_OK;
+}
+
+/* Weight format 2 ("fp8") keeps the KV cache of its decode steps in e4m3 as well (1 byte per element, unscaled, saturating at 448;
+ * default on).  on = 0: bf16 rows, as the other formats.  Before vc_model_finalize. */
+VC_API int vc_model_set_fp8_kv(vc_model* m, int on) {
+    if (!m) return VC_ERR_INVALID;
+    if (m->finalized) return VC_ERR_STATE;
+    m->fp8_kv = on != 0;
     return VC_OK;
 }
 

@@ -384,6 +384,7 @@ struct AttnProbsArgs {
     int mask_stride;
     int Tk;                // key columns of an output row (0: T — the prefill form)
     int q_pos0;            // position of query 0: query t sees keys 0 .. q_pos0 + t (a cached decode step: T = 1, q_pos0 = its position)
+    const uint8_t* k8;     // e4m3 cache rows [B,H,kv_stride,hd] (the fp8 weight format's KV), or nullptr
 };
 void launch_attn_probs(const AttnProbsArgs& a, hipStream_t s);
 // q of ONE new token per row, rotated to position `pos`, for launch_attn_probs on a cached decode step: qkv rows [B, 3 H hd] (bf16, or

@@ -178,6 +178,9 @@ __global__ __launch_bounds__(64) void attn_probs_kernel(AttnProbsArgs p) {
         float s = 0.f;
         if (p.k32) {
             for (int d = 0; d < p.hd; ++d) s = fmaf(qs[d], p.k32[ko + d], s);
+        } else if (p.k8 != nullptr) {   // e4m3 cache rows (the fp8 weight format's KV)
+            const uint8_t* row = p.k8 + (bh * p.kv_stride + key) * (size_t)p.hd;
+            for (int d = 0; d < p.hd; ++d) s = fmaf(qs[d], fp82f_sw(row[d]), s);
         } else if (p.k_hi == nullptr && p.k24 != nullptr) {
             const char* row = reinterpret_cast<const char*>(p.k24) + (bh * p.kv_stride + key) * (size_t)(3 * p.hd);
             const uint16_t* hi = reinterpret_cast<const uint16_t*>(row);

@@ -154,6 +154,11 @@ class HipEngine:
         self._check(self.lib.vc_model_set_weight_format(self._model, code))
         self.weight_format = fmt
 
+    def set_fp8_kv(self, on: bool):
+        """'fp8' weight format: e4m3 KV cache for the decode steps (default) or bf16 rows.  Before finalize()."""
+        self._check(self.lib.vc_model_set_fp8_kv(self._model, 1 if on else 0))
+        self.fp8_kv = bool(on)
+
     def set_layer_limit(self, n_layers: int):
         """parity diagnostic: prefills evaluate only the first n decoder layers (0 = all)"""
         self._check(self.lib.vc_model_set_layer_limit(self._model, int(n_layers)))

@@ -456,7 +456,10 @@ class _HipCausalLMBase:
         if max_new_tokens is None:
             max_new_tokens = (max_length - T) if max_length is not None else 20
         eos = self.config.eos_token_id if eos_token_id is None else eos_token_id
-        eos = None if (eos is not None and int(eos) < 0) else eos
+        # an int or a list of ids (HF's BeamSearchScorer takes both and tests membership); negative = none
+        eos_list = [int(e) for e in (eos if isinstance(eos, (list, tuple)) else ([] if eos is None else [eos])) if int(e) >= 0]
+        eos_set = set(eos_list)
+        eos = eos_list[0] if eos_list else None          # what pads / terminates a finished row (HF: eos_token_id[0])
         pad = pad_token_id if pad_token_id is not None else (self.config.pad_token_id if self.config.pad_token_id is not None else eos)
         segs = segs if self.variant != "llava" else None
         depths = depths if self.variant == "vcoder_ds" else None
@@ -519,9 +522,18 @@ class _HipCausalLMBase:
                     kth = torch.topk(w, sample["top_k"])[0][..., -1, None]
                     w = w.masked_fill(w < kth, float("-inf"))
                 if sample["top_p"] < 1.0:
-                    w = _top_p_filter(w, sample["top_p"])
+                    w = _top_p_filter(w, sample["top_p"], min_tokens_to_keep=2)   # 4.31: min_tokens_to_keep = 2 when num_beams > 1
                 flat = w.view(B, nb * V)
-                draw = torch.multinomial(torch.softmax(flat, dim=-1), 2 * nb, generator=sample["generator"])
+                probs = torch.softmax(flat, dim=-1)
+                # torch.multinomial without replacement needs >= 2n non-zero entries (step 0: only beam 0 is alive, and a tight
+                # top_p / top_k can leave fewer): the finite-score continuations are topped up with the next-best ones by score
+                short = (probs > 0).sum(-1) < 2 * nb
+                if bool(short.any()):
+                    fill = torch.topk(scores.view(B, nb * V), 2 * nb, dim=1).indices
+                    tiny = torch.zeros_like(probs).scatter(1, fill, torch.finfo(probs.dtype).tiny)
+                    probs = torch.where(short[:, None] & (probs == 0), tiny, probs)
+                    flat = torch.where(short[:, None] & torch.isinf(flat) & (tiny > 0), scores.view(B, nb * V), flat)
+                draw = torch.multinomial(probs, 2 * nb, generator=sample["generator"])
                 top_s, order = torch.sort(torch.gather(flat, -1, draw), descending=True, dim=1)
                 top_i = torch.gather(draw, -1, order)
                 scores = w
@@ -537,7 +549,7 @@ class _HipCausalLMBase:
                 k = 0
                 for rank in range(2 * nb):
                     tok, sc, src = int(next_tok[b, rank]), float(top_s[b, rank]), b * nb + int(next_idx[b, rank])
-                    if eos is not None and tok == int(eos):
+                    if tok in eos_set:
                         if rank >= nb:
                             continue
                         add_hyp(b, seqs[src].clone(), sc)
@@ -607,13 +619,13 @@ def _reference_keyword_stop(crit):
     return out
 
 
-def _top_p_filter(scores, top_p: float):
+def _top_p_filter(scores, top_p: float, min_tokens_to_keep: int = 1):
     import torch
 
     s, idx = torch.sort(scores, descending=False, dim=-1)
     cum = s.softmax(-1).cumsum(-1)
     remove = cum <= (1 - top_p)
-    remove[..., -1:] = False
+    remove[..., -min_tokens_to_keep:] = False
     mask = remove.scatter(1, idx, remove)
     return scores.masked_fill(mask, float("-inf"))
 
