@@ -76,6 +76,11 @@ int vc_model_load_tensor(vc_model* m, const char* hf_key, const void* host_ptr, 
 int vc_model_synth_tensor(vc_model* m, const char* hf_key, const int64_t* shape, int ndim, uint32_t tensor_seed,
                           float offset, float halfwidth);
 /* after the last tensor: fuses QKV / interleaves gate-up / packs decode copies; fails listing a missing key */
+/* on = 1: a sample's results do not depend on the batch (or the rank's shard) it runs in — the prefill GEMMs skip their split-K
+ * remainder round, whose slicing follows the tile count; everything else already is batch-invariant.  The reference's rows are
+ * independent of the batch size; with it the ids of N ranks x B equal those of one rank x N B bit for bit.
+ * Costs a short last round of tiles per GEMM.  Default 0.  Applies to every session of the model. */
+int vc_model_set_batch_invariant(vc_model* m, int on);
 /* weight format 2 ("fp8"): KV cache of the decode steps in e4m3 (default 1) or bf16 (0).  Before vc_model_finalize. */
 int vc_model_set_fp8_kv(vc_model* m, int on);
 int vc_model_finalize(vc_model* m);

@@ -835,6 +835,39 @@ def test_bench_two_ranks_self_launched(tmp_path):
     assert np.array_equal(got, ref), "gathered ids of the 2-rank run differ from the single-process ids"
 
 
+def test_batch_invariant_mode_true_dims():
+    """vc_model_set_batch_invariant at true 7b dims (2 layers): one batch of 4 gives every sample the BITS — prefill logits and
+    greedy ids — of two batches of 2 and of four batches of 1 (SURVEY §4 test 4 / §0 quirk 6: a rank's shard of a global batch
+    equals the single-GPU run of that batch), in the bf16 and the split mode.  (Without it the split-K remainder round of a
+    prefill GEMM depends on the tile count: the comparison below is expected to find differing low-order bits at these sizes.)"""
+    cfg = vcfg.vicuna_7b("vcoder_ds")
+    cfg.num_hidden_layers = 2
+    cfg.vit_num_layers = 3
+    eng = HipEngine(cfg)
+    eng.load_synthetic(21)
+    eng.finalize()
+    ids = np.stack([synth.synth_prompt_ids(cfg.vocab_size, "vcoder_ds", sample=b) for b in range(4)])
+    imgs, segs, deps = synth.synth_batch(4, 336)
+
+    def run(lo, hi):
+        last, _, _ = eng.prefill(ids[lo:hi], imgs[lo:hi], segs[lo:hi], deps[lo:hi])
+        return last, eng.generate_greedy(ids[lo:hi], imgs[lo:hi], segs[lo:hi], deps[lo:hi], max_new_tokens=6)
+    base4, _ = run(0, 4)
+    differs_by_default = not np.array_equal(base4[:2], run(0, 2)[0])
+    for mode in ("bf16", "split"):
+        eng.set_precision(mode)
+        eng.set_batch_invariant(True)
+        l4, g4 = run(0, 4)
+        for lo, hi in ((0, 2), (2, 4), (1, 2), (3, 4)):
+            l, g_ = run(lo, hi)
+            assert np.array_equal(l, l4[lo:hi]), f"{mode}: prefill logits of samples {lo}..{hi - 1} depend on the batch"
+            assert np.array_equal(g_, g4[lo:hi]), f"{mode}: greedy ids of samples {lo}..{hi - 1} depend on the batch"
+        eng.set_batch_invariant(False)
+    eng.set_precision("bf16")
+    print("default mode: a batch of 4 and a batch of 2 differ in the low-order bits of the prefill logits:", differs_by_default)
+    eng.close()
+
+
 @pytest.mark.parametrize("gather", ["torch", "cabi"])
 def test_bench_force_dist_one_gpu(tmp_path, gather):
     """`bench.py --gpus 1 --force-dist`: the multi-GPU code path on ONE GPU with the REAL backend — init_process_group("nccl",

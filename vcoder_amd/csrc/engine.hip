@@ -234,6 +234,7 @@ struct vc_model {
     struct vc_pool* pool = nullptr;  // the root model's shared decode pool (created on first use; sessions point at it)
     bool pool_profile = false;       // root model: the pool's step graphs carry in-situ timing stamps (vc_pool_profile)
     bool fp8_kv = true;              // weight format 2: the KV cache of the bf16-step modes in e4m3 (vc_model_set_fp8_kv)
+    bool batch_invariant = false;    // root model: a sample's bits do not depend on the batch it runs in (vc_model_set_batch_invariant)
     vc_model* root = nullptr;        // the model that owns the weights (itself for a root)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float t_encode = 0, t_prefill = 0, t_decode = 0;
@@ -497,6 +498,9 @@ void emit_attentions(vc_model* m, int l, int B, int S, AttnProbsArgs a, int Tk =
 
 // ------------------------------------------------------------------------------------------------
 // GEMM helpers
+// vc_model_set_batch_invariant: no split-K remainder round (its slices — and so the order in which a row's k-blocks are summed —
+// depend on the number of output tiles, i.e. on how many rows share the launch)
+inline bool batch_invariant(const vc_model* m) { return (m->root ? m->root : m)->batch_invariant; }
 inline bool prefill_fold_on() {
     const char* e = getenv("VC_PREFILL_FOLD");
     return e && atoi(e) != 0;
@@ -523,7 +527,7 @@ void gemm(vc_model* m, const bf16_t* A, const bf16_t* W, const float* bias, void
           int epi, int lda = 0, const NormFold* fold = nullptr) {
     GemmArgs a{A, W, bias, out, M, N, K, lda > 0 ? lda : K, K, ldo};
     apply_fold(a, fold);
-    if ((long)((M + 255) / 256) * ((N + 255) / 256) > 256) {  // only problems with more than one round of tiles can use it
+    if (!batch_invariant(m) && (long)((M + 255) / 256) * ((N + 255) / 256) > 256) {  // only problems with more than one round of tiles can use it
         m->gemm_ws.ensure((size_t)64 << 20);
         a.ws = m->gemm_ws.as<float>();
         a.ws_bytes = m->gemm_ws.cap;
@@ -537,7 +541,7 @@ void gemm_f8(vc_model* m, const bf16_t* A, const uint8_t* Wq, const float* wscal
              int epi) {
     if (A) launch_quant_act_rows(A, K, m->a8.as<uint8_t>(), m->a8_scale.as<float>(), M, K, m->st);
     GemmArgs a{reinterpret_cast<const bf16_t*>(m->a8.p), reinterpret_cast<const bf16_t*>(Wq), nullptr, out, M, N, K, K, K, ldo};
-    if ((long)((M + 255) / 256) * ((N + 255) / 256) > 256) {
+    if (!batch_invariant(m) && (long)((M + 255) / 256) * ((N + 255) / 256) > 256) {
         m->gemm_ws.ensure((size_t)64 << 20);
         a.ws = m->gemm_ws.as<float>();
         a.ws_bytes = m->gemm_ws.cap;
@@ -560,7 +564,7 @@ void gemm_split(vc_model* m, const bf16_t* A, const bf16_t* W, const float* bias
         a.w_lo_off = (long long)(reinterpret_cast<const char*>(Wl) - reinterpret_cast<const char*>(W));
     }
     apply_fold(a, fold);
-    if ((long)((M + 255) / 256) * ((N + 255) / 256) > 256) {
+    if (!batch_invariant(m) && (long)((M + 255) / 256) * ((N + 255) / 256) > 256) {
         m->gemm_ws.ensure((size_t)64 << 20);
         a.ws = m->gemm_ws.as<float>();
         a.ws_bytes = m->gemm_ws.cap;
@@ -2166,6 +2170,18 @@ VC_API int vc_model_set_fp8_kv(vc_model* m, int on) {
     if (!m) return VC_ERR_INVALID;
     if (m->finalized) return VC_ERR_STATE;
     m->fp8_kv = on != 0;
+    return VC_OK;
+}
+
+/* Batch invariance (the reference's rows do not depend on the batch size; §4 test 4: the gathered stream of
+ * N ranks == the single-GPU stream of the same global batch).  By default a prefill GEMM whose last round of output tiles is short
+ * cuts that round into K-slices, and the number of slices follows from the tile count — so a sample's low-order bits can differ
+ * between a batch of 4 and two batches of 2 (1e-6-level; visible only through near-tied greedy choices).  on = 1: no remainder
+ * split — every output row is summed in one fixed k order whatever shares its launch (the decode steps, attention and row kernels
+ * already are), at the price of a short last round of tiles per GEMM (~2-4 % of a prefill).  Applies to all sessions of the model. */
+VC_API int vc_model_set_batch_invariant(vc_model* m, int on) {
+    if (!m) return VC_ERR_INVALID;
+    (m->root ? m->root : m)->batch_invariant = on != 0;
     return VC_OK;
 }
 

@@ -154,6 +154,10 @@ class HipEngine:
         self._check(self.lib.vc_model_set_weight_format(self._model, code))
         self.weight_format = fmt
 
+    def set_batch_invariant(self, on: bool = True):
+        """a sample's bits independent of the batch / shard it runs in (vc_model_set_batch_invariant): N ranks x B == one rank x N B"""
+        self._check(self.lib.vc_model_set_batch_invariant(self._model, 1 if on else 0))
+
     def set_fp8_kv(self, on: bool):
         """'fp8' weight format: e4m3 KV cache for the decode steps (default) or bf16 rows.  Before finalize()."""
         self._check(self.lib.vc_model_set_fp8_kv(self._model, 1 if on else 0))
