@@ -61,6 +61,8 @@ def parse_args():
                          "per-step id all-gather, the device barriers and the MAX all-reduce of the timing (and with --gather cabi "
                          "a one-rank RCCL communicator inside the library): the multi-GPU code path on a one-GPU box")
     ap.add_argument("--dump-ids", default=None, help="write the gathered ids of the last timed step to this .npy (tests)")
+    ap.add_argument("--no-pool-hold", action="store_true",
+                    help="pool policy A/B: step whatever rows are active even while another call is prefilling (vc_pool_set_hold(0))")
     ap.add_argument("--no-insitu", action="store_true",
                     help="do not stamp the pool's decode-step launches (roofline then reports the isolated replay); A/B of the stamps' cost")
     ap.add_argument("--no-extra-legs", action="store_true",
@@ -449,6 +451,8 @@ def main():
     insitu_on = not args.no_insitu and os.environ.get("VC_POOL", "1") != "0"
     if insitu_on:
         eng.pool_profile(True)
+    if args.no_pool_hold:
+        eng.pool_set_hold(False)
     sessions = [eng] + [eng.fork() for _ in range(n_sess - 1)]
 
     def run_steps(k: int, px):

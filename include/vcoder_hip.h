@@ -268,6 +268,11 @@ int vc_pool_step_counts(vc_model* m, unsigned long long* counts4);
  * stores, no atomics), and one small launch per step folds the slots into per-(span, kind) sums of (latest end - earliest start).  Takes effect when the pool is next (re)built, i.e. while
  * no generate() is in flight.  bf16 path only.  No reference counterpart (the reference has no timing code). */
 int vc_pool_profile(vc_model* m, int on);
+/* Pool scheduling: on = 1 (default) the pool does not step while a generate() call that already holds rows is still prefilling —
+ * it waits for that request to join instead of running a step beside the prefill's GEMMs (2-7x a step's time) that the joiner
+ * would need again anyway; on = 0 steps whatever rows are active (lower inter-token latency for the calls in flight, lower
+ * throughput).  No reference counterpart (the reference runs one generate() at a time). */
+int vc_pool_set_hold(vc_model* m, int on);
 /* sums since the last reset, each [4 spans: 8 / 16 / 24 / 32 rows][6 kinds: qkv, decode attention, o_proj, gate/up, down, lm_head]:
  * exec_us = earliest workgroup start -> latest workgroup end of the launches; period_us = latest end of the previous launch of the
  * step -> latest end of this one (dispatch, drain and inter-kernel gap included: what the step's dependency chain pays per launch;

@@ -117,6 +117,8 @@ def declare(lib: C.CDLL) -> C.CDLL:
     lib.vc_model_set_fp8_kv.restype = C.c_int
     lib.vc_model_inexact_tensors.argtypes = [vp]
     lib.vc_model_inexact_tensors.restype = C.c_int
+    lib.vc_pool_set_hold.argtypes = [vp, i32]
+    lib.vc_pool_set_hold.restype = C.c_int
     lib.vc_pool_profile.argtypes = [vp, i32]
     lib.vc_pool_profile.restype = C.c_int
     lib.vc_pool_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_ulonglong), i32]

@@ -235,6 +235,7 @@ struct vc_model {
     bool pool_profile = false;       // root model: the pool's step graphs carry in-situ timing stamps (vc_pool_profile)
     bool fp8_kv = true;              // weight format 2: the KV cache of the bf16-step modes in e4m3 (vc_model_set_fp8_kv)
     bool batch_invariant = false;    // root model: a sample's bits do not depend on the batch it runs in (vc_model_set_batch_invariant)
+    bool pool_hold = true;           // root model: the pool does not step while a call holding rows is still prefilling (vc_pool_set_hold)
     vc_model* root = nullptr;        // the model that owns the weights (itself for a root)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float t_encode = 0, t_prefill = 0, t_decode = 0;
@@ -2711,6 +2712,11 @@ struct vc_pool {
     hipEvent_t step_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     unsigned long steps_run = 0;
     unsigned long long steps_by_span[VC_POOL_ROWS / 8] = {};  // steps launched over 8 / 16 / 24 / 32 rows (vc_pool_step_counts)
+    // generate() calls that hold rows and have not yet handed their request to the driver (encode + prefill being enqueued): with
+    // the hold policy (vc_pool_set_hold) the driver waits for them instead of stepping the rows it has — a step that runs beside a
+    // prefill's GEMMs takes 2-7x its time (profiles/r05_d_decode_kernels_alone_vs_corun.md) and the joiner needs a full set of
+    // steps of its own anyway, so nothing is gained by starting without it
+    int prefilling = 0;
     // in-situ timing (vc_pool_profile): the step graphs were captured with stamp slots; prof_acc[span][kind] = {exec ticks,
     // period ticks, launches}
     bool prof = false;
@@ -2812,6 +2818,11 @@ void pool_driver(vc_pool* p) {
             };
             retire_finished();
             if (p->active.empty()) continue;
+            if (p->root->pool_hold && p->prefilling > 0) {
+                // somebody is about to join: wait for its request (or for it to give up) rather than step without it
+                p->cv_driver.wait(lk, [&] { return p->stop || !p->pending.empty() || p->prefilling == 0; });
+                continue;
+            }
             int top = 0;
             for (PoolRequest* rq : p->active) top = std::max(top, rq->row0 + rq->B);
             const int gi = (top + 7) / 8 - 1;  // the step covers rows [0, top) rounded up to 8: free rows above cost nothing
@@ -3022,7 +3033,15 @@ void generate_on_pool(vc_model* m, const int64_t* ids, int B, int T, const float
         });
         for (int r = row0; r < row0 + B; ++r) p->used[r] = true;
         rq.row0 = row0;
+        p->prefilling += 1;
     }
+    bool counted_prefilling = true;
+    auto done_prefilling = [&]() {   // p->mu held
+        if (!counted_prefilling) return;
+        counted_prefilling = false;
+        p->prefilling -= 1;
+        p->cv_driver.notify_all();
+    };
     auto release_rows = [&]() {
         std::lock_guard<std::mutex> lk(p->mu);
         for (int r = rq.row0; r < rq.row0 + B; ++r) p->used[r] = false;
@@ -3063,6 +3082,7 @@ void generate_on_pool(vc_model* m, const int64_t* ids, int B, int T, const float
         std::unique_lock<std::mutex> lk(p->mu);
         REQUIRE(!p->stop, VC_ERR_STATE, "the decode pool has stopped after an error");
         p->pending.push_back(&rq);
+        done_prefilling();
         p->cv_driver.notify_all();
         int reported = 0;
         std::vector<int> part;
@@ -3114,6 +3134,7 @@ void generate_on_pool(vc_model* m, const int64_t* ids, int B, int T, const float
     } catch (...) {
         {   // a request that is still queued / active must not outlive this frame
             std::unique_lock<std::mutex> lk(p->mu);
+            done_prefilling();
             auto it = std::find(p->pending.begin(), p->pending.end(), &rq);
             if (it != p->pending.end()) p->pending.erase(it);
             else if (!rq.done && std::find(p->active.begin(), p->active.end(), &rq) != p->active.end()) {
@@ -3480,6 +3501,22 @@ VC_API int vc_pool_step_counts(vc_model* m, unsigned long long* counts4) {
  * tiny launch per step folds the slots into per-(span, kind) sums, so that a measurement covers every launch of a timed region as
  * it ran there (beside whatever the other sessions had on the GPU), not a replay.  Takes effect when the pool is next (re)built,
  * i.e. while it is idle.  bf16 path only (the split step keeps its graphs). */
+/* Pool scheduling policy.  on = 1 (default): the pool does not launch a decode step while a generate() call that already holds
+ * rows is still in its encode / prefill phase — it waits for that request to join (a step beside a prefill's GEMMs runs at a
+ * fraction of its speed, and the joiner needs a full set of steps of its own anyway).  Throughput policy: the requests already
+ * decoding see one pause of about a prefill when somebody joins.  on = 0: step whatever rows are active (lowest inter-token
+ * latency for the requests in flight).  Applies to every session of the model. */
+VC_API int vc_pool_set_hold(vc_model* m, int on) {
+    if (!m) return VC_ERR_INVALID;
+    vc_model* root = m->root ? m->root : m;
+    root->pool_hold = on != 0;
+    if (root->pool) {
+        std::lock_guard<std::mutex> lk(root->pool->mu);
+        root->pool->cv_driver.notify_all();
+    }
+    return VC_OK;
+}
+
 VC_API int vc_pool_profile(vc_model* m, int on) {
     if (!m) return VC_ERR_INVALID;
     vc_model* root = m->root ? m->root : m;

@@ -552,6 +552,10 @@ class HipEngine:
 
     PROFILE_KINDS = ("qkv", "attention", "o_proj", "gate_up", "down", "lm_head")
 
+    def pool_set_hold(self, on: bool = True):
+        """pool policy (vc_pool_set_hold): True (default) = no decode step while a call that holds rows is still prefilling"""
+        self._check(self.lib.vc_pool_set_hold(self._model, 1 if on else 0))
+
     def pool_profile(self, on: bool = True):
         """in-situ timing of the pool's decode-step launches (vc_pool_profile): takes effect when the pool is next (re)built"""
         self._check(self.lib.vc_pool_profile(self._model, 1 if on else 0))
