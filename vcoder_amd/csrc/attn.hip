@@ -534,14 +534,13 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && QS == 1 && !SPLIT) ? 4 :
     }
 }
 
-// VC_ATTN_SCHED (see attention_kernel): 0 = plain 3-D grid, 1 = XCD-grouped heads + heaviest query block first, 2 = heaviest
-// first only, 3 = XCD-grouped only; unset = by shape
+// workgroup order (AttnArgs::sched, see attention_kernel): 0 = plain 3-D grid, 1 = XCD-grouped heads + heaviest query block first,
+// 2 = heaviest first only, 3 = XCD-grouped only
 static dim3 attention_grid(AttnArgs& a, int QB) {
     // measured (profiles/r03_l_*): causal prefill shape 2 < 3 < 0 = 1 (165-175 / 179-187 / 186-200 us); ViT shape 3 < 0 < 2
-    // (78-85 / 85-92 / 88-94 us) — the default is 2 for a causal pass, 3 otherwise
-    static const int sched_env = getenv("VC_ATTN_SCHED") ? atoi(getenv("VC_ATTN_SCHED")) : -1;
+    // (78-85 / 85-92 / 88-94 us) — 2 for a causal pass, 3 otherwise
     a.nqb = (a.T + QB - 1) / QB;
-    a.sched = sched_env >= 0 ? sched_env : (a.causal ? 2 : 3);
+    a.sched = a.causal ? 2 : 3;
     if ((a.sched == 1 || a.sched == 3) && (a.B * a.H) % 8 != 0) a.sched = a.sched == 1 ? 2 : 0;
     return a.sched ? dim3(a.nqb * a.H * a.B) : dim3(a.nqb, a.H, a.B);
 }
@@ -862,11 +861,9 @@ void launch_attention_decode_fused(const AttnDecodeFusedArgs& a, hipStream_t s) 
     static const int uk = getenv("VC_DATTN_UK") ? atoi(getenv("VC_DATTN_UK")) : 8;
     if (a.kv32 == 3) {  // bf16 step over e4m3 caches (the fp8 weight format)
         // rows in flight per lane: 16 elements per load cost 16 + 16 query / accumulator registers; 8 rows took 156 VGPRs (one
-        // workgroup per CU).  VC_DATTN8_UK = 4 (tuning; default 6)
-        static const int uk8 = getenv("VC_DATTN8_UK") ? atoi(getenv("VC_DATTN8_UK")) : 6;
+        // workgroup per CU); 6 rows: 124 VGPRs, two workgroups per CU (profiles/r04_n_kbench_dattn_kv8_uk.txt)
         if (a.hd == 128) {
-            if (uk8 == 4) VC_LAUNCH((attention_decode_fused_kernel<128, 4, 3>), grid, block, 0, s, a);
-            else VC_LAUNCH((attention_decode_fused_kernel<128, 6, 3>), grid, block, 0, s, a);   // 124 VGPRs: two workgroups per CU
+            VC_LAUNCH((attention_decode_fused_kernel<128, 6, 3>), grid, block, 0, s, a);
         } else {
             VC_LAUNCH((attention_decode_fused_kernel<64, 4, 3>), grid, block, 0, s, a);
         }

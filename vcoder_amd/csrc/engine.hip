@@ -70,41 +70,11 @@ inline size_t rup(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // invalidate the graph capture of) other sessions' streams
 thread_local hipStream_t t_stream = nullptr;
 
-// Stream creation with an optional CU mask (experiment knob): `env` = "first:count" restricts the stream to
-// `count` compute units starting at mask bit `first`.  On gfx942/gfx950 the KFD deals mask bits round-robin over the XCDs
-// (bit i -> XCD i % 8), so a contiguous bit range is an equal share of every XCD.  VC_POOL_CU_RANGE masks the decode pool's
-// stream (HBM-bound steps), VC_SESSION_CU_RANGE the sessions' streams (MFMA-bound encode + prefill): disjoint ranges let the
-// two phases run side by side on separate CUs instead of time-sharing all of them.
-hipStream_t make_stream(const char* env) {
+// Every session and the decode pool get their own non-blocking stream.  (Rounds 3-4 measured CU masks and queue priorities for
+// them — disjoint CU ranges for the MFMA-bound and the HBM-bound phase, high / low priority queues: all negative,
+// profiles/r03_a_cu_mask_experiment.md, r03_q_stream_priority_and_inflight.md — and the knobs were removed in round 5.)
+hipStream_t make_stream() {
     hipStream_t st = nullptr;
-    const char* v = env ? getenv(env) : nullptr;
-    int first = 0, count = 0;
-#ifndef VC_EMU
-    if (v && sscanf(v, "%d:%d", &first, &count) == 2 && count > 0 && first >= 0) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        HIPCHK(hipGetDevice(&dev));
-        HIPCHK(hipGetDeviceProperties(&prop, dev));
-        const int ncu = prop.multiProcessorCount;
-        REQUIRE(first + count <= ncu, VC_ERR_INVALID, "%s=%s: the device has %d compute units", env, v, ncu);
-        std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
-        for (int i = first; i < first + count; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
-        HIPCHK(hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()));
-        return st;
-    }
-#endif
-    (void)v; (void)first; (void)count;
-#ifndef VC_EMU
-    // <env>_PRIO = high | low (experiment knob): queue priority of the stream
-    const std::string pe = env ? std::string(env) + "_PRIO" : std::string();
-    const char* pv = env ? getenv(pe.c_str()) : nullptr;
-    if (pv && (pv[0] == 'h' || pv[0] == 'l')) {
-        int least = 0, greatest = 0;
-        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIPCHK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, pv[0] == 'h' ? greatest : least));
-        return st;
-    }
-#endif
     // non-blocking: no implicit synchronisation with the legacy NULL stream (torch's default stream, other sessions)
     HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     return st;
@@ -1949,7 +1919,7 @@ VC_API int vc_init(int device_id, vc_ctx** out) {
     REQUIRE(n > 0 && device_id >= 0 && device_id < n, VC_ERR_HIP, "no HIP device %d (found %d)", device_id, n);
     HIPCHK(hipSetDevice(device_id));
     ctx->device = device_id;
-    ctx->stream = make_stream("VC_SESSION_CU_RANGE");
+    ctx->stream = make_stream();
     *out = ctx;
     GUARD_END(ctx)
 }
@@ -2933,7 +2903,7 @@ vc_pool* pool_for(vc_model* m, int need_S, int need_out) {
         p->capS = std::min((int)rup(std::max(need_S, 2048), 64), c.max_positions / 64 * 64);
         p->out_stride = std::max(need_out, p->capS);
         REQUIRE(p->capS >= need_S, VC_ERR_INVALID, "sequence %d exceeds max_position_embeddings=%d", need_S, c.max_positions);
-        p->st = make_stream("VC_POOL_CU_RANGE");
+        p->st = make_stream();
         t_stream = p->st;  // zero-fills of the new buffers
         const size_t kvb = (size_t)c.layers * R * H * p->capS * root->hd * es;
         p->kc.ensure(kvb, true);
@@ -3063,9 +3033,7 @@ void generate_on_pool(vc_model* m, const int64_t* ids, int B, int T, const float
         // ---- encode + prefill, keys / values straight into the pool's rows
         m->cur_pos = -1;
         int S = 0;
-        static const bool use_gate = !(getenv("VC_PREFILL_GATE") && atoi(getenv("VC_PREFILL_GATE")) == 0);
-        std::unique_lock<std::mutex> gate(g_prefill_gate, std::defer_lock);
-        if (use_gate) gate.lock();
+        std::unique_lock<std::mutex> gate(g_prefill_gate);
         do_prefill(m, ids, B, T, img, seg, depth, on_dev, 1, max_new, false, &S);
         DBG_HIP("do_prefill");
         m->last_S = S;
@@ -3076,7 +3044,7 @@ void generate_on_pool(vc_model* m, const int64_t* ids, int B, int T, const float
         if (m->ev[2]) HIPCHK(hipEventRecord(m->ev[2], m->st));
         HIPCHK(hipEventRecord(rq.prefill_done, m->st));
         DBG_HIP("finish_prefill");
-        if (use_gate) gate.unlock();
+        gate.unlock();
         fill_rows(rq.rec, B, g, S, tail.data(), rq.row0 * p->out_stride, p->out_stride);
         // ---- join, then sleep until the driver retires the request (streaming: wake per report)
         std::unique_lock<std::mutex> lk(p->mu);
@@ -3162,9 +3130,7 @@ void generate_on_session(vc_model* m, const int64_t* ids, int B, int T, const fl
     int S = 0;
     // Sessions of one process take turns in the MFMA-bound encode+prefill phase: two prefills side by side only slow
     // each other (and every decode in flight), while ONE prefill overlaps well with the HBM-bound decodes of the others.
-    static const bool use_gate = !(getenv("VC_PREFILL_GATE") && atoi(getenv("VC_PREFILL_GATE")) == 0);
-    std::unique_lock<std::mutex> gate(g_prefill_gate, std::defer_lock);
-    if (use_gate) gate.lock();
+    std::unique_lock<std::mutex> gate(g_prefill_gate);
     do_prefill(m, ids, B, T, img, seg, depth, on_dev, 1, max_new, true, &S);  // generate() always builds a mask
     m->last_S = S;
     REQUIRE(S + max_new <= m->capS, VC_ERR_INVALID, "prompt %d + max_new %d exceeds the KV capacity %d", S, max_new, m->capS);
@@ -3179,7 +3145,7 @@ void generate_on_session(vc_model* m, const int64_t* ids, int B, int T, const fl
     HIPCHK(hipMemcpyAsync(m->out_ids.p, fill.data(), fill.size() * 4, hipMemcpyHostToDevice, m->st));
     launch_select_embed(select_args(m, v, v.logits, B, 1), m->st);  // step 0 -> 1; the position stays at S
     HIPCHK(hipStreamSynchronize(m->st));
-    if (use_gate) gate.unlock();
+    gate.unlock();
     int produced = 1, reported = 0;
     const bool can_finish = g.eos >= 0 || g.n_stop > 0;
     std::vector<int> rec((size_t)B * RS_STRIDE), part;

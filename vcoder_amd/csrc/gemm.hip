@@ -559,8 +559,7 @@ static void launch_gemm_f8(const GemmArgs& a, int epilogue, hipStream_t s) {
     const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
     const size_t sh2 = 2 * (256 * 128 + 256 * 128);
     static const int sk_on = getenv("VC_GEMM_SPLITK") ? atoi(getenv("VC_GEMM_SPLITK")) : 1;
-    static const int tile_group = getenv("VC_GEMM_GROUP") ? atoi(getenv("VC_GEMM_GROUP")) : 4;
-    static const int xcd_on = getenv("VC_GEMM_XCD") ? atoi(getenv("VC_GEMM_XCD")) : 1;
+    constexpr int tile_group = 4, xcd_on = 1;   // as in launch_gemm below
     GemmArgs ask = a;
     ask.tile_group = tile_group;
     ask.xcd_remap_on = xcd_on;
@@ -621,8 +620,8 @@ void launch_gemm(const GemmArgs& a, int epilogue, hipStream_t s) {
             // split-K for a short last round of the 8-phase kernel (VC_GEMM_SPLITK=0 disables): rem tiles left over
             // after the full rounds of 256 are cut into ks = 256 / rem K-slices each, so the round is ~1/ks as long
             static const int sk_on = getenv("VC_GEMM_SPLITK") ? atoi(getenv("VC_GEMM_SPLITK")) : 1;
-            static const int tile_group = getenv("VC_GEMM_GROUP") ? atoi(getenv("VC_GEMM_GROUP")) : 4;  // m-tiles per sweep group (measured: 4 and 2 beat 8 / 16 / 38 by 2-6 %)
-            static const int xcd_on = getenv("VC_GEMM_XCD") ? atoi(getenv("VC_GEMM_XCD")) : 1;
+            // m-tiles per sweep group (measured: 4 and 2 beat 8 / 16 / 38 by 2-6 %) and the XCD remap of the tile order (on: +-3 %)
+            constexpr int tile_group = 4, xcd_on = 1;
             GemmArgs ask = a;
             ask.tile_group = tile_group;
             ask.xcd_remap_on = xcd_on;

@@ -36,7 +36,7 @@ struct GemmArgs {
     float* ws;
     size_t ws_bytes;
     int sk_full, sk_ks;
-    int tile_group, xcd_remap_on;  // tile-order tuning knobs (launch_gemm fills them: VC_GEMM_GROUP / VC_GEMM_XCD)
+    int tile_group, xcd_remap_on;  // tile order (launch_gemm fills them: 4 m-tiles per sweep group, XCD remap on)
     // f8 != 0: A and W point at OCP e4m3 bytes (lda / ldw in elements = bytes, K % 128 == 0) and the accumulator is
     // multiplied by a_scale[m] * w_scale[n] before bias / epilogue (EPI_BF16, EPI_RESID_F32, EPI_SWIGLU only)
     int f8;
