@@ -358,9 +358,13 @@ def extra_legs(args, eng7, cfg7, ids7, dev_px7, lone_ids7, fast_value, n_new):
             leg["parity"] = {"what": "e4m3 weights + e4m3 activation rows in the prefill linears: no fp32-reference tolerance applies "
                                      "end to end (the format's own re-rounding noise compounds over 40 layers); pinned PER LAYER, "
                                      "teacher-forced on the oracle's own layer inputs at these dimensions",
-                             "test": "tests/test_gpu_e2e.py::test_fp8_formats_per_layer_teacher_forced",
-                             "per_layer_vs_oracle_of_max_abs_x": {"w8a16": {"rms": 6.1e-4, "max": 3.6e-3}, "fp8": {"rms": 7.0e-3, "max": 3.8e-2}},
-                             "tolerances_in_test": {"w8a16": {"rms": 2e-3, "max": 2e-2}, "fp8": {"rms": 1.5e-2, "max": 8e-2}},
+                             "tests": ["tests/test_gpu_e2e.py::test_fp8_formats_per_layer_teacher_forced (tolerances asserted there: W8A16 rms 2e-3 / "
+                                       "max 2e-2 of |x_out|max, fp8 rms 1.5e-2 / max 8e-2)",
+                                       "tests/test_gpu_e2e.py::test_fp8_formats_per_layer_with_massive_activation_channels (three hidden channels 300 x "
+                                       "the rest, deviations relative to the layer update)",
+                                       "tests/test_gpu_fulldepth.py::test_fp8_formats_vs_bf16_full_depth_13b (40 layers: logit correlation with the bf16 "
+                                       "path >= 0.75; e4m3 KV against bf16 KV >= 0.98)"],
+                             "measured": "the runs of these tests on MI355X are committed under profiles/ (r05_g_fp8_*.txt); no figure is restated here",
                              "quantiser_bytes_and_scales_vs_torch_float8_e4m3fn": "bit-exact",
                              "kv_cache": "e4m3 rows (no scale): bytes == torch's e4m3 cast of the bf16 rows, decode attention == the fp32 "
                                          "oracle on the dequantised cache to one bf16 rounding (tests/kernel_cases.py::check_kv8); the "
