@@ -16,10 +16,20 @@ def main():
     db = sys.argv[1]
     c = sqlite3.connect(db)
     cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
-    rows = c.execute("select name, start, end from kernels").fetchall()
+    # total work-items of the launch, whatever this rocprofv3 calls the columns: the decode attention keeps ONE kernel name for every
+    # row count (grid = heads x rows workgroups of 512 threads), so its launches are told apart by the grid
+    gcols = [g for g in ("grid_size", "grid_x", "grid_y", "grid_z", "grid_size_x", "grid_size_y", "grid_size_z") if g in cols]
+    sel = "name, start, end" + "".join(", " + g for g in gcols)
+    rows = c.execute(f"select {sel} from kernels").fetchall()
     agg = {}
-    for name, s, e in rows:
+    for row in rows:
+        name, s, e = row[:3]
         k = short(name)
+        if "attention_decode_fused_kernel" in name and gcols:
+            g = dict(zip(gcols, row[3:]))
+            total = g.get("grid_size") or ((g.get("grid_x") or g.get("grid_size_x") or 1) * (g.get("grid_y") or g.get("grid_size_y") or 1) *
+                                           (g.get("grid_z") or g.get("grid_size_z") or 1))
+            k += f" [{int(total) // 512} workgroups = heads x rows]"
         a = agg.setdefault(k, [0, 0])
         a[0] += 1
         a[1] += e - s

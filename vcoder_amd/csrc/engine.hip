@@ -2922,7 +2922,8 @@ vc_pool* pool_for(vc_model* m, int need_S, int need_out) {
         p->sk_counters.ensure((size_t)sk_counters_n(c) * 4, true);
         t_stream = m->st;
         for (auto& e : p->step_ev) HIPCHK(hipEventCreate(&e));
-        p->prof = root->pool_profile && !want_split;   // (a split step's GEMVs may take two passes: the slot layout assumes one)
+        // (a split step's GEMVs may take two passes: the slot layout assumes one; the fold kernel walks at most 512 slots)
+        p->prof = root->pool_profile && !want_split && 5 * c.layers + 1 <= 512;
         if (p->prof) {
             const size_t nslots = (size_t)5 * c.layers + 1;
             p->stamps.ensure(nslots * STAMP_SLOT_WORDS * 4, true);

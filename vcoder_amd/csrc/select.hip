@@ -315,12 +315,21 @@ __global__ __launch_bounds__(256) void stamp_accumulate_kernel(unsigned* stamps,
         last = atomic_inc_agent(scratch) == (unsigned)(n - 1) ? 1u : 0u;
     }
     __syncthreads();
-    if (!last || tid != 0) return;
+    if (!last) return;
+    // the last arriver: all its threads fetch the per-slot results side by side (sc1 loads), one thread walks them in launch order
+    constexpr int MAXS = 512;
+    __shared__ unsigned sst[MAXS], sen[MAXS];
+    for (int s_ = tid; s_ < n && s_ < MAXS; s_ += 256) {
+        sst[s_] = ld_agent_u32(scratch + 1 + 2 * s_);
+        sen[s_] = ld_agent_u32(scratch + 2 + 2 * s_);
+    }
+    __syncthreads();
+    if (tid != 0) return;
     unsigned prev_end = 0;
     bool have_prev = false;
     unsigned long long ex[PROF_KINDS] = {}, pe[PROF_KINDS] = {}, cn[PROF_KINDS] = {};
-    for (int s_ = 0; s_ < n; ++s_) {
-        const unsigned st = ld_agent_u32(scratch + 1 + 2 * s_), en = ld_agent_u32(scratch + 2 + 2 * s_);
+    for (int s_ = 0; s_ < n && s_ < MAXS; ++s_) {
+        const unsigned st = sst[s_], en = sen[s_];
         if (!(st & 1u)) continue;
         const int kind = s_ < 5 * layers ? s_ % 5 : 5;
         const unsigned e_ = en - (st & ~1u);
