@@ -275,16 +275,17 @@ __global__ __launch_bounds__(256) void stamp_accumulate_kernel(unsigned* stamps,
         hi = -0x7fffffff;
     }
     __syncthreads();
+    // all loads first (one 8-byte load per entry, issued back to back), then the re-zeroing stores: a store that depends on its own
+    // load serialises the eight round trips of a thread
+    u32x2 tt[STAMP_WGS / 256];
+#pragma unroll
+    for (int i = 0; i < STAMP_WGS / 256; ++i) tt[i] = ld8(slot + 2 * (i * 256 + tid));
     unsigned t0[STAMP_WGS / 256], t1[STAMP_WGS / 256];
 #pragma unroll
     for (int i = 0; i < STAMP_WGS / 256; ++i) {
-        const int w = i * 256 + tid;
-        t0[i] = slot[2 * w];
-        t1[i] = slot[2 * w + 1];
-        if (t0[i] | t1[i]) {
-            slot[2 * w] = 0;
-            slot[2 * w + 1] = 0;
-        }
+        t0[i] = tt[i][0];
+        t1[i] = tt[i][1];
+        if (t0[i] | t1[i]) st8(slot + 2 * (i * 256 + tid), u32x2{0u, 0u});
         if (t0[i] != 0 && t1[i] != 0) ref = t0[i];   // any valid entry serves as the reference (benign race: all are valid)
     }
     __syncthreads();
