@@ -269,9 +269,11 @@ REL_TOL_VS_FP32 = 4.0e-2
 def test_full_size_7b_c2():
     """BASELINE configs[1] AS WRITTEN: VCoder-DS 7b, all 32 decoder + 23 ViT layers, the C2 prompt, B = 8, 128 greedy tokens —
     lone call, 4 concurrent calls through the decode pool (what bench.py's `value` measures), split mode, strict mode; fp32
-    oracle teacher-forced on rows {0, 7}."""
+    oracle teacher-forced on rows {0, 7} with the split ids AND on row 0 with the bf16 path's own ids: the benchmarked kernels are
+    compared with the oracle DIRECTLY at full size (round 4 compared them with the device's split path to save the third oracle
+    row; the 13b case still does)."""
     cfg = vcfg.vicuna_7b("vcoder_ds")
-    r = run_case(cfg, B=8, n_new=128, seed=42, oracle_rows=(0, 7), checkpoints=(2, 8, 16, 32), strict_tokens=8, fast_vs="split")
+    r = run_case(cfg, B=8, n_new=128, seed=42, oracle_rows=(0, 7), checkpoints=(2, 8, 16, 32), strict_tokens=8, fast_vs="oracle")
     assert r["err32"].max() < REL_TOL_VS_FP32 * max(1.0, r["scale"])
     assert r["e_split"] < 1e-3
 
