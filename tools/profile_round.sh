@@ -18,6 +18,7 @@ cd /tmp
 timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o ks -- python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extra-legs > $OUT/${TAG}_trace_bench.json 2> $OUT/${TAG}_trace.err
 DB=$(find $OUT/${TAG}_trace -name "*.db" | head -1)
 python $ROOT/tools/rocpd_summary.py "$DB" $OUT/${TAG}_kernel_stats_pooled.md > /dev/null 2>> $OUT/${TAG}_trace.err
+python $ROOT/tools/rocpd_overlap.py "$DB" $OUT/${TAG}_alone_vs_corun_pooled.md > /dev/null 2>> $OUT/${TAG}_trace.err
 rm -rf $OUT/${TAG}_trace
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace1 -o ks -- python $ROOT/bench.py --steps 1 --warmup 1 --inflight 1 --no-cpu-baseline --no-extra-legs > $OUT/${TAG}_trace1_bench.json 2> $OUT/${TAG}_trace1.err
 DB=$(find $OUT/${TAG}_trace1 -name "*.db" | head -1)
@@ -41,5 +42,6 @@ rm -rf $OUT/${TAG}_pmc
 timeout 300 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d $OUT/${TAG}_pmcsq -o pmcsq -- python $ROOT/tools/kbench.py gemm attn gemm_f8 > $OUT/${TAG}_pmcsq_kbench.txt 2> $OUT/${TAG}_pmcsq.err
 DB3=$(find $OUT/${TAG}_pmcsq -name "*.db" | head -1)
 python $ROOT/tools/pmc_summary.py "$DB3" > $OUT/${TAG}_pmc_sq_summary.txt 2>> $OUT/${TAG}_pmcsq.err
+python $ROOT/tools/pmc_mfma_busy.py $OUT/${TAG}_pmc_sq_summary.txt $OUT/${TAG}_mfma_busy.md > /dev/null 2>> $OUT/${TAG}_pmcsq.err
 rm -rf $OUT/${TAG}_pmcsq
 head -14 $OUT/${TAG}_kernel_stats_pooled.md; tail -30 $OUT/${TAG}_pmc_summary.txt
