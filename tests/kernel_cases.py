@@ -1014,8 +1014,8 @@ def check_gemm_split(be, M, N, K, epi, bias=True, seed=0, ws_mb=0, pad=64, wlo=F
     return e
 
 
-def check_gemm_split_wlo(be, M, N, K, epi, seed=0):
-    return check_gemm_split(be, M, N, K, epi, bias=epi != 5, seed=seed, wlo=True)
+def check_gemm_split_wlo(be, M, N, K, epi, seed=0, ws_mb=0):
+    return check_gemm_split(be, M, N, K, epi, bias=epi != 5, seed=seed, wlo=True, ws_mb=ws_mb)
 
 
 def check_weight_planes(be, n=5000, seed=0):

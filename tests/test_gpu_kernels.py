@@ -243,6 +243,7 @@ def test_weight_lo_plane_kernels(be):
     kc.check_gemm_split_wlo(be, 2432, 4096, 11008, 4, seed=2)       # down: RESID, odd tile count
     kc.check_gemm_split_wlo(be, 1216, 22016, 4096, 5, seed=3)       # gate/up: SwiGLU with stacked hi / lo output
     kc.check_gemm_split_wlo(be, 577, 1024, 1024, 3, seed=4)         # ViT shape (128^2 DMA kernel)
+    kc.check_gemm_split_wlo(be, 9728, 12288, 4096, 3, seed=5, ws_mb=64)   # B = 8 prefill rows: split-K remainder round over the three segments
     kc.check_gemm_f32_wlo(be, 70, 512, 1024, 3)
     for (M, N, K, epi, G, ks) in [(8, 12288, 4096, 1, 8, 0), (16, 22016, 4096, 3, 16, 0), (32, 4096, 11008, 2, 32, 0),
                                   (29, 32000, 4096, 1, 32, 0), (24, 4096, 4096, 2, 24, 0)]:

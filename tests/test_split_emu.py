@@ -74,6 +74,7 @@ def test_weight_lo_plane_kernels(be):
         kc.check_gemm_split_wlo(be, 70, 136, 128, epi, seed=epi)                 # 128^2 DMA kernel
     kc.check_gemm_split_wlo(be, 1030, 520, 192, 3, seed=7)                       # 8-phase kernel, ragged M / N
     kc.check_gemm_split_wlo(be, 1024, 512, 64, 4, seed=8)                        # one weight k-tile per segment
+    kc.check_gemm_split_wlo(be, 1024, 16640 - 8, 64, 3, seed=9, ws_mb=4)         # split-K remainder round over the three segments
     kc.check_gemm_f32_wlo(be, 33, 96, 100, 3)
     for (M, N, K, epi, G, ks) in [(5, 64, 256, 1, 8, 0), (13, 48, 320, 2, 16, 0), (29, 96, 576, 3, 32, 0), (32, 64, 1024, 1, 32, 4),
                                   (21, 80, 384, 0, 24, 2)]:
