@@ -83,6 +83,10 @@ int vc_model_synth_tensor(vc_model* m, const char* hf_key, const int64_t* shape,
 int vc_model_set_batch_invariant(vc_model* m, int on);
 /* weight format 2 ("fp8"): KV cache of the decode steps in e4m3 (default 1) or bf16 (0).  Before vc_model_finalize. */
 int vc_model_set_fp8_kv(vc_model* m, int on);
+/* vc_model_synth_tensor with the value classes of the reference's checkpoints: rounding 0 bf16, 1 fp16-valued, 2 unrounded fp32
+ * (vcoder_amd/synth.py synth_tensor(rounding=...)); 1 and 2 take the fp32 load path and keep weight lo planes */
+int vc_model_synth_tensor_rounded(vc_model* m, const char* hf_key, const int64_t* shape, int ndim, uint32_t tensor_seed, float offset,
+                                  float halfwidth, int rounding);
 int vc_model_finalize(vc_model* m);
 /* Number of loaded tensors whose fp32 source held values bf16 cannot represent — the reference's own checkpoints: an fp16 LLM
  * (model/builder.py:25-40, torch_dtype=float16) and an fp32 CLIP hub checkpoint (multimodal_encoder/clip_encoder.py:22-27).  Every

@@ -196,6 +196,9 @@ void vck_attention_decode_kv8(const uint16_t* qkv, uint8_t* k, uint8_t* v, uint1
 /* deterministic synthetic tensors (vcoder_amd/synth.py) and dtype converts */
 void vck_synth_bf16(uint16_t* out, uint64_t n, uint32_t tseed, float offset, float halfwidth, void* stream);
 void vck_synth_f32(float* out, uint64_t n, uint32_t tseed, float offset, float halfwidth, void* stream);
+/* the generator's value before the bf16 rounding, as an fp16 checkpoint holds it (rounding 1) or unrounded fp32 (2):
+ * vcoder_amd/synth.py synth_tensor(rounding="fp16" | "fp32") */
+void vck_synth_f32_rounded(float* out, uint64_t n, uint32_t tseed, float offset, float halfwidth, int rounding, void* stream);
 void vck_f32_to_bf16(const float* in, uint16_t* out, uint64_t n, void* stream);
 void vck_bf16_to_f32(const uint16_t* in, float* out, uint64_t n, void* stream);
 

@@ -574,6 +574,13 @@ def check_synth(be, name="model.layers.3.mlp.up_proj.weight", n=5000):
     be.sync()
     assert np.array_equal(be.host_f32(ob), synth.synth_tensor(name, (n,), 42, 0.0, hw))
     assert np.array_equal(be.host_f32(of), synth.synth_tensor(name, (n,), 42, 1.0, 0.1))
+    # the value classes of the reference's checkpoints: fp16-valued (normal range, and a width that reaches fp16 subnormals) / fp32
+    for rounding, off, w in (("fp16", 0.0, hw), ("fp16", 0.0, 1e-4), ("fp16", 1.0, 0.1), ("fp32", 0.0, hw)):
+        o = be.zeros((n,), "f32")
+        lib.vck_synth_f32_rounded(be.ptr(o), ctypes.c_uint64(n), ctypes.c_uint32(ts), ctypes.c_float(off), ctypes.c_float(w),
+                                  synth.ROUNDING_CODE[rounding], None)
+        be.sync()
+        assert np.array_equal(be.host_f32(o), synth.synth_tensor(name, (n,), 42, off, w, rounding)), (rounding, off, w)
 
 
 # ---- fused decode-step kernels ------------------------------------------------------------------------------------

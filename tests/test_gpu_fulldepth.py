@@ -36,7 +36,9 @@ class LazyState(dict):
         return dict.__getitem__(self, k).float()
 
 
-def device_state_dict(eng, cfg, seed, prefixes=None):
+def device_state_dict(eng, cfg, seed, prefixes=None, dtypes="bf16"):
+    """the seeded checkpoint regenerated on the device and copied back in its own value class: bf16, or (dtypes="reference") fp16 for
+    the LLM / projector tensors and fp32 for the CLIP tower — exactly the values vc_model_synth_tensor_rounded loaded"""
     dev = torch.device("cuda:0")
     sd = LazyState()
     for key, shape, off, hw in synth.tensor_specs(cfg):
@@ -45,6 +47,19 @@ def device_state_dict(eng, cfg, seed, prefixes=None):
         if "depth_mm_projector" in key or "mm2_projector" in key or "vcoder_lm_emb" in key:
             continue                      # dead at inference: the oracle never reads them
         n = int(np.prod(shape))
+        if dtypes == "reference":
+            rounding = synth.reference_rounding(key)
+            buf = torch.empty(n, dtype=torch.float32, device=dev)
+            eng.lib.vck_synth_f32_rounded(ctypes.c_void_p(buf.data_ptr()), ctypes.c_uint64(n), ctypes.c_uint32(synth.tensor_seed(key, seed)),
+                                          ctypes.c_float(off), ctypes.c_float(hw), synth.ROUNDING_CODE[rounding], None)
+            torch.cuda.synchronize()
+            host = buf.cpu()
+            if rounding == "fp16":
+                h16 = host.to(torch.float16)
+                assert torch.equal(h16.float(), host), f"{key}: not fp16-representable"
+                host = h16                                  # exact, half the host memory
+            dict.__setitem__(sd, key, host.reshape(shape))
+            continue
         buf = torch.empty(n, dtype=torch.int16, device=dev)
         eng.lib.vck_synth_bf16(ctypes.c_void_p(buf.data_ptr()), ctypes.c_uint64(n), ctypes.c_uint32(synth.tensor_seed(key, seed)),
                                ctypes.c_float(off), ctypes.c_float(hw), None)
@@ -122,7 +137,7 @@ def _concurrent(root, n_calls, fn):
 
 
 def run_case(cfg, B, n_new, seed, oracle_rows, checkpoints, strict_tokens, split=True, pooled_calls=4, lib=None,
-             fast_vs="oracle"):
+             fast_vs="oracle", dtypes="bf16"):
     """The FULL-SIZE call of a BASELINE configuration (B sequences of the C2 prompt, n_new greedy tokens, every layer) on the
     device in its precision modes, checked against ONE teacher-forced fp32 oracle pass over the rows `oracle_rows`:
 
@@ -143,8 +158,9 @@ def run_case(cfg, B, n_new, seed, oracle_rows, checkpoints, strict_tokens, split
     assert fast_vs in ("oracle", "split") and (split or fast_vs == "oracle")
     t0 = time.time()
     eng = HipEngine(cfg, lib=lib)
-    eng.load_synthetic(seed)
+    eng.load_synthetic(seed, dtypes=dtypes)      # "reference": fp16-valued LLM, fp32-valued tower -> weight lo planes
     eng.finalize()
+    assert (eng.inexact_tensors() > 0) == (dtypes == "reference")
     ids = np.stack([synth.synth_prompt_ids(cfg.vocab_size, "vcoder_ds", sample=b) for b in range(B)])
     imgs, segs, deps = synth.synth_batch(B, cfg.vit_image_size)
     rows = list(oracle_rows)
@@ -188,7 +204,8 @@ def run_case(cfg, B, n_new, seed, oracle_rows, checkpoints, strict_tokens, split
     strict_logits, strict_ids = np.stack(s_steps, 1), np.stack(s_toks, 1)
     eng.set_precision("bf16")
     t_dev = time.time() - t0
-    sd = device_state_dict(eng, cfg, seed) if lib is None else cpu_ref.as_torch_state(synth.synth_state_dict(cfg, seed))
+    sd = (device_state_dict(eng, cfg, seed, dtypes=dtypes) if lib is None
+          else cpu_ref.as_torch_state(synth.synth_state_dict(cfg, seed, dtypes=dtypes)))
     eng.close()
     t_sd = time.time() - t0 - t_dev
     # ---- ONE fp32 oracle pass (= the reference's CPU path): the oracle rows forced with the split ids, then oracle_rows[0]
@@ -276,6 +293,21 @@ def test_full_size_7b_c2():
     r = run_case(cfg, B=8, n_new=128, seed=42, oracle_rows=(0, 7), checkpoints=(2, 8, 16, 32), strict_tokens=8, fast_vs="oracle")
     assert r["err32"].max() < REL_TOL_VS_FP32 * max(1.0, r["scale"])
     assert r["e_split"] < 1e-3
+
+
+def test_full_depth_7b_inexact_checkpoint():
+    """VCoder-DS 7b at FULL depth (32 decoder + 23 ViT layers, the C2 prompt) on a checkpoint with the value classes of the
+    reference's own — fp16-valued LLM / projector tensors (model/builder.py:25-40 loads torch_dtype=float16), an fp32-valued CLIP
+    tower (multimodal_encoder/clip_encoder.py:22-27) — generated on the device (vc_model_synth_tensor_rounded), which bf16 cannot
+    hold: every matrix keeps a lo plane.  B = 2, 16 greedy tokens: SPLIT mode (three-segment prefill GEMMs, lo-plane decode GEMV)
+    and STRICT mode against the fp32 oracle on the SAME values, 1e-3 absolute, ids identical at every step; the bf16 path (which
+    rounds the weights) against the split path for the record."""
+    cfg = vcfg.vicuna_7b("vcoder_ds")
+    r = run_case(cfg, B=2, n_new=16, seed=43, oracle_rows=(0, 1), checkpoints=(), strict_tokens=4, split=True, pooled_calls=1,
+                 fast_vs="split", dtypes="reference")
+    assert r["e_split"] < 1e-3 and r["e_strict"] < 1e-3
+    print(f"    bf16 path on the inexact checkpoint vs the split path: |dlogit|max {r['err32'].max():.4f} (rel {r['err32'].max() / r['scale']:.2e})")
+    assert r["err32"].max() < 2 * REL_TOL_VS_FP32 * max(1.0, r["scale"])
 
 
 def test_full_size_13b_c3():

@@ -57,6 +57,8 @@ def declare(lib: C.CDLL) -> C.CDLL:
     lib.vc_model_destroy.restype = None
     lib.vc_model_load_tensor.argtypes = [vp, C.c_char_p, vp, i32, i64p, i32]
     lib.vc_model_synth_tensor.argtypes = [vp, C.c_char_p, i64p, i32, C.c_uint32, C.c_float, C.c_float]
+    lib.vc_model_synth_tensor_rounded.argtypes = [vp, C.c_char_p, i64p, i32, C.c_uint32, C.c_float, C.c_float, i32]
+    lib.vc_model_synth_tensor_rounded.restype = C.c_int
     lib.vc_model_finalize.argtypes = [vp]
     lib.vc_model_set_precision.argtypes = [vp, i32]
     lib.vc_model_set_precision.restype = C.c_int

@@ -2108,6 +2108,29 @@ VC_API int vc_model_synth_tensor(vc_model* m, const char* hf_key, const int64_t*
     GUARD_END(m->ctx)
 }
 
+/* The same generator with the value classes of the reference's own checkpoints: rounding 0 = bf16 (vc_model_synth_tensor), 1 = the
+ * value an fp16 checkpoint holds, 2 = unrounded fp32 (vcoder_amd/synth.py synth_tensor(rounding=...)).  1 and 2 go through the fp32
+ * load path, i.e. keep weight lo planes (vc_model_inexact_tensors). */
+VC_API int vc_model_synth_tensor_rounded(vc_model* m, const char* hf_key, const int64_t* shape, int ndim, uint32_t tensor_seed,
+                                         float offset, float halfwidth, int rounding) {
+    if (!m) return VC_ERR_INVALID;
+    if (rounding == 0) return vc_model_synth_tensor(m, hf_key, shape, ndim, tensor_seed, offset, halfwidth);
+    int rc = VC_OK;
+    GUARD_BEGIN
+    USE_DEVICE(m->ctx);
+    REQUIRE(hf_key && shape && ndim >= 1 && ndim <= 8 && (rounding == 1 || rounding == 2), VC_ERR_INVALID, "bad synth_tensor arguments");
+    REQUIRE(!m->finalized, VC_ERR_STATE, "model already finalized");
+    size_t numel = 1;
+    for (int i = 0; i < ndim; ++i) numel *= (size_t)shape[i];
+    REQUIRE(numel < ((size_t)1 << 32), VC_ERR_INVALID, "tensor too large for the 32-bit generator");
+    m->stage.ensure(numel * 4);
+    launch_synth_f32_rounded(m->stage.as<float>(), numel, tensor_seed, offset, halfwidth, rounding, m->st);
+    rc = place_tensor(m, hf_key, m->stage.p, VC_F32, shape, ndim);
+    HIPCHK(hipStreamSynchronize(m->st));
+    if (rc != VC_OK) return rc;
+    GUARD_END(m->ctx)
+}
+
 /* 0: bf16 MFMA path (default, benchmarked); 1: strict fp32 path (fp32 activations + fp32 MFMA, ~1e-6 from the fp32 CPU
  * reference; slow).  Takes effect at the next prefill. */
 VC_API int vc_model_set_precision(vc_model* m, int mode) {

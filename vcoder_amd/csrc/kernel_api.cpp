@@ -159,6 +159,9 @@ VCK_EXPORT void vck_advance(int* step_dev, int* pos_dev, int* ctx_dev, void* str
 VCK_EXPORT void vck_synth_bf16(uint16_t* out, uint64_t n, uint32_t tseed, float offset, float halfwidth, void* stream) {
     launch_synth_bf16(out, (size_t)n, tseed, offset, halfwidth, S(stream));
 }
+VCK_EXPORT void vck_synth_f32_rounded(float* out, uint64_t n, uint32_t tseed, float offset, float halfwidth, int rounding, void* stream) {
+    launch_synth_f32_rounded(out, (size_t)n, tseed, offset, halfwidth, rounding, S(stream));
+}
 VCK_EXPORT void vck_synth_f32(float* out, uint64_t n, uint32_t tseed, float offset, float halfwidth, void* stream) {
     launch_synth_f32(out, (size_t)n, tseed, offset, halfwidth, S(stream));
 }

@@ -421,6 +421,8 @@ void launch_crop_normalize(const uint8_t* in, int in_h, int in_w, int top, int l
 // ---- misc ---------------------------------------------------------------------------------------
 void launch_synth_bf16(bf16_t* out, size_t n, uint32_t tseed, float offset, float halfwidth, hipStream_t s);
 void launch_synth_f32(float* out, size_t n, uint32_t tseed, float offset, float halfwidth, hipStream_t s);
+// the unrounded generator value, as fp16-representable (rounding 1) or fp32 (2): synth.py synth_tensor(rounding="fp16" | "fp32")
+void launch_synth_f32_rounded(float* out, size_t n, uint32_t tseed, float offset, float halfwidth, int rounding, hipStream_t s);
 constexpr int ROW_SUM_PARTS = 32;  // out: [rows][ROW_SUM_PARTS] partial sums
 void launch_row_sum(const float* x, size_t n_per_row, int rows, float* out, hipStream_t s);
 // rows of one layer's K or V cache permuted in place through `tmp`: row r <- old row perm[r], live prefix only (beam search)

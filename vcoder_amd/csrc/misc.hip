@@ -118,10 +118,40 @@ __global__ __launch_bounds__(256) void synth_f32_kernel(float* out, size_t n, ui
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
         out[i] = synth_value((uint32_t)i, tseed, offset, scale);
 }
+// the same generator with the value classes of the reference's own checkpoints (vcoder_amd/synth.py synth_tensor(rounding=...)):
+// rounding 1 = the value an fp16 checkpoint holds (RNE to 11 significant bits, fp16 range / subnormals), 2 = unrounded fp32
+VC_DEV float round_to_fp16(float v) {
+    // RNE to fp16 and back, in integer arithmetic (identical on the device and the emulator): normal range 2^-14 .. 65504,
+    // subnormals in steps of 2^-24
+    const float a = fabsf(v);
+    if (a >= 65520.f) return v < 0 ? -INFINITY : INFINITY;
+    float q;
+    if (a < 6.103515625e-05f) {                                  // subnormal: multiples of 2^-24
+        q = rintf(a * 16777216.f) * 5.9604644775390625e-08f;
+    } else {
+        uint32_t u = __builtin_bit_cast(uint32_t, a);
+        u = (u + 0x00000FFFu + ((u >> 13) & 1u)) & 0xFFFFE000u;   // 23 -> 10 mantissa bits, ties to even
+        q = __builtin_bit_cast(float, u);
+    }
+    return v < 0 ? -q : q;
+}
+__global__ __launch_bounds__(256) void synth_f32_rounded_kernel(float* out, size_t n, uint32_t tseed, float offset, float scale, int rounding) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        uint32_t x = (uint32_t)i * 0x9E3779B1u + tseed;
+        x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+        const float u = (float)(x >> 8);
+        float v = __fmul_rn(u - 8388607.5f, scale);
+        if (offset != 0.f) v = __fadd_rn(v, offset);
+        out[i] = rounding == 1 ? round_to_fp16(v) : v;
+    }
+}
 static unsigned grid_for(size_t n) { return (unsigned)min((size_t)8192, (n + 255) / 256); }
 void launch_synth_bf16(bf16_t* out, size_t n, uint32_t tseed, float offset, float halfwidth, hipStream_t s) {
     VC_LAUNCH(synth_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, s, out, n, tseed, offset,
               (float)(halfwidth / 8388608.0));
+}
+void launch_synth_f32_rounded(float* out, size_t n, uint32_t tseed, float offset, float halfwidth, int rounding, hipStream_t s) {
+    VC_LAUNCH(synth_f32_rounded_kernel, dim3(grid_for(n)), dim3(256), 0, s, out, n, tseed, offset, (float)(halfwidth / 8388608.0), rounding);
 }
 void launch_synth_f32(float* out, size_t n, uint32_t tseed, float offset, float halfwidth, hipStream_t s) {
     VC_LAUNCH(synth_f32_kernel, dim3(grid_for(n)), dim3(256), 0, s, out, n, tseed, offset,

@@ -131,13 +131,16 @@ class HipEngine:
                 dead += 1
         return used, dead
 
-    def load_synthetic(self, seed: int = 42):
-        """Seeded synthetic checkpoint generated ON THE DEVICE, bit-identical to synth.synth_state_dict."""
+    def load_synthetic(self, seed: int = 42, dtypes: str = "bf16"):
+        """Seeded synthetic checkpoint generated ON THE DEVICE, bit-identical to synth.synth_state_dict(cfg, seed, dtypes=dtypes):
+        "bf16" (default), or "reference" — fp16-valued LLM / projector tensors and an fp32-valued CLIP tower, the value classes of
+        the reference's own checkpoints, which keep weight lo planes (inexact_tensors() > 0)."""
         for key, shape, off, hw in synth.tensor_specs(self.cfg):
             sh = (C.c_int64 * len(shape))(*shape)
-            self._check(self.lib.vc_model_synth_tensor(self._model, key.encode(), sh, len(shape),
-                                                       C.c_uint32(synth.tensor_seed(key, seed)), C.c_float(off),
-                                                       C.c_float(hw)))
+            rounding = 0 if dtypes == "bf16" else synth.ROUNDING_CODE[synth.reference_rounding(key)]
+            self._check(self.lib.vc_model_synth_tensor_rounded(self._model, key.encode(), sh, len(shape),
+                                                               C.c_uint32(synth.tensor_seed(key, seed)), C.c_float(off),
+                                                               C.c_float(hw), rounding))
 
     def set_precision(self, mode: str):
         """'bf16' (default: bf16 MFMA operands, what the benchmark runs); 'strict' (fp32 activations on fp32 MFMA —

@@ -188,6 +188,14 @@ def projector_depth(ptype: str) -> int:
     raise ValueError(f"Unknown projector type: {ptype}")
 
 
+ROUNDING_CODE = {"bf16": 0, "fp16": 1, "fp32": 2}   # vc_model_synth_tensor_rounded / vck_synth_f32_rounded
+
+
+def reference_rounding(key: str) -> str:
+    """the value class a tensor has in the reference's own checkpoints: the CLIP tower fp32 (hub checkpoint), everything else fp16"""
+    return "fp32" if "vision_tower" in key else "fp16"
+
+
 def synth_state_dict(cfg, seed: int = 42, only_prefix: str | None = None, dtypes: str = "bf16") -> Dict[str, np.ndarray]:
     """dtypes="bf16": every value bf16-representable (the default checkpoint of the tests and the benchmark).
     dtypes="reference": the value classes of the reference's own checkpoints — the LLM, its head, embeddings and the projectors
@@ -198,9 +206,7 @@ def synth_state_dict(cfg, seed: int = 42, only_prefix: str | None = None, dtypes
     for key, shape, off, hw in tensor_specs(cfg):
         if only_prefix is not None and not key.startswith(only_prefix):
             continue
-        rounding = "bf16"
-        if dtypes == "reference":
-            rounding = "fp32" if "vision_tower" in key else "fp16"
+        rounding = reference_rounding(key) if dtypes == "reference" else "bf16"
         out[key] = synth_tensor(key, shape, seed, off, hw, rounding)
     return out
 
