@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5, call J: the whole -m gpu suite on the current tree + smoke + the default bench line (with the extra legs).
 cd "$GRAFT_REPO_ROOT" || exit 1
-ROOT=$GRAFT_REPO_ROOT; O=$ROOT/gpurun_out; T=r05_j
+ROOT=$GRAFT_REPO_ROOT; O=$ROOT/gpurun_out; T=${TAG:-r05_j}
 mkdir -p $O
 timeout 1500 python -m pytest tests -q -x -m gpu 2>&1 | tail -6 | tee $O/${T}_gpu_suite.txt
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $O/${T}_smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/${T}_smoke.log
