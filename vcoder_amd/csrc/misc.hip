@@ -101,13 +101,20 @@ void launch_advance(int* step_dev, int* pos_dev, int* ctx_dev, hipStream_t s) {
 }
 
 // ---- synthetic checkpoint generator: bit-identical to vcoder_amd/synth.py:synth_tensor ----------------
-VC_DEV float synth_value(uint32_t idx, uint32_t tseed, float offset, float scale) {
+// (`__fmul_rn` / `__fadd_rn` are plain `*` / `+` in this ROCm's headers, and HIP compiles with -ffp-contract=fast: without the
+// pragma the multiply-add below is ONE fma — one rounding where vcoder_amd/synth.py (numpy) has two: the fp32 values with an offset
+// differed by an ulp in 5 % of the elements (found by the fp16 / fp32 value classes of round 5; the bf16 class rounds it away))
+VC_DEV float synth_value_f32(uint32_t idx, uint32_t tseed, float offset, float scale) {
+#pragma clang fp contract(off)
     uint32_t x = idx * 0x9E3779B1u + tseed;
     x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
     const float u = (float)(x >> 8);
-    float v = __fmul_rn(u - 8388607.5f, scale);
-    if (offset != 0.f) v = __fadd_rn(v, offset);
-    return bf2f(f2bf(v));
+    float v = (u - 8388607.5f) * scale;
+    if (offset != 0.f) v = v + offset;
+    return v;
+}
+VC_DEV float synth_value(uint32_t idx, uint32_t tseed, float offset, float scale) {
+    return bf2f(f2bf(synth_value_f32(idx, tseed, offset, scale)));
 }
 __global__ __launch_bounds__(256) void synth_bf16_kernel(bf16_t* out, size_t n, uint32_t tseed, float offset,
                                                          float scale) {
@@ -137,11 +144,7 @@ VC_DEV float round_to_fp16(float v) {
 }
 __global__ __launch_bounds__(256) void synth_f32_rounded_kernel(float* out, size_t n, uint32_t tseed, float offset, float scale, int rounding) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        uint32_t x = (uint32_t)i * 0x9E3779B1u + tseed;
-        x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
-        const float u = (float)(x >> 8);
-        float v = __fmul_rn(u - 8388607.5f, scale);
-        if (offset != 0.f) v = __fadd_rn(v, offset);
+        const float v = synth_value_f32((uint32_t)i, tseed, offset, scale);
         out[i] = rounding == 1 ? round_to_fp16(v) : v;
     }
 }
