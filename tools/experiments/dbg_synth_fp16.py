@@ -1,3 +1,7 @@
+"""Round 5 debugging aid: the device generator of the fp16- / fp32-valued checkpoint classes (vck_synth_f32_rounded) against
+vcoder_amd/synth.py (numpy) over 2^20 elements of an offset tensor.  It found that hipcc contracted the generator's multiply-add
+into one fma (-ffp-contract=fast; __fmul_rn / __fadd_rn are plain operators in this ROCm): 5 % of the fp32 values were an ulp off
+numpy's.  Fixed with `#pragma clang fp contract(off)` in csrc/misc.hip synth_value_f32; prints 0 / 0 mismatches since."""
 import sys, ctypes, numpy as np
 sys.path[:0] = ['/root/repo', '/root/repo/oracle', '/root/repo/tests']
 import kernel_cases as kc
