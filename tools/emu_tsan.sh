@@ -2,7 +2,7 @@
 # TEST TOOL: the host engine's threads under ThreadSanitizer.  Builds the emulator library with csrc/engine.hip TSan-instrumented
 # and a C++ stress harness on the C ABI (tools/emu_tsan/stress.cpp: concurrent generate() calls of several sessions through the
 # decode pool, each result compared with the lone call), and runs it WITHOUT Python in the process.
-# usage: tools/emu_tsan.sh [sessions] [calls per session]
+# usage: tools/emu_tsan.sh [sessions] [calls per session]      (round 5, with the pool's hold policy: 4 x 3 calls, no report)
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 CXX=${CXX:-/opt/rocm/lib/llvm/bin/clang++}
