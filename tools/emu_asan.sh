@@ -3,7 +3,7 @@
 # AddressSanitizer.  Builds a variant of the emulator library in which engine.hip is ASan-instrumented (the kernels run on the
 # emulator's own lane fibers and stay uninstrumented: their stack switching is not something ASan follows) and runs the engine /
 # pool / fuzz / split tests against it.  usage: tools/emu_asan.sh [pytest args...]     (round 3: 48 tests, no report; round 5: 56 tests, no report)
-# VC_SAN=ubsan: UndefinedBehaviorSanitizer (minimal runtime) instead — reports print as "ubsan: <kind>" lines (round 3: none).
+# VC_SAN=ubsan: UndefinedBehaviorSanitizer (minimal runtime) instead — reports print as "ubsan: <kind>" lines (rounds 3 and 5: none).
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 CXX=${CXX:-/opt/rocm/lib/llvm/bin/clang++}
