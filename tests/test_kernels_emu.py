@@ -173,8 +173,6 @@ def test_alternate_kernel_variants():
         # tile-order knobs of the GEMM (8-phase kernel forced onto every small, ragged, 1-3 k-tile case; split-K rounds
         # of the bf16 and the e4m3 form)
         (dict(VC_GEMM_VARIANT="5"), "test_gemm"),
-        # deeper load windows of the decode attention
-        (dict(VC_DATTN_UK="16"), "test_fused_decode"),
         # 2: the one-barrier 256x256 kernel; 4: 256x256 as 4 waves x (128 x 128)
         (dict(VC_GEMM_VARIANT="2"), plain_gemm),
         (dict(VC_GEMM_VARIANT="4"), plain_gemm),

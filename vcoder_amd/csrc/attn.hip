@@ -857,8 +857,8 @@ __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeF
 
 void launch_attention_decode_fused(const AttnDecodeFusedArgs& a, hipStream_t s) {
     const dim3 grid(a.H, a.B), block(512);
-    // VC_DATTN_UK: row loads in flight per lane (tuning knob; 8 = 8 KiB per wave, two workgroups per CU)
-    static const int uk = getenv("VC_DATTN_UK") ? atoi(getenv("VC_DATTN_UK")) : 8;
+    // 8 row loads in flight per lane (8 KiB per wave, two workgroups per CU): 12 and 16 measured slower at every row count
+    // (profiles/r05_u_kbench_dattn_uk.txt: 32 rows 99.4 / 103.4 / 108.7 us) and their instantiations were removed in round 5
     if (a.kv32 == 3) {  // bf16 step over e4m3 caches (the fp8 weight format)
         // rows in flight per lane: 16 elements per load cost 16 + 16 query / accumulator registers; 8 rows took 156 VGPRs (one
         // workgroup per CU); 6 rows: 124 VGPRs, two workgroups per CU (profiles/r04_n_kbench_dattn_kv8_uk.txt)
@@ -881,9 +881,7 @@ void launch_attention_decode_fused(const AttnDecodeFusedArgs& a, hipStream_t s) 
         return;
     }
     if (a.hd == 128) {
-        if (uk == 12) VC_LAUNCH((attention_decode_fused_kernel<128, 12>), grid, block, 0, s, a);
-        else if (uk == 16) VC_LAUNCH((attention_decode_fused_kernel<128, 16>), grid, block, 0, s, a);
-        else VC_LAUNCH((attention_decode_fused_kernel<128, 8>), grid, block, 0, s, a);
+        VC_LAUNCH((attention_decode_fused_kernel<128, 8>), grid, block, 0, s, a);
     } else {
         VC_LAUNCH((attention_decode_fused_kernel<64, 8>), grid, block, 0, s, a);
     }
