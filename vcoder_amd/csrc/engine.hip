@@ -2813,7 +2813,7 @@ void pool_driver(vc_pool* p) {
             if (p->active.empty()) continue;
             if (p->root->pool_hold && p->prefilling > 0) {
                 // somebody is about to join: wait for its request (or for it to give up) rather than step without it
-                p->cv_driver.wait(lk, [&] { return p->stop || !p->pending.empty() || p->prefilling == 0; });
+                p->cv_driver.wait(lk, [&] { return p->stop || !p->pending.empty() || p->prefilling == 0 || !p->root->pool_hold; });
                 continue;
             }
             int top = 0;
