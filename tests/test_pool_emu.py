@@ -106,6 +106,47 @@ def test_pool_profile_counts_every_launch_and_changes_no_id(emu_lib):
     assert np.array_equal(root.generate_greedy(ids, imgs, segs, deps, max_new_tokens=6), plain)   # rebuilt without the slots
 
 
+def test_pool_hold_policy_changes_scheduling_not_ids(emu_lib):
+    """vc_pool_set_hold: with the policy on (default) the pool waits for a call that holds rows and is still prefilling instead of
+    stepping without it — fewer, fuller steps; off, it steps whatever is active.  Either way every request gets the ids of its own
+    session loop."""
+    names = ["ds_img_depth_seg", "ds_img_only", "ds_img_seg"]
+    root = e2e_cases.engine_for("vcoder_ds", emu_lib)
+    cases, refs = [], []
+    for n in names:
+        g, cfg, ids, imgs, segs, deps = e2e_cases.fixture_inputs(n)
+        cases.append((ids, imgs, segs, deps))
+        refs.append(session_loop_ids(root, ids, imgs, segs, deps, 5))
+    sessions = [root, root.fork(), root.fork()]
+    steps = {}
+    try:
+        for hold in (True, False):
+            root.pool_set_hold(hold)
+            s0 = root.pool_step_counts()
+            outs, errs = [None] * 3, []
+
+            def work(i):
+                try:
+                    outs[i] = sessions[i].generate_greedy(*cases[i], max_new_tokens=5)
+                except BaseException as e:
+                    errs.append(e)
+            ths = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+            assert not errs, errs
+            for i in range(3):
+                assert np.array_equal(outs[i], refs[i]), f"hold={hold}: request {i} differs from its session loop"
+            steps[hold] = sum(a - b for a, b in zip(root.pool_step_counts(), s0))
+        # three requests of 4 cached steps each: 4 steps when they all share every step, up to 12 when none do
+        assert 4 <= steps[True] <= 12 and 4 <= steps[False] <= 12, steps
+    finally:
+        root.pool_set_hold(True)
+        for s in sessions[1:]:
+            s.close()
+
+
 def test_pool_mixes_eos_stops_and_sampling(emu_lib):
     """Rows of one step with different generation parameters: an EOS request that ends early, a keyword-stop request, a
     sampled request and a plain greedy one, all in flight together; each equals its lone run."""
