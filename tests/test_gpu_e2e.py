@@ -956,6 +956,8 @@ def test_decode_pool_tiny():
     import test_pool_emu as tp
 
     tp.test_concurrent_requests_share_steps_and_keep_their_ids(None)
+    tp.test_pool_profile_counts_every_launch_and_changes_no_id(None)      # round 5: in-situ timing slots
+    tp.test_pool_hold_policy_changes_scheduling_not_ids(None)             # round 5: vc_pool_set_hold
     tp.test_pool_mixes_eos_stops_and_sampling(None)
     tp.test_pool_queues_requests_beyond_its_rows(None)
 

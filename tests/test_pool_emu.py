@@ -36,6 +36,9 @@ def test_concurrent_requests_share_steps_and_keep_their_ids(emu_lib):
     sessions = [root, root.fork(), root.fork()]
     outs = [[None] * 3 for _ in sessions]
     errs = []
+    # (a pool left behind by an earlier test in another mode — split, profiling — is rebuilt by the first call, which restarts its
+    # histogram: one warm call first)
+    root.generate_greedy(*cases[1], max_new_tokens=2)
     steps0 = root.pool_step_counts()
 
     def work(si):
