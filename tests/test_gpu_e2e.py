@@ -249,7 +249,7 @@ def test_inexact_checkpoint(name, mode):
 def test_inexact_checkpoint_true_dims():
     """The same at true 7b / ViT-L dims (2 + 2 layers): split and strict vs the fp32 oracle on the fp16- / fp32-valued weights
     (1e-3 absolute, ids equal), the split decode step through the lo-plane form of the workgroup-shared GEMV; the bf16 fast
-    path's deviation on the same checkpoint for the record."""
+    path on the same checkpoint: prefill within 1.7e-2 of |logit|max, its teacher-forced decode step within 4x its prefill's deviation."""
     import torch
     import cpu_ref
 
@@ -271,6 +271,12 @@ def test_inexact_checkpoint_true_dims():
         o_lg2 = om.decode_step(tok.tolist(), cache)
     fast_last, _, _ = eng.prefill(ids, imgs, segs, deps)
     ef = np.abs(fast_last - o_last[:, -1].numpy()).max()
+    fast_lg2, _ = eng.decode_step(tok)   # teacher-forced with the oracle's token: the bf16 path's cached step sees the oracle's prefix
+    ef2 = np.abs(fast_lg2 - o_lg2[:, -1].numpy()).max()
+    scale = float(np.abs(o_last.numpy()).max())
+    print(f"true-dims inexact checkpoint, bf16 path: prefill err={ef:.2e} decode err={ef2:.2e} of |logit|max {scale:.2f}")
+    # measured on MI355X: 5.6e-2 at |logit|max 6.58 = 8.5e-3 relative (3.4e-2 absolute on the bf16-exact checkpoint of the shape) -> 2x
+    assert ef < 1.7e-2 * scale and ef2 <= 4 * ef, (ef, ef2, scale)
     for mode in ("split", "strict"):
         eng.set_precision(mode)
         last, _, _ = eng.prefill(ids, imgs, segs, deps)

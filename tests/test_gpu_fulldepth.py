@@ -281,6 +281,7 @@ def run_case(cfg, B, n_new, seed, oracle_rows, checkpoints, strict_tokens, split
 # absolute), growing like sqrt(depth): 5.6e-3 @ 2 layers, 1.1e-2 @ 8, 1.35e-2 @ 16, 2.3e-2 @ 32.  Split and strict mode: 1e-3
 # ABSOLUTE (BASELINE.json), asserted inside run_case.
 REL_TOL_VS_FP32 = 4.0e-2
+REL_TOL_VS_FP32_INEXACT = 6.0e-2   # the same path on an fp16- / fp32-valued checkpoint (weights rounded to bf16 as well): 3.0e-2 measured
 
 
 def test_full_size_7b_c2():
@@ -307,7 +308,9 @@ def test_full_depth_7b_inexact_checkpoint():
                  fast_vs="split", dtypes="reference")
     assert r["e_split"] < 1e-3 and r["e_strict"] < 1e-3
     print(f"    bf16 path on the inexact checkpoint vs the split path: |dlogit|max {r['err32'].max():.4f} (rel {r['err32'].max() / r['scale']:.2e})")
-    assert r["err32"].max() < 2 * REL_TOL_VS_FP32 * max(1.0, r["scale"])
+    # measured on MI355X (profiles/r05_o_inexact_checkpoint_full_depth_7b.txt): 0.19 at |logit|max 6.42 = 3.0e-2 -> 2x (round 5
+    # asserted 2 x REL_TOL_VS_FP32 = 8e-2 without a measurement behind it)
+    assert r["err32"].max() < REL_TOL_VS_FP32_INEXACT * max(1.0, r["scale"])
 
 
 def test_full_size_13b_c3():
