@@ -63,6 +63,8 @@ def parse_args():
     ap.add_argument("--dump-ids", default=None, help="write the gathered ids of the last timed step to this .npy (tests)")
     ap.add_argument("--no-pool-hold", action="store_true",
                     help="pool policy A/B: step whatever rows are active even while another call is prefilling (vc_pool_set_hold(0))")
+    ap.add_argument("--no-qkv-fused", action="store_true",
+                    help="A/B: the prefill's QKV projection as the separate GEMM + split / RoPE launches of rounds 1-5 (vc_model_set_qkv_fused(0))")
     ap.add_argument("--no-insitu", action="store_true",
                     help="do not stamp the pool's decode-step launches (roofline then reports the isolated replay); A/B of the stamps' cost")
     ap.add_argument("--no-extra-legs", action="store_true",
@@ -457,6 +459,8 @@ def main():
         eng.pool_profile(True)
     if args.no_pool_hold:
         eng.pool_set_hold(False)
+    if args.no_qkv_fused:
+        eng.set_qkv_fused(0)
     sessions = [eng] + [eng.fork() for _ in range(n_sess - 1)]
 
     def run_steps(k: int, px):

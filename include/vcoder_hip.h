@@ -81,6 +81,11 @@ int vc_model_synth_tensor(vc_model* m, const char* hf_key, const int64_t* shape,
  * independent of the batch size; with it the ids of N ranks x B equal those of one rank x N B bit for bit.
  * Costs a short last round of tiles per GEMM.  Default 0.  Applies to every session of the model. */
 int vc_model_set_batch_invariant(vc_model* m, int on);
+/* Round 6: the prefill's QKV GEMM applies RoPE, splits the heads and writes Q / the KV-cache rows / the V^T scratch in its epilogue
+ * (replaces [HF] llama/modeling_llama.py:254-262 "q/k/v_proj -> view -> apply_rotary_pos_emb -> cache update" as ONE launch); default 1.
+ * 0 = the separate GEMM + split launches of rounds 1-5 (regression / A-B); 1 = fused from 1024 token rows (where the 256 x 256 GEMM
+ * kernel runs anyway); 2 = fused for every problem size.  Needs head_dim 128 and hidden_size % 256 == 0, else the separate launches. */
+int vc_model_set_qkv_fused(vc_model* m, int on);
 /* weight format 2 ("fp8"): KV cache of the decode steps in e4m3 (default 1) or bf16 (0).  Before vc_model_finalize. */
 int vc_model_set_fp8_kv(vc_model* m, int on);
 /* vc_model_synth_tensor with the value classes of the reference's checkpoints: rounding 0 bf16, 1 fp16-valued, 2 unrounded fp32

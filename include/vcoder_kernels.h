@@ -158,6 +158,18 @@ void vck_gemv_split_wlo(const uint16_t* X, const void* Wp, const void* Wp_lo, vo
 /* which kernel serves the decode GEMV of precision mode "split": 0 = per-wave rings (gemv_dma_kernel; two weight passes of 16
  * rows per 32-row step), 1 / -1 (default) = workgroup-shared activation chunks (gemv_wg_kernel; hi + lo planes in one pass) */
 void vck_set_gemv_variant(int v);
+/* K12 + K13 + K14 in one launch (round 6): the fused-QKV projection of a prefill layer whose epilogue applies RoPE, splits the heads
+ * and writes Q [B,H,q_stride,128], roped K rows and V rows [B,H,kv_stride,128] (and / or their e4m3 cache rows k8 / v8
+ * [B,H,kv8_stride,128]) and the V^T scratch [B,H,128,vt_stride] in the flash kernel's key order — bit for bit what vck_gemm
+ * (EPI_BF16) + vck_qkv_split_kv / _kv8 produce.  A [B * T, lda] bf16, W [3 * H * 128, K] bf16 (HF q / k / v rows stacked); f8 != 0:
+ * A and W are e4m3 bytes with a_scale [B * T] / w_scale [3 * H * 128].  (H * 128) % 256 == 0.  ws: optional split-K workspace. */
+void vck_gemm_qkv(const void* A, const float* a_scale, const void* W, const float* w_scale, const float* bias, int B, int T, int H, int K,
+                  int lda, uint16_t* q, uint16_t* k, uint16_t* v, uint16_t* vt, uint8_t* k8, uint8_t* v8, int q_stride, int kv_stride,
+                  int vt_stride, int kv8_stride, const float* rope_cos, const float* rope_sin, int f8, float* ws, size_t ws_bytes,
+                  void* stream);
+/* overrides VC_GEMM_VARIANT inside one process (< 0: back to the environment's value): 1 = default (8-phase 256 x 256 for large
+ * problems on v_mfma_f32_16x16x32_bf16), 6 = the same schedule on v_mfma_f32_32x32x16_bf16, 7 = that form for every size */
+void vck_set_gemm_variant(int v);
 /* NT = ceil(tiles / 256) tiles per workgroup for bf16 matrices of more than 512 tiles, one deep-ringed workgroup per CU (NT in
  * 3, 4, 6, 7): -1 / 1 = the classes that measured faster (default), 0 = off, 2 = every class.  Results are bit-identical
  * whichever is set. */

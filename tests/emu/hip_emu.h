@@ -244,6 +244,7 @@ inline float __fadd_rn(float a, float b) { return a + b; }
 
 namespace vc {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 inline int lane_id() { return vc_emu::g_cur->lane; }
@@ -327,6 +328,35 @@ inline f32x4 mfma16_f8(u32x4 a0, u32x4 a1, u32x4 b0, u32x4 b1, f32x4 c) {
             acc = (float)a2;
         } else {
             for (int k = 0; k < 128; ++k) acc += prod[k];
+        }
+        d[r] = c[r] + acc;
+    }
+    vc_emu::wave_sync();
+    return d;
+}
+
+// v_mfma_f32_32x32x16_bf16: A[i][k] in lane i + 32 (k / 8) elem k % 8, B likewise by column, D[i][j] in lane j + 32 ((i / 4) % 2),
+// reg i % 4 + 4 (i / 8)
+inline f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
+    auto& w = vc_emu::g_cur->blk->waves[vc_emu::g_cur->wave];
+    const int lane = vc_emu::g_cur->lane;
+    memcpy(w.xchg[lane], &a, 16);
+    memcpy(w.xchg[lane] + 16, &b, 16);
+    vc_emu::wave_sync();
+    const int j = lane & 31;
+    f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float acc = 0.f;
+        for (int k = 0; k < 16; ++k) {
+            uint16_t ab, bb;
+            memcpy(&ab, w.xchg[i + 32 * (k / 8)] + 2 * (k % 8), 2);
+            memcpy(&bb, w.xchg[j + 32 * (k / 8)] + 16 + 2 * (k % 8), 2);
+            uint32_t au = (uint32_t)ab << 16, bu = (uint32_t)bb << 16;
+            float af, bf;
+            memcpy(&af, &au, 4);
+            memcpy(&bf, &bu, 4);
+            acc += af * bf;
         }
         d[r] = c[r] + acc;
     }

@@ -501,6 +501,75 @@ def check_qkv_split(be, B, T, H, hd, rope):
     assert np.array_equal(be.host_f32(vt2), gv)
 
 
+def check_gemm_qkv_fused(be, B, T, H, K, bias=False, ws_mb=0, f8=False, kv8=False, seed=0):
+    """EPI_QKV (round 6): the QKV GEMM whose epilogue applies RoPE, splits the heads and writes Q, the K / V cache rows
+    (bf16 and / or e4m3) and the V^T scratch — against the two launches it replaces (vck_gemm EPI_BF16 + vck_qkv_split_kv / _kv8):
+    every output BIT FOR BIT, nothing written behind T, for sample lengths that are and are not multiples of 32 (padded token
+    rows), ragged last tiles, split-K remainder rounds, the e4m3 operand form."""
+    from vcoder_amd import quant
+
+    rng = np.random.RandomState(seed)
+    hd, D = 128, H * 128
+    M = B * T
+    A = bf16_round(rng.randn(M, K))
+    W = bf16_round(rng.randn(3 * D, K) * 0.05)
+    b = (rng.randn(3 * D) * 0.1).astype(np.float32) if bias else None
+    Ts = (T + 63) // 64 * 64
+    S_cap = Ts + 64
+    cos, sin = rope_tables(S_cap, hd)
+    cd, sd = be.f32(cos), be.f32(sin)
+    ws = be.zeros((max(ws_mb, 1) << 18,), "f32")
+    wsp, wsb = (be.ptr(ws) if ws_mb else None), ctypes.c_size_t(ws_mb << 20)
+    qkv = be.zeros((M, 3 * D), "bf16")
+    if f8:
+        Ad, Q, sad = be.bf16(A), be.zeros((M, K), "u8"), be.zeros((M,), "f32")
+        _call(be, "vck_quant_act_rows", Ad, K, Q, sad, M, K)
+        Wb, Wq, swd, Wrow = be.bf16(W), be.zeros((3 * D * K,), "u8"), be.zeros((3 * D,), "f32"), be.zeros((3 * D, K), "u8")
+        _call(be, "vck_quantize_fp8_rows", Wb, Wq, swd, Wrow, 3 * D, K)
+        be.lib.vck_gemm_f8(be.ptr(Q), be.ptr(sad), be.ptr(Wrow), be.ptr(swd), be.ptr(qkv), M, 3 * D, K, 3 * D, 0, wsp, wsb, None)
+        Aop, Wop, asc, wsc = Q, Wrow, sad, swd
+    else:
+        Aop, Wop, asc, wsc = be.bf16(A), be.bf16(W), None, None
+        bd = be.f32(b) if bias else None
+        be.lib.vck_gemm_ws(be.ptr(Aop), be.ptr(Wop), be.ptr(bd), be.ptr(qkv), M, 3 * D, K, K, K, 3 * D, 0, wsp, wsb, None)
+    be.sync()
+    mk = lambda: (be.zeros((B, H, Ts, hd), "bf16"), be.zeros((B, H, S_cap, hd), "bf16"), be.zeros((B, H, S_cap, hd), "bf16"),
+                  be.zeros((B, H, hd, Ts), "bf16"), be.zeros((B, H, S_cap, hd), "u8"), be.zeros((B, H, S_cap, hd), "u8"))
+    q1, k1, v1, vt1, k81, v81 = mk()
+    q2, k2, v2, vt2, k82, v82 = mk()
+    if kv8:   # e4m3 cache rows; the bf16 K rows go to a scratch of stride Ts (the flash kernel's operand)
+        k1, k2 = be.zeros((B, H, Ts, hd), "bf16"), be.zeros((B, H, Ts, hd), "bf16")
+        be.lib.vck_qkv_split_kv8(be.ptr(qkv), be.ptr(q1), be.ptr(k1), be.ptr(k81), be.ptr(v81), be.ptr(vt1), B, T, H, hd, Ts, Ts, Ts,
+                                 S_cap, be.ptr(cd), be.ptr(sd), None)
+    else:
+        be.lib.vck_qkv_split_kv(be.ptr(qkv), be.ptr(q1), be.ptr(k1), be.ptr(v1), be.ptr(vt1), B, T, H, hd, Ts, S_cap, Ts, be.ptr(cd),
+                                be.ptr(sd), None)
+    be.sync()
+    bd = be.f32(b) if (bias and not f8) else None
+    be.lib.vck_gemm_qkv(be.ptr(Aop), be.ptr(asc), be.ptr(Wop), be.ptr(wsc), be.ptr(bd), B, T, H, K, K, be.ptr(q2), be.ptr(k2),
+                        None if kv8 else be.ptr(v2), be.ptr(vt2), be.ptr(k82) if kv8 else None, be.ptr(v82) if kv8 else None,
+                        Ts, Ts if kv8 else S_cap, Ts, S_cap, be.ptr(cd), be.ptr(sd), int(f8), wsp, wsb, None)
+    be.sync()
+    host = lambda t: np.asarray(t.cpu().numpy() if hasattr(t, "cpu") else t)
+    # With a split-K workspace and T off the 32-token grid the padded and the plain token rows sit in different tiles, so a row may
+    # be summed in K-slices by one launch and in one piece by the other: fp32 summation order, i.e. single bf16 roundings, may differ
+    exact = not (ws_mb and T % 32)
+    for name, a1, a2 in (("q", q1, q2), ("k", k1, k2), ("v", v1, v2), ("vt", vt1, vt2)):
+        g1, g2 = be.host_f32(a1), be.host_f32(a2)
+        if exact:
+            assert np.array_equal(g1, g2), f"fused QKV epilogue: {name} differs from gemm + qkv_split (B{B} T{T} H{H} K{K} f8={f8} kv8={kv8}): " \
+                                           f"{int((g1 != g2).sum())} of {g1.size} elements, max {np.abs(g1 - g2).max()}"
+        else:
+            assert np.array_equal(g1 == 0, g2 == 0) or np.abs(g1 - g2).max() <= 2.0 ** -7 * np.abs(g1).max()
+            assert np.abs(g1 - g2).max() <= 2.0 ** -7 * np.abs(g1).max() and (g1 != g2).mean() < 0.02, \
+                f"fused QKV epilogue: {name}: {(g1 != g2).mean():.4f} of the elements differ, max {np.abs(g1 - g2).max()}"
+    if exact:
+        assert np.array_equal(host(k81), host(k82)) and np.array_equal(host(v81), host(v82)), "fused QKV epilogue: e4m3 cache rows differ"
+    else:
+        assert (host(k81) != host(k82)).mean() < 0.02 and (host(v81) != host(v82)).mean() < 0.02
+    assert be.host_f32(q2).any() and be.host_f32(vt2).any()
+
+
 def check_attention(be, B, H, T, hd, causal, seed=0, spike=False):
     rng = np.random.RandomState(seed)
     Ts = (T + 63) // 64 * 64

@@ -27,6 +27,33 @@ def test_strict_mode_meets_north_star_bar(emu_lib, name):
     assert r["logits_err"] < 1e-4 and r["decode_logits_err"] < 1e-4
 
 
+@pytest.mark.parametrize("fmt", ["bf16", "fp8"])
+def test_qkv_fused_epilogue_through_the_engine(emu_lib, fmt):
+    """Round 6: the prefill with RoPE + head split + KV write inside the QKV GEMM's epilogue gives the bits of the
+    separate GEMM + qkv_split launches — all-position logits, the KV cache the decode steps then read (teacher-forced steps),
+    generate() — for a spliced length that is not a multiple of 32 (padded token rows), bf16 and the fp8 format (e4m3 cache rows)."""
+    import numpy as np
+    from vcoder_amd.engine import HipEngine
+
+    g, cfg, ids, imgs, segs, deps = e2e_cases.fixture_inputs("ds_img_depth_seg")
+    eng = HipEngine(cfg, lib=emu_lib)
+    eng.load_synthetic(int(g["seed"]))
+    if fmt != "bf16":
+        eng.set_weight_format(fmt)
+    eng.finalize()
+    outs = []
+    for on in (0, 2):
+        eng.set_qkv_fused(on)
+        last, full, S = eng.prefill(ids, imgs, segs, deps, all_logits=True)
+        assert S % 32 != 0
+        tok = np.argmax(last, -1).astype(np.int32)
+        steps = [eng.decode_step(tok)[0] for _ in range(3)]
+        outs.append((full, np.stack(steps), eng.generate_greedy(ids, imgs, segs, deps, max_new_tokens=6)))
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
+    eng.close()
+
+
 def test_other_projector_types_fixture(emu_lib):
     """'linear' <image> adapter + 'mlp3x_gelu' <seg> / <depth> adapter, fixture of the live reference (round 3): fast path
     within the bf16 tolerance, strict and split modes within 1e-3 with bit-exact ids ('identity': under -m gpu)."""

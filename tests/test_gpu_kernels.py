@@ -25,6 +25,31 @@ def test_gemm(be, M, N, K, epi, bias):
     kc.check_gemm(be, M, N, K, epi, bias)
 
 
+@pytest.mark.parametrize("B,T,H,K,ws,f8,kv8", [(8, 1216, 32, 4096, 64, False, False), (2, 1217, 40, 5120, 0, False, False),
+                                               (2, 1217, 40, 5120, 64, False, False), (3, 1190, 32, 4096, 0, True, True),
+                                               (3, 1190, 32, 4096, 64, True, True), (1, 96, 2, 256, 0, False, False)])
+def test_gemm_qkv_fused_epilogue(be, B, T, H, K, ws, f8, kv8):
+    """Round 6: the QKV GEMM with RoPE + head split + KV write in its epilogue at the 7b (B = 8: split-K remainder round +
+    the QKV fix-up launch) and 13b geometries, sample lengths off the 32-token grid, the e4m3 operand / e4m3 cache form: every output
+    bit for bit what vck_gemm + vck_qkv_split_kv / _kv8 write (with a split-K workspace AND a length off the grid the two forms slice
+    different tiles: single bf16 roundings may then differ, nothing else)."""
+    kc.check_gemm_qkv_fused(be, B, T, H, K, ws_mb=ws, f8=f8, kv8=kv8)
+
+
+@pytest.mark.parametrize("M,N,K,epi,bias,ws", [(1154, 3072, 1024, 0, True, 0), (1154, 4096, 1024, 1, True, 0), (1152, 4096, 4096, 2, True, 0),
+                                               (1216, 12288, 4096, 3, False, 0), (1216, 22016, 4096, 5, False, 0),
+                                               (9728, 4096, 4096, 4, False, 64), (9728, 12288, 4096, 0, False, 64),
+                                               (70, 264, 192, 0, True, 0)])
+def test_gemm_mfma_32x32x16(be, M, N, K, epi, bias, ws):
+    """The 8-phase schedule on v_mfma_f32_32x32x16_bf16 (vck_set_gemm_variant 7: every size, incl. ragged tiles and split-K
+    remainder rounds) against float64 — fragment maps, the (row >> 1) & 7 tile swizzle and the 32 x 32 C/D layout on hardware."""
+    be.lib.vck_set_gemm_variant(7)
+    try:
+        kc.check_gemm(be, M, N, K, epi, bias, ws_mb=ws)
+    finally:
+        be.lib.vck_set_gemm_variant(-1)
+
+
 @pytest.mark.parametrize("M,N,K,epi", [(8, 12288, 4096, 0), (8, 4096, 4096, 2), (8, 22016, 4096, 3),
                                        (8, 4096, 11008, 2), (8, 32000, 4096, 1), (16, 15360, 5120, 0), (1, 320, 256, 1),
                                        (3, 48, 288, 1)])

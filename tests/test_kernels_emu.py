@@ -157,6 +157,18 @@ def test_strict_fp32_kernels(be):
     kc.check_qkv_rope_f32(be, 1, 1, 2, 64, 11)
 
 
+@pytest.mark.parametrize("B,T,H,K,bias,ws,f8,kv8", [(2, 96, 2, 128, False, 0, False, False), (2, 70, 2, 192, True, 0, False, False),
+                                                     (3, 133, 4, 128, False, 0, False, True), (1, 64, 2, 256, False, 0, True, True)])
+def test_gemm_qkv_fused_epilogue(be, B, T, H, K, bias, ws, f8, kv8):
+    kc.check_gemm_qkv_fused(be, B, T, H, K, bias=bias, ws_mb=ws, f8=f8, kv8=kv8)
+
+
+def test_gemm_qkv_fused_epilogue_splitk_round(be):
+    """more than one round of 256 tiles with a short last round: K-slices + the QKV fix-up launch (2 x 640 tokens, H = 22:
+    5 x 66 = 330 tiles -> 74 remainder tiles in 3 slices)"""
+    kc.check_gemm_qkv_fused(be, 2, 630, 22, 192, ws_mb=64)
+
+
 def test_alternate_kernel_variants():
     """The non-default template variants stay correct: the same cases in subprocesses with the tuning knobs flipped (the
     library reads them once per process); the sweeps run side by side."""
@@ -176,6 +188,11 @@ def test_alternate_kernel_variants():
         # 2: the one-barrier 256x256 kernel; 4: 256x256 as 4 waves x (128 x 128)
         (dict(VC_GEMM_VARIANT="2"), plain_gemm),
         (dict(VC_GEMM_VARIANT="4"), plain_gemm),
+        # 7: the 8-phase kernel on v_mfma_f32_32x32x16_bf16 for every size (round 6): ragged tiles, all epilogues, split-K rounds,
+        # and the split mode's K-wrapped / lo-plane forms
+        # (the fused-QKV check compares two launches bit for bit, and its reference GEMM would run on the other MFMA shape, whose
+        # 16-wide k-steps round differently: excluded here)
+        (dict(VC_GEMM_VARIANT="7"), "(" + plain_gemm + " or (test_gemm and splitk and not f8) or test_gemm_split or lo_plane) and not qkv_fused"),
     ]
     procs = []
     for knobs, sel in sweeps:

@@ -50,6 +50,56 @@ def bench_gemm():
         print(f"gemm+ws {name:9s}                         : {us:9.1f} us  {2 * M * N * K / us / 1e6:7.1f} TFLOP/s", flush=True)
 
 
+def bench_gemm32():
+    """Round 6 go / no-go: the 8-phase 256 x 256 schedule on v_mfma_f32_16x16x32_bf16 (variant 1) against the same schedule on
+    v_mfma_f32_32x32x16_bf16 (variant 6), random and constant operands, with the split-K workspace (the engine's form)."""
+    ws = torch.zeros(16 << 20, device=dev)
+    for (M, N, K, epi, name) in [(9728, 12288, 4096, 0, "llm qkv"), (9728, 4096, 4096, 4, "llm o"),
+                                 (9728, 22016, 4096, 5, "llm gate-up"), (9728, 4096, 11008, 4, "llm down"),
+                                 (19456, 15360, 5120, 0, "13b qkv"), (19456, 27648, 5120, 5, "13b gate-up"),
+                                 (13848, 3072, 1024, 0, "vit qkv"), (13848, 4096, 1024, 1, "vit fc1"),
+                                 (13848, 1024, 4096, 4, "vit fc2"), (13824, 4096, 4096, 0, "adapter 2")]:
+        for fill in ("random", "const"):
+            if fill == "random":
+                A, W = bf16(M, K), bf16(N, K, scale=0.02)
+            else:
+                A, W = torch.full((M, K), 0.5, device=dev, dtype=torch.bfloat16), torch.full((N, K), 0.01, device=dev, dtype=torch.bfloat16)
+            out = torch.zeros((M, N), dtype=torch.float32 if epi in (3, 4) else torch.bfloat16, device=dev)
+            ldo = N // 2 if epi == 5 else N
+            res = []
+            for v in (1, 6, 1, 6):
+                lib.vck_set_gemm_variant(v)
+                us = timeit(lambda: lib.vck_gemm_ws(P(A), P(W), None, P(out), M, N, K, K, K, ldo, epi, P(ws), C.c_size_t(64 << 20), None),
+                            iters=10)
+                res.append(us)
+            lib.vck_set_gemm_variant(-1)
+            f = lambda us: 2 * M * N * K / us / 1e6
+            print(f"gemm32 {name:12s} {fill:6s} M{M} N{N} K{K} epi{epi}: 16x16x32 {res[0]:8.1f} / {res[2]:8.1f} us ({f(min(res[0], res[2])):6.1f} TF/s)   "
+                  f"32x32x16 {res[1]:8.1f} / {res[3]:8.1f} us ({f(min(res[1], res[3])):6.1f} TF/s)   ratio {min(res[1], res[3]) / min(res[0], res[2]):.3f}", flush=True)
+
+
+def bench_gemm_qkv():
+    """Round 6: the QKV projection of a prefill layer as GEMM (EPI_BF16) + qkv_split against the GEMM with RoPE + head split + KV write
+    in its epilogue (vck_gemm_qkv), with / without the split-K workspace."""
+    for (B, T, H, K, name) in [(8, 1216, 32, 4096, "7b B=8"), (16, 1216, 40, 5120, "13b B=16"), (8, 1217, 32, 4096, "7b B=8 S=1217")]:
+        D, M = H * 128, B * T
+        Ts, S_cap = (T + 63) // 64 * 64, 1344
+        A, W = bf16(M, K), bf16(3 * D, K, scale=0.02)
+        qkv = torch.zeros((M, 3 * D), dtype=torch.bfloat16, device=dev)
+        q, vt = torch.zeros((B, H, Ts, 128), dtype=torch.bfloat16, device=dev), torch.zeros((B, H, 128, Ts), dtype=torch.bfloat16, device=dev)
+        k, v = torch.zeros((B, H, S_cap, 128), dtype=torch.bfloat16, device=dev), torch.zeros((B, H, S_cap, 128), dtype=torch.bfloat16, device=dev)
+        cos, sin = torch.rand(S_cap, 64, device=dev), torch.rand(S_cap, 64, device=dev)
+        ws = torch.zeros(16 << 20, device=dev)
+        for wsb in (64 << 20, 0):
+            wp = P(ws) if wsb else None
+            g = timeit(lambda: lib.vck_gemm_ws(P(A), P(W), None, P(qkv), M, 3 * D, K, K, K, 3 * D, 0, wp, C.c_size_t(wsb), None), iters=10)
+            sp = timeit(lambda: lib.vck_qkv_split_kv(P(qkv), P(q), P(k), P(v), P(vt), B, T, H, 128, Ts, S_cap, Ts, P(cos), P(sin), None), iters=10)
+            f = timeit(lambda: lib.vck_gemm_qkv(P(A), None, P(W), None, None, B, T, H, K, K, P(q), P(k), P(v), P(vt), None, None, Ts, S_cap,
+                                                 Ts, 0, P(cos), P(sin), 0, wp, C.c_size_t(wsb), None), iters=10)
+            print(f"gemm_qkv {name:14s} ws={wsb >> 20:2d}MiB: gemm {g:8.1f} + split {sp:6.1f} = {g + sp:8.1f} us   fused {f:8.1f} us   "
+                  f"({2 * M * 3 * D * K / f / 1e6:6.1f} TF/s)", flush=True)
+
+
 def bench_gemm_f8():
     """W8A8 prefill linears (weight format 2): the activation quantiser and the e4m3 x e4m3 GEMM, next to the bf16 GEMM of the
     same shape (7b B=8 and 13b B=16 prefill shapes)."""
@@ -438,7 +488,7 @@ def bench_dattn():
 
 if __name__ == "__main__":
     what = sys.argv[1:] or ["gemm", "gemv", "attn", "dattn"]
-    table = {"gemm": bench_gemm, "gemv": bench_gemv, "attn": bench_attn, "dattn": bench_dattn, "gemv_fp8": bench_gemv_fp8,
+    table = {"gemm_qkv": bench_gemm_qkv, "gemm32": bench_gemm32, "gemm": bench_gemm, "gemv": bench_gemv, "attn": bench_attn, "dattn": bench_dattn, "gemv_fp8": bench_gemv_fp8,
              "gemv13": bench_gemv13, "gemv_pair": bench_gemv_pair, "gemv_rows": bench_gemv_rows, "dattn_rows": bench_dattn_rows,
              "gemm_f8": bench_gemm_f8, "gemv_rows8": bench_gemv_rows8, "gemv_wide": bench_gemv_wide, "gemm_chunk": bench_gemm_chunk,
              "dattn_split": bench_dattn_split, "dattn_kv8": bench_dattn_kv8}

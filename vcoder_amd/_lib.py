@@ -115,6 +115,8 @@ def declare(lib: C.CDLL) -> C.CDLL:
     lib.vc_pool_step_counts.restype = C.c_int
     lib.vc_model_set_batch_invariant.argtypes = [vp, i32]
     lib.vc_model_set_batch_invariant.restype = C.c_int
+    lib.vc_model_set_qkv_fused.argtypes = [vp, i32]
+    lib.vc_model_set_qkv_fused.restype = C.c_int
     lib.vc_model_set_fp8_kv.argtypes = [vp, i32]
     lib.vc_model_set_fp8_kv.restype = C.c_int
     lib.vc_model_inexact_tensors.argtypes = [vp]

@@ -205,6 +205,8 @@ struct vc_model {
     bool pool_profile = false;       // root model: the pool's step graphs carry in-situ timing stamps (vc_pool_profile)
     bool fp8_kv = true;              // weight format 2: the KV cache of the bf16-step modes in e4m3 (vc_model_set_fp8_kv)
     bool batch_invariant = false;    // root model: a sample's bits do not depend on the batch it runs in (vc_model_set_batch_invariant)
+    int qkv_fused = 1;               // root model: RoPE + head split + KV write in the prefill's QKV GEMM epilogue (vc_model_set_qkv_fused):
+                                     // 0 off, 1 for problems the 256 x 256 GEMM kernel serves anyway (>= 1024 token rows), 2 always
     bool pool_hold = true;           // root model: the pool does not step while a call holding rows is still prefilling (vc_pool_set_hold)
     vc_model* root = nullptr;        // the model that owns the weights (itself for a root)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -472,6 +474,7 @@ void emit_attentions(vc_model* m, int l, int B, int S, AttnProbsArgs a, int Tk =
 // vc_model_set_batch_invariant: no split-K remainder round (its slices — and so the order in which a row's k-blocks are summed —
 // depend on the number of output tiles, i.e. on how many rows share the launch)
 inline bool batch_invariant(const vc_model* m) { return (m->root ? m->root : m)->batch_invariant; }
+inline const vc_model* root_of(const vc_model* m) { return m->root ? m->root : m; }
 inline bool prefill_fold_on() {
     const char* e = getenv("VC_PREFILL_FOLD");
     return e && atoi(e) != 0;
@@ -495,9 +498,10 @@ static void apply_fold(GemmArgs& a, const NormFold* f) {
     a.npart = f->npart;
 }
 void gemm(vc_model* m, const bf16_t* A, const bf16_t* W, const float* bias, void* out, int M, int N, int K, int ldo,
-          int epi, int lda = 0, const NormFold* fold = nullptr) {
+          int epi, int lda = 0, const NormFold* fold = nullptr, const QkvEpiArgs* qe = nullptr) {
     GemmArgs a{A, W, bias, out, M, N, K, lda > 0 ? lda : K, K, ldo};
     apply_fold(a, fold);
+    if (qe) a.qe = *qe;
     if (!batch_invariant(m) && (long)((M + 255) / 256) * ((N + 255) / 256) > 256) {  // only problems with more than one round of tiles can use it
         m->gemm_ws.ensure((size_t)64 << 20);
         a.ws = m->gemm_ws.as<float>();
@@ -509,9 +513,10 @@ void gemm(vc_model* m, const bf16_t* A, const bf16_t* W, const float* bias, void
 // out = epi((Q @ Wq^T) * a_scale[m] * w_scale[n]) on the K=128 scaled MFMA
 // A == nullptr: the e4m3 rows and scales are already in m->a8 / m->a8_scale (launch_rmsnorm_q8)
 void gemm_f8(vc_model* m, const bf16_t* A, const uint8_t* Wq, const float* wscale, void* out, int M, int N, int K, int ldo,
-             int epi) {
+             int epi, const QkvEpiArgs* qe = nullptr) {
     if (A) launch_quant_act_rows(A, K, m->a8.as<uint8_t>(), m->a8_scale.as<float>(), M, K, m->st);
     GemmArgs a{reinterpret_cast<const bf16_t*>(m->a8.p), reinterpret_cast<const bf16_t*>(Wq), nullptr, out, M, N, K, K, K, ldo};
+    if (qe) a.qe = *qe;
     if (!batch_invariant(m) && (long)((M + 255) / 256) * ((N + 255) / 256) > 256) {
         m->gemm_ws.ensure((size_t)64 << 20);
         a.ws = m->gemm_ws.as<float>();
@@ -1344,15 +1349,11 @@ void run_prefill_layers(vc_model* m, const KvTarget& kv, int B, int S, int l0 = 
     NormFold prod{nullptr, m->xn.as<bf16_t>(), nullptr, m->p_ssq.as<float>(), D + XN_PAD, 0, m->npart};
     const NormFold cons{rstd};
     bool have_xg = false;   // xn holds bf16(x * g) of the CURRENT x for the norm about to be consumed, rstd its row scales
+    // the fused QKV epilogue: hd 128, two heads per 256-row weight tile, a problem the 256 x 256 kernel serves anyway
+    const int qf = root_of(m)->qkv_fused;
+    const bool qkv_fused = qf && m->hd == 128 && D % 256 == 0 && (qf > 1 || (long)B * rup(S, 32) >= 1024);
     for (int l = l0; l < nl; ++l) {
         const LlmLayer& L = m->llm[l];
-        if (f8) {  // RMSNorm writes the e4m3 operand of the QKV GEMM directly
-            launch_rmsnorm_q8(m->x.as<float>(), L.in_norm, m->a8.as<uint8_t>(), m->a8_scale.as<float>(), M, D, c.rms_eps, m->st);
-            gemm_f8(m, nullptr, L.qkv_q, L.qkv_s, m->qkv.p, M, 3 * D, D, 3 * D, EPI_BF16);
-        } else {
-            if (!have_xg) launch_rmsnorm(m->x.as<float>(), L.in_norm, m->xn.as<bf16_t>(), M, D, c.rms_eps, m->st, D + XN_PAD);
-            gemm(m, m->xn.as<bf16_t>(), L.qkv_w, nullptr, m->qkv.p, M, 3 * D, D, 3 * D, EPI_BF16, D + XN_PAD, have_xg ? &cons : nullptr);
-        }
         // K and V rows go to the cache (key-major: what the decode steps stream); the V^T tiles of this layer's flash
         // attention live in a per-call scratch [B,H,hd,Sr]
         // (kv.es == 1, the e4m3 cache of the fp8 format: the flash kernel of THIS prefill reads bf16 K rows from a per-call
@@ -1360,11 +1361,36 @@ void run_prefill_layers(vc_model* m, const KvTarget& kv, int B, int S, int l0 = 
         const bool kv8 = kv.es == 1;
         bf16_t* kflash = kv8 ? m->k_pre.as<bf16_t>() : kcache(m, kv, l);
         const int kflash_stride = kv8 ? Sr : kv.capS;
-        QkvSplitArgs qa{m->qkv.as<bf16_t>(), m->q.as<bf16_t>(), kflash, m->vt_pre.as<bf16_t>(), B, S, H, m->hd, S, kflash_stride,
-                        nullptr, m->rope_cos, m->rope_sin, kv8 ? nullptr : vcache(m, kv, l), Sr,
-                        kv8 ? reinterpret_cast<uint8_t*>(kcache(m, kv, l)) : nullptr,
-                        kv8 ? reinterpret_cast<uint8_t*>(vcache(m, kv, l)) : nullptr, kv.capS};
-        launch_qkv_split(qa, m->st);
+        // round 6: RoPE + head split + KV write in the QKV GEMM's epilogue — the fused [M, 3D] rows are never
+        // written and qkv_split_kernel's pass (105 us per 7b layer at B = 8, 263 us at 13b B = 16) is gone.  The token rows of that
+        // GEMM are the samples padded to a multiple of 32 (EPI_QKV, kernels.h); same bits as the two launches it replaces.
+        const int Sp = (int)rup(S, 32);
+        if (qkv_fused) {
+            QkvEpiArgs qe{m->q.as<bf16_t>(), kflash, kv8 ? nullptr : vcache(m, kv, l), m->vt_pre.as<bf16_t>(),
+                          kv8 ? reinterpret_cast<uint8_t*>(kcache(m, kv, l)) : nullptr,
+                          kv8 ? reinterpret_cast<uint8_t*>(vcache(m, kv, l)) : nullptr, m->rope_cos, m->rope_sin, B, S, Sp, H, S,
+                          kflash_stride, Sr, kv.capS};
+            if (f8) {
+                launch_rmsnorm_q8(m->x.as<float>(), L.in_norm, m->a8.as<uint8_t>(), m->a8_scale.as<float>(), M, D, c.rms_eps, m->st);
+                gemm_f8(m, nullptr, L.qkv_q, L.qkv_s, nullptr, B * Sp, 3 * D, D, 0, EPI_QKV, &qe);
+            } else {
+                if (!have_xg) launch_rmsnorm(m->x.as<float>(), L.in_norm, m->xn.as<bf16_t>(), M, D, c.rms_eps, m->st, D + XN_PAD);
+                gemm(m, m->xn.as<bf16_t>(), L.qkv_w, nullptr, nullptr, B * Sp, 3 * D, D, 0, EPI_QKV, D + XN_PAD, have_xg ? &cons : nullptr, &qe);
+            }
+        } else {
+            if (f8) {  // RMSNorm writes the e4m3 operand of the QKV GEMM directly
+                launch_rmsnorm_q8(m->x.as<float>(), L.in_norm, m->a8.as<uint8_t>(), m->a8_scale.as<float>(), M, D, c.rms_eps, m->st);
+                gemm_f8(m, nullptr, L.qkv_q, L.qkv_s, m->qkv.p, M, 3 * D, D, 3 * D, EPI_BF16);
+            } else {
+                if (!have_xg) launch_rmsnorm(m->x.as<float>(), L.in_norm, m->xn.as<bf16_t>(), M, D, c.rms_eps, m->st, D + XN_PAD);
+                gemm(m, m->xn.as<bf16_t>(), L.qkv_w, nullptr, m->qkv.p, M, 3 * D, D, 3 * D, EPI_BF16, D + XN_PAD, have_xg ? &cons : nullptr);
+            }
+            QkvSplitArgs qa{m->qkv.as<bf16_t>(), m->q.as<bf16_t>(), kflash, m->vt_pre.as<bf16_t>(), B, S, H, m->hd, S, kflash_stride,
+                            nullptr, m->rope_cos, m->rope_sin, kv8 ? nullptr : vcache(m, kv, l), Sr,
+                            kv8 ? reinterpret_cast<uint8_t*>(kcache(m, kv, l)) : nullptr,
+                            kv8 ? reinterpret_cast<uint8_t*>(vcache(m, kv, l)) : nullptr, kv.capS};
+            launch_qkv_split(qa, m->st);
+        }
         AttnArgs aa{m->q.as<bf16_t>(), kflash, m->vt_pre.as<bf16_t>(), m->attn.as<bf16_t>(), B, H, S, m->hd, S, kflash_stride, 1,
                     1.0f / sqrtf((float)m->hd), Sr};
         if (m->has_kmask) {
@@ -2176,6 +2202,17 @@ VC_API int vc_model_set_fp8_kv(vc_model* m, int on) {
 VC_API int vc_model_set_batch_invariant(vc_model* m, int on) {
     if (!m) return VC_ERR_INVALID;
     (m->root ? m->root : m)->batch_invariant = on != 0;
+    return VC_OK;
+}
+
+/* The prefill's QKV projection with RoPE + head split + KV-cache write in the GEMM's epilogue (default on): on = 0 runs the
+ * two launches it replaces (EPI_BF16 GEMM + qkv_split_kernel) — same bits when the padded and the plain token count give the GEMM the
+ * same tile rounds, A/B and regression switch; on = 2 takes the fused form for every problem size (default 1: from 1024 token rows,
+ * where the 256 x 256 kernel is used anyway).  Applies to all sessions of the model. */
+VC_API int vc_model_set_qkv_fused(vc_model* m, int on) {
+    if (!m) return VC_ERR_INVALID;
+    if (on < 0 || on > 2) return VC_ERR_INVALID;
+    (m->root ? m->root : m)->qkv_fused = on;
     return VC_OK;
 }
 

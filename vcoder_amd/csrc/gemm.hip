@@ -120,6 +120,51 @@ VC_DEV long long a_koff(int kt, const GemmArgs& p) {
     return (long long)((p.kwrap > 0 && kt >= 2 * p.kwrap) ? kt - 2 * p.kwrap : kt) * 128;
 }
 
+
+// ---- EPI_QKV (kernels.h QkvEpiArgs): RoPE + head split + KV write in the QKV GEMM's epilogue ---------------------------------
+// weight row behind row `row` (0..127) of X half `h` of the 256-row tile at n0: {head 2a: d 0..63 | head 2a+1: d 0..63} in half 0,
+// the same heads' d 64..127 in half 1 — wave group g = row / 64 then owns ONE head in both halves
+VC_DEV int qkv_wrow(int n0, int h, int row) { return n0 + (row >> 6) * 128 + h * 64 + (row & 63); }
+// A row behind padded token row mp = b * Tp + t (clamped into the sample; the stores of such rows are masked)
+VC_DEV int qkv_arow(const QkvEpiArgs& e, int mp) {
+    const int b = min(mp / e.Tp, e.B - 1);
+    return b * e.T + min(mp - b * e.Tp, e.T - 1);
+}
+// 4 rotate-half pairs (x = d0 + i, y = d0 + 64 + i) of token (b, t), head `head`: the projection is rounded to bf16 first (the value
+// the unfused path stores in its fused rows), RoPE in fp32 on the rounded values in qkv_split_kernel's expression forms, rounded
+// again; which = 0: Q rows, 1: K rows (+ the e4m3 cache row)
+VC_DEV void qkv_rope_store(const QkvEpiArgs& e, int which, int head, int b, int t, int dl, f32x4 x, f32x4 y) {
+    const u32x2 xb = pack_bf4(x), yb = pack_bf4(y);
+    const f32x4 cs = ld16f(e.rope_cos + (size_t)t * 64 + dl), sn = ld16f(e.rope_sin + (size_t)t * 64 + dl);
+    u32x2 olo, ohi;
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+        const float x0 = bf2f_lo(xb[h2]), x1 = bf2f_hi(xb[h2]), y0 = bf2f_lo(yb[h2]), y1 = bf2f_hi(yb[h2]);
+        const float c0 = cs[2 * h2], c1 = cs[2 * h2 + 1], s0 = sn[2 * h2], s1 = sn[2 * h2 + 1];
+        olo[h2] = pack_bf2(x0 * c0 - y0 * s0, x1 * c1 - y1 * s1);
+        ohi[h2] = pack_bf2(y0 * c0 + x0 * s0, y1 * c1 + x1 * s1);
+    }
+    const size_t bh = (size_t)b * e.H + head;
+    bf16_t* dst = which == 0 ? e.q + (bh * e.q_stride + t) * 128 : e.k + (bh * e.kv_stride + t) * 128;
+    st8(dst + dl, olo);
+    st8(dst + 64 + dl, ohi);
+    if (which == 1 && e.k8 != nullptr) {
+        uint8_t* d8 = e.k8 + (bh * e.kv8_stride + t) * 128;
+        *reinterpret_cast<uint32_t*>(d8 + dl) = f32x4_to_fp8x4(bf2f_lo(olo[0]), bf2f_hi(olo[0]), bf2f_lo(olo[1]), bf2f_hi(olo[1]));
+        *reinterpret_cast<uint32_t*>(d8 + 64 + dl) = f32x4_to_fp8x4(bf2f_lo(ohi[0]), bf2f_hi(ohi[0]), bf2f_lo(ohi[1]), bf2f_hi(ohi[1]));
+    }
+}
+// 4 value features d0 .. d0 + 3 of token (b, t) into the cache row(s)
+VC_DEV void qkv_v_store(const QkvEpiArgs& e, int head, int b, int t, int d0, u32x2 vb) {
+    const size_t bh = (size_t)b * e.H + head;
+    if (e.v != nullptr) st8(e.v + (bh * e.kv_stride + t) * 128 + d0, vb);
+    if (e.v8 != nullptr)
+        *reinterpret_cast<uint32_t*>(e.v8 + (bh * e.kv8_stride + t) * 128 + d0) =
+            f32x4_to_fp8x4(bf2f_lo(vb[0]), bf2f_hi(vb[0]), bf2f_lo(vb[1]), bf2f_hi(vb[1]));
+}
+// column of key kk (0..31) of a 32-key block inside the V^T scratch row (attn.hip vt_chunk_key0: chunk c holds keys 4c..4c+3, 16+4c..16+4c+3)
+VC_DEV int vt_pos32(int kk) { return ((kk & 15) >> 2) * 8 + (kk & 3) + 4 * (kk >> 4); }
+
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     VC_DYNAMIC_SMEM(char, smem);  // [2 stages][W tile | A tile]
@@ -323,8 +368,20 @@ __global__ __launch_bounds__(WN * WM * 64) void gemm_bf16_dma_kernel(GemmArgs p)
 // instruction sums over all of them.  The epilogue multiplies the fp32 accumulator by a_scale[m] * w_scale[n] (exact: powers of two).
 // KWRAP (precision mode "split"): the weight's k-tile index wraps after p.kwrap tiles (compile-time flag: the default
 // instantiation keeps the weight source a plain `base + kt * 128`, exactly the round-2 loop)
-template <int EPI, bool F8 = false, bool KWRAP = false>
+// M32 (round 6): the same schedule on v_mfma_f32_32x32x16_bf16.  A wave's 128 x 64 output is 4 x 2 accumulators of 32 x 32 instead
+// of 8 x 4 of 16 x 16; a quadrant (64 n x 32 m x BK) is 8 MFMAs of 32 cycles instead of 16 of 16, fed by the same number of
+// ds_read_b128 (a fragment = 32 rows x 16 k: lane l reads row l % 32, chunk 2 s + l / 32 of k-step s).  Half the MFMA issues per
+// flop, an exact 32-cycle back-to-back cadence (the 16 x 16 x 32 form issues at ~17 instead of 16), and half the operand-register
+// reads per flop.  The tile rows are swizzled by (row >> 1) & 7 instead of row & 7: the 16 lanes of a ds_read_b128 group then
+// cover rows {0-3, 12-15, 20-27} (or {4-11, 16-19, 28-31}) of ONE chunk column — 8 row pairs with distinct (row >> 1) & 7, two
+// parities each = 16 distinct 16-byte bank slots.  C/D: lane l holds token l % 32 and, per register group rg = reg / 4, the 4
+// consecutive features 8 rg + 4 (l / 32) + reg % 4 (cdna_hip_programming.md section 3) — the lane-local epilogues are unchanged.
+template <bool M32> VC_DEV int swz8(int r, int c) { return r * 128 + ((c ^ ((M32 ? r >> 1 : r) & 7)) << 4); }
+
+template <int EPI, bool F8 = false, bool KWRAP = false, bool M32 = false>
 __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
+    static_assert(!(F8 && M32), "the 32 x 32 form is instantiated for bf16 operands");
+    static_assert(!(EPI == EPI_QKV && (M32 || KWRAP)), "the fused QKV epilogue is built on the 16 x 16 accumulator layout of the bf16 / e4m3 forms");
     constexpr int HALF = 128 * 128, TILE = 4 * HALF;  // bytes
     constexpr int ES = F8 ? 1 : 2;                    // bytes per operand element; a k-tile is 128 bytes of every row
     constexpr int SY0 = 0, SX0 = HALF, SY1 = 2 * HALF, SX1 = 3 * HALF;
@@ -355,10 +412,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = (i * 8 + wave) * 8 + (lane >> 3);
-            const int sw = ((lane & 7) ^ (row & 7)) << 4;
-            x_src[h][i] = reinterpret_cast<const char*>(p.W) + (size_t)min(n0 + h * 128 + row, p.N - 1) * p.ldw * ES + sw +
+            const int sw = ((lane & 7) ^ ((M32 ? row >> 1 : row) & 7)) << 4;
+            const int wrow = EPI == EPI_QKV ? qkv_wrow(n0, h, row) : n0 + h * 128 + row;
+            int arow = min(m0 + h * 128 + row, p.M - 1);
+            if constexpr (EPI == EPI_QKV) arow = qkv_arow(p.qe, arow);
+            x_src[h][i] = reinterpret_cast<const char*>(p.W) + (size_t)min(wrow, p.N - 1) * p.ldw * ES + sw +
                           (KWRAP ? (size_t)0 : (size_t)kt_first * 128);
-            y_src[h][i] = reinterpret_cast<const char*>(p.A) + (size_t)min(m0 + h * 128 + row, p.M - 1) * p.lda * ES + sw +
+            y_src[h][i] = reinterpret_cast<const char*>(p.A) + (size_t)arow * p.lda * ES + sw +
                           (KWRAP ? (size_t)0 : (size_t)kt_first * 128);
         }
     const int nk = (int)((long)(ks + 1) * nk_all / KS) - kt_first;  // k-tiles of this workgroup
@@ -377,6 +437,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
         glds16(y_src[h][1] + ak, dst + 8192);
     };
     f32x4 acc[2][4][2][2];  // [x half][i][y half][j]
+    f32x16 acc32[2][2][2];  // M32: [x half][32-row fragment][y half]
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -384,27 +445,54 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[a][i][b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int frow = lane & 15, fchunk = lane >> 4;
+                for (int j = 0; j < 2; ++j) {
+                    if constexpr (M32) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc32[a][i >> 1][b][(i & 1) * 8 + j * 4 + e] = 0.f;
+                    } else {
+                        acc[a][i][b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+    const int frow = M32 ? lane & 31 : lane & 15, fchunk = M32 ? lane >> 5 : lane >> 4;
     // X0 is dead after phase 1 and X1 is first read in phase 2: one register set serves both halves
-    u32x4 fx[4][2], fy[2][2][2];  // [fragment][ks], [half][fragment][ks]
+    u32x4 fx[4][2], fy[2][2][2];  // [fragment][ks], [half][fragment][ks]; M32: fx[2 fi + s / 2][s & 1], fy[half][s / 2][s & 1]
     auto read_x = [&](const char* base, int h) {
+        if constexpr (M32) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int fi = 0; fi < 2; ++fi)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                fx[i][ks] = ld16(base + (h ? SX1 : SX0) + swz(g * 64 + i * 16 + frow, ks * 4 + fchunk));
+                for (int s_ = 0; s_ < 4; ++s_)
+                    fx[2 * fi + (s_ >> 1)][s_ & 1] = ld16(base + (h ? SX1 : SX0) + swz8<true>(g * 64 + fi * 32 + frow, 2 * s_ + fchunk));
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    fx[i][ks] = ld16(base + (h ? SX1 : SX0) + swz(g * 64 + i * 16 + frow, ks * 4 + fchunk));
+        }
     };
     auto read_y = [&](const char* base, int h) {
+        if constexpr (M32) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int s_ = 0; s_ < 4; ++s_)
+                fy[h][s_ >> 1][s_ & 1] = ld16(base + (h ? SY1 : SY0) + swz8<true>(q * 32 + frow, 2 * s_ + fchunk));
+        } else {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                fy[h][j][ks] = ld16(base + (h ? SY1 : SY0) + swz(q * 32 + j * 16 + frow, ks * 4 + fchunk));
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    fy[h][j][ks] = ld16(base + (h ? SY1 : SY0) + swz(q * 32 + j * 16 + frow, ks * 4 + fchunk));
+        }
     };
     auto quadrant = [&](int hx, int hy) {
         set_prio<1>();
-        if constexpr (F8) {
+        if constexpr (M32) {
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                for (int fi = 0; fi < 2; ++fi)
+                    acc32[hx][fi][hy] = mfma32(fx[2 * fi + (s_ >> 1)][s_ & 1], fy[hy][s_ >> 1][s_ & 1], acc32[hx][fi][hy]);
+        } else if constexpr (F8) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -469,6 +557,36 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     }
     if (g == 0) wg_barrier_raw();
 
+    if constexpr (M32) {
+        // lane holds out[m][n .. n + 3] with m = .. + lane % 32 and n = .. + fi * 32 + rg * 8 + (lane / 32) * 4
+        float* wsb = KS > 1 ? p.ws + ((size_t)(pid - p.sk_full) * KS + ks) * 65536 : nullptr;
+        float rs32[2] = {1.f, 1.f};
+        if (p.row_scale && KS == 1) {
+#pragma unroll
+            for (int hy = 0; hy < 2; ++hy) rs32[hy] = p.row_scale[min(m0 + hy * 128 + q * 32 + (lane & 31), p.M - 1)];
+        }
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx)
+#pragma unroll
+            for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int nl = hx * 128 + g * 64 + fi * 32 + rg * 8 + (lane >> 5) * 4;
+                    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (KS == 1 && p.bias && n0 + nl < p.N) bv = ld16f(p.bias + n0 + nl);
+#pragma unroll
+                    for (int hy = 0; hy < 2; ++hy) {
+                        const int ml = hy * 128 + q * 32 + (lane & 31);
+                        const f32x4 v = f32x4{acc32[hx][fi][hy][rg * 4], acc32[hx][fi][hy][rg * 4 + 1], acc32[hx][fi][hy][rg * 4 + 2],
+                                              acc32[hx][fi][hy][rg * 4 + 3]};
+                        if (KS > 1) st16f(wsb + ml * 256 + nl, v);
+                        else if constexpr (EPI != EPI_QKV) {
+                            if (n0 + nl < p.N && m0 + ml < p.M) store_out<EPI>(p, m0 + ml, n0 + nl, v * rs32[hy] + bv);
+                        }
+                    }
+                }
+        return;
+    }
     if (KS > 1) {  // partial tile -> workspace [remainder tile][slice][256 m][256 n]; the fix-up launch finishes it
         float* base = p.ws + ((size_t)(pid - p.sk_full) * KS + ks) * 65536;
 #pragma unroll
@@ -481,6 +599,81 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
                     for (int j = 0; j < 2; ++j)
                         st16f(base + (hy * 128 + q * 32 + j * 16 + (lane & 15)) * 256 + hx * 128 + g * 64 + i * 16 + (lane >> 4) * 4,
                               acc[hx][i][hy][j]);
+        return;
+    }
+    if constexpr (EPI == EPI_QKV) {
+        // lane holds, for its wave group's head, features d = hx * 64 + i * 16 + G * 4 + (0..3) of tokens hy * 128 + q * 32 + j * 16 + l15
+        const QkvEpiArgs& e = p.qe;
+        const int D = e.H * 128;
+        const int which = n0 / D, head = (n0 - which * D) / 128 + g;
+        const int G = lane >> 4, l15 = lane & 15;
+        int tb[2][2], tt[2][2];
+        bool ok[2][2];
+        float rs[2][2];
+#pragma unroll
+        for (int hy = 0; hy < 2; ++hy)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int mp = m0 + hy * 128 + q * 32 + j * 16 + l15;
+                tb[hy][j] = mp / e.Tp;
+                tt[hy][j] = mp - tb[hy][j] * e.Tp;
+                ok[hy][j] = mp < p.M && tt[hy][j] < e.T;
+                const int src = qkv_arow(e, min(mp, p.M - 1));
+                rs[hy][j] = F8 ? p.a_scale[src] : (p.row_scale ? p.row_scale[src] : 1.f);
+            }
+        if (which < 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int dl = i * 16 + G * 4, nx = n0 + g * 128 + dl;   // nx: the weight row (= output column) of x; y is 64 further
+                f32x4 bx = f32x4{0.f, 0.f, 0.f, 0.f}, by = bx, swx = f32x4{1.f, 1.f, 1.f, 1.f}, swy = swx;
+                if (p.bias) {
+                    bx = ld16f(p.bias + nx);
+                    by = ld16f(p.bias + nx + 64);
+                }
+                if constexpr (F8) {
+                    swx = ld16f(p.w_scale + nx);
+                    swy = ld16f(p.w_scale + nx + 64);
+                }
+#pragma unroll
+                for (int hy = 0; hy < 2; ++hy)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        if (ok[hy][j])
+                            qkv_rope_store(e, which, head, tb[hy][j], tt[hy][j], dl, acc[0][i][hy][j] * (swx * rs[hy][j]) + bx,
+                                           acc[1][i][hy][j] * (swy * rs[hy][j]) + by);
+            }
+        } else {
+#pragma unroll
+            for (int hx = 0; hx < 2; ++hx)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int d0 = hx * 64 + i * 16 + G * 4, nv = n0 + g * 128 + d0;
+                    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f}, sw = f32x4{1.f, 1.f, 1.f, 1.f};
+                    if (p.bias) bv = ld16f(p.bias + nv);
+                    if constexpr (F8) sw = ld16f(p.w_scale + nv);
+#pragma unroll
+                    for (int hy = 0; hy < 2; ++hy) {
+                        u32x2 vb[2];
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            vb[j] = pack_bf4(acc[hx][i][hy][j] * (sw * rs[hy][j]) + bv);
+                            if (ok[hy][j]) qkv_v_store(e, head, tb[hy][j], tt[hy][j], d0, vb[j]);
+                            else vb[j] = u32x2{0u, 0u};   // keys behind the sequence are zeros in the V^T scratch
+                        }
+                        // P[f] = feature d0 + f of the lane's two tokens (keys kk = l15 and 16 + l15 of the 32-key block); after the
+                        // quad transpose lane r = l15 & 3 holds feature d0 + r of keys 4c .. 4c + 3 and 16 + 4c .. 16 + 4c + 3
+                        // (c = l15 >> 2): chunk c of the block in the flash kernel's key order — one 16-byte store
+                        uint32_t P[4] = {(vb[0][0] & 0xFFFFu) | (vb[1][0] << 16), (vb[0][0] >> 16) | (vb[1][0] & 0xFFFF0000u),
+                                         (vb[0][1] & 0xFFFFu) | (vb[1][1] << 16), (vb[0][1] >> 16) | (vb[1][1] & 0xFFFF0000u)};
+                        quad_transpose4(P, l15 & 3);
+                        const int base = m0 + hy * 128 + q * 32, bb = base / e.Tp, t0 = base - bb * e.Tp, c = l15 >> 2;
+                        if (base < p.M && t0 + 4 * c < e.T)
+                            st16(e.vt + (((size_t)bb * e.H + head) * 128 + d0 + (l15 & 3)) * e.vt_stride + t0 + 8 * c,
+                                 u32x4{(P[0] & 0xFFFFu) | (P[1] << 16), (P[2] & 0xFFFFu) | (P[3] << 16), (P[0] >> 16) | (P[1] & 0xFFFF0000u),
+                                       (P[2] >> 16) | (P[3] & 0xFFFF0000u)});
+                    }
+                }
+        }
         return;
     }
     // ---- epilogue: lane holds out[m][n..n+3]
@@ -507,7 +700,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
                 for (int j = 0; j < 2; ++j) {
                     const int m = m0 + hy * 128 + q * 32 + j * 16 + (lane & 15);
                     if (m >= p.M) continue;
-                    if constexpr (F8) store_out<EPI>(p, m, n, acc[hx][i][hy][j] * (sw * p.a_scale[m]) + bv);
+                    if constexpr (EPI == EPI_QKV) {
+                    } else if constexpr (F8) store_out<EPI>(p, m, n, acc[hx][i][hy][j] * (sw * p.a_scale[m]) + bv);
                     else store_out<EPI>(p, m, n, acc[hx][i][hy][j] * rsc[hy][j] + bv);
                 }
         }
@@ -531,6 +725,62 @@ __global__ __launch_bounds__(256) void gemm_splitk_fixup_kernel(GemmArgs p) {
     if (p.row_scale) v = v * p.row_scale[m];
     if (p.bias) v = v + ld16f(p.bias + n);
     store_out<EPI, true>(p, m, n, v);
+}
+
+
+// ... and of the fused-QKV epilogue: one thread = the rotate-half pairs (x at tile column c, y at column 128 + c) of 4 features of
+// one token of a remainder tile; V^T elements are stored one by one here (a few remainder tiles per launch)
+__global__ __launch_bounds__(256) void gemm_splitk_fixup_qkv_kernel(GemmArgs p) {
+    const QkvEpiArgs& e = p.qe;
+    const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
+    const int r = blockIdx.x >> 5;
+    const int idx = ((int)(blockIdx.x & 31) << 8) + threadIdx.x;
+    const int ml = idx >> 5, cx = (idx & 31) << 2;   // cx: tile column of x (0..124) = g * 64 + dl
+    int tm, tn;
+    tile_from_pid(p.sk_full + r, tiles_m, tiles_n, tm, tn, p.tile_group);
+    const int mp = tm * 256 + ml, n0 = tn * 256;
+    const int b = mp / e.Tp, t = mp - b * e.Tp;
+    if (mp >= p.M || t >= e.T) return;
+    const float* base = p.ws + (size_t)r * p.sk_ks * 65536 + ml * 256 + cx;
+    f32x4 x = ld16f(base), y = ld16f(base + 128);
+    for (int k = 1; k < p.sk_ks; ++k) {
+        x = x + ld16f(base + (size_t)k * 65536);
+        y = y + ld16f(base + (size_t)k * 65536 + 128);
+    }
+    const int D = e.H * 128, which = n0 / D, g = cx >> 6, dl = cx & 63, head = (n0 - which * D) / 128 + g, nx = n0 + g * 128 + dl;
+    const int src = b * e.T + t;
+    if (p.f8) {
+        x = x * (ld16f(p.w_scale + nx) * p.a_scale[src]);
+        y = y * (ld16f(p.w_scale + nx + 64) * p.a_scale[src]);
+    }
+    if (p.row_scale) {
+        x = x * p.row_scale[src];
+        y = y * p.row_scale[src];
+    }
+    if (p.bias) {
+        x = x + ld16f(p.bias + nx);
+        y = y + ld16f(p.bias + nx + 64);
+    }
+    if (which < 2) {
+        qkv_rope_store(e, which, head, b, t, dl, x, y);
+        return;
+    }
+    const u32x2 vx = pack_bf4(x), vy = pack_bf4(y);
+    qkv_v_store(e, head, b, t, dl, vx);
+    qkv_v_store(e, head, b, t, 64 + dl, vy);
+    bf16_t* vt = e.vt + (((size_t)b * e.H + head) * 128) * e.vt_stride + (t & ~31) + vt_pos32(t & 31);
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        vt[(size_t)(dl + f) * e.vt_stride] = (bf16_t)(f & 1 ? vx[f >> 1] >> 16 : vx[f >> 1] & 0xFFFFu);
+        vt[(size_t)(64 + dl + f) * e.vt_stride] = (bf16_t)(f & 1 ? vy[f >> 1] >> 16 : vy[f >> 1] & 0xFFFFu);
+    }
+    if (t == e.T - 1)   // the keys behind the sequence inside its last 32-key block are zeros (as the tile epilogue writes them)
+        for (int kk = (t & 31) + 1; kk < 32; ++kk)
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                e.vt[(((size_t)b * e.H + head) * 128 + dl + f) * e.vt_stride + (t & ~31) + vt_pos32(kk)] = 0;
+                e.vt[(((size_t)b * e.H + head) * 128 + 64 + dl + f) * e.vt_stride + (t & ~31) + vt_pos32(kk)] = 0;
+            }
 }
 
 // rstd of every row from the sum-of-squares partials a RESID epilogue published (one wave per row, fixed order)
@@ -587,6 +837,16 @@ static void launch_gemm_f8(const GemmArgs& a, int epilogue, hipStream_t s) {
         if (ask.sk_ks > 1)                                                                             \
             VC_LAUNCH((gemm_splitk_fixup_kernel<E>), dim3((unsigned)(rem * 64)), dim3(256), 0, s, ask); \
     } while (0)
+    if (epilogue == EPI_QKV) {
+        static bool once = false;
+        if (!once) {
+            allow_big_lds_gemm(gemm_bf16_8phase_kernel<EPI_QKV, true>, sh2);
+            once = true;
+        }
+        VC_LAUNCH((gemm_bf16_8phase_kernel<EPI_QKV, true>), gsk, b2, sh2, s, ask);
+        if (ask.sk_ks > 1) VC_LAUNCH(gemm_splitk_fixup_qkv_kernel, dim3((unsigned)(rem * 32)), dim3(256), 0, s, ask);
+        return;
+    }
     switch (epilogue) {
         case EPI_BF16: VC_G8(EPI_BF16); break;
         case EPI_RESID_F32: VC_G8(EPI_RESID_F32); break;
@@ -596,10 +856,48 @@ static void launch_gemm_f8(const GemmArgs& a, int epilogue, hipStream_t s) {
 #undef VC_G8
 }
 
+// test / benchmark hook (vck_set_gemm_variant): overrides VC_GEMM_VARIANT inside one process; < 0 = the environment's
+static int g_gemm_variant = -1;
+void set_gemm_variant(int v) { g_gemm_variant = v; }
+
 void launch_gemm(const GemmArgs& a, int epilogue, hipStream_t s) {
     if (a.xg_out && (epilogue != EPI_RESID_F32 || a.N % 16 != 0 || !a.xg_w || !a.ssq_out || a.npart < a.N / 16))
         throw std::runtime_error("gemm: the folded-RMSNorm producer needs EPI_RESID_F32, N % 16 == 0, xg_w, ssq_out, npart >= N / 16");
+    if (epilogue == EPI_QKV) {
+        const QkvEpiArgs& e = a.qe;
+        if (a.kwrap > 0 || a.xg_out || e.H <= 0 || (e.H * 128) % 256 != 0 || a.N != 3 * e.H * 128 || e.Tp % 32 != 0 || e.Tp < e.T ||
+            a.M != e.B * e.Tp || !e.q || !e.k || !e.vt || !e.rope_cos || !e.rope_sin || (!e.v && !e.v8))
+            throw std::runtime_error("gemm: EPI_QKV needs hd 128, D % 256 == 0, N = 3 D, M = B * Tp with Tp = rup(T, 32), q / k / v / vt and the RoPE tables");
+    }
     if (a.f8) return launch_gemm_f8(a, epilogue, s);
+    if (epilogue == EPI_QKV) {   // always the 8-phase 256 x 256 kernel on the 16 x 16 x 32 MFMA (any size: rows are clamped, stores masked)
+        const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+        const size_t sh2 = 2 * (256 * 128 + 256 * 128);
+        static const int sk_on = getenv("VC_GEMM_SPLITK") ? atoi(getenv("VC_GEMM_SPLITK")) : 1;
+        GemmArgs ask = a;
+        ask.tile_group = 4;
+        ask.xcd_remap_on = 1;
+        ask.sk_full = (int)t256;
+        ask.sk_ks = 1;
+        const long rem = t256 % 256;
+        if (sk_on && a.ws && t256 > 256 && rem > 0 && rem <= 128) {
+            int ks = (int)std::min<long>(256 / rem, 8);
+            ks = std::min(ks, a.K / BK);
+            while (ks > 1 && (size_t)rem * ks * 65536 * 4 > a.ws_bytes) --ks;
+            if (ks > 1) {
+                ask.sk_full = (int)(t256 - rem);
+                ask.sk_ks = ks;
+            }
+        }
+        static bool once = false;
+        if (!once) {
+            allow_big_lds_gemm(gemm_bf16_8phase_kernel<EPI_QKV>, sh2);
+            once = true;
+        }
+        VC_LAUNCH((gemm_bf16_8phase_kernel<EPI_QKV>), dim3((unsigned)(ask.sk_ks > 1 ? ask.sk_full + rem * ask.sk_ks : t256)), dim3(512), sh2, s, ask);
+        if (ask.sk_ks > 1) VC_LAUNCH(gemm_splitk_fixup_qkv_kernel, dim3((unsigned)(rem * 32)), dim3(256), 0, s, ask);
+        return;
+    }
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const dim3 grid(tiles), block(256);
     const size_t shmem = 4 * TILE_BYTES;
@@ -608,7 +906,13 @@ void launch_gemm(const GemmArgs& a, int epilogue, hipStream_t s) {
     // same geometry); 2 force the one-barrier 256x256 DMA kernel (947-1087 TFLOP/s where the 8-phase schedule reaches
     // 1068-1281); 3 force DMA 128x128; 4 force 256x256 as 4 waves x (128x128) (1 wave per SIMD: 20-25 % slower than 2
     // with this simple loop); 5 force the 8-phase kernel for every size
-    static const int variant = getenv("VC_GEMM_VARIANT") ? atoi(getenv("VC_GEMM_VARIANT")) : 1;
+    static const int env_variant = getenv("VC_GEMM_VARIANT") ? atoi(getenv("VC_GEMM_VARIANT")) : 1;
+    int variant = g_gemm_variant >= 0 ? g_gemm_variant : env_variant;
+    // 6 / 7: the 8-phase kernel on the 32 x 32 x 16 MFMA for large problems / for every size (the folded-RMSNorm producer's row
+    // sums assume the 16 x 16 accumulator layout: it keeps the 16 x 16 form)
+    const bool m32 = (variant == 6 || variant == 7) && !a.xg_out;
+    if (variant == 6) variant = 1;
+    if (variant == 7) variant = 5;
     if (variant >= 1) {
         const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
         const bool big = variant == 2 || variant == 4 || variant == 5 || (variant == 1 && a.M >= 1024 && a.N >= 512);
@@ -646,9 +950,16 @@ void launch_gemm(const GemmArgs& a, int epilogue, hipStream_t s) {
             allow_big_lds_gemm(gemm_bf16_dma_kernel<E, 2, 2, 8, 8>, sh2);                                  \
             allow_big_lds_gemm(gemm_bf16_8phase_kernel<E>, sh2);                                           \
             allow_big_lds_gemm(gemm_bf16_8phase_kernel<E, false, true>, sh2);                              \
+            allow_big_lds_gemm(gemm_bf16_8phase_kernel<E, false, false, true>, sh2);                       \
+            allow_big_lds_gemm(gemm_bf16_8phase_kernel<E, false, true, true>, sh2);                        \
             once = true;                                                                                   \
         }                                                                                                  \
-        if (phased && ask.kwrap > 0) {                                                                     \
+        if (phased && m32) {                                                                               \
+            if (ask.kwrap > 0) VC_LAUNCH((gemm_bf16_8phase_kernel<E, false, true, true>), gsk, b2, sh2, s, ask);   \
+            else VC_LAUNCH((gemm_bf16_8phase_kernel<E, false, false, true>), gsk, b2, sh2, s, ask);        \
+            if (ask.sk_ks > 1)                                                                             \
+                VC_LAUNCH((gemm_splitk_fixup_kernel<E>), dim3((unsigned)(rem * 64)), dim3(256), 0, s, ask); \
+        } else if (phased && ask.kwrap > 0) {                                                              \
             VC_LAUNCH((gemm_bf16_8phase_kernel<E, false, true>), gsk, b2, sh2, s, ask);                    \
             if (ask.sk_ks > 1)                                                                             \
                 VC_LAUNCH((gemm_splitk_fixup_kernel<E>), dim3((unsigned)(rem * 64)), dim3(256), 0, s, ask); \

@@ -29,6 +29,22 @@ VCK_EXPORT void vck_gemm_f8(const uint8_t* A, const float* a_scale, const uint8_
     a.w_scale = w_scale;
     launch_gemm(a, epi, S(stream));
 }
+/* the QKV GEMM of a prefill layer with RoPE + head split + KV write in its epilogue (EPI_QKV; kernels.h QkvEpiArgs): A [B * T, lda]
+ * bf16 (or e4m3 rows + a_scale with f8 != 0: W then e4m3 [3 D, K] + w_scale), W [3 D, K]; hd = 128 */
+VCK_EXPORT void vck_gemm_qkv(const void* A, const float* a_scale, const void* W, const float* w_scale, const float* bias, int B, int T,
+                             int H, int K, int lda, uint16_t* q, uint16_t* k, uint16_t* v, uint16_t* vt, uint8_t* k8, uint8_t* v8,
+                             int q_stride, int kv_stride, int vt_stride, int kv8_stride, const float* rope_cos, const float* rope_sin,
+                             int f8, float* ws, size_t ws_bytes, void* stream) {
+    const int Tp = (T + 31) / 32 * 32;
+    GemmArgs a{reinterpret_cast<const bf16_t*>(A), reinterpret_cast<const bf16_t*>(W), bias, nullptr, B * Tp, 3 * H * 128, K, lda, K, 0};
+    a.ws = ws;
+    a.ws_bytes = ws_bytes;
+    a.f8 = f8;
+    a.a_scale = a_scale;
+    a.w_scale = w_scale;
+    a.qe = QkvEpiArgs{q, k, v, vt, k8, v8, rope_cos, rope_sin, B, T, Tp, H, q_stride, kv_stride, vt_stride, kv8_stride};
+    launch_gemm(a, EPI_QKV, S(stream));
+}
 VCK_EXPORT void vck_quant_act_rows(const uint16_t* A, int lda, uint8_t* Q, float* scale, int M, int K, void* stream) {
     launch_quant_act_rows(A, lda, Q, scale, M, K, S(stream));
 }
@@ -260,6 +276,7 @@ VCK_EXPORT void vck_gemv_full(const uint16_t* X, const void* Wp, const float* ws
 }
 /* split-mode GEMV: 0 = per-wave rings, 1 / -1 = workgroup-shared activation chunks (default) */
 VCK_EXPORT void vck_set_gemv_variant(int v) { set_gemv_variant(v); }
+VCK_EXPORT void vck_set_gemm_variant(int v) { set_gemm_variant(v); }
 VCK_EXPORT void vck_set_gemv_wide(int v) { set_gemv_wide(v); }
 VCK_EXPORT unsigned long long vck_gemv_wide_launches() { return gemv_wide_launches(); }
 VCK_EXPORT unsigned long long vck_gemv_wg_launches() { return gemv_wg_launches(); }

@@ -21,6 +21,28 @@ enum GemmEpilogue : int {
     EPI_F32 = 3,         // out fp32 [M,N]   = acc + bias                        (patchify K1, logits K18)
     EPI_RESID_F32 = 4,   // out fp32 [M,N]  += acc + bias  (in-place residual)   (K6, K7, K16, K17)
     EPI_SWIGLU = 5,      // W rows interleaved (gate,up): out bf16 [M,N/2] = silu(g)*u   (K17)
+    EPI_QKV = 6,         // fused-QKV projection of a prefill: RoPE + head split + KV-cache write in the epilogue (K13/K14, GemmArgs::qe)
+};
+
+// EPI_QKV (round 6; SURVEY K13 "fused into K12 epilogue / KV-write"; [HF] llama/modeling_llama.py:113-160,254-262): the QKV GEMM of
+// a prefill layer writes, instead of the fused [M, 3D] bf16 rows qkv_split_kernel used to re-read, directly
+//   q  [B,H,q_stride,hd]   roped queries                      k  [B,H,kv_stride,hd]   roped keys (the cache, or the flash scratch)
+//   v  [B,H,kv_stride,hd]  value rows of the cache            vt [B,H,hd,vt_stride]   V^T scratch in the flash kernel's key order
+//   k8 / v8 [B,H,kv8_stride,hd] e4m3 cache rows (fp8 weight format; v may then be nullptr)
+// with the bits qkv_split_kernel produces (projection rounded to bf16, RoPE in fp32 on the rounded values, rounded again).
+// hd = 128, (H * hd) % 256 == 0, N = 3 H hd.  The kernel reads the weight rows of a 256-row tile in the order
+// {head 2a: d 0..63 | head 2a+1: d 0..63 | head 2a: d 64..127 | head 2a+1: d 64..127} (a row permutation of its LDS-DMA source
+// addresses: the weights stay as they are), so a lane's accumulators of the tile's two halves are the rotate-half partners
+// d and d + 64 of ONE head and the RoPE is lane-local.  The token rows of the GEMM are the samples padded to Tp = rup(T, 32)
+// (M = B * Tp; row b * Tp + t reads A row b * T + min(t, T - 1), stores are masked to t < T): a 32-token block of the tile never
+// straddles two samples, and a quad transpose inside the wave turns a lane's 4 features x 2 tokens into the 16-byte
+// 8-key chunks of the V^T scratch.
+struct QkvEpiArgs {
+    bf16_t *q, *k, *v, *vt;
+    uint8_t *k8, *v8;
+    const float *rope_cos, *rope_sin;   // fp32 [max_pos, hd/2]; position = t
+    int B, T, Tp, H;
+    int q_stride, kv_stride, vt_stride, kv8_stride;
 };
 
 struct GemmArgs {
@@ -62,6 +84,7 @@ struct GemmArgs {
     const float* xg_w;
     float* ssq_out;
     int ld_xg, xg_lo, npart;
+    QkvEpiArgs qe;   // EPI_QKV only
 };
 void launch_gemm(const GemmArgs& a, int epilogue, hipStream_t s);
 // rstd[m] = rsqrt(sum_{p < nparts} ssq[m * npart + p] / D + eps): the row scales of the consumer of a folded RMSNorm
@@ -118,6 +141,7 @@ struct GemvArgs {
 void launch_gemv(const GemvArgs& a, int epilogue, hipStream_t s);
 // the decode GEMV of precision mode "split": 0 = per-wave rings (two weight passes of 16 rows), -1 / 1 = the workgroup-shared form
 void set_gemv_variant(int v);
+void set_gemm_variant(int v);   // overrides VC_GEMM_VARIANT inside one process (< 0: the environment's); 6 / 7 = the 32 x 32 x 16 MFMA form
 void set_gemv_wide(int v);       // -1 / 1 = the measured classes (default), 0 = off, 2 = every class (launch_gemv_wide)
 unsigned long gemv_wide_launches();
 bool gemv_wg_enabled();                          // the workgroup-shared form serves the split step's GEMVs

@@ -40,6 +40,7 @@ inline void check_launch(const char* what) {
 namespace vc {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef uint16_t bf16_t;  // raw bf16 bit pattern
@@ -161,6 +162,11 @@ VC_DEV f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_hw, a),
                                                    __builtin_bit_cast(bf16x8_hw, b), c, 0, 0, 0);
 }
+// v_mfma_f32_32x32x16_bf16: A[i][k]: lane i + 32 (k / 8), elem k % 8 (i < 32, k < 16); B[k][j]: lane j + 32 (k / 8), elem k % 8;
+// D[i][j]: lane j + 32 ((i / 4) % 2), reg i % 4 + 4 (i / 8)  (cdna_hip_programming.md section 3)
+VC_DEV f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_hw, a), __builtin_bit_cast(bf16x8_hw, b), c, 0, 0, 0);
+}
 // v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain): A[i][k]: lane i+16k; B[k][j]: lane j+16k; D as for bf16
 VC_DEV f32x4 mfma16_f32(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 // v_mfma_scale_f32_16x16x128_f8f6f4 with both operands OCP e4m3 and every block scale 2^0 (E8M0 127): the K = 128 fp8
@@ -219,6 +225,30 @@ template <int N> VC_DEV float lanes_sum(float s) {
     return s;
 }
 #endif
+
+// exchange inside aligned quads of lanes: the value of lane l ^ 1 / l ^ 2 (DPP quad_perm [1,0,3,2] / [2,3,0,1] on the device)
+#ifdef VC_EMU
+VC_DEV uint32_t quad_xor1(uint32_t v) { return shfl_xor(v, 1); }
+VC_DEV uint32_t quad_xor2(uint32_t v) { return shfl_xor(v, 2); }
+#else
+VC_DEV uint32_t quad_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); }
+VC_DEV uint32_t quad_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false); }
+#endif
+// 4 x 4 transpose of 32-bit values across an aligned quad of lanes: afterwards P[s] of lane r (= lane & 3) is what lane s held in P[r]
+VC_DEV void quad_transpose4(uint32_t (&P)[4], int r) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const uint32_t got = quad_xor1((r & 1) ? P[2 * a] : P[2 * a + 1]);
+        if (r & 1) P[2 * a] = got;
+        else P[2 * a + 1] = got;
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const uint32_t got = quad_xor2((r & 2) ? P[b] : P[b + 2]);
+        if (r & 2) P[b] = got;
+        else P[b + 2] = got;
+    }
+}
 
 // max of three without the canonicalising v_max x, x hipcc puts in front of every fmaxf operand it cannot prove quiet
 #ifdef VC_EMU

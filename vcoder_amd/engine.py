@@ -161,6 +161,11 @@ class HipEngine:
         """a sample's bits independent of the batch / shard it runs in (vc_model_set_batch_invariant): N ranks x B == one rank x N B"""
         self._check(self.lib.vc_model_set_batch_invariant(self._model, 1 if on else 0))
 
+    def set_qkv_fused(self, on=True):
+        """RoPE + head split + KV write in the prefill's QKV GEMM epilogue (default on from 1024 token rows); False / 0 = the separate
+        launches (A/B, regression), 2 = the fused form for every problem size"""
+        self._check(self.lib.vc_model_set_qkv_fused(self._model, int(on)))
+
     def set_fp8_kv(self, on: bool):
         """'fp8' weight format: e4m3 KV cache for the decode steps (default) or bf16 rows.  Before finalize()."""
         self._check(self.lib.vc_model_set_fp8_kv(self._model, 1 if on else 0))
