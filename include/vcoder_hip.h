@@ -99,6 +99,12 @@ int vc_model_finalize(vc_model* m);
  * checkpoint's values to ~16 mantissa bits; exact for fp16 values), the bf16 fast path uses the bf16-rounded weights alone.
  * 0 for a bf16 checkpoint.  >= 0, or a negative vc_status. */
 int vc_model_inexact_tensors(vc_model* m);
+/* Round 6: which 16-bit format the MFMA operands / stored activations of THIS library have: 0 = bfloat16 (libvcoder_hip.so), 1 = IEEE
+ * fp16 (libvcoder_hip_f16.so — same sources, same C ABI, built with -DVC_F16: fp16 operands on v_mfma_f32_16x16x32_f16 at the bf16
+ * rate, conversions saturating at 65504; the operand precision of the reference's own GPU path, vcoder_llava/model/builder.py:39
+ * torch_dtype=float16 and :142).  "bf16" in the names and comments of this header then reads "the library's operand format": an
+ * fp16-valued checkpoint is held exactly (vc_model_inexact_tensors counts what fp16 cannot hold). */
+int vc_operand_format(void);
 
 /* arithmetic mode: 0 = bf16 MFMA operands, fp32 accumulate/residual/softmax (default; what bench.py measures);
  * 1 = strict: fp32 activations end to end on fp32 MFMA (slow) — within ~1e-5 of the reference's fp32 CPU path;
@@ -282,6 +288,9 @@ int vc_pool_profile(vc_model* m, int on);
  * would need again anyway; on = 0 steps whatever rows are active (lower inter-token latency for the calls in flight, lower
  * throughput).  No reference counterpart (the reference runs one generate() at a time). */
 int vc_pool_set_hold(vc_model* m, int on);
+/* Rows of the shared decode pool: 32 (default) or 64 (round-6 measurement: two 32-row weight passes per step).  Takes effect when the
+ * pool is next built (idle).  64 rows: bf16 step only, no in-situ timing. */
+int vc_pool_set_rows(vc_model* m, int rows);
 /* sums since the last reset, each [4 spans: 8 / 16 / 24 / 32 rows][6 kinds: qkv, decode attention, o_proj, gate/up, down, lm_head]:
  * exec_us = earliest workgroup start -> latest workgroup end of the launches; period_us = latest end of the previous launch of the
  * step -> latest end of this one (dispatch, drain and inter-kernel gap included: what the step's dependency chain pays per launch;

@@ -62,12 +62,16 @@ class Rounder:
     inputs of the decoder linears are quantised per token row (`q8`) while the pass is a prefill (W8A8), and the KV cache the
     cached decode steps read holds e4m3 values (llama_layer)."""
 
-    def __init__(self, emu_bf16: bool, act_fp8: bool = False):
+    def __init__(self, emu_bf16, act_fp8: bool = False):
+        # emu_bf16: False = fp32; True / "bf16" = the device's bf16 rounding points; "fp16" = the same points in IEEE fp16, saturating
+        # at 65504 (libvcoder_hip_f16.so, the -DVC_F16 build of the kernels: vcoder_amd/csrc/vc_device.h)
         self.emu = emu_bf16
         self.act_fp8 = act_fp8
         self.prefill = False
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        if self.emu == "fp16":
+            return x.clamp(-65504.0, 65504.0).to(torch.float16).to(torch.float32)
         return _bf16(x) if self.emu else x
 
     def q8(self, x: torch.Tensor) -> torch.Tensor:

@@ -335,6 +335,27 @@ inline f32x4 mfma16_f8(u32x4 a0, u32x4 a1, u32x4 b0, u32x4 b1, f32x4 c) {
     return d;
 }
 
+// one 16-bit MFMA operand element as a float: bf16, or fp16 in the -DVC_F16 build (vc_device.h)
+inline float emu_operand(uint16_t b) {
+#ifdef VC_F16
+    const uint32_t sign = (uint32_t)(b & 0x8000u) << 16, e = (b >> 10) & 31u, m = b & 0x3FFu;
+    uint32_t u;
+    float f;
+    if (e == 0) {
+        f = (float)m * 5.9604644775390625e-08f;
+        memcpy(&u, &f, 4);
+        u |= sign;
+    } else if (e == 31) u = sign | 0x7F800000u | (m << 13);
+    else u = sign | ((e + 112u) << 23) | (m << 13);
+    memcpy(&f, &u, 4);
+    return f;
+#else
+    uint32_t u = (uint32_t)b << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+#endif
+}
 // v_mfma_f32_32x32x16_bf16: A[i][k] in lane i + 32 (k / 8) elem k % 8, B likewise by column, D[i][j] in lane j + 32 ((i / 4) % 2),
 // reg i % 4 + 4 (i / 8)
 inline f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
@@ -352,11 +373,7 @@ inline f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
             uint16_t ab, bb;
             memcpy(&ab, w.xchg[i + 32 * (k / 8)] + 2 * (k % 8), 2);
             memcpy(&bb, w.xchg[j + 32 * (k / 8)] + 16 + 2 * (k % 8), 2);
-            uint32_t au = (uint32_t)ab << 16, bu = (uint32_t)bb << 16;
-            float af, bf;
-            memcpy(&af, &au, 4);
-            memcpy(&bf, &bu, 4);
-            acc += af * bf;
+            acc += emu_operand(ab) * emu_operand(bb);
         }
         d[r] = c[r] + acc;
     }
@@ -380,11 +397,7 @@ inline f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
             uint16_t ab, bb;
             memcpy(&ab, w.xchg[i + 16 * (k / 8)] + 2 * (k % 8), 2);
             memcpy(&bb, w.xchg[j + 16 * (k / 8)] + 16 + 2 * (k % 8), 2);
-            uint32_t au = (uint32_t)ab << 16, bu = (uint32_t)bb << 16;
-            float af, bf;
-            memcpy(&af, &au, 4);
-            memcpy(&bf, &bu, 4);
-            acc += af * bf;
+            acc += emu_operand(ab) * emu_operand(bb);
         }
         d[r] = c[r] + acc;
     }

@@ -30,16 +30,34 @@ def bf16_round(x: np.ndarray) -> np.ndarray:
     return synth.round_to_bf16(np.asarray(x, dtype=np.float32))
 
 
+def _op_bits(a, operands):
+    """fp32 array -> the bit patterns of the library's 16-bit operand format (uint16): bfloat16, or IEEE fp16 for the -DVC_F16 build"""
+    a = np.asarray(a, dtype=np.float32)
+    if operands == "fp16":
+        return np.ascontiguousarray(np.clip(a, -65504.0, 65504.0).astype(np.float16)).view(np.uint16).reshape(np.shape(a))
+    return synth.to_bf16_bits(a).reshape(np.shape(a))
+
+
+def _op_decode(bits, operands):
+    bits = np.ascontiguousarray(bits).view(np.uint16)
+    if operands == "fp16":
+        return bits.view(np.float16).astype(np.float32).reshape(bits.shape)
+    return synth.from_bf16_bits(bits).reshape(bits.shape)
+
+
 class EmuBackend:
     name = "emu"
 
-    def __init__(self):
+    def __init__(self, operands: str = "bf16"):
         # VC_EMU_LIB: another build of the emulator library (e.g. with the host engine under AddressSanitizer, tools/emu_asan.sh)
-        path = os.environ.get("VC_EMU_LIB") or os.path.join(ROOT, "tests", "emu", "libvcoder_emu.so")
+        self.operands = operands
+        f16 = operands == "fp16"
+        path = os.path.join(ROOT, "tests", "emu", "libvcoder_emu_f16.so") if f16 else \
+            (os.environ.get("VC_EMU_LIB") or os.path.join(ROOT, "tests", "emu", "libvcoder_emu.so"))
         if not os.path.exists(path):
             import subprocess
 
-            subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build_emu.sh")])
+            subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build_emu.sh")] + (["f16"] if f16 else []))
         self.lib = ctypes.CDLL(path)
 
     # every array handed to a kernel ends (to 16 bytes) at an inaccessible page — an out-of-bounds access faults (VC_EMU_GUARD=0:
@@ -66,8 +84,8 @@ class EmuBackend:
     def f32(self, a):
         return self._guard(np.ascontiguousarray(a, dtype=np.float32))
 
-    def bf16(self, a):
-        return self._guard(synth.to_bf16_bits(np.asarray(a, dtype=np.float32)).reshape(np.shape(a)))
+    def bf16(self, a):   # "bf16" = the library's 16-bit operand format
+        return self._guard(_op_bits(a, self.operands))
 
     def i32(self, a):
         return self._guard(np.ascontiguousarray(a, dtype=np.int32))
@@ -79,7 +97,7 @@ class EmuBackend:
         return None if a is None else a.ctypes.data_as(c_p)
 
     def host_f32(self, a):
-        return synth.from_bf16_bits(a).reshape(a.shape) if a.dtype == np.uint16 else np.array(a)
+        return _op_decode(a, self.operands) if a.dtype == np.uint16 else np.array(a)
 
     def host_i32(self, a):
         return np.array(a)
@@ -91,18 +109,18 @@ class EmuBackend:
 class HipBackend:
     name = "hip"
 
-    def __init__(self):
+    def __init__(self, operands: str = "bf16"):
         from vcoder_amd import _lib
 
-        self.lib = _lib.load()
+        self.operands = operands
+        self.lib = _lib.load(operands)
         self.dev = torch.device("cuda:0")
 
     def f32(self, a):
         return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.dev)
 
-    def bf16(self, a):
-        bits = synth.to_bf16_bits(np.asarray(a, dtype=np.float32)).reshape(np.shape(a))
-        return torch.from_numpy(bits.view(np.int16)).to(self.dev)
+    def bf16(self, a):   # "bf16" = the library's 16-bit operand format
+        return torch.from_numpy(_op_bits(a, self.operands).view(np.int16)).to(self.dev)
 
     def i32(self, a):
         return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(self.dev)
@@ -116,7 +134,7 @@ class HipBackend:
 
     def host_f32(self, a):
         if a.dtype == torch.int16:
-            return synth.from_bf16_bits(a.cpu().numpy().view(np.uint16)).reshape(tuple(a.shape))
+            return _op_decode(a.cpu().numpy(), self.operands).reshape(tuple(a.shape))
         return a.cpu().numpy()
 
     def host_i32(self, a):

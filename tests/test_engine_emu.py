@@ -54,6 +54,16 @@ def test_qkv_fused_epilogue_through_the_engine(emu_lib, fmt):
     eng.close()
 
 
+def test_fp16_operand_library_fixture():
+    """Round 6: the kernels built with -DVC_F16 (IEEE fp16 MFMA operands — the precision of the reference's own GPU path — on the
+    emulator's -DVC_F16 build): logits of a live-reference fixture at all positions and every cached step within 1.2e-3 of
+    |logit|max (measured 4.7e-4; the bf16 build: 4e-3), greedy ids equal, generate() == the step loop."""
+    be16 = kc.EmuBackend("fp16")
+    assert be16.lib.vc_operand_format() == 1
+    r = e2e_cases.check_fixture_fp16("ds_img_depth_seg", lib=be16.lib)
+    assert r["ids_equal"] and r["logits_rel_err_vs_ref"] < 1e-3
+
+
 def test_other_projector_types_fixture(emu_lib):
     """'linear' <image> adapter + 'mlp3x_gelu' <seg> / <depth> adapter, fixture of the live reference (round 3): fast path
     within the bf16 tolerance, strict and split modes within 1e-3 with bit-exact ids ('identity': under -m gpu)."""

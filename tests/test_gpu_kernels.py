@@ -15,6 +15,30 @@ def be():
     return kc.HipBackend()
 
 
+@pytest.fixture(scope="module")
+def be16():
+    """libvcoder_hip_f16.so: the same kernels built with -DVC_F16 (IEEE fp16 MFMA operands, round 6)"""
+    return kc.HipBackend("fp16")
+
+
+def test_fp16_operand_library_kernels(be16):
+    """The -DVC_F16 build of the kernels at true shapes — v_mfma_f32_16x16x32_f16 fragments, the saturating fp16 conversions, the
+    fp16 forms of every epilogue: GEMM (8-phase 256 x 256 incl. a split-K round, the 128 x 128 form), the decode GEMV ring kernel,
+    flash attention, the fused QKV epilogue (bit for bit against GEMM + split), against the same float64 references and tolerances
+    as the bf16 build (whose operands hold 3 bits less)."""
+    assert be16.lib.vc_operand_format() == 1
+    kc.check_gemm(be16, 1216, 12288, 4096, 0, False)
+    kc.check_gemm(be16, 1154, 4096, 1024, 1, True)
+    kc.check_gemm(be16, 1216, 22016, 4096, 5, False)
+    kc.check_gemm(be16, 9728, 4096, 4096, 4, False, ws_mb=64)
+    kc.check_gemm(be16, 70, 264, 192, 3, True)
+    kc.check_gemv(be16, 8, 12288, 4096, 0)
+    kc.check_gemv(be16, 8, 4096, 11008, 2)
+    kc.check_attention(be16, 2, 32, 1216, 128, True)
+    kc.check_attention(be16, 3, 16, 577, 64, False)
+    kc.check_gemm_qkv_fused(be16, 2, 1216, 32, 4096)
+
+
 # (M, N, K, epilogue): ViT QKV/out/fc1/fc2, patchify, adapters, Llama qkv/o/gate-up/down, ragged edges
 @pytest.mark.parametrize("M,N,K,epi,bias", [
     (1154, 3072, 1024, 0, True), (1154, 1024, 1024, 4, True), (1154, 4096, 1024, 1, True), (1154, 1024, 4096, 4, True),

@@ -115,6 +115,8 @@ def declare(lib: C.CDLL) -> C.CDLL:
     lib.vc_pool_step_counts.restype = C.c_int
     lib.vc_model_set_batch_invariant.argtypes = [vp, i32]
     lib.vc_model_set_batch_invariant.restype = C.c_int
+    lib.vc_pool_set_rows.argtypes = [vp, i32]
+    lib.vc_pool_set_rows.restype = C.c_int
     lib.vc_model_set_qkv_fused.argtypes = [vp, i32]
     lib.vc_model_set_qkv_fused.restype = C.c_int
     lib.vc_model_set_fp8_kv.argtypes = [vp, i32]
@@ -138,21 +140,37 @@ def declare(lib: C.CDLL) -> C.CDLL:
 
 
 _lib = None
+_lib_f16 = None
+LIB_PATH_F16 = os.environ.get("VCODER_HIP_LIB_F16") or os.path.join(HERE, "lib", "libvcoder_hip_f16.so")
 
 
-def load() -> C.CDLL:
-    """Load the HIP library.  Raises if it has not been built — never falls back to anything else."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        try:  # not a fallback: the same HIP library, compiled now (hipcc, gfx950, a few seconds)
+def load(operands: str = "bf16") -> C.CDLL:
+    """operands="bf16": libvcoder_hip.so (the benchmarked path); "fp16": libvcoder_hip_f16.so — the same kernels and C ABI with IEEE
+    fp16 MFMA operands (include/vcoder_hip.h vc_operand_format), the precision of the reference's own GPU path.  No fallback of one
+    to the other, and none to a CPU path: a missing library is an error."""
+    global _lib, _lib_f16
+    if operands not in ("bf16", "fp16"):
+        raise ValueError("operands: 'bf16' or 'fp16'")
+    f16 = operands == "fp16"
+    cached = _lib_f16 if f16 else _lib
+    if cached is not None:
+        return cached
+    path = LIB_PATH_F16 if f16 else LIB_PATH
+    if not os.path.exists(path):
+        try:  # not a fallback: the same HIP library, compiled now (hipcc, gfx950)
             from . import build as _build
 
-            _build.build(verbose=False)
+            _build.build(verbose=False, operands=operands)
         except Exception as e:
             raise RuntimeError(
-                f"{LIB_PATH} is missing and could not be built ({e}): run `python -m vcoder_amd.build` (hipcc, gfx950). "
-                "vcoder_amd has no CPU fallback.") from e
-    _lib = declare(C.CDLL(LIB_PATH))
-    return _lib
+                f"{path} is missing and could not be built ({e}): run `python -m vcoder_amd.build{' --fp16' if f16 else ''}` "
+                "(hipcc, gfx950).  vcoder_amd has no CPU fallback.") from e
+    lib = declare(C.CDLL(path))
+    lib.vc_operand_format.restype = C.c_int
+    if lib.vc_operand_format() != (1 if f16 else 0):
+        raise RuntimeError(f"{path} was built for the other operand format")
+    if f16:
+        _lib_f16 = lib
+    else:
+        _lib = lib
+    return lib

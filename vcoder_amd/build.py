@@ -32,9 +32,22 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+LIB_F16 = os.path.join(LIBDIR, "libvcoder_hip_f16.so")
+
+
+def build(force: bool = False, verbose: bool = True, operands: str = "bf16") -> str:
+    """operands="bf16": libvcoder_hip.so (the benchmarked path); "fp16": libvcoder_hip_f16.so — the same sources with -DVC_F16 (fp16
+    MFMA operands, include/vcoder_hip.h vc_operand_format); "all": both, returns the bf16 library's path."""
+    if operands == "all":
+        build(force, verbose, "fp16")
+        return build(force, verbose, "bf16")
+    f16 = operands == "fp16"
+    return _build(force, verbose, LIB_F16 if f16 else LIB, "obj_f16" if f16 else "obj", ["-DVC_F16"] if f16 else [])
+
+
+def _build(force: bool, verbose: bool, LIB: str, objname: str, extra) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
-    objdir = os.path.join(LIBDIR, "obj")
+    objdir = os.path.join(LIBDIR, objname)
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     cc = hipcc()
@@ -44,7 +57,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         if force or _stale(obj, [sp] + hdrs):
-            cmd = [cc] + FLAGS + ["-x", "hip", "-c", sp, "-o", obj]
+            cmd = [cc] + FLAGS + extra + ["-x", "hip", "-c", sp, "-o", obj]
             if verbose:
                 print("[vcoder_amd.build]", " ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, cwd=CSRC)))
@@ -60,4 +73,4 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, operands="all" if "--all" in sys.argv else ("fp16" if "--fp16" in sys.argv else "bf16")))

@@ -56,9 +56,11 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(QkvSplitArgs p) {
                 for (int e = 0; e < 4; ++e) {
                     float x0 = bf2f_lo(lo[e]), x1 = bf2f_hi(lo[e]), y0 = bf2f_lo(hi[e]), y1 = bf2f_hi(hi[e]);
                     const float c0 = cs[2 * e], c1 = cs[2 * e + 1], s0 = sn[2 * e], s1 = sn[2 * e + 1];
-                    // out[d] = x*cos - y*sin ; out[d+hd/2] = y*cos + x*sin
-                    olo[e] = pack_bf2(x0 * c0 - y0 * s0, x1 * c1 - y1 * s1);
-                    ohi[e] = pack_bf2(y0 * c0 + x0 * s0, y1 * c1 + x1 * s1);
+                    float a0, b0, a1, b1;   // out[d] = x*cos - y*sin ; out[d+hd/2] = y*cos + x*sin
+                    rope_pair(x0, y0, c0, s0, a0, b0);
+                    rope_pair(x1, y1, c1, s1, a1, b1);
+                    olo[e] = pack_bf2(a0, a1);
+                    ohi[e] = pack_bf2(b0, b1);
                 }
             }
             bf16_t* dst = which == 0 ? p.q + (((size_t)b * p.H + h) * p.q_stride + t) * HD

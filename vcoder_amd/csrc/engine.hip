@@ -18,6 +18,7 @@
 #include <condition_variable>
 #include <deque>
 #include <map>
+#include <set>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -38,7 +39,8 @@ static const int VC_MAX_ROWS = 16;          // sequences one prefill / one sessi
 // bytes (K = 4096 bf16) the 9728 x 12288 QKV GEMM of the 7b model ran 19 % slower (915 vs 770 us; address aliasing
 // between the concurrently fetched panels — tools/experiments/gemm_rounds.py); no other shape cares.
 static const int XN_PAD = 64;
-static const int VC_POOL_ROWS = 32;         // rows of the shared decode pool (two MFMA token-slot groups)
+static const int VC_POOL_ROWS = 32;         // rows of the shared decode pool (two MFMA token-slot groups = one weight pass per step)
+static const int VC_POOL_ROWS_MAX = 64;     // vc_pool_set_rows(64): a pool whose step takes two 32-row weight passes (measurement)
 
 #include "engine_ctx.h"
 
@@ -146,8 +148,8 @@ struct vc_model {
     // "split" contract against hi + lo (w to ~16 mantissa bits; exact for fp16 values); the bf16 fast path uses hi alone.
     // Written while loading / finalizing only; sessions read their root's map.
     std::map<const void*, bf16_t*> lo_of;
-    int inexact_tensors = 0;   // loaded tensors that needed a lo plane (vc_model_inexact_tensors)
-    bf16_t* embed_lo = nullptr;
+    std::set<std::pair<const void*, size_t>> inexact_regions;   // (matrix, offset) of every loaded tensor that needed a lo plane
+    Buf cvt_tmp;               // fp16-operand build: fp32 image of a bfloat16 checkpoint tensor on its way to the planes kernel
     unsigned* inexact_flag = nullptr;   // device word for the loader's check
     std::map<std::string, bool> need;
     // weights
@@ -207,7 +209,9 @@ struct vc_model {
     bool batch_invariant = false;    // root model: a sample's bits do not depend on the batch it runs in (vc_model_set_batch_invariant)
     int qkv_fused = 1;               // root model: RoPE + head split + KV write in the prefill's QKV GEMM epilogue (vc_model_set_qkv_fused):
                                      // 0 off, 1 for problems the 256 x 256 GEMM kernel serves anyway (>= 1024 token rows), 2 always
-    bool pool_hold = true;           // root model: the pool does not step while a call holding rows is still prefilling (vc_pool_set_hold)
+    int pool_rows = VC_POOL_ROWS;    // root model: rows of the decode pool when it is next built (vc_pool_set_rows)
+    std::atomic<bool> pool_hold{true};   // root model: the pool does not step while a call holding rows is still prefilling
+                                         // (vc_pool_set_hold; written by any caller thread, read by the pool's driver thread)
     vc_model* root = nullptr;        // the model that owns the weights (itself for a root)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float t_encode = 0, t_prefill = 0, t_decode = 0;
@@ -296,20 +300,35 @@ const bf16_t* lo_plane(const vc_model* m, const void* hi) {
 // matrix).  fp32 sources that bf16 cannot hold exactly get (and from then on fill) the matrix's lo plane.
 void to_bf16(vc_model* m, bf16_t* base, size_t off, size_t base_elems, const void* src, int dtype, size_t n) {
     bf16_t* dst = base + off;
-    if (dtype == VC_BF16) {
-        HIPCHK(hipMemcpyAsync(dst, src, n * 2, hipMemcpyDeviceToDevice, m->st));
-        return;
-    }
-    if (!m->inexact_flag) m->inexact_flag = walloc<unsigned>(m, 64, true);
     auto it = m->lo_of.find(base);
     bf16_t* lo = it == m->lo_of.end() ? nullptr : it->second;
+    if (dtype == VC_BF16) {
+#if VC_OPERAND_FP16
+        // the fp16-operand build: bfloat16 checkpoint bits are widened and take the fp32 path (fp16 holds every bf16 value of
+        // magnitude 2^-17 .. 65504 exactly; what it cannot hold gets a lo plane like any other inexact tensor)
+        m->cvt_tmp.ensure(n * 4);
+        launch_truebf16_to_f32(reinterpret_cast<const uint16_t*>(src), m->cvt_tmp.as<float>(), n, m->st);
+        src = m->cvt_tmp.p;
+#else
+        HIPCHK(hipMemcpyAsync(dst, src, n * 2, hipMemcpyDeviceToDevice, m->st));
+        // a key loaded twice — an fp16 / fp32 source first (which made the lo plane), then a bf16 override (a projector-only
+        // checkpoint saved in bf16): the exact reload must not leave the first load's lo values behind
+        if (lo) HIPCHK(hipMemsetAsync(lo + off, 0, n * 2, m->st));
+        m->inexact_regions.erase({base, off});
+        return;
+#endif
+    }
+    if (!m->inexact_flag) m->inexact_flag = walloc<unsigned>(m, 64, true);
     HIPCHK(hipMemsetAsync(m->inexact_flag, 0, 4, m->st));
     launch_f32_to_bf16_planes(reinterpret_cast<const float*>(src), dst, lo ? lo + off : nullptr, n, m->inexact_flag, m->st);
     unsigned flag = 0;
     HIPCHK(hipMemcpyAsync(&flag, m->inexact_flag, 4, hipMemcpyDeviceToHost, m->st));
     HIPCHK(hipStreamSynchronize(m->st));
-    if (!flag) return;
-    m->inexact_tensors += 1;
+    if (!flag) {
+        m->inexact_regions.erase({base, off});   // (an exact reload of a region: its lo values were just rewritten as zeros)
+        return;
+    }
+    m->inexact_regions.insert({base, off});      // counted once per tensor, however often it is loaded
     if (!lo) {
         lo = walloc<bf16_t>(m, base_elems, true);   // zero: the parts of the matrix loaded from exact data
         m->lo_of[base] = lo;
@@ -319,7 +338,7 @@ void to_bf16(vc_model* m, bf16_t* base, size_t off, size_t base_elems, const voi
 void to_bf16(vc_model* m, bf16_t* dst, const void* src, int dtype, size_t n) { to_bf16(m, dst, 0, n, src, dtype, n); }
 void to_f32(vc_model* m, float* dst, const void* src, int dtype, size_t n) {
     if (dtype == VC_F32) HIPCHK(hipMemcpyAsync(dst, src, n * 4, hipMemcpyDeviceToDevice, m->st));
-    else launch_bf16_to_f32(reinterpret_cast<const bf16_t*>(src), dst, n, m->st);
+    else launch_truebf16_to_f32(reinterpret_cast<const uint16_t*>(src), dst, n, m->st);   // checkpoint bits: bfloat16 in every build
 }
 
 // place a tensor that already sits on the device (`src`, dtype) into its inference layout
@@ -2126,9 +2145,17 @@ VC_API int vc_model_synth_tensor(vc_model* m, const char* hf_key, const int64_t*
     size_t numel = 1;
     for (int i = 0; i < ndim; ++i) numel *= (size_t)shape[i];
     REQUIRE(numel < ((size_t)1 << 32), VC_ERR_INVALID, "tensor too large for the 32-bit generator");
+#if VC_OPERAND_FP16
+    // the fp16-operand build: the generator's values (on the bfloat16 grid, as in every build) are staged as fp32 and take the fp32
+    // load path — VC_BF16 sources are bfloat16 BITS, which is not what launch_synth_bf16 writes here
+    m->stage.ensure(numel * 4);
+    launch_synth_f32(m->stage.as<float>(), numel, tensor_seed, offset, halfwidth, m->st);
+    rc = place_tensor(m, hf_key, m->stage.p, VC_F32, shape, ndim);
+#else
     m->stage.ensure(numel * 2);
     launch_synth_bf16(m->stage.as<bf16_t>(), numel, tensor_seed, offset, halfwidth, m->st);
     rc = place_tensor(m, hf_key, m->stage.p, VC_BF16, shape, ndim);
+#endif
     HIPCHK(hipStreamSynchronize(m->st));
     if (rc != VC_OK) return rc;
     GUARD_END(m->ctx)
@@ -2226,13 +2253,18 @@ VC_API int vc_model_set_layer_limit(vc_model* m, int n_layers) {
     return VC_OK;
 }
 
+/* 16-bit operand format this library was built for: 0 = bfloat16 (libvcoder_hip.so, the benchmarked path), 1 = IEEE fp16
+ * (libvcoder_hip_f16.so: the same kernels built with -DVC_F16 — v_mfma_f32_16x16x32_f16, saturating fp16 conversions; the
+ * precision of the reference's own GPU path, vcoder_llava/model/builder.py:39,142) */
+VC_API int vc_operand_format(void) { return VC_OPERAND_FP16; }
+
 /* Number of loaded tensors whose fp32 source held values bf16 cannot represent (an fp16 / fp32 checkpoint; 0 for a bf16 one).
  * Each keeps a bf16 lo plane: precision modes "strict" and "split" compute with hi + lo (the checkpoint's values to ~16 mantissa
  * bits, exact for fp16), the bf16 fast path with the bf16-rounded weights alone. */
 VC_API int vc_model_inexact_tensors(vc_model* m) {
     if (!m) return VC_ERR_INVALID;
     const vc_model* r = m->root ? m->root : m;
-    return r->inexact_tensors;
+    return (int)r->inexact_regions.size();
 }
 
 VC_API int vc_model_finalize(vc_model* m) {
@@ -2667,6 +2699,9 @@ int trim_columns(const GenParams& g, const int32_t* out_ids, int ld, const int* 
     return std::min(produced, last);
 }
 
+// one encode + prefill at a time PER PROCESS (two MFMA-bound phases side by side only slow each other down).  The deployment is
+// one process per GPU, so per process == per device; a process driving several devices would serialise their
+// prefills' ENQUEUEING here (not their execution) and should then gate per device instead.
 std::mutex g_prefill_gate;
 
 // =================================================================================================
@@ -2724,24 +2759,24 @@ struct vc_pool {
     vc_model* root = nullptr;
     int device = 0;
     hipStream_t st = nullptr;
-    int R = VC_POOL_ROWS, capS = 0, out_stride = 0;
+    int R = VC_POOL_ROWS, capS = 0, out_stride = 0;   // R: rows of THIS pool (root->pool_rows when it was built)
     bool split = false;               // built for precision mode "split": fp32 KV, stacked hi / lo step operands
     int kv_es = 2;                    // bytes per cache element: 2 bf16, 1 e4m3 (fp8 weight format), 3 / 4 fp24 / fp32 (split)
     int split_G = 16;                 // rows per stacked hi / lo group: 16 (per-wave-ring GEMV: two weight passes per 32-row step)
                                       // or 32 (workgroup-shared GEMV: one)
     Buf kc, vc, rows, x_dec, xg_dec, qkv_dec, attn_dec, h_dec, logits, next_tok, out_ids, ssq, sk_scratch, sk_counters;
-    hipGraphExec_t graph[VC_POOL_ROWS / 8] = {};    // one decode step over rows [0, 8 * (i + 1))
+    hipGraphExec_t graph[VC_POOL_ROWS_MAX / 8] = {};    // one decode step over rows [0, 8 * (i + 1))
     std::mutex mu;
     std::condition_variable cv_driver, cv_rows;
     std::deque<PoolRequest*> pending;
     std::vector<PoolRequest*> active;
-    bool used[VC_POOL_ROWS] = {};
+    bool used[VC_POOL_ROWS_MAX] = {};
     int users = 0;                    // generate() calls inside the pool (rows held or waited for)
     bool stop = false;
     std::thread driver;
     hipEvent_t step_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     unsigned long steps_run = 0;
-    unsigned long long steps_by_span[VC_POOL_ROWS / 8] = {};  // steps launched over 8 / 16 / 24 / 32 rows (vc_pool_step_counts)
+    unsigned long long steps_by_span[VC_POOL_ROWS_MAX / 8] = {};  // steps launched over 8 / 16 / 24 / 32 (... 64) rows (vc_pool_step_counts)
     // generate() calls that hold rows and have not yet handed their request to the driver (encode + prefill being enqueued): with
     // the hold policy (vc_pool_set_hold) the driver waits for them instead of stepping the rows it has — a step that runs beside a
     // prefill's GEMMs takes 2-7x its time (profiles/r05_d_decode_kernels_alone_vs_corun.md) and the joiner needs a full set of
@@ -2848,9 +2883,15 @@ void pool_driver(vc_pool* p) {
             };
             retire_finished();
             if (p->active.empty()) continue;
-            if (p->root->pool_hold && p->prefilling > 0) {
+            if (p->root->pool_hold.load() && p->prefilling > 0) {
                 // somebody is about to join: wait for its request (or for it to give up) rather than step without it
-                p->cv_driver.wait(lk, [&] { return p->stop || !p->pending.empty() || p->prefilling == 0 || !p->root->pool_hold; });
+                // (a request cancelled by its caller — steps_left forced to 0, generate_on_pool's failure path — ends the wait too:
+                // the loop's next pass retires it instead of keeping its caller blocked for somebody else's whole prefill)
+                p->cv_driver.wait(lk, [&] {
+                    bool cancelled = false;
+                    for (PoolRequest* rq : p->active) cancelled = cancelled || rq->steps_left <= 0;
+                    return p->stop || !p->pending.empty() || p->prefilling == 0 || !p->root->pool_hold.load() || cancelled;
+                });
                 continue;
             }
             int top = 0;
@@ -2931,6 +2972,14 @@ int pool_split_G(const vc_model* root) {
 // stopped after an error) is rebuilt, a busy one makes the caller wait for it to drain.  The pool is returned ACQUIRED:
 // p->users was incremented while g_pool_create was still held, so no concurrent pool_for can find it idle and destroy it
 // before the caller has registered (callers release with pool_release).
+// whether a pool built now for `root` carries the in-situ timing slots: asked for, a bf16-step pool (a split step's GEMVs may take
+// two passes: the slot layout assumes one — as do the two weight passes of a 64-row pool), and within the fold kernel's 512 slots.
+// ONE definition for the rebuild test and the build (with the slot limit missing from the test, a > 102-layer model
+// with profiling on would have rebuilt its pool on every generate()).
+bool pool_wants_prof(const vc_model* root, bool want_split) {
+    return root->pool_profile && !want_split && root->pool_rows <= VC_POOL_ROWS && 5 * root->c.layers + 1 <= 512;
+}
+
 vc_pool* pool_for(vc_model* m, int need_S, int need_out) {
     vc_model* root = m->root ? m->root : m;
     const vc_model_cfg& c = root->c;
@@ -2941,7 +2990,7 @@ vc_pool* pool_for(vc_model* m, int need_S, int need_out) {
         std::unique_lock<std::mutex> lk(p->mu);
         // (a split pool laid out for the other GEMV form — set_gemv_variant switched since it was built — is rebuilt as well)
         if (p->capS < need_S || p->out_stride < need_out || p->stop || p->split != want_split ||
-            (want_split && p->split_G != pool_split_G(root)) || p->prof != (root->pool_profile && !want_split)) {
+            (want_split && p->split_G != pool_split_G(root)) || p->prof != pool_wants_prof(root, want_split) || p->R != root->pool_rows) {
             p->cv_rows.wait(lk, [&] { return p->users == 0; });
             lk.unlock();
             pool_destroy(p);
@@ -2957,6 +3006,8 @@ vc_pool* pool_for(vc_model* m, int need_S, int need_out) {
         p->device = root->ctx->device;
         p->split = want_split;
         p->split_G = pool_split_G(root);
+        p->R = root->pool_rows;
+        REQUIRE(!(want_split && p->R > VC_POOL_ROWS), VC_ERR_STATE, "a %d-row pool serves the bf16 step only", p->R);
         const int D = c.hidden, F = c.ffn, H = c.heads, R = p->R;
         const size_t es = want_split ? (size_t)split_kv_es() : (size_t)step_kv_es(root), two = want_split ? 2 : 1;
         p->kv_es = (int)es;
@@ -2983,7 +3034,7 @@ vc_pool* pool_for(vc_model* m, int need_S, int need_out) {
         t_stream = m->st;
         for (auto& e : p->step_ev) HIPCHK(hipEventCreate(&e));
         // (a split step's GEMVs may take two passes: the slot layout assumes one; the fold kernel walks at most 512 slots)
-        p->prof = root->pool_profile && !want_split && 5 * c.layers + 1 <= 512;
+        p->prof = pool_wants_prof(root, want_split);
         if (p->prof) {
             const size_t nslots = (size_t)5 * c.layers + 1;
             p->stamps.ensure(nslots * STAMP_SLOT_WORDS * 4, true);
@@ -3518,7 +3569,9 @@ VC_API int vc_pool_step_counts(vc_model* m, unsigned long long* counts4) {
     for (int i = 0; i < 4; ++i) counts4[i] = 0;
     if (root->pool) {
         std::lock_guard<std::mutex> lk(root->pool->mu);
-        for (int i = 0; i < 4 && i < VC_POOL_ROWS / 8; ++i) counts4[i] = root->pool->steps_by_span[i];
+        for (int i = 0; i < 4; ++i) counts4[i] = root->pool->steps_by_span[i];
+        // (a 64-row pool, vc_pool_set_rows: its steps over 40 .. 64 rows are reported with the 32-row count — two weight passes each)
+        for (int i = 4; i < VC_POOL_ROWS_MAX / 8; ++i) counts4[3] += root->pool->steps_by_span[i];
     }
     return VC_OK;
 }
@@ -3536,11 +3589,22 @@ VC_API int vc_pool_step_counts(vc_model* m, unsigned long long* counts4) {
 VC_API int vc_pool_set_hold(vc_model* m, int on) {
     if (!m) return VC_ERR_INVALID;
     vc_model* root = m->root ? m->root : m;
-    root->pool_hold = on != 0;
+    root->pool_hold.store(on != 0);
+    // the pool may be rebuilt (destroyed and re-created) by pool_for under g_pool_create while this runs on another thread
+    std::lock_guard<std::mutex> create_lk(g_pool_create);
     if (root->pool) {
         std::lock_guard<std::mutex> lk(root->pool->mu);
         root->pool->cv_driver.notify_all();
     }
+    return VC_OK;
+}
+
+/* Rows of the decode pool: 32 (default; one weight pass per step: two MFMA token-slot groups) or 64 (measurement, round 6: a step
+ * then takes TWO 32-row weight passes, i.e. what two 32-row pools would stream, plus the attention of 64 rows).  Takes effect when
+ * the pool is next (re)built, i.e. while it is idle; a 64-row pool serves the bf16 step only and carries no in-situ timing slots. */
+VC_API int vc_pool_set_rows(vc_model* m, int rows) {
+    if (!m || (rows != VC_POOL_ROWS && rows != VC_POOL_ROWS_MAX)) return VC_ERR_INVALID;
+    (m->root ? m->root : m)->pool_rows = rows;
     return VC_OK;
 }
 

@@ -131,7 +131,7 @@ VC_DEV int qkv_arow(const QkvEpiArgs& e, int mp) {
     return b * e.T + min(mp - b * e.Tp, e.T - 1);
 }
 // 4 rotate-half pairs (x = d0 + i, y = d0 + 64 + i) of token (b, t), head `head`: the projection is rounded to bf16 first (the value
-// the unfused path stores in its fused rows), RoPE in fp32 on the rounded values in qkv_split_kernel's expression forms, rounded
+// the unfused path stores in its fused rows), RoPE in fp32 on the rounded values (rope_pair, the split kernel's own function), rounded
 // again; which = 0: Q rows, 1: K rows (+ the e4m3 cache row)
 VC_DEV void qkv_rope_store(const QkvEpiArgs& e, int which, int head, int b, int t, int dl, f32x4 x, f32x4 y) {
     const u32x2 xb = pack_bf4(x), yb = pack_bf4(y);
@@ -141,8 +141,11 @@ VC_DEV void qkv_rope_store(const QkvEpiArgs& e, int which, int head, int b, int 
     for (int h2 = 0; h2 < 2; ++h2) {
         const float x0 = bf2f_lo(xb[h2]), x1 = bf2f_hi(xb[h2]), y0 = bf2f_lo(yb[h2]), y1 = bf2f_hi(yb[h2]);
         const float c0 = cs[2 * h2], c1 = cs[2 * h2 + 1], s0 = sn[2 * h2], s1 = sn[2 * h2 + 1];
-        olo[h2] = pack_bf2(x0 * c0 - y0 * s0, x1 * c1 - y1 * s1);
-        ohi[h2] = pack_bf2(y0 * c0 + x0 * s0, y1 * c1 + x1 * s1);
+        float a0, b0, a1, b1;
+        rope_pair(x0, y0, c0, s0, a0, b0);
+        rope_pair(x1, y1, c1, s1, a1, b1);
+        olo[h2] = pack_bf2(a0, a1);
+        ohi[h2] = pack_bf2(b0, b1);
     }
     const size_t bh = (size_t)b * e.H + head;
     bf16_t* dst = which == 0 ? e.q + (bh * e.q_stride + t) * 128 : e.k + (bh * e.kv_stride + t) * 128;

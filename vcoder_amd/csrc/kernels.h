@@ -10,6 +10,15 @@
 #include <hip/hip_runtime.h>
 #endif
 
+// 16-bit operand format of this build (vc_device.h): bfloat16, or IEEE fp16 with -DVC_F16 (libvcoder_hip_f16.so)
+#ifndef VC_OPERAND_FP16
+#ifdef VC_F16
+#define VC_OPERAND_FP16 1
+#else
+#define VC_OPERAND_FP16 0
+#endif
+#endif
+
 namespace vc {
 
 typedef uint16_t bf16_t;
@@ -456,6 +465,7 @@ void launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
 // hi = bf16(in), lo = bf16(in - hi) (nullptr: skipped), *inexact = 1 if any in != hi (checkpoints bf16 cannot hold: the weight lo
 // planes of the strict / split precision modes)
 void launch_f32_to_bf16_planes(const float* in, bf16_t* hi, bf16_t* lo, size_t n, unsigned* inexact, hipStream_t s);
-void launch_bf16_to_f32(const bf16_t* in, float* out, size_t n, hipStream_t s);
+void launch_bf16_to_f32(const bf16_t* in, float* out, size_t n, hipStream_t s);   // `in` in the build's 16-bit operand format
+void launch_truebf16_to_f32(const uint16_t* in, float* out, size_t n, hipStream_t s);   // `in` = bfloat16 bits (checkpoint data)
 
 }  // namespace vc

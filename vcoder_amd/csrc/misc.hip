@@ -113,8 +113,8 @@ VC_DEV float synth_value_f32(uint32_t idx, uint32_t tseed, float offset, float s
     if (offset != 0.f) v = v + offset;
     return v;
 }
-VC_DEV float synth_value(uint32_t idx, uint32_t tseed, float offset, float scale) {
-    return bf2f(f2bf(synth_value_f32(idx, tseed, offset, scale)));
+VC_DEV float synth_value(uint32_t idx, uint32_t tseed, float offset, float scale) {   // on the bfloat16 grid in EVERY build (synth.py)
+    return true_bf2f(true_f2bf(synth_value_f32(idx, tseed, offset, scale)));
 }
 __global__ __launch_bounds__(256) void synth_bf16_kernel(bf16_t* out, size_t n, uint32_t tseed, float offset,
                                                          float scale) {
@@ -225,6 +225,13 @@ __global__ __launch_bounds__(256) void f32_to_bf16_planes_kernel(const float* in
         any = any || r != 0.f;
     }
     if (any && inexact != nullptr) *inexact = 1u;   // (every writer stores the same value)
+}
+// checkpoint data that arrives as bfloat16 bits -> fp32 (whatever this build's 16-bit operand format is)
+__global__ __launch_bounds__(256) void truebf16_to_f32_kernel(const uint16_t* in, float* out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = true_bf2f(in[i]);
+}
+void launch_truebf16_to_f32(const uint16_t* in, float* out, size_t n, hipStream_t s) {
+    VC_LAUNCH(truebf16_to_f32_kernel, dim3(grid_for(n)), dim3(256), 0, s, in, out, n);
 }
 void launch_f32_to_bf16_planes(const float* in, bf16_t* hi, bf16_t* lo, size_t n, unsigned* inexact, hipStream_t s) {
     VC_LAUNCH(f32_to_bf16_planes_kernel, dim3(grid_for(n)), dim3(256), 0, s, in, hi, lo, n, inexact);

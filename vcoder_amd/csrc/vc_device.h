@@ -45,22 +45,69 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef uint16_t bf16_t;  // raw bf16 bit pattern
 
-// ---- bf16 <-> fp32 -------------------------------------------------------------------------
+// ---- the 16-bit operand format <-> fp32 ----------------------------------------------------------
+// `bf16_t` is the 16-bit container of every MFMA operand and every stored activation.  The product library holds bf16 in it (8
+// significant bits, fp32's range: the benchmarked path).  Built with -DVC_F16 (libvcoder_hip_f16.so, round 6) the SAME kernels hold
+// IEEE fp16 in it — 11 significant bits, the precision of the reference's own GPU path (vcoder_llava/model/builder.py:39
+// torch_dtype=float16, :142 the tower cast to fp16) — and contract with v_mfma_f32_16x16x32_f16, which runs at the bf16 rate on the
+// same byte layout.  Conversions saturate at +-65504 (an overflowing activation must not become inf; the fp32 residual stream,
+// norms, softmax and RoPE are unaffected).  Everything else in the kernels moves 16-bit elements without looking inside them.
+// true_bf2f / true_f2bf are ALWAYS bfloat16: checkpoint data that arrives as bf16 bits, the synthetic generator's value grid.
+VC_DEV float true_bf2f(uint16_t b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }
+VC_DEV uint16_t true_f2bf(float f) {
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifdef VC_F16
+VC_DEV float sat_f16(float f) { return __builtin_fminf(__builtin_fmaxf(f, -65504.f), 65504.f); }   // (NaN passes through)
+#ifdef VC_EMU
+// software IEEE fp16 <-> fp32 (RNE, subnormals) for the host build: the host compiler's _Float16 needs runtime-library calls whose
+// ABI differs between toolchains
+VC_DEV float h2f_sw(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3FFu;
+    if (e == 0) {
+        const float v = (float)m * 5.9604644775390625e-08f;   // m * 2^-24
+        return __builtin_bit_cast(float, sign | __builtin_bit_cast(uint32_t, v));
+    }
+    if (e == 31) return __builtin_bit_cast(float, sign | 0x7F800000u | (m << 13));
+    return __builtin_bit_cast(float, sign | ((e + 112u) << 23) | (m << 13));
+}
+VC_DEV uint16_t f2h_sw(float f) {   // |f| <= 65504 (callers saturate) or NaN
+    const uint32_t u = __builtin_bit_cast(uint32_t, f), sign = (u >> 16) & 0x8000u, a = u & 0x7FFFFFFFu;
+    if (a > 0x7F800000u) return (uint16_t)(sign | 0x7E00u);
+    const float af = __builtin_bit_cast(float, a);
+    if (af < 6.103515625e-05f) return (uint16_t)(sign | (uint32_t)(int)rintf(af * 16777216.f));   // subnormals: units of 2^-24 (RNE; 1024 -> 2^-14)
+    uint32_t r = a + 0x00000FFFu + ((a >> 13) & 1u);   // RNE on bit 13
+    return (uint16_t)(sign | (((r >> 23) - 112u) << 10) | ((r >> 13) & 0x3FFu));
+}
+VC_DEV float bf2f(bf16_t b) { return h2f_sw(b); }
+VC_DEV float bf2f_lo(uint32_t packed) { return h2f_sw((uint16_t)(packed & 0xFFFFu)); }
+VC_DEV float bf2f_hi(uint32_t packed) { return h2f_sw((uint16_t)(packed >> 16)); }
+VC_DEV bf16_t f2bf(float f) { return f2h_sw(sat_f16(f)); }
+VC_DEV uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+#else
+VC_DEV float bf2f(bf16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
+VC_DEV float bf2f_lo(uint32_t packed) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(packed & 0xFFFFu)); }
+VC_DEV float bf2f_hi(uint32_t packed) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(packed >> 16)); }
+VC_DEV bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (_Float16)sat_f16(f)); }   // RNE
+typedef _Float16 f16x2_hw __attribute__((ext_vector_type(2)));
+VC_DEV uint32_t pack_bf2(float lo, float hi) {   // one v_cvt_pk_f16_f32 (gfx950) behind the two clamps
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{sat_f16(lo), sat_f16(hi)}, f16x2_hw));
+}
+#endif
+#else
 VC_DEV float bf2f(bf16_t b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }
 VC_DEV float bf2f_lo(uint32_t packed) { return __builtin_bit_cast(float, packed << 16); }
 VC_DEV float bf2f_hi(uint32_t packed) { return __builtin_bit_cast(float, packed & 0xFFFF0000u); }
 
 #ifdef VC_EMU
-VC_DEV bf16_t f2bf(float f) {
-    uint32_t u = __builtin_bit_cast(uint32_t, f);
-    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+VC_DEV bf16_t f2bf(float f) { return true_f2bf(f); }
 #else
 VC_DEV bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }  // v_cvt_pk_bf16_f32 (RNE)
 #endif
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifdef VC_EMU
 VC_DEV uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
 #else
@@ -69,6 +116,7 @@ typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
 VC_DEV uint32_t pack_bf2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2_hw));
 }
+#endif
 #endif
 
 // ---- fp24: the top 24 bits of an fp32 (sign, 8 exponent, 15 mantissa bits; round to nearest even) -----------------------------
@@ -123,10 +171,8 @@ VC_DEV float fp82f_sw(uint32_t b) {
 }
 // 4 packed fp8 -> 4 bf16 (two packed words), exact
 #ifdef VC_EMU
-VC_DEV u32x2 fp8x4_to_bf16x4(uint32_t v) {
-    auto hi16 = [](float f) { return __builtin_bit_cast(uint32_t, f) >> 16; };
-    return u32x2{hi16(fp82f_sw(v & 0xFF)) | (hi16(fp82f_sw((v >> 8) & 0xFF)) << 16),
-                 hi16(fp82f_sw((v >> 16) & 0xFF)) | (hi16(fp82f_sw(v >> 24)) << 16)};
+VC_DEV u32x2 fp8x4_to_bf16x4(uint32_t v) {   // (every e4m3 value is exact in bf16 and in fp16)
+    return u32x2{pack_bf2(fp82f_sw(v & 0xFF), fp82f_sw((v >> 8) & 0xFF)), pack_bf2(fp82f_sw((v >> 16) & 0xFF), fp82f_sw(v >> 24))};
 }
 #else
 typedef float f32x2_hw __attribute__((ext_vector_type(2)));
@@ -157,15 +203,26 @@ VC_DEV uint32_t f32x4_to_fp8x4(float a, float b, float c, float d) {
 
 // ---- MFMA ----------------------------------------------------------------------------------
 #ifndef VC_EMU
+#ifdef VC_F16
+typedef _Float16 bf16x8_hw __attribute__((ext_vector_type(8)));   // (the operand vector type of this build: fp16)
+VC_DEV f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(bf16x8_hw, a), __builtin_bit_cast(bf16x8_hw, b), c, 0, 0, 0);
+}
+#else
 typedef __bf16 bf16x8_hw __attribute__((ext_vector_type(8)));
 VC_DEV f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_hw, a),
                                                    __builtin_bit_cast(bf16x8_hw, b), c, 0, 0, 0);
 }
+#endif
 // v_mfma_f32_32x32x16_bf16: A[i][k]: lane i + 32 (k / 8), elem k % 8 (i < 32, k < 16); B[k][j]: lane j + 32 (k / 8), elem k % 8;
 // D[i][j]: lane j + 32 ((i / 4) % 2), reg i % 4 + 4 (i / 8)  (cdna_hip_programming.md section 3)
 VC_DEV f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
+#ifdef VC_F16
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(bf16x8_hw, a), __builtin_bit_cast(bf16x8_hw, b), c, 0, 0, 0);
+#else
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_hw, a), __builtin_bit_cast(bf16x8_hw, b), c, 0, 0, 0);
+#endif
 }
 // v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain): A[i][k]: lane i+16k; B[k][j]: lane j+16k; D as for bf16
 VC_DEV f32x4 mfma16_f32(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
@@ -225,6 +282,16 @@ template <int N> VC_DEV float lanes_sum(float s) {
     return s;
 }
 #endif
+
+// rotate-half RoPE of one pair (x, y) = (element d, element d + hd / 2): out[d] = x cos - y sin, out[d + hd/2] = y cos + x sin
+// ([HF] llama/modeling_llama.py:130-160).  ONE definition with explicit fused multiply-adds and no further contraction, so that the
+// prefill's split kernel and the QKV GEMM's fused epilogue produce the same bits in every build (left to -ffp-contract=fast the two
+// call sites were contracted differently in the fp16-operand build: 4e-5 of the elements an ulp apart).
+VC_DEV void rope_pair(float x, float y, float c, float s, float& ox, float& oy) {
+#pragma clang fp contract(off)
+    ox = __builtin_fmaf(x, c, -(y * s));
+    oy = __builtin_fmaf(y, c, x * s);
+}
 
 // exchange inside aligned quads of lanes: the value of lane l ^ 1 / l ^ 2 (DPP quad_perm [1,0,3,2] / [2,3,0,1] on the device)
 #ifdef VC_EMU

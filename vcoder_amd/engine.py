@@ -24,10 +24,13 @@ class HipEngine:
 
     MAX_BATCH = 16   # sequences a replica prefills / decodes at a time (csrc/engine.hip)
 
-    def __init__(self, cfg: VCoderConfig, device_index: int = 0, lib: Optional[C.CDLL] = None, _parent=None):
+    def __init__(self, cfg: VCoderConfig, device_index: int = 0, lib: Optional[C.CDLL] = None, _parent=None, operands: str = "bf16"):
+        """operands: "bf16" — the benchmarked library; "fp16" — libvcoder_hip_f16.so, the same engine and kernels with IEEE fp16 MFMA
+        operands (the precision of the reference's own GPU path, vcoder_llava/model/builder.py:39,142; same throughput)."""
         cfg.validate()
         self.cfg = cfg
-        self.lib = lib if lib is not None else _lib.load()
+        self.operands = _parent.operands if _parent is not None else operands
+        self.lib = lib if lib is not None else _lib.load(self.operands)
         self._lib_arg = lib
         if lib is not None:
             _lib.declare(self.lib)
@@ -563,6 +566,10 @@ class HipEngine:
     def pool_set_hold(self, on: bool = True):
         """pool policy (vc_pool_set_hold): True (default) = no decode step while a call that holds rows is still prefilling"""
         self._check(self.lib.vc_pool_set_hold(self._model, 1 if on else 0))
+
+    def pool_set_rows(self, rows: int = 32):
+        """rows of the shared decode pool (32 default; 64 = two weight passes per step, measurement) — when the pool is next built"""
+        self._check(self.lib.vc_pool_set_rows(self._model, int(rows)))
 
     def pool_profile(self, on: bool = True):
         """in-situ timing of the pool's decode-step launches (vc_pool_profile): takes effect when the pool is next (re)built"""
