@@ -478,7 +478,8 @@ def main():
     n_sess = max(1, min(args.inflight, args.steps))
     # in-situ timing of the pool's decode-step kernels (vc_pool_profile): every launch of the timed region stamps its earliest
     # workgroup start / latest workgroup end with the device's wall clock; `roofline` is computed from those sums
-    insitu_on = not args.no_insitu and os.environ.get("VC_POOL", "1") != "0"
+    pooled_run = os.environ.get("VC_POOL", "1") != "0"
+    insitu_on = not args.no_insitu and pooled_run
     if insitu_on:
         eng.pool_profile(True)
     if args.no_pool_hold:
@@ -560,6 +561,43 @@ def main():
     other_px = dev_px if args.host_pixels else host_px
     dt_other, outs_other = timed(k_side, other_px)
     ids_checked = ids_checked and all(np.array_equal(np.asarray(o), np.asarray(lone_gathered)) for o in outs_other)
+    # (a2) inter-token latency of the SAME configuration (the hold policy and the pool trade it for throughput —
+    # say how much): every call streams its new column after every pooled step (vc_generate's token callback, stream_every = 1) and
+    # the host stamps the arrivals; two batches per session, so that every call also sees the others' joins (a hold = one pause of
+    # about a prefill).  Outside the timed region: the callbacks cost a D2H copy per step and call.
+    lat = None
+    if pooled_run and n_sess > 1:
+        stamps = [[] for _ in range(n_sess)]
+
+        def lat_worker(si):
+            for _ in range(2):
+                arr = stamps[si]
+                arr.append(None)   # call boundary
+                sessions[si].generate(ids, *dev_px, max_new_tokens=N_new, eos_token_id=None,
+                                      on_tokens=lambda first, cols, arr=arr: arr.append((time.perf_counter(), first, cols.shape[1])), stream_every=1)
+        ths = [threading.Thread(target=lat_worker, args=(si,)) for si in range(n_sess)]
+        for t_ in ths:
+            t_.start()
+        for t_ in ths:
+            t_.join()
+        gaps = []
+        for arr in stamps:
+            prev = None
+            for ev in arr:
+                if ev is None:
+                    prev = None
+                    continue
+                if prev is not None and ev[2] > 0:
+                    gaps.extend([(ev[0] - prev[0]) * 1e3 / ev[2]] * ev[2])   # a report that carries k columns: k tokens, gap / k each
+                prev = ev
+        if gaps:
+            g_ = np.sort(np.asarray(gaps))
+            lat = {"unit": "ms between consecutive tokens of one generate() call, as its streamer callback sees them",
+                   "p50": float(g_[len(g_) // 2]), "p90": float(g_[int(len(g_) * 0.9)]), "p99": float(g_[int(len(g_) * 0.99)]),
+                   "max": float(g_[-1]), "tokens": int(len(g_)), "calls_in_flight": n_sess,
+                   "pool_hold_policy": not args.no_pool_hold,
+                   "note": "max = a step that waited for another call's encode + prefill (the hold policy) — vc_pool_set_hold(m, 0) steps "
+                           "whatever rows are active instead"}
     # (b) the same step strictly one batch at a time on this rank
     fence()
     t1 = time.perf_counter()
@@ -730,6 +768,7 @@ def main():
             "ids_checked": bool(ids_checked),
             "ids_check": {"what": "ids of EVERY step of the timed region (and of the side legs) == ids of the same batch generated "
                                   "alone, bit for bit", "steps_checked": args.steps + k_side + 2, "mismatching_timed_steps": bad_steps},
+            "inter_token_latency_ms": lat,
             "phase_ms_one_session": timings,  # encode / prefill / decode wall time of one batch run alone
             "one_batch_at_a_time": {"value": B / solo, "unit": "images/s per GPU", "ms_per_step": solo * 1e3,
                                     "label": "c2_as_written" if (args.model == "7b" and B == 8 and args.weights == "bf16") else "one generate() call at a time",

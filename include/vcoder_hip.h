@@ -132,7 +132,7 @@ int vc_debug_prefill_layers(vc_model* m, int l0, int l1, const float* x_in, int 
  * phases compute with one set of effective weights.  2 = fp8, BASELINE.json configs[4] ("fp8 weights, CDNA4 fp8 MFMA"):
  * the weights and decode steps of 1, and the prefill's decoder linears quantise their activation rows to e4m3 (one
  * power-of-two scale per token row) and run e4m3 x e4m3 on v_mfma_scale_f32_16x16x128_f8f6f4 (W8A8, twice the bf16
- * MFMA rate), and the KV cache holds e4m3 rows (no scale, saturating; VC_FP8_KV=0: bf16 rows) — half the bytes of the stream
+ * MFMA rate), and the KV cache holds e4m3 rows (no scale, saturating; vc_model_set_fp8_kv(m, 0) before vc_model_finalize: bf16 rows) — half the bytes of the stream
  * that dominates the pooled 13b decode step.  The reference's counterpart is `load_8bit` (builder.py:31-33, bitsandbytes LLM.int8 — also 8-bit
  * weights x 8-bit activations).  Call before vc_model_finalize. */
 int vc_model_set_weight_format(vc_model* m, int fmt);

@@ -16,9 +16,29 @@ class LazyState(dict):
         return dict.__getitem__(self, k).float()
 
 
-def device_state_dict(eng, cfg, seed, prefixes=None, dtypes="bf16"):
+DECODER_LINEARS = ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj")
+
+
+def effective_fp8_rows(W_bf16: torch.Tensor) -> torch.Tensor:
+    """W [N, K] bf16 (any device) -> the EFFECTIVE weights of the fp8 formats, bf16: per output row the power-of-two scale s = 2^e
+    with the smallest e such that max|W[n]| <= 448 * 2^e, q = e4m3fn(W[n] / s) (RNE), W_eff = q * s — vcoder_amd/quant.py's rule
+    (row_scales' bit arithmetic) with torch's float8_e4m3fn cast, which that module equals byte for byte."""
+    Wf = W_bf16.float()
+    amax = Wf.abs().amax(dim=1)
+    u = amax.view(torch.int32)
+    e = (u >> 23) - 127 - torch.where((u & 0x007FFFFF) <= 0x00600000, 8, 7)
+    e = torch.where(amax > 0, e, torch.zeros_like(e))
+    s = torch.ldexp(torch.ones_like(amax), e)[:, None]
+    q = (Wf / s).to(torch.float8_e4m3fn).float()
+    eff = (q * s).to(torch.bfloat16)
+    assert torch.equal(eff.float(), q * s), "q * 2^e must be exact in bf16"
+    return eff
+
+
+def device_state_dict(eng, cfg, seed, prefixes=None, dtypes="bf16", effective_fp8=False):
     """the seeded checkpoint regenerated on the device and copied back in its own value class: bf16, or (dtypes="reference") fp16 for
-    the LLM / projector tensors and fp32 for the CLIP tower — exactly the values vc_model_synth_tensor_rounded loaded"""
+    the LLM / projector tensors and fp32 for the CLIP tower — exactly the values vc_model_synth_tensor_rounded loaded.
+    effective_fp8: the seven decoder linears per layer replaced by their e4m3-quantised effective values (effective_fp8_rows)."""
     dev = torch.device("cuda:0")
     sd = LazyState()
     for key, shape, off, hw in synth.tensor_specs(cfg):
@@ -44,5 +64,8 @@ def device_state_dict(eng, cfg, seed, prefixes=None, dtypes="bf16"):
         eng.lib.vck_synth_bf16(ctypes.c_void_p(buf.data_ptr()), ctypes.c_uint64(n), ctypes.c_uint32(synth.tensor_seed(key, seed)),
                                ctypes.c_float(off), ctypes.c_float(hw), None)
         torch.cuda.synchronize()
-        dict.__setitem__(sd, key, buf.cpu().view(torch.bfloat16).reshape(shape))
+        w = buf.view(torch.bfloat16).reshape(shape)
+        if effective_fp8 and key.startswith("model.layers.") and any(f".{n}.weight" in key for n in DECODER_LINEARS):
+            w = effective_fp8_rows(w)      # what vc_model_set_weight_format(w8a16 / fp8) computes with (quantised at finalize)
+        dict.__setitem__(sd, key, w.cpu())
     return sd

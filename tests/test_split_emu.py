@@ -68,6 +68,50 @@ def test_inexact_checkpoint(be, name, mode):
     print(name, mode, r)
 
 
+def test_lo_plane_bookkeeping_of_the_loader(be):
+    """(i) a tensor loaded twice — first from an fp16-valued source (a lo plane is made), then as bf16 bits (a projector /
+    override checkpoint saved in bf16) — must not keep the first load's lo values: the strict logits equal those of an engine that
+    only ever saw the bf16 tensor; vc_model_inexact_tensors counts tensors, not loads.  (ii) precision mode split on a checkpoint
+    with lo planes is REFUSED by vc_model_set_precision when the workgroup-shared GEMV is switched off (it used to throw out of a
+    launch)."""
+    import torch
+    from vcoder_amd import synth
+    from vcoder_amd.engine import HipEngine
+
+    g, cfg, ids, imgs, segs, deps = e2e_cases.fixture_inputs("ds_img_depth_seg")
+    sd = synth.synth_state_dict(cfg, int(g["seed"]), dtypes="reference")
+    key = "model.mm_projector.0.weight"
+    w16 = torch.from_numpy(np.ascontiguousarray(sd[key])).to(torch.bfloat16)      # what a bf16 override checkpoint holds
+    a = HipEngine(cfg, lib=be.lib)
+    a.load_state_dict(sd)
+    n0 = a.inexact_tensors()
+    a.load_tensor(key, torch.from_numpy(np.ascontiguousarray(sd[key])))            # the same fp32 source again: still one tensor
+    assert a.inexact_tensors() == n0
+    a.load_tensor(key, w16)                                                        # the bf16 override
+    assert a.inexact_tensors() == n0 - 1
+    a.finalize()
+    b = HipEngine(cfg, lib=be.lib)
+    b.load_state_dict({**sd, key: w16})
+    b.finalize()
+    assert b.inexact_tensors() == n0 - 1
+    for e_ in (a, b):
+        e_.set_precision("strict")
+    la, _, _ = a.prefill(ids, imgs, segs, deps)
+    lb, _, _ = b.prefill(ids, imgs, segs, deps)
+    assert np.array_equal(la, lb), "a stale lo plane survived the bf16 reload"
+    b.close()
+    a.set_precision("bf16")
+    be.lib.vck_set_gemv_variant(0)
+    try:
+        with pytest.raises(Exception) as ei:
+            a.set_precision("split")
+        assert "lo planes" in str(ei.value)
+    finally:
+        be.lib.vck_set_gemv_variant(-1)
+    a.set_precision("split")       # with the default GEMV form the mode is available again
+    a.close()
+
+
 def test_weight_lo_plane_kernels(be):
     kc.check_weight_planes(be)
     for epi in (0, 3, 4, 5):

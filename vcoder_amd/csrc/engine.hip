@@ -2188,6 +2188,17 @@ VC_API int vc_model_synth_tensor_rounded(vc_model* m, const char* hf_key, const 
  * reference; slow).  Takes effect at the next prefill. */
 VC_API int vc_model_set_precision(vc_model* m, int mode) {
     if (!m || mode < 0 || mode > 2) return VC_ERR_INVALID;
+    if (mode == 2) {
+        // split mode on a checkpoint with weight lo planes: its decode GEMV is the workgroup-shared form only — refuse HERE what
+        // would otherwise surface as an exception out of a launch (possibly inside a graph capture)
+        const vc_model* root = m->root ? m->root : m;
+        // (the e4m3 weight formats re-round the decoder linears and drop their lo planes: only K = hidden matrices keep one then)
+        if (!root->lo_of.empty() && (!gemv_wg_enabled() || root->c.hidden % 64 != 0 || (root->weight_format == 0 && root->c.ffn % 64 != 0))) {
+            m->ctx->err = std::string("precision mode split on a checkpoint with weight lo planes (fp16 / fp32 values) needs the workgroup-shared "
+                              "decode GEMV (vck_set_gemv_variant != 0, hidden_size and intermediate_size multiples of 64)");
+            return VC_ERR_STATE;
+        }
+    }
     if (mode != m->precision) {  // the decode graph bakes the step's kernels and buffers in
         (void)hipSetDevice(m->ctx->device);
         (void)hipStreamSynchronize(m->st);
