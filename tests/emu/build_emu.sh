@@ -12,7 +12,9 @@ for f in $SRC/gemm.hip $SRC/norm.hip $SRC/attn.hip $SRC/decode.hip $SRC/misc.hip
   [ -f "$f" ] || continue
   o=$B/$(basename $f .hip).o
   mkdir -p $B
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ $SRC/vc_device.h -nt "$o" ] || [ $SRC/kernels.h -nt "$o" ] || [ hip_emu.h -nt "$o" ]; then
+  stale=0
+  for d in "$f" $SRC/vc_device.h $SRC/kernels.h hip_emu.h $SRC/engine_*.inc; do [ "$d" -nt "$o" ] && stale=1; done
+  if [ ! -f "$o" ] || [ $stale = 1 ]; then
     $CXX -x c++ -std=c++17 -O2 -fPIC -DVC_EMU $DEF -I. -I$SRC -c "$f" -o "$o"
   fi
   OBJS="$OBJS $o"

@@ -14,7 +14,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libvcoder_hip.so")
 SOURCES = ["gemm.hip", "norm.hip", "attn.hip", "decode.hip", "misc.hip", "select.hip", "strict.hip", "preprocess.hip", "engine.hip", "comm.hip", "kernel_api.cpp"]
-HEADERS = ["vc_device.h", "kernels.h", "engine_ctx.h", os.path.join("..", "..", "include", "vcoder_hip.h")]
+# (engine.hip is one translation unit made of engine_*.inc parts: they count as its headers for the staleness check)
+HEADERS = ["vc_device.h", "kernels.h", "engine_ctx.h", "engine_weights.inc", "engine_linears.inc", "engine_vision.inc", "engine_llm.inc",
+           "engine_abi.inc", "engine_pool.inc", "engine_profile.inc", os.path.join("..", "..", "include", "vcoder_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result"]
 
 

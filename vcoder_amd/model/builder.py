@@ -12,11 +12,13 @@ from .language_model import LlavaLlamaForCausalLM, VCoderDSLlavaLlamaForCausalLM
 
 
 def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, load_4bit=False, device_map="auto",
-                          device="cuda", weight_format=None):
+                          device="cuda", weight_format=None, operands="bf16"):
     """Signature and return value of the reference's loader (builder.py:25,154).  load_8bit=True selects the 8-bit
     weight format of this build, 'w8a16' (e4m3 decoder weights, bf16 activations); `weight_format` (an addition, keyword
     only in practice) names a format directly: 'bf16' | 'w8a16' | 'fp8' (the latter also runs the prefill linears on
-    e4m3 activations — BASELINE configs[4]; faster, and noisier: DESIGN.md section 4.2b)."""
+    e4m3 activations — BASELINE configs[4]; faster, and noisier: DESIGN.md section 4.2b).  `operands` (an addition): 'bf16' — the
+    benchmarked library; 'fp16' — libvcoder_hip_f16.so, IEEE fp16 MFMA operands, what the reference's torch_dtype=torch.float16
+    (builder.py:39) and its fp16 tower (:142) compute with: an fp16 checkpoint is held exactly."""
     if load_4bit:
         raise NotImplementedError("bitsandbytes NF4 loading is a CUDA-only path of the reference; the MI355X build runs "
                                   "bf16 weights or, with load_8bit=True, fp8-e4m3 decoder weights (W8A16)")
@@ -41,7 +43,7 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, l
         cfg.variant = "llava"
         tensors = (checkpoint.iter_lora_merged(model_base, model_path) if "lora" in name
                    else checkpoint.iter_base_with_projector(model_base, model_path))
-        model = LlavaLlamaForCausalLM.from_tensors(cfg, tensors, device=device, weight_format=fmt)
+        model = LlavaLlamaForCausalLM.from_tensors(cfg, tensors, device=device, weight_format=fmt, operands=operands)
     else:
         if "lora" in name:
             import warnings
@@ -55,7 +57,7 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, l
             cls = VCoderLlavaLlamaForCausalLM
         else:
             cls = LlavaLlamaForCausalLM
-        model = cls.from_pretrained(model_path, low_cpu_mem_usage=True, device=device, weight_format=fmt)
+        model = cls.from_pretrained(model_path, low_cpu_mem_usage=True, device=device, weight_format=fmt, operands=operands)
     context_len = model.config.max_sequence_length if getattr(model.config, "max_sequence_length", None) else 2048
     vision_tower = model.get_vision_tower()
     if not vision_tower.is_loaded or vision_tower.image_processor is None:

@@ -82,7 +82,9 @@ class _HipCausalLMBase:
     variant = "llava"
     model_type = "llava"
 
-    def __init__(self, config: VCoderConfig, device="cuda", _lib_override=None):
+    def __init__(self, config: VCoderConfig, device="cuda", _lib_override=None, operands="bf16"):
+        """operands (an addition of this build): "bf16" — libvcoder_hip.so, the benchmarked path; "fp16" — libvcoder_hip_f16.so, the
+        same kernels with IEEE fp16 MFMA operands: the operand precision of the reference's own GPU path (builder.py:39,142)."""
         if config.variant != self.variant:
             config.variant = self.variant
         self.config = config
@@ -91,7 +93,7 @@ class _HipCausalLMBase:
         idx = 0
         if ":" in self._device_str:
             idx = int(self._device_str.split(":")[1])
-        self.engine = HipEngine(config, device_index=idx, lib=_lib_override)
+        self.engine = HipEngine(config, device_index=idx, lib=_lib_override, operands=operands)
         tower = self.model.get_vision_tower()
         if tower is not None:
             tower._engine = self.engine          # CLIPVisionTower.forward runs on the engine's tower kernels
@@ -178,7 +180,7 @@ class _HipCausalLMBase:
 
     @classmethod
     def from_pretrained(cls, model_path: str, low_cpu_mem_usage=True, device="cuda", config=None, weight_format="bf16",
-                        **kwargs):
+                        operands="bf16", **kwargs):
         """Loads config.json + weight shards; the CLIP tower comes from the checkpoint if present, else from the
         local directory `config.mm_vision_tower` (the reference downloads it: clip_encoder.py:22-27 — there is no
         network here, so a hub name that is not a local directory is an error)."""
@@ -190,14 +192,15 @@ class _HipCausalLMBase:
             # an HF PretrainedConfig handed over by AutoModelForCausalLM.from_pretrained (vcoder_amd/hf_register.py)
             config = VCoderConfig.from_hf_dict(config.to_dict(), os.path.basename(os.path.normpath(str(model_path))))
         cfg = config if config is not None else VCoderConfig.from_pretrained(model_path, os.path.basename(model_path))
-        return cls.from_tensors(cfg, checkpoint.iter_checkpoint_tensors(model_path), device=device, weight_format=weight_format)
+        return cls.from_tensors(cfg, checkpoint.iter_checkpoint_tensors(model_path), device=device, weight_format=weight_format,
+                                operands=operands)
 
     @classmethod
-    def from_tensors(cls, cfg: VCoderConfig, tensors, device="cuda", weight_format="bf16", _lib_override=None):
+    def from_tensors(cls, cfg: VCoderConfig, tensors, device="cuda", weight_format="bf16", _lib_override=None, operands="bf16"):
         """A model from an iterator of (HF state-dict key, tensor) pairs — one checkpoint, or a base checkpoint overlaid with
         merged LoRA deltas / projector weights (model/builder.py).  The CLIP tower comes from the stream when it carries
         `vision_tower` keys, else from the local directory `config.mm_vision_tower`."""
-        model = cls(cfg, device=device, _lib_override=_lib_override)
+        model = cls(cfg, device=device, _lib_override=_lib_override, operands=operands)
         saw_tower = False
         for k, v in tensors:
             saw_tower |= "vision_tower" in k
