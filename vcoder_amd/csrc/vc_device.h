@@ -446,10 +446,33 @@ VC_DEV void wait_vmcnt_n(int n) {
         VC_VMCASE(10) VC_VMCASE(11) VC_VMCASE(12) VC_VMCASE(13) VC_VMCASE(14) VC_VMCASE(15) VC_VMCASE(16) VC_VMCASE(17)
         VC_VMCASE(18) VC_VMCASE(19) VC_VMCASE(20) VC_VMCASE(21) VC_VMCASE(22) VC_VMCASE(23) VC_VMCASE(24) VC_VMCASE(25)
         VC_VMCASE(26) VC_VMCASE(27) VC_VMCASE(28) VC_VMCASE(29) VC_VMCASE(30) VC_VMCASE(31) VC_VMCASE(32)
+        VC_VMCASE(33) VC_VMCASE(34) VC_VMCASE(35) VC_VMCASE(36) VC_VMCASE(37) VC_VMCASE(38) VC_VMCASE(39) VC_VMCASE(40) VC_VMCASE(41)
+        VC_VMCASE(42) VC_VMCASE(43) VC_VMCASE(44) VC_VMCASE(45) VC_VMCASE(46) VC_VMCASE(47) VC_VMCASE(48) VC_VMCASE(49) VC_VMCASE(50)
+        VC_VMCASE(51) VC_VMCASE(52) VC_VMCASE(53) VC_VMCASE(54) VC_VMCASE(55) VC_VMCASE(56) VC_VMCASE(57) VC_VMCASE(58) VC_VMCASE(59)
+        VC_VMCASE(60) VC_VMCASE(61) VC_VMCASE(62) VC_VMCASE(63)
 #undef VC_VMCASE
         default: wait_vmcnt<0>(); break;
     }
 }
+#endif
+
+// ---- 16-byte global load into REGISTERS, waited for by COUNT in the same in-order vmcnt queue as the LDS-DMAs -------------------
+// LLVM waits with vmcnt(0) for any register load that is outstanding together with LDS-DMAs (it models the mixed queue as
+// unordered), so a register stream that runs beside a DMA ring cannot be written as C++ loads.  The load is inline asm — the
+// compiler sees a value that exists at once — and the kernel orders things by hand: wait_vmcnt<N>() (loads return in order), then
+// pin_loaded(v) on every register the wait covers BEFORE its first use (the use then cannot be scheduled above the wait).
+// Between the load and its pin the compiler must not touch the register (a copy would read bytes that have not landed):
+// tools/check_async_loads.py verifies that on the ISA of every kernel that uses these.
+#ifdef VC_EMU
+VC_DEV void gld16_async(u32x4& dst, const void* gsrc) { vc_emu::reg_load_issue(gsrc, &dst); }
+VC_DEV void gld16_async(f32x4& dst, const void* gsrc) { vc_emu::reg_load_issue(gsrc, &dst); }
+VC_DEV void pin_loaded(u32x4&) {}
+VC_DEV void pin_loaded(f32x4&) {}
+#else
+VC_DEV void gld16_async(u32x4& dst, const void* gsrc) { asm volatile("global_load_dwordx4 %0, %1, off ; vc_async_load" : "=v"(dst) : "v"(gsrc) : "memory"); }
+VC_DEV void gld16_async(f32x4& dst, const void* gsrc) { asm volatile("global_load_dwordx4 %0, %1, off ; vc_async_load" : "=v"(dst) : "v"(gsrc) : "memory"); }
+VC_DEV void pin_loaded(u32x4& v) { asm volatile("; vc_async_pin %0" : "+v"(v)); }
+VC_DEV void pin_loaded(f32x4& v) { asm volatile("; vc_async_pin %0" : "+v"(v)); }
 #endif
 
 // LDS hand-off between lanes of ONE wave (write by some lanes, read by others, no other wave involved): the LDS queue of
