@@ -65,8 +65,6 @@ def parse_args():
                     help="pool policy A/B: step whatever rows are active even while another call is prefilling (vc_pool_set_hold(0))")
     ap.add_argument("--no-qkv-fused", action="store_true",
                     help="A/B: the prefill's QKV projection as the separate GEMM + split / RoPE launches of rounds 1-5 (vc_model_set_qkv_fused(0))")
-    ap.add_argument("--gemv-xr", type=int, default=None,
-                    help="A/B: vck_set_gemv_xr — 0 = the LDS-operand ring kernel for o_proj / down, 4 / 6 / 8 = the register-operand form at that ring depth")
     ap.add_argument("--no-insitu", action="store_true",
                     help="do not stamp the pool's decode-step launches (roofline then reports the isolated replay); A/B of the stamps' cost")
     ap.add_argument("--no-extra-legs", action="store_true",
@@ -488,9 +486,6 @@ def main():
         eng.pool_set_hold(False)
     if args.no_qkv_fused:
         eng.set_qkv_fused(0)
-    if args.gemv_xr is not None:
-        from vcoder_amd import _lib as _vlib
-        _vlib.load().vck_set_gemv_xr(int(args.gemv_xr))
     sessions = [eng] + [eng.fork() for _ in range(n_sess - 1)]
 
     def run_steps(k: int, px):

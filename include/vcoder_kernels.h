@@ -175,9 +175,6 @@ void vck_set_gemm_variant(int v);
  * whichever is set. */
 void vck_set_gemv_wide(int v);
 unsigned long long vck_gemv_wide_launches(void);
-/* the register-operand form of the ring kernel (csrc/decode.hip gemv_xr_kernel): 0 off, -1 / 1 default, 4 / 6 / 8 = ring depth */
-void vck_set_gemv_xr(int v);
-unsigned long long vck_gemv_xr_launches(void);
 unsigned long long vck_gemv_wg_launches(void);   /* launches the workgroup-shared form has served (tests) */
 void vck_rmsnorm_split(const float* x, const int* row_idx, const float* w, uint16_t* y, int rows, int D, float eps, int ldy,
                        uint64_t lo_off, void* stream);

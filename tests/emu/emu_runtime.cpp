@@ -160,20 +160,6 @@ void dma_issue(const void* src, void* dst, const void* wave_base) {
     }
     f->dma[f->dma_tail++ % 128] = PendingDma{src, dst};
 }
-void reg_load_issue(const void* src, void* dst_reg) {
-    Fiber* f = g_cur;
-    if (!f || !dma_deferred()) {
-        memcpy(dst_reg, src, 16);
-        return;
-    }
-    memset(dst_reg, 0xFF, 16);   // bf16 / fp16 / fp32 NaN patterns: a use before the wait shows up in every parity check
-    if (f->dma_tail - f->dma_head >= 128) {
-        const PendingDma& d = f->dma[f->dma_head++ % 128];
-        memcpy(d.dst, d.src, 16);
-        lds_write(d.dst, false);
-    }
-    f->dma[f->dma_tail++ % 128] = PendingDma{src, dst_reg};
-}
 void dma_wait(int keep_newest) {
     Fiber* f = g_cur;
     if (!f) return;

@@ -111,9 +111,6 @@ inline void lds_read(const void* p) { if (g_race) lds_read_slow(p); }
 inline void lds_write(const void* p, bool dma_issue_only) { if (g_race) lds_write_slow(p, dma_issue_only); }
 void dma_issue(const void* src, void* dst, const void* wave_base);
 void dma_wait(int keep_newest);
-// a 16-byte global load into a REGISTER that the kernel waits for by count (vc_device.h gld16_async): queued with the lane's LDS-DMAs
-// (one in-order vmcnt queue), the destination POISONED until the wait lands it
-void reg_load_issue(const void* src, void* dst_reg);
 void block_barrier();
 void wave_sync();
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);

@@ -1531,34 +1531,6 @@ def check_gemv_wide(be, N, K, epi, rows, norm=True, seed=0):
         be.lib.vck_set_gemv_wide(-1)
 
 
-def check_gemv_xr(be, N, K, epi, rows, norm=False, depths=(8,), seed=0):
-    """the register-operand form of the ring kernel (vck_set_gemv_xr; csrc/decode.hip gemv_xr_kernel — weights alone in the LDS ring,
-    the activation fragments fetched into VGPRs by count-waited loads) for the matrices of <= 256 tiles: bit for bit the LDS-operand
-    form's result at every row count and ring depth, and within tolerance of float64"""
-    be.lib.vck_gemv_xr_launches.restype = ctypes.c_ulonglong
-    try:
-        rng = np.random.RandomState(seed)
-        c = _wg_case(be, rng, 32, N, K, epi, norm, 0)
-        worst = 0.0
-        for M in rows:
-            be.lib.vck_set_gemv_xr(0)
-            _, raw0, ex0 = _wg_run_plain(be, c, M)
-            for d in depths:
-                be.lib.vck_set_gemv_xr(d)
-                n0 = be.lib.vck_gemv_xr_launches()
-                val, raw1, ex1 = _wg_run_plain(be, c, M)
-                assert be.lib.vck_gemv_xr_launches() == n0 + 1, f"M{M} N{N} epi{epi}: not served by the register-operand form"
-                assert np.array_equal(raw0, raw1), f"M{M} N{N} K{K} epi{epi} depth {d}: the register-operand form changed the bits"
-                for key in (ex0 or {}):
-                    assert np.array_equal(ex0[key], ex1[key]), f"M{M} N{N} K{K} epi{epi} depth {d}: the register-operand form changed {key}"
-                e = rel_err(val, c["ref"][:M])
-                assert e < (2 ** -8 if epi in (0, 3) else 2e-5), f"gemv xr M{M} N{N} K{K} epi{epi}: rel err {e}"
-                worst = max(worst, e)
-        return worst
-    finally:
-        be.lib.vck_set_gemv_xr(-1)
-
-
 def _wg_run_plain(be, c, M, sk=None):
     """one bf16 launch over the first M rows of a _wg_case (sk: the split-K buffers, or none) -> (float64 values, raw output, extras)"""
     N, K, epi, No = c["N"], c["K"], c["epi"], c["No"]

@@ -276,18 +276,6 @@ def test_gemv_wg_rows_agree(be, N, K, epi, G):
     kc.check_gemv_wg_rows_agree(be, N, K, epi, True, G)
 
 
-@pytest.mark.parametrize("N,K,epi,norm,rows", [(4096, 4096, 2, False, (1, 8, 13, 16, 17, 24, 29, 32)), (4096, 11008, 2, False, (8, 16, 24, 32)),
-                                               (2048, 4096 + 64 * 5 + 32, 2, False, (7, 32)), (4096, 4096, 0, True, (8, 32)),
-                                               (1024, 1024, 1, True, (16, 32)), (2048, 2048, 3, True, (8, 24))])
-def test_gemv_register_operand_form(be, N, K, epi, norm, rows):
-    """gemv_xr_kernel — weights alone in the LDS ring, the activation fragments in VGPRs through count-waited asm loads that share
-    the in-order vmcnt queue with the weight DMAs — gives the LDS-operand ring kernel's bits at the 7b o_proj / down shapes, every row
-    count and ring depth (the RESID epilogue is the one the engine launches it with; depths 4 / 6 exist for it only)"""
-    kc.check_gemv_xr(be, N, K, epi, rows, norm, depths=(4, 6, 8) if epi == 2 else (8,))
-    for _ in range(3):   # the loads are ordered by counts, not by data: repeat (a count that is one slot short is a race, not a constant)
-        kc.check_gemv_xr(be, N, K, epi, rows[-1:], norm, depths=(8,), seed=_ + 1)
-
-
 @pytest.mark.parametrize("N,K,epi,rows", [(12288, 4096, 0, (8, 16, 19, 29, 32)), (16 * 767, 4096, 0, (13, 32)), (15360, 5120, 0, (8, 16, 24, 32)),
                                           (22016, 4096, 3, (8, 16, 24, 32)), (27648, 5120, 3, (8, 16, 32))])
 def test_gemv_wide_geometry(be, N, K, epi, rows):

@@ -228,17 +228,6 @@ def test_gemv_wide_geometry(be, N, K, epi, norm, rows):
     kc.check_gemv_wide(be, N, K, epi, rows, norm)
 
 
-@pytest.mark.parametrize("N,K,epi,norm,rows,depths", [(48, 64 * 8 * 8, 2, False, (5, 16, 19, 32), (4, 6, 8)),      # cnt == R (7b o_proj's shape of loop)
-                                                      (32, 64 * 8 * 21 + 5 * 64, 2, False, (8, 29), (4, 6, 8)),  # ragged shares: 21 / 22 slots per wave
-                                                      (32, 64 * 19 + 32, 2, False, (3, 32), (8,)),               # odd k-tile count, cnt < R for some waves
-                                                      (64, 64 * 8 * 3, 0, True, (13, 24), (8,)), (32, 1024, 3, True, (16, 17), (8,)),
-                                                      (16, 64 * 8 * 17, 1, True, (1, 32), (8,))])
-def test_gemv_register_operand_form(be, N, K, epi, norm, rows, depths):
-    """gemv_xr_kernel (weights alone in the LDS ring, activation fragments in VGPRs through count-waited loads) gives the bits of the
-    LDS-operand ring kernel: full rounds, the round whose re-arms run out, short shares, the half line of an odd k-tile count"""
-    kc.check_gemv_xr(be, N, K, epi, rows, norm, depths)
-
-
 @pytest.mark.parametrize("N,K,epi,G,ks", [(64, 512, 0, True, 0), (48, 1024, 1, True, 4), (64, 256, 3, True, 0), (32, 512, 2, True, 2)])
 def test_gemv_wg_rows_agree(be, N, K, epi, G, ks):
     kc.check_gemv_wg_rows_agree(be, N, K, epi, True, G, ks)

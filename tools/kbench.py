@@ -200,35 +200,6 @@ def bench_gemv_rows():
         print(f"gemv_rows M{M:2d} all GEMVs of a 7b decode step: {tot / 1e3:6.3f} ms = {tot / 1e3 / M:6.4f} ms per row", flush=True)
 
 
-def bench_gemv_xr():
-    """o_proj / down (one 16-output tile per 8-wave workgroup, 256 workgroups) at 8 / 16 / 24 / 32 rows: the LDS-operand ring kernel
-    (vck_set_gemv_xr(0)) against the register-operand form at ring depths 4 / 6 / 8 (csrc/decode.hip gemv_xr_kernel)"""
-    for (N, K, name) in [(4096, 4096, "o"), (4096, 11008, "down")]:
-        X = bf16(32, K)
-        Ws = [bf16(N * K, scale=0.02) for _ in range(8)]
-        out = torch.zeros((32, N), dtype=torch.float32, device=dev)
-        npart = (4096 // 16 + 15) // 16 * 16
-        ssq = torch.rand(32, npart, device=dev)
-        gw = torch.rand(N, device=dev) + 0.5
-        xg = torch.zeros((32, N), dtype=torch.bfloat16, device=dev)
-        scratch = torch.zeros(4 * (N // 16) * 2 * 256, device=dev)
-        counters = torch.zeros(N // 16 * 2, dtype=torch.int32, device=dev)
-        for M in (8, 16, 24, 32):
-            row = []
-            for v in (0, 4, 6, 8):
-                lib.vck_set_gemv_xr(v)
-                it = [0]
-
-                def f():
-                    it[0] += 1
-                    lib.vck_gemv_ex(P(X), P(Ws[it[0] % 8]), None, P(out), None, P(ssq), P(gw), P(xg), npart, C.c_float(1e-5),
-                                    P(scratch), P(counters), 0, M, N, K, N, 2, None)
-                us = timeit(f, iters=80)
-                row.append(f"{'ring' if v == 0 else 'xr' + str(v)} {us:6.2f} us {2 * N * K / us / 1e3:6.0f} GB/s")
-            print(f"gemv_xr {name:5s} N{N} K{K} M{M:2d}: " + " | ".join(row), flush=True)
-    lib.vck_set_gemv_xr(-1)
-
-
 def bench_gemv_wide():
     """ring-kernel GEMV, pair geometry (vck_set_gemv_wide 0) vs the "wide" one (2: ceil(tiles / 256) tiles per workgroup, one deep
     ring per CU, every class) on every > 512-tile matrix of the 7b and 13b models at 8 / 16 / 24 / 32 rows; same bits?"""
@@ -520,6 +491,6 @@ if __name__ == "__main__":
     table = {"gemm_qkv": bench_gemm_qkv, "gemm32": bench_gemm32, "gemm": bench_gemm, "gemv": bench_gemv, "attn": bench_attn, "dattn": bench_dattn, "gemv_fp8": bench_gemv_fp8,
              "gemv13": bench_gemv13, "gemv_pair": bench_gemv_pair, "gemv_rows": bench_gemv_rows, "dattn_rows": bench_dattn_rows,
              "gemm_f8": bench_gemm_f8, "gemv_rows8": bench_gemv_rows8, "gemv_wide": bench_gemv_wide, "gemm_chunk": bench_gemm_chunk,
-             "dattn_split": bench_dattn_split, "dattn_kv8": bench_dattn_kv8, "gemv_xr": bench_gemv_xr}
+             "dattn_split": bench_dattn_split, "dattn_kv8": bench_dattn_kv8}
     for w in what:
         table[w]()

@@ -17,7 +17,6 @@
 #include <atomic>
 #include <stdexcept>
 #include <string>
-#include <type_traits>
 
 #include "vc_device.h"
 #include "kernels.h"
@@ -377,163 +376,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
         for (int r = 0; r < cnt; ++r) consume(r, r);
     }
     gemv_ring_finish<WAVES, NT, MG, EPI, FP8>(p, acc, ring, &ss_part[0][0], nt0, ks, KS, ovalid);
-    stamp_end(p.stamp, blockIdx.x);
-}
-
-// ---- the ring kernel with the activation operand in REGISTERS ("xr"; bf16 weights, no split rows; round 6) ----------------------
-// gemv_dma_kernel's ring carries the activation pieces of a k-line beside its weight blocks: at 32 rows a slot of the 256-tile
-// matrices (o_proj, down: one tile per 8-wave workgroup) is 2 KiB of weights + 4 KiB of activations, so 160 KiB of LDS keep only
-// 48 KiB of WEIGHTS in flight per CU — and the measured rate follows the weight bytes in flight (o_proj 3.0, down 3.8 TB/s at 48 KiB;
-// qkv 4.65 at 72; gate/up 5.3 at 96: profiles/r06_m_bench_driver_shaped.json).  Here the ring holds weights only and a lane fetches
-// its MFMA B fragments — 16 bytes of row 16q + m, chunk kk * 4 + g of the k-line — straight from L2 into VGPRs, with
-// gld16_async (vc_device.h): the loads sit in the SAME in-order vmcnt queue as the weight DMAs, issued slot by slot at the same
-// depth R (a shallower register prefetch would bound the ring too: a slot's wait covers everything issued before its youngest
-// operation), and the counted wait of a slot covers both.  R * MG * 8 VGPRs hold the fragments; the LDS holds R * 2 * NT KiB per
-// wave of weights: 8 waves x 8 slots = the WHOLE 128-KiB weight tile of o_proj in flight from the first instruction on.
-// K partition (k-line -> wave), MFMA order and the tail are gemv_dma_kernel's: the same bits.
-template <int WAVES, int NT, int R, int EPI, int MG>
-__global__ __launch_bounds__(WAVES * 64) void gemv_xr_kernel(GemvArgs p) {
-    constexpr int WB = 2 * NT;               // 1-KiB weight blocks per slot (a k-line = two 32-wide k-tiles)
-    constexpr int OPS = WB + 2 * MG;         // vector-memory operations per slot: weight DMAs + fragment loads
-    constexpr int SLOT = WB * 1024;
-    static_assert(R * OPS <= 63, "vmcnt is a 6-bit counter");
-    static_assert(WAVES * R * SLOT >= WAVES * NT * MG * 1024, "the ring is re-used for the cross-wave reduction");
-    stamp_begin(p.stamp, blockIdx.x);
-    VC_DYNAMIC_SMEM(char, ring);             // [WAVES][R][SLOT]
-    __shared__ float ss_part[WAVES][16 * MG];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ntiles = p.N >> 4;
-    const int KS = p.ksplit > 1 ? p.ksplit : 1;
-    const int ks = (int)blockIdx.x % KS;
-    const int nt0 = ((int)blockIdx.x / KS) * NT;
-    const int nkt = p.K >> 5;
-    const int nit = (nkt + 1) / 2;
-    const int it0 = (int)((long)ks * nit / KS), it1 = (int)((long)(ks + 1) * nit / KS);
-    const int m = lane & 15, g = lane >> 4;
-    bool mvalid[MG], ovalid[MG];
-#pragma unroll
-    for (int q = 0; q < MG; ++q) mvalid[q] = ovalid[q] = m + 16 * q < p.M;
-    char* my = ring + wave * (R * SLOT);
-    const char* wsrc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-        wsrc[t] = reinterpret_cast<const char*>(p.Wp) + ((size_t)min(nt0 + t, ntiles - 1) * nkt * 64 + lane) * 16;
-    const char* xsrc[MG];                    // row 16q + m of X (rows past M re-read row 0; zeroed where consumed), chunk g of the line
-#pragma unroll
-    for (int q = 0; q < MG; ++q) xsrc[q] = reinterpret_cast<const char*>(p.X + (size_t)(mvalid[q] ? m + 16 * q : 0) * p.K) + g * 16;
-    const int kline_last = (p.K * 2 + 127) / 128 - 1;
-    const bool half_line = (p.K * 2) % 128 != 0;   // odd k-tile count: the last line of a row holds one k-tile
-    const int cnt = max(0, (it1 - it0 - wave + WAVES - 1) / WAVES);  // slots (k-lines) of this wave (wave-uniform)
-    const int is_last = it0 + (cnt > 0 ? wave + (cnt - 1) * WAVES : 0);
-    u32x4 xr[R][MG][2];
-    auto issue = [&](int i, int j) {         // j = i % R, a compile-time constant at every call site
-        char* dst = my + j * SLOT;
-        const int is = min(it0 + wave + i * WAVES, is_last);             // (a null slot re-reads the wave's last line)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const size_t kt = (size_t)min(is * 2 + kk, nkt - 1);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) glds16_nt(wsrc[t] + kt * 1024, dst + (kk * NT + t) * 1024);
-        }
-        const size_t line = (size_t)min(is, kline_last) * 128;
-#pragma unroll
-        for (int q = 0; q < MG; ++q) {
-            gld16_async(xr[j][q][0], xsrc[q] + line);
-            // (the missing second k-tile of a half line re-reads the first; the consumer zeroes that fragment)
-            gld16_async(xr[j][q][1], xsrc[q] + line + ((half_line && is >= kline_last) ? 0 : 64));
-        }
-    };
-    f32x4 acc[NT][MG];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int q = 0; q < MG; ++q) acc[t][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // `last` (a literal at every call site): only the last round can hold the missing half of an odd last line or a null slot
-    auto consume = [&](int i, int j, bool last) {
-        const char* sl = my + j * SLOT + lane * 16;
-#pragma unroll
-        for (int q = 0; q < MG; ++q) {
-            pin_loaded(xr[j][q][0]);
-            pin_loaded(xr[j][q][1]);
-        }
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            u32x4 w[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) w[t] = ld16(sl + (kk * NT + t) * 1024);
-            const bool tail = last && ((it0 + wave + i * WAVES) * 2 + kk >= nkt || i >= cnt);
-            u32x4 x[MG];
-#pragma unroll
-            for (int q = 0; q < MG; ++q) {
-                x[q] = xr[j][q][kk];
-                if (!mvalid[q] || tail) x[q] = u32x4{0u, 0u, 0u, 0u};
-            }
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int q = 0; q < MG; ++q) acc[t][q] = mfma16(w[t], x[q], acc[t][q]);
-        }
-        wait_lgkmcnt<0>();  // the slot's fragment reads have retired before it is re-armed
-    };
-    // 1/rms partials (gemv_dma_kernel): plain loads after the ring is primed — the compiler's wait for them is vmcnt(0), which here
-    // also lands the first R slots
-    constexpr int SQ = 6;
-    const int nq = p.npart >> 2;
-    auto ssq_reduce = [&]() {
-        if (p.ssq_in == nullptr) return;
-        f32x4 sq[MG][SQ];
-#pragma unroll
-        for (int q = 0; q < MG; ++q) {
-            const float* sp = p.ssq_in + (size_t)(ovalid[q] ? m + 16 * q : 0) * p.npart;
-#pragma unroll
-            for (int j = 0; j < SQ; ++j) sq[q][j] = ld16f(sp + min(wave * 4 + g + j * WAVES * 4, nq - 1) * 4);
-        }
-#pragma unroll
-        for (int q = 0; q < MG; ++q) {
-#pragma unroll
-            for (int j = 0; j < SQ; ++j)
-                if (wave * 4 + g + j * WAVES * 4 >= nq) sq[q][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-            for (int j = 0; j < SQ; j += 2) {
-                s0 += (sq[q][j][0] + sq[q][j][1]) + (sq[q][j][2] + sq[q][j][3]);
-                s1 += (sq[q][j + 1][0] + sq[q][j + 1][1]) + (sq[q][j + 1][2] + sq[q][j + 1][3]);
-            }
-            float ss = s0 + s1;
-            const float* sp = p.ssq_in + (size_t)(ovalid[q] ? m + 16 * q : 0) * p.npart;
-            for (int qi = wave * 4 + g + SQ * WAVES * 4; qi < nq; qi += WAVES * 4) {
-                const f32x4 v = ld16f(sp + qi * 4);
-                ss += (v[0] + v[1]) + (v[2] + v[3]);
-            }
-            ss += shfl_xor(ss, 16);
-            ss += shfl_xor(ss, 32);
-            if (g == 0) ss_part[wave][16 * q + m] = ss;
-        }
-    };
-    // ONE path for every share: ceil(cnt / R) rounds of R steps with compile-time ring / register indices.  Slots past the wave's
-    // share are NULL slots — they re-fetch the wave's last line (L2 hits) and feed zeros — so that no register is in flight across a
-    // data-dependent branch: the register allocator keeps one assignment through prime -> loop -> last round, which is what
-    // tools/check_async_loads.py verifies (a dispatch on the remainder made it copy registers whose loads had not landed).
-    // Cost: < R null slots per wave (7b o_proj: 8 slots = one round, none; down: 21.5 -> 24).
-    const int nr = max(1, (cnt + R - 1) / R);
-#pragma unroll
-    for (int r = 0; r < R; ++r) issue(r, r);
-    ssq_reduce();
-    int i0 = 0;
-    for (int b = 0; b < nr - 1; ++b, i0 += R) {
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-            wait_vmcnt<(R - 1) * OPS>();
-            consume(i0 + j, j, false);
-            issue(i0 + j + R, j);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-        wait_vmcnt_n((R - 1 - j) * OPS);
-        consume(i0 + j, j, true);
-    }
-    gemv_ring_finish<WAVES, NT, MG, EPI, false>(p, acc, ring, &ss_part[0][0], nt0, ks, KS, ovalid);
     stamp_end(p.stamp, blockIdx.x);
 }
 
@@ -1027,48 +869,6 @@ static bool launch_gemv_wide(const GemvArgs& a, int epi, hipStream_t s) {
     return false;
 }
 
-// ---- the register-operand form of the ring kernel (gemv_xr_kernel; set_gemv_xr: 0 = off, -1 / 1 = the default depth, 4 / 6 / 8 = ring
-// depth R for the sweeps of tools/kbench.py gemv_xr) for the matrices of at most 256 tiles: one tile per 8-wave workgroup, the K
-// partition of gemv_dma_kernel's <= 256-tile class (8 waves, no K-slices), so the bits are those of the LDS-operand form
-#ifndef VC_GEMV_XR_DEFAULT
-#define VC_GEMV_XR_DEFAULT 0   // (until measured: tools/gpu/r06_o.sh)
-#endif
-static int g_gemv_xr = -1;
-static std::atomic<unsigned long> g_gemv_xr_launches{0};
-void set_gemv_xr(int v) { g_gemv_xr = v; }
-unsigned long gemv_xr_launches() { return g_gemv_xr_launches.load(std::memory_order_relaxed); }
-template <int R, int MG, int EPI>
-static void launch_gemv_xr1(const GemvArgs& a, hipStream_t s) {
-    constexpr int WAVES = 8, NT = 1;
-    const dim3 grid(a.N / 16), block(WAVES * 64);
-    constexpr size_t shmem = (size_t)WAVES * R * 2 * NT * 1024;
-    static_assert(shmem + WAVES * 16 * MG * 4 <= 160 * 1024, "ring exceeds the LDS of a CU");
-    static bool once = false;
-    if (!once) {
-        allow_big_lds(gemv_xr_kernel<WAVES, NT, R, EPI, MG>, shmem);
-        once = true;
-    }
-    VC_LAUNCH((gemv_xr_kernel<WAVES, NT, R, EPI, MG>), grid, block, shmem, s, a);
-}
-static bool launch_gemv_xr(const GemvArgs& a, int epi, hipStream_t s) {
-    const int v = g_gemv_xr < 0 ? VC_GEMV_XR_DEFAULT : g_gemv_xr;
-    if (!v || a.wscale || a.Wp_lo || a.split_rows || a.ksplit > 1 || a.N / 16 > 256 || a.M > 32) return false;
-    const int R = v == 1 ? 8 : v;
-    const int mg = a.M <= 16 ? 1 : 2;
-#define VC_XR(R_, MG_, E_)                                               \
-    if (R == R_ && mg == MG_ && epi == E_) {                             \
-        launch_gemv_xr1<R_, MG_, E_>(a, s);                              \
-        g_gemv_xr_launches.fetch_add(1, std::memory_order_relaxed);      \
-        return true;                                                     \
-    }
-#define VC_XR_E(R_, MG_) VC_XR(R_, MG_, GEMV_BF16) VC_XR(R_, MG_, GEMV_F32) VC_XR(R_, MG_, GEMV_RESID_F32) VC_XR(R_, MG_, GEMV_SWIGLU)
-    VC_XR_E(8, 1) VC_XR_E(8, 2)
-    VC_XR(4, 1, GEMV_RESID_F32) VC_XR(4, 2, GEMV_RESID_F32) VC_XR(6, 1, GEMV_RESID_F32) VC_XR(6, 2, GEMV_RESID_F32)
-#undef VC_XR_E
-#undef VC_XR
-    return false;
-}
-
 void launch_gemv(const GemvArgs& a, int epilogue, hipStream_t s) {
     if (gemv_wg_enabled() && gemv_wg_applies(a)) {
         launch_gemv_wg(a, epilogue, s);
@@ -1091,7 +891,6 @@ void launch_gemv(const GemvArgs& a, int epilogue, hipStream_t s) {
         return;
     }
     if (launch_gemv_wide(a, epilogue, s)) return;
-    if (launch_gemv_xr(a, epilogue, s)) return;
     if (a.wscale) launch_gemv_f<true>(a, epilogue, s);
     else launch_gemv_f<false>(a, epilogue, s);
 }

@@ -279,8 +279,6 @@ VCK_EXPORT void vck_set_gemv_variant(int v) { set_gemv_variant(v); }
 VCK_EXPORT void vck_set_gemm_variant(int v) { set_gemm_variant(v); }
 VCK_EXPORT void vck_set_gemv_wide(int v) { set_gemv_wide(v); }
 VCK_EXPORT unsigned long long vck_gemv_wide_launches() { return gemv_wide_launches(); }
-VCK_EXPORT void vck_set_gemv_xr(int v) { set_gemv_xr(v); }
-VCK_EXPORT unsigned long long vck_gemv_xr_launches() { return gemv_xr_launches(); }
 VCK_EXPORT unsigned long long vck_gemv_wg_launches() { return gemv_wg_launches(); }
 VCK_EXPORT void vck_rmsnorm_split(const float* x, const int* row_idx, const float* w, uint16_t* y, int rows, int D, float eps,
                                   int ldy, uint64_t lo_off, void* stream) {

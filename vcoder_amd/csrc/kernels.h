@@ -153,8 +153,6 @@ void set_gemv_variant(int v);
 void set_gemm_variant(int v);   // overrides VC_GEMM_VARIANT inside one process (< 0: the environment's); 6 / 7 = the 32 x 32 x 16 MFMA form
 void set_gemv_wide(int v);       // -1 / 1 = the measured classes (default), 0 = off, 2 = every class (launch_gemv_wide)
 unsigned long gemv_wide_launches();
-void set_gemv_xr(int v);         // the register-operand ring kernel of the <= 256-tile matrices: 0 off, -1 / 1 default, 4 / 6 / 8 ring depth
-unsigned long gemv_xr_launches();
 bool gemv_wg_enabled();                          // the workgroup-shared form serves the split step's GEMVs
 bool gemv_wg_applies(int K, bool fp8_weights);   // ... for a matrix with this K / weight format
 unsigned long gemv_wg_launches();   // launches served by the workgroup-shared form so far (tests)

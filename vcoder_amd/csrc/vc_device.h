@@ -456,25 +456,6 @@ VC_DEV void wait_vmcnt_n(int n) {
 }
 #endif
 
-// ---- 16-byte global load into REGISTERS, waited for by COUNT in the same in-order vmcnt queue as the LDS-DMAs -------------------
-// LLVM waits with vmcnt(0) for any register load that is outstanding together with LDS-DMAs (it models the mixed queue as
-// unordered), so a register stream that runs beside a DMA ring cannot be written as C++ loads.  The load is inline asm — the
-// compiler sees a value that exists at once — and the kernel orders things by hand: wait_vmcnt<N>() (loads return in order), then
-// pin_loaded(v) on every register the wait covers BEFORE its first use (the use then cannot be scheduled above the wait).
-// Between the load and its pin the compiler must not touch the register (a copy would read bytes that have not landed):
-// tools/check_async_loads.py verifies that on the ISA of every kernel that uses these.
-#ifdef VC_EMU
-VC_DEV void gld16_async(u32x4& dst, const void* gsrc) { vc_emu::reg_load_issue(gsrc, &dst); }
-VC_DEV void gld16_async(f32x4& dst, const void* gsrc) { vc_emu::reg_load_issue(gsrc, &dst); }
-VC_DEV void pin_loaded(u32x4&) {}
-VC_DEV void pin_loaded(f32x4&) {}
-#else
-VC_DEV void gld16_async(u32x4& dst, const void* gsrc) { asm volatile("global_load_dwordx4 %0, %1, off ; vc_async_load" : "=v"(dst) : "v"(gsrc) : "memory"); }
-VC_DEV void gld16_async(f32x4& dst, const void* gsrc) { asm volatile("global_load_dwordx4 %0, %1, off ; vc_async_load" : "=v"(dst) : "v"(gsrc) : "memory"); }
-VC_DEV void pin_loaded(u32x4& v) { asm volatile("; vc_async_pin %0" : "+v"(v)); }
-VC_DEV void pin_loaded(f32x4& v) { asm volatile("; vc_async_pin %0" : "+v"(v)); }
-#endif
-
 // LDS hand-off between lanes of ONE wave (write by some lanes, read by others, no other wave involved): the LDS queue of
 // a wave is in order, so the hardware needs nothing; the emulator's lane fibers need a rendezvous
 #ifdef VC_EMU
