@@ -47,8 +47,8 @@ def device_state_dict(eng, cfg, seed, prefixes=None, dtypes="bf16", effective_fp
         if "depth_mm_projector" in key or "mm2_projector" in key or "vcoder_lm_emb" in key:
             continue                      # dead at inference: the oracle never reads them
         n = int(np.prod(shape))
-        if dtypes == "reference":
-            rounding = synth.reference_rounding(key)
+        if dtypes in synth.REFERENCE_CLASSES:
+            rounding = synth.reference_rounding(key, dtypes)
             buf = torch.empty(n, dtype=torch.float32, device=dev)
             eng.lib.vck_synth_f32_rounded(ctypes.c_void_p(buf.data_ptr()), ctypes.c_uint64(n), ctypes.c_uint32(synth.tensor_seed(key, seed)),
                                           ctypes.c_float(off), ctypes.c_float(hw), synth.ROUNDING_CODE[rounding], None)

@@ -244,6 +244,11 @@ def test_full_depth_parity_logic_on_the_tiny_model(emu_lib):
     r = fd.run_case(vcfg.tiny("vcoder_ds"), B=2, n_new=4, seed=43, oracle_rows=(1,), checkpoints=(), strict_tokens=2,
                     pooled_calls=1, lib=emu_lib, fast_vs="split", dtypes="reference")
     assert r["e_strict"] < 1e-4 and r["e_split"] < 1e-4
+    # ... and with the values the reference COMPUTES with: model/builder.py:142 casts the loaded tower to fp16 ("reference_loaded",
+    # the class the full-depth GPU case runs)
+    r = fd.run_case(vcfg.tiny("vcoder_ds"), B=2, n_new=4, seed=43, oracle_rows=(1,), checkpoints=(), strict_tokens=2,
+                    pooled_calls=1, lib=emu_lib, fast_vs="split", dtypes="reference_loaded")
+    assert r["e_strict"] < 1e-4 and r["e_split"] < 1e-4
 
 
 def test_context_limit_is_a_clean_error(emu_lib):

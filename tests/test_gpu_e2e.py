@@ -256,8 +256,11 @@ def test_inexact_checkpoint(name, mode):
     assert r["logits_err"] < 1e-4 and r["decode_logits_err"] < 1e-4, r
 
 
-def test_inexact_checkpoint_true_dims():
-    """The same at true 7b / ViT-L dims (2 + 2 layers): split and strict vs the fp32 oracle on the fp16- / fp32-valued weights
+@pytest.mark.parametrize("dtypes", ["reference", "reference_loaded"])
+def test_inexact_checkpoint_true_dims(dtypes):
+    """("reference": the files' value classes, an fp32-valued tower; "reference_loaded": the tower as model/builder.py:142 casts it,
+    fp16-valued — what the reference computes with.)
+    The same at true 7b / ViT-L dims (2 + 2 layers): split and strict vs the fp32 oracle on the fp16- / fp32-valued weights
     (1e-3 absolute, ids equal), the split decode step through the lo-plane form of the workgroup-shared GEMV; the bf16 fast
     path on the same checkpoint: prefill within 1.7e-2 of |logit|max, its teacher-forced decode step within 4x its prefill's deviation."""
     import torch
@@ -266,7 +269,7 @@ def test_inexact_checkpoint_true_dims():
     cfg = vcfg.vicuna_7b("vcoder_ds")
     cfg.num_hidden_layers = 2
     cfg.vit_num_layers = 3
-    sd = synth.synth_state_dict(cfg, 13, dtypes="reference")
+    sd = synth.synth_state_dict(cfg, 13, dtypes=dtypes)
     eng = HipEngine(cfg)
     eng.load_state_dict(sd)
     eng.finalize()

@@ -122,9 +122,9 @@ def run_case(cfg, B, n_new, seed, oracle_rows, checkpoints, strict_tokens, split
     assert fast_vs in ("oracle", "split") and (split or fast_vs == "oracle")
     t0 = time.time()
     eng = HipEngine(cfg, lib=lib)
-    eng.load_synthetic(seed, dtypes=dtypes)      # "reference": fp16-valued LLM, fp32-valued tower -> weight lo planes
+    eng.load_synthetic(seed, dtypes=dtypes)      # "reference" / "reference_loaded": fp16-valued LLM, fp32- / fp16-valued tower -> weight lo planes
     eng.finalize()
-    assert (eng.inexact_tensors() > 0) == (dtypes == "reference")
+    assert (eng.inexact_tensors() > 0) == (dtypes in synth.REFERENCE_CLASSES)
     ids = np.stack([synth.synth_prompt_ids(cfg.vocab_size, "vcoder_ds", sample=b) for b in range(B)])
     imgs, segs, deps = synth.synth_batch(B, cfg.vit_image_size)
     rows = list(oracle_rows)
@@ -262,15 +262,16 @@ def test_full_size_7b_c2():
 
 
 def test_full_depth_7b_inexact_checkpoint():
-    """VCoder-DS 7b at FULL depth (32 decoder + 23 ViT layers, the C2 prompt) on a checkpoint with the value classes of the
-    reference's own — fp16-valued LLM / projector tensors (model/builder.py:25-40 loads torch_dtype=float16), an fp32-valued CLIP
-    tower (multimodal_encoder/clip_encoder.py:22-27) — generated on the device (vc_model_synth_tensor_rounded), which bf16 cannot
-    hold: every matrix keeps a lo plane.  B = 2, 16 greedy tokens: SPLIT mode (three-segment prefill GEMMs, lo-plane decode GEMV)
+    """VCoder-DS 7b at FULL depth (32 decoder + 23 ViT layers, the C2 prompt) on a checkpoint with the values the reference COMPUTES
+    with — fp16-valued LLM / projector tensors (model/builder.py:25-40 loads torch_dtype=float16) and the CLIP tower as
+    model/builder.py:142 casts it at load, fp16-valued too ("reference_loaded"; the fp32-valued tower of the hub file is the stress
+    case of test_inexact_checkpoint_true_dims) — generated on the device (vc_model_synth_tensor_rounded), which bf16 cannot
+    hold: every matrix keeps a lo plane, and hi + lo holds every value EXACTLY.  B = 2, 16 greedy tokens: SPLIT mode (three-segment prefill GEMMs, lo-plane decode GEMV)
     and STRICT mode against the fp32 oracle on the SAME values, 1e-3 absolute, ids identical at every step; the bf16 path (which
     rounds the weights) against the split path for the record."""
     cfg = vcfg.vicuna_7b("vcoder_ds")
     r = run_case(cfg, B=2, n_new=16, seed=43, oracle_rows=(1,), checkpoints=(), strict_tokens=4, split=True, pooled_calls=1,
-                 fast_vs="split", dtypes="reference")
+                 fast_vs="split", dtypes="reference_loaded")
     assert r["e_split"] < 1e-3 and r["e_strict"] < 1e-3
     print(f"    bf16 path on the inexact checkpoint vs the split path: |dlogit|max {r['err32'].max():.4f} (rel {r['err32'].max() / r['scale']:.2e})")
     # measured on MI355X (profiles/r05_o_inexact_checkpoint_full_depth_7b.txt): 0.19 at |logit|max 6.42 = 3.0e-2 -> 2x (round 5

@@ -119,6 +119,7 @@ def test_e4m3_kv_cache_kernels(be):
     """the fp8 weight format's KV cache (1 byte per element): the prefill's writer and the bf16 step's decode attention"""
     kc.check_kv8(be, 3, 2, 128, 140)
     kc.check_kv8(be, 10, 1, 64, 70, T_prefill=33, seed=1)
+    kc.check_kv8(be, 1, 2, 128, 400, T_prefill=33, seed=2)   # past one round of the e4m3 rows (384 keys): the early first batch
 
 
 def test_fused_decode_kernels(be):
@@ -132,6 +133,14 @@ def test_fused_decode_kernels(be):
     kc.check_attention_decode_fused(be, 1, 1, 64, 5)
     kc.check_attention_decode_fused(be, 3, 2, 128, 300, per_row=True)   # a position per row, one row inactive (the pool)
     kc.check_attention_decode_fused(be, 2, 1, 64, 40, per_row=True)
+    # the first K batch requested behind phase 0's operand loads (pos >= one round of the 8 waves: 256 keys at hd 128, 512 at 64) and
+    # the old order on either side of that boundary
+    kc.check_attention_decode_fused(be, 2, 1, 128, 256, seed=2)
+    kc.check_attention_decode_fused(be, 1, 1, 128, 255, seed=3)
+    kc.check_attention_decode_fused(be, 1, 2, 128, 600, seed=4)
+    kc.check_attention_decode_fused(be, 1, 1, 64, 520, seed=5)
+    kc.check_attention_decode_kv32(be, 2, 1, 128, 300, seed=6)   # the split step's fp32 / fp24 caches past one round (192 keys)
+    kc.check_attention_decode_kv32(be, 1, 1, 128, 100, seed=7)
     kc.check_select_embed(be, 3, 320, 256)
 
 

@@ -647,6 +647,29 @@ __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeF
     const int D = p.H * HD;
     char* kbase = reinterpret_cast<char*>(p.k) + bh * p.kv_stride * ROWB;
     char* vbase = reinterpret_cast<char*>(p.v) + bh * p.kv_stride * ROWB;
+    // Both streams run as a ROLLING window of UK loads per lane (phase 1 / 3 below).  wave-uniform base + one 32-bit byte offset per
+    // lane (the scalar-base addressing form: half the address VGPRs); rows past the context are clamped to the last valid row
+    constexpr int EPL_ = EPL;
+    const int krow = lane / LPK, kcol = (lane % LPK) * EPL_;
+    auto row_off = [&](int key) { return (uint32_t)(min(key, ctx - 1) * ROWB) + (uint32_t)(kcol * ESZ); };
+    // fp24: the lo plane of the row, 8 bytes per lane
+    auto lo_off = [&](int key) { return (uint32_t)(min(key, ctx - 1) * ROWB) + (uint32_t)(2 * HD + kcol); };
+    u32x4 kv[UK];
+    u32x2 kl[F24 ? UK : 1];
+    auto first_k = [&]() {
+#pragma unroll
+        for (int u = 0; u < UK; ++u) {
+            kv[u] = ld16_stream(kbase + row_off(wave * KPW * UK + u * KPW + krow));
+            if constexpr (F24) kl[u] = ld8_stream(kbase + lo_off(wave * KPW * UK + u * KPW + krow));
+        }
+    };
+    // The first K batch (keys < BATCH) does not depend on phase 0 unless it contains the new token's own row: it is requested BEHIND
+    // phase 0's operand loads and BEFORE its arithmetic and stores (round 6) — loads return in order, so the rotation waits for its
+    // operands only, and the barrier's drain of the appended rows overlaps the batch's flight instead of preceding it (one HBM
+    // round trip less per launch).  Requested unconditionally (a branch around it makes the compiler count the operands' wait for
+    // the path WITHOUT the batch, i.e. wait for half of it); a context shorter than one round requests it again behind the
+    // barrier, the only case in which the first request can have read the new row before it was written.
+    const bool early = pos >= BATCH;
     // ---- phase 0: rotate q,k of the new token, append k / v to the cache (global) and keep q in LDS
     if (tid < HD / 2) {
         const int d = tid;
@@ -655,6 +678,8 @@ __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeF
             const float* row = reinterpret_cast<const float*>(p.qkv) + (size_t)b * (3 * D) + h * HD;
             const float q0 = row[d], q1 = row[d + HD / 2];
             const float k0 = row[D + d], k1 = row[D + d + HD / 2];
+            const float v0 = row[2 * D + d], v1 = row[2 * D + d + HD / 2];
+            first_k();
             q_s[d] = q0 * c - q1 * s;
             q_s[d + HD / 2] = q1 * c + q0 * s;
             if constexpr (F24) {
@@ -667,20 +692,23 @@ __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeF
                 put(ko, d, k0 * c - k1 * s);
                 put(ko, d + HD / 2, k1 * c + k0 * s);
                 char* vo = vbase + (size_t)pos * ROWB;
-                put(vo, d, row[2 * D + d]);
-                put(vo, d + HD / 2, row[2 * D + d + HD / 2]);
+                put(vo, d, v0);
+                put(vo, d + HD / 2, v1);
             } else {
                 float* ko = reinterpret_cast<float*>(kbase) + (size_t)pos * HD;
                 ko[d] = k0 * c - k1 * s;
                 ko[d + HD / 2] = k1 * c + k0 * s;
                 float* vo = reinterpret_cast<float*>(vbase) + (size_t)pos * HD;
-                vo[d] = row[2 * D + d];
-                vo[d + HD / 2] = row[2 * D + d + HD / 2];
+                vo[d] = v0;
+                vo[d + HD / 2] = v1;
             }
         } else {
             const bf16_t* row = p.qkv + (size_t)b * (3 * D) + h * HD;
-            const float q0 = bf2f(row[d]), q1 = bf2f(row[d + HD / 2]);
-            const float k0 = bf2f(row[D + d]), k1 = bf2f(row[D + d + HD / 2]);
+            const bf16_t rq0 = row[d], rq1 = row[d + HD / 2], rk0 = row[D + d], rk1 = row[D + d + HD / 2];
+            const bf16_t v0 = row[2 * D + d], v1 = row[2 * D + d + HD / 2];
+            first_k();
+            const float q0 = bf2f(rq0), q1 = bf2f(rq1);
+            const float k0 = bf2f(rk0), k1 = bf2f(rk1);
             q_s[d] = bf2f(f2bf(q0 * c - q1 * s));            // q is rounded to bf16 exactly like the unfused path
             q_s[d + HD / 2] = bf2f(f2bf(q1 * c + q0 * s));
             if constexpr (F8) {   // e4m3 rows: the bf16 values the bf16 cache would hold, re-rounded (as the prefill's writer does)
@@ -688,17 +716,19 @@ __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeF
                 ko[d] = f2fp8(bf2f(f2bf(k0 * c - k1 * s)));
                 ko[d + HD / 2] = f2fp8(bf2f(f2bf(k1 * c + k0 * s)));
                 uint8_t* vo = reinterpret_cast<uint8_t*>(vbase) + (size_t)pos * HD;
-                vo[d] = f2fp8(bf2f(row[2 * D + d]));
-                vo[d + HD / 2] = f2fp8(bf2f(row[2 * D + d + HD / 2]));
+                vo[d] = f2fp8(bf2f(v0));
+                vo[d + HD / 2] = f2fp8(bf2f(v1));
             } else {
                 bf16_t* ko = reinterpret_cast<bf16_t*>(kbase) + (size_t)pos * HD;
                 ko[d] = f2bf(k0 * c - k1 * s);
                 ko[d + HD / 2] = f2bf(k1 * c + k0 * s);
                 bf16_t* vo = reinterpret_cast<bf16_t*>(vbase) + (size_t)pos * HD;
-                vo[d] = row[2 * D + d];
-                vo[d + HD / 2] = row[2 * D + d + HD / 2];
+                vo[d] = v0;
+                vo[d + HD / 2] = v1;
             }
         }
+    } else {
+        first_k();
     }
     __syncthreads();  // workgroup-scope release/acquire: the appended K / V rows are visible to this block
     // ---- phase 1: scores
@@ -706,17 +736,11 @@ __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeF
 #pragma unroll
     for (int e = 0; e < EPL; ++e) qv[e] = q_s[(lane % LPK) * EPL + e];
     const int ctx_pad = (ctx + BATCH - 1) / BATCH * BATCH;
-    const int krow = lane / LPK, kcol = (lane % LPK) * EPL;
     // keys hidden by the attention_mask of the row's prefill (vc_decode_step loops that keep a caller's mask; nullptr: none).
     // The new token's own key (position pos) is always visible.
     const uint8_t* kmask = p.key_mask != nullptr ? p.key_mask + (size_t)b * p.mask_stride : nullptr;
-    // Both streams run as a ROLLING window of UK loads per lane: a register is re-requested for the next batch as soon as
-    // its row has been consumed, so UK rows stay in flight with UK registers (no second set).  Rows past the context are
-    // clamped to the last valid row (one cached line, p = 0 / score masked): no branch around the loads.
-    // wave-uniform base + one 32-bit byte offset per lane (the scalar-base addressing form: half the address VGPRs)
-    auto row_off = [&](int key) { return (uint32_t)(min(key, ctx - 1) * ROWB) + (uint32_t)(kcol * ESZ); };
-    // fp24: the lo plane of the row, 8 bytes per lane
-    auto lo_off = [&](int key) { return (uint32_t)(min(key, ctx - 1) * ROWB) + (uint32_t)(2 * HD + kcol); };
+    // (a register of the rolling window is re-requested for the next batch as soon as its row has been consumed: UK rows in flight
+    // with UK registers, no second set; no branch around the loads)
     auto dot = [&](const u32x4& r, const u32x2& rl) {
         float s = 0.f;
         if constexpr (F24) {
@@ -739,13 +763,7 @@ __global__ __launch_bounds__(512) void attention_decode_fused_kernel(AttnDecodeF
         }
         return s;
     };
-    u32x4 kv[UK];
-    u32x2 kl[F24 ? UK : 1];
-#pragma unroll
-    for (int u = 0; u < UK; ++u) {
-        kv[u] = ld16_stream(kbase + row_off(wave * KPW * UK + u * KPW + krow));
-        if constexpr (F24) kl[u] = ld8_stream(kbase + lo_off(wave * KPW * UK + u * KPW + krow));
-    }
+    if (!early) first_k();
     for (int kb = wave * KPW * UK; kb < ctx_pad; kb += BATCH) {
 #pragma unroll
         for (int u = 0; u < UK; ++u) {

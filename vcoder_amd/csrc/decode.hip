@@ -26,8 +26,14 @@ namespace vc {
 
 // shared epilogue: `v` = out[m][n..n+3] partial sums already reduced over the waves of the workgroup
 // `m` = token row (0 .. 16*MG-1), `SSW` = row slots per wave in ss_part (16 * MG)
+// `pre` (RESID epilogue): the residual values out[m][n..n+3] and the norm weights xg_w[n..n+3], requested by the caller ahead of time
+struct GemvResidPre {
+    f32x4 o, gw;
+    bool have;
+};
 template <int WAVES, int EPI, bool FP8, int SSW = 16>
-VC_DEV void gemv_epilogue(const GemvArgs& p, f32x4 v, const float* ss_part /*[WAVES][SSW]*/, int nt, int m, int g, bool mvalid) {
+VC_DEV void gemv_epilogue(const GemvArgs& p, f32x4 v, const float* ss_part /*[WAVES][SSW]*/, int nt, int m, int g, bool mvalid,
+                          const GemvResidPre* pre = nullptr) {
     const int n = nt * 16 + g * 4;  // lane holds out[m][n..n+3]
     if constexpr (FP8) v = v * ld16f(p.wscale + n);
     if (p.ssq_in != nullptr) {
@@ -39,10 +45,10 @@ VC_DEV void gemv_epilogue(const GemvArgs& p, f32x4 v, const float* ss_part /*[WA
     if constexpr (EPI == GEMV_RESID_F32) {
         float* o = reinterpret_cast<float*>(p.out) + (size_t)(mvalid ? m : 0) * p.ldo + n;
         if (mvalid) {
-            v = ld16f(o) + v;
+            v = (pre != nullptr && pre->have ? pre->o : ld16f(o)) + v;
             st16f(o, v);
             if (p.xg_out) {  // the consumer's operand: bf16(x * g) of the updated residual values
-                const f32x4 gw = ld16f(p.xg_w + n);
+                const f32x4 gw = pre != nullptr && pre->have ? pre->gw : ld16f(p.xg_w + n);
                 const f32x4 t = {v[0] * gw[0], v[1] * gw[1], v[2] * gw[2], v[3] * gw[3]};
                 const u32x2 hi = {pack_bf2(t[0], t[1]), pack_bf2(t[2], t[3])};
                 st8(p.xg_out + (size_t)m * p.N + n, hi);
@@ -98,6 +104,20 @@ VC_DEV void gemv_ring_finish(const GemvArgs& p, f32x4 (&acc)[NT][MG], char* ring
     const int m = lane & 15, g = lane >> 4;
     const int ntiles = p.N >> 4;
     const int SR = p.split_rows;
+    // RESID epilogue, one unit per wave: the residual values and norm weights the epilogue adds are requested BEFORE the cross-wave
+    // reduction (two barriers and the LDS sums then overlap their round trip; round 6).  Unconditional loads at clamped addresses —
+    // a guarded load would be waited for at the end of its guard
+    GemvResidPre pre{f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, false};
+    if constexpr (EPI == GEMV_RESID_F32 && NT * MG <= WAVES) {
+        if (wave < NT * MG && p.xg_w != nullptr) {   // (wave-uniform)
+            const int ft = wave % NT, fq = wave / NT;
+            const int nt = min(nt0 + ft, ntiles - 1), mrow = ovalid[fq] ? m + 16 * fq : 0;
+            const int n = nt * 16 + g * 4;
+            pre.o = ld16f(reinterpret_cast<const float*>(p.out) + (size_t)mrow * p.ldo + n);
+            pre.gw = ld16f(p.xg_w + n);
+            pre.have = true;
+        }
+    }
     __syncthreads();  // every wave is done with its ring before `red` overwrites it
     float* red = reinterpret_cast<float*>(ring);  // [WAVES][NT][MG][64][4]
 #pragma unroll
@@ -158,7 +178,7 @@ VC_DEV void gemv_ring_finish(const GemvArgs& p, f32x4 (&acc)[NT][MG], char* ring
         }
         if (lane == 0) st_agent_u32(&p.sk_counters[unit], 0u);  // re-armed for the next launch (stream order)
     }
-    gemv_epilogue<WAVES, EPI, FP8, 16 * MG>(p, v, ss_part, nt, m + 16 * fq, g, ovalid[fq]);
+    gemv_epilogue<WAVES, EPI, FP8, 16 * MG>(p, v, ss_part, nt, m + 16 * fq, g, ovalid[fq], &pre);
     }
 }
 

@@ -140,7 +140,7 @@ class HipEngine:
         the reference's own checkpoints, which keep weight lo planes (inexact_tensors() > 0)."""
         for key, shape, off, hw in synth.tensor_specs(self.cfg):
             sh = (C.c_int64 * len(shape))(*shape)
-            rounding = 0 if dtypes == "bf16" else synth.ROUNDING_CODE[synth.reference_rounding(key)]
+            rounding = 0 if dtypes == "bf16" else synth.ROUNDING_CODE[synth.reference_rounding(key, dtypes)]
             self._check(self.lib.vc_model_synth_tensor_rounded(self._model, key.encode(), sh, len(shape),
                                                                C.c_uint32(synth.tensor_seed(key, seed)), C.c_float(off),
                                                                C.c_float(hw), rounding))

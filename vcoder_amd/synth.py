@@ -191,8 +191,16 @@ def projector_depth(ptype: str) -> int:
 ROUNDING_CODE = {"bf16": 0, "fp16": 1, "fp32": 2}   # vc_model_synth_tensor_rounded / vck_synth_f32_rounded
 
 
-def reference_rounding(key: str) -> str:
-    """the value class a tensor has in the reference's own checkpoints: the CLIP tower fp32 (hub checkpoint), everything else fp16"""
+REFERENCE_CLASSES = ("reference", "reference_loaded")
+
+
+def reference_rounding(key: str, dtypes: str = "reference") -> str:
+    """the value class of a tensor in the reference's own checkpoints.  "reference": as the files hold them — the CLIP tower fp32 (hub
+    checkpoint), everything else fp16.  "reference_loaded": as the reference COMPUTES with them — model/builder.py:142 casts the
+    loaded tower to fp16 (`vision_tower.to(device=device, dtype=torch.float16)`), so every tensor is fp16-valued (and a bf16 hi + lo
+    pair holds each of them exactly)."""
+    if dtypes == "reference_loaded":
+        return "fp16"
     return "fp32" if "vision_tower" in key else "fp16"
 
 
@@ -201,12 +209,14 @@ def synth_state_dict(cfg, seed: int = 42, only_prefix: str | None = None, dtypes
     dtypes="reference": the value classes of the reference's own checkpoints — the LLM, its head, embeddings and the projectors
     fp16-valued (model/builder.py:25-40 loads them with torch_dtype=float16), the CLIP tower fp32-valued (the hub checkpoint,
     multimodal_encoder/clip_encoder.py:22-27) — which bf16 cannot hold: vc_model_inexact_tensors() > 0, and the strict / split
-    precision modes must add the lo planes back to stay within 1e-3 of an fp32 oracle run on THESE values."""
+    precision modes must add the lo planes back to stay within 1e-3 of an fp32 oracle run on THESE values.
+    dtypes="reference_loaded": the values the reference computes with — the tower fp16-valued too (model/builder.py:142)."""
+    assert dtypes in ("bf16",) + REFERENCE_CLASSES, dtypes
     out = {}
     for key, shape, off, hw in tensor_specs(cfg):
         if only_prefix is not None and not key.startswith(only_prefix):
             continue
-        rounding = reference_rounding(key) if dtypes == "reference" else "bf16"
+        rounding = reference_rounding(key, dtypes) if dtypes in REFERENCE_CLASSES else "bf16"
         out[key] = synth_tensor(key, shape, seed, off, hw, rounding)
     return out
 
