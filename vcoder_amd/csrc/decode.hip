@@ -421,9 +421,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_dma_kernel(GemvArgs p) {
 // WL (an inexact checkpoint: w = bf16 hi + bf16 lo, GemvArgs::Wp_lo): the slot also carries the lo plane's blocks of the line, and
 // every lo fragment feeds one more MFMA against the activation HI plane — x.w = x_hi.w_hi + x_lo.w_hi + x_hi.w_lo, the prefill GEMM's
 // third K segment (gemm.hip w_koff); twice the weight bytes per step.
-template <int NTW, int XP, int KH, int CL, int R, int EPI, bool WL = false>
-__global__ __launch_bounds__(256) void gemv_wg_kernel(GemvArgs p) {
-    constexpr int WAVES = 4;
+template <int NTW, int XP, int KH, int CL, int R, int EPI, bool WL = false, int WAVES = 4>
+__global__ __launch_bounds__(WAVES * 64) void gemv_wg_kernel(GemvArgs p) {
     constexpr int MG = (XP + 1) / 2;          // MFMA row groups of 16 token rows
     constexpr int P = XP * KH;                // 1-KiB activation pieces (8 rows x 128 B) per line
     constexpr int WO = 2 * NTW * (WL ? 2 : 1);   // weight DMA instructions per line (2 k-tiles x NTW tiles [x hi, lo planes])
@@ -536,13 +535,13 @@ __global__ __launch_bounds__(256) void gemv_wg_kernel(GemvArgs p) {
         for (int q = 0; q < MG; ++q) {
             const float* sp = p.ssq_in + (size_t)(ovalid[q] ? m + 16 * q : 0) * p.npart;
 #pragma unroll
-            for (int j = 0; j < SQ; ++j) sq[q][j] = ld16f(sp + min(wave * 4 + g + j * 16, nq - 1) * 4);
+            for (int j = 0; j < SQ; ++j) sq[q][j] = ld16f(sp + min(wave * 4 + g + j * WAVES * 4, nq - 1) * 4);
         }
 #pragma unroll
         for (int q = 0; q < MG; ++q)
 #pragma unroll
             for (int j = 0; j < SQ; ++j)
-                if (wave * 4 + g + j * 16 >= nq) sq[q][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (wave * 4 + g + j * WAVES * 4 >= nq) sq[q][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < MG; ++q) {
             float s0 = 0.f, s1 = 0.f;
@@ -763,21 +762,21 @@ static int wg_kslices(int ntiles, int K) {
     return ks;
 }
 
-template <int XP, int CL, int R, bool WL>
+template <int XP, int CL, int R, bool WL, int WAVES = 4>
 static void launch_gemv_wg_e(const GemvArgs& a, int epi, hipStream_t s) {
     constexpr int NTW = 1, KH = 2;
-    const int groups = (a.N / 16 + 4 * NTW - 1) / (4 * NTW);
-    const dim3 grid((unsigned)(groups * (a.ksplit > 1 ? a.ksplit : 1))), block(256);
-    constexpr size_t shmem = (size_t)(2 * CL * XP * KH + 4 * R * 2 * NTW * (WL ? 2 : 1)) * 1024;
-    static_assert(shmem + 4 * 16 * ((XP + 1) / 2) * 4 <= 160 * 1024, "exceeds the LDS of a CU");
+    const int groups = (a.N / 16 + WAVES * NTW - 1) / (WAVES * NTW);
+    const dim3 grid((unsigned)(groups * (a.ksplit > 1 ? a.ksplit : 1))), block(WAVES * 64);
+    constexpr size_t shmem = (size_t)(2 * CL * XP * KH + WAVES * R * 2 * NTW * (WL ? 2 : 1)) * 1024;
+    static_assert(shmem + WAVES * 16 * ((XP + 1) / 2) * 4 <= 160 * 1024, "exceeds the LDS of a CU");
 #define VC_GEMV_WG(E)                                                                                                   \
     do {                                                                                                                \
         static bool once = false;                                                                                       \
         if (!once) {                                                                                                    \
-            allow_big_lds(gemv_wg_kernel<NTW, XP, KH, CL, R, E, WL>, shmem);                                            \
+            allow_big_lds(gemv_wg_kernel<NTW, XP, KH, CL, R, E, WL, WAVES>, shmem);                                     \
             once = true;                                                                                                \
         }                                                                                                               \
-        VC_LAUNCH((gemv_wg_kernel<NTW, XP, KH, CL, R, E, WL>), grid, block, shmem, s, a);                               \
+        VC_LAUNCH((gemv_wg_kernel<NTW, XP, KH, CL, R, E, WL, WAVES>), grid, block, shmem, s, a);                        \
     } while (0)
     switch (epi) {
         case GEMV_BF16: VC_GEMV_WG(GEMV_BF16); break;
@@ -807,6 +806,17 @@ static bool gemv_wg_applies(const GemvArgs& a) {
     return a.split_rows >= a.M && a.split_rows <= 32 && a.split_rows % 8 == 0;
 }
 
+// Waves (= tiles) per workgroup: 4, or 6 where that lowers the tile count of the BUSIEST CU — round 6: with four tiles per workgroup
+// 7b gate / up is 344 workgroups (88 CUs hold two, 168 one: the launch lasts 8 tiles on a CU for 5.4 on average) and qkv 192 x 2
+// K-slices = 384 (half the CUs hold two); with six they are 230 and 256 workgroups, one per CU.  A function of the matrix alone
+// (the K-slices are wg_kslices's, whatever the choice: the sums keep their order; only the rstd partials are added per wave).
+// set_gemv_variant(2) keeps 4 everywhere (A/B).
+static int wg_waves(int ntiles, int ks) {
+    if (g_gemv_variant == 2) return 4;
+    auto busiest = [&](int w) { return (((ntiles + w - 1) / w) * ks + 255) / 256 * w; };   // tiles (x 1 / ks of K) of the busiest CU
+    return busiest(6) < busiest(4) ? 6 : 4;
+}
+
 static void launch_gemv_wg(const GemvArgs& a0, int epi, hipStream_t s) {
     GemvArgs a = a0;
     const int ntiles = a.N / 16;
@@ -819,8 +829,29 @@ static void launch_gemv_wg(const GemvArgs& a0, int epi, hipStream_t s) {
     g_gemv_wg_launches.fetch_add(1, std::memory_order_relaxed);
     // chunk length / ring depth by the activation pieces per line, so that two workgroups fit a CU (<= 72 KiB each); with the
     // weight's lo plane (an inexact checkpoint) the slots are twice as large: one workgroup per CU (80 - 96 KiB)
+    const int xp = (a.M + 7) / 8;
+    if (wg_waves(ntiles, ks) == 6) {
+        // six tiles per workgroup where that spreads the launch evenly (7b qkv: 128 groups x 2 K-slices = 256 workgroups; gate / up:
+        // 230; 13b o / down: 54 x 4 = 216): ONE workgroup per CU, so the ring can be deeper (R = 6; 4 with the lo plane's blocks)
+        if (a.Wp_lo != nullptr) {
+            switch (xp) {
+                case 1: launch_gemv_wg_e<1, 3, 4, true, 6>(a, epi, s); break;
+                case 2: launch_gemv_wg_e<2, 3, 4, true, 6>(a, epi, s); break;
+                case 3: launch_gemv_wg_e<3, 2, 4, true, 6>(a, epi, s); break;
+                default: launch_gemv_wg_e<4, 3, 4, true, 6>(a, epi, s); break;
+            }
+            return;
+        }
+        switch (xp) {
+            case 1: launch_gemv_wg_e<1, 3, 6, false, 6>(a, epi, s); break;
+            case 2: launch_gemv_wg_e<2, 3, 6, false, 6>(a, epi, s); break;
+            case 3: launch_gemv_wg_e<3, 2, 6, false, 6>(a, epi, s); break;
+            default: launch_gemv_wg_e<4, 3, 6, false, 6>(a, epi, s); break;
+        }
+        return;
+    }
     if (a.Wp_lo != nullptr) {
-        switch ((a.M + 7) / 8) {
+        switch (xp) {
             case 1: launch_gemv_wg_e<1, 4, 4, true>(a, epi, s); break;
             case 2: launch_gemv_wg_e<2, 4, 4, true>(a, epi, s); break;
             case 3: launch_gemv_wg_e<3, 2, 4, true>(a, epi, s); break;
@@ -828,7 +859,7 @@ static void launch_gemv_wg(const GemvArgs& a0, int epi, hipStream_t s) {
         }
         return;
     }
-    switch ((a.M + 7) / 8) {
+    switch (xp) {
         case 1: launch_gemv_wg_e<1, 4, 4, false>(a, epi, s); break;
         case 2: launch_gemv_wg_e<2, 4, 4, false>(a, epi, s); break;
         case 3: launch_gemv_wg_e<3, 2, 4, false>(a, epi, s); break;
