@@ -65,6 +65,8 @@ def parse_args():
                     help="pool policy A/B: step whatever rows are active even while another call is prefilling (vc_pool_set_hold(0))")
     ap.add_argument("--no-qkv-fused", action="store_true",
                     help="A/B: the prefill's QKV projection as the separate GEMM + split / RoPE launches of rounds 1-5 (vc_model_set_qkv_fused(0))")
+    ap.add_argument("--gemv-variant", type=int, default=None,
+                    help="A/B: vck_set_gemv_variant — 2 = four waves per workgroup in the split step's GEMV everywhere (rounds 4-5), default = the launcher's choice")
     ap.add_argument("--no-insitu", action="store_true",
                     help="do not stamp the pool's decode-step launches (roofline then reports the isolated replay); A/B of the stamps' cost")
     ap.add_argument("--no-extra-legs", action="store_true",
@@ -486,6 +488,9 @@ def main():
         eng.pool_set_hold(False)
     if args.no_qkv_fused:
         eng.set_qkv_fused(0)
+    if args.gemv_variant is not None:
+        from vcoder_amd import _lib as _vlib
+        _vlib.load().vck_set_gemv_variant(int(args.gemv_variant))
     sessions = [eng] + [eng.fork() for _ in range(n_sess - 1)]
 
     def run_steps(k: int, px):

@@ -156,7 +156,8 @@ void vck_gemv_split_wlo(const uint16_t* X, const void* Wp, const void* Wp_lo, vo
                         const float* xg_w, uint16_t* xg_out, int npart, float eps, float* sk_scratch, unsigned long long sk_scratch_floats,
                         unsigned* sk_counters, int sk_counters_n, int ksplit, int M, int N, int K, int ldo, int epi, int G, void* stream);
 /* which kernel serves the decode GEMV of precision mode "split": 0 = per-wave rings (gemv_dma_kernel; two weight passes of 16
- * rows per 32-row step), 1 / -1 (default) = workgroup-shared activation chunks (gemv_wg_kernel; hi + lo planes in one pass) */
+ * rows per 32-row step), 1 / -1 (default) = workgroup-shared activation chunks (gemv_wg_kernel; hi + lo planes in one pass) with
+ * four or six tiles per workgroup as the launcher chooses per matrix; 2 = four everywhere (A/B), 3 = six everywhere (tests) */
 void vck_set_gemv_variant(int v);
 /* K12 + K13 + K14 in one launch (round 6): the fused-QKV projection of a prefill layer whose epilogue applies RoPE, splits the heads
  * and writes Q [B,H,q_stride,128], roped K rows and V rows [B,H,kv_stride,128] (and / or their e4m3 cache rows k8 / v8

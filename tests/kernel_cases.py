@@ -1506,6 +1506,32 @@ def check_gemv_wg_rows_agree(be, N, K, epi, norm=True, G=True, ksplit=0, seed=0)
         be.lib.vck_set_gemv_variant(-1)
 
 
+def check_gemv_wg_six_waves(be, N, K, epi, rows, norm, ksplit=0, seed=0):
+    """gemv_wg_kernel with SIX waves (= tiles) per workgroup (round 6: the geometry of the matrices whose four-wave launch leaves CUs
+    with twice the tiles of others; vck_set_gemv_variant(3) forces it on any matrix, 2 forces four): the K-slices and the order
+    of every sum are the four-wave geometry's, so without the folded RMSNorm the BITS are equal; with it only the rstd partials
+    are added per wave (6 shares instead of 4): rstd moves by an fp32 ulp, a hi + lo output by up to 2^-17 — within tolerance of
+    float64 either way"""
+    try:
+        rng = np.random.RandomState(seed)
+        c = _wg_case(be, rng, 32, N, K, epi, norm, 32)
+        for M in rows:
+            G = 8 if M <= 8 else 16 if M <= 16 else 24 if M <= 24 else 32
+            be.lib.vck_set_gemv_variant(2)
+            v4, raw4, ex4 = _wg_run(be, c, M, G, ksplit)
+            be.lib.vck_set_gemv_variant(3)
+            v6, raw6, ex6 = _wg_run(be, c, M, G, ksplit)
+            e = rel_err(v6, c["ref"][:M])
+            assert e < 3e-5, f"gemv_wg six waves M{M} N{N} K{K} epi{epi} ks{ksplit}: rel err {e}"
+            if not norm:
+                for a, b in zip(raw4, raw6):
+                    assert np.array_equal(a, b), f"M{M} N{N} K{K} epi{epi} ks{ksplit}: six waves per workgroup changed the bits"
+            else:
+                assert rel_err(v6, v4) < 3e-5   # (the float64 tolerance: bf16-valued outputs are hi + lo pairs, ~2^-17 each)
+    finally:
+        be.lib.vck_set_gemv_variant(-1)
+
+
 def check_gemv_wide(be, N, K, epi, rows, norm=True, seed=0):
     """the "wide" geometry of the ring kernel (vck_set_gemv_wide: ceil(tiles / 256) tiles per 4-wave workgroup, deep ring; on by
     default for the classes that measured faster, 2 = every class): bit for bit the pair geometry's result at every row count

@@ -307,7 +307,10 @@ def test_inexact_checkpoint_true_dims(dtypes):
     eng16.load_state_dict(sd)
     eng16.finalize()
     n_tower = sum(1 for k, v in sd.items() if "vision_tower" in k and np.asarray(v).ndim >= 2)
-    assert 0 < eng16.inexact_tensors() <= n_tower, (eng16.inexact_tensors(), n_tower)
+    if dtypes == "reference":
+        assert 0 < eng16.inexact_tensors() <= n_tower, (eng16.inexact_tensors(), n_tower)
+    else:   # the tower as the reference casts it: the whole checkpoint is fp16-valued and this library holds it exactly
+        assert eng16.inexact_tensors() == 0
     h_last, _, _ = eng16.prefill(ids, imgs, segs, deps)
     h_lg2, _ = eng16.decode_step(tok)
     eh, eh2 = np.abs(h_last - o_last[:, -1].numpy()).max(), np.abs(h_lg2 - o_lg2[:, -1].numpy()).max()

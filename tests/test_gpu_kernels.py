@@ -299,6 +299,14 @@ def test_weight_lo_plane_kernels(be):
         kc.check_gemv_split_wlo(be, M, N, K, epi, G, ks)
 
 
+@pytest.mark.parametrize("N,K,epi,norm,rows", [(12288, 4096, 1, False, (8, 29)), (22016, 4096, 3, False, (8, 32)), (5120, 13824, 2, False, (16, 32)),
+                                               (22016, 4096, 3, True, (13, 32))])
+def test_gemv_wg_six_waves_per_workgroup(be, N, K, epi, norm, rows):
+    """the balanced geometry of the split step's GEMV (six tiles per workgroup: 7b qkv 256 workgroups, gate / up 230, 13b down 216)
+    against the four-wave geometry at the true shapes: equal bits without the folded norm, the float64 tolerance with it"""
+    kc.check_gemv_wg_six_waves(be, N, K, epi, rows, norm)
+
+
 def test_gemv_wg_is_race_free_and_bit_reproducible(be):
     """hand-placed counted vmcnt waits + one bare barrier per chunk: back-to-back launches must all give the first launch's bits"""
     import numpy as np

@@ -237,6 +237,22 @@ def test_gemv_wide_geometry(be, N, K, epi, norm, rows):
     kc.check_gemv_wide(be, N, K, epi, rows, norm)
 
 
+@pytest.mark.parametrize("N,K,epi,norm,rows,ks", [(16 * 13, 576, 0, False, (5, 16, 19, 32), 0), (16 * 13, 576, 2, False, (8, 29), 2),
+                                                  (16 * 7, 1024, 1, False, (13, 32), 4), (16 * 12, 320, 3, False, (8, 24), 0),
+                                                  (16 * 13, 576, 2, True, (8, 32), 3), (16 * 6, 256, 0, True, (16, 17), 0)])
+def test_gemv_wg_six_waves_per_workgroup(be, N, K, epi, norm, rows, ks):
+    """six tiles per workgroup (the balanced geometry of 7b qkv / gate-up and 13b o / down in precision mode split): the four-wave
+    geometry's bits without the folded norm, its values within the float64 tolerance with it; ragged last workgroup, K-slices, every epilogue"""
+    kc.check_gemv_wg_six_waves(be, N, K, epi, rows, norm, ks)
+
+
+def test_gemv_wg_chooses_six_waves_for_unbalanced_launches(be):
+    """1376 tiles (7b gate / up): 344 four-wave workgroups would leave 88 CUs with two — the launcher takes six waves (230
+    workgroups); the result against float64 as for every other geometry"""
+    kc.check_gemv_wg(be, 29, 16 * 1376, 128, 3, True, 32, 0)
+    kc.check_gemv_wg(be, 8, 16 * 1376, 128, 3, False, 8, 0, seed=1)
+
+
 @pytest.mark.parametrize("N,K,epi,G,ks", [(64, 512, 0, True, 0), (48, 1024, 1, True, 4), (64, 256, 3, True, 0), (32, 512, 2, True, 2)])
 def test_gemv_wg_rows_agree(be, N, K, epi, G, ks):
     kc.check_gemv_wg_rows_agree(be, N, K, epi, True, G, ks)

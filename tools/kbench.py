@@ -200,6 +200,47 @@ def bench_gemv_rows():
         print(f"gemv_rows M{M:2d} all GEMVs of a 7b decode step: {tot / 1e3:6.3f} ms = {tot / 1e3 / M:6.4f} ms per row", flush=True)
 
 
+def bench_gemv_wg():
+    """the GEMV of precision mode "split" (gemv_wg_kernel: hi / lo activation rows in one weight pass) at the 7b shapes, 8 and 32 rows:
+    four waves per workgroup everywhere (vck_set_gemv_variant(2), rounds 4-5) against the launcher's choice (six where that balances
+    the launch: qkv, gate / up)"""
+    lib.vck_gemv_full.restype = None
+    for M, G in ((8, 8), (32, 32)):
+        tot = {2: 0.0, -1: 0.0}
+        for (N, K, epi, name, cnt) in [(12288, 4096, 1, "qkv", 32), (4096, 4096, 2, "o", 32), (22016, 4096, 3, "gate-up", 32),
+                                       (4096, 11008, 2, "down", 32), (32000, 4096, 1, "lm_head", 1)]:
+            X = bf16(2 * G, K)
+            Ws = [bf16(N * K, scale=0.02) for _ in range(8)]
+            rows_out = 2 * G if epi == 3 else 32
+            out = torch.zeros((max(rows_out, 32), N), dtype=torch.float32 if epi in (1, 2) else torch.bfloat16, device=dev)
+            ldo = N // 2 if epi == 3 else N
+            npart = (max(K, N) // 16 + 15) // 16 * 16
+            ssq = torch.rand(32, npart, device=dev)
+            ssq_out = torch.zeros(32, npart, device=dev)
+            gw = torch.rand(N, device=dev) + 0.5
+            xg = torch.zeros((2 * G, N), dtype=torch.bfloat16, device=dev)
+            nsk = 4 * (N // 16) * 2 * 256
+            scratch = torch.zeros(nsk, device=dev)
+            counters = torch.zeros(N // 16 * 2, dtype=torch.int32, device=dev)
+            row = []
+            for v in (2, -1):
+                lib.vck_set_gemv_variant(v)
+                it = [0]
+
+                def f():
+                    it[0] += 1
+                    prod = epi == 2
+                    lib.vck_gemv_full(P(X), P(Ws[it[0] % 8]), None, P(out), None if prod else P(ssq), P(ssq_out) if prod else None,
+                                      P(gw) if prod else None, P(xg) if prod else None, C.c_int(npart), C.c_float(1e-5), P(scratch),
+                                      C.c_ulonglong(nsk), P(counters), C.c_int(N // 16 * 2), C.c_int(0), M, N, K, ldo, epi, G, None)
+                us = timeit(f, iters=60)
+                tot[v] += us * cnt
+                row.append(f"{'4 waves' if v == 2 else 'chosen '} {us:6.2f} us {2 * N * K / us / 1e3:6.0f} GB/s")
+            print(f"gemv_wg M{M:2d} {name:8s} N{N} K{K}: " + " | ".join(row), flush=True)
+        print(f"gemv_wg M{M:2d} all GEMVs of a 7b split step: 4 waves {tot[2] / 1e3:6.3f} ms | chosen {tot[-1] / 1e3:6.3f} ms", flush=True)
+    lib.vck_set_gemv_variant(-1)
+
+
 def bench_gemv_wide():
     """ring-kernel GEMV, pair geometry (vck_set_gemv_wide 0) vs the "wide" one (2: ceil(tiles / 256) tiles per workgroup, one deep
     ring per CU, every class) on every > 512-tile matrix of the 7b and 13b models at 8 / 16 / 24 / 32 rows; same bits?"""
@@ -491,6 +532,6 @@ if __name__ == "__main__":
     table = {"gemm_qkv": bench_gemm_qkv, "gemm32": bench_gemm32, "gemm": bench_gemm, "gemv": bench_gemv, "attn": bench_attn, "dattn": bench_dattn, "gemv_fp8": bench_gemv_fp8,
              "gemv13": bench_gemv13, "gemv_pair": bench_gemv_pair, "gemv_rows": bench_gemv_rows, "dattn_rows": bench_dattn_rows,
              "gemm_f8": bench_gemm_f8, "gemv_rows8": bench_gemv_rows8, "gemv_wide": bench_gemv_wide, "gemm_chunk": bench_gemm_chunk,
-             "dattn_split": bench_dattn_split, "dattn_kv8": bench_dattn_kv8}
+             "dattn_split": bench_dattn_split, "dattn_kv8": bench_dattn_kv8, "gemv_wg": bench_gemv_wg}
     for w in what:
         table[w]()

@@ -810,9 +810,10 @@ static bool gemv_wg_applies(const GemvArgs& a) {
 // 7b gate / up is 344 workgroups (88 CUs hold two, 168 one: the launch lasts 8 tiles on a CU for 5.4 on average) and qkv 192 x 2
 // K-slices = 384 (half the CUs hold two); with six they are 230 and 256 workgroups, one per CU.  A function of the matrix alone
 // (the K-slices are wg_kslices's, whatever the choice: the sums keep their order; only the rstd partials are added per wave).
-// set_gemv_variant(2) keeps 4 everywhere (A/B).
+// set_gemv_variant(2) keeps 4 everywhere (A/B), 3 takes 6 everywhere (tests).
 static int wg_waves(int ntiles, int ks) {
     if (g_gemv_variant == 2) return 4;
+    if (g_gemv_variant == 3) return 6;   // (tests: the six-wave geometry on matrices too small to choose it)
     auto busiest = [&](int w) { return (((ntiles + w - 1) / w) * ks + 255) / 256 * w; };   // tiles (x 1 / ks of K) of the busiest CU
     return busiest(6) < busiest(4) ? 6 : 4;
 }
