@@ -252,11 +252,13 @@ REL_TOL_VS_FP32_INEXACT = 6.0e-2   # the same path on an fp16- / fp32-valued che
 def test_full_size_7b_c2():
     """BASELINE configs[1] AS WRITTEN: VCoder-DS 7b, all 32 decoder + 23 ViT layers, the C2 prompt, B = 8, 128 greedy tokens —
     lone call, 4 concurrent calls through the decode pool (what bench.py's `value` measures), split mode, strict mode; fp32
-    oracle teacher-forced on rows {0, 7} with the split ids AND on row 0 with the bf16 path's own ids: the benchmarked kernels are
-    compared with the oracle DIRECTLY at full size (round 4 compared them with the device's split path to save the third oracle
-    row; the 13b case still does)."""
+    oracle teacher-forced on row 7 (the last of the batch) with the split ids AND with the bf16 path's own ids: the benchmarked
+    kernels are compared with the oracle DIRECTLY at full size (round 4 compared them with the device's split path to save an oracle
+    row; the 13b case still does).  (Rounds 3-6 also forced row 0 with the split ids: a third sample of the one batched oracle pass,
+    ~20 s of the suite's budget on the box's 16 host CPUs — dropped at the end of round 6; rows 0 of the batch are what the fixtures,
+    the true-dims cases and the full-depth inexact case run.)"""
     cfg = vcfg.vicuna_7b("vcoder_ds")
-    r = run_case(cfg, B=8, n_new=128, seed=42, oracle_rows=(0, 7), checkpoints=(2, 8, 16, 32), strict_tokens=8, fast_vs="oracle")
+    r = run_case(cfg, B=8, n_new=128, seed=42, oracle_rows=(7,), checkpoints=(2, 8, 16, 32), strict_tokens=8, fast_vs="oracle")
     assert r["err32"].max() < REL_TOL_VS_FP32 * max(1.0, r["scale"])
     assert r["e_split"] < 1e-3
 
