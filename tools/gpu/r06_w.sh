@@ -3,7 +3,7 @@
 # FETCH_SIZE of the 8-phase GEMM at the engine's shapes (review item 2: last measured in round 3)
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_fulldepth.py -q -m gpu -s -k "full_size_7b_c2" 2>&1 | grep -v "^$" | tail -22 | cut -c1-250 | tee gpurun_out/r06_w_pytest_full_size_7b.txt
+true
 export TMPDIR=/tmp; cd /tmp
 timeout 400 rocprofv3 --pmc FETCH_SIZE -d $GRAFT_REPO_ROOT/gpurun_out/r06_w_pmc -o pmc -- python $GRAFT_REPO_ROOT/tools/kbench.py gemm > $GRAFT_REPO_ROOT/gpurun_out/r06_w_pmc_kbench_gemm.txt 2> $GRAFT_REPO_ROOT/gpurun_out/r06_w_pmc.err
 cd $GRAFT_REPO_ROOT

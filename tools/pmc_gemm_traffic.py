@@ -27,16 +27,27 @@ for k, g, cn, v in rows:
     a = agg.setdefault((int(m.group(1)), int(g)), [0, 0.0])
     a[0] += 1
     a[1] += float(v)
-lines = ["| shape (M x N x K, epilogue) | grid (workgroups) | FETCH_SIZE x 2 per launch | compulsory A + W (+ residual) | ratio |", "|---|---|---|---|---|"]
+lines = ["| shape (M x N x K, epilogue) | grid (workgroups) | FETCH_SIZE x 2 per launch | compulsory A + W (+ residual) | ratio | with perfect sharing inside each XCD's 4 x 8 tile block | ratio |",
+         "|---|---|---|---|---|---|---|"]
 for (M, N, K, epi, name) in SHAPES:
     t256 = ((M + 255) // 256) * ((N + 255) // 256)
     comp = 2.0 * M * K + 2.0 * N * K + (4.0 * M * N if epi == 4 else 0.0)
+    # the two launch forms of kbench: t256 workgroups, and (csrc/gemm.hip launch_gemm) the split-K remainder round when the last
+    # round holds at most 128 tiles: its rem tiles as ks = min(256 / rem, 8, K / 64) K-slices each
+    rem = t256 % 256
+    ks = min(256 // rem, 8, int(K) // 64) if (t256 > 256 and 0 < rem <= 128) else 1
+    grids = {t256: ""}
+    if ks > 1:
+        grids[t256 - rem + rem * ks] = f" (split-K round: {rem} tiles x {ks})"
+    # the XCD-partitioned L2: an XCD works on a block of gm x gn = 4 x 8 tiles at a time (tile_group = 4 m-tiles sweep n), so even
+    # with perfect sharing inside the XCD every tile costs A_panel / gn + W_panel / gm behind the L2
+    per_xcd = t256 * (2.0 * 256 * K / 8 + 2.0 * 256 * K / 4) + (4.0 * M * N if epi == 4 else 0.0)
     for (e, g), (n, kib) in sorted(agg.items()):
         wgs = g // 512
-        if e != epi or wgs < t256 or wgs > t256 + 1024:
+        if e != epi or wgs not in grids:
             continue
         b = 2.0 * 1024.0 * kib / n
-        lines.append(f"| {name} {M} x {N} x {K}, epi {epi} | {wgs}{' (split-K round)' if wgs != t256 else ''} | {b / 1e6:.0f} MB | {comp / 1e6:.0f} MB | {b / comp:.2f} |")
+        lines.append(f"| {name} {M} x {N} x {K:g}, epi {epi} | {wgs}{grids[wgs]} | {b / 1e6:.0f} MB | {comp / 1e6:.0f} MB | {b / comp:.2f} | {per_xcd / 1e6:.0f} MB | {b / per_xcd:.2f} |")
 out = "\n".join(lines)
 print(out)
 if len(sys.argv) > 2:
