@@ -1,4 +1,5 @@
 #!/bin/bash
+# (RECORD of a call on commit 6135b14: gemv_xr_kernel, kbench gemv_xr and bench.py --gemv-xr were removed again afterwards — DESIGN.md 9.13)
 # round 6, call O: gemv_xr_kernel — the ring kernel of o_proj / down with the activation fragments in VGPRs (count-waited asm loads) and
 # weights alone in the LDS ring.  Parity first (bit-equal to the LDS-operand form), kbench by ring depth, then the bench A/B on one box.
 cd "$GRAFT_REPO_ROOT" || exit 1

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (RECORD: the two-wave experiment and kbench gemv_wg2 existed only in the working tree of this call — DESIGN.md 4.2c)
 # round 6, call T: the failing reference_loaded case with its traceback; kbench of the two-wave x two-slice experiment for o_proj / down (split)
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
