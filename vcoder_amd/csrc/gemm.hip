@@ -61,8 +61,10 @@ VC_DEV f32x4 bf4_residual(f32x4 v, u32x2 hi) {
 // MFMA accumulator layout (lanes l, l ^ 16, l ^ 32, l ^ 48 = the 16 columns of one token)
 // (the consumer side of the folded RMSNorm — GemmArgs::row_scale — is applied by the callers, which hold a row's scale in a
 // register across the columns they store)
+// `resid` (EPI_RESID_F32): the residual values out[m][n..n+3] when the caller requested them ahead of time (the 8-phase kernel's
+// epilogue: a load inside the caller's bounds guard is waited for with vmcnt(0) at the end of the guard, one round trip per store)
 template <int EPI, bool FIX = false>
-VC_DEV void store_out(const GemmArgs& p, int m, int n, f32x4 v) {
+VC_DEV void store_out(const GemmArgs& p, int m, int n, f32x4 v, const f32x4* resid = nullptr, const f32x4* xgw = nullptr) {
     if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_QGELU || EPI == EPI_BF16_GELU) {
         if constexpr (EPI == EPI_BF16_QGELU) {
 #pragma unroll
@@ -80,10 +82,10 @@ VC_DEV void store_out(const GemmArgs& p, int m, int n, f32x4 v) {
         st16f(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n, v);
     } else if constexpr (EPI == EPI_RESID_F32) {
         float* o = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n;
-        v = ld16f(o) + v;
+        v = (resid != nullptr ? *resid : ld16f(o)) + v;
         st16f(o, v);
         if (p.xg_out) {   // folded RMSNorm, producer side: the next GEMM's operand and the row's sum-of-squares partial
-            const f32x4 t = v * ld16f(p.xg_w + n);
+            const f32x4 t = v * (xgw != nullptr ? *xgw : ld16f(p.xg_w + n));
             const u32x2 hi = pack_bf4(t);
             bf16_t* d = p.xg_out + (size_t)m * p.ld_xg + n;
             st8(d, hi);
@@ -133,9 +135,9 @@ VC_DEV int qkv_arow(const QkvEpiArgs& e, int mp) {
 // 4 rotate-half pairs (x = d0 + i, y = d0 + 64 + i) of token (b, t), head `head`: the projection is rounded to bf16 first (the value
 // the unfused path stores in its fused rows), RoPE in fp32 on the rounded values (rope_pair, the split kernel's own function), rounded
 // again; which = 0: Q rows, 1: K rows (+ the e4m3 cache row)
-VC_DEV void qkv_rope_store(const QkvEpiArgs& e, int which, int head, int b, int t, int dl, f32x4 x, f32x4 y) {
+// cs / sn: rope_cos / rope_sin [t][dl .. dl + 3] (the GEMM's epilogue requests them ahead of its bounds guards)
+VC_DEV void qkv_rope_store(const QkvEpiArgs& e, int which, int head, int b, int t, int dl, f32x4 x, f32x4 y, f32x4 cs, f32x4 sn) {
     const u32x2 xb = pack_bf4(x), yb = pack_bf4(y);
-    const f32x4 cs = ld16f(e.rope_cos + (size_t)t * 64 + dl), sn = ld16f(e.rope_sin + (size_t)t * 64 + dl);
     u32x2 olo, ohi;
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2) {
@@ -156,6 +158,9 @@ VC_DEV void qkv_rope_store(const QkvEpiArgs& e, int which, int head, int b, int 
         *reinterpret_cast<uint32_t*>(d8 + dl) = f32x4_to_fp8x4(bf2f_lo(olo[0]), bf2f_hi(olo[0]), bf2f_lo(olo[1]), bf2f_hi(olo[1]));
         *reinterpret_cast<uint32_t*>(d8 + 64 + dl) = f32x4_to_fp8x4(bf2f_lo(ohi[0]), bf2f_hi(ohi[0]), bf2f_lo(ohi[1]), bf2f_hi(ohi[1]));
     }
+}
+VC_DEV void qkv_rope_store(const QkvEpiArgs& e, int which, int head, int b, int t, int dl, f32x4 x, f32x4 y) {
+    qkv_rope_store(e, which, head, b, t, dl, x, y, ld16f(e.rope_cos + (size_t)t * 64 + dl), ld16f(e.rope_sin + (size_t)t * 64 + dl));
 }
 // 4 value features d0 .. d0 + 3 of token (b, t) into the cache row(s)
 VC_DEV void qkv_v_store(const QkvEpiArgs& e, int head, int b, int t, int d0, u32x2 vb) {
@@ -637,13 +642,38 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
                     swx = ld16f(p.w_scale + nx);
                     swy = ld16f(p.w_scale + nx + 64);
                 }
+                // the cos / sin rows of the lane's four tokens: requested together at a clamped token and waited for OUTSIDE the
+                // guards (round 6, as the RESID epilogue below: inside the guard every store paid its own table round trip and the
+                // drain of the stores before it)
+                f32x4 csv[2][2], snv[2][2];
+#pragma unroll
+                for (int hy = 0; hy < 2; ++hy)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const size_t tc = (size_t)min(tt[hy][j], e.T - 1) * 64 + dl;
+                        csv[hy][j] = ld16f(e.rope_cos + tc);
+                        snv[hy][j] = ld16f(e.rope_sin + tc);
+                    }
+#pragma unroll
+                for (int hy = 0; hy < 2; ++hy)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        pin_vgprs(csv[hy][j]);
+                        pin_vgprs(snv[hy][j]);
+                    }
+                pin_vgprs(bx);
+                pin_vgprs(by);
+                if constexpr (F8) {
+                    pin_vgprs(swx);
+                    pin_vgprs(swy);
+                }
 #pragma unroll
                 for (int hy = 0; hy < 2; ++hy)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         if (ok[hy][j])
                             qkv_rope_store(e, which, head, tb[hy][j], tt[hy][j], dl, acc[0][i][hy][j] * (swx * rs[hy][j]) + bx,
-                                           acc[1][i][hy][j] * (swy * rs[hy][j]) + by);
+                                           acc[1][i][hy][j] * (swy * rs[hy][j]) + by, csv[hy][j], snv[hy][j]);
             }
         } else {
 #pragma unroll
@@ -654,6 +684,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
                     f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f}, sw = f32x4{1.f, 1.f, 1.f, 1.f};
                     if (p.bias) bv = ld16f(p.bias + nv);
                     if constexpr (F8) sw = ld16f(p.w_scale + nv);
+                    pin_vgprs(bv);
+                    if constexpr (F8) pin_vgprs(sw);
 #pragma unroll
                     for (int hy = 0; hy < 2; ++hy) {
                         u32x2 vb[2];
@@ -687,27 +719,81 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) rsc[hy][j] = p.row_scale[min(m0 + hy * 128 + q * 32 + j * 16 + (lane & 15), p.M - 1)];
     }
+    // Everything the stores need from memory is requested AHEAD of the bounds guards, unconditionally at clamped addresses and in
+    // batches (round 6, ISA): a load inside a guard is waited for with vmcnt(0) where the guard ends, so the RESID epilogue of
+    // rounds 1-5 paid 32 DEPENDENT residual round trips per lane (a quarter of the o_proj launch: MFMA-busy 49 % where the other
+    // epilogues' kernels show 60-67 %), the bias / weight-scale loads 8.  Now: the column operands of a tile half together, the
+    // residual values of two column groups (8 loads) together.
+    float asc[2][2] = {{1.f, 1.f}, {1.f, 1.f}};   // W8A8: the activation rows' scales
+    if constexpr (F8) {
 #pragma unroll
-    for (int hx = 0; hx < 2; ++hx)
+        for (int hy = 0; hy < 2; ++hy)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) asc[hy][j] = p.a_scale[min(m0 + hy * 128 + q * 32 + j * 16 + (lane & 15), p.M - 1)];
+    }
+#pragma unroll
+    for (int hx = 0; hx < 2; ++hx) {
+        f32x4 bvh[4], swh[4], gwh[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int n = n0 + hx * 128 + g * 64 + i * 16 + (lane >> 4) * 4;
-            if (n >= p.N) continue;
-            f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (p.bias) bv = ld16f(p.bias + n);
-            f32x4 sw = f32x4{1.f, 1.f, 1.f, 1.f};
-            if constexpr (F8) sw = ld16f(p.w_scale + n);
-#pragma unroll
-            for (int hy = 0; hy < 2; ++hy)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int m = m0 + hy * 128 + q * 32 + j * 16 + (lane & 15);
-                    if (m >= p.M) continue;
-                    if constexpr (EPI == EPI_QKV) {
-                    } else if constexpr (F8) store_out<EPI>(p, m, n, acc[hx][i][hy][j] * (sw * p.a_scale[m]) + bv);
-                    else store_out<EPI>(p, m, n, acc[hx][i][hy][j] * rsc[hy][j] + bv);
-                }
+            const int nc = min(n0 + hx * 128 + g * 64 + i * 16 + (lane >> 4) * 4, p.N - 4);
+            bvh[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            swh[i] = f32x4{1.f, 1.f, 1.f, 1.f};
+            if (p.bias) bvh[i] = ld16f(p.bias + nc);          // (wave-uniform test: the four loads of the half go out together)
+            if constexpr (F8) swh[i] = ld16f(p.w_scale + nc);
+            if constexpr (EPI == EPI_RESID_F32) {             // folded-RMSNorm producer: the consumer's norm weights of these columns
+                gwh[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (p.xg_out) gwh[i] = ld16f(p.xg_w + nc);
+            }
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            pin_vgprs(bvh[i]);
+            if constexpr (F8) pin_vgprs(swh[i]);
+            if constexpr (EPI == EPI_RESID_F32) pin_vgprs(gwh[i]);
+        }
+#pragma unroll
+        for (int ip = 0; ip < 2; ++ip) {
+            f32x4 res[2][2][2];
+            if constexpr (EPI == EPI_RESID_F32) {
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int hy = 0; hy < 2; ++hy)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int nc = min(n0 + hx * 128 + g * 64 + (ip * 2 + ii) * 16 + (lane >> 4) * 4, p.N - 4);
+                            const int mc = min(m0 + hy * 128 + q * 32 + j * 16 + (lane & 15), p.M - 1);
+                            res[ii][hy][j] = ld16f(reinterpret_cast<const float*>(p.out) + (size_t)mc * p.ldo + nc);
+                        }
+                // ... and waited for HERE, outside the guards (an empty asm that takes the registers): a first use inside a guard
+                // leaves them pending on the path around it, and every later guarded use then drains the stores issued since
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int hy = 0; hy < 2; ++hy)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) pin_vgprs(res[ii][hy][j]);
+            }
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int i = ip * 2 + ii;
+                const int n = n0 + hx * 128 + g * 64 + i * 16 + (lane >> 4) * 4;
+                if (n >= p.N) continue;
+#pragma unroll
+                for (int hy = 0; hy < 2; ++hy)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int m = m0 + hy * 128 + q * 32 + j * 16 + (lane & 15);
+                        if (m >= p.M) continue;
+                        if constexpr (EPI == EPI_QKV) {
+                        } else if constexpr (F8) store_out<EPI>(p, m, n, acc[hx][i][hy][j] * (swh[i] * asc[hy][j]) + bvh[i]);
+                        else if constexpr (EPI == EPI_RESID_F32) store_out<EPI>(p, m, n, acc[hx][i][hy][j] * rsc[hy][j] + bvh[i], &res[ii][hy][j], &gwh[i]);
+                        else store_out<EPI>(p, m, n, acc[hx][i][hy][j] * rsc[hy][j] + bvh[i]);
+                    }
+            }
+        }
+    }
 }
 
 // sums the K-slices of the split remainder tiles in k order and applies the epilogue (one thread = out[m][n..n+3])
