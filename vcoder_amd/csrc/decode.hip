@@ -1034,8 +1034,62 @@ __global__ __launch_bounds__(256) void quant_act_rows_kernel(const bf16_t* A, in
         st16(Q + (size_t)m * K + c * 16, u32x4{q[0], q[1], q[2], q[3]});
     }
 }
+// The same with the row held in REGISTERS (round 6): NC 32-byte pieces per thread, requested back to back at clamped offsets (the
+// loop form above has one load in flight per thread and reads the row twice), one pass over HBM.  K % 16 == 0, K <= NC * 256 * 16.
+template <int NC>
+__global__ __launch_bounds__(256) void quant_act_rows_reg_kernel(const bf16_t* A, int lda, uint8_t* Q, float* scale, int K) {
+    __shared__ float red[4];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const bf16_t* row = A + (size_t)m * lda;
+    const int n16 = K >> 4;                    // 16-element pieces of the row
+    u32x4 v0[NC], v1[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = min(tid + i * 256, n16 - 1);
+        v0[i] = ld16(row + c * 16);
+        v1[i] = ld16(row + c * 16 + 8);
+    }
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        if (tid + i * 256 >= n16) v0[i] = v1[i] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            amax = fmaxf(amax, fmaxf(fabsf(bf2f_lo(v0[i][e])), fabsf(bf2f_hi(v0[i][e]))));
+            amax = fmaxf(amax, fmaxf(fabsf(bf2f_lo(v1[i][e])), fabsf(bf2f_hi(v1[i][e]))));
+        }
+    }
+    amax = wave_max(amax);
+    if ((tid & 63) == 0) red[tid >> 6] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    int e = 0;
+    if (amax > 0.f) {
+        const uint32_t u = __builtin_bit_cast(uint32_t, amax);
+        e = (int)(u >> 23) - 127 - ((u & 0x007FFFFFu) <= 0x00600000u ? 8 : 7);
+    }
+    const float inv = __builtin_bit_cast(float, (uint32_t)(127 - e) << 23);
+    if (tid == 0) scale[m] = __builtin_bit_cast(float, (uint32_t)(e + 127) << 23);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = tid + i * 256;
+        if (c >= n16) continue;
+        uint32_t q[4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t pk = j < 4 ? v0[i][j] : v1[i][j - 4];
+            const uint32_t a = f2fp8(bf2f_lo(pk) * inv), b = f2fp8(bf2f_hi(pk) * inv);
+            if ((j & 1) == 0) q[j >> 1] = a | (b << 8);
+            else q[j >> 1] |= (a << 16) | (b << 24);
+        }
+        st16(Q + (size_t)m * K + c * 16, u32x4{q[0], q[1], q[2], q[3]});
+    }
+}
 void launch_quant_act_rows(const bf16_t* A, int lda, uint8_t* Q, float* scale, int M, int K, hipStream_t s) {
-    VC_LAUNCH(quant_act_rows_kernel, dim3((unsigned)M), dim3(256), 0, s, A, lda, Q, scale, K);
+    const dim3 grid((unsigned)M), block(256);
+    if (K % 16 == 0 && K <= 2 * 4096) VC_LAUNCH((quant_act_rows_reg_kernel<2>), grid, block, 0, s, A, lda, Q, scale, K);
+    else if (K % 16 == 0 && K <= 4 * 4096) VC_LAUNCH((quant_act_rows_reg_kernel<4>), grid, block, 0, s, A, lda, Q, scale, K);
+    else VC_LAUNCH(quant_act_rows_kernel, grid, block, 0, s, A, lda, Q, scale, K);
 }
 
 // W [N,K] row-major -> packed fragment order (done once at weight-load time)

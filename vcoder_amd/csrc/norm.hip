@@ -22,18 +22,31 @@ VC_DEV void norm_row(const float* __restrict__ x, const float* __restrict__ w, c
                      const float* __restrict__ add1, size_t lo_off = 0) {
     const int lane = lane_id();
     const int nch = D >> 2;
+    // Every load is UNCONDITIONAL at a clamped chunk (masked afterwards) and the loops that load only load (round 6, ISA): a load under
+    // `if (c < nch)` — true for every lane at D = 4096, which the compiler cannot know — is waited for with vmcnt(0) where its guard ends,
+    // so a wave had ONE 1-KiB load in flight at a time and the kernel's rate was occupancy x 1 KiB per HBM latency (5.3 TB/s at 64 VGPRs,
+    // 2.5 TB/s for the 128-VGPR instances).  Now a wave requests its whole row, then the weights in batches of WB.
     f32x4 v[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) v[i] = ld16f(x + min(lane + i * 64, nch - 1) * 4);
+    if (add0) {
+        f32x4 a[MAXV];
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) a[i] = ld16f(add0 + min(lane + i * 64, nch - 1) * 4);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) v[i] = v[i] + a[i];
+    }
+    if (add1) {
+        f32x4 a[MAXV];
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) a[i] = ld16f(add1 + min(lane + i * 64, nch - 1) * 4);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) v[i] = v[i] + a[i];
+    }
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-        const int c = lane + i * 64;
-        if (c < nch) {
-            v[i] = ld16f(x + c * 4);
-            if (add0) v[i] = v[i] + ld16f(add0 + c * 4);
-            if (add1) v[i] = v[i] + ld16f(add1 + c * 4);
-        } else {
-            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        if (lane + i * 64 >= nch) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     }
     float mean = 0.f;
@@ -51,24 +64,40 @@ VC_DEV void norm_row(const float* __restrict__ x, const float* __restrict__ w, c
         }
     }
     const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    constexpr int WB = MAXV < 8 ? MAXV : (MAXV % 8 == 0 ? 8 : 4);   // chunks per weight batch (MAXV in 4, 16, 20, 32)
+    static_assert(MAXV % WB == 0, "weight batches");
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c = lane + i * 64;
-        if (c < nch) {
-            const f32x4 wv = ld16f(w + c * 4);
-            f32x4 o;
+    for (int i0 = 0; i0 < MAXV; i0 += WB) {
+        f32x4 wv[WB], bv[WB];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * wv[e];
-            if (!RMS) o = o + ld16f(b + c * 4);
-            if constexpr (OUT == 1) {
-                st16f(reinterpret_cast<float*>(y) + c * 4, o);
-            } else {
-                u32x2 pk = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
-                st8(reinterpret_cast<bf16_t*>(y) + c * 4, pk);
-                if constexpr (OUT == 2) {
-                    const u32x2 lo = {pack_bf2(o[0] - bf2f_lo(pk[0]), o[1] - bf2f_hi(pk[0])),
-                                      pack_bf2(o[2] - bf2f_lo(pk[1]), o[3] - bf2f_hi(pk[1]))};
-                    st8(reinterpret_cast<bf16_t*>(y) + lo_off + c * 4, lo);
+        for (int k = 0; k < WB; ++k) {
+            const int cc = min(lane + (i0 + k) * 64, nch - 1);
+            wv[k] = ld16f(w + cc * 4);
+            if (!RMS) bv[k] = ld16f(b + cc * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < WB; ++k) {   // (an empty asm that takes the registers: the batch is waited for HERE, not inside the guards below)
+            pin_vgprs(wv[k]);
+            if (!RMS) pin_vgprs(bv[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < WB; ++k) {
+            const int i = i0 + k, c = lane + i * 64;
+            if (c < nch) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * wv[k][e];
+                if (!RMS) o = o + bv[k];
+                if constexpr (OUT == 1) {
+                    st16f(reinterpret_cast<float*>(y) + c * 4, o);
+                } else {
+                    u32x2 pk = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+                    st8(reinterpret_cast<bf16_t*>(y) + c * 4, pk);
+                    if constexpr (OUT == 2) {
+                        const u32x2 lo = {pack_bf2(o[0] - bf2f_lo(pk[0]), o[1] - bf2f_hi(pk[0])),
+                                          pack_bf2(o[2] - bf2f_lo(pk[1]), o[3] - bf2f_hi(pk[1]))};
+                        st8(reinterpret_cast<bf16_t*>(y) + lo_off + c * 4, lo);
+                    }
                 }
             }
         }
@@ -99,6 +128,7 @@ static void launch_norm_f32(const float* x, const int* idx, const float* w, cons
     const dim3 grid((rows + 3) / 4), block(256);
     if (D <= 1024) VC_LAUNCH((norm_f32_kernel<4, RMS>), grid, block, 0, s, x, idx, w, b, y, rows, D, eps);
     else if (D <= 4096) VC_LAUNCH((norm_f32_kernel<16, RMS>), grid, block, 0, s, x, idx, w, b, y, rows, D, eps);
+    else if (D <= 5120) VC_LAUNCH((norm_f32_kernel<20, RMS>), grid, block, 0, s, x, idx, w, b, y, rows, D, eps);
     else VC_LAUNCH((norm_f32_kernel<32, RMS>), grid, block, 0, s, x, idx, w, b, y, rows, D, eps);
 }
 void launch_layernorm_f32(const float* x, const float* w, const float* b, float* y, int rows, int D, float eps,
@@ -125,6 +155,7 @@ static void launch_norm_split(const float* x, const int* idx, const float* w, co
     const dim3 grid((rows + 3) / 4), block(256);
     if (D <= 1024) VC_LAUNCH((norm_split_kernel<4, RMS>), grid, block, 0, s, x, idx, w, b, y, rows, D, eps, ldy, lo_off);
     else if (D <= 4096) VC_LAUNCH((norm_split_kernel<16, RMS>), grid, block, 0, s, x, idx, w, b, y, rows, D, eps, ldy, lo_off);
+    else if (D <= 5120) VC_LAUNCH((norm_split_kernel<20, RMS>), grid, block, 0, s, x, idx, w, b, y, rows, D, eps, ldy, lo_off);
     else VC_LAUNCH((norm_split_kernel<32, RMS>), grid, block, 0, s, x, idx, w, b, y, rows, D, eps, ldy, lo_off);
 }
 void launch_layernorm_split(const float* x, const float* w, const float* b, bf16_t* y, int rows, int D, float eps, int ldy,
@@ -143,6 +174,7 @@ static void launch_norm(const float* x, const int* idx, const float* w, const fl
     if (ldy <= 0) ldy = D;
     if (D <= 1024) VC_LAUNCH((norm_kernel<4, RMS>), grid, block, 0, s, x, idx, w, b, y, rows, D, eps, ldy);
     else if (D <= 4096) VC_LAUNCH((norm_kernel<16, RMS>), grid, block, 0, s, x, idx, w, b, y, rows, D, eps, ldy);
+    else if (D <= 5120) VC_LAUNCH((norm_kernel<20, RMS>), grid, block, 0, s, x, idx, w, b, y, rows, D, eps, ldy);
     else VC_LAUNCH((norm_kernel<32, RMS>), grid, block, 0, s, x, idx, w, b, y, rows, D, eps, ldy);
 }
 
@@ -170,26 +202,35 @@ __global__ __launch_bounds__(256) void rmsnorm_q8_kernel(const float* x, const f
     const int lane = lane_id();
     const int nch = D >> 2;
     const float* xr = x + (size_t)row * D;
+    // unconditional loads at clamped chunks, masked afterwards; the row first, then the weights (norm_row says why)
     f32x4 v[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) v[i] = ld16f(xr + min(lane + i * 64, nch - 1) * 4);
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-        const int c = lane + i * 64;
-        v[i] = c < nch ? ld16f(xr + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (lane + i * 64 >= nch) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < 4; ++e) ss += v[i][e] * v[i][e];
     }
     const float rstd = rsqrtf(wave_sum(ss) / (float)D + eps);
     float amax = 0.f;
+    constexpr int WB = MAXV < 8 ? MAXV : (MAXV % 8 == 0 ? 8 : 4);
+    static_assert(MAXV % WB == 0, "weight batches");
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c = lane + i * 64;
-        if (c < nch) {
-            const f32x4 wv = ld16f(w + c * 4);
+    for (int i0 = 0; i0 < MAXV; i0 += WB) {
+        f32x4 wv[WB];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[i][e] = bf2f(f2bf(v[i][e] * rstd * wv[e]));
-                amax = fmaxf(amax, fabsf(v[i][e]));
+        for (int k = 0; k < WB; ++k) wv[k] = ld16f(w + min(lane + (i0 + k) * 64, nch - 1) * 4);
+#pragma unroll
+        for (int k = 0; k < WB; ++k) {
+            const int i = i0 + k;
+            if (lane + i * 64 < nch) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[i][e] = bf2f(f2bf(v[i][e] * rstd * wv[k][e]));
+                    amax = fmaxf(amax, fabsf(v[i][e]));
+                }
             }
         }
     }
@@ -216,6 +257,7 @@ void launch_rmsnorm_q8(const float* x, const float* w, uint8_t* q, float* scale,
     const dim3 grid((rows + 3) / 4), block(256);
     if (D <= 1024) VC_LAUNCH((rmsnorm_q8_kernel<4>), grid, block, 0, s, x, w, q, scale, rows, D, eps);
     else if (D <= 4096) VC_LAUNCH((rmsnorm_q8_kernel<16>), grid, block, 0, s, x, w, q, scale, rows, D, eps);
+    else if (D <= 5120) VC_LAUNCH((rmsnorm_q8_kernel<20>), grid, block, 0, s, x, w, q, scale, rows, D, eps);
     else VC_LAUNCH((rmsnorm_q8_kernel<32>), grid, block, 0, s, x, w, q, scale, rows, D, eps);
 }
 

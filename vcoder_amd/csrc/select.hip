@@ -91,33 +91,35 @@ VC_DEV void block_argmax(float& v, int& i, BlockRed& r, int lane, int wave) {
 // bf16 embedding row -> fp32 residual row + sum-of-squares partials + xg = bf16(x * g) (the first GEMV's operand)
 // xg_lo != nullptr (precision mode "split"): additionally the lo row bf16(x * g - xg) of the stacked hi / lo group
 // sp_lo != nullptr: the lo plane of an inexact checkpoint's table row (x = hi + lo; split mode)
+// chunk c (8 columns) of the row; returns the chunk's sum of squares
+VC_DEV float embed_chunk_ssq(const bf16_t* sp, float* dp, const float* gw, bf16_t* xg, int c, bf16_t* xg_lo, const bf16_t* sp_lo) {
+    const u32x4 v = ld16(sp + c * 8);
+    f32x4 a = {bf2f_lo(v[0]), bf2f_hi(v[0]), bf2f_lo(v[1]), bf2f_hi(v[1])};
+    f32x4 b = {bf2f_lo(v[2]), bf2f_hi(v[2]), bf2f_lo(v[3]), bf2f_hi(v[3])};
+    if (sp_lo != nullptr) {
+        const u32x4 w = ld16(sp_lo + c * 8);
+        a = a + f32x4{bf2f_lo(w[0]), bf2f_hi(w[0]), bf2f_lo(w[1]), bf2f_hi(w[1])};
+        b = b + f32x4{bf2f_lo(w[2]), bf2f_hi(w[2]), bf2f_lo(w[3]), bf2f_hi(w[3])};
+    }
+    st16f(dp + c * 8, a);
+    st16f(dp + c * 8 + 4, b);
+    const f32x4 g0 = ld16f(gw + c * 8), g1 = ld16f(gw + c * 8 + 4);
+    const f32x4 ta = {a[0] * g0[0], a[1] * g0[1], a[2] * g0[2], a[3] * g0[3]};
+    const f32x4 tb = {b[0] * g1[0], b[1] * g1[1], b[2] * g1[2], b[3] * g1[3]};
+    const u32x4 hi = {pack_bf2(ta[0], ta[1]), pack_bf2(ta[2], ta[3]), pack_bf2(tb[0], tb[1]), pack_bf2(tb[2], tb[3])};
+    st16(xg + c * 8, hi);
+    if (xg_lo != nullptr)
+        st16(xg_lo + c * 8, u32x4{pack_bf2(ta[0] - bf2f_lo(hi[0]), ta[1] - bf2f_hi(hi[0])),
+                                  pack_bf2(ta[2] - bf2f_lo(hi[1]), ta[3] - bf2f_hi(hi[1])),
+                                  pack_bf2(tb[0] - bf2f_lo(hi[2]), tb[1] - bf2f_hi(hi[2])),
+                                  pack_bf2(tb[2] - bf2f_lo(hi[3]), tb[3] - bf2f_hi(hi[3]))});
+    return ((a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3])) +
+           ((b[0] * b[0] + b[1] * b[1]) + (b[2] * b[2] + b[3] * b[3]));
+}
 VC_DEV void embed_row_ssq(const bf16_t* sp, float* dp, float* ssq_row, const float* gw, bf16_t* xg, int D, int npart,
                           int lane, bf16_t* xg_lo = nullptr, const bf16_t* sp_lo = nullptr) {
     float ss = 0.f;
-    for (int c = lane; c < D / 8; c += 64) {
-        const u32x4 v = ld16(sp + c * 8);
-        f32x4 a = {bf2f_lo(v[0]), bf2f_hi(v[0]), bf2f_lo(v[1]), bf2f_hi(v[1])};
-        f32x4 b = {bf2f_lo(v[2]), bf2f_hi(v[2]), bf2f_lo(v[3]), bf2f_hi(v[3])};
-        if (sp_lo != nullptr) {
-            const u32x4 w = ld16(sp_lo + c * 8);
-            a = a + f32x4{bf2f_lo(w[0]), bf2f_hi(w[0]), bf2f_lo(w[1]), bf2f_hi(w[1])};
-            b = b + f32x4{bf2f_lo(w[2]), bf2f_hi(w[2]), bf2f_lo(w[3]), bf2f_hi(w[3])};
-        }
-        st16f(dp + c * 8, a);
-        st16f(dp + c * 8 + 4, b);
-        const f32x4 g0 = ld16f(gw + c * 8), g1 = ld16f(gw + c * 8 + 4);
-        const f32x4 ta = {a[0] * g0[0], a[1] * g0[1], a[2] * g0[2], a[3] * g0[3]};
-        const f32x4 tb = {b[0] * g1[0], b[1] * g1[1], b[2] * g1[2], b[3] * g1[3]};
-        const u32x4 hi = {pack_bf2(ta[0], ta[1]), pack_bf2(ta[2], ta[3]), pack_bf2(tb[0], tb[1]), pack_bf2(tb[2], tb[3])};
-        st16(xg + c * 8, hi);
-        if (xg_lo != nullptr)
-            st16(xg_lo + c * 8, u32x4{pack_bf2(ta[0] - bf2f_lo(hi[0]), ta[1] - bf2f_hi(hi[0])),
-                                      pack_bf2(ta[2] - bf2f_lo(hi[1]), ta[3] - bf2f_hi(hi[1])),
-                                      pack_bf2(tb[0] - bf2f_lo(hi[2]), tb[1] - bf2f_hi(hi[2])),
-                                      pack_bf2(tb[2] - bf2f_lo(hi[3]), tb[3] - bf2f_hi(hi[3]))});
-        ss += ((a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3])) +
-              ((b[0] * b[0] + b[1] * b[1]) + (b[2] * b[2] + b[3] * b[3]));
-    }
+    for (int c = lane; c < D / 8; c += 64) ss += embed_chunk_ssq(sp, dp, gw, xg, c, xg_lo, sp_lo);
     ss = wave_sum(ss);
     for (int q = lane; q < npart; q += 64) ssq_row[q] = q == 0 ? ss : 0.f;
 }
@@ -242,13 +244,31 @@ __global__ __launch_bounds__(1024) void select_embed_kernel(SelectArgs p) {
         if (p.advance & 2) rs[RS_POS] += 1;
     }
     __syncthreads();
-    if (wave == 0 && p.embed != nullptr) {
-        const int tok = tok_s;
-        const int G = p.xg_G;  // split mode: row r -> hi at row (r / G) * 2G + r % G of xg, lo G rows further
-        const size_t xrow = G ? (size_t)(r / G) * 2 * G + r % G : (size_t)r;
-        embed_row_ssq(p.embed + (size_t)tok * p.D, p.x + (size_t)r * p.D, p.ssq + (size_t)r * p.npart, p.xg_w,
-                      p.xg + xrow * p.D, p.D, p.npart, lane, G ? p.xg + (xrow + G) * p.D : nullptr,
-                      p.embed_lo ? p.embed_lo + (size_t)tok * p.D : nullptr);
+    if (p.embed == nullptr) return;
+    const int tok = tok_s;
+    const int G = p.xg_G;  // split mode: row r -> hi at row (r / G) * 2G + r % G of xg, lo G rows further
+    const size_t xrow = G ? (size_t)(r / G) * 2 * G + r % G : (size_t)r;
+    const bf16_t* sp = p.embed + (size_t)tok * p.D;
+    const bf16_t* sp_lo = p.embed_lo ? p.embed_lo + (size_t)tok * p.D : nullptr;
+    bf16_t* xg = p.xg + xrow * p.D;
+    bf16_t* xg_lo = G ? p.xg + (xrow + G) * p.D : nullptr;
+    const int nch = p.D / 8;
+    if (nch > 1024) {   // rows wider than 8192: one wave walks the row
+        if (wave == 0) embed_row_ssq(sp, p.x + (size_t)r * p.D, p.ssq + (size_t)r * p.npart, p.xg_w, xg, p.D, p.npart, lane, xg_lo, sp_lo);
+        return;
+    }
+    // The row's 16-byte chunks over the WHOLE block, one per thread (round 6: one wave used to walk them, D / 512 dependent round
+    // trips to a table row nobody has touched, on the critical path of every decode step); the sum of squares keeps its order — a
+    // lane's chunks lane, lane + 64, ... added in sequence, then the wave reduction — through an LDS array of per-chunk partials
+    __shared__ float part[1024];
+    if (tid < nch) part[tid] = embed_chunk_ssq(sp, p.x + (size_t)r * p.D, p.xg_w, xg, tid, xg_lo, sp_lo);
+    __syncthreads();
+    if (wave == 0) {
+        float ss = 0.f;
+        for (int c = lane; c < nch; c += 64) ss += part[c];
+        ss = wave_sum(ss);
+        float* ssq_row = p.ssq + (size_t)r * p.npart;
+        for (int q = lane; q < p.npart; q += 64) ssq_row[q] = q == 0 ? ss : 0.f;
     }
 }
 
