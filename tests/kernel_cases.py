@@ -402,6 +402,41 @@ def check_rmsnorm(be, rows, D, gather=False, seed=0):
     assert e < 2 ** -8, f"rmsnorm rel err {e}"
 
 
+def check_quant_act_rows_exhaustive(be):
+    """vck_quant_act_rows over EVERY finite bf16 value v with |v| <= 448 * s, at three power-of-two row scales s (each row carries
+    448 * s so that its scale is s): the bytes the device writes — since round 6 the hardware's v_cvt_pk_fp8_f32 in the register-resident
+    kernel — equal the host restatement's (vcoder_amd/quant.py, the software round-to-nearest-even encode), ties, subnormals and
+    the largest finite value included."""
+    from vcoder_amd import quant
+
+    bits = np.arange(65536, dtype=np.uint32).astype(np.uint32) << 16
+    vals = bits.view(np.float32)
+    vals = vals[np.isfinite(vals) & (np.abs(vals) <= 448.0) & ((np.abs(vals) >= 2.0 ** -60) | (vals == 0))]   # (the bf16 denormals would not stay bf16 when scaled down)
+    K = 4096
+    rows = []
+    for sc in (1.0, 32.0, 0.125):
+        v = (vals * np.float32(sc)).astype(np.float32)            # exact: a power of two
+        n = -(-len(v) // (K - 1))
+        for r in range(n):
+            row = np.zeros(K, np.float32)
+            chunk = v[r * (K - 1):(r + 1) * (K - 1)]
+            row[0] = 448.0 * sc                                   # pins the row's scale to sc
+            row[1:1 + len(chunk)] = chunk
+            rows.append(row)
+    A = np.stack(rows, 0)
+    assert np.array_equal(bf16_round(A), A)
+    qa, sa, _ = quant.quantize_rows(A)
+    M = A.shape[0]
+    Ad, Q, sad = be.bf16(A), be.zeros((M, K), "u8"), be.zeros((M,), "f32")
+    _call(be, "vck_quant_act_rows", Ad, K, Q, sad, M, K)
+    host = lambda t: np.asarray(t.cpu().numpy() if hasattr(t, "cpu") else t)
+    assert np.array_equal(be.host_f32(sad), sa), "row scales differ"
+    got = host(Q)
+    bad = np.argwhere(got != qa)
+    assert bad.size == 0, f"{len(bad)} bytes differ, first at {bad[0]}: value {A[tuple(bad[0])]!r} scale {sa[bad[0][0]]} device {got[tuple(bad[0])]:#x} host {qa[tuple(bad[0])]:#x}"
+    return M
+
+
 def check_rmsnorm_q8(be, rows, D, seed=0):
     """RMSNorm straight into the e4m3 operand: bit-identical to vck_rmsnorm followed by vck_quant_act_rows, and to
     vcoder_amd/quant.py on the kernel's own bf16 row."""

@@ -121,6 +121,7 @@ def test_small_ops(be):
     kc.check_rmsnorm(be, 3, 256)
     kc.check_rmsnorm_q8(be, 9728, 4096)
     kc.check_rmsnorm_q8(be, 37, 5120)
+    kc.check_quant_act_rows_exhaustive(be)   # every bf16 value at three row scales: the hardware fp8 conversion == the host's software encode
     kc.check_im2col(be, 3, 336, 14, 640)
     kc.check_im2col(be, 2, 56, 14, 640)
     kc.check_vit_embed_ln(be, 3, 577, 1024)

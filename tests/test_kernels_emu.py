@@ -88,6 +88,7 @@ def test_rmsnorm(be, rows, D, gather):
 @pytest.mark.parametrize("rows,D", [(9, 256), (5, 1280), (3, 5120)])
 def test_rmsnorm_q8(be, rows, D):
     kc.check_rmsnorm_q8(be, rows, D)
+    kc.check_quant_act_rows_exhaustive(be)
 
 
 def test_vit_front(be):

@@ -1076,11 +1076,9 @@ __global__ __launch_bounds__(256) void quant_act_rows_reg_kernel(const bf16_t* A
         if (c >= n16) continue;
         uint32_t q[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const uint32_t pk = j < 4 ? v0[i][j] : v1[i][j - 4];
-            const uint32_t a = f2fp8(bf2f_lo(pk) * inv), b = f2fp8(bf2f_hi(pk) * inv);
-            if ((j & 1) == 0) q[j >> 1] = a | (b << 8);
-            else q[j >> 1] |= (a << 16) | (b << 24);
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t p0 = j < 2 ? v0[i][2 * j] : v1[i][2 * j - 4], p1 = j < 2 ? v0[i][2 * j + 1] : v1[i][2 * j - 3];
+            q[j] = f32x4_to_fp8x4_inrange(bf2f_lo(p0) * inv, bf2f_hi(p0) * inv, bf2f_lo(p1) * inv, bf2f_hi(p1) * inv);
         }
         st16(Q + (size_t)m * K + c * 16, u32x4{q[0], q[1], q[2], q[3]});
     }

@@ -247,8 +247,7 @@ __global__ __launch_bounds__(256) void rmsnorm_q8_kernel(const float* x, const f
     for (int i = 0; i < MAXV; ++i) {
         const int c = lane + i * 64;
         if (c < nch) {
-            const uint32_t pk = (uint32_t)f2fp8(v[i][0] * inv) | ((uint32_t)f2fp8(v[i][1] * inv) << 8) |
-                                ((uint32_t)f2fp8(v[i][2] * inv) << 16) | ((uint32_t)f2fp8(v[i][3] * inv) << 24);
+            const uint32_t pk = f32x4_to_fp8x4_inrange(v[i][0] * inv, v[i][1] * inv, v[i][2] * inv, v[i][3] * inv);
             *reinterpret_cast<uint32_t*>(qr + c * 4) = pk;
         }
     }

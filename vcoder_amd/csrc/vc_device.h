@@ -163,6 +163,23 @@ VC_DEV uint8_t f2fp8(float x) {
     const uint32_t code = ((uint32_t)(e + 7) << 3) + (uint32_t)(int)rintf((m - 1.f) * 8.f);  // mantissa carry rolls over
     return (uint8_t)(sign | (code > 0x7Eu ? 0x7Eu : code));
 }
+// Four values that are KNOWN to be finite and within +-448 (an activation row already divided by its own power-of-two scale: the
+// row's maximum maps to <= 448 by construction) -> four e4m3 bytes.  On the device one v_cvt_pk_fp8_f32 per pair (round to nearest
+// even, OCP e4m3 on gfx950): for such inputs the same bytes as f2fp8 — checked on the device for EVERY bf16 value at three scales
+// against the host restatement (tests/kernel_cases.py check_quant_act_rows_exhaustive) — at a twentieth of the instructions (round 6:
+// the software encode was most of rmsnorm_q8_kernel's and quant_act_rows_kernel's time).  Anything that may overflow, be infinite or
+// NaN keeps f2fp8 (the KV-cache writers, the load-time weight quantiser).
+#ifdef VC_EMU
+VC_DEV uint32_t f32x4_to_fp8x4_inrange(float a, float b, float c, float d) {
+    return (uint32_t)f2fp8(a) | ((uint32_t)f2fp8(b) << 8) | ((uint32_t)f2fp8(c) << 16) | ((uint32_t)f2fp8(d) << 24);
+}
+#else
+VC_DEV uint32_t f32x4_to_fp8x4_inrange(float a, float b, float c, float d) {
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (uint32_t)w;
+}
+#endif
 VC_DEV float fp82f_sw(uint32_t b) {
     const int e = (int)((b >> 3) & 15u), m = (int)(b & 7u);
     const float mag = e == 0 ? (float)m * 0.001953125f
