@@ -59,10 +59,12 @@ def test_gemv_32_rows(be, N, K, epi, norm, ks):
     kc.check_gemv_rows_agree_across_variants(be, N, K, epi, norm, ks)
 
 
-@pytest.mark.parametrize("N,K,epi,norm", [(24576, 128, 3, True), (64, 256, 0, True), (4096, 192, 2, False)])
+@pytest.mark.parametrize("N,K,epi,norm", [(24576, 128, 3, True), (64, 256, 0, True), (4096, 192, 2, False),
+                                          (16 * 767, 128, 0, True), (16 * 900, 192, 0, False), (16 * 1376, 128, 3, True), (16 * 1727, 64, 3, True)])
 def test_gemv_32_rows_w8a16(be, N, K, epi, norm):
-    """the same promise with e4m3 weights; N = 24576 (1536 tiles) takes the 4-tiles-per-workgroup geometry, whose
-    finishing stage gives every wave two (tile, row group) units"""
+    """the same promise with e4m3 weights; the matrices of more than 512 tiles take the one-workgroup-per-CU geometry at 17..32 rows
+    since round 6 (3 / 4 / 6 / 7 tiles per workgroup, ragged last workgroup included), whose finishing stage gives every wave
+    several (tile, row group) units — against the pair geometry that serves the same rows in 8- and 16-row passes"""
     kc.check_gemv_rows_agree_across_variants(be, N, K, epi, norm, fp8=True)
 
 

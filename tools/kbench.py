@@ -296,9 +296,11 @@ def bench_gemm_chunk():
 
 
 def bench_gemv_rows8():
-    """W8A16 weights at 17..32 rows: gate/up (7b, 13b) and qkv, consumer form (VC_GEMV8_NT4=0/1 switches the gate/up geometry)"""
+    """W8A16 weights at 17..32 rows (the pool's rows under the fp8 weight formats): qkv and gate / up of the 7b and 13b models — the pair
+    geometry (vck_set_gemv_wide(0)) against the one-workgroup-per-CU geometry (default since round 6 for > 512 tiles)"""
     for M in (16, 24, 32):
-        for (N, K, epi, name) in [(22016, 4096, 3, "7b gate-up"), (27648, 5120, 3, "13b gate-up"), (12288, 4096, 0, "7b qkv")]:
+        for (N, K, epi, name) in [(12288, 4096, 0, "7b qkv"), (22016, 4096, 3, "7b gate-up"), (15360, 5120, 0, "13b qkv"),
+                                  (27648, 5120, 3, "13b gate-up")]:
             X = bf16(32, K)
             Ws = []
             sc = torch.zeros(N, device=dev)
@@ -312,14 +314,19 @@ def bench_gemv_rows8():
             ldo = N // 2 if epi == 3 else N
             npart = (K // 16 + 15) // 16 * 16
             ssq = torch.rand(32, npart, device=dev)
-            it = [0]
+            row = []
+            for wide in (0, -1):
+                lib.vck_set_gemv_wide(wide)
+                it = [0]
 
-            def f():
-                it[0] += 1
-                lib.vck_gemv_ex(P(X), P(Ws[it[0] % 6]), P(sc), P(out), P(ssq), None, None, None, npart, C.c_float(1e-5),
-                                None, None, 0, M, N, K, ldo, epi, None)
-            us = timeit(f, iters=40)
-            print(f"gemv_rows8 M{M:2d} {name:12s} N{N} K{K}: {us:7.1f} us  {N * K / us / 1e3:7.1f} GB/s", flush=True)
+                def f():
+                    it[0] += 1
+                    lib.vck_gemv_ex(P(X), P(Ws[it[0] % 6]), P(sc), P(out), P(ssq), None, None, None, npart, C.c_float(1e-5),
+                                    None, None, 0, M, N, K, ldo, epi, None)
+                us = timeit(f, iters=60)
+                row.append(f"{'pairs' if wide == 0 else 'wide '} {us:6.1f} us {N * K / us / 1e3:6.0f} GB/s")
+            print(f"gemv_rows8 M{M:2d} {name:12s} N{N} K{K}: " + " | ".join(row), flush=True)
+    lib.vck_set_gemv_wide(-1)
 
 
 def bench_dattn_rows():

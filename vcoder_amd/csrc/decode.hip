@@ -898,9 +898,45 @@ static void launch_gemv_wide1(const GemvArgs& a, hipStream_t s) {
     }
     VC_LAUNCH((gemv_dma_kernel<WAVES, NT, R, EPI, false, XP>), grid, block, shmem, s, a);
 }
+// W8A16 (round 6): the same idea for the e4m3 weights at the pool's 17..32 rows.  A slot there is NT KiB of weights + 3-4 KiB of
+// activation pieces, so the pair geometry (NT = 2, a 2-slot ring, 2-3 workgroups per CU) keeps ~30 KiB of weights in flight per CU
+// — qkv 3.2, gate / up 4.1 TB/s at 13b (profiles/r06_ad_kernel_stats_13b_fp8.md); ceil(tiles / 256) tiles per workgroup put one
+// workgroup on every CU with a ring as deep as the LDS allows (48-84 KiB of weights in flight) and read the activation rows
+// NT / 2 times less often.  Four waves, no K-slices: the pair geometry's K partition, the same bits.
+template <int NT, int R, int XP, int EPI>
+static void launch_gemv_wide8_1(const GemvArgs& a, hipStream_t s) {
+    constexpr int WAVES = 4;
+    const dim3 grid((a.N / 16 + NT - 1) / NT), block(WAVES * 64);
+    constexpr size_t shmem = (size_t)WAVES * R * (NT + XP) * 1024;
+    static_assert(shmem + WAVES * 16 * ((XP + 1) / 2) * 4 <= 160 * 1024, "ring exceeds the LDS of a CU");
+    static bool once = false;
+    if (!once) {
+        allow_big_lds(gemv_dma_kernel<WAVES, NT, R, EPI, true, XP>, shmem);
+        once = true;
+    }
+    VC_LAUNCH((gemv_dma_kernel<WAVES, NT, R, EPI, true, XP>), grid, block, shmem, s, a);
+}
+static bool launch_gemv_wide8(const GemvArgs& a, int epi, hipStream_t s) {
+    const int tiles = a.N / 16, xr = x_rows(a);
+    if (tiles <= 512 || xr <= 16 || a.K % 64 != 0) return false;
+    const int nt = (tiles + 255) / 256;
+    if ((tiles + nt - 1) / nt < 218) return false;
+    const int xp = xr <= 24 ? 3 : 4;
+#define VC_WIDE8(NT_, R_, XP_, E_)                                         \
+    if (nt == NT_ && xp == XP_ && epi == E_) {                             \
+        launch_gemv_wide8_1<NT_, R_, XP_, E_>(a, s);                       \
+        g_gemv_wide_launches.fetch_add(1, std::memory_order_relaxed);      \
+        return true;                                                       \
+    }
+    VC_WIDE8(3, 6, 3, GEMV_BF16) VC_WIDE8(3, 5, 4, GEMV_BF16) VC_WIDE8(4, 5, 3, GEMV_BF16) VC_WIDE8(4, 4, 4, GEMV_BF16)
+    VC_WIDE8(6, 4, 3, GEMV_SWIGLU) VC_WIDE8(6, 3, 4, GEMV_SWIGLU) VC_WIDE8(7, 3, 3, GEMV_SWIGLU) VC_WIDE8(7, 3, 4, GEMV_SWIGLU)
+#undef VC_WIDE8
+    return false;
+}
 static bool launch_gemv_wide(const GemvArgs& a, int epi, hipStream_t s) {
     const int wide = g_gemv_wide < 0 ? 1 : g_gemv_wide;
-    if (!wide || a.wscale || a.ksplit > 1 || a.split_rows) return false;
+    if (!wide || a.ksplit > 1 || a.split_rows) return false;
+    if (a.wscale) return launch_gemv_wide8(a, epi, s);
     const int tiles = a.N / 16;
     if (tiles <= 512) return false;
     const int nt = (tiles + 255) / 256;
