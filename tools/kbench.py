@@ -298,7 +298,7 @@ def bench_gemm_chunk():
 def bench_gemv_rows8():
     """W8A16 weights at 17..32 rows (the pool's rows under the fp8 weight formats): qkv and gate / up of the 7b and 13b models — the pair
     geometry (vck_set_gemv_wide(0)) against the one-workgroup-per-CU geometry (default since round 6 for > 512 tiles)"""
-    for M in (16, 24, 32):
+    for M in (12, 16, 24, 32):
         for (N, K, epi, name) in [(12288, 4096, 0, "7b qkv"), (22016, 4096, 3, "7b gate-up"), (15360, 5120, 0, "13b qkv"),
                                   (27648, 5120, 3, "13b gate-up")]:
             X = bf16(32, K)
@@ -315,7 +315,7 @@ def bench_gemv_rows8():
             npart = (K // 16 + 15) // 16 * 16
             ssq = torch.rand(32, npart, device=dev)
             row = []
-            for wide in (0, -1):
+            for wide in (0, -1, 2):
                 lib.vck_set_gemv_wide(wide)
                 it = [0]
 
@@ -324,9 +324,43 @@ def bench_gemv_rows8():
                     lib.vck_gemv_ex(P(X), P(Ws[it[0] % 6]), P(sc), P(out), P(ssq), None, None, None, npart, C.c_float(1e-5),
                                     None, None, 0, M, N, K, ldo, epi, None)
                 us = timeit(f, iters=60)
-                row.append(f"{'pairs' if wide == 0 else 'wide '} {us:6.1f} us {N * K / us / 1e3:6.0f} GB/s")
+                row.append(f"{'pairs' if wide == 0 else 'default' if wide < 0 else 'wide everywhere'} {us:6.1f} us {N * K / us / 1e3:6.0f} GB/s")
             print(f"gemv_rows8 M{M:2d} {name:12s} N{N} K{K}: " + " | ".join(row), flush=True)
     lib.vck_set_gemv_wide(-1)
+
+
+def bench_gemv_fp8_ks():
+    """13b o_proj / down with W8A16 weights (320 tiles: the 257..512-tile class, tile pairs x KS_MID = 3 K-slices by default — a choice
+    measured with bf16 weights): explicit K-slice counts at 8 / 16 / 32 rows"""
+    for (N, K, name) in [(5120, 5120, "13b o"), (5120, 13824, "13b down")]:
+        X = bf16(32, K)
+        Ws = []
+        sc = torch.zeros(N, device=dev)
+        for _ in range(6):
+            W = bf16(N, K, scale=0.02)
+            Wq = torch.zeros(N * K, dtype=torch.uint8, device=dev)
+            lib.vck_quantize_fp8(P(W), P(Wq), P(sc), N, K, None)
+            Ws.append(Wq)
+        torch.cuda.synchronize()
+        out = torch.zeros((32, N), dtype=torch.float32, device=dev)
+        npart = (max(K, N) // 16 + 15) // 16 * 16
+        ssq_out = torch.zeros(32, npart, device=dev)
+        gw = torch.rand(N, device=dev) + 0.5
+        xg = torch.zeros((32, N), dtype=torch.bfloat16, device=dev)
+        scratch = torch.zeros(8 * (N // 16) * 2 * 256, device=dev)
+        counters = torch.zeros(N // 16 * 2, dtype=torch.int32, device=dev)
+        for M in (8, 16, 32):
+            row = []
+            for ks in (0, 1, 2, 3, 4, 6):
+                it = [0]
+
+                def f():
+                    it[0] += 1
+                    lib.vck_gemv_ex(P(X), P(Ws[it[0] % 6]), P(sc), P(out), None, P(ssq_out), P(gw), P(xg), npart, C.c_float(1e-5),
+                                    P(scratch), P(counters), ks, M, N, K, N, 2, None)
+                us = timeit(f, iters=60)
+                row.append(f"ks {'default' if ks == 0 else ks}: {us:5.1f} us")
+            print(f"gemv_fp8_ks {name:8s} N{N} K{K} M{M:2d}: " + " | ".join(row), flush=True)
 
 
 def bench_dattn_rows():
@@ -539,6 +573,6 @@ if __name__ == "__main__":
     table = {"gemm_qkv": bench_gemm_qkv, "gemm32": bench_gemm32, "gemm": bench_gemm, "gemv": bench_gemv, "attn": bench_attn, "dattn": bench_dattn, "gemv_fp8": bench_gemv_fp8,
              "gemv13": bench_gemv13, "gemv_pair": bench_gemv_pair, "gemv_rows": bench_gemv_rows, "dattn_rows": bench_dattn_rows,
              "gemm_f8": bench_gemm_f8, "gemv_rows8": bench_gemv_rows8, "gemv_wide": bench_gemv_wide, "gemm_chunk": bench_gemm_chunk,
-             "dattn_split": bench_dattn_split, "dattn_kv8": bench_dattn_kv8, "gemv_wg": bench_gemv_wg}
+             "dattn_split": bench_dattn_split, "dattn_kv8": bench_dattn_kv8, "gemv_wg": bench_gemv_wg, "gemv_fp8_ks": bench_gemv_fp8_ks}
     for w in what:
         table[w]()

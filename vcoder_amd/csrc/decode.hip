@@ -902,7 +902,9 @@ static void launch_gemv_wide1(const GemvArgs& a, hipStream_t s) {
 // activation pieces, so the pair geometry (NT = 2, a 2-slot ring, 2-3 workgroups per CU) keeps ~30 KiB of weights in flight per CU
 // — qkv 3.2, gate / up 4.1 TB/s at 13b (profiles/r06_ad_kernel_stats_13b_fp8.md); ceil(tiles / 256) tiles per workgroup put one
 // workgroup on every CU with a ring as deep as the LDS allows (48-84 KiB of weights in flight) and read the activation rows
-// NT / 2 times less often.  Four waves, no K-slices: the pair geometry's K partition, the same bits.
+// NT / 2 times less often.  Four waves, no K-slices: the pair geometry's K partition, the same bits.  From 9 rows on (measured at 12 /
+// 16 / 24 / 32 rows, profiles/r06_af_kbench_gemv_rows8.txt: 13b gate / up 31.7 -> 27.0 us at 16 rows, 33.2 -> 29.8 at 32; 13b qkv 17.4
+// -> 16.6 and 23.9 -> 19.9; the one loss is 13b qkv at 12 rows, 16.4 -> 16.7); 8 rows and below keep pairs (slots of NT + 1 KiB).
 template <int NT, int R, int XP, int EPI>
 static void launch_gemv_wide8_1(const GemvArgs& a, hipStream_t s) {
     constexpr int WAVES = 4;
@@ -918,16 +920,17 @@ static void launch_gemv_wide8_1(const GemvArgs& a, hipStream_t s) {
 }
 static bool launch_gemv_wide8(const GemvArgs& a, int epi, hipStream_t s) {
     const int tiles = a.N / 16, xr = x_rows(a);
-    if (tiles <= 512 || xr <= 16 || a.K % 64 != 0) return false;
+    if (tiles <= 512 || xr <= 8 || a.K % 64 != 0) return false;
     const int nt = (tiles + 255) / 256;
     if ((tiles + nt - 1) / nt < 218) return false;
-    const int xp = xr <= 24 ? 3 : 4;
+    const int xp = xr <= 16 ? 2 : xr <= 24 ? 3 : 4;
 #define VC_WIDE8(NT_, R_, XP_, E_)                                         \
     if (nt == NT_ && xp == XP_ && epi == E_) {                             \
         launch_gemv_wide8_1<NT_, R_, XP_, E_>(a, s);                       \
         g_gemv_wide_launches.fetch_add(1, std::memory_order_relaxed);      \
         return true;                                                       \
     }
+    VC_WIDE8(3, 7, 2, GEMV_BF16) VC_WIDE8(4, 6, 2, GEMV_BF16) VC_WIDE8(6, 4, 2, GEMV_SWIGLU) VC_WIDE8(7, 4, 2, GEMV_SWIGLU)
     VC_WIDE8(3, 6, 3, GEMV_BF16) VC_WIDE8(3, 5, 4, GEMV_BF16) VC_WIDE8(4, 5, 3, GEMV_BF16) VC_WIDE8(4, 4, 4, GEMV_BF16)
     VC_WIDE8(6, 4, 3, GEMV_SWIGLU) VC_WIDE8(6, 3, 4, GEMV_SWIGLU) VC_WIDE8(7, 3, 3, GEMV_SWIGLU) VC_WIDE8(7, 3, 4, GEMV_SWIGLU)
 #undef VC_WIDE8
