@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_kernels_under_another_wave_order(order):
     env = dict(os.environ, VC_EMU_ORDER=order, VC_EMU_RACE="1")   # ... and with the dynamic-LDS race check on (hip_emu.h)
     cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_kernels_emu.py"), "-x", "-q", "-p", "no:cacheprovider",
-           "-k", "attention or gemm or gemv or qkv or decode"]
+           "-k", "attention or gemm or gemv or qkv or decode or norm or select or q8 or sampling"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
     if r.returncode != 0:
         # (a one-in-40 failure seen while this test was written turned out to be the EMULATOR's own arrival counter — a plain
